@@ -1,0 +1,687 @@
+"""CPU oracle for the DistantSpeech per-frame enhancement hot path (NumPy restatement).
+
+TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module, and only as the *checker* (or the timed CPU baseline), never as the thing shipped.
+The product path (``distantspeech_amd``) never imports it and fails loudly without its HIP library.
+
+What it is: a vectorised-over-bins NumPy restatement of the reference algorithms, each function
+citing the reference ``file:line`` (paths relative to /root/reference) it follows.  Arithmetic is
+float64/complex128 like the reference (``dtype=np.float32`` gives an all-fp32 restatement used to
+predict the fp32 GPU kernels' error).
+
+Parity pin: the reference holds no golden vectors or known-answer tests for this path
+(SURVEY.md §4), so this oracle is pinned against outputs of the reference itself, generated in
+the build container by ``tests/golden/make_golden.py`` (which imports the reference from
+/root/reference through ``tests/golden/_ref_shim.py``) and committed as ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks every function here against those fixtures.
+
+Third-party arithmetic the reference calls and which is not under /root/reference
+(numpy.fft.rfft/irfft, numpy.linalg.inv, scipy.signal.get_window/convolve; reference pins
+numpy==1.21.6, scipy==1.8.0, librosa==0.9.1 in requirements.txt:57,74,110) is used here at the
+versions of this image; the fixtures pin the results at those versions.
+"""
+import numpy as np
+
+__all__ = [
+    "sqrt_hann", "OracleTransform", "OracleMicArray", "compute_tau", "gen_noise_msc",
+    "steering_from_doa", "fixed_weights", "circular_tao", "OracleMCRA", "OracleAdaptiveMVDR",
+    "OracleFixedBeamformer", "OracleMcMcra", "OracleOmlsaMulti", "OracleGSC",
+    "OracleSubbandLMS", "OracleSubbandLmsMc", "OracleSubbandRLS", "synth_utterance",
+]
+
+
+# --------------------------------------------------------------------------------------------
+# transform/transform.py
+# --------------------------------------------------------------------------------------------
+def sqrt_hann(n_fft):
+    """sqrt of the periodic Hann window — transform/transform.py:418-419
+    (librosa.filters.get_window('hann', n, fftbins=True) == scipy.signal.get_window, periodic:
+    w[n] = 0.5 - 0.5 cos(2 pi n / N))."""
+    n = np.arange(n_fft)
+    return np.sqrt(0.5 - 0.5 * np.cos(2.0 * np.pi * n / n_fft))
+
+
+class OracleTransform:
+    """Streaming STFT/ISTFT with carried overlap — transform/transform.py:407-481."""
+
+    def __init__(self, channel=1, n_fft=256, hop_length=128, dtype=np.float64):
+        self.channel = channel
+        self.n_fft = n_fft
+        self.hop_length = hop_length
+        self.window = sqrt_hann(n_fft)                      # :418-419
+        self.half_bin = int(n_fft / 2 + 1)                  # :420
+        self.overlap = n_fft - hop_length                   # :424
+        self.previous_input = np.zeros((self.overlap, channel))   # :425
+        self.previous_output = np.zeros((self.overlap, channel))  # :426
+        self.W0 = np.sum(self.window ** 2)                  # :428
+        self.rt = np.dtype(dtype)
+
+    def stft(self, x):
+        """x [samples, channels] (or [samples]) -> Y [half_bin, frames, channels] complex128 whose
+        values are rounded to complex64 (module stft dtype default, transform.py:17,212,220)."""
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x[:, None]
+        x = np.vstack((self.previous_input, x))             # :438
+        n_frames = 1 + int((x.shape[0] - self.n_fft) / self.hop_length)   # :441
+        idx = np.arange(self.n_fft)[:, None] + self.hop_length * np.arange(n_frames)[None, :]
+        Y = np.zeros((self.half_bin, n_frames, self.channel), dtype=np.complex128)
+        for ch in range(self.channel):
+            frames = x[:, ch][idx]                          # util.frame, center=False (:209)
+            if self.rt == np.float32:
+                spec = np.fft.rfft((self.window.astype(np.float32)[:, None] * frames.astype(np.float32)), axis=0)
+            else:
+                spec = np.fft.rfft(self.window[:, None] * frames, axis=0)   # :220
+            Y[:, :, ch] = spec.astype(np.complex64)         # :212 complex64 storage
+            self.previous_input[:, ch] = x[-self.overlap:, ch]              # :451
+        return Y
+
+    def istft(self, Y):
+        """Y [half_bin, frames, channels] -> [frames*hop] (or [frames*hop, channels]).
+        irfft in float64, overlap-add into a float32 buffer (transform.py:243,359,234),
+        carried tail (:476-477), scale hop/W0 (:479)."""
+        Y = np.asarray(Y)
+        if Y.ndim == 1:
+            Y = Y[:, None, None]                            # :461-462
+        if Y.ndim == 2:
+            Y = Y[:, None, :]                               # :463-464 (2-D means [K, channels])
+        half_bin, n_frames, n_channels = Y.shape
+        assert n_channels <= self.channel
+        hop, n_fft = self.hop_length, self.n_fft
+        out = np.zeros((hop * n_frames, n_channels))
+        for ch in range(n_channels):
+            ytmp = self.window[:, None] * np.fft.irfft(Y[:, :, ch], axis=0)   # :368
+            y = np.zeros(n_fft + hop * (n_frames - 1), dtype=np.float32)       # :358-359
+            for f in range(n_frames):
+                y[f * hop:f * hop + n_fft] += ytmp[:, f]                        # :232-234 (rounds to f32)
+            y[: self.overlap] += self.previous_output[:, ch]                   # :476
+            self.previous_output[:, ch] = y[-self.overlap:]                    # :477
+            out[:, ch] = y[: -self.overlap] * hop / self.W0                    # :479
+        return out.squeeze()
+
+
+# --------------------------------------------------------------------------------------------
+# beamformer/MicArray.py, gen_noise_msc.py, beamformer.py (geometry + fixed weights; host set-up)
+# --------------------------------------------------------------------------------------------
+class OracleMicArray:
+    """Geometry subset of MicArray — beamformer/MicArray.py:20-75."""
+
+    def __init__(self, arrayType="circular", r=0.032, c=343, M=4, n_fft=256, fs=16000):
+        self.arrayType = arrayType
+        self.r, self.c, self.M, self.n_fft, self.fs = r, c, M, n_fft, fs
+        self.half_bin = round(n_fft / 2 + 1)
+        self.gamma = np.arange(0, 360, int(360 / M)) * np.pi / 180        # :33
+        self.omega = 2 * np.pi * np.arange(self.half_bin) * fs / n_fft     # :36
+        self.mic_loc = np.zeros((M, 3))
+        if arrayType == "circular":                                       # :62-66
+            az = np.arange(0, 360, int(360 / M)) * np.pi / 180
+            self.mic_loc[:, 0] = r * np.cos(0.0) * np.cos(az)
+            self.mic_loc[:, 1] = r * np.cos(0.0) * np.sin(az)
+            self.mic_loc[:, 2] = r * np.sin(0.0)
+        elif arrayType == "linear":                                       # :67-68
+            self.mic_loc[:, 0] = -(np.arange(M) - (M - 1) / 2) * r
+        else:
+            raise ValueError(arrayType)
+
+
+def compute_tau(mic, incident_angle_rad):
+    """Far-field delay per mic w.r.t. the origin — module fn beamformer/MicArray.py:149-187."""
+    az, el = float(incident_angle_rad[0]), float(incident_angle_rad[1])
+    p0 = -1 * np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+    tau = np.zeros((mic.M, 1))
+    for m in range(mic.M):
+        loc = -1 * mic.mic_loc[m, :]
+        nrm = np.linalg.norm(loc)
+        cos_theta = np.sum(loc * p0) / (np.linalg.norm(p0) * nrm + 1e-12)
+        tau[m] = -1 * nrm * cos_theta / mic.c
+    return tau
+
+
+def gen_noise_msc(mic, nfft=256, Fvv_max=0.9998):
+    """Diffuse-field coherence (sinc model) — beamformer/gen_noise_msc.py:7-28."""
+    M, c, fs = mic.M, mic.c, mic.fs
+    half_bin = round(nfft / 2 + 1)
+    Fvv = np.zeros((half_bin, M, M))
+    f = np.linspace(0, fs / 2, half_bin)
+    f[0] = 1e-6
+    for i in range(M):
+        for j in range(M):
+            dij = np.sqrt(np.sum((mic.mic_loc[i, :] - mic.mic_loc[j, :]) ** 2))
+            if i == j:
+                Fvv[:, i, j] = Fvv_max
+            else:
+                Fvv[:, i, j] = np.sin(2 * np.pi * f * dij / c) / (2 * np.pi * f * dij / c)
+    return Fvv
+
+
+def steering_from_doa(mic, nfft, look_angle_deg):
+    """a0[k,m] = exp(-j w_k tau_m) — beamformer/beamformer.py:267-289 (with MicArray.n_fft == nfft,
+    SURVEY §8a-5; bins >= mic.half_bin stay zero exactly like the reference loop :286)."""
+    half_bin = round(nfft / 2 + 1)
+    omega = 2 * np.pi * np.arange(half_bin) * mic.fs / nfft             # beamformer.py:248
+    tau0 = compute_tau(mic, np.array(look_angle_deg) / 180 * np.pi)
+    a0 = np.zeros((half_bin, mic.M), dtype=complex)
+    kmax = min(half_bin, mic.half_bin)
+    a0[:kmax, :] = np.exp(-1j * omega[:kmax, None] * tau0[None, :, 0])
+    return a0
+
+
+def fixed_weights(mic, nfft, look_angle_deg, weightType="DS", diag_value=1e-3):
+    """DS: a0/M; SD: G^-1 a /(a^H G^-1 a), G = Fvv + diag — beamformer/beamformer.py:338-373,
+    compute_mvdr_weight :133-155 (base-class semantics: Fvv = gen_noise_msc(mic, nfft), :262)."""
+    a0 = steering_from_doa(mic, nfft, look_angle_deg)
+    if weightType == "DS":
+        return a0 / mic.M
+    if weightType == "SD":
+        Fvv = gen_noise_msc(mic, nfft)
+        Ginv = np.linalg.inv(Fvv + np.eye(mic.M) * diag_value)
+        num = Ginv @ a0[..., None]
+        w = num / (a0[:, None, :].conj() @ num)
+        return w[..., 0]
+    raise ValueError(weightType)
+
+
+def circular_tao(r, c, gamma, angle_rad):
+    """tao_m = -r cos(el) cos(az - gamma_m)/c — adaptivebeamformer.py:52, GSC.py:186."""
+    return -1 * r * np.cos(angle_rad[1]) * np.cos(angle_rad[0] - gamma) / c
+
+
+# --------------------------------------------------------------------------------------------
+# noise_estimation/NoiseEstimationBase.py + mcra.py
+# --------------------------------------------------------------------------------------------
+class OracleMCRA:
+    """NoiseEstimationMCRA — noise_estimation/mcra.py:20-77, NoiseEstimationBase.py:5-60."""
+
+    def __init__(self, nfft=256, p_max=0.999, p_min=1e-3, L=15, dtype=np.float64):
+        rt = np.dtype(dtype).type
+        self.rt = rt
+        self.half_bin = int(nfft / 2 + 1)
+        K = self.half_bin
+        self.lambda_d = np.zeros(K, dtype=rt)
+        self.alpha_d, self.alpha_s, self.delta_s, self.alpha_p = rt(0.95), rt(0.8), rt(5), rt(0.2)
+        self.ell = 1                                        # Base :18
+        self.b = [rt(0.25), rt(0.5), rt(0.25)]              # Base :19
+        self.S = np.zeros(K, dtype=rt)
+        self.Smin = np.zeros(K, dtype=rt)
+        self.Stmp = np.zeros(K, dtype=rt)
+        self.p = np.zeros(K, dtype=rt)
+        self.alpha_tilde = np.zeros(K, dtype=rt)
+        self.p_max, self.p_min = rt(p_max), rt(p_min)
+        self.L = L                                          # mcra.py:25
+        self.frm_cnt = 0
+
+    def estimation(self, Y):
+        rt = self.rt
+        Y = np.asarray(Y)
+        if np.iscomplexobj(Y):
+            Y = np.abs(Y) ** 2                              # :29-30
+        if Y.ndim > 1:
+            Y = Y[:, 0]
+        Y = Y.astype(rt)
+        K = self.half_bin
+        assert len(Y) == K
+        one = rt(1)
+        if self.frm_cnt == 0:                               # :38-41
+            self.Smin[:K - 1] = Y[:K - 1]
+            self.Stmp[:K - 1] = Y[:K - 1]
+            self.lambda_d[:K - 1] = Y[:K - 1]
+            self.p[:K - 1] = 0                              # :68-69 (frm_cnt < 2L)
+        else:
+            self.p[0] = 0                                   # :43-45
+            sl = slice(1, K - 1)
+            Sf = Y[0:K - 2] * self.b[0] + Y[1:K - 1] * self.b[1] + Y[2:K] * self.b[2]   # :46
+            self.S[sl] = self.alpha_s * self.S[sl] + (one - self.alpha_s) * Sf          # :47
+            self.Smin[sl] = np.minimum(self.Smin[sl], self.S[sl])                       # :49
+            self.Stmp[sl] = np.minimum(self.Stmp[sl], self.S[sl])                       # :50
+            if self.ell % self.L == 0:                      # :52-56 (applies to every bin of the frame)
+                self.Smin[sl] = np.minimum(self.Stmp[sl], self.S[sl])
+                self.Stmp[sl] = self.S[sl]
+                self.ell = 0
+            Sr = self.S[sl] / (self.Smin[sl] + rt(1e-6))    # :58
+            I = (Sr > self.delta_s).astype(rt)              # :60-63
+            self.p[sl] = self.alpha_p * self.p[sl] + (one - self.alpha_p) * I           # :65-67
+            if self.frm_cnt < self.L * 2:                   # :68-69
+                self.p[sl] = 0
+        self.p = np.maximum(np.minimum(self.p, self.p_max), self.p_min)                 # :70
+        self.frm_cnt += 1
+        self.lambda_d[K - 1] = rt(1e-8)                     # :73
+        self.ell += 1
+        self.update_noise_psd(Y)
+        return self.lambda_d
+
+    def update_noise_psd(self, Y, beta=1.0):
+        """NoiseEstimationBase.py:56-60."""
+        rt = self.rt
+        self.alpha_tilde = self.alpha_d + (rt(1) - self.alpha_d) * self.p
+        self.lambda_d = self.alpha_tilde * self.lambda_d + rt(beta) * (rt(1) - self.alpha_tilde) * Y
+
+
+def smooth_psd(x, previous_x, win, alpha):
+    """3-tap frequency smoothing (zero-padded edges) + time smoothing —
+    NoiseEstimationBase.py:33-51 (scipy.signal.convolve 'full', centre slice)."""
+    xp = np.concatenate(([0.0], x, [0.0])).astype(x.dtype)
+    sm = win[0] * xp[2:] + win[1] * xp[1:-1] + win[2] * xp[:-2]
+    return alpha * previous_x + (1 - alpha) * sm
+
+
+# --------------------------------------------------------------------------------------------
+# beamformer/adaptivebeamformer.py (config 2) and fixedbeamformer.py (config 1)
+# --------------------------------------------------------------------------------------------
+METHODS = ["src", "DS", "MVDR", "TFGSC"]     # adaptivebeamformer.py:36
+
+
+class OracleAdaptiveMVDR:
+    """adaptivebeamfomer.process — beamformer/adaptivebeamformer.py:44-128 (estPos=None, VAD-gated).
+
+    Defined for any number of hops per call as "T successive one-hop calls" (SURVEY §8b chunking
+    contract; the reference is only valid one hop per call at HEAD, adaptivebeamformer.py:122)."""
+
+    def __init__(self, mic, frameLen=512, hop=None, nfft=None, dtype=np.float64, mcra_L=15):
+        self.M = mic.M
+        self.nfft = int(nfft) if nfft else int(frameLen)
+        self.hop = int(hop) if hop else int(frameLen // 2)
+        self.half_bin = round(self.nfft / 2 + 1)
+        self.r, self.c, self.fs, self.gamma = mic.r, mic.c, mic.fs, mic.gamma
+        self.omega = 2 * np.pi * np.arange(self.half_bin) * self.fs / self.nfft   # :20
+        self.rt = np.dtype(dtype).type
+        self.ct = np.complex64 if self.rt == np.float32 else np.complex128
+        K, M = self.half_bin, self.M
+        self.H = np.ones((M, K), dtype=self.ct) / M                     # :22
+        self.Rvv = np.zeros((K, M, M), dtype=self.ct)                   # :32-34
+        self.Rvv_inv = np.zeros((K, M, M), dtype=self.ct)
+        self.Ryy = np.zeros((K, M, M), dtype=self.ct)
+        self.transformer = OracleTransform(n_fft=self.nfft, hop_length=self.hop, channel=M, dtype=dtype)
+        self.mcra = OracleMCRA(nfft=self.nfft, L=mcra_L, dtype=dtype)   # :40
+
+    def process_frame(self, Zk, angle_rad, method=2):
+        """Zk [K, M] one STFT frame -> Y [K].  :69-120."""
+        rt, ct = self.rt, self.ct
+        K, M = self.half_bin, self.M
+        tao = circular_tao(self.r, self.c, self.gamma, angle_rad)       # :52
+        a = np.exp(-1j * self.omega[:, None] * tao[None, :]).astype(ct)  # :84  [K, M]
+        Z = Zk.astype(ct)
+        alpha_y, alpha_v, diag = rt(0.8), rt(0.9998), rt(1e-6)          # :65-66,89
+        self.mcra.estimation(np.abs(Z[:, 0] * np.conj(Z[:, 0])))        # :81
+        zz = Z[:, :, None] * np.conj(Z[:, None, :])                     # z z^H  [K, M, M]
+        self.Ryy = alpha_y * self.Ryy + (rt(1) - alpha_y) * zz          # :86-88
+        upd = self.mcra.p < rt(0.4)                                     # :94
+        self.Rvv[upd] = alpha_v * self.Rvv[upd] + (rt(1) - alpha_v) * zz[upd]   # :97-99
+        if upd.any():
+            self.Rvv_inv[upd] = np.linalg.inv(self.Rvv[upd] + diag * np.eye(M, dtype=rt))   # :103-104
+        name = METHODS[method]
+        if name == "src":                                               # beamformer.py:320-322
+            H = np.zeros((K, M), dtype=ct)
+            H[:, 0] = a[:, 0]
+        elif name == "DS":                                              # beamformer.py:323-324
+            H = a / M
+        elif name == "MVDR":                                            # beamformer.py:325-326
+            num = (self.Rvv_inv @ a[:, :, None])[..., 0]
+            den = np.sum(np.conj(a) * num, axis=1)
+            H = num / den[:, None]
+        elif name == "TFGSC":                                           # beamformer.py:327-333
+            temp = self.Rvv_inv @ self.Ryy
+            tr = np.trace(temp, axis1=1, axis2=2)
+            col0 = temp[:, :, 0].copy()
+            col0[:, 0] -= 1
+            H = col0 / (tr - M)[:, None]
+        else:
+            raise ValueError(name)
+        self.H = H.T.copy()                                             # [M, K] like the reference
+        return np.sum(np.conj(H) * Z, axis=1)                           # :119-120
+
+    def process(self, x, angle_rad, method=2):
+        """x [M, T*hop] -> y [T*hop]; equals T one-hop reference calls concatenated."""
+        X = self.transformer.stft(np.asarray(x).T)                      # :49
+        T = X.shape[1]
+        out = []
+        for t in range(T):   # one ISTFT call per hop, exactly like T one-hop reference calls (:122)
+            Yt = self.process_frame(X[:, t, :], angle_rad, method)
+            out.append(np.atleast_1d(self.transformer.istft(Yt[:, None, None])))
+        return np.concatenate(out)
+
+
+class OracleFixedBeamformer:
+    """FixedBeamformer.process (DS or SD weights) — beamformer/fixedbeamformer.py:147-207 with the
+    base-class weight semantics (beamformer.py:338-373) because the subclass's gen_noise_msc call
+    has a shape bug at nfft != 256 (fixedbeamformer.py:140)."""
+
+    def __init__(self, mic, frameLen=512, hop=None, nfft=None, angle=(197, 0), weightType="DS", dtype=np.float64):
+        self.mic = mic
+        self.M = mic.M
+        self.nfft = int(nfft) if nfft else int(frameLen)
+        self.hop = int(hop) if hop else int(frameLen // 2)
+        self.half_bin = round(self.nfft / 2 + 1)
+        self.weightType = weightType
+        self.angle = list(angle)
+        self.W = fixed_weights(mic, self.nfft, self.angle, weightType)
+        self.transform = OracleTransform(n_fft=self.nfft, hop_length=self.hop, channel=self.M, dtype=dtype)
+
+    def process(self, x, angle=None):
+        """x [samples, channels] -> [samples]."""
+        if angle is not None and list(angle) != self.angle:
+            self.angle = list(angle)
+            self.W = fixed_weights(self.mic, self.nfft, self.angle, self.weightType)
+        D = self.transform.stft(x)
+        Yf = np.einsum("kc,ktc->kt", self.W.conj(), D)[:, :, None]     # :163 per frame
+        return np.atleast_1d(self.transform.istft(Yf))
+
+
+# --------------------------------------------------------------------------------------------
+# noise_estimation/mc_mcra.py
+# --------------------------------------------------------------------------------------------
+class OracleMcMcra:
+    """McMcra (multichannel SPP with real covariances + Wiener-type gain) — mc_mcra.py:25-224."""
+
+    def __init__(self, nfft=256, channels=4, dtype=np.float64):
+        rt = np.dtype(dtype).type
+        self.rt = rt
+        self.M = channels
+        self.half_bin = int(nfft / 2 + 1)
+        K, M = self.half_bin, channels
+        self.alpha_d, self.alpha = rt(0.95), rt(0.92)                   # :36,38
+        self.psi_0, self.psi_tilde_0 = rt(100), rt(100)                 # :60-61
+        self.p = np.zeros(K, dtype=rt)
+        self.G = np.zeros(K, dtype=rt)
+        self.G_H1 = np.zeros(K, dtype=rt)
+        self.q_local = np.ones(K, dtype=rt) * rt(0.999)
+        self.Phi_yy = np.zeros((K, M, M), dtype=rt)                     # reference layout [M, M, K] (:68-69)
+        self.Phi_vv = np.zeros((K, M, M), dtype=rt)
+        self.xi = np.zeros(K, dtype=rt)
+        self.gamma = np.zeros(K, dtype=rt)
+        self.psi = np.zeros(K, dtype=rt)
+        self.psi_tilde = np.zeros(K, dtype=rt)
+        self.frm_cnt = 0
+
+    def estimation(self, y):
+        """y [K, M] complex — :179-208."""
+        rt = self.rt
+        M = self.M
+        y = np.asarray(y)
+        yy = np.real(np.conj(y[:, :, None]) * y[:, None, :]).astype(rt)     # Re(conj(y)^T y)  :182-184
+        self.Phi_yy = self.alpha * self.Phi_yy + (rt(1) - self.alpha) * yy
+        if self.frm_cnt < 5:                                                # :186-187
+            self.Phi_vv = self.Phi_yy.copy()
+        Phi_xx = self.Phi_yy - self.Phi_vv                                  # :189
+        inv = np.linalg.inv(self.Phi_vv + np.eye(M, dtype=rt) * rt(1e-6))   # :191
+        tr = np.trace(inv @ self.Phi_yy, axis1=1, axis2=2)
+        self.xi = np.minimum(np.maximum(tr - M, rt(1e-6)), rt(1e6))         # :193-194
+        A = inv @ Phi_xx @ inv
+        # Re(conj(y) A y^T) with real A: sum_ij A_ij Re(conj(y_i) y_j)       :196-198
+        g = np.real(np.einsum("ki,kij,kj->k", np.conj(y), A.astype(np.complex128 if rt == np.float64 else np.complex64), y))
+        self.gamma = np.minimum(np.maximum(g.astype(rt), rt(1e-6)), rt(1e6))            # :199
+        # compute_q_local :91-105
+        self.psi = np.real(np.einsum("ki,kij,kj->k", y, inv.astype(y.dtype), np.conj(y))).astype(rt)
+        self.psi_tilde = tr.astype(rt)
+        q_max, q_min = rt(0.99), rt(0.01)
+        lin = (self.psi_tilde_0 - self.psi_tilde) / (self.psi_tilde_0 - M)
+        lin = np.minimum(np.maximum(lin, q_min), q_max)
+        q = np.where((self.psi >= self.psi_0) | (self.psi_tilde > self.psi_tilde_0), q_min,
+                     np.where(self.psi_tilde < M, q_max, lin)).astype(rt)
+        self.q_local = q
+        self.q = q                                                          # :138
+        # compute_p(p_max=0.99, p_min=0.01) :143-151,204
+        p = 1 / (1 + q / (1 - q) * (1 + self.xi) * np.exp(-1 * (self.gamma / (1 + self.xi))))
+        self.p = np.minimum(np.maximum(p, rt(0.01)), rt(0.99)).astype(rt)
+        # update_noise_psd :210-224
+        at = (self.alpha_d + (rt(1) - self.alpha_d) * self.p)[:, None, None]
+        self.Phi_vv = (at * self.Phi_vv + (rt(1) - at) * yy).astype(rt)
+        # compute_weight :153-157
+        Gmin = rt(0.0631)
+        self.G_H1 = self.xi / (1 + self.xi)
+        G = np.power(self.G_H1, self.p) * np.power(Gmin, (1 - self.p))
+        G = np.maximum(np.minimum(G, rt(1)), Gmin)
+        G[:2] = 0
+        self.G = G.astype(rt)
+        self.frm_cnt += 1
+
+
+# --------------------------------------------------------------------------------------------
+# noise_estimation/omlsa_multi.py
+# --------------------------------------------------------------------------------------------
+class OracleOmlsaMulti:
+    """NsOmlsaMulti (TBRR-OMLSA, Wiener G_H1) — omlsa_multi.py:27-156."""
+
+    def __init__(self, nfft=256, M=4, cal_weights=False, dtype=np.float64):
+        self.half_bin = int(nfft / 2 + 1)
+        K = self.half_bin
+        self.M = M
+        self.G_H1 = np.ones(K)
+        self.G = np.ones(K)
+        self.Gmin = np.power(10, (-12 / 10))                 # :35-36
+        self.gamma = np.ones(K)
+        self.zeta_Y = np.ones(K)
+        self.zeta_U = np.zeros((M - 1, K))
+        self.MU_Y = np.ones(K)
+        self.MU_U = np.zeros((M - 1, K))
+        self.q_hat = np.ones(K)
+        self.q_min, self.q_max = 1e-6, 0.9999998             # :54-55
+        self.alpha_d = 0.85                                  # :57
+        self.xi_hat = np.ones(K)
+        self.p = np.zeros(K)
+        self.lambda_d = np.zeros(K)
+        self.first_frame = 1
+        self.noise_est_fixed = OracleMCRA(nfft=nfft)         # :65-67 (L=15 default of NoiseEstimationMCRA)
+        self.noise_est_ref = [OracleMCRA(nfft=nfft) for _ in range(M - 1)]
+        self.win = np.array([0.25, 0.5, 0.25])
+        self.alpha_s = 0.8
+        self.cal_weights = cal_weights
+        self.Omega = np.ones(K)
+        self.gamma_s = np.ones(K)
+
+    def estimation(self, y, u):
+        """y [K] power of beam output, u [K, M-1] powers of the references — :73-156."""
+        y = np.asarray(y, dtype=np.float64)
+        u = np.asarray(u, dtype=np.float64)
+        assert len(y) == self.half_bin
+        self.MU_Y = self.noise_est_fixed.estimation(y)                      # :83
+        for ch in range(self.M - 1):
+            self.MU_U[ch, :] = self.noise_est_ref[ch].estimation(u[:, ch])  # :84-85
+        if self.first_frame == 1:                                           # :87-93
+            self.first_frame = 0
+            self.lambda_d = y.copy()
+            self.zeta_Y = y.copy()
+            self.zeta_U = u.T.copy()
+            return None
+        alpha = 0.921
+        self.zeta_Y = smooth_psd(y, self.zeta_Y, self.win, self.alpha_s)    # :98
+        for ch in range(self.M - 1):
+            self.zeta_U[ch, :] = smooth_psd(u[:, ch], self.zeta_U[ch, :], self.win, self.alpha_s)
+        eps = 0.01
+        self.Omega = np.maximum(self.zeta_Y - self.MU_Y, 1e-6) / (
+            np.maximum(np.max(self.zeta_U - self.MU_U, axis=0), eps * self.MU_Y) + 1e-6)   # :107-109
+        self.Omega = np.minimum(np.maximum(self.Omega, 0.1), 100)           # :110-111
+        Bmin = 1.66
+        self.gamma_s = np.minimum(y / (self.MU_Y * Bmin + 1e-6), 100)       # :115
+        gamma_high, gamma_low, Omega_high, Omega_low = 10.0, 1.0, 3.0, 0.3  # :117-120
+        q = np.maximum((gamma_high - self.gamma_s) / (gamma_high - gamma_low),
+                       (Omega_high - self.Omega) / (Omega_high - Omega_low))
+        q = np.where((self.gamma_s < gamma_low) | (self.Omega < Omega_low), 1.0, q)   # :122-129
+        self.q_hat = np.minimum(np.maximum(q, self.q_min), self.q_max)      # :130
+        gamma_pre = self.gamma.copy()
+        self.gamma = y / np.maximum(self.lambda_d, 1e-10)                   # :134
+        self.xi_hat = alpha * np.power(self.G_H1, 2) * gamma_pre + (1 - alpha) * np.maximum(self.gamma - 1, 0)  # :137
+        nu = self.gamma * self.xi_hat / (1 + self.xi_hat)                   # :140
+        self.G_H1 = self.xi_hat / (1 + self.xi_hat)                         # :144
+        self.p = 1 / (1 + self.q_hat / (1 - self.q_hat) * (1 + self.xi_hat) * np.exp(-1 * nu))   # :147
+        at = self.alpha_d + (1 - self.alpha_d) * self.p                     # Base :57 (alpha_d = 0.85 here)
+        self.lambda_d = at * self.lambda_d + 1.47 * (1 - at) * y            # :149
+        if self.cal_weights:                                                # :152-154
+            G = np.power(self.G_H1, self.p) * np.power(self.Gmin, (1 - self.p))
+            self.G = np.maximum(np.minimum(G, 1), self.Gmin)
+        return self.lambda_d
+
+
+# --------------------------------------------------------------------------------------------
+# beamformer/GSC.py (config 3)
+# --------------------------------------------------------------------------------------------
+class OracleGSC:
+    """GSC.process (frequency-domain GSC + SPP-controlled LMS AIC + McMcra gain) — GSC.py:174-294."""
+
+    def __init__(self, mic, frameLen=512, dtype=np.float64, with_dead_state=True):
+        self.M = mic.M
+        self.nfft = int(frameLen)                           # beamformer.py:239-240 via GSC.py:33
+        self.hop = int(frameLen // 2)
+        self.half_bin = round(self.nfft / 2 + 1)
+        self.r, self.c, self.fs, self.gamma = mic.r, mic.c, mic.fs, mic.gamma
+        self.omega = 2 * np.pi * np.arange(self.half_bin) * self.fs / self.nfft
+        K, M = self.half_bin, self.M
+        self.G = np.zeros((M - 1, K), dtype=complex)        # :72
+        self.U = np.zeros((M - 1, K), dtype=complex)
+        self.Yfbf = np.zeros(K, dtype=complex)
+        self.transformer = OracleTransform(n_fft=self.nfft, hop_length=self.hop, channel=M, dtype=dtype)
+        self.spp = OracleMcMcra(nfft=self.nfft, channels=M)                 # :80-81
+        self.with_dead_state = with_dead_state
+        self.mcra = OracleMCRA(nfft=self.nfft)                              # :77 (output-dead)
+        self.omlsa_multi = OracleOmlsaMulti(nfft=self.nfft, cal_weights=True, M=M)   # :78 (output-dead)
+
+    def process_frame(self, Zk, angle_rad, method=2):
+        M = self.M
+        mu = 0.01                                                            # :202
+        tao = circular_tao(self.r, self.c, self.gamma, angle_rad)           # :186,209
+        a = np.exp(-1j * self.omega[:, None] * tao[None, :])                # [K, M]
+        self.spp.estimation(Zk)                                              # :225
+        if self.with_dead_state:
+            self.mcra.estimation(np.abs(Zk[:, 0] * np.conj(Zk[:, 0])))      # :240
+        if method == 0:
+            return Zk[:, 0].copy()                                           # :242-243
+        W = a / np.sum(np.conj(a) * a, axis=1, keepdims=True)               # :219  W = a/(a^H a)
+        # U_i = BM[:, i]^H z = conj(a_0) z_0 - conj(a_{i+1}) z_{i+1}          :220-222,261
+        U = np.conj(a[:, 0:1]) * Zk[:, 0:1] - np.conj(a[:, 1:]) * Zk[:, 1:]  # [K, M-1]
+        Yfbf = np.sum(np.conj(W) * Zk, axis=1)                               # :263
+        G = self.G.T                                                         # [K, M-1]
+        Y = Yfbf - np.sum(np.conj(G) * U, axis=1)                            # :266
+        G = G + mu * (1 - self.spp.p)[:, None] * U * np.conj(Y)[:, None]     # :270-274 (Pest == 1)
+        self.G = G.T.copy()
+        self.U = U.T.copy()
+        self.Yfbf = Yfbf
+        if self.with_dead_state:
+            self.omlsa_multi.estimation(np.real(Y * np.conj(Y)), np.real(U * np.conj(U)))   # :281-283
+        return Y * self.spp.G                                                # :286
+
+    def process(self, x, angle_rad, method=2):
+        """x [M, T*hop] -> y [T*hop] (T successive one-hop reference calls)."""
+        X = self.transformer.stft(np.asarray(x).T)
+        T = X.shape[1]
+        out = []
+        for t in range(T):   # one ISTFT call per hop, exactly like T one-hop reference calls (:288)
+            Yt = self.process_frame(X[:, t, :], angle_rad, method)
+            out.append(np.atleast_1d(self.transformer.istft(Yt[:, None, None])))
+        return np.concatenate(out)
+
+
+# --------------------------------------------------------------------------------------------
+# adaptivefilter/SubbandAF.py, SubbandLMS.py, SubbandLmsMc.py, SubbandRLS.py (frequency-domain input)
+# --------------------------------------------------------------------------------------------
+class OracleSubbandLMS:
+    """SubbandLMS.update with complex [K] inputs — SubbandAF.py:12-111, SubbandLMS.py:28-84."""
+
+    def __init__(self, filter_len=2, num_bands=512, mu=0.1, normalization=True, alpha=0.9):
+        self.N = filter_len
+        self.half_band = int(num_bands / 2) + 1
+        K = self.half_band
+        self.W = np.zeros((K, filter_len), dtype=complex)
+        self.mu = mu
+        self.norm = normalization
+        self.alpha = alpha
+        self.input_buffer = np.zeros((K, filter_len), dtype=complex)
+        self.P = np.zeros(K)
+
+    def update(self, x_n, d_n, alpha=1e-4, p=None):
+        K = self.half_band
+        p = np.ones(K) if p is None else (np.full(K, p) if np.isscalar(p) else np.asarray(p).reshape(K))
+        self.input_buffer[:, 1:] = self.input_buffer[:, :-1].copy()         # SubbandAF.py:50-51
+        self.input_buffer[:, 0] = x_n
+        out = np.einsum("ij,ij->i", self.W.conj(), self.input_buffer)       # SubbandAF.py:107
+        err = d_n - out * p                                                  # SubbandLMS.py:66-68
+        if self.norm:
+            self.P = self.alpha * self.P + (1 - self.alpha) * np.sum(
+                self.input_buffer.conj() * self.input_buffer, axis=-1).real  # :72-75
+            grad = self.input_buffer * err[:, None].conj() / (self.P[:, None] + alpha)
+        else:
+            grad = self.input_buffer * err[:, None].conj()
+        self.W = self.W + 2 * self.mu * grad * p[:, None]                    # SubbandAF.py:86
+        return err, self.W
+
+
+class OracleSubbandLmsMc:
+    """SubbandLmsMc.update with complex [K, M] inputs — SubbandLmsMc.py:144-191."""
+
+    def __init__(self, filter_len=2, num_bands=512, channel=4, mu=0.1, normalization=True, alpha=0.9):
+        self.N, self.M = filter_len, channel
+        self.half_band = int(num_bands / 2) + 1
+        K = self.half_band
+        self.W = np.zeros((K, filter_len, channel), dtype=complex)
+        self.mu, self.norm, self.alpha = mu, normalization, alpha
+        self.input_buffer = np.zeros((K, filter_len, channel), dtype=complex)
+        self.P = np.zeros(K)
+
+    def update(self, x_n, d_n, alpha=1e-4, p=None):
+        K = self.half_band
+        self.input_buffer[:, 1:, :] = self.input_buffer[:, :-1, :].copy()
+        self.input_buffer[:, 0, :] = x_n
+        out = np.einsum("ijk,ijk->i", self.W.conj(), self.input_buffer)
+        pv = None if p is None else np.asarray(p).reshape(K)
+        err = d_n - out * pv if pv is not None else d_n - out               # :168-172
+        if self.norm:
+            self.P = self.alpha * self.P + (1 - self.alpha) * np.einsum(
+                "ijk,ijk->i", self.input_buffer.conj(), self.input_buffer).real / self.M    # :174-180
+            grad = self.input_buffer * err[:, None, None].conj() / (self.P[:, None, None] + alpha)
+        else:
+            grad = self.input_buffer * err[:, None, None].conj()
+        if pv is not None:
+            self.W = self.W + 2 * self.mu * grad * pv[:, None, None]        # :136-137
+        else:
+            self.W = self.W + 2 * self.mu * grad
+        return err, self.W
+
+
+class OracleSubbandRLS:
+    """SubbandRLS.update with complex [K] inputs — SubbandRLS.py:12-71."""
+
+    def __init__(self, filter_len=2, num_bands=512, forgetting_factor=0.998, mu=0.5):
+        self.N = filter_len
+        self.half_band = int(num_bands / 2) + 1
+        K = self.half_band
+        self.W = np.zeros((K, filter_len), dtype=complex)
+        self.mu = mu
+        self.lam = forgetting_factor
+        self.lam_inv = 1.0 / forgetting_factor
+        self.input_buffer = np.zeros((K, filter_len), dtype=complex)
+        self.P = np.tile(np.eye(filter_len, dtype=complex) / 1e-3, (K, 1, 1))   # :40-42
+
+    def update(self, x_n, d_n, p=None):
+        self.input_buffer[:, 1:] = self.input_buffer[:, :-1].copy()
+        self.input_buffer[:, 0] = x_n
+        X = self.input_buffer
+        out = np.einsum("ij,ij->i", self.W.conj(), X)
+        err = d_n - out                                                      # :52
+        num = (self.P @ X[:, :, None])[..., 0]                               # :55
+        kn = num / (self.lam + np.sum(X.conj() * num, axis=-1, keepdims=True))   # :56-60
+        self.P = (self.P - kn[..., None] @ X[:, None, :].conj() @ self.P) * self.lam_inv   # :63
+        self.W = self.W + 2 * self.mu * (err[:, None].conj() * kn)           # :65-66
+        return err, self.W
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic input (SURVEY §8d / BASELINE.md §3) — shared by tests and the cpu_baseline leg
+# --------------------------------------------------------------------------------------------
+def synth_utterance(utt_index, n_samples, mic, angle_deg=(197, 0), fs=16000):
+    """Seeded synthetic M-channel utterance [M, n_samples] float32: white noise sigma=0.05 per mic
+    + 0.5 s on / 0.5 s off band-limited (300-3400 Hz) Gaussian source sigma=0.1 delayed per mic by
+    the far-field delays of `angle_deg` (fractional delays applied as a phase ramp in the DFT domain)."""
+    rng = np.random.default_rng(1234 + int(utt_index))
+    M = mic.M
+    noise = rng.standard_normal((M, n_samples)) * 0.05
+    src = rng.standard_normal(n_samples)
+    S = np.fft.rfft(src)
+    f = np.fft.rfftfreq(n_samples, 1.0 / fs)
+    S[(f < 300) | (f > 3400)] = 0
+    gate = ((np.arange(n_samples) // (fs // 2)) % 2 == 0).astype(np.float64)
+    tau = compute_tau(mic, np.array(angle_deg) / 180 * np.pi)[:, 0]
+    x = np.empty((M, n_samples))
+    for m in range(M):
+        sm = np.fft.irfft(S * np.exp(-2j * np.pi * f * tau[m]), n_samples)
+        sm = sm / (np.std(sm) + 1e-12) * 0.1
+        x[m] = sm * gate + noise[m]
+    return x.astype(np.float32)

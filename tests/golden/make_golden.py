@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE (wangwei2009/DistantSpeech) in this container.
+
+TEST INFRASTRUCTURE.  Needs /root/reference (read-only mount) — it does not exist on the GPU box;
+only the .npz files this script writes travel.  Nothing from the reference is copied: the fixtures
+hold inputs and the reference's numeric outputs only.
+
+    python tests/golden/make_golden.py            # (re)writes tests/golden/*.npz
+
+Repairs applied to broken reference entry points, each recorded in the fixture's
+``meta`` string:
+  R1  FixedBeamformer / adaptivebeamfomer are built with ``cls.__new__`` + ``beamformer.__init__``
+      + a replay of the remaining ctor body (their own ctors pass c=/fs= that
+      beamformer.__init__ no longer accepts: fixedbeamformer.py:99, adaptivebeamformer.py:13).
+  R2  MicArray(..., n_fft=nfft) so compute_steering_vector_from_doa fills all bins (beamformer.py:286).
+  R3  adaptivebeamfomer.process / GSC.process are called ONE HOP PER CALL and concatenated
+      (they hand a 2-D [K, T] array to Transform.istft, which reads 2-D as [K, channels]).
+  R4  SD weights at 512-FFT via the base class beamformer.compute_weights(weightType='SD')
+      (FixedBeamformer.compute_weights calls gen_noise_msc with nfft=256: shape error).
+  R5  stray prints silenced (fixedbeamformer.py:68-74).
+Third-party versions at generation time are recorded in every fixture.
+"""
+import contextlib
+import glob
+import io
+import os
+import sys
+
+import numpy as np
+import scipy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_shim  # noqa: E402
+
+_ref_shim.install()
+
+from scipy.io import wavfile  # noqa: E402
+from scipy.signal import windows  # noqa: E402
+
+from DistantSpeech.adaptivefilter.SubbandLMS import SubbandLMS  # noqa: E402
+from DistantSpeech.adaptivefilter.SubbandLmsMc import SubbandLmsMc  # noqa: E402
+from DistantSpeech.adaptivefilter.SubbandRLS import SubbandRLS  # noqa: E402
+from DistantSpeech.beamformer.adaptivebeamformer import adaptivebeamfomer  # noqa: E402
+from DistantSpeech.beamformer.beamformer import beamformer  # noqa: E402
+from DistantSpeech.beamformer.fixedbeamformer import FixedBeamformer  # noqa: E402
+from DistantSpeech.beamformer.GSC import GSC  # noqa: E402
+from DistantSpeech.beamformer.MicArray import MicArray  # noqa: E402
+from DistantSpeech.noise_estimation.mc_mcra import McMcra  # noqa: E402
+from DistantSpeech.noise_estimation.mcra import NoiseEstimationMCRA  # noqa: E402
+from DistantSpeech.noise_estimation.omlsa_multi import NsOmlsaMulti  # noqa: E402
+from DistantSpeech.transform.transform import Transform  # noqa: E402
+
+VERSIONS = "numpy=%s scipy=%s python=%s" % (np.__version__, scipy.__version__, sys.version.split()[0])
+ANGLE = np.array([197, 0]) / 180 * np.pi
+
+
+def save(name, meta, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, meta=np.array(meta + " | " + VERSIONS), **arrays)
+    print("wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def rec1_int16(start_s=3.0, dur_s=3.0):
+    """[4, L] int16 excerpt of the reference's own test recording (example/test_audio/rec1)."""
+    files = sorted(glob.glob(os.path.join(_ref_shim.REFERENCE_ROOT, "example/test_audio/rec1/*.wav")))
+    chans = []
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for f in files:
+            sr, d = wavfile.read(f)
+            assert sr == 16000 and d.dtype == np.int16
+            chans.append(d[int(start_s * sr): int((start_s + dur_s) * sr)])
+    x = np.stack(chans)
+    L = (x.shape[1] // 256) * 256
+    return x[:, :L]
+
+
+def synth(seed, M, L):
+    rng = np.random.default_rng(seed)
+    t = np.arange(L) / 16000.0
+    s = np.sin(2 * np.pi * 440 * t) * (np.sin(2 * np.pi * 1.5 * t) > 0) * 0.2
+    x = rng.standard_normal((M, L)) * 0.05 + s[None, :] * (1 + 0.1 * np.arange(M))[:, None]
+    return x.astype(np.float32)
+
+
+def make_adaptive(mic, nfft, hop):
+    """R1: adaptivebeamfomer without its broken ctor (adaptivebeamformer.py:13-42 replayed)."""
+    obj = adaptivebeamfomer.__new__(adaptivebeamfomer)
+    beamformer.__init__(obj, mic, frame_len=nfft, hop=hop, nfft=nfft)
+    obj.M = mic.M
+    obj.gamma = mic.gamma
+    obj.window = windows.hann(obj.frameLen, sym=False)
+    obj.win_scale = np.sqrt(1.0 / obj.window.sum() ** 2)
+    obj.freq_bin = np.linspace(0, obj.half_bin - 1, obj.half_bin)
+    obj.omega = 2 * np.pi * obj.freq_bin * obj.fs / obj.nfft
+    obj.H = np.ones([obj.M, obj.half_bin], dtype=complex) / obj.M
+    obj.angle = np.array([0, 0]) / 180 * np.pi
+    obj.method = "MVDR"
+    obj.frameCount = 0
+    obj.calc = 0
+    obj.estPos = None
+    obj.Rvv = np.zeros((obj.half_bin, obj.M, obj.M), dtype=complex)
+    obj.Rvv_inv = np.zeros((obj.half_bin, obj.M, obj.M), dtype=complex)
+    obj.Ryy = np.zeros((obj.half_bin, obj.M, obj.M), dtype=complex)
+    obj.AlgorithmList = ["src", "DS", "MVDR", "TFGSC"]
+    obj.AlgorithmIndex = 0
+    obj.transformer = Transform(n_fft=obj.nfft, hop_length=obj.hop, channel=obj.M)
+    obj.mcra = NoiseEstimationMCRA(nfft=obj.nfft)
+    obj.update_noise_psd_flag = 0
+    return obj
+
+
+def make_fixed(mic, nfft, hop, angle_deg, weightType):
+    """R1 + R4: FixedBeamformer without its broken ctor; weights from the base class."""
+    obj = FixedBeamformer.__new__(FixedBeamformer)
+    beamformer.__init__(obj, mic, frame_len=nfft, hop=hop, nfft=nfft)
+    obj.angle = list(angle_deg)
+    obj.AlgorithmList = ["src", "DS", "MVDR"]
+    obj.AlgorithmIndex = 0
+    obj.W = beamformer.compute_weights(obj, look_angle=list(angle_deg), weightType=weightType)
+    return obj
+
+
+# ------------------------------------------------------------------------------------------------
+def g1_transform():
+    rng = np.random.default_rng(11)
+    for (nfft, hop, M) in [(512, 256, 4), (1024, 512, 2), (256, 128, 1)]:
+        L = hop * 12
+        x = (rng.standard_normal((L, M)) * 0.1).astype(np.float32)
+        t1 = Transform(n_fft=nfft, hop_length=hop, channel=M)
+        Y_one = t1.stft(x.astype(np.float64))
+        y_one = t1.istft(Y_one)
+        # chunked: 1 hop, then 3 hops, then the rest
+        t2 = Transform(n_fft=nfft, hop_length=hop, channel=M)
+        cuts = [0, hop, 4 * hop, L]
+        Ys, ys = [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            Yc = t2.stft(x[a:b].astype(np.float64))
+            Ys.append(Yc)
+            ys.append(np.atleast_2d(t2.istft(Yc).T).T.reshape(b - a, -1))
+        Y_chunk = np.concatenate(Ys, axis=1)
+        y_chunk = np.concatenate(ys, axis=0)
+        assert np.array_equal(Y_one, Y_chunk)
+        save("g1_transform_%d_%d_%d" % (nfft, hop, M),
+             "Transform.stft/istft transform.py:430-481; chunked==one-shot verified bit-for-bit at generation",
+             x=x, Y=Y_one.astype(np.complex64), y=np.asarray(y_one).reshape(L, -1),
+             y_chunk=y_chunk, params=np.array([nfft, hop, M]))
+
+
+def g2_weights():
+    for (atype, M, r, nfft, ang) in [("circular", 4, 0.032, 512, (197, 0)), ("linear", 6, 0.05, 512, (60, 0)),
+                                      ("circular", 8, 0.05, 1024, (197, 10))]:
+        mic = MicArray(arrayType=atype, r=r, M=M, n_fft=nfft)      # R2
+        bf = beamformer(mic, frame_len=nfft, hop=nfft // 2, nfft=nfft)
+        a0 = bf.compute_steering_vector_from_doa(look_angle=ang)
+        Wds = bf.compute_weights(look_angle=list(ang), weightType="DS")
+        Wsd = bf.compute_weights(look_angle=list(ang), weightType="SD")   # R4
+        save("g2_weights_%s_M%d_%d" % (atype, M, nfft),
+             "beamformer.compute_steering_vector_from_doa/compute_weights beamformer.py:267-289,338-373; R2 R4",
+             a0=a0, Wds=Wds, Wsd=Wsd, Fvv=bf.Fvv, mic_loc=mic.mic_loc, gamma=mic.gamma,
+             params=np.array([M, nfft, ang[0], ang[1]], dtype=np.float64), r=np.array(r))
+
+
+def g3_mcra(x16):
+    x = x16.astype(np.float32) / 32768.0
+    tr = Transform(n_fft=512, hop_length=256, channel=1)
+    D = tr.stft(x[0].astype(np.float64))[:, :, 0]
+    P = np.abs(D * np.conj(D))
+    for L in (15, 10):
+        est = NoiseEstimationMCRA(nfft=512)
+        est.L = L
+        T = P.shape[1]
+        lam = np.zeros((T, 257)); p = np.zeros((T, 257)); S = np.zeros((T, 257)); Smin = np.zeros((T, 257))
+        for n in range(T):
+            est.estimation(P[:, n].copy())
+            lam[n], p[n], S[n], Smin[n] = est.lambda_d, est.p, est.S, est.Smin
+        save("g3_mcra_L%d" % L, "NoiseEstimationMCRA.estimation mcra.py:27-77 on |STFT(rec1 ch0)|^2, L=%d" % L,
+             P=P.T.copy(), lambda_d=lam, p=p, S=S[::8], Smin=Smin[::8])
+
+
+def g4_adaptive(x16):
+    cases = [("rec1", x16.astype(np.float32) / 32768.0, 4, 512, 256, 2),
+             ("synth", synth(5, 4, 256 * 90), 4, 512, 256, 2),
+             ("synth_ds", synth(6, 4, 256 * 40), 4, 512, 256, 1),
+             ("synth_src", synth(6, 4, 256 * 40), 4, 512, 256, 0),
+             ("synth_tfgsc", synth(8, 4, 256 * 60), 4, 512, 256, 3),
+             ("synth_m6", synth(7, 6, 256 * 60), 6, 512, 256, 2),
+             ("synth_m8_1024", synth(9, 8, 512 * 40), 8, 1024, 512, 2)]
+    for name, x, M, nfft, hop, method in cases:
+        mic = MicArray(arrayType="circular", r=0.032 if M == 4 else 0.05, M=M, n_fft=nfft)   # R2
+        ab = make_adaptive(mic, nfft, hop)                                                 # R1
+        T = x.shape[1] // hop
+        ys = []
+        snap = {}
+        with contextlib.redirect_stdout(io.StringIO()):
+            for t in range(T):                                                             # R3
+                out = ab.process(x[:, t * hop:(t + 1) * hop].astype(np.float64), ANGLE, method=method)
+                ys.append(np.atleast_1d(out["data"]))
+                if name in ("rec1", "synth") and t in (0, 30, 61):
+                    snap["Rvv_t%d" % t] = ab.Rvv.copy()
+                    snap["H_t%d" % t] = ab.H.copy()
+                    snap["p_t%d" % t] = ab.mcra.p.copy()
+        y = np.concatenate(ys)
+        save("g4_adaptive_%s" % name,
+             "adaptivebeamfomer.process(method=%d) adaptivebeamformer.py:44-128 hop-by-hop; R1 R2 R3; angle=197deg"
+             % method,
+             x=(x16 if name == "rec1" else x), y=y, Rvv=ab.Rvv, Rvv_inv=ab.Rvv_inv, Ryy=ab.Ryy, H=ab.H,
+             mcra_p=ab.mcra.p, mcra_lambda_d=ab.mcra.lambda_d,
+             params=np.array([M, nfft, hop, method]), r=np.array(mic.r), **snap)
+
+
+def g2b_fixed(x16):
+    x = x16.astype(np.float32) / 32768.0
+    mic = MicArray(arrayType="circular", r=0.032, M=4, n_fft=512)                          # R2
+    for wt in ("DS", "SD"):
+        fb = make_fixed(mic, 512, 256, (197, 0), wt)                                       # R1 R4
+        # mirror FixedBeamformer.process body (:190-207) without the per-call weight recompute
+        xt = x.T.astype(np.float64)[: 256 * 100]
+        D = fb.transform.stft(xt)
+        Yf = np.zeros((D.shape[0], D.shape[1], 1), dtype=complex)
+        for n in range(D.shape[1]):
+            Yf[:, n, 0] = fb.process_freframe(D[:, n, :])
+        y = fb.transform.istft(Yf)
+        save("g2b_fixed_%s" % wt,
+             "FixedBeamformer.process_freframe loop + Transform fixedbeamformer.py:147-207; R1 R2 R4; angle=197deg",
+             x=x16[:, : 256 * 100], y=y, W=fb.W)
+
+
+def g5_mcmcra(x16):
+    x = x16.astype(np.float32) / 32768.0
+    for name, xx, M in (("rec1", x, 4), ("synth_m6", synth(21, 6, 256 * 60), 6)):
+        tr = Transform(n_fft=512, hop_length=256, channel=M)
+        D = tr.stft(xx.T.astype(np.float64))
+        est = McMcra(nfft=512, channels=M)
+        T = D.shape[1]
+        p = np.zeros((T, 257)); G = np.zeros((T, 257)); xi = np.zeros((T, 257)); gam = np.zeros((T, 257))
+        for n in range(T):
+            est.estimation(D[:, n, :])
+            p[n], G[n], xi[n], gam[n] = est.p, est.G, est.xi, est.gamma
+        save("g5_mcmcra_%s" % name, "McMcra.estimation mc_mcra.py:179-224 frame by frame on Transform.stft output",
+             x=(x16 if name == "rec1" else xx), p=p, G=G, xi=xi[::8], gamma=gam[::8],
+             Phi_vv=np.moveaxis(est.Phi_vv, 2, 0), Phi_yy=np.moveaxis(est.Phi_yy, 2, 0), params=np.array([M, 512, 256]))
+
+
+def g6_gsc(x16):
+    x = x16.astype(np.float32) / 32768.0
+    for name, xx, M, method in (("rec1", x, 4, 2), ("synth_m6", synth(31, 6, 256 * 50), 6, 2),
+                                ("synth_m0", synth(32, 4, 256 * 20), 4, 0)):
+        mic = MicArray(arrayType="circular", r=0.032 if M == 4 else 0.05, M=M, n_fft=512)  # R2
+        with contextlib.redirect_stdout(io.StringIO()):                                    # R5
+            g = GSC(mic, frameLen=512, angle=[197, 0])
+        T = xx.shape[1] // 256
+        ys = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for t in range(T):                                                             # R3
+                out = g.process(xx[:, t * 256:(t + 1) * 256].astype(np.float64), ANGLE, method=method)
+                ys.append(np.atleast_1d(out["data"]))
+        y = np.concatenate(ys)
+        save("g6_gsc_%s" % name,
+             "GSC.process(method=%d) GSC.py:174-294 hop-by-hop; R2 R3 R5; angle=197deg" % method,
+             x=(x16 if name == "rec1" else xx), y=y, G=g.G, spp_G=g.spp.G, spp_p=g.spp.p,
+             omlsa_G=g.omlsa_multi.G, omlsa_p=g.omlsa_multi.p, omlsa_lambda_d=np.asarray(g.omlsa_multi.lambda_d),
+             mcra_p=g.mcra.p, params=np.array([M, 512, 256, method]), r=np.array(mic.r))
+
+
+def g7_omlsa():
+    rng = np.random.default_rng(41)
+    K, M, T = 257, 4, 120
+    env = 1.0 + 4.0 * (np.sin(np.arange(T) / 9.0) > 0.6)
+    y = (rng.chisquare(2, size=(T, K)) * 0.01 * env[:, None])
+    u = (rng.chisquare(2, size=(T, K, M - 1)) * 0.01)
+    est = NsOmlsaMulti(nfft=512, M=M, cal_weights=True)
+    G = np.zeros((T, K)); p = np.zeros((T, K)); lam = np.zeros((T, K)); xi = np.zeros((T, K)); q = np.zeros((T, K))
+    for n in range(T):
+        est.estimation(y[n].copy(), u[n].copy())
+        G[n], p[n], lam[n], xi[n], q[n] = est.G, est.p, est.lambda_d, est.xi_hat, est.q_hat
+    save("g7_omlsa", "NsOmlsaMulti.estimation omlsa_multi.py:73-156 (cal_weights=True) on chi2 powers",
+         y=y, u=u, G=G, p=p, lambda_d=lam, xi_hat=xi[::8], q_hat=q[::8])
+
+
+def g8_subband():
+    rng = np.random.default_rng(51)
+    K, T, M = 257, 60, 3
+    x = (rng.standard_normal((T, K)) + 1j * rng.standard_normal((T, K))) * 0.3
+    h0, h1 = 0.7 - 0.2j, -0.3 + 0.1j
+    d = np.conj(h0) * x + np.conj(h1) * np.vstack([np.zeros((1, K)), x[:-1]]) + 0.01 * rng.standard_normal((T, K))
+    pp = rng.uniform(0.0, 1.0, size=(T, K))
+    lms = SubbandLMS(filter_len=2, num_bands=512, mu=0.1)
+    rls = SubbandRLS(filter_len=2, num_bands=512)
+    e_l = np.zeros((T, K), dtype=complex); e_r = np.zeros((T, K), dtype=complex)
+    for n in range(T):
+        e_l[n], _ = lms.update(x[n].copy(), d[n].copy(), p=pp[n].copy())
+        e_r[n], _ = rls.update(x[n].copy(), d[n].copy())
+    xm = (rng.standard_normal((T, K, M)) + 1j * rng.standard_normal((T, K, M))) * 0.3
+    dm = np.sum(xm * np.array([0.5, -0.25j, 0.1])[None, None, :], axis=2)
+    mc = SubbandLmsMc(filter_len=2, num_bands=512, channel=M, mu=0.1)
+    e_m = np.zeros((T, K), dtype=complex)
+    for n in range(T):
+        e_m[n], _ = mc.update(xm[n][:, None, :].copy(), dm[n].copy(), p=pp[n][:, None].copy())  # x_n is [K, 1, C] (SubbandLmsMc.py:93)
+    save("g8_subband", "SubbandLMS/SubbandRLS/SubbandLmsMc.update with complex [K] inputs "
+         "(SubbandLMS.py:28-84, SubbandRLS.py:44-71, SubbandLmsMc.py:144-191)",
+         x=x, d=d, p=pp, e_lms=e_l, W_lms=lms.W, P_lms=lms.P, e_rls=e_r, W_rls=rls.W, P_rls=rls.P,
+         xm=xm, dm=dm, e_mc=e_m, W_mc=mc.W, P_mc=mc.P)
+
+
+def main():
+    x16 = rec1_int16(3.0, 3.0)
+    g1_transform()
+    g2_weights()
+    g2b_fixed(x16)
+    g3_mcra(x16)
+    g4_adaptive(x16)
+    g5_mcmcra(x16)
+    g6_gsc(x16)
+    g7_omlsa()
+    g8_subband()
+
+
+if __name__ == "__main__":
+    main()

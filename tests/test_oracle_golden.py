@@ -1,0 +1,167 @@
+"""Pin the CPU oracle (oracle/ds_oracle.py) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+
+from oracle import ds_oracle as O
+from conftest import rms
+
+ANGLE = np.array([197, 0]) / 180 * np.pi
+
+
+def _mic(M, nfft, r=None, atype="circular"):
+    return O.OracleMicArray(arrayType=atype, r=(0.032 if M == 4 else 0.05) if r is None else r, M=M, n_fft=nfft)
+
+
+@pytest.mark.parametrize("name", ["g1_transform_512_256_4", "g1_transform_1024_512_2", "g1_transform_256_128_1"])
+def test_transform(golden, name):
+    g = golden(name)
+    nfft, hop, M = [int(v) for v in g["params"]]
+    x = g["x"]
+    t = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop)
+    Y = t.stft(x)
+    assert np.array_equal(Y.astype(np.complex64), g["Y"])          # bit-exact complex64 STFT
+    y = np.asarray(t.istft(Y)).reshape(x.shape[0], -1)
+    assert np.max(np.abs(y - g["y"])) < 1e-7
+    # chunked == one-shot
+    t2 = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop)
+    cuts = [0, hop, 4 * hop, x.shape[0]]
+    ys = [np.asarray(t2.istft(t2.stft(x[a:b]))).reshape(b - a, -1) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.max(np.abs(np.concatenate(ys) - g["y_chunk"])) < 1e-7
+
+
+@pytest.mark.parametrize("name,atype", [("g2_weights_circular_M4_512", "circular"), ("g2_weights_linear_M6_512", "linear"),
+                                        ("g2_weights_circular_M8_1024", "circular")])
+def test_weights(golden, name, atype):
+    g = golden(name)
+    M, nfft, az, el = g["params"]
+    M, nfft = int(M), int(nfft)
+    mic = _mic(M, nfft, r=float(g["r"]), atype=atype)
+    assert np.allclose(mic.mic_loc, g["mic_loc"], atol=1e-15)
+    assert np.allclose(O.steering_from_doa(mic, nfft, (az, el)), g["a0"], atol=1e-12)
+    assert np.allclose(O.gen_noise_msc(mic, nfft), g["Fvv"], atol=1e-12)
+    assert np.allclose(O.fixed_weights(mic, nfft, (az, el), "DS"), g["Wds"], atol=1e-12)
+    assert np.allclose(O.fixed_weights(mic, nfft, (az, el), "SD"), g["Wsd"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("wt", ["DS", "SD"])
+def test_fixed_beamformer(golden, wt):
+    g = golden("g2b_fixed_" + wt)
+    x = g["x"].astype(np.float32) / 32768.0
+    fb = O.OracleFixedBeamformer(_mic(4, 512), frameLen=512, angle=(197, 0), weightType=wt)
+    assert np.allclose(fb.W, g["W"], rtol=1e-9, atol=1e-9)
+    y = fb.process(x.T)
+    assert rms(y - g["y"]) < 1e-7 * max(rms(g["y"]), 1e-3)
+
+
+@pytest.mark.parametrize("L", [15, 10])
+def test_mcra(golden, L):
+    g = golden("g3_mcra_L%d" % L)
+    est = O.OracleMCRA(nfft=512, L=L)
+    P = g["P"]
+    for n in range(P.shape[0]):
+        est.estimation(P[n])
+        assert np.allclose(est.lambda_d, g["lambda_d"][n], rtol=1e-12, atol=1e-18), n
+        assert np.allclose(est.p, g["p"][n], rtol=1e-12, atol=1e-15), n
+        if n % 8 == 0:
+            assert np.allclose(est.S, g["S"][n // 8], rtol=1e-12, atol=1e-18)
+            assert np.allclose(est.Smin, g["Smin"][n // 8], rtol=1e-12, atol=1e-18)
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth", "synth_ds", "synth_src", "synth_tfgsc", "synth_m6", "synth_m8_1024"])
+def test_adaptive_mvdr(golden, name):
+    g = golden("g4_adaptive_" + name)
+    M, nfft, hop, method = [int(v) for v in g["params"]]
+    x = g["x"]
+    if x.dtype == np.int16:
+        x = x.astype(np.float32) / 32768.0
+    ab = O.OracleAdaptiveMVDR(_mic(M, nfft, r=float(g["r"])), frameLen=nfft, hop=hop, nfft=nfft)
+    y = ab.process(x, ANGLE, method=method)
+    ref = g["y"]
+    assert y.shape == ref.shape
+    assert rms(y - ref) < 1e-7 * max(rms(ref), 1e-3), rms(y - ref)
+    assert np.allclose(ab.Rvv, g["Rvv"], rtol=1e-9, atol=1e-14)
+    assert np.allclose(ab.Ryy, g["Ryy"], rtol=1e-9, atol=1e-14)
+    assert np.allclose(ab.mcra.p, g["mcra_p"], rtol=1e-10, atol=1e-14)
+    if method == 2:
+        assert np.allclose(ab.H, g["H"], rtol=1e-5, atol=1e-7)
+
+
+def test_adaptive_mvdr_chunk_invariance(golden):
+    g = golden("g4_adaptive_synth")
+    x = g["x"][:, : 256 * 40]
+    mic = _mic(4, 512)
+    a = O.OracleAdaptiveMVDR(mic, 512).process(x, ANGLE)
+    b_ = O.OracleAdaptiveMVDR(mic, 512)
+    b = np.concatenate([b_.process(x[:, : 256 * 7], ANGLE), b_.process(x[:, 256 * 7:], ANGLE)])
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+def test_mcmcra(golden, name):
+    g = golden("g5_mcmcra_" + name)
+    M, nfft, hop = [int(v) for v in g["params"]]
+    x = g["x"]
+    if x.dtype == np.int16:
+        x = x.astype(np.float32) / 32768.0
+    D = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop).stft(x.T)
+    est = O.OracleMcMcra(nfft=nfft, channels=M)
+    for n in range(D.shape[1]):
+        est.estimation(D[:, n, :])
+        assert np.allclose(est.p, g["p"][n], rtol=1e-6, atol=1e-9), n
+        assert np.allclose(est.G, g["G"][n], rtol=1e-6, atol=1e-9), n
+        if n % 8 == 0:
+            assert np.allclose(est.xi, g["xi"][n // 8], rtol=1e-6, atol=1e-9)
+            assert np.allclose(est.gamma, g["gamma"][n // 8], rtol=1e-6, atol=1e-9)
+    assert np.allclose(est.Phi_vv, g["Phi_vv"], rtol=1e-9, atol=1e-14)
+    assert np.allclose(est.Phi_yy, g["Phi_yy"], rtol=1e-9, atol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6", "synth_m0"])
+def test_gsc(golden, name):
+    g = golden("g6_gsc_" + name)
+    M, nfft, hop, method = [int(v) for v in g["params"]]
+    x = g["x"]
+    if x.dtype == np.int16:
+        x = x.astype(np.float32) / 32768.0
+    gsc = O.OracleGSC(_mic(M, nfft, r=float(g["r"])), frameLen=nfft)
+    y = gsc.process(x, ANGLE, method=method)
+    ref = g["y"]
+    assert rms(y - ref) < 1e-7 * max(rms(ref), 1e-3), rms(y - ref)
+    assert np.allclose(gsc.spp.p, g["spp_p"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(gsc.spp.G, g["spp_G"], rtol=1e-6, atol=1e-9)
+    if method != 0:
+        assert np.allclose(gsc.G, g["G"], rtol=1e-7, atol=1e-10)
+        assert np.allclose(gsc.omlsa_multi.G, g["omlsa_G"], rtol=1e-6, atol=1e-9)
+        assert np.allclose(gsc.omlsa_multi.p, g["omlsa_p"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(gsc.mcra.p, g["mcra_p"], rtol=1e-10, atol=1e-14)
+
+
+def test_omlsa(golden):
+    g = golden("g7_omlsa")
+    est = O.OracleOmlsaMulti(nfft=512, M=4, cal_weights=True)
+    for n in range(g["y"].shape[0]):
+        est.estimation(g["y"][n], g["u"][n])
+        assert np.allclose(est.G, g["G"][n], rtol=1e-9, atol=1e-12), n
+        assert np.allclose(est.p, g["p"][n], rtol=1e-9, atol=1e-12), n
+        assert np.allclose(est.lambda_d, g["lambda_d"][n], rtol=1e-9, atol=1e-15), n
+        if n % 8 == 0:
+            assert np.allclose(est.xi_hat, g["xi_hat"][n // 8], rtol=1e-9, atol=1e-12)
+            assert np.allclose(est.q_hat, g["q_hat"][n // 8], rtol=1e-9, atol=1e-12)
+
+
+def test_subband(golden):
+    g = golden("g8_subband")
+    lms, rls = O.OracleSubbandLMS(2, 512, mu=0.1), O.OracleSubbandRLS(2, 512)
+    mc = O.OracleSubbandLmsMc(2, 512, channel=g["xm"].shape[2], mu=0.1)
+    for n in range(g["x"].shape[0]):
+        e, _ = lms.update(g["x"][n], g["d"][n], p=g["p"][n])
+        assert np.allclose(e, g["e_lms"][n], rtol=1e-10, atol=1e-12)
+        e, _ = rls.update(g["x"][n], g["d"][n])
+        assert np.allclose(e, g["e_rls"][n], rtol=1e-8, atol=1e-10)
+        e, _ = mc.update(g["xm"][n], g["dm"][n], p=g["p"][n])
+        assert np.allclose(e, g["e_mc"][n], rtol=1e-10, atol=1e-12)
+    assert np.allclose(lms.W, g["W_lms"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(rls.W, g["W_rls"], rtol=1e-7, atol=1e-10)
+    assert np.allclose(rls.P, g["P_rls"], rtol=1e-6, atol=1e-8)
+    assert np.allclose(mc.W, g["W_mc"], rtol=1e-9, atol=1e-12)
