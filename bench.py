@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py — enhanced frames/s of the MVDR hot path (BASELINE.json configs[1]):
+adaptive MVDR, 4 mics, 16 kHz, 512-FFT / 256-hop, batch = 1024 synthetic utterances per GPU.
+
+A "step" is one pass of the hot path over the batch in the streaming-callback regime: ONE hop
+(256 samples x 4 channels) of every utterance in -> one hop of enhanced audio out, all carried
+state (STFT tail, OLA tail, Rvv, MCRA trackers) read from and written back to HBM (T = 1 in
+SURVEY.md section 8d).  Inputs are resident in HBM before the timed region starts.
+
+    python bench.py --gpus 1 --steps 625 --warmup 25
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`."""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+M, NFFT, HOP, BATCH, FS = 4, 512, 256, 1024, 16000
+ANGLE = np.array([197.0, 0.0]) / 180.0 * np.pi
+# algorithmic bytes per frame at T hops per call
+#   bytes(T) = M*hop*4 (in) + hop*4 (out) + 2*S/T,  S = 43 156 B of output-affecting state per utterance
+S_STATE = 4096 + 1024 + 257 * 16 * 8 + 5 * 257 * 4
+
+
+def algorithmic_bytes_per_frame(T):
+    return M * HOP * 4 + HOP * 4 + 2.0 * S_STATE / T
+
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def synth_batch_torch(torch, B, L, device, seed):
+    """[B, M, L] float32 on `device`: white noise sigma=0.05 per mic + 0.5 s on/off band-limited
+    (300-3400 Hz) Gaussian source sigma=0.1 steered from 197 deg through the array delays
+    (BASELINE.md section 3), generated on the GPU."""
+    from distantspeech_amd.mic_array import MicArray, compute_tau
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + seed)
+    mic = MicArray(M=M, n_fft=NFFT)
+    tau = torch.tensor(compute_tau(mic, ANGLE)[:, 0], dtype=torch.float32, device=device)
+    x = torch.empty((B, M, L), dtype=torch.float32, device=device)
+    f = torch.fft.rfftfreq(L, 1.0 / FS).to(device)
+    band = ((f >= 300) & (f <= 3400)).to(torch.float32)
+    gate = ((torch.arange(L, device=device) // (FS // 2)) % 2 == 0).to(torch.float32)
+    chunk = 64
+    for b0 in range(0, B, chunk):
+        b1 = min(B, b0 + chunk)
+        S = torch.fft.rfft(torch.randn((b1 - b0, L), generator=g, device=device)) * band
+        for m in range(M):
+            ph = torch.exp(-2j * math.pi * f * tau[m])
+            s = torch.fft.irfft(S * ph, n=L)
+            s = s / (s.std(dim=1, keepdim=True) + 1e-12) * 0.1
+            x[b0:b1, m] = s * gate + 0.05 * torch.randn((b1 - b0, L), generator=g, device=device)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline leg: the oracle (a "port": NumPy restatement of the reference) on the host cores
+# ------------------------------------------------------------------------------------------------
+def _cpu_worker(args):
+    utt, frames = args
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from oracle import ds_oracle as O
+    mic = O.OracleMicArray(M=M, n_fft=NFFT)
+    x = O.synth_utterance(utt, HOP * frames, mic)
+    ab = O.OracleAdaptiveMVDR(mic, NFFT)
+    t0 = time.perf_counter()
+    for t in range(frames):                       # one hop per call: the same regime as the GPU step
+        ab.process(x[:, t * HOP:(t + 1) * HOP], ANGLE, 2)
+    return frames, time.perf_counter() - t0
+
+
+def cpu_baseline(budget_s=12.0):
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    # calibrate on one core, then size the sample to ~budget_s of wall time per core
+    f0, t0 = _cpu_worker((0, 40))
+    per_core = f0 / t0
+    frames = int(max(40, min(2000, per_core * budget_s)))
+    ctx = mp.get_context("spawn")
+    t_start = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(u, frames) for u in range(cores)])
+    wall = time.perf_counter() - t_start
+    busy = max(r[1] for r in res)
+    total = sum(r[0] for r in res)
+    return {"value": round(total / busy, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d utterances x %d hops (one hop per call), oracle/ds_oracle.py OracleAdaptiveMVDR, "
+                      "one process per core; %.1f s wall" % (cores, frames, wall),
+            "per_core": round(total / busy / cores, 1)}
+
+
+def load_traffic():
+    """HBM bytes per launch from the committed PMC profile of this same command (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=625)
+    ap.add_argument("--warmup", type=int, default=25)
+    ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU (BASELINE cfg2: 1024)")
+    ap.add_argument("--hops-per-step", type=int, default=1, help="T: hops per call (1 = streaming callback regime)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from distantspeech_amd import BatchEngine, dist as dsdist
+    from distantspeech_amd import _lib as L
+    from distantspeech_amd.mic_array import MicArray
+
+    rank, local_rank, world = dsdist.init()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    B, K, W, T = args.batch, args.steps, args.warmup, args.hops_per_step
+    hops_total = (K + W) * T
+    Ltot = hops_total * HOP
+    x = synth_batch_torch(torch, B, Ltot, device, seed=rank)
+    y = torch.empty((B, Ltot), dtype=torch.float32, device=device)
+
+    eng = BatchEngine(L.ALGO_ADAPTIVE, M, NFFT, HOP, batch=B, device=local_rank)
+    mic = MicArray(M=M, n_fft=NFFT)
+    tao = -1 * mic.r * np.cos(ANGLE[1]) * np.cos(ANGLE[0] - mic.gamma) / mic.c
+    omega = 2 * np.pi * np.arange(NFFT // 2 + 1) * FS / NFFT
+    eng.set_steering(np.exp(-1j * omega[:, None] * tao[None, :]))
+    eng.set_method(L.METHOD_MVDR)
+
+    stream = torch.cuda.current_stream().cuda_stream
+    xp, yp = x.data_ptr(), y.data_ptr()
+
+    def step(i):
+        off = i * T * HOP
+        eng.process_device(xp + 4 * off, L.LAYOUT_CHANNELS_SAMPLES, M * Ltot, T * HOP, yp + 4 * off, Ltot,
+                           stream=stream, x_chan_stride=Ltot)
+
+    for i in range(W):
+        step(i)
+    torch.cuda.synchronize()
+    dsdist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(W, W + K):
+        step(i)
+    ev1.record()
+    torch.cuda.synchronize()
+    dsdist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+
+    frames_rank = B * K * T
+    frames, t_max = dsdist.reduce_throughput(frames_rank, elapsed, device=device)
+    assert bool(torch.isfinite(y[:, W * T * HOP:]).all()), "non-finite output"
+
+    if rank == 0:
+        launch_ms = dev_ms / K                                  # average launch duration (HIP events, same stream)
+        alg_bytes = algorithmic_bytes_per_frame(T) * B * T      # per launch
+        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "enhanced frames/sec (4-mic, 512-FFT)", "value": round(frames / t_max, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(t_max / K * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "adaptive MVDR (adaptivebeamfomer.process method=2), 4 mics, 16 kHz, 512-FFT/256-hop, "
+                                   "batch=%d utterances per GPU, %d hop(s) per call (streaming callback regime), "
+                                   "state resident in HBM" % (B, T),
+                       "batch_per_gpu": B, "hops_per_call": T, "n_mics": M, "nfft": NFFT, "hop": HOP},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(),
+                         "kernel": "ds_frames_kernel<512,4,ADAPTIVE>", "launch_ms": round(launch_ms, 5),
+                         "algorithmic_bytes_per_frame": algorithmic_bytes_per_frame(T)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

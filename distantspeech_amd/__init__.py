@@ -1,0 +1,11 @@
+"""distantspeech_amd — MI355X-native per-frame multichannel speech enhancement
+(streaming STFT -> beamformer -> post-filter -> ISTFT overlap-add), a drop-in for that hot path of
+wangwei2009/DistantSpeech.  The compute lives in libdsenh.so (hand-written HIP for gfx950,
+C-ABI in include/dsenh.h); this package mirrors the reference's Python object interface on top."""
+from . import _lib
+from .engine import BatchEngine
+from .mic_array import MicArray, compute_tau, gen_noise_msc
+from .beamformer import beamformer, FixedBeamformer, adaptivebeamfomer, GSC, compute_mvdr_weight
+
+__all__ = ["BatchEngine", "MicArray", "compute_tau", "gen_noise_msc", "beamformer", "FixedBeamformer",
+           "adaptivebeamfomer", "GSC", "compute_mvdr_weight"]

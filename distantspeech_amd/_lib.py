@@ -1,0 +1,107 @@
+"""ctypes binding of libdsenh.so (C-ABI in include/dsenh.h).
+
+The library holds the hand-written gfx950 kernels; there is NO CPU implementation behind this
+module.  If the shared library is missing (not built) or no HIP device is visible, every entry
+point fails loudly."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsenh.so")
+
+DS_OK = 0
+ALGO_FIXED, ALGO_ADAPTIVE, ALGO_GSC = 0, 1, 2
+METHOD_SRC, METHOD_DS, METHOD_MVDR, METHOD_TFGSC = 0, 1, 2, 3
+LAYOUT_SAMPLES_CHANNELS, LAYOUT_CHANNELS_SAMPLES = 0, 1
+PARAM_METHOD, PARAM_MCRA_L, PARAM_ALPHA_Y, PARAM_ALPHA_V, PARAM_DIAG, PARAM_GATE, PARAM_MU = 1, 2, 3, 4, 5, 6, 7
+(FIELD_RVV, FIELD_RYY, FIELD_MCRA_S, FIELD_MCRA_SMIN, FIELD_MCRA_STMP, FIELD_MCRA_P, FIELD_MCRA_LAMBDA_D,
+ FIELD_PHI_YY, FIELD_PHI_VV, FIELD_G_AIC, FIELD_STFT_TAIL, FIELD_OLA_TAIL, FIELD_COUNTERS) = range(1, 14)
+
+
+class ds_config(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_int32), ("algo", ctypes.c_int32), ("n_mics", ctypes.c_int32),
+        ("nfft", ctypes.c_int32), ("hop", ctypes.c_int32), ("batch", ctypes.c_int32),
+        ("track_ryy", ctypes.c_int32), ("mcra_L", ctypes.c_int32), ("device", ctypes.c_int32),
+        ("alpha_y", ctypes.c_float), ("alpha_v", ctypes.c_float), ("diag", ctypes.c_float),
+        ("gate", ctypes.c_float), ("mu", ctypes.c_float),
+    ]
+
+
+class DsError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("libdsenh error %d: %s" % (code, text))
+        self.code = code
+
+
+_lib = None
+
+# every symbol include/dsenh.h declares (tests check that the built library exports all of them)
+EXPORTS = [
+    "ds_version", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
+    "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_device", "ds_synchronize",
+    "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_export_state",
+    "ds_import_state",
+]
+
+
+def load():
+    """Load libdsenh.so; raises with build instructions if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "distantspeech_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C distantspeech_amd/csrc` (needs hipcc, --offload-arch=gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, cf_, cll, csz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_size_t
+    lib.ds_version.restype = ci
+    lib.ds_device_count.restype = ci
+    lib.ds_strerror.restype = ctypes.c_char_p
+    lib.ds_strerror.argtypes = [ci]
+    lib.ds_create.restype = ci
+    lib.ds_create.argtypes = [ctypes.POINTER(ds_config), ctypes.POINTER(vp)]
+    lib.ds_destroy.restype = ci
+    lib.ds_destroy.argtypes = [vp]
+    lib.ds_reset.restype = ci
+    lib.ds_reset.argtypes = [vp]
+    lib.ds_last_error.restype = ctypes.c_char_p
+    lib.ds_last_error.argtypes = [vp]
+    lib.ds_set_steering.restype = ci
+    lib.ds_set_steering.argtypes = [vp, vp, ci]
+    lib.ds_set_param_i.restype = ci
+    lib.ds_set_param_i.argtypes = [vp, ci, ci]
+    lib.ds_set_param_f.restype = ci
+    lib.ds_set_param_f.argtypes = [vp, ci, cf_]
+    lib.ds_process.restype = ci
+    lib.ds_process.argtypes = [vp, vp, ci, ci, vp]
+    lib.ds_process_device.restype = ci
+    lib.ds_process_device.argtypes = [vp, vp, ci, cll, cll, ci, vp, cll, ci, ci, vp]
+    lib.ds_synchronize.restype = ci
+    lib.ds_synchronize.argtypes = [vp]
+    lib.ds_timing_begin.restype = ci
+    lib.ds_timing_begin.argtypes = [vp]
+    lib.ds_timing_end.restype = ci
+    lib.ds_timing_end.argtypes = [vp, ctypes.POINTER(cf_)]
+    lib.ds_get_state.restype = ci
+    lib.ds_get_state.argtypes = [vp, ci, vp, csz]
+    lib.ds_field_bytes.restype = csz
+    lib.ds_field_bytes.argtypes = [vp, ci]
+    lib.ds_state_bytes.restype = csz
+    lib.ds_state_bytes.argtypes = [vp]
+    lib.ds_export_state.restype = ci
+    lib.ds_export_state.argtypes = [vp, vp, csz]
+    lib.ds_import_state.restype = ci
+    lib.ds_import_state.argtypes = [vp, vp, csz]
+    _lib = lib
+    return lib
+
+
+def check(rc, handle=None):
+    if rc != DS_OK:
+        lib = load()
+        text = lib.ds_last_error(handle)
+        text = text.decode() if text else lib.ds_strerror(rc).decode()
+        raise DsError(rc, text)

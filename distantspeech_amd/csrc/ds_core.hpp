@@ -1,0 +1,703 @@
+// ds_core.hpp — single-source block program of the fused per-frame enhancement kernel.
+//
+// One workgroup owns one utterance and walks its frames in order:
+//   hop of M-channel samples -> LDS -> windowed real FFT (packed N/2-point complex Stockham, LDS)
+//   -> one thread per frequency bin: MCRA / covariance recursion / Hermitian solve / weights
+//   -> inverse packed real FFT -> windowed overlap-add -> hop of enhanced samples.
+// Per-bin state (covariances, MCRA trackers) lives in registers for the whole call and in HBM
+// between calls as float4 planes [plane][bin] so that every state access is a 16-byte-per-lane
+// coalesced load/store.
+//
+// The program is written against an "Exec" policy: ex.phase(f) runs f(tid, regs) for every
+// thread of the block and then synchronises.  dsenh.hip instantiates it with a HIP policy
+// (f runs once per GPU thread, then __syncthreads()).  tests/emul/ instantiates it with a serial
+// CPU policy purely to unit-test the index arithmetic without a GPU; that build is test
+// infrastructure and is never loaded by the product package.
+//
+// Reference semantics (paths relative to /root/reference/DistantSpeech):
+//   STFT/ISTFT            transform/transform.py:407-481
+//   MCRA                  noise_estimation/mcra.py:27-77, NoiseEstimationBase.py:56-60
+//   adaptive MVDR         beamformer/adaptivebeamformer.py:44-128, beamformer/beamformer.py:306-336
+//   fixed beamformer      beamformer/fixedbeamformer.py:147-207
+//   FD-GSC + McMcra gain  beamformer/GSC.py:174-294, noise_estimation/mc_mcra.py:91-224
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DS_HD __host__ __device__ __forceinline__
+#else
+#include <cmath>
+#define DS_HD inline
+#endif
+
+namespace ds {
+
+#if defined(__HIPCC__)
+typedef float4 vec4;
+#else
+struct alignas(16) vec4 { float x, y, z, w; };
+#endif
+
+struct cf { float x, y; };
+
+DS_HD cf mk(float a, float b) { cf r; r.x = a; r.y = b; return r; }
+DS_HD cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
+DS_HD cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
+DS_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+DS_HD cf cmulc(cf a, cf b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+DS_HD cf cconj(cf a) { return mk(a.x, -a.y); }
+DS_HD cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
+DS_HD float cabs2(cf a) { return a.x * a.x + a.y * a.y; }
+DS_HD cf cdiv(cf a, cf b) { float d = 1.0f / (b.x * b.x + b.y * b.y); return mk((a.x * b.x + a.y * b.y) * d, (a.y * b.x - a.x * b.y) * d); }
+
+DS_HD float fminf_(float a, float b) { return a < b ? a : b; }
+DS_HD float fmaxf_(float a, float b) { return a > b ? a : b; }
+
+enum { ALGO_FIXED = 0, ALGO_ADAPTIVE = 1, ALGO_GSC = 2 };
+enum { METHOD_SRC = 0, METHOD_DS = 1, METHOD_MVDR = 2, METHOD_TFGSC = 3 };
+
+// ---------------------------------------------------------------------------------------------
+// Launch parameters (plain data; passed to the kernel by value)
+// ---------------------------------------------------------------------------------------------
+struct Params {
+    const float* x;           // input samples (device)
+    float* y;                 // output samples (device), [B][T*hop]
+    long long x_batch_stride; // elements between utterances
+    long long x_sample_stride;
+    long long x_chan_stride;
+    long long y_batch_stride;
+    int T;                    // hops in this call
+    int batch0;               // first utterance handled by block 0 (state / io index offset)
+    vec4* bins;               // per-bin state planes [B][NP][KP]
+    float* tail_in;           // STFT overlap [B][M][hop]
+    float* tail_out;          // OLA overlap  [B][hop]
+    int* counters;            // [B][4]  {mcra frm_cnt, mcra ell, spp frm_cnt, reserved}
+    const cf* twN;            // [N/2+1]  exp(-2 pi j i / N)
+    const float* win;         // [N] sqrt-Hann
+    const cf* steer;          // [K][M] steering vector a (adaptive/GSC) or weights W (fixed)
+    long long steer_batch_stride;   // 0: one look direction shared by the batch
+    int method;               // METHOD_* (adaptive) ; GSC: 0 = pass channel 0, else GSC
+    int mcra_L;               // MCRA minimum-search window (mcra.py:25)
+    float out_scale;          // hop / W0 (transform.py:479)
+    float alpha_y, alpha_v;   // adaptivebeamformer.py:65-66
+    float diag;               // adaptivebeamformer.py:89
+    float gate;               // adaptivebeamformer.py:94
+    float mu;                 // GSC.py:202
+};
+
+// number of per-bin state floats / planes
+template <int M, int ALGO, bool RYY> struct StateLayout {
+    static constexpr int NF =
+        ALGO == ALGO_ADAPTIVE ? (M * M + 5 + (RYY ? M * M : 0))
+        : ALGO == ALGO_GSC    ? (M * (M + 1) + 2 * (M - 1))
+                              : 0;
+    static constexpr int NP = (NF + 3) / 4;
+    // ADAPTIVE float map
+    static constexpr int R_DIAG = 0;                 // M reals
+    static constexpr int R_OFF = M;                  // M(M-1)/2 complex, (i<j) row-major
+    static constexpr int MC_S = M * M;               // S, Smin, Stmp, p, lambda_d
+    static constexpr int RYY_DIAG = M * M + 5;
+    static constexpr int RYY_OFF = M * M + 5 + M;
+    // GSC float map
+    static constexpr int PYY = 0;                    // sym packed (i<=j) row-major, M(M+1)/2
+    static constexpr int PVV = M * (M + 1) / 2;
+    static constexpr int GA = M * (M + 1);           // (M-1) complex
+};
+
+DS_HD constexpr int off_index(int i, int j, int M) {   // i<j -> index among strictly-upper entries
+    return i * M - (i * (i + 1)) / 2 + (j - i - 1);
+}
+DS_HD constexpr int sym_index(int i, int j, int M) {   // i<=j -> index among upper-incl-diag entries
+    return i * M - (i * (i - 1)) / 2 + (j - i);
+}
+
+template <int NFFT, int M> struct Shared {
+    static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2;
+    float xbuf[M][N];     // two halves: [old hop | new hop], roles swap every frame
+    cf fa[M][NC];
+    cf fb[M][NC];
+    cf tw[NC + 1];
+    float win[N];
+    float pw[K + 3];      // |Z_0|^2 for the MCRA frequency stencil
+    cf Y[K + 1];          // beamformer output spectrum
+    float tail[HOP];      // overlap-add tail
+};
+
+template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
+    cf Z[M];
+    float st[StateLayout<M, ALGO, RYY>::NP * 4 + 1];
+    vec4 pre[NPRE];
+};
+
+// ---------------------------------------------------------------------------------------------
+// FFT stages (Stockham autosort, radix 4 / radix 2), all channels of the block at once
+// ---------------------------------------------------------------------------------------------
+template <int R, int SIGN> DS_HD void butterfly(cf* v) {
+    if constexpr (R == 4) {
+        cf t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]);
+        cf d = csub(v[1], v[3]);
+        cf t3 = SIGN < 0 ? mk(d.y, -d.x) : mk(-d.y, d.x);   // (-/+ j) * d
+        v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
+    } else {
+        cf a = v[0], b = v[1];
+        v[0] = cadd(a, b); v[1] = csub(a, b);
+    }
+}
+
+// in/out: [MCH][NC].  FROM_X: read windowed real samples packed as (x[2n], x[2n+1]) from xbuf.
+template <int NFFT, int M, int MCH, int R, int SIGN, bool FROM_X>
+DS_HD void fft_stage(int tid, int nt, Shared<NFFT, M>& sh, const cf* in, cf* out, int Ns, int old_half) {
+    constexpr int NC = NFFT / 2, NB = NC / R, HOP = NFFT / 2;
+    const int tstride = NFFT / (Ns * R);
+    for (int idx = tid; idx < MCH * NB; idx += nt) {
+        const int ch = idx / NB, j = idx - ch * NB;
+        const int k = j & (Ns - 1);
+        cf v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = j + r * NB;
+            if constexpr (FROM_X) {
+                const int s = 2 * n;
+                const int pos = s < HOP ? old_half * HOP + s : (old_half ^ 1) * HOP + (s - HOP);
+                v[r] = mk(sh.win[s] * sh.xbuf[ch][pos], sh.win[s + 1] * sh.xbuf[ch][pos + 1]);
+            } else {
+                v[r] = in[ch * NC + n];
+            }
+        }
+        if (Ns > 1) {
+            cf w1 = sh.tw[k * tstride];
+            if (SIGN > 0) w1 = cconj(w1);
+            if constexpr (R == 4) {
+                cf w2 = sh.tw[2 * k * tstride];
+                if (SIGN > 0) w2 = cconj(w2);
+                cf w3 = cmul(w1, w2);
+                v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3);
+            } else {
+                v[1] = cmul(v[1], w1);
+            }
+        }
+        butterfly<R, SIGN>(v);
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[ch * NC + j0 + r * Ns] = v[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MCRA (one bin) — mcra.py:27-77.  k: bin, K: half_bin.  st: S,Smin,Stmp,p,lambda_d.
+// frm_cnt / ell are the frame-level counters *before* this frame; `reset` = (ell % L == 0).
+// ---------------------------------------------------------------------------------------------
+DS_HD void mcra_bin(float* st, int k, int K, const float* pw, int frm_cnt, bool reset, int L) {
+    const float alpha_s = 0.8f, one_m_alpha_s = (float)(1.0 - 0.8), delta_s = 5.0f;
+    const float alpha_p = 0.2f, one_m_alpha_p = (float)(1.0 - 0.2), alpha_d = 0.95f, one_m_alpha_d = (float)(1.0 - 0.95);
+    const float p_max = 0.999f, p_min = 1e-3f;
+    float S = st[0], Smin = st[1], Stmp = st[2], p = st[3], lam = st[4];
+    const float Yk = pw[k];
+    if (frm_cnt == 0) {
+        if (k < K - 1) { Smin = Yk; Stmp = Yk; lam = Yk; p = 0.0f; }                 // :38-41,68-69
+    } else if (k == 0) {
+        p = 0.0f;                                                                     // :43-45
+    } else if (k < K - 1) {
+        const float Sf = pw[k - 1] * 0.25f + Yk * 0.5f + pw[k + 1] * 0.25f;           // :46
+        S = alpha_s * S + one_m_alpha_s * Sf;                                         // :47
+        Smin = fminf_(Smin, S); Stmp = fminf_(Stmp, S);                               // :49-50
+        if (reset) { Smin = fminf_(Stmp, S); Stmp = S; }                              // :52-56
+        const float Sr = S / (Smin + 1e-6f);                                          // :58
+        const float I = Sr > delta_s ? 1.0f : 0.0f;                                   // :60-63
+        p = alpha_p * p + one_m_alpha_p * I;                                          // :65-67
+        if (frm_cnt < 2 * L) p = 0.0f;                                                // :68-69
+    }
+    p = fmaxf_(fminf_(p, p_max), p_min);                                              // :70
+    if (k == K - 1) lam = 1e-8f;                                                      // :73
+    const float at = alpha_d + one_m_alpha_d * p;                                     // Base :57
+    lam = at * lam + (1.0f - at) * Yk;                                                // Base :60
+    st[0] = S; st[1] = Smin; st[2] = Stmp; st[3] = p; st[4] = lam;
+}
+
+// Hermitian packed (diag reals d[M], strictly-upper complex o[]) helpers ------------------------
+template <int M> DS_HD cf herm_get(const float* d, const float* o, int i, int j) {   // element (i,j)
+    if (i == j) return mk(d[i], 0.0f);
+    if (i < j) { int q = off_index(i, j, M); return mk(o[2 * q], o[2 * q + 1]); }
+    int q = off_index(j, i, M); return mk(o[2 * q], -o[2 * q + 1]);
+}
+
+// rank-1 recursive update  R <- a R + b z z^H   (adaptivebeamformer.py:86-88,97-99)
+template <int M> DS_HD void herm_rank1(float* d, float* o, const cf* z, float a, float b) {
+#pragma unroll
+    for (int i = 0; i < M; ++i) d[i] = a * d[i] + b * cabs2(z[i]);
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = i + 1; j < M; ++j) {
+            const int q = off_index(i, j, M);
+            const cf zz = cmulc(z[i], z[j]);
+            o[2 * q] = a * o[2 * q] + b * zz.x;
+            o[2 * q + 1] = a * o[2 * q + 1] + b * zz.y;
+        }
+}
+
+// Cholesky factor of A = R + diag*I (Hermitian PD), L lower: Ld real diagonal (stored inverted),
+// Lo strictly-lower complex packed by (i>j) -> off_index(j,i).
+template <int M> struct Chol {
+    float inv[M];
+    cf lo[M * (M - 1) / 2 + 1];
+    DS_HD cf L(int i, int j) const { return lo[off_index(j, i, M)]; }   // i>j
+    DS_HD void factor(const float* d, const float* o, float diag) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            float s = d[j] + diag;
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= cabs2(L(j, k));
+            s = fmaxf_(s, 1e-30f);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const float r = rsqrtf(s);
+#else
+            const float r = 1.0f / sqrtf(s);
+#endif
+            inv[j] = r;
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) {
+                cf a = herm_get<M>(d, o, i, j);
+#pragma unroll
+                for (int k = 0; k < j; ++k) a = csub(a, cmulc(L(i, k), L(j, k)));
+                lo[off_index(j, i, M)] = cscale(a, r);
+            }
+        }
+    }
+    // solve A v = b
+    DS_HD void solve(const cf* b, cf* v) const {
+        cf u[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            cf a = b[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) a = csub(a, cmul(L(i, k), u[k]));
+            u[i] = cscale(a, inv[i]);
+        }
+#pragma unroll
+        for (int i = M - 1; i >= 0; --i) {
+            cf a = u[i];
+#pragma unroll
+            for (int k = i + 1; k < M; ++k) a = csub(a, cmul(cconj(L(k, i)), v[k]));
+            v[i] = cscale(a, inv[i]);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Per-bin algorithms.  Return the beamformer output Y[k].
+// ---------------------------------------------------------------------------------------------
+template <int M, bool RYY>
+DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
+    typedef StateLayout<M, ALGO_ADAPTIVE, RYY> SL;
+    float* d = st + SL::R_DIAG;
+    float* o = st + SL::R_OFF;
+    if (RYY) herm_rank1<M>(st + SL::RYY_DIAG, st + SL::RYY_OFF, Z, p.alpha_y, 1.0f - p.alpha_y);      // :86-88
+    if (st[SL::MC_S + 3] < p.gate) herm_rank1<M>(d, o, Z, p.alpha_v, 1.0f - p.alpha_v);               // :94-99
+    cf acc = mk(0.0f, 0.0f);
+    if (p.method == METHOD_SRC) {                              // beamformer.py:320-322
+        acc = cmulc(Z[0], a[0]);
+    } else if (p.method == METHOD_DS) {                        // beamformer.py:323-324
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc = cadd(acc, cmulc(Z[m], a[m]));
+        acc = cscale(acc, 1.0f / M);
+    } else if (p.method == METHOD_MVDR) {                      // beamformer.py:325-326, :103-104
+        Chol<M> ch;
+        ch.factor(d, o, p.diag);
+        cf v[M];
+        ch.solve(a, v);
+        cf den = mk(0.0f, 0.0f), num = mk(0.0f, 0.0f);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            den = cadd(den, cmulc(v[m], a[m]));                // a^H v
+            num = cadd(num, cmulc(Z[m], v[m]));                // v^H z
+        }
+        acc = cdiv(num, cconj(den));                           // sum conj(v/den) z
+    } else if (RYY) {                                          // TFGSC, beamformer.py:327-333
+        Chol<M> ch;
+        ch.factor(d, o, p.diag);
+        const float* yd = st + SL::RYY_DIAG;
+        const float* yo = st + SL::RYY_OFF;
+        cf tr = mk(0.0f, 0.0f);
+        cf col0[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            cf b[M], v[M];
+#pragma unroll
+            for (int i = 0; i < M; ++i) b[i] = herm_get<M>(yd, yo, i, j);
+            ch.solve(b, v);                                    // column j of Rvv_inv @ Ryy
+            tr = cadd(tr, v[j]);
+            if (j == 0) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) col0[i] = v[i];
+            }
+        }
+        col0[0].x -= 1.0f;
+        const cf den = mk(tr.x - (float)M, tr.y);
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc = cadd(acc, cmulc(Z[m], cdiv(col0[m], den)));
+    }
+    return acc;
+}
+
+template <int M> DS_HD cf fixed_bin(const cf* Z, const cf* w) {   // fixedbeamformer.py:163
+    cf acc = mk(0.0f, 0.0f);
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc = cadd(acc, cmulc(Z[m], w[m]));
+    return acc;
+}
+
+// real symmetric packed helpers (GSC / McMcra) --------------------------------------------------
+template <int M> DS_HD float sym_get(const float* s, int i, int j) {
+    return i <= j ? s[sym_index(i, j, M)] : s[sym_index(j, i, M)];
+}
+
+// McMcra.estimation for one bin (mc_mcra.py:179-224) + FD-GSC LMS (GSC.py:245-286).
+template <int M>
+DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, int spp_frm_cnt) {
+    typedef StateLayout<M, ALGO_GSC, false> SL;
+    constexpr int NS = M * (M + 1) / 2;
+    float* pyy = st + SL::PYY;
+    float* pvv = st + SL::PVV;
+    float* ga = st + SL::GA;
+    const float alpha = 0.92f, one_m_alpha = (float)(1.0 - 0.92);
+    float yy[NS];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = i; j < M; ++j) {
+            const int q = sym_index(i, j, M);
+            yy[q] = Z[i].x * Z[j].x + Z[i].y * Z[j].y;         // Re(conj(y_i) y_j)  :182-184
+            pyy[q] = alpha * pyy[q] + one_m_alpha * yy[q];
+        }
+    if (spp_frm_cnt < 5) {                                     // :186-187
+#pragma unroll
+        for (int q = 0; q < NS; ++q) pvv[q] = pyy[q];
+    }
+    // real Cholesky of Phi_vv + 1e-6 I, then full inverse (needed for the traces)  :191
+    float Lm[M][M];
+    float inv_d[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        float s = sym_get<M>(pvv, j, j) + 1e-6f;
+#pragma unroll
+        for (int q = 0; q < j; ++q) s -= Lm[j][q] * Lm[j][q];
+        s = fmaxf_(s, 1e-30f);
+        const float r = 1.0f / sqrtf(s);
+        inv_d[j] = r;
+        Lm[j][j] = s * r;
+#pragma unroll
+        for (int i = j + 1; i < M; ++i) {
+            float t = sym_get<M>(pvv, i, j);
+#pragma unroll
+            for (int q = 0; q < j; ++q) t -= Lm[i][q] * Lm[j][q];
+            Lm[i][j] = t * r;
+        }
+    }
+    // Linv (lower) by forward substitution on identity columns
+    float Li[M][M];
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            if (i < c) { Li[i][c] = 0.0f; continue; }
+            float t = (i == c) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int q = c; q < i; ++q) t -= Lm[i][q] * Li[q][c];
+            Li[i][c] = t * inv_d[i];
+        }
+    }
+    // inv = Li^T Li (symmetric)
+    float iv[NS];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = i; j < M; ++j) {
+            float t = 0.0f;
+#pragma unroll
+            for (int q = j; q < M; ++q) t += Li[q][i] * Li[q][j];
+            iv[sym_index(i, j, M)] = t;
+        }
+    // tr = trace(inv Phi_yy) ; psi = sum inv_ij yy_ij ; gamma = sum A_ij yy_ij, A = inv Phi_xx inv
+    float tr = 0.0f, psi = 0.0f;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const float e = sym_get<M>(iv, i, j);
+            tr += e * sym_get<M>(pyy, i, j);
+            psi += e * sym_get<M>(yy, i, j);
+        }
+    float xi = fminf_(fmaxf_(tr - (float)M, 1e-6f), 1e6f);                               // :193-194
+    // B = Phi_xx inv  (M x M), A = inv B
+    float Bm[M][M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            float t = 0.0f;
+#pragma unroll
+            for (int q = 0; q < M; ++q) t += (sym_get<M>(pyy, i, q) - sym_get<M>(pvv, i, q)) * sym_get<M>(iv, q, j);
+            Bm[i][j] = t;
+        }
+    float gam = 0.0f;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            float t = 0.0f;
+#pragma unroll
+            for (int q = 0; q < M; ++q) t += sym_get<M>(iv, i, q) * Bm[q][j];
+            gam += t * sym_get<M>(yy, i, j);
+        }
+    gam = fminf_(fmaxf_(gam, 1e-6f), 1e6f);                                               // :199
+    // q_local :91-105
+    const float q_max = 0.99f, q_min = 0.01f, psi0 = 100.0f;
+    float q;
+    if (psi >= psi0 || tr > psi0) q = q_min;
+    else if (tr < (float)M) q = q_max;
+    else q = fminf_(fmaxf_((psi0 - tr) / (psi0 - (float)M), q_min), q_max);
+    // p :143-151
+    float pp = 1.0f / (1.0f + q / (1.0f - q) * (1.0f + xi) * expf(-1.0f * (gam / (1.0f + xi))));
+    pp = fminf_(fmaxf_(pp, 0.01f), 0.99f);
+    // noise PSD update :210-224
+    const float at = 0.95f + (float)(1.0 - 0.95) * pp;
+#pragma unroll
+    for (int q2 = 0; q2 < NS; ++q2) pvv[q2] = at * pvv[q2] + (1.0f - at) * yy[q2];
+    // gain :153-157
+    const float Gmin = 0.0631f;
+    const float gh1 = xi / (1.0f + xi);
+    float G = powf(gh1, pp) * powf(Gmin, 1.0f - pp);
+    G = fmaxf_(fminf_(G, 1.0f), Gmin);
+    if (k < 2) G = 0.0f;
+    if (p.method == 0) return Z[0];                                                        // GSC.py:242-243
+    // FD-GSC: W = a/(a^H a), U_i = conj(a_0) z_0 - conj(a_{i+1}) z_{i+1}                   GSC.py:219-222,261-266
+    float aa = 0.0f;
+    cf yf = mk(0.0f, 0.0f);
+#pragma unroll
+    for (int m = 0; m < M; ++m) { aa += cabs2(a[m]); yf = cadd(yf, cmulc(Z[m], a[m])); }
+    yf = cscale(yf, 1.0f / aa);
+    const cf u0 = cmulc(Z[0], a[0]);
+    cf U[M - 1];
+    cf Yk = yf;
+#pragma unroll
+    for (int i = 0; i < M - 1; ++i) {
+        U[i] = csub(u0, cmulc(Z[i + 1], a[i + 1]));
+        Yk = csub(Yk, cmulc(U[i], mk(ga[2 * i], ga[2 * i + 1])));                           // conj(G_i) U_i
+    }
+    const float step = p.mu * (1.0f - pp);                                                  // GSC.py:270-274
+#pragma unroll
+    for (int i = 0; i < M - 1; ++i) {
+        const cf g = cmulc(U[i], Yk);                                                       // U_i conj(Y)
+        ga[2 * i] += step * g.x;
+        ga[2 * i + 1] += step * g.y;
+    }
+    return cscale(Yk, G);                                                                   // GSC.py:286
+}
+
+// ---------------------------------------------------------------------------------------------
+// The block program
+// ---------------------------------------------------------------------------------------------
+template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
+    static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2;
+    static constexpr int NT = NC + 64;                       // one thread per bin + the Nyquist bin's wave
+    static constexpr int KP = (K + 3) & ~3;                  // padded plane length
+    typedef StateLayout<M, ALGO, RYY> SL;
+    static constexpr int NP = SL::NP;
+    static constexpr int NV4 = HOP * M / 4;                  // float4 per hop of input
+    static constexpr int NPRE = (NV4 + NT - 1) / NT;
+    typedef Shared<NFFT, M> Sh;
+    typedef Regs<M, ALGO, RYY, NPRE> Rg;
+    static constexpr bool FWD_FINAL_IS_FB = (NC != 512);     // 128: 4 stages, 256: 4 stages, 512: 5 stages
+    static constexpr bool INV_FINAL_IS_FA = (NC != 512);
+
+    // issue the global loads of hop t (all channels) into registers
+    static DS_HD void prefetch(const Params& p, long long xb, int t, int tid, Rg& r) {
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int v = tid + i * NT;
+            if (v < NV4) {
+                long long off;
+                if (p.x_sample_stride == 1) {                // [M][L]
+                    const int m = v / (HOP / 4), q = v - m * (HOP / 4);
+                    off = xb + (long long)m * p.x_chan_stride + (long long)t * HOP + 4 * q;
+                } else {                                     // [L][M] interleaved
+                    off = xb + (long long)t * HOP * M + 4 * v;
+                }
+                r.pre[i] = *reinterpret_cast<const vec4*>(p.x + off);
+            }
+        }
+    }
+    // registers -> LDS new half
+    static DS_HD void commit(const Params& p, Sh& sh, int new_half, int tid, const Rg& r) {
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            const int v = tid + i * NT;
+            if (v < NV4) {
+                const float e[4] = {r.pre[i].x, r.pre[i].y, r.pre[i].z, r.pre[i].w};
+                if (p.x_sample_stride == 1) {
+                    const int m = v / (HOP / 4), q = v - m * (HOP / 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sh.xbuf[m][new_half * HOP + 4 * q + c] = e[c];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int lin = 4 * v + c, n = lin / M, m = lin - n * M;
+                        sh.xbuf[m][new_half * HOP + n] = e[c];
+                    }
+                }
+            }
+        }
+    }
+
+    template <class Exec> static DS_HD void run(Exec& ex, const Params& p, int blk, Sh& sh) {
+        const int b = p.batch0 + blk;
+        const long long xb = (long long)blk * p.x_batch_stride;
+        const long long yb = (long long)blk * p.y_batch_stride;
+        vec4* bins = p.bins + (long long)b * NP * KP;
+        float* tin = p.tail_in + (long long)b * M * HOP;
+        float* tout = p.tail_out + (long long)b * HOP;
+        int* cnt = p.counters + (long long)b * 4;
+        const cf* steer = p.steer + (long long)b * p.steer_batch_stride;
+        int frm_cnt = cnt[0], ell = cnt[1], spp_cnt = cnt[2];
+        int old_half = 0;
+
+        // ---- prologue: tables, tails, per-bin state ---------------------------------------------
+        ex.phase([&](int tid, Rg& r) {
+            for (int i = tid; i <= NC; i += NT) sh.tw[i] = p.twN[i];
+            for (int i = tid; i < N; i += NT) sh.win[i] = p.win[i];
+            for (int i = tid; i < M * HOP; i += NT) sh.xbuf[i / HOP][i % HOP] = tin[i];   // old half = 0
+            for (int i = tid; i < HOP; i += NT) sh.tail[i] = tout[i];
+            if (tid < K) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const vec4 v = bins[q * KP + tid];
+                    r.st[4 * q] = v.x; r.st[4 * q + 1] = v.y; r.st[4 * q + 2] = v.z; r.st[4 * q + 3] = v.w;
+                }
+            }
+            prefetch(p, xb, 0, tid, r);
+        });
+
+        for (int t = 0; t < p.T; ++t) {
+            const int new_half = old_half ^ 1;
+            // ---- hop t into LDS, start fetching hop t+1 ------------------------------------------
+            ex.phase([&](int tid, Rg& r) {
+                commit(p, sh, new_half, tid, r);
+                if (t + 1 < p.T) prefetch(p, xb, t + 1, tid, r);
+            });
+            // ---- forward FFT: M packed real transforms -------------------------------------------
+            cf* fa = &sh.fa[0][0];
+            cf* fb = &sh.fb[0][0];
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, true>(tid, NT, sh, nullptr, fa, 1, old_half); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false>(tid, NT, sh, fa, fb, 4, 0); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false>(tid, NT, sh, fb, fa, 16, 0); });
+            if (NC == 128) {
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 2, -1, false>(tid, NT, sh, fa, fb, 64, 0); });
+            } else {
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false>(tid, NT, sh, fa, fb, 64, 0); });
+                if (NC == 512)
+                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 2, -1, false>(tid, NT, sh, fb, fa, 256, 0); });
+            }
+            const cf* F = FWD_FINAL_IS_FB ? fb : fa;
+            // ---- split packed spectrum -> Z[k][m]; publish |Z_0|^2 for the MCRA stencil ----------
+            ex.phase([&](int tid, Rg& r) {
+                if (tid < K) {
+                    const int k = tid, k1 = k & (NC - 1), k2 = (NC - k) & (NC - 1);
+                    const cf w = sh.tw[k];
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const cf A = F[m * NC + k1], Bc = cconj(F[m * NC + k2]);
+                        const cf E = cscale(cadd(A, Bc), 0.5f);
+                        const cf D = csub(A, Bc);
+                        const cf O = mk(0.5f * D.y, -0.5f * D.x);          // D / (2j)
+                        r.Z[m] = cadd(E, cmul(w, O));
+                    }
+                    if (k == 0 || k == NC) {
+#pragma unroll
+                        for (int m = 0; m < M; ++m) r.Z[m].y = 0.0f;
+                    }
+                    sh.pw[k] = cabs2(r.Z[0]);
+                }
+            });
+            // ---- per-bin recursion -> Y[k] --------------------------------------------------------
+            const bool reset = (frm_cnt != 0) && (ell % p.mcra_L == 0);
+            ex.phase([&](int tid, Rg& r) {
+                if (tid < K) {
+                    const int k = tid;
+                    cf a[M];
+#pragma unroll
+                    for (int m = 0; m < M; ++m) a[m] = steer[k * M + m];
+                    cf Yk;
+                    if constexpr (ALGO == ALGO_FIXED) {
+                        Yk = fixed_bin<M>(r.Z, a);
+                    } else if constexpr (ALGO == ALGO_ADAPTIVE) {
+                        mcra_bin(r.st + SL::MC_S, k, K, sh.pw, frm_cnt, reset, p.mcra_L);
+                        Yk = adaptive_bin<M, RYY>(r.st, r.Z, a, p);
+                    } else {
+                        Yk = gsc_bin<M>(r.st, r.Z, a, p, k, spp_cnt);
+                    }
+                    if (k == 0 || k == NC) Yk.y = 0.0f;                     // irfft ignores these imaginary parts
+                    sh.Y[k] = Yk;
+                }
+            });
+            if (ALGO == ALGO_ADAPTIVE) {
+                if (reset) ell = 0;
+                frm_cnt += 1; ell += 1;
+            }
+            if (ALGO == ALGO_GSC) spp_cnt += 1;
+            // ---- inverse packed real FFT -----------------------------------------------------------
+            ex.phase([&](int tid, Rg&) {
+                if (tid < NC) {
+                    const int k = tid;
+                    const cf A = sh.Y[k], Bc = cconj(sh.Y[NC - k]);
+                    const cf E = cscale(cadd(A, Bc), 0.5f);
+                    const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tw[k]));
+                    fa[k] = mk(E.x - O.y, E.y + O.x);                       // E + j O
+                }
+            });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false>(tid, NT, sh, fa, fb, 1, 0); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false>(tid, NT, sh, fb, fa, 4, 0); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false>(tid, NT, sh, fa, fb, 16, 0); });
+            if (NC == 128) {
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 2, +1, false>(tid, NT, sh, fb, fa, 64, 0); });
+            } else {
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false>(tid, NT, sh, fb, fa, 64, 0); });
+                if (NC == 512)
+                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 2, +1, false>(tid, NT, sh, fa, fb, 256, 0); });
+            }
+            const cf* Zi = INV_FINAL_IS_FA ? fa : fb;
+            // ---- window, overlap-add, emit hop t ---------------------------------------------------
+            ex.phase([&](int tid, Rg&) {
+                if (tid < NC / 2) {
+                    const int i = tid;
+                    const float sc = 1.0f / (float)NC;
+                    const cf z1 = Zi[i], z2 = Zi[i + NC / 2];
+                    const float y0 = sh.win[2 * i] * (z1.x * sc), y1 = sh.win[2 * i + 1] * (z1.y * sc);
+                    const float o0 = (y0 + sh.tail[2 * i]) * p.out_scale, o1 = (y1 + sh.tail[2 * i + 1]) * p.out_scale;
+                    sh.tail[2 * i] = sh.win[HOP + 2 * i] * (z2.x * sc);
+                    sh.tail[2 * i + 1] = sh.win[HOP + 2 * i + 1] * (z2.y * sc);
+                    float* dst = p.y + yb + (long long)t * HOP + 2 * i;
+                    dst[0] = o0; dst[1] = o1;
+                }
+            });
+            old_half = new_half;
+        }
+
+        // ---- epilogue: state back to HBM -----------------------------------------------------------
+        ex.phase([&](int tid, Rg& r) {
+            for (int i = tid; i < M * HOP; i += NT) tin[i] = sh.xbuf[i / HOP][old_half * HOP + i % HOP];
+            for (int i = tid; i < HOP; i += NT) tout[i] = sh.tail[i];
+            if (tid < K) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    vec4 v; v.x = r.st[4 * q]; v.y = r.st[4 * q + 1]; v.z = r.st[4 * q + 2]; v.w = r.st[4 * q + 3];
+                    bins[q * KP + tid] = v;
+                }
+            }
+            if (tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }
+        });
+    }
+};
+
+}  // namespace ds

@@ -1,0 +1,62 @@
+// ds_kernels.hpp — kernel template + per-TU instantiation helpers for libdsenh.so (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ds_core.hpp"
+
+namespace ds {
+
+typedef hipError_t (*launch_fn)(const Params& p, int nblocks, hipStream_t stream);
+
+struct KernelInfo {
+    launch_fn launch;
+    int NP;   // float4 state planes per bin
+    int KP;   // padded plane length
+    int NT;   // threads per block
+};
+
+// lookups implemented in ds_kernels_*.hip; launch == nullptr when the combination is not compiled
+KernelInfo lookup_fixed(int nfft, int M);
+KernelInfo lookup_adaptive_noryy(int nfft, int M);
+KernelInfo lookup_adaptive_ryy(int nfft, int M);
+KernelInfo lookup_gsc(int nfft, int M);
+
+#if defined(__HIPCC__)
+template <class Rg> struct HipExec {
+    Rg r;
+    template <class F> __device__ __forceinline__ void phase(F f) {
+        f((int)threadIdx.x, r);
+        __syncthreads();
+    }
+};
+
+template <int NFFT, int M, int ALGO, bool RYY>
+__global__ void __launch_bounds__(NFFT / 2 + 64) ds_frames_kernel(Params p) {
+    typedef Engine<NFFT, M, ALGO, RYY> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+
+template <int NFFT, int M, int ALGO, bool RYY>
+hipError_t launch_frames(const Params& p, int nblocks, hipStream_t stream) {
+    typedef Engine<NFFT, M, ALGO, RYY> E;
+    hipLaunchKernelGGL((ds_frames_kernel<NFFT, M, ALGO, RYY>), dim3(nblocks), dim3(E::NT), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <int NFFT, int M, int ALGO, bool RYY> KernelInfo make_info() {
+    typedef Engine<NFFT, M, ALGO, RYY> E;
+    KernelInfo ki;
+    ki.launch = &launch_frames<NFFT, M, ALGO, RYY>;
+    ki.NP = E::NP; ki.KP = E::KP; ki.NT = E::NT;
+    return ki;
+}
+
+#define DS_FOR_EACH_SHAPE(X) \
+    X(256, 2) X(256, 4) X(256, 6) X(256, 8) \
+    X(512, 2) X(512, 4) X(512, 6) X(512, 8) \
+    X(1024, 2) X(1024, 4) X(1024, 6) X(1024, 8)
+#endif
+
+}  // namespace ds

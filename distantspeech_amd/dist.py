@@ -1,0 +1,52 @@
+"""Multi-GPU plumbing: one process per GPU, utterances sharded by rank, no collective on the data
+path (utterances never interact).  The only exchange is the final throughput
+reduction (SUM of frames, MAX of elapsed) over torch.distributed — RCCL over xGMI on the GPU box
+(backend "nccl"), gloo in the CPU tests."""
+import os
+
+
+def env_world():
+    """(rank, local_rank, world_size) from the torchrun environment (1-process defaults)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard_range(total, rank, world):
+    """contiguous shard [lo, hi) of `total` utterances for `rank` (sizes differ by at most one)."""
+    base, rem = divmod(int(total), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init(backend=None):
+    """init torch.distributed from the environment when WORLD_SIZE > 1; returns (rank, local_rank, world)."""
+    rank, local_rank, world = env_world()
+    if world > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if backend is None:
+                import torch
+                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def reduce_throughput(frames, elapsed_s, device=None):
+    """(total frames over ranks, max elapsed over ranks): the one collective of the job."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return int(frames), float(elapsed_s)
+    f = torch.tensor([float(frames)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
+    dist.all_reduce(f, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(round(f.item())), float(t.item())

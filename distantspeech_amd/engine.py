@@ -1,0 +1,125 @@
+"""BatchEngine — thin Python owner of one native ds_handle (B independent utterances on one GPU).
+
+All signal processing happens in libdsenh.so's HIP kernels; this class only moves pointers."""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+
+
+class BatchEngine:
+    def __init__(self, algo, n_mics, nfft, hop=None, batch=1, track_ryy=False, mcra_L=15, device=-1,
+                 alpha_y=0.0, alpha_v=0.0, diag=0.0, gate=0.0, mu=0.0):
+        self._lib = L.load()
+        hop = nfft // 2 if hop is None else int(hop)
+        cfg = L.ds_config(ctypes.sizeof(L.ds_config), int(algo), int(n_mics), int(nfft), hop, int(batch),
+                          int(bool(track_ryy)), int(mcra_L), int(device), alpha_y, alpha_v, diag, gate, mu)
+        h = ctypes.c_void_p()
+        L.check(self._lib.ds_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        self.algo, self.M, self.nfft, self.hop, self.batch = int(algo), int(n_mics), int(nfft), hop, int(batch)
+        self.K = nfft // 2 + 1
+        self.track_ryy = bool(track_ryy)
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ds_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        L.check(self._lib.ds_reset(self._h), self._h)
+
+    # -- set-up ---------------------------------------------------------------------------------
+    def set_steering(self, a):
+        """a: complex [K, M] (shared) or [B, K, M] (one look direction per utterance)."""
+        a = np.ascontiguousarray(a, dtype=np.complex64)
+        if a.shape[-2:] != (self.K, self.M) or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[0] != self.batch):
+            raise ValueError("steering must be [K=%d, M=%d] or [B=%d, K, M], got %s" % (self.K, self.M, self.batch, a.shape))
+        L.check(self._lib.ds_set_steering(self._h, a.ctypes.data_as(ctypes.c_void_p), int(a.ndim == 3)), self._h)
+
+    def set_method(self, method):
+        L.check(self._lib.ds_set_param_i(self._h, L.PARAM_METHOD, int(method)), self._h)
+
+    def set_mcra_L(self, value):
+        L.check(self._lib.ds_set_param_i(self._h, L.PARAM_MCRA_L, int(value)), self._h)
+
+    def set_param_f(self, pid, value):
+        L.check(self._lib.ds_set_param_f(self._h, int(pid), float(value)), self._h)
+
+    # -- hot path -------------------------------------------------------------------------------
+    def process(self, x, layout):
+        """Host arrays.  x: [B, L, M] (layout 0) or [B, M, L] (layout 1) -> y [B, L] float32."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 3 or x.shape[0] != self.batch:
+            raise ValueError("x must be [B=%d, ...] 3-D, got %s" % (self.batch, x.shape))
+        n = x.shape[1] if layout == L.LAYOUT_SAMPLES_CHANNELS else x.shape[2]
+        m = x.shape[2] if layout == L.LAYOUT_SAMPLES_CHANNELS else x.shape[1]
+        if m != self.M:
+            raise ValueError("expected %d channels, got %d" % (self.M, m))
+        y = np.empty((self.batch, n), dtype=np.float32)
+        L.check(self._lib.ds_process(self._h, x.ctypes.data_as(ctypes.c_void_p), int(layout), int(n),
+                                     y.ctypes.data_as(ctypes.c_void_p)), self._h)
+        return y
+
+    def process_device(self, x_ptr, layout, x_batch_stride, n_samples, y_ptr, y_batch_stride, first=0, count=None,
+                       stream=None, x_chan_stride=0):
+        """Device pointers (ints), asynchronous on `stream` (int hipStream_t) or the handle's stream."""
+        count = self.batch - first if count is None else count
+        L.check(self._lib.ds_process_device(self._h, ctypes.c_void_p(x_ptr), int(layout), int(x_batch_stride),
+                                            int(x_chan_stride), int(n_samples), ctypes.c_void_p(y_ptr),
+                                            int(y_batch_stride), int(first),
+                                            int(count), ctypes.c_void_p(stream) if stream else None), self._h)
+
+    def synchronize(self):
+        L.check(self._lib.ds_synchronize(self._h), self._h)
+
+    def timing_begin(self):
+        L.check(self._lib.ds_timing_begin(self._h), self._h)
+
+    def timing_end(self):
+        ms = ctypes.c_float(0)
+        L.check(self._lib.ds_timing_end(self._h, ctypes.byref(ms)), self._h)
+        return ms.value
+
+    # -- state ----------------------------------------------------------------------------------
+    def get_field(self, field):
+        nbytes = self._lib.ds_field_bytes(self._h, int(field))
+        if nbytes == 0:
+            raise AttributeError("state field %d is not available for this configuration" % field)
+        B, K, M = self.batch, self.K, self.M
+        if field == L.FIELD_COUNTERS:
+            out = np.empty((B, 4), dtype=np.int32)
+        else:
+            out = np.empty(nbytes // 4, dtype=np.float32)
+        L.check(self._lib.ds_get_state(self._h, int(field), out.ctypes.data_as(ctypes.c_void_p), nbytes), self._h)
+        if field in (L.FIELD_RVV, L.FIELD_RYY):
+            return out.view(np.complex64).reshape(B, K, M, M)
+        if field in (L.FIELD_PHI_YY, L.FIELD_PHI_VV):
+            return out.reshape(B, K, M, M)
+        if field == L.FIELD_G_AIC:
+            return out.view(np.complex64).reshape(B, K, M - 1)
+        if field == L.FIELD_STFT_TAIL:
+            return out.reshape(B, M, self.hop)
+        if field == L.FIELD_OLA_TAIL:
+            return out.reshape(B, self.hop)
+        if field == L.FIELD_COUNTERS:
+            return out
+        return out.reshape(B, K)
+
+    def export_state(self):
+        n = self._lib.ds_state_bytes(self._h)
+        buf = np.empty(n, dtype=np.uint8)
+        L.check(self._lib.ds_export_state(self._h, buf.ctypes.data_as(ctypes.c_void_p), n), self._h)
+        return buf
+
+    def import_state(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        L.check(self._lib.ds_import_state(self._h, buf.ctypes.data_as(ctypes.c_void_p), buf.size), self._h)

@@ -1,0 +1,161 @@
+/* dsenh.h — C-ABI of libdsenh.so: MI355X-native per-frame multichannel speech enhancement
+ * (streaming STFT -> beamformer -> post-filter -> ISTFT overlap-add) batched over independent
+ * utterances.  Plain C, no torch / HIP types in any signature (streams travel as void*).
+ *
+ * Each entry point replaces a piece of the reference's Python object interface
+ * (wangwei2009/DistantSpeech; paths relative to the reference root):
+ *
+ *   ds_create / ds_destroy / ds_reset
+ *       constructors + attribute state of  beamformer/beamformer.py:223-265,
+ *       beamformer/fixedbeamformer.py:96-107, beamformer/adaptivebeamformer.py:10-42,
+ *       beamformer/GSC.py:27-87, transform/transform.py:407-428 (state: previous_input/output),
+ *       noise_estimation/NoiseEstimationBase.py:5-31, noise_estimation/mc_mcra.py:25-80
+ *   ds_set_steering
+ *       the per-look-direction set-up the reference redoes inside process():
+ *       a[k,m] = exp(-j w_k tau_m)  (adaptivebeamformer.py:52,84 ; GSC.py:186,205-222) or the fixed
+ *       weights W[k,m] (beamformer.py:338-373 ; fixedbeamformer.py:109-145)
+ *   ds_process / ds_process_device
+ *       FixedBeamformer.process        fixedbeamformer.py:167-207   (algo DS_ALGO_FIXED)
+ *       adaptivebeamfomer.process      adaptivebeamformer.py:44-128 (algo DS_ALGO_ADAPTIVE)
+ *       GSC.process                    GSC.py:174-294               (algo DS_ALGO_GSC)
+ *       each including Transform.stft / Transform.istft (transform.py:430-481) and the realtime
+ *       callback contract  realtime/realtime_processing.py:78-84 (chunk in -> chunk out, state carried)
+ *   ds_get_state
+ *       the attributes users read back after process(): Rvv/Ryy (adaptivebeamformer.py:32-34),
+ *       mcra.S/Smin/Stmp/p/lambda_d (NoiseEstimationBase.py:11-24), spp.Phi_yy/Phi_vv
+ *       (mc_mcra.py:68-69), G (GSC.py:72), Transform.previous_input/previous_output (transform.py:425-426)
+ *   ds_set_param_i / ds_set_param_f
+ *       attributes users poke after construction (e.g. mcra.L = 10 in the notebooks; `method` argument)
+ *
+ * Conventions: every function returns 0 (DS_OK) or a negative DS_E* code; ds_last_error() gives
+ * the text.  A handle is NOT thread-safe (the reference objects are single-caller too).
+ * Chunking contract: n_samples must be a multiple of hop; state is carried across calls; a call
+ * with T hops is defined as T successive one-hop calls of the reference.
+ */
+#ifndef DSENH_H
+#define DSENH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DS_VERSION 100
+
+/* error codes */
+#define DS_OK 0
+#define DS_EINVAL (-1)       /* bad argument / NULL handle                       */
+#define DS_ESHAPE (-2)       /* n_samples not a multiple of hop, size mismatch    */
+#define DS_EUNSUPPORTED (-3) /* configuration with no compiled kernel             */
+#define DS_EHIP (-4)         /* HIP runtime error (text in ds_last_error)         */
+#define DS_ENOMEM (-5)
+#define DS_ESTATE (-6)       /* call order (e.g. process before set_steering)     */
+
+/* ds_config.algo */
+#define DS_ALGO_FIXED 0      /* FixedBeamformer: Y = sum conj(W) X                */
+#define DS_ALGO_ADAPTIVE 1   /* adaptivebeamfomer: MCRA-gated Rvv, src/DS/MVDR/TFGSC */
+#define DS_ALGO_GSC 2        /* GSC: FD blocking matrix + SPP-controlled LMS + McMcra gain */
+
+/* `method` (AlgorithmList, adaptivebeamformer.py:36) */
+#define DS_METHOD_SRC 0
+#define DS_METHOD_DS 1
+#define DS_METHOD_MVDR 2
+#define DS_METHOD_TFGSC 3    /* needs ds_config.track_ryy = 1 */
+
+/* sample layouts of x (per utterance) */
+#define DS_LAYOUT_SAMPLES_CHANNELS 0   /* x[L][M]  (FixedBeamformer.process, Transform.stft) */
+#define DS_LAYOUT_CHANNELS_SAMPLES 1   /* x[M][L]  (adaptivebeamfomer.process, GSC.process)  */
+
+typedef struct ds_handle ds_handle;
+
+typedef struct ds_config {
+    int32_t struct_size; /* = sizeof(ds_config) */
+    int32_t algo;
+    int32_t n_mics;      /* M: 2, 4, 6 or 8 */
+    int32_t nfft;        /* 256, 512 or 1024 */
+    int32_t hop;         /* must equal nfft / 2 (the only overlap the reference's callers use) */
+    int32_t batch;       /* independent utterances resident on this device */
+    int32_t track_ryy;   /* adaptive: also keep Ryy like the reference (needed by TFGSC) */
+    int32_t mcra_L;      /* 0 -> 15 (mcra.py:25) */
+    int32_t device;      /* HIP ordinal, -1 = current device */
+    float alpha_y;       /* 0 -> 0.8     adaptivebeamformer.py:65 */
+    float alpha_v;       /* 0 -> 0.9998  adaptivebeamformer.py:66 */
+    float diag;          /* 0 -> 1e-6    adaptivebeamformer.py:89 */
+    float gate;          /* 0 -> 0.4     adaptivebeamformer.py:94 */
+    float mu;            /* 0 -> 0.01    GSC.py:202 */
+} ds_config;
+
+/* ds_set_param_* ids */
+#define DS_PARAM_METHOD 1   /* int   */
+#define DS_PARAM_MCRA_L 2   /* int   */
+#define DS_PARAM_ALPHA_Y 3  /* float */
+#define DS_PARAM_ALPHA_V 4
+#define DS_PARAM_DIAG 5
+#define DS_PARAM_GATE 6
+#define DS_PARAM_MU 7
+
+/* ds_get_state fields; all arrays are float32, complex = interleaved (re, im) */
+#define DS_FIELD_RVV 1        /* [B][K][M][M][2]  */
+#define DS_FIELD_RYY 2        /* [B][K][M][M][2]  (track_ryy) */
+#define DS_FIELD_MCRA_S 3     /* [B][K] */
+#define DS_FIELD_MCRA_SMIN 4
+#define DS_FIELD_MCRA_STMP 5
+#define DS_FIELD_MCRA_P 6
+#define DS_FIELD_MCRA_LAMBDA_D 7
+#define DS_FIELD_PHI_YY 8     /* [B][K][M][M] real */
+#define DS_FIELD_PHI_VV 9
+#define DS_FIELD_G_AIC 10     /* [B][K][M-1][2] */
+#define DS_FIELD_STFT_TAIL 11 /* [B][M][hop]  Transform.previous_input  */
+#define DS_FIELD_OLA_TAIL 12  /* [B][hop]     Transform.previous_output */
+#define DS_FIELD_COUNTERS 13  /* int32 [B][4] {mcra.frm_cnt, mcra.ell, spp.frm_cnt, 0} */
+
+int ds_version(void);
+int ds_device_count(void);
+const char* ds_strerror(int code);
+
+int ds_create(const ds_config* cfg, ds_handle** out);
+int ds_destroy(ds_handle* h);
+/* zero all per-utterance state (like constructing fresh reference objects) */
+int ds_reset(ds_handle* h);
+const char* ds_last_error(const ds_handle* h);
+
+/* steer: complex float [K][M] (per_utterance == 0) or [B][K][M] (per_utterance != 0), host memory.
+ * For DS_ALGO_FIXED these are the beamformer weights W; otherwise the steering vector a. */
+int ds_set_steering(ds_handle* h, const float* steer, int per_utterance);
+
+int ds_set_param_i(ds_handle* h, int id, int value);
+int ds_set_param_f(ds_handle* h, int id, float value);
+
+/* Host-buffer call (the realtime-callback form): x is [B] x layout, y is [B][n_samples];
+ * synchronous: returns after the enhanced samples are in y. */
+int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y);
+
+/* Device-buffer call: pointers are HIP device memory, 16-byte aligned; strides in elements.
+ * x_chan_stride: elements between channels for DS_LAYOUT_CHANNELS_SAMPLES (0 = n_samples, i.e. a
+ * dense [M][n_samples] chunk; pass the row length when x is a window into a longer [M][L] recording).
+ * Asynchronous on `stream` (a hipStream_t passed as void*; NULL = the handle's own stream).
+ * Processes utterances [first, first + count) of the handle; x/y point at utterance `first`. */
+int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
+                      int n_samples, float* y_dev, long long y_batch_stride, int first, int count, void* stream);
+
+int ds_synchronize(ds_handle* h);
+
+/* hipEvent bracket on the handle's stream (kernel timing for bench.py) */
+int ds_timing_begin(ds_handle* h);
+int ds_timing_end(ds_handle* h, float* elapsed_ms);
+
+/* copy one state field to host memory; `bytes` must equal the field size */
+int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes);
+size_t ds_field_bytes(const ds_handle* h, int field);
+
+/* opaque checkpoint of all carried state (the reference never serialises its state) */
+size_t ds_state_bytes(const ds_handle* h);
+int ds_export_state(ds_handle* h, void* dst, size_t bytes);
+int ds_import_state(ds_handle* h, const void* src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSENH_H */

@@ -1,0 +1,41 @@
+"""Shared helpers for the parity tests (golden fixtures -> inputs, steering vectors)."""
+import os
+
+import numpy as np
+
+from oracle import ds_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ANGLE = np.array([197, 0]) / 180 * np.pi
+
+# north-star tolerance: output within 1e-4 RMS of the NumPy reference (BASELINE.json);
+# the fp32 kernels are expected (and asserted) to be ~50x better than that on these inputs.
+TOL_RMS = 1e-4
+
+
+def rms(a):
+    a = np.asarray(a)
+    return float(np.sqrt(np.mean(np.abs(a) ** 2)))
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def as_float(x):
+    return x.astype(np.float32) / 32768.0 if x.dtype == np.int16 else x.astype(np.float32)
+
+
+def oracle_mic(M, nfft, r=None, atype="circular"):
+    return O.OracleMicArray(arrayType=atype, r=(0.032 if M == 4 else 0.05) if r is None else r, M=M, n_fft=nfft)
+
+
+def steering(M, nfft, r, angle=ANGLE):
+    mic = oracle_mic(M, nfft, r)
+    tao = O.circular_tao(mic.r, mic.c, mic.gamma, angle)
+    omega = 2 * np.pi * np.arange(nfft // 2 + 1) * 16000 / nfft
+    return np.exp(-1j * omega[:, None] * tao[None, :])
+
+
+ADAPTIVE_CASES = ["rec1", "synth", "synth_ds", "synth_src", "synth_tfgsc", "synth_m6", "synth_m8_1024"]
+GSC_CASES = ["rec1", "synth_m6", "synth_m4", "synth_m0"]

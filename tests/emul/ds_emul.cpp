@@ -1,0 +1,102 @@
+// ds_emul.cpp — TEST INFRASTRUCTURE: serial CPU execution of the *kernel block program*
+// (distantspeech_amd/csrc/ds_core.hpp) so that its index arithmetic and recursions can be
+// unit-tested in the CPU-only container.  Built by tests/emul/build.py into tests/emul/libds_emul.so,
+// loaded only by tests/test_kernel_emul.py.  The product package never loads it and has no CPU path.
+#include <cstring>
+#include <vector>
+
+#include "../../distantspeech_amd/csrc/ds_core.hpp"
+#include "../../distantspeech_amd/csrc/ds_tables.hpp"
+
+namespace {
+
+template <class Rg> struct CpuExec {
+    std::vector<Rg> R;
+    int nt;
+    template <class F> void phase(F f) {
+        for (int t = 0; t < nt; ++t) f(t, R[t]);
+    }
+};
+
+template <int NFFT, int M, int ALGO, bool RYY> int run_t(ds::Params p, int batch) {
+    typedef ds::Engine<NFFT, M, ALGO, RYY> E;
+    std::vector<ds::cf> tw;
+    std::vector<float> win;
+    ds::make_tables(NFFT, NFFT / 2, tw, win, p.out_scale);
+    p.twN = tw.data();
+    p.win = win.data();
+    typename E::Sh* sh = new typename E::Sh();
+    for (int b = 0; b < batch; ++b) {
+        CpuExec<typename E::Rg> ex;
+        ex.nt = E::NT;
+        ex.R.resize(E::NT);
+        std::memset((void*)ex.R.data(), 0, sizeof(typename E::Rg) * E::NT);
+        E::run(ex, p, b, *sh);
+    }
+    delete sh;
+    return 0;
+}
+
+template <int NFFT, int M> int run_nm(int algo, int ryy, const ds::Params& p, int batch) {
+    if (algo == ds::ALGO_FIXED) return run_t<NFFT, M, ds::ALGO_FIXED, false>(p, batch);
+    if (algo == ds::ALGO_ADAPTIVE && !ryy) return run_t<NFFT, M, ds::ALGO_ADAPTIVE, false>(p, batch);
+    if (algo == ds::ALGO_ADAPTIVE && ryy) return run_t<NFFT, M, ds::ALGO_ADAPTIVE, true>(p, batch);
+    if (algo == ds::ALGO_GSC) return run_t<NFFT, M, ds::ALGO_GSC, false>(p, batch);
+    return -1;
+}
+
+template <int NFFT> int run_n(int M, int algo, int ryy, const ds::Params& p, int batch) {
+    switch (M) {
+        case 2: return run_nm<NFFT, 2>(algo, ryy, p, batch);
+        case 4: return run_nm<NFFT, 4>(algo, ryy, p, batch);
+        case 6: return run_nm<NFFT, 6>(algo, ryy, p, batch);
+        case 8: return run_nm<NFFT, 8>(algo, ryy, p, batch);
+    }
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+// sizes of the per-bin plane storage for (algo, M, ryy): returns NP, writes KP
+int emul_layout(int algo, int nfft, int M, int ryy, int* kp) {
+    const int K = nfft / 2 + 1;
+    *kp = (K + 3) & ~3;
+    int nf = 0;
+    if (algo == ds::ALGO_ADAPTIVE) nf = M * M + 5 + (ryy ? M * M : 0);
+    if (algo == ds::ALGO_GSC) nf = M * (M + 1) + 2 * (M - 1);
+    return (nf + 3) / 4;
+}
+
+int emul_run(int algo, int nfft, int M, int ryy, int batch, const float* x, int layout, int n_samples, float* y,
+             float* bins, float* tail_in, float* tail_out, int* counters, const float* steer, int steer_per_utt,
+             int method, int mcra_L, float alpha_y, float alpha_v, float diag, float gate, float mu) {
+    ds::Params p;
+    std::memset(&p, 0, sizeof p);
+    const int hop = nfft / 2, K = nfft / 2 + 1;
+    p.x = x;
+    p.y = y;
+    p.x_batch_stride = (long long)M * n_samples;
+    p.y_batch_stride = n_samples;
+    if (layout == 1) { p.x_sample_stride = 1; p.x_chan_stride = n_samples; }
+    else { p.x_sample_stride = M; p.x_chan_stride = 1; }
+    p.T = n_samples / hop;
+    p.batch0 = 0;
+    p.bins = reinterpret_cast<ds::vec4*>(bins);
+    p.tail_in = tail_in;
+    p.tail_out = tail_out;
+    p.counters = counters;
+    p.steer = reinterpret_cast<const ds::cf*>(steer);
+    p.steer_batch_stride = steer_per_utt ? (long long)K * M : 0;
+    p.method = method;
+    p.mcra_L = mcra_L;
+    p.alpha_y = alpha_y; p.alpha_v = alpha_v; p.diag = diag; p.gate = gate; p.mu = mu;
+    switch (nfft) {
+        case 256: return run_n<256>(M, algo, ryy, p, batch);
+        case 512: return run_n<512>(M, algo, ryy, p, batch);
+        case 1024: return run_n<1024>(M, algo, ryy, p, batch);
+    }
+    return -1;
+}
+}

@@ -246,7 +246,8 @@ def g5_mcmcra(x16):
 
 def g6_gsc(x16):
     x = x16.astype(np.float32) / 32768.0
-    for name, xx, M, method in (("rec1", x, 4, 2), ("synth_m6", synth(31, 6, 256 * 50), 6, 2),
+    for name, xx, M, method in (("rec1", x, 4, 2), ("synth_m6", synth(31, 6, 256 * 50) * np.float32(0.1), 6, 2),
+                                ("synth_m4", synth(33, 4, 256 * 50) * np.float32(0.1), 4, 2),
                                 ("synth_m0", synth(32, 4, 256 * 20), 4, 0)):
         mic = MicArray(arrayType="circular", r=0.032 if M == 4 else 0.05, M=M, n_fft=512)  # R2
         with contextlib.redirect_stdout(io.StringIO()):                                    # R5
@@ -306,16 +307,21 @@ def g8_subband():
 
 
 def main():
+    only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
+
+    def want(tag):
+        return not only or tag in only
+
     x16 = rec1_int16(3.0, 3.0)
-    g1_transform()
-    g2_weights()
-    g2b_fixed(x16)
-    g3_mcra(x16)
-    g4_adaptive(x16)
-    g5_mcmcra(x16)
-    g6_gsc(x16)
-    g7_omlsa()
-    g8_subband()
+    if want("g1"): g1_transform()
+    if want("g2"): g2_weights()
+    if want("g2b"): g2b_fixed(x16)
+    if want("g3"): g3_mcra(x16)
+    if want("g4"): g4_adaptive(x16)
+    if want("g5"): g5_mcmcra(x16)
+    if want("g6"): g6_gsc(x16)
+    if want("g7"): g7_omlsa()
+    if want("g8"): g8_subband()
 
 
 if __name__ == "__main__":

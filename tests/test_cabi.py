@@ -1,0 +1,60 @@
+"""The C-ABI library loads and exports every symbol include/dsenh.h declares; argument checking
+that needs no GPU.  (No compute calls here: the library has no CPU path.)"""
+import ctypes
+import os
+import re
+
+import pytest
+
+from distantspeech_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "dsenh.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ds_[a-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "libdsenh.so does not export %s" % n
+    assert sorted(L.EXPORTS) == names
+
+
+def test_version_and_strerror():
+    lib = L.load()
+    assert lib.ds_version() == 100
+    assert lib.ds_strerror(-2).decode().startswith("shape")
+
+
+def test_config_struct_matches_header():
+    # 9 int32 + 5 float, no padding
+    assert ctypes.sizeof(L.ds_config) == 14 * 4
+
+
+def test_create_rejects_bad_configs_before_touching_the_gpu():
+    lib = L.load()
+    h = ctypes.c_void_p()
+    bad_hop = L.ds_config(ctypes.sizeof(L.ds_config), L.ALGO_ADAPTIVE, 4, 512, 128, 1, 0, 0, -1, 0, 0, 0, 0, 0)
+    assert lib.ds_create(ctypes.byref(bad_hop), ctypes.byref(h)) == -3          # DS_EUNSUPPORTED
+    bad_m = L.ds_config(ctypes.sizeof(L.ds_config), L.ALGO_ADAPTIVE, 5, 512, 256, 1, 0, 0, -1, 0, 0, 0, 0, 0)
+    assert lib.ds_create(ctypes.byref(bad_m), ctypes.byref(h)) == -3
+    bad_size = L.ds_config(8, L.ALGO_ADAPTIVE, 4, 512, 256, 1, 0, 0, -1, 0, 0, 0, 0, 0)
+    assert lib.ds_create(ctypes.byref(bad_size), ctypes.byref(h)) == -1         # DS_EINVAL
+    assert lib.ds_create(None, ctypes.byref(h)) == -1
+    assert not h.value
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a HIP device the product path must fail loudly, not compute on the CPU."""
+    lib = L.load()
+    if lib.ds_device_count() > 0:
+        pytest.skip("GPU present")
+    import distantspeech_amd as d
+    with pytest.raises(L.DsError):
+        d.adaptivebeamfomer(d.MicArray(M=4, n_fft=512), 512)

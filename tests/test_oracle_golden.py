@@ -117,7 +117,7 @@ def test_mcmcra(golden, name):
     assert np.allclose(est.Phi_yy, g["Phi_yy"], rtol=1e-9, atol=1e-14)
 
 
-@pytest.mark.parametrize("name", ["rec1", "synth_m6", "synth_m0"])
+@pytest.mark.parametrize("name", ["rec1", "synth_m6", "synth_m4", "synth_m0"])
 def test_gsc(golden, name):
     g = golden("g6_gsc_" + name)
     M, nfft, hop, method = [int(v) for v in g["params"]]
