@@ -146,30 +146,28 @@ def main():
     eng.set_steering(np.exp(-1j * omega[:, None] * tao[None, :]))
     eng.set_method(L.METHOD_MVDR)
 
-    stream = torch.cuda.current_stream().cuda_stream
     xp, yp = x.data_ptr(), y.data_ptr()
+    torch.cuda.synchronize()          # inputs resident before anything is launched on the engine's stream
 
-    def step(i):
-        off = i * T * HOP
-        eng.process_device(xp + 4 * off, L.LAYOUT_CHANNELS_SAMPLES, M * Ltot, T * HOP, yp + 4 * off, Ltot,
-                           stream=stream, x_chan_stride=Ltot)
+    def run_steps(first_step, n):
+        """n successive steps (one native call; launches go to the engine's own HIP stream)."""
+        off = first_step * T * HOP
+        eng.process_device_seq(xp + 4 * off, L.LAYOUT_CHANNELS_SAMPLES, M * Ltot, Ltot, T * HOP, T * HOP, n,
+                               yp + 4 * off, Ltot, T * HOP)
 
-    for i in range(W):
-        step(i)
+    run_steps(0, W)
+    eng.synchronize()
     torch.cuda.synchronize()
     dsdist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
-    for i in range(W, W + K):
-        step(i)
-    ev1.record()
+    eng.timing_begin()                # hipEvent on the stream the kernels are launched on
+    run_steps(W, K)
+    dev_ms = eng.timing_end()         # records the end event and waits for it
     torch.cuda.synchronize()
     dsdist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
 
     frames_rank = B * K * T
     frames, t_max = dsdist.reduce_throughput(frames_rank, elapsed, device=device)

@@ -39,7 +39,8 @@ _lib = None
 # every symbol include/dsenh.h declares (tests check that the built library exports all of them)
 EXPORTS = [
     "ds_version", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
-    "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_device", "ds_synchronize",
+    "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_device",
+    "ds_process_device_seq", "ds_synchronize",
     "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_export_state",
     "ds_import_state",
 ]
@@ -79,6 +80,8 @@ def load():
     lib.ds_process.argtypes = [vp, vp, ci, ci, vp]
     lib.ds_process_device.restype = ci
     lib.ds_process_device.argtypes = [vp, vp, ci, cll, cll, ci, vp, cll, ci, ci, vp]
+    lib.ds_process_device_seq.restype = ci
+    lib.ds_process_device_seq.argtypes = [vp, vp, ci, cll, cll, cll, ci, ci, vp, cll, cll, ci, ci, vp, ci]
     lib.ds_synchronize.restype = ci
     lib.ds_synchronize.argtypes = [vp]
     lib.ds_timing_begin.restype = ci

@@ -35,6 +35,10 @@ struct ds_handle {
     int steer_per_utt;
     bool steer_set;
     // staging for host-pointer calls
+    // cached hipGraph of a ds_process_device_seq() sequence
+    hipGraphExec_t graph_exec;
+    long long graph_key[16];
+    bool graph_valid;
     float* x_stage;
     float* y_stage;
     size_t x_stage_elems, y_stage_elems;
@@ -168,6 +172,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->twN = nullptr; h->win = nullptr; h->steer = nullptr; h->x_stage = nullptr; h->y_stage = nullptr;
     h->x_stage_elems = h->y_stage_elems = 0;
     h->steer_per_utt = 0; h->steer_set = false;
+    h->graph_exec = nullptr; h->graph_valid = false;
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
     h->alpha_y = cfg->alpha_y > 0 ? cfg->alpha_y : 0.8f;
@@ -222,6 +227,7 @@ int ds_destroy(ds_handle* h) {
     (void)hipFree(h->bins); (void)hipFree(h->tail_in); (void)hipFree(h->tail_out); (void)hipFree(h->counters);
     (void)hipFree(h->twN); (void)hipFree(h->win); (void)hipFree(h->steer);
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -311,6 +317,59 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
     p.batch0 = first;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     DS_HIP(h, h->ki.launch(p, count, s));
+    return DS_OK;
+}
+
+int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
+                          long long x_call_stride, int n_samples_per_call, int n_calls, float* y_dev,
+                          long long y_batch_stride, long long y_call_stride, int first, int count, void* stream,
+                          int graph) {
+    if (!h) return DS_EINVAL;
+    if (n_calls < 0 || (x_call_stride & 3) || (y_call_stride & 3))
+        return fail(h, DS_EINVAL, "ds_process_device_seq: bad n_calls / call strides (must be multiples of 4 elements)");
+    if (n_calls == 0) return DS_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    if (graph == 0) {
+        for (int i = 0; i < n_calls; ++i) {
+            int rc = ds_process_device(h, x_dev + (long long)i * x_call_stride, layout, x_batch_stride, x_chan_stride,
+                                       n_samples_per_call, y_dev + (long long)i * y_call_stride, y_batch_stride, first,
+                                       count, (void*)s);
+            if (rc) return rc;
+        }
+        return DS_OK;
+    }
+    int rc = set_device(h);
+    if (rc) return rc;
+    float fl[6] = {h->alpha_y, h->alpha_v, h->diag, h->gate, h->mu, 0.0f};
+    long long fbits[3];
+    std::memcpy(fbits, fl, sizeof fbits);
+    const long long key[16] = {(long long)(uintptr_t)x_dev, (long long)(uintptr_t)y_dev, layout, x_batch_stride, x_chan_stride,
+                               x_call_stride, n_samples_per_call, n_calls, y_batch_stride, y_call_stride,
+                               ((long long)first << 32) | (unsigned)count, ((long long)h->method << 32) | (unsigned)h->mcra_L,
+                               fbits[0], fbits[1], fbits[2], (long long)(uintptr_t)h->steer};
+    if (!h->graph_valid || std::memcmp(key, h->graph_key, sizeof key) != 0) {
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        h->graph_valid = false;
+        hipStream_t cs = h->stream;                       // capture on the handle's own stream
+        DS_HIP(h, hipStreamSynchronize(cs));
+        DS_HIP(h, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        int crc = DS_OK;
+        for (int i = 0; i < n_calls && crc == DS_OK; ++i)
+            crc = ds_process_device(h, x_dev + (long long)i * x_call_stride, layout, x_batch_stride, x_chan_stride,
+                                    n_samples_per_call, y_dev + (long long)i * y_call_stride, y_batch_stride, first, count,
+                                    (void*)cs);
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(cs, &g);
+        if (crc != DS_OK) { if (g) (void)hipGraphDestroy(g); return crc; }
+        if (e != hipSuccess) return fail(h, DS_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        e = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return fail(h, DS_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+        std::memcpy(h->graph_key, key, sizeof key);
+        h->graph_valid = true;
+    }
+    if (graph == 2) return DS_OK;
+    DS_HIP(h, hipGraphLaunch(h->graph_exec, s));
     return DS_OK;
 }
 

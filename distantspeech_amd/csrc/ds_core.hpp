@@ -41,15 +41,35 @@ struct alignas(16) vec4 { float x, y, z, w; };
 
 struct cf { float x, y; };
 
+// All floating-point contraction is explicit: the library is compiled with -ffp-contract=off and every
+// fused multiply-add below is written as fma_(), so a value's rounding never depends on which copy of
+// an unrolled / peeled loop the compiler happened to emit (chunked calls == one long call, bit for bit).
+DS_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DS_HD cf mk(float a, float b) { cf r; r.x = a; r.y = b; return r; }
 DS_HD cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
 DS_HD cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
-DS_HD cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-DS_HD cf cmulc(cf a, cf b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }   // a * conj(b)
+DS_HD cf cmul(cf a, cf b) { return mk(fma_(a.x, b.x, -(a.y * b.y)), fma_(a.x, b.y, a.y * b.x)); }
+DS_HD cf cmulc(cf a, cf b) { return mk(fma_(a.x, b.x, a.y * b.y), fma_(a.y, b.x, -(a.x * b.y))); }   // a * conj(b)
 DS_HD cf cconj(cf a) { return mk(a.x, -a.y); }
 DS_HD cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
-DS_HD float cabs2(cf a) { return a.x * a.x + a.y * a.y; }
-DS_HD cf cdiv(cf a, cf b) { float d = 1.0f / (b.x * b.x + b.y * b.y); return mk((a.x * b.x + a.y * b.y) * d, (a.y * b.x - a.x * b.y) * d); }
+DS_HD float cabs2(cf a) { return fma_(a.x, a.x, a.y * a.y); }
+DS_HD cf cfma(cf acc, cf a, cf b) {        // acc + a * b
+    return mk(fma_(a.x, b.x, fma_(-a.y, b.y, acc.x)), fma_(a.x, b.y, fma_(a.y, b.x, acc.y)));
+}
+DS_HD cf cfmac(cf acc, cf a, cf b) {       // acc + a * conj(b)
+    return mk(fma_(a.x, b.x, fma_(a.y, b.y, acc.x)), fma_(a.y, b.x, fma_(-a.x, b.y, acc.y)));
+}
+DS_HD cf cfnma(cf acc, cf a, cf b) {       // acc - a * b
+    return mk(fma_(-a.x, b.x, fma_(a.y, b.y, acc.x)), fma_(-a.x, b.y, fma_(-a.y, b.x, acc.y)));
+}
+DS_HD cf cfnmac(cf acc, cf a, cf b) {      // acc - a * conj(b)
+    return mk(fma_(-a.x, b.x, fma_(-a.y, b.y, acc.x)), fma_(-a.y, b.x, fma_(a.x, b.y, acc.y)));
+}
+DS_HD cf cdiv(cf a, cf b) {
+    const float d = 1.0f / cabs2(b);
+    const cf n = cmulc(a, b);
+    return mk(n.x * d, n.y * d);
+}
 
 DS_HD float fminf_(float a, float b) { return a < b ? a : b; }
 DS_HD float fmaxf_(float a, float b) { return a > b ? a : b; }
@@ -199,19 +219,19 @@ DS_HD void mcra_bin(float* st, int k, int K, const float* pw, int frm_cnt, bool 
     } else if (k == 0) {
         p = 0.0f;                                                                     // :43-45
     } else if (k < K - 1) {
-        const float Sf = pw[k - 1] * 0.25f + Yk * 0.5f + pw[k + 1] * 0.25f;           // :46
-        S = alpha_s * S + one_m_alpha_s * Sf;                                         // :47
+        const float Sf = fma_(pw[k + 1], 0.25f, fma_(Yk, 0.5f, pw[k - 1] * 0.25f));           // :46
+        S = fma_(alpha_s, S, one_m_alpha_s * Sf);                                         // :47
         Smin = fminf_(Smin, S); Stmp = fminf_(Stmp, S);                               // :49-50
         if (reset) { Smin = fminf_(Stmp, S); Stmp = S; }                              // :52-56
         const float Sr = S / (Smin + 1e-6f);                                          // :58
         const float I = Sr > delta_s ? 1.0f : 0.0f;                                   // :60-63
-        p = alpha_p * p + one_m_alpha_p * I;                                          // :65-67
+        p = fma_(alpha_p, p, one_m_alpha_p * I);                                          // :65-67
         if (frm_cnt < 2 * L) p = 0.0f;                                                // :68-69
     }
     p = fmaxf_(fminf_(p, p_max), p_min);                                              // :70
     if (k == K - 1) lam = 1e-8f;                                                      // :73
-    const float at = alpha_d + one_m_alpha_d * p;                                     // Base :57
-    lam = at * lam + (1.0f - at) * Yk;                                                // Base :60
+    const float at = fma_(one_m_alpha_d, p, alpha_d);                                     // Base :57
+    lam = fma_(at, lam, (1.0f - at) * Yk);                                                // Base :60
     st[0] = S; st[1] = Smin; st[2] = Stmp; st[3] = p; st[4] = lam;
 }
 
@@ -225,15 +245,15 @@ template <int M> DS_HD cf herm_get(const float* d, const float* o, int i, int j)
 // rank-1 recursive update  R <- a R + b z z^H   (adaptivebeamformer.py:86-88,97-99)
 template <int M> DS_HD void herm_rank1(float* d, float* o, const cf* z, float a, float b) {
 #pragma unroll
-    for (int i = 0; i < M; ++i) d[i] = a * d[i] + b * cabs2(z[i]);
+    for (int i = 0; i < M; ++i) d[i] = fma_(a, d[i], b * cabs2(z[i]));
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
         for (int j = i + 1; j < M; ++j) {
             const int q = off_index(i, j, M);
             const cf zz = cmulc(z[i], z[j]);
-            o[2 * q] = a * o[2 * q] + b * zz.x;
-            o[2 * q + 1] = a * o[2 * q + 1] + b * zz.y;
+            o[2 * q] = fma_(a, o[2 * q], b * zz.x);
+            o[2 * q + 1] = fma_(a, o[2 * q + 1], b * zz.y);
         }
 }
 
@@ -248,7 +268,7 @@ template <int M> struct Chol {
         for (int j = 0; j < M; ++j) {
             float s = d[j] + diag;
 #pragma unroll
-            for (int k = 0; k < j; ++k) s -= cabs2(L(j, k));
+            for (int k = 0; k < j; ++k) { const cf l = L(j, k); s = fma_(-l.x, l.x, fma_(-l.y, l.y, s)); }
             s = fmaxf_(s, 1e-30f);
 #if defined(__HIP_DEVICE_COMPILE__)
             const float r = rsqrtf(s);
@@ -260,7 +280,7 @@ template <int M> struct Chol {
             for (int i = j + 1; i < M; ++i) {
                 cf a = herm_get<M>(d, o, i, j);
 #pragma unroll
-                for (int k = 0; k < j; ++k) a = csub(a, cmulc(L(i, k), L(j, k)));
+                for (int k = 0; k < j; ++k) a = cfnmac(a, L(i, k), L(j, k));
                 lo[off_index(j, i, M)] = cscale(a, r);
             }
         }
@@ -272,14 +292,14 @@ template <int M> struct Chol {
         for (int i = 0; i < M; ++i) {
             cf a = b[i];
 #pragma unroll
-            for (int k = 0; k < i; ++k) a = csub(a, cmul(L(i, k), u[k]));
+            for (int k = 0; k < i; ++k) a = cfnma(a, L(i, k), u[k]);
             u[i] = cscale(a, inv[i]);
         }
 #pragma unroll
         for (int i = M - 1; i >= 0; --i) {
             cf a = u[i];
 #pragma unroll
-            for (int k = i + 1; k < M; ++k) a = csub(a, cmul(cconj(L(k, i)), v[k]));
+            for (int k = i + 1; k < M; ++k) a = cfnmac(a, v[k], L(k, i));
             v[i] = cscale(a, inv[i]);
         }
     }
@@ -300,7 +320,7 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
         acc = cmulc(Z[0], a[0]);
     } else if (p.method == METHOD_DS) {                        // beamformer.py:323-324
 #pragma unroll
-        for (int m = 0; m < M; ++m) acc = cadd(acc, cmulc(Z[m], a[m]));
+        for (int m = 0; m < M; ++m) acc = cfmac(acc, Z[m], a[m]);
         acc = cscale(acc, 1.0f / M);
     } else if (p.method == METHOD_MVDR) {                      // beamformer.py:325-326, :103-104
         Chol<M> ch;
@@ -310,8 +330,8 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
         cf den = mk(0.0f, 0.0f), num = mk(0.0f, 0.0f);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
-            den = cadd(den, cmulc(v[m], a[m]));                // a^H v
-            num = cadd(num, cmulc(Z[m], v[m]));                // v^H z
+            den = cfmac(den, v[m], a[m]);                      // a^H v
+            num = cfmac(num, Z[m], v[m]);                      // v^H z
         }
         acc = cdiv(num, cconj(den));                           // sum conj(v/den) z
     } else if (RYY) {                                          // TFGSC, beamformer.py:327-333
@@ -336,7 +356,7 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
         col0[0].x -= 1.0f;
         const cf den = mk(tr.x - (float)M, tr.y);
 #pragma unroll
-        for (int m = 0; m < M; ++m) acc = cadd(acc, cmulc(Z[m], cdiv(col0[m], den)));
+        for (int m = 0; m < M; ++m) acc = cfmac(acc, Z[m], cdiv(col0[m], den));
     }
     return acc;
 }
@@ -344,7 +364,7 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
 template <int M> DS_HD cf fixed_bin(const cf* Z, const cf* w) {   // fixedbeamformer.py:163
     cf acc = mk(0.0f, 0.0f);
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc = cadd(acc, cmulc(Z[m], w[m]));
+    for (int m = 0; m < M; ++m) acc = cfmac(acc, Z[m], w[m]);
     return acc;
 }
 
@@ -368,8 +388,8 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
 #pragma unroll
         for (int j = i; j < M; ++j) {
             const int q = sym_index(i, j, M);
-            yy[q] = Z[i].x * Z[j].x + Z[i].y * Z[j].y;         // Re(conj(y_i) y_j)  :182-184
-            pyy[q] = alpha * pyy[q] + one_m_alpha * yy[q];
+            yy[q] = fma_(Z[i].x, Z[j].x, Z[i].y * Z[j].y);         // Re(conj(y_i) y_j)  :182-184
+            pyy[q] = fma_(alpha, pyy[q], one_m_alpha * yy[q]);
         }
     if (spp_frm_cnt < 5) {                                     // :186-187
 #pragma unroll
@@ -382,7 +402,7 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
     for (int j = 0; j < M; ++j) {
         float s = sym_get<M>(pvv, j, j) + 1e-6f;
 #pragma unroll
-        for (int q = 0; q < j; ++q) s -= Lm[j][q] * Lm[j][q];
+        for (int q = 0; q < j; ++q) s = fma_(-Lm[j][q], Lm[j][q], s);
         s = fmaxf_(s, 1e-30f);
         const float r = 1.0f / sqrtf(s);
         inv_d[j] = r;
@@ -391,7 +411,7 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
         for (int i = j + 1; i < M; ++i) {
             float t = sym_get<M>(pvv, i, j);
 #pragma unroll
-            for (int q = 0; q < j; ++q) t -= Lm[i][q] * Lm[j][q];
+            for (int q = 0; q < j; ++q) t = fma_(-Lm[i][q], Lm[j][q], t);
             Lm[i][j] = t * r;
         }
     }
@@ -404,7 +424,7 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
             if (i < c) { Li[i][c] = 0.0f; continue; }
             float t = (i == c) ? 1.0f : 0.0f;
 #pragma unroll
-            for (int q = c; q < i; ++q) t -= Lm[i][q] * Li[q][c];
+            for (int q = c; q < i; ++q) t = fma_(-Lm[i][q], Li[q][c], t);
             Li[i][c] = t * inv_d[i];
         }
     }
@@ -416,7 +436,7 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
         for (int j = i; j < M; ++j) {
             float t = 0.0f;
 #pragma unroll
-            for (int q = j; q < M; ++q) t += Li[q][i] * Li[q][j];
+            for (int q = j; q < M; ++q) t = fma_(Li[q][i], Li[q][j], t);
             iv[sym_index(i, j, M)] = t;
         }
     // tr = trace(inv Phi_yy) ; psi = sum inv_ij yy_ij ; gamma = sum A_ij yy_ij, A = inv Phi_xx inv
@@ -426,8 +446,8 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
 #pragma unroll
         for (int j = 0; j < M; ++j) {
             const float e = sym_get<M>(iv, i, j);
-            tr += e * sym_get<M>(pyy, i, j);
-            psi += e * sym_get<M>(yy, i, j);
+            tr = fma_(e, sym_get<M>(pyy, i, j), tr);
+            psi = fma_(e, sym_get<M>(yy, i, j), psi);
         }
     float xi = fminf_(fmaxf_(tr - (float)M, 1e-6f), 1e6f);                               // :193-194
     // B = Phi_xx inv  (M x M), A = inv B
@@ -438,7 +458,7 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
         for (int j = 0; j < M; ++j) {
             float t = 0.0f;
 #pragma unroll
-            for (int q = 0; q < M; ++q) t += (sym_get<M>(pyy, i, q) - sym_get<M>(pvv, i, q)) * sym_get<M>(iv, q, j);
+            for (int q = 0; q < M; ++q) t = fma_(sym_get<M>(pyy, i, q) - sym_get<M>(pvv, i, q), sym_get<M>(iv, q, j), t);
             Bm[i][j] = t;
         }
     float gam = 0.0f;
@@ -448,8 +468,8 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
         for (int j = 0; j < M; ++j) {
             float t = 0.0f;
 #pragma unroll
-            for (int q = 0; q < M; ++q) t += sym_get<M>(iv, i, q) * Bm[q][j];
-            gam += t * sym_get<M>(yy, i, j);
+            for (int q = 0; q < M; ++q) t = fma_(sym_get<M>(iv, i, q), Bm[q][j], t);
+            gam = fma_(t, sym_get<M>(yy, i, j), gam);
         }
     gam = fminf_(fmaxf_(gam, 1e-6f), 1e6f);                                               // :199
     // q_local :91-105
@@ -464,7 +484,7 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
     // noise PSD update :210-224
     const float at = 0.95f + (float)(1.0 - 0.95) * pp;
 #pragma unroll
-    for (int q2 = 0; q2 < NS; ++q2) pvv[q2] = at * pvv[q2] + (1.0f - at) * yy[q2];
+    for (int q2 = 0; q2 < NS; ++q2) pvv[q2] = fma_(at, pvv[q2], (1.0f - at) * yy[q2]);
     // gain :153-157
     const float Gmin = 0.0631f;
     const float gh1 = xi / (1.0f + xi);
@@ -476,7 +496,7 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
     float aa = 0.0f;
     cf yf = mk(0.0f, 0.0f);
 #pragma unroll
-    for (int m = 0; m < M; ++m) { aa += cabs2(a[m]); yf = cadd(yf, cmulc(Z[m], a[m])); }
+    for (int m = 0; m < M; ++m) { aa += cabs2(a[m]); yf = cfmac(yf, Z[m], a[m]); }
     yf = cscale(yf, 1.0f / aa);
     const cf u0 = cmulc(Z[0], a[0]);
     cf U[M - 1];
@@ -484,14 +504,14 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
 #pragma unroll
     for (int i = 0; i < M - 1; ++i) {
         U[i] = csub(u0, cmulc(Z[i + 1], a[i + 1]));
-        Yk = csub(Yk, cmulc(U[i], mk(ga[2 * i], ga[2 * i + 1])));                           // conj(G_i) U_i
+        Yk = cfnmac(Yk, U[i], mk(ga[2 * i], ga[2 * i + 1]));                           // conj(G_i) U_i
     }
     const float step = p.mu * (1.0f - pp);                                                  // GSC.py:270-274
 #pragma unroll
     for (int i = 0; i < M - 1; ++i) {
         const cf g = cmulc(U[i], Yk);                                                       // U_i conj(Y)
-        ga[2 * i] += step * g.x;
-        ga[2 * i + 1] += step * g.y;
+        ga[2 * i] = fma_(step, g.x, ga[2 * i]);
+        ga[2 * i + 1] = fma_(step, g.y, ga[2 * i + 1]);
     }
     return cscale(Yk, G);                                                                   // GSC.py:286
 }
@@ -611,7 +631,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                         const cf E = cscale(cadd(A, Bc), 0.5f);
                         const cf D = csub(A, Bc);
                         const cf O = mk(0.5f * D.y, -0.5f * D.x);          // D / (2j)
-                        r.Z[m] = cadd(E, cmul(w, O));
+                        r.Z[m] = cfma(E, w, O);
                     }
                     if (k == 0 || k == NC) {
 #pragma unroll

@@ -78,6 +78,16 @@ class BatchEngine:
                                             int(y_batch_stride), int(first),
                                             int(count), ctypes.c_void_p(stream) if stream else None), self._h)
 
+    def process_device_seq(self, x_ptr, layout, x_batch_stride, x_chan_stride, x_call_stride, n_samples_per_call,
+                           n_calls, y_ptr, y_batch_stride, y_call_stride, first=0, count=None, stream=None, graph=0):
+        """n_calls successive process_device() calls enqueued by one native call (graph=1: hipGraph replay,
+        graph=2: only build the graph)."""
+        count = self.batch - first if count is None else count
+        L.check(self._lib.ds_process_device_seq(
+            self._h, ctypes.c_void_p(x_ptr), int(layout), int(x_batch_stride), int(x_chan_stride), int(x_call_stride),
+            int(n_samples_per_call), int(n_calls), ctypes.c_void_p(y_ptr), int(y_batch_stride), int(y_call_stride),
+            int(first), int(count), ctypes.c_void_p(stream) if stream else None, int(graph)), self._h)
+
     def synchronize(self):
         L.check(self._lib.ds_synchronize(self._h), self._h)
 

@@ -140,6 +140,17 @@ int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y
 int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
                       int n_samples, float* y_dev, long long y_batch_stride, int first, int count, void* stream);
 
+/* n_calls successive ds_process_device() calls enqueued from one host call: call i reads
+ * x_dev + i * x_call_stride and writes y_dev + i * y_call_stride (elements).  This is the realtime
+ * shell's loop (realtime/realtime_processing.py:113-136: one process() per captured chunk) hoisted into
+ * the library so the host does not pay one FFI crossing per chunk.
+ * graph: 0 = plain launches; 1 = replay the sequence as a hipGraph (captured and cached on first use for
+ * this exact argument set); 2 = only build/cache the graph, launch nothing. */
+int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
+                          long long x_call_stride, int n_samples_per_call, int n_calls, float* y_dev,
+                          long long y_batch_stride, long long y_call_stride, int first, int count, void* stream,
+                          int graph);
+
 int ds_synchronize(ds_handle* h);
 
 /* hipEvent bracket on the handle's stream (kernel timing for bench.py) */
