@@ -132,16 +132,18 @@ DS_HD constexpr int sym_index(int i, int j, int M) {   // i<=j -> index among up
     return i * M - (i * (i - 1)) / 2 + (j - i);
 }
 
-template <int NFFT, int M> struct Shared {
+template <int NFFT, int M, int NYQF = 4> struct Shared {
     static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2;
     float xbuf[M][N];     // two halves: [old hop | new hop], roles swap every frame
-    cf fa[M][NC];
-    cf fb[M][NC];
+    static constexpr int NCP = NC + NC / 4;   // room for the bank-conflict padding of the early FFT stages
+    cf fa[M][NCP];
+    cf fb[M][NCP];
     cf tw[NC + 1];
     float win[N];
     float pw[K + 3];      // |Z_0|^2 for the MCRA frequency stencil
     cf Y[K + 1];          // beamformer output spectrum
     float tail[HOP];      // overlap-add tail
+    float nyq[NYQF];      // per-bin state of the Nyquist bin (k = N/2), processed by thread 0 in a second pass
 };
 
 template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
@@ -165,10 +167,20 @@ template <int R, int SIGN> DS_HD void butterfly(cf* v) {
     }
 }
 
-// in/out: [MCH][NC].  FROM_X: read windowed real samples packed as (x[2n], x[2n+1]) from xbuf.
-template <int NFFT, int M, int MCH, int R, int SIGN, bool FROM_X>
-DS_HD void fft_stage(int tid, int nt, Shared<NFFT, M>& sh, const cf* in, cf* out, int Ns, int old_half) {
-    constexpr int NC = NFFT / 2, NB = NC / R, HOP = NFFT / 2;
+// LDS index padding of an FFT buffer.  The radix-4 Stockham stage with sub-transform size Ns writes
+// out[(j - k) * 4 + k + r * Ns]: for Ns = 1 a stride of 4 complex, for Ns = 4 runs of 4 complex every 16 —
+// 4-way bank conflicts for ds_write_b64 on a linear buffer.  PAD 1 (i + i/16) makes the Ns = 1 pattern
+// conflict-free, PAD 2 (i + 4*(i/16)) the Ns = 4 pattern; later stages write contiguous runs (PAD 0).
+template <int PAD> DS_HD int padi(int i) {
+    if constexpr (PAD == 1) return i + (i >> 4);
+    else if constexpr (PAD == 2) return i + ((i >> 4) << 2);
+    else return i;
+}
+
+// in/out: [MCH][NCP].  FROM_X: read windowed real samples packed as (x[2n], x[2n+1]) from xbuf.
+template <int NFFT, int M, int MCH, int R, int SIGN, bool FROM_X, int PIN, int POUT, class ShT>
+DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, int old_half) {
+    constexpr int NC = NFFT / 2, NB = NC / R, HOP = NFFT / 2, NCP = ShT::NCP;
     const int tstride = NFFT / (Ns * R);
     for (int idx = tid; idx < MCH * NB; idx += nt) {
         const int ch = idx / NB, j = idx - ch * NB;
@@ -182,7 +194,7 @@ DS_HD void fft_stage(int tid, int nt, Shared<NFFT, M>& sh, const cf* in, cf* out
                 const int pos = s < HOP ? old_half * HOP + s : (old_half ^ 1) * HOP + (s - HOP);
                 v[r] = mk(sh.win[s] * sh.xbuf[ch][pos], sh.win[s + 1] * sh.xbuf[ch][pos + 1]);
             } else {
-                v[r] = in[ch * NC + n];
+                v[r] = in[ch * NCP + padi<PIN>(n)];
             }
         }
         if (Ns > 1) {
@@ -200,7 +212,7 @@ DS_HD void fft_stage(int tid, int nt, Shared<NFFT, M>& sh, const cf* in, cf* out
         butterfly<R, SIGN>(v);
         const int j0 = (j - k) * R + k;
 #pragma unroll
-        for (int r = 0; r < R; ++r) out[ch * NC + j0 + r * Ns] = v[r];
+        for (int r = 0; r < R; ++r) out[ch * NCP + padi<POUT>(j0 + r * Ns)] = v[r];
     }
 }
 
@@ -305,6 +317,54 @@ template <int M> struct Chol {
     }
 };
 
+// MVDR output without forming the inverse or the weights:
+//   Y = sum_m conj(w_m) z_m,  w = A^-1 a / (a^H A^-1 a),  A = R + diag*I = L L^H
+//     = (u^H t) / (u^H u),    u = L^-1 a,  t = L^-1 z
+// (adaptivebeamformer.py:103-112,119-120 + beamformer.py:325-326).  Right-looking Cholesky on a working
+// copy of A with both forward substitutions fused into the column sweep: no back-substitution,
+// no stored factor, real denominator.
+template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag, const cf* a, const cf* z) {
+    float Ad[M];
+    cf Al[M * (M - 1) / 2 + 1];          // strictly-lower A_ij (i>j) at off_index(j, i)
+    cf u[M], t[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) { Ad[i] = d[i] + diag; u[i] = a[i]; t[i] = z[i]; }
+#pragma unroll
+    for (int q = 0; q < M * (M - 1) / 2; ++q) Al[q] = mk(o[2 * q], -o[2 * q + 1]);   // A_ij = conj(R_ji)
+    float nu = 0.0f;
+    cf ut = mk(0.0f, 0.0f);
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const float sj = fmaxf_(Ad[j], 1e-30f);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float r = rsqrtf(sj);
+#else
+        const float r = 1.0f / sqrtf(sj);
+#endif
+        const cf uj = cscale(u[j], r), tj = cscale(t[j], r);
+        nu = fma_(uj.x, uj.x, fma_(uj.y, uj.y, nu));
+        ut = cfmac(ut, tj, uj);                                  // += conj(u_j) t_j
+        cf Lc[M];
+#pragma unroll
+        for (int i = j + 1; i < M; ++i) {
+            Lc[i] = cscale(Al[off_index(j, i, M)], r);
+            u[i] = cfnma(u[i], Lc[i], uj);
+            t[i] = cfnma(t[i], Lc[i], tj);
+        }
+#pragma unroll
+        for (int i = j + 1; i < M; ++i) {
+            Ad[i] = fma_(-Lc[i].x, Lc[i].x, fma_(-Lc[i].y, Lc[i].y, Ad[i]));
+#pragma unroll
+            for (int k = j + 1; k < i; ++k) {
+                const int q = off_index(k, i, M);
+                Al[q] = cfnmac(Al[q], Lc[i], Lc[k]);             // A_ik -= L_ij conj(L_kj)
+            }
+        }
+    }
+    const float inv = 1.0f / nu;
+    return mk(ut.x * inv, ut.y * inv);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-bin algorithms.  Return the beamformer output Y[k].
 // ---------------------------------------------------------------------------------------------
@@ -323,17 +383,7 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
         for (int m = 0; m < M; ++m) acc = cfmac(acc, Z[m], a[m]);
         acc = cscale(acc, 1.0f / M);
     } else if (p.method == METHOD_MVDR) {                      // beamformer.py:325-326, :103-104
-        Chol<M> ch;
-        ch.factor(d, o, p.diag);
-        cf v[M];
-        ch.solve(a, v);
-        cf den = mk(0.0f, 0.0f), num = mk(0.0f, 0.0f);
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            den = cfmac(den, v[m], a[m]);                      // a^H v
-            num = cfmac(num, Z[m], v[m]);                      // v^H z
-        }
-        acc = cdiv(num, cconj(den));                           // sum conj(v/den) z
+        acc = mvdr_output<M>(d, o, p.diag, a, Z);
     } else if (RYY) {                                          // TFGSC, beamformer.py:327-333
         Chol<M> ch;
         ch.factor(d, o, p.diag);
@@ -521,13 +571,13 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
 // ---------------------------------------------------------------------------------------------
 template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
     static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2;
-    static constexpr int NT = NC + 64;                       // one thread per bin + the Nyquist bin's wave
+    static constexpr int NT = NC;                            // one thread per bin 0..NC-1; thread 0 also does bin NC
     static constexpr int KP = (K + 3) & ~3;                  // padded plane length
     typedef StateLayout<M, ALGO, RYY> SL;
     static constexpr int NP = SL::NP;
     static constexpr int NV4 = HOP * M / 4;                  // float4 per hop of input
     static constexpr int NPRE = (NV4 + NT - 1) / NT;
-    typedef Shared<NFFT, M> Sh;
+    typedef Shared<NFFT, M, (SL::NP > 0 ? SL::NP * 4 : 4)> Sh;
     typedef Regs<M, ALGO, RYY, NPRE> Rg;
     static constexpr bool FWD_FINAL_IS_FB = (NC != 512);     // 128: 4 stages, 256: 4 stages, 512: 5 stages
     static constexpr bool INV_FINAL_IS_FA = (NC != 512);
@@ -571,6 +621,24 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         }
     }
 
+    // one frequency bin: MCRA / covariance recursion / solve -> Y[k]
+    static DS_HD cf bin_program(float* st, const cf* Z, const cf* steer, int k, const Sh& sh, const Params& p,
+                                int frm_cnt, bool reset, int spp_cnt) {
+        cf a[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) a[m] = steer[k * M + m];
+        cf Yk;
+        if constexpr (ALGO == ALGO_FIXED) {
+            Yk = fixed_bin<M>(Z, a);
+        } else if constexpr (ALGO == ALGO_ADAPTIVE) {
+            mcra_bin(st + SL::MC_S, k, K, sh.pw, frm_cnt, reset, p.mcra_L);
+            Yk = adaptive_bin<M, RYY>(st, Z, a, p);
+        } else {
+            Yk = gsc_bin<M>(st, Z, a, p, k, spp_cnt);
+        }
+        return Yk;
+    }
+
     template <class Exec> static DS_HD void run(Exec& ex, const Params& p, int blk, Sh& sh) {
         const int b = p.batch0 + blk;
         const long long xb = (long long)blk * p.x_batch_stride;
@@ -589,12 +657,14 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             for (int i = tid; i < N; i += NT) sh.win[i] = p.win[i];
             for (int i = tid; i < M * HOP; i += NT) sh.xbuf[i / HOP][i % HOP] = tin[i];   // old half = 0
             for (int i = tid; i < HOP; i += NT) sh.tail[i] = tout[i];
-            if (tid < K) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    const vec4 v = bins[q * KP + tid];
-                    r.st[4 * q] = v.x; r.st[4 * q + 1] = v.y; r.st[4 * q + 2] = v.z; r.st[4 * q + 3] = v.w;
-                }
+            for (int q = 0; q < NP; ++q) {
+                const vec4 v = bins[q * KP + tid];
+                r.st[4 * q] = v.x; r.st[4 * q + 1] = v.y; r.st[4 * q + 2] = v.z; r.st[4 * q + 3] = v.w;
+            }
+            if (tid < NP) {                                   // Nyquist bin's planes -> LDS
+                const vec4 v = bins[tid * KP + NC];
+                sh.nyq[4 * tid] = v.x; sh.nyq[4 * tid + 1] = v.y; sh.nyq[4 * tid + 2] = v.z; sh.nyq[4 * tid + 3] = v.w;
             }
             prefetch(p, xb, 0, tid, r);
         });
@@ -609,56 +679,51 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // ---- forward FFT: M packed real transforms -------------------------------------------
             cf* fa = &sh.fa[0][0];
             cf* fb = &sh.fb[0][0];
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, true>(tid, NT, sh, nullptr, fa, 1, old_half); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false>(tid, NT, sh, fa, fb, 4, 0); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false>(tid, NT, sh, fb, fa, 16, 0); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0); });
             if (NC == 128) {
-                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 2, -1, false>(tid, NT, sh, fa, fb, 64, 0); });
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 2, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0); });
             } else {
-                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false>(tid, NT, sh, fa, fb, 64, 0); });
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0); });
                 if (NC == 512)
-                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 2, -1, false>(tid, NT, sh, fb, fa, 256, 0); });
+                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 2, -1, false, 0, 0>(tid, NT, sh, fb, fa, 256, 0); });
             }
             const cf* F = FWD_FINAL_IS_FB ? fb : fa;
             // ---- split packed spectrum -> Z[k][m]; publish |Z_0|^2 for the MCRA stencil ----------
             ex.phase([&](int tid, Rg& r) {
-                if (tid < K) {
-                    const int k = tid, k1 = k & (NC - 1), k2 = (NC - k) & (NC - 1);
-                    const cf w = sh.tw[k];
+                const int k = tid, k2 = (NC - k) & (NC - 1);
+                const cf w = sh.tw[k];
 #pragma unroll
-                    for (int m = 0; m < M; ++m) {
-                        const cf A = F[m * NC + k1], Bc = cconj(F[m * NC + k2]);
-                        const cf E = cscale(cadd(A, Bc), 0.5f);
-                        const cf D = csub(A, Bc);
-                        const cf O = mk(0.5f * D.y, -0.5f * D.x);          // D / (2j)
-                        r.Z[m] = cfma(E, w, O);
-                    }
-                    if (k == 0 || k == NC) {
-#pragma unroll
-                        for (int m = 0; m < M; ++m) r.Z[m].y = 0.0f;
-                    }
-                    sh.pw[k] = cabs2(r.Z[0]);
+                for (int m = 0; m < M; ++m) {
+                    const cf A = F[m * Sh::NCP + k], Bc = cconj(F[m * Sh::NCP + k2]);
+                    const cf E = cscale(cadd(A, Bc), 0.5f);
+                    const cf D = csub(A, Bc);
+                    const cf O = mk(0.5f * D.y, -0.5f * D.x);          // D / (2j)
+                    r.Z[m] = cfma(E, w, O);
                 }
+                if (k == 0) {
+#pragma unroll
+                    for (int m = 0; m < M; ++m) r.Z[m].y = 0.0f;
+                    const cf F0 = F[0];
+                    const float zn = F0.x - F0.y;                       // channel-0 Nyquist bin
+                    sh.pw[NC] = zn * zn;
+                }
+                sh.pw[k] = cabs2(r.Z[0]);
             });
             // ---- per-bin recursion -> Y[k] --------------------------------------------------------
             const bool reset = (frm_cnt != 0) && (ell % p.mcra_L == 0);
             ex.phase([&](int tid, Rg& r) {
-                if (tid < K) {
-                    const int k = tid;
-                    cf a[M];
+                cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt);
+                if (tid == 0) Yk.y = 0.0f;                              // irfft ignores Im Y[0] and Im Y[N/2]
+                sh.Y[tid] = Yk;
+                if (tid == 0) {                                         // second pass: the Nyquist bin, state in LDS
+                    cf Zn[M];
 #pragma unroll
-                    for (int m = 0; m < M; ++m) a[m] = steer[k * M + m];
-                    cf Yk;
-                    if constexpr (ALGO == ALGO_FIXED) {
-                        Yk = fixed_bin<M>(r.Z, a);
-                    } else if constexpr (ALGO == ALGO_ADAPTIVE) {
-                        mcra_bin(r.st + SL::MC_S, k, K, sh.pw, frm_cnt, reset, p.mcra_L);
-                        Yk = adaptive_bin<M, RYY>(r.st, r.Z, a, p);
-                    } else {
-                        Yk = gsc_bin<M>(r.st, r.Z, a, p, k, spp_cnt);
-                    }
-                    if (k == 0 || k == NC) Yk.y = 0.0f;                     // irfft ignores these imaginary parts
-                    sh.Y[k] = Yk;
+                    for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; Zn[m] = mk(F0.x - F0.y, 0.0f); }
+                    cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_cnt, reset, spp_cnt);
+                    Yn.y = 0.0f;
+                    sh.Y[NC] = Yn;
                 }
             });
             if (ALGO == ALGO_ADAPTIVE) {
@@ -668,23 +733,21 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             if (ALGO == ALGO_GSC) spp_cnt += 1;
             // ---- inverse packed real FFT -----------------------------------------------------------
             ex.phase([&](int tid, Rg&) {
-                if (tid < NC) {
-                    const int k = tid;
-                    const cf A = sh.Y[k], Bc = cconj(sh.Y[NC - k]);
-                    const cf E = cscale(cadd(A, Bc), 0.5f);
-                    const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tw[k]));
-                    fa[k] = mk(E.x - O.y, E.y + O.x);                       // E + j O
-                }
+                const int k = tid;
+                const cf A = sh.Y[k], Bc = cconj(sh.Y[NC - k]);
+                const cf E = cscale(cadd(A, Bc), 0.5f);
+                const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tw[k]));
+                fa[k] = mk(E.x - O.y, E.y + O.x);                       // E + j O
             });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false>(tid, NT, sh, fa, fb, 1, 0); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false>(tid, NT, sh, fb, fa, 4, 0); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false>(tid, NT, sh, fa, fb, 16, 0); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false, 0, 1>(tid, NT, sh, fa, fb, 1, 0); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false, 1, 2>(tid, NT, sh, fb, fa, 4, 0); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false, 2, 0>(tid, NT, sh, fa, fb, 16, 0); });
             if (NC == 128) {
-                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 2, +1, false>(tid, NT, sh, fb, fa, 64, 0); });
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 2, +1, false, 0, 0>(tid, NT, sh, fb, fa, 64, 0); });
             } else {
-                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false>(tid, NT, sh, fb, fa, 64, 0); });
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false, 0, 0>(tid, NT, sh, fb, fa, 64, 0); });
                 if (NC == 512)
-                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 2, +1, false>(tid, NT, sh, fa, fb, 256, 0); });
+                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 2, +1, false, 0, 0>(tid, NT, sh, fa, fb, 256, 0); });
             }
             const cf* Zi = INV_FINAL_IS_FA ? fa : fb;
             // ---- window, overlap-add, emit hop t ---------------------------------------------------
@@ -708,12 +771,14 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         ex.phase([&](int tid, Rg& r) {
             for (int i = tid; i < M * HOP; i += NT) tin[i] = sh.xbuf[i / HOP][old_half * HOP + i % HOP];
             for (int i = tid; i < HOP; i += NT) tout[i] = sh.tail[i];
-            if (tid < K) {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    vec4 v; v.x = r.st[4 * q]; v.y = r.st[4 * q + 1]; v.z = r.st[4 * q + 2]; v.w = r.st[4 * q + 3];
-                    bins[q * KP + tid] = v;
-                }
+            for (int q = 0; q < NP; ++q) {
+                vec4 v; v.x = r.st[4 * q]; v.y = r.st[4 * q + 1]; v.z = r.st[4 * q + 2]; v.w = r.st[4 * q + 3];
+                bins[q * KP + tid] = v;
+            }
+            if (tid < NP) {
+                vec4 v; v.x = sh.nyq[4 * tid]; v.y = sh.nyq[4 * tid + 1]; v.z = sh.nyq[4 * tid + 2]; v.w = sh.nyq[4 * tid + 3];
+                bins[tid * KP + NC] = v;
             }
             if (tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }
         });

@@ -25,13 +25,18 @@ KernelInfo lookup_gsc(int nfft, int M);
 template <class Rg> struct HipExec {
     Rg r;
     template <class F> __device__ __forceinline__ void phase(F f) {
-        f((int)threadIdx.x, r);
+        // The thread id is laundered through an empty asm so that per-thread LDS addresses are recomputed
+        // inside each phase instead of being hoisted out of the frame loop and kept live in VGPRs for the
+        // whole kernel (that hoisting cost ~60 VGPRs and a block of occupancy).
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        f(tid, r);
         __syncthreads();
     }
 };
 
 template <int NFFT, int M, int ALGO, bool RYY>
-__global__ void __launch_bounds__(NFFT / 2 + 64) ds_frames_kernel(Params p) {
+__global__ void __launch_bounds__(NFFT / 2) ds_frames_kernel(Params p) {
     typedef Engine<NFFT, M, ALGO, RYY> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
