@@ -134,11 +134,12 @@ DS_HD constexpr int sym_index(int i, int j, int M) {   // i<=j -> index among up
 
 template <int NFFT, int M, int NYQF = 4> struct Shared {
     static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2;
-    float xbuf[M][N];     // two halves: [old hop | new hop], roles swap every frame
+    alignas(16) float xbuf[M][N];     // two halves: [old hop | new hop], roles swap every frame
     static constexpr int NCP = NC + NC / 4;   // room for the bank-conflict padding of the early FFT stages
     cf fa[M][NCP];
     cf fb[M][NCP];
-    cf tw[NC + 1];
+    cf tw[NC + 1];        // exp(-2 pi j i / N): split / merge of the packed real transform
+    vec4 stw[NC];         // per-stage twiddles, contiguous per stage: stw[Ns + k] = (w1, w2), w_r = exp(-2 pi j k r / (4 Ns))
     float win[N];
     float pw[K + 3];      // |Z_0|^2 for the MCRA frequency stencil
     cf Y[K + 1];          // beamformer output spectrum
@@ -181,7 +182,6 @@ template <int PAD> DS_HD int padi(int i) {
 template <int NFFT, int M, int MCH, int R, int SIGN, bool FROM_X, int PIN, int POUT, class ShT>
 DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, int old_half) {
     constexpr int NC = NFFT / 2, NB = NC / R, HOP = NFFT / 2, NCP = ShT::NCP;
-    const int tstride = NFFT / (Ns * R);
     for (int idx = tid; idx < MCH * NB; idx += nt) {
         const int ch = idx / NB, j = idx - ch * NB;
         const int k = j & (Ns - 1);
@@ -198,10 +198,11 @@ DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, in
             }
         }
         if (Ns > 1) {
-            cf w1 = sh.tw[k * tstride];
+            const vec4 wv = sh.stw[Ns + k];                  // consecutive lanes -> consecutive k: conflict-free
+            cf w1 = mk(wv.x, wv.y);
             if (SIGN > 0) w1 = cconj(w1);
             if constexpr (R == 4) {
-                cf w2 = sh.tw[2 * k * tstride];
+                cf w2 = mk(wv.z, wv.w);
                 if (SIGN > 0) w2 = cconj(w2);
                 cf w3 = cmul(w1, w2);
                 v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3);
@@ -608,8 +609,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 const float e[4] = {r.pre[i].x, r.pre[i].y, r.pre[i].z, r.pre[i].w};
                 if (p.x_sample_stride == 1) {
                     const int m = v / (HOP / 4), q = v - m * (HOP / 4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) sh.xbuf[m][new_half * HOP + 4 * q + c] = e[c];
+                    *reinterpret_cast<vec4*>(&sh.xbuf[m][new_half * HOP + 4 * q]) = r.pre[i];   // one 16-byte LDS store
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -654,6 +654,20 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         // ---- prologue: tables, tails, per-bin state ---------------------------------------------
         ex.phase([&](int tid, Rg& r) {
             for (int i = tid; i <= NC; i += NT) sh.tw[i] = p.twN[i];
+            for (int i = tid; i < NC; i += NT) {             // stage twiddle table (see Shared::stw)
+                if (i >= 4) {
+                    const int Ns = i >= 256 ? 256 : i >= 64 ? 64 : i >= 16 ? 16 : 4;
+                    const int k = i - Ns;
+                    if (k < Ns) {
+                        const int R = (Ns * 4 <= NC) ? 4 : 2;     // the last stage of NC = 128 / 512 is radix-2
+                        const int ts = N / (Ns * R);
+                        const cf w1 = p.twN[k * ts];
+                        const cf w2 = R == 4 ? p.twN[2 * k * ts] : mk(1.0f, 0.0f);
+                        vec4 wv; wv.x = w1.x; wv.y = w1.y; wv.z = w2.x; wv.w = w2.y;
+                        sh.stw[i] = wv;
+                    }
+                }
+            }
             for (int i = tid; i < N; i += NT) sh.win[i] = p.win[i];
             for (int i = tid; i < M * HOP; i += NT) sh.xbuf[i / HOP][i % HOP] = tin[i];   // old half = 0
             for (int i = tid; i < HOP; i += NT) sh.tail[i] = tout[i];
