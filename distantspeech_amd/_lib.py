@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsenh.so")
+LIB_PATH = os.environ.get("DSENH_LIB", os.path.join(_HERE, "libdsenh.so"))   # DSENH_LIB: A/B of kernel builds
 
 DS_OK = 0
 ALGO_FIXED, ALGO_ADAPTIVE, ALGO_GSC = 0, 1, 2

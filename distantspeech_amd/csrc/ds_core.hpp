@@ -94,6 +94,7 @@ struct Params {
     float* tail_out;          // OLA overlap  [B][hop]
     int* counters;            // [B][4]  {mcra frm_cnt, mcra ell, spp frm_cnt, reserved}
     const cf* twN;            // [N/2+1]  exp(-2 pi j i / N)
+    const vec4* stw;          // [N/2] per-stage FFT twiddles: stw[Ns + k] = (w1, w2), w_r = exp(-2 pi j k r / (Ns R))
     const float* win;         // [N] sqrt-Hann
     const cf* steer;          // [K][M] steering vector a (adaptive/GSC) or weights W (fixed)
     long long steer_batch_stride;   // 0: one look direction shared by the batch
@@ -139,7 +140,8 @@ template <int NFFT, int M, int NYQF = 4> struct Shared {
     cf fa[M][NCP];
     cf fb[M][NCP];
     cf tw[NC + 1];        // exp(-2 pi j i / N): split / merge of the packed real transform
-    vec4 stw[NC];         // per-stage twiddles, contiguous per stage: stw[Ns + k] = (w1, w2), w_r = exp(-2 pi j k r / (4 Ns))
+    static constexpr int NSTW = NC == 512 ? 512 : 128;   // entries used: [4, 2 * (largest Ns))
+    vec4 stw[NSTW];       // per-stage twiddles, contiguous per stage: stw[Ns + k] = (w1, w2), w_r = exp(-2 pi j k r / (4 Ns))
     float win[N];
     float pw[K + 3];      // |Z_0|^2 for the MCRA frequency stencil
     cf Y[K + 1];          // beamformer output spectrum
@@ -654,20 +656,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         // ---- prologue: tables, tails, per-bin state ---------------------------------------------
         ex.phase([&](int tid, Rg& r) {
             for (int i = tid; i <= NC; i += NT) sh.tw[i] = p.twN[i];
-            for (int i = tid; i < NC; i += NT) {             // stage twiddle table (see Shared::stw)
-                if (i >= 4) {
-                    const int Ns = i >= 256 ? 256 : i >= 64 ? 64 : i >= 16 ? 16 : 4;
-                    const int k = i - Ns;
-                    if (k < Ns) {
-                        const int R = (Ns * 4 <= NC) ? 4 : 2;     // the last stage of NC = 128 / 512 is radix-2
-                        const int ts = N / (Ns * R);
-                        const cf w1 = p.twN[k * ts];
-                        const cf w2 = R == 4 ? p.twN[2 * k * ts] : mk(1.0f, 0.0f);
-                        vec4 wv; wv.x = w1.x; wv.y = w1.y; wv.z = w2.x; wv.w = w2.y;
-                        sh.stw[i] = wv;
-                    }
-                }
-            }
+            for (int i = tid; i < Sh::NSTW; i += NT) sh.stw[i] = p.stw[i];   // per-stage twiddles (host table, see Shared::stw)
             for (int i = tid; i < N; i += NT) sh.win[i] = p.win[i];
             for (int i = tid; i < M * HOP; i += NT) sh.xbuf[i / HOP][i % HOP] = tin[i];   // old half = 0
             for (int i = tid; i < HOP; i += NT) sh.tail[i] = tout[i];

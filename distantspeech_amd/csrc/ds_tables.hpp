@@ -9,6 +9,25 @@ namespace ds {
 
 // twN[i] = exp(-2 pi j i / N), i = 0..N/2 ; win = sqrt(periodic Hann) (transform/transform.py:418-419);
 // out_scale = hop / sum(win^2) (transform.py:428,479).  Computed in double, rounded once.
+// stw[Ns + k] = (w1, w2) for the Stockham stage with sub-transform size Ns (4, 16, 64, 256), k < Ns:
+// w_r = exp(-2 pi j k r / (Ns R)), R = 4 except the closing radix-2 stage of the 128- and 512-point plans.
+inline void make_stage_twiddles(int N, std::vector<vec4>& stw) {
+    const int NC = N / 2;
+    const double PI = 3.14159265358979323846;
+    stw.assign(NC, vec4{1.0f, 0.0f, 1.0f, 0.0f});
+    for (int Ns = 4; Ns < NC; Ns *= 4) {
+        const int R = (Ns * 4 <= NC) ? 4 : 2;
+        for (int k = 0; k < Ns && Ns + k < NC; ++k) {
+            const double a1 = -2.0 * PI * (double)k / (double)(Ns * R);
+            vec4 w;
+            w.x = (float)std::cos(a1); w.y = (float)std::sin(a1);
+            w.z = R == 4 ? (float)std::cos(2.0 * a1) : 1.0f;
+            w.w = R == 4 ? (float)std::sin(2.0 * a1) : 0.0f;
+            stw[Ns + k] = w;
+        }
+    }
+}
+
 inline void make_tables(int N, int hop, std::vector<cf>& tw, std::vector<float>& win, float& out_scale) {
     const int NC = N / 2;
     const double PI = 3.14159265358979323846;

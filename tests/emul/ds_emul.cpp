@@ -23,6 +23,9 @@ template <int NFFT, int M, int ALGO, bool RYY> int run_t(ds::Params p, int batch
     std::vector<ds::cf> tw;
     std::vector<float> win;
     ds::make_tables(NFFT, NFFT / 2, tw, win, p.out_scale);
+    std::vector<ds::vec4> stw;
+    ds::make_stage_twiddles(NFFT, stw);
+    p.stw = stw.data();
     p.twN = tw.data();
     p.win = win.data();
     typename E::Sh* sh = new typename E::Sh();
