@@ -29,9 +29,7 @@ struct ds_handle {
     float* tail_in;
     float* tail_out;
     int* counters;
-    cf* twN;
-    ds::vec4* stw;
-    float* win;
+    ds::vec4* tables;
     cf* steer;
     int steer_per_utt;
     bool steer_set;
@@ -95,9 +93,7 @@ void fill_params(const ds_handle* h, Params& p) {
     p.tail_in = h->tail_in;
     p.tail_out = h->tail_out;
     p.counters = h->counters;
-    p.twN = h->twN;
-    p.stw = h->stw;
-    p.win = h->win;
+    p.tables = h->tables;
     p.steer = h->steer;
     p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
     p.method = h->method;
@@ -171,7 +167,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->NP = ki.NP;
     h->NT = ki.NT;
     h->bins = nullptr; h->tail_in = nullptr; h->tail_out = nullptr; h->counters = nullptr;
-    h->twN = nullptr; h->stw = nullptr; h->win = nullptr; h->steer = nullptr; h->x_stage = nullptr; h->y_stage = nullptr;
+    h->tables = nullptr; h->steer = nullptr; h->x_stage = nullptr; h->y_stage = nullptr;
     h->x_stage_elems = h->y_stage_elems = 0;
     h->steer_per_utt = 0; h->steer_set = false;
     h->graph_exec = nullptr; h->graph_valid = false;
@@ -205,19 +201,12 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     DS_CRE(hipMalloc((void**)&h->tail_out, tail_out_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->counters, counters_bytes(h)));
     const int N = cfg->nfft, NC = N / 2;
-    DS_CRE(hipMalloc((void**)&h->twN, (size_t)(NC + 1) * sizeof(cf)));
-    DS_CRE(hipMalloc((void**)&h->stw, (size_t)NC * sizeof(ds::vec4)));
-    DS_CRE(hipMalloc((void**)&h->win, (size_t)N * sizeof(float)));
     DS_CRE(hipMalloc((void**)&h->steer, (size_t)h->K * cfg->n_mics * sizeof(cf)));
     {
-        std::vector<cf> tw;
-        std::vector<float> win;
-        ds::make_tables(N, cfg->hop, tw, win, h->out_scale);
-        DS_CRE(hipMemcpy(h->twN, tw.data(), tw.size() * sizeof(cf), hipMemcpyHostToDevice));
-        DS_CRE(hipMemcpy(h->win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
-        std::vector<ds::vec4> stw;
-        ds::make_stage_twiddles(N, stw);
-        DS_CRE(hipMemcpy(h->stw, stw.data(), stw.size() * sizeof(ds::vec4), hipMemcpyHostToDevice));
+        std::vector<float> blob;
+        ds::make_table_blob(N, cfg->hop, blob, h->out_scale);
+        DS_CRE(hipMalloc((void**)&h->tables, blob.size() * sizeof(float)));
+        DS_CRE(hipMemcpy(h->tables, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
     }
 #undef DS_CRE
     int rc = zero_state(h);
@@ -231,7 +220,7 @@ int ds_destroy(ds_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->bins); (void)hipFree(h->tail_in); (void)hipFree(h->tail_out); (void)hipFree(h->counters);
-    (void)hipFree(h->twN); (void)hipFree(h->stw); (void)hipFree(h->win); (void)hipFree(h->steer);
+    (void)hipFree(h->tables); (void)hipFree(h->steer);
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -93,9 +93,7 @@ struct Params {
     float* tail_in;           // STFT overlap [B][M][hop]
     float* tail_out;          // OLA overlap  [B][hop]
     int* counters;            // [B][4]  {mcra frm_cnt, mcra ell, spp frm_cnt, reserved}
-    const cf* twN;            // [N/2+1]  exp(-2 pi j i / N)
-    const vec4* stw;          // [N/2] per-stage FFT twiddles: stw[Ns + k] = (w1, w2), w_r = exp(-2 pi j k r / (Ns R))
-    const float* win;         // [N] sqrt-Hann
+    const vec4* tables;       // Tables<NFFT> blob (twiddles, per-stage twiddles, sqrt-Hann window)
     const cf* steer;          // [K][M] steering vector a (adaptive/GSC) or weights W (fixed)
     long long steer_batch_stride;   // 0: one look direction shared by the batch
     int method;               // METHOD_* (adaptive) ; GSC: 0 = pass channel 0, else GSC
@@ -133,20 +131,28 @@ DS_HD constexpr int sym_index(int i, int j, int M) {   // i<=j -> index among up
     return i * M - (i * (i - 1)) / 2 + (j - i);
 }
 
+// Constant tables, laid out identically in HBM (built once on the host, ds_tables.hpp) and in LDS so the
+// prologue copies them with 16-byte loads/stores.
+template <int NFFT> struct Tables {
+    static constexpr int N = NFFT, NC = NFFT / 2;
+    static constexpr int NSTW = NC == 512 ? 512 : 128;   // entries used: [4, 2 * (largest Ns))
+    cf tw[NC + 2];        // exp(-2 pi j i / N), i = 0..NC (+1 pad): split / merge of the packed real transform
+    vec4 stw[NSTW];       // per-stage twiddles, contiguous per stage: stw[Ns + k] = (w1, w2), w_r = exp(-2 pi j k r / (Ns R))
+    float win[N];         // sqrt-Hann
+    static constexpr int NV4 = ((NC + 2) * 8 + NSTW * 16 + N * 4) / 16;
+};
+
 template <int NFFT, int M, int NYQF = 4> struct Shared {
     static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2;
     alignas(16) float xbuf[M][N];     // two halves: [old hop | new hop], roles swap every frame
     static constexpr int NCP = NC + NC / 4;   // room for the bank-conflict padding of the early FFT stages
     cf fa[M][NCP];
     cf fb[M][NCP];
-    cf tw[NC + 1];        // exp(-2 pi j i / N): split / merge of the packed real transform
-    static constexpr int NSTW = NC == 512 ? 512 : 128;   // entries used: [4, 2 * (largest Ns))
-    vec4 stw[NSTW];       // per-stage twiddles, contiguous per stage: stw[Ns + k] = (w1, w2), w_r = exp(-2 pi j k r / (4 Ns))
-    float win[N];
+    alignas(16) Tables<NFFT> tb;
     float pw[K + 3];      // |Z_0|^2 for the MCRA frequency stencil
     cf Y[K + 1];          // beamformer output spectrum
-    float tail[HOP];      // overlap-add tail
-    float nyq[NYQF];      // per-bin state of the Nyquist bin (k = N/2), processed by thread 0 in a second pass
+    alignas(16) float tail[HOP];      // overlap-add tail
+    alignas(16) float nyq[NYQF];      // per-bin state of the Nyquist bin (k = N/2), processed by thread 0 in a second pass
 };
 
 template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
@@ -194,13 +200,13 @@ DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, in
             if constexpr (FROM_X) {
                 const int s = 2 * n;
                 const int pos = s < HOP ? old_half * HOP + s : (old_half ^ 1) * HOP + (s - HOP);
-                v[r] = mk(sh.win[s] * sh.xbuf[ch][pos], sh.win[s + 1] * sh.xbuf[ch][pos + 1]);
+                v[r] = mk(sh.tb.win[s] * sh.xbuf[ch][pos], sh.tb.win[s + 1] * sh.xbuf[ch][pos + 1]);
             } else {
                 v[r] = in[ch * NCP + padi<PIN>(n)];
             }
         }
         if (Ns > 1) {
-            const vec4 wv = sh.stw[Ns + k];                  // consecutive lanes -> consecutive k: conflict-free
+            const vec4 wv = sh.tb.stw[Ns + k];                  // consecutive lanes -> consecutive k: conflict-free
             cf w1 = mk(wv.x, wv.y);
             if (SIGN > 0) w1 = cconj(w1);
             if constexpr (R == 4) {
@@ -574,7 +580,9 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
 // ---------------------------------------------------------------------------------------------
 template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
     static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2;
-    static constexpr int NT = NC;                            // one thread per bin 0..NC-1; thread 0 also does bin NC
+    static constexpr int NT = NC;                            // one thread per bin 0..NC-1
+    static constexpr int NYQ_TID = NT > 64 ? 64 : 0;         // thread (wave 1) that also runs the Nyquist bin k = NC
+    static constexpr int INV_T0 = NT / 2;                    // inverse-FFT butterflies run on threads [NT/2, NT)
     static constexpr int KP = (K + 3) & ~3;                  // padded plane length
     typedef StateLayout<M, ALGO, RYY> SL;
     static constexpr int NP = SL::NP;
@@ -655,11 +663,17 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
 
         // ---- prologue: tables, tails, per-bin state ---------------------------------------------
         ex.phase([&](int tid, Rg& r) {
-            for (int i = tid; i <= NC; i += NT) sh.tw[i] = p.twN[i];
-            for (int i = tid; i < Sh::NSTW; i += NT) sh.stw[i] = p.stw[i];   // per-stage twiddles (host table, see Shared::stw)
-            for (int i = tid; i < N; i += NT) sh.win[i] = p.win[i];
-            for (int i = tid; i < M * HOP; i += NT) sh.xbuf[i / HOP][i % HOP] = tin[i];   // old half = 0
-            for (int i = tid; i < HOP; i += NT) sh.tail[i] = tout[i];
+            {   // tables, STFT tail (-> old half 0) and OLA tail: 16-byte copies
+                vec4* tb4 = reinterpret_cast<vec4*>(&sh.tb);
+                for (int i = tid; i < Tables<NFFT>::NV4; i += NT) tb4[i] = p.tables[i];
+                const vec4* tin4 = reinterpret_cast<const vec4*>(tin);
+                for (int i = tid; i < M * HOP / 4; i += NT) {
+                    const int m = i / (HOP / 4), q = i - m * (HOP / 4);
+                    *reinterpret_cast<vec4*>(&sh.xbuf[m][4 * q]) = tin4[i];
+                }
+                const vec4* tout4 = reinterpret_cast<const vec4*>(tout);
+                for (int i = tid; i < HOP / 4; i += NT) *reinterpret_cast<vec4*>(&sh.tail[4 * i]) = tout4[i];
+            }
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 const vec4 v = bins[q * KP + tid];
@@ -672,7 +686,12 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             prefetch(p, xb, 0, tid, r);
         });
 
-        for (int t = 0; t < p.T; ++t) {
+#ifdef DS_ABLATE_NOFRAMES     // timing experiment only: state movement without the frame program
+        const int T_run = 0;
+#else
+        const int T_run = p.T;
+#endif
+        for (int t = 0; t < T_run; ++t) {
             const int new_half = old_half ^ 1;
             // ---- hop t into LDS, start fetching hop t+1 ------------------------------------------
             ex.phase([&](int tid, Rg& r) {
@@ -696,7 +715,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // ---- split packed spectrum -> Z[k][m]; publish |Z_0|^2 for the MCRA stencil ----------
             ex.phase([&](int tid, Rg& r) {
                 const int k = tid, k2 = (NC - k) & (NC - 1);
-                const cf w = sh.tw[k];
+                const cf w = sh.tb.tw[k];
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     const cf A = F[m * Sh::NCP + k], Bc = cconj(F[m * Sh::NCP + k2]);
@@ -720,7 +739,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt);
                 if (tid == 0) Yk.y = 0.0f;                              // irfft ignores Im Y[0] and Im Y[N/2]
                 sh.Y[tid] = Yk;
-                if (tid == 0) {                                         // second pass: the Nyquist bin, state in LDS
+                if (tid == NYQ_TID) {                                   // second pass: the Nyquist bin, state in LDS
                     cf Zn[M];
 #pragma unroll
                     for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; Zn[m] = mk(F0.x - F0.y, 0.0f); }
@@ -739,18 +758,18 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 const int k = tid;
                 const cf A = sh.Y[k], Bc = cconj(sh.Y[NC - k]);
                 const cf E = cscale(cadd(A, Bc), 0.5f);
-                const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tw[k]));
+                const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tb.tw[k]));
                 fa[k] = mk(E.x - O.y, E.y + O.x);                       // E + j O
             });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false, 0, 1>(tid, NT, sh, fa, fb, 1, 0); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false, 1, 2>(tid, NT, sh, fb, fa, 4, 0); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false, 2, 0>(tid, NT, sh, fa, fb, 16, 0); });
+            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 4, +1, false, 0, 1>(tid - INV_T0, NT, sh, fa, fb, 1, 0); });
+            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 4, +1, false, 1, 2>(tid - INV_T0, NT, sh, fb, fa, 4, 0); });
+            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 4, +1, false, 2, 0>(tid - INV_T0, NT, sh, fa, fb, 16, 0); });
             if (NC == 128) {
-                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 2, +1, false, 0, 0>(tid, NT, sh, fb, fa, 64, 0); });
+                ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 2, +1, false, 0, 0>(tid - INV_T0, NT, sh, fb, fa, 64, 0); });
             } else {
-                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 4, +1, false, 0, 0>(tid, NT, sh, fb, fa, 64, 0); });
+                ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 4, +1, false, 0, 0>(tid - INV_T0, NT, sh, fb, fa, 64, 0); });
                 if (NC == 512)
-                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 1, 2, +1, false, 0, 0>(tid, NT, sh, fa, fb, 256, 0); });
+                    ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 2, +1, false, 0, 0>(tid - INV_T0, NT, sh, fa, fb, 256, 0); });
             }
             const cf* Zi = INV_FINAL_IS_FA ? fa : fb;
             // ---- window, overlap-add, emit hop t ---------------------------------------------------
@@ -759,10 +778,10 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     const int i = tid;
                     const float sc = 1.0f / (float)NC;
                     const cf z1 = Zi[i], z2 = Zi[i + NC / 2];
-                    const float y0 = sh.win[2 * i] * (z1.x * sc), y1 = sh.win[2 * i + 1] * (z1.y * sc);
+                    const float y0 = sh.tb.win[2 * i] * (z1.x * sc), y1 = sh.tb.win[2 * i + 1] * (z1.y * sc);
                     const float o0 = (y0 + sh.tail[2 * i]) * p.out_scale, o1 = (y1 + sh.tail[2 * i + 1]) * p.out_scale;
-                    sh.tail[2 * i] = sh.win[HOP + 2 * i] * (z2.x * sc);
-                    sh.tail[2 * i + 1] = sh.win[HOP + 2 * i + 1] * (z2.y * sc);
+                    sh.tail[2 * i] = sh.tb.win[HOP + 2 * i] * (z2.x * sc);
+                    sh.tail[2 * i + 1] = sh.tb.win[HOP + 2 * i + 1] * (z2.y * sc);
                     float* dst = p.y + yb + (long long)t * HOP + 2 * i;
                     dst[0] = o0; dst[1] = o1;
                 }
@@ -772,8 +791,15 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
 
         // ---- epilogue: state back to HBM -----------------------------------------------------------
         ex.phase([&](int tid, Rg& r) {
-            for (int i = tid; i < M * HOP; i += NT) tin[i] = sh.xbuf[i / HOP][old_half * HOP + i % HOP];
-            for (int i = tid; i < HOP; i += NT) tout[i] = sh.tail[i];
+            {
+                vec4* tin4 = reinterpret_cast<vec4*>(tin);
+                for (int i = tid; i < M * HOP / 4; i += NT) {
+                    const int m = i / (HOP / 4), q = i - m * (HOP / 4);
+                    tin4[i] = *reinterpret_cast<const vec4*>(&sh.xbuf[m][old_half * HOP + 4 * q]);
+                }
+                vec4* tout4 = reinterpret_cast<vec4*>(tout);
+                for (int i = tid; i < HOP / 4; i += NT) tout4[i] = *reinterpret_cast<const vec4*>(&sh.tail[4 * i]);
+            }
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 vec4 v; v.x = r.st[4 * q]; v.y = r.st[4 * q + 1]; v.z = r.st[4 * q + 2]; v.w = r.st[4 * q + 3];

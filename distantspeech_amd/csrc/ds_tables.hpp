@@ -50,4 +50,21 @@ inline void make_tables(int N, int hop, std::vector<cf>& tw, std::vector<float>&
     out_scale = (float)((double)hop / W0);
 }
 
+// The Tables<NFFT> blob exactly as the kernel's LDS copy expects it: [tw: N/2+2 cf][stw: NSTW vec4][win: N float].
+inline void make_table_blob(int N, int hop, std::vector<float>& blob, float& out_scale) {
+    const int NC = N / 2, NSTW = NC == 512 ? 512 : 128;
+    std::vector<cf> tw;
+    std::vector<float> win;
+    std::vector<vec4> stw;
+    make_tables(N, hop, tw, win, out_scale);
+    make_stage_twiddles(N, stw);
+    blob.assign((size_t)(NC + 2) * 2 + (size_t)NSTW * 4 + N, 0.0f);
+    float* q = blob.data();
+    for (int i = 0; i <= NC; ++i) { q[2 * i] = tw[i].x; q[2 * i + 1] = tw[i].y; }
+    q += (NC + 2) * 2;
+    for (int i = 0; i < NSTW && i < (int)stw.size(); ++i) { q[4 * i] = stw[i].x; q[4 * i + 1] = stw[i].y; q[4 * i + 2] = stw[i].z; q[4 * i + 3] = stw[i].w; }
+    q += NSTW * 4;
+    for (int n = 0; n < N; ++n) q[n] = win[n];
+}
+
 }  // namespace ds

@@ -20,14 +20,11 @@ template <class Rg> struct CpuExec {
 
 template <int NFFT, int M, int ALGO, bool RYY> int run_t(ds::Params p, int batch) {
     typedef ds::Engine<NFFT, M, ALGO, RYY> E;
-    std::vector<ds::cf> tw;
-    std::vector<float> win;
-    ds::make_tables(NFFT, NFFT / 2, tw, win, p.out_scale);
-    std::vector<ds::vec4> stw;
-    ds::make_stage_twiddles(NFFT, stw);
-    p.stw = stw.data();
-    p.twN = tw.data();
-    p.win = win.data();
+    std::vector<float> blob;
+    ds::make_table_blob(NFFT, NFFT / 2, blob, p.out_scale);
+    std::vector<ds::vec4> blob4(blob.size() / 4);
+    std::memcpy((void*)blob4.data(), blob.data(), blob.size() * sizeof(float));
+    p.tables = blob4.data();
     typename E::Sh* sh = new typename E::Sh();
     for (int b = 0; b < batch; ++b) {
         CpuExec<typename E::Rg> ex;

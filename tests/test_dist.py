@@ -1,0 +1,47 @@
+"""Multi-process path on CPU (gloo, world_size 2): shard arithmetic and the final throughput reduction
+(the only collective of the job; on the GPU box the same code runs over RCCL)."""
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_exactly():
+    from distantspeech_amd.dist import shard_range
+    for total in (1, 7, 1024, 1025, 16384):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    from distantspeech_amd import dist as d
+    r, lr, w = d.init(backend="gloo")
+    lo, hi = d.shard_range(1025, r, w)
+    d.barrier()
+    frames, t = d.reduce_throughput((hi - lo) * 10, 1.0 + r)      # rank 1 is "slower"
+    q.put((r, lo, hi, frames, t))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_reduce():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(timeout=60) for p in ps]
+    assert [r[1:3] for r in res] == [(0, 513), (513, 1025)]
+    assert all(r[3] == 10250 and abs(r[4] - 2.0) < 1e-9 for r in res)     # SUM of frames, MAX of elapsed
