@@ -11,11 +11,13 @@ LIB_PATH = os.environ.get("DSENH_LIB", os.path.join(_HERE, "libdsenh.so"))   # D
 
 DS_OK = 0
 ALGO_FIXED, ALGO_ADAPTIVE, ALGO_GSC = 0, 1, 2
+ALGO_TRANSFORM, ALGO_MCRA, ALGO_MCMCRA, ALGO_OMLSA, ALGO_SUBLMS, ALGO_SUBRLS = 3, 4, 5, 6, 7, 8
+MEM_HOST, MEM_DEVICE = 0, 1
 METHOD_SRC, METHOD_DS, METHOD_MVDR, METHOD_TFGSC = 0, 1, 2, 3
 LAYOUT_SAMPLES_CHANNELS, LAYOUT_CHANNELS_SAMPLES = 0, 1
 PARAM_METHOD, PARAM_MCRA_L, PARAM_ALPHA_Y, PARAM_ALPHA_V, PARAM_DIAG, PARAM_GATE, PARAM_MU = 1, 2, 3, 4, 5, 6, 7
 (FIELD_RVV, FIELD_RYY, FIELD_MCRA_S, FIELD_MCRA_SMIN, FIELD_MCRA_STMP, FIELD_MCRA_P, FIELD_MCRA_LAMBDA_D,
- FIELD_PHI_YY, FIELD_PHI_VV, FIELD_G_AIC, FIELD_STFT_TAIL, FIELD_OLA_TAIL, FIELD_COUNTERS) = range(1, 14)
+ FIELD_PHI_YY, FIELD_PHI_VV, FIELD_G_AIC, FIELD_STFT_TAIL, FIELD_OLA_TAIL, FIELD_COUNTERS, FIELD_OP_STATE) = range(1, 15)
 
 
 class ds_config(ctypes.Structure):
@@ -25,6 +27,8 @@ class ds_config(ctypes.Structure):
         ("track_ryy", ctypes.c_int32), ("mcra_L", ctypes.c_int32), ("device", ctypes.c_int32),
         ("alpha_y", ctypes.c_float), ("alpha_v", ctypes.c_float), ("diag", ctypes.c_float),
         ("gate", ctypes.c_float), ("mu", ctypes.c_float),
+        ("filter_len", ctypes.c_int32), ("no_norm", ctypes.c_int32), ("filt_mu", ctypes.c_float),
+        ("filt_alpha", ctypes.c_float), ("rls_lambda", ctypes.c_float),
     ]
 
 
@@ -40,7 +44,8 @@ _lib = None
 EXPORTS = [
     "ds_version", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
     "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_device",
-    "ds_process_device_seq", "ds_synchronize",
+    "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcmcra_estimate", "ds_omlsa_estimate",
+    "ds_sublms_update", "ds_subrls_update", "ds_synchronize",
     "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_export_state",
     "ds_import_state",
 ]
@@ -82,6 +87,12 @@ def load():
     lib.ds_process_device.argtypes = [vp, vp, ci, cll, cll, ci, vp, cll, ci, ci, vp]
     lib.ds_process_device_seq.restype = ci
     lib.ds_process_device_seq.argtypes = [vp, vp, ci, cll, cll, cll, ci, ci, vp, cll, cll, ci, ci, vp, ci]
+    for name, args in (("ds_stft", [vp, vp, ci, ci, vp, ci]), ("ds_istft", [vp, vp, ci, ci, vp, ci]),
+                       ("ds_mcra_estimate", [vp, vp, ci, ci, vp, ci]), ("ds_mcmcra_estimate", [vp, vp, ci, vp, vp, ci]),
+                       ("ds_omlsa_estimate", [vp, vp, vp, ci, vp, vp, vp, ci]),
+                       ("ds_sublms_update", [vp, vp, vp, vp, ci, vp, ci]), ("ds_subrls_update", [vp, vp, vp, ci, vp, ci])):
+        getattr(lib, name).restype = ci
+        getattr(lib, name).argtypes = args
     lib.ds_synchronize.restype = ci
     lib.ds_synchronize.argtypes = [vp]
     lib.ds_timing_begin.restype = ci

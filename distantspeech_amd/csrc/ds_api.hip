@@ -11,6 +11,7 @@
 
 #include "../../include/dsenh.h"
 #include "ds_kernels.hpp"
+#include "ds_ops.hpp"
 #include "ds_tables.hpp"
 
 using ds::cf;
@@ -34,6 +35,16 @@ struct ds_handle {
     int steer_per_utt;
     bool steer_set;
     // staging for host-pointer calls
+    // frame-level objects (DS_ALGO_TRANSFORM .. DS_ALGO_SUBRLS)
+    KernelInfo ki_istft;
+    int op;                     // ds::OP_* or -1
+    float* opst;                // operator state [B][NF][KP]
+    int NF;
+    int op_frm, op_ell, op_first;   // uniform counters of the operator handle
+    int filter_len, norm;
+    float filt_mu, filt_alpha, rls_lambda;
+    float* dev_buf[7];          // staging for host-pointer frame-level calls (3 in, 1 scratch, 3 out)
+    size_t dev_buf_bytes[7];
     // cached hipGraph of a ds_process_device_seq() sequence
     hipGraphExec_t graph_exec;
     long long graph_key[16];
@@ -67,7 +78,11 @@ int fail(ds_handle* h, int code, const std::string& msg) {
 
 size_t bins_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * h->NP * h->KP * sizeof(ds::vec4); }
 size_t tail_in_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * h->cfg.n_mics * h->cfg.hop * sizeof(float); }
-size_t tail_out_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * h->cfg.hop * sizeof(float); }
+size_t tail_out_bytes(const ds_handle* h) {
+    const size_t ch = h->cfg.algo == DS_ALGO_TRANSFORM ? (size_t)h->cfg.n_mics : 1;   // Transform keeps one OLA tail per channel
+    return (size_t)h->cfg.batch * ch * h->cfg.hop * sizeof(float);
+}
+size_t opst_bytes(const ds_handle* h) { return h->op >= 0 ? (size_t)h->cfg.batch * h->NF * h->KP * sizeof(float) : 0; }
 size_t counters_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * 4 * sizeof(int); }
 
 int set_device(ds_handle* h) {
@@ -83,6 +98,25 @@ int zero_state(ds_handle* h) {
     std::vector<int> c((size_t)h->cfg.batch * 4, 0);
     for (int b = 0; b < h->cfg.batch; ++b) c[(size_t)b * 4 + 1] = 1;
     DS_HIP(h, hipMemcpyAsync(h->counters, c.data(), counters_bytes(h), hipMemcpyHostToDevice, h->stream));
+    if (h->op >= 0) {
+        // operator state: zeros, except the rows the reference initialises to non-zero values
+        std::vector<float> st((size_t)h->cfg.batch * h->NF * h->KP, 0.0f);
+        auto fill_row = [&](int f, float v) {
+            for (int b = 0; b < h->cfg.batch; ++b)
+                for (int k = 0; k < h->KP; ++k) st[((size_t)b * h->NF + f) * h->KP + k] = v;
+        };
+        if (h->op == ds::OP_OMLSA) {                       // omlsa_multi.py:33-58: gamma, G_H1, G, xi_hat, q_hat = 1
+            const int o_s = 5 * h->cfg.n_mics + 1 + (h->cfg.n_mics - 1);
+            fill_row(o_s + 1, 1.0f); fill_row(o_s + 2, 1.0f); fill_row(o_s + 3, 1.0f); fill_row(o_s + 5, 1.0f); fill_row(o_s + 6, 1.0f);
+            fill_row(5 * h->cfg.n_mics, 1.0f);             // zeta_Y = 1
+        }
+        if (h->op == ds::OP_SUBRLS) {                      // SubbandRLS.py:40-42: P = I / 1e-3
+            const int N = h->filter_len;
+            for (int i = 0; i < N; ++i) fill_row(4 * N + 2 * (i * N + i), 1000.0f);
+        }
+        DS_HIP(h, hipMemcpyAsync(h->opst, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        h->op_frm = 0; h->op_ell = 1; h->op_first = 1;
+    }
     DS_HIP(h, hipStreamSynchronize(h->stream));
     return DS_OK;
 }
@@ -138,23 +172,50 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     if (cfg->struct_size != (int32_t)sizeof(ds_config)) return fail(nullptr, DS_EINVAL, "ds_create: struct_size mismatch");
     *out = nullptr;
     if (cfg->batch <= 0) return fail(nullptr, DS_EINVAL, "ds_create: batch must be > 0");
-    if (cfg->hop * 2 != cfg->nfft)
+    if (cfg->algo <= DS_ALGO_TRANSFORM && cfg->hop * 2 != cfg->nfft)
         return fail(nullptr, DS_EUNSUPPORTED, "ds_create: only hop == nfft/2 is supported");
     KernelInfo ki = {nullptr, 0, 0, 0};
+    KernelInfo ki_istft = {nullptr, 0, 0, 0};
+    int op = -1, NF = 0;
+    const int KPo = (cfg->nfft / 2 + 1 + 3) & ~3;
+    const int flen = cfg->filter_len > 0 ? cfg->filter_len : 2;
     switch (cfg->algo) {
         case DS_ALGO_FIXED: ki = ds::lookup_fixed(cfg->nfft, cfg->n_mics); break;
         case DS_ALGO_ADAPTIVE:
             ki = cfg->track_ryy ? ds::lookup_adaptive_ryy(cfg->nfft, cfg->n_mics) : ds::lookup_adaptive_noryy(cfg->nfft, cfg->n_mics);
             break;
         case DS_ALGO_GSC: ki = ds::lookup_gsc(cfg->nfft, cfg->n_mics); break;
+        case DS_ALGO_TRANSFORM:
+            ki = ds::lookup_stft(cfg->nfft, cfg->n_mics);
+            ki_istft = ds::lookup_istft(cfg->nfft, cfg->n_mics);
+            break;
+        case DS_ALGO_MCRA: op = ds::OP_MCRA; NF = 5; break;
+        case DS_ALGO_MCMCRA:
+            if (cfg->n_mics == 2 || cfg->n_mics == 4 || cfg->n_mics == 6 || cfg->n_mics == 8) {
+                op = ds::OP_MCMCRA; NF = cfg->n_mics * (cfg->n_mics + 1) + 4;
+            }
+            break;
+        case DS_ALGO_OMLSA:
+            if (cfg->n_mics >= 2 && cfg->n_mics <= 16) { op = ds::OP_OMLSA; NF = ds::omlsa_nf(cfg->n_mics); }
+            break;
+        case DS_ALGO_SUBLMS:
+            if (cfg->n_mics >= 1 && cfg->n_mics <= 16 && flen <= 8) { op = ds::OP_SUBLMS; NF = ds::sublms_nf(flen, cfg->n_mics); }
+            break;
+        case DS_ALGO_SUBRLS:
+            if (flen <= ds::RLS_NMAX) { op = ds::OP_SUBRLS; NF = ds::subrls_nf(flen); }
+            break;
         default: return fail(nullptr, DS_EINVAL, "ds_create: unknown algo");
     }
-    if (!ki.launch) {
-        char buf[160];
-        snprintf(buf, sizeof buf, "ds_create: no kernel for algo=%d nfft=%d n_mics=%d (nfft in {256,512,1024}, n_mics in {2,4,6,8})",
+    if (op >= 0) {
+        if (cfg->nfft < 4 || (cfg->nfft & 1)) return fail(nullptr, DS_EUNSUPPORTED, "ds_create: nfft must be even");
+        ki.launch = nullptr; ki.NP = 0; ki.KP = KPo; ki.NT = 256;
+    } else if (!ki.launch) {
+        char buf[200];
+        snprintf(buf, sizeof buf, "ds_create: no kernel for algo=%d nfft=%d n_mics=%d (nfft in {256,512,1024}, n_mics in {2,4,6,8}; Transform also n_mics=1)",
                  cfg->algo, cfg->nfft, cfg->n_mics);
         return fail(nullptr, DS_EUNSUPPORTED, buf);
     }
+    if (cfg->algo >= DS_ALGO_MCRA && op < 0) return fail(nullptr, DS_EUNSUPPORTED, "ds_create: unsupported n_mics / filter_len for this frame-level object");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, DS_EHIP, "ds_create: no HIP device visible (libdsenh has no CPU path)");
@@ -171,6 +232,13 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->x_stage_elems = h->y_stage_elems = 0;
     h->steer_per_utt = 0; h->steer_set = false;
     h->graph_exec = nullptr; h->graph_valid = false;
+    h->ki_istft = ki_istft; h->op = op; h->opst = nullptr; h->NF = NF;
+    h->op_frm = 0; h->op_ell = 1; h->op_first = 1;
+    h->filter_len = flen; h->norm = cfg->no_norm ? 0 : 1;
+    h->filt_mu = cfg->filt_mu > 0 ? cfg->filt_mu : (cfg->algo == DS_ALGO_SUBRLS ? 0.5f : 0.1f);
+    h->filt_alpha = cfg->filt_alpha > 0 ? cfg->filt_alpha : 0.9f;
+    h->rls_lambda = cfg->rls_lambda > 0 ? cfg->rls_lambda : 0.998f;
+    for (int i = 0; i < 7; ++i) { h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0; }
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
     h->alpha_y = cfg->alpha_y > 0 ? cfg->alpha_y : 0.8f;
@@ -200,6 +268,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     DS_CRE(hipMalloc((void**)&h->tail_in, tail_in_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->tail_out, tail_out_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->counters, counters_bytes(h)));
+    if (h->op >= 0) DS_CRE(hipMalloc((void**)&h->opst, (size_t)cfg->batch * h->NF * h->KP * sizeof(float)));
     const int N = cfg->nfft, NC = N / 2;
     DS_CRE(hipMalloc((void**)&h->steer, (size_t)h->K * cfg->n_mics * sizeof(cf)));
     {
@@ -221,7 +290,8 @@ int ds_destroy(ds_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->bins); (void)hipFree(h->tail_in); (void)hipFree(h->tail_out); (void)hipFree(h->counters);
     (void)hipFree(h->tables); (void)hipFree(h->steer);
-    (void)hipFree(h->x_stage); (void)hipFree(h->y_stage);
+    (void)hipFree(h->x_stage); (void)hipFree(h->y_stage); (void)hipFree(h->opst);
+    for (int i = 0; i < 7; ++i) (void)hipFree(h->dev_buf[i]);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -288,6 +358,7 @@ int ds_set_param_f(ds_handle* h, int id, float value) {
 int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
                       int n_samples, float* y_dev, long long y_batch_stride, int first, int count, void* stream) {
     if (!h || !x_dev || !y_dev) return fail(h, DS_EINVAL, "ds_process_device: NULL argument");
+    if (h->cfg.algo > DS_ALGO_GSC) return fail(h, DS_ESTATE, "ds_process_device: this handle is a frame-level object; use ds_stft / ds_*_estimate / ds_sub*_update");
     if (!h->steer_set) return fail(h, DS_ESTATE, "ds_process_device: call ds_set_steering first");
     if (n_samples < 0 || n_samples % h->cfg.hop != 0)
         return fail(h, DS_ESHAPE, "ds_process_device: n_samples must be a multiple of hop");
@@ -398,6 +469,159 @@ int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y
     return DS_OK;
 }
 
+// ---- frame-level entry points ---------------------------------------------------------------------
+namespace {
+
+// make sure staging slot `i` holds at least `bytes`
+int stage_reserve(ds_handle* h, int i, size_t bytes) {
+    if (bytes <= h->dev_buf_bytes[i]) return DS_OK;
+    DS_HIP(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(h->dev_buf[i]); h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0;
+    DS_HIP(h, hipMalloc((void**)&h->dev_buf[i], bytes));
+    h->dev_buf_bytes[i] = bytes;
+    return DS_OK;
+}
+
+struct IoSpec { const float* in[3]; size_t in_bytes[3]; float* out[3]; size_t out_bytes[3]; };
+
+// resolve host/device pointers: for DS_MEM_HOST copy inputs to staging and return device aliases
+int io_begin(ds_handle* h, int mem, const IoSpec& io, const float* din[3], float* dout[3]) {
+    for (int i = 0; i < 3; ++i) {
+        din[i] = io.in[i]; dout[i] = io.out[i];
+        if (mem == DS_MEM_HOST) {
+            if (io.in[i]) {
+                int rc = stage_reserve(h, i, io.in_bytes[i]); if (rc) return rc;
+                DS_HIP(h, hipMemcpyAsync(h->dev_buf[i], io.in[i], io.in_bytes[i], hipMemcpyHostToDevice, h->stream));
+                din[i] = h->dev_buf[i];
+            }
+            if (io.out[i]) {
+                int rc = stage_reserve(h, 4 + i, io.out_bytes[i]); if (rc) return rc;
+                dout[i] = h->dev_buf[4 + i];
+            }
+        }
+    }
+    return DS_OK;
+}
+
+int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[3]) {
+    if (mem == DS_MEM_HOST) {
+        for (int i = 0; i < 3; ++i)
+            if (io.out[i]) DS_HIP(h, hipMemcpyAsync(io.out[i], dout[i], io.out_bytes[i], hipMemcpyDeviceToHost, h->stream));
+        DS_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return DS_OK;
+}
+
+int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int mem, const IoSpec& io, int is_complex, int has_p) {
+    if (!h) return DS_EINVAL;
+    if (h->cfg.algo != want_algo) return fail(h, DS_ESTATE, std::string(who) + ": handle was created for a different algo");
+    if (n_frames < 0) return fail(h, DS_ESHAPE, std::string(who) + ": n_frames < 0");
+    if (n_frames == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const float* din[3]; float* dout[3];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames;
+    p.st = h->opst; p.NF = h->NF;
+    p.in0 = din[0]; p.in1 = din[1]; p.in2 = din[2];
+    p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2];
+    p.M = h->cfg.n_mics; p.N = h->filter_len;
+    p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = h->mcra_L; p.first_frame = h->op_first;
+    p.in_complex = is_complex; p.has_p = has_p; p.norm = h->norm;
+    p.mu = h->filt_mu; p.alpha = h->filt_alpha; p.reg = 1e-4f; p.lam = h->rls_lambda;
+    DS_HIP(h, ds::launch_binop(h->op, p, h->stream));
+    // advance the uniform counters exactly like the kernel did (mcra.py:52-56,72-74)
+    for (int t = 0; t < n_frames; ++t) {
+        if (h->op_frm != 0 && h->op_ell % h->mcra_L == 0) h->op_ell = 0;
+        h->op_frm += 1; h->op_ell += 1;
+    }
+    h->op_first = 0;
+    return io_end(h, mem, io, dout);
+}
+
+}  // namespace
+
+int ds_stft(ds_handle* h, const float* x, int layout, int n_samples, float* Y, int mem) {
+    if (!h || !x || !Y) return fail(h, DS_EINVAL, "ds_stft: NULL argument");
+    if (h->cfg.algo != DS_ALGO_TRANSFORM) return fail(h, DS_ESTATE, "ds_stft: handle is not a DS_ALGO_TRANSFORM object");
+    if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_stft: n_samples must be a multiple of hop");
+    if (layout != DS_LAYOUT_SAMPLES_CHANNELS && layout != DS_LAYOUT_CHANNELS_SAMPLES) return fail(h, DS_EINVAL, "ds_stft: unknown layout");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t B = h->cfg.batch, M = h->cfg.n_mics, T = n_samples / h->cfg.hop;
+    IoSpec io = {{x, nullptr, nullptr}, {B * M * (size_t)n_samples * 4, 0, 0}, {Y, nullptr, nullptr}, {B * T * h->K * M * 8, 0, 0}};
+    const float* din[3]; float* dout[3];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    Params p;
+    fill_params(h, p);
+    p.x = din[0]; p.y = dout[0];
+    p.x_batch_stride = (long long)(M * (size_t)n_samples);
+    p.y_batch_stride = (long long)(T * h->K * M * 2);
+    if (layout == DS_LAYOUT_CHANNELS_SAMPLES) { p.x_sample_stride = 1; p.x_chan_stride = n_samples; }
+    else { p.x_sample_stride = (long long)M; p.x_chan_stride = 1; }
+    p.T = (int)T; p.batch0 = 0;
+    DS_HIP(h, h->ki.launch(p, h->cfg.batch, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+int ds_istft(ds_handle* h, const float* Y, int n_frames, int n_channels, float* y, int mem) {
+    if (!h || !Y || !y) return fail(h, DS_EINVAL, "ds_istft: NULL argument");
+    if (h->cfg.algo != DS_ALGO_TRANSFORM) return fail(h, DS_ESTATE, "ds_istft: handle is not a DS_ALGO_TRANSFORM object");
+    if (n_channels < 1 || n_channels > h->cfg.n_mics)                       // transform.py:466
+        return fail(h, DS_ESHAPE, "ds_istft: n_channels must be in 1..channel");
+    if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_istft: n_frames < 0");
+    if (n_frames == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t B = h->cfg.batch, C = n_channels, T = n_frames;
+    IoSpec io = {{Y, nullptr, nullptr}, {B * T * h->K * C * 8, 0, 0}, {y, nullptr, nullptr}, {B * T * h->cfg.hop * C * 4, 0, 0}};
+    const float* din[3]; float* dout[3];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    Params p;
+    fill_params(h, p);
+    p.x = din[0]; p.y = dout[0];
+    p.x_batch_stride = (long long)(T * h->K * C * 2);
+    p.y_batch_stride = (long long)(T * h->cfg.hop * C);
+    p.T = (int)T; p.batch0 = 0; p.method = n_channels;
+    DS_HIP(h, h->ki_istft.launch(p, h->cfg.batch, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+int ds_mcra_estimate(ds_handle* h, const float* Y, int is_complex, int n_frames, float* lambda_d, int mem) {
+    if (!h || !Y || !lambda_d) return fail(h, DS_EINVAL, "ds_mcra_estimate: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{Y, nullptr, nullptr}, {n * (is_complex ? 8 : 4), 0, 0}, {lambda_d, nullptr, nullptr}, {n * 4, 0, 0}};
+    return run_binop(h, DS_ALGO_MCRA, "ds_mcra_estimate", n_frames, mem, io, is_complex ? 1 : 0, 0);
+}
+
+int ds_mcmcra_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* G, int mem) {
+    if (!h || !y || !p || !G) return fail(h, DS_EINVAL, "ds_mcmcra_estimate: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{y, nullptr, nullptr}, {n * h->cfg.n_mics * 8, 0, 0}, {p, G, nullptr}, {n * 4, n * 4, 0}};
+    return run_binop(h, DS_ALGO_MCMCRA, "ds_mcmcra_estimate", n_frames, mem, io, 0, 0);
+}
+
+int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem) {
+    if (!h || !y || !u || !lambda_d || !G || !p) return fail(h, DS_EINVAL, "ds_omlsa_estimate: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{y, u, nullptr}, {n * 4, n * (h->cfg.n_mics - 1) * 4, 0}, {lambda_d, G, p}, {n * 4, n * 4, n * 4}};
+    return run_binop(h, DS_ALGO_OMLSA, "ds_omlsa_estimate", n_frames, mem, io, 0, 0);
+}
+
+int ds_sublms_update(ds_handle* h, const float* x, const float* d, const float* p, int n_frames, float* err, int mem) {
+    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_sublms_update: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{x, d, p}, {n * h->cfg.n_mics * 8, n * 8, p ? n * 4 : 0}, {err, nullptr, nullptr}, {n * 8, 0, 0}};
+    return run_binop(h, DS_ALGO_SUBLMS, "ds_sublms_update", n_frames, mem, io, 0, p ? 1 : 0);
+}
+
+int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames, float* err, int mem) {
+    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_subrls_update: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{x, d, nullptr}, {n * 8, n * 8, 0}, {err, nullptr, nullptr}, {n * 8, 0, 0}};
+    return run_binop(h, DS_ALGO_SUBRLS, "ds_subrls_update", n_frames, mem, io, 0, 0);
+}
+
 int ds_synchronize(ds_handle* h) {
     if (!h) return DS_EINVAL;
     int rc = set_device(h);
@@ -438,6 +662,7 @@ size_t ds_field_bytes(const ds_handle* h, int field) {
         case DS_FIELD_STFT_TAIL: return tail_in_bytes(h);
         case DS_FIELD_OLA_TAIL: return tail_out_bytes(h);
         case DS_FIELD_COUNTERS: return counters_bytes(h);
+        case DS_FIELD_OP_STATE: return opst_bytes(h);
         default: return 0;
     }
 }
@@ -452,7 +677,15 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
     DS_HIP(h, hipStreamSynchronize(h->stream));
     if (field == DS_FIELD_STFT_TAIL) { DS_HIP(h, hipMemcpy(dst, h->tail_in, need, hipMemcpyDeviceToHost)); return DS_OK; }
     if (field == DS_FIELD_OLA_TAIL) { DS_HIP(h, hipMemcpy(dst, h->tail_out, need, hipMemcpyDeviceToHost)); return DS_OK; }
-    if (field == DS_FIELD_COUNTERS) { DS_HIP(h, hipMemcpy(dst, h->counters, need, hipMemcpyDeviceToHost)); return DS_OK; }
+    if (field == DS_FIELD_COUNTERS) {
+        DS_HIP(h, hipMemcpy(dst, h->counters, need, hipMemcpyDeviceToHost));
+        if (h->op >= 0) {                                 // operator handles keep uniform counters on the host
+            int* c = (int*)dst;
+            for (int b = 0; b < h->cfg.batch; ++b) { c[4 * b] = h->op_frm; c[4 * b + 1] = h->op_ell; c[4 * b + 2] = h->op_frm; c[4 * b + 3] = h->op_first; }
+        }
+        return DS_OK;
+    }
+    if (field == DS_FIELD_OP_STATE) { DS_HIP(h, hipMemcpy(dst, h->opst, need, hipMemcpyDeviceToHost)); return DS_OK; }
     // per-bin fields: pull the raw planes and unpack on the host
     std::vector<float> raw(bins_bytes(h) / sizeof(float));
     DS_HIP(h, hipMemcpy(raw.data(), h->bins, bins_bytes(h), hipMemcpyDeviceToHost));
@@ -511,7 +744,7 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
 
 size_t ds_state_bytes(const ds_handle* h) {
     if (!h) return 0;
-    return bins_bytes(h) + tail_in_bytes(h) + tail_out_bytes(h) + counters_bytes(h);
+    return bins_bytes(h) + tail_in_bytes(h) + tail_out_bytes(h) + counters_bytes(h) + opst_bytes(h) + 4 * sizeof(int);
 }
 
 int ds_export_state(ds_handle* h, void* dst, size_t bytes) {
@@ -525,7 +758,11 @@ int ds_export_state(ds_handle* h, void* dst, size_t bytes) {
     d += bins_bytes(h);
     DS_HIP(h, hipMemcpy(d, h->tail_in, tail_in_bytes(h), hipMemcpyDeviceToHost)); d += tail_in_bytes(h);
     DS_HIP(h, hipMemcpy(d, h->tail_out, tail_out_bytes(h), hipMemcpyDeviceToHost)); d += tail_out_bytes(h);
-    DS_HIP(h, hipMemcpy(d, h->counters, counters_bytes(h), hipMemcpyDeviceToHost));
+    DS_HIP(h, hipMemcpy(d, h->counters, counters_bytes(h), hipMemcpyDeviceToHost)); d += counters_bytes(h);
+    if (opst_bytes(h)) DS_HIP(h, hipMemcpy(d, h->opst, opst_bytes(h), hipMemcpyDeviceToHost));
+    d += opst_bytes(h);
+    const int uc[4] = {h->op_frm, h->op_ell, h->op_first, 0};
+    std::memcpy(d, uc, sizeof uc);
     return DS_OK;
 }
 
@@ -540,7 +777,12 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
     s += bins_bytes(h);
     DS_HIP(h, hipMemcpy(h->tail_in, s, tail_in_bytes(h), hipMemcpyHostToDevice)); s += tail_in_bytes(h);
     DS_HIP(h, hipMemcpy(h->tail_out, s, tail_out_bytes(h), hipMemcpyHostToDevice)); s += tail_out_bytes(h);
-    DS_HIP(h, hipMemcpy(h->counters, s, counters_bytes(h), hipMemcpyHostToDevice));
+    DS_HIP(h, hipMemcpy(h->counters, s, counters_bytes(h), hipMemcpyHostToDevice)); s += counters_bytes(h);
+    if (opst_bytes(h)) DS_HIP(h, hipMemcpy(h->opst, s, opst_bytes(h), hipMemcpyHostToDevice));
+    s += opst_bytes(h);
+    int uc[4];
+    std::memcpy(uc, s, sizeof uc);
+    h->op_frm = uc[0]; h->op_ell = uc[1]; h->op_first = uc[2];
     return DS_OK;
 }
 

@@ -187,8 +187,8 @@ template <int PAD> DS_HD int padi(int i) {
 }
 
 // in/out: [MCH][NCP].  FROM_X: read windowed real samples packed as (x[2n], x[2n+1]) from xbuf.
-template <int NFFT, int M, int MCH, int R, int SIGN, bool FROM_X, int PIN, int POUT, class ShT>
-DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, int old_half) {
+template <int NFFT, int M, int R, int SIGN, bool FROM_X, int PIN, int POUT, class ShT>
+DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, int old_half, int MCH) {
     constexpr int NC = NFFT / 2, NB = NC / R, HOP = NFFT / 2, NCP = ShT::NCP;
     for (int idx = tid; idx < MCH * NB; idx += nt) {
         const int ch = idx / NB, j = idx - ch * NB;
@@ -229,18 +229,17 @@ DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, in
 // MCRA (one bin) — mcra.py:27-77.  k: bin, K: half_bin.  st: S,Smin,Stmp,p,lambda_d.
 // frm_cnt / ell are the frame-level counters *before* this frame; `reset` = (ell % L == 0).
 // ---------------------------------------------------------------------------------------------
-DS_HD void mcra_bin(float* st, int k, int K, const float* pw, int frm_cnt, bool reset, int L) {
+DS_HD void mcra_bin(float* st, int k, int K, float Ykm1, float Yk, float Ykp1, int frm_cnt, bool reset, int L) {
     const float alpha_s = 0.8f, one_m_alpha_s = (float)(1.0 - 0.8), delta_s = 5.0f;
     const float alpha_p = 0.2f, one_m_alpha_p = (float)(1.0 - 0.2), alpha_d = 0.95f, one_m_alpha_d = (float)(1.0 - 0.95);
     const float p_max = 0.999f, p_min = 1e-3f;
     float S = st[0], Smin = st[1], Stmp = st[2], p = st[3], lam = st[4];
-    const float Yk = pw[k];
     if (frm_cnt == 0) {
         if (k < K - 1) { Smin = Yk; Stmp = Yk; lam = Yk; p = 0.0f; }                 // :38-41,68-69
     } else if (k == 0) {
         p = 0.0f;                                                                     // :43-45
     } else if (k < K - 1) {
-        const float Sf = fma_(pw[k + 1], 0.25f, fma_(Yk, 0.5f, pw[k - 1] * 0.25f));           // :46
+        const float Sf = fma_(Ykp1, 0.25f, fma_(Yk, 0.5f, Ykm1 * 0.25f));           // :46
         S = fma_(alpha_s, S, one_m_alpha_s * Sf);                                         // :47
         Smin = fminf_(Smin, S); Stmp = fminf_(Stmp, S);                               // :49-50
         if (reset) { Smin = fminf_(Stmp, S); Stmp = S; }                              // :52-56
@@ -432,14 +431,12 @@ template <int M> DS_HD float sym_get(const float* s, int i, int j) {
     return i <= j ? s[sym_index(i, j, M)] : s[sym_index(j, i, M)];
 }
 
-// McMcra.estimation for one bin (mc_mcra.py:179-224) + FD-GSC LMS (GSC.py:245-286).
+// McMcra.estimation for one bin (mc_mcra.py:179-224): state pyy/pvv = packed real-symmetric Phi_yy / Phi_vv.
+// Returns the speech presence probability p, the gain G and (for state read-back) xi, gamma.
 template <int M>
-DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, int spp_frm_cnt) {
-    typedef StateLayout<M, ALGO_GSC, false> SL;
+DS_HD void mcmcra_bin(float* pyy, float* pvv, const cf* Z, int k, int spp_frm_cnt, float& p_out, float& G_out,
+                      float& xi_out, float& gamma_out) {
     constexpr int NS = M * (M + 1) / 2;
-    float* pyy = st + SL::PYY;
-    float* pvv = st + SL::PVV;
-    float* ga = st + SL::GA;
     const float alpha = 0.92f, one_m_alpha = (float)(1.0 - 0.92);
     float yy[NS];
 #pragma unroll
@@ -550,6 +547,16 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
     float G = powf(gh1, pp) * powf(Gmin, 1.0f - pp);
     G = fmaxf_(fminf_(G, 1.0f), Gmin);
     if (k < 2) G = 0.0f;
+    p_out = pp; G_out = G; xi_out = xi; gamma_out = gam;
+}
+
+// GSC.process for one bin: McMcra SPP/gain (GSC.py:225) + FD-GSC with SPP-stepped LMS canceller (GSC.py:245-286).
+template <int M>
+DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, int spp_frm_cnt) {
+    typedef StateLayout<M, ALGO_GSC, false> SL;
+    float* ga = st + SL::GA;
+    float pp, G, xi, gam;
+    mcmcra_bin<M>(st + SL::PYY, st + SL::PVV, Z, k, spp_frm_cnt, pp, G, xi, gam);
     if (p.method == 0) return Z[0];                                                        // GSC.py:242-243
     // FD-GSC: W = a/(a^H a), U_i = conj(a_0) z_0 - conj(a_{i+1}) z_{i+1}                   GSC.py:219-222,261-266
     float aa = 0.0f;
@@ -641,7 +648,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         if constexpr (ALGO == ALGO_FIXED) {
             Yk = fixed_bin<M>(Z, a);
         } else if constexpr (ALGO == ALGO_ADAPTIVE) {
-            mcra_bin(st + SL::MC_S, k, K, sh.pw, frm_cnt, reset, p.mcra_L);
+            mcra_bin(st + SL::MC_S, k, K, sh.pw[k > 0 ? k - 1 : 0], sh.pw[k], sh.pw[k + 1], frm_cnt, reset, p.mcra_L);
             Yk = adaptive_bin<M, RYY>(st, Z, a, p);
         } else {
             Yk = gsc_bin<M>(st, Z, a, p, k, spp_cnt);
@@ -701,15 +708,15 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // ---- forward FFT: M packed real transforms -------------------------------------------
             cf* fa = &sh.fa[0][0];
             cf* fb = &sh.fb[0][0];
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half, M); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0, M); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0, M); });
             if (NC == 128) {
-                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 2, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0); });
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0, M); });
             } else {
-                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 4, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0); });
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0, M); });
                 if (NC == 512)
-                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, M, 2, -1, false, 0, 0>(tid, NT, sh, fb, fa, 256, 0); });
+                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, -1, false, 0, 0>(tid, NT, sh, fb, fa, 256, 0, M); });
             }
             const cf* F = FWD_FINAL_IS_FB ? fb : fa;
             // ---- split packed spectrum -> Z[k][m]; publish |Z_0|^2 for the MCRA stencil ----------
@@ -761,15 +768,15 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tb.tw[k]));
                 fa[k] = mk(E.x - O.y, E.y + O.x);                       // E + j O
             });
-            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 4, +1, false, 0, 1>(tid - INV_T0, NT, sh, fa, fb, 1, 0); });
-            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 4, +1, false, 1, 2>(tid - INV_T0, NT, sh, fb, fa, 4, 0); });
-            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 4, +1, false, 2, 0>(tid - INV_T0, NT, sh, fa, fb, 16, 0); });
+            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 0, 1>(tid - INV_T0, NT, sh, fa, fb, 1, 0, 1); });
+            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 1, 2>(tid - INV_T0, NT, sh, fb, fa, 4, 0, 1); });
+            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 2, 0>(tid - INV_T0, NT, sh, fa, fb, 16, 0, 1); });
             if (NC == 128) {
-                ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 2, +1, false, 0, 0>(tid - INV_T0, NT, sh, fb, fa, 64, 0); });
+                ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid - INV_T0, NT, sh, fb, fa, 64, 0, 1); });
             } else {
-                ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 4, +1, false, 0, 0>(tid - INV_T0, NT, sh, fb, fa, 64, 0); });
+                ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 0, 0>(tid - INV_T0, NT, sh, fb, fa, 64, 0, 1); });
                 if (NC == 512)
-                    ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 1, 2, +1, false, 0, 0>(tid - INV_T0, NT, sh, fa, fb, 256, 0); });
+                    ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid - INV_T0, NT, sh, fa, fb, 256, 0, 1); });
             }
             const cf* Zi = INV_FINAL_IS_FA ? fa : fb;
             // ---- window, overlap-add, emit hop t ---------------------------------------------------
@@ -810,6 +817,168 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 bins[tid * KP + NC] = v;
             }
             if (tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }
+        });
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Stand-alone streaming STFT / ISTFT (Transform.stft / Transform.istft, transform/transform.py:430-481)
+// for callers that drive the frame-level operators themselves.  Same FFT machinery as the fused
+// engine; one workgroup per utterance.
+//   STFT : x [B][..layout..]  ->  Y complex [B][T][K][M]   (p.y, p.y_batch_stride in floats)
+//   ISTFT: Y complex [B][T][K][C] (p.x, p.x_batch_stride in floats) -> y [B][T*hop][C]   (C = p.method <= M)
+// ---------------------------------------------------------------------------------------------
+template <int NFFT, int M> struct StftEngine {
+    typedef Engine<NFFT, M, ALGO_FIXED, false> EB;
+    static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2, NT = NC;
+    typedef typename EB::Sh Sh;
+    typedef typename EB::Rg Rg;
+
+    template <class Exec> static DS_HD void run(Exec& ex, const Params& p, int blk, Sh& sh) {
+        const int b = p.batch0 + blk;
+        const long long xb = (long long)blk * p.x_batch_stride;
+        float* tin = p.tail_in + (long long)b * M * HOP;
+        cf* Yout = reinterpret_cast<cf*>(p.y + (long long)blk * p.y_batch_stride);
+        int old_half = 0;
+        ex.phase([&](int tid, Rg& r) {
+            vec4* tb4 = reinterpret_cast<vec4*>(&sh.tb);
+            for (int i = tid; i < Tables<NFFT>::NV4; i += NT) tb4[i] = p.tables[i];
+            const vec4* tin4 = reinterpret_cast<const vec4*>(tin);
+            for (int i = tid; i < M * HOP / 4; i += NT) {
+                const int m = i / (HOP / 4), q = i - m * (HOP / 4);
+                *reinterpret_cast<vec4*>(&sh.xbuf[m][4 * q]) = tin4[i];
+            }
+            EB::prefetch(p, xb, 0, tid, r);
+        });
+        for (int t = 0; t < p.T; ++t) {
+            const int new_half = old_half ^ 1;
+            ex.phase([&](int tid, Rg& r) {
+                EB::commit(p, sh, new_half, tid, r);
+                if (t + 1 < p.T) EB::prefetch(p, xb, t + 1, tid, r);
+            });
+            cf* fa = &sh.fa[0][0];
+            cf* fb = &sh.fb[0][0];
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half, M); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0, M); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0, M); });
+            if (NC == 128) {
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0, M); });
+            } else {
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0, M); });
+                if (NC == 512)
+                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, -1, false, 0, 0>(tid, NT, sh, fb, fa, 256, 0, M); });
+            }
+            const cf* F = EB::FWD_FINAL_IS_FB ? fb : fa;
+            ex.phase([&](int tid, Rg&) {
+                const int k = tid, k2 = (NC - k) & (NC - 1);
+                const cf w = sh.tb.tw[k];
+                cf* dst = Yout + ((long long)t * K + k) * M;
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const cf A = F[m * Sh::NCP + k], Bc = cconj(F[m * Sh::NCP + k2]);
+                    const cf E = cscale(cadd(A, Bc), 0.5f);
+                    const cf D = csub(A, Bc);
+                    const cf O = mk(0.5f * D.y, -0.5f * D.x);
+                    cf Z = cfma(E, w, O);
+                    if (k == 0) Z.y = 0.0f;
+                    dst[m] = Z;
+                }
+                if (k == 0) {                                  // Nyquist bin
+                    cf* dn = Yout + ((long long)t * K + NC) * M;
+#pragma unroll
+                    for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; dn[m] = mk(F0.x - F0.y, 0.0f); }
+                }
+            });
+            old_half = new_half;
+        }
+        ex.phase([&](int tid, Rg&) {
+            vec4* tin4 = reinterpret_cast<vec4*>(tin);
+            for (int i = tid; i < M * HOP / 4; i += NT) {
+                const int m = i / (HOP / 4), q = i - m * (HOP / 4);
+                tin4[i] = *reinterpret_cast<const vec4*>(&sh.xbuf[m][old_half * HOP + 4 * q]);
+            }
+        });
+    }
+};
+
+template <int NFFT, int M> struct SharedIstft {
+    static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2;
+    static constexpr int NCP = NC + NC / 4;
+    cf fa[M][NCP];
+    cf fb[M][NCP];
+    alignas(16) Tables<NFFT> tb;
+    alignas(16) float tail[M][HOP];
+};
+
+template <int NFFT, int M> struct IstftEngine {
+    static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2, NT = NC;
+    typedef SharedIstft<NFFT, M> Sh;
+    struct Rg { int unused; };
+
+    template <class Exec> static DS_HD void run(Exec& ex, const Params& p, int blk, Sh& sh) {
+        const int b = p.batch0 + blk;
+        const int C = p.method;                                // channels in this call (<= M)
+        const cf* Yin = reinterpret_cast<const cf*>(p.x + (long long)blk * p.x_batch_stride);
+        float* yout = p.y + (long long)blk * p.y_batch_stride;
+        float* tout = p.tail_out + (long long)b * M * HOP;
+        ex.phase([&](int tid, Rg&) {
+            vec4* tb4 = reinterpret_cast<vec4*>(&sh.tb);
+            for (int i = tid; i < Tables<NFFT>::NV4; i += NT) tb4[i] = p.tables[i];
+            const vec4* t4 = reinterpret_cast<const vec4*>(tout);
+            for (int i = tid; i < M * HOP / 4; i += NT) {
+                const int m = i / (HOP / 4), q = i - m * (HOP / 4);
+                *reinterpret_cast<vec4*>(&sh.tail[m][4 * q]) = t4[i];
+            }
+        });
+        cf* fa = &sh.fa[0][0];
+        cf* fb = &sh.fb[0][0];
+        for (int t = 0; t < p.T; ++t) {
+            ex.phase([&](int tid, Rg&) {
+                const int k = tid;
+                const cf* Yt = Yin + (long long)t * K * C;
+                const cf w = cconj(sh.tb.tw[k]);
+                for (int c = 0; c < C; ++c) {
+                    cf A = Yt[(long long)k * C + c], B = Yt[(long long)(NC - k) * C + c];
+                    if (k == 0) { A.y = 0.0f; B.y = 0.0f; }     // irfft ignores Im Y[0], Im Y[N/2]
+                    const cf Bc = cconj(B);
+                    const cf E = cscale(cadd(A, Bc), 0.5f);
+                    const cf O = cmul(cscale(csub(A, Bc), 0.5f), w);
+                    fa[c * Sh::NCP + k] = mk(E.x - O.y, E.y + O.x);
+                }
+            });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 0, 1>(tid, NT, sh, fa, fb, 1, 0, C); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 1, 2>(tid, NT, sh, fb, fa, 4, 0, C); });
+            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 2, 0>(tid, NT, sh, fa, fb, 16, 0, C); });
+            if (NC == 128) {
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid, NT, sh, fb, fa, 64, 0, C); });
+            } else {
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 0, 0>(tid, NT, sh, fb, fa, 64, 0, C); });
+                if (NC == 512)
+                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid, NT, sh, fa, fb, 256, 0, C); });
+            }
+            const cf* Zi = (NC != 512) ? fa : fb;
+            ex.phase([&](int tid, Rg&) {
+                if (tid < NC / 2) {
+                    const int i = tid;
+                    const float sc = 1.0f / (float)NC;
+                    for (int c = 0; c < C; ++c) {
+                        const cf z1 = Zi[c * Sh::NCP + i], z2 = Zi[c * Sh::NCP + i + NC / 2];
+                        const float y0 = sh.tb.win[2 * i] * (z1.x * sc), y1 = sh.tb.win[2 * i + 1] * (z1.y * sc);
+                        const float o0 = (y0 + sh.tail[c][2 * i]) * p.out_scale, o1 = (y1 + sh.tail[c][2 * i + 1]) * p.out_scale;
+                        sh.tail[c][2 * i] = sh.tb.win[HOP + 2 * i] * (z2.x * sc);
+                        sh.tail[c][2 * i + 1] = sh.tb.win[HOP + 2 * i + 1] * (z2.y * sc);
+                        yout[((long long)t * HOP + 2 * i) * C + c] = o0;
+                        yout[((long long)t * HOP + 2 * i + 1) * C + c] = o1;
+                    }
+                }
+            });
+        }
+        ex.phase([&](int tid, Rg&) {
+            vec4* t4 = reinterpret_cast<vec4*>(tout);
+            for (int i = tid; i < M * HOP / 4; i += NT) {
+                const int m = i / (HOP / 4), q = i - m * (HOP / 4);
+                t4[i] = *reinterpret_cast<const vec4*>(&sh.tail[m][4 * q]);
+            }
         });
     }
 };

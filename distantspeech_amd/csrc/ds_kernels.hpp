@@ -20,6 +20,10 @@ KernelInfo lookup_fixed(int nfft, int M);
 KernelInfo lookup_adaptive_noryy(int nfft, int M);
 KernelInfo lookup_adaptive_ryy(int nfft, int M);
 KernelInfo lookup_gsc(int nfft, int M);
+KernelInfo lookup_stft(int nfft, int M);      // ds_kernels_ops.hip
+KernelInfo lookup_istft(int nfft, int M);
+struct OpParams;
+hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream);
 
 #if defined(__HIPCC__)
 template <class Rg> struct HipExec {

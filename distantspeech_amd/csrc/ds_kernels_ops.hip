@@ -1,0 +1,65 @@
+// ds_kernels_ops.hip — stand-alone STFT / ISTFT kernels and the frame-level (utterance, bin) operator
+// kernel (MCRA, McMcra, NsOmlsaMulti, subband LMS / RLS) for gfx950.
+#include "ds_kernels.hpp"
+#include "ds_ops.hpp"
+
+namespace ds {
+
+template <int NFFT, int M> __global__ void __launch_bounds__(NFFT / 2) ds_stft_kernel(Params p) {
+    typedef StftEngine<NFFT, M> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+
+template <int NFFT, int M> __global__ void __launch_bounds__(NFFT / 2) ds_istft_kernel(Params p) {
+    typedef IstftEngine<NFFT, M> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+
+template <int NFFT, int M> hipError_t launch_stft(const Params& p, int nblocks, hipStream_t stream) {
+    hipLaunchKernelGGL((ds_stft_kernel<NFFT, M>), dim3(nblocks), dim3(NFFT / 2), 0, stream, p);
+    return hipGetLastError();
+}
+template <int NFFT, int M> hipError_t launch_istft(const Params& p, int nblocks, hipStream_t stream) {
+    hipLaunchKernelGGL((ds_istft_kernel<NFFT, M>), dim3(nblocks), dim3(NFFT / 2), 0, stream, p);
+    return hipGetLastError();
+}
+
+#define DS_FOR_EACH_TSHAPE(X) \
+    X(256, 1) X(256, 2) X(256, 4) X(256, 6) X(256, 8) \
+    X(512, 1) X(512, 2) X(512, 4) X(512, 6) X(512, 8) \
+    X(1024, 1) X(1024, 2) X(1024, 4) X(1024, 6) X(1024, 8)
+
+KernelInfo lookup_stft(int nfft, int M) {
+#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {&launch_stft<NFFT_, M_>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
+    DS_FOR_EACH_TSHAPE(X)
+#undef X
+    KernelInfo none = {nullptr, 0, 0, 0};
+    return none;
+}
+KernelInfo lookup_istft(int nfft, int M) {
+#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {&launch_istft<NFFT_, M_>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
+    DS_FOR_EACH_TSHAPE(X)
+#undef X
+    KernelInfo none = {nullptr, 0, 0, 0};
+    return none;
+}
+
+__global__ void __launch_bounds__(256) ds_binop_kernel(int op, OpParams p) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(i / p.KP), k = (int)(i - (long long)b * p.KP);
+    if (b >= p.B || k >= p.K) return;
+    run_op(op, p, b, k);
+}
+
+hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream) {
+    const long long total = (long long)p.B * p.KP;
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(ds_binop_kernel, dim3(blocks), dim3(256), 0, stream, op, p);
+    return hipGetLastError();
+}
+
+}  // namespace ds

@@ -1,0 +1,297 @@
+// ds_ops.hpp — frame-level operators of the hot path as stand-alone (utterance, bin) programs:
+// the L2 objects the reference lets callers drive frame by frame:
+//   NoiseEstimationMCRA.estimation   noise_estimation/mcra.py:27-77
+//   McMcra.estimation                noise_estimation/mc_mcra.py:179-224
+//   NsOmlsaMulti.estimation          noise_estimation/omlsa_multi.py:73-156
+//   SubbandLMS / SubbandLmsMc.update adaptivefilter/SubbandLMS.py:28-84, SubbandLmsMc.py:144-191
+//   SubbandRLS.update                adaptivefilter/SubbandRLS.py:44-71
+// One GPU thread owns one (utterance, bin) and walks the T frames of the call; state is a
+// structure-of-arrays [B][NF][KP] of floats so that lane k touches address k: coalesced.
+// Written single-source (DS_HD) so tests/emul can run the same code serially on the CPU.
+#pragma once
+#include "ds_core.hpp"
+
+namespace ds {
+
+enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4 };
+
+struct OpParams {
+    int B, K, KP, T;          // utterances, bins, padded plane length, frames in this call
+    float* st;                // state [B][NF][KP]
+    int NF;
+    const float* in0;         // op-specific inputs (device)
+    const float* in1;
+    const float* in2;
+    float* out0;              // op-specific outputs (device)
+    float* out1;
+    float* out2;
+    int M;                    // channels: mics (McMcra), beam + references (OMLSA), filter channels (subband LMS)
+    int N;                    // filter taps
+    int frm_cnt, ell, L;      // MCRA counters before the first frame of the call (uniform over the batch)
+    int first_frame;          // OMLSA: 1 until the first estimation() has run
+    int in_complex;           // MCRA: input is complex, take |.|^2 (mcra.py:29-30)
+    int has_p;                // subband LMS: per-bin update probability given
+    int norm;                 // subband LMS: power normalisation on (SubbandAF.py:18)
+    float mu, alpha, reg, lam;   // step, power smoothing, regulariser (update(alpha=1e-4)), RLS forgetting factor
+};
+
+DS_HD float& st_at(const OpParams& p, int b, int f, int k) { return p.st[((long long)b * p.NF + f) * p.KP + k]; }
+
+// advance the uniform MCRA counters by one frame (mcra.py:52-56,72-74); returns `reset` for this frame
+DS_HD bool mcra_tick(int& frm, int& ell, int L) {
+    const bool reset = (frm != 0) && (ell % L == 0);
+    if (reset) ell = 0;
+    return reset;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MCRA: in0 = Y [B][T][K] power (or complex [B][T][K][2]), out0 = lambda_d [B][T][K].  state: S,Smin,Stmp,p,lambda_d
+// ------------------------------------------------------------------------------------------------
+DS_HD float mcra_in(const OpParams& p, long long base, int k) {
+    if (p.in_complex) { const float re = p.in0[2 * (base + k)], im = p.in0[2 * (base + k) + 1]; return fma_(re, re, im * im); }
+    return p.in0[base + k];
+}
+
+DS_HD void op_mcra(const OpParams& p, int b, int k) {
+    float st[5];
+#pragma unroll
+    for (int f = 0; f < 5; ++f) st[f] = st_at(p, b, f, k);
+    int frm = p.frm_cnt, ell = p.ell;
+    for (int t = 0; t < p.T; ++t) {
+        const long long base = ((long long)b * p.T + t) * p.K;
+        const bool reset = mcra_tick(frm, ell, p.L);
+        const float y0 = mcra_in(p, base, k);
+        const float ym = k > 0 ? mcra_in(p, base, k - 1) : 0.0f;
+        const float yp = k < p.K - 1 ? mcra_in(p, base, k + 1) : 0.0f;
+        mcra_bin(st, k, p.K, ym, y0, yp, frm, reset, p.L);
+        frm += 1; ell += 1;
+        p.out0[base + k] = st[4];
+    }
+#pragma unroll
+    for (int f = 0; f < 5; ++f) st_at(p, b, f, k) = st[f];
+}
+
+// ------------------------------------------------------------------------------------------------
+// McMcra: in0 = y complex [B][T][K][M]; out0 = p, out1 = G [B][T][K].
+// state: Phi_yy, Phi_vv (packed symmetric), then xi, gamma, p, G of the last frame (attributes users read)
+// ------------------------------------------------------------------------------------------------
+template <int M> DS_HD void op_mcmcra(const OpParams& p, int b, int k) {
+    constexpr int NS = M * (M + 1) / 2;
+    float pyy[NS], pvv[NS];
+#pragma unroll
+    for (int f = 0; f < NS; ++f) { pyy[f] = st_at(p, b, f, k); pvv[f] = st_at(p, b, NS + f, k); }
+    float pp = 0, G = 0, xi = 0, gam = 0;
+    int frm = p.frm_cnt;
+    for (int t = 0; t < p.T; ++t) {
+        const long long base = (((long long)b * p.T + t) * p.K + k) * M;
+        cf Z[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) Z[m] = mk(p.in0[2 * (base + m)], p.in0[2 * (base + m) + 1]);
+        mcmcra_bin<M>(pyy, pvv, Z, k, frm, pp, G, xi, gam);
+        frm += 1;
+        const long long ob = ((long long)b * p.T + t) * p.K + k;
+        p.out0[ob] = pp;
+        p.out1[ob] = G;
+    }
+#pragma unroll
+    for (int f = 0; f < NS; ++f) { st_at(p, b, f, k) = pyy[f]; st_at(p, b, NS + f, k) = pvv[f]; }
+    if (p.T > 0) {
+        st_at(p, b, 2 * NS + 0, k) = xi; st_at(p, b, 2 * NS + 1, k) = gam;
+        st_at(p, b, 2 * NS + 2, k) = pp; st_at(p, b, 2 * NS + 3, k) = G;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NsOmlsaMulti: in0 = y [B][T][K] (beam power), in1 = u [B][T][K][M-1] (reference powers);
+// out0 = lambda_d, out1 = G, out2 = p  [B][T][K].
+// state floats: [0,5M) M MCRAs (beam first), then zeta_Y, zeta_U[M-1], lambda_d, gamma, G_H1, G, p, xi_hat, q_hat
+// ------------------------------------------------------------------------------------------------
+DS_HD int omlsa_nf(int M) { return 5 * M + (M - 1) + 8; }
+
+DS_HD void op_omlsa(const OpParams& p, int b, int k) {
+    const int M = p.M, K = p.K, R = M - 1;
+    const int o_zy = 5 * M, o_zu = 5 * M + 1, o_s = 5 * M + 1 + R;   // o_s: lambda_d, gamma, G_H1, G, p, xi_hat, q_hat
+    int frm = p.frm_cnt, ell = p.ell, first = p.first_frame;
+    const float Gmin = 0.06309573444801933f;               // 10^(-12/10)  (omlsa_multi.py:35-36)
+    for (int t = 0; t < p.T; ++t) {
+        const long long yb = ((long long)b * p.T + t) * K;
+        const long long ub = yb * R;
+        const bool reset = mcra_tick(frm, ell, p.L);
+        const float y0 = p.in0[yb + k];
+        const float ym = k > 0 ? p.in0[yb + k - 1] : 0.0f, yp = k < K - 1 ? p.in0[yb + k + 1] : 0.0f;
+        // M minima-controlled noise trackers (:83-85)
+        float mc[5];
+#pragma unroll
+        for (int f = 0; f < 5; ++f) mc[f] = st_at(p, b, f, k);
+        mcra_bin(mc, k, K, ym, y0, yp, frm, reset, p.L);
+#pragma unroll
+        for (int f = 0; f < 5; ++f) st_at(p, b, f, k) = mc[f];
+        const float MU_Y = mc[4];
+        float zu_minus_mu_max = -3.0e38f;
+        for (int ch = 0; ch < R; ++ch) {
+            const float u0 = p.in1[ub + (long long)k * R + ch];
+            const float um = k > 0 ? p.in1[ub + (long long)(k - 1) * R + ch] : 0.0f;
+            const float up = k < K - 1 ? p.in1[ub + (long long)(k + 1) * R + ch] : 0.0f;
+#pragma unroll
+            for (int f = 0; f < 5; ++f) mc[f] = st_at(p, b, 5 * (ch + 1) + f, k);
+            mcra_bin(mc, k, K, um, u0, up, frm, reset, p.L);
+#pragma unroll
+            for (int f = 0; f < 5; ++f) st_at(p, b, 5 * (ch + 1) + f, k) = mc[f];
+            float zu;
+            if (first) zu = u0;                                                           // :92-93
+            else zu = fma_(0.8f, st_at(p, b, o_zu + ch, k), (float)(1.0 - 0.8) * fma_(up, 0.25f, fma_(u0, 0.5f, um * 0.25f)));   // :100
+            st_at(p, b, o_zu + ch, k) = zu;
+            zu_minus_mu_max = fmaxf_(zu_minus_mu_max, zu - mc[4]);
+        }
+        frm += 1; ell += 1;
+        const long long ob = yb + k;
+        if (first) {                                                                       // :87-93
+            first = 0;
+            st_at(p, b, o_s + 0, k) = y0;
+            st_at(p, b, o_zy, k) = y0;
+            p.out0[ob] = y0; p.out1[ob] = st_at(p, b, o_s + 3, k); p.out2[ob] = st_at(p, b, o_s + 4, k);
+            continue;
+        }
+        const float zy = fma_(0.8f, st_at(p, b, o_zy, k), (float)(1.0 - 0.8) * fma_(yp, 0.25f, fma_(y0, 0.5f, ym * 0.25f)));   // :98
+        st_at(p, b, o_zy, k) = zy;
+        float Omega = fmaxf_(zy - MU_Y, 1e-6f) / (fmaxf_(zu_minus_mu_max, 0.01f * MU_Y) + 1e-6f);   // :107-109
+        Omega = fminf_(fmaxf_(Omega, 0.1f), 100.0f);
+        const float gamma_s = fminf_(y0 / fma_(MU_Y, 1.66f, 1e-6f), 100.0f);                     // :115
+        float q;
+        if (gamma_s < 1.0f || Omega < 0.3f) q = 1.0f;                                            // :122-129
+        else q = fmaxf_((10.0f - gamma_s) / (10.0f - 1.0f), (3.0f - Omega) / (3.0f - 0.3f));
+        q = fminf_(fmaxf_(q, 1e-6f), 0.9999998f);                                                // :130
+        float lam = st_at(p, b, o_s + 0, k);
+        const float gamma_pre = st_at(p, b, o_s + 1, k), gh1_pre = st_at(p, b, o_s + 2, k);
+        const float gamma = y0 / fmaxf_(lam, 1e-10f);                                            // :134
+        const float xi = fma_(0.921f * gh1_pre * gh1_pre, gamma_pre, (float)(1.0 - 0.921) * fmaxf_(gamma - 1.0f, 0.0f));   // :137
+        const float nu = gamma * xi / (1.0f + xi);                                               // :140
+        const float gh1 = xi / (1.0f + xi);                                                      // :144
+        const float pp = 1.0f / (1.0f + q / (1.0f - q) * (1.0f + xi) * expf(-nu));               // :147
+        const float at = fma_((float)(1.0 - 0.85), pp, 0.85f);                                   // Base :57, alpha_d = 0.85
+        lam = fma_(at, lam, 1.47f * (1.0f - at) * y0);                                           // :149
+        float G = powf(gh1, pp) * powf(Gmin, 1.0f - pp);                                         // :153
+        G = fmaxf_(fminf_(G, 1.0f), Gmin);
+        st_at(p, b, o_s + 0, k) = lam; st_at(p, b, o_s + 1, k) = gamma; st_at(p, b, o_s + 2, k) = gh1;
+        st_at(p, b, o_s + 3, k) = G; st_at(p, b, o_s + 4, k) = pp; st_at(p, b, o_s + 5, k) = xi; st_at(p, b, o_s + 6, k) = q;
+        p.out0[ob] = lam; p.out1[ob] = G; p.out2[ob] = pp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Subband (N)LMS, single- or multi-channel: in0 = x complex [B][T][K][C], in1 = d complex [B][T][K],
+// in2 = p [B][T][K] (optional); out0 = err complex [B][T][K].
+// state floats: W [N][C] complex, input_buffer [N][C] complex, P
+// ------------------------------------------------------------------------------------------------
+DS_HD int sublms_nf(int N, int C) { return 4 * N * C + 1; }
+
+DS_HD void op_sublms(const OpParams& p, int b, int k) {
+    const int N = p.N, C = p.M, NC2 = 2 * N * C;
+    for (int t = 0; t < p.T; ++t) {
+        const long long fb = ((long long)b * p.T + t) * p.K + k;
+        // shift register (SubbandAF.py:50-51 / SubbandLmsMc.py:62-63)
+        for (int n = N - 1; n > 0; --n)
+            for (int c = 0; c < 2 * C; ++c) st_at(p, b, NC2 + n * 2 * C + c, k) = st_at(p, b, NC2 + (n - 1) * 2 * C + c, k);
+        for (int c = 0; c < C; ++c) {
+            st_at(p, b, NC2 + 2 * c, k) = p.in0[2 * (fb * C + c)];
+            st_at(p, b, NC2 + 2 * c + 1, k) = p.in0[2 * (fb * C + c) + 1];
+        }
+        cf out = mk(0.0f, 0.0f);
+        float pw = 0.0f;
+        for (int i = 0; i < N * C; ++i) {
+            const cf w = mk(st_at(p, b, 2 * i, k), st_at(p, b, 2 * i + 1, k));
+            const cf x = mk(st_at(p, b, NC2 + 2 * i, k), st_at(p, b, NC2 + 2 * i + 1, k));
+            out = cfmac(out, x, w);                        // conj(W) X  (SubbandAF.py:107)
+            pw += cabs2(x);
+        }
+        const float pk = p.has_p ? p.in2[fb] : 1.0f;
+        const cf d = mk(p.in1[2 * fb], p.in1[2 * fb + 1]);
+        const cf err = mk(fma_(-out.x, pk, d.x), fma_(-out.y, pk, d.y));      // d - out * p  (SubbandLMS.py:66-68)
+        float scale = 1.0f;
+        if (p.norm) {
+            float P = st_at(p, b, 2 * NC2, k);
+            P = fma_(p.alpha, P, (1.0f - p.alpha) * (pw / (float)C));           // SubbandLMS.py:72-75 ; /M in SubbandLmsMc.py:174-180
+            st_at(p, b, 2 * NC2, k) = P;
+            scale = 1.0f / (P + p.reg);
+        }
+        const float g = 2.0f * p.mu * pk * scale;                              // SubbandAF.py:86
+        for (int i = 0; i < N * C; ++i) {
+            const cf x = mk(st_at(p, b, NC2 + 2 * i, k), st_at(p, b, NC2 + 2 * i + 1, k));
+            const cf gr = cmulc(x, err);                                        // X conj(err)
+            st_at(p, b, 2 * i, k) = fma_(g, gr.x, st_at(p, b, 2 * i, k));
+            st_at(p, b, 2 * i + 1, k) = fma_(g, gr.y, st_at(p, b, 2 * i + 1, k));
+        }
+        p.out0[2 * fb] = err.x; p.out0[2 * fb + 1] = err.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Subband RLS: in0 = x complex [B][T][K], in1 = d complex [B][T][K]; out0 = err complex [B][T][K].
+// state floats: W [N] complex, input_buffer [N] complex, P [N][N] complex
+// ------------------------------------------------------------------------------------------------
+constexpr int RLS_NMAX = 4;
+DS_HD int subrls_nf(int N) { return 4 * N + 2 * N * N; }
+
+DS_HD void op_subrls(const OpParams& p, int b, int k) {
+    const int N = p.N, oX = 2 * N, oP = 4 * N;
+    const float lam_inv = 1.0f / p.lam;
+    for (int t = 0; t < p.T; ++t) {
+        const long long fb = ((long long)b * p.T + t) * p.K + k;
+        for (int n = N - 1; n > 0; --n) {
+            st_at(p, b, oX + 2 * n, k) = st_at(p, b, oX + 2 * (n - 1), k);
+            st_at(p, b, oX + 2 * n + 1, k) = st_at(p, b, oX + 2 * (n - 1) + 1, k);
+        }
+        st_at(p, b, oX, k) = p.in0[2 * fb];
+        st_at(p, b, oX + 1, k) = p.in0[2 * fb + 1];
+        cf X[RLS_NMAX], num[RLS_NMAX], xhP[RLS_NMAX];
+        cf out = mk(0.0f, 0.0f);
+        for (int i = 0; i < N; ++i) {
+            X[i] = mk(st_at(p, b, oX + 2 * i, k), st_at(p, b, oX + 2 * i + 1, k));
+            out = cfmac(out, X[i], mk(st_at(p, b, 2 * i, k), st_at(p, b, 2 * i + 1, k)));
+        }
+        const cf d = mk(p.in1[2 * fb], p.in1[2 * fb + 1]);
+        const cf err = csub(d, out);                                             // SubbandRLS.py:52
+        cf den = mk(p.lam, 0.0f);
+        for (int i = 0; i < N; ++i) {
+            cf a = mk(0.0f, 0.0f), r = mk(0.0f, 0.0f);
+            for (int j = 0; j < N; ++j) {
+                a = cfma(a, mk(st_at(p, b, oP + 2 * (i * N + j), k), st_at(p, b, oP + 2 * (i * N + j) + 1, k)), X[j]);   // (P x)_i
+                r = cfmac(r, mk(st_at(p, b, oP + 2 * (j * N + i), k), st_at(p, b, oP + 2 * (j * N + i) + 1, k)), X[j]);  // (x^H P)_i
+            }
+            num[i] = a; xhP[i] = r;
+            den = cfmac(den, a, X[i]);                                            // + conj(x_i) (P x)_i   :56-60
+        }
+        for (int i = 0; i < N; ++i) {
+            const cf kn = cdiv(num[i], den);
+            for (int j = 0; j < N; ++j) {                                        // P = (P - kn x^H P) / lambda   :63
+                const int q = oP + 2 * (i * N + j);
+                const cf pij = cfnma(mk(st_at(p, b, q, k), st_at(p, b, q + 1, k)), kn, xhP[j]);
+                st_at(p, b, q, k) = pij.x * lam_inv;
+                st_at(p, b, q + 1, k) = pij.y * lam_inv;
+            }
+            const cf g = cmulc(kn, err);                                         // conj(err) kn   :65
+            st_at(p, b, 2 * i, k) = fma_(2.0f * p.mu, g.x, st_at(p, b, 2 * i, k));
+            st_at(p, b, 2 * i + 1, k) = fma_(2.0f * p.mu, g.y, st_at(p, b, 2 * i + 1, k));
+        }
+        p.out0[2 * fb] = err.x; p.out0[2 * fb + 1] = err.y;
+    }
+}
+
+// dispatch one (b, k) of an operator
+DS_HD void run_op(int op, const OpParams& p, int b, int k) {
+    if (op == OP_MCRA) op_mcra(p, b, k);
+    else if (op == OP_OMLSA) op_omlsa(p, b, k);
+    else if (op == OP_SUBLMS) op_sublms(p, b, k);
+    else if (op == OP_SUBRLS) op_subrls(p, b, k);
+    else if (op == OP_MCMCRA) {
+        switch (p.M) {
+            case 2: op_mcmcra<2>(p, b, k); break;
+            case 4: op_mcmcra<4>(p, b, k); break;
+            case 6: op_mcmcra<6>(p, b, k); break;
+            case 8: op_mcmcra<8>(p, b, k); break;
+            default: break;
+        }
+    }
+}
+
+}  // namespace ds

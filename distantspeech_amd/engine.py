@@ -10,11 +10,13 @@ from . import _lib as L
 
 class BatchEngine:
     def __init__(self, algo, n_mics, nfft, hop=None, batch=1, track_ryy=False, mcra_L=15, device=-1,
-                 alpha_y=0.0, alpha_v=0.0, diag=0.0, gate=0.0, mu=0.0):
+                 alpha_y=0.0, alpha_v=0.0, diag=0.0, gate=0.0, mu=0.0, filter_len=0, no_norm=False, filt_mu=0.0,
+                 filt_alpha=0.0, rls_lambda=0.0):
         self._lib = L.load()
         hop = nfft // 2 if hop is None else int(hop)
         cfg = L.ds_config(ctypes.sizeof(L.ds_config), int(algo), int(n_mics), int(nfft), hop, int(batch),
-                          int(bool(track_ryy)), int(mcra_L), int(device), alpha_y, alpha_v, diag, gate, mu)
+                          int(bool(track_ryy)), int(mcra_L), int(device), alpha_y, alpha_v, diag, gate, mu,
+                          int(filter_len), int(bool(no_norm)), filt_mu, filt_alpha, rls_lambda)
         h = ctypes.c_void_p()
         L.check(self._lib.ds_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
@@ -98,6 +100,77 @@ class BatchEngine:
         ms = ctypes.c_float(0)
         L.check(self._lib.ds_timing_end(self._h, ctypes.byref(ms)), self._h)
         return ms.value
+
+    # -- frame-level objects (host arrays) -------------------------------------------------------
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+
+    def stft(self, x, layout):
+        """x [B, L, M] (layout 0) or [B, M, L] (layout 1) -> Y complex64 [B, T, K, M]."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[1] if layout == L.LAYOUT_SAMPLES_CHANNELS else x.shape[2]
+        Y = np.empty((self.batch, n // self.hop, self.K, self.M), dtype=np.complex64)
+        L.check(self._lib.ds_stft(self._h, self._p(x), int(layout), int(n), self._p(Y), L.MEM_HOST), self._h)
+        return Y
+
+    def istft(self, Y):
+        """Y complex [B, T, K, C] (C <= M) -> y float32 [B, T*hop, C]."""
+        Y = np.ascontiguousarray(Y, dtype=np.complex64)
+        B, T, K, C = Y.shape
+        y = np.empty((B, T * self.hop, C), dtype=np.float32)
+        L.check(self._lib.ds_istft(self._h, self._p(Y), int(T), int(C), self._p(y), L.MEM_HOST), self._h)
+        return y
+
+    def mcra_estimate(self, Y):
+        """Y [B, T, K] float power or complex -> lambda_d [B, T, K]."""
+        cplx = np.iscomplexobj(Y)
+        Y = np.ascontiguousarray(Y, dtype=np.complex64 if cplx else np.float32)
+        out = np.empty(Y.shape, dtype=np.float32)
+        L.check(self._lib.ds_mcra_estimate(self._h, self._p(Y), int(cplx), int(Y.shape[1]), self._p(out), L.MEM_HOST), self._h)
+        return out
+
+    def mcmcra_estimate(self, y):
+        """y complex [B, T, K, M] -> (p, G) [B, T, K]."""
+        y = np.ascontiguousarray(y, dtype=np.complex64)
+        p = np.empty(y.shape[:3], dtype=np.float32)
+        G = np.empty(y.shape[:3], dtype=np.float32)
+        L.check(self._lib.ds_mcmcra_estimate(self._h, self._p(y), int(y.shape[1]), self._p(p), self._p(G), L.MEM_HOST), self._h)
+        return p, G
+
+    def omlsa_estimate(self, y, u):
+        """y [B, T, K], u [B, T, K, M-1] powers -> (lambda_d, G, p) [B, T, K]."""
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        u = np.ascontiguousarray(u, dtype=np.float32)
+        lam, G, p = (np.empty(y.shape, dtype=np.float32) for _ in range(3))
+        L.check(self._lib.ds_omlsa_estimate(self._h, self._p(y), self._p(u), int(y.shape[1]), self._p(lam), self._p(G),
+                                            self._p(p), L.MEM_HOST), self._h)
+        return lam, G, p
+
+    def sublms_update(self, x, d, p=None):
+        """x complex [B, T, K, C], d complex [B, T, K], p [B, T, K] or None -> err complex [B, T, K]."""
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        d = np.ascontiguousarray(d, dtype=np.complex64)
+        pp = None if p is None else np.ascontiguousarray(p, dtype=np.float32)
+        err = np.empty(d.shape, dtype=np.complex64)
+        L.check(self._lib.ds_sublms_update(self._h, self._p(x), self._p(d), self._p(pp) if pp is not None else None,
+                                           int(d.shape[1]), self._p(err), L.MEM_HOST), self._h)
+        return err
+
+    def subrls_update(self, x, d):
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        d = np.ascontiguousarray(d, dtype=np.complex64)
+        err = np.empty(d.shape, dtype=np.complex64)
+        L.check(self._lib.ds_subrls_update(self._h, self._p(x), self._p(d), int(d.shape[1]), self._p(err), L.MEM_HOST), self._h)
+        return err
+
+    def op_state(self):
+        """raw operator state [B, NF, K] (rows documented in distantspeech_amd/ops.py)."""
+        nbytes = self._lib.ds_field_bytes(self._h, L.FIELD_OP_STATE)
+        out = np.empty(nbytes // 4, dtype=np.float32)
+        L.check(self._lib.ds_get_state(self._h, L.FIELD_OP_STATE, out.ctypes.data_as(ctypes.c_void_p), nbytes), self._h)
+        KP = (self.K + 3) & ~3
+        return out.reshape(self.batch, -1, KP)[:, :, : self.K]
 
     # -- state ----------------------------------------------------------------------------------
     def get_field(self, field):

@@ -1,0 +1,334 @@
+"""Frame-level objects with the reference's names and call contracts, backed by libdsenh.so kernels.
+
+  Transform             stft / istft / analysis / synthesis   (transform/transform.py:407-496)
+  NoiseEstimationMCRA   estimation(Y) -> lambda_d             (noise_estimation/mcra.py:20-77)
+  McMcra                estimation(y) ; attrs p, G, xi, gamma (noise_estimation/mc_mcra.py:25-224)
+  NsOmlsaMulti          estimation(y, u) -> lambda_d          (noise_estimation/omlsa_multi.py:27-156)
+  SubbandLMS / SubbandLmsMc / SubbandRLS   update(x_n, d_n, p=) -> (err, W)
+                                                              (adaptivefilter/SubbandLMS.py, SubbandLmsMc.py, SubbandRLS.py)
+
+Every class accepts ``batch=B`` (default 1 = the reference's shapes; B > 1 adds a leading batch axis).
+All arithmetic runs on the GPU (fp32); the classes only reshape arrays between the reference's
+layouts and the native [B][T][K][..] layout."""
+import numpy as np
+
+from . import _lib as L
+from .engine import BatchEngine
+
+
+class _Base(object):
+    batch = 1
+
+    def _sq(self, a):
+        return a[0] if self.batch == 1 else a
+
+    def _add_batch(self, a, ndim_single):
+        a = np.asarray(a)
+        if a.ndim == ndim_single:
+            if self.batch != 1:
+                raise ValueError("object built with batch=%d; pass arrays with a leading batch axis" % self.batch)
+            a = a[None]
+        return a
+
+
+class Transform(_Base):
+    """Streaming multichannel STFT / ISTFT with carried overlap — transform/transform.py:407-496."""
+
+    def __init__(self, channel=1, n_fft=256, hop_length=128, window=None, batch=1, device=-1):
+        if window is not None:
+            raise NotImplementedError("only the default sqrt-Hann window is built into the kernels")
+        self.channel, self.n_fft, self.frame_length, self.hop_length = channel, n_fft, n_fft, hop_length
+        self.half_bin = int(n_fft / 2 + 1)
+        self.window = np.sqrt(0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft))
+        self.win_len = n_fft
+        self.overlap = n_fft - hop_length
+        self.W0 = np.sum(self.window ** 2)
+        self.batch = int(batch)
+        self._eng = BatchEngine(L.ALGO_TRANSFORM, channel, n_fft, hop_length, batch=batch, device=device)
+
+    def stft(self, x):
+        """x [samples, channels] or [samples] -> [half_bin, frames, channels] complex128."""
+        x = np.asarray(x)
+        if x.ndim == 1 and self.batch == 1:
+            x = x[:, None]
+        x = self._add_batch(x, 2)
+        if x.shape[1] % self.hop_length != 0:
+            raise ValueError("samples (%d) must be a multiple of hop (%d)" % (x.shape[1], self.hop_length))
+        Y = self._eng.stft(x, L.LAYOUT_SAMPLES_CHANNELS)                    # [B, T, K, C]
+        return self._sq(np.transpose(Y, (0, 2, 1, 3)).astype(np.complex128))
+
+    def istft(self, Y):
+        """Y [half_bin], [half_bin, channels] (one frame) or [half_bin, frames, channels] -> [samples(, ch)]."""
+        Y = np.asarray(Y)
+        if self.batch == 1:
+            if Y.ndim == 1:
+                Y = Y[:, None, None]                                        # transform.py:461-462
+            if Y.ndim == 2:
+                Y = Y[:, None, :]                                           # :463-464: 2-D means [K, channels]
+            Y = Y[None]
+        half_bin, n_channels = Y.shape[1], Y.shape[3]
+        assert n_channels <= self.channel, 'n_channels:{} != self.channel:{}'.format(n_channels, self.channel)
+        y = self._eng.istft(np.transpose(Y, (0, 2, 1, 3)))                  # [B, L, C]
+        out = y.astype(np.float64)
+        return np.squeeze(out[0]) if self.batch == 1 else out
+
+    def magphase(self, D, power=1):
+        mag = np.abs(D) ** power
+        return mag, np.exp(1.0j * np.angle(D))
+
+    analysis = stft
+    synthesis = istft
+
+    @property
+    def previous_input(self):
+        return self._sq(np.swapaxes(self._eng.get_field(L.FIELD_STFT_TAIL), 1, 2).astype(np.float64))
+
+
+class NoiseEstimationMCRA(_Base):
+    """Minima-controlled recursive averaging — noise_estimation/mcra.py:20-77, NoiseEstimationBase.py:5-60."""
+
+    def __init__(self, nfft=256, p_max=0.999, p_min=1e-3, batch=1, device=-1):
+        self.nfft, self.half_bin, self.batch = nfft, int(nfft / 2 + 1), int(batch)
+        self.p_max, self.p_min = p_max, p_min
+        self._L = 15
+        self._eng = BatchEngine(L.ALGO_MCRA, 1, nfft, batch=batch, device=device)
+
+    @property
+    def L(self):
+        return self._L
+
+    @L.setter
+    def L(self, v):
+        self._L = int(v)
+        self._eng.set_mcra_L(int(v))
+
+    def estimation(self, Y):
+        """Y [half_bin] power (or complex, or [half_bin, ch] -> column 0) -> lambda_d [half_bin]."""
+        Y = np.asarray(Y)
+        if self.batch == 1:
+            if Y.ndim > 1:
+                Y = Y[:, 0]                                                 # mcra.py:32-33
+            Y = Y[None]
+        assert Y.shape[-1] == self.half_bin, 'len(Y):{} != half_bin:{}'.format(Y.shape[-1], self.half_bin)
+        lam = self._eng.mcra_estimate(Y[:, None, :])                        # one frame
+        return self._sq(lam[:, 0, :].astype(np.float64))
+
+    def _row(self, f):
+        return self._sq(self._eng.op_state()[:, f, :].astype(np.float64))
+
+    S = property(lambda s: s._row(0))
+    Smin = property(lambda s: s._row(1))
+    Stmp = property(lambda s: s._row(2))
+    p = property(lambda s: s._row(3))
+    lambda_d = property(lambda s: s._row(4))
+    frm_cnt = property(lambda s: int(s._eng.get_field(L.FIELD_COUNTERS)[0, 0]))
+
+
+class McMcra(_Base):
+    """Multichannel speech presence probability with real covariances — noise_estimation/mc_mcra.py:25-224."""
+
+    def __init__(self, nfft=256, channels=4, batch=1, device=-1):
+        self.nfft, self.half_bin, self.channels, self.M, self.batch = nfft, int(nfft / 2 + 1), channels, channels, int(batch)
+        self._eng = BatchEngine(L.ALGO_MCMCRA, channels, nfft, batch=batch, device=device)
+        self._ns = channels * (channels + 1) // 2
+
+    def estimation(self, y):
+        """y complex [half_bin, channels] (one frame); results in attributes p, G, xi, gamma."""
+        y = self._add_batch(y, 2)
+        self._eng.mcmcra_estimate(y[:, None, :, :])
+
+    def _row(self, f):
+        return self._sq(self._eng.op_state()[:, f, :].astype(np.float64))
+
+    def _sym(self, base):
+        st = self._eng.op_state()
+        M = self.M
+        out = np.zeros((self.batch, M, M, self.half_bin))
+        q = 0
+        for i in range(M):
+            for j in range(i, M):
+                out[:, i, j, :] = out[:, j, i, :] = st[:, base + q, :]
+                q += 1
+        return self._sq(out)                                               # reference layout [M, M, half_bin]
+
+    Phi_yy = property(lambda s: s._sym(0))
+    Phi_vv = property(lambda s: s._sym(s._ns))
+    xi = property(lambda s: s._row(2 * s._ns + 0))
+    gamma = property(lambda s: s._row(2 * s._ns + 1))
+    p = property(lambda s: s._row(2 * s._ns + 2))
+    G = property(lambda s: s._row(2 * s._ns + 3))
+    frm_cnt = property(lambda s: int(s._eng.get_field(L.FIELD_COUNTERS)[0, 0]))
+
+
+class NsOmlsaMulti(_Base):
+    """Multichannel (TBRR) OMLSA noise estimate and gain — noise_estimation/omlsa_multi.py:27-156."""
+
+    def __init__(self, nfft=256, M=4, cal_weights=False, batch=1, device=-1):
+        self.nfft, self.half_bin, self.M, self.cal_weights, self.batch = nfft, int(nfft / 2 + 1), M, cal_weights, int(batch)
+        self._eng = BatchEngine(L.ALGO_OMLSA, M, nfft, batch=batch, device=device)
+        self._o = 5 * M + 1 + (M - 1)
+        self._first = True
+
+    def estimation(self, y, u):
+        """y [half_bin] beam power, u [half_bin, M-1] reference powers -> lambda_d (None on the first call)."""
+        y = self._add_batch(y, 1)
+        u = self._add_batch(u, 2)
+        assert y.shape[-1] == self.half_bin
+        lam, G, p = self._eng.omlsa_estimate(y[:, None, :], u[:, None, :, :])
+        if self._first:                                                     # omlsa_multi.py:87-93 returns nothing
+            self._first = False
+            return None
+        return self._sq(lam[:, 0, :].astype(np.float64))
+
+    def _row(self, f):
+        return self._sq(self._eng.op_state()[:, f, :].astype(np.float64))
+
+    lambda_d = property(lambda s: s._row(s._o + 0))
+    gamma = property(lambda s: s._row(s._o + 1))
+    G_H1 = property(lambda s: s._row(s._o + 2))
+    p = property(lambda s: s._row(s._o + 4))
+    xi_hat = property(lambda s: s._row(s._o + 5))
+    q_hat = property(lambda s: s._row(s._o + 6))
+
+    @property
+    def G(self):
+        g = self._row(self._o + 3)
+        return g if self.cal_weights else np.ones_like(g)                   # :152-154 only with cal_weights
+
+
+class _SubbandBase(_Base):
+    def _W(self, N, C):
+        st = self._eng.op_state()                                           # rows: W [N][C] (re, im) first
+        w = st[:, : 2 * N * C, :].reshape(self.batch, N, C, 2, self.half_band)
+        return (w[:, :, :, 0, :] + 1j * w[:, :, :, 1, :]).astype(np.complex128)   # [B, N, C, K]
+
+    def _td(self, a):
+        return 'float' in str(np.asarray(a).dtype)
+
+
+class SubbandLMS(_SubbandBase):
+    """Per-band N-tap (N)LMS — adaptivefilter/SubbandLMS.py:12-84 (SubbandAF.py:12-111)."""
+
+    def __init__(self, filter_len=2, num_bands=512, mu=0.1, normalization=True, alpha=0.9, m=2, hop_length=None,
+                 input_td=False, batch=1, device=-1):
+        self.filter_len, self.half_band, self.batch = filter_len, int(num_bands / 2) + 1, int(batch)
+        self.hop_length = int(num_bands / 2) if hop_length is None else hop_length
+        self.num_bands = num_bands
+        self._eng = BatchEngine(L.ALGO_SUBLMS, 1, num_bands, batch=batch, device=device, filter_len=filter_len,
+                                no_norm=not normalization, filt_mu=mu, filt_alpha=alpha)
+        self._tx = self._td_ = None
+        self._device = device
+
+    def _transforms(self):
+        if self._tx is None:
+            self._tx = Transform(n_fft=self.num_bands, hop_length=self.hop_length, batch=self.batch, device=self._device)
+            self._td_ = Transform(n_fft=self.num_bands, hop_length=self.hop_length, batch=self.batch, device=self._device)
+        return self._tx, self._td_
+
+    def update(self, x_n, d_n, alpha=1e-4, p=None):
+        """x_n, d_n: [half_band] complex (or [hop] float -> analysed/synthesised internally); p scalar/[half_band]/None."""
+        x_n, d_n = np.asarray(x_n), np.asarray(d_n)
+        assert x_n.shape == d_n.shape, 'x_n and d_n must be same shape of [samples, ]'
+        td = self._td(x_n) and self._td(d_n)
+        if td:                                                              # SubbandAF.py:54-57
+            tx, tdd = self._transforms()
+            x_n = np.squeeze(tx.analysis(x_n))
+            d_n = np.squeeze(tdd.analysis(d_n))
+        x = self._add_batch(x_n, 1)
+        d = self._add_batch(d_n, 1)
+        pp = None
+        if p is not None:
+            pp = np.broadcast_to(np.asarray(p, dtype=np.float32).reshape(self.batch, -1) if np.ndim(p) else
+                                 np.full((self.batch, 1), p, dtype=np.float32), (self.batch, self.half_band))
+            pp = pp[:, None, :]
+        err = self._eng.sublms_update(x[:, None, :, None], d[:, None, :], pp)[:, 0, :]
+        W = self.W
+        if td:
+            return tdd.synthesis(self._sq(err)), W
+        return self._sq(err.astype(np.complex128)), W
+
+    @property
+    def W(self):
+        return self._sq(np.transpose(self._W(self.filter_len, 1)[:, :, 0, :], (0, 2, 1)))   # [half_band, filter_len]
+
+
+class SubbandLmsMc(_SubbandBase):
+    """Multichannel per-band (N)LMS — adaptivefilter/SubbandLmsMc.py:13-191."""
+
+    def __init__(self, filter_len=2, num_bands=512, channel=1, mu=0.1, normalization=True, alpha=0.9, m=2,
+                 hop_length=None, input_td=False, batch=1, device=-1):
+        self.filter_len, self.half_band, self.M, self.batch = filter_len, int(num_bands / 2) + 1, channel, int(batch)
+        self.hop_length = int(num_bands / 2) if hop_length is None else hop_length
+        self.num_bands = num_bands
+        self._eng = BatchEngine(L.ALGO_SUBLMS, channel, num_bands, batch=batch, device=device, filter_len=filter_len,
+                                no_norm=not normalization, filt_mu=mu, filt_alpha=alpha)
+        self._tx = self._td_ = None
+        self._device = device
+
+    def update(self, x_n, d_n, alpha=1e-4, p=None):
+        """x_n [half_band, 1, channel] complex (or [samples, channel] float), d_n [half_band] (or [samples]);
+        p [half_band, 1] or None."""
+        x_n, d_n = np.asarray(x_n), np.asarray(d_n)
+        td = self._td(x_n) and self._td(d_n)
+        if td:                                                              # SubbandLmsMc.py:86-92
+            if self._tx is None:
+                self._tx = Transform(n_fft=self.num_bands, hop_length=self.hop_length, channel=self.M, batch=self.batch,
+                                     device=self._device)
+                self._td_ = Transform(n_fft=self.num_bands, hop_length=self.hop_length, batch=self.batch, device=self._device)
+            x_n = self._tx.analysis(x_n)
+            d_n = np.squeeze(self._td_.analysis(d_n))
+        x = self._add_batch(x_n, 3)[:, :, 0, :]                             # [B, K, C]  (SubbandLmsMc.py:93)
+        d = self._add_batch(d_n, 1)
+        pp = None
+        if p is not None:
+            pp = np.asarray(p, dtype=np.float32).reshape(self.batch, 1, self.half_band)
+        err = self._eng.sublms_update(x[:, None, :, :], d[:, None, :], pp)[:, 0, :]
+        if td:
+            return self._td_.synthesis(self._sq(err)), self.W
+        return self._sq(err.astype(np.complex128)), self.W
+
+    @property
+    def W(self):
+        return self._sq(np.transpose(self._W(self.filter_len, self.M), (0, 3, 1, 2)))   # [half_band, filter_len, channel]
+
+
+class SubbandRLS(_SubbandBase):
+    """Per-band N-tap RLS — adaptivefilter/SubbandRLS.py:12-71."""
+
+    def __init__(self, filter_len=2, num_bands=512, forgetting_factor=0.998, mu=0.5, normalization=True, alpha=0.9, m=2,
+                 hop_length=None, input_td=False, batch=1, device=-1):
+        self.filter_len, self.half_band, self.batch = filter_len, int(num_bands / 2) + 1, int(batch)
+        self.hop_length = int(num_bands / 2) if hop_length is None else hop_length
+        self.num_bands = num_bands
+        self.forgetting_factor = forgetting_factor
+        self._eng = BatchEngine(L.ALGO_SUBRLS, 1, num_bands, batch=batch, device=device, filter_len=filter_len,
+                                filt_mu=mu, rls_lambda=forgetting_factor)
+        self._tx = self._td_ = None
+        self._device = device
+
+    def update(self, x_n, d_n, alpha=1e-4, p=None):
+        x_n, d_n = np.asarray(x_n), np.asarray(d_n)
+        td = self._td(x_n) and self._td(d_n)
+        if td:
+            if self._tx is None:
+                self._tx = Transform(n_fft=self.num_bands, hop_length=self.hop_length, batch=self.batch, device=self._device)
+                self._td_ = Transform(n_fft=self.num_bands, hop_length=self.hop_length, batch=self.batch, device=self._device)
+            x_n = np.squeeze(self._tx.analysis(x_n))
+            d_n = np.squeeze(self._td_.analysis(d_n))
+        x = self._add_batch(x_n, 1)
+        d = self._add_batch(d_n, 1)
+        err = self._eng.subrls_update(x[:, None, :], d[:, None, :])[:, 0, :]
+        if td:
+            return self._td_.synthesis(self._sq(err)), self.W
+        return self._sq(err.astype(np.complex128)), self.W
+
+    @property
+    def W(self):
+        return self._sq(np.transpose(self._W(self.filter_len, 1)[:, :, 0, :], (0, 2, 1)))
+
+    @property
+    def P(self):
+        N = self.filter_len
+        st = self._eng.op_state()[:, 4 * N: 4 * N + 2 * N * N, :].reshape(self.batch, N, N, 2, self.half_band)
+        P = (st[:, :, :, 0, :] + 1j * st[:, :, :, 1, :]).astype(np.complex128)
+        return self._sq(np.transpose(P, (0, 3, 1, 2)))                      # [half_band, N, N]

@@ -57,6 +57,17 @@ extern "C" {
 #define DS_ALGO_FIXED 0      /* FixedBeamformer: Y = sum conj(W) X                */
 #define DS_ALGO_ADAPTIVE 1   /* adaptivebeamfomer: MCRA-gated Rvv, src/DS/MVDR/TFGSC */
 #define DS_ALGO_GSC 2        /* GSC: FD blocking matrix + SPP-controlled LMS + McMcra gain */
+/* frame-level objects (drive them with the ds_stft / ds_*_estimate / ds_sub*_update entry points) */
+#define DS_ALGO_TRANSFORM 3  /* Transform.stft / istft               transform/transform.py:407-481 */
+#define DS_ALGO_MCRA 4       /* NoiseEstimationMCRA.estimation       noise_estimation/mcra.py:27-77 */
+#define DS_ALGO_MCMCRA 5     /* McMcra.estimation                    noise_estimation/mc_mcra.py:179-224 */
+#define DS_ALGO_OMLSA 6      /* NsOmlsaMulti.estimation              noise_estimation/omlsa_multi.py:73-156 */
+#define DS_ALGO_SUBLMS 7     /* SubbandLMS (n_mics=1) / SubbandLmsMc (n_mics=C) .update   adaptivefilter/SubbandLMS.py, SubbandLmsMc.py */
+#define DS_ALGO_SUBRLS 8     /* SubbandRLS.update                    adaptivefilter/SubbandRLS.py:44-71 */
+
+/* `mem` argument of the frame-level entry points */
+#define DS_MEM_HOST 0
+#define DS_MEM_DEVICE 1
 
 /* `method` (AlgorithmList, adaptivebeamformer.py:36) */
 #define DS_METHOD_SRC 0
@@ -85,6 +96,12 @@ typedef struct ds_config {
     float diag;          /* 0 -> 1e-6    adaptivebeamformer.py:89 */
     float gate;          /* 0 -> 0.4     adaptivebeamformer.py:94 */
     float mu;            /* 0 -> 0.01    GSC.py:202 */
+    /* frame-level filters (DS_ALGO_SUBLMS / DS_ALGO_SUBRLS); 0 -> the reference's defaults */
+    int32_t filter_len;  /* taps per band, 1..4; 0 -> 2           SubbandAF.py:15 */
+    int32_t no_norm;     /* 1 -> plain LMS (normalization=False)  SubbandAF.py:18 */
+    float filt_mu;       /* 0 -> 0.1 (LMS) / 0.5 (RLS)            SubbandAF.py:17, SubbandRLS.py:17 */
+    float filt_alpha;    /* 0 -> 0.9   power smoothing            SubbandAF.py:19 */
+    float rls_lambda;    /* 0 -> 0.998 forgetting factor          SubbandRLS.py:16 */
 } ds_config;
 
 /* ds_set_param_* ids */
@@ -110,6 +127,7 @@ typedef struct ds_config {
 #define DS_FIELD_STFT_TAIL 11 /* [B][M][hop]  Transform.previous_input  */
 #define DS_FIELD_OLA_TAIL 12  /* [B][hop]     Transform.previous_output */
 #define DS_FIELD_COUNTERS 13  /* int32 [B][4] {mcra.frm_cnt, mcra.ell, spp.frm_cnt, 0} */
+#define DS_FIELD_OP_STATE 14  /* frame-level objects: raw state [B][NF][KP] float32 (row map in distantspeech_amd/ops.py) */
 
 int ds_version(void);
 int ds_device_count(void);
@@ -150,6 +168,25 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
                           long long x_call_stride, int n_samples_per_call, int n_calls, float* y_dev,
                           long long y_batch_stride, long long y_call_stride, int first, int count, void* stream,
                           int graph);
+
+/* ---- frame-level entry points: the L2 objects callers drive frame by frame.
+ * Arrays carry a leading batch dimension B and a frame dimension T ("T successive calls"); complex =
+ * interleaved (re, im) float32; `mem` = DS_MEM_HOST (synchronous, staged) or DS_MEM_DEVICE (asynchronous
+ * on the handle's stream).
+ *   ds_stft            x [B] x layout, n_samples  -> Y complex [B][T][K][M]            (Transform.stft)
+ *   ds_istft           Y complex [B][T][K][C], C <= M -> y [B][T*hop][C]              (Transform.istft)
+ *   ds_mcra_estimate   Y [B][T][K] power (or complex if is_complex) -> lambda_d [B][T][K]
+ *   ds_mcmcra_estimate y complex [B][T][K][M] -> p, G [B][T][K]
+ *   ds_omlsa_estimate  y [B][T][K], u [B][T][K][M-1] powers -> lambda_d, G, p [B][T][K]
+ *   ds_sublms_update   x complex [B][T][K][C], d complex [B][T][K], p [B][T][K] or NULL -> err complex [B][T][K]
+ *   ds_subrls_update   x complex [B][T][K], d complex [B][T][K] -> err complex [B][T][K]                        */
+int ds_stft(ds_handle* h, const float* x, int layout, int n_samples, float* Y, int mem);
+int ds_istft(ds_handle* h, const float* Y, int n_frames, int n_channels, float* y, int mem);
+int ds_mcra_estimate(ds_handle* h, const float* Y, int is_complex, int n_frames, float* lambda_d, int mem);
+int ds_mcmcra_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* G, int mem);
+int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem);
+int ds_sublms_update(ds_handle* h, const float* x, const float* d, const float* p, int n_frames, float* err, int mem);
+int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames, float* err, int mem);
 
 int ds_synchronize(ds_handle* h);
 

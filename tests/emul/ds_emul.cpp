@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../distantspeech_amd/csrc/ds_core.hpp"
+#include "../../distantspeech_amd/csrc/ds_ops.hpp"
 #include "../../distantspeech_amd/csrc/ds_tables.hpp"
 
 namespace {
@@ -55,9 +56,76 @@ template <int NFFT> int run_n(int M, int algo, int ryy, const ds::Params& p, int
     return -1;
 }
 
+template <class E> int run_engine(ds::Params p, int batch, int nfft) {
+    std::vector<float> blob;
+    ds::make_table_blob(nfft, nfft / 2, blob, p.out_scale);
+    std::vector<ds::vec4> blob4(blob.size() / 4);
+    std::memcpy((void*)blob4.data(), blob.data(), blob.size() * sizeof(float));
+    p.tables = blob4.data();
+    typename E::Sh* sh = new typename E::Sh();
+    for (int b = 0; b < batch; ++b) {
+        CpuExec<typename E::Rg> ex;
+        ex.nt = E::NT;
+        ex.R.resize(E::NT);
+        E::run(ex, p, b, *sh);
+    }
+    delete sh;
+    return 0;
+}
+
+template <int NFFT> int run_tf(int M, bool inverse, const ds::Params& p, int batch) {
+#define TF(M_) if (M == M_) return inverse ? run_engine<ds::IstftEngine<NFFT, M_>>(p, batch, NFFT) : run_engine<ds::StftEngine<NFFT, M_>>(p, batch, NFFT);
+    TF(1) TF(2) TF(4) TF(6) TF(8)
+#undef TF
+    return -1;
+}
+
 }  // namespace
 
 extern "C" {
+
+// Transform.stft: x -> Y complex [B][T][K][M]; tail_in [B][M][hop] carried
+int emul_stft(int nfft, int M, int batch, const float* x, int layout, int n_samples, float* Y, float* tail_in) {
+    ds::Params p;
+    std::memset(&p, 0, sizeof p);
+    const int hop = nfft / 2, K = nfft / 2 + 1, T = n_samples / hop;
+    p.x = x; p.y = Y;
+    p.x_batch_stride = (long long)M * n_samples;
+    p.y_batch_stride = (long long)T * K * M * 2;
+    if (layout == 1) { p.x_sample_stride = 1; p.x_chan_stride = n_samples; } else { p.x_sample_stride = M; p.x_chan_stride = 1; }
+    p.T = T; p.tail_in = tail_in;
+    switch (nfft) { case 256: return run_tf<256>(M, false, p, batch); case 512: return run_tf<512>(M, false, p, batch); case 1024: return run_tf<1024>(M, false, p, batch); }
+    return -1;
+}
+
+// Transform.istft: Y complex [B][T][K][C] -> y [B][T*hop][C]; tail_out [B][M][hop] carried
+int emul_istft(int nfft, int M, int batch, const float* Y, int T, int C, float* y, float* tail_out) {
+    ds::Params p;
+    std::memset(&p, 0, sizeof p);
+    const int hop = nfft / 2, K = nfft / 2 + 1;
+    p.x = Y; p.y = y;
+    p.x_batch_stride = (long long)T * K * C * 2;
+    p.y_batch_stride = (long long)T * hop * C;
+    p.T = T; p.method = C; p.tail_out = tail_out;
+    switch (nfft) { case 256: return run_tf<256>(M, true, p, batch); case 512: return run_tf<512>(M, true, p, batch); case 1024: return run_tf<1024>(M, true, p, batch); }
+    return -1;
+}
+
+// frame-level operators: serial loop over (b, k) of ds::run_op
+int emul_op(int op, int B, int K, int T, float* st, int NF, const float* in0, const float* in1, const float* in2, float* out0,
+            float* out1, float* out2, int M, int N, int frm_cnt, int ell, int L, int first_frame, int in_complex, int has_p,
+            int norm, float mu, float alpha, float reg, float lam) {
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = st; p.NF = NF;
+    p.in0 = in0; p.in1 = in1; p.in2 = in2; p.out0 = out0; p.out1 = out1; p.out2 = out2;
+    p.M = M; p.N = N; p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.first_frame = first_frame;
+    p.in_complex = in_complex; p.has_p = has_p; p.norm = norm; p.mu = mu; p.alpha = alpha; p.reg = reg; p.lam = lam;
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < K; ++k) ds::run_op(op, p, b, k);
+    return 0;
+}
+
 
 // sizes of the per-bin plane storage for (algo, M, ryy): returns NP, writes KP
 int emul_layout(int algo, int nfft, int M, int ryy, int* kp) {

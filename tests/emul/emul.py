@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SO = os.path.join(HERE, "libds_emul.so")
 SRCS = [os.path.join(HERE, "ds_emul.cpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_core.hpp"),
-        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tables.hpp")]
+        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_ops.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tables.hpp")]
 
 
 def build(force=False):
@@ -76,3 +76,69 @@ class EmulEngine:
     def field(self, f):
         """float index f of every bin -> [B, K]"""
         return self.bins[:, f // 4, : self.K, f % 4]
+
+
+def _vp(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class EmulTransform:
+    """Transform.stft / istft through the kernel block programs (StftEngine / IstftEngine)."""
+
+    def __init__(self, nfft, M, batch=1):
+        self.nfft, self.M, self.batch, self.hop, self.K = nfft, M, batch, nfft // 2, nfft // 2 + 1
+        self.tail_in = np.zeros((batch, M, self.hop), dtype=np.float32)
+        self.tail_out = np.zeros((batch, M, self.hop), dtype=np.float32)
+
+    def stft(self, x, layout=0):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[1] if layout == 0 else x.shape[2]
+        Y = np.zeros((self.batch, n // self.hop, self.K, self.M), dtype=np.complex64)
+        assert lib().emul_stft(self.nfft, self.M, self.batch, _vp(x), layout, n, _vp(Y), _vp(self.tail_in)) == 0
+        return Y
+
+    def istft(self, Y):
+        Y = np.ascontiguousarray(Y, dtype=np.complex64)
+        B, T, K, C = Y.shape
+        y = np.zeros((B, T * self.hop, C), dtype=np.float32)
+        assert lib().emul_istft(self.nfft, self.M, self.batch, _vp(Y), T, C, _vp(y), _vp(self.tail_out)) == 0
+        return y
+
+
+class EmulOp:
+    """One frame-level operator handle (state + uniform counters), mirrors run_binop() in ds_api.hip."""
+    OPS = {"mcra": 0, "mcmcra": 1, "omlsa": 2, "sublms": 3, "subrls": 4}
+
+    def __init__(self, op, nfft, M=1, N=2, batch=1, mu=None, alpha=0.9, lam=0.998, norm=1, L=15):
+        self.op, self.B, self.K, self.M, self.N = self.OPS[op], batch, nfft // 2 + 1, M, N
+        self.KP = (self.K + 3) & ~3
+        self.NF = {0: 5, 1: M * (M + 1) + 4, 2: 5 * M + (M - 1) + 8, 3: 4 * N * M + 1, 4: 4 * N + 2 * N * N}[self.op]
+        self.st = np.zeros((batch, self.NF, self.KP), dtype=np.float32)
+        if self.op == 2:
+            o = 5 * M + 1 + (M - 1)
+            for f in (o + 1, o + 2, o + 3, o + 5, o + 6, 5 * M):
+                self.st[:, f, :] = 1.0
+        if self.op == 4:
+            for i in range(N):
+                self.st[:, 4 * N + 2 * (i * N + i), :] = 1000.0
+        self.frm, self.ell, self.first, self.L = 0, 1, 1, L
+        self.mu = mu if mu is not None else (0.5 if self.op == 4 else 0.1)
+        self.alpha, self.lam, self.norm = alpha, lam, norm
+
+    def run(self, in0, in1=None, in2=None, n_out=1, out_complex=False, in_complex=0):
+        in0 = np.ascontiguousarray(in0)
+        T = in0.shape[1]
+        outs = [np.zeros((self.B, T, self.K), dtype=np.complex64 if out_complex else np.float32) for _ in range(n_out)]
+        o = outs + [None] * (3 - n_out)
+        f = ctypes.c_float
+        rc = lib().emul_op(self.op, self.B, self.K, T, _vp(self.st), self.NF, _vp(in0), _vp(in1), _vp(in2), _vp(o[0]), _vp(o[1]),
+                           _vp(o[2]), self.M, self.N, self.frm, self.ell, self.L, self.first, int(in_complex),
+                           int(in2 is not None), self.norm, f(self.mu), f(self.alpha), f(1e-4), f(self.lam))
+        assert rc == 0
+        for _ in range(T):
+            if self.frm != 0 and self.ell % self.L == 0:
+                self.ell = 0
+            self.frm += 1
+            self.ell += 1
+        self.first = 0
+        return outs

@@ -33,14 +33,20 @@ def test_version_and_strerror():
 
 
 def test_config_struct_matches_header():
-    # 9 int32 + 5 float, no padding
-    assert ctypes.sizeof(L.ds_config) == 14 * 4
+    # the struct in include/dsenh.h: count its int32_t / float members (no padding: all 4-byte fields)
+    text = open(os.path.join(ROOT, "include", "dsenh.h")).read()
+    body = text[text.index("typedef struct ds_config {"):text.index("} ds_config;")]
+    n_fields = len(re.findall(r"^\s*(int32_t|float)\s+\w+;", body, flags=re.M))
+    assert n_fields == len(L.ds_config._fields_) == 19
+    assert ctypes.sizeof(L.ds_config) == 4 * n_fields
 
 
 def test_create_rejects_bad_configs_before_touching_the_gpu():
     lib = L.load()
     h = ctypes.c_void_p()
     bad_hop = L.ds_config(ctypes.sizeof(L.ds_config), L.ALGO_ADAPTIVE, 4, 512, 128, 1, 0, 0, -1, 0, 0, 0, 0, 0)
+    bad_taps = L.ds_config(ctypes.sizeof(L.ds_config), L.ALGO_SUBRLS, 1, 512, 256, 1, 0, 0, -1, 0, 0, 0, 0, 0, 9)
+    assert lib.ds_create(ctypes.byref(bad_taps), ctypes.byref(h)) == -3
     assert lib.ds_create(ctypes.byref(bad_hop), ctypes.byref(h)) == -3          # DS_EUNSUPPORTED
     bad_m = L.ds_config(ctypes.sizeof(L.ds_config), L.ALGO_ADAPTIVE, 5, 512, 256, 1, 0, 0, -1, 0, 0, 0, 0, 0)
     assert lib.ds_create(ctypes.byref(bad_m), ctypes.byref(h)) == -3

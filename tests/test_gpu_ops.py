@@ -1,0 +1,154 @@
+"""GPU parity of the frame-level objects (Transform, NoiseEstimationMCRA, McMcra, NsOmlsaMulti,
+SubbandLMS / SubbandLmsMc / SubbandRLS) through the C-ABI, driven frame by frame exactly like the
+reference's notebooks / __main__ blocks drive them, against the reference's golden vectors."""
+import numpy as np
+import pytest
+
+from _cases import as_float, load, rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ds():
+    import distantspeech_amd as d
+    from distantspeech_amd import _lib as L
+    assert L.load().ds_device_count() > 0
+    return d
+
+
+@pytest.mark.parametrize("name", ["g1_transform_512_256_4", "g1_transform_1024_512_2", "g1_transform_256_128_1"])
+def test_transform(ds, name):
+    g = load(name)
+    nfft, hop, M = [int(v) for v in g["params"]]
+    x = g["x"]
+    t = ds.Transform(channel=M, n_fft=nfft, hop_length=hop)
+    Y = t.stft(x if M > 1 else x[:, 0])
+    assert Y.shape == g["Y"].shape and Y.dtype == np.complex128
+    assert rms(Y - g["Y"]) < 2e-6 * rms(g["Y"])
+    y = np.asarray(t.istft(Y)).reshape(x.shape[0], -1)
+    assert np.max(np.abs(y - g["y"])) < 5e-6
+    # chunked like the streaming loop in transform.py:517-522 == one shot (bitwise)
+    t2 = ds.Transform(channel=M, n_fft=nfft, hop_length=hop)
+    ys = []
+    for n in range(0, x.shape[0], hop):
+        X = t2.analysis(x[n:n + hop] if M > 1 else x[n:n + hop, 0])
+        ys.append(np.asarray(t2.synthesis(X)).reshape(hop, -1))
+    assert np.array_equal(np.concatenate(ys), y)
+    with pytest.raises(ValueError):
+        t2.stft(np.zeros((hop + 1, M), np.float32) if M > 1 else np.zeros(hop + 1, np.float32))
+    if M > 1:                                       # single-frame 2-D input means [K, channels] (transform.py:463-464)
+        t3 = ds.Transform(channel=M, n_fft=nfft, hop_length=hop)
+        y1 = t3.istft(Y[:, 0, :])
+        assert y1.shape == (hop, M)
+        assert np.allclose(y1, y[:hop], atol=1e-6)
+
+
+@pytest.mark.parametrize("L", [15, 10])
+def test_mcra(ds, L):
+    g = load("g3_mcra_L%d" % L)
+    est = ds.NoiseEstimationMCRA(nfft=512)
+    est.L = L
+    P = g["P"]
+    lam = np.stack([est.estimation(P[n]) for n in range(P.shape[0])])
+    ref = g["lambda_d"]
+    assert np.median(np.abs(lam - ref) / (np.abs(ref) + 1e-12)) < 1e-5
+    assert np.mean(np.abs(est.p - g["p"][-1]) > 1e-3) < 0.02
+    assert est.frm_cnt == P.shape[0]
+    est2 = ds.NoiseEstimationMCRA(nfft=512)         # complex input -> |.|^2 (mcra.py:29-30)
+    a = est2.estimation(np.sqrt(P[0]) * np.exp(1j * 0.3))
+    assert np.allclose(a, ds.NoiseEstimationMCRA(nfft=512).estimation(P[0]), rtol=1e-5, atol=1e-12)
+    with pytest.raises(AssertionError):
+        est2.estimation(np.zeros(100))
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+def test_mcmcra(ds, name):
+    g = load("g5_mcmcra_" + name)
+    M, nfft, hop = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    D = ds.Transform(channel=M, n_fft=nfft, hop_length=hop).stft(x.T)
+    est = ds.McMcra(nfft=nfft, channels=M)
+    p = np.zeros_like(g["p"]); G = np.zeros_like(g["G"])
+    for n in range(D.shape[1]):
+        est.estimation(D[:, n, :])
+        p[n], G[n] = est.p, est.G
+    assert np.mean(np.abs(p - g["p"]) > 2e-2) < 0.02
+    assert np.median(np.abs(G - g["G"])) < 1e-4 and np.mean(np.abs(G - g["G"]) > 2e-2) < 0.02
+    assert est.Phi_vv.shape == (M, M, nfft // 2 + 1)
+    ref = np.moveaxis(g["Phi_vv"], 0, 2)
+    assert rms(est.Phi_vv - ref) < 2e-2 * rms(ref)
+
+
+def test_omlsa(ds):
+    g = load("g7_omlsa")
+    est = ds.NsOmlsaMulti(nfft=512, M=4, cal_weights=True)
+    T = g["y"].shape[0]
+    G = np.zeros((T, 257)); p = np.zeros((T, 257)); lam = np.zeros((T, 257))
+    for n in range(T):
+        r = est.estimation(g["y"][n], g["u"][n])
+        assert (r is None) == (n == 0)
+        G[n], p[n], lam[n] = est.G, est.p, est.lambda_d
+    assert np.median(np.abs(G[1:] - g["G"][1:])) < 1e-5 and np.mean(np.abs(G[1:] - g["G"][1:]) > 1e-2) < 0.01
+    assert np.median(np.abs(p[1:] - g["p"][1:])) < 1e-5
+    assert np.median(np.abs(lam[1:] - g["lambda_d"][1:]) / (g["lambda_d"][1:] + 1e-12)) < 1e-4
+
+
+def test_subband_filters(ds):
+    g = load("g8_subband")
+    x, d, pp = g["x"], g["d"], g["p"]
+    lms = ds.SubbandLMS(filter_len=2, num_bands=512, mu=0.1)
+    rls = ds.SubbandRLS(filter_len=2, num_bands=512)
+    mc = ds.SubbandLmsMc(filter_len=2, num_bands=512, channel=g["xm"].shape[2], mu=0.1)
+    e_l, e_r, e_m = [], [], []
+    for n in range(x.shape[0]):
+        e_l.append(lms.update(x[n], d[n], p=pp[n])[0])
+        e_r.append(rls.update(x[n], d[n])[0])
+        e_m.append(mc.update(g["xm"][n][:, None, :], g["dm"][n], p=pp[n][:, None])[0])
+    assert rms(np.array(e_l) - g["e_lms"]) < 1e-5 * max(rms(g["e_lms"]), 1.0)
+    assert rms(np.array(e_r) - g["e_rls"]) < 1e-4 * max(rms(g["e_rls"]), 1.0)
+    assert rms(np.array(e_m) - g["e_mc"]) < 1e-5 * max(rms(g["e_mc"]), 1.0)
+    assert lms.W.shape == g["W_lms"].shape and rms(lms.W - g["W_lms"]) < 1e-4 * rms(g["W_lms"])
+    assert rls.W.shape == g["W_rls"].shape and rms(rls.W - g["W_rls"]) < 1e-3 * rms(g["W_rls"])
+    assert mc.W.shape == g["W_mc"].shape and rms(mc.W - g["W_mc"]) < 1e-4 * rms(g["W_mc"])
+    assert rls.P.shape == g["P_rls"].shape and rms(rls.P - g["P_rls"]) < 1e-2 * rms(g["P_rls"])
+
+
+def test_subband_time_domain_path(ds):
+    """float inputs: the filter analyses x and d itself and returns a time-domain error (SubbandAF.py:53-60,
+    SubbandLMS.py:82-83); checked against Transform + frequency-domain update + synthesis done by hand."""
+    rng = np.random.default_rng(5)
+    hop = 256
+    x = (rng.standard_normal(hop * 20) * 0.1).astype(np.float32)
+    d = (np.convolve(x, [0.5, -0.2, 0.1])[: x.size] + 0.01 * rng.standard_normal(x.size)).astype(np.float32)
+    f1 = ds.SubbandLMS(filter_len=2, num_bands=512, mu=0.1)
+    f2 = ds.SubbandLMS(filter_len=2, num_bands=512, mu=0.1)
+    tx, td = ds.Transform(n_fft=512, hop_length=hop), ds.Transform(n_fft=512, hop_length=hop)
+    for n in range(0, x.size, hop):
+        e_td, _ = f1.update(x[n:n + hop], d[n:n + hop])
+        X, D = np.squeeze(tx.analysis(x[n:n + hop])), np.squeeze(td.analysis(d[n:n + hop]))
+        e_fd, _ = f2.update(X, D)
+        assert np.allclose(e_td, td.synthesis(e_fd), atol=1e-6)
+    assert e_td.shape == (hop,)
+
+
+def test_batched_ops_match_single(ds):
+    """batch axis: B independent MCRA / McMcra streams == B single objects (bitwise)."""
+    rng = np.random.default_rng(9)
+    B, T, K, M = 3, 40, 257, 4
+    P = rng.chisquare(2, size=(B, T, K)).astype(np.float32)
+    big = ds.NoiseEstimationMCRA(nfft=512, batch=B)
+    lam = np.stack([big.estimation(P[:, t]) for t in range(T)], axis=1)
+    for b in range(B):
+        one = ds.NoiseEstimationMCRA(nfft=512)
+        ref = np.stack([one.estimation(P[b, t]) for t in range(T)])
+        assert np.array_equal(lam[b], ref)
+    y = (rng.standard_normal((B, T, K, M)) + 1j * rng.standard_normal((B, T, K, M))).astype(np.complex64)
+    bigm = ds.McMcra(nfft=512, channels=M, batch=B)
+    for t in range(T):
+        bigm.estimation(y[:, t])
+    for b in range(B):
+        one = ds.McMcra(nfft=512, channels=M)
+        for t in range(T):
+            one.estimation(y[b, t])
+        assert np.array_equal(bigm.G[b], one.G) and np.array_equal(bigm.p[b], one.p)

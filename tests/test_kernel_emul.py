@@ -92,3 +92,86 @@ def test_emul_transform_roundtrip(nfft, M):
     y = e.process(x[None], 0)[0]
     assert np.max(np.abs(y[hop:] - x[:-hop, 0])) < 2e-6
     assert np.max(np.abs(y[:hop])) == 0.0 or np.max(np.abs(y[:hop] - 0)) < 1.0   # first hop holds the fade-in
+
+
+# ------------------------------------------------------------------------------------------------
+# frame-level objects (ds_ops.hpp, StftEngine / IstftEngine) against the reference's golden vectors
+# ------------------------------------------------------------------------------------------------
+from emul.emul import EmulOp, EmulTransform  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["g1_transform_512_256_4", "g1_transform_1024_512_2", "g1_transform_256_128_1"])
+def test_emul_transform_golden(name):
+    g = load(name)
+    nfft, hop, M = [int(v) for v in g["params"]]
+    x = g["x"]
+    t = EmulTransform(nfft, M)
+    Y = t.stft(x[None], 0)[0]                                    # [T, K, M]
+    ref = np.transpose(g["Y"], (1, 0, 2))
+    assert rms(Y - ref) < 2e-6 * rms(ref)
+    y = t.istft(Y[None])[0]
+    assert np.max(np.abs(y - g["y"])) < 5e-6
+    # chunked == one-shot bit for bit
+    t2 = EmulTransform(nfft, M)
+    cuts = [0, hop, 4 * hop, x.shape[0]]
+    ys = [t2.istft(t2.stft(x[None, a:b], 0))[0] for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(ys), y)
+    # istft of fewer channels than the Transform was built with (transform.py:466)
+    t3 = EmulTransform(nfft, M)
+    y1 = t3.istft(np.ascontiguousarray(Y[None, :, :, :1]))[0]
+    assert np.array_equal(y1[:, 0], y[:, 0])
+
+
+@pytest.mark.parametrize("L", [15, 10])
+def test_emul_mcra_golden(L):
+    g = load("g3_mcra_L%d" % L)
+    P = g["P"].astype(np.float32)
+    op = EmulOp("mcra", 512, L=L)
+    lam_all = op.run(P[None, :100])[0][0]
+    lam_b = np.concatenate([op.run(P[None, t:t + 1])[0][0] for t in range(100, P.shape[0])])   # frame-by-frame continues
+    lam = np.concatenate([lam_all, lam_b])
+    ref = g["lambda_d"]
+    assert np.median(np.abs(lam - ref) / (np.abs(ref) + 1e-12)) < 1e-5
+    p = op.st[0, 3, :257]
+    assert np.mean(np.abs(p - g["p"][-1]) > 1e-3) < 0.02
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+def test_emul_mcmcra_golden(name):
+    g = load("g5_mcmcra_" + name)
+    M, nfft, hop = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    D = EmulTransform(nfft, M).stft(np.ascontiguousarray(x.T)[None], 0)            # [1, T, K, M]
+    op = EmulOp("mcmcra", nfft, M=M)
+    p, G = op.run(D, n_out=2)
+    assert np.mean(np.abs(p[0] - g["p"]) > 2e-2) < 0.02
+    assert np.mean(np.abs(G[0] - g["G"]) > 2e-2) < 0.02
+    assert np.median(np.abs(G[0] - g["G"])) < 1e-4
+
+
+def test_emul_omlsa_golden():
+    g = load("g7_omlsa")
+    op = EmulOp("omlsa", 512, M=4)
+    lam, G, p = op.run(g["y"][None].astype(np.float32), g["u"][None].astype(np.float32), n_out=3)
+    T = g["y"].shape[0]
+    assert np.median(np.abs(G[0][1:] - g["G"][1:])) < 1e-5 and np.mean(np.abs(G[0][1:] - g["G"][1:]) > 1e-2) < 0.01
+    assert np.median(np.abs(p[0][1:] - g["p"][1:])) < 1e-5
+    ref = g["lambda_d"][1:]
+    assert np.median(np.abs(lam[0][1:] - ref) / (np.abs(ref) + 1e-12)) < 1e-4
+
+
+def test_emul_subband_golden():
+    g = load("g8_subband")
+    x, d, pp = g["x"].astype(np.complex64), g["d"].astype(np.complex64), g["p"].astype(np.float32)
+    lms = EmulOp("sublms", 512, M=1, N=2, mu=0.1)
+    e = lms.run(x[None, :, :, None], d[None], pp[None], out_complex=True)[0][0]
+    assert rms(e - g["e_lms"]) < 1e-5 * max(rms(g["e_lms"]), 1.0)
+    rls = EmulOp("subrls", 512, N=2)
+    e = rls.run(x[None], d[None], out_complex=True)[0][0]
+    assert rms(e - g["e_rls"]) < 1e-4 * max(rms(g["e_rls"]), 1.0)
+    xm, dm = g["xm"].astype(np.complex64), g["dm"].astype(np.complex64)
+    mc = EmulOp("sublms", 512, M=xm.shape[2], N=2, mu=0.1)
+    e = mc.run(xm[None], dm[None], pp[None], out_complex=True)[0][0]
+    assert rms(e - g["e_mc"]) < 1e-5 * max(rms(g["e_mc"]), 1.0)
+    W = (mc.st[0, 0:12:2, :257] + 1j * mc.st[0, 1:12:2, :257]).reshape(2, 3, 257)
+    assert rms(np.transpose(W, (2, 0, 1)) - g["W_mc"]) < 1e-4 * rms(g["W_mc"])
