@@ -47,6 +47,9 @@ struct ds_handle {
     size_t dev_buf_bytes[7];
     // cached hipGraph of a ds_process_device_seq() sequence
     hipGraphExec_t graph_exec;
+    int split;                  // DS_PARAM_SPLIT: utterance groups captured as parallel graph branches
+    hipStream_t side[7];        // side streams for the extra branches
+    hipEvent_t ev_fork, ev_join[7];
     long long graph_key[16];
     bool graph_valid;
     float* x_stage;
@@ -232,6 +235,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->x_stage_elems = h->y_stage_elems = 0;
     h->steer_per_utt = 0; h->steer_set = false;
     h->graph_exec = nullptr; h->graph_valid = false;
+    h->split = 1; h->ev_fork = nullptr;
+    for (int i = 0; i < 7; ++i) { h->side[i] = nullptr; h->ev_join[i] = nullptr; }
     h->ki_istft = ki_istft; h->op = op; h->opst = nullptr; h->NF = NF;
     h->op_frm = 0; h->op_ell = 1; h->op_first = 1;
     h->filter_len = flen; h->norm = cfg->no_norm ? 0 : 1;
@@ -293,6 +298,8 @@ int ds_destroy(ds_handle* h) {
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage); (void)hipFree(h->opst);
     for (int i = 0; i < 7; ++i) (void)hipFree(h->dev_buf[i]);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    for (int i = 0; i < 7; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -338,6 +345,10 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
         case DS_PARAM_MCRA_L:
             if (value <= 0) return fail(h, DS_EINVAL, "mcra_L must be > 0");
             h->mcra_L = value;
+            return DS_OK;
+        case DS_PARAM_SPLIT:
+            if (value < 1 || value > 8) return fail(h, DS_EINVAL, "split must be 1..8");
+            h->split = value; h->graph_valid = false;
             return DS_OK;
         default: return fail(h, DS_EINVAL, "unknown int parameter id");
     }
@@ -412,18 +423,40 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     const long long key[16] = {(long long)(uintptr_t)x_dev, (long long)(uintptr_t)y_dev, layout, x_batch_stride, x_chan_stride,
                                x_call_stride, n_samples_per_call, n_calls, y_batch_stride, y_call_stride,
                                ((long long)first << 32) | (unsigned)count, ((long long)h->method << 32) | (unsigned)h->mcra_L,
-                               fbits[0], fbits[1], fbits[2], (long long)(uintptr_t)h->steer};
+                               fbits[0], fbits[1], fbits[2] ^ ((long long)h->split << 40), (long long)(uintptr_t)h->steer};
     if (!h->graph_valid || std::memcmp(key, h->graph_key, sizeof key) != 0) {
         if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
         h->graph_valid = false;
         hipStream_t cs = h->stream;                       // capture on the handle's own stream
         DS_HIP(h, hipStreamSynchronize(cs));
+        const int ns = h->split < count ? h->split : (count > 0 ? count : 1);
+        if (ns > 1) {
+            if (!h->ev_fork) DS_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            for (int i = 0; i < ns - 1; ++i) {
+                if (!h->side[i]) DS_HIP(h, hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking));
+                if (!h->ev_join[i]) DS_HIP(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+            }
+        }
         DS_HIP(h, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         int crc = DS_OK;
-        for (int i = 0; i < n_calls && crc == DS_OK; ++i)
-            crc = ds_process_device(h, x_dev + (long long)i * x_call_stride, layout, x_batch_stride, x_chan_stride,
-                                    n_samples_per_call, y_dev + (long long)i * y_call_stride, y_batch_stride, first, count,
-                                    (void*)cs);
+        if (ns > 1) {
+            // independent utterance groups become parallel branches of the graph: while one group's kernels are in
+            // their state-load / store phases the other group's kernels compute (utterances never interact)
+            hipError_t e1 = hipEventRecord(h->ev_fork, cs);
+            for (int g2 = 0; g2 < ns - 1 && e1 == hipSuccess; ++g2) e1 = hipStreamWaitEvent(h->side[g2], h->ev_fork, 0);
+            if (e1 != hipSuccess) crc = DS_EHIP;
+        }
+        for (int g2 = 0; g2 < ns && crc == DS_OK; ++g2) {
+            const int lo = (int)((long long)count * g2 / ns), hi = (int)((long long)count * (g2 + 1) / ns);
+            hipStream_t bs = g2 == 0 ? cs : h->side[g2 - 1];
+            for (int i = 0; i < n_calls && crc == DS_OK; ++i)
+                crc = ds_process_device(h, x_dev + (long long)i * x_call_stride + (long long)lo * x_batch_stride, layout, x_batch_stride,
+                                        x_chan_stride, n_samples_per_call, y_dev + (long long)i * y_call_stride + (long long)lo * y_batch_stride,
+                                        y_batch_stride, first + lo, hi - lo, (void*)bs);
+            if (g2 > 0 && crc == DS_OK) {
+                if (hipEventRecord(h->ev_join[g2 - 1], bs) != hipSuccess || hipStreamWaitEvent(cs, h->ev_join[g2 - 1], 0) != hipSuccess) crc = DS_EHIP;
+            }
+        }
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(cs, &g);
         if (crc != DS_OK) { if (g) (void)hipGraphDestroy(g); return crc; }

@@ -50,6 +50,10 @@ class BatchEngine:
     def set_method(self, method):
         L.check(self._lib.ds_set_param_i(self._h, L.PARAM_METHOD, int(method)), self._h)
 
+    def set_split(self, n):
+        """graph mode of process_device_seq: run n utterance groups as parallel branches (memory/compute overlap)."""
+        L.check(self._lib.ds_set_param_i(self._h, L.PARAM_SPLIT, int(n)), self._h)
+
     def set_mcra_L(self, value):
         L.check(self._lib.ds_set_param_i(self._h, L.PARAM_MCRA_L, int(value)), self._h)
 

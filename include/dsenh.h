@@ -112,6 +112,7 @@ typedef struct ds_config {
 #define DS_PARAM_DIAG 5
 #define DS_PARAM_GATE 6
 #define DS_PARAM_MU 7
+#define DS_PARAM_SPLIT 8   /* int: utterance groups run as parallel hipGraph branches in ds_process_device_seq(graph=1); default 1 */
 
 /* ds_get_state fields; all arrays are float32, complex = interleaved (re, im) */
 #define DS_FIELD_RVV 1        /* [B][K][M][M][2]  */
