@@ -198,6 +198,11 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
                 op = ds::OP_MCMCRA; NF = cfg->n_mics * (cfg->n_mics + 1) + 4;
             }
             break;
+        case DS_ALGO_MCSPPBASE:
+            if (cfg->n_mics == 2 || cfg->n_mics == 4 || cfg->n_mics == 6 || cfg->n_mics == 8) {
+                op = ds::OP_MCSPPBASE; NF = ds::mcsppbase_nf(cfg->n_mics);
+            }
+            break;
         case DS_ALGO_OMLSA:
             if (cfg->n_mics >= 2 && cfg->n_mics <= 16) { op = ds::OP_OMLSA; NF = ds::omlsa_nf(cfg->n_mics); }
             break;
@@ -632,6 +637,13 @@ int ds_mcmcra_estimate(ds_handle* h, const float* y, int n_frames, float* p, flo
     const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
     IoSpec io = {{y, nullptr, nullptr}, {n * h->cfg.n_mics * 8, 0, 0}, {p, G, nullptr}, {n * 4, n * 4, 0}};
     return run_binop(h, DS_ALGO_MCMCRA, "ds_mcmcra_estimate", n_frames, mem, io, 0, 0);
+}
+
+int ds_mcsppbase_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* w, int mem) {
+    if (!h || !y || !p || !w) return fail(h, DS_EINVAL, "ds_mcsppbase_estimate: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{y, nullptr, nullptr}, {n * h->cfg.n_mics * 8, 0, 0}, {p, w, nullptr}, {n * 4, n * h->cfg.n_mics * 8, 0}};
+    return run_binop(h, DS_ALGO_MCSPPBASE, "ds_mcsppbase_estimate", n_frames, mem, io, 0, 0);
 }
 
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem) {

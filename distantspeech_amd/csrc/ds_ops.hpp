@@ -13,7 +13,7 @@
 
 namespace ds {
 
-enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4 };
+enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4, OP_MCSPPBASE = 5 };
 
 struct OpParams {
     int B, K, KP, T;          // utterances, bins, padded plane length, frames in this call
@@ -277,13 +277,164 @@ DS_HD void op_subrls(const OpParams& p, int b, int k) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// McSppBase.estimation + compute_pmwf_weight (noise_estimation/mcspp_base.py:262-324,220-240):
+// in0 = y complex [B][T][K][M]; out0 = p [B][T][K], out1 = w complex [B][T][K][M] (PMWF weights).
+// state floats: Phi_yy (Hermitian packed: M diag + M(M-1)/2 complex), Phi_vv (same), MCRA(5), xi, gamma, p, w[M] complex
+// ------------------------------------------------------------------------------------------------
+DS_HD int mcsppbase_nf(int M) { return 2 * M * M + 5 + 3 + 2 * M; }
+
+template <int M> DS_HD void op_mcsppbase(const OpParams& p, int b, int k) {
+    constexpr int NS = M * (M + 1) / 2, NO = M * (M - 1) / 2;
+    float yd[M], yo[2 * NO + 1], vd[M], vo[2 * NO + 1], mc[5];
+#pragma unroll
+    for (int f = 0; f < M; ++f) { yd[f] = st_at(p, b, f, k); vd[f] = st_at(p, b, M * M + f, k); }
+#pragma unroll
+    for (int f = 0; f < 2 * NO; ++f) { yo[f] = st_at(p, b, M + f, k); vo[f] = st_at(p, b, M * M + M + f, k); }
+#pragma unroll
+    for (int f = 0; f < 5; ++f) mc[f] = st_at(p, b, 2 * M * M + f, k);
+    int frm = p.frm_cnt, ell = p.ell;
+    float xi = 0, gam = 0, pp = 0;
+    cf w[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) w[m] = mk(0.0f, 0.0f);
+    for (int t = 0; t < p.T; ++t) {
+        const long long fb = ((long long)b * p.T + t) * p.K;
+        const long long base = (fb + k) * M;
+        cf Z[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) Z[m] = mk(p.in0[2 * (base + m)], p.in0[2 * (base + m) + 1]);
+        herm_rank1<M>(yd, yo, Z, 0.92f, (float)(1.0 - 0.92));                 // estimate_noisy_psd :86-92
+        // real-symmetric inverse of Re(Phi_vv) + 1e-6 I  (:277-279)
+        float sv[NS], sx[NS];
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = i; j < M; ++j) {
+                const int q = sym_index(i, j, M);
+                if (i == j) { sv[q] = vd[i]; sx[q] = yd[i] - vd[i]; }
+                else { const int o = off_index(i, j, M); sv[q] = vo[2 * o]; sx[q] = yo[2 * o] - vo[2 * o]; }
+            }
+        float Lm[M][M], inv_d[M], Li[M][M], iv[NS];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            float s = sym_get<M>(sv, j, j) + 1e-6f;
+#pragma unroll
+            for (int q = 0; q < j; ++q) s = fma_(-Lm[j][q], Lm[j][q], s);
+            s = fmaxf_(s, 1e-30f);
+            const float r = 1.0f / sqrtf(s);
+            inv_d[j] = r; Lm[j][j] = s * r;
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) {
+                float tt = sym_get<M>(sv, i, j);
+#pragma unroll
+                for (int q = 0; q < j; ++q) tt = fma_(-Lm[i][q], Lm[j][q], tt);
+                Lm[i][j] = tt * r;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < M; ++c)
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                if (i < c) { Li[i][c] = 0.0f; continue; }
+                float tt = (i == c) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int q = c; q < i; ++q) tt = fma_(-Lm[i][q], Li[q][c], tt);
+                Li[i][c] = tt * inv_d[i];
+            }
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = i; j < M; ++j) {
+                float tt = 0.0f;
+#pragma unroll
+                for (int q = j; q < M; ++q) tt = fma_(Li[q][i], Li[q][j], tt);
+                iv[sym_index(i, j, M)] = tt;
+            }
+        // xi = trace(inv Re(Phi_xx)) ; gamma = Re(y^H inv Re(Phi_xx) inv y)  (:281-285) ; v = inv y
+        float tr = 0.0f;
+        cf v[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            cf a = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const float e = sym_get<M>(iv, i, j);
+                tr = fma_(e, sym_get<M>(sx, i, j), tr);
+                a.x = fma_(e, Z[j].x, a.x); a.y = fma_(e, Z[j].y, a.y);
+            }
+            v[i] = a;
+        }
+        float g = 0.0f;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j)
+                g = fma_(sym_get<M>(sx, i, j), fma_(v[i].x, v[j].x, v[i].y * v[j].y), g);   // Re(conj(v_i) v_j) Pxx_ij
+        xi = fminf_(fmaxf_(tr, 1e-6f), 1e6f);                                  // :287
+        gam = fminf_(fmaxf_(g, 1e-6f), 1e6f);                                  // :288
+        // compute_q (:96-118): MCRA on |y_0|^2, q = sqrt(1 - p_mcra)
+        const bool reset = mcra_tick(frm, ell, p.L);
+        const float y0 = cabs2(Z[0]);
+        float ym = 0.0f, yp = 0.0f;
+        if (k > 0) { const long long q = (fb + k - 1) * M; ym = cabs2(mk(p.in0[2 * q], p.in0[2 * q + 1])); }
+        if (k < p.K - 1) { const long long q = (fb + k + 1) * M; yp = cabs2(mk(p.in0[2 * q], p.in0[2 * q + 1])); }
+        mcra_bin(mc, k, p.K, ym, y0, yp, frm, reset, p.L);
+        frm += 1; ell += 1;
+        float q = sqrtf(1.0f - mc[3]);
+        q = fminf_(fmaxf_(q, 0.01f), 0.99f);
+        pp = 1.0f / (1.0f + q / (1.0f - q) * (1.0f + xi) * expf(-1.0f * (gam / (1.0f + xi))));   // :120-135
+        pp = fminf_(fmaxf_(pp, 0.01f), 0.99f);
+        // PMWF weights from Phi_xx (complex, before the noise update) and the real inverse (:220-240, :293)
+        const float wsc = 1.0f / (1.0f + xi);
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            cf a = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                const cf x0 = csub(herm_get<M>(yd, yo, j, 0), herm_get<M>(vd, vo, j, 0));   // Phi_xx[j][0]
+                const float e = sym_get<M>(iv, i, j);
+                a.x = fma_(e, x0.x, a.x); a.y = fma_(e, x0.y, a.y);
+            }
+            w[i] = cscale(a, wsc);
+        }
+        // update_noise_psd (:299-324): alpha_d = 0.92
+        const float at = fma_((float)(1.0 - 0.92), pp, 0.92f);
+        herm_rank1<M>(vd, vo, Z, at, 1.0f - at);
+        const long long ob = fb + k;
+        p.out0[ob] = pp;
+#pragma unroll
+        for (int m = 0; m < M; ++m) { p.out1[2 * (ob * M + m)] = w[m].x; p.out1[2 * (ob * M + m) + 1] = w[m].y; }
+    }
+#pragma unroll
+    for (int f = 0; f < M; ++f) { st_at(p, b, f, k) = yd[f]; st_at(p, b, M * M + f, k) = vd[f]; }
+#pragma unroll
+    for (int f = 0; f < 2 * NO; ++f) { st_at(p, b, M + f, k) = yo[f]; st_at(p, b, M * M + M + f, k) = vo[f]; }
+#pragma unroll
+    for (int f = 0; f < 5; ++f) st_at(p, b, 2 * M * M + f, k) = mc[f];
+    if (p.T > 0) {
+        const int o = 2 * M * M + 5;
+        st_at(p, b, o, k) = xi; st_at(p, b, o + 1, k) = gam; st_at(p, b, o + 2, k) = pp;
+#pragma unroll
+        for (int m = 0; m < M; ++m) { st_at(p, b, o + 3 + 2 * m, k) = w[m].x; st_at(p, b, o + 4 + 2 * m, k) = w[m].y; }
+    }
+}
+
 // dispatch one (b, k) of an operator
 DS_HD void run_op(int op, const OpParams& p, int b, int k) {
     if (op == OP_MCRA) op_mcra(p, b, k);
     else if (op == OP_OMLSA) op_omlsa(p, b, k);
     else if (op == OP_SUBLMS) op_sublms(p, b, k);
     else if (op == OP_SUBRLS) op_subrls(p, b, k);
-    else if (op == OP_MCMCRA) {
+    else if (op == OP_MCSPPBASE) {
+        switch (p.M) {
+            case 2: op_mcsppbase<2>(p, b, k); break;
+            case 4: op_mcsppbase<4>(p, b, k); break;
+            case 6: op_mcsppbase<6>(p, b, k); break;
+            case 8: op_mcsppbase<8>(p, b, k); break;
+            default: break;
+        }
+    } else if (op == OP_MCMCRA) {
         switch (p.M) {
             case 2: op_mcmcra<2>(p, b, k); break;
             case 4: op_mcmcra<4>(p, b, k); break;

@@ -142,6 +142,14 @@ class BatchEngine:
         L.check(self._lib.ds_mcmcra_estimate(self._h, self._p(y), int(y.shape[1]), self._p(p), self._p(G), L.MEM_HOST), self._h)
         return p, G
 
+    def mcsppbase_estimate(self, y):
+        """y complex [B, T, K, M] -> (p [B, T, K], w complex [B, T, K, M])."""
+        y = np.ascontiguousarray(y, dtype=np.complex64)
+        p = np.empty(y.shape[:3], dtype=np.float32)
+        w = np.empty(y.shape, dtype=np.complex64)
+        L.check(self._lib.ds_mcsppbase_estimate(self._h, self._p(y), int(y.shape[1]), self._p(p), self._p(w), L.MEM_HOST), self._h)
+        return p, w
+
     def omlsa_estimate(self, y, u):
         """y [B, T, K], u [B, T, K, M-1] powers -> (lambda_d, G, p) [B, T, K]."""
         y = np.ascontiguousarray(y, dtype=np.float32)

@@ -160,6 +160,53 @@ class McMcra(_Base):
     frm_cnt = property(lambda s: int(s._eng.get_field(L.FIELD_COUNTERS)[0, 0]))
 
 
+class McSppBase(_Base):
+    """Multichannel SPP with MCRA prior + PMWF weights — noise_estimation/mcspp_base.py:28-324."""
+
+    def __init__(self, nfft=256, channels=4, batch=1, device=-1):
+        self.nfft, self.half_bin, self.channels, self.batch = nfft, int(nfft / 2 + 1), channels, int(batch)
+        self._eng = BatchEngine(L.ALGO_MCSPPBASE, channels, nfft, batch=batch, device=device)
+        self._o = 2 * channels * channels + 5
+
+    def estimation(self, y):
+        """y complex [half_bin, channels] -> p [half_bin]; PMWF weights in `w` [half_bin, channels]."""
+        y = self._add_batch(y, 2)
+        p, w = self._eng.mcsppbase_estimate(y[:, None, :, :])
+        self._w = w[:, 0].astype(np.complex128)
+        return self._sq(p[:, 0, :].astype(np.float64))
+
+    def _row(self, f):
+        return self._sq(self._eng.op_state()[:, f, :].astype(np.float64))
+
+    def _herm(self, base):
+        st = self._eng.op_state().astype(np.float64)
+        M = self.channels
+        out = np.zeros((self.batch, self.half_bin, M, M), dtype=complex)
+        q = 0
+        for i in range(M):
+            out[:, :, i, i] = st[:, base + i, :]
+        for i in range(M):
+            for j in range(i + 1, M):
+                v = st[:, base + M + 2 * q, :] + 1j * st[:, base + M + 2 * q + 1, :]
+                out[:, :, i, j] = v
+                out[:, :, j, i] = np.conj(v)
+                q += 1
+        return self._sq(out)                                               # [half_bin, M, M] like the reference
+
+    Phi_yy = property(lambda s: s._herm(0))
+    Phi_vv = property(lambda s: s._herm(s.channels * s.channels))
+    xi = property(lambda s: s._row(s._o + 0))
+    gamma = property(lambda s: s._row(s._o + 1))
+    p = property(lambda s: s._row(s._o + 2))
+    w = property(lambda s: s._sq(s._w))
+
+    @property
+    def Phi_vv_inv(self):
+        """inv(Re(Phi_vv) + 1e-6 I) (mcspp_base.py:277-279), derived on the host on demand."""
+        R = np.real(self._herm(self.channels * self.channels))
+        return np.linalg.inv(R + np.eye(self.channels) * 1e-6).astype(complex)
+
+
 class NsOmlsaMulti(_Base):
     """Multichannel (TBRR) OMLSA noise estimate and gain — noise_estimation/omlsa_multi.py:27-156."""
 

@@ -26,7 +26,7 @@ import numpy as np
 __all__ = [
     "sqrt_hann", "OracleTransform", "OracleMicArray", "compute_tau", "gen_noise_msc",
     "steering_from_doa", "fixed_weights", "circular_tao", "OracleMCRA", "OracleAdaptiveMVDR",
-    "OracleFixedBeamformer", "OracleMcMcra", "OracleOmlsaMulti", "OracleGSC",
+    "OracleFixedBeamformer", "OracleMcMcra", "OracleMcSppBase", "OracleOmlsaMulti", "OracleGSC",
     "OracleSubbandLMS", "OracleSubbandLmsMc", "OracleSubbandRLS", "synth_utterance",
 ]
 
@@ -434,6 +434,49 @@ class OracleMcMcra:
         G[:2] = 0
         self.G = G.astype(rt)
         self.frm_cnt += 1
+
+
+class OracleMcSppBase:
+    """McSppBase.estimation + compute_pmwf_weight — noise_estimation/mcspp_base.py:28-324."""
+
+    def __init__(self, nfft=256, channels=4):
+        self.M = channels
+        self.half_bin = int(nfft / 2 + 1)
+        K, M = self.half_bin, channels
+        self.alpha_d, self.alpha = 0.92, 0.92                                # :37,39
+        self.p = np.zeros(K)
+        self.q = np.ones(K) * 0.6
+        self.w = np.zeros((K, M), dtype=complex)
+        self.Phi_yy = np.zeros((K, M, M), dtype=complex)
+        self.Phi_vv = np.zeros((K, M, M), dtype=complex)
+        self.Phi_vv_inv = np.zeros((K, M, M), dtype=complex)
+        self.Phi_xx = np.zeros((K, M, M), dtype=complex)
+        self.xi = np.zeros(K)
+        self.gamma = np.zeros(K)
+        self.mcra = OracleMCRA(nfft=nfft, L=15)                              # :75-76
+        self.frm_cnt = 0
+
+    def estimation(self, y):
+        M = self.M
+        y = np.asarray(y, dtype=complex)
+        psd_yy = np.einsum('ij,il->ijl', y, y.conj())                        # :88
+        self.Phi_yy = self.alpha * self.Phi_yy + (1 - self.alpha) * psd_yy   # :90
+        self.Phi_xx = self.Phi_yy - self.Phi_vv                              # :275
+        inv = np.linalg.inv(self.Phi_vv.real + np.eye(M) * 1e-6)             # :277-279
+        self.Phi_vv_inv = inv.astype(complex)
+        xi = np.trace(inv @ self.Phi_xx.real, axis1=-2, axis2=-1)            # :281
+        g = (y[:, None, :].conj() @ inv @ self.Phi_xx.real @ inv @ y[:, :, None]).real.squeeze()   # :283-285
+        self.xi = np.minimum(np.maximum(xi, 1e-6), 1e6)
+        self.gamma = np.minimum(np.maximum(g, 1e-6), 1e6)
+        self.mcra.estimation(np.abs(y[:, 0] * np.conj(y[:, 0])))             # compute_q :113-118
+        self.q = np.minimum(np.maximum(np.sqrt(1 - self.mcra.p), 0.01), 0.99)
+        p = 1 / (1 + self.q / (1 - self.q) * (1 + self.xi) * np.exp(-1 * (self.gamma / (1 + self.xi))))   # :133
+        self.p = np.minimum(np.maximum(p, 0.01), 0.99)
+        at = (self.alpha_d + (1 - self.alpha_d) * self.p)[:, None, None]     # :314
+        self.Phi_vv = at * self.Phi_vv + (1 - at) * psd_yy                   # :319-321
+        self.w = (self.Phi_vv_inv @ self.Phi_xx)[:, :, 0] / (1 + self.xi[:, None])   # :238-240 (u = e_0, beta = 1)
+        self.frm_cnt += 1
+        return self.p
 
 
 # --------------------------------------------------------------------------------------------

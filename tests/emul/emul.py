@@ -107,12 +107,13 @@ class EmulTransform:
 
 class EmulOp:
     """One frame-level operator handle (state + uniform counters), mirrors run_binop() in ds_api.hip."""
-    OPS = {"mcra": 0, "mcmcra": 1, "omlsa": 2, "sublms": 3, "subrls": 4}
+    OPS = {"mcra": 0, "mcmcra": 1, "omlsa": 2, "sublms": 3, "subrls": 4, "mcsppbase": 5}
 
     def __init__(self, op, nfft, M=1, N=2, batch=1, mu=None, alpha=0.9, lam=0.998, norm=1, L=15):
         self.op, self.B, self.K, self.M, self.N = self.OPS[op], batch, nfft // 2 + 1, M, N
         self.KP = (self.K + 3) & ~3
-        self.NF = {0: 5, 1: M * (M + 1) + 4, 2: 5 * M + (M - 1) + 8, 3: 4 * N * M + 1, 4: 4 * N + 2 * N * N}[self.op]
+        self.NF = {0: 5, 1: M * (M + 1) + 4, 2: 5 * M + (M - 1) + 8, 3: 4 * N * M + 1, 4: 4 * N + 2 * N * N,
+                   5: 2 * M * M + 8 + 2 * M}[self.op]
         self.st = np.zeros((batch, self.NF, self.KP), dtype=np.float32)
         if self.op == 2:
             o = 5 * M + 1 + (M - 1)
@@ -125,10 +126,14 @@ class EmulOp:
         self.mu = mu if mu is not None else (0.5 if self.op == 4 else 0.1)
         self.alpha, self.lam, self.norm = alpha, lam, norm
 
-    def run(self, in0, in1=None, in2=None, n_out=1, out_complex=False, in_complex=0):
+    def run(self, in0, in1=None, in2=None, n_out=1, out_complex=False, in_complex=0, out_shapes=None):
         in0 = np.ascontiguousarray(in0)
         T = in0.shape[1]
-        outs = [np.zeros((self.B, T, self.K), dtype=np.complex64 if out_complex else np.float32) for _ in range(n_out)]
+        if out_shapes is not None:
+            outs = [np.zeros((self.B, T, self.K) + tuple(sh), dtype=dt) for sh, dt in out_shapes]
+            n_out = len(outs)
+        else:
+            outs = [np.zeros((self.B, T, self.K), dtype=np.complex64 if out_complex else np.float32) for _ in range(n_out)]
         o = outs + [None] * (3 - n_out)
         f = ctypes.c_float
         rc = lib().emul_op(self.op, self.B, self.K, T, _vp(self.st), self.NF, _vp(in0), _vp(in1), _vp(in2), _vp(o[0]), _vp(o[1]),

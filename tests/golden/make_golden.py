@@ -48,6 +48,7 @@ from DistantSpeech.beamformer.GSC import GSC  # noqa: E402
 from DistantSpeech.beamformer.MicArray import MicArray  # noqa: E402
 from DistantSpeech.noise_estimation.mc_mcra import McMcra  # noqa: E402
 from DistantSpeech.noise_estimation.mcra import NoiseEstimationMCRA  # noqa: E402
+from DistantSpeech.noise_estimation.mcspp_base import McSppBase  # noqa: E402
 from DistantSpeech.noise_estimation.omlsa_multi import NsOmlsaMulti  # noqa: E402
 from DistantSpeech.transform.transform import Transform  # noqa: E402
 
@@ -306,6 +307,22 @@ def g8_subband():
          xm=xm, dm=dm, e_mc=e_m, W_mc=mc.W, P_mc=mc.P)
 
 
+def g9_mcsppbase(x16):
+    x = x16.astype(np.float32) / 32768.0
+    for name, xx, M in (("rec1", x, 4), ("synth_m6", synth(61, 6, 256 * 60), 6)):
+        tr = Transform(n_fft=512, hop_length=256, channel=M)
+        D = tr.stft(xx.T.astype(np.float64))
+        est = McSppBase(nfft=512, channels=M)
+        T = D.shape[1]
+        p = np.zeros((T, 257)); xi = np.zeros((T, 257)); w = np.zeros((T, 257, M), dtype=complex)
+        for n in range(T):
+            est.estimation(D[:, n, :])
+            p[n], xi[n], w[n] = est.p, est.xi, est.w
+        save("g9_mcsppbase_%s" % name, "McSppBase.estimation + compute_pmwf_weight mcspp_base.py:220-324 frame by frame",
+             x=(x16 if name == "rec1" else xx), p=p, xi=xi[::8], w=w[::4].astype(np.complex64), w_last=est.w, gamma=est.gamma,
+             Phi_vv=est.Phi_vv, Phi_yy=est.Phi_yy, mcra_p=est.mcra.p, params=np.array([M, 512, 256]))
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -322,6 +339,7 @@ def main():
     if want("g6"): g6_gsc(x16)
     if want("g7"): g7_omlsa()
     if want("g8"): g8_subband()
+    if want("g9"): g9_mcsppbase(x16)
 
 
 if __name__ == "__main__":

@@ -152,3 +152,19 @@ def test_batched_ops_match_single(ds):
         for t in range(T):
             one.estimation(y[b, t])
         assert np.array_equal(bigm.G[b], one.G) and np.array_equal(bigm.p[b], one.p)
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+def test_mcsppbase(ds, name):
+    g = load("g9_mcsppbase_" + name)
+    M, nfft, hop = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    D = ds.Transform(channel=M, n_fft=nfft, hop_length=hop).stft(x.T)
+    est = ds.McSppBase(nfft=nfft, channels=M)
+    p = np.stack([est.estimation(D[:, n, :]) for n in range(D.shape[1])])
+    assert np.mean(np.abs(p - g["p"]) > 2e-2) < 0.02 and np.median(np.abs(p - g["p"])) < 1e-4
+    assert est.w.shape == g["w_last"].shape
+    assert np.median(np.abs(est.w - g["w_last"])) < 1e-3 * np.median(np.abs(g["w_last"])) + 1e-5
+    ref = g["Phi_vv"]
+    assert rms(est.Phi_vv - ref) < 2e-2 * rms(ref)
+    assert est.Phi_vv_inv.shape == ref.shape

@@ -175,3 +175,17 @@ def test_emul_subband_golden():
     assert rms(e - g["e_mc"]) < 1e-5 * max(rms(g["e_mc"]), 1.0)
     W = (mc.st[0, 0:12:2, :257] + 1j * mc.st[0, 1:12:2, :257]).reshape(2, 3, 257)
     assert rms(np.transpose(W, (2, 0, 1)) - g["W_mc"]) < 1e-4 * rms(g["W_mc"])
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+def test_emul_mcsppbase_golden(name):
+    g = load("g9_mcsppbase_" + name)
+    M, nfft, hop = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    D = EmulTransform(nfft, M).stft(np.ascontiguousarray(x.T)[None], 0)
+    op = EmulOp("mcsppbase", nfft, M=M)
+    p, w = op.run(D, out_shapes=[((), np.float32), ((M,), np.complex64)])
+    assert np.mean(np.abs(p[0] - g["p"]) > 2e-2) < 0.02 and np.median(np.abs(p[0] - g["p"])) < 1e-4
+    wref = g["w"]
+    d = np.abs(w[0][::4] - wref)
+    assert np.median(d) < 1e-4 * max(np.median(np.abs(wref)), 1e-3) + 1e-5

@@ -165,3 +165,21 @@ def test_subband(golden):
     assert np.allclose(rls.W, g["W_rls"], rtol=1e-7, atol=1e-10)
     assert np.allclose(rls.P, g["P_rls"], rtol=1e-6, atol=1e-8)
     assert np.allclose(mc.W, g["W_mc"], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+def test_mcsppbase(golden, name):
+    g = golden("g9_mcsppbase_" + name)
+    M, nfft, hop = [int(v) for v in g["params"]]
+    x = g["x"]
+    if x.dtype == np.int16:
+        x = x.astype(np.float32) / 32768.0
+    D = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop).stft(x.T)
+    est = O.OracleMcSppBase(nfft=nfft, channels=M)
+    for n in range(D.shape[1]):
+        est.estimation(D[:, n, :])
+        assert np.allclose(est.p, g["p"][n], rtol=1e-6, atol=1e-9), n
+        if n % 8 == 0:
+            assert np.allclose(est.xi, g["xi"][n // 8], rtol=1e-6, atol=1e-9)
+    assert np.allclose(est.w, g["w_last"], rtol=1e-5, atol=1e-8)
+    assert np.allclose(est.Phi_vv, g["Phi_vv"], rtol=1e-9, atol=1e-14)
