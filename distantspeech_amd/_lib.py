@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("DSENH_LIB", os.path.join(_HERE, "libdsenh.so"))   # D
 
 DS_OK = 0
 ALGO_FIXED, ALGO_ADAPTIVE, ALGO_GSC = 0, 1, 2
-ALGO_TRANSFORM, ALGO_MCRA, ALGO_MCMCRA, ALGO_OMLSA, ALGO_SUBLMS, ALGO_SUBRLS, ALGO_MCSPPBASE = 3, 4, 5, 6, 7, 8, 9
+ALGO_TRANSFORM, ALGO_MCRA, ALGO_MCMCRA, ALGO_OMLSA, ALGO_SUBLMS, ALGO_SUBRLS, ALGO_MCSPPBASE, ALGO_WPE = 3, 4, 5, 6, 7, 8, 9, 10
 MEM_HOST, MEM_DEVICE = 0, 1
 METHOD_SRC, METHOD_DS, METHOD_MVDR, METHOD_TFGSC = 0, 1, 2, 3
 LAYOUT_SAMPLES_CHANNELS, LAYOUT_CHANNELS_SAMPLES = 0, 1
@@ -46,7 +46,7 @@ EXPORTS = [
     "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_device",
     "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcmcra_estimate", "ds_mcsppbase_estimate",
     "ds_omlsa_estimate",
-    "ds_sublms_update", "ds_subrls_update", "ds_synchronize",
+    "ds_sublms_update", "ds_subrls_update", "ds_wpe_update", "ds_synchronize",
     "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_export_state",
     "ds_import_state",
 ]
@@ -91,7 +91,8 @@ def load():
     for name, args in (("ds_stft", [vp, vp, ci, ci, vp, ci]), ("ds_istft", [vp, vp, ci, ci, vp, ci]),
                        ("ds_mcra_estimate", [vp, vp, ci, ci, vp, ci]), ("ds_mcmcra_estimate", [vp, vp, ci, vp, vp, ci]), ("ds_mcsppbase_estimate", [vp, vp, ci, vp, vp, ci]),
                        ("ds_omlsa_estimate", [vp, vp, vp, ci, vp, vp, vp, ci]),
-                       ("ds_sublms_update", [vp, vp, vp, vp, ci, vp, ci]), ("ds_subrls_update", [vp, vp, vp, ci, vp, ci])):
+                       ("ds_sublms_update", [vp, vp, vp, vp, ci, vp, ci]), ("ds_subrls_update", [vp, vp, vp, ci, vp, ci]),
+                       ("ds_wpe_update", [vp, vp, vp, ci, vp, ci])):
         getattr(lib, name).restype = ci
         getattr(lib, name).argtypes = args
     lib.ds_synchronize.restype = ci

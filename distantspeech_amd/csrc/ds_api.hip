@@ -113,6 +113,10 @@ int zero_state(ds_handle* h) {
             fill_row(o_s + 1, 1.0f); fill_row(o_s + 2, 1.0f); fill_row(o_s + 3, 1.0f); fill_row(o_s + 5, 1.0f); fill_row(o_s + 6, 1.0f);
             fill_row(5 * h->cfg.n_mics, 1.0f);             // zeta_Y = 1
         }
+        if (h->op == ds::OP_WPE) {                         // awpe.py:69-73: P = I * 1e-3
+            const int CN = h->cfg.n_mics * h->filter_len, oP = 2 * h->cfg.n_mics * CN + 2 * CN;
+            for (int i = 0; i < CN; ++i) fill_row(oP + 2 * (i * CN + i), 1e-3f);
+        }
         if (h->op == ds::OP_SUBRLS) {                      // SubbandRLS.py:40-42: P = I / 1e-3
             const int N = h->filter_len;
             for (int i = 0; i < N; ++i) fill_row(4 * N + 2 * (i * N + i), 1000.0f);
@@ -211,6 +215,11 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             break;
         case DS_ALGO_SUBRLS:
             if (flen <= ds::RLS_NMAX) { op = ds::OP_SUBRLS; NF = ds::subrls_nf(flen); }
+            break;
+        case DS_ALGO_WPE:
+            if (cfg->n_mics >= 1 && cfg->n_mics <= ds::WPE_CMAX && cfg->n_mics * flen <= ds::WPE_CNMAX) {
+                op = ds::OP_WPE; NF = ds::wpe_nf(cfg->n_mics, flen);
+            }
             break;
         default: return fail(nullptr, DS_EINVAL, "ds_create: unknown algo");
     }
@@ -665,6 +674,13 @@ int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames,
     const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
     IoSpec io = {{x, d, nullptr}, {n * 8, n * 8, 0}, {err, nullptr, nullptr}, {n * 8, 0, 0}};
     return run_binop(h, DS_ALGO_SUBRLS, "ds_subrls_update", n_frames, mem, io, 0, 0);
+}
+
+int ds_wpe_update(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem) {
+    if (!h || !x_delayed || !d || !err) return fail(h, DS_EINVAL, "ds_wpe_update: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K * h->cfg.n_mics;
+    IoSpec io = {{x_delayed, d, nullptr}, {n * 8, n * 8, 0}, {err, nullptr, nullptr}, {n * 8, 0, 0}};
+    return run_binop(h, DS_ALGO_WPE, "ds_wpe_update", n_frames, mem, io, 0, 0);
 }
 
 int ds_synchronize(ds_handle* h) {

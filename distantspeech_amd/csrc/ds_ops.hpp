@@ -13,7 +13,7 @@
 
 namespace ds {
 
-enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4, OP_MCSPPBASE = 5 };
+enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4, OP_MCSPPBASE = 5, OP_WPE = 6 };
 
 struct OpParams {
     int B, K, KP, T;          // utterances, bins, padded plane length, frames in this call
@@ -420,12 +420,79 @@ template <int M> DS_HD void op_mcsppbase(const OpParams& p, int b, int k) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// RLS-based online WPE, frequency-domain core of Wpe.update (dereverberation/awpe.py:129-192) on the STFT grid:
+// in0 = x_delayed complex [B][T][K][C] (the frame from `delay` hops ago), in1 = d complex [B][T][K][C] (current frame);
+// out0 = err complex [B][T][K][C] (dereverberated frame, all channels).
+// state floats: W [C][C*N] complex, input_buffer [C][N] complex, P [C*N][C*N] complex, var
+// ------------------------------------------------------------------------------------------------
+constexpr int WPE_CNMAX = 16, WPE_CMAX = 8;
+DS_HD int wpe_nf(int C, int N) { const int CN = C * N; return 2 * C * CN + 2 * CN + 2 * CN * CN + 1; }
+
+DS_HD void op_wpe(const OpParams& p, int b, int k) {
+    const int C = p.M, N = p.N, CN = C * N;
+    const int oX = 2 * C * CN, oP = oX + 2 * CN, oV = oP + 2 * CN * CN;
+    const float lam = p.lam, lam_inv = 1.0f / p.lam;
+    for (int t = 0; t < p.T; ++t) {
+        const long long fb = (((long long)b * p.T + t) * p.K + k) * C;
+        // buffer_input (:80-102): per channel shift along the taps, newest delayed frame at tap 0
+        for (int c = 0; c < C; ++c) {
+            for (int n = N - 1; n > 0; --n) {
+                st_at(p, b, oX + 2 * (c * N + n), k) = st_at(p, b, oX + 2 * (c * N + n - 1), k);
+                st_at(p, b, oX + 2 * (c * N + n) + 1, k) = st_at(p, b, oX + 2 * (c * N + n - 1) + 1, k);
+            }
+            st_at(p, b, oX + 2 * (c * N), k) = p.in0[2 * (fb + c)];
+            st_at(p, b, oX + 2 * (c * N) + 1, k) = p.in0[2 * (fb + c) + 1];
+        }
+        cf X[WPE_CNMAX], num[WPE_CNMAX], xhP[WPE_CNMAX], err[WPE_CMAX];
+        for (int i = 0; i < CN; ++i) X[i] = mk(st_at(p, b, oX + 2 * i, k), st_at(p, b, oX + 2 * i + 1, k));
+        float dpow = 0.0f;
+        for (int c = 0; c < C; ++c) {                                          // err = d - W^H X  (:158-161)
+            cf out = mk(0.0f, 0.0f);
+            for (int i = 0; i < CN; ++i)
+                out = cfmac(out, X[i], mk(st_at(p, b, 2 * (c * CN + i), k), st_at(p, b, 2 * (c * CN + i) + 1, k)));
+            const cf d = mk(p.in1[2 * (fb + c)], p.in1[2 * (fb + c) + 1]);
+            err[c] = csub(d, out);
+            dpow += cabs2(d);
+        }
+        float var = st_at(p, b, oV, k);
+        var = fma_(0.98f, var, (float)(1.0 - 0.98) * (dpow / (float)C));         // :163-165
+        st_at(p, b, oV, k) = var;
+        cf den = mk(lam * var, 0.0f);
+        for (int i = 0; i < CN; ++i) {
+            cf a = mk(0.0f, 0.0f), r = mk(0.0f, 0.0f);
+            for (int j = 0; j < CN; ++j) {
+                a = cfma(a, mk(st_at(p, b, oP + 2 * (i * CN + j), k), st_at(p, b, oP + 2 * (i * CN + j) + 1, k)), X[j]);   // (P X)_i
+                r = cfmac(r, mk(st_at(p, b, oP + 2 * (j * CN + i), k), st_at(p, b, oP + 2 * (j * CN + i) + 1, k)), X[j]);  // (X^H P)_i
+            }
+            num[i] = a; xhP[i] = r;
+            den = cfmac(den, a, X[i]);                                            // :174-180
+        }
+        for (int i = 0; i < CN; ++i) {
+            const cf kn = cdiv(num[i], den);
+            for (int j = 0; j < CN; ++j) {                                        // P = (P - kn (X^H P)) / lambda  :183-185
+                const int q = oP + 2 * (i * CN + j);
+                const cf pij = cfnma(mk(st_at(p, b, q, k), st_at(p, b, q + 1, k)), kn, xhP[j]);
+                st_at(p, b, q, k) = pij.x * lam_inv;
+                st_at(p, b, q + 1, k) = pij.y * lam_inv;
+            }
+            for (int c = 0; c < C; ++c) {                                         // W_c += conj(err_c) kn  :188-189
+                const cf g = cmulc(kn, err[c]);
+                st_at(p, b, 2 * (c * CN + i), k) += g.x;
+                st_at(p, b, 2 * (c * CN + i) + 1, k) += g.y;
+            }
+        }
+        for (int c = 0; c < C; ++c) { p.out0[2 * (fb + c)] = err[c].x; p.out0[2 * (fb + c) + 1] = err[c].y; }
+    }
+}
+
 // dispatch one (b, k) of an operator
 DS_HD void run_op(int op, const OpParams& p, int b, int k) {
     if (op == OP_MCRA) op_mcra(p, b, k);
     else if (op == OP_OMLSA) op_omlsa(p, b, k);
     else if (op == OP_SUBLMS) op_sublms(p, b, k);
     else if (op == OP_SUBRLS) op_subrls(p, b, k);
+    else if (op == OP_WPE) op_wpe(p, b, k);
     else if (op == OP_MCSPPBASE) {
         switch (p.M) {
             case 2: op_mcsppbase<2>(p, b, k); break;

@@ -176,6 +176,14 @@ class BatchEngine:
         L.check(self._lib.ds_subrls_update(self._h, self._p(x), self._p(d), int(d.shape[1]), self._p(err), L.MEM_HOST), self._h)
         return err
 
+    def wpe_update(self, xd, d):
+        """xd, d complex [B, T, K, C] -> err complex [B, T, K, C]."""
+        xd = np.ascontiguousarray(xd, dtype=np.complex64)
+        d = np.ascontiguousarray(d, dtype=np.complex64)
+        err = np.empty(d.shape, dtype=np.complex64)
+        L.check(self._lib.ds_wpe_update(self._h, self._p(xd), self._p(d), int(d.shape[1]), self._p(err), L.MEM_HOST), self._h)
+        return err
+
     def op_state(self):
         """raw operator state [B, NF, K] (rows documented in distantspeech_amd/ops.py)."""
         nbytes = self._lib.ds_field_bytes(self._h, L.FIELD_OP_STATE)

@@ -6,6 +6,7 @@
   NsOmlsaMulti          estimation(y, u) -> lambda_d          (noise_estimation/omlsa_multi.py:27-156)
   SubbandLMS / SubbandLmsMc / SubbandRLS   update(x_n, d_n, p=) -> (err, W)
                                                               (adaptivefilter/SubbandLMS.py, SubbandLmsMc.py, SubbandRLS.py)
+  Wpe                   update(x_n) -> (out, W)               (dereverberation/awpe.py:28-192, on the STFT grid)
 
 Every class accepts ``batch=B`` (default 1 = the reference's shapes; B > 1 adds a leading batch axis).
 All arithmetic runs on the GPU (fp32); the classes only reshape arrays between the reference's
@@ -379,3 +380,52 @@ class SubbandRLS(_SubbandBase):
         st = self._eng.op_state()[:, 4 * N: 4 * N + 2 * N * N, :].reshape(self.batch, N, N, 2, self.half_band)
         P = (st[:, :, :, 0, :] + 1j * st[:, :, :, 1, :]).astype(np.complex128)
         return self._sq(np.transpose(P, (0, 3, 1, 2)))                      # [half_band, N, N]
+
+
+class Wpe(_SubbandBase):
+    """RLS-based online WPE dereverberation — dereverberation/awpe.py:28-192.
+
+    The reference's Wpe does not run at HEAD (undefined check_input_data, awpe.py:150) and sits on the
+    Nyquist filterbank; this class implements the same equations on the STFT (Transform) grid with
+    check_input_data(xd, x) := (analysis(xd), analysis(x)) — the semantics the golden vectors g10 pin
+    (tests/golden/make_golden.py R6, R7).  update() returns the dereverberated channel 0 in the time domain."""
+
+    def __init__(self, channels=2, filter_len=2, num_bands=512, forgetting_factor=0.998, delay=4, mu=0.5,
+                 normalization=True, alpha=0.9, m=2, hop_length=None, input_td=False, batch=1, device=-1):
+        self.channels, self.filter_len, self.half_band, self.batch = channels, filter_len, int(num_bands / 2) + 1, int(batch)
+        self.hop_length = int(num_bands / 2) if hop_length is None else hop_length
+        self.D = delay
+        self.forgetting_factor = forgetting_factor
+        self._eng = BatchEngine(L.ALGO_WPE, channels, num_bands, batch=batch, device=device, filter_len=filter_len,
+                                rls_lambda=forgetting_factor)
+        self.transform_d = Transform(channel=channels, n_fft=num_bands, hop_length=self.hop_length, batch=batch, device=device)
+        # x delayed by D*hop samples has the STFT frames of x from D calls ago (zero history before that)
+        self._ring = [np.zeros((self.batch, self.half_band, channels), dtype=np.complex64) for _ in range(delay)]
+
+    def update(self, x_n, alpha=1e-4, p=None):
+        """x_n [hop, channels] float -> (dereverberated channel 0 [hop], W [half_band, channels, channels*filter_len])."""
+        x = self._add_batch(x_n, 2)
+        if x.shape[1] != self.hop_length:
+            raise ValueError("Wpe.update takes one hop (%d samples) per call" % self.hop_length)
+        D = self.transform_d._eng.stft(x, L.LAYOUT_SAMPLES_CHANNELS)[:, 0]         # [B, K, C] current frame
+        self._ring.append(D)
+        Xd = self._ring.pop(0) if self.D > 0 else D
+        err = self._eng.wpe_update(Xd[:, None], D[:, None])                          # [B, 1, K, C]
+        y = self.transform_d._eng.istft(np.ascontiguousarray(err[:, :, :, :1]))      # channel 0 -> [B, hop, 1]
+        out = y[:, :, 0].astype(np.float64)
+        return self._sq(out), self.W
+
+    @property
+    def W(self):
+        C, CN = self.channels, self.channels * self.filter_len
+        st = self._eng.op_state()[:, : 2 * C * CN, :].reshape(self.batch, C, CN, 2, self.half_band)
+        W = (st[:, :, :, 0, :] + 1j * st[:, :, :, 1, :]).astype(np.complex128)
+        return self._sq(np.transpose(W, (0, 3, 1, 2)))                               # [half_band, C, C*N]
+
+    @property
+    def P(self):
+        C, CN = self.channels, self.channels * self.filter_len
+        o = 2 * C * CN + 2 * CN
+        st = self._eng.op_state()[:, o: o + 2 * CN * CN, :].reshape(self.batch, CN, CN, 2, self.half_band)
+        P = (st[:, :, :, 0, :] + 1j * st[:, :, :, 1, :]).astype(np.complex128)
+        return self._sq(np.transpose(P, (0, 3, 1, 2)))

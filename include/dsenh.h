@@ -64,6 +64,7 @@ extern "C" {
 #define DS_ALGO_OMLSA 6      /* NsOmlsaMulti.estimation              noise_estimation/omlsa_multi.py:73-156 */
 #define DS_ALGO_SUBLMS 7     /* SubbandLMS (n_mics=1) / SubbandLmsMc (n_mics=C) .update   adaptivefilter/SubbandLMS.py, SubbandLmsMc.py */
 #define DS_ALGO_SUBRLS 8     /* SubbandRLS.update                    adaptivefilter/SubbandRLS.py:44-71 */
+#define DS_ALGO_WPE 10       /* Wpe.update frequency-domain core (RLS-WPE on the STFT grid)  dereverberation/awpe.py:129-192 */
 #define DS_ALGO_MCSPPBASE 9  /* McSppBase.estimation + PMWF weights  noise_estimation/mcspp_base.py:220-324 */
 
 /* `mem` argument of the frame-level entry points */
@@ -182,7 +183,9 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
  *   ds_mcsppbase_estimate y complex [B][T][K][M] -> p [B][T][K], w complex [B][T][K][M] (PMWF weights)
  *   ds_omlsa_estimate  y [B][T][K], u [B][T][K][M-1] powers -> lambda_d, G, p [B][T][K]
  *   ds_sublms_update   x complex [B][T][K][C], d complex [B][T][K], p [B][T][K] or NULL -> err complex [B][T][K]
- *   ds_subrls_update   x complex [B][T][K], d complex [B][T][K] -> err complex [B][T][K]                        */
+ *   ds_subrls_update   x complex [B][T][K], d complex [B][T][K] -> err complex [B][T][K]
+ *   ds_wpe_update      x_delayed complex [B][T][K][C], d complex [B][T][K][C] -> err complex [B][T][K][C]
+ *                      (n_mics = C channels, filter_len = taps; the caller supplies the `delay`-hops-old frame)    */
 int ds_stft(ds_handle* h, const float* x, int layout, int n_samples, float* Y, int mem);
 int ds_istft(ds_handle* h, const float* Y, int n_frames, int n_channels, float* y, int mem);
 int ds_mcra_estimate(ds_handle* h, const float* Y, int is_complex, int n_frames, float* lambda_d, int mem);
@@ -191,6 +194,7 @@ int ds_mcsppbase_estimate(ds_handle* h, const float* y, int n_frames, float* p, 
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem);
 int ds_sublms_update(ds_handle* h, const float* x, const float* d, const float* p, int n_frames, float* err, int mem);
 int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames, float* err, int mem);
+int ds_wpe_update(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem);
 
 int ds_synchronize(ds_handle* h);
 

@@ -27,7 +27,7 @@ __all__ = [
     "sqrt_hann", "OracleTransform", "OracleMicArray", "compute_tau", "gen_noise_msc",
     "steering_from_doa", "fixed_weights", "circular_tao", "OracleMCRA", "OracleAdaptiveMVDR",
     "OracleFixedBeamformer", "OracleMcMcra", "OracleMcSppBase", "OracleOmlsaMulti", "OracleGSC",
-    "OracleSubbandLMS", "OracleSubbandLmsMc", "OracleSubbandRLS", "synth_utterance",
+    "OracleSubbandLMS", "OracleSubbandLmsMc", "OracleSubbandRLS", "OracleWpe", "synth_utterance",
 ]
 
 
@@ -704,6 +704,60 @@ class OracleSubbandRLS:
         self.P = (self.P - kn[..., None] @ X[:, None, :].conj() @ self.P) * self.lam_inv   # :63
         self.W = self.W + 2 * self.mu * (err[:, None].conj() * kn)           # :65-66
         return err, self.W
+
+
+# --------------------------------------------------------------------------------------------
+# dereverberation/awpe.py — PARITY UNPINNED BY THE REFERENCE AS SHIPPED: Wpe.update calls an undefined
+# check_input_data (awpe.py:150) and is built on the Subband filterbank.  This restates the equations on the
+# STFT (Transform) grid with check_input_data(xd, x) := (analysis(xd), analysis(x)), return_td = True
+# (the analogue of SubbandAF.update_input_data, SubbandAF.py:53-60) — SURVEY §8a-21's build decision.  The golden
+# vectors (g10) come from the reference with exactly these two patches applied (make_golden.py R6, R7).
+# --------------------------------------------------------------------------------------------
+class OracleWpe:
+    """Wpe.update — dereverberation/awpe.py:28-192 (on the STFT grid, see above)."""
+
+    def __init__(self, channels=2, filter_len=2, num_bands=512, forgetting_factor=0.998, delay=4, hop_length=None):
+        self.C, self.N = channels, filter_len
+        self.half_band = int(num_bands / 2) + 1
+        self.hop = int(num_bands / 2) if hop_length is None else hop_length
+        K, C, N = self.half_band, channels, filter_len
+        self.input_buffer = np.zeros((K, C, N), dtype=complex)                    # :58
+        self.W = np.zeros((K, C, C * N), dtype=complex)                           # :61
+        self.lam, self.lam_inv = forgetting_factor, 1.0 / forgetting_factor
+        self.P = np.tile(np.eye(C * N, dtype=complex) * 1e-3, (K, 1, 1))          # :69-73
+        self.D = delay
+        self.delay_buf = np.zeros((delay * self.hop, C))                          # DelaySamples(hop, D*hop) :75-76
+        self.var = np.zeros((K, 1))
+        self.transform_x = OracleTransform(channel=C, n_fft=num_bands, hop_length=self.hop)
+        self.transform_d = OracleTransform(channel=C, n_fft=num_bands, hop_length=self.hop)
+
+    def update_fd(self, x_delayed, d_n):
+        """frequency-domain core: x_delayed, d_n [K, C] -> err [K, C]  (:152-189)."""
+        K, C, N = self.half_band, self.C, self.N
+        if N > 1:
+            self.input_buffer[:, :, 1:] = self.input_buffer[:, :, :-1].copy()     # :96-100
+        self.input_buffer[:, :, 0] = x_delayed
+        X = np.reshape(self.input_buffer, (K, -1))                                # :154
+        err = d_n - np.einsum('kmi, ki->km', self.W.conj(), X)                    # :156-159
+        var_n = np.abs(np.einsum('ij, ij->i', d_n.conj(), d_n)) / C               # :162
+        self.var = 0.98 * self.var + (1 - 0.98) * var_n[:, None]                  # :163
+        num = np.einsum('kij, kj->ki', self.P, X)                                 # :172
+        kn = num / (self.lam * self.var + np.sum(X.conj() * num, axis=-1, keepdims=True))   # :173-178
+        self.P = (self.P - np.einsum('ij,il,ilk->ijk', kn, X.conj(), self.P)) * self.lam_inv   # :181-183
+        for ch in range(C):
+            self.W[:, ch, :] = self.W[:, ch, :] + err[:, ch:ch + 1].conj() * kn   # :186-187
+        return err
+
+    def update(self, x_n):
+        """x_n [hop, C] float -> dereverberated channel 0 [hop]  (:129-192)."""
+        x_n = np.asarray(x_n, dtype=np.float64)
+        buf = np.vstack((self.delay_buf, x_n))
+        xd = buf[: x_n.shape[0]].copy()                                           # delayed by D*hop samples
+        self.delay_buf = buf[x_n.shape[0]:].copy()
+        Xd = self.transform_x.stft(xd)[:, 0, :]
+        Dn = self.transform_d.stft(x_n)[:, 0, :]
+        err = self.update_fd(Xd, Dn)
+        return np.atleast_1d(self.transform_d.istft(err[:, 0])), self.W
 
 
 # --------------------------------------------------------------------------------------------

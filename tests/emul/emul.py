@@ -107,18 +107,23 @@ class EmulTransform:
 
 class EmulOp:
     """One frame-level operator handle (state + uniform counters), mirrors run_binop() in ds_api.hip."""
-    OPS = {"mcra": 0, "mcmcra": 1, "omlsa": 2, "sublms": 3, "subrls": 4, "mcsppbase": 5}
+    OPS = {"mcra": 0, "mcmcra": 1, "omlsa": 2, "sublms": 3, "subrls": 4, "mcsppbase": 5, "wpe": 6}
 
     def __init__(self, op, nfft, M=1, N=2, batch=1, mu=None, alpha=0.9, lam=0.998, norm=1, L=15):
         self.op, self.B, self.K, self.M, self.N = self.OPS[op], batch, nfft // 2 + 1, M, N
         self.KP = (self.K + 3) & ~3
         self.NF = {0: 5, 1: M * (M + 1) + 4, 2: 5 * M + (M - 1) + 8, 3: 4 * N * M + 1, 4: 4 * N + 2 * N * N,
-                   5: 2 * M * M + 8 + 2 * M}[self.op]
+                   5: 2 * M * M + 8 + 2 * M,
+                   6: 2 * M * M * N + 2 * M * N + 2 * (M * N) ** 2 + 1}[self.op]
         self.st = np.zeros((batch, self.NF, self.KP), dtype=np.float32)
         if self.op == 2:
             o = 5 * M + 1 + (M - 1)
             for f in (o + 1, o + 2, o + 3, o + 5, o + 6, 5 * M):
                 self.st[:, f, :] = 1.0
+        if self.op == 6:
+            CN = M * N
+            for i in range(CN):
+                self.st[:, 2 * M * CN + 2 * CN + 2 * (i * CN + i), :] = 1e-3
         if self.op == 4:
             for i in range(N):
                 self.st[:, 4 * N + 2 * (i * N + i), :] = 1000.0

@@ -18,6 +18,10 @@ Repairs applied to broken reference entry points, each recorded
   R4  SD weights at 512-FFT via the base class beamformer.compute_weights(weightType='SD')
       (FixedBeamformer.compute_weights calls gen_noise_msc with nfft=256: shape error).
   R5  stray prints silenced (fixedbeamformer.py:68-74).
+  R6  Wpe (g10 only): `awpe.Subband := Transform` — the reference builds Wpe on its Nyquist filterbank whose
+      design does not terminate at the sizes of interest; the STFT grid is used instead.
+  R7  Wpe (g10 only): `Wpe.check_input_data(xd, x)` is undefined at HEAD (awpe.py:150); defined here as the
+      analogue of SubbandAF.update_input_data (SubbandAF.py:53-60): analyse both signals, set return_td = True.
 Third-party versions at generation time are recorded in every fixture.
 """
 import contextlib
@@ -323,6 +327,35 @@ def g9_mcsppbase(x16):
              Phi_vv=est.Phi_vv, Phi_yy=est.Phi_yy, mcra_p=est.mcra.p, params=np.array([M, 512, 256]))
 
 
+def g10_wpe():
+    from DistantSpeech.dereverberation import awpe
+    awpe.Subband = Transform                                                              # R6
+
+    def check_input_data(self, xd, x):                                                    # R7
+        self.return_td = True
+        return np.squeeze(self.transform_x.analysis(xd)), np.squeeze(self.transform_d.analysis(x))
+
+    awpe.Wpe.check_input_data = check_input_data
+    rng = np.random.default_rng(71)
+    for name, C, N, D, nb in (("c4n2", 4, 2, 2, 256), ("c2n3", 2, 3, 1, 512)):
+        hop = nb // 2
+        T = 50
+        s0 = rng.standard_normal(hop * T + 4000) * 0.1
+        h = rng.standard_normal((C, 3000)) * np.exp(-np.arange(3000) / 600.0)[None, :] * 0.2
+        h[:, 0] = 1.0
+        x = np.stack([np.convolve(s0, h[c])[: hop * T] for c in range(C)], axis=1)
+        x = (x + 0.01 * rng.standard_normal(x.shape)).astype(np.float32)
+        with contextlib.redirect_stdout(io.StringIO()):
+            wpe = awpe.Wpe(filter_len=N, delay=D, channels=C, num_bands=nb, hop_length=hop)
+        outs = []
+        for n in range(T):
+            out, _ = wpe.update(x[n * hop:(n + 1) * hop].astype(np.float64))
+            outs.append(np.atleast_1d(out))
+        save("g10_wpe_%s" % name,
+             "Wpe.update awpe.py:129-192 hop-by-hop on the STFT grid; R6 R7 (PARITY UNPINNED by the reference as shipped)",
+             x=x, y=np.concatenate(outs), W=wpe.W, P=wpe.P, var=wpe.var, params=np.array([C, N, D, nb, hop]))
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -340,6 +373,7 @@ def main():
     if want("g7"): g7_omlsa()
     if want("g8"): g8_subband()
     if want("g9"): g9_mcsppbase(x16)
+    if want("g10"): g10_wpe()
 
 
 if __name__ == "__main__":

@@ -189,3 +189,18 @@ def test_emul_mcsppbase_golden(name):
     wref = g["w"]
     d = np.abs(w[0][::4] - wref)
     assert np.median(d) < 1e-4 * max(np.median(np.abs(wref)), 1e-3) + 1e-5
+
+
+@pytest.mark.parametrize("name", ["c4n2", "c2n3"])
+def test_emul_wpe_golden(name):
+    g = load("g10_wpe_" + name)
+    C, N, D, nb, hop = [int(v) for v in g["params"]]
+    x = g["x"]
+    T = x.shape[0] // hop
+    tf = EmulTransform(nb, C)
+    Dn = tf.stft(x[None], 0)                                                   # [1, T, K, C]
+    Xd = np.concatenate([np.zeros((1, D) + Dn.shape[2:], np.complex64), Dn[:, : T - D]], axis=1)
+    op = EmulOp("wpe", nb, M=C, N=N, lam=0.998)
+    err = op.run(Xd, Dn, out_shapes=[((C,), np.complex64)])[0]
+    y = tf.istft(np.ascontiguousarray(err[:, :, :, :1]))[0, :, 0]
+    assert rms(y - g["y"]) < 2e-4 * max(rms(g["y"]), 1e-3)

@@ -183,3 +183,16 @@ def test_mcsppbase(golden, name):
             assert np.allclose(est.xi, g["xi"][n // 8], rtol=1e-6, atol=1e-9)
     assert np.allclose(est.w, g["w_last"], rtol=1e-5, atol=1e-8)
     assert np.allclose(est.Phi_vv, g["Phi_vv"], rtol=1e-9, atol=1e-14)
+
+
+@pytest.mark.parametrize("name", ["c4n2", "c2n3"])
+def test_wpe(golden, name):
+    """parity pinned only against the *patched* reference (make_golden.py R6, R7): Wpe does not run as shipped."""
+    g = golden("g10_wpe_" + name)
+    C, N, D, nb, hop = [int(v) for v in g["params"]]
+    wpe = O.OracleWpe(channels=C, filter_len=N, num_bands=nb, delay=D, hop_length=hop)
+    x = g["x"]
+    y = np.concatenate([wpe.update(x[n:n + hop])[0] for n in range(0, x.shape[0], hop)])
+    assert rms(y - g["y"]) < 1e-7 * max(rms(g["y"]), 1e-3)
+    assert np.allclose(wpe.W, g["W"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(wpe.P, g["P"], rtol=1e-6, atol=1e-12)
