@@ -19,24 +19,36 @@ def shard_range(total, rank, world):
 
 
 def init(backend=None):
-    """init torch.distributed from the environment when WORLD_SIZE > 1; returns (rank, local_rank, world)."""
+    """Select this rank's GPU, then init torch.distributed from the environment when WORLD_SIZE > 1.
+    Returns (rank, local_rank, world).  Env overrides for single-GPU testing: DS_DIST_BACKEND (e.g. gloo),
+    DS_FORCE_DEVICE (ordinal every rank should use)."""
     rank, local_rank, world = env_world()
+    dev = int(os.environ.get("DS_FORCE_DEVICE", local_rank))
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.set_device(dev)          # before the process group exists: RCCL binds to the current device
+    except ImportError:
+        torch = None
     if world > 1:
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend is None:
-                import torch
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                backend = os.environ.get("DS_DIST_BACKEND") or ("nccl" if torch is not None and torch.cuda.is_available() else "gloo")
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    return rank, local_rank, world
+    return rank, dev, world
 
 
 def barrier():
+    import torch
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def reduce_throughput(frames, elapsed_s, device=None):
