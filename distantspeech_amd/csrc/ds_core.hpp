@@ -495,37 +495,38 @@ DS_HD void mcmcra_bin(float* pyy, float* pvv, const cf* Z, int k, int spp_frm_cn
             for (int q = j; q < M; ++q) t = fma_(Li[q][i], Li[q][j], t);
             iv[sym_index(i, j, M)] = t;
         }
-    // tr = trace(inv Phi_yy) ; psi = sum inv_ij yy_ij ; gamma = sum A_ij yy_ij, A = inv Phi_xx inv
+    // tr = trace(inv Phi_yy), psi = Re(y inv y^H) = sum inv_ij yy_ij, gamma = Re(y^H inv Phi_xx inv y) = v^H Phi_xx v
+    // with v = inv y (inv, Phi_* real symmetric): all three are weighted sums over the upper triangle.
     float tr = 0.0f, psi = 0.0f;
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int j = 0; j < M; ++j) {
-            const float e = sym_get<M>(iv, i, j);
-            tr = fma_(e, sym_get<M>(pyy, i, j), tr);
-            psi = fma_(e, sym_get<M>(yy, i, j), psi);
+        for (int j = i; j < M; ++j) {
+            const int q = sym_index(i, j, M);
+            const float e = (i == j) ? iv[q] : 2.0f * iv[q];
+            tr = fma_(e, pyy[q], tr);
+            psi = fma_(e, yy[q], psi);
         }
     float xi = fminf_(fmaxf_(tr - (float)M, 1e-6f), 1e6f);                               // :193-194
-    // B = Phi_xx inv  (M x M), A = inv B
-    float Bm[M][M];
+    cf v[M];
 #pragma unroll
-    for (int i = 0; i < M; ++i)
+    for (int i = 0; i < M; ++i) {
+        cf acc = mk(0.0f, 0.0f);
 #pragma unroll
         for (int j = 0; j < M; ++j) {
-            float t = 0.0f;
-#pragma unroll
-            for (int q = 0; q < M; ++q) t = fma_(sym_get<M>(pyy, i, q) - sym_get<M>(pvv, i, q), sym_get<M>(iv, q, j), t);
-            Bm[i][j] = t;
+            const float e = sym_get<M>(iv, i, j);
+            acc.x = fma_(e, Z[j].x, acc.x); acc.y = fma_(e, Z[j].y, acc.y);
         }
+        v[i] = acc;
+    }
     float gam = 0.0f;
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int j = 0; j < M; ++j) {
-            float t = 0.0f;
-#pragma unroll
-            for (int q = 0; q < M; ++q) t = fma_(sym_get<M>(iv, i, q), Bm[q][j], t);
-            gam = fma_(t, sym_get<M>(yy, i, j), gam);
+        for (int j = i; j < M; ++j) {
+            const int q = sym_index(i, j, M);
+            const float vv = fma_(v[i].x, v[j].x, v[i].y * v[j].y);                       // Re(conj(v_i) v_j)
+            gam = fma_((i == j) ? (pyy[q] - pvv[q]) : 2.0f * (pyy[q] - pvv[q]), vv, gam);
         }
     gam = fminf_(fmaxf_(gam, 1e-6f), 1e6f);                                               // :199
     // q_local :91-105
@@ -544,7 +545,7 @@ DS_HD void mcmcra_bin(float* pyy, float* pvv, const cf* Z, int k, int spp_frm_cn
     // gain :153-157
     const float Gmin = 0.0631f;
     const float gh1 = xi / (1.0f + xi);
-    float G = powf(gh1, pp) * powf(Gmin, 1.0f - pp);
+    float G = exp2f(fma_(pp, log2f(gh1), (1.0f - pp) * log2f(Gmin)));                      // G_H1^p Gmin^(1-p)
     G = fmaxf_(fminf_(G, 1.0f), Gmin);
     if (k < 2) G = 0.0f;
     p_out = pp; G_out = G; xi_out = xi; gamma_out = gam;

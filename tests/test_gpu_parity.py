@@ -210,3 +210,31 @@ def test_full_batch_properties(ds):
     for b in (3, 600):
         ref = O.OracleAdaptiveMVDR(omic, nfft).process(x[b], ANGLE, 2)
         assert rms(ym[b] - ref) < 1e-5
+
+
+def test_full_batch_properties_gsc(ds):
+    """BASELINE cfg3 size (GSC + LMS canceller + McMcra gain, B = 4096): batch independence, streaming == one-shot
+    (bitwise, state included), oracle spot checks."""
+    from distantspeech_amd import _lib as L
+    B, M, nfft, hop, T = 4096, 4, 512, 256, 24
+    omic = oracle_mic(M, nfft, 0.032)
+    base = np.stack([O.synth_utterance(200 + b, hop * T, omic) * 0.2 for b in range(8)]).astype(np.float32)
+    gains = np.random.default_rng(2).uniform(0.5, 1.5, size=(B, 1, 1)).astype(np.float32)
+    x = base[np.arange(B) % 8] * gains
+    a = steering(M, nfft, 0.032)
+    eng = ds.BatchEngine(L.ALGO_GSC, M, nfft, batch=B)
+    eng.set_steering(a); eng.set_method(2)
+    y = eng.process(x, 1)
+    assert np.all(np.isfinite(y))
+    idx = [0, 5, 2047, 4095]
+    small = ds.BatchEngine(L.ALGO_GSC, M, nfft, batch=len(idx))
+    small.set_steering(a); small.set_method(2)
+    assert np.array_equal(small.process(x[idx], 1), y[idx])
+    eng2 = ds.BatchEngine(L.ALGO_GSC, M, nfft, batch=B)
+    eng2.set_steering(a); eng2.set_method(2)
+    ys = np.concatenate([eng2.process(x[:, :, t * hop:(t + 1) * hop], 1) for t in range(T)], axis=1)
+    assert np.array_equal(ys, y)
+    assert np.array_equal(eng2.export_state(), eng.export_state())
+    for b in (3, 4000):
+        ref = O.OracleGSC(omic, nfft, with_dead_state=False).process(x[b], ANGLE, 2)
+        assert rms(y[b] - ref) < TOL_RMS
