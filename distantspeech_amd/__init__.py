@@ -6,8 +6,8 @@ from . import _lib
 from .engine import BatchEngine
 from .mic_array import MicArray, compute_tau, gen_noise_msc
 from .beamformer import beamformer, FixedBeamformer, adaptivebeamfomer, GSC, compute_mvdr_weight
-from .ops import Transform, NoiseEstimationMCRA, McMcra, McSppBase, NsOmlsaMulti, SubbandLMS, SubbandLmsMc, SubbandRLS, Wpe
+from .ops import Transform, NoiseEstimationMCRA, McMcra, McSppBase, McSpp, steering, NsOmlsaMulti, SubbandLMS, SubbandLmsMc, SubbandRLS, Wpe
 
 __all__ = ["BatchEngine", "MicArray", "compute_tau", "gen_noise_msc", "beamformer", "FixedBeamformer",
-           "adaptivebeamfomer", "GSC", "compute_mvdr_weight", "Transform", "NoiseEstimationMCRA", "McMcra", "McSppBase", "NsOmlsaMulti",
+           "adaptivebeamfomer", "GSC", "compute_mvdr_weight", "Transform", "NoiseEstimationMCRA", "McMcra", "McSppBase", "McSpp", "steering", "NsOmlsaMulti",
            "SubbandLMS", "SubbandLmsMc", "SubbandRLS", "Wpe"]

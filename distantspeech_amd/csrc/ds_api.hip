@@ -43,8 +43,9 @@ struct ds_handle {
     int op_frm, op_ell, op_first;   // uniform counters of the operator handle
     int filter_len, norm;
     float filt_mu, filt_alpha, rls_lambda;
-    float* dev_buf[7];          // staging for host-pointer frame-level calls (3 in, 1 scratch, 3 out)
-    size_t dev_buf_bytes[7];
+    float* dev_buf[10];         // staging for host-pointer frame-level calls (3 in, 1 scratch, 5 out, 1 aux table)
+    size_t dev_buf_bytes[10];
+    size_t aux_floats;
     // cached hipGraph of a ds_process_device_seq() sequence
     hipGraphExec_t graph_exec;
     int split;                  // DS_PARAM_SPLIT: utterance groups captured as parallel graph branches
@@ -101,7 +102,7 @@ int zero_state(ds_handle* h) {
     std::vector<int> c((size_t)h->cfg.batch * 4, 0);
     for (int b = 0; b < h->cfg.batch; ++b) c[(size_t)b * 4 + 1] = 1;
     DS_HIP(h, hipMemcpyAsync(h->counters, c.data(), counters_bytes(h), hipMemcpyHostToDevice, h->stream));
-    if (h->op >= 0) {
+    if (h->op >= 0 && h->NF > 0) {
         // operator state: zeros, except the rows the reference initialises to non-zero values
         std::vector<float> st((size_t)h->cfg.batch * h->NF * h->KP, 0.0f);
         auto fill_row = [&](int f, float v) {
@@ -207,6 +208,12 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
                 op = ds::OP_MCSPPBASE; NF = ds::mcsppbase_nf(cfg->n_mics);
             }
             break;
+        case DS_ALGO_MCSPP:
+            if (ds::op_supported(ds::OP_MCSPP, cfg->n_mics) && cfg->n_mics >= 3) { op = ds::OP_MCSPP; NF = ds::mcspp_nf(cfg->n_mics); }
+            break;
+        case DS_ALGO_LINALG:
+            if (ds::op_supported(ds::OP_STEERING, cfg->n_mics)) { op = ds::OP_STEERING; NF = 0; }
+            break;
         case DS_ALGO_OMLSA:
             if (cfg->n_mics >= 2 && cfg->n_mics <= 16) { op = ds::OP_OMLSA; NF = ds::omlsa_nf(cfg->n_mics); }
             break;
@@ -257,7 +264,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->filt_mu = cfg->filt_mu > 0 ? cfg->filt_mu : (cfg->algo == DS_ALGO_SUBRLS ? 0.5f : 0.1f);
     h->filt_alpha = cfg->filt_alpha > 0 ? cfg->filt_alpha : 0.9f;
     h->rls_lambda = cfg->rls_lambda > 0 ? cfg->rls_lambda : 0.998f;
-    for (int i = 0; i < 7; ++i) { h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0; }
+    for (int i = 0; i < 10; ++i) { h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0; }
+    h->aux_floats = 0;
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
     h->alpha_y = cfg->alpha_y > 0 ? cfg->alpha_y : 0.8f;
@@ -287,7 +295,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     DS_CRE(hipMalloc((void**)&h->tail_in, tail_in_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->tail_out, tail_out_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->counters, counters_bytes(h)));
-    if (h->op >= 0) DS_CRE(hipMalloc((void**)&h->opst, (size_t)cfg->batch * h->NF * h->KP * sizeof(float)));
+    if (h->op >= 0 && h->NF > 0) DS_CRE(hipMalloc((void**)&h->opst, (size_t)cfg->batch * h->NF * h->KP * sizeof(float)));
     const int N = cfg->nfft, NC = N / 2;
     DS_CRE(hipMalloc((void**)&h->steer, (size_t)h->K * cfg->n_mics * sizeof(cf)));
     {
@@ -310,7 +318,7 @@ int ds_destroy(ds_handle* h) {
     (void)hipFree(h->bins); (void)hipFree(h->tail_in); (void)hipFree(h->tail_out); (void)hipFree(h->counters);
     (void)hipFree(h->tables); (void)hipFree(h->steer);
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage); (void)hipFree(h->opst);
-    for (int i = 0; i < 7; ++i) (void)hipFree(h->dev_buf[i]);
+    for (int i = 0; i < 10; ++i) (void)hipFree(h->dev_buf[i]);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     for (int i = 0; i < 7; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -529,14 +537,15 @@ int stage_reserve(ds_handle* h, int i, size_t bytes) {
     return DS_OK;
 }
 
-struct IoSpec { const float* in[3]; size_t in_bytes[3]; float* out[3]; size_t out_bytes[3]; };
+struct IoSpec { const float* in[3]; size_t in_bytes[3]; float* out[5]; size_t out_bytes[5]; };
 
 // resolve host/device pointers: for DS_MEM_HOST copy inputs to staging and return device aliases
-int io_begin(ds_handle* h, int mem, const IoSpec& io, const float* din[3], float* dout[3]) {
-    for (int i = 0; i < 3; ++i) {
-        din[i] = io.in[i]; dout[i] = io.out[i];
+int io_begin(ds_handle* h, int mem, const IoSpec& io, const float* din[3], float* dout[5]) {
+    for (int i = 0; i < 5; ++i) {
+        if (i < 3) din[i] = io.in[i];
+        dout[i] = io.out[i];
         if (mem == DS_MEM_HOST) {
-            if (io.in[i]) {
+            if (i < 3 && io.in[i]) {
                 int rc = stage_reserve(h, i, io.in_bytes[i]); if (rc) return rc;
                 DS_HIP(h, hipMemcpyAsync(h->dev_buf[i], io.in[i], io.in_bytes[i], hipMemcpyHostToDevice, h->stream));
                 din[i] = h->dev_buf[i];
@@ -550,9 +559,9 @@ int io_begin(ds_handle* h, int mem, const IoSpec& io, const float* din[3], float
     return DS_OK;
 }
 
-int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[3]) {
+int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[5]) {
     if (mem == DS_MEM_HOST) {
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 5; ++i)
             if (io.out[i]) DS_HIP(h, hipMemcpyAsync(io.out[i], dout[i], io.out_bytes[i], hipMemcpyDeviceToHost, h->stream));
         DS_HIP(h, hipStreamSynchronize(h->stream));
     }
@@ -565,7 +574,7 @@ int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int me
     if (n_frames < 0) return fail(h, DS_ESHAPE, std::string(who) + ": n_frames < 0");
     if (n_frames == 0) return DS_OK;
     int rc = set_device(h); if (rc) return rc;
-    const float* din[3]; float* dout[3];
+    const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
@@ -598,7 +607,7 @@ int ds_stft(ds_handle* h, const float* x, int layout, int n_samples, float* Y, i
     int rc = set_device(h); if (rc) return rc;
     const size_t B = h->cfg.batch, M = h->cfg.n_mics, T = n_samples / h->cfg.hop;
     IoSpec io = {{x, nullptr, nullptr}, {B * M * (size_t)n_samples * 4, 0, 0}, {Y, nullptr, nullptr}, {B * T * h->K * M * 8, 0, 0}};
-    const float* din[3]; float* dout[3];
+    const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
     Params p;
     fill_params(h, p);
@@ -622,7 +631,7 @@ int ds_istft(ds_handle* h, const float* Y, int n_frames, int n_channels, float* 
     int rc = set_device(h); if (rc) return rc;
     const size_t B = h->cfg.batch, C = n_channels, T = n_frames;
     IoSpec io = {{Y, nullptr, nullptr}, {B * T * h->K * C * 8, 0, 0}, {y, nullptr, nullptr}, {B * T * h->cfg.hop * C * 4, 0, 0}};
-    const float* din[3]; float* dout[3];
+    const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
     Params p;
     fill_params(h, p);
@@ -653,6 +662,73 @@ int ds_mcsppbase_estimate(ds_handle* h, const float* y, int n_frames, float* p, 
     const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
     IoSpec io = {{y, nullptr, nullptr}, {n * h->cfg.n_mics * 8, 0, 0}, {p, w, nullptr}, {n * 4, n * h->cfg.n_mics * 8, 0}};
     return run_binop(h, DS_ALGO_MCSPPBASE, "ds_mcsppbase_estimate", n_frames, mem, io, 0, 0);
+}
+
+int ds_set_aux(ds_handle* h, const float* table, size_t n_floats) {
+    if (!h || !table || n_floats == 0) return fail(h, DS_EINVAL, "ds_set_aux: NULL argument");
+    int rc = set_device(h); if (rc) return rc;
+    rc = stage_reserve(h, 9, n_floats * sizeof(float)); if (rc) return rc;
+    DS_HIP(h, hipMemcpy(h->dev_buf[9], table, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    h->aux_floats = n_floats;
+    return DS_OK;
+}
+
+int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, float* w_pmwf, float* yout, float* phi_xx,
+                      float* phi_vv_inv, int mem) {
+    if (!h || !y || !p_out || !w_pmwf) return fail(h, DS_EINVAL, "ds_mcspp_estimate: NULL argument");
+    if (h->cfg.algo != DS_ALGO_MCSPP) return fail(h, DS_ESTATE, "ds_mcspp_estimate: handle was created for a different algo");
+    if ((phi_xx == nullptr) != (phi_vv_inv == nullptr)) return fail(h, DS_EINVAL, "ds_mcspp_estimate: phi_xx and phi_vv_inv go together");
+    if (h->aux_floats < (size_t)h->K) return fail(h, DS_ESTATE, "ds_mcspp_estimate: call ds_set_aux(h, Fn[K]) first");
+    if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_mcspp_estimate: n_frames < 0");
+    if (n_frames == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t n = (size_t)h->cfg.batch * n_frames * h->K, M = h->cfg.n_mics;
+    IoSpec io = {{y, nullptr, nullptr}, {n * M * 8, 0, 0}, {p_out, w_pmwf, yout, phi_xx, phi_vv_inv},
+                 {n * 4, n * M * 8, yout ? n * 8 : 0, phi_xx ? n * M * M * 8 : 0, phi_vv_inv ? n * M * M * 8 : 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    rc = stage_reserve(h, 3, n * 4); if (rc) return rc;                      // Gamma [B][T][K]
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames; p.st = h->opst; p.NF = h->NF; p.M = h->cfg.n_mics;
+    p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = 65;                      // mccdr.py:60-61
+    p.in0 = din[0]; p.in1 = h->dev_buf[9]; p.out0 = h->dev_buf[3];
+    DS_HIP(h, ds::launch_binop(ds::OP_MCCDR, p, h->stream));
+    p.in1 = h->dev_buf[3]; p.N = 9;
+    p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
+    DS_HIP(h, ds::launch_binop(ds::OP_MCSPP, p, h->stream));
+    for (int t = 0; t < n_frames; ++t) {
+        if (h->op_frm != 0 && h->op_ell % 65 == 0) h->op_ell = 0;
+        h->op_frm += 1; h->op_ell += 1;
+    }
+    return io_end(h, mem, io, dout);
+}
+
+static int run_linalg(ds_handle* h, int op, const char* who, const IoSpec& io, int mem) {
+    if (h->cfg.algo != DS_ALGO_LINALG) return fail(h, DS_ESTATE, std::string(who) + ": handle is not a DS_ALGO_LINALG object");
+    int rc = set_device(h); if (rc) return rc;
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = 1; p.M = h->cfg.n_mics;
+    p.in0 = din[0]; p.in1 = din[1]; p.out0 = dout[0];
+    DS_HIP(h, ds::launch_binop(op, p, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+int ds_steering(ds_handle* h, const float* XX, float* v, int mem) {
+    if (!h || !XX || !v) return fail(h, DS_EINVAL, "ds_steering: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
+    IoSpec io = {{XX, nullptr, nullptr}, {n * M * M * 8, 0, 0}, {v, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
+    return run_linalg(h, ds::OP_STEERING, "ds_steering", io, mem);
+}
+
+int ds_mvdr_weight(ds_handle* h, const float* steer, const float* Rinv, float* w, int mem) {
+    if (!h || !steer || !Rinv || !w) return fail(h, DS_EINVAL, "ds_mvdr_weight: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
+    IoSpec io = {{steer, Rinv, nullptr}, {n * M * 8, n * M * M * 8, 0}, {w, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
+    return run_linalg(h, ds::OP_MVDRW, "ds_mvdr_weight", io, mem);
 }
 
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem) {

@@ -48,18 +48,24 @@ KernelInfo lookup_istft(int nfft, int M) {
     return none;
 }
 
-__global__ void __launch_bounds__(256) ds_binop_kernel(int op, OpParams p) {
+template <int OP, int M> __global__ void __launch_bounds__(256) ds_binop_kernel(OpParams p) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int b = (int)(i / p.KP), k = (int)(i - (long long)b * p.KP);
     if (b >= p.B || k >= p.K) return;
-    run_op(op, p, b, k);
+    run_op_t<OP, M>(p, b, k);
 }
 
 hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream) {
     const long long total = (long long)p.B * p.KP;
     const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(ds_binop_kernel, dim3(blocks), dim3(256), 0, stream, op, p);
-    return hipGetLastError();
+#define X(OP_, M_)                                                                                         \
+    if (op == OP_ && (!op_is_matrix(OP_) || p.M == M_)) {                                                    \
+        hipLaunchKernelGGL((ds_binop_kernel<OP_, M_>), dim3(blocks), dim3(256), 0, stream, p);               \
+        return hipGetLastError();                                                                            \
+    }
+    DS_FOR_EACH_OP(X)
+#undef X
+    return hipErrorInvalidValue;
 }
 
 }  // namespace ds

@@ -13,7 +13,8 @@
 
 namespace ds {
 
-enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4, OP_MCSPPBASE = 5, OP_WPE = 6 };
+enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4, OP_MCSPPBASE = 5, OP_WPE = 6, OP_MCCDR = 7, OP_MCSPP = 8, OP_STEERING = 9,
+       OP_MVDRW = 10 };
 
 struct OpParams {
     int B, K, KP, T;          // utterances, bins, padded plane length, frames in this call
@@ -25,6 +26,8 @@ struct OpParams {
     float* out0;              // op-specific outputs (device)
     float* out1;
     float* out2;
+    float* out3;              // optional extra outputs (McSpp: Phi_xx, Phi_vv_inv as they stand at the end of estimation())
+    float* out4;
     int M;                    // channels: mics (McMcra), beam + references (OMLSA), filter channels (subband LMS)
     int N;                    // filter taps
     int frm_cnt, ell, L;      // MCRA counters before the first frame of the call (uniform over the batch)
@@ -486,30 +489,391 @@ DS_HD void op_wpe(const OpParams& p, int b, int k) {
     }
 }
 
-// dispatch one (b, k) of an operator
-DS_HD void run_op(int op, const OpParams& p, int b, int k) {
-    if (op == OP_MCRA) op_mcra(p, b, k);
-    else if (op == OP_OMLSA) op_omlsa(p, b, k);
-    else if (op == OP_SUBLMS) op_sublms(p, b, k);
-    else if (op == OP_SUBRLS) op_subrls(p, b, k);
-    else if (op == OP_WPE) op_wpe(p, b, k);
-    else if (op == OP_MCSPPBASE) {
-        switch (p.M) {
-            case 2: op_mcsppbase<2>(p, b, k); break;
-            case 4: op_mcsppbase<4>(p, b, k); break;
-            case 6: op_mcsppbase<6>(p, b, k); break;
-            case 8: op_mcsppbase<8>(p, b, k); break;
-            default: break;
-        }
-    } else if (op == OP_MCMCRA) {
-        switch (p.M) {
-            case 2: op_mcmcra<2>(p, b, k); break;
-            case 4: op_mcmcra<4>(p, b, k); break;
-            case 6: op_mcmcra<6>(p, b, k); break;
-            case 8: op_mcmcra<8>(p, b, k); break;
-            default: break;
+// ------------------------------------------------------------------------------------------------
+// Small complex-Hermitian linear algebra in registers (full M x M arrays; M <= 8)
+// ------------------------------------------------------------------------------------------------
+// inverse of the Hermitian positive-definite A (overwritten): Cholesky A = L L^H, Linv, inv = Linv^H Linv
+template <int M> DS_HD void herm_inverse(cf (&A)[M][M], cf (&inv)[M][M]) {
+    float invd[M];
+    cf L[M][M], Li[M][M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        float s = A[j][j].x;
+#pragma unroll
+        for (int q = 0; q < j; ++q) s = fma_(-L[j][q].x, L[j][q].x, fma_(-L[j][q].y, L[j][q].y, s));
+        s = fmaxf_(s, 1e-30f);
+        const float r = 1.0f / sqrtf(s);
+        invd[j] = r;
+#pragma unroll
+        for (int i = j + 1; i < M; ++i) {
+            cf a = A[i][j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) a = cfnmac(a, L[i][q], L[j][q]);
+            L[i][j] = cscale(a, r);
         }
     }
+#pragma unroll
+    for (int c = 0; c < M; ++c)
+#pragma unroll
+        for (int i = c; i < M; ++i) {
+            cf t = (i == c) ? mk(1.0f, 0.0f) : mk(0.0f, 0.0f);
+#pragma unroll
+            for (int q = c; q < i; ++q) t = cfnma(t, L[i][q], Li[q][c]);
+            Li[i][c] = cscale(t, invd[i]);
+        }
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = i; j < M; ++j) {
+            cf t = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int q = j; q < M; ++q) t = cfmac(t, Li[q][j], Li[q][i]);     // sum conj(Li_qi) Li_qj
+            inv[i][j] = t;
+            inv[j][i] = cconj(t);
+        }
+}
+
+// principal eigenvector (largest eigenvalue) of the Hermitian A by cyclic complex Jacobi, phase-normalised by
+// element 0 (beamformer/beamformer.py:10-31: np.linalg.eigh(...)[1][:, :, -1] / exp(j angle(v0)))
+template <int M> DS_HD void herm_principal(cf (&A)[M][M], cf* v) {
+    cf V[M][M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) V[i][j] = mk(i == j ? 1.0f : 0.0f, 0.0f);
+    for (int sweep = 0; sweep < 8; ++sweep) {
+#pragma unroll
+        for (int p = 0; p < M - 1; ++p)
+#pragma unroll
+            for (int q = p + 1; q < M; ++q) {
+                const cf apq = A[p][q];
+                const float mag2 = cabs2(apq);
+                if (mag2 > 1e-37f) {
+                    const float mag = sqrtf(mag2);
+                    const cf e = cscale(apq, 1.0f / mag);
+                    const float app = A[p][p].x, aqq = A[q][q].x;
+                    const float tau = (aqq - app) / (2.0f * mag);
+                    const float t = (tau >= 0.0f ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(fma_(tau, tau, 1.0f)));
+                    const float c = 1.0f / sqrtf(fma_(t, t, 1.0f)), sn = t * c;
+                    const cf se = cscale(e, sn);                                   // s e^{j phi}
+#pragma unroll
+                    for (int k = 0; k < M; ++k) {
+                        if (k != p && k != q) {
+                            const cf akp = A[k][p], akq = A[k][q];
+                            const cf np_ = cfnmac(cscale(akp, c), akq, se);        // c akp - s conj(e) akq
+                            const cf nq_ = cfma(cscale(akq, c), se, akp);          // s e akp + c akq
+                            A[k][p] = np_; A[k][q] = nq_;
+                            A[p][k] = cconj(np_); A[q][k] = cconj(nq_);
+                        }
+                    }
+                    A[p][p] = mk(fma_(-t, mag, app), 0.0f);
+                    A[q][q] = mk(fma_(t, mag, aqq), 0.0f);
+                    A[p][q] = mk(0.0f, 0.0f); A[q][p] = mk(0.0f, 0.0f);
+#pragma unroll
+                    for (int k = 0; k < M; ++k) {
+                        const cf vkp = V[k][p], vkq = V[k][q];
+                        V[k][p] = cfnmac(cscale(vkp, c), vkq, se);
+                        V[k][q] = cfma(cscale(vkq, c), se, vkp);
+                    }
+                }
+            }
+    }
+    int best = 0;
+    float wmax = A[0][0].x;
+#pragma unroll
+    for (int i = 1; i < M; ++i) if (A[i][i].x >= wmax) { wmax = A[i][i].x; best = i; }   // ties: the last one, like eigh's ascending order
+    cf v0 = mk(1.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < M; ++i) if (i == best) v0 = V[0][i];
+    const float n0 = sqrtf(cabs2(v0));
+    const cf ph = n0 > 0.0f ? cscale(cconj(v0), 1.0f / n0) : mk(1.0f, 0.0f);       // exp(-j angle(v0))
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        cf vk = mk(0.0f, 0.0f);
+#pragma unroll
+        for (int i = 0; i < M; ++i) if (i == best) vk = V[k][i];
+        v[k] = cmul(vk, ph);
+    }
+}
+
+// w = R^-1 a / (a^H R^-1 a)   (beamformer/beamformer.py:133-155)
+template <int M> DS_HD void mvdr_weight(const cf (&Rinv)[M][M], const cf* a, cf* w) {
+    cf num[M];
+    cf den = mk(0.0f, 0.0f);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        cf t = mk(0.0f, 0.0f);
+#pragma unroll
+        for (int j = 0; j < M; ++j) t = cfma(t, Rinv[i][j], a[j]);
+        num[i] = t;
+        den = cfmac(den, t, a[i]);                                                 // + conj(a_i) num_i
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) w[i] = cdiv(num[i], den);
+}
+
+template <int M> DS_HD void herm_unpack(const float* d, const float* o, cf (&A)[M][M]) {
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) A[i][j] = herm_get<M>(d, o, i, j);
+}
+
+// ------------------------------------------------------------------------------------------------
+// McCDR.estimation (noise_estimation/mccdr.py:122-177 + coherence/BinauralEnhancement.py:24-62), mic pair (1, 2):
+// in0 = y complex [B][T][K][M], in1 = Fn [K] (diffuse coherence of the pair); out0 = Gamma [B][T][K].
+// state floats: Pxii_1, Pxii_2, Re/Im Pxij_12, MCRA(5)
+// ------------------------------------------------------------------------------------------------
+DS_HD void op_mccdr(const OpParams& p, int b, int k) {
+    const int M = p.M;
+    float p1 = st_at(p, b, 0, k), p2 = st_at(p, b, 1, k);
+    cf x12 = mk(st_at(p, b, 2, k), st_at(p, b, 3, k));
+    float mc[5];
+#pragma unroll
+    for (int f = 0; f < 5; ++f) mc[f] = st_at(p, b, 4 + f, k);
+    int frm = p.frm_cnt, ell = p.ell;
+    const float Fn = p.in1[k], Fn2 = Fn * Fn;
+    for (int t = 0; t < p.T; ++t) {
+        const long long fb = ((long long)b * p.T + t) * p.K;
+        const long long base = (fb + k) * M;
+        const cf y0 = mk(p.in0[2 * base], p.in0[2 * base + 1]);
+        const cf y1 = mk(p.in0[2 * (base + 1)], p.in0[2 * (base + 1) + 1]);
+        const cf y2 = mk(p.in0[2 * (base + 2)], p.in0[2 * (base + 2) + 1]);
+        p1 = fma_(0.9f, p1, (float)(1.0 - 0.9) * cabs2(y1));                       // BinauralEnhancement.py:49-52
+        p2 = fma_(0.9f, p2, (float)(1.0 - 0.9) * cabs2(y2));
+        const cf c12 = cmulc(y1, y2);
+        x12 = mk(fma_(0.9f, x12.x, (float)(1.0 - 0.9) * c12.x), fma_(0.9f, x12.y, (float)(1.0 - 0.9) * c12.y));   // :55-61
+        const float rn = 1.0f / sqrtf(p1 * p2);
+        const cf Fx = cscale(x12, rn);                                             // updateMSC :28
+        const float Fx2 = cabs2(Fx);
+        const float rad = fma_(Fn2, Fx.x * Fx.x, -Fn2 * Fx2) + Fn2 - 2.0f * Fn * Fx.x + Fx2;
+        float G = (Fn * Fx.x - Fx2 - sqrtf(rad)) / fminf_(Fx2 - 1.0f, -1e-3f);     // mccdr.py:141-145
+        G = G * G;
+        if (G > 1.0f) G = 1.0f;                                                    // :160-161 (NaN stays NaN like numpy)
+        if (G < 0.0f) G = 1e-3f;
+        const bool reset = mcra_tick(frm, ell, p.L);
+        const float pw0 = cabs2(y0);
+        float ym = 0.0f, yp = 0.0f;
+        if (k > 0) { const long long q = (fb + k - 1) * M; ym = cabs2(mk(p.in0[2 * q], p.in0[2 * q + 1])); }
+        if (k < p.K - 1) { const long long q = (fb + k + 1) * M; yp = cabs2(mk(p.in0[2 * q], p.in0[2 * q + 1])); }
+        mcra_bin(mc, k, p.K, ym, pw0, yp, frm, reset, p.L);                        // :174 (L = 65)
+        frm += 1; ell += 1;
+        p.out0[fb + k] = sqrtf(G * mc[3]);                                         // :175
+    }
+    st_at(p, b, 0, k) = p1; st_at(p, b, 1, k) = p2; st_at(p, b, 2, k) = x12.x; st_at(p, b, 3, k) = x12.y;
+#pragma unroll
+    for (int f = 0; f < 5; ++f) st_at(p, b, 4 + f, k) = mc[f];
+}
+
+// ------------------------------------------------------------------------------------------------
+// McSpp.estimation (noise_estimation/mcspp.py:244-305) with the notebook's online MVDR (example/mvdr.ipynb cell 4:
+// steering(Phi_xx) -> compute_mvdr_weight(steer, Phi_vv_inv) -> sum conj(w) y) fused behind it:
+// in0 = y complex [B][T][K][M], in1 = Gamma [B][T][K] (op_mccdr);
+// out0 = p [B][T][K], out1 = w_pmwf complex [B][T][K][M], out2 = Yout complex [B][T][K] (optional),
+// out3 = Phi_xx, out4 = Phi_vv_inv complex [B][T][K][M][M] (optional).
+// state floats (row offset p.N): Phi_yy, Phi_vv Hermitian packed (M*M each), xi, gamma, p
+// ------------------------------------------------------------------------------------------------
+DS_HD int mcspp_nf(int M) { return 9 + 2 * M * M + 3; }
+
+template <int M> DS_HD void op_mcspp(const OpParams& p, int b, int k) {
+    constexpr int NO = M * (M - 1) / 2;
+    const int o0 = p.N;                                                            // state row offset of the McSpp part
+    float yd[M], yo[2 * NO + 1], vd[M], vo[2 * NO + 1];
+#pragma unroll
+    for (int f = 0; f < M; ++f) { yd[f] = st_at(p, b, o0 + f, k); vd[f] = st_at(p, b, o0 + M * M + f, k); }
+#pragma unroll
+    for (int f = 0; f < 2 * NO; ++f) { yo[f] = st_at(p, b, o0 + M + f, k); vo[f] = st_at(p, b, o0 + M * M + M + f, k); }
+    int frm = p.frm_cnt;
+    const int fmin = (int)(500.0 * (2 * (p.K - 1)) / 16000.0), fmax = (int)(2000.0 * (2 * (p.K - 1)) / 16000.0);   // :258-259
+    float xi = 0, gam = 0, pp = 0;
+    for (int t = 0; t < p.T; ++t) {
+        const long long fb = ((long long)b * p.T + t) * p.K;
+        const long long base = (fb + k) * M;
+        cf Z[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) Z[m] = mk(p.in0[2 * (base + m)], p.in0[2 * (base + m) + 1]);
+        float q = 1.0f - p.in1[fb + k];                                            // compute_q :113-116
+        float qsum = 0.0f;
+        for (int j = fmin; j < fmax; ++j) qsum += 1.0f - p.in1[fb + j];            // np.mean(q[fmin:fmax]) :260
+        const float q_avg = qsum / (float)(fmax - fmin);
+        const float dv = fma_(q_avg, 1e-1f, (1.0f - q_avg) * 1e-4f);               // :254-262
+        herm_rank1<M>(yd, yo, Z, 0.92f, (float)(1.0 - 0.92));                      // :264-266
+        if (frm < 10) {                                                            // :273-275
+#pragma unroll
+            for (int f = 0; f < M; ++f) vd[f] = yd[f];
+#pragma unroll
+            for (int f = 0; f < 2 * NO; ++f) vo[f] = yo[f];
+            q = 0.99f;
+        }
+        // estimation_core :201-242
+        cf Pyy[M][M], A[M][M], inv[M][M];
+        herm_unpack<M>(yd, yo, Pyy);
+        herm_unpack<M>(vd, vo, A);
+#pragma unroll
+        for (int i = 0; i < M; ++i) A[i][i].x += dv;
+        herm_inverse<M>(A, inv);
+        float tr = 0.0f;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) tr = fma_(inv[i][j].x, Pyy[i][j].x, fma_(inv[i][j].y, Pyy[i][j].y, tr));   // Re(inv_ij Pyy_ji)
+        if (tr - (float)M < 0.0f) {                                                // :219-228
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < M; ++j) A[i][j] = Pyy[i][j];
+            if (frm < 5) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) A[i][i].x += dv;
+            }
+            herm_inverse<M>(A, inv);
+            tr = 0.0f;
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < M; ++j) tr = fma_(inv[i][j].x, Pyy[i][j].x, fma_(inv[i][j].y, Pyy[i][j].y, tr));
+        }
+        xi = fminf_(fmaxf_(tr - (float)M, 1e-6f), 1e8f);                           // :230
+        cf v[M];
+        float yv = 0.0f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            cf acc = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < M; ++j) acc = cfma(acc, inv[i][j], Z[j]);
+            v[i] = acc;
+            yv = fma_(Z[i].x, acc.x, fma_(Z[i].y, acc.y, yv));                      // Re(conj(y_i) v_i)
+        }
+        float vPv = 0.0f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            cf acc = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < M; ++j) acc = cfma(acc, Pyy[i][j], v[j]);
+            vPv = fma_(v[i].x, acc.x, fma_(v[i].y, acc.y, vPv));                    // Re(conj(v_i) (Pyy v)_i)
+        }
+        gam = fminf_(fmaxf_(vPv - yv, 1e-6f), 1e8f);                               // :232-236
+        pp = 1.0f / (1.0f + q / (1.0f - q) * (1.0f + xi) * expf(-1.0f * (gam / (1.0f + xi))));   // compute_p :75-92
+        pp = fminf_(fmaxf_(pp, 0.0f), 1.0f);
+        // Phi_xx = Phi_yy - Phi_vv (before the noise update)
+        cf Pxx[M][M];
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) Pxx[i][j] = csub(Pyy[i][j], herm_get<M>(vd, vo, i, j));
+        // update_noise_psd (alpha_d = 0.92)
+        const float at = fma_((float)(1.0 - 0.92), pp, 0.92f);
+        herm_rank1<M>(vd, vo, Z, at, 1.0f - at);
+        const long long ob = fb + k;
+        p.out0[ob] = pp;
+        const float wsc = 1.0f / (10.0f + xi);                                     // compute_pmwf_weight beta = 10 :283
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            cf acc = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < M; ++j) acc = cfma(acc, inv[i][j], Pxx[j][0]);
+            p.out1[2 * (ob * M + i)] = acc.x * wsc; p.out1[2 * (ob * M + i) + 1] = acc.y * wsc;
+        }
+        if (p.out3) {
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < M; ++j) {
+                    const long long q2 = 2 * ((ob * M + i) * M + j);
+                    p.out3[q2] = Pxx[i][j].x; p.out3[q2 + 1] = Pxx[i][j].y;
+                    p.out4[q2] = inv[i][j].x; p.out4[q2 + 1] = inv[i][j].y;
+                }
+        }
+        if (p.out2) {                                                              // mvdr.ipynb cell 4
+            cf sv[M], w[M];
+            herm_principal<M>(Pxx, sv);
+            mvdr_weight<M>(inv, sv, w);
+            cf Y = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int m = 0; m < M; ++m) Y = cfmac(Y, Z[m], w[m]);
+            p.out2[2 * ob] = Y.x; p.out2[2 * ob + 1] = Y.y;
+        }
+        frm += 1;
+    }
+#pragma unroll
+    for (int f = 0; f < M; ++f) { st_at(p, b, o0 + f, k) = yd[f]; st_at(p, b, o0 + M * M + f, k) = vd[f]; }
+#pragma unroll
+    for (int f = 0; f < 2 * NO; ++f) { st_at(p, b, o0 + M + f, k) = yo[f]; st_at(p, b, o0 + M * M + M + f, k) = vo[f]; }
+    if (p.T > 0) { st_at(p, b, o0 + 2 * M * M, k) = xi; st_at(p, b, o0 + 2 * M * M + 1, k) = gam; st_at(p, b, o0 + 2 * M * M + 2, k) = pp; }
+}
+
+// stateless: steering(XXs) — in0 = XX complex [B][K][M][M] -> out0 = v complex [B][K][M]
+template <int M> DS_HD void op_steering(const OpParams& p, int b, int k) {
+    cf A[M][M], v[M];
+    const long long base = ((long long)b * p.K + k) * M * M;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) A[i][j] = mk(p.in0[2 * (base + i * M + j)], p.in0[2 * (base + i * M + j) + 1]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {                        // eigh reads one triangle: use the lower one like LAPACK 'L'
+        A[i][i].y = 0.0f;
+#pragma unroll
+        for (int j = i + 1; j < M; ++j) A[i][j] = cconj(A[j][i]);
+    }
+    herm_principal<M>(A, v);
+    const long long ob = ((long long)b * p.K + k) * M;
+#pragma unroll
+    for (int m = 0; m < M; ++m) { p.out0[2 * (ob + m)] = v[m].x; p.out0[2 * (ob + m) + 1] = v[m].y; }
+}
+
+// stateless: compute_mvdr_weight — in0 = steer complex [B][K][M], in1 = Rvv_inv complex [B][K][M][M] -> out0 = w [B][K][M]
+template <int M> DS_HD void op_mvdrw(const OpParams& p, int b, int k) {
+    cf R[M][M], a[M], w[M];
+    const long long rb = ((long long)b * p.K + k) * M * M, ab = ((long long)b * p.K + k) * M;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        a[i] = mk(p.in0[2 * (ab + i)], p.in0[2 * (ab + i) + 1]);
+#pragma unroll
+        for (int j = 0; j < M; ++j) R[i][j] = mk(p.in1[2 * (rb + i * M + j)], p.in1[2 * (rb + i * M + j) + 1]);
+    }
+    mvdr_weight<M>(R, a, w);
+#pragma unroll
+    for (int m = 0; m < M; ++m) { p.out0[2 * (ab + m)] = w[m].x; p.out0[2 * (ab + m) + 1] = w[m].y; }
+}
+
+// dispatch one (b, k) of an operator; OP and (for the matrix operators) M are compile-time so every operator
+// gets its own register allocation
+template <int OP, int M> DS_HD void run_op_t(const OpParams& p, int b, int k) {
+    if constexpr (OP == OP_MCRA) op_mcra(p, b, k);
+    else if constexpr (OP == OP_OMLSA) op_omlsa(p, b, k);
+    else if constexpr (OP == OP_SUBLMS) op_sublms(p, b, k);
+    else if constexpr (OP == OP_SUBRLS) op_subrls(p, b, k);
+    else if constexpr (OP == OP_WPE) op_wpe(p, b, k);
+    else if constexpr (OP == OP_MCCDR) op_mccdr(p, b, k);
+    else if constexpr (OP == OP_MCMCRA) op_mcmcra<M>(p, b, k);
+    else if constexpr (OP == OP_MCSPPBASE) op_mcsppbase<M>(p, b, k);
+    else if constexpr (OP == OP_MCSPP) op_mcspp<M>(p, b, k);
+    else if constexpr (OP == OP_STEERING) op_steering<M>(p, b, k);
+    else if constexpr (OP == OP_MVDRW) op_mvdrw<M>(p, b, k);
+}
+
+inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_MCSPP || op == OP_STEERING || op == OP_MVDRW; }
+
+// is (op, M) a supported combination?  (matrix operators: M in {2, 4, 6, 8}; McSpp / steering / mvdr weight: {2, 4, 6})
+inline bool op_supported(int op, int M) {
+    if (op == OP_MCMCRA || op == OP_MCSPPBASE) return M == 2 || M == 4 || M == 6 || M == 8;
+    if (op == OP_MCSPP || op == OP_STEERING || op == OP_MVDRW) return M == 2 || M == 4 || M == 6;
+    return true;
+}
+
+#define DS_OP_M_LIST(X, OP_) X(OP_, 2) X(OP_, 4) X(OP_, 6) X(OP_, 8)
+#define DS_OP_M3_LIST(X, OP_) X(OP_, 2) X(OP_, 4) X(OP_, 6)
+#define DS_FOR_EACH_OP(X) \
+    X(OP_MCRA, 1) X(OP_OMLSA, 1) X(OP_SUBLMS, 1) X(OP_SUBRLS, 1) X(OP_WPE, 1) X(OP_MCCDR, 1) \
+    DS_OP_M_LIST(X, OP_MCMCRA) DS_OP_M_LIST(X, OP_MCSPPBASE) \
+    DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_STEERING) DS_OP_M3_LIST(X, OP_MVDRW)
+
+// runtime dispatch for the serial CPU run in tests/emul (the GPU launches one specialised kernel per (OP, M))
+inline void run_op(int op, const OpParams& p, int b, int k) {
+#define X(OP_, M_) if (op == OP_ && (!op_is_matrix(OP_) || p.M == M_)) { run_op_t<OP_, M_>(p, b, k); return; }
+    DS_FOR_EACH_OP(X)
+#undef X
 }
 
 }  // namespace ds

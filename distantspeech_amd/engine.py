@@ -150,6 +150,39 @@ class BatchEngine:
         L.check(self._lib.ds_mcsppbase_estimate(self._h, self._p(y), int(y.shape[1]), self._p(p), self._p(w), L.MEM_HOST), self._h)
         return p, w
 
+    def set_aux(self, table):
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        L.check(self._lib.ds_set_aux(self._h, self._p(t), t.size), self._h)
+
+    def mcspp_estimate(self, y, want_yout=True, want_matrices=False):
+        """y complex [B, T, K, M] -> dict(p, w_pmwf[, yout][, phi_xx, phi_vv_inv])."""
+        y = np.ascontiguousarray(y, dtype=np.complex64)
+        B, T, K, M = y.shape
+        out = {"p": np.empty((B, T, K), np.float32), "w_pmwf": np.empty((B, T, K, M), np.complex64)}
+        if want_yout:
+            out["yout"] = np.empty((B, T, K), np.complex64)
+        if want_matrices:
+            out["phi_xx"] = np.empty((B, T, K, M, M), np.complex64)
+            out["phi_vv_inv"] = np.empty((B, T, K, M, M), np.complex64)
+        g = lambda k: self._p(out[k]) if k in out else None
+        L.check(self._lib.ds_mcspp_estimate(self._h, self._p(y), int(T), g("p"), g("w_pmwf"), g("yout"), g("phi_xx"),
+                                            g("phi_vv_inv"), L.MEM_HOST), self._h)
+        return out
+
+    def steering(self, XX):
+        """XX complex [B, K, M, M] -> principal eigenvectors [B, K, M] (phase-normalised by element 0)."""
+        XX = np.ascontiguousarray(XX, dtype=np.complex64)
+        v = np.empty(XX.shape[:3], dtype=np.complex64)
+        L.check(self._lib.ds_steering(self._h, self._p(XX), self._p(v), L.MEM_HOST), self._h)
+        return v
+
+    def mvdr_weight(self, steer, Rinv):
+        steer = np.ascontiguousarray(steer, dtype=np.complex64)
+        Rinv = np.ascontiguousarray(Rinv, dtype=np.complex64)
+        w = np.empty(steer.shape, dtype=np.complex64)
+        L.check(self._lib.ds_mvdr_weight(self._h, self._p(steer), self._p(Rinv), self._p(w), L.MEM_HOST), self._h)
+        return w
+
     def omlsa_estimate(self, y, u):
         """y [B, T, K], u [B, T, K, M-1] powers -> (lambda_d, G, p) [B, T, K]."""
         y = np.ascontiguousarray(y, dtype=np.float32)

@@ -208,6 +208,81 @@ class McSppBase(_Base):
         return np.linalg.inv(R + np.eye(self.channels) * 1e-6).astype(complex)
 
 
+class McSpp(_Base):
+    """Multichannel SPP with a coherent-to-diffuse-ratio prior (McCDR) — noise_estimation/mcspp.py:46-305,
+    mccdr.py:25-177.  estimation(y) returns p and leaves Phi_xx / Phi_vv_inv / w exactly as the reference does after the
+    call; `mvdr_out` additionally holds the notebook's online-MVDR output for that frame (example/mvdr.ipynb cell 4:
+    steering(Phi_xx) -> compute_mvdr_weight(steer, Phi_vv_inv) -> sum conj(w) y), computed in the same kernel.
+
+    Like the reference, the McCDR prior hard-wires a circular r = 0.032 array of `channels` microphones and uses the
+    pair (1, 2) (mccdr.py:63,141); unlike the reference (IndexError, mcspp.py:54) any supported channel count works."""
+
+    def __init__(self, nfft=256, channels=4, mic_array=None, batch=1, device=-1):
+        from .mic_array import MicArray, gen_noise_msc
+        self.nfft, self.half_bin, self.channels, self.batch = nfft, int(nfft / 2 + 1), channels, int(batch)
+        self._eng = BatchEngine(L.ALGO_MCSPP, channels, nfft, batch=batch, device=device)
+        cdr_mic = MicArray(arrayType="circular", r=0.032, M=channels)                 # mccdr.py:63
+        self._eng.set_aux(gen_noise_msc(cdr_mic, nfft)[:, 1, 2])
+        self.mic_array = mic_array
+        if mic_array is not None:
+            self.steer_vector = mic_array.steering_vector(look_direction=30).T          # mcspp.py:64-66
+        self._last = None
+        self._o = 9 + 2 * channels * channels
+        self.frm_cnt = 0
+
+    def estimation(self, y, diag_value=1e-4, repeat=False):
+        """y complex [half_bin, channels] -> p [half_bin]."""
+        if repeat:
+            raise NotImplementedError("repeat=True (a second estimation_core pass) is not built")
+        y = self._add_batch(y, 2)
+        self._last = self._eng.mcspp_estimate(y[:, None, :, :], want_yout=True, want_matrices=True)
+        self.frm_cnt += 1
+        return self.p
+
+    def _get(self, key):
+        if self._last is None:
+            raise AttributeError("call estimation() first")
+        return self._sq(self._last[key][:, 0])
+
+    p = property(lambda s: s._get("p").astype(np.float64))
+    w = property(lambda s: s._get("w_pmwf").astype(np.complex128))
+    Phi_xx = property(lambda s: s._get("phi_xx").astype(np.complex128))
+    Phi_vv_inv = property(lambda s: s._get("phi_vv_inv").astype(np.complex128))
+    mvdr_out = property(lambda s: s._get("yout").astype(np.complex128))
+    xi = property(lambda s: s._sq(s._eng.op_state()[:, s._o, :].astype(np.float64)))
+    gamma = property(lambda s: s._sq(s._eng.op_state()[:, s._o + 1, :].astype(np.float64)))
+
+
+_linalg_engines = {}
+
+
+def _linalg(K, M, B):
+    key = (K, M, B)
+    if key not in _linalg_engines:
+        _linalg_engines[key] = BatchEngine(L.ALGO_LINALG, M, 2 * (K - 1), batch=B)
+    return _linalg_engines[key]
+
+
+def steering(XXs):
+    """principal eigenvector of each Hermitian matrix [bins, M, M] -> [bins, M], phase-normalised by the reference
+    sensor — beamformer/beamformer.py:10-31 (batched complex Jacobi on the GPU)."""
+    XXs = np.asarray(XXs)
+    single = XXs.ndim == 3
+    X = XXs[None] if single else XXs
+    v = _linalg(X.shape[1], X.shape[2], X.shape[0]).steering(X).astype(np.complex128)
+    return v[0] if single else v
+
+
+def compute_mvdr_weight(steer_vector, Rvv_inv, Gmin=0.0631, beta=1):
+    """w = R^-1 a / (a^H R^-1 a) per bin — beamformer/beamformer.py:133-155 (GPU)."""
+    a, R = np.asarray(steer_vector), np.asarray(Rvv_inv)
+    single = a.ndim == 2
+    if single:
+        a, R = a[None], R[None]
+    w = _linalg(a.shape[1], a.shape[2], a.shape[0]).mvdr_weight(a, R).astype(np.complex128)
+    return w[0] if single else w
+
+
 class NsOmlsaMulti(_Base):
     """Multichannel (TBRR) OMLSA noise estimate and gain — noise_estimation/omlsa_multi.py:27-156."""
 

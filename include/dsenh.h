@@ -65,6 +65,8 @@ extern "C" {
 #define DS_ALGO_SUBLMS 7     /* SubbandLMS (n_mics=1) / SubbandLmsMc (n_mics=C) .update   adaptivefilter/SubbandLMS.py, SubbandLmsMc.py */
 #define DS_ALGO_SUBRLS 8     /* SubbandRLS.update                    adaptivefilter/SubbandRLS.py:44-71 */
 #define DS_ALGO_WPE 10       /* Wpe.update frequency-domain core (RLS-WPE on the STFT grid)  dereverberation/awpe.py:129-192 */
+#define DS_ALGO_MCSPP 11     /* McSpp.estimation (McCDR prior) + fused steering/MVDR   noise_estimation/mcspp.py:244-305, mccdr.py:122-177 */
+#define DS_ALGO_LINALG 12    /* stateless per-bin helpers: steering(), compute_mvdr_weight()   beamformer/beamformer.py:10-31,133-155 */
 #define DS_ALGO_MCSPPBASE 9  /* McSppBase.estimation + PMWF weights  noise_estimation/mcspp_base.py:220-324 */
 
 /* `mem` argument of the frame-level entry points */
@@ -181,6 +183,12 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
  *   ds_mcra_estimate   Y [B][T][K] power (or complex if is_complex) -> lambda_d [B][T][K]
  *   ds_mcmcra_estimate y complex [B][T][K][M] -> p, G [B][T][K]
  *   ds_mcsppbase_estimate y complex [B][T][K][M] -> p [B][T][K], w complex [B][T][K][M] (PMWF weights)
+ *   ds_mcspp_estimate  y complex [B][T][K][M] -> p [B][T][K], w_pmwf complex [B][T][K][M]; optional (NULL to skip):
+ *                      yout complex [B][T][K] = the notebook's online MVDR output (steering(Phi_xx) -> compute_mvdr_weight
+ *                      -> sum conj(w) y, example/mvdr.ipynb cell 4), phi_xx / phi_vv_inv complex [B][T][K][M][M].
+ *                      Needs ds_set_aux(h, Fn[K]) first: diffuse coherence of microphones 1,2 (mccdr.py:141).
+ *   ds_steering        XX complex [B][K][M][M] -> v complex [B][K][M]     (DS_ALGO_LINALG handle)
+ *   ds_mvdr_weight     steer complex [B][K][M], Rinv complex [B][K][M][M] -> w complex [B][K][M]
  *   ds_omlsa_estimate  y [B][T][K], u [B][T][K][M-1] powers -> lambda_d, G, p [B][T][K]
  *   ds_sublms_update   x complex [B][T][K][C], d complex [B][T][K], p [B][T][K] or NULL -> err complex [B][T][K]
  *   ds_subrls_update   x complex [B][T][K], d complex [B][T][K] -> err complex [B][T][K]
@@ -191,6 +199,11 @@ int ds_istft(ds_handle* h, const float* Y, int n_frames, int n_channels, float* 
 int ds_mcra_estimate(ds_handle* h, const float* Y, int is_complex, int n_frames, float* lambda_d, int mem);
 int ds_mcmcra_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* G, int mem);
 int ds_mcsppbase_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* w, int mem);
+int ds_set_aux(ds_handle* h, const float* table, size_t n_floats);
+int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* w_pmwf, float* yout, float* phi_xx,
+                      float* phi_vv_inv, int mem);
+int ds_steering(ds_handle* h, const float* XX, float* v, int mem);
+int ds_mvdr_weight(ds_handle* h, const float* steer, const float* Rinv, float* w, int mem);
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem);
 int ds_sublms_update(ds_handle* h, const float* x, const float* d, const float* p, int n_frames, float* err, int mem);
 int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames, float* err, int mem);

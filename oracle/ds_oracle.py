@@ -26,7 +26,8 @@ import numpy as np
 __all__ = [
     "sqrt_hann", "OracleTransform", "OracleMicArray", "compute_tau", "gen_noise_msc",
     "steering_from_doa", "fixed_weights", "circular_tao", "OracleMCRA", "OracleAdaptiveMVDR",
-    "OracleFixedBeamformer", "OracleMcMcra", "OracleMcSppBase", "OracleOmlsaMulti", "OracleGSC",
+    "OracleFixedBeamformer", "OracleMcMcra", "OracleMcSppBase", "OracleMcCDR", "OracleMcSpp", "steering",
+    "compute_mvdr_weight", "OracleOmlsaMulti", "OracleGSC",
     "OracleSubbandLMS", "OracleSubbandLmsMc", "OracleSubbandRLS", "OracleWpe", "synth_utterance",
 ]
 
@@ -475,6 +476,109 @@ class OracleMcSppBase:
         at = (self.alpha_d + (1 - self.alpha_d) * self.p)[:, None, None]     # :314
         self.Phi_vv = at * self.Phi_vv + (1 - at) * psd_yy                   # :319-321
         self.w = (self.Phi_vv_inv @ self.Phi_xx)[:, :, 0] / (1 + self.xi[:, None])   # :238-240 (u = e_0, beta = 1)
+        self.frm_cnt += 1
+        return self.p
+
+
+class OracleMcCDR:
+    """McCDR.estimation (coherent-to-diffuse-ratio speech presence prior) — noise_estimation/mccdr.py:25-177,
+    with the pieces of coherence/BinauralEnhancement.py it drives (update_CSD_PSD :33-62, updateMSC :24-31).
+    Only the (1, 2) microphone pair enters the result (mccdr.py:141-143)."""
+
+    def __init__(self, nfft=256, channels=4):
+        self.M = channels
+        self.half_bin = int(nfft / 2 + 1)
+        K = self.half_bin
+        mic = OracleMicArray(arrayType="circular", r=0.032, M=channels)            # mccdr.py:63
+        self.Fn = gen_noise_msc(mic, nfft)[:, 1, 2]                                # BinauralEnhancement -> beamformer.Fvv
+        self.Pxii = np.zeros((K, channels))
+        self.Pxij12 = np.zeros(K, dtype=complex)
+        self.mcra = OracleMCRA(nfft=nfft, L=65)                                    # mccdr.py:60-61
+
+    def estimation(self, y):
+        alpha = 0.9                                                                # mccdr.py:131
+        self.Pxii = alpha * self.Pxii + (1 - alpha) * np.real(y * y.conj())        # BinauralEnhancement.py:49-52
+        self.Pxij12 = alpha * self.Pxij12 + (1 - alpha) * (y[:, 1] * y[:, 2].conj())   # :55-61 (pair (1,2))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            Fx = self.Pxij12 / np.sqrt(self.Pxii[:, 1] * self.Pxii[:, 2])          # updateMSC :28
+            Fn = self.Fn
+            Fn2 = Fn ** 2
+            Fx2 = np.abs(Fx) ** 2
+            Gamma = (Fn * Fx.real - Fx2 - np.sqrt(Fn2 * Fx.real ** 2 - Fn2 * Fx2 + Fn2 - 2 * Fn * Fx.real + Fx2)) / (
+                np.minimum(Fx2 - 1, -1e-3))                                        # mccdr.py:137-145
+            Gamma = Gamma ** 2
+            Gamma[Gamma > 1] = 1
+            Gamma[Gamma < 0] = 1e-3
+        self.mcra.estimation(y[:, 0])                                              # :174 (complex -> |.|^2)
+        return np.sqrt(Gamma * self.mcra.p)                                        # :175
+
+
+def steering(XXs):
+    """principal eigenvector of each Hermitian matrix, phase-normalised by the reference sensor —
+    beamformer/beamformer.py:10-31."""
+    vs = np.linalg.eigh(XXs)[1][:, :, -1]
+    return vs / np.exp(1j * np.angle(vs[:, 0:1]))
+
+
+def compute_mvdr_weight(steer_vector, Rvv_inv):
+    """w = R^-1 a / (a^H R^-1 a) — beamformer/beamformer.py:133-155."""
+    num = Rvv_inv @ steer_vector[..., None]
+    return (num / (steer_vector[:, None, :].conj() @ num))[..., 0]
+
+
+class OracleMcSpp:
+    """McSpp.estimation — noise_estimation/mcspp.py:46-305 (q from McCDR, complex covariances, PMWF beta = 10)."""
+
+    def __init__(self, nfft=256, channels=4):
+        self.M, self.nfft = channels, nfft
+        self.half_bin = int(nfft / 2 + 1)
+        K, M = self.half_bin, channels
+        self.mccdr = OracleMcCDR(nfft=nfft, channels=channels)
+        self.alpha_d, self.alpha = 0.92, 0.92                                      # :60-61
+        self.Phi_yy = np.zeros((K, M, M), dtype=complex)
+        self.Phi_vv = np.zeros((K, M, M), dtype=complex)
+        self.Phi_vv_inv = np.zeros((K, M, M), dtype=complex)
+        self.Phi_xx = np.zeros((K, M, M), dtype=complex)
+        self.p = np.zeros(K)
+        self.w = np.zeros((K, M), dtype=complex)
+        self.frm_cnt = 0
+
+    def _core(self, y, diag_bin):
+        M = self.M
+        self.Phi_vv = 0.5 * (self.Phi_vv + np.conj(self.Phi_vv.swapaxes(-1, -2)))  # :210
+        self.Phi_xx = self.Phi_yy - self.Phi_vv                                    # :212
+        self.Phi_vv_inv = np.linalg.inv(self.Phi_vv + diag_bin)                    # :214
+        xi = np.trace(np.real(self.Phi_vv_inv @ self.Phi_yy), axis1=-2, axis2=-1) - M   # :217
+        index = np.where(xi < 0)
+        if self.frm_cnt < 5:                                                       # :223-226
+            self.Phi_vv_inv[index] = np.linalg.inv(self.Phi_yy[index] + diag_bin[index])
+        else:
+            self.Phi_vv_inv[index] = np.linalg.inv(self.Phi_yy[index])
+        xi = np.trace(np.real(self.Phi_vv_inv @ self.Phi_yy), axis1=-2, axis2=-1) - M   # :228
+        self.xi = np.minimum(np.maximum(xi, 1e-6), 1e8)                            # :230
+        g = (y[:, None, :].conj() @ self.Phi_vv_inv @ self.Phi_yy @ self.Phi_vv_inv @ y[:, :, None]
+             - y[:, None, :].conj() @ self.Phi_vv_inv @ y[:, :, None]).real.squeeze()   # :232-235
+        self.gamma = np.minimum(np.maximum(g, 1e-6), 1e8)
+        p = 1 / (1 + self.q / (1 - self.q) * (1 + self.xi) * np.exp(-1 * (self.gamma / (1 + self.xi))))   # compute_p
+        self.p = np.minimum(np.maximum(p, 0.0), 1.0)
+
+    def estimation(self, y):
+        M = self.M
+        y = np.asarray(y, dtype=complex)
+        self.q = 1 - self.mccdr.estimation(y)                                      # compute_q :113-116
+        fmin, fmax = int(500 * self.nfft / 16000), int(2000 * self.nfft / 16000)   # :258-259
+        q_avg = np.mean(self.q[fmin:fmax])
+        dv = q_avg * 1e-1 + (1 - q_avg) * 1e-4                                     # :254-262
+        psd_yy = np.einsum('ij,il->ijl', y, y.conj())
+        self.Phi_yy = self.alpha * self.Phi_yy + (1 - self.alpha) * psd_yy         # :266
+        if self.frm_cnt < 10:                                                      # :273-275
+            self.Phi_vv = self.Phi_yy.copy()
+            self.q = np.full(self.half_bin, 0.99)
+        diag_bin = np.array(np.broadcast_to(np.eye(M) * dv, (self.half_bin, M, M)))    # :203-204 (eye * (eye * dv))
+        self._core(y, diag_bin)
+        at = (self.alpha_d + (1 - self.alpha_d) * self.p)[:, None, None]           # update_noise_psd
+        self.Phi_vv = at * self.Phi_vv + (1 - at) * psd_yy
+        self.w = (self.Phi_vv_inv @ self.Phi_xx)[:, :, 0] / (10 + self.xi[:, None])    # compute_pmwf_weight beta=10 :283
         self.frm_cnt += 1
         return self.p
 

@@ -113,12 +113,12 @@ int emul_istft(int nfft, int M, int batch, const float* Y, int T, int C, float* 
 
 // frame-level operators: serial loop over (b, k) of ds::run_op
 int emul_op(int op, int B, int K, int T, float* st, int NF, const float* in0, const float* in1, const float* in2, float* out0,
-            float* out1, float* out2, int M, int N, int frm_cnt, int ell, int L, int first_frame, int in_complex, int has_p,
+            float* out1, float* out2, float* out3, float* out4, int M, int N, int frm_cnt, int ell, int L, int first_frame, int in_complex, int has_p,
             int norm, float mu, float alpha, float reg, float lam) {
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
     p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = st; p.NF = NF;
-    p.in0 = in0; p.in1 = in1; p.in2 = in2; p.out0 = out0; p.out1 = out1; p.out2 = out2;
+    p.in0 = in0; p.in1 = in1; p.in2 = in2; p.out0 = out0; p.out1 = out1; p.out2 = out2; p.out3 = out3; p.out4 = out4;
     p.M = M; p.N = N; p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.first_frame = first_frame;
     p.in_complex = in_complex; p.has_p = has_p; p.norm = norm; p.mu = mu; p.alpha = alpha; p.reg = reg; p.lam = lam;
     for (int b = 0; b < B; ++b)

@@ -107,14 +107,14 @@ class EmulTransform:
 
 class EmulOp:
     """One frame-level operator handle (state + uniform counters), mirrors run_binop() in ds_api.hip."""
-    OPS = {"mcra": 0, "mcmcra": 1, "omlsa": 2, "sublms": 3, "subrls": 4, "mcsppbase": 5, "wpe": 6}
+    OPS = {"mcra": 0, "mcmcra": 1, "omlsa": 2, "sublms": 3, "subrls": 4, "mcsppbase": 5, "wpe": 6, "mccdr": 7, "mcspp": 8, "steering": 9, "mvdrw": 10}
 
     def __init__(self, op, nfft, M=1, N=2, batch=1, mu=None, alpha=0.9, lam=0.998, norm=1, L=15):
         self.op, self.B, self.K, self.M, self.N = self.OPS[op], batch, nfft // 2 + 1, M, N
         self.KP = (self.K + 3) & ~3
         self.NF = {0: 5, 1: M * (M + 1) + 4, 2: 5 * M + (M - 1) + 8, 3: 4 * N * M + 1, 4: 4 * N + 2 * N * N,
                    5: 2 * M * M + 8 + 2 * M,
-                   6: 2 * M * M * N + 2 * M * N + 2 * (M * N) ** 2 + 1}[self.op]
+                   6: 2 * M * M * N + 2 * M * N + 2 * (M * N) ** 2 + 1, 7: 9, 8: 9 + 2 * M * M + 3, 9: 1, 10: 1}[self.op]
         self.st = np.zeros((batch, self.NF, self.KP), dtype=np.float32)
         if self.op == 2:
             o = 5 * M + 1 + (M - 1)
@@ -139,16 +139,33 @@ class EmulOp:
             n_out = len(outs)
         else:
             outs = [np.zeros((self.B, T, self.K), dtype=np.complex64 if out_complex else np.float32) for _ in range(n_out)]
-        o = outs + [None] * (3 - n_out)
+        o = outs + [None] * (5 - n_out)
         f = ctypes.c_float
-        rc = lib().emul_op(self.op, self.B, self.K, T, _vp(self.st), self.NF, _vp(in0), _vp(in1), _vp(in2), _vp(o[0]), _vp(o[1]),
-                           _vp(o[2]), self.M, self.N, self.frm, self.ell, self.L, self.first, int(in_complex),
-                           int(in2 is not None), self.norm, f(self.mu), f(self.alpha), f(1e-4), f(self.lam))
+        L = getattr(self, "L_override", self.L)
+        rc = lib().emul_op(getattr(self, "op_override", self.op), self.B, self.K, T, _vp(self.st), self.NF, _vp(in0), _vp(in1),
+                           _vp(in2), _vp(o[0]), _vp(o[1]), _vp(o[2]), _vp(o[3]), _vp(o[4]), self.M, getattr(self, "N_override", self.N),
+                           self.frm, self.ell, L, self.first, int(in_complex), int(in2 is not None), self.norm, f(self.mu),
+                           f(self.alpha), f(1e-4), f(self.lam))
         assert rc == 0
-        for _ in range(T):
-            if self.frm != 0 and self.ell % self.L == 0:
-                self.ell = 0
-            self.frm += 1
-            self.ell += 1
-        self.first = 0
+        if not getattr(self, "hold_counters", False):
+            for _ in range(T):
+                if self.frm != 0 and self.ell % L == 0:
+                    self.ell = 0
+                self.frm += 1
+                self.ell += 1
+            self.first = 0
+        return outs
+
+    def run_mcspp(self, y, Fn, want_yout=True, want_matrices=False):
+        """McSpp handle: McCDR pass (L = 65) then McSpp pass, like ds_mcspp_estimate()."""
+        y = np.ascontiguousarray(y, dtype=np.complex64)
+        B, T, K, M = y.shape
+        self.op_override, self.L_override, self.hold_counters = 7, 65, True
+        gamma = self.run(y, np.ascontiguousarray(Fn, dtype=np.float32))[0]
+        self.op_override, self.N_override, self.hold_counters = 8, 9, False
+        shapes = [((), np.float32), ((M,), np.complex64)]
+        shapes.append(((), np.complex64))
+        if want_matrices:
+            shapes += [((M, M), np.complex64), ((M, M), np.complex64)]
+        outs = self.run(y, gamma, out_shapes=shapes)
         return outs

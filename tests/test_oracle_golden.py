@@ -196,3 +196,25 @@ def test_wpe(golden, name):
     assert rms(y - g["y"]) < 1e-7 * max(rms(g["y"]), 1e-3)
     assert np.allclose(wpe.W, g["W"], rtol=1e-6, atol=1e-9)
     assert np.allclose(wpe.P, g["P"], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+def test_mcspp_notebook_flow(golden, name):
+    """McSpp + steering + compute_mvdr_weight, driven like example/mvdr.ipynb cell 4."""
+    g = golden("g11_mcspp_" + name)
+    M, nfft, hop = [int(v) for v in g["params"]]
+    x = g["x"]
+    if x.dtype == np.int16:
+        x = x.astype(np.float32) / 32768.0
+    D = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop).stft(x.T)
+    est = O.OracleMcSpp(nfft, M)
+    T = D.shape[1]
+    Y = np.zeros((T, nfft // 2 + 1), dtype=complex)
+    with np.errstate(all="ignore"):
+        for n in range(T):
+            p = est.estimation(D[:, n, :])
+            assert np.allclose(p, g["p"][n], rtol=1e-7, atol=1e-10), n
+            w = O.compute_mvdr_weight(O.steering(est.Phi_xx), est.Phi_vv_inv)
+            Y[n] = np.einsum("ij,ij->i", w.conj(), D[:, n, :])
+    assert rms(Y - g["Yout"]) < 1e-6 * rms(g["Yout"])
+    assert np.allclose(est.Phi_vv_inv, g["Phi_vv_inv"], rtol=1e-6, atol=1e-9)
