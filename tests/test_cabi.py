@@ -64,3 +64,11 @@ def test_no_cpu_fallback_without_gpu():
     import distantspeech_amd as d
     with pytest.raises(L.DsError):
         d.adaptivebeamfomer(d.MicArray(M=4, n_fft=512), 512)
+
+
+def test_library_is_not_older_than_its_sources():
+    """catches a stale in-tree libdsenh.so (the .so travels to the GPU box as built here)."""
+    csrc = os.path.join(ROOT, "distantspeech_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".hip"))] + [os.path.join(ROOT, "include", "dsenh.h")]
+    newest = max(os.path.getmtime(f) for f in srcs)
+    assert os.path.getmtime(L.LIB_PATH) >= newest, "libdsenh.so is older than its sources: run __graft_entry__.build()"
