@@ -8,6 +8,8 @@ from .mic_array import MicArray, compute_tau, gen_noise_msc
 from .beamformer import beamformer, FixedBeamformer, adaptivebeamfomer, GSC, compute_mvdr_weight
 from .ops import Transform, NoiseEstimationMCRA, McMcra, McSppBase, McSpp, steering, NsOmlsaMulti, SubbandLMS, SubbandLmsMc, SubbandRLS, Wpe
 
-__all__ = ["BatchEngine", "MicArray", "compute_tau", "gen_noise_msc", "beamformer", "FixedBeamformer",
+from .subband_gsc import SubbandGSC, TimeAlignment, FilterDcNotch16, DelaySamples, fractional_delay_filter_bank
+
+__all__ = ["SubbandGSC", "TimeAlignment", "FilterDcNotch16", "DelaySamples", "fractional_delay_filter_bank", "BatchEngine", "MicArray", "compute_tau", "gen_noise_msc", "beamformer", "FixedBeamformer",
            "adaptivebeamfomer", "GSC", "compute_mvdr_weight", "Transform", "NoiseEstimationMCRA", "McMcra", "McSppBase", "McSpp", "steering", "NsOmlsaMulti",
            "SubbandLMS", "SubbandLmsMc", "SubbandRLS", "Wpe"]

@@ -46,6 +46,9 @@ struct ds_handle {
     float* dev_buf[10];         // staging for host-pointer frame-level calls (3 in, 1 scratch, 5 out, 1 aux table)
     size_t dev_buf_bytes[10];
     size_t aux_floats;
+    float* td_mem;              // DS_ALGO_FRONTEND: notch memories [B][M][2]
+    float* td_cache[2];         // FIR history ping-pong [B][L-1][M]
+    int td_L, td_cur;
     // cached hipGraph of a ds_process_device_seq() sequence
     hipGraphExec_t graph_exec;
     int split;                  // DS_PARAM_SPLIT: utterance groups captured as parallel graph branches
@@ -102,6 +105,11 @@ int zero_state(ds_handle* h) {
     std::vector<int> c((size_t)h->cfg.batch * 4, 0);
     for (int b = 0; b < h->cfg.batch; ++b) c[(size_t)b * 4 + 1] = 1;
     DS_HIP(h, hipMemcpyAsync(h->counters, c.data(), counters_bytes(h), hipMemcpyHostToDevice, h->stream));
+    if (h->cfg.algo == DS_ALGO_FRONTEND) {
+        DS_HIP(h, hipMemsetAsync(h->td_mem, 0, (size_t)h->cfg.batch * h->cfg.n_mics * 2 * sizeof(float), h->stream));
+        for (int i = 0; i < 2; ++i)
+            if (h->td_cache[i]) DS_HIP(h, hipMemsetAsync(h->td_cache[i], 0, (size_t)h->cfg.batch * (h->td_L > 1 ? h->td_L - 1 : 1) * h->cfg.n_mics * sizeof(float), h->stream));
+    }
     if (h->op >= 0 && h->NF > 0) {
         // operator state: zeros, except the rows the reference initialises to non-zero values
         std::vector<float> st((size_t)h->cfg.batch * h->NF * h->KP, 0.0f);
@@ -211,6 +219,9 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         case DS_ALGO_MCSPP:
             if (ds::op_supported(ds::OP_MCSPP, cfg->n_mics) && cfg->n_mics >= 3) { op = ds::OP_MCSPP; NF = ds::mcspp_nf(cfg->n_mics); }
             break;
+        case DS_ALGO_FRONTEND:
+            if (cfg->n_mics >= 1 && cfg->n_mics <= 16) { op = 100; NF = 0; }
+            break;
         case DS_ALGO_LINALG:
             if (ds::op_supported(ds::OP_STEERING, cfg->n_mics)) { op = ds::OP_STEERING; NF = 0; }
             break;
@@ -266,6 +277,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->rls_lambda = cfg->rls_lambda > 0 ? cfg->rls_lambda : 0.998f;
     for (int i = 0; i < 10; ++i) { h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0; }
     h->aux_floats = 0;
+    h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
     h->alpha_y = cfg->alpha_y > 0 ? cfg->alpha_y : 0.8f;
@@ -295,6 +307,10 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     DS_CRE(hipMalloc((void**)&h->tail_in, tail_in_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->tail_out, tail_out_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->counters, counters_bytes(h)));
+    if (cfg->algo == DS_ALGO_FRONTEND) {
+        DS_CRE(hipMalloc((void**)&h->td_mem, (size_t)cfg->batch * cfg->n_mics * 2 * sizeof(float)));
+        DS_CRE(hipMemset(h->td_mem, 0, (size_t)cfg->batch * cfg->n_mics * 2 * sizeof(float)));
+    }
     if (h->op >= 0 && h->NF > 0) DS_CRE(hipMalloc((void**)&h->opst, (size_t)cfg->batch * h->NF * h->KP * sizeof(float)));
     const int N = cfg->nfft, NC = N / 2;
     DS_CRE(hipMalloc((void**)&h->steer, (size_t)h->K * cfg->n_mics * sizeof(cf)));
@@ -319,6 +335,7 @@ int ds_destroy(ds_handle* h) {
     (void)hipFree(h->tables); (void)hipFree(h->steer);
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage); (void)hipFree(h->opst);
     for (int i = 0; i < 10; ++i) (void)hipFree(h->dev_buf[i]);
+    (void)hipFree(h->td_mem); (void)hipFree(h->td_cache[0]); (void)hipFree(h->td_cache[1]);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     for (int i = 0; i < 7; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -729,6 +746,56 @@ int ds_mvdr_weight(ds_handle* h, const float* steer, const float* Rinv, float* w
     const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
     IoSpec io = {{steer, Rinv, nullptr}, {n * M * 8, n * M * M * 8, 0}, {w, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
     return run_linalg(h, ds::OP_MVDRW, "ds_mvdr_weight", io, mem);
+}
+
+int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem) {
+    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_dcnotch: NULL argument");
+    if (h->cfg.algo != DS_ALGO_FRONTEND) return fail(h, DS_ESTATE, "ds_dcnotch: handle is not a DS_ALGO_FRONTEND object");
+    if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_dcnotch: n_samples < 0");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t n = (size_t)h->cfg.batch * h->cfg.n_mics * n_samples;
+    IoSpec io = {{x, nullptr, nullptr}, {n * 4, 0, 0}, {y, nullptr, nullptr, nullptr, nullptr}, {n * 4, 0, 0, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::TdParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.M = h->cfg.n_mics; p.n = n_samples; p.x = din[0]; p.y = dout[0]; p.mem = h->td_mem;
+    p.radius = h->cfg.filt_alpha > 0 ? h->cfg.filt_alpha : 0.9f;
+    DS_HIP(h, ds::launch_dcnotch(p, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mean, int mem) {
+    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_firbank: NULL argument");
+    if (h->cfg.algo != DS_ALGO_FRONTEND) return fail(h, DS_ESTATE, "ds_firbank: handle is not a DS_ALGO_FRONTEND object");
+    const int M = h->cfg.n_mics;
+    if (h->aux_floats == 0 || h->aux_floats % M != 0) return fail(h, DS_ESTATE, "ds_firbank: call ds_set_aux(h, coef[L][M]) first");
+    const int Lt = (int)(h->aux_floats / M);
+    if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_firbank: n_samples < 0");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    if (h->td_L != Lt) {                                                      // (re)allocate the history for this tap count
+        DS_HIP(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < 2; ++i) {
+            (void)hipFree(h->td_cache[i]); h->td_cache[i] = nullptr;
+            const size_t cb = (size_t)h->cfg.batch * (Lt > 1 ? Lt - 1 : 1) * M * sizeof(float);
+            DS_HIP(h, hipMalloc((void**)&h->td_cache[i], cb));
+            DS_HIP(h, hipMemset(h->td_cache[i], 0, cb));
+        }
+        h->td_L = Lt; h->td_cur = 0;
+    }
+    const size_t n = (size_t)h->cfg.batch * n_samples;
+    IoSpec io = {{x, nullptr, nullptr}, {n * M * 4, 0, 0}, {y, mean, nullptr, nullptr, nullptr}, {n * M * 4, mean ? n * 4 : 0, 0, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::TdParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.M = M; p.n = n_samples; p.L = Lt; p.x = din[0]; p.y = dout[0]; p.mean = dout[1];
+    p.coef = h->dev_buf[9]; p.cache_in = h->td_cache[h->td_cur]; p.cache_out = h->td_cache[h->td_cur ^ 1];
+    DS_HIP(h, ds::launch_fir(p, h->stream));
+    h->td_cur ^= 1;
+    return io_end(h, mem, io, dout);
 }
 
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem) {

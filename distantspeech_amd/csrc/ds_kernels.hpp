@@ -24,6 +24,9 @@ KernelInfo lookup_stft(int nfft, int M);      // ds_kernels_ops.hip
 KernelInfo lookup_istft(int nfft, int M);
 struct OpParams;
 hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream);
+struct TdParams;
+hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream);
+hipError_t launch_fir(const TdParams& p, hipStream_t stream);
 
 #if defined(__HIPCC__)
 template <class Rg> struct HipExec {

@@ -68,4 +68,27 @@ hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
+__global__ void __launch_bounds__(64) ds_dcnotch_kernel(TdParams p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < p.B * p.M) td_dcnotch(p, i / p.M, i % p.M);
+}
+__global__ void __launch_bounds__(256) ds_fir_kernel(TdParams p) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long long)p.B * p.n) td_fir(p, (int)(i / p.n), (int)(i % p.n));
+}
+__global__ void __launch_bounds__(256) ds_fir_cache_kernel(TdParams p) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long long)p.B * (p.L - 1)) td_fir_cache(p, (int)(i / (p.L - 1)), (int)(i % (p.L - 1)));
+}
+
+hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(ds_dcnotch_kernel, dim3((p.B * p.M + 63) / 64), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_fir(const TdParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(ds_fir_kernel, dim3((unsigned)(((long long)p.B * p.n + 255) / 256)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(ds_fir_cache_kernel, dim3((unsigned)(((long long)p.B * (p.L - 1) + 255) / 256)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 }  // namespace ds

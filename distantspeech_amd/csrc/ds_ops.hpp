@@ -876,4 +876,66 @@ inline void run_op(int op, const OpParams& p, int b, int k) {
 #undef X
 }
 
+// ------------------------------------------------------------------------------------------------
+// Time-domain front-end conditioning either side of the STFT:
+//   FilterDcNotch16.filter_dc_notch16   adaptivefilter/feature.py:32-49   (2-state IIR, one lane per (utterance, channel))
+//   TimeAlignment.process / fir_filter  beamformer/fixedbeamformer.py:13-93 (fractional-delay FIR bank with carried history)
+// ------------------------------------------------------------------------------------------------
+struct TdParams {
+    int B, M, n, L;            // utterances, channels, samples in this call, FIR taps
+    const float* x;            // notch: [B][M][n] ; FIR: [B][n][M]
+    float* y;                  // same layout as x
+    float* mean;               // FIR: optional [B][n] channel mean of y (SubbandGSC.fixed_beamformer, SubbandGSC.py:143)
+    float* mem;                // notch: [B][M][2]
+    const float* coef;         // FIR: [L][M]
+    const float* cache_in;     // FIR: [B][L-1][M]
+    float* cache_out;          // FIR: [B][L-1][M] (the other half of a ping-pong pair)
+    float radius;
+};
+
+DS_HD void td_dcnotch(const TdParams& p, int b, int m) {
+    const float r = p.radius;
+    const float den2 = fma_(r, r, 0.7f * (1.0f - r) * (1.0f - r));
+    float m0 = p.mem[((long long)b * p.M + m) * 2], m1 = p.mem[((long long)b * p.M + m) * 2 + 1];
+    const float* x = p.x + ((long long)b * p.M + m) * p.n;
+    float* y = p.y + ((long long)b * p.M + m) * p.n;
+    for (int i = 0; i < p.n; ++i) {
+        const float vin = x[i];
+        const float vout = m0 + vin;
+        m0 = m1 + 2.0f * (-vin + r * vout);
+        m1 = vin - den2 * vout;
+        y[i] = r * vout;
+    }
+    p.mem[((long long)b * p.M + m) * 2] = m0; p.mem[((long long)b * p.M + m) * 2 + 1] = m1;
+}
+
+// one output sample (all channels) of the FIR bank: y[n][m] = sum_i c[i][m] x[n - i][m], history from the cache
+DS_HD void td_fir(const TdParams& p, int b, int i) {
+    const int M = p.M, L = p.L;
+    const float* x = p.x + (long long)b * p.n * M;
+    const float* cache = p.cache_in + (long long)b * (L - 1) * M;
+    float acc_mean = 0.0f;
+    for (int m = 0; m < M; ++m) {
+        float acc = 0.0f;
+        for (int j = 0; j < L; ++j) {
+            const int s = i - j;                                        // sample index relative to this call
+            const float v = s >= 0 ? x[(long long)s * M + m] : cache[(long long)(L - 1 + s) * M + m];
+            acc = fma_(p.coef[(long long)j * M + m], v, acc);
+        }
+        p.y[((long long)b * p.n + i) * M + m] = acc;
+        acc_mean += acc;
+    }
+    if (p.mean) p.mean[(long long)b * p.n + i] = acc_mean / (float)M;
+}
+
+// new history = last L-1 samples of [cache ; x]
+DS_HD void td_fir_cache(const TdParams& p, int b, int i) {
+    const int M = p.M, L = p.L;
+    const int s = i + p.n - (L - 1);                                    // position in x of history slot i (may be negative)
+    for (int m = 0; m < M; ++m) {
+        const float v = s >= 0 ? p.x[((long long)b * p.n + s) * M + m] : p.cache_in[((long long)b * (L - 1) + (i + p.n)) * M + m];
+        p.cache_out[((long long)b * (L - 1) + i) * M + m] = v;
+    }
+}
+
 }  // namespace ds

@@ -183,6 +183,22 @@ class BatchEngine:
         L.check(self._lib.ds_mvdr_weight(self._h, self._p(steer), self._p(Rinv), self._p(w), L.MEM_HOST), self._h)
         return w
 
+    def dcnotch(self, x):
+        """x [B, M, n] float32 -> y [B, M, n]  (FilterDcNotch16 per channel, state carried)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty_like(x)
+        L.check(self._lib.ds_dcnotch(self._h, self._p(x), int(x.shape[2]), self._p(y), L.MEM_HOST), self._h)
+        return y
+
+    def firbank(self, x, want_mean=True):
+        """x [B, n, M] -> (y [B, n, M], channel mean [B, n])  (TimeAlignment FIR bank, history carried)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty_like(x)
+        mean = np.empty(x.shape[:2], dtype=np.float32) if want_mean else None
+        L.check(self._lib.ds_firbank(self._h, self._p(x), int(x.shape[1]), self._p(y), self._p(mean) if want_mean else None,
+                                     L.MEM_HOST), self._h)
+        return y, mean
+
     def omlsa_estimate(self, y, u):
         """y [B, T, K], u [B, T, K, M-1] powers -> (lambda_d, G, p) [B, T, K]."""
         y = np.ascontiguousarray(y, dtype=np.float32)

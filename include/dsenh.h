@@ -67,6 +67,7 @@ extern "C" {
 #define DS_ALGO_WPE 10       /* Wpe.update frequency-domain core (RLS-WPE on the STFT grid)  dereverberation/awpe.py:129-192 */
 #define DS_ALGO_MCSPP 11     /* McSpp.estimation (McCDR prior) + fused steering/MVDR   noise_estimation/mcspp.py:244-305, mccdr.py:122-177 */
 #define DS_ALGO_LINALG 12    /* stateless per-bin helpers: steering(), compute_mvdr_weight()   beamformer/beamformer.py:10-31,133-155 */
+#define DS_ALGO_FRONTEND 13  /* time-domain conditioning: FilterDcNotch16 (feature.py:32-49), TimeAlignment FIR bank (fixedbeamformer.py:13-93) */
 #define DS_ALGO_MCSPPBASE 9  /* McSppBase.estimation + PMWF weights  noise_estimation/mcspp_base.py:220-324 */
 
 /* `mem` argument of the frame-level entry points */
@@ -189,6 +190,8 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
  *                      Needs ds_set_aux(h, Fn[K]) first: diffuse coherence of microphones 1,2 (mccdr.py:141).
  *   ds_steering        XX complex [B][K][M][M] -> v complex [B][K][M]     (DS_ALGO_LINALG handle)
  *   ds_mvdr_weight     steer complex [B][K][M], Rinv complex [B][K][M][M] -> w complex [B][K][M]
+ *   ds_dcnotch         x [B][M][n] -> y [B][M][n]   (DS_ALGO_FRONTEND handle; radius = ds_config.filt_alpha, 0 -> 0.9)
+ *   ds_firbank         x [B][n][M] -> y [B][n][M] (+ optional channel mean [B][n]); coefficients [L][M] via ds_set_aux
  *   ds_omlsa_estimate  y [B][T][K], u [B][T][K][M-1] powers -> lambda_d, G, p [B][T][K]
  *   ds_sublms_update   x complex [B][T][K][C], d complex [B][T][K], p [B][T][K] or NULL -> err complex [B][T][K]
  *   ds_subrls_update   x complex [B][T][K], d complex [B][T][K] -> err complex [B][T][K]
@@ -204,6 +207,8 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p, floa
                       float* phi_vv_inv, int mem);
 int ds_steering(ds_handle* h, const float* XX, float* v, int mem);
 int ds_mvdr_weight(ds_handle* h, const float* steer, const float* Rinv, float* w, int mem);
+int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem);
+int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mean, int mem);
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem);
 int ds_sublms_update(ds_handle* h, const float* x, const float* d, const float* p, int n_frames, float* err, int mem);
 int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames, float* err, int mem);

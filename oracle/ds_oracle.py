@@ -28,7 +28,8 @@ __all__ = [
     "steering_from_doa", "fixed_weights", "circular_tao", "OracleMCRA", "OracleAdaptiveMVDR",
     "OracleFixedBeamformer", "OracleMcMcra", "OracleMcSppBase", "OracleMcCDR", "OracleMcSpp", "steering",
     "compute_mvdr_weight", "OracleOmlsaMulti", "OracleGSC",
-    "OracleSubbandLMS", "OracleSubbandLmsMc", "OracleSubbandRLS", "OracleWpe", "synth_utterance",
+    "OracleSubbandLMS", "OracleSubbandLmsMc", "OracleSubbandRLS", "OracleWpe", "fractional_delay_filter_bank",
+    "OracleDcNotch", "OracleTimeAlignment", "OracleDelaySamples", "OracleSubbandGSC", "synth_utterance",
 ]
 
 
@@ -862,6 +863,145 @@ class OracleWpe:
         Dn = self.transform_d.stft(x_n)[:, 0, :]
         err = self.update_fd(Xd, Dn)
         return np.atleast_1d(self.transform_d.istft(err[:, 0])), self.W
+
+
+# --------------------------------------------------------------------------------------------
+# front-end conditioning + SubbandGSC (config 5 structure)
+# --------------------------------------------------------------------------------------------
+def fractional_delay_filter_bank(delays):
+    """windowed-sinc fractional delay bank [filter_len, chs] — transform/multirate.py:4-51."""
+    delays = np.array(delays, dtype=float)
+    delays -= delays.min()
+    N, Lw = delays.shape[0], 81
+    filter_length = Lw + int(np.ceil(delays).max())
+    bank = np.zeros((N, filter_length))
+    di = np.floor(delays).astype(np.int64)
+    df = delays - di
+    T = np.arange(Lw)
+    for i in range(N):
+        bank[i, di[i]:di[i] + Lw] = np.hanning(Lw) * np.sinc(T - df[i] - (Lw - 1) / 2)
+    return bank.T
+
+
+class OracleDcNotch:
+    """FilterDcNotch16.filter_dc_notch16 — adaptivefilter/feature.py:32-49."""
+
+    def __init__(self, radius=0.9):
+        self.radius = radius
+        self.mem = np.zeros(2)
+
+    def filter(self, x):
+        r = self.radius
+        den2 = r * r + 0.7 * (1 - r) * (1 - r)
+        out = np.zeros(len(x))
+        m0, m1 = self.mem
+        for i in range(len(x)):
+            vin = x[i]
+            vout = m0 + vin
+            m0 = m1 + 2 * (-vin + r * vout)
+            m1 = vin - den2 * vout
+            out[i] = r * vout
+        self.mem = np.array([m0, m1])
+        return out
+
+
+class OracleTimeAlignment:
+    """TimeAlignment (fractional-delay FIR pre-steering) — beamformer/fixedbeamformer.py:13-93."""
+
+    def __init__(self, mic, angle_rad, fs=16000):
+        tau = compute_tau(mic, angle_rad)                                       # :65 (MicArray.compute_tau)
+        tau = -(tau - np.max(tau))                                              # :67
+        self.delay_filter = fractional_delay_filter_bank(np.array(tau)[:, 0] * fs)   # :68-70
+        self.L = self.delay_filter.shape[0]
+        self.cache = np.zeros((self.L - 1, mic.M))
+
+    def process(self, x):
+        """x [samples, chs] -> [samples, chs]  (fir_filter :13-48: causal FIR with carried history)."""
+        full = np.vstack((self.cache, x))
+        out = np.zeros(x.shape)
+        for m in range(x.shape[1]):
+            out[:, m] = np.convolve(full[:, m], self.delay_filter[:, m])[self.L - 1: self.L - 1 + x.shape[0]]
+        self.cache = full[-(self.L - 1):, :].copy()
+        return out
+
+
+class OracleDelaySamples:
+    """DelaySamples — beamformer/utils.py:241-274."""
+
+    def __init__(self, data_len, delay, channel=1):
+        self.n_delay = delay
+        self.buffer = np.zeros((data_len + delay, channel))
+
+    def delay(self, x):
+        if x.ndim == 1:
+            x = x[:, None]
+        n = x.shape[0]
+        if self.n_delay == 0:
+            return x
+        self.buffer[-n:, :] = x
+        out = self.buffer[:n, :].copy()
+        self.buffer[: self.n_delay, :] = self.buffer[-self.n_delay:, :]
+        return out
+
+
+class OracleSubbandGSC:
+    """SubbandGSC.process (postfilter=False) — beamformer/SubbandGSC.py:67-262.
+    `rls_bm=True` is the config-5 composition of SURVEY section 8a-19: the adaptive blocking filters are
+    SubbandRLS(filter_len=2, num_bands=2*frameLen) instead of SubbandLMS (a composition we define)."""
+
+    def __init__(self, mic, frameLen=256, angle_deg=(197, 0), rls_bm=False):
+        self.M, self.frameLen = mic.M, frameLen
+        nb, hop, M = 2 * frameLen, frameLen, mic.M
+        self.angle = np.array(angle_deg) / 180 * np.pi
+        self.time_alignment = OracleTimeAlignment(mic, self.angle)               # :85
+        self.rls_bm = rls_bm
+        if rls_bm:
+            self.bm = [OracleSubbandRLS(filter_len=2, num_bands=nb) for _ in range(M)]
+        else:
+            self.bm = [OracleSubbandLMS(filter_len=2, num_bands=nb, mu=1e-1) for _ in range(M)]      # :99-101
+        self.bm_tx = [OracleTransform(n_fft=nb, hop_length=hop) for _ in range(M)]
+        self.bm_td = [OracleTransform(n_fft=nb, hop_length=hop) for _ in range(M)]
+        self.aic = OracleSubbandLmsMc(filter_len=2, num_bands=nb, channel=M, mu=0.01, alpha=0.8)     # :103-109
+        self.aic_tx = OracleTransform(n_fft=nb, hop_length=hop, channel=M)
+        self.aic_td = OracleTransform(n_fft=nb, hop_length=hop)
+        self.delay_fbf = OracleDelaySamples(frameLen, frameLen)                  # :111
+        self.spp = OracleMcSpp(nfft=nb, channels=M)                              # :115
+        self.transform = OracleTransform(n_fft=nb, hop_length=hop, channel=M)    # :117
+        self.dc_notch = [OracleDcNotch(radius=0.98) for _ in range(M)]           # :122-124
+
+    def process(self, x):
+        """x [M, L] -> (output [L], fix_output [L], bm_output [L, M], p [K, blocks], aligned_output [L, M])."""
+        x = np.array(x, dtype=np.float64)
+        M, FL = self.M, self.frameLen
+        for m in range(M):
+            x[m, :] = self.dc_notch[m].filter(x[m, :])                           # :177-178
+        nblk = x.shape[1] // FL
+        output = np.zeros(x.shape[1]); fix_output = np.zeros(x.shape[1])
+        bm_output = np.zeros((x.shape[1], M)); aligned = np.zeros((x.shape[1], M))
+        p = np.zeros((self.spp.half_bin, nblk))
+        for n in range(nblk):
+            sl = slice(n * FL, (n + 1) * FL)
+            xa = self.time_alignment.process(x[:, sl].T)                         # :201
+            aligned[sl] = xa
+            D = self.transform.stft(xa)                                          # :204
+            fixed = np.mean(xa, axis=1, keepdims=True)                           # :206
+            with np.errstate(all="ignore"):
+                p[:, n] = self.spp.estimation(D[:, 0, :])                        # :208
+            for m in range(M):                                                   # :217-223
+                X = self.bm_tx[m].stft(fixed[:, 0])[:, 0, 0]
+                Dm = self.bm_td[m].stft(xa[:, m])[:, 0, 0]
+                if self.rls_bm:
+                    err, _ = self.bm[m].update(X, Dm)
+                else:
+                    err, _ = self.bm[m].update(X, Dm, p=p[:, n])
+                bm_output[sl, m] = self.bm_td[m].istft(err)
+            fixed_d = self.delay_fbf.delay(fixed)                                # :226
+            Xa = self.aic_tx.stft(bm_output[sl, :])                              # :230-234 (x_n -> [K, 1, C])
+            Dd = self.aic_td.stft(fixed_d[:, 0])[:, 0, 0]
+            err, _ = self.aic.update(Xa[:, 0, :], Dd, p=1 - p[:, n])
+            output[sl] = self.aic_td.istft(err)
+            fix_output[sl] = fixed_d[:, 0]
+        return output, fix_output, bm_output, p, aligned
 
 
 # --------------------------------------------------------------------------------------------

@@ -167,4 +167,26 @@ int emul_run(int algo, int nfft, int M, int ryy, int batch, const float* x, int 
     }
     return -1;
 }
+
+// time-domain front-end: serial loops over the same per-thread programs the GPU runs
+int emul_dcnotch(int B, int M, int n, const float* x, float* y, float* mem, float radius) {
+    ds::TdParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = B; p.M = M; p.n = n; p.x = x; p.y = y; p.mem = mem; p.radius = radius;
+    for (int b = 0; b < B; ++b)
+        for (int m = 0; m < M; ++m) ds::td_dcnotch(p, b, m);
+    return 0;
+}
+
+int emul_firbank(int B, int M, int n, int L, const float* x, float* y, float* mean, const float* coef, const float* cache_in,
+                 float* cache_out) {
+    ds::TdParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = B; p.M = M; p.n = n; p.L = L; p.x = x; p.y = y; p.mean = mean; p.coef = coef; p.cache_in = cache_in; p.cache_out = cache_out;
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < n; ++i) ds::td_fir(p, b, i);
+        for (int i = 0; i < L - 1; ++i) ds::td_fir_cache(p, b, i);
+    }
+    return 0;
+}
 }

@@ -169,3 +169,31 @@ class EmulOp:
             shapes += [((M, M), np.complex64), ((M, M), np.complex64)]
         outs = self.run(y, gamma, out_shapes=shapes)
         return outs
+
+
+class EmulFrontend:
+    """FilterDcNotch16 + TimeAlignment FIR bank through the kernel per-thread programs (td_dcnotch / td_fir)."""
+
+    def __init__(self, M, coef=None, radius=0.9, batch=1):
+        self.M, self.B, self.radius = M, batch, radius
+        self.mem = np.zeros((batch, M, 2), dtype=np.float32)
+        self.coef = None if coef is None else np.ascontiguousarray(coef, dtype=np.float32)
+        if coef is not None:
+            self.L = self.coef.shape[0]
+            self.cache = [np.zeros((batch, self.L - 1, M), dtype=np.float32) for _ in range(2)]
+            self.cur = 0
+
+    def dcnotch(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.zeros_like(x)
+        assert lib().emul_dcnotch(self.B, self.M, x.shape[2], _vp(x), _vp(y), _vp(self.mem), ctypes.c_float(self.radius)) == 0
+        return y
+
+    def firbank(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.zeros_like(x)
+        mean = np.zeros(x.shape[:2], dtype=np.float32)
+        assert lib().emul_firbank(self.B, self.M, x.shape[1], self.L, _vp(x), _vp(y), _vp(mean), _vp(self.coef),
+                                  _vp(self.cache[self.cur]), _vp(self.cache[self.cur ^ 1])) == 0
+        self.cur ^= 1
+        return y, mean

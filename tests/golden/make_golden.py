@@ -22,6 +22,8 @@ Repairs applied to broken reference entry points, each recorded
       design does not terminate at the sizes of interest; the STFT grid is used instead.
   R8  McSpp with M != 4 (g11 synth_m6 only): `mcspp.mccdr = McCDR(nfft, channels=M)` — McSpp builds its McCDR with the
       default 4 channels (mcspp.py:54) and raises IndexError for other array sizes.
+  R9  SubbandGSC (g12 only): `DistantSpeech.beamformer.FDGSC.DelayObj = object` before importing SubbandGSC
+      (SubbandGSC.py:23 imports a DelayObj that FDGSC.py does not define).
   R7  Wpe (g10 only): `Wpe.check_input_data(xd, x)` is undefined at HEAD (awpe.py:150); defined here as the
       analogue of SubbandAF.update_input_data (SubbandAF.py:53-60): analyse both signals, set return_td = True.
 Third-party versions at generation time are recorded in every fixture.
@@ -389,6 +391,32 @@ def g11_mcspp(x16):
              steer_last=sv, w_last=w, Phi_xx=est.Phi_xx, Phi_vv_inv=est.Phi_vv_inv, Phi_vv=est.Phi_vv, params=np.array([M, 512, 256]))
 
 
+def g12_subbandgsc(x16):
+    import DistantSpeech.beamformer.FDGSC as FD
+    FD.DelayObj = object                                                                   # R9 (SURVEY 8c repair 6)
+    from DistantSpeech.beamformer.SubbandGSC import SubbandGSC
+    from DistantSpeech.noise_estimation.mccdr import McCDR
+    from DistantSpeech.adaptivefilter.SubbandRLS import SubbandRLS
+    x = x16.astype(np.float32) / 32768.0
+    for name, xx, M, rls in (("rec1", x[:, : 256 * 120], 4, False), ("synth_m6", synth(91, 6, 256 * 60), 6, False),
+                             ("synth_m6_rls", synth(92, 6, 256 * 60), 6, True)):
+        mic = MicArray(arrayType="circular", r=0.032 if M == 4 else 0.05, M=M, n_fft=512)
+        with contextlib.redirect_stdout(io.StringIO()):
+            g = SubbandGSC(mic, frameLen=256, angle=[197, 0])
+            if M != 4:
+                g.spp.mccdr = McCDR(512, channels=M)                                       # R8
+            if rls:
+                g.bm = [SubbandRLS(filter_len=2, num_bands=512) for _ in range(M)]          # config-5 composition (ours)
+            with np.errstate(all="ignore"):
+                out, fix, bm, p, al = g.process(xx.astype(np.float64).copy())
+        save("g12_subbandgsc_%s" % name,
+             "SubbandGSC.process(postfilter=False) SubbandGSC.py:170-262; R9 (FDGSC.DelayObj patched)"
+             + ("; R8" if M != 4 else "") + ("; bm := SubbandRLS(filter_len=2) (config-5 composition defined by us)" if rls else ""),
+             x=(x16[:, : 256 * 120] if name == "rec1" else xx), output=out, fix_output=fix, bm_output=bm.astype(np.float32), p=p,
+             aligned_output=al.astype(np.float32), delay_filter=g.time_alignment.delay_filter, params=np.array([M, 256, int(rls)]),
+             r=np.array(mic.r))
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -408,6 +436,7 @@ def main():
     if want("g9"): g9_mcsppbase(x16)
     if want("g10"): g10_wpe()
     if want("g11"): g11_mcspp(x16)
+    if want("g12"): g12_subbandgsc(x16)
 
 
 if __name__ == "__main__":

@@ -224,3 +224,39 @@ def test_steering_and_mvdr_weight_random(ds):
         assert np.max(np.abs(v - ref)) < 5e-4
         Rinv = np.linalg.inv(Bm @ np.conj(np.swapaxes(Bm, 1, 2)) + np.eye(M))
         assert np.max(np.abs(compute_mvdr_weight(ref, Rinv) - O.compute_mvdr_weight(ref, Rinv))) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6", "synth_m6_rls"])
+def test_subband_gsc(ds, name):
+    """SubbandGSC.process (config-5 structure; `_rls` = the SubbandRLS blocking-filter composition) vs the reference."""
+    g = load("g12_subbandgsc_" + name)
+    M, FL, rls = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    mic = ds.MicArray(arrayType="circular", r=float(g["r"]), M=M, n_fft=512)
+    sg = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], bm_filter="rls" if rls else "lms")
+    assert np.allclose(sg.time_alignment.delay_filter, g["delay_filter"], atol=1e-12)
+    # two calls (state carried across process() calls) == the reference's single call
+    half = (x.shape[1] // FL // 2) * FL
+    o1 = sg.process(x[:, :half])
+    o2 = sg.process(x[:, half:])
+    out = np.concatenate([o1[0], o2[0]]); bm = np.concatenate([o1[2], o2[2]]); al = np.concatenate([o1[4], o2[4]])
+    p = np.concatenate([o1[3], o2[3]], axis=1)
+    assert rms(al - g["aligned_output"]) < 1e-5 * rms(g["aligned_output"])
+    assert np.median(np.abs(p - g["p"])) < 1e-3
+    assert rms(bm - g["bm_output"]) < 2e-2 * rms(g["bm_output"])
+    assert rms(out - g["output"]) < 5e-2 * rms(g["output"])
+    with pytest.raises(NotImplementedError):
+        sg.process(x[:, :FL], postfilter=True)
+
+
+def test_frontend_mirrors(ds):
+    from oracle import ds_oracle as O
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(256 * 5) * 0.1 + 0.02)
+    f = ds.FilterDcNotch16(radius=0.98)
+    y = np.concatenate([f.filter_dc_notch16(x[a:a + 256])[0] for a in range(0, x.size, 256)])
+    assert np.max(np.abs(y - O.OracleDcNotch(0.98).filter(x))) < 2e-5
+    d = ds.DelaySamples(10, 25, channel=2)
+    z = rng.standard_normal((100, 2))
+    out = np.concatenate([d.delay(z[a:a + 10]) for a in range(0, 100, 10)])
+    assert np.allclose(out[25:], z[:-25]) and np.all(out[:25] == 0)

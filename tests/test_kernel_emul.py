@@ -248,3 +248,26 @@ def test_emul_steering_and_mvdr_weight():
         ww = o2.run(ref[None, None].astype(np.complex64), Rinv[None, None].astype(np.complex64).reshape(1, 1, K, M * M),
                     out_shapes=[((M,), np.complex64)])[0][0, 0]
         assert np.max(np.abs(ww - O.compute_mvdr_weight(ref, Rinv))) < 1e-4
+
+
+def test_emul_frontend_ops():
+    """FilterDcNotch16 and the TimeAlignment FIR bank against the oracle restatements (chunked, state carried)."""
+    from emul.emul import EmulFrontend
+    from oracle import ds_oracle as O
+    rng = np.random.default_rng(12)
+    M, n = 4, 256 * 6
+    x = (rng.standard_normal((M, n)) * 0.1 + 0.05).astype(np.float32)
+    mic = O.OracleMicArray(M=M, n_fft=512)
+    ta = O.OracleTimeAlignment(mic, np.array([197, 0]) / 180 * np.pi)
+    fe = EmulFrontend(M, coef=ta.delay_filter, radius=0.98)
+    y = np.concatenate([fe.dcnotch(x[None, :, a:a + 256 * 2])[0] for a in range(0, n, 256 * 2)], axis=1)
+    ref = np.stack([O.OracleDcNotch(0.98).filter(x[m].astype(np.float64)) for m in range(M)])
+    assert np.max(np.abs(y - ref)) < 2e-5
+    outs, means = [], []
+    for a in range(0, n, 256):
+        yy, mm = fe.firbank(np.ascontiguousarray(x[:, a:a + 256].T)[None])
+        outs.append(yy[0]); means.append(mm[0])
+    ya = np.concatenate(outs)
+    ra = np.concatenate([ta.process(x[:, a:a + 256].T.astype(np.float64)) for a in range(0, n, 256)])
+    assert np.max(np.abs(ya - ra)) < 1e-5
+    assert np.max(np.abs(np.concatenate(means) - ra.mean(axis=1))) < 1e-5

@@ -218,3 +218,18 @@ def test_mcspp_notebook_flow(golden, name):
             Y[n] = np.einsum("ij,ij->i", w.conj(), D[:, n, :])
     assert rms(Y - g["Yout"]) < 1e-6 * rms(g["Yout"])
     assert np.allclose(est.Phi_vv_inv, g["Phi_vv_inv"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6", "synth_m6_rls"])
+def test_subband_gsc(golden, name):
+    g = golden("g12_subbandgsc_" + name)
+    M, FL, rls = [int(v) for v in g["params"]]
+    x = g["x"]
+    if x.dtype == np.int16:
+        x = x.astype(np.float32) / 32768.0
+    sg = O.OracleSubbandGSC(_mic(M, 512, r=float(g["r"])), FL, (197, 0), rls_bm=bool(rls))
+    assert np.allclose(sg.time_alignment.delay_filter, g["delay_filter"], atol=1e-14)
+    out, fix, bm, p, al = sg.process(x)
+    assert rms(out - g["output"]) < 1e-6 * rms(g["output"])
+    assert rms(bm - g["bm_output"]) < 1e-6 * rms(g["bm_output"])
+    assert np.max(np.abs(p - g["p"])) < 1e-6
