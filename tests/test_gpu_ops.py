@@ -241,7 +241,7 @@ def test_subband_gsc(ds, name):
     o2 = sg.process(x[:, half:])
     out = np.concatenate([o1[0], o2[0]]); bm = np.concatenate([o1[2], o2[2]]); al = np.concatenate([o1[4], o2[4]])
     p = np.concatenate([o1[3], o2[3]], axis=1)
-    assert rms(al - g["aligned_output"]) < 1e-5 * rms(g["aligned_output"])
+    assert rms(al - g["aligned_output"]) < 1e-4 * rms(g["aligned_output"])        # fp32 IIR notch + 84-tap FIR
     assert np.median(np.abs(p - g["p"])) < 1e-3
     assert rms(bm - g["bm_output"]) < 2e-2 * rms(g["bm_output"])
     assert rms(out - g["output"]) < 5e-2 * rms(g["output"])
