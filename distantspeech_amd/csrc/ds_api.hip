@@ -12,6 +12,7 @@
 #include "../../include/dsenh.h"
 #include "ds_kernels.hpp"
 #include "ds_ops.hpp"
+#include "ds_tdfilter.hpp"
 #include "ds_tables.hpp"
 
 using ds::cf;
@@ -49,6 +50,7 @@ struct ds_handle {
     float* td_mem;              // DS_ALGO_FRONTEND: notch memories [B][M][2]
     float* td_cache[2];         // FIR history ping-pong [B][L-1][M]
     int td_L, td_cur;
+    float* tdf_w; float* tdf_buf; float* tdf_P;     // DS_ALGO_TDNLMS / TDRLS state
     // cached hipGraph of a ds_process_device_seq() sequence
     hipGraphExec_t graph_exec;
     int split;                  // DS_PARAM_SPLIT: utterance groups captured as parallel graph branches
@@ -105,6 +107,18 @@ int zero_state(ds_handle* h) {
     std::vector<int> c((size_t)h->cfg.batch * 4, 0);
     for (int b = 0; b < h->cfg.batch; ++b) c[(size_t)b * 4 + 1] = 1;
     DS_HIP(h, hipMemcpyAsync(h->counters, c.data(), counters_bytes(h), hipMemcpyHostToDevice, h->stream));
+    if (h->cfg.algo == DS_ALGO_TDNLMS || h->cfg.algo == DS_ALGO_TDRLS) {
+        const size_t Lf = h->cfg.filter_len, Bt = h->cfg.batch;
+        DS_HIP(h, hipMemsetAsync(h->tdf_w, 0, Bt * Lf * sizeof(float), h->stream));
+        DS_HIP(h, hipMemsetAsync(h->tdf_buf, 0, Bt * Lf * sizeof(float), h->stream));
+        if (h->tdf_P) {                                                        // RLS.py:20: P = eye / delta, delta = 1e-3
+            std::vector<float> P0(Bt * Lf * Lf, 0.0f);
+            for (size_t b = 0; b < Bt; ++b)
+                for (size_t i = 0; i < Lf; ++i) P0[(b * Lf + i) * Lf + i] = 1000.0f;
+            DS_HIP(h, hipMemcpyAsync(h->tdf_P, P0.data(), P0.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            DS_HIP(h, hipStreamSynchronize(h->stream));
+        }
+    }
     if (h->cfg.algo == DS_ALGO_FRONTEND) {
         DS_HIP(h, hipMemsetAsync(h->td_mem, 0, (size_t)h->cfg.batch * h->cfg.n_mics * 2 * sizeof(float), h->stream));
         for (int i = 0; i < 2; ++i)
@@ -195,6 +209,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     int op = -1, NF = 0;
     const int KPo = (cfg->nfft / 2 + 1 + 3) & ~3;
     const int flen = cfg->filter_len > 0 ? cfg->filter_len : 2;
+    const bool is_tdf = cfg->algo == DS_ALGO_TDNLMS || cfg->algo == DS_ALGO_TDRLS;
     switch (cfg->algo) {
         case DS_ALGO_FIXED: ki = ds::lookup_fixed(cfg->nfft, cfg->n_mics); break;
         case DS_ALGO_ADAPTIVE:
@@ -218,6 +233,12 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             break;
         case DS_ALGO_MCSPP:
             if (ds::op_supported(ds::OP_MCSPP, cfg->n_mics) && cfg->n_mics >= 3) { op = ds::OP_MCSPP; NF = ds::mcspp_nf(cfg->n_mics); }
+            break;
+        case DS_ALGO_TDNLMS:
+            if (cfg->filter_len >= 1 && cfg->filter_len <= ds::TDF_LMAX) { op = 101; NF = 0; }
+            break;
+        case DS_ALGO_TDRLS:
+            if (cfg->filter_len >= 1 && cfg->filter_len <= ds::TDF_RLS_LMAX) { op = 102; NF = 0; }
             break;
         case DS_ALGO_FRONTEND:
             if (cfg->n_mics >= 1 && cfg->n_mics <= 16) { op = 100; NF = 0; }
@@ -277,6 +298,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->rls_lambda = cfg->rls_lambda > 0 ? cfg->rls_lambda : 0.998f;
     for (int i = 0; i < 10; ++i) { h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0; }
     h->aux_floats = 0;
+    h->tdf_w = h->tdf_buf = h->tdf_P = nullptr;
     h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
@@ -307,6 +329,14 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     DS_CRE(hipMalloc((void**)&h->tail_in, tail_in_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->tail_out, tail_out_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->counters, counters_bytes(h)));
+    if (is_tdf) {
+        const size_t Lf = cfg->filter_len;
+        DS_CRE(hipMalloc((void**)&h->tdf_w, (size_t)cfg->batch * Lf * sizeof(float)));
+        DS_CRE(hipMalloc((void**)&h->tdf_buf, (size_t)cfg->batch * Lf * sizeof(float)));
+        if (cfg->algo == DS_ALGO_TDRLS) DS_CRE(hipMalloc((void**)&h->tdf_P, (size_t)cfg->batch * Lf * Lf * sizeof(float)));
+        h->filt_mu = cfg->filt_mu > 0 ? cfg->filt_mu : (cfg->algo == DS_ALGO_TDRLS ? 0.5f : 0.1f);
+        h->rls_lambda = cfg->rls_lambda > 0 ? cfg->rls_lambda : 0.9998f;                 // RLS.py:15
+    }
     if (cfg->algo == DS_ALGO_FRONTEND) {
         DS_CRE(hipMalloc((void**)&h->td_mem, (size_t)cfg->batch * cfg->n_mics * 2 * sizeof(float)));
         DS_CRE(hipMemset(h->td_mem, 0, (size_t)cfg->batch * cfg->n_mics * 2 * sizeof(float)));
@@ -335,6 +365,7 @@ int ds_destroy(ds_handle* h) {
     (void)hipFree(h->tables); (void)hipFree(h->steer);
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage); (void)hipFree(h->opst);
     for (int i = 0; i < 10; ++i) (void)hipFree(h->dev_buf[i]);
+    (void)hipFree(h->tdf_w); (void)hipFree(h->tdf_buf); (void)hipFree(h->tdf_P);
     (void)hipFree(h->td_mem); (void)hipFree(h->td_cache[0]); (void)hipFree(h->td_cache[1]);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     for (int i = 0; i < 7; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
@@ -798,6 +829,27 @@ int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mea
     return io_end(h, mem, io, dout);
 }
 
+int ds_tdfilter_update(ds_handle* h, const float* x, const float* d, int n_samples, float p_upd, float* err, int mem) {
+    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_tdfilter_update: NULL argument");
+    if (h->cfg.algo != DS_ALGO_TDNLMS && h->cfg.algo != DS_ALGO_TDRLS)
+        return fail(h, DS_ESTATE, "ds_tdfilter_update: handle is not a DS_ALGO_TDNLMS / DS_ALGO_TDRLS object");
+    if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_tdfilter_update: n_samples < 0");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t n = (size_t)h->cfg.batch * n_samples;
+    IoSpec io = {{x, d, nullptr}, {n * 4, n * 4, 0}, {err, nullptr, nullptr, nullptr, nullptr}, {n * 4, 0, 0, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::TdfParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.n = n_samples; p.L = h->cfg.filter_len;
+    p.mode = h->cfg.algo == DS_ALGO_TDRLS ? ds::TDF_RLS : ds::TDF_NLMS;
+    p.x = din[0]; p.d = din[1]; p.err = dout[0]; p.w = h->tdf_w; p.buf = h->tdf_buf; p.P = h->tdf_P;
+    p.mu = h->filt_mu; p.eps = 1e-4f; p.p = p_upd; p.lam = h->rls_lambda; p.norm = h->norm;
+    DS_HIP(h, ds::launch_tdfilter(p, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem) {
     if (!h || !y || !u || !lambda_d || !G || !p) return fail(h, DS_EINVAL, "ds_omlsa_estimate: NULL argument");
     const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
@@ -866,7 +918,9 @@ size_t ds_field_bytes(const ds_handle* h, int field) {
         case DS_FIELD_STFT_TAIL: return tail_in_bytes(h);
         case DS_FIELD_OLA_TAIL: return tail_out_bytes(h);
         case DS_FIELD_COUNTERS: return counters_bytes(h);
-        case DS_FIELD_OP_STATE: return opst_bytes(h);
+        case DS_FIELD_OP_STATE:
+            if (h->tdf_w) return (size_t)h->cfg.batch * h->cfg.filter_len * sizeof(float);
+            return opst_bytes(h);
         default: return 0;
     }
 }
@@ -889,7 +943,10 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
         }
         return DS_OK;
     }
-    if (field == DS_FIELD_OP_STATE) { DS_HIP(h, hipMemcpy(dst, h->opst, need, hipMemcpyDeviceToHost)); return DS_OK; }
+    if (field == DS_FIELD_OP_STATE) {
+        DS_HIP(h, hipMemcpy(dst, h->tdf_w ? (const void*)h->tdf_w : (const void*)h->opst, need, hipMemcpyDeviceToHost));
+        return DS_OK;
+    }
     // per-bin fields: pull the raw planes and unpack on the host
     std::vector<float> raw(bins_bytes(h) / sizeof(float));
     DS_HIP(h, hipMemcpy(raw.data(), h->bins, bins_bytes(h), hipMemcpyDeviceToHost));

@@ -27,6 +27,8 @@ hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream);
 struct TdParams;
 hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream);
 hipError_t launch_fir(const TdParams& p, hipStream_t stream);
+struct TdfParams;
+hipError_t launch_tdfilter(const TdfParams& p, hipStream_t stream);
 
 #if defined(__HIPCC__)
 template <class Rg> struct HipExec {

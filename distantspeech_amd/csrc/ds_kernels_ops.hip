@@ -2,6 +2,7 @@
 // kernel (MCRA, McMcra, NsOmlsaMulti, subband LMS / RLS) for gfx950.
 #include "ds_kernels.hpp"
 #include "ds_ops.hpp"
+#include "ds_tdfilter.hpp"
 
 namespace ds {
 
@@ -88,6 +89,16 @@ hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream) {
 hipError_t launch_fir(const TdParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(ds_fir_kernel, dim3((unsigned)(((long long)p.B * p.n + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(ds_fir_cache_kernel, dim3((unsigned)(((long long)p.B * (p.L - 1) + 255) / 256)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(TDF_NT) ds_tdfilter_kernel(TdfParams p) {
+    __shared__ TdfShared sh;
+    HipExec<TdfRegs> ex;
+    TdfEngine::run(ex, p, (int)blockIdx.x, sh);
+}
+hipError_t launch_tdfilter(const TdfParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(ds_tdfilter_kernel, dim3(p.B), dim3(TDF_NT), 0, stream, p);
     return hipGetLastError();
 }
 

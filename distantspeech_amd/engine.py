@@ -183,6 +183,21 @@ class BatchEngine:
         L.check(self._lib.ds_mvdr_weight(self._h, self._p(steer), self._p(Rinv), self._p(w), L.MEM_HOST), self._h)
         return w
 
+    def tdfilter_update(self, x, d, p=1.0):
+        """x, d [B, n] samples -> err [B, n]  (n successive sample-wise NLMS / RLS updates)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        err = np.empty_like(x)
+        L.check(self._lib.ds_tdfilter_update(self._h, self._p(x), self._p(d), int(x.shape[1]), float(p), self._p(err),
+                                             L.MEM_HOST), self._h)
+        return err
+
+    def tdfilter_weights(self):
+        nbytes = self._lib.ds_field_bytes(self._h, L.FIELD_OP_STATE)
+        out = np.empty(nbytes // 4, dtype=np.float32)
+        L.check(self._lib.ds_get_state(self._h, L.FIELD_OP_STATE, out.ctypes.data_as(ctypes.c_void_p), nbytes), self._h)
+        return out.reshape(self.batch, -1)
+
     def dcnotch(self, x):
         """x [B, M, n] float32 -> y [B, M, n]  (FilterDcNotch16 per channel, state carried)."""
         x = np.ascontiguousarray(x, dtype=np.float32)

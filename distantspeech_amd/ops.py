@@ -504,3 +504,44 @@ class Wpe(_SubbandBase):
         st = self._eng.op_state()[:, o: o + 2 * CN * CN, :].reshape(self.batch, CN, CN, 2, self.half_band)
         P = (st[:, :, :, 0, :] + 1j * st[:, :, :, 1, :]).astype(np.complex128)
         return self._sq(np.transpose(P, (0, 3, 1, 2)))
+
+
+class BaseFilter(_Base):
+    """Sample-wise time-domain NLMS — adaptivefilter/BaseFilter.py:25-110 (filter_len <= 1024 on the GPU)."""
+
+    def __init__(self, filter_len=1024, mu=0.1, normalization=True, batch=1, device=-1):
+        self.filter_len, self.mu, self.norm, self.batch = filter_len, mu, normalization, int(batch)
+        self._eng = BatchEngine(L.ALGO_TDNLMS, 1, 512, batch=batch, device=device, filter_len=filter_len, filt_mu=mu,
+                                no_norm=not normalization)
+
+    def update(self, x_n, d_n, eps=1e-4, p=1.0):
+        """one sample in -> (err, w [filter_len, 1])."""
+        x = np.asarray(x_n, dtype=np.float32).reshape(self.batch, 1)
+        d = np.asarray(d_n, dtype=np.float32).reshape(self.batch, 1)
+        err = self._eng.tdfilter_update(x, d, p=p)[:, 0]
+        return self._sq(err.astype(np.float64)), self.w
+
+    def filter(self, data, data_d):
+        """run the whole signal (n successive update() calls in one kernel launch) -> err [n]."""
+        x = self._add_batch(np.asarray(data, dtype=np.float32), 1)
+        d = self._add_batch(np.asarray(data_d, dtype=np.float32), 1)
+        return self._sq(self._eng.tdfilter_update(x, d).astype(np.float64))
+
+    @property
+    def w(self):
+        return self._sq(self._eng.tdfilter_weights().astype(np.float64)[:, :, None])
+
+
+class Rls(BaseFilter):
+    """Sample-wise time-domain RLS — adaptivefilter/RLS.py:14-42 (filter_len <= 64 on the GPU: P lives in LDS)."""
+
+    def __init__(self, filter_len=1024, mu=0.5, forgetting_factor=0.9998, delta=1e-3, normalization=True, batch=1, device=-1):
+        if delta != 1e-3:
+            raise NotImplementedError("delta is fixed to the reference default 1e-3")
+        self.filter_len, self.mu, self.norm, self.batch = filter_len, mu, normalization, int(batch)
+        self.forgetting_factor = forgetting_factor
+        self._eng = BatchEngine(L.ALGO_TDRLS, 1, 512, batch=batch, device=device, filter_len=filter_len, filt_mu=mu,
+                                rls_lambda=forgetting_factor)
+
+    def update(self, x_n, d_n, alpha=1e-4):
+        return BaseFilter.update(self, x_n, d_n)

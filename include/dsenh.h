@@ -68,6 +68,8 @@ extern "C" {
 #define DS_ALGO_MCSPP 11     /* McSpp.estimation (McCDR prior) + fused steering/MVDR   noise_estimation/mcspp.py:244-305, mccdr.py:122-177 */
 #define DS_ALGO_LINALG 12    /* stateless per-bin helpers: steering(), compute_mvdr_weight()   beamformer/beamformer.py:10-31,133-155 */
 #define DS_ALGO_FRONTEND 13  /* time-domain conditioning: FilterDcNotch16 (feature.py:32-49), TimeAlignment FIR bank (fixedbeamformer.py:13-93) */
+#define DS_ALGO_TDNLMS 14     /* BaseFilter.update (sample-wise NLMS)  adaptivefilter/BaseFilter.py:52-85; filter_len <= 1024 */
+#define DS_ALGO_TDRLS 15      /* Rls.update (sample-wise RLS)         adaptivefilter/RLS.py:26-42; filter_len <= 64 */
 #define DS_ALGO_MCSPPBASE 9  /* McSppBase.estimation + PMWF weights  noise_estimation/mcspp_base.py:220-324 */
 
 /* `mem` argument of the frame-level entry points */
@@ -192,6 +194,9 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
  *   ds_mvdr_weight     steer complex [B][K][M], Rinv complex [B][K][M][M] -> w complex [B][K][M]
  *   ds_dcnotch         x [B][M][n] -> y [B][M][n]   (DS_ALGO_FRONTEND handle; radius = ds_config.filt_alpha, 0 -> 0.9)
  *   ds_firbank         x [B][n][M] -> y [B][n][M] (+ optional channel mean [B][n]); coefficients [L][M] via ds_set_aux
+ *   ds_tdfilter_update x [B][n], d [B][n] samples -> err [B][n]; n successive BaseFilter.update / Rls.update calls
+ *                      (DS_ALGO_TDNLMS: filt_mu 0 -> 0.1, p = update probability; DS_ALGO_TDRLS: filt_mu 0 -> 0.5,
+ *                      rls_lambda 0 -> 0.9998); weights via ds_get_state(DS_FIELD_OP_STATE) = [B][L]
  *   ds_omlsa_estimate  y [B][T][K], u [B][T][K][M-1] powers -> lambda_d, G, p [B][T][K]
  *   ds_sublms_update   x complex [B][T][K][C], d complex [B][T][K], p [B][T][K] or NULL -> err complex [B][T][K]
  *   ds_subrls_update   x complex [B][T][K], d complex [B][T][K] -> err complex [B][T][K]
@@ -209,6 +214,7 @@ int ds_steering(ds_handle* h, const float* XX, float* v, int mem);
 int ds_mvdr_weight(ds_handle* h, const float* steer, const float* Rinv, float* w, int mem);
 int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem);
 int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mean, int mem);
+int ds_tdfilter_update(ds_handle* h, const float* x, const float* d, int n_samples, float p, float* err, int mem);
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem);
 int ds_sublms_update(ds_handle* h, const float* x, const float* d, const float* p, int n_frames, float* err, int mem);
 int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames, float* err, int mem);

@@ -29,7 +29,7 @@ __all__ = [
     "OracleFixedBeamformer", "OracleMcMcra", "OracleMcSppBase", "OracleMcCDR", "OracleMcSpp", "steering",
     "compute_mvdr_weight", "OracleOmlsaMulti", "OracleGSC",
     "OracleSubbandLMS", "OracleSubbandLmsMc", "OracleSubbandRLS", "OracleWpe", "fractional_delay_filter_bank",
-    "OracleDcNotch", "OracleTimeAlignment", "OracleDelaySamples", "OracleSubbandGSC", "synth_utterance",
+    "OracleNlms", "OracleRls", "OracleDcNotch", "OracleTimeAlignment", "OracleDelaySamples", "OracleSubbandGSC", "synth_utterance",
 ]
 
 
@@ -863,6 +863,47 @@ class OracleWpe:
         Dn = self.transform_d.stft(x_n)[:, 0, :]
         err = self.update_fd(Xd, Dn)
         return np.atleast_1d(self.transform_d.istft(err[:, 0])), self.W
+
+
+# --------------------------------------------------------------------------------------------
+# adaptivefilter/BaseFilter.py, RLS.py — sample-wise time-domain definitions
+# --------------------------------------------------------------------------------------------
+class OracleNlms:
+    """BaseFilter.update — adaptivefilter/BaseFilter.py:25-85."""
+
+    def __init__(self, filter_len=1024, mu=0.1, normalization=True):
+        self.w = np.zeros(filter_len)
+        self.buf = np.zeros(filter_len)
+        self.mu, self.norm = mu, normalization
+
+    def update(self, x_n, d_n, eps=1e-4, p=1.0):
+        self.buf[1:] = self.buf[:-1].copy()                                  # :43-44
+        self.buf[0] = x_n
+        err = d_n - self.w @ self.buf                                         # :73
+        grad = self.buf * err / (self.buf @ self.buf + eps) if self.norm else self.buf * err   # :75-78
+        self.w = self.w + 2 * p * self.mu * grad                              # :82
+        return err, self.w
+
+
+class OracleRls:
+    """Rls.update — adaptivefilter/RLS.py:14-42."""
+
+    def __init__(self, filter_len=1024, mu=0.5, forgetting_factor=0.9998, delta=1e-3):
+        self.w = np.zeros(filter_len)
+        self.buf = np.zeros(filter_len)
+        self.mu = mu
+        self.P = np.eye(filter_len) / delta                                   # :20
+        self.lam = forgetting_factor
+
+    def update(self, x_n, d_n):
+        self.buf[1:] = self.buf[:-1].copy()
+        self.buf[0] = x_n
+        err = d_n - self.w @ self.buf                                         # :30
+        num = self.P @ self.buf                                               # :33
+        kn = num / (self.lam + self.buf @ num)                                # :34
+        self.P = (self.P - np.outer(kn, self.buf @ self.P)) / self.lam        # :37
+        self.w = self.w + 2 * self.mu * err * kn                              # :39-40
+        return err, self.w
 
 
 # --------------------------------------------------------------------------------------------

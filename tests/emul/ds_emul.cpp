@@ -8,6 +8,7 @@
 #include "../../distantspeech_amd/csrc/ds_core.hpp"
 #include "../../distantspeech_amd/csrc/ds_ops.hpp"
 #include "../../distantspeech_amd/csrc/ds_tables.hpp"
+#include "../../distantspeech_amd/csrc/ds_tdfilter.hpp"
 
 namespace {
 
@@ -187,6 +188,23 @@ int emul_firbank(int B, int M, int n, int L, const float* x, float* y, float* me
         for (int i = 0; i < n; ++i) ds::td_fir(p, b, i);
         for (int i = 0; i < L - 1; ++i) ds::td_fir_cache(p, b, i);
     }
+    return 0;
+}
+
+int emul_tdfilter(int mode, int B, int n, int L, const float* x, const float* d, float* err, float* w, float* buf, float* P,
+                  float mu, float eps, float pp, float lam, int norm) {
+    ds::TdfParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = B; p.n = n; p.L = L; p.mode = mode; p.x = x; p.d = d; p.err = err; p.w = w; p.buf = buf; p.P = P;
+    p.mu = mu; p.eps = eps; p.p = pp; p.lam = lam; p.norm = norm;
+    ds::TdfShared* sh = new ds::TdfShared();
+    for (int b = 0; b < B; ++b) {
+        CpuExec<ds::TdfRegs> ex;
+        ex.nt = ds::TDF_NT;
+        ex.R.resize(ds::TDF_NT);
+        ds::TdfEngine::run(ex, p, b, *sh);
+    }
+    delete sh;
     return 0;
 }
 }

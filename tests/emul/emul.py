@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 SO = os.path.join(HERE, "libds_emul.so")
 SRCS = [os.path.join(HERE, "ds_emul.cpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_core.hpp"),
-        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_ops.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tables.hpp")]
+        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_ops.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tables.hpp"),
+        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tdfilter.hpp")]
 
 
 def build(force=False):
@@ -197,3 +198,21 @@ class EmulFrontend:
                                   _vp(self.cache[self.cur]), _vp(self.cache[self.cur ^ 1])) == 0
         self.cur ^= 1
         return y, mean
+
+
+class EmulTdFilter:
+    """sample-wise NLMS / RLS block program (ds_tdfilter.hpp)."""
+
+    def __init__(self, mode, L, mu, lam=0.9998, norm=1, batch=1):
+        self.mode, self.L, self.mu, self.lam, self.norm, self.B = mode, L, mu, lam, norm, batch
+        self.w = np.zeros((batch, L), np.float32)
+        self.buf = np.zeros((batch, L), np.float32)
+        self.P = np.tile(np.eye(L, dtype=np.float32) * 1000.0, (batch, 1, 1)) if mode == 1 else np.zeros((1,), np.float32)
+
+    def update(self, x, d, p=1.0):
+        x = np.ascontiguousarray(x, np.float32); d = np.ascontiguousarray(d, np.float32)
+        err = np.zeros_like(x)
+        f = ctypes.c_float
+        assert lib().emul_tdfilter(self.mode, self.B, x.shape[1], self.L, _vp(x), _vp(d), _vp(err), _vp(self.w), _vp(self.buf),
+                                   _vp(self.P), f(self.mu), f(1e-4), f(p), f(self.lam), self.norm) == 0
+        return err

@@ -417,6 +417,34 @@ def g12_subbandgsc(x16):
              r=np.array(mic.r))
 
 
+def g13_tdfilters():
+    from DistantSpeech.adaptivefilter.BaseFilter import BaseFilter
+    from DistantSpeech.adaptivefilter.RLS import Rls
+    rng = np.random.default_rng(101)
+    n = 3000
+    x = rng.standard_normal(n) * 0.3
+    h = rng.standard_normal(40) * np.exp(-np.arange(40) / 8.0)
+    d = np.convolve(x, h)[:n] + 0.01 * rng.standard_normal(n)
+    nl = BaseFilter(filter_len=64, mu=0.1)
+    e1 = np.zeros(n)
+    for i in range(n):
+        e, _ = nl.update(x[i], d[i])
+        e1[i] = np.squeeze(e)
+    nl2 = BaseFilter(filter_len=300, mu=0.2, normalization=False)
+    e3 = np.zeros(1000)
+    for i in range(1000):
+        e, _ = nl2.update(x[i] * 0.1, d[i] * 0.1, p=0.5)
+        e3[i] = np.squeeze(e)
+    rl = Rls(filter_len=32)
+    e2 = np.zeros(n)
+    for i in range(n):
+        e, _ = rl.update(x[i], d[i])
+        e2[i] = np.squeeze(e)
+    save("g13_tdfilters", "BaseFilter.update (BaseFilter.py:52-85; filter_len 64 normalised, 300 plain LMS p=0.5) and Rls.update "
+         "(RLS.py:26-42; filter_len 32) sample by sample",
+         x=x, d=d, e_nlms=e1, w_nlms=nl.w[:, 0], e_lms=e3, w_lms=nl2.w[:, 0], e_rls=e2, w_rls=rl.w[:, 0], P_rls=rl.P)
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -437,6 +465,7 @@ def main():
     if want("g10"): g10_wpe()
     if want("g11"): g11_mcspp(x16)
     if want("g12"): g12_subbandgsc(x16)
+    if want("g13"): g13_tdfilters()
 
 
 if __name__ == "__main__":

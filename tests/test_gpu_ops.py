@@ -260,3 +260,25 @@ def test_frontend_mirrors(ds):
     z = rng.standard_normal((100, 2))
     out = np.concatenate([d.delay(z[a:a + 10]) for a in range(0, 100, 10)])
     assert np.allclose(out[25:], z[:-25]) and np.all(out[:25] == 0)
+
+
+def test_td_filters(ds):
+    """BaseFilter.update / Rls.update (sample-wise definitions) vs the reference."""
+    g = load("g13_tdfilters")
+    x, d = g["x"], g["d"]
+    nl = ds.BaseFilter(filter_len=64, mu=0.1)
+    e_first = np.array([nl.update(x[i], d[i])[0] for i in range(50)])            # sample by sample like the reference loop
+    e_rest = nl.filter(x[50:], d[50:])                                            # the rest in one launch
+    e = np.concatenate([e_first, e_rest])
+    assert rms(e - g["e_nlms"]) < 1e-4 * rms(g["e_nlms"])
+    assert nl.w.shape == (64, 1) and rms(nl.w[:, 0] - g["w_nlms"]) < 1e-4 * rms(g["w_nlms"])
+    l2 = ds.BaseFilter(filter_len=300, mu=0.2, normalization=False)
+    e3 = np.array([l2.update(x[i] * 0.1, d[i] * 0.1, p=0.5)[0] for i in range(1000)])
+    assert rms(e3 - g["e_lms"]) < 1e-4 * rms(g["e_lms"])
+    rl = ds.Rls(filter_len=32)
+    e2 = rl.filter(x, d)
+    assert rms(e2 - g["e_rls"]) < 2e-2 * rms(g["e_rls"])
+    assert rms(rl.w[:, 0] - g["w_rls"]) < 2e-2 * rms(g["w_rls"])
+    from distantspeech_amd import _lib as L
+    with pytest.raises(L.DsError):
+        ds.Rls(filter_len=1024)                                                   # P = 1024 x 1024 does not fit the LDS design

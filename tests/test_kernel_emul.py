@@ -271,3 +271,20 @@ def test_emul_frontend_ops():
     ra = np.concatenate([ta.process(x[:, a:a + 256].T.astype(np.float64)) for a in range(0, n, 256)])
     assert np.max(np.abs(ya - ra)) < 1e-5
     assert np.max(np.abs(np.concatenate(means) - ra.mean(axis=1))) < 1e-5
+
+
+def test_emul_td_filters_golden():
+    """sample-wise NLMS / LMS / RLS block program vs the reference (chunked calls, state carried)."""
+    from emul.emul import EmulTdFilter
+    g = load("g13_tdfilters")
+    x, d = g["x"].astype(np.float32), g["d"].astype(np.float32)
+    nl = EmulTdFilter(0, 64, 0.1)
+    e = np.concatenate([nl.update(x[None, a:a + 700], d[None, a:a + 700])[0] for a in range(0, x.size, 700)])
+    assert rms(e - g["e_nlms"]) < 1e-4 * rms(g["e_nlms"]) and rms(nl.w[0] - g["w_nlms"]) < 1e-4 * rms(g["w_nlms"])
+    l2 = EmulTdFilter(0, 300, 0.2, norm=0)
+    e = l2.update(x[None, :1000] * np.float32(0.1), d[None, :1000] * np.float32(0.1), p=0.5)[0]
+    assert rms(e - g["e_lms"]) < 1e-4 * rms(g["e_lms"])
+    rl = EmulTdFilter(1, 32, 0.5)
+    e = np.concatenate([rl.update(x[None, a:a + 1000], d[None, a:a + 1000])[0] for a in range(0, x.size, 1000)])
+    assert rms(e - g["e_rls"]) < 2e-2 * rms(g["e_rls"])          # fp32 RLS with P0 = 1e3 I, lambda = 0.9998
+    assert rms(rl.w[0] - g["w_rls"]) < 2e-2 * rms(g["w_rls"])

@@ -233,3 +233,16 @@ def test_subband_gsc(golden, name):
     assert rms(out - g["output"]) < 1e-6 * rms(g["output"])
     assert rms(bm - g["bm_output"]) < 1e-6 * rms(g["bm_output"])
     assert np.max(np.abs(p - g["p"])) < 1e-6
+
+
+def test_td_filters(golden):
+    g = golden("g13_tdfilters")
+    x, d = g["x"], g["d"]
+    nl, rl = O.OracleNlms(64, 0.1), O.OracleRls(32)
+    e1 = np.array([nl.update(x[i], d[i])[0] for i in range(x.size)])
+    e2 = np.array([rl.update(x[i], d[i])[0] for i in range(x.size)])
+    assert np.allclose(e1, g["e_nlms"], rtol=1e-9, atol=1e-12) and np.allclose(nl.w, g["w_nlms"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(e2, g["e_rls"], rtol=1e-6, atol=1e-9) and np.allclose(rl.w, g["w_rls"], rtol=1e-6, atol=1e-9)
+    l2 = O.OracleNlms(300, 0.2, normalization=False)
+    e3 = np.array([l2.update(x[i] * 0.1, d[i] * 0.1, p=0.5)[0] for i in range(1000)])
+    assert np.allclose(e3, g["e_lms"], rtol=1e-9, atol=1e-12)
