@@ -159,6 +159,7 @@ template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
     cf Z[M];
     float st[StateLayout<M, ALGO, RYY>::NP * 4 + 1];
     vec4 pre[NPRE];
+    const vec4* xp[NPRE];     // this lane's read position in the input stream (advanced one hop per frame)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -601,20 +602,31 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
     static constexpr bool FWD_FINAL_IS_FB = (NC != 512);     // 128: 4 stages, 256: 4 stages, 512: 5 stages
     static constexpr bool INV_FINAL_IS_FA = (NC != 512);
 
-    // issue the global loads of hop t (all channels) into registers
-    static DS_HD void prefetch(const Params& p, long long xb, int t, int tid, Rg& r) {
+    // this lane's first input address (hop 0); the stream is then walked by pointer increments
+    static DS_HD void prefetch_init(const Params& p, long long xb, int tid, Rg& r) {
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
             const int v = tid + i * NT;
+            long long off = xb;
             if (v < NV4) {
-                long long off;
                 if (p.x_sample_stride == 1) {                // [M][L]
                     const int m = v / (HOP / 4), q = v - m * (HOP / 4);
-                    off = xb + (long long)m * p.x_chan_stride + (long long)t * HOP + 4 * q;
+                    off = xb + (long long)m * p.x_chan_stride + 4 * q;
                 } else {                                     // [L][M] interleaved
-                    off = xb + (long long)t * HOP * M + 4 * v;
+                    off = xb + 4 * v;
                 }
-                r.pre[i] = *reinterpret_cast<const vec4*>(p.x + off);
+            }
+            r.xp[i] = reinterpret_cast<const vec4*>(p.x + off);
+        }
+    }
+    // issue the global loads of the next hop (all channels) into registers
+    static DS_HD void prefetch(const Params& p, long long, int, int tid, Rg& r) {
+        const int step = p.x_sample_stride == 1 ? HOP / 4 : HOP * M / 4;   // vec4 per hop along this lane's stream
+#pragma unroll
+        for (int i = 0; i < NPRE; ++i) {
+            if (tid + i * NT < NV4) {
+                r.pre[i] = *r.xp[i];
+                r.xp[i] += step;
             }
         }
     }
@@ -691,6 +703,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 const vec4 v = bins[tid * KP + NC];
                 sh.nyq[4 * tid] = v.x; sh.nyq[4 * tid + 1] = v.y; sh.nyq[4 * tid + 2] = v.z; sh.nyq[4 * tid + 3] = v.w;
             }
+            prefetch_init(p, xb, tid, r);
             prefetch(p, xb, 0, tid, r);
         });
 
@@ -849,6 +862,7 @@ template <int NFFT, int M> struct StftEngine {
                 const int m = i / (HOP / 4), q = i - m * (HOP / 4);
                 *reinterpret_cast<vec4*>(&sh.xbuf[m][4 * q]) = tin4[i];
             }
+            EB::prefetch_init(p, xb, tid, r);
             EB::prefetch(p, xb, 0, tid, r);
         });
         for (int t = 0; t < p.T; ++t) {
