@@ -65,39 +65,39 @@ def synth_batch_torch(torch, B, L, device, seed):
 
 
 # ------------------------------------------------------------------------------------------------
-# CPU baseline leg: the oracle (a "port": NumPy restatement of the reference) on the host cores
+# CPU baseline leg: the oracle (a "port": plain-C double-precision restatement of the reference's loop,
+# oracle/c/ds_oracle_mvdr.c, pinned to the reference's golden vectors) on the host cores, one thread per core
 # ------------------------------------------------------------------------------------------------
-def _cpu_worker(args):
-    utt, frames = args
-    os.environ["OMP_NUM_THREADS"] = "1"
+def cpu_baseline(budget_s=10.0):
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import ds_oracle as O
-    mic = O.OracleMicArray(M=M, n_fft=NFFT)
-    x = O.synth_utterance(utt, HOP * frames, mic)
-    ab = O.OracleAdaptiveMVDR(mic, NFFT)
-    t0 = time.perf_counter()
-    for t in range(frames):                       # one hop per call: the same regime as the GPU step
-        ab.process(x[:, t * HOP:(t + 1) * HOP], ANGLE, 2)
-    return frames, time.perf_counter() - t0
-
-
-def cpu_baseline(budget_s=12.0):
-    import multiprocessing as mp
+    from oracle.c_oracle import COracleMVDR
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
-    # calibrate on one core, then size the sample to ~budget_s of wall time per core
-    f0, t0 = _cpu_worker((0, 40))
-    per_core = f0 / t0
-    frames = int(max(40, min(2000, per_core * budget_s)))
-    ctx = mp.get_context("spawn")
+    cores = max(1, min(cores, 256))
+    mic = O.OracleMicArray(M=M, n_fft=NFFT)
+    tao = O.circular_tao(mic.r, mic.c, mic.gamma, ANGLE)
+    omega = 2 * np.pi * np.arange(NFFT // 2 + 1) * FS / NFFT
+    steer = np.exp(-1j * omega[:, None] * tao[None, :])
+
+    def work(args):                                  # ctypes releases the GIL: threads run on separate cores
+        utt, frames = args
+        x = O.synth_utterance(utt, HOP * frames, mic)
+        eng = COracleMVDR(steer, NFFT, HOP)
+        t0 = time.perf_counter()
+        eng.process(x)                               # hop-by-hop inside (one hop per reference call)
+        return frames, time.perf_counter() - t0
+
+    f0, t0 = work((0, 200))                          # calibrate on one core, size the sample to ~budget_s per core
+    frames = int(max(200, min(625 * 16, f0 / t0 * budget_s / 4)))
     t_start = time.perf_counter()
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(u, frames) for u in range(cores)])
+    with ThreadPoolExecutor(cores) as pool:
+        res = list(pool.map(work, [(u, frames) for u in range(cores)]))
     wall = time.perf_counter() - t_start
     busy = max(r[1] for r in res)
     total = sum(r[0] for r in res)
     return {"value": round(total / busy, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d utterances x %d hops (one hop per call), oracle/ds_oracle.py OracleAdaptiveMVDR, "
-                      "one process per core; %.1f s wall" % (cores, frames, wall),
+            "sample": "%d utterances x %d hops (one hop per call), oracle/c/ds_oracle_mvdr.c (plain C, fp64), one thread "
+                      "per core; %.1f s wall" % (cores, frames, wall),
             "per_core": round(total / busy / cores, 1)}
 
 
