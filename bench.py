@@ -32,8 +32,12 @@ ANGLE = np.array([197.0, 0.0]) / 180.0 * np.pi
 S_STATE = 4096 + 1024 + 257 * 16 * 8 + 5 * 257 * 4
 
 
-def algorithmic_bytes_per_frame(T):
-    return M * HOP * 4 + HOP * 4 + 2.0 * S_STATE / T
+# cfg3 (GSC + McMcra gain): S = 5120 tails + G_aic 3*257*8 + Phi_yy, Phi_vv 2*16*257*4 = 44 184 B ; cfg1 (fixed): tails only
+S_STATE_BY_ALGO = {"mvdr": S_STATE, "gsc": 5120 + 3 * 257 * 8 + 2 * 16 * 257 * 4, "fixed": 5120}
+
+
+def algorithmic_bytes_per_frame(T, algo="mvdr"):
+    return M * HOP * 4 + HOP * 4 + 2.0 * S_STATE_BY_ALGO[algo] / T
 
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -73,31 +77,32 @@ def cpu_baseline(budget_s=10.0):
     from oracle import ds_oracle as O
     from oracle.c_oracle import COracleMVDR
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 256))
+    cores = max(1, min(cores, 64))                   # threads actually used (reported as `cores`)
     mic = O.OracleMicArray(M=M, n_fft=NFFT)
     tao = O.circular_tao(mic.r, mic.c, mic.gamma, ANGLE)
     omega = 2 * np.pi * np.arange(NFFT // 2 + 1) * FS / NFFT
     steer = np.exp(-1j * omega[:, None] * tao[None, :])
+    n_distinct = 8
 
     def work(args):                                  # ctypes releases the GIL: threads run on separate cores
-        utt, frames = args
-        x = O.synth_utterance(utt, HOP * frames, mic)
+        x, = args
         eng = COracleMVDR(steer, NFFT, HOP)
         t0 = time.perf_counter()
         eng.process(x)                               # hop-by-hop inside (one hop per reference call)
-        return frames, time.perf_counter() - t0
+        return x.shape[1] // HOP, time.perf_counter() - t0
 
-    f0, t0 = work((0, 200))                          # calibrate on one core, size the sample to ~budget_s per core
-    frames = int(max(200, min(625 * 16, f0 / t0 * budget_s / 4)))
+    f0, t0 = work((O.synth_utterance(0, HOP * 200, mic),))      # calibrate on one core, then ~budget_s/4 of work per thread
+    frames = int(max(200, min(625 * 4, f0 / t0 * budget_s / 4)))
+    xs = [O.synth_utterance(u, HOP * frames, mic) for u in range(n_distinct)]   # inputs built before the timed region
     t_start = time.perf_counter()
     with ThreadPoolExecutor(cores) as pool:
-        res = list(pool.map(work, [(u, frames) for u in range(cores)]))
+        res = list(pool.map(work, [(xs[u % n_distinct],) for u in range(cores)]))
     wall = time.perf_counter() - t_start
     busy = max(r[1] for r in res)
     total = sum(r[0] for r in res)
     return {"value": round(total / busy, 1), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d utterances x %d hops (one hop per call), oracle/c/ds_oracle_mvdr.c (plain C, fp64), one thread "
-                      "per core; %.1f s wall" % (cores, frames, wall),
+            "sample": "%d streams x %d hops (one hop per call; %d distinct synthetic utterances), oracle/c/ds_oracle_mvdr.c "
+                      "(plain C, fp64), one thread per core; %.1f s wall" % (cores, frames, n_distinct, wall),
             "per_core": round(total / busy / cores, 1)}
 
 
@@ -119,6 +124,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU (BASELINE cfg2: 1024)")
     ap.add_argument("--hops-per-step", type=int, default=1, help="T: hops per call (1 = streaming callback regime)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--algo", default="mvdr", choices=["mvdr", "gsc", "fixed"],
+                    help="mvdr = BASELINE cfg2 (the headline); gsc = cfg3 (use --batch 4096); fixed = cfg1 on the GPU")
     args = ap.parse_args()
 
     import torch
@@ -139,12 +146,15 @@ def main():
     x = synth_batch_torch(torch, B, Ltot, device, seed=rank)
     y = torch.empty((B, Ltot), dtype=torch.float32, device=device)
 
-    eng = BatchEngine(L.ALGO_ADAPTIVE, M, NFFT, HOP, batch=B, device=local_rank)
+    algo_id = {"mvdr": L.ALGO_ADAPTIVE, "gsc": L.ALGO_GSC, "fixed": L.ALGO_FIXED}[args.algo]
+    eng = BatchEngine(algo_id, M, NFFT, HOP, batch=B, device=local_rank)
     mic = MicArray(M=M, n_fft=NFFT)
     tao = -1 * mic.r * np.cos(ANGLE[1]) * np.cos(ANGLE[0] - mic.gamma) / mic.c
     omega = 2 * np.pi * np.arange(NFFT // 2 + 1) * FS / NFFT
-    eng.set_steering(np.exp(-1j * omega[:, None] * tao[None, :]))
-    eng.set_method(L.METHOD_MVDR)
+    a = np.exp(-1j * omega[:, None] * tao[None, :])
+    eng.set_steering(a / M if args.algo == "fixed" else a)          # fixed: delay-and-sum weights W = a / M
+    if args.algo != "fixed":
+        eng.set_method(L.METHOD_MVDR)
 
     xp, yp = x.data_ptr(), y.data_ptr()
     torch.cuda.synchronize()          # inputs resident before anything is launched on the engine's stream
@@ -175,22 +185,25 @@ def main():
 
     if rank == 0:
         launch_ms = dev_ms / K                                  # average launch duration (HIP events, same stream)
-        alg_bytes = algorithmic_bytes_per_frame(T) * B * T      # per launch
+        alg_bytes = algorithmic_bytes_per_frame(T, args.algo) * B * T      # per launch
         achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
         out = {
             "metric": "enhanced frames/sec (4-mic, 512-FFT)", "value": round(frames / t_max, 1), "unit": "frames/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(t_max / K * 1e3, 5),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "adaptive MVDR (adaptivebeamfomer.process method=2), 4 mics, 16 kHz, 512-FFT/256-hop, "
+            "config": {"workload": "%s, 4 mics, 16 kHz, 512-FFT/256-hop, "
                                    "batch=%d utterances per GPU, %d hop(s) per call (streaming callback regime), "
-                                   "state resident in HBM" % (B, T),
+                                   "state resident in HBM" % (
+                                       {"mvdr": "adaptive MVDR (adaptivebeamfomer.process method=2)",
+                                        "gsc": "GSC + LMS canceller + McMcra gain (GSC.process method=2)",
+                                        "fixed": "delay-and-sum (FixedBeamformer.process)"}[args.algo], B, T),
                        "batch_per_gpu": B, "hops_per_call": T, "n_mics": M, "nfft": NFFT, "hop": HOP},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic(),
-                         "kernel": "ds_frames_kernel<512,4,ADAPTIVE>", "launch_ms": round(launch_ms, 5),
-                         "algorithmic_bytes_per_frame": algorithmic_bytes_per_frame(T)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic() if (args.algo == "mvdr" and B == BATCH and T == 1) else None,
+                         "kernel": "ds_frames_kernel<512,4,%s>" % {"mvdr": "ADAPTIVE", "gsc": "GSC", "fixed": "FIXED"}[args.algo], "launch_ms": round(launch_ms, 5),
+                         "algorithmic_bytes_per_frame": algorithmic_bytes_per_frame(T, args.algo)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.algo == "mvdr":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
 

@@ -238,3 +238,22 @@ def test_full_batch_properties_gsc(ds):
     for b in (3, 4000):
         ref = O.OracleGSC(omic, nfft, with_dead_state=False).process(x[b], ANGLE, 2)
         assert rms(y[b] - ref) < TOL_RMS
+
+
+def test_long_utterance_drift(ds):
+    """40 s streams (2 500 hops; SURVEY section 7: fp32 branch flips / drift show up on long inputs): the fp32 GPU path
+    stays within the north-star RMS of the fp64 plain-C oracle, hop by hop state included."""
+    from distantspeech_amd import _lib as L
+    from oracle.c_oracle import COracleMVDR
+    M, nfft, hop, T, B = 4, 512, 256, 2500, 4
+    omic = oracle_mic(M, nfft, 0.032)
+    x = np.stack([O.synth_utterance(300 + b, hop * T, omic) for b in range(B)])
+    a = steering(M, nfft, 0.032)
+    eng = ds.BatchEngine(L.ALGO_ADAPTIVE, M, nfft, batch=B)
+    eng.set_steering(a)
+    y = np.concatenate([eng.process(x[:, :, c:c + hop * 500], 1) for c in range(0, hop * T, hop * 500)], axis=1)
+    for b in range(B):
+        ref = COracleMVDR(a, nfft, hop).process(x[b])
+        err = rms(y[b] - ref)
+        assert err < TOL_RMS, (b, err)
+        assert rms(y[b, -hop * 200:] - ref[-hop * 200:]) < TOL_RMS          # no growth at the end of the stream
