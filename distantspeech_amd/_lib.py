@@ -43,7 +43,7 @@ _lib = None
 # every symbol include/dsenh.h declares (tests check that the built library exports all of them)
 EXPORTS = [
     "ds_version", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
-    "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_device",
+    "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_pcm16", "ds_process_device",
     "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcmcra_estimate", "ds_mcsppbase_estimate", "ds_set_aux", "ds_mcspp_estimate", "ds_steering",
     "ds_mvdr_weight", "ds_dcnotch", "ds_firbank", "ds_tdfilter_update",
     "ds_omlsa_estimate",
@@ -85,6 +85,8 @@ def load():
     lib.ds_set_param_f.argtypes = [vp, ci, cf_]
     lib.ds_process.restype = ci
     lib.ds_process.argtypes = [vp, vp, ci, ci, vp]
+    lib.ds_process_pcm16.restype = ci
+    lib.ds_process_pcm16.argtypes = [vp, vp, ci, ci, ci, vp]
     lib.ds_process_device.restype = ci
     lib.ds_process_device.argtypes = [vp, vp, ci, cll, cll, ci, vp, cll, ci, ci, vp]
     lib.ds_process_device_seq.restype = ci

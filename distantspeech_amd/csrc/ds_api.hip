@@ -878,6 +878,31 @@ int ds_wpe_update(ds_handle* h, const float* x_delayed, const float* d, int n_fr
     return run_binop(h, DS_ALGO_WPE, "ds_wpe_update", n_frames, mem, io, 0, 0);
 }
 
+int ds_process_pcm16(ds_handle* h, const int16_t* pcm, int n_total_channels, int first_channel, int n_samples, int16_t* out) {
+    if (!h || !pcm || !out) return fail(h, DS_EINVAL, "ds_process_pcm16: NULL argument");
+    if (h->cfg.algo > DS_ALGO_GSC) return fail(h, DS_ESTATE, "ds_process_pcm16: handle is a frame-level object");
+    const int M = h->cfg.n_mics;
+    if (first_channel < 0 || first_channel + M > n_total_channels) return fail(h, DS_ESHAPE, "ds_process_pcm16: microphone channels outside the frame");
+    if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_process_pcm16: n_samples must be a multiple of hop");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t B = h->cfg.batch, L = n_samples;
+    const size_t xe = B * L * M, ye = B * L, pe = B * L * n_total_channels;
+    rc = stage_reserve(h, 0, pe * sizeof(int16_t)); if (rc) return rc;        // raw PCM in
+    rc = stage_reserve(h, 1, xe * sizeof(float)); if (rc) return rc;          // float mics [B][L][M]
+    rc = stage_reserve(h, 4, ye * sizeof(float)); if (rc) return rc;          // enhanced float
+    rc = stage_reserve(h, 5, ye * sizeof(int16_t)); if (rc) return rc;        // enhanced PCM
+    DS_HIP(h, hipMemcpyAsync(h->dev_buf[0], pcm, pe * sizeof(int16_t), hipMemcpyHostToDevice, h->stream));
+    DS_HIP(h, ds::launch_pcm16_to_float((const short*)h->dev_buf[0], h->dev_buf[1], (long long)xe, n_total_channels, first_channel, M, h->stream));
+    rc = ds_process_device(h, h->dev_buf[1], DS_LAYOUT_SAMPLES_CHANNELS, (long long)(L * M), 0, n_samples, h->dev_buf[4], (long long)L, 0,
+                           h->cfg.batch, nullptr);
+    if (rc) return rc;
+    DS_HIP(h, ds::launch_float_to_pcm16(h->dev_buf[4], (short*)h->dev_buf[5], (long long)ye, h->stream));
+    DS_HIP(h, hipMemcpyAsync(out, h->dev_buf[5], ye * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
+    DS_HIP(h, hipStreamSynchronize(h->stream));
+    return DS_OK;
+}
+
 int ds_synchronize(ds_handle* h) {
     if (!h) return DS_EINVAL;
     int rc = set_device(h);

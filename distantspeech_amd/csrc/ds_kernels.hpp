@@ -27,6 +27,8 @@ hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream);
 struct TdParams;
 hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream);
 hipError_t launch_fir(const TdParams& p, hipStream_t stream);
+hipError_t launch_pcm16_to_float(const short* pcm, float* x, long long n, int Ctot, int c0, int M, hipStream_t stream);
+hipError_t launch_float_to_pcm16(const float* y, short* pcm, long long n, hipStream_t stream);
 struct TdfParams;
 hipError_t launch_tdfilter(const TdfParams& p, hipStream_t stream);
 

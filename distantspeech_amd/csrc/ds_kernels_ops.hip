@@ -102,4 +102,29 @@ hipError_t launch_tdfilter(const TdfParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// realtime wire format (realtime/realtime_processing.py:119-133): int16 LE interleaved [L][C_total] -> float32 / 32768,
+// channels [c0, c0 + M) -> x [B][L][M]; enhanced float -> (y * 32768) truncated to int16
+__global__ void __launch_bounds__(256) ds_pcm16_to_float_kernel(const short* pcm, float* x, long long n, int Ctot, int c0, int M) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // over B * L * M
+    if (i >= n) return;
+    const long long s = i / M;
+    const int m = (int)(i - s * M);
+    x[i] = (float)pcm[s * Ctot + c0 + m] / 32768.0f;
+}
+__global__ void __launch_bounds__(256) ds_float_to_pcm16_kernel(const float* y, short* pcm, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = y[i] * 32768.0f;
+    v = fminf(fmaxf(v, -32768.0f), 32767.0f);                                   // astype('<i2') would wrap; saturate instead
+    pcm[i] = (short)(int)v;                                                     // truncation toward zero like astype
+}
+hipError_t launch_pcm16_to_float(const short* pcm, float* x, long long n, int Ctot, int c0, int M, hipStream_t stream) {
+    hipLaunchKernelGGL(ds_pcm16_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pcm, x, n, Ctot, c0, M);
+    return hipGetLastError();
+}
+hipError_t launch_float_to_pcm16(const float* y, short* pcm, long long n, hipStream_t stream) {
+    hipLaunchKernelGGL(ds_float_to_pcm16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, y, pcm, n);
+    return hipGetLastError();
+}
+
 }  // namespace ds

@@ -75,6 +75,16 @@ class BatchEngine:
                                      y.ctypes.data_as(ctypes.c_void_p)), self._h)
         return y
 
+    def process_pcm16(self, pcm, first_channel=0):
+        """Realtime wire format: pcm int16 [B, L, C_total] interleaved -> enhanced int16 [B, L] (conversion on the GPU)."""
+        pcm = np.ascontiguousarray(pcm, dtype="<i2")
+        if pcm.ndim != 3 or pcm.shape[0] != self.batch:
+            raise ValueError("pcm must be [B=%d, samples, channels]" % self.batch)
+        out = np.empty(pcm.shape[:2], dtype="<i2")
+        L.check(self._lib.ds_process_pcm16(self._h, pcm.ctypes.data_as(ctypes.c_void_p), int(pcm.shape[2]), int(first_channel),
+                                           int(pcm.shape[1]), out.ctypes.data_as(ctypes.c_void_p)), self._h)
+        return out
+
     def process_device(self, x_ptr, layout, x_batch_stride, n_samples, y_ptr, y_batch_stride, first=0, count=None,
                        stream=None, x_chan_stride=0):
         """Device pointers (ints), asynchronous on `stream` (int hipStream_t) or the handle's stream."""

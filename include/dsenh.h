@@ -158,6 +158,12 @@ int ds_set_param_f(ds_handle* h, int id, float value);
  * synchronous: returns after the enhanced samples are in y. */
 int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y);
 
+/* Realtime wire format (realtime/realtime_processing.py:113-136): pcm = int16 little-endian interleaved [B][n_samples][n_total_channels]
+ * straight from the capture device; channels [first_channel, first_channel + n_mics) are the microphones; they are scaled by
+ * 1/32768 exactly like the shell does (:119), enhanced, and written back as int16 (y * 32768, truncated; out-of-range saturates)
+ * to out [B][n_samples].  Conversion happens on the GPU. */
+int ds_process_pcm16(ds_handle* h, const int16_t* pcm, int n_total_channels, int first_channel, int n_samples, int16_t* out);
+
 /* Device-buffer call: pointers are HIP device memory, 16-byte aligned; strides in elements.
  * x_chan_stride: elements between channels for DS_LAYOUT_CHANNELS_SAMPLES (0 = n_samples, i.e. a
  * dense [M][n_samples] chunk; pass the row length when x is a window into a longer [M][L] recording).

@@ -257,3 +257,28 @@ def test_long_utterance_drift(ds):
         err = rms(y[b] - ref)
         assert err < TOL_RMS, (b, err)
         assert rms(y[b, -hop * 200:] - ref[-hop * 200:]) < TOL_RMS          # no growth at the end of the stream
+
+
+def test_realtime_pcm16_wire_format(ds):
+    """the realtime shell's chunk format (realtime/realtime_processing.py:113-136): int16 interleaved 6-channel frames,
+    microphones in channels 1..4, chunk = 1024 samples; GPU-side conversion == the shell's numpy conversion + process()."""
+    from distantspeech_amd import _lib as L
+    g = load("g4_adaptive_rec1")
+    x16 = g["x"][:, : 1024 * 12]                                            # [4, L] int16
+    Ltot = x16.shape[1]
+    frames = np.zeros((Ltot, 6), dtype="<i2")
+    frames[:, 1:5] = x16.T
+    frames[:, 0] = 123; frames[:, 5] = -77                                   # other channels must be ignored
+    a = steering(4, 512, 0.032)
+    eng = ds.BatchEngine(L.ALGO_ADAPTIVE, 4, 512, batch=1); eng.set_steering(a)
+    ref = ds.BatchEngine(L.ALGO_ADAPTIVE, 4, 512, batch=1); ref.set_steering(a)
+    outs, refs = [], []
+    for c in range(0, Ltot, 1024):                                           # CHUNK = 1024 like the shell
+        chunk = frames[c:c + 1024]
+        outs.append(eng.process_pcm16(chunk[None], first_channel=1)[0])
+        samps = chunk.astype(np.float32) / 32768.0                           # the shell's own conversion (:119-121)
+        y = ref.process(samps[None, :, 1:5], L.LAYOUT_SAMPLES_CHANNELS)[0]
+        refs.append((y * 32768).astype("<i2"))                               # (:131)
+    assert np.array_equal(np.concatenate(outs), np.concatenate(refs))
+    with pytest.raises(L.DsError):
+        eng.process_pcm16(frames[None, :1024], first_channel=4)              # microphones would run past the frame
