@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     text = open(os.path.join(ROOT, "include", "dsenh.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ds_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(ds_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
