@@ -160,6 +160,7 @@ template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
     float st[StateLayout<M, ALGO, RYY>::NP * 4 + 1];
     vec4 pre[NPRE];
     const vec4* xp[NPRE];     // this lane's read position in the input stream (advanced one hop per frame)
+    vec4 nyq;                 // prologue: plane `tid` of the Nyquist bin on its way to LDS
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -694,17 +695,16 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 const vec4* tout4 = reinterpret_cast<const vec4*>(tout);
                 for (int i = tid; i < HOP / 4; i += NT) *reinterpret_cast<vec4*>(&sh.tail[4 * i]) = tout4[i];
             }
+            prefetch_init(p, xb, tid, r);
+            prefetch(p, xb, 0, tid, r);
+            // state planes are issued LAST and consumed first in the per-bin phase: they stay in flight while the
+            // forward FFT of the first hop runs (loads retire in order, so nothing above waits for them)
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
                 const vec4 v = bins[q * KP + tid];
                 r.st[4 * q] = v.x; r.st[4 * q + 1] = v.y; r.st[4 * q + 2] = v.z; r.st[4 * q + 3] = v.w;
             }
-            if (tid < NP) {                                   // Nyquist bin's planes -> LDS
-                const vec4 v = bins[tid * KP + NC];
-                sh.nyq[4 * tid] = v.x; sh.nyq[4 * tid + 1] = v.y; sh.nyq[4 * tid + 2] = v.z; sh.nyq[4 * tid + 3] = v.w;
-            }
-            prefetch_init(p, xb, tid, r);
-            prefetch(p, xb, 0, tid, r);
+            r.nyq = bins[(tid < NP ? tid : 0) * KP + NC];        // Nyquist bin's planes: parked in a register until the split phase
         });
 
 #ifdef DS_ABLATE_NOFRAMES     // timing experiment only: state movement without the frame program
@@ -735,6 +735,9 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             const cf* F = FWD_FINAL_IS_FB ? fb : fa;
             // ---- split packed spectrum -> Z[k][m]; publish |Z_0|^2 for the MCRA stencil ----------
             ex.phase([&](int tid, Rg& r) {
+                if (t == 0 && tid < NP) {                               // Nyquist planes -> LDS (loaded in the prologue)
+                    sh.nyq[4 * tid] = r.nyq.x; sh.nyq[4 * tid + 1] = r.nyq.y; sh.nyq[4 * tid + 2] = r.nyq.z; sh.nyq[4 * tid + 3] = r.nyq.w;
+                }
                 const int k = tid, k2 = (NC - k) & (NC - 1);
                 const cf w = sh.tb.tw[k];
 #pragma unroll
