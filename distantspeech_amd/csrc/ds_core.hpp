@@ -704,7 +704,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 const vec4 v = bins[q * KP + tid];
                 r.st[4 * q] = v.x; r.st[4 * q + 1] = v.y; r.st[4 * q + 2] = v.z; r.st[4 * q + 3] = v.w;
             }
-            r.nyq = bins[(tid < NP ? tid : 0) * KP + NC];        // Nyquist bin's planes: parked in a register until the split phase
+            if constexpr (NP > 0) r.nyq = bins[(tid < NP ? tid : 0) * KP + NC];   // Nyquist planes: parked in a register until the split phase
         });
 
 #ifdef DS_ABLATE_NOFRAMES     // timing experiment only: state movement without the frame program
