@@ -29,7 +29,8 @@ __all__ = [
     "OracleFixedBeamformer", "OracleMcMcra", "OracleMcSppBase", "OracleMcCDR", "OracleMcSpp", "steering",
     "compute_mvdr_weight", "OracleOmlsaMulti", "OracleGSC",
     "OracleSubbandLMS", "OracleSubbandLmsMc", "OracleSubbandRLS", "OracleWpe", "fractional_delay_filter_bank",
-    "OracleNlms", "OracleRls", "OracleDcNotch", "OracleTimeAlignment", "OracleDelaySamples", "OracleSubbandGSC", "synth_utterance",
+    "OracleNlms", "OracleRls", "OracleDcNotch", "OracleTimeAlignment", "OracleDelaySamples", "OracleSubbandGSC", "OracleFastFreqLms", "OracleTDGSC", "OracleFDGSC",
+    "synth_utterance",
 ]
 
 
@@ -1043,6 +1044,195 @@ class OracleSubbandGSC:
             output[sl] = self.aic_td.istft(err)
             fix_output[sl] = fixed_d[:, 0]
         return output, fix_output, bm_output, p, aligned
+
+
+# --------------------------------------------------------------------------------------------
+# overlap-save frequency-domain adaptive filters and the two GSCs built on them
+# --------------------------------------------------------------------------------------------
+class OracleFastFreqLms:
+    """Overlap-save FDAF — adaptivefilter/FastFreqLms.py:48-245 (two_path=False).
+    kind "plain" = FastFreqLms.update (:204-245); "bm" = AdaptiveBlockingMatrixFilter.update (gsc_bm.py:61-122,
+    coefficient-clamped); "aic" = AdaptiveInterferenceCancellation.update (gsc_aic.py:53-108, norm-limited)."""
+
+    def __init__(self, filter_len=128, mu=0.01, constrain=True, n_channels=1, alpha=0.9, non_causal=False,
+                 kind="plain", weight_norm=False):
+        self.filter_len, self.mu, self.constrain, self.n_channels, self.alpha = filter_len, mu, constrain, n_channels, alpha
+        self.hop_len, self.win_len = filter_len, 2 * filter_len                      # :62-63
+        self.input_buffer = np.zeros((self.win_len, n_channels))                     # :65
+        self.n_fft = 2 ** (int(np.log2(self.hop_len + filter_len - 1)) + 1)           # :70-71
+        self.overlap = self.win_len - self.hop_len
+        self.W = np.zeros((self.n_fft // 2 + 1, n_channels), dtype=complex)           # :76
+        self.w = np.zeros((filter_len, n_channels))
+        self.P = np.zeros((self.n_fft // 2 + 1, 1))                                   # :78
+        self.non_causal = non_causal
+        self.delay_samples = OracleDelaySamples(filter_len, filter_len // 2) if non_causal else None   # :85
+        self.kind, self.weight_norm = kind, weight_norm
+        n = self.n_fft
+        self.m_upper = np.full(n // 2, 0.001)                                         # gsc_bm.py:48-59
+        self.m_lower = np.full(n // 2, -0.001)
+        self.m_upper[n // 4] = 0.9
+        self.m_upper[[n // 4 + 1, n // 4 - 1]] = 0.3
+        self.m_upper[[n // 4 + 2, n // 4 - 2]] = 0.05
+
+    def update(self, x, d, p=1.0, fir_truncate=None, update=True):
+        """x [hop] or [hop, C]; d [hop] or [hop, 1]; p scalar or [K, 1] -> (e [hop, 1], w [filter_len, C])."""
+        x = np.asarray(x, dtype=np.float64)
+        d = np.asarray(d, dtype=np.float64)
+        if x.ndim == 1:
+            x = x[:, None]
+        n, hop = self.n_fft, self.hop_len
+        self.input_buffer[: self.overlap] = self.input_buffer[-self.overlap:]         # :130
+        self.input_buffer[-hop:] = x                                                  # :131
+        X = np.fft.rfft(self.input_buffer, n=n, axis=0)                               # :155
+        self.P = self.alpha * self.P + (1 - self.alpha) * np.sum(np.real(X.conj() * X), axis=1, keepdims=True)   # :156
+        y = np.fft.irfft(np.sum(X * self.W, axis=-1))[-hop:][:, None]                 # :159-160
+        if self.non_causal:
+            d = self.delay_samples.delay(d)                                           # :167-168
+        if d.ndim == 1:
+            d = d[:, None]
+        e = d - y                                                                     # :172
+        E = np.fft.rfft(np.concatenate((np.zeros((self.overlap, 1)), e), axis=0), n=n, axis=0)   # :183-185
+        self.P[self.P < 1e-4] = 1e-4                                                  # :187
+        grad = X.conj() * E / self.P                                                  # :188
+        norm = 1.0
+        if self.kind == "plain":
+            if self.constrain:                                                        # :194-198
+                g = np.fft.irfft(grad, n=n, axis=0)
+                g[-hop:] = 0
+                grad = np.fft.rfft(g, n=n, axis=0)
+            if update:
+                self.W = self.W + p * 2 * self.mu * grad                              # :235
+        else:
+            if update:
+                self.W = self.W + p * self.mu * grad                                  # gsc_bm.py:91 / gsc_aic.py:79
+            if self.kind == "aic" and self.weight_norm:                               # gsc_aic.py:81-88
+                nrm = np.sum(np.abs(self.W) ** 2) / n / n
+                norm = np.sqrt(0.003 / nrm) if nrm > 0.003 else 1.0
+            if self.constrain:
+                w = np.fft.irfft(self.W, n=n, axis=0) * norm                          # gsc_aic.py:93 / gsc_bm.py:94
+                w[-hop:] = 0
+                if self.kind == "bm":                                                 # gsc_bm.py:97-108: every tap below n/2
+                    w[: n // 2] = np.minimum(np.maximum(w[: n // 2], self.m_lower[:, None]), self.m_upper[:, None])
+                self.W = np.fft.rfft(w, n=n, axis=0)
+        self.w = np.fft.irfft(self.W, n=n, axis=0)[: self.filter_len, :]              # :237-238
+        if fir_truncate is not None:                                                  # :240-244
+            ws = self.w.copy()
+            ws[:fir_truncate] = 0.0
+            ws[-fir_truncate:] = 0.0
+            self.W = np.fft.rfft(ws * norm, n=n, axis=0)
+        return e, self.w
+
+
+def _td_blocking_matrix(x):
+    """adjacent-pair differences — TDGSC.py:69-87."""
+    return x[:, :-1] - x[:, 1:]
+
+
+class OracleTDGSC:
+    """TDGSC.process — beamformer/TDGSC.py:24-175."""
+
+    def __init__(self, mic, frameLen=256, angle_deg=(197, 0)):
+        self.M, self.frameLen = mic.M, frameLen
+        nb, M = 2 * frameLen, mic.M
+        self.time_alignment = OracleTimeAlignment(mic, np.array(angle_deg) / 180 * np.pi)      # :36
+        self.aic_filter = OracleFastFreqLms(filter_len=frameLen, n_channels=M - 1, non_causal=True)   # :37
+        self.dc_notch = [OracleDcNotch(radius=0.98) for _ in range(M)]                # :38-40
+        self.spp = OracleMCRA(nfft=nb, L=65)                                          # :42-43,46
+        self.transform = OracleTransform(n_fft=nb, hop_length=frameLen)               # :44
+        self.omlsa_multi = OracleOmlsaMulti(nfft=nb, cal_weights=True, M=M)           # :48
+        self.transform_fbf = OracleTransform(n_fft=nb, hop_length=frameLen)           # :49
+        self.transform_bm = OracleTransform(n_fft=nb, hop_length=frameLen, channel=M - 1)   # :50
+
+    def process(self, x, postfilter=False):
+        """x [samples, chs] -> (output [samples], p [K, blocks], output_bm [samples, chs-1])."""
+        x = np.array(x, dtype=np.float64)
+        M, FL = self.M, self.frameLen
+        for m in range(M):
+            x[:, m] = self.dc_notch[m].filter(x[:, m])                                # :129-130
+        nblk = x.shape[0] // FL
+        output = np.zeros(x.shape[0]); output_bm = np.zeros((x.shape[0], M - 1))
+        p = np.zeros((self.spp.half_bin, nblk))
+        for n in range(nblk):
+            sl = slice(n * FL, (n + 1) * FL)
+            xa = self.time_alignment.process(x[sl])                                   # :143 -> :66
+            fixed = np.mean(xa, axis=1, keepdims=True)                                # :67
+            D = self.transform.stft(fixed)                                            # :145
+            self.spp.estimation(D[:, 0, :])                                           # :146
+            p[:, n] = self.spp.p
+            bm = _td_blocking_matrix(xa)                                              # :149
+            out_n, _ = self.aic_filter.update(bm, fixed, fir_truncate=30, p=1 - p[:, n:n + 1])   # :152-156 -> :105
+            if postfilter:                                                            # :158-170
+                Y = self.transform_fbf.stft(out_n)
+                U = self.transform_bm.stft(bm)
+                self.omlsa_multi.estimation(np.real(Y[:, 0, 0] * np.conj(Y[:, 0, 0])), np.real(U[:, 0, :] * np.conj(U[:, 0, :])))
+                Y[:, 0, 0] = Y[:, 0, 0] * np.sqrt(self.omlsa_multi.G)
+                out_n = self.transform_fbf.istft(Y)
+            output_bm[sl] = bm
+            output[sl] = np.squeeze(out_n)
+        return output, p, output_bm
+
+
+class OracleFDGSC:
+    """FDGSC.process (blocking-matrix mode 3) — beamformer/FDGSC.py:38-317."""
+
+    def __init__(self, mic, frameLen=256, angle_deg=(197, 0)):
+        self.M, self.frameLen = mic.M, frameLen
+        nb, M = 2 * frameLen, mic.M
+        self.time_alignment = OracleTimeAlignment(mic, np.array(angle_deg) / 180 * np.pi)      # :56
+        self.bm = [OracleFastFreqLms(filter_len=frameLen, mu=0.1, alpha=0.9, kind="bm") for _ in range(M)]   # :71-81
+        self.aic_filter = OracleFastFreqLms(filter_len=frameLen, n_channels=M, mu=0.1, alpha=0.9, kind="aic",
+                                            weight_norm=True)                         # :83-91
+        self.delay_fbf = OracleDelaySamples(frameLen, frameLen)                       # :93
+        self.delay_aligned = OracleDelaySamples(frameLen, frameLen // 2, channel=M)   # :96
+        self.spp = OracleMCRA(nfft=nb, L=60)                                          # :99-100
+        self.transform_x = OracleTransform(n_fft=nb, hop_length=frameLen, channel=M)  # :106
+        self.omlsa_multi = OracleOmlsaMulti(nfft=nb, cal_weights=True, M=M)           # :108
+        self.transform_fbf = OracleTransform(n_fft=nb, hop_length=frameLen)           # :109
+        self.transform_bm = OracleTransform(n_fft=nb, hop_length=frameLen, channel=M - 1)   # :110
+        self.dc_notch = [OracleDcNotch(radius=0.98) for _ in range(M)]                # :114-116
+
+    def process(self, x, postfilter=False, dc_notch=True):
+        """x [samples, chs] -> (output, p, fix_output, fix_output_delayed, bm_output, aligned, aligned_delayed)."""
+        x = np.array(x, dtype=np.float64)
+        M, FL = self.M, self.frameLen
+        if dc_notch:
+            for m in range(M):
+                x[:, m] = self.dc_notch[m].filter(x[:, m])                            # :213-215
+        ns = x.shape[0]
+        nblk = ns // FL
+        output = np.zeros(ns); bm_output = np.zeros((ns, M))
+        aligned = np.zeros((ns, M)); aligned_d = np.zeros((ns, M))
+        fix = np.zeros(ns); fix_d = np.zeros(ns)
+        p = np.zeros((self.spp.half_bin, nblk))
+        for n in range(nblk):
+            sl = slice(n * FL, (n + 1) * FL)
+            xa = self.time_alignment.process(x[sl])                                   # :235
+            fixed = np.mean(xa, axis=1, keepdims=True)                                # :238
+            D = self.transform_x.stft(x[sl])                                          # :241
+            self.spp.estimation(D[:, 0, :])                                           # :243 (channel 0 only, mcra.py:32-33)
+            p[:, n] = self.spp.p
+            if np.mean(p[32:128, n]) > 0.8:                                           # :248-255
+                lo = p[:32, n]
+                lo[lo < 0.8] = 0.8
+            xad = self.delay_aligned.delay(xa)                                        # :258
+            bm_n = np.zeros((FL, M))
+            for m in range(M):                                                        # :259-264 -> :185-195 (mode 3, p = 1.0)
+                e, _ = self.bm[m].update(fixed, xad[:, m], p=1.0)
+                bm_n[:, m] = e[:, 0]
+            bm_output[sl] = bm_n
+            fixed_dn = self.delay_fbf.delay(fixed)                                    # :270
+            Y = self.transform_fbf.stft(fixed_dn)                                     # :273 (advances the shared transform_fbf state)
+            out_n, _ = self.aic_filter.update(bm_n, fixed_dn, p=1 - np.mean(p[:, n]))   # :278-284
+            if postfilter:                                                            # :286-298
+                Y = self.transform_fbf.stft(out_n)
+                U = self.transform_bm.stft(bm_output[:, :-1])                         # :288 — the WHOLE array, every block
+                self.omlsa_multi.estimation(np.real(Y[:, 0, 0] * np.conj(Y[:, 0, 0])), np.real(U[:, 0, :] * np.conj(U[:, 0, :])))
+                Y[:, 0, 0] = Y[:, 0, 0] * np.sqrt(self.omlsa_multi.G)
+                out_n = self.transform_fbf.istft(Y)
+            fix[sl] = fixed[:, 0]; fix_d[sl] = fixed_dn[:, 0]
+            aligned[sl] = xa; aligned_d[sl] = xad
+            output[sl] = np.squeeze(out_n)
+        return output, p, fix, fix_d, bm_output, aligned, aligned_d
 
 
 # --------------------------------------------------------------------------------------------

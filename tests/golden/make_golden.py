@@ -445,6 +445,100 @@ def g13_tdfilters():
          x=x, d=d, e_nlms=e1, w_nlms=nl.w[:, 0], e_lms=e3, w_lms=nl2.w[:, 0], e_rls=e2, w_rls=rl.w[:, 0], P_rls=rl.P)
 
 
+def g14_fdaf():
+    from DistantSpeech.adaptivefilter.FastFreqLms import FastFreqLms
+    from DistantSpeech.beamformer.gsc_bm import AdaptiveBlockingMatrixFilter
+    from DistantSpeech.beamformer.gsc_aic import AdaptiveInterferenceCancellation
+    rng = np.random.default_rng(141)
+
+    def run(f, x, d, p, trunc):
+        hop = f.hop_len
+        nb = x.shape[0] // hop
+        e = np.zeros(nb * hop)
+        for n in range(nb):
+            pn = p[n] if np.ndim(p) == 1 else p[n][:, None]
+            en, w = f.update(x[n * hop:(n + 1) * hop], d[n * hop:(n + 1) * hop], p=pn, fir_truncate=trunc)
+            e[n * hop:(n + 1) * hop] = en[:, 0]
+        return e, np.array(w), np.array(f.W), np.array(f.P[:, 0])
+
+    # (a) single channel, causal, unit p — plain system identification
+    L, nb = 64, 40
+    x = rng.standard_normal(L * nb) * 0.3
+    h = rng.standard_normal(40) * np.exp(-np.arange(40) / 8.0)
+    d = np.convolve(x, h)[: L * nb] + 0.01 * rng.standard_normal(L * nb)
+    f = FastFreqLms(filter_len=L, mu=0.05)
+    pa = np.ones(nb)
+    e, w, W, P = run(f, x, d, pa, None)
+    out = dict(a_x=x, a_d=d, a_p=pa, a_e=e, a_w=w, a_W=W, a_P=P, a_params=np.array([L, 1, 0.05, 0.9, 0, -1]))
+    # (b) three channels, non-causal, per-bin p, fir_truncate=30 — the TDGSC canceller's configuration (TDGSC.py:37,105)
+    L, nb, C = 256, 30, 3
+    x = rng.standard_normal((L * nb, C)) * 0.2
+    d = sum(np.convolve(x[:, c], rng.standard_normal(60) * np.exp(-np.arange(60) / 10.0))[: L * nb] for c in range(C))
+    d = d + 0.01 * rng.standard_normal(L * nb)
+    pb = rng.uniform(0, 1, (nb, L + 1))
+    f = FastFreqLms(filter_len=L, n_channels=C, non_causal=True)
+    e, w, W, P = run(f, x, d, pb, 30)
+    out.update(b_x=x, b_d=d, b_p=pb, b_e=e, b_w=w, b_W=W, b_P=P, b_params=np.array([L, C, 0.01, 0.9, 1, 30]))
+    # (c) coefficient-clamped blocking filter (FDGSC.py:71-81 configuration)
+    L, nb = 256, 30
+    x = rng.standard_normal(L * nb) * 0.2
+    d = np.concatenate((np.zeros(L // 2), x))[: L * nb] * 0.8 + 0.02 * rng.standard_normal(L * nb)
+    f = AdaptiveBlockingMatrixFilter(filter_len=L, mu=0.1, alpha=0.9, non_causal=False, constrain=True)
+    pc = np.ones(nb)
+    e, w, W, P = run(f, x, d, pc, None)
+    out.update(c_x=x, c_d=d, c_p=pc, c_e=e, c_w=w, c_W=W, c_P=P, c_params=np.array([L, 1, 0.1, 0.9, 0, -1]))
+    # (d) norm-limited canceller (FDGSC.py:83-91 configuration), scalar p per block; strong coupling so the limiter engages
+    L, nb, C = 128, 40, 4
+    x = rng.standard_normal((L * nb, C)) * 0.2
+    d = sum(np.convolve(x[:, c], rng.standard_normal(30) * 0.6)[: L * nb] for c in range(C))
+    f = AdaptiveInterferenceCancellation(filter_len=L, n_channels=C, mu=0.1, alpha=0.9, non_causal=False, constrain=True,
+                                         weight_norm=True)
+    pd_ = rng.uniform(0.2, 1.0, nb)
+    e, w, W, P = run(f, x, d, pd_, None)
+    nrm = np.sum(np.abs(W) ** 2) / f.n_fft / f.n_fft
+    out.update(d_x=x, d_d=d, d_p=pd_, d_e=e, d_w=w, d_W=W, d_P=P, d_params=np.array([L, C, 0.1, 0.9, 0, -1]), d_final_norm=np.array(nrm))
+    save("g14_fdaf", "FastFreqLms.update (FastFreqLms.py:204-245), AdaptiveBlockingMatrixFilter.update (gsc_bm.py:61-122), "
+         "AdaptiveInterferenceCancellation.update (gsc_aic.py:53-108) block by block; params = [filter_len, n_channels, mu, alpha, "
+         "non_causal, fir_truncate(-1 = None)]", **out)
+
+
+def g15_tdgsc(x16):
+    from DistantSpeech.beamformer.TDGSC import TDGSC
+    x = x16.astype(np.float32) / 32768.0
+    for name, xx, M, pf in (("rec1", x[:, : 256 * 150], 4, False), ("rec1_pf", x[:, : 256 * 150], 4, True),
+                            ("synth_m6_pf", synth(151, 6, 256 * 80), 6, True)):
+        mic = MicArray(arrayType="circular", r=0.032 if M == 4 else 0.05, M=M, n_fft=512)
+        with contextlib.redirect_stdout(io.StringIO()):
+            g = TDGSC(mic, frameLen=256, angle=[197, 0])
+            out, p, obm = g.process(xx.T.astype(np.float64).copy(), postfilter=pf)
+        save("g15_tdgsc_%s" % name, "TDGSC.process(postfilter=%s) TDGSC.py:110-175" % pf,
+             x=(x16[:, : 256 * 150] if name.startswith("rec1") else xx), output=out, p=p, output_bm=obm.astype(np.float32),
+             w=np.array(g.aic_filter.w), params=np.array([M, 256, int(pf)]), r=np.array(mic.r))
+
+
+def g16_fdgsc(x16):
+    from DistantSpeech.beamformer.FDGSC import FDGSC
+    x = x16.astype(np.float32) / 32768.0
+    # broadband burst after the SPP's 2L = 120 start-up blocks: drives mean(p[32:128]) over 0.8 (FDGSC.py:251-253)
+    rng = np.random.default_rng(162)
+    burst = rng.standard_normal((4, 256 * 180)) * 0.01
+    s = rng.standard_normal(256 * 180) * 0.3
+    s[: 256 * 135] = 0
+    s[256 * 160:] = 0
+    burst = (burst + s[None, :]).astype(np.float32)
+    for name, xx, M, pf in (("rec1", x[:, : 256 * 150], 4, False), ("rec1_pf", x[:, : 256 * 150], 4, True),
+                            ("synth_m6_pf", synth(161, 6, 256 * 80), 6, True), ("burst", burst, 4, False)):
+        mic = MicArray(arrayType="circular", r=0.032 if M == 4 else 0.05, M=M, n_fft=512)
+        with contextlib.redirect_stdout(io.StringIO()):
+            g = FDGSC(mic, frameLen=256, angle=[197, 0])
+            r = g.process(xx.T.astype(np.float64).copy(), postfilter=pf)
+        save("g16_fdgsc_%s" % name, "FDGSC.process(postfilter=%s, dc_notch=True) FDGSC.py:201-317 (blocking-matrix mode 3)" % pf,
+             x=(x16[:, : 256 * 150] if name.startswith("rec1") else xx), output=r[0], p=r[1], fix_output=r[2],
+             fix_output_delayed=r[3], bm_output=r[4].astype(np.float32), aligned_output_delayed=r[6].astype(np.float32),
+             w_aic=np.array(g.aic_filter.w).astype(np.float32), w_bm0=np.array(g.bm[0].w), params=np.array([M, 256, int(pf)]),
+             r=np.array(mic.r))
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -466,6 +560,9 @@ def main():
     if want("g11"): g11_mcspp(x16)
     if want("g12"): g12_subbandgsc(x16)
     if want("g13"): g13_tdfilters()
+    if want("g14"): g14_fdaf()
+    if want("g15"): g15_tdgsc(x16)
+    if want("g16"): g16_fdgsc(x16)
 
 
 if __name__ == "__main__":

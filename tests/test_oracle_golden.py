@@ -246,3 +246,58 @@ def test_td_filters(golden):
     l2 = O.OracleNlms(300, 0.2, normalization=False)
     e3 = np.array([l2.update(x[i] * 0.1, d[i] * 0.1, p=0.5)[0] for i in range(1000)])
     assert np.allclose(e3, g["e_lms"], rtol=1e-9, atol=1e-12)
+
+
+def _run_fdaf(f, x, d, p, trunc):
+    hop = f.hop_len
+    nb = x.shape[0] // hop
+    e = np.zeros(nb * hop)
+    for n in range(nb):
+        pn = p[n] if np.ndim(p) == 1 else p[n][:, None]
+        en, _ = f.update(x[n * hop:(n + 1) * hop], d[n * hop:(n + 1) * hop], p=pn, fir_truncate=trunc)
+        e[n * hop:(n + 1) * hop] = en[:, 0]
+    return e
+
+
+@pytest.mark.parametrize("case,kind", [("a", "plain"), ("b", "plain"), ("c", "bm"), ("d", "aic")])
+def test_fdaf(golden, case, kind):
+    g = golden("g14_fdaf")
+    L, C, mu, alpha, nc, trunc = g[case + "_params"]
+    f = O.OracleFastFreqLms(filter_len=int(L), mu=float(mu), n_channels=int(C), alpha=float(alpha), non_causal=bool(nc),
+                            kind=kind, weight_norm=(kind == "aic"))
+    e = _run_fdaf(f, g[case + "_x"], g[case + "_d"], g[case + "_p"], None if trunc < 0 else int(trunc))
+    assert np.allclose(e, g[case + "_e"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(f.w, g[case + "_w"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(f.W, g[case + "_W"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(f.P[:, 0], g[case + "_P"], rtol=1e-9, atol=1e-12)
+    if case == "d":
+        assert float(g["d_final_norm"]) > 0.0029          # the norm limiter was active in the fixture
+
+
+@pytest.mark.parametrize("name", ["rec1", "rec1_pf", "synth_m6_pf"])
+def test_tdgsc(golden, name):
+    g = golden("g15_tdgsc_" + name)
+    M, FL, pf = [int(v) for v in g["params"]]
+    x = g["x"].astype(np.float32) / 32768.0 if g["x"].dtype == np.int16 else g["x"]
+    o = O.OracleTDGSC(_mic(M, 512, r=float(g["r"])), frameLen=FL, angle_deg=(197, 0))
+    out, p, obm = o.process(x.T.astype(np.float64), postfilter=bool(pf))
+    assert np.allclose(p, g["p"], atol=1e-12)
+    assert rms(obm - g["output_bm"]) < 1e-6 * rms(g["output_bm"])
+    assert rms(out - g["output"]) < 1e-7 * rms(g["output"])
+    assert np.allclose(o.aic_filter.w, g["w"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["rec1", "rec1_pf", "synth_m6_pf", "burst"])
+def test_fdgsc(golden, name):
+    g = golden("g16_fdgsc_" + name)
+    M, FL, pf = [int(v) for v in g["params"]]
+    x = g["x"].astype(np.float32) / 32768.0 if g["x"].dtype == np.int16 else g["x"]
+    o = O.OracleFDGSC(_mic(M, 512, r=float(g["r"])), frameLen=FL, angle_deg=(197, 0))
+    out, p, fix, fix_d, bm, al, al_d = o.process(x.T.astype(np.float64), postfilter=bool(pf))
+    assert np.allclose(p, g["p"], atol=1e-12)
+    assert rms(fix - g["fix_output"]) < 1e-9 * rms(g["fix_output"])
+    assert rms(fix_d - g["fix_output_delayed"]) < 1e-9 * rms(g["fix_output_delayed"])
+    assert rms(bm - g["bm_output"]) < 1e-6 * rms(g["bm_output"])
+    assert rms(al_d - g["aligned_output_delayed"]) < 1e-6 * rms(g["aligned_output_delayed"])
+    assert rms(out - g["output"]) < 1e-7 * rms(g["output"])
+    assert np.allclose(o.bm[0].w, g["w_bm0"], rtol=1e-7, atol=1e-10)
