@@ -13,6 +13,7 @@
 #include "ds_kernels.hpp"
 #include "ds_ops.hpp"
 #include "ds_tdfilter.hpp"
+#include "ds_fdaf.hpp"
 #include "ds_tables.hpp"
 
 using ds::cf;
@@ -51,6 +52,7 @@ struct ds_handle {
     float* td_cache[2];         // FIR history ping-pong [B][L-1][M]
     int td_L, td_cur;
     float* tdf_w; float* tdf_buf; float* tdf_P;     // DS_ALGO_TDNLMS / TDRLS state
+    int fdaf_kind, fdaf_constrain, fdaf_non_causal, fdaf_weight_norm;   // DS_ALGO_FDAF (state lives in opst)
     // cached hipGraph of a ds_process_device_seq() sequence
     hipGraphExec_t graph_exec;
     int split;                  // DS_PARAM_SPLIT: utterance groups captured as parallel graph branches
@@ -243,6 +245,12 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         case DS_ALGO_FRONTEND:
             if (cfg->n_mics >= 1 && cfg->n_mics <= 16) { op = 100; NF = 0; }
             break;
+        case DS_ALGO_FDAF:
+            if ((cfg->nfft == 128 || cfg->nfft == 256 || cfg->nfft == 512 || cfg->nfft == 1024) && cfg->n_mics >= 1 && cfg->n_mics <= 8) {
+                op = 103;
+                NF = (int)((ds::fdaf_state_floats(cfg->nfft, cfg->n_mics) + KPo - 1) / KPo);
+            }
+            break;
         case DS_ALGO_LINALG:
             if (ds::op_supported(ds::OP_STEERING, cfg->n_mics)) { op = ds::OP_STEERING; NF = 0; }
             break;
@@ -299,6 +307,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     for (int i = 0; i < 10; ++i) { h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0; }
     h->aux_floats = 0;
     h->tdf_w = h->tdf_buf = h->tdf_P = nullptr;
+    h->fdaf_kind = DS_FDAF_PLAIN; h->fdaf_constrain = 1; h->fdaf_non_causal = 0; h->fdaf_weight_norm = 0;
     h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
@@ -416,6 +425,13 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
             if (value <= 0) return fail(h, DS_EINVAL, "mcra_L must be > 0");
             h->mcra_L = value;
             return DS_OK;
+        case DS_PARAM_FDAF_KIND:
+            if (value < DS_FDAF_PLAIN || value > DS_FDAF_AIC) return fail(h, DS_EINVAL, "FDAF kind must be 0..2");
+            h->fdaf_kind = value;
+            return DS_OK;
+        case DS_PARAM_FDAF_CONSTRAIN: h->fdaf_constrain = value != 0; return DS_OK;
+        case DS_PARAM_FDAF_NON_CAUSAL: h->fdaf_non_causal = value != 0; return DS_OK;
+        case DS_PARAM_FDAF_WEIGHT_NORM: h->fdaf_weight_norm = value != 0; return DS_OK;
         case DS_PARAM_SPLIT:
             if (value < 1 || value > 8) return fail(h, DS_EINVAL, "split must be 1..8");
             h->split = value; h->graph_valid = false;
@@ -797,13 +813,13 @@ int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem) {
     return io_end(h, mem, io, dout);
 }
 
-int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mean, int mem) {
-    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_firbank: NULL argument");
-    if (h->cfg.algo != DS_ALGO_FRONTEND) return fail(h, DS_ESTATE, "ds_firbank: handle is not a DS_ALGO_FRONTEND object");
+int ds_firbank_bm(ds_handle* h, const float* x, int n_samples, float* y, float* mean, float* bm, int mem) {
+    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_firbank_bm: NULL argument");
+    if (h->cfg.algo != DS_ALGO_FRONTEND) return fail(h, DS_ESTATE, "ds_firbank_bm: handle is not a DS_ALGO_FRONTEND object");
     const int M = h->cfg.n_mics;
-    if (h->aux_floats == 0 || h->aux_floats % M != 0) return fail(h, DS_ESTATE, "ds_firbank: call ds_set_aux(h, coef[L][M]) first");
+    if (h->aux_floats == 0 || h->aux_floats % M != 0) return fail(h, DS_ESTATE, "ds_firbank_bm: call ds_set_aux(h, coef[L][M]) first");
     const int Lt = (int)(h->aux_floats / M);
-    if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_firbank: n_samples < 0");
+    if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_firbank_bm: n_samples < 0");
     if (n_samples == 0) return DS_OK;
     int rc = set_device(h); if (rc) return rc;
     if (h->td_L != Lt) {                                                      // (re)allocate the history for this tap count
@@ -817,16 +833,20 @@ int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mea
         h->td_L = Lt; h->td_cur = 0;
     }
     const size_t n = (size_t)h->cfg.batch * n_samples;
-    IoSpec io = {{x, nullptr, nullptr}, {n * M * 4, 0, 0}, {y, mean, nullptr, nullptr, nullptr}, {n * M * 4, mean ? n * 4 : 0, 0, 0, 0}};
+    IoSpec io = {{x, nullptr, nullptr}, {n * M * 4, 0, 0}, {y, mean, bm, nullptr, nullptr}, {n * M * 4, mean ? n * 4 : 0, bm ? n * (M - 1) * 4 : 0, 0, 0}};
     const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
     ds::TdParams p;
     std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.M = M; p.n = n_samples; p.L = Lt; p.x = din[0]; p.y = dout[0]; p.mean = dout[1];
+    p.B = h->cfg.batch; p.M = M; p.n = n_samples; p.L = Lt; p.x = din[0]; p.y = dout[0]; p.mean = dout[1]; p.diff = bm ? dout[2] : nullptr;
     p.coef = h->dev_buf[9]; p.cache_in = h->td_cache[h->td_cur]; p.cache_out = h->td_cache[h->td_cur ^ 1];
     DS_HIP(h, ds::launch_fir(p, h->stream));
     h->td_cur ^= 1;
     return io_end(h, mem, io, dout);
+}
+
+int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mean, int mem) {
+    return ds_firbank_bm(h, x, n_samples, y, mean, nullptr, mem);
 }
 
 int ds_tdfilter_update(ds_handle* h, const float* x, const float* d, int n_samples, float p_upd, float* err, int mem) {
@@ -847,6 +867,36 @@ int ds_tdfilter_update(ds_handle* h, const float* x, const float* d, int n_sampl
     p.x = din[0]; p.d = din[1]; p.err = dout[0]; p.w = h->tdf_w; p.buf = h->tdf_buf; p.P = h->tdf_P;
     p.mu = h->filt_mu; p.eps = 1e-4f; p.p = p_upd; p.lam = h->rls_lambda; p.norm = h->norm;
     DS_HIP(h, ds::launch_tdfilter(p, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* pp, int p_mode, int n_blocks, int fir_truncate,
+                   float* err, float* w_out, int mem) {
+    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_fdaf_update: NULL argument");
+    if (h->cfg.algo != DS_ALGO_FDAF) return fail(h, DS_ESTATE, "ds_fdaf_update: handle is not a DS_ALGO_FDAF object");
+    if (n_blocks < 0) return fail(h, DS_ESHAPE, "ds_fdaf_update: n_blocks < 0");
+    if (p_mode < DS_FDAF_P_NONE || p_mode > DS_FDAF_P_BIN || (p_mode != DS_FDAF_P_NONE && !pp))
+        return fail(h, DS_EINVAL, "ds_fdaf_update: p_mode / p mismatch");
+    const int L = h->cfg.nfft / 2, C = h->cfg.n_mics;
+    if (fir_truncate > L) return fail(h, DS_ESHAPE, "ds_fdaf_update: fir_truncate > filter_len");
+    if (n_blocks == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t n = (size_t)h->cfg.batch * n_blocks * L;
+    const size_t pbytes = p_mode == DS_FDAF_P_NONE ? 0 : (size_t)h->cfg.batch * n_blocks * (p_mode == DS_FDAF_P_BIN ? h->K : 1) * 4;
+    IoSpec io = {{x, d, p_mode == DS_FDAF_P_NONE ? nullptr : pp}, {n * C * 4, n * 4, pbytes},
+                 {err, w_out, nullptr, nullptr, nullptr}, {n * 4, w_out ? (size_t)h->cfg.batch * L * C * 4 : 0, 0, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::FdafParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.T = n_blocks; p.C = C;
+    p.kind = h->fdaf_kind; p.constrain = h->fdaf_constrain; p.non_causal = h->fdaf_non_causal; p.weight_norm = h->fdaf_weight_norm;
+    p.trunc = fir_truncate < 0 ? -1 : fir_truncate; p.p_mode = p_mode;
+    p.mu = h->filt_mu; p.alpha = h->filt_alpha;
+    p.x = din[0]; p.d = din[1]; p.p = din[2]; p.err = dout[0]; p.w_out = w_out ? dout[1] : nullptr;
+    p.state = h->opst; p.state_stride = (long long)h->NF * h->KP;
+    p.tables = h->tables;
+    DS_HIP(h, ds::launch_fdaf(p, h->cfg.nfft, h->stream));
     return io_end(h, mem, io, dout);
 }
 

@@ -160,17 +160,20 @@ DS_HD void op_omlsa(const OpParams& p, int b, int k) {
         float Omega = fmaxf_(zy - MU_Y, 1e-6f) / (fmaxf_(zu_minus_mu_max, 0.01f * MU_Y) + 1e-6f);   // :107-109
         Omega = fminf_(fmaxf_(Omega, 0.1f), 100.0f);
         const float gamma_s = fminf_(y0 / fma_(MU_Y, 1.66f, 1e-6f), 100.0f);                     // :115
-        float q;
-        if (gamma_s < 1.0f || Omega < 0.3f) q = 1.0f;                                            // :122-129
-        else q = fmaxf_((10.0f - gamma_s) / (10.0f - 1.0f), (3.0f - Omega) / (3.0f - 0.3f));
-        q = fminf_(fmaxf_(q, 1e-6f), 0.9999998f);                                                // :130
+        // :122-130.  The reference clips q to [1e-6, 0.9999998] and then uses q / (1 - q); in fp32 1 - 0.9999998f is off by
+        // 10 %, so the complement 1 - q = min((gamma_s - 1) / 9, (Omega - 0.3) / 2.7) is formed directly and clipped instead.
+        float omq;
+        if (gamma_s < 1.0f || Omega < 0.3f) omq = 0.0f;
+        else omq = fminf_((gamma_s - 1.0f) / (10.0f - 1.0f), (Omega - 0.3f) / (3.0f - 0.3f));
+        omq = fminf_(fmaxf_(omq, 2e-7f), 1.0f - 1e-6f);
+        const float q = 1.0f - omq;
         float lam = st_at(p, b, o_s + 0, k);
         const float gamma_pre = st_at(p, b, o_s + 1, k), gh1_pre = st_at(p, b, o_s + 2, k);
         const float gamma = y0 / fmaxf_(lam, 1e-10f);                                            // :134
         const float xi = fma_(0.921f * gh1_pre * gh1_pre, gamma_pre, (float)(1.0 - 0.921) * fmaxf_(gamma - 1.0f, 0.0f));   // :137
         const float nu = gamma * xi / (1.0f + xi);                                               // :140
         const float gh1 = xi / (1.0f + xi);                                                      // :144
-        const float pp = 1.0f / (1.0f + q / (1.0f - q) * (1.0f + xi) * expf(-nu));               // :147
+        const float pp = 1.0f / (1.0f + (1.0f - omq) / omq * (1.0f + xi) * expf(-nu));           // :147
         const float at = fma_((float)(1.0 - 0.85), pp, 0.85f);                                   // Base :57, alpha_d = 0.85
         lam = fma_(at, lam, 1.47f * (1.0f - at) * y0);                                           // :149
         float G = powf(gh1, pp) * powf(Gmin, 1.0f - pp);                                         // :153
@@ -886,6 +889,7 @@ struct TdParams {
     const float* x;            // notch: [B][M][n] ; FIR: [B][n][M]
     float* y;                  // same layout as x
     float* mean;               // FIR: optional [B][n] channel mean of y (SubbandGSC.fixed_beamformer, SubbandGSC.py:143)
+    float* diff;               // FIR: optional [B][n][M-1] adjacent-pair differences y[m] - y[m+1] (TDGSC.blocking_matrix, TDGSC.py:69-87)
     float* mem;                // notch: [B][M][2]
     const float* coef;         // FIR: [L][M]
     const float* cache_in;     // FIR: [B][L-1][M]
@@ -914,7 +918,7 @@ DS_HD void td_fir(const TdParams& p, int b, int i) {
     const int M = p.M, L = p.L;
     const float* x = p.x + (long long)b * p.n * M;
     const float* cache = p.cache_in + (long long)b * (L - 1) * M;
-    float acc_mean = 0.0f;
+    float acc_mean = 0.0f, prev = 0.0f;
     for (int m = 0; m < M; ++m) {
         float acc = 0.0f;
         for (int j = 0; j < L; ++j) {
@@ -924,6 +928,8 @@ DS_HD void td_fir(const TdParams& p, int b, int i) {
         }
         p.y[((long long)b * p.n + i) * M + m] = acc;
         acc_mean += acc;
+        if (p.diff && m > 0) p.diff[((long long)b * p.n + i) * (M - 1) + m - 1] = prev - acc;
+        prev = acc;
     }
     if (p.mean) p.mean[(long long)b * p.n + i] = acc_mean / (float)M;
 }

@@ -202,6 +202,48 @@ class BatchEngine:
                                              L.MEM_HOST), self._h)
         return err
 
+    def set_fdaf(self, kind=0, constrain=True, non_causal=False, weight_norm=False):
+        """select the overlap-save FDAF variant of a DS_ALGO_FDAF handle (plain / clamped blocking filter / norm-limited canceller)."""
+        for pid, v in ((L.PARAM_FDAF_KIND, kind), (L.PARAM_FDAF_CONSTRAIN, constrain), (L.PARAM_FDAF_NON_CAUSAL, non_causal),
+                       (L.PARAM_FDAF_WEIGHT_NORM, weight_norm)):
+            L.check(self._lib.ds_set_param_i(self._h, pid, int(v)), self._h)
+
+    def fdaf_update(self, x, d, p=None, fir_truncate=None, want_w=True):
+        """x [B, T*L, C], d [B, T*L] samples (L = nfft/2), p None | [B, T] | [B, T, K] -> (err [B, T*L], w [B, L, C] | None):
+        T successive block updates in one launch."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        Lb = self.nfft // 2
+        if x.ndim != 3 or x.shape[0] != self.batch or x.shape[2] != self.M or x.shape[1] % Lb or d.shape != x.shape[:2]:
+            raise ValueError("fdaf_update: x must be [B=%d, T*%d, C=%d] and d [B, T*%d]" % (self.batch, Lb, self.M, Lb))
+        T = x.shape[1] // Lb
+        if p is None:
+            pm, pp = L.FDAF_P_NONE, None
+        else:
+            pp = np.ascontiguousarray(p, dtype=np.float32)
+            if pp.shape == (self.batch, T):
+                pm = L.FDAF_P_BLOCK
+            elif pp.shape == (self.batch, T, self.K):
+                pm = L.FDAF_P_BIN
+            else:
+                raise ValueError("fdaf_update: p must be [B, T] or [B, T, K=%d], got %s" % (self.K, pp.shape))
+        err = np.empty_like(d)
+        w = np.empty((self.batch, Lb, self.M), dtype=np.float32) if want_w else None
+        L.check(self._lib.ds_fdaf_update(self._h, self._p(x), self._p(d), self._p(pp) if pp is not None else None, pm, T,
+                                         -1 if fir_truncate is None else int(fir_truncate), self._p(err),
+                                         self._p(w) if want_w else None, L.MEM_HOST), self._h)
+        return err, w
+
+    def fdaf_state(self):
+        """(W complex [B, C, K], P [B, K]) of a DS_ALGO_FDAF handle."""
+        nbytes = self._lib.ds_field_bytes(self._h, L.FIELD_OP_STATE)
+        out = np.empty(nbytes // 4, dtype=np.float32)
+        L.check(self._lib.ds_get_state(self._h, L.FIELD_OP_STATE, out.ctypes.data_as(ctypes.c_void_p), nbytes), self._h)
+        st = out.reshape(self.batch, -1)
+        C, K = self.M, self.K
+        W = st[:, : 2 * C * K].copy().view(np.complex64).reshape(self.batch, C, K)
+        return W, st[:, 2 * C * K: 2 * C * K + K].copy()
+
     def tdfilter_weights(self):
         nbytes = self._lib.ds_field_bytes(self._h, L.FIELD_OP_STATE)
         out = np.empty(nbytes // 4, dtype=np.float32)
@@ -215,14 +257,20 @@ class BatchEngine:
         L.check(self._lib.ds_dcnotch(self._h, self._p(x), int(x.shape[2]), self._p(y), L.MEM_HOST), self._h)
         return y
 
-    def firbank(self, x, want_mean=True):
-        """x [B, n, M] -> (y [B, n, M], channel mean [B, n])  (TimeAlignment FIR bank, history carried)."""
+    def firbank(self, x, want_mean=True, want_bm=False):
+        """x [B, n, M] -> (y [B, n, M], channel mean [B, n])  (TimeAlignment FIR bank, history carried);
+        want_bm adds the adjacent-pair differences y[m] - y[m+1] as a third result [B, n, M-1] (TDGSC.py:69-87)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         y = np.empty_like(x)
         mean = np.empty(x.shape[:2], dtype=np.float32) if want_mean else None
-        L.check(self._lib.ds_firbank(self._h, self._p(x), int(x.shape[1]), self._p(y), self._p(mean) if want_mean else None,
-                                     L.MEM_HOST), self._h)
-        return y, mean
+        if not want_bm:
+            L.check(self._lib.ds_firbank(self._h, self._p(x), int(x.shape[1]), self._p(y), self._p(mean) if want_mean else None,
+                                         L.MEM_HOST), self._h)
+            return y, mean
+        bm = np.empty(x.shape[:2] + (x.shape[2] - 1,), dtype=np.float32)
+        L.check(self._lib.ds_firbank_bm(self._h, self._p(x), int(x.shape[1]), self._p(y), self._p(mean) if want_mean else None,
+                                        self._p(bm), L.MEM_HOST), self._h)
+        return y, mean, bm
 
     def omlsa_estimate(self, y, u):
         """y [B, T, K], u [B, T, K, M-1] powers -> (lambda_d, G, p) [B, T, K]."""

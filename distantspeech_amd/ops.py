@@ -545,3 +545,94 @@ class Rls(BaseFilter):
 
     def update(self, x_n, d_n, alpha=1e-4):
         return BaseFilter.update(self, x_n, d_n)
+
+
+class FastFreqLms(_Base):
+    """Overlap-save frequency-domain block LMS — adaptivefilter/FastFreqLms.py:48-245.
+    One `update` = one block of `filter_len` samples through the ds_fdaf kernel (n_fft = 2 * filter_len,
+    filter_len in {64, 128, 256, 512}, n_channels <= 8); `filter` runs a whole signal in one launch."""
+
+    _KIND = L.FDAF_PLAIN
+
+    def __init__(self, filter_len=128, hop_len=None, win_len=None, mu=0.01, constrain=True, n_channels=1, alpha=0.9,
+                 non_causal=False, two_path=False, batch=1, device=-1, weight_norm=False):
+        if two_path:
+            raise NotImplementedError("two_path (foreground/background filters, FastFreqLms.py:99-104) is not built")
+        if (hop_len is not None and hop_len != filter_len) or (win_len is not None and win_len != 2 * filter_len):
+            raise NotImplementedError("only the default framing hop_len = filter_len, win_len = 2 * filter_len is built")
+        self.filter_len, self.hop_len, self.win_len, self.mu = filter_len, filter_len, 2 * filter_len, mu
+        self.n_channels, self.alpha, self.constrain, self.non_causal = n_channels, alpha, constrain, non_causal
+        self.n_fft = 2 ** (int(np.log2(self.hop_len + filter_len - 1)) + 1)                  # :70-71
+        if self.n_fft != 2 * filter_len:
+            raise NotImplementedError("filter_len must be a power of two (n_fft = 2 * filter_len); got %d" % filter_len)
+        self.overlap = self.win_len - self.hop_len
+        self.batch = int(batch)
+        self._eng = BatchEngine(L.ALGO_FDAF, n_channels, self.n_fft, batch=batch, device=device, filt_mu=mu, filt_alpha=alpha)
+        self._eng.set_fdaf(self._KIND, constrain=constrain, non_causal=non_causal, weight_norm=weight_norm)
+        self._w = np.zeros((self.batch, filter_len, n_channels))
+
+    def update(self, x_n_vec, d_n_vec, update=True, p=1.0, fir_truncate=None, filter_p=False):
+        """x [hop] or [hop, C]; d [hop] or [hop, 1]; p scalar or [K, 1] -> (e [hop, 1], w [filter_len, C])."""
+        x = np.asarray(x_n_vec, dtype=np.float32)
+        d = np.asarray(d_n_vec, dtype=np.float32)
+        if self.batch == 1:
+            x = x.reshape(1, self.hop_len, self.n_channels)
+            d = d.reshape(1, self.hop_len)
+        else:
+            x = x.reshape(self.batch, self.hop_len, self.n_channels)
+            d = d.reshape(self.batch, self.hop_len)
+        K = self.n_fft // 2 + 1
+        if not update:
+            pp = np.zeros((self.batch, 1), dtype=np.float32)                                  # W + 0 * grad
+        elif np.ndim(p) == 0:
+            pp = None if float(p) == 1.0 else np.full((self.batch, 1), float(p), dtype=np.float32)
+        else:
+            pp = np.asarray(p, dtype=np.float32).reshape(self.batch, 1, K)
+        e, w = self._eng.fdaf_update(x, d, p=pp, fir_truncate=fir_truncate)
+        self._w = w.astype(np.float64)
+        return self._sq(e.astype(np.float64)[:, :, None]), self.w
+
+    def filter(self, x, d, p=None, fir_truncate=None):
+        """whole signal: x [n, C] (n a multiple of filter_len), d [n], p None | [T] | [T, K] -> e [n]."""
+        x = np.asarray(x, dtype=np.float32)
+        if self.n_channels == 1 and x.ndim == (1 if self.batch == 1 else 2):
+            x = x[..., None]
+        x = self._add_batch(x, 2)
+        d = self._add_batch(np.asarray(d, dtype=np.float32), 1)
+        if p is not None:
+            p = np.asarray(p, dtype=np.float32)
+            p = p[None] if self.batch == 1 else p
+        e, w = self._eng.fdaf_update(x, d, p=p, fir_truncate=fir_truncate)
+        self._w = w.astype(np.float64)
+        return self._sq(e.astype(np.float64))
+
+    @property
+    def w(self):
+        return self._sq(self._w)
+
+    @property
+    def W(self):
+        W, _ = self._eng.fdaf_state()
+        return self._sq(np.swapaxes(W, 1, 2).astype(np.complex128))                          # [K, C]
+
+    @property
+    def P(self):
+        _, P = self._eng.fdaf_state()
+        return self._sq(P.astype(np.float64)[:, :, None])
+
+
+class AdaptiveBlockingMatrixFilter(FastFreqLms):
+    """Coefficient-clamped FDAF of the adaptive blocking matrix — beamformer/gsc_bm.py:22-122."""
+    _KIND = L.FDAF_BM
+
+
+class AdaptiveInterferenceCancellation(FastFreqLms):
+    """Norm-limited FDAF of the interference canceller — beamformer/gsc_aic.py:25-108."""
+    _KIND = L.FDAF_AIC
+
+    def __init__(self, filter_len=128, hop_len=None, win_len=None, mu=0.01, constrain=True, weight_norm=False, n_channels=1,
+                 alpha=0.9, non_causal=False, two_path=False, batch=1, device=-1):
+        FastFreqLms.__init__(self, filter_len=filter_len, hop_len=hop_len, win_len=win_len, mu=mu, constrain=constrain,
+                             n_channels=n_channels, alpha=alpha, non_causal=non_causal, two_path=two_path, batch=batch,
+                             device=device, weight_norm=weight_norm)
+        self.weight_norm = weight_norm

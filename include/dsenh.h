@@ -70,6 +70,9 @@ extern "C" {
 #define DS_ALGO_FRONTEND 13  /* time-domain conditioning: FilterDcNotch16 (feature.py:32-49), TimeAlignment FIR bank (fixedbeamformer.py:13-93) */
 #define DS_ALGO_TDNLMS 14     /* BaseFilter.update (sample-wise NLMS)  adaptivefilter/BaseFilter.py:52-85; filter_len <= 1024 */
 #define DS_ALGO_TDRLS 15      /* Rls.update (sample-wise RLS)         adaptivefilter/RLS.py:26-42; filter_len <= 64 */
+#define DS_ALGO_FDAF 16       /* overlap-save FDAF block filters: FastFreqLms.update (adaptivefilter/FastFreqLms.py:204-245),
+                                 AdaptiveBlockingMatrixFilter.update (beamformer/gsc_bm.py:61-122), AdaptiveInterferenceCancellation.update
+                                 (beamformer/gsc_aic.py:53-108); nfft = 2 * filter_len in {128,256,512,1024}, n_mics = input channels <= 8 */
 #define DS_ALGO_MCSPPBASE 9  /* McSppBase.estimation + PMWF weights  noise_estimation/mcspp_base.py:220-324 */
 
 /* `mem` argument of the frame-level entry points */
@@ -112,6 +115,12 @@ typedef struct ds_config {
 } ds_config;
 
 /* ds_set_param_* ids */
+#define DS_FDAF_PLAIN 0
+#define DS_FDAF_BM 1
+#define DS_FDAF_AIC 2
+#define DS_FDAF_P_NONE 0
+#define DS_FDAF_P_BLOCK 1
+#define DS_FDAF_P_BIN 2
 #define DS_PARAM_METHOD 1   /* int   */
 #define DS_PARAM_MCRA_L 2   /* int   */
 #define DS_PARAM_ALPHA_Y 3  /* float */
@@ -119,6 +128,10 @@ typedef struct ds_config {
 #define DS_PARAM_DIAG 5
 #define DS_PARAM_GATE 6
 #define DS_PARAM_MU 7
+#define DS_PARAM_FDAF_KIND 9         /* int: DS_FDAF_PLAIN / DS_FDAF_BM / DS_FDAF_AIC (DS_ALGO_FDAF handles) */
+#define DS_PARAM_FDAF_CONSTRAIN 10   /* int 0/1: gradient (plain) or coefficient (bm, aic) constraint; default 1 */
+#define DS_PARAM_FDAF_NON_CAUSAL 11  /* int 0/1: delay the desired signal by filter_len / 2 (FastFreqLms.py:84-85,167-168); default 0 */
+#define DS_PARAM_FDAF_WEIGHT_NORM 12 /* int 0/1: norm limiter of the canceller (gsc_aic.py:81-88); default 0 */
 #define DS_PARAM_SPLIT 8   /* int: utterance groups run as parallel hipGraph branches in ds_process_device_seq(graph=1); default 1 */
 
 /* ds_get_state fields; all arrays are float32, complex = interleaved (re, im) */
@@ -200,9 +213,15 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
  *   ds_mvdr_weight     steer complex [B][K][M], Rinv complex [B][K][M][M] -> w complex [B][K][M]
  *   ds_dcnotch         x [B][M][n] -> y [B][M][n]   (DS_ALGO_FRONTEND handle; radius = ds_config.filt_alpha, 0 -> 0.9)
  *   ds_firbank         x [B][n][M] -> y [B][n][M] (+ optional channel mean [B][n]); coefficients [L][M] via ds_set_aux
+ *   ds_firbank_bm      ds_firbank + optional bm [B][n][M-1] = y[m] - y[m+1], the fixed blocking matrix of TDGSC (TDGSC.py:69-87)
  *   ds_tdfilter_update x [B][n], d [B][n] samples -> err [B][n]; n successive BaseFilter.update / Rls.update calls
  *                      (DS_ALGO_TDNLMS: filt_mu 0 -> 0.1, p = update probability; DS_ALGO_TDRLS: filt_mu 0 -> 0.5,
  *                      rls_lambda 0 -> 0.9998); weights via ds_get_state(DS_FIELD_OP_STATE) = [B][L]
+ *   ds_fdaf_update     x [B][T*L][C], d [B][T*L] samples (L = nfft / 2 = filter_len) -> err [B][T*L]; T successive .update calls of
+ *                      the kind selected with DS_PARAM_FDAF_KIND (mu = filt_mu, 0 -> 0.1; alpha = filt_alpha, 0 -> 0.9).
+ *                      p_mode DS_FDAF_P_NONE (p = 1), DS_FDAF_P_BLOCK (p [B][T]) or DS_FDAF_P_BIN (p [B][T][K]);
+ *                      fir_truncate < 0 = None; w_out (or NULL) [B][L][C] = self.w after the last block.
+ *                      State (W, P, input and delay buffers) via ds_get_state(DS_FIELD_OP_STATE), see DESIGN.md.
  *   ds_omlsa_estimate  y [B][T][K], u [B][T][K][M-1] powers -> lambda_d, G, p [B][T][K]
  *   ds_sublms_update   x complex [B][T][K][C], d complex [B][T][K], p [B][T][K] or NULL -> err complex [B][T][K]
  *   ds_subrls_update   x complex [B][T][K], d complex [B][T][K] -> err complex [B][T][K]
@@ -220,7 +239,10 @@ int ds_steering(ds_handle* h, const float* XX, float* v, int mem);
 int ds_mvdr_weight(ds_handle* h, const float* steer, const float* Rinv, float* w, int mem);
 int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem);
 int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mean, int mem);
+int ds_firbank_bm(ds_handle* h, const float* x, int n_samples, float* y, float* mean, float* bm, int mem);
 int ds_tdfilter_update(ds_handle* h, const float* x, const float* d, int n_samples, float p, float* err, int mem);
+int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* p, int p_mode, int n_blocks, int fir_truncate,
+                   float* err, float* w_out, int mem);
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem);
 int ds_sublms_update(ds_handle* h, const float* x, const float* d, const float* p, int n_frames, float* err, int mem);
 int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames, float* err, int mem);

@@ -9,6 +9,7 @@
 #include "../../distantspeech_amd/csrc/ds_ops.hpp"
 #include "../../distantspeech_amd/csrc/ds_tables.hpp"
 #include "../../distantspeech_amd/csrc/ds_tdfilter.hpp"
+#include "../../distantspeech_amd/csrc/ds_fdaf.hpp"
 
 namespace {
 
@@ -65,6 +66,25 @@ template <class E> int run_engine(ds::Params p, int batch, int nfft) {
     p.tables = blob4.data();
     typename E::Sh* sh = new typename E::Sh();
     for (int b = 0; b < batch; ++b) {
+        CpuExec<typename E::Rg> ex;
+        ex.nt = E::NT;
+        ex.R.resize(E::NT);
+        E::run(ex, p, b, *sh);
+    }
+    delete sh;
+    return 0;
+}
+
+template <int NFFT, int CMAX> int run_fdaf(ds::FdafParams p) {
+    typedef ds::FdafEngine<NFFT, CMAX> E;
+    std::vector<float> blob;
+    float os;
+    ds::make_table_blob(NFFT, NFFT / 2, blob, os);
+    std::vector<ds::vec4> blob4(blob.size() / 4);
+    std::memcpy((void*)blob4.data(), blob.data(), blob.size() * sizeof(float));
+    p.tables = blob4.data();
+    typename E::Sh* sh = new typename E::Sh();
+    for (int b = 0; b < p.B; ++b) {
         CpuExec<typename E::Rg> ex;
         ex.nt = E::NT;
         ex.R.resize(E::NT);
@@ -206,5 +226,18 @@ int emul_tdfilter(int mode, int B, int n, int L, const float* x, const float* d,
     }
     delete sh;
     return 0;
+}
+int emul_fdaf(int nfft, int B, int T, int C, int kind, int constrain, int non_causal, int weight_norm, int trunc, int p_mode,
+              float mu, float alpha, const float* x, const float* d, const float* pp, float* err, float* w_out,
+              float* state) {
+    ds::FdafParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = B; p.T = T; p.C = C; p.kind = kind; p.constrain = constrain; p.non_causal = non_causal; p.weight_norm = weight_norm;
+    p.trunc = trunc; p.p_mode = p_mode; p.mu = mu; p.alpha = alpha; p.x = x; p.d = d; p.p = pp; p.err = err; p.w_out = w_out;
+    p.state = state; p.state_stride = ds::fdaf_state_floats(nfft, C);
+#define FD(N_) if (nfft == N_) { if (C == 1) return run_fdaf<N_, 1>(p); if (C <= 4) return run_fdaf<N_, 4>(p); if (C <= 8) return run_fdaf<N_, 8>(p); }
+    FD(128) FD(256) FD(512) FD(1024)
+#undef FD
+    return -1;
 }
 }

@@ -14,7 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 SO = os.path.join(HERE, "libds_emul.so")
 SRCS = [os.path.join(HERE, "ds_emul.cpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_core.hpp"),
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_ops.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tables.hpp"),
-        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tdfilter.hpp")]
+        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tdfilter.hpp"),
+        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_fdaf.hpp")]
 
 
 def build(force=False):
@@ -216,3 +217,40 @@ class EmulTdFilter:
         assert lib().emul_tdfilter(self.mode, self.B, x.shape[1], self.L, _vp(x), _vp(d), _vp(err), _vp(self.w), _vp(self.buf),
                                    _vp(self.P), f(self.mu), f(1e-4), f(p), f(self.lam), self.norm) == 0
         return err
+
+
+class EmulFdaf:
+    """overlap-save FDAF block program (ds_fdaf.hpp); kind 0 plain / 1 clamped blocking filter / 2 norm-limited canceller."""
+
+    def __init__(self, filter_len, n_channels=1, mu=0.01, alpha=0.9, kind=0, constrain=True, non_causal=False,
+                 weight_norm=False, batch=1):
+        self.L, self.C, self.mu, self.alpha, self.kind, self.B = filter_len, n_channels, mu, alpha, kind, batch
+        self.constrain, self.non_causal, self.weight_norm = int(constrain), int(non_causal), int(weight_norm)
+        K, C, L = filter_len + 1, n_channels, filter_len
+        self.K = K
+        self.state = np.zeros((batch, 2 * C * K + K + C * L + L // 2), np.float32)
+
+    @property
+    def W(self):
+        C, K = self.C, self.K
+        return self.state[:, :2 * C * K].copy().view(np.complex64).reshape(self.B, C, K)
+
+    @property
+    def P(self):
+        C, K = self.C, self.K
+        return self.state[:, 2 * C * K:2 * C * K + K]
+
+    def update(self, x, d, p=None, fir_truncate=None, want_w=True):
+        """x [B, T*L, C], d [B, T*L], p None | [B, T] | [B, T, K] -> (err [B, T*L], w [B, L, C])."""
+        x = np.ascontiguousarray(x, np.float32); d = np.ascontiguousarray(d, np.float32)
+        T = x.shape[1] // self.L
+        err = np.zeros_like(d)
+        w = np.zeros((self.B, self.L, self.C), np.float32)
+        pm = 0 if p is None else (1 if np.ndim(p) == 2 else 2)
+        pp = np.zeros(1, np.float32) if p is None else np.ascontiguousarray(p, np.float32)
+        f = ctypes.c_float
+        rc = lib().emul_fdaf(2 * self.L, self.B, T, self.C, self.kind, self.constrain, self.non_causal, self.weight_norm,
+                             -1 if fir_truncate is None else int(fir_truncate), pm, f(self.mu), f(self.alpha), _vp(x), _vp(d), _vp(pp),
+                             _vp(err), _vp(w) if want_w else None, _vp(self.state))
+        assert rc == 0
+        return err, w

@@ -282,3 +282,82 @@ def test_td_filters(ds):
     from distantspeech_amd import _lib as L
     with pytest.raises(L.DsError):
         ds.Rls(filter_len=1024)                                                   # P = 1024 x 1024 does not fit the LDS design
+
+
+def _fdaf_obj(ds, case, g, batch=1):
+    Lf, C, mu, alpha, nc, trunc = g[case + "_params"]
+    kw = dict(filter_len=int(Lf), mu=float(mu), n_channels=int(C), alpha=float(alpha), non_causal=bool(nc), batch=batch)
+    if case == "c":
+        return ds.AdaptiveBlockingMatrixFilter(**kw), None
+    if case == "d":
+        return ds.AdaptiveInterferenceCancellation(weight_norm=True, **kw), None
+    return ds.FastFreqLms(**kw), (None if trunc < 0 else int(trunc))
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_fdaf(ds, case):
+    """FastFreqLms / AdaptiveBlockingMatrixFilter / AdaptiveInterferenceCancellation .update block by block
+    like the reference's loops, and the whole signal in one launch, vs the reference's golden vectors."""
+    g = load("g14_fdaf")
+    f, trunc = _fdaf_obj(ds, case, g)
+    x, d, p = g[case + "_x"], g[case + "_d"], g[case + "_p"]
+    hop = f.hop_len
+    nb = x.shape[0] // hop
+    e = np.zeros(nb * hop)
+    for n in range(nb):
+        pn = float(p[n]) if p.ndim == 1 else p[n][:, None]
+        en, w = f.update(x[n * hop:(n + 1) * hop], d[n * hop:(n + 1) * hop], p=pn, fir_truncate=trunc)
+        assert en.shape == (hop, 1) and w.shape == (f.filter_len, f.n_channels)
+        e[n * hop:(n + 1) * hop] = en[:, 0]
+    assert rms(e - g[case + "_e"]) < 1e-4 * rms(g[case + "_e"])                   # north-star tolerance; measured ~1e-6
+    assert rms(f.w - g[case + "_w"]) < 1e-4 * rms(g[case + "_w"])
+    assert rms(f.W - g[case + "_W"]) < 1e-4 * rms(g[case + "_W"])
+    assert rms(f.P[:, 0] - g[case + "_P"]) < 1e-5 * rms(g[case + "_P"])
+    # all blocks in one launch == block by block, bitwise
+    f2, _ = _fdaf_obj(ds, case, g)
+    e2 = f2.filter(x, d, p=p, fir_truncate=trunc)
+    assert np.array_equal(e2, e) and np.array_equal(f2.w, f.w)
+    # a batch of 3 instances, the middle one fed the fixture
+    f3, _ = _fdaf_obj(ds, case, g, batch=3)
+    xb = np.stack([x * 0.5, x, x * 0.0]).reshape(3, x.shape[0], -1)
+    e3 = f3.filter(xb, np.stack([d, d, d]), p=np.stack([p, p, p]), fir_truncate=trunc)
+    assert np.array_equal(e3[1], e)
+    with pytest.raises(NotImplementedError):
+        ds.FastFreqLms(filter_len=64, two_path=True)
+    with pytest.raises(Exception):
+        ds.FastFreqLms(filter_len=100)                                             # n_fft = 256 != 2 * filter_len: no kernel
+
+
+@pytest.mark.parametrize("name", ["rec1", "rec1_pf", "synth_m6_pf"])
+def test_tdgsc(ds, name):
+    """TDGSC.process (time-aligned FBF + pairwise BM + MCRA-controlled FDAF canceller + OMLSA gain) vs the reference."""
+    g = load("g15_tdgsc_" + name)
+    M, FL, pf = [int(v) for v in g["params"]]
+    x = as_float(g["x"]).T
+    mic = ds.MicArray(arrayType="circular", r=float(g["r"]), M=M, n_fft=512)
+    tg = ds.TDGSC(mic, frameLen=FL, angle=[197, 0])
+    half = (x.shape[0] // FL // 2) * FL                                            # state carried across process() calls
+    o1 = tg.process(x[:half], postfilter=bool(pf))
+    o2 = tg.process(x[half:], postfilter=bool(pf))
+    out = np.concatenate([o1[0], o2[0]]); p = np.concatenate([o1[1], o2[1]], axis=1); bm = np.concatenate([o1[2], o2[2]])
+    assert np.median(np.abs(p - g["p"])) < 1e-3
+    assert rms(bm - g["output_bm"]) < 1e-4 * rms(g["output_bm"])
+    assert rms(out - g["output"]) < 1e-3 * rms(g["output"])
+    assert rms(tg.aic_filter.w - g["w"]) < 1e-3 * rms(g["w"])
+
+
+@pytest.mark.parametrize("name", ["rec1", "rec1_pf", "synth_m6_pf", "burst"])
+def test_fdgsc(ds, name):
+    """FDGSC.process (adaptive blocking matrix mode 3 + norm-limited canceller + OMLSA gain) vs the reference."""
+    g = load("g16_fdgsc_" + name)
+    M, FL, pf = [int(v) for v in g["params"]]
+    x = as_float(g["x"]).T
+    mic = ds.MicArray(arrayType="circular", r=float(g["r"]), M=M, n_fft=512)
+    fg = ds.FDGSC(mic, frameLen=FL, angle=[197, 0])
+    out, p, fix, fix_d, bm, al, al_d = fg.process(x, postfilter=bool(pf))
+    assert np.median(np.abs(p - g["p"])) < 1e-3
+    assert rms(fix - g["fix_output"]) < 1e-4 * rms(g["fix_output"])
+    assert rms(fix_d - g["fix_output_delayed"]) < 1e-4 * rms(g["fix_output_delayed"])
+    assert rms(al_d - g["aligned_output_delayed"]) < 1e-4 * rms(g["aligned_output_delayed"])
+    assert rms(bm - g["bm_output"]) < 1e-3 * rms(g["bm_output"])
+    assert rms(out - g["output"]) < 1e-3 * rms(g["output"])

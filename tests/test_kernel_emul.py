@@ -288,3 +288,28 @@ def test_emul_td_filters_golden():
     e = np.concatenate([rl.update(x[None, a:a + 1000], d[None, a:a + 1000])[0] for a in range(0, x.size, 1000)])
     assert rms(e - g["e_rls"]) < 2e-2 * rms(g["e_rls"])          # fp32 RLS with P0 = 1e3 I, lambda = 0.9998
     assert rms(rl.w[0] - g["w_rls"]) < 2e-2 * rms(g["w_rls"])
+
+
+@pytest.mark.parametrize("case,kind", [("a", 0), ("b", 0), ("c", 1), ("d", 2)])
+def test_emul_fdaf_golden(case, kind):
+    """overlap-save FDAF block program (ds_fdaf.hpp: plain / clamped blocking filter / norm-limited canceller) vs the
+    reference's vectors; a call split in two is bit-identical to one call."""
+    from emul.emul import EmulFdaf
+    g = load("g14_fdaf")
+    Lf, C, mu, alpha, nc, trunc = g[case + "_params"]
+    Lf, C = int(Lf), int(C)
+    trunc = None if trunc < 0 else int(trunc)
+    x, d, p = g[case + "_x"].reshape(-1, C)[None], g[case + "_d"][None], g[case + "_p"][None]
+    mk = lambda: EmulFdaf(Lf, C, mu=float(mu), alpha=float(alpha), kind=kind, non_causal=bool(nc), weight_norm=(kind == 2))
+    f = mk()
+    e, w = f.update(x, d, p=p, fir_truncate=trunc)
+    assert rms(e[0] - g[case + "_e"]) < 1e-5 * rms(g[case + "_e"])
+    assert rms(w[0] - g[case + "_w"]) < 1e-5 * rms(g[case + "_w"])
+    assert rms(f.W[0].T - g[case + "_W"]) < 1e-5 * rms(g[case + "_W"])
+    assert rms(f.P[0] - g[case + "_P"]) < 1e-6 * rms(g[case + "_P"])
+    f2 = mk()
+    T = x.shape[1] // Lf
+    cut = (T // 3) * Lf
+    e1, _ = f2.update(x[:, :cut], d[:, :cut], p=p[:, :T // 3], fir_truncate=trunc, want_w=False)
+    e2, w2 = f2.update(x[:, cut:], d[:, cut:], p=p[:, T // 3:], fir_truncate=trunc)
+    assert np.array_equal(np.concatenate([e1, e2], axis=1), e) and np.array_equal(w2, w)
