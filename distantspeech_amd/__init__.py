@@ -10,8 +10,9 @@ from .ops import Transform, NoiseEstimationMCRA, McMcra, McSppBase, McSpp, steer
 
 from .subband_gsc import SubbandGSC, TimeAlignment, FilterDcNotch16, DelaySamples, fractional_delay_filter_bank
 from .td_gsc import TDGSC, FDGSC
+from .dereverb_mvdr import WpeMvdrPostfilter
 
 __all__ = ["SubbandGSC", "TimeAlignment", "FilterDcNotch16", "DelaySamples", "fractional_delay_filter_bank", "BatchEngine", "MicArray", "compute_tau", "gen_noise_msc", "beamformer", "FixedBeamformer",
            "adaptivebeamfomer", "GSC", "compute_mvdr_weight", "Transform", "NoiseEstimationMCRA", "McMcra", "McSppBase", "McSpp", "steering", "NsOmlsaMulti",
            "SubbandLMS", "SubbandLmsMc", "SubbandRLS", "Wpe", "BaseFilter", "Rls", "FastFreqLms", "AdaptiveBlockingMatrixFilter", "AdaptiveInterferenceCancellation",
-           "TDGSC", "FDGSC"]
+           "TDGSC", "FDGSC", "WpeMvdrPostfilter"]

@@ -13,6 +13,7 @@ DS_OK = 0
 ALGO_FIXED, ALGO_ADAPTIVE, ALGO_GSC = 0, 1, 2
 ALGO_TRANSFORM, ALGO_MCRA, ALGO_MCMCRA, ALGO_OMLSA, ALGO_SUBLMS, ALGO_SUBRLS, ALGO_MCSPPBASE, ALGO_WPE, ALGO_MCSPP, ALGO_LINALG, ALGO_FRONTEND, ALGO_TDNLMS, ALGO_TDRLS = 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 ALGO_FDAF = 16
+ALGO_ADAPTIVE_FRAMES = 17
 FDAF_PLAIN, FDAF_BM, FDAF_AIC = 0, 1, 2
 FDAF_P_NONE, FDAF_P_BLOCK, FDAF_P_BIN = 0, 1, 2
 PARAM_FDAF_KIND, PARAM_FDAF_CONSTRAIN, PARAM_FDAF_NON_CAUSAL, PARAM_FDAF_WEIGHT_NORM = 9, 10, 11, 12
@@ -49,7 +50,7 @@ EXPORTS = [
     "ds_version", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
     "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_pcm16", "ds_process_device",
     "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcmcra_estimate", "ds_mcsppbase_estimate", "ds_set_aux", "ds_mcspp_estimate", "ds_steering",
-    "ds_mvdr_weight", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update",
+    "ds_mvdr_weight", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames",
     "ds_omlsa_estimate",
     "ds_sublms_update", "ds_subrls_update", "ds_wpe_update", "ds_synchronize",
     "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_export_state",
@@ -112,6 +113,8 @@ def load():
     lib.ds_mvdr_weight.argtypes = [vp, vp, vp, vp, ci]
     lib.ds_tdfilter_update.restype = ci
     lib.ds_tdfilter_update.argtypes = [vp, vp, vp, ci, cf_, vp, ci]
+    lib.ds_adaptive_frames.restype = ci
+    lib.ds_adaptive_frames.argtypes = [vp, vp, vp, ci, vp, ci]
     lib.ds_fdaf_update.restype = ci
     lib.ds_fdaf_update.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, ci]
     lib.ds_dcnotch.restype = ci

@@ -245,6 +245,9 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         case DS_ALGO_FRONTEND:
             if (cfg->n_mics >= 1 && cfg->n_mics <= 16) { op = 100; NF = 0; }
             break;
+        case DS_ALGO_ADAPTIVE_FRAMES:
+            if (ds::op_supported(ds::OP_ADAPTIVE, cfg->n_mics)) { op = ds::OP_ADAPTIVE; NF = cfg->n_mics * cfg->n_mics + 5; }
+            break;
         case DS_ALGO_FDAF:
             if ((cfg->nfft == 128 || cfg->nfft == 256 || cfg->nfft == 512 || cfg->nfft == 1024) && cfg->n_mics >= 1 && cfg->n_mics <= 8) {
                 op = 103;
@@ -650,6 +653,8 @@ int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int me
     p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = h->mcra_L; p.first_frame = h->op_first;
     p.in_complex = is_complex; p.has_p = has_p; p.norm = h->norm;
     p.mu = h->filt_mu; p.alpha = h->filt_alpha; p.reg = 1e-4f; p.lam = h->rls_lambda;
+    p.steer = h->steer; p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
+    p.method = h->method; p.alpha_v = h->alpha_v; p.gate = h->gate; p.diag = h->diag;
     DS_HIP(h, ds::launch_binop(h->op, p, h->stream));
     // advance the uniform counters exactly like the kernel did (mcra.py:52-56,72-74)
     for (int t = 0; t < n_frames; ++t) {
@@ -868,6 +873,15 @@ int ds_tdfilter_update(ds_handle* h, const float* x, const float* d, int n_sampl
     p.mu = h->filt_mu; p.eps = 1e-4f; p.p = p_upd; p.lam = h->rls_lambda; p.norm = h->norm;
     DS_HIP(h, ds::launch_tdfilter(p, h->stream));
     return io_end(h, mem, io, dout);
+}
+
+int ds_adaptive_frames(ds_handle* h, const float* Z, const float* gain, int n_frames, float* Y, int mem) {
+    if (!h || !Z || !Y) return fail(h, DS_EINVAL, "ds_adaptive_frames: NULL argument");
+    if (h->cfg.algo == DS_ALGO_ADAPTIVE_FRAMES && !h->steer_set) return fail(h, DS_ESTATE, "ds_adaptive_frames: call ds_set_steering first");
+    if (h->method == DS_METHOD_TFGSC) return fail(h, DS_EUNSUPPORTED, "ds_adaptive_frames: TFGSC needs Ryy, use the fused DS_ALGO_ADAPTIVE kernel");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{Z, gain, nullptr}, {n * h->cfg.n_mics * 8, gain ? n * 4 : 0, 0}, {Y, nullptr, nullptr}, {n * 8, 0, 0}};
+    return run_binop(h, DS_ALGO_ADAPTIVE_FRAMES, "ds_adaptive_frames", n_frames, mem, io, 0, gain ? 1 : 0);
 }
 
 int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* pp, int p_mode, int n_blocks, int fir_truncate,

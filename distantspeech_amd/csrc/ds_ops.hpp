@@ -14,7 +14,7 @@
 namespace ds {
 
 enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4, OP_MCSPPBASE = 5, OP_WPE = 6, OP_MCCDR = 7, OP_MCSPP = 8, OP_STEERING = 9,
-       OP_MVDRW = 10 };
+       OP_MVDRW = 10, OP_ADAPTIVE = 11 };
 
 struct OpParams {
     int B, K, KP, T;          // utterances, bins, padded plane length, frames in this call
@@ -36,6 +36,10 @@ struct OpParams {
     int has_p;                // subband LMS: per-bin update probability given
     int norm;                 // subband LMS: power normalisation on (SubbandAF.py:18)
     float mu, alpha, reg, lam;   // step, power smoothing, regulariser (update(alpha=1e-4)), RLS forgetting factor
+    const cf* steer;          // OP_ADAPTIVE: steering vector a [K][M] (or [B][K][M] with steer_batch_stride)
+    long long steer_batch_stride;
+    int method;               // OP_ADAPTIVE: METHOD_SRC / DS / MVDR
+    float alpha_v, gate, diag;   // OP_ADAPTIVE: adaptivebeamformer.py:66,94,89
 };
 
 DS_HD float& st_at(const OpParams& p, int b, int f, int k) { return p.st[((long long)b * p.NF + f) * p.KP + k]; }
@@ -842,6 +846,44 @@ template <int M> DS_HD void op_mvdrw(const OpParams& p, int b, int k) {
 
 // dispatch one (b, k) of an operator; OP and (for the matrix operators) M are compile-time so every operator
 // gets its own register allocation
+// ------------------------------------------------------------------------------------------------
+// adaptivebeamfomer frame loop on STFT frames — beamformer/adaptivebeamformer.py:69-120 with getweights
+// (beamformer.py:306-336), i.e. the per-bin program of the fused DS_ALGO_ADAPTIVE kernel as a frame-level operator:
+// in0 = Z complex [B][T][K][M], in1 = optional post-filter gain [B][T][K] (has_p); out0 = Y complex [B][T][K] (= w^H Z * gain).
+// state floats: Rvv Hermitian-packed (M diagonal reals, M(M-1)/2 complex upper entries), MCRA S,Smin,Stmp,p,lambda_d
+// ------------------------------------------------------------------------------------------------
+template <int M> DS_HD void op_adaptive(const OpParams& p, int b, int k) {
+    typedef StateLayout<M, ALGO_ADAPTIVE, false> SL;
+    float st[SL::NF];
+#pragma unroll
+    for (int f = 0; f < SL::NF; ++f) st[f] = st_at(p, b, f, k);
+    cf a[M];
+    const cf* sv = p.steer + (long long)b * p.steer_batch_stride + (long long)k * M;
+#pragma unroll
+    for (int m = 0; m < M; ++m) a[m] = sv[m];
+    Params q;
+    q.method = p.method; q.alpha_y = 0.8f; q.alpha_v = p.alpha_v; q.gate = p.gate; q.diag = p.diag;
+    int frm = p.frm_cnt, ell = p.ell;
+    for (int t = 0; t < p.T; ++t) {
+        const long long fb = ((long long)b * p.T + t) * p.K;
+        const long long base = (fb + k) * M;
+        cf Z[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) Z[m] = mk(p.in0[2 * (base + m)], p.in0[2 * (base + m) + 1]);
+        const bool reset = mcra_tick(frm, ell, p.L);
+        float ym = 0.0f, yp = 0.0f;
+        if (k > 0) { const long long i = (fb + k - 1) * M; ym = cabs2(mk(p.in0[2 * i], p.in0[2 * i + 1])); }
+        if (k < p.K - 1) { const long long i = (fb + k + 1) * M; yp = cabs2(mk(p.in0[2 * i], p.in0[2 * i + 1])); }
+        mcra_bin(st + SL::MC_S, k, p.K, ym, cabs2(Z[0]), yp, frm, reset, p.L);          // :81
+        frm += 1; ell += 1;
+        cf Y = adaptive_bin<M, false>(st, Z, a, q);
+        if (p.has_p) Y = cscale(Y, p.in1[fb + k]);
+        p.out0[2 * (fb + k)] = Y.x; p.out0[2 * (fb + k) + 1] = Y.y;
+    }
+#pragma unroll
+    for (int f = 0; f < SL::NF; ++f) st_at(p, b, f, k) = st[f];
+}
+
 template <int OP, int M> DS_HD void run_op_t(const OpParams& p, int b, int k) {
     if constexpr (OP == OP_MCRA) op_mcra(p, b, k);
     else if constexpr (OP == OP_OMLSA) op_omlsa(p, b, k);
@@ -854,13 +896,14 @@ template <int OP, int M> DS_HD void run_op_t(const OpParams& p, int b, int k) {
     else if constexpr (OP == OP_MCSPP) op_mcspp<M>(p, b, k);
     else if constexpr (OP == OP_STEERING) op_steering<M>(p, b, k);
     else if constexpr (OP == OP_MVDRW) op_mvdrw<M>(p, b, k);
+    else if constexpr (OP == OP_ADAPTIVE) op_adaptive<M>(p, b, k);
 }
 
-inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_MCSPP || op == OP_STEERING || op == OP_MVDRW; }
+inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_MCSPP || op == OP_STEERING || op == OP_MVDRW || op == OP_ADAPTIVE; }
 
 // is (op, M) a supported combination?  (matrix operators: M in {2, 4, 6, 8}; McSpp / steering / mvdr weight: {2, 4, 6})
 inline bool op_supported(int op, int M) {
-    if (op == OP_MCMCRA || op == OP_MCSPPBASE) return M == 2 || M == 4 || M == 6 || M == 8;
+    if (op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_ADAPTIVE) return M == 2 || M == 4 || M == 6 || M == 8;
     if (op == OP_MCSPP || op == OP_STEERING || op == OP_MVDRW) return M == 2 || M == 4 || M == 6;
     return true;
 }
@@ -869,7 +912,7 @@ inline bool op_supported(int op, int M) {
 #define DS_OP_M3_LIST(X, OP_) X(OP_, 2) X(OP_, 4) X(OP_, 6)
 #define DS_FOR_EACH_OP(X) \
     X(OP_MCRA, 1) X(OP_OMLSA, 1) X(OP_SUBLMS, 1) X(OP_SUBRLS, 1) X(OP_WPE, 1) X(OP_MCCDR, 1) \
-    DS_OP_M_LIST(X, OP_MCMCRA) DS_OP_M_LIST(X, OP_MCSPPBASE) \
+    DS_OP_M_LIST(X, OP_MCMCRA) DS_OP_M_LIST(X, OP_MCSPPBASE) DS_OP_M_LIST(X, OP_ADAPTIVE) \
     DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_STEERING) DS_OP_M3_LIST(X, OP_MVDRW)
 
 // runtime dispatch for the serial CPU run in tests/emul (the GPU launches one specialised kernel per (OP, M))

@@ -202,6 +202,16 @@ class BatchEngine:
                                              L.MEM_HOST), self._h)
         return err
 
+    def adaptive_frames(self, Z, gain=None):
+        """Z complex [B, T, K, M] STFT frames, gain [B, T, K] or None -> Y complex [B, T, K]: the adaptivebeamfomer frame loop
+        (MCRA-gated Rvv, src/DS/MVDR weights) as a frame-level operator, times the optional post-filter gain."""
+        Z = np.ascontiguousarray(Z, dtype=np.complex64)
+        g = None if gain is None else np.ascontiguousarray(gain, dtype=np.float32)
+        Y = np.empty(Z.shape[:3], dtype=np.complex64)
+        L.check(self._lib.ds_adaptive_frames(self._h, self._p(Z), self._p(g) if g is not None else None, int(Z.shape[1]),
+                                             self._p(Y), L.MEM_HOST), self._h)
+        return Y
+
     def set_fdaf(self, kind=0, constrain=True, non_causal=False, weight_norm=False):
         """select the overlap-save FDAF variant of a DS_ALGO_FDAF handle (plain / clamped blocking filter / norm-limited canceller)."""
         for pid, v in ((L.PARAM_FDAF_KIND, kind), (L.PARAM_FDAF_CONSTRAIN, constrain), (L.PARAM_FDAF_NON_CAUSAL, non_causal),

@@ -73,6 +73,8 @@ extern "C" {
 #define DS_ALGO_FDAF 16       /* overlap-save FDAF block filters: FastFreqLms.update (adaptivefilter/FastFreqLms.py:204-245),
                                  AdaptiveBlockingMatrixFilter.update (beamformer/gsc_bm.py:61-122), AdaptiveInterferenceCancellation.update
                                  (beamformer/gsc_aic.py:53-108); nfft = 2 * filter_len in {128,256,512,1024}, n_mics = input channels <= 8 */
+#define DS_ALGO_ADAPTIVE_FRAMES 17 /* adaptivebeamfomer's frame loop on STFT frames (adaptivebeamformer.py:69-120): the per-bin program of
+                                     DS_ALGO_ADAPTIVE as a frame-level operator, with an optional post-filter gain input */
 #define DS_ALGO_MCSPPBASE 9  /* McSppBase.estimation + PMWF weights  noise_estimation/mcspp_base.py:220-324 */
 
 /* `mem` argument of the frame-level entry points */
@@ -217,6 +219,9 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
  *   ds_tdfilter_update x [B][n], d [B][n] samples -> err [B][n]; n successive BaseFilter.update / Rls.update calls
  *                      (DS_ALGO_TDNLMS: filt_mu 0 -> 0.1, p = update probability; DS_ALGO_TDRLS: filt_mu 0 -> 0.5,
  *                      rls_lambda 0 -> 0.9998); weights via ds_get_state(DS_FIELD_OP_STATE) = [B][L]
+ *   ds_adaptive_frames Z complex [B][T][K][M], gain [B][T][K] or NULL -> Y complex [B][T][K] = (w^H Z) * gain with the MCRA-gated
+ *                      Rvv recursion and src/DS/MVDR weights of adaptivebeamfomer.process (DS_ALGO_ADAPTIVE_FRAMES handle;
+ *                      ds_set_steering, DS_PARAM_METHOD / MCRA_L / ALPHA_V / DIAG / GATE as for DS_ALGO_ADAPTIVE)
  *   ds_fdaf_update     x [B][T*L][C], d [B][T*L] samples (L = nfft / 2 = filter_len) -> err [B][T*L]; T successive .update calls of
  *                      the kind selected with DS_PARAM_FDAF_KIND (mu = filt_mu, 0 -> 0.1; alpha = filt_alpha, 0 -> 0.9).
  *                      p_mode DS_FDAF_P_NONE (p = 1), DS_FDAF_P_BLOCK (p [B][T]) or DS_FDAF_P_BIN (p [B][T][K]);
@@ -241,6 +246,7 @@ int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem);
 int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mean, int mem);
 int ds_firbank_bm(ds_handle* h, const float* x, int n_samples, float* y, float* mean, float* bm, int mem);
 int ds_tdfilter_update(ds_handle* h, const float* x, const float* d, int n_samples, float p, float* err, int mem);
+int ds_adaptive_frames(ds_handle* h, const float* Z, const float* gain, int n_frames, float* Y, int mem);
 int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* p, int p_mode, int n_blocks, int fir_truncate,
                    float* err, float* w_out, int mem);
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem);

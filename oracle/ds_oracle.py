@@ -29,7 +29,7 @@ __all__ = [
     "OracleFixedBeamformer", "OracleMcMcra", "OracleMcSppBase", "OracleMcCDR", "OracleMcSpp", "steering",
     "compute_mvdr_weight", "OracleOmlsaMulti", "OracleGSC",
     "OracleSubbandLMS", "OracleSubbandLmsMc", "OracleSubbandRLS", "OracleWpe", "fractional_delay_filter_bank",
-    "OracleNlms", "OracleRls", "OracleDcNotch", "OracleTimeAlignment", "OracleDelaySamples", "OracleSubbandGSC", "OracleFastFreqLms", "OracleTDGSC", "OracleFDGSC",
+    "OracleNlms", "OracleRls", "OracleDcNotch", "OracleTimeAlignment", "OracleDelaySamples", "OracleSubbandGSC", "OracleFastFreqLms", "OracleTDGSC", "OracleFDGSC", "OracleWpeMvdrPostfilter",
     "synth_utterance",
 ]
 
@@ -1233,6 +1233,42 @@ class OracleFDGSC:
             aligned[sl] = xa; aligned_d[sl] = xad
             output[sl] = np.squeeze(out_n)
         return output, p, fix, fix_d, bm_output, aligned, aligned_d
+
+
+# --------------------------------------------------------------------------------------------
+# BASELINE config 4: WPE dereverberation -> adaptive MVDR -> SPP gain (a composition the reference never writes down)
+# --------------------------------------------------------------------------------------------
+class OracleWpeMvdrPostfilter:
+    """Config-4 composition, defined here from the reference's own pieces because no reference class composes them
+    (parity of the composition is therefore UNPINNED by the reference; each piece is pinned: Wpe G10 (patched reference),
+    adaptivebeamfomer G4, McMcra G5):
+      D   = Transform.stft(x)                              transform.py:430-453
+      E   = Wpe frequency-domain core on (D delayed by `delay` frames, D), all C channels   awpe.py:152-189
+      G   = McMcra.estimation(E).G                          mc_mcra.py:179-224 (the GSC post-filter convention, GSC.py:225,286)
+      Y   = adaptivebeamfomer frame loop on E (MCRA-gated Rvv, MVDR weights) * G          adaptivebeamformer.py:69-120
+      out = Transform.istft(Y)                              transform.py:455-481"""
+
+    def __init__(self, mic, nfft=1024, hop=512, taps=2, delay=4, mcra_L=15):
+        M = mic.M
+        self.M, self.nfft, self.hop = M, nfft, hop
+        self.tf = OracleTransform(channel=M, n_fft=nfft, hop_length=hop)
+        self.wpe = OracleWpe(channels=M, filter_len=taps, num_bands=nfft, delay=delay, hop_length=hop)
+        self.mvdr = OracleAdaptiveMVDR(mic, frameLen=nfft, hop=hop, nfft=nfft, mcra_L=mcra_L)
+        self.spp = OracleMcMcra(nfft=nfft, channels=M)
+        self.ring = [np.zeros((nfft // 2 + 1, M), dtype=complex) for _ in range(delay)]
+
+    def process(self, x, angle_rad, method=2):
+        """x [M, T*hop] -> y [T*hop]."""
+        D = self.tf.stft(np.asarray(x).T)
+        out = []
+        for t in range(D.shape[1]):
+            self.ring.append(D[:, t, :])
+            Xd = self.ring.pop(0)
+            E = self.wpe.update_fd(Xd, D[:, t, :])
+            self.spp.estimation(E)
+            Y = self.mvdr.process_frame(E, angle_rad, method) * self.spp.G
+            out.append(np.atleast_1d(self.tf.istft(Y[:, None, None])))
+        return np.concatenate(out)
 
 
 # --------------------------------------------------------------------------------------------

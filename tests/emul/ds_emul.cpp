@@ -148,6 +148,20 @@ int emul_op(int op, int B, int K, int T, float* st, int NF, const float* in0, co
 }
 
 
+int emul_adaptive_frames(int B, int K, int T, int M, float* st, int NF, const float* Z, const float* gain, float* Y, const float* steer,
+                         int frm_cnt, int ell, int L, int method, float alpha_v, float gate, float diag) {
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = st; p.NF = NF; p.in0 = Z; p.in1 = gain; p.out0 = Y; p.M = M;
+    p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.has_p = gain != nullptr;
+    p.steer = reinterpret_cast<const ds::cf*>(steer); p.steer_batch_stride = 0;
+    p.method = method; p.alpha_v = alpha_v; p.gate = gate; p.diag = diag;
+    if (!ds::op_supported(ds::OP_ADAPTIVE, M)) return -1;
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < K; ++k) ds::run_op(ds::OP_ADAPTIVE, p, b, k);
+    return 0;
+}
+
 // sizes of the per-bin plane storage for (algo, M, ryy): returns NP, writes KP
 int emul_layout(int algo, int nfft, int M, int ryy, int* kp) {
     const int K = nfft / 2 + 1;

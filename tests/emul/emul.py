@@ -254,3 +254,31 @@ class EmulFdaf:
                              _vp(err), _vp(w) if want_w else None, _vp(self.state))
         assert rc == 0
         return err, w
+
+
+class EmulAdaptiveFrames:
+    """adaptivebeamfomer's frame loop as a frame-level operator (op_adaptive in ds_ops.hpp)."""
+
+    def __init__(self, nfft, M, steer, batch=1, L=15, method=2):
+        self.B, self.K, self.M, self.L, self.method = batch, nfft // 2 + 1, M, L, method
+        self.KP = (self.K + 3) & ~3
+        self.NF = M * M + 5
+        self.st = np.zeros((batch, self.NF, self.KP), dtype=np.float32)
+        self.steer = np.ascontiguousarray(steer, dtype=np.complex64)
+        self.frm, self.ell = 0, 1
+
+    def run(self, Z, gain=None):
+        Z = np.ascontiguousarray(Z, dtype=np.complex64)
+        T = Z.shape[1]
+        Y = np.zeros((self.B, T, self.K), dtype=np.complex64)
+        g = None if gain is None else np.ascontiguousarray(gain, dtype=np.float32)
+        f = ctypes.c_float
+        rc = lib().emul_adaptive_frames(self.B, self.K, T, self.M, _vp(self.st), self.NF, _vp(Z), _vp(g), _vp(Y), _vp(self.steer),
+                                        self.frm, self.ell, self.L, self.method, f(0.9998), f(0.4), f(1e-6))
+        assert rc == 0
+        for _ in range(T):
+            if self.frm != 0 and self.ell % self.L == 0:
+                self.ell = 0
+            self.frm += 1
+            self.ell += 1
+        return Y

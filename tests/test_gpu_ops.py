@@ -361,3 +361,28 @@ def test_fdgsc(ds, name):
     assert rms(al_d - g["aligned_output_delayed"]) < 1e-4 * rms(g["aligned_output_delayed"])
     assert rms(bm - g["bm_output"]) < 1e-3 * rms(g["bm_output"])
     assert rms(out - g["output"]) < 1e-3 * rms(g["output"])
+
+
+@pytest.mark.parametrize("M,nfft", [(8, 1024), (4, 512)])
+def test_wpe_mvdr_postfilter(ds, M, nfft):
+    """BASELINE config 4 (8-mic, 1024-FFT: WPE dereverberation -> adaptive MVDR -> SPP gain) vs the oracle's composition of the
+    same pinned pieces (the reference never composes them: OracleWpeMvdrPostfilter docstring).  Batch of 3 distinct utterances,
+    fed in two calls; tolerance = the north star's 1e-4 RMS (absolute, signals are O(0.1)) and 1e-3 relative."""
+    from oracle import ds_oracle as O
+    from _cases import ANGLE, oracle_mic
+    hop, T, B = nfft // 2, 40, 3
+    omic = oracle_mic(M, nfft)
+    xs = np.stack([O.synth_utterance(10 + b, T * hop, omic) for b in range(B)])
+    ref = np.stack([O.OracleWpeMvdrPostfilter(omic, nfft=nfft, hop=hop).process(xs[b], ANGLE) for b in range(B)])
+    mic = ds.MicArray(arrayType="circular", r=omic.r, M=M, n_fft=nfft)
+    obj = ds.WpeMvdrPostfilter(mic, frameLen=nfft, hop=hop, batch=B)
+    cut = 13 * hop
+    y = np.concatenate([obj.process(xs[:, :, :cut], ANGLE)["data"], obj.process(xs[:, :, cut:], ANGLE)["data"]], axis=1)
+    for b in range(B):
+        assert rms(y[b] - ref[b]) < 1e-4
+        assert rms(y[b] - ref[b]) < 1e-3 * rms(ref[b])
+    one = ds.WpeMvdrPostfilter(mic, frameLen=nfft, hop=hop)
+    y1 = one.process(xs[1], ANGLE)["data"]
+    assert np.array_equal(y1, y[1])                                   # batch independence and chunking, bitwise
+    with pytest.raises(ValueError):
+        one.process(xs[1][:, : hop + 1], ANGLE)

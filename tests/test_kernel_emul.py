@@ -313,3 +313,23 @@ def test_emul_fdaf_golden(case, kind):
     e1, _ = f2.update(x[:, :cut], d[:, :cut], p=p[:, :T // 3], fir_truncate=trunc, want_w=False)
     e2, w2 = f2.update(x[:, cut:], d[:, cut:], p=p[:, T // 3:], fir_truncate=trunc)
     assert np.array_equal(np.concatenate([e1, e2], axis=1), e) and np.array_equal(w2, w)
+
+
+@pytest.mark.parametrize("M,nfft", [(4, 512), (8, 1024)])
+def test_emul_adaptive_frames(M, nfft):
+    """op_adaptive (the adaptivebeamfomer frame loop as a frame-level operator, used by the config-4 chain) vs the oracle's
+    process_frame on the same STFT frames; split calls carry the state."""
+    from emul.emul import EmulAdaptiveFrames
+    from oracle import ds_oracle as O
+    from _cases import oracle_mic
+    hop, T = nfft // 2, 50
+    mic = oracle_mic(M, nfft)
+    x = O.synth_utterance(5, T * hop, mic)
+    D = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop).stft(x.T)
+    mv = O.OracleAdaptiveMVDR(mic, frameLen=nfft, hop=hop, nfft=nfft)
+    Yo = np.stack([mv.process_frame(D[:, t, :], ANGLE, 2) for t in range(T)])
+    em = EmulAdaptiveFrames(nfft, M, steering(M, nfft, mic.r))
+    Z = np.transpose(D, (1, 0, 2))[None]
+    g = np.linspace(0.2, 1.0, T * (nfft // 2 + 1)).reshape(1, T, -1).astype(np.float32)
+    Ye = np.concatenate([em.run(Z[:, :20], g[:, :20]), em.run(Z[:, 20:], g[:, 20:])], axis=1)[0]
+    assert rms(Ye - Yo * g[0]) < 1e-4 * rms(Yo)
