@@ -14,6 +14,8 @@ ALGO_FIXED, ALGO_ADAPTIVE, ALGO_GSC = 0, 1, 2
 ALGO_TRANSFORM, ALGO_MCRA, ALGO_MCMCRA, ALGO_OMLSA, ALGO_SUBLMS, ALGO_SUBRLS, ALGO_MCSPPBASE, ALGO_WPE, ALGO_MCSPP, ALGO_LINALG, ALGO_FRONTEND, ALGO_TDNLMS, ALGO_TDRLS = 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
 ALGO_FDAF = 16
 ALGO_ADAPTIVE_FRAMES = 17
+ALGO_WPE_MVDR = 18
+PARAM_WPE_DELAY = 13
 FDAF_PLAIN, FDAF_BM, FDAF_AIC = 0, 1, 2
 FDAF_P_NONE, FDAF_P_BLOCK, FDAF_P_BIN = 0, 1, 2
 PARAM_FDAF_KIND, PARAM_FDAF_CONSTRAIN, PARAM_FDAF_NON_CAUSAL, PARAM_FDAF_WEIGHT_NORM = 9, 10, 11, 12

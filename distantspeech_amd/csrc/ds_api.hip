@@ -53,6 +53,13 @@ struct ds_handle {
     int td_L, td_cur;
     float* tdf_w; float* tdf_buf; float* tdf_P;     // DS_ALGO_TDNLMS / TDRLS state
     int fdaf_kind, fdaf_constrain, fdaf_non_causal, fdaf_weight_norm;   // DS_ALGO_FDAF (state lives in opst)
+    // DS_ALGO_WPE_MVDR: a chain of operator handles sharing this handle's stream, device-resident between the stages
+    ds_handle* sub[5];          // analysis transform (M ch), WPE, McMcra, adaptive frame loop, synthesis transform (1 ch)
+    bool owns_stream;
+    int wpe_delay;
+    float* chain_buf[8];        // D, -, E, p, G, Y, ring of the last wpe_delay analysis frames, -
+    size_t chain_bytes[8];
+    int hist_cur;               // ring slot of the oldest frame
     // cached hipGraph of a ds_process_device_seq() sequence
     hipGraphExec_t graph_exec;
     int split;                  // DS_PARAM_SPLIT: utterance groups captured as parallel graph branches
@@ -138,9 +145,12 @@ int zero_state(ds_handle* h) {
             fill_row(o_s + 1, 1.0f); fill_row(o_s + 2, 1.0f); fill_row(o_s + 3, 1.0f); fill_row(o_s + 5, 1.0f); fill_row(o_s + 6, 1.0f);
             fill_row(5 * h->cfg.n_mics, 1.0f);             // zeta_Y = 1
         }
-        if (h->op == ds::OP_WPE) {                         // awpe.py:69-73: P = I * 1e-3
-            const int CN = h->cfg.n_mics * h->filter_len, oP = 2 * h->cfg.n_mics * CN + 2 * CN;
-            for (int i = 0; i < CN; ++i) fill_row(oP + 2 * (i * CN + i), 1e-3f);
+        if (h->op == ds::OP_WPE) {                         // awpe.py:69-73: P = I * 1e-3 (bin blocks of ds_wpe.hpp)
+            const int C = h->cfg.n_mics, N = h->filter_len, CN = C * N, SB = ds::wpe_bin_floats(C, N);
+            for (int b = 0; b < h->cfg.batch; ++b)
+                for (int k = 0; k < h->K; ++k)
+                    for (int i = 0; i < CN; ++i)
+                        st[(size_t)b * h->NF * h->KP + (size_t)k * SB + 2 * (i * CN + i)] = 1e-3f;
         }
         if (h->op == ds::OP_SUBRLS) {                      // SubbandRLS.py:40-42: P = I / 1e-3
             const int N = h->filter_len;
@@ -248,6 +258,9 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         case DS_ALGO_ADAPTIVE_FRAMES:
             if (ds::op_supported(ds::OP_ADAPTIVE, cfg->n_mics)) { op = ds::OP_ADAPTIVE; NF = cfg->n_mics * cfg->n_mics + 5; }
             break;
+        case DS_ALGO_WPE_MVDR:
+            if (ds::op_supported(ds::OP_ADAPTIVE, cfg->n_mics) && cfg->hop * 2 == cfg->nfft && cfg->n_mics * flen <= ds::WPE_CNMAX) { op = 104; NF = 0; }
+            break;
         case DS_ALGO_FDAF:
             if ((cfg->nfft == 128 || cfg->nfft == 256 || cfg->nfft == 512 || cfg->nfft == 1024) && cfg->n_mics >= 1 && cfg->n_mics <= 8) {
                 op = 103;
@@ -268,7 +281,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             break;
         case DS_ALGO_WPE:
             if (cfg->n_mics >= 1 && cfg->n_mics <= ds::WPE_CMAX && cfg->n_mics * flen <= ds::WPE_CNMAX) {
-                op = ds::OP_WPE; NF = ds::wpe_nf(cfg->n_mics, flen);
+                op = ds::OP_WPE;
+                NF = (int)(((long long)(cfg->nfft / 2 + 1) * ds::wpe_bin_floats(cfg->n_mics, flen) + KPo - 1) / KPo);   // [B][K][bin block]
             }
             break;
         default: return fail(nullptr, DS_EINVAL, "ds_create: unknown algo");
@@ -311,6 +325,9 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->aux_floats = 0;
     h->tdf_w = h->tdf_buf = h->tdf_P = nullptr;
     h->fdaf_kind = DS_FDAF_PLAIN; h->fdaf_constrain = 1; h->fdaf_non_causal = 0; h->fdaf_weight_norm = 0;
+    for (int i = 0; i < 5; ++i) h->sub[i] = nullptr;
+    for (int i = 0; i < 8; ++i) { h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0; }
+    h->owns_stream = true; h->wpe_delay = 4; h->hist_cur = 0;
     h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
@@ -365,6 +382,18 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
 #undef DS_CRE
     int rc = zero_state(h);
     if (rc != DS_OK) { std::string m = h->err; ds_destroy(h); return fail(nullptr, rc, m); }
+    if (cfg->algo == DS_ALGO_WPE_MVDR) {
+        const int algos[5] = {DS_ALGO_TRANSFORM, DS_ALGO_WPE, DS_ALGO_MCMCRA, DS_ALGO_ADAPTIVE_FRAMES, DS_ALGO_TRANSFORM};
+        for (int i = 0; i < 5; ++i) {
+            ds_config c = *cfg;
+            c.algo = algos[i]; c.device = h->device;
+            if (i == 4) c.n_mics = 1;
+            rc = ds_create(&c, &h->sub[i]);
+            if (rc != DS_OK) { std::string m = g_err; ds_destroy(h); return fail(nullptr, rc, "ds_create(DS_ALGO_WPE_MVDR): stage " + std::to_string(i) + ": " + m); }
+            (void)hipStreamDestroy(h->sub[i]->stream);          // every stage runs on the chain's stream
+            h->sub[i]->stream = h->stream; h->sub[i]->owns_stream = false;
+        }
+    }
     *out = h;
     return DS_OK;
 }
@@ -373,6 +402,8 @@ int ds_destroy(ds_handle* h) {
     if (!h) return DS_EINVAL;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 5; ++i) if (h->sub[i]) (void)ds_destroy(h->sub[i]);
+    for (int i = 0; i < 8; ++i) (void)hipFree(h->chain_buf[i]);
     (void)hipFree(h->bins); (void)hipFree(h->tail_in); (void)hipFree(h->tail_out); (void)hipFree(h->counters);
     (void)hipFree(h->tables); (void)hipFree(h->steer);
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage); (void)hipFree(h->opst);
@@ -384,7 +415,7 @@ int ds_destroy(ds_handle* h) {
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return DS_OK;
 }
@@ -393,6 +424,10 @@ int ds_reset(ds_handle* h) {
     if (!h) return DS_EINVAL;
     int rc = set_device(h);
     if (rc) return rc;
+    for (int i = 0; i < 5; ++i)
+        if (h->sub[i]) { rc = ds_reset(h->sub[i]); if (rc) return fail(h, rc, h->sub[i]->err); }
+    if (h->chain_buf[6]) DS_HIP(h, hipMemsetAsync(h->chain_buf[6], 0, h->chain_bytes[6], h->stream));
+    h->hist_cur = 0;
     return zero_state(h);
 }
 
@@ -412,12 +447,22 @@ int ds_set_steering(ds_handle* h, const float* steer, int per_utterance) {
     DS_HIP(h, hipMemcpyAsync(h->steer, steer, need, hipMemcpyHostToDevice, h->stream));
     DS_HIP(h, hipStreamSynchronize(h->stream));
     h->steer_set = true;
+    if (h->sub[3]) { rc = ds_set_steering(h->sub[3], steer, per_utterance); if (rc) return fail(h, rc, h->sub[3]->err); }
     return DS_OK;
 }
 
 int ds_set_param_i(ds_handle* h, int id, int value) {
     if (!h) return DS_EINVAL;
+    if (h->sub[3] && (id == DS_PARAM_METHOD || id == DS_PARAM_MCRA_L)) {
+        const int rc = ds_set_param_i(h->sub[3], id, value);
+        if (rc) return fail(h, rc, h->sub[3]->err);
+    }
     switch (id) {
+        case DS_PARAM_WPE_DELAY:
+            if (h->cfg.algo != DS_ALGO_WPE_MVDR || value < 0 || value > 64) return fail(h, DS_EINVAL, "wpe delay: chain handles only, 0..64 frames");
+            if (h->chain_buf[6]) return fail(h, DS_ESTATE, "wpe delay must be set before the first call");
+            h->wpe_delay = value;
+            return DS_OK;
         case DS_PARAM_METHOD:
             if (value < 0 || value > 3) return fail(h, DS_EINVAL, "method must be 0..3");
             if (value == DS_METHOD_TFGSC && h->cfg.algo == DS_ALGO_ADAPTIVE && !h->cfg.track_ryy)
@@ -445,6 +490,7 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
 
 int ds_set_param_f(ds_handle* h, int id, float value) {
     if (!h) return DS_EINVAL;
+    if (h->sub[3] && (id == DS_PARAM_ALPHA_V || id == DS_PARAM_DIAG || id == DS_PARAM_GATE)) (void)ds_set_param_f(h->sub[3], id, value);
     switch (id) {
         case DS_PARAM_ALPHA_Y: h->alpha_y = value; return DS_OK;
         case DS_PARAM_ALPHA_V: h->alpha_v = value; return DS_OK;
@@ -455,9 +501,21 @@ int ds_set_param_f(ds_handle* h, int id, float value) {
     }
 }
 
+static int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
+                                int n_samples, float* y_dev, long long y_batch_stride);
+
 int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
                       int n_samples, float* y_dev, long long y_batch_stride, int first, int count, void* stream) {
     if (!h || !x_dev || !y_dev) return fail(h, DS_EINVAL, "ds_process_device: NULL argument");
+    if (h->cfg.algo == DS_ALGO_WPE_MVDR) {
+        if (first != 0 || count != h->cfg.batch) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle processes its whole batch");
+        if (stream && (hipStream_t)stream != h->stream) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle runs on its own stream (pass NULL)");
+        if (!h->steer_set) return fail(h, DS_ESTATE, "ds_process_device: call ds_set_steering first");
+        if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_process_device: n_samples must be a multiple of hop");
+        if (layout != DS_LAYOUT_SAMPLES_CHANNELS && layout != DS_LAYOUT_CHANNELS_SAMPLES) return fail(h, DS_EINVAL, "ds_process_device: unknown layout");
+        if (n_samples == 0) return DS_OK;
+        return chain_process_device(h, x_dev, layout, x_batch_stride, x_chan_stride, n_samples, y_dev, y_batch_stride);
+    }
     if (h->cfg.algo > DS_ALGO_GSC) return fail(h, DS_ESTATE, "ds_process_device: this handle is a frame-level object; use ds_stft / ds_*_estimate / ds_sub*_update");
     if (!h->steer_set) return fail(h, DS_ESTATE, "ds_process_device: call ds_set_steering first");
     if (n_samples < 0 || n_samples % h->cfg.hop != 0)
@@ -495,6 +553,8 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
         return fail(h, DS_EINVAL, "ds_process_device_seq: bad n_calls / call strides (must be multiples of 4 elements)");
     if (n_calls == 0) return DS_OK;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    if (graph != 0 && h->cfg.algo == DS_ALGO_WPE_MVDR)
+        return fail(h, DS_EUNSUPPORTED, "ds_process_device_seq: chain handles keep frame counters on the host; use graph = 0");
     if (graph == 0) {
         for (int i = 0; i < n_calls; ++i) {
             int rc = ds_process_device(h, x_dev + (long long)i * x_call_stride, layout, x_batch_stride, x_chan_stride,
@@ -935,11 +995,87 @@ int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames,
     return run_binop(h, DS_ALGO_SUBRLS, "ds_subrls_update", n_frames, mem, io, 0, 0);
 }
 
+static int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len) {
+    if (!h || (!x_delayed && !ring) || !d || !err) return fail(h, DS_EINVAL, "ds_wpe_update: NULL argument");
+    if (h->cfg.algo != DS_ALGO_WPE) return fail(h, DS_ESTATE, "ds_wpe_update: handle was created for a different algo");
+    if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_wpe_update: n_frames < 0");
+    if (n_frames == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t n = (size_t)h->cfg.batch * n_frames * h->K * h->cfg.n_mics * 8;
+    IoSpec io = {{x_delayed, d, nullptr}, {x_delayed ? n : 0, n, 0}, {err, nullptr, nullptr}, {n, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::WpeParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.K = h->K; p.T = n_frames; p.C = h->cfg.n_mics; p.N = h->filter_len;
+    p.xd = din[0]; p.d = din[1]; p.err = dout[0]; p.state = h->opst; p.lam = h->rls_lambda;
+    p.ustride = (long long)h->NF * h->KP;
+    p.ring = ring; p.ring_pos = ring_pos; p.ring_len = ring_len;
+    DS_HIP(h, ds::launch_wpe(p, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
 int ds_wpe_update(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem) {
-    if (!h || !x_delayed || !d || !err) return fail(h, DS_EINVAL, "ds_wpe_update: NULL argument");
-    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K * h->cfg.n_mics;
-    IoSpec io = {{x_delayed, d, nullptr}, {n * 8, n * 8, 0}, {err, nullptr, nullptr}, {n * 8, 0, 0}};
-    return run_binop(h, DS_ALGO_WPE, "ds_wpe_update", n_frames, mem, io, 0, 0);
+    if (!x_delayed) return fail(h, DS_EINVAL, "ds_wpe_update: NULL argument");
+    return wpe_run(h, x_delayed, d, n_frames, err, mem, nullptr, 0, 0);
+}
+
+// DS_ALGO_WPE_MVDR: STFT -> frame delay line -> WPE -> McMcra gain -> adaptive MVDR frame loop x gain -> ISTFT, every stage a
+// kernel on h->stream reading the previous stage's device buffer (nothing returns to the host between the stages)
+static int chain_reserve(ds_handle* h, int T) {
+    const size_t B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, d = h->wpe_delay > 0 ? h->wpe_delay : 1;
+    const size_t need[8] = {B * T * K * M * 8, 0, B * T * K * M * 8, B * T * K * 4, B * T * K * 4, B * T * K * 8, B * d * K * M * 8, 0};
+    for (int i = 0; i < 8; ++i) {
+        if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
+        DS_HIP(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
+        DS_HIP(h, hipMalloc((void**)&h->chain_buf[i], need[i]));
+        h->chain_bytes[i] = need[i];
+        if (i >= 6) DS_HIP(h, hipMemset(h->chain_buf[i], 0, need[i]));      // the stream starts from silence (DelaySamples, awpe.py:75-76)
+    }
+    return DS_OK;
+}
+
+static int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
+                                int n_samples, float* y_dev, long long y_batch_stride) {
+    int rc = set_device(h); if (rc) return rc;
+    const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, T = n_samples / h->cfg.hop;
+    rc = chain_reserve(h, T); if (rc) return rc;
+    float *D = h->chain_buf[0], *E = h->chain_buf[2], *pp = h->chain_buf[3], *G = h->chain_buf[4], *Y = h->chain_buf[5];
+#define DS_SUB(i, call) do { int rc_ = (call); if (rc_) return fail(h, rc_, h->sub[i]->err); } while (0)
+    {   // analysis, strided input like the fused kernels take it
+        ds_handle* t = h->sub[0];
+        Params p;
+        fill_params(t, p);
+        p.x = x_dev; p.y = D;
+        p.x_batch_stride = x_batch_stride;
+        p.y_batch_stride = (long long)T * K * M * 2;
+        if (layout == DS_LAYOUT_CHANNELS_SAMPLES) { p.x_sample_stride = 1; p.x_chan_stride = x_chan_stride > 0 ? x_chan_stride : n_samples; }
+        else { p.x_sample_stride = M; p.x_chan_stride = 1; }
+        p.T = T; p.batch0 = 0;
+        DS_HIP(h, t->ki.launch(p, B, h->stream));
+    }
+    // delayed input of the prediction filter: a ring of the last wpe_delay analysis frames kept by the WPE kernel itself
+    if (h->wpe_delay > 0) {
+        DS_SUB(1, wpe_run(h->sub[1], nullptr, D, T, E, DS_MEM_DEVICE, h->chain_buf[6], h->hist_cur, h->wpe_delay));
+        h->hist_cur = (h->hist_cur + T) % h->wpe_delay;
+    } else {
+        DS_SUB(1, wpe_run(h->sub[1], D, D, T, E, DS_MEM_DEVICE, nullptr, 0, 0));
+    }
+    DS_SUB(2, ds_mcmcra_estimate(h->sub[2], E, T, pp, G, DS_MEM_DEVICE));
+    DS_SUB(3, ds_adaptive_frames(h->sub[3], E, G, T, Y, DS_MEM_DEVICE));
+    {   // synthesis straight into the caller's (strided) output
+        ds_handle* t = h->sub[4];
+        Params p;
+        fill_params(t, p);
+        p.x = Y; p.y = y_dev;
+        p.x_batch_stride = (long long)T * K * 2;
+        p.y_batch_stride = y_batch_stride;
+        p.T = T; p.batch0 = 0; p.method = 1;
+        DS_HIP(h, t->ki_istft.launch(p, B, h->stream));
+    }
+#undef DS_SUB
+    return DS_OK;
 }
 
 int ds_process_pcm16(ds_handle* h, const int16_t* pcm, int n_total_channels, int first_channel, int n_samples, int16_t* out) {
@@ -1092,9 +1228,18 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
     return DS_OK;
 }
 
+static size_t own_state_bytes(const ds_handle* h) {
+    return bins_bytes(h) + tail_in_bytes(h) + tail_out_bytes(h) + counters_bytes(h) + opst_bytes(h) + 4 * sizeof(int);
+}
+static size_t chain_hist_bytes(const ds_handle* h) {
+    return h->cfg.algo == DS_ALGO_WPE_MVDR ? (size_t)h->cfg.batch * (h->wpe_delay > 0 ? h->wpe_delay : 1) * h->K * h->cfg.n_mics * 8 : 0;
+}
+
 size_t ds_state_bytes(const ds_handle* h) {
     if (!h) return 0;
-    return bins_bytes(h) + tail_in_bytes(h) + tail_out_bytes(h) + counters_bytes(h) + opst_bytes(h) + 4 * sizeof(int);
+    size_t n = own_state_bytes(h) + chain_hist_bytes(h);
+    for (int i = 0; i < 5; ++i) if (h->sub[i]) n += ds_state_bytes(h->sub[i]);
+    return n;
 }
 
 int ds_export_state(ds_handle* h, void* dst, size_t bytes) {
@@ -1111,8 +1256,19 @@ int ds_export_state(ds_handle* h, void* dst, size_t bytes) {
     DS_HIP(h, hipMemcpy(d, h->counters, counters_bytes(h), hipMemcpyDeviceToHost)); d += counters_bytes(h);
     if (opst_bytes(h)) DS_HIP(h, hipMemcpy(d, h->opst, opst_bytes(h), hipMemcpyDeviceToHost));
     d += opst_bytes(h);
-    const int uc[4] = {h->op_frm, h->op_ell, h->op_first, 0};
+    const int uc[4] = {h->op_frm, h->op_ell, h->op_first, h->hist_cur};
     std::memcpy(d, uc, sizeof uc);
+    d += sizeof uc;
+    for (int i = 0; i < 5; ++i)
+        if (h->sub[i]) {
+            const size_t n = ds_state_bytes(h->sub[i]);
+            rc = ds_export_state(h->sub[i], d, n); if (rc) return fail(h, rc, h->sub[i]->err);
+            d += n;
+        }
+    if (chain_hist_bytes(h)) {
+        rc = chain_reserve(h, 1); if (rc) return rc;
+        DS_HIP(h, hipMemcpy(d, h->chain_buf[6], chain_hist_bytes(h), hipMemcpyDeviceToHost));
+    }
     return DS_OK;
 }
 
@@ -1132,7 +1288,18 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
     s += opst_bytes(h);
     int uc[4];
     std::memcpy(uc, s, sizeof uc);
-    h->op_frm = uc[0]; h->op_ell = uc[1]; h->op_first = uc[2];
+    s += sizeof uc;
+    h->op_frm = uc[0]; h->op_ell = uc[1]; h->op_first = uc[2]; h->hist_cur = uc[3];
+    for (int i = 0; i < 5; ++i)
+        if (h->sub[i]) {
+            const size_t n = ds_state_bytes(h->sub[i]);
+            rc = ds_import_state(h->sub[i], s, n); if (rc) return fail(h, rc, h->sub[i]->err);
+            s += n;
+        }
+    if (chain_hist_bytes(h)) {
+        rc = chain_reserve(h, 1); if (rc) return rc;
+        DS_HIP(h, hipMemcpy(h->chain_buf[6], s, chain_hist_bytes(h), hipMemcpyHostToDevice));
+    }
     return DS_OK;
 }
 

@@ -102,6 +102,21 @@ hipError_t launch_tdfilter(const TdfParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int LPB> __global__ void __launch_bounds__(WPE_NT) ds_wpe_kernel(WpeParams p) {
+    typedef WpeEngine<LPB> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+hipError_t launch_wpe(const WpeParams& p, hipStream_t stream) {
+    const int lpb = wpe_lanes_per_bin(p.C * p.N), bpw = WPE_NT / lpb;
+    const unsigned blocks = (unsigned)(((long long)p.B * p.K + bpw - 1) / bpw);
+    if (lpb == 4) hipLaunchKernelGGL(ds_wpe_kernel<4>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
+    else if (lpb == 8) hipLaunchKernelGGL(ds_wpe_kernel<8>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
+    else hipLaunchKernelGGL(ds_wpe_kernel<16>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
+    return hipGetLastError();
+}
+
 // realtime wire format (realtime/realtime_processing.py:119-133): int16 LE interleaved [L][C_total] -> float32 / 32768,
 // channels [c0, c0 + M) -> x [B][L][M]; enhanced float -> (y * 32768) truncated to int16
 __global__ void __launch_bounds__(256) ds_pcm16_to_float_kernel(const short* pcm, float* x, long long n, int Ctot, int c0, int M) {

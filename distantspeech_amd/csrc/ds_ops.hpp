@@ -10,6 +10,7 @@
 // Written single-source (DS_HD) so tests/emul can run the same code serially on the CPU.
 #pragma once
 #include "ds_core.hpp"
+#include "ds_wpe.hpp"     // OP_WPE handles run the lane-parallel block program of ds_wpe.hpp, not a per-thread operator
 
 namespace ds {
 
@@ -431,72 +432,6 @@ template <int M> DS_HD void op_mcsppbase(const OpParams& p, int b, int k) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// RLS-based online WPE, frequency-domain core of Wpe.update (dereverberation/awpe.py:129-192) on the STFT grid:
-// in0 = x_delayed complex [B][T][K][C] (the frame from `delay` hops ago), in1 = d complex [B][T][K][C] (current frame);
-// out0 = err complex [B][T][K][C] (dereverberated frame, all channels).
-// state floats: W [C][C*N] complex, input_buffer [C][N] complex, P [C*N][C*N] complex, var
-// ------------------------------------------------------------------------------------------------
-constexpr int WPE_CNMAX = 16, WPE_CMAX = 8;
-DS_HD int wpe_nf(int C, int N) { const int CN = C * N; return 2 * C * CN + 2 * CN + 2 * CN * CN + 1; }
-
-DS_HD void op_wpe(const OpParams& p, int b, int k) {
-    const int C = p.M, N = p.N, CN = C * N;
-    const int oX = 2 * C * CN, oP = oX + 2 * CN, oV = oP + 2 * CN * CN;
-    const float lam = p.lam, lam_inv = 1.0f / p.lam;
-    for (int t = 0; t < p.T; ++t) {
-        const long long fb = (((long long)b * p.T + t) * p.K + k) * C;
-        // buffer_input (:80-102): per channel shift along the taps, newest delayed frame at tap 0
-        for (int c = 0; c < C; ++c) {
-            for (int n = N - 1; n > 0; --n) {
-                st_at(p, b, oX + 2 * (c * N + n), k) = st_at(p, b, oX + 2 * (c * N + n - 1), k);
-                st_at(p, b, oX + 2 * (c * N + n) + 1, k) = st_at(p, b, oX + 2 * (c * N + n - 1) + 1, k);
-            }
-            st_at(p, b, oX + 2 * (c * N), k) = p.in0[2 * (fb + c)];
-            st_at(p, b, oX + 2 * (c * N) + 1, k) = p.in0[2 * (fb + c) + 1];
-        }
-        cf X[WPE_CNMAX], num[WPE_CNMAX], xhP[WPE_CNMAX], err[WPE_CMAX];
-        for (int i = 0; i < CN; ++i) X[i] = mk(st_at(p, b, oX + 2 * i, k), st_at(p, b, oX + 2 * i + 1, k));
-        float dpow = 0.0f;
-        for (int c = 0; c < C; ++c) {                                          // err = d - W^H X  (:158-161)
-            cf out = mk(0.0f, 0.0f);
-            for (int i = 0; i < CN; ++i)
-                out = cfmac(out, X[i], mk(st_at(p, b, 2 * (c * CN + i), k), st_at(p, b, 2 * (c * CN + i) + 1, k)));
-            const cf d = mk(p.in1[2 * (fb + c)], p.in1[2 * (fb + c) + 1]);
-            err[c] = csub(d, out);
-            dpow += cabs2(d);
-        }
-        float var = st_at(p, b, oV, k);
-        var = fma_(0.98f, var, (float)(1.0 - 0.98) * (dpow / (float)C));         // :163-165
-        st_at(p, b, oV, k) = var;
-        cf den = mk(lam * var, 0.0f);
-        for (int i = 0; i < CN; ++i) {
-            cf a = mk(0.0f, 0.0f), r = mk(0.0f, 0.0f);
-            for (int j = 0; j < CN; ++j) {
-                a = cfma(a, mk(st_at(p, b, oP + 2 * (i * CN + j), k), st_at(p, b, oP + 2 * (i * CN + j) + 1, k)), X[j]);   // (P X)_i
-                r = cfmac(r, mk(st_at(p, b, oP + 2 * (j * CN + i), k), st_at(p, b, oP + 2 * (j * CN + i) + 1, k)), X[j]);  // (X^H P)_i
-            }
-            num[i] = a; xhP[i] = r;
-            den = cfmac(den, a, X[i]);                                            // :174-180
-        }
-        for (int i = 0; i < CN; ++i) {
-            const cf kn = cdiv(num[i], den);
-            for (int j = 0; j < CN; ++j) {                                        // P = (P - kn (X^H P)) / lambda  :183-185
-                const int q = oP + 2 * (i * CN + j);
-                const cf pij = cfnma(mk(st_at(p, b, q, k), st_at(p, b, q + 1, k)), kn, xhP[j]);
-                st_at(p, b, q, k) = pij.x * lam_inv;
-                st_at(p, b, q + 1, k) = pij.y * lam_inv;
-            }
-            for (int c = 0; c < C; ++c) {                                         // W_c += conj(err_c) kn  :188-189
-                const cf g = cmulc(kn, err[c]);
-                st_at(p, b, 2 * (c * CN + i), k) += g.x;
-                st_at(p, b, 2 * (c * CN + i) + 1, k) += g.y;
-            }
-        }
-        for (int c = 0; c < C; ++c) { p.out0[2 * (fb + c)] = err[c].x; p.out0[2 * (fb + c) + 1] = err[c].y; }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Small complex-Hermitian linear algebra in registers (full M x M arrays; M <= 8)
 // ------------------------------------------------------------------------------------------------
 // inverse of the Hermitian positive-definite A (overwritten): Cholesky A = L L^H, Linv, inv = Linv^H Linv
@@ -889,7 +824,6 @@ template <int OP, int M> DS_HD void run_op_t(const OpParams& p, int b, int k) {
     else if constexpr (OP == OP_OMLSA) op_omlsa(p, b, k);
     else if constexpr (OP == OP_SUBLMS) op_sublms(p, b, k);
     else if constexpr (OP == OP_SUBRLS) op_subrls(p, b, k);
-    else if constexpr (OP == OP_WPE) op_wpe(p, b, k);
     else if constexpr (OP == OP_MCCDR) op_mccdr(p, b, k);
     else if constexpr (OP == OP_MCMCRA) op_mcmcra<M>(p, b, k);
     else if constexpr (OP == OP_MCSPPBASE) op_mcsppbase<M>(p, b, k);
@@ -911,7 +845,7 @@ inline bool op_supported(int op, int M) {
 #define DS_OP_M_LIST(X, OP_) X(OP_, 2) X(OP_, 4) X(OP_, 6) X(OP_, 8)
 #define DS_OP_M3_LIST(X, OP_) X(OP_, 2) X(OP_, 4) X(OP_, 6)
 #define DS_FOR_EACH_OP(X) \
-    X(OP_MCRA, 1) X(OP_OMLSA, 1) X(OP_SUBLMS, 1) X(OP_SUBRLS, 1) X(OP_WPE, 1) X(OP_MCCDR, 1) \
+    X(OP_MCRA, 1) X(OP_OMLSA, 1) X(OP_SUBLMS, 1) X(OP_SUBRLS, 1) X(OP_MCCDR, 1) \
     DS_OP_M_LIST(X, OP_MCMCRA) DS_OP_M_LIST(X, OP_MCSPPBASE) DS_OP_M_LIST(X, OP_ADAPTIVE) \
     DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_STEERING) DS_OP_M3_LIST(X, OP_MVDRW)
 

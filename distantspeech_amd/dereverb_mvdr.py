@@ -2,9 +2,10 @@
 
 The reference has the three pieces (Wpe.update dereverberation/awpe.py:129-192, adaptivebeamfomer.process
 beamformer/adaptivebeamformer.py:44-128, the McMcra gain post-filter of GSC.py:225,286) but no class that chains them;
-this module defines the chain the way GSC.process chains its stages (one STFT, per-frame stages on the spectrum, one ISTFT)
-and runs every stage in a libdsenh kernel: ds_stft -> ds_wpe_update -> ds_mcmcra_estimate -> ds_adaptive_frames (gain applied
-in the kernel) -> ds_istft.  All T hops of a call go through each kernel in one launch."""
+the chain is defined the way GSC.process chains its stages (one STFT, per-frame stages on the spectrum, one ISTFT) and
+lives behind ONE native handle (DS_ALGO_WPE_MVDR): ds_process() runs STFT -> frame delay line -> ds_wpe_update (all channels)
+-> ds_mcmcra_estimate -> ds_adaptive_frames (gain applied in the kernel) -> ISTFT as six launches on the handle's stream,
+device-resident between the stages, all T hops of a call per launch.  This class only mirrors adaptivebeamfomer's interface."""
 import numpy as np
 
 from . import _lib as L
@@ -19,15 +20,10 @@ class WpeMvdrPostfilter(object):
         self.nfft = int(nfft) if nfft else int(frameLen)
         self.hop = int(hop) if hop else self.nfft // 2
         self.half_bin = self.nfft // 2 + 1
-        M, B = self.M, self.batch
-        self.transform = BatchEngine(L.ALGO_TRANSFORM, M, self.nfft, self.hop, batch=B, device=device)
-        self.wpe = BatchEngine(L.ALGO_WPE, M, self.nfft, batch=B, device=device, filter_len=taps, rls_lambda=forgetting_factor)
-        self.spp = BatchEngine(L.ALGO_MCMCRA, M, self.nfft, batch=B, device=device)
-        self.mvdr = BatchEngine(L.ALGO_ADAPTIVE_FRAMES, M, self.nfft, batch=B, device=device, mcra_L=mcra_L)
-        self.mvdr.set_mcra_L(mcra_L)
-        self._tf_out = BatchEngine(L.ALGO_TRANSFORM, 1, self.nfft, self.hop, batch=B, device=device)
-        self.delay = int(delay)
-        self._hist = np.zeros((B, self.delay, self.half_bin, M), dtype=np.complex64)     # the last `delay` analysis frames
+        self._eng = BatchEngine(L.ALGO_WPE_MVDR, self.M, self.nfft, self.hop, batch=batch, device=device, filter_len=taps,
+                                rls_lambda=forgetting_factor, mcra_L=mcra_L)
+        self._eng.set_mcra_L(mcra_L)
+        self._eng.set_wpe_delay(delay)
         self._angle = None
 
     def _steer(self, angle):
@@ -50,18 +46,8 @@ class WpeMvdrPostfilter(object):
             raise ValueError("x must be [n_chs=%d, k * %d samples]" % (self.M, self.hop))
         key = tuple(np.asarray(angle, dtype=float).ravel())
         if key != self._angle:
-            self.mvdr.set_steering(self._steer(angle))
+            self._eng.set_steering(self._steer(angle))
             self._angle = key
-        self.mvdr.set_method(method)
-        D = self.transform.stft(x, L.LAYOUT_CHANNELS_SAMPLES)                      # [B, T, K, M]
-        T = D.shape[1]
-        if T == 0:
-            return {"data": np.zeros((0,) if single else (self.batch, 0))}
-        seq = np.concatenate((self._hist, D), axis=1)
-        Xd = np.ascontiguousarray(seq[:, :T])                                      # frame t - delay
-        self._hist = np.ascontiguousarray(seq[:, T:])
-        E = self.wpe.wpe_update(Xd, D)                                             # [B, T, K, M]
-        _, G = self.spp.mcmcra_estimate(E)
-        Y = self.mvdr.adaptive_frames(E, G)                                        # [B, T, K]
-        y = self._tf_out.istft(Y[:, :, :, None])[:, :, 0].astype(np.float64)
+        self._eng.set_method(method)
+        y = self._eng.process(x, L.LAYOUT_CHANNELS_SAMPLES).astype(np.float64)
         return {"data": y[0] if single else y}

@@ -54,6 +54,10 @@ class BatchEngine:
         """graph mode of process_device_seq: run n utterance groups as parallel branches (memory/compute overlap)."""
         L.check(self._lib.ds_set_param_i(self._h, L.PARAM_SPLIT, int(n)), self._h)
 
+    def set_wpe_delay(self, frames):
+        """prediction delay (frames) of a DS_ALGO_WPE_MVDR chain handle; before the first call."""
+        L.check(self._lib.ds_set_param_i(self._h, L.PARAM_WPE_DELAY, int(frames)), self._h)
+
     def set_mcra_L(self, value):
         L.check(self._lib.ds_set_param_i(self._h, L.PARAM_MCRA_L, int(value)), self._h)
 
@@ -315,6 +319,13 @@ class BatchEngine:
         err = np.empty(d.shape, dtype=np.complex64)
         L.check(self._lib.ds_wpe_update(self._h, self._p(xd), self._p(d), int(d.shape[1]), self._p(err), L.MEM_HOST), self._h)
         return err
+
+    def op_state_raw(self):
+        """the operator state exactly as it sits in HBM (flat float32 per utterance)."""
+        nbytes = self._lib.ds_field_bytes(self._h, L.FIELD_OP_STATE)
+        out = np.empty(nbytes // 4, dtype=np.float32)
+        L.check(self._lib.ds_get_state(self._h, L.FIELD_OP_STATE, out.ctypes.data_as(ctypes.c_void_p), nbytes), self._h)
+        return out.reshape(self.batch, -1)
 
     def op_state(self):
         """raw operator state [B, NF, K] (rows documented in distantspeech_amd/ops.py)."""

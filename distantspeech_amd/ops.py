@@ -490,20 +490,22 @@ class Wpe(_SubbandBase):
         out = y[:, :, 0].astype(np.float64)
         return self._sq(out), self.W
 
+    def _blocks(self):
+        """per-bin state blocks [B, K, slots, CN] complex (layout of csrc/ds_wpe.hpp: slot q < CN: P[:, q]; then W[c, :]; then taps)."""
+        C, CN = self.channels, self.channels * self.filter_len
+        SB = ((CN + C + 1) * CN * 2 + 1 + 3) & ~3
+        raw = self._eng.op_state_raw().reshape(self.batch, -1)[:, : self.half_band * SB].reshape(self.batch, self.half_band, SB)
+        return raw[:, :, : (CN + C + 1) * CN * 2].copy().view(np.complex64).reshape(self.batch, self.half_band, CN + C + 1, CN)
+
     @property
     def W(self):
         C, CN = self.channels, self.channels * self.filter_len
-        st = self._eng.op_state()[:, : 2 * C * CN, :].reshape(self.batch, C, CN, 2, self.half_band)
-        W = (st[:, :, :, 0, :] + 1j * st[:, :, :, 1, :]).astype(np.complex128)
-        return self._sq(np.transpose(W, (0, 3, 1, 2)))                               # [half_band, C, C*N]
+        return self._sq(self._blocks()[:, :, CN:CN + C, :].astype(np.complex128))     # [half_band, C, C*N]
 
     @property
     def P(self):
-        C, CN = self.channels, self.channels * self.filter_len
-        o = 2 * C * CN + 2 * CN
-        st = self._eng.op_state()[:, o: o + 2 * CN * CN, :].reshape(self.batch, CN, CN, 2, self.half_band)
-        P = (st[:, :, :, 0, :] + 1j * st[:, :, :, 1, :]).astype(np.complex128)
-        return self._sq(np.transpose(P, (0, 3, 1, 2)))
+        CN = self.channels * self.filter_len
+        return self._sq(np.swapaxes(self._blocks()[:, :, :CN, :], 2, 3).astype(np.complex128))   # [half_band, CN, CN]
 
 
 class BaseFilter(_Base):

@@ -75,6 +75,10 @@ extern "C" {
                                  (beamformer/gsc_aic.py:53-108); nfft = 2 * filter_len in {128,256,512,1024}, n_mics = input channels <= 8 */
 #define DS_ALGO_ADAPTIVE_FRAMES 17 /* adaptivebeamfomer's frame loop on STFT frames (adaptivebeamformer.py:69-120): the per-bin program of
                                      DS_ALGO_ADAPTIVE as a frame-level operator, with an optional post-filter gain input */
+#define DS_ALGO_WPE_MVDR 18    /* BASELINE config 4 as ONE handle behind ds_process / ds_process_device: STFT -> WPE (awpe.py:152-189, all channels,
+                                 `filter_len` taps, `wpe_delay`-frame prediction delay = ds_config.mcra_L field is NOT reused: see ds_config.filter_len /
+                                 DS_PARAM_WPE_DELAY) -> McMcra gain (mc_mcra.py:179-224) -> adaptive MVDR frame loop (adaptivebeamformer.py:69-120)
+                                 x gain -> ISTFT; device-resident between the stages, all on the handle's stream */
 #define DS_ALGO_MCSPPBASE 9  /* McSppBase.estimation + PMWF weights  noise_estimation/mcspp_base.py:220-324 */
 
 /* `mem` argument of the frame-level entry points */
@@ -134,6 +138,7 @@ typedef struct ds_config {
 #define DS_PARAM_FDAF_CONSTRAIN 10   /* int 0/1: gradient (plain) or coefficient (bm, aic) constraint; default 1 */
 #define DS_PARAM_FDAF_NON_CAUSAL 11  /* int 0/1: delay the desired signal by filter_len / 2 (FastFreqLms.py:84-85,167-168); default 0 */
 #define DS_PARAM_FDAF_WEIGHT_NORM 12 /* int 0/1: norm limiter of the canceller (gsc_aic.py:81-88); default 0 */
+#define DS_PARAM_WPE_DELAY 13        /* int >= 0: prediction delay of the DS_ALGO_WPE_MVDR chain in frames (awpe.py:36, default 4); set before the first call */
 #define DS_PARAM_SPLIT 8   /* int: utterance groups run as parallel hipGraph branches in ds_process_device_seq(graph=1); default 1 */
 
 /* ds_get_state fields; all arrays are float32, complex = interleaved (re, im) */

@@ -94,6 +94,20 @@ template <int NFFT, int CMAX> int run_fdaf(ds::FdafParams p) {
     return 0;
 }
 
+template <int LPB> int run_wpe(const ds::WpeParams& p) {
+    typedef ds::WpeEngine<LPB> E;
+    typename E::Sh* sh = new typename E::Sh();
+    const int blocks = (int)(((long long)p.B * p.K + E::BPW - 1) / E::BPW);
+    for (int b = 0; b < blocks; ++b) {
+        CpuExec<typename E::Rg> ex;
+        ex.nt = E::NT;
+        ex.R.resize(E::NT);
+        E::run(ex, p, b, *sh);
+    }
+    delete sh;
+    return 0;
+}
+
 template <int NFFT> int run_tf(int M, bool inverse, const ds::Params& p, int batch) {
 #define TF(M_) if (M == M_) return inverse ? run_engine<ds::IstftEngine<NFFT, M_>>(p, batch, NFFT) : run_engine<ds::StftEngine<NFFT, M_>>(p, batch, NFFT);
     TF(1) TF(2) TF(4) TF(6) TF(8)
@@ -160,6 +174,15 @@ int emul_adaptive_frames(int B, int K, int T, int M, float* st, int NF, const fl
     for (int b = 0; b < B; ++b)
         for (int k = 0; k < K; ++k) ds::run_op(ds::OP_ADAPTIVE, p, b, k);
     return 0;
+}
+
+int emul_wpe(int B, int K, int T, int C, int N, const float* xd, const float* d, float* err, float* state, float lam) {
+    ds::WpeParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = B; p.K = K; p.T = T; p.C = C; p.N = N; p.xd = xd; p.d = d; p.err = err; p.state = state;
+    p.ustride = (long long)K * ds::wpe_bin_floats(C, N); p.lam = lam;
+    const int lpb = ds::wpe_lanes_per_bin(C * N);
+    return lpb == 4 ? run_wpe<4>(p) : lpb == 8 ? run_wpe<8>(p) : run_wpe<16>(p);
 }
 
 // sizes of the per-bin plane storage for (algo, M, ryy): returns NP, writes KP

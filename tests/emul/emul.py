@@ -15,7 +15,7 @@ SO = os.path.join(HERE, "libds_emul.so")
 SRCS = [os.path.join(HERE, "ds_emul.cpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_core.hpp"),
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_ops.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tables.hpp"),
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tdfilter.hpp"),
-        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_fdaf.hpp")]
+        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_fdaf.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_wpe.hpp")]
 
 
 def build(force=False):
@@ -282,3 +282,22 @@ class EmulAdaptiveFrames:
             self.frm += 1
             self.ell += 1
         return Y
+
+
+class EmulWpe:
+    """lane-parallel RLS-WPE block program (ds_wpe.hpp); state = one block per (utterance, bin), see wpe_bin_floats()."""
+
+    def __init__(self, nfft, C, N, batch=1, lam=0.998):
+        self.B, self.K, self.C, self.N, self.lam = batch, nfft // 2 + 1, C, N, lam
+        CN = C * N
+        self.SB = ((CN + C + 1) * CN * 2 + 1 + 3) & ~3
+        self.state = np.zeros((batch, self.K, self.SB), np.float32)
+        for i in range(CN):
+            self.state[:, :, 2 * (i * CN + i)] = 1e-3
+
+    def run(self, xd, d):
+        xd = np.ascontiguousarray(xd, np.complex64); d = np.ascontiguousarray(d, np.complex64)
+        err = np.zeros_like(d)
+        assert lib().emul_wpe(self.B, self.K, d.shape[1], self.C, self.N, _vp(xd), _vp(d), _vp(err), _vp(self.state),
+                              ctypes.c_float(self.lam)) == 0
+        return err

@@ -386,3 +386,14 @@ def test_wpe_mvdr_postfilter(ds, M, nfft):
     assert np.array_equal(y1, y[1])                                   # batch independence and chunking, bitwise
     with pytest.raises(ValueError):
         one.process(xs[1][:, : hop + 1], ANGLE)
+    # checkpoint / resume of the whole chain (every stage's state + the WPE delay ring), and reset
+    a = ds.WpeMvdrPostfilter(mic, frameLen=nfft, hop=hop)
+    a.process(xs[1][:, : 7 * hop], ANGLE)
+    blob = a._eng.export_state()
+    tail = a.process(xs[1][:, 7 * hop:], ANGLE)["data"]
+    b2 = ds.WpeMvdrPostfilter(mic, frameLen=nfft, hop=hop)
+    b2.process(xs[0][:, : 3 * hop], ANGLE)                               # dirty it first
+    b2._eng.import_state(blob)
+    assert np.array_equal(b2.process(xs[1][:, 7 * hop:], ANGLE)["data"], tail)
+    b2._eng.reset()
+    assert np.array_equal(b2.process(xs[1], ANGLE)["data"], y1)

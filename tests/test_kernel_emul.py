@@ -200,8 +200,9 @@ def test_emul_wpe_golden(name):
     tf = EmulTransform(nb, C)
     Dn = tf.stft(x[None], 0)                                                   # [1, T, K, C]
     Xd = np.concatenate([np.zeros((1, D) + Dn.shape[2:], np.complex64), Dn[:, : T - D]], axis=1)
-    op = EmulOp("wpe", nb, M=C, N=N, lam=0.998)
-    err = op.run(Xd, Dn, out_shapes=[((C,), np.complex64)])[0]
+    from emul.emul import EmulWpe
+    op = EmulWpe(nb, C, N)
+    err = np.concatenate([op.run(Xd[:, :7], Dn[:, :7]), op.run(Xd[:, 7:], Dn[:, 7:])], axis=1)     # state carried across calls
     y = tf.istft(np.ascontiguousarray(err[:, :, :, :1]))[0, :, 0]
     assert rms(y - g["y"]) < 2e-4 * max(rms(g["y"]), 1e-3)
 
