@@ -53,12 +53,13 @@ struct ds_handle {
     int td_L, td_cur;
     float* tdf_w; float* tdf_buf; float* tdf_P;     // DS_ALGO_TDNLMS / TDRLS state
     int fdaf_kind, fdaf_constrain, fdaf_non_causal, fdaf_weight_norm;   // DS_ALGO_FDAF (state lives in opst)
+    int x_fan, p_complement;    // subband LMS / RLS inside a chain: shared reference input, 1 - p (OpParams)
     // DS_ALGO_WPE_MVDR: a chain of operator handles sharing this handle's stream, device-resident between the stages
-    ds_handle* sub[5];          // analysis transform (M ch), WPE, McMcra, adaptive frame loop, synthesis transform (1 ch)
+    ds_handle* sub[10];         // WPE_MVDR: analysis transform, WPE, McMcra, adaptive frame loop, synthesis transform; SUBBAND_GSC: see chain2_*
     bool owns_stream;
     int wpe_delay;
-    float* chain_buf[8];        // D, -, E, p, G, Y, ring of the last wpe_delay analysis frames, -
-    size_t chain_bytes[8];
+    float* chain_buf[16];       // WPE_MVDR: D, -, E, p, G, Y, ring of the last wpe_delay analysis frames; SUBBAND_GSC: see chain2_reserve
+    size_t chain_bytes[16];
     int hist_cur;               // ring slot of the oldest frame
     // cached hipGraph of a ds_process_device_seq() sequence
     hipGraphExec_t graph_exec;
@@ -258,6 +259,9 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         case DS_ALGO_ADAPTIVE_FRAMES:
             if (ds::op_supported(ds::OP_ADAPTIVE, cfg->n_mics)) { op = ds::OP_ADAPTIVE; NF = cfg->n_mics * cfg->n_mics + 5; }
             break;
+        case DS_ALGO_SUBBAND_GSC:
+            if (ds::op_supported(ds::OP_MCSPP, cfg->n_mics) && cfg->n_mics >= 3 && cfg->hop * 2 == cfg->nfft && flen <= ds::RLS_NMAX) { op = 105; NF = 0; }
+            break;
         case DS_ALGO_WPE_MVDR:
             if (ds::op_supported(ds::OP_ADAPTIVE, cfg->n_mics) && cfg->hop * 2 == cfg->nfft && cfg->n_mics * flen <= ds::WPE_CNMAX) { op = 104; NF = 0; }
             break;
@@ -324,9 +328,10 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     for (int i = 0; i < 10; ++i) { h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0; }
     h->aux_floats = 0;
     h->tdf_w = h->tdf_buf = h->tdf_P = nullptr;
+    h->x_fan = 1; h->p_complement = 0;
     h->fdaf_kind = DS_FDAF_PLAIN; h->fdaf_constrain = 1; h->fdaf_non_causal = 0; h->fdaf_weight_norm = 0;
-    for (int i = 0; i < 5; ++i) h->sub[i] = nullptr;
-    for (int i = 0; i < 8; ++i) { h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0; }
+    for (int i = 0; i < 10; ++i) h->sub[i] = nullptr;
+    for (int i = 0; i < 16; ++i) { h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0; }
     h->owns_stream = true; h->wpe_delay = 4; h->hist_cur = 0;
     h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
@@ -394,6 +399,34 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             h->sub[i]->stream = h->stream; h->sub[i]->owns_stream = false;
         }
     }
+    if (cfg->algo == DS_ALGO_SUBBAND_GSC) {
+        // stages of SubbandGSC.__init__ (SubbandGSC.py:85-124): 0 front end (notch radius 0.98 + TimeAlignment), 1 transform (M),
+        // 2 McSpp, 3 bm[m].transform_x (identical for all m: one 1-channel transform), 4 bm[m].transform_d (B * M 1-channel
+        // transforms: analysis of the aligned channels and synthesis of the blocking-filter outputs), 5 the M blocking filters as one
+        // batch of B * M, 6 aic_filter.transform_x (M), 7 aic_filter (SubbandLmsMc, mu 0.01, alpha 0.8), 8 aic_filter.transform_d
+        const int M = cfg->n_mics;
+        const bool rls = cfg->rls_lambda > 0.0f;
+        for (int i = 0; i < 9; ++i) {
+            ds_config c = *cfg;
+            c.device = h->device; c.filter_len = flen;
+            switch (i) {
+                case 0: c.algo = DS_ALGO_FRONTEND; c.filt_alpha = 0.98f; break;
+                case 1: case 6: c.algo = DS_ALGO_TRANSFORM; break;
+                case 2: c.algo = DS_ALGO_MCSPP; break;
+                case 3: case 8: c.algo = DS_ALGO_TRANSFORM; c.n_mics = 1; break;
+                case 4: c.algo = DS_ALGO_TRANSFORM; c.n_mics = 1; c.batch = cfg->batch * M; break;
+                case 5: c.algo = rls ? DS_ALGO_SUBRLS : DS_ALGO_SUBLMS; c.n_mics = 1; c.batch = cfg->batch * M;
+                        c.filt_mu = rls ? 0.0f : 0.1f; c.filt_alpha = 0.0f; break;           // SubbandGSC.py:99-101 / SubbandRLS defaults
+                case 7: c.algo = DS_ALGO_SUBLMS; c.filt_mu = 0.01f; c.filt_alpha = 0.8f; c.rls_lambda = 0.0f; break;   // :103-109
+            }
+            rc = ds_create(&c, &h->sub[i]);
+            if (rc != DS_OK) { std::string m = g_err; ds_destroy(h); return fail(nullptr, rc, "ds_create(DS_ALGO_SUBBAND_GSC): stage " + std::to_string(i) + ": " + m); }
+            (void)hipStreamDestroy(h->sub[i]->stream);
+            h->sub[i]->stream = h->stream; h->sub[i]->owns_stream = false;
+        }
+        h->sub[5]->x_fan = M;                 // the M blocking filters of an utterance share its fixed-beamformer spectrum and p
+        h->sub[7]->p_complement = 1;          // SubbandGSC.py:232: p = 1 - p
+    }
     *out = h;
     return DS_OK;
 }
@@ -402,8 +435,8 @@ int ds_destroy(ds_handle* h) {
     if (!h) return DS_EINVAL;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 5; ++i) if (h->sub[i]) (void)ds_destroy(h->sub[i]);
-    for (int i = 0; i < 8; ++i) (void)hipFree(h->chain_buf[i]);
+    for (int i = 0; i < 10; ++i) if (h->sub[i]) (void)ds_destroy(h->sub[i]);
+    for (int i = 0; i < 16; ++i) (void)hipFree(h->chain_buf[i]);
     (void)hipFree(h->bins); (void)hipFree(h->tail_in); (void)hipFree(h->tail_out); (void)hipFree(h->counters);
     (void)hipFree(h->tables); (void)hipFree(h->steer);
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage); (void)hipFree(h->opst);
@@ -424,9 +457,12 @@ int ds_reset(ds_handle* h) {
     if (!h) return DS_EINVAL;
     int rc = set_device(h);
     if (rc) return rc;
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 10; ++i)
         if (h->sub[i]) { rc = ds_reset(h->sub[i]); if (rc) return fail(h, rc, h->sub[i]->err); }
-    if (h->chain_buf[6]) DS_HIP(h, hipMemsetAsync(h->chain_buf[6], 0, h->chain_bytes[6], h->stream));
+    if (h->cfg.algo == DS_ALGO_WPE_MVDR && h->chain_buf[6]) DS_HIP(h, hipMemsetAsync(h->chain_buf[6], 0, h->chain_bytes[6], h->stream));
+    if (h->cfg.algo == DS_ALGO_SUBBAND_GSC)
+        for (int i = 13; i < 15; ++i)
+            if (h->chain_buf[i]) DS_HIP(h, hipMemsetAsync(h->chain_buf[i], 0, h->chain_bytes[i], h->stream));
     h->hist_cur = 0;
     return zero_state(h);
 }
@@ -503,10 +539,21 @@ int ds_set_param_f(ds_handle* h, int id, float value) {
 
 static int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
                                 int n_samples, float* y_dev, long long y_batch_stride);
+static int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
+                      float* fix_dev, float* bm_dev, float* p_dev, float* al_dev);
 
 int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
                       int n_samples, float* y_dev, long long y_batch_stride, int first, int count, void* stream) {
     if (!h || !x_dev || !y_dev) return fail(h, DS_EINVAL, "ds_process_device: NULL argument");
+    if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) {
+        if (first != 0 || count != h->cfg.batch) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle processes its whole batch");
+        if (stream && (hipStream_t)stream != h->stream) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle runs on its own stream (pass NULL)");
+        if (layout != DS_LAYOUT_CHANNELS_SAMPLES) return fail(h, DS_EUNSUPPORTED, "ds_process_device: the SubbandGSC chain takes [B][M][n] input");
+        if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_process_device: n_samples must be a multiple of hop");
+        if (n_samples == 0) return DS_OK;
+        return chain2_run(h, x_dev, x_batch_stride, x_chan_stride > 0 ? x_chan_stride : n_samples, n_samples, y_dev, y_batch_stride,
+                          nullptr, nullptr, nullptr, nullptr);
+    }
     if (h->cfg.algo == DS_ALGO_WPE_MVDR) {
         if (first != 0 || count != h->cfg.batch) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle processes its whole batch");
         if (stream && (hipStream_t)stream != h->stream) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle runs on its own stream (pass NULL)");
@@ -553,7 +600,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
         return fail(h, DS_EINVAL, "ds_process_device_seq: bad n_calls / call strides (must be multiples of 4 elements)");
     if (n_calls == 0) return DS_OK;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    if (graph != 0 && h->cfg.algo == DS_ALGO_WPE_MVDR)
+    if (graph != 0 && (h->cfg.algo == DS_ALGO_WPE_MVDR || h->cfg.algo == DS_ALGO_SUBBAND_GSC))
         return fail(h, DS_EUNSUPPORTED, "ds_process_device_seq: chain handles keep frame counters on the host; use graph = 0");
     if (graph == 0) {
         for (int i = 0; i < n_calls; ++i) {
@@ -713,6 +760,7 @@ int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int me
     p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = h->mcra_L; p.first_frame = h->op_first;
     p.in_complex = is_complex; p.has_p = has_p; p.norm = h->norm;
     p.mu = h->filt_mu; p.alpha = h->filt_alpha; p.reg = 1e-4f; p.lam = h->rls_lambda;
+    p.x_fan = h->x_fan > 0 ? h->x_fan : 1; p.p_complement = h->p_complement;
     p.steer = h->steer; p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
     p.method = h->method; p.alpha_v = h->alpha_v; p.gate = h->gate; p.diag = h->diag;
     DS_HIP(h, ds::launch_binop(h->op, p, h->stream));
@@ -1078,6 +1126,142 @@ static int chain_process_device(ds_handle* h, const float* x_dev, int layout, lo
     return DS_OK;
 }
 
+// ---- DS_ALGO_SUBBAND_GSC: SubbandGSC.process (SubbandGSC.py:170-262) as a device-resident chain ------------------------------
+// buffers: 0 xn [B][M][n] (notched), 1 xa [B][M][n] (aligned), 2 fixed [B][n], 3 D c[B][T][K][M], 4 p [B][T][K], 5 PMWF scratch,
+// 6 F c[B][T][K], 7 Dm c[B*M][T][K], 8 E c[B*M][T][K], 9 bm_td [B][M][n], 10 Xa c[B][T][K][M], 11 Dd c[B][T][K], 12 e2 c[B][T][K],
+// 13 F of the previous block c[B][K] (state), 14 fixed output of the previous block [B][hop] (state)
+static int chain2_reserve(ds_handle* h, int n) {
+    const size_t B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, T = n / h->cfg.hop, hop = h->cfg.hop;
+    const size_t need[15] = {B * M * n * 4, B * M * n * 4, B * n * 4, B * T * K * M * 8, B * T * K * 4, B * T * K * M * 8, B * T * K * 8,
+                             B * M * T * K * 8, B * M * T * K * 8, B * M * n * 4, B * T * K * M * 8, B * T * K * 8, B * T * K * 8,
+                             B * K * 8, B * hop * 4};
+    for (int i = 0; i < 15; ++i) {
+        if (need[i] <= h->chain_bytes[i]) continue;
+        DS_HIP(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
+        DS_HIP(h, hipMalloc((void**)&h->chain_buf[i], need[i]));
+        h->chain_bytes[i] = need[i];
+        if (i >= 13) DS_HIP(h, hipMemset(h->chain_buf[i], 0, need[i]));       // delay_fbf starts from silence (SubbandGSC.py:111)
+    }
+    return DS_OK;
+}
+
+// launch the STFT of sub-handle `t` on dense channel-major input x [batch][C][n] -> Y [batch][T][K][C]
+static int chain_stft(ds_handle* h, ds_handle* t, const float* x, int n, float* Y) {
+    Params p;
+    fill_params(t, p);
+    const int C = t->cfg.n_mics, T = n / t->cfg.hop;
+    p.x = x; p.y = Y;
+    p.x_batch_stride = (long long)C * n; p.x_sample_stride = 1; p.x_chan_stride = n;
+    p.y_batch_stride = (long long)T * t->K * C * 2;
+    p.T = T; p.batch0 = 0;
+    DS_HIP(h, t->ki.launch(p, t->cfg.batch, h->stream));
+    return DS_OK;
+}
+static int chain_istft(ds_handle* h, ds_handle* t, const float* Y, int T, float* y, long long y_batch_stride) {
+    Params p;
+    fill_params(t, p);
+    p.x = Y; p.y = y;
+    p.x_batch_stride = (long long)T * t->K * 2;
+    p.y_batch_stride = y_batch_stride;
+    p.T = T; p.batch0 = 0; p.method = 1;
+    DS_HIP(h, t->ki_istft.launch(p, t->cfg.batch, h->stream));
+    return DS_OK;
+}
+
+// x_dev: [B][M][n] with element strides (x_bstride, x_cstride); y_dev [B] rows of n with stride y_bstride; the optional outputs dense
+static int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
+                      float* fix_dev, float* bm_dev, float* p_dev, float* al_dev) {
+    int rc = set_device(h); if (rc) return rc;
+    ds_handle* fe = h->sub[0];
+    const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, hop = h->cfg.hop, T = n / hop;
+    if (fe->aux_floats == 0 || fe->aux_floats % M != 0 || h->sub[2]->aux_floats < (size_t)K)
+        return fail(h, DS_ESTATE, "SubbandGSC chain: call ds_chain_set_aux(DS_CHAIN_AUX_FIR) and (DS_CHAIN_AUX_COHERENCE) first");
+    rc = chain2_reserve(h, n); if (rc) return rc;
+    float** cb = h->chain_buf;
+#define DS_SUB(i, call) do { int rc_ = (call); if (rc_) return fail(h, rc_, h->sub[i]->err); } while (0)
+    {   // :177-178 DC notch per channel, then :201,206 TimeAlignment FIR bank + channel mean (the fixed beamformer)
+        ds::TdParams p;
+        std::memset(&p, 0, sizeof p);
+        p.B = B; p.M = M; p.n = n; p.x = x_dev; p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.y = cb[0]; p.mem = fe->td_mem;
+        p.radius = fe->cfg.filt_alpha;
+        DS_HIP(h, ds::launch_dcnotch(p, h->stream));
+        const int Lt = (int)(fe->aux_floats / M);
+        if (fe->td_L != Lt) {
+            DS_HIP(h, hipStreamSynchronize(h->stream));
+            for (int i = 0; i < 2; ++i) {
+                (void)hipFree(fe->td_cache[i]); fe->td_cache[i] = nullptr;
+                const size_t cbytes = (size_t)B * (Lt > 1 ? Lt - 1 : 1) * M * sizeof(float);
+                DS_HIP(h, hipMalloc((void**)&fe->td_cache[i], cbytes));
+                DS_HIP(h, hipMemset(fe->td_cache[i], 0, cbytes));
+            }
+            fe->td_L = Lt; fe->td_cur = 0;
+        }
+        std::memset(&p, 0, sizeof p);
+        p.B = B; p.M = M; p.n = n; p.L = Lt; p.x = cb[0]; p.x_chan_major = 1; p.y = cb[1]; p.y_chan_major = 1; p.mean = cb[2];
+        p.coef = fe->dev_buf[9]; p.cache_in = fe->td_cache[fe->td_cur]; p.cache_out = fe->td_cache[fe->td_cur ^ 1];
+        DS_HIP(h, ds::launch_fir(p, h->stream));
+        fe->td_cur ^= 1;
+    }
+    rc = chain_stft(h, h->sub[1], cb[1], n, cb[3]); if (rc) return rc;                                   // :204  D
+    DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[3], T, cb[4], cb[5], nullptr, nullptr, nullptr, DS_MEM_DEVICE));   // :208  p
+    rc = chain_stft(h, h->sub[3], cb[2], n, cb[6]); if (rc) return rc;                                   // bm[m].transform_x: F
+    rc = chain_stft(h, h->sub[4], cb[1], n, cb[7]); if (rc) return rc;                                   // bm[m].transform_d analysis: B*M channels
+    if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[6], cb[7], T, cb[8], DS_MEM_DEVICE));
+    else DS_SUB(5, ds_sublms_update(h->sub[5], cb[6], cb[7], cb[4], T, cb[8], DS_MEM_DEVICE));           // :217-223
+    rc = chain_istft(h, h->sub[4], cb[8], T, cb[9], n); if (rc) return rc;                               // bm outputs, [B*M][n] = [B][M][n]
+    rc = chain_stft(h, h->sub[6], cb[9], n, cb[10]); if (rc) return rc;                                  // :230-234  aic transform_x
+    {   // :226 delay_fbf: the canceller's desired signal is the fixed output one block late = F shifted by one frame
+        const size_t fr = (size_t)K * 8;
+        if (T > 1) DS_HIP(h, hipMemcpy2DAsync((char*)cb[11] + fr, T * fr, cb[6], T * fr, (T - 1) * fr, B, hipMemcpyDeviceToDevice, h->stream));
+        DS_HIP(h, hipMemcpy2DAsync(cb[11], T * fr, cb[13], fr, fr, B, hipMemcpyDeviceToDevice, h->stream));
+        DS_HIP(h, hipMemcpy2DAsync(cb[13], fr, (char*)cb[6] + (T - 1) * fr, T * fr, fr, B, hipMemcpyDeviceToDevice, h->stream));
+    }
+    DS_SUB(7, ds_sublms_update(h->sub[7], cb[10], cb[11], cb[4], T, cb[12], DS_MEM_DEVICE));
+    rc = chain_istft(h, h->sub[8], cb[12], T, y_dev, y_bstride); if (rc) return rc;
+    {   // fix_output = fixed beamformer output delayed by one block (:226,255); the carried block is state either way
+        const size_t blk = (size_t)hop * 4, row = (size_t)n * 4;
+        if (fix_dev) {
+            if (T > 1) DS_HIP(h, hipMemcpy2DAsync((char*)fix_dev + blk, row, cb[2], row, row - blk, B, hipMemcpyDeviceToDevice, h->stream));
+            DS_HIP(h, hipMemcpy2DAsync(fix_dev, row, cb[14], blk, blk, B, hipMemcpyDeviceToDevice, h->stream));
+        }
+        DS_HIP(h, hipMemcpy2DAsync(cb[14], blk, (char*)cb[2] + (row - blk), row, blk, B, hipMemcpyDeviceToDevice, h->stream));
+    }
+    const size_t nb = (size_t)B * M * n * 4;
+    if (bm_dev) DS_HIP(h, hipMemcpyAsync(bm_dev, cb[9], nb, hipMemcpyDeviceToDevice, h->stream));
+    if (al_dev) DS_HIP(h, hipMemcpyAsync(al_dev, cb[1], nb, hipMemcpyDeviceToDevice, h->stream));
+    if (p_dev) DS_HIP(h, hipMemcpyAsync(p_dev, cb[4], (size_t)B * T * K * 4, hipMemcpyDeviceToDevice, h->stream));
+#undef DS_SUB
+    return DS_OK;
+}
+
+int ds_chain_set_aux(ds_handle* h, int which, const float* table, size_t n_floats) {
+    if (!h || !table) return fail(h, DS_EINVAL, "ds_chain_set_aux: NULL argument");
+    if (h->cfg.algo != DS_ALGO_SUBBAND_GSC) return fail(h, DS_ESTATE, "ds_chain_set_aux: handle is not a DS_ALGO_SUBBAND_GSC object");
+    ds_handle* t = which == DS_CHAIN_AUX_FIR ? h->sub[0] : which == DS_CHAIN_AUX_COHERENCE ? h->sub[2] : nullptr;
+    if (!t) return fail(h, DS_EINVAL, "ds_chain_set_aux: unknown table id");
+    const int rc = ds_set_aux(t, table, n_floats);
+    return rc ? fail(h, rc, t->err) : DS_OK;
+}
+
+int ds_subband_gsc_process(ds_handle* h, const float* x, int n_samples, float* y, float* fix_output, float* bm_output, float* pp,
+                           float* aligned, int mem) {
+    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_subband_gsc_process: NULL argument");
+    if (h->cfg.algo != DS_ALGO_SUBBAND_GSC) return fail(h, DS_ESTATE, "ds_subband_gsc_process: handle is not a DS_ALGO_SUBBAND_GSC object");
+    if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_subband_gsc_process: n_samples must be a multiple of hop");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t B = h->cfg.batch, M = h->cfg.n_mics, n = n_samples, T = n / h->cfg.hop;
+    IoSpec io = {{x, nullptr, nullptr}, {B * M * n * 4, 0, 0}, {y, fix_output, bm_output, pp, aligned},
+                 {B * n * 4, fix_output ? B * n * 4 : 0, bm_output ? B * M * n * 4 : 0, pp ? B * T * h->K * 4 : 0, aligned ? B * M * n * 4 : 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    rc = chain2_run(h, din[0], (long long)(M * n), (long long)n, n_samples, dout[0], (long long)n, fix_output ? dout[1] : nullptr,
+                    bm_output ? dout[2] : nullptr, pp ? dout[3] : nullptr, aligned ? dout[4] : nullptr);
+    if (rc) return rc;
+    return io_end(h, mem, io, dout);
+}
+
 int ds_process_pcm16(ds_handle* h, const int16_t* pcm, int n_total_channels, int first_channel, int n_samples, int16_t* out) {
     if (!h || !pcm || !out) return fail(h, DS_EINVAL, "ds_process_pcm16: NULL argument");
     if (h->cfg.algo > DS_ALGO_GSC) return fail(h, DS_ESTATE, "ds_process_pcm16: handle is a frame-level object");
@@ -1232,13 +1416,14 @@ static size_t own_state_bytes(const ds_handle* h) {
     return bins_bytes(h) + tail_in_bytes(h) + tail_out_bytes(h) + counters_bytes(h) + opst_bytes(h) + 4 * sizeof(int);
 }
 static size_t chain_hist_bytes(const ds_handle* h) {
+    if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) return (size_t)h->cfg.batch * (h->K * 8 + h->cfg.hop * 4);
     return h->cfg.algo == DS_ALGO_WPE_MVDR ? (size_t)h->cfg.batch * (h->wpe_delay > 0 ? h->wpe_delay : 1) * h->K * h->cfg.n_mics * 8 : 0;
 }
 
 size_t ds_state_bytes(const ds_handle* h) {
     if (!h) return 0;
     size_t n = own_state_bytes(h) + chain_hist_bytes(h);
-    for (int i = 0; i < 5; ++i) if (h->sub[i]) n += ds_state_bytes(h->sub[i]);
+    for (int i = 0; i < 10; ++i) if (h->sub[i]) n += ds_state_bytes(h->sub[i]);
     return n;
 }
 
@@ -1259,13 +1444,18 @@ int ds_export_state(ds_handle* h, void* dst, size_t bytes) {
     const int uc[4] = {h->op_frm, h->op_ell, h->op_first, h->hist_cur};
     std::memcpy(d, uc, sizeof uc);
     d += sizeof uc;
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 10; ++i)
         if (h->sub[i]) {
             const size_t n = ds_state_bytes(h->sub[i]);
             rc = ds_export_state(h->sub[i], d, n); if (rc) return fail(h, rc, h->sub[i]->err);
             d += n;
         }
-    if (chain_hist_bytes(h)) {
+    if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) {
+        rc = chain2_reserve(h, h->cfg.hop); if (rc) return rc;
+        const size_t n13 = (size_t)h->cfg.batch * h->K * 8, n14 = (size_t)h->cfg.batch * h->cfg.hop * 4;
+        DS_HIP(h, hipMemcpy(d, h->chain_buf[13], n13, hipMemcpyDeviceToHost));
+        DS_HIP(h, hipMemcpy(d + n13, h->chain_buf[14], n14, hipMemcpyDeviceToHost));
+    } else if (chain_hist_bytes(h)) {
         rc = chain_reserve(h, 1); if (rc) return rc;
         DS_HIP(h, hipMemcpy(d, h->chain_buf[6], chain_hist_bytes(h), hipMemcpyDeviceToHost));
     }
@@ -1290,13 +1480,18 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
     std::memcpy(uc, s, sizeof uc);
     s += sizeof uc;
     h->op_frm = uc[0]; h->op_ell = uc[1]; h->op_first = uc[2]; h->hist_cur = uc[3];
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 10; ++i)
         if (h->sub[i]) {
             const size_t n = ds_state_bytes(h->sub[i]);
             rc = ds_import_state(h->sub[i], s, n); if (rc) return fail(h, rc, h->sub[i]->err);
             s += n;
         }
-    if (chain_hist_bytes(h)) {
+    if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) {
+        rc = chain2_reserve(h, h->cfg.hop); if (rc) return rc;
+        const size_t n13 = (size_t)h->cfg.batch * h->K * 8, n14 = (size_t)h->cfg.batch * h->cfg.hop * 4;
+        DS_HIP(h, hipMemcpy(h->chain_buf[13], s, n13, hipMemcpyHostToDevice));
+        DS_HIP(h, hipMemcpy(h->chain_buf[14], s + n13, n14, hipMemcpyHostToDevice));
+    } else if (chain_hist_bytes(h)) {
         rc = chain_reserve(h, 1); if (rc) return rc;
         DS_HIP(h, hipMemcpy(h->chain_buf[6], s, chain_hist_bytes(h), hipMemcpyHostToDevice));
     }

@@ -69,13 +69,142 @@ hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
-__global__ void __launch_bounds__(64) ds_dcnotch_kernel(TdParams p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < p.B * p.M) td_dcnotch(p, i / p.M, i % p.M);
+// FilterDcNotch16 (ds_ops.hpp td_dcnotch is the definition; same arithmetic, same order).  The recursion is serial in time, so a
+// lane owns one (utterance, channel) row; the rows of a block move through LDS in 64 x 64 tiles so that global loads and stores are
+// 256-byte row segments instead of one cache line per lane.
+constexpr int NOTCH_ROWS = 64, NOTCH_TS = 64;
+__global__ void __launch_bounds__(NOTCH_ROWS) ds_dcnotch_kernel(TdParams p) {
+    __shared__ float tile[2][NOTCH_ROWS][NOTCH_TS + 1];
+    const int lane = threadIdx.x, row0 = blockIdx.x * NOTCH_ROWS, rows = p.B * p.M;
+    const int my = row0 + lane;
+    const float r = p.radius;
+    const float den2 = fma_(r, r, 0.7f * (1.0f - r) * (1.0f - r));
+    float m0 = 0.0f, m1 = 0.0f;
+    if (my < rows) { m0 = p.mem[(long long)my * 2]; m1 = p.mem[(long long)my * 2 + 1]; }
+    // row c of the block starts at xr[c] (computed once; lane c holds it, read back through LDS-free shuffles is not needed:
+    // every lane recomputes the 64 bases from (b, m) arithmetic only once per call)
+    const float* base[NOTCH_ROWS / 16][16];
+#pragma unroll
+    for (int g = 0; g < NOTCH_ROWS / 16; ++g)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int rr = row0 + g * 16 + u < rows ? row0 + g * 16 + u : rows - 1;
+            const int b = rr / p.M, m = rr - b * p.M;
+            base[g][u] = p.x_bstride ? p.x + (long long)b * p.x_bstride + (long long)m * p.x_cstride : p.x + (long long)rr * p.n;
+        }
+    float v[NOTCH_ROWS];
+    auto fetch = [&](int s0) {                                              // all 64 row segments of a tile in flight at once
+        const bool on = s0 + lane < p.n;
+#pragma unroll
+        for (int g = 0; g < NOTCH_ROWS / 16; ++g)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[g * 16 + u] = on ? base[g][u][s0 + lane] : 0.0f;
+    };
+    fetch(0);
+    int cur = 0;
+    for (int s0 = 0; s0 < p.n; s0 += NOTCH_TS, cur ^= 1) {
+        const int ns = p.n - s0 < NOTCH_TS ? p.n - s0 : NOTCH_TS;
+#pragma unroll
+        for (int c = 0; c < NOTCH_ROWS; ++c) tile[cur][c][lane] = v[c];
+        __syncthreads();
+        if (s0 + NOTCH_TS < p.n) fetch(s0 + NOTCH_TS);                       // next tile's loads fly behind this tile's recursion
+        if (my < rows)
+            for (int i = 0; i < ns; ++i) {
+                const float vin = tile[cur][lane][i];
+                const float vout = m0 + vin;
+                m0 = m1 + 2.0f * (-vin + r * vout);
+                m1 = vin - den2 * vout;
+                tile[cur][lane][i] = r * vout;
+            }
+        __syncthreads();
+        for (int c = 0; c < NOTCH_ROWS && row0 + c < rows; ++c)
+            if (lane < ns) p.y[(long long)(row0 + c) * p.n + s0 + lane] = tile[cur][c][lane];
+    }
+    if (my < rows) { p.mem[(long long)my * 2] = m0; p.mem[(long long)my * 2 + 1] = m1; }
 }
-__global__ void __launch_bounds__(256) ds_fir_kernel(TdParams p) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (long long)p.B * p.n) td_fir(p, (int)(i / p.n), (int)(i % p.n));
+
+// TimeAlignment FIR bank (td_fir is the definition).  One block = one utterance x FIR_TS consecutive outputs, a lane = 4 consecutive
+// outputs of every channel.  The input window (history from the cache, then x) sits in LDS split into 4 phase arrays (sample 4q + c at
+// [c][q]) so that the lanes' reads are consecutive words for any tap; the taps slide through registers: one LDS read of x and one
+// (broadcast) read of a coefficient per 4 multiply-adds.  Every output accumulates its taps in the order j = 0 .. L-1, like td_fir.
+constexpr int FIR_TS = 512, FIR_NT = FIR_TS / 4, FIR_MMAX = 16, FIR_LMAX = 120, FIR_PAD = 8;
+__global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdParams p) {
+    extern __shared__ float lds[];
+    const int M = p.M, L = p.L, b = blockIdx.y, i0 = blockIdx.x * FIR_TS;
+    const int nt = p.n - i0 < FIR_TS ? p.n - i0 : FIR_TS;                 // outputs of this tile
+    const int W = FIR_TS + FIR_LMAX + FIR_PAD;                             // window samples kept per channel (4 phases x W / 4)
+    float* xs = lds;                                                       // [M][4][W / 4]
+    float* cs = lds + (size_t)M * W;                                       // [L][M]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L * M; i += FIR_NT) cs[i] = p.coef[i];
+    for (int i = tid; i < M * FIR_PAD; i += FIR_NT) {                      // zero entries in front of the window: taps past L read them
+        const int m = i / FIR_PAD, w = i - m * FIR_PAD;
+        xs[(size_t)m * W + (w & 3) * (W / 4) + (w >> 2)] = 0.0f;
+    }
+    const long long xs_s = p.x_chan_major ? 1 : M, xs_c = p.x_chan_major ? p.n : 1;
+    const float* xb = p.x + (long long)b * p.n * M;
+    const float* cache = p.cache_in + (long long)b * (L - 1) * M;
+    // window index w = 0 .. nt + L - 2  <->  sample s = i0 + w - (L - 1)
+    const int nw = nt + L - 1, total = M * nw;
+    for (int base = 0; base < total; base += 8 * FIR_NT) {                 // 8 loads in flight per lane
+        float v[8];
+        int at[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * FIR_NT + tid;
+            at[u] = -1;
+            v[u] = 0.0f;
+            if (idx < total) {
+                const int m = idx / nw, w = idx - m * nw;
+                const int s = i0 + w - (L - 1);
+                v[u] = s >= 0 ? xb[(long long)s * xs_s + m * xs_c] : cache[(long long)(L - 1 + s) * M + m];
+                at[u] = m * W + ((w + FIR_PAD) & 3) * (W / 4) + ((w + FIR_PAD) >> 2);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (at[u] >= 0) xs[at[u]] = v[u];
+    }
+    __syncthreads();
+    const int o0 = 4 * tid;                                                // first output of this lane within the tile
+    if (o0 >= nt) return;
+    float mean[4] = {0.0f, 0.0f, 0.0f, 0.0f}, prev[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int m = 0; m < M; ++m) {
+        const float* xm = xs + (size_t)m * W;
+        auto X = [&](int e) {                                              // x[i0 + o0 + e]; window index (+ FIR_PAD zero entries in front)
+            const int w = o0 + e + (L - 1) + FIR_PAD;
+            return xm[(w & 3) * (W / 4) + (w >> 2)];
+        };
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // taps in blocks of 4: outputs o = 0..3 take tap jb + u from x[o - u - jb]: 7 window values per block, 3 of them carried over
+        float xw[7];                                                       // xw[e + 3] = x[o0 - jb + e], e = -3 .. 3
+        xw[4] = X(1); xw[5] = X(2); xw[6] = X(3);
+        xw[3] = X(0);
+        for (int jb = 0; jb < L; jb += 4) {
+            xw[0] = X(-jb - 3); xw[1] = X(-jb - 2); xw[2] = X(-jb - 1);
+            float cj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cj[u] = jb + u < L ? cs[(jb + u) * M + m] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)                                    // tap order j = jb + u ascending for every output
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = fma_(cj[u], xw[o - u + 3], acc[o]);
+            xw[6] = xw[2]; xw[5] = xw[1]; xw[4] = xw[0];                   // next block: base moves 4 samples back
+            xw[3] = X(-jb - 4);
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int i = i0 + o0 + o;
+            if (o0 + o >= nt) break;
+            if (p.y_chan_major) p.y[((long long)b * M + m) * p.n + i] = acc[o];
+            else p.y[((long long)b * p.n + i) * M + m] = acc[o];
+            mean[o] += acc[o];
+            if (p.diff && m > 0) p.diff[((long long)b * p.n + i) * (M - 1) + m - 1] = prev[o] - acc[o];
+            prev[o] = acc[o];
+        }
+    }
+    if (p.mean)
+        for (int o = 0; o < 4 && o0 + o < nt; ++o) p.mean[(long long)b * p.n + i0 + o0 + o] = mean[o] / (float)M;
 }
 __global__ void __launch_bounds__(256) ds_fir_cache_kernel(TdParams p) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,12 +212,15 @@ __global__ void __launch_bounds__(256) ds_fir_cache_kernel(TdParams p) {
 }
 
 hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(ds_dcnotch_kernel, dim3((p.B * p.M + 63) / 64), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL(ds_dcnotch_kernel, dim3((p.B * p.M + NOTCH_ROWS - 1) / NOTCH_ROWS), dim3(NOTCH_ROWS), 0, stream, p);
     return hipGetLastError();
 }
 hipError_t launch_fir(const TdParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(ds_fir_kernel, dim3((unsigned)(((long long)p.B * p.n + 255) / 256)), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(ds_fir_cache_kernel, dim3((unsigned)(((long long)p.B * (p.L - 1) + 255) / 256)), dim3(256), 0, stream, p);
+    if (p.M > FIR_MMAX || p.L > FIR_LMAX || p.L < 1) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)p.M * (FIR_TS + FIR_LMAX + FIR_PAD) + (size_t)p.L * p.M) * sizeof(float);
+    hipLaunchKernelGGL(ds_fir_kernel, dim3((unsigned)((p.n + FIR_TS - 1) / FIR_TS), (unsigned)p.B), dim3(FIR_NT), lds, stream, p);
+    if (p.L > 1)
+        hipLaunchKernelGGL(ds_fir_cache_kernel, dim3((unsigned)(((long long)p.B * (p.L - 1) + 255) / 256)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

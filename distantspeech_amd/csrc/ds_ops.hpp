@@ -37,6 +37,9 @@ struct OpParams {
     int has_p;                // subband LMS: per-bin update probability given
     int norm;                 // subband LMS: power normalisation on (SubbandAF.py:18)
     float mu, alpha, reg, lam;   // step, power smoothing, regulariser (update(alpha=1e-4)), RLS forgetting factor
+    int x_fan;                // subband LMS / RLS: instances b share the reference input (and p) of utterance b / x_fan (SubbandGSC's M
+                              // blocking filters as one batch of B * M single-channel filters); 1 = one input per instance
+    int p_complement;         // subband LMS: use 1 - p (SubbandGSC.py:232 passes p = 1 - p to the canceller)
     const cf* steer;          // OP_ADAPTIVE: steering vector a [K][M] (or [B][K][M] with steer_batch_stride)
     long long steer_batch_stride;
     int method;               // OP_ADAPTIVE: METHOD_SRC / DS / MVDR
@@ -200,12 +203,13 @@ DS_HD void op_sublms(const OpParams& p, int b, int k) {
     const int N = p.N, C = p.M, NC2 = 2 * N * C;
     for (int t = 0; t < p.T; ++t) {
         const long long fb = ((long long)b * p.T + t) * p.K + k;
+        const long long fx = ((long long)(b / p.x_fan) * p.T + t) * p.K + k;
         // shift register (SubbandAF.py:50-51 / SubbandLmsMc.py:62-63)
         for (int n = N - 1; n > 0; --n)
             for (int c = 0; c < 2 * C; ++c) st_at(p, b, NC2 + n * 2 * C + c, k) = st_at(p, b, NC2 + (n - 1) * 2 * C + c, k);
         for (int c = 0; c < C; ++c) {
-            st_at(p, b, NC2 + 2 * c, k) = p.in0[2 * (fb * C + c)];
-            st_at(p, b, NC2 + 2 * c + 1, k) = p.in0[2 * (fb * C + c) + 1];
+            st_at(p, b, NC2 + 2 * c, k) = p.in0[2 * (fx * C + c)];
+            st_at(p, b, NC2 + 2 * c + 1, k) = p.in0[2 * (fx * C + c) + 1];
         }
         cf out = mk(0.0f, 0.0f);
         float pw = 0.0f;
@@ -215,7 +219,8 @@ DS_HD void op_sublms(const OpParams& p, int b, int k) {
             out = cfmac(out, x, w);                        // conj(W) X  (SubbandAF.py:107)
             pw += cabs2(x);
         }
-        const float pk = p.has_p ? p.in2[fb] : 1.0f;
+        float pk = p.has_p ? p.in2[fx] : 1.0f;
+        if (p.p_complement) pk = 1.0f - pk;
         const cf d = mk(p.in1[2 * fb], p.in1[2 * fb + 1]);
         const cf err = mk(fma_(-out.x, pk, d.x), fma_(-out.y, pk, d.y));      // d - out * p  (SubbandLMS.py:66-68)
         float scale = 1.0f;
@@ -252,8 +257,9 @@ DS_HD void op_subrls(const OpParams& p, int b, int k) {
             st_at(p, b, oX + 2 * n, k) = st_at(p, b, oX + 2 * (n - 1), k);
             st_at(p, b, oX + 2 * n + 1, k) = st_at(p, b, oX + 2 * (n - 1) + 1, k);
         }
-        st_at(p, b, oX, k) = p.in0[2 * fb];
-        st_at(p, b, oX + 1, k) = p.in0[2 * fb + 1];
+        const long long fx = ((long long)(b / p.x_fan) * p.T + t) * p.K + k;
+        st_at(p, b, oX, k) = p.in0[2 * fx];
+        st_at(p, b, oX + 1, k) = p.in0[2 * fx + 1];
         cf X[RLS_NMAX], num[RLS_NMAX], xhP[RLS_NMAX];
         cf out = mk(0.0f, 0.0f);
         for (int i = 0; i < N; ++i) {
@@ -867,6 +873,9 @@ struct TdParams {
     float* y;                  // same layout as x
     float* mean;               // FIR: optional [B][n] channel mean of y (SubbandGSC.fixed_beamformer, SubbandGSC.py:143)
     float* diff;               // FIR: optional [B][n][M-1] adjacent-pair differences y[m] - y[m+1] (TDGSC.blocking_matrix, TDGSC.py:69-87)
+    int y_chan_major;          // FIR: write y as [B][M][n] (what the per-channel transforms of the SubbandGSC chain read) instead of [B][n][M]
+    int x_chan_major;          // FIR: read x as [B][M][n]
+    long long x_bstride, x_cstride;   // notch: element strides of x between utterances / channels (0 = dense [B][M][n])
     float* mem;                // notch: [B][M][2]
     const float* coef;         // FIR: [L][M]
     const float* cache_in;     // FIR: [B][L-1][M]
@@ -878,7 +887,7 @@ DS_HD void td_dcnotch(const TdParams& p, int b, int m) {
     const float r = p.radius;
     const float den2 = fma_(r, r, 0.7f * (1.0f - r) * (1.0f - r));
     float m0 = p.mem[((long long)b * p.M + m) * 2], m1 = p.mem[((long long)b * p.M + m) * 2 + 1];
-    const float* x = p.x + ((long long)b * p.M + m) * p.n;
+    const float* x = p.x_bstride ? p.x + (long long)b * p.x_bstride + (long long)m * p.x_cstride : p.x + ((long long)b * p.M + m) * p.n;
     float* y = p.y + ((long long)b * p.M + m) * p.n;
     for (int i = 0; i < p.n; ++i) {
         const float vin = x[i];
@@ -894,16 +903,18 @@ DS_HD void td_dcnotch(const TdParams& p, int b, int m) {
 DS_HD void td_fir(const TdParams& p, int b, int i) {
     const int M = p.M, L = p.L;
     const float* x = p.x + (long long)b * p.n * M;
+    const long long xs = p.x_chan_major ? 1 : M, xc = p.x_chan_major ? p.n : 1;      // sample / channel strides of x
     const float* cache = p.cache_in + (long long)b * (L - 1) * M;
     float acc_mean = 0.0f, prev = 0.0f;
     for (int m = 0; m < M; ++m) {
         float acc = 0.0f;
         for (int j = 0; j < L; ++j) {
             const int s = i - j;                                        // sample index relative to this call
-            const float v = s >= 0 ? x[(long long)s * M + m] : cache[(long long)(L - 1 + s) * M + m];
+            const float v = s >= 0 ? x[(long long)s * xs + m * xc] : cache[(long long)(L - 1 + s) * M + m];
             acc = fma_(p.coef[(long long)j * M + m], v, acc);
         }
-        p.y[((long long)b * p.n + i) * M + m] = acc;
+        if (p.y_chan_major) p.y[((long long)b * M + m) * p.n + i] = acc;
+        else p.y[((long long)b * p.n + i) * M + m] = acc;
         acc_mean += acc;
         if (p.diff && m > 0) p.diff[((long long)b * p.n + i) * (M - 1) + m - 1] = prev - acc;
         prev = acc;
@@ -916,7 +927,8 @@ DS_HD void td_fir_cache(const TdParams& p, int b, int i) {
     const int M = p.M, L = p.L;
     const int s = i + p.n - (L - 1);                                    // position in x of history slot i (may be negative)
     for (int m = 0; m < M; ++m) {
-        const float v = s >= 0 ? p.x[((long long)b * p.n + s) * M + m] : p.cache_in[((long long)b * (L - 1) + (i + p.n)) * M + m];
+        const float v = s >= 0 ? (p.x_chan_major ? p.x[((long long)b * M + m) * p.n + s] : p.x[((long long)b * p.n + s) * M + m])
+                               : p.cache_in[((long long)b * (L - 1) + (i + p.n)) * M + m];
         p.cache_out[((long long)b * (L - 1) + i) * M + m] = v;
     }
 }

@@ -206,6 +206,29 @@ class BatchEngine:
                                              L.MEM_HOST), self._h)
         return err
 
+    def chain_set_aux(self, which, table):
+        """constant table of a chain handle (L.CHAIN_AUX_FIR: TimeAlignment coefficients [L, M]; L.CHAIN_AUX_COHERENCE: Fn [K])."""
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        L.check(self._lib.ds_chain_set_aux(self._h, int(which), self._p(t), t.size), self._h)
+
+    def subband_gsc_process(self, x, extras=True):
+        """DS_ALGO_SUBBAND_GSC: x [B, M, n] -> (y [B, n], fix_output [B, n], bm_output [B, M, n], p [B, T, K], aligned [B, M, n])
+        (the four extras are None with extras=False)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 3 or x.shape[0] != self.batch or x.shape[1] != self.M:
+            raise ValueError("x must be [B=%d, M=%d, n]" % (self.batch, self.M))
+        n = x.shape[2]
+        y = np.empty((self.batch, n), dtype=np.float32)
+        fix = bm = p = al = None
+        if extras:
+            fix = np.empty((self.batch, n), dtype=np.float32)
+            bm = np.empty((self.batch, self.M, n), dtype=np.float32)
+            p = np.empty((self.batch, n // self.hop, self.K), dtype=np.float32)
+            al = np.empty((self.batch, self.M, n), dtype=np.float32)
+        q = lambda a: self._p(a) if a is not None else None
+        L.check(self._lib.ds_subband_gsc_process(self._h, self._p(x), int(n), self._p(y), q(fix), q(bm), q(p), q(al), L.MEM_HOST), self._h)
+        return y, fix, bm, p, al
+
     def adaptive_frames(self, Z, gain=None):
         """Z complex [B, T, K, M] STFT frames, gain [B, T, K] or None -> Y complex [B, T, K]: the adaptivebeamfomer frame loop
         (MCRA-gated Rvv, src/DS/MVDR weights) as a frame-level operator, times the optional post-filter gain."""

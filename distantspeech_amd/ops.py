@@ -217,12 +217,17 @@ class McSpp(_Base):
     Like the reference, the McCDR prior hard-wires a circular r = 0.032 array of `channels` microphones and uses the
     pair (1, 2) (mccdr.py:63,141); unlike the reference (IndexError, mcspp.py:54) any supported channel count works."""
 
-    def __init__(self, nfft=256, channels=4, mic_array=None, batch=1, device=-1):
+    @staticmethod
+    def diffuse_coherence(channels, nfft):
+        """Fn[K]: diffuse-field coherence of microphones 1, 2 of the circular r = 0.032 array McCDR hard-wires (mccdr.py:63,141)."""
         from .mic_array import MicArray, gen_noise_msc
+        channels = getattr(channels, "M", channels)
+        return gen_noise_msc(MicArray(arrayType="circular", r=0.032, M=channels), nfft)[:, 1, 2]
+
+    def __init__(self, nfft=256, channels=4, mic_array=None, batch=1, device=-1):
         self.nfft, self.half_bin, self.channels, self.batch = nfft, int(nfft / 2 + 1), channels, int(batch)
         self._eng = BatchEngine(L.ALGO_MCSPP, channels, nfft, batch=batch, device=device)
-        cdr_mic = MicArray(arrayType="circular", r=0.032, M=channels)                 # mccdr.py:63
-        self._eng.set_aux(gen_noise_msc(cdr_mic, nfft)[:, 1, 2])
+        self._eng.set_aux(self.diffuse_coherence(channels, nfft))
         self.mic_array = mic_array
         if mic_array is not None:
             self.steer_vector = mic_array.steering_vector(look_direction=30).T          # mcspp.py:64-66

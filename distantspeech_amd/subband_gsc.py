@@ -6,10 +6,9 @@
   DelaySamples                   beamformer/utils.py:241-274        (a buffer; no arithmetic)
   SubbandGSC                     beamformer/SubbandGSC.py:67-262
 
-Every arithmetic stage of SubbandGSC.process runs in a libdsenh kernel (FIR bank + channel mean, STFT, McSpp,
-the M adaptive blocking filters as ONE batched subband-LMS/RLS launch, ISTFT, re-analysis, multichannel canceller,
-ISTFT); this module only sequences the calls and moves buffers.  A single fused kernel for this composition is
-planned; the operator-level composition is the parity-first version."""
+SubbandGSC.process runs behind one native chain handle (DS_ALGO_SUBBAND_GSC): FIR bank + channel mean, STFT, McSpp, the M adaptive
+blocking filters as ONE batched subband-LMS/RLS launch, ISTFT, re-analysis, multichannel canceller, ISTFT — device-resident
+between the stages; this module builds the constant tables and mirrors the reference's interface."""
 import numpy as np
 
 from . import _lib as L
@@ -95,31 +94,27 @@ class SubbandGSC(object):
     """Subband GSC: time alignment -> mean fixed beamformer -> M SPP-controlled adaptive blocking filters ->
     multichannel adaptive interference canceller — beamformer/SubbandGSC.py:67-262.
 
-    `bm_filter="rls"` swaps the blocking filters for SubbandRLS(filter_len=2) — the BASELINE config-5 composition
-    (defined by us, the reference never composes it)."""
+    The whole of process() runs behind ONE native handle (DS_ALGO_SUBBAND_GSC, csrc/ds_api.hip chain2_run): notch, FIR bank + mean
+    beamformer, the five transforms, McSpp, the M blocking filters as one batched launch, the canceller — every stage a kernel on the
+    handle's stream reading the previous stage's device buffer, all blocks of a call per launch.  `bm_filter="rls"` swaps the
+    blocking filters for SubbandRLS(filter_len=2) — the BASELINE config-5 composition (defined by us, the
+    reference never composes it)."""
 
     def __init__(self, mic_array: MicArray, frameLen=256, angle=[197, 0], batch=1, device=-1, bm_filter="lms"):
         self.M, self.frameLen, self.batch = mic_array.M, frameLen, int(batch)
         self.MicArray = mic_array
-        M, B, nb = self.M, self.batch, 2 * frameLen
-        self.nfft, self.hop, self.half_bin = nb, frameLen, frameLen + 1
+        self.nfft, self.hop, self.half_bin = 2 * frameLen, frameLen, frameLen + 1
         self.angle = np.array(angle) / 180 * np.pi if isinstance(angle, list) else angle
-        self.time_alignment = TimeAlignment(mic_array, angle=self.angle, batch=B, device=device)           # :85
-        self._notch = BatchEngine(L.ALGO_FRONTEND, M, nb, batch=B, device=device, filt_alpha=0.98)          # :122-124
-        self.transform = BatchEngine(L.ALGO_TRANSFORM, M, nb, frameLen, batch=B, device=device)             # :117
-        self.spp = McSpp(nfft=nb, channels=M, batch=B, device=device)                                        # :115
-        self._tf_fixed = BatchEngine(L.ALGO_TRANSFORM, 1, nb, frameLen, batch=B, device=device)             # bm[m].transform_x (identical for all m)
         self.bm_filter = bm_filter
-        if bm_filter == "rls":
-            self._bm = BatchEngine(L.ALGO_SUBRLS, 1, nb, batch=B * M, device=device, filter_len=2)
-        else:
-            self._bm = BatchEngine(L.ALGO_SUBLMS, 1, nb, batch=B * M, device=device, filter_len=2, filt_mu=1e-1)   # :99-101
-        self._tf_bm = BatchEngine(L.ALGO_TRANSFORM, M, nb, frameLen, batch=B, device=device)                # bm[m].transform_d synthesis
-        self._tf_aic_x = BatchEngine(L.ALGO_TRANSFORM, M, nb, frameLen, batch=B, device=device)             # aic_filter.transform_x
-        self._aic = BatchEngine(L.ALGO_SUBLMS, M, nb, batch=B, device=device, filter_len=2, filt_mu=0.01, filt_alpha=0.8)   # :103-109
-        self._tf_aic_d = BatchEngine(L.ALGO_TRANSFORM, 1, nb, frameLen, batch=B, device=device)             # aic_filter.transform_d
-        self._F_prev = np.zeros((B, self.half_bin), dtype=np.complex64)     # STFT of the fixed output delayed by one block (:111,226)
-        self._fix_prev = np.zeros((B, frameLen), dtype=np.float32)
+        self._eng = BatchEngine(L.ALGO_SUBBAND_GSC, self.M, self.nfft, self.hop, batch=batch, device=device, filter_len=2,
+                                rls_lambda=0.998 if bm_filter == "rls" else 0.0)              # SubbandRLS.py:30 forgetting factor
+        tau = compute_tau(mic_array, self.angle)
+        self.tau = -(tau - np.max(tau))                                                        # fixedbeamformer.py:67
+        self.delay_filter = fractional_delay_filter_bank(np.array(self.tau)[:, 0] * mic_array.fs)   # :68-70
+        self.time_alignment = type("TimeAlignmentTables", (object,), dict(delay_filter=self.delay_filter, tau=self.tau,
+                                                                              delay_filter_len=self.delay_filter.shape[0]))()   # :85
+        self._eng.chain_set_aux(L.CHAIN_AUX_FIR, self.delay_filter)
+        self._eng.chain_set_aux(L.CHAIN_AUX_COHERENCE, McSpp.diffuse_coherence(mic_array, self.nfft))
 
     def fixed_beamformer(self, x):
         return np.mean(x, axis=1, keepdims=True)
@@ -137,39 +132,9 @@ class SubbandGSC(object):
             if self.batch != 1:
                 raise ValueError("object built with batch=%d; pass [B, n_chs, n_samples]" % self.batch)
             x = x[None]
-        B, M, FL, K = self.batch, self.M, self.frameLen, self.half_bin
-        if x.shape[1] != M or x.shape[2] % FL != 0:
-            raise ValueError("x must be [n_chs=%d, k * %d samples]" % (M, FL))
-        x = self._notch.dcnotch(x)                                              # :177-178
-        nblk = x.shape[2] // FL
-        output = np.zeros((B, nblk * FL)); fix_output = np.zeros((B, nblk * FL))
-        bm_output = np.zeros((B, nblk * FL, M)); aligned = np.zeros((B, nblk * FL, M))
-        p = np.zeros((B, K, nblk))
-        for n in range(nblk):
-            sl = slice(n * FL, (n + 1) * FL)
-            xa, fixed = self.time_alignment.process_with_mean(np.ascontiguousarray(np.swapaxes(x[:, :, sl], 1, 2)))   # :201,206
-            aligned[:, sl] = xa
-            D = self.transform.stft(xa, L.LAYOUT_SAMPLES_CHANNELS)[:, 0]        # [B, K, M]   :204
-            pn = self.spp._eng.mcspp_estimate(D[:, None], want_yout=False)["p"][:, 0]   # :208
-            p[:, :, n] = pn
-            F = self._tf_fixed.stft(fixed[:, :, None], L.LAYOUT_SAMPLES_CHANNELS)[:, 0, :, 0]   # [B, K]
-            # M adaptive blocking filters as one batched launch: utterance-major, filter-minor   :217-223
-            xin = np.repeat(F[:, None, :], M, axis=1).reshape(B * M, 1, K)
-            din = np.ascontiguousarray(np.swapaxes(D, 1, 2)).reshape(B * M, 1, K)
-            if self.bm_filter == "rls":
-                err = self._bm.subrls_update(xin, din)
-            else:
-                pin = np.repeat(pn[:, None, :], M, axis=1).reshape(B * M, 1, K)
-                err = self._bm.sublms_update(xin[..., None], din, pin)
-            E = np.ascontiguousarray(np.swapaxes(err.reshape(B, M, K), 1, 2))   # [B, K, M]
-            bm_td = self._tf_bm.istft(E[:, None])                               # [B, FL, M]
-            bm_output[:, sl] = bm_td
-            Xa = self._tf_aic_x.stft(bm_td, L.LAYOUT_SAMPLES_CHANNELS)[:, 0]    # [B, K, M]   :230-234
-            Dd = self._F_prev                                                   # analysis of the block-delayed fixed output
-            e2 = self._aic.sublms_update(Xa[:, None], Dd[:, None], (1.0 - pn)[:, None])
-            out_td = self._tf_aic_d.istft(e2[:, :, :, None])[:, :, 0]
-            output[:, sl] = out_td
-            fix_output[:, sl] = self._fix_prev
-            self._F_prev, self._fix_prev = F, fixed
-        sq = (lambda a: a[0]) if single else (lambda a: a)
-        return sq(output), sq(fix_output), sq(bm_output), sq(p), sq(aligned)
+        if x.shape[1] != self.M or x.shape[2] % self.frameLen != 0:
+            raise ValueError("x must be [n_chs=%d, k * %d samples]" % (self.M, self.frameLen))
+        y, fix, bm, p, al = self._eng.subband_gsc_process(x)
+        out = (y.astype(np.float64), fix.astype(np.float64), np.swapaxes(bm, 1, 2).astype(np.float64),
+               np.swapaxes(p, 1, 2).astype(np.float64), np.swapaxes(al, 1, 2).astype(np.float64))
+        return tuple(a[0] for a in out) if single else out

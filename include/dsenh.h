@@ -79,6 +79,11 @@ extern "C" {
                                  `filter_len` taps, `wpe_delay`-frame prediction delay = ds_config.mcra_L field is NOT reused: see ds_config.filter_len /
                                  DS_PARAM_WPE_DELAY) -> McMcra gain (mc_mcra.py:179-224) -> adaptive MVDR frame loop (adaptivebeamformer.py:69-120)
                                  x gain -> ISTFT; device-resident between the stages, all on the handle's stream */
+#define DS_ALGO_SUBBAND_GSC 19 /* SubbandGSC.process (beamformer/SubbandGSC.py:170-262; BASELINE config 5 with rls_lambda > 0) as ONE handle:
+                                 DC notch -> TimeAlignment FIR bank + mean beamformer -> STFT -> McSpp -> M adaptive blocking filters (one
+                                 batched subband LMS, or RLS when ds_config.rls_lambda > 0) -> ISTFT/STFT -> multichannel subband-LMS canceller
+                                 -> ISTFT, device-resident between the stages; nfft = 2 * frameLen, hop = frameLen, n_mics in {2,4,6},
+                                 filter_len taps (0 -> 2).  Needs ds_chain_set_aux() for the FIR bank and the McCDR coherence first */
 #define DS_ALGO_MCSPPBASE 9  /* McSppBase.estimation + PMWF weights  noise_estimation/mcspp_base.py:220-324 */
 
 /* `mem` argument of the frame-level entry points */
@@ -251,6 +256,13 @@ int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem);
 int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mean, int mem);
 int ds_firbank_bm(ds_handle* h, const float* x, int n_samples, float* y, float* mean, float* bm, int mem);
 int ds_tdfilter_update(ds_handle* h, const float* x, const float* d, int n_samples, float p, float* err, int mem);
+#define DS_CHAIN_AUX_FIR 0        /* TimeAlignment coefficients [L][M] (fixedbeamformer.py:68-70) */
+#define DS_CHAIN_AUX_COHERENCE 1 /* diffuse coherence Fn[K] of microphones 1, 2 (mccdr.py:141) */
+int ds_chain_set_aux(ds_handle* h, int which, const float* table, size_t n_floats);
+/* DS_ALGO_SUBBAND_GSC: x [B][M][n] (n a multiple of hop) -> y [B][n]; optional (NULL to skip) fix_output [B][n] (the fixed beamformer
+ * output delayed by one block), bm_output [B][M][n], p [B][T][K], aligned [B][M][n] — the tuple SubbandGSC.process returns */
+int ds_subband_gsc_process(ds_handle* h, const float* x, int n_samples, float* y, float* fix_output, float* bm_output, float* p,
+                           float* aligned, int mem);
 int ds_adaptive_frames(ds_handle* h, const float* Z, const float* gain, int n_frames, float* Y, int mem);
 int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* p, int p_mode, int n_blocks, int fir_truncate,
                    float* err, float* w_out, int mem);

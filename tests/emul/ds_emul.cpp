@@ -156,6 +156,7 @@ int emul_op(int op, int B, int K, int T, float* st, int NF, const float* in0, co
     p.in0 = in0; p.in1 = in1; p.in2 = in2; p.out0 = out0; p.out1 = out1; p.out2 = out2; p.out3 = out3; p.out4 = out4;
     p.M = M; p.N = N; p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.first_frame = first_frame;
     p.in_complex = in_complex; p.has_p = has_p; p.norm = norm; p.mu = mu; p.alpha = alpha; p.reg = reg; p.lam = lam;
+    p.x_fan = 1;
     for (int b = 0; b < B; ++b)
         for (int k = 0; k < K; ++k) ds::run_op(op, p, b, k);
     return 0;
