@@ -864,14 +864,16 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, 
                  {n * 4, n * M * 8, yout ? n * 8 : 0, phi_xx ? n * M * M * 8 : 0, phi_vv_inv ? n * M * M * 8 : 0}};
     const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    rc = stage_reserve(h, 3, n * 4); if (rc) return rc;                      // Gamma [B][T][K]
+    const size_t nbt = (size_t)h->cfg.batch * n_frames;
+    rc = stage_reserve(h, 3, (n + nbt) * 4); if (rc) return rc;              // Gamma [B][T][K], then its band mean [B][T]
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
     p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames; p.st = h->opst; p.NF = h->NF; p.M = h->cfg.n_mics;
     p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = 65;                      // mccdr.py:60-61
     p.in0 = din[0]; p.in1 = h->dev_buf[9]; p.out0 = h->dev_buf[3];
     DS_HIP(h, ds::launch_binop(ds::OP_MCCDR, p, h->stream));
-    p.in1 = h->dev_buf[3]; p.N = 9;
+    DS_HIP(h, ds::launch_mcspp_qavg(h->dev_buf[3], h->dev_buf[3] + n, (int)nbt, h->K, h->stream));
+    p.in1 = h->dev_buf[3]; p.in2 = h->dev_buf[3] + n; p.N = 9;
     p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
     DS_HIP(h, ds::launch_binop(ds::OP_MCSPP, p, h->stream));
     for (int t = 0; t < n_frames; ++t) {

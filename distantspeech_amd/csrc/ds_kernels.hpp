@@ -31,6 +31,7 @@ hipError_t launch_pcm16_to_float(const short* pcm, float* x, long long n, int Ct
 hipError_t launch_float_to_pcm16(const float* y, short* pcm, long long n, hipStream_t stream);
 struct TdfParams;
 hipError_t launch_tdfilter(const TdfParams& p, hipStream_t stream);
+hipError_t launch_mcspp_qavg(const float* gamma, float* out, int rows, int K, hipStream_t stream);
 struct WpeParams;
 hipError_t launch_wpe(const WpeParams& p, hipStream_t stream);
 struct FdafParams;

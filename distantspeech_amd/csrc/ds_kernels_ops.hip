@@ -249,6 +249,17 @@ hipError_t launch_wpe(const WpeParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// McSpp's band-averaged prior np.mean(q[fmin:fmax]) (mcspp.py:258-260) once per (utterance, frame) instead of once per bin
+__global__ void __launch_bounds__(64) ds_mcspp_qavg_kernel(const float* gamma, float* out, int rows, int K, int fmin, int fmax) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) out[r] = mcspp_qavg(gamma + (long long)r * K, fmin, fmax);
+}
+hipError_t launch_mcspp_qavg(const float* gamma, float* out, int rows, int K, hipStream_t stream) {
+    const int fmin = (int)(500.0 * (2 * (K - 1)) / 16000.0), fmax = (int)(2000.0 * (2 * (K - 1)) / 16000.0);
+    hipLaunchKernelGGL(ds_mcspp_qavg_kernel, dim3((rows + 63) / 64), dim3(64), 0, stream, gamma, out, rows, K, fmin, fmax);
+    return hipGetLastError();
+}
+
 // realtime wire format (realtime/realtime_processing.py:119-133): int16 LE interleaved [L][C_total] -> float32 / 32768,
 // channels [c0, c0 + M) -> x [B][L][M]; enhanced float -> (y * 32768) truncated to int16
 __global__ void __launch_bounds__(256) ds_pcm16_to_float_kernel(const short* pcm, float* x, long long n, int Ctot, int c0, int M) {

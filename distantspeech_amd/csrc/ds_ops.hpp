@@ -199,7 +199,7 @@ DS_HD void op_omlsa(const OpParams& p, int b, int k) {
 // ------------------------------------------------------------------------------------------------
 DS_HD int sublms_nf(int N, int C) { return 4 * N * C + 1; }
 
-DS_HD void op_sublms(const OpParams& p, int b, int k) {
+DS_HD void op_sublms_generic(const OpParams& p, int b, int k) {
     const int N = p.N, C = p.M, NC2 = 2 * N * C;
     for (int t = 0; t < p.T; ++t) {
         const long long fb = ((long long)b * p.T + t) * p.K + k;
@@ -241,6 +241,67 @@ DS_HD void op_sublms(const OpParams& p, int b, int k) {
     }
 }
 
+// the same recursion with W, the tap buffer and P held in registers for the T frames of the call (state read once, written once)
+template <int N, int C> DS_HD void op_sublms_t(const OpParams& p, int b, int k) {
+    constexpr int NC = N * C, NC2 = 2 * NC;
+    cf W[NC], X[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        W[i] = mk(st_at(p, b, 2 * i, k), st_at(p, b, 2 * i + 1, k));
+        X[i] = mk(st_at(p, b, NC2 + 2 * i, k), st_at(p, b, NC2 + 2 * i + 1, k));
+    }
+    float P = st_at(p, b, 2 * NC2, k);
+    for (int t = 0; t < p.T; ++t) {
+        const long long fb = ((long long)b * p.T + t) * p.K + k;
+        const long long fx = ((long long)(b / p.x_fan) * p.T + t) * p.K + k;
+#pragma unroll
+        for (int n = N - 1; n > 0; --n)
+#pragma unroll
+            for (int c = 0; c < C; ++c) X[n * C + c] = X[(n - 1) * C + c];
+#pragma unroll
+        for (int c = 0; c < C; ++c) X[c] = mk(p.in0[2 * (fx * C + c)], p.in0[2 * (fx * C + c) + 1]);
+        cf out = mk(0.0f, 0.0f);
+        float pw = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) { out = cfmac(out, X[i], W[i]); pw += cabs2(X[i]); }
+        float pk = p.has_p ? p.in2[fx] : 1.0f;
+        if (p.p_complement) pk = 1.0f - pk;
+        const cf d = mk(p.in1[2 * fb], p.in1[2 * fb + 1]);
+        const cf err = mk(fma_(-out.x, pk, d.x), fma_(-out.y, pk, d.y));
+        float scale = 1.0f;
+        if (p.norm) {
+            P = fma_(p.alpha, P, (1.0f - p.alpha) * (pw / (float)C));
+            scale = 1.0f / (P + p.reg);
+        }
+        const float g = 2.0f * p.mu * pk * scale;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const cf gr = cmulc(X[i], err);
+            W[i] = mk(fma_(g, gr.x, W[i].x), fma_(g, gr.y, W[i].y));
+        }
+        p.out0[2 * fb] = err.x; p.out0[2 * fb + 1] = err.y;
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        st_at(p, b, 2 * i, k) = W[i].x; st_at(p, b, 2 * i + 1, k) = W[i].y;
+        st_at(p, b, NC2 + 2 * i, k) = X[i].x; st_at(p, b, NC2 + 2 * i + 1, k) = X[i].y;
+    }
+    if (p.norm) st_at(p, b, 2 * NC2, k) = P;
+}
+
+DS_HD void op_sublms(const OpParams& p, int b, int k) {
+    if (p.N == 2) {                                   // the reference's tap count everywhere it builds these filters
+        switch (p.M) {
+            case 1: return op_sublms_t<2, 1>(p, b, k);
+            case 2: return op_sublms_t<2, 2>(p, b, k);
+            case 4: return op_sublms_t<2, 4>(p, b, k);
+            case 6: return op_sublms_t<2, 6>(p, b, k);
+            case 8: return op_sublms_t<2, 8>(p, b, k);
+        }
+    }
+    op_sublms_generic(p, b, k);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Subband RLS: in0 = x complex [B][T][K], in1 = d complex [B][T][K]; out0 = err complex [B][T][K].
 // state floats: W [N] complex, input_buffer [N] complex, P [N][N] complex
@@ -248,49 +309,66 @@ DS_HD void op_sublms(const OpParams& p, int b, int k) {
 constexpr int RLS_NMAX = 4;
 DS_HD int subrls_nf(int N) { return 4 * N + 2 * N * N; }
 
-DS_HD void op_subrls(const OpParams& p, int b, int k) {
-    const int N = p.N, oX = 2 * N, oP = 4 * N;
+template <int N> DS_HD void op_subrls_t(const OpParams& p, int b, int k) {
+    constexpr int oX = 2 * N, oP = 4 * N;
     const float lam_inv = 1.0f / p.lam;
+    cf W[N], X[N], P[N][N];                              // in registers for the T frames of the call
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        W[i] = mk(st_at(p, b, 2 * i, k), st_at(p, b, 2 * i + 1, k));
+        X[i] = mk(st_at(p, b, oX + 2 * i, k), st_at(p, b, oX + 2 * i + 1, k));
+#pragma unroll
+        for (int j = 0; j < N; ++j) P[i][j] = mk(st_at(p, b, oP + 2 * (i * N + j), k), st_at(p, b, oP + 2 * (i * N + j) + 1, k));
+    }
     for (int t = 0; t < p.T; ++t) {
         const long long fb = ((long long)b * p.T + t) * p.K + k;
-        for (int n = N - 1; n > 0; --n) {
-            st_at(p, b, oX + 2 * n, k) = st_at(p, b, oX + 2 * (n - 1), k);
-            st_at(p, b, oX + 2 * n + 1, k) = st_at(p, b, oX + 2 * (n - 1) + 1, k);
-        }
         const long long fx = ((long long)(b / p.x_fan) * p.T + t) * p.K + k;
-        st_at(p, b, oX, k) = p.in0[2 * fx];
-        st_at(p, b, oX + 1, k) = p.in0[2 * fx + 1];
-        cf X[RLS_NMAX], num[RLS_NMAX], xhP[RLS_NMAX];
+#pragma unroll
+        for (int n = N - 1; n > 0; --n) X[n] = X[n - 1];
+        X[0] = mk(p.in0[2 * fx], p.in0[2 * fx + 1]);
+        cf num[N], xhP[N];
         cf out = mk(0.0f, 0.0f);
-        for (int i = 0; i < N; ++i) {
-            X[i] = mk(st_at(p, b, oX + 2 * i, k), st_at(p, b, oX + 2 * i + 1, k));
-            out = cfmac(out, X[i], mk(st_at(p, b, 2 * i, k), st_at(p, b, 2 * i + 1, k)));
-        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) out = cfmac(out, X[i], W[i]);
         const cf d = mk(p.in1[2 * fb], p.in1[2 * fb + 1]);
         const cf err = csub(d, out);                                             // SubbandRLS.py:52
         cf den = mk(p.lam, 0.0f);
+#pragma unroll
         for (int i = 0; i < N; ++i) {
             cf a = mk(0.0f, 0.0f), r = mk(0.0f, 0.0f);
+#pragma unroll
             for (int j = 0; j < N; ++j) {
-                a = cfma(a, mk(st_at(p, b, oP + 2 * (i * N + j), k), st_at(p, b, oP + 2 * (i * N + j) + 1, k)), X[j]);   // (P x)_i
-                r = cfmac(r, mk(st_at(p, b, oP + 2 * (j * N + i), k), st_at(p, b, oP + 2 * (j * N + i) + 1, k)), X[j]);  // (x^H P)_i
+                a = cfma(a, P[i][j], X[j]);                                       // (P x)_i
+                r = cfmac(r, P[j][i], X[j]);                                      // (x^H P)_i
             }
             num[i] = a; xhP[i] = r;
             den = cfmac(den, a, X[i]);                                            // + conj(x_i) (P x)_i   :56-60
         }
+#pragma unroll
         for (int i = 0; i < N; ++i) {
             const cf kn = cdiv(num[i], den);
-            for (int j = 0; j < N; ++j) {                                        // P = (P - kn x^H P) / lambda   :63
-                const int q = oP + 2 * (i * N + j);
-                const cf pij = cfnma(mk(st_at(p, b, q, k), st_at(p, b, q + 1, k)), kn, xhP[j]);
-                st_at(p, b, q, k) = pij.x * lam_inv;
-                st_at(p, b, q + 1, k) = pij.y * lam_inv;
-            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) P[i][j] = cscale(cfnma(P[i][j], kn, xhP[j]), lam_inv);   // P = (P - kn x^H P) / lambda   :63
             const cf g = cmulc(kn, err);                                         // conj(err) kn   :65
-            st_at(p, b, 2 * i, k) = fma_(2.0f * p.mu, g.x, st_at(p, b, 2 * i, k));
-            st_at(p, b, 2 * i + 1, k) = fma_(2.0f * p.mu, g.y, st_at(p, b, 2 * i + 1, k));
+            W[i] = mk(fma_(2.0f * p.mu, g.x, W[i].x), fma_(2.0f * p.mu, g.y, W[i].y));
         }
         p.out0[2 * fb] = err.x; p.out0[2 * fb + 1] = err.y;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        st_at(p, b, 2 * i, k) = W[i].x; st_at(p, b, 2 * i + 1, k) = W[i].y;
+        st_at(p, b, oX + 2 * i, k) = X[i].x; st_at(p, b, oX + 2 * i + 1, k) = X[i].y;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { st_at(p, b, oP + 2 * (i * N + j), k) = P[i][j].x; st_at(p, b, oP + 2 * (i * N + j) + 1, k) = P[i][j].y; }
+    }
+}
+
+DS_HD void op_subrls(const OpParams& p, int b, int k) {
+    switch (p.N) {
+        case 1: return op_subrls_t<1>(p, b, k);
+        case 2: return op_subrls_t<2>(p, b, k);
+        case 3: return op_subrls_t<3>(p, b, k);
+        default: return op_subrls_t<4>(p, b, k);
     }
 }
 
@@ -623,6 +701,13 @@ DS_HD void op_mccdr(const OpParams& p, int b, int k) {
 // ------------------------------------------------------------------------------------------------
 DS_HD int mcspp_nf(int M) { return 9 + 2 * M * M + 3; }
 
+// np.mean(q[fmin:fmax]) of one frame (mcspp.py:260), q = 1 - Gamma; summed in bin order
+DS_HD float mcspp_qavg(const float* gamma_frame, int fmin, int fmax) {
+    float qsum = 0.0f;
+    for (int j = fmin; j < fmax; ++j) qsum += 1.0f - gamma_frame[j];
+    return qsum / (float)(fmax - fmin);
+}
+
 template <int M> DS_HD void op_mcspp(const OpParams& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
     const int o0 = p.N;                                                            // state row offset of the McSpp part
@@ -641,9 +726,12 @@ template <int M> DS_HD void op_mcspp(const OpParams& p, int b, int k) {
 #pragma unroll
         for (int m = 0; m < M; ++m) Z[m] = mk(p.in0[2 * (base + m)], p.in0[2 * (base + m) + 1]);
         float q = 1.0f - p.in1[fb + k];                                            // compute_q :113-116
-        float qsum = 0.0f;
-        for (int j = fmin; j < fmax; ++j) qsum += 1.0f - p.in1[fb + j];            // np.mean(q[fmin:fmax]) :260
-        const float q_avg = qsum / (float)(fmax - fmin);
+        float q_avg;
+        if (p.in2) {
+            q_avg = p.in2[(long long)b * p.T + t];                                 // mcspp_qavg() ran once per (utterance, frame)
+        } else {
+            q_avg = mcspp_qavg(p.in1 + fb, fmin, fmax);
+        }
         const float dv = fma_(q_avg, 1e-1f, (1.0f - q_avg) * 1e-4f);               // :254-262
         herm_rank1<M>(yd, yo, Z, 0.92f, (float)(1.0 - 0.92));                      // :264-266
         if (frm < 10) {                                                            // :273-275
