@@ -72,6 +72,16 @@ def load():
             "distantspeech_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C distantspeech_amd/csrc` (needs hipcc, --offload-arch=gfx950). "
             "There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own HIP/HSA runtime; two runtimes coexist in one process only when PyTorch's initialises
+    # first (observed on this image: torch 2.10+rocm7.0 next to /opt/rocm 7.2).  If torch is already imported, let it go first.
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        try:
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, cf_, cll, csz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_size_t
     lib.ds_version.restype = ci

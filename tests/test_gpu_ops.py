@@ -397,3 +397,40 @@ def test_wpe_mvdr_postfilter(ds, M, nfft):
     assert np.array_equal(b2.process(xs[1][:, 7 * hop:], ANGLE)["data"], tail)
     b2._eng.reset()
     assert np.array_equal(b2.process(xs[1], ANGLE)["data"], y1)
+
+
+def test_chain_handles_error_behaviour(ds):
+    """the two chain handles refuse what they cannot do, loudly: missing tables / steering, ragged lengths, wrong layout,
+    partial batches, graph replay; an empty call is a no-op."""
+    from distantspeech_amd import _lib as L
+    from distantspeech_amd._lib import DsError
+    eng = ds.BatchEngine(L.ALGO_SUBBAND_GSC, 4, 512, 256, batch=2, filter_len=2)
+    x = np.zeros((2, 4, 512), np.float32)
+    with pytest.raises(DsError, match="ds_chain_set_aux"):
+        eng.subband_gsc_process(x)                                         # FIR bank / coherence tables not set
+    mic = ds.MicArray(arrayType="circular", r=0.032, M=4, n_fft=512)
+    sg = ds.SubbandGSC(mic, frameLen=256, batch=2)
+    with pytest.raises(ValueError):
+        sg.process(np.zeros((2, 4, 300)))                                  # not a multiple of the block
+    with pytest.raises(ValueError):
+        sg.process(np.zeros((2, 3, 512)))                                  # wrong channel count
+    y = sg.process(np.zeros((2, 4, 0)))
+    assert y[0].shape == (2, 0)
+    with pytest.raises(DsError, match="chain"):
+        sg._eng.process(np.zeros((2, 512, 4), np.float32), L.LAYOUT_SAMPLES_CHANNELS)   # the chain takes [B][M][n]
+    with pytest.raises(DsError):
+        ds.BatchEngine(L.ALGO_SUBBAND_GSC, 8, 512, 256, batch=1)           # McSpp is built for 2..6 microphones
+    ch = ds.BatchEngine(L.ALGO_WPE_MVDR, 4, 512, 256, batch=2, filter_len=2)
+    with pytest.raises(DsError, match="ds_set_steering"):
+        ch.process(np.zeros((2, 4, 512), np.float32), L.LAYOUT_CHANNELS_SAMPLES)
+    ch.set_steering(np.ones((257, 4), np.complex64))
+    assert ch.process(np.zeros((2, 4, 512), np.float32), L.LAYOUT_CHANNELS_SAMPLES).shape == (2, 512)
+    with pytest.raises(DsError, match="delay"):
+        ch.set_wpe_delay(2)                                                # after the first call
+    fake_x, fake_y = 0x100000, 0x200000           # never dereferenced: both calls must be refused during validation
+    with pytest.raises(DsError, match="whole batch"):
+        ch.process_device_seq(fake_x, 1, 4 * 512, 512, 256, 256, 1, fake_y, 512, 256, first=0, count=1, graph=0)
+    with pytest.raises(DsError, match="graph"):
+        ch.process_device_seq(fake_x, 1, 4 * 512, 512, 256, 256, 2, fake_y, 512, 256, graph=1)
+    with pytest.raises(DsError):
+        ds.BatchEngine(L.ALGO_WPE_MVDR, 8, 1024, 512, batch=1, filter_len=3)   # C * N = 24 > 16 lanes per bin
