@@ -1,84 +1,10 @@
 // ds_api.hip — handle management and the C-ABI of libdsenh.so (see include/dsenh.h).
 // No CPU compute path lives here: every ds_process* call launches the gfx950 kernels.
-#include <hip/hip_runtime.h>
+#include "ds_handle.hpp"
 
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
+using namespace dsi;
 
-#include "../../include/dsenh.h"
-#include "ds_kernels.hpp"
-#include "ds_ops.hpp"
-#include "ds_tdfilter.hpp"
-#include "ds_fdaf.hpp"
-#include "ds_tables.hpp"
-
-using ds::cf;
-using ds::KernelInfo;
-using ds::Params;
-
-struct ds_handle {
-    ds_config cfg;
-    int K, KP, NP, NT;
-    KernelInfo ki;
-    int device;
-    hipStream_t stream;
-    hipEvent_t ev0, ev1;
-    // device state
-    ds::vec4* bins;
-    float* tail_in;
-    float* tail_out;
-    int* counters;
-    ds::vec4* tables;
-    cf* steer;
-    int steer_per_utt;
-    bool steer_set;
-    // staging for host-pointer calls
-    // frame-level objects (DS_ALGO_TRANSFORM .. DS_ALGO_SUBRLS)
-    KernelInfo ki_istft;
-    int op;                     // ds::OP_* or -1
-    float* opst;                // operator state [B][NF][KP]
-    int NF;
-    int op_frm, op_ell, op_first;   // uniform counters of the operator handle
-    int filter_len, norm;
-    float filt_mu, filt_alpha, rls_lambda;
-    float* dev_buf[10];         // staging for host-pointer frame-level calls (3 in, 1 scratch, 5 out, 1 aux table)
-    size_t dev_buf_bytes[10];
-    size_t aux_floats;
-    float* td_mem;              // DS_ALGO_FRONTEND: notch memories [B][M][2]
-    float* td_cache[2];         // FIR history ping-pong [B][L-1][M]
-    int td_L, td_cur;
-    float* tdf_w; float* tdf_buf; float* tdf_P;     // DS_ALGO_TDNLMS / TDRLS state
-    int fdaf_kind, fdaf_constrain, fdaf_non_causal, fdaf_weight_norm;   // DS_ALGO_FDAF (state lives in opst)
-    int x_fan, p_complement;    // subband LMS / RLS inside a chain: shared reference input, 1 - p (OpParams)
-    // DS_ALGO_WPE_MVDR: a chain of operator handles sharing this handle's stream, device-resident between the stages
-    ds_handle* sub[10];         // WPE_MVDR: analysis transform, WPE, McMcra, adaptive frame loop, synthesis transform; SUBBAND_GSC: see chain2_*
-    bool owns_stream;
-    int wpe_delay;
-    float* chain_buf[16];       // WPE_MVDR: D, -, E, p, G, Y, ring of the last wpe_delay analysis frames; SUBBAND_GSC: see chain2_reserve
-    size_t chain_bytes[16];
-    int hist_cur;               // ring slot of the oldest frame
-    // cached hipGraph of a ds_process_device_seq() sequence
-    hipGraphExec_t graph_exec;
-    int split;                  // DS_PARAM_SPLIT: utterance groups captured as parallel graph branches
-    hipStream_t side[7];        // side streams for the extra branches
-    hipEvent_t ev_fork, ev_join[7];
-    long long graph_key[16];
-    bool graph_valid;
-    float* x_stage;
-    float* y_stage;
-    size_t x_stage_elems, y_stage_elems;
-    // params
-    int method;
-    int mcra_L;
-    float alpha_y, alpha_v, diag, gate, mu, out_scale;
-    std::string err;
-};
-
-namespace {
+namespace dsi {
 
 thread_local std::string g_err;
 
@@ -88,12 +14,6 @@ int fail(ds_handle* h, int code, const std::string& msg) {
     return code;
 }
 
-#define DS_HIP(h, call)                                                                          \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return fail(h, DS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));          \
-    } while (0)
 
 size_t bins_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * h->NP * h->KP * sizeof(ds::vec4); }
 size_t tail_in_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * h->cfg.n_mics * h->cfg.hop * sizeof(float); }
@@ -183,7 +103,7 @@ void fill_params(const ds_handle* h, Params& p) {
     p.mu = h->mu;
 }
 
-}  // namespace
+}  // namespace dsi
 
 extern "C" {
 
@@ -537,10 +457,6 @@ int ds_set_param_f(ds_handle* h, int id, float value) {
     }
 }
 
-static int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
-                                int n_samples, float* y_dev, long long y_batch_stride);
-static int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
-                      float* fix_dev, float* bm_dev, float* p_dev, float* al_dev);
 
 int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
                       int n_samples, float* y_dev, long long y_batch_stride, int first, int count, void* stream) {
@@ -699,571 +615,6 @@ int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y
 }
 
 // ---- frame-level entry points ---------------------------------------------------------------------
-namespace {
-
-// make sure staging slot `i` holds at least `bytes`
-int stage_reserve(ds_handle* h, int i, size_t bytes) {
-    if (bytes <= h->dev_buf_bytes[i]) return DS_OK;
-    DS_HIP(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(h->dev_buf[i]); h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0;
-    DS_HIP(h, hipMalloc((void**)&h->dev_buf[i], bytes));
-    h->dev_buf_bytes[i] = bytes;
-    return DS_OK;
-}
-
-struct IoSpec { const float* in[3]; size_t in_bytes[3]; float* out[5]; size_t out_bytes[5]; };
-
-// resolve host/device pointers: for DS_MEM_HOST copy inputs to staging and return device aliases
-int io_begin(ds_handle* h, int mem, const IoSpec& io, const float* din[3], float* dout[5]) {
-    for (int i = 0; i < 5; ++i) {
-        if (i < 3) din[i] = io.in[i];
-        dout[i] = io.out[i];
-        if (mem == DS_MEM_HOST) {
-            if (i < 3 && io.in[i]) {
-                int rc = stage_reserve(h, i, io.in_bytes[i]); if (rc) return rc;
-                DS_HIP(h, hipMemcpyAsync(h->dev_buf[i], io.in[i], io.in_bytes[i], hipMemcpyHostToDevice, h->stream));
-                din[i] = h->dev_buf[i];
-            }
-            if (io.out[i]) {
-                int rc = stage_reserve(h, 4 + i, io.out_bytes[i]); if (rc) return rc;
-                dout[i] = h->dev_buf[4 + i];
-            }
-        }
-    }
-    return DS_OK;
-}
-
-int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[5]) {
-    if (mem == DS_MEM_HOST) {
-        for (int i = 0; i < 5; ++i)
-            if (io.out[i]) DS_HIP(h, hipMemcpyAsync(io.out[i], dout[i], io.out_bytes[i], hipMemcpyDeviceToHost, h->stream));
-        DS_HIP(h, hipStreamSynchronize(h->stream));
-    }
-    return DS_OK;
-}
-
-int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int mem, const IoSpec& io, int is_complex, int has_p) {
-    if (!h) return DS_EINVAL;
-    if (h->cfg.algo != want_algo) return fail(h, DS_ESTATE, std::string(who) + ": handle was created for a different algo");
-    if (n_frames < 0) return fail(h, DS_ESHAPE, std::string(who) + ": n_frames < 0");
-    if (n_frames == 0) return DS_OK;
-    int rc = set_device(h); if (rc) return rc;
-    const float* din[3]; float* dout[5];
-    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    ds::OpParams p;
-    std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames;
-    p.st = h->opst; p.NF = h->NF;
-    p.in0 = din[0]; p.in1 = din[1]; p.in2 = din[2];
-    p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2];
-    p.M = h->cfg.n_mics; p.N = h->filter_len;
-    p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = h->mcra_L; p.first_frame = h->op_first;
-    p.in_complex = is_complex; p.has_p = has_p; p.norm = h->norm;
-    p.mu = h->filt_mu; p.alpha = h->filt_alpha; p.reg = 1e-4f; p.lam = h->rls_lambda;
-    p.x_fan = h->x_fan > 0 ? h->x_fan : 1; p.p_complement = h->p_complement;
-    p.steer = h->steer; p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
-    p.method = h->method; p.alpha_v = h->alpha_v; p.gate = h->gate; p.diag = h->diag;
-    DS_HIP(h, ds::launch_binop(h->op, p, h->stream));
-    // advance the uniform counters exactly like the kernel did (mcra.py:52-56,72-74)
-    for (int t = 0; t < n_frames; ++t) {
-        if (h->op_frm != 0 && h->op_ell % h->mcra_L == 0) h->op_ell = 0;
-        h->op_frm += 1; h->op_ell += 1;
-    }
-    h->op_first = 0;
-    return io_end(h, mem, io, dout);
-}
-
-}  // namespace
-
-int ds_stft(ds_handle* h, const float* x, int layout, int n_samples, float* Y, int mem) {
-    if (!h || !x || !Y) return fail(h, DS_EINVAL, "ds_stft: NULL argument");
-    if (h->cfg.algo != DS_ALGO_TRANSFORM) return fail(h, DS_ESTATE, "ds_stft: handle is not a DS_ALGO_TRANSFORM object");
-    if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_stft: n_samples must be a multiple of hop");
-    if (layout != DS_LAYOUT_SAMPLES_CHANNELS && layout != DS_LAYOUT_CHANNELS_SAMPLES) return fail(h, DS_EINVAL, "ds_stft: unknown layout");
-    if (n_samples == 0) return DS_OK;
-    int rc = set_device(h); if (rc) return rc;
-    const size_t B = h->cfg.batch, M = h->cfg.n_mics, T = n_samples / h->cfg.hop;
-    IoSpec io = {{x, nullptr, nullptr}, {B * M * (size_t)n_samples * 4, 0, 0}, {Y, nullptr, nullptr}, {B * T * h->K * M * 8, 0, 0}};
-    const float* din[3]; float* dout[5];
-    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    Params p;
-    fill_params(h, p);
-    p.x = din[0]; p.y = dout[0];
-    p.x_batch_stride = (long long)(M * (size_t)n_samples);
-    p.y_batch_stride = (long long)(T * h->K * M * 2);
-    if (layout == DS_LAYOUT_CHANNELS_SAMPLES) { p.x_sample_stride = 1; p.x_chan_stride = n_samples; }
-    else { p.x_sample_stride = (long long)M; p.x_chan_stride = 1; }
-    p.T = (int)T; p.batch0 = 0;
-    DS_HIP(h, h->ki.launch(p, h->cfg.batch, h->stream));
-    return io_end(h, mem, io, dout);
-}
-
-int ds_istft(ds_handle* h, const float* Y, int n_frames, int n_channels, float* y, int mem) {
-    if (!h || !Y || !y) return fail(h, DS_EINVAL, "ds_istft: NULL argument");
-    if (h->cfg.algo != DS_ALGO_TRANSFORM) return fail(h, DS_ESTATE, "ds_istft: handle is not a DS_ALGO_TRANSFORM object");
-    if (n_channels < 1 || n_channels > h->cfg.n_mics)                       // transform.py:466
-        return fail(h, DS_ESHAPE, "ds_istft: n_channels must be in 1..channel");
-    if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_istft: n_frames < 0");
-    if (n_frames == 0) return DS_OK;
-    int rc = set_device(h); if (rc) return rc;
-    const size_t B = h->cfg.batch, C = n_channels, T = n_frames;
-    IoSpec io = {{Y, nullptr, nullptr}, {B * T * h->K * C * 8, 0, 0}, {y, nullptr, nullptr}, {B * T * h->cfg.hop * C * 4, 0, 0}};
-    const float* din[3]; float* dout[5];
-    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    Params p;
-    fill_params(h, p);
-    p.x = din[0]; p.y = dout[0];
-    p.x_batch_stride = (long long)(T * h->K * C * 2);
-    p.y_batch_stride = (long long)(T * h->cfg.hop * C);
-    p.T = (int)T; p.batch0 = 0; p.method = n_channels;
-    DS_HIP(h, h->ki_istft.launch(p, h->cfg.batch, h->stream));
-    return io_end(h, mem, io, dout);
-}
-
-int ds_mcra_estimate(ds_handle* h, const float* Y, int is_complex, int n_frames, float* lambda_d, int mem) {
-    if (!h || !Y || !lambda_d) return fail(h, DS_EINVAL, "ds_mcra_estimate: NULL argument");
-    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
-    IoSpec io = {{Y, nullptr, nullptr}, {n * (is_complex ? 8 : 4), 0, 0}, {lambda_d, nullptr, nullptr}, {n * 4, 0, 0}};
-    return run_binop(h, DS_ALGO_MCRA, "ds_mcra_estimate", n_frames, mem, io, is_complex ? 1 : 0, 0);
-}
-
-int ds_mcmcra_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* G, int mem) {
-    if (!h || !y || !p || !G) return fail(h, DS_EINVAL, "ds_mcmcra_estimate: NULL argument");
-    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
-    IoSpec io = {{y, nullptr, nullptr}, {n * h->cfg.n_mics * 8, 0, 0}, {p, G, nullptr}, {n * 4, n * 4, 0}};
-    return run_binop(h, DS_ALGO_MCMCRA, "ds_mcmcra_estimate", n_frames, mem, io, 0, 0);
-}
-
-int ds_mcsppbase_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* w, int mem) {
-    if (!h || !y || !p || !w) return fail(h, DS_EINVAL, "ds_mcsppbase_estimate: NULL argument");
-    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
-    IoSpec io = {{y, nullptr, nullptr}, {n * h->cfg.n_mics * 8, 0, 0}, {p, w, nullptr}, {n * 4, n * h->cfg.n_mics * 8, 0}};
-    return run_binop(h, DS_ALGO_MCSPPBASE, "ds_mcsppbase_estimate", n_frames, mem, io, 0, 0);
-}
-
-int ds_set_aux(ds_handle* h, const float* table, size_t n_floats) {
-    if (!h || !table || n_floats == 0) return fail(h, DS_EINVAL, "ds_set_aux: NULL argument");
-    int rc = set_device(h); if (rc) return rc;
-    rc = stage_reserve(h, 9, n_floats * sizeof(float)); if (rc) return rc;
-    DS_HIP(h, hipMemcpy(h->dev_buf[9], table, n_floats * sizeof(float), hipMemcpyHostToDevice));
-    h->aux_floats = n_floats;
-    return DS_OK;
-}
-
-int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, float* w_pmwf, float* yout, float* phi_xx,
-                      float* phi_vv_inv, int mem) {
-    if (!h || !y || !p_out || !w_pmwf) return fail(h, DS_EINVAL, "ds_mcspp_estimate: NULL argument");
-    if (h->cfg.algo != DS_ALGO_MCSPP) return fail(h, DS_ESTATE, "ds_mcspp_estimate: handle was created for a different algo");
-    if ((phi_xx == nullptr) != (phi_vv_inv == nullptr)) return fail(h, DS_EINVAL, "ds_mcspp_estimate: phi_xx and phi_vv_inv go together");
-    if (h->aux_floats < (size_t)h->K) return fail(h, DS_ESTATE, "ds_mcspp_estimate: call ds_set_aux(h, Fn[K]) first");
-    if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_mcspp_estimate: n_frames < 0");
-    if (n_frames == 0) return DS_OK;
-    int rc = set_device(h); if (rc) return rc;
-    const size_t n = (size_t)h->cfg.batch * n_frames * h->K, M = h->cfg.n_mics;
-    IoSpec io = {{y, nullptr, nullptr}, {n * M * 8, 0, 0}, {p_out, w_pmwf, yout, phi_xx, phi_vv_inv},
-                 {n * 4, n * M * 8, yout ? n * 8 : 0, phi_xx ? n * M * M * 8 : 0, phi_vv_inv ? n * M * M * 8 : 0}};
-    const float* din[3]; float* dout[5];
-    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    const size_t nbt = (size_t)h->cfg.batch * n_frames;
-    rc = stage_reserve(h, 3, (n + nbt) * 4); if (rc) return rc;              // Gamma [B][T][K], then its band mean [B][T]
-    ds::OpParams p;
-    std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames; p.st = h->opst; p.NF = h->NF; p.M = h->cfg.n_mics;
-    p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = 65;                      // mccdr.py:60-61
-    p.in0 = din[0]; p.in1 = h->dev_buf[9]; p.out0 = h->dev_buf[3];
-    DS_HIP(h, ds::launch_binop(ds::OP_MCCDR, p, h->stream));
-    DS_HIP(h, ds::launch_mcspp_qavg(h->dev_buf[3], h->dev_buf[3] + n, (int)nbt, h->K, h->stream));
-    p.in1 = h->dev_buf[3]; p.in2 = h->dev_buf[3] + n; p.N = 9;
-    p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
-    DS_HIP(h, ds::launch_binop(ds::OP_MCSPP, p, h->stream));
-    for (int t = 0; t < n_frames; ++t) {
-        if (h->op_frm != 0 && h->op_ell % 65 == 0) h->op_ell = 0;
-        h->op_frm += 1; h->op_ell += 1;
-    }
-    return io_end(h, mem, io, dout);
-}
-
-static int run_linalg(ds_handle* h, int op, const char* who, const IoSpec& io, int mem) {
-    if (h->cfg.algo != DS_ALGO_LINALG) return fail(h, DS_ESTATE, std::string(who) + ": handle is not a DS_ALGO_LINALG object");
-    int rc = set_device(h); if (rc) return rc;
-    const float* din[3]; float* dout[5];
-    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    ds::OpParams p;
-    std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = 1; p.M = h->cfg.n_mics;
-    p.in0 = din[0]; p.in1 = din[1]; p.out0 = dout[0];
-    DS_HIP(h, ds::launch_binop(op, p, h->stream));
-    return io_end(h, mem, io, dout);
-}
-
-int ds_steering(ds_handle* h, const float* XX, float* v, int mem) {
-    if (!h || !XX || !v) return fail(h, DS_EINVAL, "ds_steering: NULL argument");
-    const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
-    IoSpec io = {{XX, nullptr, nullptr}, {n * M * M * 8, 0, 0}, {v, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
-    return run_linalg(h, ds::OP_STEERING, "ds_steering", io, mem);
-}
-
-int ds_mvdr_weight(ds_handle* h, const float* steer, const float* Rinv, float* w, int mem) {
-    if (!h || !steer || !Rinv || !w) return fail(h, DS_EINVAL, "ds_mvdr_weight: NULL argument");
-    const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
-    IoSpec io = {{steer, Rinv, nullptr}, {n * M * 8, n * M * M * 8, 0}, {w, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
-    return run_linalg(h, ds::OP_MVDRW, "ds_mvdr_weight", io, mem);
-}
-
-int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem) {
-    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_dcnotch: NULL argument");
-    if (h->cfg.algo != DS_ALGO_FRONTEND) return fail(h, DS_ESTATE, "ds_dcnotch: handle is not a DS_ALGO_FRONTEND object");
-    if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_dcnotch: n_samples < 0");
-    if (n_samples == 0) return DS_OK;
-    int rc = set_device(h); if (rc) return rc;
-    const size_t n = (size_t)h->cfg.batch * h->cfg.n_mics * n_samples;
-    IoSpec io = {{x, nullptr, nullptr}, {n * 4, 0, 0}, {y, nullptr, nullptr, nullptr, nullptr}, {n * 4, 0, 0, 0, 0}};
-    const float* din[3]; float* dout[5];
-    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    ds::TdParams p;
-    std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.M = h->cfg.n_mics; p.n = n_samples; p.x = din[0]; p.y = dout[0]; p.mem = h->td_mem;
-    p.radius = h->cfg.filt_alpha > 0 ? h->cfg.filt_alpha : 0.9f;
-    DS_HIP(h, ds::launch_dcnotch(p, h->stream));
-    return io_end(h, mem, io, dout);
-}
-
-int ds_firbank_bm(ds_handle* h, const float* x, int n_samples, float* y, float* mean, float* bm, int mem) {
-    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_firbank_bm: NULL argument");
-    if (h->cfg.algo != DS_ALGO_FRONTEND) return fail(h, DS_ESTATE, "ds_firbank_bm: handle is not a DS_ALGO_FRONTEND object");
-    const int M = h->cfg.n_mics;
-    if (h->aux_floats == 0 || h->aux_floats % M != 0) return fail(h, DS_ESTATE, "ds_firbank_bm: call ds_set_aux(h, coef[L][M]) first");
-    const int Lt = (int)(h->aux_floats / M);
-    if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_firbank_bm: n_samples < 0");
-    if (n_samples == 0) return DS_OK;
-    int rc = set_device(h); if (rc) return rc;
-    if (h->td_L != Lt) {                                                      // (re)allocate the history for this tap count
-        DS_HIP(h, hipStreamSynchronize(h->stream));
-        for (int i = 0; i < 2; ++i) {
-            (void)hipFree(h->td_cache[i]); h->td_cache[i] = nullptr;
-            const size_t cb = (size_t)h->cfg.batch * (Lt > 1 ? Lt - 1 : 1) * M * sizeof(float);
-            DS_HIP(h, hipMalloc((void**)&h->td_cache[i], cb));
-            DS_HIP(h, hipMemset(h->td_cache[i], 0, cb));
-        }
-        h->td_L = Lt; h->td_cur = 0;
-    }
-    const size_t n = (size_t)h->cfg.batch * n_samples;
-    IoSpec io = {{x, nullptr, nullptr}, {n * M * 4, 0, 0}, {y, mean, bm, nullptr, nullptr}, {n * M * 4, mean ? n * 4 : 0, bm ? n * (M - 1) * 4 : 0, 0, 0}};
-    const float* din[3]; float* dout[5];
-    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    ds::TdParams p;
-    std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.M = M; p.n = n_samples; p.L = Lt; p.x = din[0]; p.y = dout[0]; p.mean = dout[1]; p.diff = bm ? dout[2] : nullptr;
-    p.coef = h->dev_buf[9]; p.cache_in = h->td_cache[h->td_cur]; p.cache_out = h->td_cache[h->td_cur ^ 1];
-    DS_HIP(h, ds::launch_fir(p, h->stream));
-    h->td_cur ^= 1;
-    return io_end(h, mem, io, dout);
-}
-
-int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mean, int mem) {
-    return ds_firbank_bm(h, x, n_samples, y, mean, nullptr, mem);
-}
-
-int ds_tdfilter_update(ds_handle* h, const float* x, const float* d, int n_samples, float p_upd, float* err, int mem) {
-    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_tdfilter_update: NULL argument");
-    if (h->cfg.algo != DS_ALGO_TDNLMS && h->cfg.algo != DS_ALGO_TDRLS)
-        return fail(h, DS_ESTATE, "ds_tdfilter_update: handle is not a DS_ALGO_TDNLMS / DS_ALGO_TDRLS object");
-    if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_tdfilter_update: n_samples < 0");
-    if (n_samples == 0) return DS_OK;
-    int rc = set_device(h); if (rc) return rc;
-    const size_t n = (size_t)h->cfg.batch * n_samples;
-    IoSpec io = {{x, d, nullptr}, {n * 4, n * 4, 0}, {err, nullptr, nullptr, nullptr, nullptr}, {n * 4, 0, 0, 0, 0}};
-    const float* din[3]; float* dout[5];
-    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    ds::TdfParams p;
-    std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.n = n_samples; p.L = h->cfg.filter_len;
-    p.mode = h->cfg.algo == DS_ALGO_TDRLS ? ds::TDF_RLS : ds::TDF_NLMS;
-    p.x = din[0]; p.d = din[1]; p.err = dout[0]; p.w = h->tdf_w; p.buf = h->tdf_buf; p.P = h->tdf_P;
-    p.mu = h->filt_mu; p.eps = 1e-4f; p.p = p_upd; p.lam = h->rls_lambda; p.norm = h->norm;
-    DS_HIP(h, ds::launch_tdfilter(p, h->stream));
-    return io_end(h, mem, io, dout);
-}
-
-int ds_adaptive_frames(ds_handle* h, const float* Z, const float* gain, int n_frames, float* Y, int mem) {
-    if (!h || !Z || !Y) return fail(h, DS_EINVAL, "ds_adaptive_frames: NULL argument");
-    if (h->cfg.algo == DS_ALGO_ADAPTIVE_FRAMES && !h->steer_set) return fail(h, DS_ESTATE, "ds_adaptive_frames: call ds_set_steering first");
-    if (h->method == DS_METHOD_TFGSC) return fail(h, DS_EUNSUPPORTED, "ds_adaptive_frames: TFGSC needs Ryy, use the fused DS_ALGO_ADAPTIVE kernel");
-    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
-    IoSpec io = {{Z, gain, nullptr}, {n * h->cfg.n_mics * 8, gain ? n * 4 : 0, 0}, {Y, nullptr, nullptr}, {n * 8, 0, 0}};
-    return run_binop(h, DS_ALGO_ADAPTIVE_FRAMES, "ds_adaptive_frames", n_frames, mem, io, 0, gain ? 1 : 0);
-}
-
-int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* pp, int p_mode, int n_blocks, int fir_truncate,
-                   float* err, float* w_out, int mem) {
-    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_fdaf_update: NULL argument");
-    if (h->cfg.algo != DS_ALGO_FDAF) return fail(h, DS_ESTATE, "ds_fdaf_update: handle is not a DS_ALGO_FDAF object");
-    if (n_blocks < 0) return fail(h, DS_ESHAPE, "ds_fdaf_update: n_blocks < 0");
-    if (p_mode < DS_FDAF_P_NONE || p_mode > DS_FDAF_P_BIN || (p_mode != DS_FDAF_P_NONE && !pp))
-        return fail(h, DS_EINVAL, "ds_fdaf_update: p_mode / p mismatch");
-    const int L = h->cfg.nfft / 2, C = h->cfg.n_mics;
-    if (fir_truncate > L) return fail(h, DS_ESHAPE, "ds_fdaf_update: fir_truncate > filter_len");
-    if (n_blocks == 0) return DS_OK;
-    int rc = set_device(h); if (rc) return rc;
-    const size_t n = (size_t)h->cfg.batch * n_blocks * L;
-    const size_t pbytes = p_mode == DS_FDAF_P_NONE ? 0 : (size_t)h->cfg.batch * n_blocks * (p_mode == DS_FDAF_P_BIN ? h->K : 1) * 4;
-    IoSpec io = {{x, d, p_mode == DS_FDAF_P_NONE ? nullptr : pp}, {n * C * 4, n * 4, pbytes},
-                 {err, w_out, nullptr, nullptr, nullptr}, {n * 4, w_out ? (size_t)h->cfg.batch * L * C * 4 : 0, 0, 0, 0}};
-    const float* din[3]; float* dout[5];
-    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    ds::FdafParams p;
-    std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.T = n_blocks; p.C = C;
-    p.kind = h->fdaf_kind; p.constrain = h->fdaf_constrain; p.non_causal = h->fdaf_non_causal; p.weight_norm = h->fdaf_weight_norm;
-    p.trunc = fir_truncate < 0 ? -1 : fir_truncate; p.p_mode = p_mode;
-    p.mu = h->filt_mu; p.alpha = h->filt_alpha;
-    p.x = din[0]; p.d = din[1]; p.p = din[2]; p.err = dout[0]; p.w_out = w_out ? dout[1] : nullptr;
-    p.state = h->opst; p.state_stride = (long long)h->NF * h->KP;
-    p.tables = h->tables;
-    DS_HIP(h, ds::launch_fdaf(p, h->cfg.nfft, h->stream));
-    return io_end(h, mem, io, dout);
-}
-
-int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem) {
-    if (!h || !y || !u || !lambda_d || !G || !p) return fail(h, DS_EINVAL, "ds_omlsa_estimate: NULL argument");
-    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
-    IoSpec io = {{y, u, nullptr}, {n * 4, n * (h->cfg.n_mics - 1) * 4, 0}, {lambda_d, G, p}, {n * 4, n * 4, n * 4}};
-    return run_binop(h, DS_ALGO_OMLSA, "ds_omlsa_estimate", n_frames, mem, io, 0, 0);
-}
-
-int ds_sublms_update(ds_handle* h, const float* x, const float* d, const float* p, int n_frames, float* err, int mem) {
-    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_sublms_update: NULL argument");
-    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
-    IoSpec io = {{x, d, p}, {n * h->cfg.n_mics * 8, n * 8, p ? n * 4 : 0}, {err, nullptr, nullptr}, {n * 8, 0, 0}};
-    return run_binop(h, DS_ALGO_SUBLMS, "ds_sublms_update", n_frames, mem, io, 0, p ? 1 : 0);
-}
-
-int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames, float* err, int mem) {
-    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_subrls_update: NULL argument");
-    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
-    IoSpec io = {{x, d, nullptr}, {n * 8, n * 8, 0}, {err, nullptr, nullptr}, {n * 8, 0, 0}};
-    return run_binop(h, DS_ALGO_SUBRLS, "ds_subrls_update", n_frames, mem, io, 0, 0);
-}
-
-static int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len) {
-    if (!h || (!x_delayed && !ring) || !d || !err) return fail(h, DS_EINVAL, "ds_wpe_update: NULL argument");
-    if (h->cfg.algo != DS_ALGO_WPE) return fail(h, DS_ESTATE, "ds_wpe_update: handle was created for a different algo");
-    if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_wpe_update: n_frames < 0");
-    if (n_frames == 0) return DS_OK;
-    int rc = set_device(h); if (rc) return rc;
-    const size_t n = (size_t)h->cfg.batch * n_frames * h->K * h->cfg.n_mics * 8;
-    IoSpec io = {{x_delayed, d, nullptr}, {x_delayed ? n : 0, n, 0}, {err, nullptr, nullptr}, {n, 0, 0}};
-    const float* din[3]; float* dout[5];
-    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    ds::WpeParams p;
-    std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.K = h->K; p.T = n_frames; p.C = h->cfg.n_mics; p.N = h->filter_len;
-    p.xd = din[0]; p.d = din[1]; p.err = dout[0]; p.state = h->opst; p.lam = h->rls_lambda;
-    p.ustride = (long long)h->NF * h->KP;
-    p.ring = ring; p.ring_pos = ring_pos; p.ring_len = ring_len;
-    DS_HIP(h, ds::launch_wpe(p, h->stream));
-    return io_end(h, mem, io, dout);
-}
-
-int ds_wpe_update(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem) {
-    if (!x_delayed) return fail(h, DS_EINVAL, "ds_wpe_update: NULL argument");
-    return wpe_run(h, x_delayed, d, n_frames, err, mem, nullptr, 0, 0);
-}
-
-// DS_ALGO_WPE_MVDR: STFT -> frame delay line -> WPE -> McMcra gain -> adaptive MVDR frame loop x gain -> ISTFT, every stage a
-// kernel on h->stream reading the previous stage's device buffer (nothing returns to the host between the stages)
-static int chain_reserve(ds_handle* h, int T) {
-    const size_t B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, d = h->wpe_delay > 0 ? h->wpe_delay : 1;
-    const size_t need[8] = {B * T * K * M * 8, 0, B * T * K * M * 8, B * T * K * 4, B * T * K * 4, B * T * K * 8, B * d * K * M * 8, 0};
-    for (int i = 0; i < 8; ++i) {
-        if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
-        DS_HIP(h, hipStreamSynchronize(h->stream));
-        (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
-        DS_HIP(h, hipMalloc((void**)&h->chain_buf[i], need[i]));
-        h->chain_bytes[i] = need[i];
-        if (i >= 6) DS_HIP(h, hipMemset(h->chain_buf[i], 0, need[i]));      // the stream starts from silence (DelaySamples, awpe.py:75-76)
-    }
-    return DS_OK;
-}
-
-static int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
-                                int n_samples, float* y_dev, long long y_batch_stride) {
-    int rc = set_device(h); if (rc) return rc;
-    const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, T = n_samples / h->cfg.hop;
-    rc = chain_reserve(h, T); if (rc) return rc;
-    float *D = h->chain_buf[0], *E = h->chain_buf[2], *pp = h->chain_buf[3], *G = h->chain_buf[4], *Y = h->chain_buf[5];
-#define DS_SUB(i, call) do { int rc_ = (call); if (rc_) return fail(h, rc_, h->sub[i]->err); } while (0)
-    {   // analysis, strided input like the fused kernels take it
-        ds_handle* t = h->sub[0];
-        Params p;
-        fill_params(t, p);
-        p.x = x_dev; p.y = D;
-        p.x_batch_stride = x_batch_stride;
-        p.y_batch_stride = (long long)T * K * M * 2;
-        if (layout == DS_LAYOUT_CHANNELS_SAMPLES) { p.x_sample_stride = 1; p.x_chan_stride = x_chan_stride > 0 ? x_chan_stride : n_samples; }
-        else { p.x_sample_stride = M; p.x_chan_stride = 1; }
-        p.T = T; p.batch0 = 0;
-        DS_HIP(h, t->ki.launch(p, B, h->stream));
-    }
-    // delayed input of the prediction filter: a ring of the last wpe_delay analysis frames kept by the WPE kernel itself
-    if (h->wpe_delay > 0) {
-        DS_SUB(1, wpe_run(h->sub[1], nullptr, D, T, E, DS_MEM_DEVICE, h->chain_buf[6], h->hist_cur, h->wpe_delay));
-        h->hist_cur = (h->hist_cur + T) % h->wpe_delay;
-    } else {
-        DS_SUB(1, wpe_run(h->sub[1], D, D, T, E, DS_MEM_DEVICE, nullptr, 0, 0));
-    }
-    DS_SUB(2, ds_mcmcra_estimate(h->sub[2], E, T, pp, G, DS_MEM_DEVICE));
-    DS_SUB(3, ds_adaptive_frames(h->sub[3], E, G, T, Y, DS_MEM_DEVICE));
-    {   // synthesis straight into the caller's (strided) output
-        ds_handle* t = h->sub[4];
-        Params p;
-        fill_params(t, p);
-        p.x = Y; p.y = y_dev;
-        p.x_batch_stride = (long long)T * K * 2;
-        p.y_batch_stride = y_batch_stride;
-        p.T = T; p.batch0 = 0; p.method = 1;
-        DS_HIP(h, t->ki_istft.launch(p, B, h->stream));
-    }
-#undef DS_SUB
-    return DS_OK;
-}
-
-// ---- DS_ALGO_SUBBAND_GSC: SubbandGSC.process (SubbandGSC.py:170-262) as a device-resident chain ------------------------------
-// buffers: 0 xn [B][M][n] (notched), 1 xa [B][M][n] (aligned), 2 fixed [B][n], 3 D c[B][T][K][M], 4 p [B][T][K], 5 PMWF scratch,
-// 6 F c[B][T][K], 7 Dm c[B*M][T][K], 8 E c[B*M][T][K], 9 bm_td [B][M][n], 10 Xa c[B][T][K][M], 11 Dd c[B][T][K], 12 e2 c[B][T][K],
-// 13 F of the previous block c[B][K] (state), 14 fixed output of the previous block [B][hop] (state)
-static int chain2_reserve(ds_handle* h, int n) {
-    const size_t B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, T = n / h->cfg.hop, hop = h->cfg.hop;
-    const size_t need[15] = {B * M * n * 4, B * M * n * 4, B * n * 4, B * T * K * M * 8, B * T * K * 4, B * T * K * M * 8, B * T * K * 8,
-                             B * M * T * K * 8, B * M * T * K * 8, B * M * n * 4, B * T * K * M * 8, B * T * K * 8, B * T * K * 8,
-                             B * K * 8, B * hop * 4};
-    for (int i = 0; i < 15; ++i) {
-        if (need[i] <= h->chain_bytes[i]) continue;
-        DS_HIP(h, hipStreamSynchronize(h->stream));
-        (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
-        DS_HIP(h, hipMalloc((void**)&h->chain_buf[i], need[i]));
-        h->chain_bytes[i] = need[i];
-        if (i >= 13) DS_HIP(h, hipMemset(h->chain_buf[i], 0, need[i]));       // delay_fbf starts from silence (SubbandGSC.py:111)
-    }
-    return DS_OK;
-}
-
-// launch the STFT of sub-handle `t` on dense channel-major input x [batch][C][n] -> Y [batch][T][K][C]
-static int chain_stft(ds_handle* h, ds_handle* t, const float* x, int n, float* Y) {
-    Params p;
-    fill_params(t, p);
-    const int C = t->cfg.n_mics, T = n / t->cfg.hop;
-    p.x = x; p.y = Y;
-    p.x_batch_stride = (long long)C * n; p.x_sample_stride = 1; p.x_chan_stride = n;
-    p.y_batch_stride = (long long)T * t->K * C * 2;
-    p.T = T; p.batch0 = 0;
-    DS_HIP(h, t->ki.launch(p, t->cfg.batch, h->stream));
-    return DS_OK;
-}
-static int chain_istft(ds_handle* h, ds_handle* t, const float* Y, int T, float* y, long long y_batch_stride) {
-    Params p;
-    fill_params(t, p);
-    p.x = Y; p.y = y;
-    p.x_batch_stride = (long long)T * t->K * 2;
-    p.y_batch_stride = y_batch_stride;
-    p.T = T; p.batch0 = 0; p.method = 1;
-    DS_HIP(h, t->ki_istft.launch(p, t->cfg.batch, h->stream));
-    return DS_OK;
-}
-
-// x_dev: [B][M][n] with element strides (x_bstride, x_cstride); y_dev [B] rows of n with stride y_bstride; the optional outputs dense
-static int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
-                      float* fix_dev, float* bm_dev, float* p_dev, float* al_dev) {
-    int rc = set_device(h); if (rc) return rc;
-    ds_handle* fe = h->sub[0];
-    const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, hop = h->cfg.hop, T = n / hop;
-    if (fe->aux_floats == 0 || fe->aux_floats % M != 0 || h->sub[2]->aux_floats < (size_t)K)
-        return fail(h, DS_ESTATE, "SubbandGSC chain: call ds_chain_set_aux(DS_CHAIN_AUX_FIR) and (DS_CHAIN_AUX_COHERENCE) first");
-    rc = chain2_reserve(h, n); if (rc) return rc;
-    float** cb = h->chain_buf;
-#define DS_SUB(i, call) do { int rc_ = (call); if (rc_) return fail(h, rc_, h->sub[i]->err); } while (0)
-    {   // :177-178 DC notch per channel, then :201,206 TimeAlignment FIR bank + channel mean (the fixed beamformer)
-        ds::TdParams p;
-        std::memset(&p, 0, sizeof p);
-        p.B = B; p.M = M; p.n = n; p.x = x_dev; p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.y = cb[0]; p.mem = fe->td_mem;
-        p.radius = fe->cfg.filt_alpha;
-        DS_HIP(h, ds::launch_dcnotch(p, h->stream));
-        const int Lt = (int)(fe->aux_floats / M);
-        if (fe->td_L != Lt) {
-            DS_HIP(h, hipStreamSynchronize(h->stream));
-            for (int i = 0; i < 2; ++i) {
-                (void)hipFree(fe->td_cache[i]); fe->td_cache[i] = nullptr;
-                const size_t cbytes = (size_t)B * (Lt > 1 ? Lt - 1 : 1) * M * sizeof(float);
-                DS_HIP(h, hipMalloc((void**)&fe->td_cache[i], cbytes));
-                DS_HIP(h, hipMemset(fe->td_cache[i], 0, cbytes));
-            }
-            fe->td_L = Lt; fe->td_cur = 0;
-        }
-        std::memset(&p, 0, sizeof p);
-        p.B = B; p.M = M; p.n = n; p.L = Lt; p.x = cb[0]; p.x_chan_major = 1; p.y = cb[1]; p.y_chan_major = 1; p.mean = cb[2];
-        p.coef = fe->dev_buf[9]; p.cache_in = fe->td_cache[fe->td_cur]; p.cache_out = fe->td_cache[fe->td_cur ^ 1];
-        DS_HIP(h, ds::launch_fir(p, h->stream));
-        fe->td_cur ^= 1;
-    }
-    rc = chain_stft(h, h->sub[1], cb[1], n, cb[3]); if (rc) return rc;                                   // :204  D
-    DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[3], T, cb[4], cb[5], nullptr, nullptr, nullptr, DS_MEM_DEVICE));   // :208  p
-    rc = chain_stft(h, h->sub[3], cb[2], n, cb[6]); if (rc) return rc;                                   // bm[m].transform_x: F
-    rc = chain_stft(h, h->sub[4], cb[1], n, cb[7]); if (rc) return rc;                                   // bm[m].transform_d analysis: B*M channels
-    if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[6], cb[7], T, cb[8], DS_MEM_DEVICE));
-    else DS_SUB(5, ds_sublms_update(h->sub[5], cb[6], cb[7], cb[4], T, cb[8], DS_MEM_DEVICE));           // :217-223
-    rc = chain_istft(h, h->sub[4], cb[8], T, cb[9], n); if (rc) return rc;                               // bm outputs, [B*M][n] = [B][M][n]
-    rc = chain_stft(h, h->sub[6], cb[9], n, cb[10]); if (rc) return rc;                                  // :230-234  aic transform_x
-    {   // :226 delay_fbf: the canceller's desired signal is the fixed output one block late = F shifted by one frame
-        const size_t fr = (size_t)K * 8;
-        if (T > 1) DS_HIP(h, hipMemcpy2DAsync((char*)cb[11] + fr, T * fr, cb[6], T * fr, (T - 1) * fr, B, hipMemcpyDeviceToDevice, h->stream));
-        DS_HIP(h, hipMemcpy2DAsync(cb[11], T * fr, cb[13], fr, fr, B, hipMemcpyDeviceToDevice, h->stream));
-        DS_HIP(h, hipMemcpy2DAsync(cb[13], fr, (char*)cb[6] + (T - 1) * fr, T * fr, fr, B, hipMemcpyDeviceToDevice, h->stream));
-    }
-    DS_SUB(7, ds_sublms_update(h->sub[7], cb[10], cb[11], cb[4], T, cb[12], DS_MEM_DEVICE));
-    rc = chain_istft(h, h->sub[8], cb[12], T, y_dev, y_bstride); if (rc) return rc;
-    {   // fix_output = fixed beamformer output delayed by one block (:226,255); the carried block is state either way
-        const size_t blk = (size_t)hop * 4, row = (size_t)n * 4;
-        if (fix_dev) {
-            if (T > 1) DS_HIP(h, hipMemcpy2DAsync((char*)fix_dev + blk, row, cb[2], row, row - blk, B, hipMemcpyDeviceToDevice, h->stream));
-            DS_HIP(h, hipMemcpy2DAsync(fix_dev, row, cb[14], blk, blk, B, hipMemcpyDeviceToDevice, h->stream));
-        }
-        DS_HIP(h, hipMemcpy2DAsync(cb[14], blk, (char*)cb[2] + (row - blk), row, blk, B, hipMemcpyDeviceToDevice, h->stream));
-    }
-    const size_t nb = (size_t)B * M * n * 4;
-    if (bm_dev) DS_HIP(h, hipMemcpyAsync(bm_dev, cb[9], nb, hipMemcpyDeviceToDevice, h->stream));
-    if (al_dev) DS_HIP(h, hipMemcpyAsync(al_dev, cb[1], nb, hipMemcpyDeviceToDevice, h->stream));
-    if (p_dev) DS_HIP(h, hipMemcpyAsync(p_dev, cb[4], (size_t)B * T * K * 4, hipMemcpyDeviceToDevice, h->stream));
-#undef DS_SUB
-    return DS_OK;
-}
-
-int ds_chain_set_aux(ds_handle* h, int which, const float* table, size_t n_floats) {
-    if (!h || !table) return fail(h, DS_EINVAL, "ds_chain_set_aux: NULL argument");
-    if (h->cfg.algo != DS_ALGO_SUBBAND_GSC) return fail(h, DS_ESTATE, "ds_chain_set_aux: handle is not a DS_ALGO_SUBBAND_GSC object");
-    ds_handle* t = which == DS_CHAIN_AUX_FIR ? h->sub[0] : which == DS_CHAIN_AUX_COHERENCE ? h->sub[2] : nullptr;
-    if (!t) return fail(h, DS_EINVAL, "ds_chain_set_aux: unknown table id");
-    const int rc = ds_set_aux(t, table, n_floats);
-    return rc ? fail(h, rc, t->err) : DS_OK;
-}
-
-int ds_subband_gsc_process(ds_handle* h, const float* x, int n_samples, float* y, float* fix_output, float* bm_output, float* pp,
-                           float* aligned, int mem) {
-    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_subband_gsc_process: NULL argument");
-    if (h->cfg.algo != DS_ALGO_SUBBAND_GSC) return fail(h, DS_ESTATE, "ds_subband_gsc_process: handle is not a DS_ALGO_SUBBAND_GSC object");
-    if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_subband_gsc_process: n_samples must be a multiple of hop");
-    if (n_samples == 0) return DS_OK;
-    int rc = set_device(h); if (rc) return rc;
-    const size_t B = h->cfg.batch, M = h->cfg.n_mics, n = n_samples, T = n / h->cfg.hop;
-    IoSpec io = {{x, nullptr, nullptr}, {B * M * n * 4, 0, 0}, {y, fix_output, bm_output, pp, aligned},
-                 {B * n * 4, fix_output ? B * n * 4 : 0, bm_output ? B * M * n * 4 : 0, pp ? B * T * h->K * 4 : 0, aligned ? B * M * n * 4 : 0}};
-    const float* din[3]; float* dout[5];
-    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    rc = chain2_run(h, din[0], (long long)(M * n), (long long)n, n_samples, dout[0], (long long)n, fix_output ? dout[1] : nullptr,
-                    bm_output ? dout[2] : nullptr, pp ? dout[3] : nullptr, aligned ? dout[4] : nullptr);
-    if (rc) return rc;
-    return io_end(h, mem, io, dout);
-}
-
 int ds_process_pcm16(ds_handle* h, const int16_t* pcm, int n_total_channels, int first_channel, int n_samples, int16_t* out) {
     if (!h || !pcm || !out) return fail(h, DS_EINVAL, "ds_process_pcm16: NULL argument");
     if (h->cfg.algo > DS_ALGO_GSC) return fail(h, DS_ESTATE, "ds_process_pcm16: handle is a frame-level object");

@@ -1,0 +1,208 @@
+// ds_api_chains.hip — the chain handles: whole reference structures behind one native handle, every stage a kernel on the
+// handle's stream reading the previous stage's device buffer.
+//   DS_ALGO_WPE_MVDR     BASELINE config 4: STFT -> RLS-WPE -> McMcra gain -> adaptive MVDR frame loop -> ISTFT
+//   DS_ALGO_SUBBAND_GSC  SubbandGSC.process (beamformer/SubbandGSC.py:170-262); BASELINE config 5 with RLS blocking filters
+#include "ds_handle.hpp"
+
+using namespace dsi;
+
+namespace dsi {
+// DS_ALGO_WPE_MVDR: STFT -> frame delay line -> WPE -> McMcra gain -> adaptive MVDR frame loop x gain -> ISTFT, every stage a
+// kernel on h->stream reading the previous stage's device buffer (nothing returns to the host between the stages)
+int chain_reserve(ds_handle* h, int T) {
+    const size_t B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, d = h->wpe_delay > 0 ? h->wpe_delay : 1;
+    const size_t need[8] = {B * T * K * M * 8, 0, B * T * K * M * 8, B * T * K * 4, B * T * K * 4, B * T * K * 8, B * d * K * M * 8, 0};
+    for (int i = 0; i < 8; ++i) {
+        if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
+        DS_HIP(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
+        DS_HIP(h, hipMalloc((void**)&h->chain_buf[i], need[i]));
+        h->chain_bytes[i] = need[i];
+        if (i >= 6) DS_HIP(h, hipMemset(h->chain_buf[i], 0, need[i]));      // the stream starts from silence (DelaySamples, awpe.py:75-76)
+    }
+    return DS_OK;
+}
+
+int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
+                                int n_samples, float* y_dev, long long y_batch_stride) {
+    int rc = set_device(h); if (rc) return rc;
+    const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, T = n_samples / h->cfg.hop;
+    rc = chain_reserve(h, T); if (rc) return rc;
+    float *D = h->chain_buf[0], *E = h->chain_buf[2], *pp = h->chain_buf[3], *G = h->chain_buf[4], *Y = h->chain_buf[5];
+#define DS_SUB(i, call) do { int rc_ = (call); if (rc_) return fail(h, rc_, h->sub[i]->err); } while (0)
+    {   // analysis, strided input like the fused kernels take it
+        ds_handle* t = h->sub[0];
+        Params p;
+        fill_params(t, p);
+        p.x = x_dev; p.y = D;
+        p.x_batch_stride = x_batch_stride;
+        p.y_batch_stride = (long long)T * K * M * 2;
+        if (layout == DS_LAYOUT_CHANNELS_SAMPLES) { p.x_sample_stride = 1; p.x_chan_stride = x_chan_stride > 0 ? x_chan_stride : n_samples; }
+        else { p.x_sample_stride = M; p.x_chan_stride = 1; }
+        p.T = T; p.batch0 = 0;
+        DS_HIP(h, t->ki.launch(p, B, h->stream));
+    }
+    // delayed input of the prediction filter: a ring of the last wpe_delay analysis frames kept by the WPE kernel itself
+    if (h->wpe_delay > 0) {
+        DS_SUB(1, wpe_run(h->sub[1], nullptr, D, T, E, DS_MEM_DEVICE, h->chain_buf[6], h->hist_cur, h->wpe_delay));
+        h->hist_cur = (h->hist_cur + T) % h->wpe_delay;
+    } else {
+        DS_SUB(1, wpe_run(h->sub[1], D, D, T, E, DS_MEM_DEVICE, nullptr, 0, 0));
+    }
+    DS_SUB(2, ds_mcmcra_estimate(h->sub[2], E, T, pp, G, DS_MEM_DEVICE));
+    DS_SUB(3, ds_adaptive_frames(h->sub[3], E, G, T, Y, DS_MEM_DEVICE));
+    {   // synthesis straight into the caller's (strided) output
+        ds_handle* t = h->sub[4];
+        Params p;
+        fill_params(t, p);
+        p.x = Y; p.y = y_dev;
+        p.x_batch_stride = (long long)T * K * 2;
+        p.y_batch_stride = y_batch_stride;
+        p.T = T; p.batch0 = 0; p.method = 1;
+        DS_HIP(h, t->ki_istft.launch(p, B, h->stream));
+    }
+#undef DS_SUB
+    return DS_OK;
+}
+
+// ---- DS_ALGO_SUBBAND_GSC: SubbandGSC.process (SubbandGSC.py:170-262) as a device-resident chain ------------------------------
+// buffers: 0 xn [B][M][n] (notched), 1 xa [B][M][n] (aligned), 2 fixed [B][n], 3 D c[B][T][K][M], 4 p [B][T][K], 5 PMWF scratch,
+// 6 F c[B][T][K], 7 Dm c[B*M][T][K], 8 E c[B*M][T][K], 9 bm_td [B][M][n], 10 Xa c[B][T][K][M], 11 Dd c[B][T][K], 12 e2 c[B][T][K],
+// 13 F of the previous block c[B][K] (state), 14 fixed output of the previous block [B][hop] (state)
+int chain2_reserve(ds_handle* h, int n) {
+    const size_t B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, T = n / h->cfg.hop, hop = h->cfg.hop;
+    const size_t need[15] = {B * M * n * 4, B * M * n * 4, B * n * 4, B * T * K * M * 8, B * T * K * 4, B * T * K * M * 8, B * T * K * 8,
+                             B * M * T * K * 8, B * M * T * K * 8, B * M * n * 4, B * T * K * M * 8, B * T * K * 8, B * T * K * 8,
+                             B * K * 8, B * hop * 4};
+    for (int i = 0; i < 15; ++i) {
+        if (need[i] <= h->chain_bytes[i]) continue;
+        DS_HIP(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
+        DS_HIP(h, hipMalloc((void**)&h->chain_buf[i], need[i]));
+        h->chain_bytes[i] = need[i];
+        if (i >= 13) DS_HIP(h, hipMemset(h->chain_buf[i], 0, need[i]));       // delay_fbf starts from silence (SubbandGSC.py:111)
+    }
+    return DS_OK;
+}
+
+// launch the STFT of sub-handle `t` on dense channel-major input x [batch][C][n] -> Y [batch][T][K][C]
+static int chain_stft(ds_handle* h, ds_handle* t, const float* x, int n, float* Y) {
+    Params p;
+    fill_params(t, p);
+    const int C = t->cfg.n_mics, T = n / t->cfg.hop;
+    p.x = x; p.y = Y;
+    p.x_batch_stride = (long long)C * n; p.x_sample_stride = 1; p.x_chan_stride = n;
+    p.y_batch_stride = (long long)T * t->K * C * 2;
+    p.T = T; p.batch0 = 0;
+    DS_HIP(h, t->ki.launch(p, t->cfg.batch, h->stream));
+    return DS_OK;
+}
+static int chain_istft(ds_handle* h, ds_handle* t, const float* Y, int T, float* y, long long y_batch_stride) {
+    Params p;
+    fill_params(t, p);
+    p.x = Y; p.y = y;
+    p.x_batch_stride = (long long)T * t->K * 2;
+    p.y_batch_stride = y_batch_stride;
+    p.T = T; p.batch0 = 0; p.method = 1;
+    DS_HIP(h, t->ki_istft.launch(p, t->cfg.batch, h->stream));
+    return DS_OK;
+}
+
+// x_dev: [B][M][n] with element strides (x_bstride, x_cstride); y_dev [B] rows of n with stride y_bstride; the optional outputs dense
+int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
+                      float* fix_dev, float* bm_dev, float* p_dev, float* al_dev) {
+    int rc = set_device(h); if (rc) return rc;
+    ds_handle* fe = h->sub[0];
+    const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, hop = h->cfg.hop, T = n / hop;
+    if (fe->aux_floats == 0 || fe->aux_floats % M != 0 || h->sub[2]->aux_floats < (size_t)K)
+        return fail(h, DS_ESTATE, "SubbandGSC chain: call ds_chain_set_aux(DS_CHAIN_AUX_FIR) and (DS_CHAIN_AUX_COHERENCE) first");
+    rc = chain2_reserve(h, n); if (rc) return rc;
+    float** cb = h->chain_buf;
+#define DS_SUB(i, call) do { int rc_ = (call); if (rc_) return fail(h, rc_, h->sub[i]->err); } while (0)
+    {   // :177-178 DC notch per channel, then :201,206 TimeAlignment FIR bank + channel mean (the fixed beamformer)
+        ds::TdParams p;
+        std::memset(&p, 0, sizeof p);
+        p.B = B; p.M = M; p.n = n; p.x = x_dev; p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.y = cb[0]; p.mem = fe->td_mem;
+        p.radius = fe->cfg.filt_alpha;
+        DS_HIP(h, ds::launch_dcnotch(p, h->stream));
+        const int Lt = (int)(fe->aux_floats / M);
+        if (fe->td_L != Lt) {
+            DS_HIP(h, hipStreamSynchronize(h->stream));
+            for (int i = 0; i < 2; ++i) {
+                (void)hipFree(fe->td_cache[i]); fe->td_cache[i] = nullptr;
+                const size_t cbytes = (size_t)B * (Lt > 1 ? Lt - 1 : 1) * M * sizeof(float);
+                DS_HIP(h, hipMalloc((void**)&fe->td_cache[i], cbytes));
+                DS_HIP(h, hipMemset(fe->td_cache[i], 0, cbytes));
+            }
+            fe->td_L = Lt; fe->td_cur = 0;
+        }
+        std::memset(&p, 0, sizeof p);
+        p.B = B; p.M = M; p.n = n; p.L = Lt; p.x = cb[0]; p.x_chan_major = 1; p.y = cb[1]; p.y_chan_major = 1; p.mean = cb[2];
+        p.coef = fe->dev_buf[9]; p.cache_in = fe->td_cache[fe->td_cur]; p.cache_out = fe->td_cache[fe->td_cur ^ 1];
+        DS_HIP(h, ds::launch_fir(p, h->stream));
+        fe->td_cur ^= 1;
+    }
+    rc = chain_stft(h, h->sub[1], cb[1], n, cb[3]); if (rc) return rc;                                   // :204  D
+    DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[3], T, cb[4], cb[5], nullptr, nullptr, nullptr, DS_MEM_DEVICE));   // :208  p
+    rc = chain_stft(h, h->sub[3], cb[2], n, cb[6]); if (rc) return rc;                                   // bm[m].transform_x: F
+    rc = chain_stft(h, h->sub[4], cb[1], n, cb[7]); if (rc) return rc;                                   // bm[m].transform_d analysis: B*M channels
+    if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[6], cb[7], T, cb[8], DS_MEM_DEVICE));
+    else DS_SUB(5, ds_sublms_update(h->sub[5], cb[6], cb[7], cb[4], T, cb[8], DS_MEM_DEVICE));           // :217-223
+    rc = chain_istft(h, h->sub[4], cb[8], T, cb[9], n); if (rc) return rc;                               // bm outputs, [B*M][n] = [B][M][n]
+    rc = chain_stft(h, h->sub[6], cb[9], n, cb[10]); if (rc) return rc;                                  // :230-234  aic transform_x
+    {   // :226 delay_fbf: the canceller's desired signal is the fixed output one block late = F shifted by one frame
+        const size_t fr = (size_t)K * 8;
+        if (T > 1) DS_HIP(h, hipMemcpy2DAsync((char*)cb[11] + fr, T * fr, cb[6], T * fr, (T - 1) * fr, B, hipMemcpyDeviceToDevice, h->stream));
+        DS_HIP(h, hipMemcpy2DAsync(cb[11], T * fr, cb[13], fr, fr, B, hipMemcpyDeviceToDevice, h->stream));
+        DS_HIP(h, hipMemcpy2DAsync(cb[13], fr, (char*)cb[6] + (T - 1) * fr, T * fr, fr, B, hipMemcpyDeviceToDevice, h->stream));
+    }
+    DS_SUB(7, ds_sublms_update(h->sub[7], cb[10], cb[11], cb[4], T, cb[12], DS_MEM_DEVICE));
+    rc = chain_istft(h, h->sub[8], cb[12], T, y_dev, y_bstride); if (rc) return rc;
+    {   // fix_output = fixed beamformer output delayed by one block (:226,255); the carried block is state either way
+        const size_t blk = (size_t)hop * 4, row = (size_t)n * 4;
+        if (fix_dev) {
+            if (T > 1) DS_HIP(h, hipMemcpy2DAsync((char*)fix_dev + blk, row, cb[2], row, row - blk, B, hipMemcpyDeviceToDevice, h->stream));
+            DS_HIP(h, hipMemcpy2DAsync(fix_dev, row, cb[14], blk, blk, B, hipMemcpyDeviceToDevice, h->stream));
+        }
+        DS_HIP(h, hipMemcpy2DAsync(cb[14], blk, (char*)cb[2] + (row - blk), row, blk, B, hipMemcpyDeviceToDevice, h->stream));
+    }
+    const size_t nb = (size_t)B * M * n * 4;
+    if (bm_dev) DS_HIP(h, hipMemcpyAsync(bm_dev, cb[9], nb, hipMemcpyDeviceToDevice, h->stream));
+    if (al_dev) DS_HIP(h, hipMemcpyAsync(al_dev, cb[1], nb, hipMemcpyDeviceToDevice, h->stream));
+    if (p_dev) DS_HIP(h, hipMemcpyAsync(p_dev, cb[4], (size_t)B * T * K * 4, hipMemcpyDeviceToDevice, h->stream));
+#undef DS_SUB
+    return DS_OK;
+}
+
+
+}  // namespace dsi
+
+extern "C" {
+int ds_chain_set_aux(ds_handle* h, int which, const float* table, size_t n_floats) {
+    if (!h || !table) return fail(h, DS_EINVAL, "ds_chain_set_aux: NULL argument");
+    if (h->cfg.algo != DS_ALGO_SUBBAND_GSC) return fail(h, DS_ESTATE, "ds_chain_set_aux: handle is not a DS_ALGO_SUBBAND_GSC object");
+    ds_handle* t = which == DS_CHAIN_AUX_FIR ? h->sub[0] : which == DS_CHAIN_AUX_COHERENCE ? h->sub[2] : nullptr;
+    if (!t) return fail(h, DS_EINVAL, "ds_chain_set_aux: unknown table id");
+    const int rc = ds_set_aux(t, table, n_floats);
+    return rc ? fail(h, rc, t->err) : DS_OK;
+}
+
+int ds_subband_gsc_process(ds_handle* h, const float* x, int n_samples, float* y, float* fix_output, float* bm_output, float* pp,
+                           float* aligned, int mem) {
+    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_subband_gsc_process: NULL argument");
+    if (h->cfg.algo != DS_ALGO_SUBBAND_GSC) return fail(h, DS_ESTATE, "ds_subband_gsc_process: handle is not a DS_ALGO_SUBBAND_GSC object");
+    if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_subband_gsc_process: n_samples must be a multiple of hop");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t B = h->cfg.batch, M = h->cfg.n_mics, n = n_samples, T = n / h->cfg.hop;
+    IoSpec io = {{x, nullptr, nullptr}, {B * M * n * 4, 0, 0}, {y, fix_output, bm_output, pp, aligned},
+                 {B * n * 4, fix_output ? B * n * 4 : 0, bm_output ? B * M * n * 4 : 0, pp ? B * T * h->K * 4 : 0, aligned ? B * M * n * 4 : 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    rc = chain2_run(h, din[0], (long long)(M * n), (long long)n, n_samples, dout[0], (long long)n, fix_output ? dout[1] : nullptr,
+                    bm_output ? dout[2] : nullptr, pp ? dout[3] : nullptr, aligned ? dout[4] : nullptr);
+    if (rc) return rc;
+    return io_end(h, mem, io, dout);
+}
+
+}  // extern "C"

@@ -1,0 +1,380 @@
+// ds_api_ops.hip — C-ABI entry points of the frame- and block-level objects (include/dsenh.h, "frame-level entry points"):
+// staging of host-pointer calls, the per-(utterance, bin) operator launches, the block kernels (FDAF, WPE, time-domain filters).
+#include "ds_handle.hpp"
+
+using namespace dsi;
+
+namespace dsi {
+
+// make sure staging slot `i` holds at least `bytes`
+int stage_reserve(ds_handle* h, int i, size_t bytes) {
+    if (bytes <= h->dev_buf_bytes[i]) return DS_OK;
+    DS_HIP(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(h->dev_buf[i]); h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0;
+    DS_HIP(h, hipMalloc((void**)&h->dev_buf[i], bytes));
+    h->dev_buf_bytes[i] = bytes;
+    return DS_OK;
+}
+
+
+// resolve host/device pointers: for DS_MEM_HOST copy inputs to staging and return device aliases
+int io_begin(ds_handle* h, int mem, const IoSpec& io, const float* din[3], float* dout[5]) {
+    for (int i = 0; i < 5; ++i) {
+        if (i < 3) din[i] = io.in[i];
+        dout[i] = io.out[i];
+        if (mem == DS_MEM_HOST) {
+            if (i < 3 && io.in[i]) {
+                int rc = stage_reserve(h, i, io.in_bytes[i]); if (rc) return rc;
+                DS_HIP(h, hipMemcpyAsync(h->dev_buf[i], io.in[i], io.in_bytes[i], hipMemcpyHostToDevice, h->stream));
+                din[i] = h->dev_buf[i];
+            }
+            if (io.out[i]) {
+                int rc = stage_reserve(h, 4 + i, io.out_bytes[i]); if (rc) return rc;
+                dout[i] = h->dev_buf[4 + i];
+            }
+        }
+    }
+    return DS_OK;
+}
+
+int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[5]) {
+    if (mem == DS_MEM_HOST) {
+        for (int i = 0; i < 5; ++i)
+            if (io.out[i]) DS_HIP(h, hipMemcpyAsync(io.out[i], dout[i], io.out_bytes[i], hipMemcpyDeviceToHost, h->stream));
+        DS_HIP(h, hipStreamSynchronize(h->stream));
+    }
+    return DS_OK;
+}
+
+int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int mem, const IoSpec& io, int is_complex, int has_p) {
+    if (!h) return DS_EINVAL;
+    if (h->cfg.algo != want_algo) return fail(h, DS_ESTATE, std::string(who) + ": handle was created for a different algo");
+    if (n_frames < 0) return fail(h, DS_ESHAPE, std::string(who) + ": n_frames < 0");
+    if (n_frames == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames;
+    p.st = h->opst; p.NF = h->NF;
+    p.in0 = din[0]; p.in1 = din[1]; p.in2 = din[2];
+    p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2];
+    p.M = h->cfg.n_mics; p.N = h->filter_len;
+    p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = h->mcra_L; p.first_frame = h->op_first;
+    p.in_complex = is_complex; p.has_p = has_p; p.norm = h->norm;
+    p.mu = h->filt_mu; p.alpha = h->filt_alpha; p.reg = 1e-4f; p.lam = h->rls_lambda;
+    p.x_fan = h->x_fan > 0 ? h->x_fan : 1; p.p_complement = h->p_complement;
+    p.steer = h->steer; p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
+    p.method = h->method; p.alpha_v = h->alpha_v; p.gate = h->gate; p.diag = h->diag;
+    DS_HIP(h, ds::launch_binop(h->op, p, h->stream));
+    // advance the uniform counters exactly like the kernel did (mcra.py:52-56,72-74)
+    for (int t = 0; t < n_frames; ++t) {
+        if (h->op_frm != 0 && h->op_ell % h->mcra_L == 0) h->op_ell = 0;
+        h->op_frm += 1; h->op_ell += 1;
+    }
+    h->op_first = 0;
+    return io_end(h, mem, io, dout);
+}
+
+int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len) {
+    if (!h || (!x_delayed && !ring) || !d || !err) return fail(h, DS_EINVAL, "ds_wpe_update: NULL argument");
+    if (h->cfg.algo != DS_ALGO_WPE) return fail(h, DS_ESTATE, "ds_wpe_update: handle was created for a different algo");
+    if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_wpe_update: n_frames < 0");
+    if (n_frames == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t n = (size_t)h->cfg.batch * n_frames * h->K * h->cfg.n_mics * 8;
+    IoSpec io = {{x_delayed, d, nullptr}, {x_delayed ? n : 0, n, 0}, {err, nullptr, nullptr}, {n, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::WpeParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.K = h->K; p.T = n_frames; p.C = h->cfg.n_mics; p.N = h->filter_len;
+    p.xd = din[0]; p.d = din[1]; p.err = dout[0]; p.state = h->opst; p.lam = h->rls_lambda;
+    p.ustride = (long long)h->NF * h->KP;
+    p.ring = ring; p.ring_pos = ring_pos; p.ring_len = ring_len;
+    DS_HIP(h, ds::launch_wpe(p, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+}  // namespace dsi
+
+extern "C" {
+
+int ds_stft(ds_handle* h, const float* x, int layout, int n_samples, float* Y, int mem) {
+    if (!h || !x || !Y) return fail(h, DS_EINVAL, "ds_stft: NULL argument");
+    if (h->cfg.algo != DS_ALGO_TRANSFORM) return fail(h, DS_ESTATE, "ds_stft: handle is not a DS_ALGO_TRANSFORM object");
+    if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_stft: n_samples must be a multiple of hop");
+    if (layout != DS_LAYOUT_SAMPLES_CHANNELS && layout != DS_LAYOUT_CHANNELS_SAMPLES) return fail(h, DS_EINVAL, "ds_stft: unknown layout");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t B = h->cfg.batch, M = h->cfg.n_mics, T = n_samples / h->cfg.hop;
+    IoSpec io = {{x, nullptr, nullptr}, {B * M * (size_t)n_samples * 4, 0, 0}, {Y, nullptr, nullptr}, {B * T * h->K * M * 8, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    Params p;
+    fill_params(h, p);
+    p.x = din[0]; p.y = dout[0];
+    p.x_batch_stride = (long long)(M * (size_t)n_samples);
+    p.y_batch_stride = (long long)(T * h->K * M * 2);
+    if (layout == DS_LAYOUT_CHANNELS_SAMPLES) { p.x_sample_stride = 1; p.x_chan_stride = n_samples; }
+    else { p.x_sample_stride = (long long)M; p.x_chan_stride = 1; }
+    p.T = (int)T; p.batch0 = 0;
+    DS_HIP(h, h->ki.launch(p, h->cfg.batch, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+int ds_istft(ds_handle* h, const float* Y, int n_frames, int n_channels, float* y, int mem) {
+    if (!h || !Y || !y) return fail(h, DS_EINVAL, "ds_istft: NULL argument");
+    if (h->cfg.algo != DS_ALGO_TRANSFORM) return fail(h, DS_ESTATE, "ds_istft: handle is not a DS_ALGO_TRANSFORM object");
+    if (n_channels < 1 || n_channels > h->cfg.n_mics)                       // transform.py:466
+        return fail(h, DS_ESHAPE, "ds_istft: n_channels must be in 1..channel");
+    if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_istft: n_frames < 0");
+    if (n_frames == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t B = h->cfg.batch, C = n_channels, T = n_frames;
+    IoSpec io = {{Y, nullptr, nullptr}, {B * T * h->K * C * 8, 0, 0}, {y, nullptr, nullptr}, {B * T * h->cfg.hop * C * 4, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    Params p;
+    fill_params(h, p);
+    p.x = din[0]; p.y = dout[0];
+    p.x_batch_stride = (long long)(T * h->K * C * 2);
+    p.y_batch_stride = (long long)(T * h->cfg.hop * C);
+    p.T = (int)T; p.batch0 = 0; p.method = n_channels;
+    DS_HIP(h, h->ki_istft.launch(p, h->cfg.batch, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+int ds_mcra_estimate(ds_handle* h, const float* Y, int is_complex, int n_frames, float* lambda_d, int mem) {
+    if (!h || !Y || !lambda_d) return fail(h, DS_EINVAL, "ds_mcra_estimate: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{Y, nullptr, nullptr}, {n * (is_complex ? 8 : 4), 0, 0}, {lambda_d, nullptr, nullptr}, {n * 4, 0, 0}};
+    return run_binop(h, DS_ALGO_MCRA, "ds_mcra_estimate", n_frames, mem, io, is_complex ? 1 : 0, 0);
+}
+
+int ds_mcmcra_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* G, int mem) {
+    if (!h || !y || !p || !G) return fail(h, DS_EINVAL, "ds_mcmcra_estimate: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{y, nullptr, nullptr}, {n * h->cfg.n_mics * 8, 0, 0}, {p, G, nullptr}, {n * 4, n * 4, 0}};
+    return run_binop(h, DS_ALGO_MCMCRA, "ds_mcmcra_estimate", n_frames, mem, io, 0, 0);
+}
+
+int ds_mcsppbase_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* w, int mem) {
+    if (!h || !y || !p || !w) return fail(h, DS_EINVAL, "ds_mcsppbase_estimate: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{y, nullptr, nullptr}, {n * h->cfg.n_mics * 8, 0, 0}, {p, w, nullptr}, {n * 4, n * h->cfg.n_mics * 8, 0}};
+    return run_binop(h, DS_ALGO_MCSPPBASE, "ds_mcsppbase_estimate", n_frames, mem, io, 0, 0);
+}
+
+int ds_set_aux(ds_handle* h, const float* table, size_t n_floats) {
+    if (!h || !table || n_floats == 0) return fail(h, DS_EINVAL, "ds_set_aux: NULL argument");
+    int rc = set_device(h); if (rc) return rc;
+    rc = stage_reserve(h, 9, n_floats * sizeof(float)); if (rc) return rc;
+    DS_HIP(h, hipMemcpy(h->dev_buf[9], table, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    h->aux_floats = n_floats;
+    return DS_OK;
+}
+
+int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, float* w_pmwf, float* yout, float* phi_xx,
+                      float* phi_vv_inv, int mem) {
+    if (!h || !y || !p_out || !w_pmwf) return fail(h, DS_EINVAL, "ds_mcspp_estimate: NULL argument");
+    if (h->cfg.algo != DS_ALGO_MCSPP) return fail(h, DS_ESTATE, "ds_mcspp_estimate: handle was created for a different algo");
+    if ((phi_xx == nullptr) != (phi_vv_inv == nullptr)) return fail(h, DS_EINVAL, "ds_mcspp_estimate: phi_xx and phi_vv_inv go together");
+    if (h->aux_floats < (size_t)h->K) return fail(h, DS_ESTATE, "ds_mcspp_estimate: call ds_set_aux(h, Fn[K]) first");
+    if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_mcspp_estimate: n_frames < 0");
+    if (n_frames == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t n = (size_t)h->cfg.batch * n_frames * h->K, M = h->cfg.n_mics;
+    IoSpec io = {{y, nullptr, nullptr}, {n * M * 8, 0, 0}, {p_out, w_pmwf, yout, phi_xx, phi_vv_inv},
+                 {n * 4, n * M * 8, yout ? n * 8 : 0, phi_xx ? n * M * M * 8 : 0, phi_vv_inv ? n * M * M * 8 : 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    const size_t nbt = (size_t)h->cfg.batch * n_frames;
+    rc = stage_reserve(h, 3, (n + nbt) * 4); if (rc) return rc;              // Gamma [B][T][K], then its band mean [B][T]
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames; p.st = h->opst; p.NF = h->NF; p.M = h->cfg.n_mics;
+    p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = 65;                      // mccdr.py:60-61
+    p.in0 = din[0]; p.in1 = h->dev_buf[9]; p.out0 = h->dev_buf[3];
+    DS_HIP(h, ds::launch_binop(ds::OP_MCCDR, p, h->stream));
+    DS_HIP(h, ds::launch_mcspp_qavg(h->dev_buf[3], h->dev_buf[3] + n, (int)nbt, h->K, h->stream));
+    p.in1 = h->dev_buf[3]; p.in2 = h->dev_buf[3] + n; p.N = 9;
+    p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
+    DS_HIP(h, ds::launch_binop(ds::OP_MCSPP, p, h->stream));
+    for (int t = 0; t < n_frames; ++t) {
+        if (h->op_frm != 0 && h->op_ell % 65 == 0) h->op_ell = 0;
+        h->op_frm += 1; h->op_ell += 1;
+    }
+    return io_end(h, mem, io, dout);
+}
+
+static int run_linalg(ds_handle* h, int op, const char* who, const IoSpec& io, int mem) {
+    if (h->cfg.algo != DS_ALGO_LINALG) return fail(h, DS_ESTATE, std::string(who) + ": handle is not a DS_ALGO_LINALG object");
+    int rc = set_device(h); if (rc) return rc;
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = 1; p.M = h->cfg.n_mics;
+    p.in0 = din[0]; p.in1 = din[1]; p.out0 = dout[0];
+    DS_HIP(h, ds::launch_binop(op, p, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+int ds_steering(ds_handle* h, const float* XX, float* v, int mem) {
+    if (!h || !XX || !v) return fail(h, DS_EINVAL, "ds_steering: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
+    IoSpec io = {{XX, nullptr, nullptr}, {n * M * M * 8, 0, 0}, {v, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
+    return run_linalg(h, ds::OP_STEERING, "ds_steering", io, mem);
+}
+
+int ds_mvdr_weight(ds_handle* h, const float* steer, const float* Rinv, float* w, int mem) {
+    if (!h || !steer || !Rinv || !w) return fail(h, DS_EINVAL, "ds_mvdr_weight: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
+    IoSpec io = {{steer, Rinv, nullptr}, {n * M * 8, n * M * M * 8, 0}, {w, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
+    return run_linalg(h, ds::OP_MVDRW, "ds_mvdr_weight", io, mem);
+}
+
+int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem) {
+    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_dcnotch: NULL argument");
+    if (h->cfg.algo != DS_ALGO_FRONTEND) return fail(h, DS_ESTATE, "ds_dcnotch: handle is not a DS_ALGO_FRONTEND object");
+    if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_dcnotch: n_samples < 0");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t n = (size_t)h->cfg.batch * h->cfg.n_mics * n_samples;
+    IoSpec io = {{x, nullptr, nullptr}, {n * 4, 0, 0}, {y, nullptr, nullptr, nullptr, nullptr}, {n * 4, 0, 0, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::TdParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.M = h->cfg.n_mics; p.n = n_samples; p.x = din[0]; p.y = dout[0]; p.mem = h->td_mem;
+    p.radius = h->cfg.filt_alpha > 0 ? h->cfg.filt_alpha : 0.9f;
+    DS_HIP(h, ds::launch_dcnotch(p, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+int ds_firbank_bm(ds_handle* h, const float* x, int n_samples, float* y, float* mean, float* bm, int mem) {
+    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_firbank_bm: NULL argument");
+    if (h->cfg.algo != DS_ALGO_FRONTEND) return fail(h, DS_ESTATE, "ds_firbank_bm: handle is not a DS_ALGO_FRONTEND object");
+    const int M = h->cfg.n_mics;
+    if (h->aux_floats == 0 || h->aux_floats % M != 0) return fail(h, DS_ESTATE, "ds_firbank_bm: call ds_set_aux(h, coef[L][M]) first");
+    const int Lt = (int)(h->aux_floats / M);
+    if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_firbank_bm: n_samples < 0");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    if (h->td_L != Lt) {                                                      // (re)allocate the history for this tap count
+        DS_HIP(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < 2; ++i) {
+            (void)hipFree(h->td_cache[i]); h->td_cache[i] = nullptr;
+            const size_t cb = (size_t)h->cfg.batch * (Lt > 1 ? Lt - 1 : 1) * M * sizeof(float);
+            DS_HIP(h, hipMalloc((void**)&h->td_cache[i], cb));
+            DS_HIP(h, hipMemset(h->td_cache[i], 0, cb));
+        }
+        h->td_L = Lt; h->td_cur = 0;
+    }
+    const size_t n = (size_t)h->cfg.batch * n_samples;
+    IoSpec io = {{x, nullptr, nullptr}, {n * M * 4, 0, 0}, {y, mean, bm, nullptr, nullptr}, {n * M * 4, mean ? n * 4 : 0, bm ? n * (M - 1) * 4 : 0, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::TdParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.M = M; p.n = n_samples; p.L = Lt; p.x = din[0]; p.y = dout[0]; p.mean = dout[1]; p.diff = bm ? dout[2] : nullptr;
+    p.coef = h->dev_buf[9]; p.cache_in = h->td_cache[h->td_cur]; p.cache_out = h->td_cache[h->td_cur ^ 1];
+    DS_HIP(h, ds::launch_fir(p, h->stream));
+    h->td_cur ^= 1;
+    return io_end(h, mem, io, dout);
+}
+
+int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mean, int mem) {
+    return ds_firbank_bm(h, x, n_samples, y, mean, nullptr, mem);
+}
+
+int ds_tdfilter_update(ds_handle* h, const float* x, const float* d, int n_samples, float p_upd, float* err, int mem) {
+    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_tdfilter_update: NULL argument");
+    if (h->cfg.algo != DS_ALGO_TDNLMS && h->cfg.algo != DS_ALGO_TDRLS)
+        return fail(h, DS_ESTATE, "ds_tdfilter_update: handle is not a DS_ALGO_TDNLMS / DS_ALGO_TDRLS object");
+    if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_tdfilter_update: n_samples < 0");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t n = (size_t)h->cfg.batch * n_samples;
+    IoSpec io = {{x, d, nullptr}, {n * 4, n * 4, 0}, {err, nullptr, nullptr, nullptr, nullptr}, {n * 4, 0, 0, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::TdfParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.n = n_samples; p.L = h->cfg.filter_len;
+    p.mode = h->cfg.algo == DS_ALGO_TDRLS ? ds::TDF_RLS : ds::TDF_NLMS;
+    p.x = din[0]; p.d = din[1]; p.err = dout[0]; p.w = h->tdf_w; p.buf = h->tdf_buf; p.P = h->tdf_P;
+    p.mu = h->filt_mu; p.eps = 1e-4f; p.p = p_upd; p.lam = h->rls_lambda; p.norm = h->norm;
+    DS_HIP(h, ds::launch_tdfilter(p, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+int ds_adaptive_frames(ds_handle* h, const float* Z, const float* gain, int n_frames, float* Y, int mem) {
+    if (!h || !Z || !Y) return fail(h, DS_EINVAL, "ds_adaptive_frames: NULL argument");
+    if (h->cfg.algo == DS_ALGO_ADAPTIVE_FRAMES && !h->steer_set) return fail(h, DS_ESTATE, "ds_adaptive_frames: call ds_set_steering first");
+    if (h->method == DS_METHOD_TFGSC) return fail(h, DS_EUNSUPPORTED, "ds_adaptive_frames: TFGSC needs Ryy, use the fused DS_ALGO_ADAPTIVE kernel");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{Z, gain, nullptr}, {n * h->cfg.n_mics * 8, gain ? n * 4 : 0, 0}, {Y, nullptr, nullptr}, {n * 8, 0, 0}};
+    return run_binop(h, DS_ALGO_ADAPTIVE_FRAMES, "ds_adaptive_frames", n_frames, mem, io, 0, gain ? 1 : 0);
+}
+
+int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* pp, int p_mode, int n_blocks, int fir_truncate,
+                   float* err, float* w_out, int mem) {
+    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_fdaf_update: NULL argument");
+    if (h->cfg.algo != DS_ALGO_FDAF) return fail(h, DS_ESTATE, "ds_fdaf_update: handle is not a DS_ALGO_FDAF object");
+    if (n_blocks < 0) return fail(h, DS_ESHAPE, "ds_fdaf_update: n_blocks < 0");
+    if (p_mode < DS_FDAF_P_NONE || p_mode > DS_FDAF_P_BIN || (p_mode != DS_FDAF_P_NONE && !pp))
+        return fail(h, DS_EINVAL, "ds_fdaf_update: p_mode / p mismatch");
+    const int L = h->cfg.nfft / 2, C = h->cfg.n_mics;
+    if (fir_truncate > L) return fail(h, DS_ESHAPE, "ds_fdaf_update: fir_truncate > filter_len");
+    if (n_blocks == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t n = (size_t)h->cfg.batch * n_blocks * L;
+    const size_t pbytes = p_mode == DS_FDAF_P_NONE ? 0 : (size_t)h->cfg.batch * n_blocks * (p_mode == DS_FDAF_P_BIN ? h->K : 1) * 4;
+    IoSpec io = {{x, d, p_mode == DS_FDAF_P_NONE ? nullptr : pp}, {n * C * 4, n * 4, pbytes},
+                 {err, w_out, nullptr, nullptr, nullptr}, {n * 4, w_out ? (size_t)h->cfg.batch * L * C * 4 : 0, 0, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::FdafParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.T = n_blocks; p.C = C;
+    p.kind = h->fdaf_kind; p.constrain = h->fdaf_constrain; p.non_causal = h->fdaf_non_causal; p.weight_norm = h->fdaf_weight_norm;
+    p.trunc = fir_truncate < 0 ? -1 : fir_truncate; p.p_mode = p_mode;
+    p.mu = h->filt_mu; p.alpha = h->filt_alpha;
+    p.x = din[0]; p.d = din[1]; p.p = din[2]; p.err = dout[0]; p.w_out = w_out ? dout[1] : nullptr;
+    p.state = h->opst; p.state_stride = (long long)h->NF * h->KP;
+    p.tables = h->tables;
+    DS_HIP(h, ds::launch_fdaf(p, h->cfg.nfft, h->stream));
+    return io_end(h, mem, io, dout);
+}
+
+int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem) {
+    if (!h || !y || !u || !lambda_d || !G || !p) return fail(h, DS_EINVAL, "ds_omlsa_estimate: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{y, u, nullptr}, {n * 4, n * (h->cfg.n_mics - 1) * 4, 0}, {lambda_d, G, p}, {n * 4, n * 4, n * 4}};
+    return run_binop(h, DS_ALGO_OMLSA, "ds_omlsa_estimate", n_frames, mem, io, 0, 0);
+}
+
+int ds_sublms_update(ds_handle* h, const float* x, const float* d, const float* p, int n_frames, float* err, int mem) {
+    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_sublms_update: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{x, d, p}, {n * h->cfg.n_mics * 8, n * 8, p ? n * 4 : 0}, {err, nullptr, nullptr}, {n * 8, 0, 0}};
+    return run_binop(h, DS_ALGO_SUBLMS, "ds_sublms_update", n_frames, mem, io, 0, p ? 1 : 0);
+}
+
+int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames, float* err, int mem) {
+    if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_subrls_update: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    IoSpec io = {{x, d, nullptr}, {n * 8, n * 8, 0}, {err, nullptr, nullptr}, {n * 8, 0, 0}};
+    return run_binop(h, DS_ALGO_SUBRLS, "ds_subrls_update", n_frames, mem, io, 0, 0);
+}
+
+
+int ds_wpe_update(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem) {
+    if (!x_delayed) return fail(h, DS_EINVAL, "ds_wpe_update: NULL argument");
+    return wpe_run(h, x_delayed, d, n_frames, err, mem, nullptr, 0, 0);
+}
+
+}  // extern "C"

@@ -1,0 +1,120 @@
+// ds_handle.hpp — internal to libdsenh.so: the handle behind the C-ABI of include/dsenh.h and the helpers the three API translation
+// units share (ds_api.hip: life cycle, parameters, the fused frame kernels, state; ds_api_ops.hip: frame- and block-level objects;
+// ds_api_chains.hip: the chain handles DS_ALGO_WPE_MVDR / DS_ALGO_SUBBAND_GSC).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/dsenh.h"
+#include "ds_kernels.hpp"
+#include "ds_ops.hpp"
+#include "ds_tdfilter.hpp"
+#include "ds_fdaf.hpp"
+#include "ds_tables.hpp"
+
+using ds::cf;
+using ds::KernelInfo;
+using ds::Params;
+
+struct ds_handle {
+    ds_config cfg;
+    int K, KP, NP, NT;
+    KernelInfo ki;
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    // device state
+    ds::vec4* bins;
+    float* tail_in;
+    float* tail_out;
+    int* counters;
+    ds::vec4* tables;
+    cf* steer;
+    int steer_per_utt;
+    bool steer_set;
+    // staging for host-pointer calls
+    // frame-level objects (DS_ALGO_TRANSFORM .. DS_ALGO_SUBRLS)
+    KernelInfo ki_istft;
+    int op;                     // ds::OP_* or -1
+    float* opst;                // operator state [B][NF][KP]
+    int NF;
+    int op_frm, op_ell, op_first;   // uniform counters of the operator handle
+    int filter_len, norm;
+    float filt_mu, filt_alpha, rls_lambda;
+    float* dev_buf[10];         // staging for host-pointer frame-level calls (3 in, 1 scratch, 5 out, 1 aux table)
+    size_t dev_buf_bytes[10];
+    size_t aux_floats;
+    float* td_mem;              // DS_ALGO_FRONTEND: notch memories [B][M][2]
+    float* td_cache[2];         // FIR history ping-pong [B][L-1][M]
+    int td_L, td_cur;
+    float* tdf_w; float* tdf_buf; float* tdf_P;     // DS_ALGO_TDNLMS / TDRLS state
+    int fdaf_kind, fdaf_constrain, fdaf_non_causal, fdaf_weight_norm;   // DS_ALGO_FDAF (state lives in opst)
+    int x_fan, p_complement;    // subband LMS / RLS inside a chain: shared reference input, 1 - p (OpParams)
+    // DS_ALGO_WPE_MVDR: a chain of operator handles sharing this handle's stream, device-resident between the stages
+    ds_handle* sub[10];         // WPE_MVDR: analysis transform, WPE, McMcra, adaptive frame loop, synthesis transform; SUBBAND_GSC: see chain2_*
+    bool owns_stream;
+    int wpe_delay;
+    float* chain_buf[16];       // WPE_MVDR: D, -, E, p, G, Y, ring of the last wpe_delay analysis frames; SUBBAND_GSC: see chain2_reserve
+    size_t chain_bytes[16];
+    int hist_cur;               // ring slot of the oldest frame
+    // cached hipGraph of a ds_process_device_seq() sequence
+    hipGraphExec_t graph_exec;
+    int split;                  // DS_PARAM_SPLIT: utterance groups captured as parallel graph branches
+    hipStream_t side[7];        // side streams for the extra branches
+    hipEvent_t ev_fork, ev_join[7];
+    long long graph_key[16];
+    bool graph_valid;
+    float* x_stage;
+    float* y_stage;
+    size_t x_stage_elems, y_stage_elems;
+    // params
+    int method;
+    int mcra_L;
+    float alpha_y, alpha_v, diag, gate, mu, out_scale;
+    std::string err;
+};
+
+namespace dsi {
+
+extern thread_local std::string g_err;
+int fail(ds_handle* h, int code, const std::string& msg);
+
+#define DS_HIP(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return dsi::fail(h, DS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+size_t bins_bytes(const ds_handle* h);
+size_t tail_in_bytes(const ds_handle* h);
+size_t tail_out_bytes(const ds_handle* h);
+size_t opst_bytes(const ds_handle* h);
+size_t counters_bytes(const ds_handle* h);
+int set_device(ds_handle* h);
+int zero_state(ds_handle* h);
+void fill_params(const ds_handle* h, Params& p);
+
+// staging for host-pointer calls of the frame-level objects (ds_api_ops.hip)
+struct IoSpec { const float* in[3]; size_t in_bytes[3]; float* out[5]; size_t out_bytes[5]; };
+int stage_reserve(ds_handle* h, int i, size_t bytes);
+int io_begin(ds_handle* h, int mem, const IoSpec& io, const float* din[3], float* dout[5]);
+int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[5]);
+int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int mem, const IoSpec& io, int is_complex, int has_p);
+int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len);
+
+// chain handles (ds_api_chains.hip)
+int chain_reserve(ds_handle* h, int T);
+int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
+                         int n_samples, float* y_dev, long long y_batch_stride);
+int chain2_reserve(ds_handle* h, int n);
+int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
+               float* fix_dev, float* bm_dev, float* p_dev, float* al_dev);
+
+}  // namespace dsi

@@ -94,7 +94,7 @@ class SubbandGSC(object):
     """Subband GSC: time alignment -> mean fixed beamformer -> M SPP-controlled adaptive blocking filters ->
     multichannel adaptive interference canceller — beamformer/SubbandGSC.py:67-262.
 
-    The whole of process() runs behind ONE native handle (DS_ALGO_SUBBAND_GSC, csrc/ds_api.hip chain2_run): notch, FIR bank + mean
+    The whole of process() runs behind ONE native handle (DS_ALGO_SUBBAND_GSC, csrc/ds_api_chains.hip chain2_run): notch, FIR bank + mean
     beamformer, the five transforms, McSpp, the M blocking filters as one batched launch, the canceller — every stage a kernel on the
     handle's stream reading the previous stage's device buffer, all blocks of a call per launch.  `bm_filter="rls"` swaps the
     blocking filters for SubbandRLS(filter_len=2) — the BASELINE config-5 composition (defined by us, the
