@@ -53,7 +53,7 @@ _lib = None
 EXPORTS = [
     "ds_version", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
     "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_pcm16", "ds_process_device",
-    "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcmcra_estimate", "ds_mcsppbase_estimate", "ds_set_aux", "ds_mcspp_estimate", "ds_steering",
+    "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcra_estimate_p", "ds_mcmcra_estimate", "ds_mcsppbase_estimate", "ds_set_aux", "ds_mcspp_estimate", "ds_steering",
     "ds_mvdr_weight", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process",
     "ds_omlsa_estimate",
     "ds_sublms_update", "ds_subrls_update", "ds_wpe_update", "ds_synchronize",
@@ -125,6 +125,8 @@ def load():
     lib.ds_steering.argtypes = [vp, vp, vp, ci]
     lib.ds_mvdr_weight.restype = ci
     lib.ds_mvdr_weight.argtypes = [vp, vp, vp, vp, ci]
+    lib.ds_mcra_estimate_p.restype = ci
+    lib.ds_mcra_estimate_p.argtypes = [vp, vp, ci, ci, vp, vp, ci]
     lib.ds_tdfilter_update.restype = ci
     lib.ds_tdfilter_update.argtypes = [vp, vp, vp, ci, cf_, vp, ci]
     lib.ds_chain_set_aux.restype = ci

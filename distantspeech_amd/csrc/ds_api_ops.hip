@@ -146,11 +146,15 @@ int ds_istft(ds_handle* h, const float* Y, int n_frames, int n_channels, float* 
     return io_end(h, mem, io, dout);
 }
 
-int ds_mcra_estimate(ds_handle* h, const float* Y, int is_complex, int n_frames, float* lambda_d, int mem) {
+int ds_mcra_estimate_p(ds_handle* h, const float* Y, int is_complex, int n_frames, float* lambda_d, float* p, int mem) {
     if (!h || !Y || !lambda_d) return fail(h, DS_EINVAL, "ds_mcra_estimate: NULL argument");
     const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
-    IoSpec io = {{Y, nullptr, nullptr}, {n * (is_complex ? 8 : 4), 0, 0}, {lambda_d, nullptr, nullptr}, {n * 4, 0, 0}};
+    IoSpec io = {{Y, nullptr, nullptr}, {n * (is_complex ? 8 : 4), 0, 0}, {lambda_d, p, nullptr}, {n * 4, p ? n * 4 : 0, 0}};
     return run_binop(h, DS_ALGO_MCRA, "ds_mcra_estimate", n_frames, mem, io, is_complex ? 1 : 0, 0);
+}
+
+int ds_mcra_estimate(ds_handle* h, const float* Y, int is_complex, int n_frames, float* lambda_d, int mem) {
+    return ds_mcra_estimate_p(h, Y, is_complex, n_frames, lambda_d, nullptr, mem);
 }
 
 int ds_mcmcra_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* G, int mem) {

@@ -56,7 +56,7 @@ DS_HD bool mcra_tick(int& frm, int& ell, int L) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// MCRA: in0 = Y [B][T][K] power (or complex [B][T][K][2]), out0 = lambda_d [B][T][K].  state: S,Smin,Stmp,p,lambda_d
+// MCRA: in0 = Y [B][T][K] power (or complex [B][T][K][2]), out0 = lambda_d [B][T][K], optional out1 = p [B][T][K].  state: S,Smin,Stmp,p,lambda_d
 // ------------------------------------------------------------------------------------------------
 DS_HD float mcra_in(const OpParams& p, long long base, int k) {
     if (p.in_complex) { const float re = p.in0[2 * (base + k)], im = p.in0[2 * (base + k) + 1]; return fma_(re, re, im * im); }
@@ -77,6 +77,7 @@ DS_HD void op_mcra(const OpParams& p, int b, int k) {
         mcra_bin(st, k, p.K, ym, y0, yp, frm, reset, p.L);
         frm += 1; ell += 1;
         p.out0[base + k] = st[4];
+        if (p.out1) p.out1[base + k] = st[3];                 // speech presence probability of this frame (mcra.p)
     }
 #pragma unroll
     for (int f = 0; f < 5; ++f) st_at(p, b, f, k) = st[f];

@@ -148,6 +148,15 @@ class BatchEngine:
         L.check(self._lib.ds_mcra_estimate(self._h, self._p(Y), int(cplx), int(Y.shape[1]), self._p(out), L.MEM_HOST), self._h)
         return out
 
+    def mcra_estimate_p(self, Y):
+        """Y [B, T, K] float power or complex -> (lambda_d, p) [B, T, K]: p = the speech presence probability after each frame."""
+        cplx = np.iscomplexobj(Y)
+        Y = np.ascontiguousarray(Y, dtype=np.complex64 if cplx else np.float32)
+        lam = np.empty(Y.shape, dtype=np.float32)
+        p = np.empty(Y.shape, dtype=np.float32)
+        L.check(self._lib.ds_mcra_estimate_p(self._h, self._p(Y), int(cplx), int(Y.shape[1]), self._p(lam), self._p(p), L.MEM_HOST), self._h)
+        return lam, p
+
     def mcmcra_estimate(self, y):
         """y complex [B, T, K, M] -> (p, G) [B, T, K]."""
         y = np.ascontiguousarray(y, dtype=np.complex64)

@@ -5,11 +5,11 @@
   FDGSC   beamformer/FDGSC.py:38-317    time alignment + M coefficient-clamped adaptive blocking filters (mode 3) +
                                         norm-limited multichannel canceller (+ OMLSA post-filter)
 
-Every signal-path stage runs in a libdsenh kernel: ds_dcnotch, ds_firbank_bm (FIR bank + channel mean + pairwise
-differences), ds_stft / ds_istft, ds_mcra_estimate, ds_fdaf_update (all FFTs of a block inside one workgroup; the M
-blocking filters of FDGSC as ONE batched launch), ds_omlsa_estimate.  This module sequences the calls, keeps the
-block delays (pure buffering) and derives the adaptation-control values from the speech-presence vector
-(1 - p, mean p, the FDGSC.py:248-255 threshold) exactly where the reference does."""
+Both structures are feed-forward from stage to stage (only state crosses blocks), so process() calls every operator ONCE with all
+the blocks of the call: ds_dcnotch, ds_firbank_bm (FIR bank + channel mean + pairwise differences), ds_stft, ds_mcra_estimate_p,
+ds_fdaf_update (all FFTs of a block inside one workgroup, the blocks walked in-kernel; FDGSC's M blocking filters are ONE batched
+launch), ds_omlsa_estimate, ds_istft.  This module sequences those calls, keeps the block delays (pure buffering) and derives the
+adaptation-control values from the speech-presence matrix (1 - p, mean p, the FDGSC.py:248-255 threshold) where the reference does."""
 import numpy as np
 
 from . import _lib as L
@@ -31,10 +31,9 @@ class _BlockGSC(object):
             raise ValueError("x must be [k * %d samples, n_chs=%d]" % (self.frameLen, self.M))
         return x, single
 
-    def _spp_block(self, frame):
-        """one MCRA step on a complex frame [B, K] -> p [B, K]."""
-        self.spp._eng.mcra_estimate(frame[:, None, :])
-        return self.spp._eng.op_state()[:, 3, :].astype(np.float64)
+    def _spp(self, frames):
+        """MCRA over the T frames of the call: complex [B, T, K] -> p [B, T, K] (mcra.p after each frame)."""
+        return self.spp._eng.mcra_estimate_p(frames)[1].astype(np.float64)
 
     @staticmethod
     def _stft_refs(tf, bm):
@@ -44,13 +43,16 @@ class _BlockGSC(object):
         return tf.stft(np.concatenate((bm.astype(np.float32), pad), axis=2), L.LAYOUT_SAMPLES_CHANNELS)[:, :, :, :-1]
 
     def _postfilter(self, out_td, U):
-        """OMLSA gain on the canceller output (TDGSC.py:158-170 / FDGSC.py:286-298): out_td [B, FL], U complex [B, K, M-1]."""
-        Y = self.transform_fbf.stft(out_td[:, :, None], L.LAYOUT_SAMPLES_CHANNELS)[:, 0, :, 0]              # [B, K]
-        y_pow = (Y.real.astype(np.float64) ** 2 + Y.imag.astype(np.float64) ** 2)
-        u_pow = (U.real.astype(np.float64) ** 2 + U.imag.astype(np.float64) ** 2)
-        _, G, _ = self.omlsa_multi._eng.omlsa_estimate(y_pow[:, None], u_pow[:, None])
-        Y = Y * np.sqrt(G[:, 0].astype(np.float64))
-        return self.transform_fbf.istft(np.ascontiguousarray(Y[:, None, :, None]))[:, :, 0]
+        """OMLSA gain on the canceller output (TDGSC.py:158-170 / FDGSC.py:286-298): out_td [B, n], U complex [B, T, K, M-1]
+        (or [B, 1, K, M-1], the same references for every frame) -> post-filtered [B, n]."""
+        Y = self.transform_fbf.stft(out_td[:, :, None], L.LAYOUT_SAMPLES_CHANNELS)[:, :, :, 0]            # [B, T, K]
+        y_pow = Y.real.astype(np.float64) ** 2 + Y.imag.astype(np.float64) ** 2
+        u_pow = U.real.astype(np.float64) ** 2 + U.imag.astype(np.float64) ** 2
+        if u_pow.shape[1] != y_pow.shape[1]:
+            u_pow = np.broadcast_to(u_pow, (u_pow.shape[0], y_pow.shape[1]) + u_pow.shape[2:])
+        _, G, _ = self.omlsa_multi._eng.omlsa_estimate(y_pow, u_pow)
+        Y = Y * np.sqrt(G.astype(np.float64))
+        return self.transform_fbf.istft(np.ascontiguousarray(Y[:, :, :, None]))[:, :, 0]
 
 
 class TDGSC(_BlockGSC):
@@ -74,26 +76,20 @@ class TDGSC(_BlockGSC):
     def process(self, x, postfilter=False):
         """x [samples, chs] (or [B, samples, chs]) -> (output [samples], p [half_bin, blocks], output_bm [samples, chs-1])."""
         x, single = self._prep(x)
-        B, M, FL = self.batch, self.M, self.frameLen
-        K = FL + 1
         x = np.swapaxes(self._notch.dcnotch(np.swapaxes(x, 1, 2)), 1, 2)                                   # :129-130
-        nblk = x.shape[1] // FL
-        output = np.zeros((B, nblk * FL)); output_bm = np.zeros((B, nblk * FL, M - 1)); p = np.zeros((B, K, nblk))
-        for n in range(nblk):
-            sl = slice(n * FL, (n + 1) * FL)
-            xa, fixed, bm = self.time_alignment._eng.firbank(np.ascontiguousarray(x[:, sl]), want_bm=True)  # :143,149
-            D = self.transform.stft(fixed[:, :, None], L.LAYOUT_SAMPLES_CHANNELS)[:, 0, :, 0]               # :145
-            pn = self._spp_block(D)                                                                         # :146-147
-            p[:, :, n] = pn
-            out_n, w = self.aic_filter._eng.fdaf_update(bm, fixed, p=(1.0 - pn)[:, None, :], fir_truncate=30)   # :152-156 -> :105
-            self.aic_filter._w = w.astype(np.float64)
-            if postfilter:                                                                                  # :158-170
-                U = self._stft_refs(self.transform_bm, bm)[:, 0]
-                out_n = self._postfilter(out_n, U)
-            output_bm[:, sl] = bm
-            output[:, sl] = out_n
-        sq = (lambda a: a[0]) if single else (lambda a: a)
-        return sq(output), sq(p), sq(output_bm)
+        if x.shape[1] == 0:
+            z = np.zeros((self.batch, 0))
+            out = (z, np.zeros((self.batch, self.frameLen + 1, 0)), np.zeros((self.batch, 0, self.M - 1)))
+            return tuple(a[0] for a in out) if single else out
+        xa, fixed, bm = self.time_alignment._eng.firbank(np.ascontiguousarray(x), want_bm=True)            # :143,149 all blocks
+        D = self.transform.stft(fixed[:, :, None], L.LAYOUT_SAMPLES_CHANNELS)[:, :, :, 0]                   # :145  [B, T, K]
+        p = self._spp(D)                                                                                    # :146-147
+        out, w = self.aic_filter._eng.fdaf_update(bm, fixed, p=1.0 - p, fir_truncate=30)                    # :152-156 -> :105
+        self.aic_filter._w = w.astype(np.float64)
+        if postfilter:                                                                                      # :158-170
+            out = self._postfilter(out, self._stft_refs(self.transform_bm, bm))
+        res = (out.astype(np.float64), np.swapaxes(p, 1, 2), bm.astype(np.float64))
+        return tuple(a[0] for a in res) if single else res
 
 
 class FDGSC(_BlockGSC):
@@ -130,50 +126,59 @@ class FDGSC(_BlockGSC):
         K, H = FL + 1, FL // 2
         if dc_notch:
             x = np.swapaxes(self._notch.dcnotch(np.swapaxes(x, 1, 2)), 1, 2)                               # :213-215
-        nblk = x.shape[1] // FL
-        ns = nblk * FL
-        output = np.zeros((B, ns)); bm_output = np.zeros((B, ns, M)); p = np.zeros((B, K, nblk))
-        aligned = np.zeros((B, ns, M)); aligned_d = np.zeros((B, ns, M)); fix = np.zeros((B, ns)); fix_d = np.zeros((B, ns))
+        x = np.ascontiguousarray(x)
+        ns = x.shape[1]
+        nblk = ns // FL
+        if nblk == 0:
+            z1, zM = np.zeros((B, 0)), np.zeros((B, 0, M))
+            out = (z1, np.zeros((B, K, 0)), z1, z1, zM, zM, zM)
+            return tuple(a[0] for a in out) if single else out
+        xa, fixed = self.time_alignment._eng.firbank(x)                                                     # :235,238  all blocks
+        D = self.transform_x.stft(x, L.LAYOUT_SAMPLES_CHANNELS)[:, :, :, 0]                                  # :241 (channel 0, mcra.py:32-33)
+        p = self._spp(D)                                                                                    # :243-244  [B, T, K]
+        hot = np.mean(p[:, :, 32:128], axis=2) > 0.8                                                        # :248-255, per block
+        lo = p[:, :, :32]
+        lo[hot[:, :, None] & (lo < 0.8)] = 0.8
+        xad = np.concatenate((self._al_tail, xa[:, : ns - H]), axis=1)                                      # :258 delay_aligned
+        self._al_tail = xa[:, ns - H:].copy()
+        # :259-264 -> :185-195: M filters, input = fixed beamformer output, desired = delayed aligned channel m, p = 1
+        xin = np.repeat(fixed[:, None, :], M, axis=1).reshape(B * M, ns, 1)
+        din = np.ascontiguousarray(np.swapaxes(xad, 1, 2)).reshape(B * M, ns)
+        e_bm, w_bm = self.bm._eng.fdaf_update(xin, din)
+        self.bm._w = w_bm.astype(np.float64)
+        bm_output = np.ascontiguousarray(np.swapaxes(e_bm.reshape(B, M, ns), 1, 2))                         # [B, n, M]
+        fix_d = np.concatenate((self._fix_prev, fixed[:, : ns - FL]), axis=1)                               # :270 delay_fbf
+        self._fix_prev = fixed[:, ns - FL:].copy()
+        pa = 1.0 - np.mean(p, axis=2)                                                                       # :282  [B, T]
+        out, w = self.aic_filter._eng.fdaf_update(bm_output, fix_d, p=pa)                                   # :278-284
+        self.aic_filter._w = w.astype(np.float64)
+        if postfilter:                                                                                      # :286-298
+            # transform_fbf is shared by the delayed fixed output (:273) and the canceller output (:287): its STFT state alternates
+            # between the two signals block by block, i.e. frame t of either analysis starts from the OTHER signal's previous block
+            out = self._postfilter_fdgsc(out, fix_d, bm_output)
+        else:
+            self.transform_fbf.stft(fix_d[:, :, None], L.LAYOUT_SAMPLES_CHANNELS)                           # :273 keeps advancing the shared state
+        res = (out.astype(np.float64), np.swapaxes(p, 1, 2), fixed.astype(np.float64), fix_d.astype(np.float64),
+               bm_output.astype(np.float64), xa.astype(np.float64), xad.astype(np.float64))
+        return tuple(a[0] for a in res) if single else res
+
+    def _postfilter_fdgsc(self, out, fix_d, bm_output):
+        """FDGSC.py:273,286-298 block by block: the shared transform_fbf and the whole-array re-analysis of bm_output make this
+        branch inherently sequential in the reference; each block is three kernel calls here."""
+        B, M, FL = self.batch, self.M, self.frameLen
+        nblk = out.shape[1] // FL
+        res = np.empty_like(out)
         U0 = None
         for n in range(nblk):
             sl = slice(n * FL, (n + 1) * FL)
-            xn = np.ascontiguousarray(x[:, sl])
-            xa, fixed = self.time_alignment._eng.firbank(xn)                                                # :235,238
-            D = self.transform_x.stft(xn, L.LAYOUT_SAMPLES_CHANNELS)[:, 0, :, 0]                            # :241 (channel 0, mcra.py:32-33)
-            pn = self._spp_block(D)                                                                         # :243-244
-            for b in range(B):                                                                              # :248-255
-                if np.mean(pn[b, 32:128]) > 0.8:
-                    lo = pn[b, :32]
-                    lo[lo < 0.8] = 0.8
-            p[:, :, n] = pn
-            xad = np.concatenate((self._al_tail, xa[:, : FL - H]), axis=1)                                  # :258
-            self._al_tail = xa[:, FL - H:].copy()
-            # :259-264 -> :185-195: M filters, input = fixed beamformer output, desired = delayed aligned channel m, p = 1
-            xin = np.repeat(fixed[:, None, :], M, axis=1).reshape(B * M, FL, 1)
-            din = np.ascontiguousarray(np.swapaxes(xad, 1, 2)).reshape(B * M, FL)
-            e_bm, w_bm = self.bm._eng.fdaf_update(xin, din)
-            self.bm._w = w_bm.astype(np.float64)
-            bm_n = np.ascontiguousarray(np.swapaxes(e_bm.reshape(B, M, FL), 1, 2))                          # [B, FL, M]
-            bm_output[:, sl] = bm_n
-            fixed_dn = self._fix_prev                                                                       # :270
-            self._fix_prev = fixed
-            self.transform_fbf.stft(fixed_dn[:, :, None], L.LAYOUT_SAMPLES_CHANNELS)                        # :273 (advances the shared state)
-            pa = (1.0 - np.mean(pn, axis=1))[:, None]                                                       # :282
-            out_n, w = self.aic_filter._eng.fdaf_update(bm_n, fixed_dn, p=pa)                               # :278-284
-            self.aic_filter._w = w.astype(np.float64)
-            if postfilter:                                                                                  # :286-298
-                # the reference re-analyses the WHOLE bm_output array every block and keeps frame 0 (:288,291): that frame is
-                # [last hop of the array at the previous call | block 0 of this array] — constant within one process() call
-                if n <= 1:
-                    prev = self._bm_last if n == 0 else np.zeros_like(self._bm_last)
-                    self._tf_u.reset()
-                    self._stft_refs(self._tf_u, prev)
-                    U0 = self._stft_refs(self._tf_u, bm_output[:, :FL, :-1])[:, 0]
-                out_n = self._postfilter(out_n, U0)
-            fix[:, sl] = fixed; fix_d[:, sl] = fixed_dn
-            aligned[:, sl] = xa; aligned_d[:, sl] = xad
-            output[:, sl] = out_n
-        if postfilter and nblk > 0:
-            self._bm_last = bm_output[:, -FL:, :-1].astype(np.float32)
-        sq = (lambda a: a[0]) if single else (lambda a: a)
-        return sq(output), sq(p), sq(fix), sq(fix_d), sq(bm_output), sq(aligned), sq(aligned_d)
+            self.transform_fbf.stft(np.ascontiguousarray(fix_d[:, sl, None]), L.LAYOUT_SAMPLES_CHANNELS)   # :273 (advances the shared state)
+            # the reference re-analyses the WHOLE bm_output array every block and keeps frame 0 (:288,291): that frame is
+            # [last hop of the array at the previous call | block 0 of this array] — constant within one process() call
+            if n <= 1:
+                prev = self._bm_last if n == 0 else np.zeros_like(self._bm_last)
+                self._tf_u.reset()
+                self._stft_refs(self._tf_u, prev)
+                U0 = self._stft_refs(self._tf_u, bm_output[:, :FL, :-1])
+            res[:, sl] = self._postfilter(np.ascontiguousarray(out[:, sl]), U0)
+        self._bm_last = bm_output[:, -FL:, :-1].astype(np.float32)
+        return res

@@ -245,6 +245,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
 int ds_stft(ds_handle* h, const float* x, int layout, int n_samples, float* Y, int mem);
 int ds_istft(ds_handle* h, const float* Y, int n_frames, int n_channels, float* y, int mem);
 int ds_mcra_estimate(ds_handle* h, const float* Y, int is_complex, int n_frames, float* lambda_d, int mem);
+int ds_mcra_estimate_p(ds_handle* h, const float* Y, int is_complex, int n_frames, float* lambda_d, float* p, int mem);   /* + p [B][T][K] (mcra.p after each frame) */
 int ds_mcmcra_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* G, int mem);
 int ds_mcsppbase_estimate(ds_handle* h, const float* y, int n_frames, float* p, float* w, int mem);
 int ds_set_aux(ds_handle* h, const float* table, size_t n_floats);
