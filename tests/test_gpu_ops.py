@@ -434,3 +434,28 @@ def test_chain_handles_error_behaviour(ds):
         ch.process_device_seq(fake_x, 1, 4 * 512, 512, 256, 256, 2, fake_y, 512, 256, graph=1)
     with pytest.raises(DsError):
         ds.BatchEngine(L.ALGO_WPE_MVDR, 8, 1024, 512, batch=1, filter_len=3)   # C * N = 24 > 16 lanes per bin
+
+
+def test_chain_handles_long_stream_drift(ds):
+    """fp32 chains against the fp64 oracle over a long stream fed in chunks (the RLS recursions of WPE / SubbandRLS are the risk):
+    the relative error of every 100-frame segment stays under the north star's 1e-4 (measured 5e-6 .. 4e-5, flat over time)."""
+    from oracle import ds_oracle as O
+    from _cases import ANGLE, oracle_mic
+    M, nfft, T = 4, 512, 800
+    hop = nfft // 2
+    omic = oracle_mic(M, nfft)
+    x = O.synth_utterance(21, T * hop, omic)
+    ref = O.OracleWpeMvdrPostfilter(omic, nfft=nfft, hop=hop).process(x, ANGLE)
+    obj = ds.WpeMvdrPostfilter(ds.MicArray(arrayType="circular", r=omic.r, M=M, n_fft=nfft), frameLen=nfft, hop=hop)
+    y = np.concatenate([obj.process(x[:, a:a + 50 * hop], ANGLE)["data"] for a in range(0, T * hop, 50 * hop)])
+    n = 100 * hop
+    assert max(rms(y[i:i + n] - ref[i:i + n]) / rms(ref[i:i + n]) for i in range(0, len(ref), n)) < 1e-4
+    M, FL, T = 6, 256, 500
+    omic = oracle_mic(M, 512)
+    x = O.synth_utterance(22, T * FL, omic) * 0.1
+    with np.errstate(all="ignore"):
+        ref = O.OracleSubbandGSC(omic, frameLen=FL, rls_bm=True).process(x)[0]
+    sg = ds.SubbandGSC(ds.MicArray(arrayType="circular", r=omic.r, M=M, n_fft=512), frameLen=FL, bm_filter="rls")
+    y = np.concatenate([sg.process(x[:, a:a + 100 * FL])[0] for a in range(0, T * FL, 100 * FL)])
+    n = 100 * FL
+    assert max(rms(y[i:i + n] - ref[i:i + n]) / rms(ref[i:i + n]) for i in range(0, len(ref), n)) < 1e-4
