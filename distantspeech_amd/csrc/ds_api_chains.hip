@@ -66,12 +66,12 @@ int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long
 }
 
 // ---- DS_ALGO_SUBBAND_GSC: SubbandGSC.process (SubbandGSC.py:170-262) as a device-resident chain ------------------------------
-// buffers: 0 xn [B][M][n] (notched), 1 xa [B][M][n] (aligned), 2 fixed [B][n], 3 D c[B][T][K][M], 4 p [B][T][K], 5 PMWF scratch,
+// buffers: 0 xn [B][M][n] (notched), 1 xa [B][M][n] (aligned), 2 fixed [B][n], 3 D c[B][T][K][M], 4 p [B][T][K], 5 (unused),
 // 6 F c[B][T][K], 7 Dm c[B*M][T][K], 8 E c[B*M][T][K], 9 bm_td [B][M][n], 10 Xa c[B][T][K][M], 11 Dd c[B][T][K], 12 e2 c[B][T][K],
 // 13 F of the previous block c[B][K] (state), 14 fixed output of the previous block [B][hop] (state)
 int chain2_reserve(ds_handle* h, int n) {
     const size_t B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, T = n / h->cfg.hop, hop = h->cfg.hop;
-    const size_t need[15] = {B * M * n * 4, B * M * n * 4, B * n * 4, B * T * K * M * 8, B * T * K * 4, B * T * K * M * 8, B * T * K * 8,
+    const size_t need[15] = {B * M * n * 4, B * M * n * 4, B * n * 4, B * T * K * M * 8, B * T * K * 4, 16, B * T * K * 8,
                              B * M * T * K * 8, B * M * T * K * 8, B * M * n * 4, B * T * K * M * 8, B * T * K * 8, B * T * K * 8,
                              B * K * 8, B * hop * 4};
     for (int i = 0; i < 15; ++i) {
@@ -143,7 +143,7 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         fe->td_cur ^= 1;
     }
     rc = chain_stft(h, h->sub[1], cb[1], n, cb[3]); if (rc) return rc;                                   // :204  D
-    DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[3], T, cb[4], cb[5], nullptr, nullptr, nullptr, DS_MEM_DEVICE));   // :208  p
+    DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[3], T, cb[4], nullptr, nullptr, nullptr, nullptr, DS_MEM_DEVICE));   // :208  p
     rc = chain_stft(h, h->sub[3], cb[2], n, cb[6]); if (rc) return rc;                                   // bm[m].transform_x: F
     rc = chain_stft(h, h->sub[4], cb[1], n, cb[7]); if (rc) return rc;                                   // bm[m].transform_d analysis: B*M channels
     if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[6], cb[7], T, cb[8], DS_MEM_DEVICE));

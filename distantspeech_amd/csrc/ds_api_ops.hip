@@ -182,7 +182,7 @@ int ds_set_aux(ds_handle* h, const float* table, size_t n_floats) {
 
 int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, float* w_pmwf, float* yout, float* phi_xx,
                       float* phi_vv_inv, int mem) {
-    if (!h || !y || !p_out || !w_pmwf) return fail(h, DS_EINVAL, "ds_mcspp_estimate: NULL argument");
+    if (!h || !y || !p_out) return fail(h, DS_EINVAL, "ds_mcspp_estimate: NULL argument");
     if (h->cfg.algo != DS_ALGO_MCSPP) return fail(h, DS_ESTATE, "ds_mcspp_estimate: handle was created for a different algo");
     if ((phi_xx == nullptr) != (phi_vv_inv == nullptr)) return fail(h, DS_EINVAL, "ds_mcspp_estimate: phi_xx and phi_vv_inv go together");
     if (h->aux_floats < (size_t)h->K) return fail(h, DS_ESTATE, "ds_mcspp_estimate: call ds_set_aux(h, Fn[K]) first");
@@ -191,7 +191,7 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, 
     int rc = set_device(h); if (rc) return rc;
     const size_t n = (size_t)h->cfg.batch * n_frames * h->K, M = h->cfg.n_mics;
     IoSpec io = {{y, nullptr, nullptr}, {n * M * 8, 0, 0}, {p_out, w_pmwf, yout, phi_xx, phi_vv_inv},
-                 {n * 4, n * M * 8, yout ? n * 8 : 0, phi_xx ? n * M * M * 8 : 0, phi_vv_inv ? n * M * M * 8 : 0}};
+                 {n * 4, w_pmwf ? n * M * 8 : 0, yout ? n * 8 : 0, phi_xx ? n * M * M * 8 : 0, phi_vv_inv ? n * M * M * 8 : 0}};
     const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
     const size_t nbt = (size_t)h->cfg.batch * n_frames;
@@ -205,7 +205,7 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, 
     DS_HIP(h, ds::launch_mcspp_qavg(h->dev_buf[3], h->dev_buf[3] + n, (int)nbt, h->K, h->stream));
     p.in1 = h->dev_buf[3]; p.in2 = h->dev_buf[3] + n; p.N = 9;
     p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
-    DS_HIP(h, ds::launch_binop(ds::OP_MCSPP, p, h->stream));
+    DS_HIP(h, ds::launch_binop((yout || phi_xx) ? ds::OP_MCSPP : ds::OP_MCSPP_LEAN, p, h->stream));
     for (int t = 0; t < n_frames; ++t) {
         if (h->op_frm != 0 && h->op_ell % 65 == 0) h->op_ell = 0;
         h->op_frm += 1; h->op_ell += 1;

@@ -15,7 +15,7 @@
 namespace ds {
 
 enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4, OP_MCSPPBASE = 5, OP_WPE = 6, OP_MCCDR = 7, OP_MCSPP = 8, OP_STEERING = 9,
-       OP_MVDRW = 10, OP_ADAPTIVE = 11 };
+       OP_MVDRW = 10, OP_ADAPTIVE = 11, OP_MCSPP_LEAN = 12 };   // LEAN: McSpp without the MVDR / matrix outputs (the SubbandGSC chain)
 
 struct OpParams {
     int B, K, KP, T;          // utterances, bins, padded plane length, frames in this call
@@ -709,7 +709,7 @@ DS_HD float mcspp_qavg(const float* gamma_frame, int fmin, int fmax) {
     return qsum / (float)(fmax - fmin);
 }
 
-template <int M> DS_HD void op_mcspp(const OpParams& p, int b, int k) {
+template <int M, bool LEAN = false> DS_HD void op_mcspp(const OpParams& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
     const int o0 = p.N;                                                            // state row offset of the McSpp part
     float yd[M], yo[2 * NO + 1], vd[M], vo[2 * NO + 1];
@@ -804,13 +804,16 @@ template <int M> DS_HD void op_mcspp(const OpParams& p, int b, int k) {
         const long long ob = fb + k;
         p.out0[ob] = pp;
         const float wsc = 1.0f / (10.0f + xi);                                     // compute_pmwf_weight beta = 10 :283
+        if (p.out1) {
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-            cf acc = mk(0.0f, 0.0f);
+            for (int i = 0; i < M; ++i) {
+                cf acc = mk(0.0f, 0.0f);
 #pragma unroll
-            for (int j = 0; j < M; ++j) acc = cfma(acc, inv[i][j], Pxx[j][0]);
-            p.out1[2 * (ob * M + i)] = acc.x * wsc; p.out1[2 * (ob * M + i) + 1] = acc.y * wsc;
+                for (int j = 0; j < M; ++j) acc = cfma(acc, inv[i][j], Pxx[j][0]);
+                p.out1[2 * (ob * M + i)] = acc.x * wsc; p.out1[2 * (ob * M + i) + 1] = acc.y * wsc;
+            }
         }
+        if constexpr (!LEAN) {
         if (p.out3) {
 #pragma unroll
             for (int i = 0; i < M; ++i)
@@ -829,6 +832,7 @@ template <int M> DS_HD void op_mcspp(const OpParams& p, int b, int k) {
 #pragma unroll
             for (int m = 0; m < M; ++m) Y = cfmac(Y, Z[m], w[m]);
             p.out2[2 * ob] = Y.x; p.out2[2 * ob + 1] = Y.y;
+        }
         }
         frm += 1;
     }
@@ -923,17 +927,18 @@ template <int OP, int M> DS_HD void run_op_t(const OpParams& p, int b, int k) {
     else if constexpr (OP == OP_MCMCRA) op_mcmcra<M>(p, b, k);
     else if constexpr (OP == OP_MCSPPBASE) op_mcsppbase<M>(p, b, k);
     else if constexpr (OP == OP_MCSPP) op_mcspp<M>(p, b, k);
+    else if constexpr (OP == OP_MCSPP_LEAN) op_mcspp<M, true>(p, b, k);
     else if constexpr (OP == OP_STEERING) op_steering<M>(p, b, k);
     else if constexpr (OP == OP_MVDRW) op_mvdrw<M>(p, b, k);
     else if constexpr (OP == OP_ADAPTIVE) op_adaptive<M>(p, b, k);
 }
 
-inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_MCSPP || op == OP_STEERING || op == OP_MVDRW || op == OP_ADAPTIVE; }
+inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_MCSPP || op == OP_STEERING || op == OP_MVDRW || op == OP_ADAPTIVE || op == OP_MCSPP_LEAN; }
 
 // is (op, M) a supported combination?  (matrix operators: M in {2, 4, 6, 8}; McSpp / steering / mvdr weight: {2, 4, 6})
 inline bool op_supported(int op, int M) {
     if (op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_ADAPTIVE) return M == 2 || M == 4 || M == 6 || M == 8;
-    if (op == OP_MCSPP || op == OP_STEERING || op == OP_MVDRW) return M == 2 || M == 4 || M == 6;
+    if (op == OP_MCSPP || op == OP_MCSPP_LEAN || op == OP_STEERING || op == OP_MVDRW) return M == 2 || M == 4 || M == 6;
     return true;
 }
 
@@ -942,7 +947,7 @@ inline bool op_supported(int op, int M) {
 #define DS_FOR_EACH_OP(X) \
     X(OP_MCRA, 1) X(OP_OMLSA, 1) X(OP_SUBLMS, 1) X(OP_SUBRLS, 1) X(OP_MCCDR, 1) \
     DS_OP_M_LIST(X, OP_MCMCRA) DS_OP_M_LIST(X, OP_MCSPPBASE) DS_OP_M_LIST(X, OP_ADAPTIVE) \
-    DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_STEERING) DS_OP_M3_LIST(X, OP_MVDRW)
+    DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_MCSPP_LEAN) DS_OP_M3_LIST(X, OP_STEERING) DS_OP_M3_LIST(X, OP_MVDRW)
 
 // runtime dispatch for the serial CPU run in tests/emul (the GPU launches one specialised kernel per (OP, M))
 inline void run_op(int op, const OpParams& p, int b, int k) {

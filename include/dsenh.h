@@ -217,7 +217,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
  *   ds_mcra_estimate   Y [B][T][K] power (or complex if is_complex) -> lambda_d [B][T][K]
  *   ds_mcmcra_estimate y complex [B][T][K][M] -> p, G [B][T][K]
  *   ds_mcsppbase_estimate y complex [B][T][K][M] -> p [B][T][K], w complex [B][T][K][M] (PMWF weights)
- *   ds_mcspp_estimate  y complex [B][T][K][M] -> p [B][T][K], w_pmwf complex [B][T][K][M]; optional (NULL to skip):
+ *   ds_mcspp_estimate  y complex [B][T][K][M] -> p [B][T][K]; optional (NULL to skip): w_pmwf complex [B][T][K][M],
  *                      yout complex [B][T][K] = the notebook's online MVDR output (steering(Phi_xx) -> compute_mvdr_weight
  *                      -> sum conj(w) y, example/mvdr.ipynb cell 4), phi_xx / phi_vv_inv complex [B][T][K][M][M].
  *                      Needs ds_set_aux(h, Fn[K]) first: diffuse coherence of microphones 1,2 (mccdr.py:141).
