@@ -626,7 +626,15 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
             if (tid + i * NT < NV4) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                // the input stream is read once: non-temporal, so that it does not evict state lines on their way in / out
+                // (measured +4..5 % at B = 1024, one hop per call; neutral in the chunked regime)
+                typedef float f4_t __attribute__((ext_vector_type(4)));
+                const f4_t q = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(r.xp[i]));
+                r.pre[i].x = q.x; r.pre[i].y = q.y; r.pre[i].z = q.z; r.pre[i].w = q.w;
+#else
                 r.pre[i] = *r.xp[i];
+#endif
                 r.xp[i] += step;
             }
         }
@@ -807,7 +815,13 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     sh.tail[2 * i] = sh.tb.win[HOP + 2 * i] * (z2.x * sc);
                     sh.tail[2 * i + 1] = sh.tb.win[HOP + 2 * i + 1] * (z2.y * sc);
                     float* dst = p.y + yb + (long long)t * HOP + 2 * i;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    typedef float f2_t __attribute__((ext_vector_type(2)));
+                    f2_t o; o.x = o0; o.y = o1;
+                    __builtin_nontemporal_store(o, reinterpret_cast<f2_t*>(dst));
+#else
                     dst[0] = o0; dst[1] = o1;
+#endif
                 }
             });
             old_half = new_half;
