@@ -64,6 +64,7 @@ extern "C" {
 #define DS_ALGO_OMLSA 6      /* NsOmlsaMulti.estimation              noise_estimation/omlsa_multi.py:73-156 */
 #define DS_ALGO_SUBLMS 7     /* SubbandLMS (n_mics=1) / SubbandLmsMc (n_mics=C) .update   adaptivefilter/SubbandLMS.py, SubbandLmsMc.py */
 #define DS_ALGO_SUBRLS 8     /* SubbandRLS.update                    adaptivefilter/SubbandRLS.py:44-71 */
+#define DS_ALGO_MCSPPBASE 9  /* McSppBase.estimation + PMWF weights  noise_estimation/mcspp_base.py:220-324 */
 #define DS_ALGO_WPE 10       /* Wpe.update frequency-domain core (RLS-WPE on the STFT grid)  dereverberation/awpe.py:129-192 */
 #define DS_ALGO_MCSPP 11     /* McSpp.estimation (McCDR prior) + fused steering/MVDR   noise_estimation/mcspp.py:244-305, mccdr.py:122-177 */
 #define DS_ALGO_LINALG 12    /* stateless per-bin helpers: steering(), compute_mvdr_weight()   beamformer/beamformer.py:10-31,133-155 */
@@ -75,16 +76,15 @@ extern "C" {
                                  (beamformer/gsc_aic.py:53-108); nfft = 2 * filter_len in {128,256,512,1024}, n_mics = input channels <= 8 */
 #define DS_ALGO_ADAPTIVE_FRAMES 17 /* adaptivebeamfomer's frame loop on STFT frames (adaptivebeamformer.py:69-120): the per-bin program of
                                      DS_ALGO_ADAPTIVE as a frame-level operator, with an optional post-filter gain input */
-#define DS_ALGO_WPE_MVDR 18    /* BASELINE config 4 as ONE handle behind ds_process / ds_process_device: STFT -> WPE (awpe.py:152-189, all channels,
-                                 `filter_len` taps, `wpe_delay`-frame prediction delay = ds_config.mcra_L field is NOT reused: see ds_config.filter_len /
-                                 DS_PARAM_WPE_DELAY) -> McMcra gain (mc_mcra.py:179-224) -> adaptive MVDR frame loop (adaptivebeamformer.py:69-120)
-                                 x gain -> ISTFT; device-resident between the stages, all on the handle's stream */
+#define DS_ALGO_WPE_MVDR 18    /* BASELINE config 4 as ONE handle behind ds_process / ds_process_device: STFT -> RLS-WPE on all channels
+                                 (awpe.py:152-189; ds_config.filter_len taps, rls_lambda forgetting factor, prediction delay DS_PARAM_WPE_DELAY
+                                 frames, default 4) -> McMcra gain (mc_mcra.py:179-224) -> adaptive MVDR frame loop (adaptivebeamformer.py:69-120)
+                                 x gain -> ISTFT; device-resident between the stages, all on the handle's stream; n_mics * filter_len <= 16 */
 #define DS_ALGO_SUBBAND_GSC 19 /* SubbandGSC.process (beamformer/SubbandGSC.py:170-262; BASELINE config 5 with rls_lambda > 0) as ONE handle:
                                  DC notch -> TimeAlignment FIR bank + mean beamformer -> STFT -> McSpp -> M adaptive blocking filters (one
                                  batched subband LMS, or RLS when ds_config.rls_lambda > 0) -> ISTFT/STFT -> multichannel subband-LMS canceller
                                  -> ISTFT, device-resident between the stages; nfft = 2 * frameLen, hop = frameLen, n_mics in {2,4,6},
                                  filter_len taps (0 -> 2).  Needs ds_chain_set_aux() for the FIR bank and the McCDR coherence first */
-#define DS_ALGO_MCSPPBASE 9  /* McSppBase.estimation + PMWF weights  noise_estimation/mcspp_base.py:220-324 */
 
 /* `mem` argument of the frame-level entry points */
 #define DS_MEM_HOST 0
