@@ -248,7 +248,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     for (int i = 0; i < 10; ++i) { h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0; }
     h->aux_floats = 0;
     h->tdf_w = h->tdf_buf = h->tdf_P = nullptr;
-    h->x_fan = 1; h->p_complement = 0;
+    h->x_fan = 1; h->p_complement = 0; h->d_interleaved = 0; h->d_prev = nullptr;
     h->fdaf_kind = DS_FDAF_PLAIN; h->fdaf_constrain = 1; h->fdaf_non_causal = 0; h->fdaf_weight_norm = 0;
     for (int i = 0; i < 10; ++i) h->sub[i] = nullptr;
     for (int i = 0; i < 16; ++i) { h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0; }
@@ -344,7 +344,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             (void)hipStreamDestroy(h->sub[i]->stream);
             h->sub[i]->stream = h->stream; h->sub[i]->owns_stream = false;
         }
-        h->sub[5]->x_fan = M;                 // the M blocking filters of an utterance share its fixed-beamformer spectrum and p
+        h->sub[5]->x_fan = M;                 // the M blocking filters of an utterance share its fixed-beamformer spectrum and p ...
+        h->sub[5]->d_interleaved = 1;         // ... and take their desired signals straight from the M-channel STFT of the aligned channels
         h->sub[7]->p_complement = 1;          // SubbandGSC.py:232: p = 1 - p
     }
     *out = h;
@@ -765,8 +766,27 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
     return DS_OK;
 }
 
+// state kept outside the common buffers: the front end's notch memories and FIR history, the sample-wise filters' weights / buffer / P
+struct ExtraState { void* ptr; size_t bytes; };
+static int extra_state(const ds_handle* h, ExtraState out[3]) {
+    int n = 0;
+    const size_t B = h->cfg.batch, M = h->cfg.n_mics, Lf = h->cfg.filter_len;
+    if (h->cfg.algo == DS_ALGO_FRONTEND) {
+        out[n++] = {h->td_mem, B * M * 2 * sizeof(float)};
+        if (h->td_L > 1) out[n++] = {h->td_cache[h->td_cur], B * (size_t)(h->td_L - 1) * M * sizeof(float)};
+    }
+    if (h->tdf_w) {
+        out[n++] = {h->tdf_w, B * Lf * sizeof(float)};
+        out[n++] = {h->tdf_buf, B * Lf * sizeof(float)};
+        if (h->tdf_P) out[n++] = {h->tdf_P, B * Lf * Lf * sizeof(float)};
+    }
+    return n;
+}
 static size_t own_state_bytes(const ds_handle* h) {
-    return bins_bytes(h) + tail_in_bytes(h) + tail_out_bytes(h) + counters_bytes(h) + opst_bytes(h) + 4 * sizeof(int);
+    ExtraState ex[3];
+    size_t n = bins_bytes(h) + tail_in_bytes(h) + tail_out_bytes(h) + counters_bytes(h) + opst_bytes(h) + 4 * sizeof(int);
+    for (int i = 0, k = extra_state(h, ex); i < k; ++i) n += ex[i].bytes;
+    return n;
 }
 static size_t chain_hist_bytes(const ds_handle* h) {
     if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) return (size_t)h->cfg.batch * (h->K * 8 + h->cfg.hop * 4);
@@ -797,6 +817,10 @@ int ds_export_state(ds_handle* h, void* dst, size_t bytes) {
     const int uc[4] = {h->op_frm, h->op_ell, h->op_first, h->hist_cur};
     std::memcpy(d, uc, sizeof uc);
     d += sizeof uc;
+    {
+        ExtraState ex[3];
+        for (int i = 0, k = extra_state(h, ex); i < k; ++i) { DS_HIP(h, hipMemcpy(d, ex[i].ptr, ex[i].bytes, hipMemcpyDeviceToHost)); d += ex[i].bytes; }
+    }
     for (int i = 0; i < 10; ++i)
         if (h->sub[i]) {
             const size_t n = ds_state_bytes(h->sub[i]);
@@ -832,6 +856,10 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
     int uc[4];
     std::memcpy(uc, s, sizeof uc);
     s += sizeof uc;
+    {
+        ExtraState ex[3];
+        for (int i = 0, k = extra_state(h, ex); i < k; ++i) { DS_HIP(h, hipMemcpy(ex[i].ptr, s, ex[i].bytes, hipMemcpyHostToDevice)); s += ex[i].bytes; }
+    }
     h->op_frm = uc[0]; h->op_ell = uc[1]; h->op_first = uc[2]; h->hist_cur = uc[3];
     for (int i = 0; i < 10; ++i)
         if (h->sub[i]) {

@@ -67,12 +67,12 @@ int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long
 
 // ---- DS_ALGO_SUBBAND_GSC: SubbandGSC.process (SubbandGSC.py:170-262) as a device-resident chain ------------------------------
 // buffers: 0 xn [B][M][n] (notched), 1 xa [B][M][n] (aligned), 2 fixed [B][n], 3 D c[B][T][K][M], 4 p [B][T][K], 5 (unused),
-// 6 F c[B][T][K], 7 Dm c[B*M][T][K], 8 E c[B*M][T][K], 9 bm_td [B][M][n], 10 Xa c[B][T][K][M], 11 Dd c[B][T][K], 12 e2 c[B][T][K],
+// 6 F c[B][T][K], 7 (unused), 8 E c[B*M][T][K], 9 bm_td [B][M][n], 10 Xa c[B][T][K][M], 11 (unused), 12 e2 c[B][T][K],
 // 13 F of the previous block c[B][K] (state), 14 fixed output of the previous block [B][hop] (state)
 int chain2_reserve(ds_handle* h, int n) {
     const size_t B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, T = n / h->cfg.hop, hop = h->cfg.hop;
     const size_t need[15] = {B * M * n * 4, B * M * n * 4, B * n * 4, B * T * K * M * 8, B * T * K * 4, 16, B * T * K * 8,
-                             B * M * T * K * 8, B * M * T * K * 8, B * M * n * 4, B * T * K * M * 8, B * T * K * 8, B * T * K * 8,
+                             16, B * M * T * K * 8, B * M * n * 4, B * T * K * M * 8, 16, B * T * K * 8,
                              B * K * 8, B * hop * 4};
     for (int i = 0; i < 15; ++i) {
         if (need[i] <= h->chain_bytes[i]) continue;
@@ -145,18 +145,16 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     rc = chain_stft(h, h->sub[1], cb[1], n, cb[3]); if (rc) return rc;                                   // :204  D
     DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[3], T, cb[4], nullptr, nullptr, nullptr, nullptr, DS_MEM_DEVICE));   // :208  p
     rc = chain_stft(h, h->sub[3], cb[2], n, cb[6]); if (rc) return rc;                                   // bm[m].transform_x: F
-    rc = chain_stft(h, h->sub[4], cb[1], n, cb[7]); if (rc) return rc;                                   // bm[m].transform_d analysis: B*M channels
-    if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[6], cb[7], T, cb[8], DS_MEM_DEVICE));
-    else DS_SUB(5, ds_sublms_update(h->sub[5], cb[6], cb[7], cb[4], T, cb[8], DS_MEM_DEVICE));           // :217-223
+    // :217-223 the M blocking filters: reference input F (shared), desired signal = channel m of D (bm[m].transform_d's analysis of the
+    // aligned channel is the same spectrum), update probability p
+    if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[6], cb[3], T, cb[8], DS_MEM_DEVICE));
+    else DS_SUB(5, ds_sublms_update(h->sub[5], cb[6], cb[3], cb[4], T, cb[8], DS_MEM_DEVICE));
     rc = chain_istft(h, h->sub[4], cb[8], T, cb[9], n); if (rc) return rc;                               // bm outputs, [B*M][n] = [B][M][n]
     rc = chain_stft(h, h->sub[6], cb[9], n, cb[10]); if (rc) return rc;                                  // :230-234  aic transform_x
-    {   // :226 delay_fbf: the canceller's desired signal is the fixed output one block late = F shifted by one frame
-        const size_t fr = (size_t)K * 8;
-        if (T > 1) DS_HIP(h, hipMemcpy2DAsync((char*)cb[11] + fr, T * fr, cb[6], T * fr, (T - 1) * fr, B, hipMemcpyDeviceToDevice, h->stream));
-        DS_HIP(h, hipMemcpy2DAsync(cb[11], T * fr, cb[13], fr, fr, B, hipMemcpyDeviceToDevice, h->stream));
-        DS_HIP(h, hipMemcpy2DAsync(cb[13], fr, (char*)cb[6] + (T - 1) * fr, T * fr, fr, B, hipMemcpyDeviceToDevice, h->stream));
-    }
-    DS_SUB(7, ds_sublms_update(h->sub[7], cb[10], cb[11], cb[4], T, cb[12], DS_MEM_DEVICE));
+    // :226 delay_fbf: the canceller's desired signal is the fixed output one block late = F one frame late; the operator keeps the
+    // carried frame in cb[13] itself
+    h->sub[7]->d_prev = cb[13];
+    DS_SUB(7, ds_sublms_update(h->sub[7], cb[10], cb[6], cb[4], T, cb[12], DS_MEM_DEVICE));
     rc = chain_istft(h, h->sub[8], cb[12], T, y_dev, y_bstride); if (rc) return rc;
     {   // fix_output = fixed beamformer output delayed by one block (:226,255); the carried block is state either way
         const size_t blk = (size_t)hop * 4, row = (size_t)n * 4;

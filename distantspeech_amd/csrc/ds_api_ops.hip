@@ -64,7 +64,7 @@ int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int me
     p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = h->mcra_L; p.first_frame = h->op_first;
     p.in_complex = is_complex; p.has_p = has_p; p.norm = h->norm;
     p.mu = h->filt_mu; p.alpha = h->filt_alpha; p.reg = 1e-4f; p.lam = h->rls_lambda;
-    p.x_fan = h->x_fan > 0 ? h->x_fan : 1; p.p_complement = h->p_complement;
+    p.x_fan = h->x_fan > 0 ? h->x_fan : 1; p.p_complement = h->p_complement; p.d_interleaved = h->d_interleaved; p.d_prev = h->d_prev;
     p.steer = h->steer; p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
     p.method = h->method; p.alpha_v = h->alpha_v; p.gate = h->gate; p.diag = h->diag;
     DS_HIP(h, ds::launch_binop(h->op, p, h->stream));

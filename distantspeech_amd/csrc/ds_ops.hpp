@@ -40,6 +40,10 @@ struct OpParams {
     int x_fan;                // subband LMS / RLS: instances b share the reference input (and p) of utterance b / x_fan (SubbandGSC's M
                               // blocking filters as one batch of B * M single-channel filters); 1 = one input per instance
     int p_complement;         // subband LMS: use 1 - p (SubbandGSC.py:232 passes p = 1 - p to the canceller)
+    int d_interleaved;        // subband LMS / RLS with x_fan > 1: the desired signals of the x_fan instances of an utterance are the channels of
+                              // one multichannel spectrum, in1 = complex [B / x_fan][T][K][x_fan] (SubbandGSC: the aligned-channel STFT)
+    float* d_prev;            // subband LMS: desired signal delayed by one frame (SubbandGSC.py:226 delay_fbf): frame t takes in1[t - 1], frame 0
+                              // takes d_prev complex [B][K], which the operator then replaces by the last frame of in1; null = no delay
     const cf* steer;          // OP_ADAPTIVE: steering vector a [K][M] (or [B][K][M] with steer_batch_stride)
     long long steer_batch_stride;
     int method;               // OP_ADAPTIVE: METHOD_SRC / DS / MVDR
@@ -200,6 +204,25 @@ DS_HD void op_omlsa(const OpParams& p, int b, int k) {
 // ------------------------------------------------------------------------------------------------
 DS_HD int sublms_nf(int N, int C) { return 4 * N * C + 1; }
 
+// desired-signal sample of instance b, frame t, bin k (see OpParams::d_interleaved / d_prev)
+DS_HD cf subband_d(const OpParams& p, int b, int t, int k) {
+    if (p.d_prev) {
+        if (t == 0) return mk(p.d_prev[2 * ((long long)b * p.K + k)], p.d_prev[2 * ((long long)b * p.K + k) + 1]);
+        t -= 1;
+    }
+    long long i;
+    if (p.d_interleaved) i = (((long long)(b / p.x_fan) * p.T + t) * p.K + k) * p.x_fan + b % p.x_fan;
+    else i = ((long long)b * p.T + t) * p.K + k;
+    return mk(p.in1[2 * i], p.in1[2 * i + 1]);
+}
+DS_HD void subband_d_carry(const OpParams& p, int b, int k) {        // after the T frames: keep the last frame of in1 for the next call
+    if (p.d_prev && p.T > 0) {
+        const long long i = ((long long)b * p.T + p.T - 1) * p.K + k;
+        p.d_prev[2 * ((long long)b * p.K + k)] = p.in1[2 * i];
+        p.d_prev[2 * ((long long)b * p.K + k) + 1] = p.in1[2 * i + 1];
+    }
+}
+
 DS_HD void op_sublms_generic(const OpParams& p, int b, int k) {
     const int N = p.N, C = p.M, NC2 = 2 * N * C;
     for (int t = 0; t < p.T; ++t) {
@@ -222,7 +245,7 @@ DS_HD void op_sublms_generic(const OpParams& p, int b, int k) {
         }
         float pk = p.has_p ? p.in2[fx] : 1.0f;
         if (p.p_complement) pk = 1.0f - pk;
-        const cf d = mk(p.in1[2 * fb], p.in1[2 * fb + 1]);
+        const cf d = subband_d(p, b, t, k);
         const cf err = mk(fma_(-out.x, pk, d.x), fma_(-out.y, pk, d.y));      // d - out * p  (SubbandLMS.py:66-68)
         float scale = 1.0f;
         if (p.norm) {
@@ -240,6 +263,7 @@ DS_HD void op_sublms_generic(const OpParams& p, int b, int k) {
         }
         p.out0[2 * fb] = err.x; p.out0[2 * fb + 1] = err.y;
     }
+    subband_d_carry(p, b, k);
 }
 
 // the same recursion with W, the tap buffer and P held in registers for the T frames of the call (state read once, written once)
@@ -267,7 +291,7 @@ template <int N, int C> DS_HD void op_sublms_t(const OpParams& p, int b, int k) 
         for (int i = 0; i < NC; ++i) { out = cfmac(out, X[i], W[i]); pw += cabs2(X[i]); }
         float pk = p.has_p ? p.in2[fx] : 1.0f;
         if (p.p_complement) pk = 1.0f - pk;
-        const cf d = mk(p.in1[2 * fb], p.in1[2 * fb + 1]);
+        const cf d = subband_d(p, b, t, k);
         const cf err = mk(fma_(-out.x, pk, d.x), fma_(-out.y, pk, d.y));
         float scale = 1.0f;
         if (p.norm) {
@@ -282,6 +306,7 @@ template <int N, int C> DS_HD void op_sublms_t(const OpParams& p, int b, int k) 
         }
         p.out0[2 * fb] = err.x; p.out0[2 * fb + 1] = err.y;
     }
+    subband_d_carry(p, b, k);
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
         st_at(p, b, 2 * i, k) = W[i].x; st_at(p, b, 2 * i + 1, k) = W[i].y;
@@ -331,7 +356,7 @@ template <int N> DS_HD void op_subrls_t(const OpParams& p, int b, int k) {
         cf out = mk(0.0f, 0.0f);
 #pragma unroll
         for (int i = 0; i < N; ++i) out = cfmac(out, X[i], W[i]);
-        const cf d = mk(p.in1[2 * fb], p.in1[2 * fb + 1]);
+        const cf d = subband_d(p, b, t, k);
         const cf err = csub(d, out);                                             // SubbandRLS.py:52
         cf den = mk(p.lam, 0.0f);
 #pragma unroll
@@ -355,6 +380,7 @@ template <int N> DS_HD void op_subrls_t(const OpParams& p, int b, int k) {
         }
         p.out0[2 * fb] = err.x; p.out0[2 * fb + 1] = err.y;
     }
+    subband_d_carry(p, b, k);
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         st_at(p, b, 2 * i, k) = W[i].x; st_at(p, b, 2 * i + 1, k) = W[i].y;

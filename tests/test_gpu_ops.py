@@ -247,6 +247,16 @@ def test_subband_gsc(ds, name):
     assert rms(out - g["output"]) < 5e-2 * rms(g["output"])
     with pytest.raises(NotImplementedError):
         sg.process(x[:, :FL], postfilter=True)
+    # checkpoint / resume of the chain: every stage's state plus the two block delays
+    a = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], bm_filter="rls" if rls else "lms")
+    a.process(x[:, : 10 * FL])
+    blob = a._eng.export_state()
+    tail = a.process(x[:, 10 * FL: 30 * FL])
+    b2 = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], bm_filter="rls" if rls else "lms")
+    b2.process(x[:, 5 * FL: 9 * FL])
+    b2._eng.import_state(blob)
+    again = b2.process(x[:, 10 * FL: 30 * FL])
+    assert all(np.array_equal(u, v) for u, v in zip(tail, again))
 
 
 def test_frontend_mirrors(ds):
