@@ -469,3 +469,40 @@ def test_chain_handles_long_stream_drift(ds):
     y = np.concatenate([sg.process(x[:, a:a + 100 * FL])[0] for a in range(0, T * FL, 100 * FL)])
     n = 100 * FL
     assert max(rms(y[i:i + n] - ref[i:i + n]) / rms(ref[i:i + n]) for i in range(0, len(ref), n)) < 1e-4
+
+
+def test_checkpoint_of_block_level_objects(ds):
+    """export_state / import_state cover the state that lives outside the per-bin planes: the front end's notch memories and FIR
+    history, the sample-wise filters' weights / buffer / P, the FDAF blocks."""
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(7)
+
+    def roundtrip(make, step):
+        a = make(); step(a, 0)
+        blob = a.export_state()
+        ref = step(a, 1)
+        b = make(); step(b, 2)                          # a differently-evolved object of the same configuration
+        b.import_state(blob)
+        got = step(b, 1)
+        assert all(np.array_equal(u, v) for u, v in zip(ref, got))
+
+    xs = [rng.standard_normal((2, 4, 512)).astype(np.float32) * 0.1 for _ in range(3)]
+    coef = rng.standard_normal((30, 4)).astype(np.float32) * 0.1
+
+    def make_fe():
+        e = ds.BatchEngine(L.ALGO_FRONTEND, 4, 512, batch=2, filt_alpha=0.98)
+        e.set_aux(coef)
+        return e
+    roundtrip(make_fe, lambda e, i: (e.dcnotch(xs[i]),) + tuple(e.firbank(np.ascontiguousarray(np.swapaxes(xs[i], 1, 2)))))
+    x1 = [rng.standard_normal((2, 300)).astype(np.float32) * 0.3 for _ in range(3)]
+    d1 = [rng.standard_normal((2, 300)).astype(np.float32) * 0.3 for _ in range(3)]
+    roundtrip(lambda: ds.BatchEngine(L.ALGO_TDNLMS, 1, 512, batch=2, filter_len=48, filt_mu=0.1), lambda e, i: (e.tdfilter_update(x1[i], d1[i]),))
+    roundtrip(lambda: ds.BatchEngine(L.ALGO_TDRLS, 1, 512, batch=2, filter_len=16), lambda e, i: (e.tdfilter_update(x1[i], d1[i]),))
+    xf = [rng.standard_normal((2, 512, 3)).astype(np.float32) * 0.2 for _ in range(3)]
+    df = [rng.standard_normal((2, 512)).astype(np.float32) * 0.2 for _ in range(3)]
+
+    def make_fdaf():
+        e = ds.BatchEngine(L.ALGO_FDAF, 3, 256, batch=2, filt_mu=0.05, filt_alpha=0.9)
+        e.set_fdaf(L.FDAF_PLAIN, non_causal=True)
+        return e
+    roundtrip(make_fdaf, lambda e, i: e.fdaf_update(xf[i], df[i], fir_truncate=10))
