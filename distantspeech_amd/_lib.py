@@ -20,6 +20,7 @@ CHAIN_AUX_FIR, CHAIN_AUX_COHERENCE = 0, 1
 PARAM_WPE_DELAY = 13
 FDAF_PLAIN, FDAF_BM, FDAF_AIC = 0, 1, 2
 FDAF_P_NONE, FDAF_P_BLOCK, FDAF_P_BIN = 0, 1, 2
+FDAF_P_COMPLEMENT = 4
 PARAM_FDAF_KIND, PARAM_FDAF_CONSTRAIN, PARAM_FDAF_NON_CAUSAL, PARAM_FDAF_WEIGHT_NORM = 9, 10, 11, 12
 MEM_HOST, MEM_DEVICE = 0, 1
 METHOD_SRC, METHOD_DS, METHOD_MVDR, METHOD_TFGSC = 0, 1, 2, 3
@@ -55,7 +56,7 @@ EXPORTS = [
     "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_pcm16", "ds_process_device",
     "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcra_estimate_p", "ds_mcmcra_estimate", "ds_mcsppbase_estimate", "ds_set_aux", "ds_mcspp_estimate", "ds_steering",
     "ds_mvdr_weight", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process",
-    "ds_omlsa_estimate",
+    "ds_omlsa_estimate", "ds_omlsa_postfilter",
     "ds_sublms_update", "ds_subrls_update", "ds_wpe_update", "ds_synchronize",
     "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_export_state",
     "ds_import_state",
@@ -127,6 +128,8 @@ def load():
     lib.ds_mvdr_weight.argtypes = [vp, vp, vp, vp, ci]
     lib.ds_mcra_estimate_p.restype = ci
     lib.ds_mcra_estimate_p.argtypes = [vp, vp, ci, ci, vp, vp, ci]
+    lib.ds_omlsa_postfilter.restype = ci
+    lib.ds_omlsa_postfilter.argtypes = [vp, vp, vp, ci, vp, vp, ci]
     lib.ds_tdfilter_update.restype = ci
     lib.ds_tdfilter_update.argtypes = [vp, vp, vp, ci, cf_, vp, ci]
     lib.ds_chain_set_aux.restype = ci

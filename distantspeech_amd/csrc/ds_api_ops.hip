@@ -59,7 +59,7 @@ int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int me
     p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames;
     p.st = h->opst; p.NF = h->NF;
     p.in0 = din[0]; p.in1 = din[1]; p.in2 = din[2];
-    p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2];
+    p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
     p.M = h->cfg.n_mics; p.N = h->filter_len;
     p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = h->mcra_L; p.first_frame = h->op_first;
     p.in_complex = is_complex; p.has_p = has_p; p.norm = h->norm;
@@ -329,15 +329,16 @@ int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* pp
     if (!h || !x || !d || !err) return fail(h, DS_EINVAL, "ds_fdaf_update: NULL argument");
     if (h->cfg.algo != DS_ALGO_FDAF) return fail(h, DS_ESTATE, "ds_fdaf_update: handle is not a DS_ALGO_FDAF object");
     if (n_blocks < 0) return fail(h, DS_ESHAPE, "ds_fdaf_update: n_blocks < 0");
-    if (p_mode < DS_FDAF_P_NONE || p_mode > DS_FDAF_P_BIN || (p_mode != DS_FDAF_P_NONE && !pp))
+    const int p_kind = p_mode & 3;
+    if (p_mode < 0 || (p_mode & ~(3 | DS_FDAF_P_COMPLEMENT)) || p_kind > DS_FDAF_P_BIN || (p_kind != DS_FDAF_P_NONE && !pp))
         return fail(h, DS_EINVAL, "ds_fdaf_update: p_mode / p mismatch");
     const int L = h->cfg.nfft / 2, C = h->cfg.n_mics;
     if (fir_truncate > L) return fail(h, DS_ESHAPE, "ds_fdaf_update: fir_truncate > filter_len");
     if (n_blocks == 0) return DS_OK;
     int rc = set_device(h); if (rc) return rc;
     const size_t n = (size_t)h->cfg.batch * n_blocks * L;
-    const size_t pbytes = p_mode == DS_FDAF_P_NONE ? 0 : (size_t)h->cfg.batch * n_blocks * (p_mode == DS_FDAF_P_BIN ? h->K : 1) * 4;
-    IoSpec io = {{x, d, p_mode == DS_FDAF_P_NONE ? nullptr : pp}, {n * C * 4, n * 4, pbytes},
+    const size_t pbytes = p_kind == DS_FDAF_P_NONE ? 0 : (size_t)h->cfg.batch * n_blocks * (p_kind == DS_FDAF_P_BIN ? h->K : 1) * 4;
+    IoSpec io = {{x, d, p_kind == DS_FDAF_P_NONE ? nullptr : pp}, {n * C * 4, n * 4, pbytes},
                  {err, w_out, nullptr, nullptr, nullptr}, {n * 4, w_out ? (size_t)h->cfg.batch * L * C * 4 : 0, 0, 0, 0}};
     const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
@@ -345,7 +346,7 @@ int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* pp
     std::memset(&p, 0, sizeof p);
     p.B = h->cfg.batch; p.T = n_blocks; p.C = C;
     p.kind = h->fdaf_kind; p.constrain = h->fdaf_constrain; p.non_causal = h->fdaf_non_causal; p.weight_norm = h->fdaf_weight_norm;
-    p.trunc = fir_truncate < 0 ? -1 : fir_truncate; p.p_mode = p_mode;
+    p.trunc = fir_truncate < 0 ? -1 : fir_truncate; p.p_mode = p_mode & 3; p.p_complement = (p_mode & DS_FDAF_P_COMPLEMENT) ? 1 : 0;
     p.mu = h->filt_mu; p.alpha = h->filt_alpha;
     p.x = din[0]; p.d = din[1]; p.p = din[2]; p.err = dout[0]; p.w_out = w_out ? dout[1] : nullptr;
     p.state = h->opst; p.state_stride = (long long)h->NF * h->KP;
@@ -359,6 +360,31 @@ int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames
     const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
     IoSpec io = {{y, u, nullptr}, {n * 4, n * (h->cfg.n_mics - 1) * 4, 0}, {lambda_d, G, p}, {n * 4, n * 4, n * 4}};
     return run_binop(h, DS_ALGO_OMLSA, "ds_omlsa_estimate", n_frames, mem, io, 0, 0);
+}
+
+int ds_omlsa_postfilter(ds_handle* h, const float* Y, const float* U, int n_frames, float* G, float* Yout, int mem) {
+    if (!h || !Y || !U || !G || !Yout) return fail(h, DS_EINVAL, "ds_omlsa_postfilter: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
+    int rc = stage_reserve(h, 3, 2 * n * 4); if (rc) return rc;                 // lambda_d and p are not returned by this entry point
+    IoSpec io = {{Y, U, nullptr}, {n * 8, n * (h->cfg.n_mics - 1) * 8, 0}, {nullptr, G, nullptr, Yout, nullptr}, {0, n * 4, 0, n * 8, 0}};
+    if (h->cfg.algo != DS_ALGO_OMLSA) return fail(h, DS_ESTATE, "ds_omlsa_postfilter: handle was created for a different algo");
+    if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_omlsa_postfilter: n_frames < 0");
+    if (n_frames == 0) return DS_OK;
+    rc = set_device(h); if (rc) return rc;
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames; p.st = h->opst; p.NF = h->NF; p.M = h->cfg.n_mics;
+    p.in0 = din[0]; p.in1 = din[1]; p.out0 = h->dev_buf[3]; p.out1 = dout[1]; p.out2 = h->dev_buf[3] + n; p.out3 = dout[3];
+    p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = h->mcra_L; p.first_frame = h->op_first; p.in_complex = 1; p.x_fan = 1;
+    DS_HIP(h, ds::launch_binop(ds::OP_OMLSA, p, h->stream));
+    for (int t = 0; t < n_frames; ++t) {
+        if (h->op_frm != 0 && h->op_ell % h->mcra_L == 0) h->op_ell = 0;
+        h->op_frm += 1; h->op_ell += 1;
+    }
+    h->op_first = 0;
+    return io_end(h, mem, io, dout);
 }
 
 int ds_sublms_update(ds_handle* h, const float* x, const float* d, const float* p, int n_frames, float* err, int mem) {

@@ -19,6 +19,7 @@ struct FdafParams {
     int kind, constrain, non_causal, weight_norm;
     int trunc;                // fir_truncate, < 0 = None
     int p_mode;               // 0: p = 1, 1: one p per block [B][T], 2: per bin [B][T][K]
+    int p_complement;         // use 1 - p (TDGSC.py:154 hands the canceller p = 1 - p)
     float mu, alpha;
     const float* x;           // [B][T * HOP][C]
     const float* d;           // [B][T * HOP]
@@ -231,6 +232,7 @@ template <int NFFT, int CMAX> struct FdafEngine {
                 float pk = 1.0f;
                 if (p.p_mode == 1) pk = p.p[(long long)b * p.T + t];
                 else if (p.p_mode == 2) pk = p.p[((long long)b * p.T + t) * K + k];
+                if (p.p_complement) pk = 1.0f - pk;
                 return pk * two * p.mu;
             };
             ex.phase([&](int tid, Rg& r) {

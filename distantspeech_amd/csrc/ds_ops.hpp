@@ -118,8 +118,9 @@ template <int M> DS_HD void op_mcmcra(const OpParams& p, int b, int k) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// NsOmlsaMulti: in0 = y [B][T][K] (beam power), in1 = u [B][T][K][M-1] (reference powers);
-// out0 = lambda_d, out1 = G, out2 = p  [B][T][K].
+// NsOmlsaMulti: in0 = y [B][T][K] (beam power), in1 = u [B][T][K][M-1] (reference powers) — or, with in_complex, the complex
+// spectra themselves (|.|^2 formed here, TDGSC.py:162-163); out0 = lambda_d, out1 = G, out2 = p  [B][T][K]; with in_complex
+// optional out3 = Y * sqrt(G) complex [B][T][K], the post-filtered beam spectrum (TDGSC.py:166-168).
 // state floats: [0,5M) M MCRAs (beam first), then zeta_Y, zeta_U[M-1], lambda_d, gamma, G_H1, G, p, xi_hat, q_hat
 // ------------------------------------------------------------------------------------------------
 DS_HD int omlsa_nf(int M) { return 5 * M + (M - 1) + 8; }
@@ -133,8 +134,11 @@ DS_HD void op_omlsa(const OpParams& p, int b, int k) {
         const long long yb = ((long long)b * p.T + t) * K;
         const long long ub = yb * R;
         const bool reset = mcra_tick(frm, ell, p.L);
-        const float y0 = p.in0[yb + k];
-        const float ym = k > 0 ? p.in0[yb + k - 1] : 0.0f, yp = k < K - 1 ? p.in0[yb + k + 1] : 0.0f;
+        auto pw = [&](const float* src, long long i) {          // power of element i of a real-power or complex-spectrum array
+            return p.in_complex ? fma_(src[2 * i], src[2 * i], src[2 * i + 1] * src[2 * i + 1]) : src[i];
+        };
+        const float y0 = pw(p.in0, yb + k);
+        const float ym = k > 0 ? pw(p.in0, yb + k - 1) : 0.0f, yp = k < K - 1 ? pw(p.in0, yb + k + 1) : 0.0f;
         // M minima-controlled noise trackers (:83-85)
         float mc[5];
 #pragma unroll
@@ -145,9 +149,9 @@ DS_HD void op_omlsa(const OpParams& p, int b, int k) {
         const float MU_Y = mc[4];
         float zu_minus_mu_max = -3.0e38f;
         for (int ch = 0; ch < R; ++ch) {
-            const float u0 = p.in1[ub + (long long)k * R + ch];
-            const float um = k > 0 ? p.in1[ub + (long long)(k - 1) * R + ch] : 0.0f;
-            const float up = k < K - 1 ? p.in1[ub + (long long)(k + 1) * R + ch] : 0.0f;
+            const float u0 = pw(p.in1, ub + (long long)k * R + ch);
+            const float um = k > 0 ? pw(p.in1, ub + (long long)(k - 1) * R + ch) : 0.0f;
+            const float up = k < K - 1 ? pw(p.in1, ub + (long long)(k + 1) * R + ch) : 0.0f;
 #pragma unroll
             for (int f = 0; f < 5; ++f) mc[f] = st_at(p, b, 5 * (ch + 1) + f, k);
             mcra_bin(mc, k, K, um, u0, up, frm, reset, p.L);
@@ -166,6 +170,10 @@ DS_HD void op_omlsa(const OpParams& p, int b, int k) {
             st_at(p, b, o_s + 0, k) = y0;
             st_at(p, b, o_zy, k) = y0;
             p.out0[ob] = y0; p.out1[ob] = st_at(p, b, o_s + 3, k); p.out2[ob] = st_at(p, b, o_s + 4, k);
+            if (p.in_complex && p.out3) {
+                const float sg = sqrtf(st_at(p, b, o_s + 3, k));
+                p.out3[2 * ob] = p.in0[2 * ob] * sg; p.out3[2 * ob + 1] = p.in0[2 * ob + 1] * sg;
+            }
             continue;
         }
         const float zy = fma_(0.8f, st_at(p, b, o_zy, k), (float)(1.0 - 0.8) * fma_(yp, 0.25f, fma_(y0, 0.5f, ym * 0.25f)));   // :98
@@ -194,6 +202,10 @@ DS_HD void op_omlsa(const OpParams& p, int b, int k) {
         st_at(p, b, o_s + 0, k) = lam; st_at(p, b, o_s + 1, k) = gamma; st_at(p, b, o_s + 2, k) = gh1;
         st_at(p, b, o_s + 3, k) = G; st_at(p, b, o_s + 4, k) = pp; st_at(p, b, o_s + 5, k) = xi; st_at(p, b, o_s + 6, k) = q;
         p.out0[ob] = lam; p.out1[ob] = G; p.out2[ob] = pp;
+        if (p.in_complex && p.out3) {
+            const float sg = sqrtf(G);
+            p.out3[2 * ob] = p.in0[2 * ob] * sg; p.out3[2 * ob + 1] = p.in0[2 * ob + 1] * sg;
+        }
     }
 }
 

@@ -254,7 +254,7 @@ class BatchEngine:
                        (L.PARAM_FDAF_WEIGHT_NORM, weight_norm)):
             L.check(self._lib.ds_set_param_i(self._h, pid, int(v)), self._h)
 
-    def fdaf_update(self, x, d, p=None, fir_truncate=None, want_w=True):
+    def fdaf_update(self, x, d, p=None, fir_truncate=None, want_w=True, p_complement=False):
         """x [B, T*L, C], d [B, T*L] samples (L = nfft/2), p None | [B, T] | [B, T, K] -> (err [B, T*L], w [B, L, C] | None):
         T successive block updates in one launch."""
         x = np.ascontiguousarray(x, dtype=np.float32)
@@ -273,6 +273,8 @@ class BatchEngine:
                 pm = L.FDAF_P_BIN
             else:
                 raise ValueError("fdaf_update: p must be [B, T] or [B, T, K=%d], got %s" % (self.K, pp.shape))
+        if p_complement:
+            pm |= L.FDAF_P_COMPLEMENT                    # the kernel forms 1 - p
         err = np.empty_like(d)
         w = np.empty((self.batch, Lb, self.M), dtype=np.float32) if want_w else None
         L.check(self._lib.ds_fdaf_update(self._h, self._p(x), self._p(d), self._p(pp) if pp is not None else None, pm, T,
@@ -326,6 +328,15 @@ class BatchEngine:
         L.check(self._lib.ds_omlsa_estimate(self._h, self._p(y), self._p(u), int(y.shape[1]), self._p(lam), self._p(G),
                                             self._p(p), L.MEM_HOST), self._h)
         return lam, G, p
+
+    def omlsa_postfilter(self, Y, U):
+        """Y complex [B, T, K] beam spectrum, U complex [B, T, K, M-1] reference spectra -> (G [B, T, K], Y * sqrt(G) complex [B, T, K])."""
+        Y = np.ascontiguousarray(Y, dtype=np.complex64)
+        U = np.ascontiguousarray(U, dtype=np.complex64)
+        G = np.empty(Y.shape, dtype=np.float32)
+        Yout = np.empty(Y.shape, dtype=np.complex64)
+        L.check(self._lib.ds_omlsa_postfilter(self._h, self._p(Y), self._p(U), int(Y.shape[1]), self._p(G), self._p(Yout), L.MEM_HOST), self._h)
+        return G, Yout
 
     def sublms_update(self, x, d, p=None):
         """x complex [B, T, K, C], d complex [B, T, K], p [B, T, K] or None -> err complex [B, T, K]."""

@@ -8,8 +8,8 @@
 Both structures are feed-forward from stage to stage (only state crosses blocks), so process() calls every operator ONCE with all
 the blocks of the call: ds_dcnotch, ds_firbank_bm (FIR bank + channel mean + pairwise differences), ds_stft, ds_mcra_estimate_p,
 ds_fdaf_update (all FFTs of a block inside one workgroup, the blocks walked in-kernel; FDGSC's M blocking filters are ONE batched
-launch), ds_omlsa_estimate, ds_istft.  This module sequences those calls, keeps the block delays (pure buffering) and derives the
-adaptation-control values from the speech-presence matrix (1 - p, mean p, the FDGSC.py:248-255 threshold) where the reference does."""
+launch), ds_omlsa_postfilter (powers, gain and its application in-kernel), ds_istft.  This module sequences those calls, keeps the block delays (pure buffering) and derives the
+adaptation-control scalars of FDGSC from the speech-presence matrix (mean p, the FDGSC.py:248-255 threshold) where the reference does."""
 import numpy as np
 
 from . import _lib as L
@@ -46,12 +46,9 @@ class _BlockGSC(object):
         """OMLSA gain on the canceller output (TDGSC.py:158-170 / FDGSC.py:286-298): out_td [B, n], U complex [B, T, K, M-1]
         (or [B, 1, K, M-1], the same references for every frame) -> post-filtered [B, n]."""
         Y = self.transform_fbf.stft(out_td[:, :, None], L.LAYOUT_SAMPLES_CHANNELS)[:, :, :, 0]            # [B, T, K]
-        y_pow = Y.real.astype(np.float64) ** 2 + Y.imag.astype(np.float64) ** 2
-        u_pow = U.real.astype(np.float64) ** 2 + U.imag.astype(np.float64) ** 2
-        if u_pow.shape[1] != y_pow.shape[1]:
-            u_pow = np.broadcast_to(u_pow, (u_pow.shape[0], y_pow.shape[1]) + u_pow.shape[2:])
-        _, G, _ = self.omlsa_multi._eng.omlsa_estimate(y_pow, u_pow)
-        Y = Y * np.sqrt(G.astype(np.float64))
+        if U.shape[1] != Y.shape[1]:
+            U = np.broadcast_to(U, (U.shape[0], Y.shape[1]) + U.shape[2:])
+        _, Y = self.omlsa_multi._eng.omlsa_postfilter(Y, U)                      # powers, OMLSA gain and Y * sqrt(G) in the kernel
         return self.transform_fbf.istft(np.ascontiguousarray(Y[:, :, :, None]))[:, :, 0]
 
 
@@ -84,7 +81,7 @@ class TDGSC(_BlockGSC):
         xa, fixed, bm = self.time_alignment._eng.firbank(np.ascontiguousarray(x), want_bm=True)            # :143,149 all blocks
         D = self.transform.stft(fixed[:, :, None], L.LAYOUT_SAMPLES_CHANNELS)[:, :, :, 0]                   # :145  [B, T, K]
         p = self._spp(D)                                                                                    # :146-147
-        out, w = self.aic_filter._eng.fdaf_update(bm, fixed, p=1.0 - p, fir_truncate=30)                    # :152-156 -> :105
+        out, w = self.aic_filter._eng.fdaf_update(bm, fixed, p=p, fir_truncate=30, p_complement=True)       # :152-156 -> :105 (p = 1 - p)
         self.aic_filter._w = w.astype(np.float64)
         if postfilter:                                                                                      # :158-170
             out = self._postfilter(out, self._stft_refs(self.transform_bm, bm))

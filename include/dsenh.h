@@ -132,6 +132,7 @@ typedef struct ds_config {
 #define DS_FDAF_P_NONE 0
 #define DS_FDAF_P_BLOCK 1
 #define DS_FDAF_P_BIN 2
+#define DS_FDAF_P_COMPLEMENT 4   /* OR-ed into p_mode: the kernel uses 1 - p (TDGSC.py:154) */
 #define DS_PARAM_METHOD 1   /* int   */
 #define DS_PARAM_MCRA_L 2   /* int   */
 #define DS_PARAM_ALPHA_Y 3  /* float */
@@ -238,6 +239,8 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
  *                      fir_truncate < 0 = None; w_out (or NULL) [B][L][C] = self.w after the last block.
  *                      State (W, P, input and delay buffers) via ds_get_state(DS_FIELD_OP_STATE), see DESIGN.md.
  *   ds_omlsa_estimate  y [B][T][K], u [B][T][K][M-1] powers -> lambda_d, G, p [B][T][K]
+ *   ds_omlsa_postfilter Y complex [B][T][K], U complex [B][T][K][M-1] -> G [B][T][K], Yout = Y * sqrt(G) complex [B][T][K]: the
+ *                      post-filter step of TDGSC / FDGSC (TDGSC.py:158-168) with the powers and the gain applied in the kernel
  *   ds_sublms_update   x complex [B][T][K][C], d complex [B][T][K], p [B][T][K] or NULL -> err complex [B][T][K]
  *   ds_subrls_update   x complex [B][T][K], d complex [B][T][K] -> err complex [B][T][K]
  *   ds_wpe_update      x_delayed complex [B][T][K][C], d complex [B][T][K][C] -> err complex [B][T][K][C]
@@ -268,6 +271,7 @@ int ds_adaptive_frames(ds_handle* h, const float* Z, const float* gain, int n_fr
 int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* p, int p_mode, int n_blocks, int fir_truncate,
                    float* err, float* w_out, int mem);
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem);
+int ds_omlsa_postfilter(ds_handle* h, const float* Y, const float* U, int n_frames, float* G, float* Yout, int mem);
 int ds_sublms_update(ds_handle* h, const float* x, const float* d, const float* p, int n_frames, float* err, int mem);
 int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames, float* err, int mem);
 int ds_wpe_update(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem);
