@@ -874,11 +874,101 @@ template <int M, bool LEAN = false> DS_HD void op_mcspp(const OpParams& p, int b
         }
         frm += 1;
     }
+    const int ks = k;
 #pragma unroll
-    for (int f = 0; f < M; ++f) { st_at(p, b, o0 + f, k) = yd[f]; st_at(p, b, o0 + M * M + f, k) = vd[f]; }
+    for (int f = 0; f < M; ++f) { st_at(p, b, o0 + f, ks) = yd[f]; st_at(p, b, o0 + M * M + f, ks) = vd[f]; }
 #pragma unroll
-    for (int f = 0; f < 2 * NO; ++f) { st_at(p, b, o0 + M + f, k) = yo[f]; st_at(p, b, o0 + M * M + M + f, k) = vo[f]; }
-    if (p.T > 0) { st_at(p, b, o0 + 2 * M * M, k) = xi; st_at(p, b, o0 + 2 * M * M + 1, k) = gam; st_at(p, b, o0 + 2 * M * M + 2, k) = pp; }
+    for (int f = 0; f < 2 * NO; ++f) { st_at(p, b, o0 + M + f, ks) = yo[f]; st_at(p, b, o0 + M * M + M + f, ks) = vo[f]; }
+    if (p.T > 0) { st_at(p, b, o0 + 2 * M * M, ks) = xi; st_at(p, b, o0 + 2 * M * M + 1, ks) = gam; st_at(p, b, o0 + 2 * M * M + 2, ks) = pp; }
+}
+
+// McSpp without the notebook-MVDR / matrix outputs (OP_MCSPP_LEAN, the SubbandGSC chain): the same estimation_core, but nothing here
+// needs inv(Phi_vv + dv I) as a matrix — tr(A^-1 Phi_yy), A^-1 y and the PMWF column are Cholesky solves on the Hermitian-packed state,
+// which is less work and fewer live registers than forming the explicit inverse (the kernel still sits at one wave per SIMD at M = 6).
+template <int M> DS_HD void op_mcspp_lean(const OpParams& p, int b, int k) {
+    constexpr int NO = M * (M - 1) / 2;
+    const int o0 = p.N;
+    float yd[M], yo[2 * NO + 1], vd[M], vo[2 * NO + 1];
+#pragma unroll
+    for (int f = 0; f < M; ++f) { yd[f] = st_at(p, b, o0 + f, k); vd[f] = st_at(p, b, o0 + M * M + f, k); }
+#pragma unroll
+    for (int f = 0; f < 2 * NO; ++f) { yo[f] = st_at(p, b, o0 + M + f, k); vo[f] = st_at(p, b, o0 + M * M + M + f, k); }
+    int frm = p.frm_cnt;
+    const int fmin = (int)(500.0 * (2 * (p.K - 1)) / 16000.0), fmax = (int)(2000.0 * (2 * (p.K - 1)) / 16000.0);   // :258-259
+    float xi = 0, gam = 0, pp = 0;
+    for (int t = 0; t < p.T; ++t) {
+        const long long fb = ((long long)b * p.T + t) * p.K;
+        const long long base = (fb + k) * M;
+        cf Z[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) Z[m] = mk(p.in0[2 * (base + m)], p.in0[2 * (base + m) + 1]);
+        float q = 1.0f - p.in1[fb + k];                                            // compute_q :113-116
+        const float q_avg = p.in2 ? p.in2[(long long)b * p.T + t] : mcspp_qavg(p.in1 + fb, fmin, fmax);
+        const float dv = fma_(q_avg, 1e-1f, (1.0f - q_avg) * 1e-4f);               // :254-262
+        herm_rank1<M>(yd, yo, Z, 0.92f, (float)(1.0 - 0.92));                      // :264-266
+        if (frm < 10) {                                                            // :273-275
+#pragma unroll
+            for (int f = 0; f < M; ++f) vd[f] = yd[f];
+#pragma unroll
+            for (int f = 0; f < 2 * NO; ++f) vo[f] = yo[f];
+            q = 0.99f;
+        }
+        // estimation_core :201-242 with A = Phi_vv + dv I = L L^H
+        Chol<M> ch;
+        auto trace_with_pyy = [&]() {                                              // Re tr(A^-1 Phi_yy) = sum_j Re (A^-1 Phi_yy[:, j])_j
+            float tr = 0.0f;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+                cf col[M], sol[M];
+#pragma unroll
+                for (int i = 0; i < M; ++i) col[i] = herm_get<M>(yd, yo, i, j);
+                ch.solve(col, sol);
+                tr += sol[j].x;
+            }
+            return tr;
+        };
+        ch.factor(vd, vo, dv);
+        float tr = trace_with_pyy();
+        if (tr - (float)M < 0.0f) {                                                // :219-228: fall back to A = Phi_yy (+ dv I early on)
+            ch.factor(yd, yo, frm < 5 ? dv : 0.0f);
+            tr = trace_with_pyy();
+        }
+        xi = fminf_(fmaxf_(tr - (float)M, 1e-6f), 1e8f);                           // :230
+        cf v[M];
+        ch.solve(Z, v);                                                            // v = A^-1 y
+        float yv = 0.0f, vPv = 0.0f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            yv = fma_(Z[i].x, v[i].x, fma_(Z[i].y, v[i].y, yv));                    // Re(conj(y_i) v_i)
+            cf acc = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < M; ++j) acc = cfma(acc, herm_get<M>(yd, yo, i, j), v[j]);
+            vPv = fma_(v[i].x, acc.x, fma_(v[i].y, acc.y, vPv));                    // Re(conj(v_i) (Phi_yy v)_i)
+        }
+        gam = fminf_(fmaxf_(vPv - yv, 1e-6f), 1e8f);                               // :232-236
+        pp = 1.0f / (1.0f + q / (1.0f - q) * (1.0f + xi) * expf(-1.0f * (gam / (1.0f + xi))));   // compute_p :75-92
+        pp = fminf_(fmaxf_(pp, 0.0f), 1.0f);
+        const long long ob = fb + k;
+        if (p.out1) {                                                              // compute_pmwf_weight beta = 10 :283, Phi_xx before the noise update
+            const float wsc = 1.0f / (10.0f + xi);
+            cf col[M], w[M];
+#pragma unroll
+            for (int i = 0; i < M; ++i) col[i] = csub(herm_get<M>(yd, yo, i, 0), herm_get<M>(vd, vo, i, 0));
+            ch.solve(col, w);
+#pragma unroll
+            for (int i = 0; i < M; ++i) { p.out1[2 * (ob * M + i)] = w[i].x * wsc; p.out1[2 * (ob * M + i) + 1] = w[i].y * wsc; }
+        }
+        const float at = fma_((float)(1.0 - 0.92), pp, 0.92f);                     // update_noise_psd (alpha_d = 0.92)
+        herm_rank1<M>(vd, vo, Z, at, 1.0f - at);
+        p.out0[ob] = pp;
+        frm += 1;
+    }
+    const int ks = k;
+#pragma unroll
+    for (int f = 0; f < M; ++f) { st_at(p, b, o0 + f, ks) = yd[f]; st_at(p, b, o0 + M * M + f, ks) = vd[f]; }
+#pragma unroll
+    for (int f = 0; f < 2 * NO; ++f) { st_at(p, b, o0 + M + f, ks) = yo[f]; st_at(p, b, o0 + M * M + M + f, ks) = vo[f]; }
+    if (p.T > 0) { st_at(p, b, o0 + 2 * M * M, ks) = xi; st_at(p, b, o0 + 2 * M * M + 1, ks) = gam; st_at(p, b, o0 + 2 * M * M + 2, ks) = pp; }
 }
 
 // stateless: steering(XXs) — in0 = XX complex [B][K][M][M] -> out0 = v complex [B][K][M]
@@ -965,7 +1055,7 @@ template <int OP, int M> DS_HD void run_op_t(const OpParams& p, int b, int k) {
     else if constexpr (OP == OP_MCMCRA) op_mcmcra<M>(p, b, k);
     else if constexpr (OP == OP_MCSPPBASE) op_mcsppbase<M>(p, b, k);
     else if constexpr (OP == OP_MCSPP) op_mcspp<M>(p, b, k);
-    else if constexpr (OP == OP_MCSPP_LEAN) op_mcspp<M, true>(p, b, k);
+    else if constexpr (OP == OP_MCSPP_LEAN) op_mcspp_lean<M>(p, b, k);
     else if constexpr (OP == OP_STEERING) op_steering<M>(p, b, k);
     else if constexpr (OP == OP_MVDRW) op_mvdrw<M>(p, b, k);
     else if constexpr (OP == OP_ADAPTIVE) op_adaptive<M>(p, b, k);
