@@ -506,3 +506,32 @@ def test_checkpoint_of_block_level_objects(ds):
         e.set_fdaf(L.FDAF_PLAIN, non_causal=True)
         return e
     roundtrip(make_fdaf, lambda e, i: e.fdaf_update(xf[i], df[i], fir_truncate=10))
+
+
+def test_mcra_p_and_omlsa_postfilter_entries(ds):
+    """ds_mcra_estimate_p returns mcra.p after every frame; ds_omlsa_postfilter = |.|^2 -> NsOmlsaMulti -> Y * sqrt(G) in one kernel."""
+    from oracle import ds_oracle as O
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(11)
+    K, T, M = 257, 60, 4
+    Y = (rng.standard_normal((1, T, K)) + 1j * rng.standard_normal((1, T, K))) * np.linspace(0.2, 1.0, T)[None, :, None]
+    U = (rng.standard_normal((1, T, K, M - 1)) + 1j * rng.standard_normal((1, T, K, M - 1))) * 0.3
+    eng = ds.BatchEngine(L.ALGO_MCRA, 1, 512, batch=1)
+    eng.set_mcra_L(10)
+    lam, p = eng.mcra_estimate_p(Y.astype(np.complex64))
+    om = O.OracleMCRA(nfft=512, L=10)
+    pref, lref = [], []
+    for t in range(T):
+        lref.append(om.estimation(Y[0, t].astype(np.complex64)).copy()); pref.append(om.p.copy())
+    assert np.max(np.abs(p[0] - np.array(pref))) < 1e-5 and rms(lam[0] - np.array(lref)) < 1e-5 * rms(np.array(lref))
+    pf = ds.BatchEngine(L.ALGO_OMLSA, M, 512, batch=1)
+    G, Yout = pf.omlsa_postfilter(Y.astype(np.complex64), U.astype(np.complex64))
+    oo = O.OracleOmlsaMulti(nfft=512, M=M, cal_weights=True)
+    Yc, Uc = Y.astype(np.complex64), U.astype(np.complex64)
+    Gref = []
+    for t in range(T):
+        oo.estimation(np.abs(Yc[0, t]).astype(np.float64) ** 2, np.abs(Uc[0, t]).astype(np.float64) ** 2)
+        Gref.append(oo.G.copy())
+    Gref = np.array(Gref)
+    assert np.median(np.abs(G[0] - Gref)) < 1e-5 and np.mean(np.abs(G[0] - Gref) > 1e-3) < 0.01      # isolated threshold flips allowed
+    assert rms(Yout[0] - Yc[0] * np.sqrt(G[0])) < 1e-6 * rms(Yc[0])
