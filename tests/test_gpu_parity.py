@@ -311,3 +311,23 @@ def test_wav_files_end_to_end(ds, tmp_path):
         _, y16 = wavfile.read(str(out))
         ref16 = (g["y"] * 32767).astype(np.int16)
         assert np.max(np.abs(y16.astype(np.int32) - ref16.astype(np.int32))) <= 2          # within int16 quantisation of 1e-4
+
+
+def test_plain_c_caller(tmp_path):
+    """the boundary is a C-ABI: examples/c/mvdr_stream.c (gcc, no Python, no HIP headers) drives an MVDR handle hop by hop and
+    produces bit for bit what the Python mirror produces on the same input."""
+    import subprocess
+    import distantspeech_amd as ds
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "mvdr_stream")
+    subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "c", "mvdr_stream.c"), "-o", exe,
+                           "-L", os.path.join(root, "distantspeech_amd"), "-ldsenh", "-lm", "-Wl,-rpath," + os.path.join(root, "distantspeech_amd")])
+    n = 256 * 40
+    x = O.synth_utterance(3, n, oracle_mic(4, 512)).astype(np.float32)
+    x.tofile(str(tmp_path / "x.f32"))
+    out = subprocess.run([exe, str(tmp_path / "x.f32"), str(tmp_path / "y.f32"), str(n)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    y_c = np.fromfile(str(tmp_path / "y.f32"), dtype=np.float32)
+    bf = ds.adaptivebeamfomer(ds.MicArray(arrayType="circular", r=0.032, M=4, n_fft=512), frameLen=512, hop=256, nfft=512, track_ryy=False)
+    y_py = np.concatenate([bf.process(x[:, s:s + 256], ANGLE, method=2)["data"] for s in range(0, n, 256)])
+    assert np.array_equal(y_c.astype(np.float64), y_py)
