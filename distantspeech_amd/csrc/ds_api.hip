@@ -216,7 +216,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         ki.launch = nullptr; ki.NP = 0; ki.KP = KPo; ki.NT = 256;
     } else if (!ki.launch) {
         char buf[200];
-        snprintf(buf, sizeof buf, "ds_create: no kernel for algo=%d nfft=%d n_mics=%d (nfft in {256,512,1024}, n_mics in {2,4,6,8}; Transform also n_mics=1)",
+        snprintf(buf, sizeof buf, "ds_create: no kernel for algo=%d nfft=%d n_mics=%d (nfft in {256,512,1024}, n_mics in {2,4,6,8}; Transform: n_mics 1..8)",
                  cfg->algo, cfg->nfft, cfg->n_mics);
         return fail(nullptr, DS_EUNSUPPORTED, buf);
     }

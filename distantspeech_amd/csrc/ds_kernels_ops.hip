@@ -30,9 +30,9 @@ template <int NFFT, int M> hipError_t launch_istft(const Params& p, int nblocks,
 }
 
 #define DS_FOR_EACH_TSHAPE(X) \
-    X(256, 1) X(256, 2) X(256, 4) X(256, 6) X(256, 8) \
-    X(512, 1) X(512, 2) X(512, 4) X(512, 6) X(512, 8) \
-    X(1024, 1) X(1024, 2) X(1024, 4) X(1024, 6) X(1024, 8)
+    X(256, 1) X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) X(256, 7) X(256, 8) \
+    X(512, 1) X(512, 2) X(512, 3) X(512, 4) X(512, 5) X(512, 6) X(512, 7) X(512, 8) \
+    X(1024, 1) X(1024, 2) X(1024, 3) X(1024, 4) X(1024, 5) X(1024, 6) X(1024, 7) X(1024, 8)
 
 KernelInfo lookup_stft(int nfft, int M) {
 #define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {&launch_stft<NFFT_, M_>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }

@@ -37,10 +37,8 @@ class _BlockGSC(object):
 
     @staticmethod
     def _stft_refs(tf, bm):
-        """STFT of the M-1 noise references [B, n, M-1] on an M-channel transform handle (the kernels are built for
-        even channel counts): the last channel is fed zeros and dropped."""
-        pad = np.zeros(bm.shape[:2] + (1,), dtype=np.float32)
-        return tf.stft(np.concatenate((bm.astype(np.float32), pad), axis=2), L.LAYOUT_SAMPLES_CHANNELS)[:, :, :, :-1]
+        """STFT of the M-1 noise references [B, n, M-1] -> complex [B, T, K, M-1]."""
+        return tf.stft(np.ascontiguousarray(bm, dtype=np.float32), L.LAYOUT_SAMPLES_CHANNELS)
 
     def _postfilter(self, out_td, U):
         """OMLSA gain on the canceller output (TDGSC.py:158-170 / FDGSC.py:286-298): out_td [B, n], U complex [B, T, K, M-1]
@@ -68,7 +66,7 @@ class TDGSC(_BlockGSC):
         self.transform = BatchEngine(L.ALGO_TRANSFORM, 1, nb, frameLen, batch=B, device=device)             # :44
         self.omlsa_multi = NsOmlsaMulti(nfft=nb, cal_weights=True, M=M, batch=B, device=device)             # :48
         self.transform_fbf = BatchEngine(L.ALGO_TRANSFORM, 1, nb, frameLen, batch=B, device=device)         # :49
-        self.transform_bm = BatchEngine(L.ALGO_TRANSFORM, M, nb, frameLen, batch=B, device=device)          # :50 (M-1 used)
+        self.transform_bm = BatchEngine(L.ALGO_TRANSFORM, M - 1, nb, frameLen, batch=B, device=device)      # :50
 
     def process(self, x, postfilter=False):
         """x [samples, chs] (or [B, samples, chs]) -> (output [samples], p [half_bin, blocks], output_bm [samples, chs-1])."""
@@ -109,11 +107,11 @@ class FDGSC(_BlockGSC):
         self.transform_x = BatchEngine(L.ALGO_TRANSFORM, M, nb, frameLen, batch=B, device=device)           # :106
         self.omlsa_multi = NsOmlsaMulti(nfft=nb, cal_weights=True, M=M, batch=B, device=device)             # :108
         self.transform_fbf = BatchEngine(L.ALGO_TRANSFORM, 1, nb, frameLen, batch=B, device=device)         # :109
-        self.transform_bm = BatchEngine(L.ALGO_TRANSFORM, M, nb, frameLen, batch=B, device=device)          # :110 (M-1 used)
+        self.transform_bm = BatchEngine(L.ALGO_TRANSFORM, M - 1, nb, frameLen, batch=B, device=device)      # :110
         self._fix_prev = np.zeros((B, frameLen), dtype=np.float32)             # delay_fbf: one block (:93)
         self._al_tail = np.zeros((B, frameLen // 2, M), dtype=np.float32)      # delay_aligned: half a block (:96)
         self._bm_last = np.zeros((B, frameLen, M - 1), dtype=np.float32)       # last hop of the array transform_bm saw last
-        self._tf_u = BatchEngine(L.ALGO_TRANSFORM, M, nb, frameLen, batch=B, device=device)
+        self._tf_u = BatchEngine(L.ALGO_TRANSFORM, M - 1, nb, frameLen, batch=B, device=device)
 
     def process(self, x, postfilter=False, dc_notch=True):
         """x [samples, chs] (or [B, samples, chs]) -> (output, p, fix_output, fix_output_delayed, bm_output,

@@ -110,7 +110,7 @@ template <int LPB> int run_wpe(const ds::WpeParams& p) {
 
 template <int NFFT> int run_tf(int M, bool inverse, const ds::Params& p, int batch) {
 #define TF(M_) if (M == M_) return inverse ? run_engine<ds::IstftEngine<NFFT, M_>>(p, batch, NFFT) : run_engine<ds::StftEngine<NFFT, M_>>(p, batch, NFFT);
-    TF(1) TF(2) TF(4) TF(6) TF(8)
+    TF(1) TF(2) TF(3) TF(4) TF(5) TF(6) TF(7) TF(8)
 #undef TF
     return -1;
 }

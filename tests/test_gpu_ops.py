@@ -17,6 +17,19 @@ def ds():
     return d
 
 
+@pytest.mark.parametrize("M", [3, 5, 7])
+def test_transform_odd_channel_counts(ds, M):
+    """Transform with 3, 5, 7 channels (the M - 1 noise references of TDGSC / FDGSC) vs the oracle."""
+    from oracle import ds_oracle as O
+    rng = np.random.default_rng(M)
+    x = rng.standard_normal((512 * 6, M)) * 0.1
+    t = ds.Transform(channel=M, n_fft=512, hop_length=256)
+    o = O.OracleTransform(channel=M, n_fft=512, hop_length=256)
+    Y, Yo = t.stft(x), o.stft(x)
+    assert rms(Y - Yo) < 2e-6 * rms(Yo)
+    assert np.max(np.abs(np.asarray(t.istft(Y)) - np.asarray(o.istft(Yo)))) < 5e-6
+
+
 @pytest.mark.parametrize("name", ["g1_transform_512_256_4", "g1_transform_1024_512_2", "g1_transform_256_128_1"])
 def test_transform(ds, name):
     g = load(name)
