@@ -3,7 +3,7 @@
 //   -> err complex [B][T][K][C] (dereverberated frame, all channels)
 // One (utterance, bin) is a CN x CN complex RLS (CN = C * N taps-by-channels, <= 16).  CN lanes share a bin: lane i keeps row i
 // of P, column i of W and tap i of the input buffer in registers for all T frames of the call; the three reductions of a frame
-// (W^H X, X^H P X, X^H P) go through LDS in a fixed order.  A workgroup of 256 lanes carries 256 / LPB bins (LPB = CN rounded up
+// (W^H X, X^H P X, X^H P) go through LDS in a fixed order.  A workgroup of 128 lanes carries 128 / LPB bins (LPB = CN rounded up
 // to 4, 8 or 16).  State per bin is one contiguous block laid out slot-major, lane-minor, so that the CN lanes of a bin read
 // consecutive 8-byte words: every state access is a fully used 128-byte segment (CN = 16), once in and once out per call.
 // Written against the Exec policy (tests/emul runs it serially on the CPU).
@@ -12,7 +12,7 @@
 
 namespace ds {
 
-constexpr int WPE_CNMAX = 16, WPE_CMAX = 8, WPE_NT = 256;
+constexpr int WPE_CNMAX = 16, WPE_CMAX = 8, WPE_NT = 128;
 
 // per-bin block: NQ = CN + C + 1 slots of CN complex, element (slot q, lane i) at 2 * (q * CN + i):
 //   q < CN: P[i][q]      CN <= q < CN + C: W[q - CN][i]      q = CN + C: input_buffer tap i      then var (1 float), padded to 16 B
