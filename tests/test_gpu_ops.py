@@ -548,3 +548,42 @@ def test_mcra_p_and_omlsa_postfilter_entries(ds):
     Gref = np.array(Gref)
     assert np.median(np.abs(G[0] - Gref)) < 1e-5 and np.mean(np.abs(G[0] - Gref) > 1e-3) < 0.01      # isolated threshold flips allowed
     assert rms(Yout[0] - Yc[0] * np.sqrt(G[0])) < 1e-6 * rms(Yc[0])
+
+
+@pytest.mark.parametrize("Lf,C,kind", [(512, 8, "plain"), (512, 1, "bm"), (64, 4, "aic"), (128, 7, "plain"), (256, 8, "aic")])
+def test_fdaf_extreme_shapes(ds, Lf, C, kind):
+    """the largest / smallest FDAF instantiations (n_fft 128 .. 1024, up to 8 channels: 118 KB of LDS per workgroup) vs the oracle."""
+    from oracle import ds_oracle as O
+    rng = np.random.default_rng(Lf + C)
+    nb = 12
+    x = rng.standard_normal((Lf * nb, C)) * 0.2
+    d = sum(np.convolve(x[:, c], rng.standard_normal(20) * 0.3)[: Lf * nb] for c in range(C)) + 0.01 * rng.standard_normal(Lf * nb)
+    p = rng.uniform(0.2, 1.0, (nb, Lf + 1))
+    o = O.OracleFastFreqLms(filter_len=Lf, mu=0.05, n_channels=C, alpha=0.9, non_causal=(kind == "plain"), kind=kind, weight_norm=(kind == "aic"))
+    eref = np.zeros(Lf * nb)
+    for n in range(nb):
+        eref[n * Lf:(n + 1) * Lf] = o.update(x[n * Lf:(n + 1) * Lf], d[n * Lf:(n + 1) * Lf], p=p[n][:, None], fir_truncate=5 if kind == "plain" else None)[0][:, 0]
+    cls = {"plain": ds.FastFreqLms, "bm": ds.AdaptiveBlockingMatrixFilter, "aic": ds.AdaptiveInterferenceCancellation}[kind]
+    kw = dict(weight_norm=True) if kind == "aic" else {}
+    f = cls(filter_len=Lf, mu=0.05, n_channels=C, alpha=0.9, non_causal=(kind == "plain"), **kw)
+    e = f.filter(x, d, p=p, fir_truncate=5 if kind == "plain" else None)
+    assert rms(e - eref) < 1e-4 * rms(eref)
+    assert rms(f.w - o.w) < 1e-3 * max(rms(o.w), 1e-6)
+
+
+@pytest.mark.parametrize("C,N", [(1, 1), (1, 4), (3, 2), (2, 8), (5, 3), (8, 2), (8, 1)])
+def test_wpe_shapes(ds, C, N):
+    """every lanes-per-bin class of the WPE kernel (C * N from 1 to 16, padded to 4 / 8 / 16 lanes) vs the oracle core."""
+    from oracle import ds_oracle as O
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(10 * C + N)
+    K, T = 129, 30
+    D = (rng.standard_normal((T, K, C)) + 1j * rng.standard_normal((T, K, C))) * 0.3
+    Xd = np.concatenate([np.zeros((2, K, C), complex), D[:-2]])
+    o = O.OracleWpe(channels=C, filter_len=N, num_bands=256, delay=2)
+    ref = np.stack([o.update_fd(Xd[t], D[t]) for t in range(T)])
+    eng = ds.BatchEngine(L.ALGO_WPE, C, 256, batch=2, filter_len=N, rls_lambda=0.998)
+    err = np.concatenate([eng.wpe_update(np.stack([Xd[:11], Xd[:11]]), np.stack([D[:11], D[:11]])),
+                          eng.wpe_update(np.stack([Xd[11:], Xd[11:]]), np.stack([D[11:], D[11:]]))], axis=1)
+    assert np.array_equal(err[0], err[1])
+    assert rms(err[0] - ref) < 2e-4 * rms(ref)
