@@ -587,3 +587,39 @@ def test_wpe_shapes(ds, C, N):
                           eng.wpe_update(np.stack([Xd[11:], Xd[11:]]), np.stack([D[11:], D[11:]]))], axis=1)
     assert np.array_equal(err[0], err[1])
     assert rms(err[0] - ref) < 2e-4 * rms(ref)
+
+
+@pytest.mark.parametrize("N,C", [(2, 1), (2, 2), (2, 4), (2, 6), (2, 8), (3, 3), (1, 5), (4, 2)])
+def test_subband_lms_shapes(ds, N, C):
+    """the register-resident specialisations of the subband LMS operator (2 taps x 1/2/4/6/8 channels) and its generic path vs the
+    oracle; a call split in two equals one call bit for bit."""
+    from oracle import ds_oracle as O
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(100 * N + C)
+    K, T = 129, 40
+    x = (rng.standard_normal((T, K, C)) + 1j * rng.standard_normal((T, K, C))) * 0.3
+    d = (rng.standard_normal((T, K)) + 1j * rng.standard_normal((T, K))) * 0.3
+    p = rng.uniform(0, 1, (T, K))
+    o = O.OracleSubbandLmsMc(filter_len=N, num_bands=256, channel=C, mu=0.05, alpha=0.8)
+    ref = np.stack([o.update(x[t], d[t], p=p[t])[0] for t in range(T)])
+    mk = lambda: ds.BatchEngine(L.ALGO_SUBLMS, C, 256, batch=1, filter_len=N, filt_mu=0.05, filt_alpha=0.8)
+    e1 = mk().sublms_update(x[None], d[None], p[None])[0]
+    eng = mk()
+    e2 = np.concatenate([eng.sublms_update(x[None, :13], d[None, :13], p[None, :13]), eng.sublms_update(x[None, 13:], d[None, 13:], p[None, 13:])], axis=1)[0]
+    assert np.array_equal(e1, e2)
+    assert rms(e1 - ref) < 1e-4 * rms(ref)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4])
+def test_subband_rls_shapes(ds, N):
+    from oracle import ds_oracle as O
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(N)
+    K, T = 129, 60
+    x = (rng.standard_normal((T, K)) + 1j * rng.standard_normal((T, K))) * 0.3
+    d = 0.5 * x + (rng.standard_normal((T, K)) + 1j * rng.standard_normal((T, K))) * 0.05
+    o = O.OracleSubbandRLS(filter_len=N, num_bands=256)
+    ref = np.stack([o.update(x[t], d[t])[0] for t in range(T)])
+    eng = ds.BatchEngine(L.ALGO_SUBRLS, 1, 256, batch=1, filter_len=N)
+    e = np.concatenate([eng.subrls_update(x[None, :21], d[None, :21]), eng.subrls_update(x[None, 21:], d[None, 21:])], axis=1)[0]
+    assert rms(e - ref) < 2e-3 * rms(ref)              # fp32 RLS from P0 = 1e3 I; the first frames carry most of the difference
