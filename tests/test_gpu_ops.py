@@ -623,3 +623,36 @@ def test_subband_rls_shapes(ds, N):
     eng = ds.BatchEngine(L.ALGO_SUBRLS, 1, 256, batch=1, filter_len=N)
     e = np.concatenate([eng.subrls_update(x[None, :21], d[None, :21]), eng.subrls_update(x[None, 21:], d[None, 21:])], axis=1)[0]
     assert rms(e - ref) < 2e-3 * rms(ref)              # fp32 RLS from P0 = 1e3 I; the first frames carry most of the difference
+
+
+@pytest.mark.parametrize("M", [2, 6, 8])
+def test_matrix_operator_shapes(ds, M):
+    """McMcra, McSppBase and the adaptive frame loop at 2, 6 and 8 microphones (the golden vectors pin 4 and 6) vs the oracle on a
+    synthetic utterance's STFT frames."""
+    from oracle import ds_oracle as O
+    from _cases import ANGLE, oracle_mic, steering
+    from distantspeech_amd import _lib as L
+    nfft, hop, T = 512, 256, 60
+    mic = oracle_mic(M, nfft, r=0.05)
+    x = O.synth_utterance(40 + M, T * hop, mic)
+    D = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop).stft(x.T)             # [K, T, M]
+    Z = np.ascontiguousarray(np.transpose(D, (1, 0, 2)))[None]                          # [1, T, K, M]
+    om = O.OracleMcMcra(nfft=nfft, channels=M)
+    pref, gref = [], []
+    for t in range(T):
+        om.estimation(D[:, t, :]); pref.append(om.p.copy()); gref.append(om.G.copy())
+    p, G = ds.BatchEngine(L.ALGO_MCMCRA, M, nfft, batch=1).mcmcra_estimate(Z)
+    assert np.median(np.abs(p[0] - np.array(pref))) < 1e-4 and np.median(np.abs(G[0] - np.array(gref))) < 1e-4
+    ob = O.OracleMcSppBase(nfft=nfft, channels=M)
+    pref = []
+    with np.errstate(all="ignore"):
+        for t in range(T):
+            ob.estimation(D[:, t, :]); pref.append(ob.p.copy())
+    pb, _ = ds.BatchEngine(L.ALGO_MCSPPBASE, M, nfft, batch=1).mcsppbase_estimate(Z)
+    assert np.median(np.abs(pb[0] - np.array(pref))) < 1e-3
+    mv = O.OracleAdaptiveMVDR(mic, frameLen=nfft, hop=hop, nfft=nfft)
+    Yref = np.stack([mv.process_frame(D[:, t, :], ANGLE, 2) for t in range(T)])
+    eng = ds.BatchEngine(L.ALGO_ADAPTIVE_FRAMES, M, nfft, batch=1)
+    eng.set_steering(steering(M, nfft, mic.r)); eng.set_method(2)
+    Y = eng.adaptive_frames(Z)[0]
+    assert rms(Y - Yref) < 1e-4 * rms(Yref)
