@@ -177,7 +177,9 @@ template <int LPB> struct WpeEngine {
                 r.var = fma_(0.98f, r.var, (float)(1.0 - 0.98) * (dpow / (float)C));       // :163-165
                 cf den = mk(lam * r.var, 0.0f);
                 for (int l = 0; l < CN; ++l) den = cadd(den, sh.dpart[s][l]);              // :174-180
-                const cf kn = cdiv(r.num, den);
+                // digital silence from the first frame on (var = 0, X = 0) makes the reference's gain 0 / 0 and its state NaN for good; the
+                // gain is 0 there instead — the only departure from awpe.py:174-180, and only where the reference has no finite value
+                const cf kn = (den.x == 0.0f && den.y == 0.0f) ? mk(0.0f, 0.0f) : cdiv(r.num, den);
 #pragma unroll
                 for (int j = 0; j < LPB; ++j)
                     if (j < CN) r.P[j] = cscale(cfnma(r.P[j], kn, sh.xh[s][j]), lam_inv);    // P = (P - kn (X^H P)) / lambda  :183-185

@@ -656,3 +656,23 @@ def test_matrix_operator_shapes(ds, M):
     eng.set_steering(steering(M, nfft, mic.r)); eng.set_method(2)
     Y = eng.adaptive_frames(Z)[0]
     assert rms(Y - Yref) < 1e-4 * rms(Yref)
+
+
+def test_chains_survive_leading_digital_silence(ds):
+    """a stream that starts with exact zeros (file padding) must not poison the recursions: the reference's WPE gain is 0 / 0 there
+    (NaN state for good); the kernels keep finite state and then track the signal."""
+    from oracle import ds_oracle as O
+    from _cases import ANGLE, oracle_mic
+    M, nfft, hop = 4, 512, 256
+    omic = oracle_mic(M, nfft)
+    x = O.synth_utterance(5, 60 * hop, omic)
+    x[:, : 8 * hop] = 0.0
+    mic = ds.MicArray(arrayType="circular", r=omic.r, M=M, n_fft=nfft)
+    y = ds.WpeMvdrPostfilter(mic, frameLen=nfft, hop=hop).process(x, ANGLE)["data"]
+    assert np.all(np.isfinite(y)) and np.all(y[: 7 * hop] == 0.0) and rms(y[30 * hop:]) > 1e-3
+    out = ds.SubbandGSC(mic, frameLen=256).process(x)
+    assert all(np.all(np.isfinite(a)) for a in out) and rms(out[0][30 * hop:]) > 1e-4
+    for cls in (ds.GSC, ds.adaptivebeamfomer):
+        kw = dict(frameLen=nfft, hop=hop, nfft=nfft) if cls is ds.adaptivebeamfomer else dict(frameLen=nfft)
+        yy = cls(mic, **kw).process(x, ANGLE, method=2)["data"]
+        assert np.all(np.isfinite(yy)) and rms(yy[30 * hop:]) > 1e-4
