@@ -382,7 +382,7 @@ int ds_reset(ds_handle* h) {
         if (h->sub[i]) { rc = ds_reset(h->sub[i]); if (rc) return fail(h, rc, h->sub[i]->err); }
     if (h->cfg.algo == DS_ALGO_WPE_MVDR && h->chain_buf[6]) DS_HIP(h, hipMemsetAsync(h->chain_buf[6], 0, h->chain_bytes[6], h->stream));
     if (h->cfg.algo == DS_ALGO_SUBBAND_GSC)
-        for (int i = 13; i < 15; ++i)
+        for (int i = G_FPREV; i <= G_FIXPREV; ++i)
             if (h->chain_buf[i]) DS_HIP(h, hipMemsetAsync(h->chain_buf[i], 0, h->chain_bytes[i], h->stream));
     h->hist_cur = 0;
     return zero_state(h);
@@ -830,8 +830,8 @@ int ds_export_state(ds_handle* h, void* dst, size_t bytes) {
     if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) {
         rc = chain2_reserve(h, h->cfg.hop); if (rc) return rc;
         const size_t n13 = (size_t)h->cfg.batch * h->K * 8, n14 = (size_t)h->cfg.batch * h->cfg.hop * 4;
-        DS_HIP(h, hipMemcpy(d, h->chain_buf[13], n13, hipMemcpyDeviceToHost));
-        DS_HIP(h, hipMemcpy(d + n13, h->chain_buf[14], n14, hipMemcpyDeviceToHost));
+        DS_HIP(h, hipMemcpy(d, h->chain_buf[G_FPREV], n13, hipMemcpyDeviceToHost));
+        DS_HIP(h, hipMemcpy(d + n13, h->chain_buf[G_FIXPREV], n14, hipMemcpyDeviceToHost));
     } else if (chain_hist_bytes(h)) {
         rc = chain_reserve(h, 1); if (rc) return rc;
         DS_HIP(h, hipMemcpy(d, h->chain_buf[6], chain_hist_bytes(h), hipMemcpyDeviceToHost));
@@ -870,8 +870,8 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
     if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) {
         rc = chain2_reserve(h, h->cfg.hop); if (rc) return rc;
         const size_t n13 = (size_t)h->cfg.batch * h->K * 8, n14 = (size_t)h->cfg.batch * h->cfg.hop * 4;
-        DS_HIP(h, hipMemcpy(h->chain_buf[13], s, n13, hipMemcpyHostToDevice));
-        DS_HIP(h, hipMemcpy(h->chain_buf[14], s + n13, n14, hipMemcpyHostToDevice));
+        DS_HIP(h, hipMemcpy(h->chain_buf[G_FPREV], s, n13, hipMemcpyHostToDevice));
+        DS_HIP(h, hipMemcpy(h->chain_buf[G_FIXPREV], s + n13, n14, hipMemcpyHostToDevice));
     } else if (chain_hist_bytes(h)) {
         rc = chain_reserve(h, 1); if (rc) return rc;
         DS_HIP(h, hipMemcpy(h->chain_buf[6], s, chain_hist_bytes(h), hipMemcpyHostToDevice));

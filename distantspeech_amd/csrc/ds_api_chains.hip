@@ -66,21 +66,21 @@ int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long
 }
 
 // ---- DS_ALGO_SUBBAND_GSC: SubbandGSC.process (SubbandGSC.py:170-262) as a device-resident chain ------------------------------
-// buffers: 0 xn [B][M][n] (notched), 1 xa [B][M][n] (aligned), 2 fixed [B][n], 3 D c[B][T][K][M], 4 p [B][T][K], 5 (unused),
-// 6 F c[B][T][K], 7 (unused), 8 E c[B*M][T][K], 9 bm_td [B][M][n], 10 Xa c[B][T][K][M], 11 (unused), 12 e2 c[B][T][K],
-// 13 F of the previous block c[B][K] (state), 14 fixed output of the previous block [B][hop] (state)
+// (the buffer indices G_* are declared in ds_handle.hpp)
 int chain2_reserve(ds_handle* h, int n) {
     const size_t B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, T = n / h->cfg.hop, hop = h->cfg.hop;
-    const size_t need[15] = {B * M * n * 4, B * M * n * 4, B * n * 4, B * T * K * M * 8, B * T * K * 4, 16, B * T * K * 8,
-                             16, B * M * T * K * 8, B * M * n * 4, B * T * K * M * 8, 16, B * T * K * 8,
-                             B * K * 8, B * hop * 4};
-    for (int i = 0; i < 15; ++i) {
-        if (need[i] <= h->chain_bytes[i]) continue;
+    size_t need[G_COUNT] = {0};
+    need[G_XN] = need[G_XA] = need[G_BM] = B * M * n * 4; need[G_FIXED] = B * n * 4;
+    need[G_D] = need[G_XAIC] = B * T * K * M * 8; need[G_P] = B * T * K * 4;
+    need[G_F] = need[G_E2] = B * T * K * 8; need[G_E] = B * M * T * K * 8;
+    need[G_FPREV] = B * K * 8; need[G_FIXPREV] = B * hop * 4;
+    for (int i = 0; i < G_COUNT; ++i) {
+        if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
         DS_HIP(h, hipStreamSynchronize(h->stream));
         (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
         DS_HIP(h, hipMalloc((void**)&h->chain_buf[i], need[i]));
         h->chain_bytes[i] = need[i];
-        if (i >= 13) DS_HIP(h, hipMemset(h->chain_buf[i], 0, need[i]));       // delay_fbf starts from silence (SubbandGSC.py:111)
+        if (i >= G_FPREV) DS_HIP(h, hipMemset(h->chain_buf[i], 0, need[i]));       // delay_fbf starts from silence (SubbandGSC.py:111)
     }
     return DS_OK;
 }
@@ -122,7 +122,7 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     {   // :177-178 DC notch per channel, then :201,206 TimeAlignment FIR bank + channel mean (the fixed beamformer)
         ds::TdParams p;
         std::memset(&p, 0, sizeof p);
-        p.B = B; p.M = M; p.n = n; p.x = x_dev; p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.y = cb[0]; p.mem = fe->td_mem;
+        p.B = B; p.M = M; p.n = n; p.x = x_dev; p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.y = cb[G_XN]; p.mem = fe->td_mem;
         p.radius = fe->cfg.filt_alpha;
         DS_HIP(h, ds::launch_dcnotch(p, h->stream));
         const int Lt = (int)(fe->aux_floats / M);
@@ -137,37 +137,37 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
             fe->td_L = Lt; fe->td_cur = 0;
         }
         std::memset(&p, 0, sizeof p);
-        p.B = B; p.M = M; p.n = n; p.L = Lt; p.x = cb[0]; p.x_chan_major = 1; p.y = cb[1]; p.y_chan_major = 1; p.mean = cb[2];
+        p.B = B; p.M = M; p.n = n; p.L = Lt; p.x = cb[G_XN]; p.x_chan_major = 1; p.y = cb[G_XA]; p.y_chan_major = 1; p.mean = cb[G_FIXED];
         p.coef = fe->dev_buf[9]; p.cache_in = fe->td_cache[fe->td_cur]; p.cache_out = fe->td_cache[fe->td_cur ^ 1];
         DS_HIP(h, ds::launch_fir(p, h->stream));
         fe->td_cur ^= 1;
     }
-    rc = chain_stft(h, h->sub[1], cb[1], n, cb[3]); if (rc) return rc;                                   // :204  D
-    DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[3], T, cb[4], nullptr, nullptr, nullptr, nullptr, DS_MEM_DEVICE));   // :208  p
-    rc = chain_stft(h, h->sub[3], cb[2], n, cb[6]); if (rc) return rc;                                   // bm[m].transform_x: F
+    rc = chain_stft(h, h->sub[1], cb[G_XA], n, cb[G_D]); if (rc) return rc;                                   // :204  D
+    DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[G_D], T, cb[G_P], nullptr, nullptr, nullptr, nullptr, DS_MEM_DEVICE));   // :208  p
+    rc = chain_stft(h, h->sub[3], cb[G_FIXED], n, cb[G_F]); if (rc) return rc;                                   // bm[m].transform_x: F
     // :217-223 the M blocking filters: reference input F (shared), desired signal = channel m of D (bm[m].transform_d's analysis of the
     // aligned channel is the same spectrum), update probability p
-    if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[6], cb[3], T, cb[8], DS_MEM_DEVICE));
-    else DS_SUB(5, ds_sublms_update(h->sub[5], cb[6], cb[3], cb[4], T, cb[8], DS_MEM_DEVICE));
-    rc = chain_istft(h, h->sub[4], cb[8], T, cb[9], n); if (rc) return rc;                               // bm outputs, [B*M][n] = [B][M][n]
-    rc = chain_stft(h, h->sub[6], cb[9], n, cb[10]); if (rc) return rc;                                  // :230-234  aic transform_x
+    if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[G_F], cb[G_D], T, cb[G_E], DS_MEM_DEVICE));
+    else DS_SUB(5, ds_sublms_update(h->sub[5], cb[G_F], cb[G_D], cb[G_P], T, cb[G_E], DS_MEM_DEVICE));
+    rc = chain_istft(h, h->sub[4], cb[G_E], T, cb[G_BM], n); if (rc) return rc;                               // bm outputs, [B*M][n] = [B][M][n]
+    rc = chain_stft(h, h->sub[6], cb[G_BM], n, cb[G_XAIC]); if (rc) return rc;                                  // :230-234  aic transform_x
     // :226 delay_fbf: the canceller's desired signal is the fixed output one block late = F one frame late; the operator keeps the
-    // carried frame in cb[13] itself
-    h->sub[7]->d_prev = cb[13];
-    DS_SUB(7, ds_sublms_update(h->sub[7], cb[10], cb[6], cb[4], T, cb[12], DS_MEM_DEVICE));
-    rc = chain_istft(h, h->sub[8], cb[12], T, y_dev, y_bstride); if (rc) return rc;
+    // carried frame in cb[G_FPREV] itself
+    h->sub[7]->d_prev = cb[G_FPREV];
+    DS_SUB(7, ds_sublms_update(h->sub[7], cb[G_XAIC], cb[G_F], cb[G_P], T, cb[G_E2], DS_MEM_DEVICE));
+    rc = chain_istft(h, h->sub[8], cb[G_E2], T, y_dev, y_bstride); if (rc) return rc;
     {   // fix_output = fixed beamformer output delayed by one block (:226,255); the carried block is state either way
         const size_t blk = (size_t)hop * 4, row = (size_t)n * 4;
         if (fix_dev) {
-            if (T > 1) DS_HIP(h, hipMemcpy2DAsync((char*)fix_dev + blk, row, cb[2], row, row - blk, B, hipMemcpyDeviceToDevice, h->stream));
-            DS_HIP(h, hipMemcpy2DAsync(fix_dev, row, cb[14], blk, blk, B, hipMemcpyDeviceToDevice, h->stream));
+            if (T > 1) DS_HIP(h, hipMemcpy2DAsync((char*)fix_dev + blk, row, cb[G_FIXED], row, row - blk, B, hipMemcpyDeviceToDevice, h->stream));
+            DS_HIP(h, hipMemcpy2DAsync(fix_dev, row, cb[G_FIXPREV], blk, blk, B, hipMemcpyDeviceToDevice, h->stream));
         }
-        DS_HIP(h, hipMemcpy2DAsync(cb[14], blk, (char*)cb[2] + (row - blk), row, blk, B, hipMemcpyDeviceToDevice, h->stream));
+        DS_HIP(h, hipMemcpy2DAsync(cb[G_FIXPREV], blk, (char*)cb[G_FIXED] + (row - blk), row, blk, B, hipMemcpyDeviceToDevice, h->stream));
     }
     const size_t nb = (size_t)B * M * n * 4;
-    if (bm_dev) DS_HIP(h, hipMemcpyAsync(bm_dev, cb[9], nb, hipMemcpyDeviceToDevice, h->stream));
-    if (al_dev) DS_HIP(h, hipMemcpyAsync(al_dev, cb[1], nb, hipMemcpyDeviceToDevice, h->stream));
-    if (p_dev) DS_HIP(h, hipMemcpyAsync(p_dev, cb[4], (size_t)B * T * K * 4, hipMemcpyDeviceToDevice, h->stream));
+    if (bm_dev) DS_HIP(h, hipMemcpyAsync(bm_dev, cb[G_BM], nb, hipMemcpyDeviceToDevice, h->stream));
+    if (al_dev) DS_HIP(h, hipMemcpyAsync(al_dev, cb[G_XA], nb, hipMemcpyDeviceToDevice, h->stream));
+    if (p_dev) DS_HIP(h, hipMemcpyAsync(p_dev, cb[G_P], (size_t)B * T * K * 4, hipMemcpyDeviceToDevice, h->stream));
 #undef DS_SUB
     return DS_OK;
 }

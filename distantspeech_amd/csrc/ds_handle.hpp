@@ -111,6 +111,22 @@ int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int me
 int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len);
 
 // chain handles (ds_api_chains.hip)
+// DS_ALGO_SUBBAND_GSC: device buffers of the chain (indices into ds_handle::chain_buf; "c" = complex64)
+enum {
+    G_XN = 0,        // [B][M][n]        input after the DC notch
+    G_XA = 1,        // [B][M][n]        time-aligned channels
+    G_FIXED = 2,     // [B][n]           fixed beamformer output (channel mean)
+    G_D = 3,         // c[B][T][K][M]    STFT of the aligned channels
+    G_P = 4,         // [B][T][K]        McSpp speech presence probability
+    G_F = 6,         // c[B][T][K]       STFT of the fixed beamformer output
+    G_E = 8,         // c[B*M][T][K]     blocking-filter errors
+    G_BM = 9,        // [B][M][n]        blocking-matrix outputs in the time domain
+    G_XAIC = 10,     // c[B][T][K][M]    their STFT: the canceller's input
+    G_E2 = 12,       // c[B][T][K]       canceller error = output spectrum
+    G_FPREV = 13,    // c[B][K]          state: F of the previous block (delay_fbf in the spectral domain)
+    G_FIXPREV = 14,  // [B][hop]         state: fixed beamformer output of the previous block
+    G_COUNT = 15
+};
 int chain_reserve(ds_handle* h, int T);
 int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
                          int n_samples, float* y_dev, long long y_batch_stride);
