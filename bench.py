@@ -126,7 +126,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--algo", default="mvdr", choices=["mvdr", "gsc", "fixed"],
                     help="mvdr = BASELINE cfg2 (the headline); gsc = cfg3 (use --batch 4096); fixed = cfg1 on the GPU")
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="BASELINE config: cfg2 = the headline (default); cfg3 = --algo gsc --batch 4096; cfg4 / cfg5 = the chain handles "
+                         "(scripts/bench_cfg4.py, scripts/bench_cfg5.py: single GPU, one JSON line per regime)")
     args = ap.parse_args()
+    if args.config in ("cfg4", "cfg5"):
+        import runpy
+        sys.argv = [sys.argv[0]]
+        runpy.run_path(os.path.join(ROOT, "scripts", "bench_%s.py" % args.config), run_name="__main__")
+        return
+    if args.config == "cfg3":
+        args.algo = "gsc"
+        if args.batch == BATCH:
+            args.batch = 4096
 
     import torch
     from distantspeech_amd import BatchEngine, dist as dsdist
