@@ -72,3 +72,17 @@ def test_library_is_not_older_than_its_sources():
     srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hpp", ".hip"))] + [os.path.join(ROOT, "include", "dsenh.h")]
     newest = max(os.path.getmtime(f) for f in srcs)
     assert os.path.getmtime(L.LIB_PATH) >= newest, "libdsenh.so is older than its sources: run __graft_entry__.build()"
+
+
+def test_integration_stub_matches_the_header():
+    """the ctypes struct a reference maintainer would paste from INTEGRATION.md has the size ds_create() checks."""
+    import ctypes
+    import re
+    from distantspeech_amd import _lib as L
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class _Cfg\(ctypes\.Structure\):.*?\n\n", text, re.S)
+    assert m, "INTEGRATION.md lost its ds_config stub"
+    ns = {"ctypes": ctypes}
+    exec(m.group(0), ns)
+    assert ctypes.sizeof(ns["_Cfg"]) == ctypes.sizeof(L.ds_config)
+    assert [f[0] for f in ns["_Cfg"]._fields_] == [f[0] for f in L.ds_config._fields_]
