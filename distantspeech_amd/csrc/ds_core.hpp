@@ -615,6 +615,9 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
 template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
     static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2;
     static constexpr int NT = NC;                            // one thread per bin 0..NC-1
+    // 512-point frames: every stage is radix-4 with exactly 64 butterflies per channel, so a channel's transform never leaves its
+    // wavefront (the 128- and 512-point plans end in a radix-2 stage with a different butterfly-to-lane map and keep their barriers)
+    static constexpr bool WAVE_FFT = NC == 256;
     static constexpr int NYQ_TID = NT > 64 ? 64 : 0;         // thread (wave 1) that also runs the Nyquist bin k = NC
     static constexpr int INV_T0 = NT / 2;                    // inverse-FFT butterflies run on threads [NT/2, NT)
     static constexpr int KP = (K + 3) & ~3;                  // padded plane length
@@ -747,16 +750,19 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         for (int t = 0; t < T_run; ++t) {
             const int new_half = old_half ^ 1;
             // ---- hop t into LDS, start fetching hop t+1 ------------------------------------------
-            ex.phase([&](int tid, Rg& r) {
+            // WAVE_FFT: a channel's transform lives inside one wavefront from the staging of its samples to the last stage, so those
+            // hand-offs need no workgroup barrier (the interleaved input layout scatters the staging across channels and keeps its barrier).
+            auto ph = [&](bool wave_local, auto f) { if (wave_local) ex.phase_wave(f); else ex.phase(f); };
+            ph(WAVE_FFT && p.x_sample_stride == 1, [&](int tid, Rg& r) {
                 commit(p, sh, new_half, tid, r);
                 if (t + 1 < p.T) prefetch(p, xb, t + 1, tid, r);
             });
             // ---- forward FFT: M packed real transforms -------------------------------------------
             cf* fa = &sh.fa[0][0];
             cf* fb = &sh.fb[0][0];
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half, M); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0, M); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0, M); });
+            ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half, M); });
+            ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0, M); });
+            ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0, M); });
             if (NC == 128) {
                 ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0, M); });
             } else {
@@ -817,9 +823,9 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tb.tw[k]));
                 fa[k] = mk(E.x - O.y, E.y + O.x);                       // E + j O
             });
-            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 0, 1>(tid - INV_T0, NT, sh, fa, fb, 1, 0, 1); });
-            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 1, 2>(tid - INV_T0, NT, sh, fb, fa, 4, 0, 1); });
-            ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 2, 0>(tid - INV_T0, NT, sh, fa, fb, 16, 0, 1); });
+            ph(WAVE_FFT, [&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 0, 1>(tid - INV_T0, NT, sh, fa, fb, 1, 0, 1); });
+            ph(WAVE_FFT, [&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 1, 2>(tid - INV_T0, NT, sh, fb, fa, 4, 0, 1); });
+            ph(WAVE_FFT, [&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 2, 0>(tid - INV_T0, NT, sh, fa, fb, 16, 0, 1); });
             if (NC == 128) {
                 ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid - INV_T0, NT, sh, fb, fa, 64, 0, 1); });
             } else {
@@ -908,15 +914,16 @@ template <int NFFT, int M> struct StftEngine {
         });
         for (int t = 0; t < p.T; ++t) {
             const int new_half = old_half ^ 1;
-            ex.phase([&](int tid, Rg& r) {
+            auto ph = [&](bool wave_local, auto f) { if (wave_local) ex.phase_wave(f); else ex.phase(f); };   // see Engine::run
+            ph(EB::WAVE_FFT && p.x_sample_stride == 1, [&](int tid, Rg& r) {
                 EB::commit(p, sh, new_half, tid, r);
                 if (t + 1 < p.T) EB::prefetch(p, xb, t + 1, tid, r);
             });
             cf* fa = &sh.fa[0][0];
             cf* fb = &sh.fb[0][0];
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half, M); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0, M); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0, M); });
+            ph(EB::WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half, M); });
+            ph(EB::WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0, M); });
+            ph(EB::WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0, M); });
             if (NC == 128) {
                 ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0, M); });
             } else {
@@ -1002,9 +1009,11 @@ template <int NFFT, int M> struct IstftEngine {
                     fa[c * Sh::NCP + k] = mk(E.x - O.y, E.y + O.x);
                 }
             });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 0, 1>(tid, NT, sh, fa, fb, 1, 0, C); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 1, 2>(tid, NT, sh, fb, fa, 4, 0, C); });
-            ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 2, 0>(tid, NT, sh, fa, fb, 16, 0, C); });
+            auto ph = [&](bool wave_local, auto f) { if (wave_local) ex.phase_wave(f); else ex.phase(f); };   // see Engine::run
+            constexpr bool WAVE_FFT = NC == 256;
+            ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 0, 1>(tid, NT, sh, fa, fb, 1, 0, C); });
+            ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 1, 2>(tid, NT, sh, fb, fa, 4, 0, C); });
+            ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 2, 0>(tid, NT, sh, fa, fb, 16, 0, C); });
             if (NC == 128) {
                 ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid, NT, sh, fb, fa, 64, 0, C); });
             } else {

@@ -88,9 +88,13 @@ template <int NFFT, int CMAX> struct FdafEngine {
     template <int SIGN, class Exec> static DS_HD cf* fft(Exec& ex, Sh& sh, int C) {
         cf* fa = &sh.fa[0][0];
         cf* fb = &sh.fb[0][0];
-        ex.phase([&](int tid, Rg&) { fft_stage<NFFT, CMAX, 4, SIGN, false, 0, 1>(tid, NT, sh, fa, fb, 1, 0, C); });
-        ex.phase([&](int tid, Rg&) { fft_stage<NFFT, CMAX, 4, SIGN, false, 1, 2>(tid, NT, sh, fb, fa, 4, 0, C); });
-        ex.phase([&](int tid, Rg&) { fft_stage<NFFT, CMAX, 4, SIGN, false, 2, 0>(tid, NT, sh, fa, fb, 16, 0, C); });
+        // 256-point plans (filter_len 256): 64 radix-4 butterflies per channel in every stage, i.e. a channel stays inside one wavefront
+        // between the stages and those hand-offs need no workgroup barrier (ds_core.hpp Engine::run)
+        constexpr bool WAVE_FFT = NC == 256;
+        auto ph = [&](bool wave_local, auto f) { if (wave_local) ex.phase_wave(f); else ex.phase(f); };
+        ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, CMAX, 4, SIGN, false, 0, 1>(tid, NT, sh, fa, fb, 1, 0, C); });
+        ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, CMAX, 4, SIGN, false, 1, 2>(tid, NT, sh, fb, fa, 4, 0, C); });
+        ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, CMAX, 4, SIGN, false, 2, 0>(tid, NT, sh, fa, fb, 16, 0, C); });
         if (NC == 128) {
             ex.phase([&](int tid, Rg&) { fft_stage<NFFT, CMAX, 2, SIGN, false, 0, 0>(tid, NT, sh, fb, fa, 64, 0, C); });
         } else if (NC >= 256) {

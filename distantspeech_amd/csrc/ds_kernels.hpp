@@ -49,6 +49,16 @@ template <class Rg> struct HipExec {
         f(tid, r);
         __syncthreads();
     }
+    // a phase whose LDS results are consumed by the same wavefront only (the caller guarantees it): no workgroup barrier — the LDS
+    // executes one wave's accesses in order, the fence keeps the compiler from moving them across the phase boundary
+    template <class F> __device__ __forceinline__ void phase_wave(F f) {
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        f(tid, r);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 };
 
 // waves per SIMD the register allocator must leave room for.  The 4-microphone kernels live at the 128-VGPR step (4 waves / SIMD = 4

@@ -19,6 +19,7 @@ template <class Rg> struct CpuExec {
     template <class F> void phase(F f) {
         for (int t = 0; t < nt; ++t) f(t, R[t]);
     }
+    template <class F> void phase_wave(F f) { phase(f); }       // wave-local hand-off: the same thing when run serially
 };
 
 template <int NFFT, int M, int ALGO, bool RYY> int run_t(ds::Params p, int batch) {
