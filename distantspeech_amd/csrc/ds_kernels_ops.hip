@@ -1,5 +1,6 @@
 // ds_kernels_ops.hip — stand-alone STFT / ISTFT kernels and the frame-level (utterance, bin) operator
 // kernel (MCRA, McMcra, NsOmlsaMulti, subband LMS / RLS) for gfx950.
+#include <cstdint>
 #include "ds_kernels.hpp"
 #include "ds_ops.hpp"
 #include "ds_tdfilter.hpp"
@@ -69,58 +70,92 @@ hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
-// FilterDcNotch16 (ds_ops.hpp td_dcnotch is the definition; same arithmetic, same order).  The recursion is serial in time, so a
-// lane owns one (utterance, channel) row; the rows of a block move through LDS in 64 x 64 tiles so that global loads and stores are
-// 256-byte row segments instead of one cache line per lane.
-constexpr int NOTCH_ROWS = 64, NOTCH_TS = 64;
-__global__ void __launch_bounds__(NOTCH_ROWS) ds_dcnotch_kernel(TdParams p) {
-    __shared__ float tile[2][NOTCH_ROWS][NOTCH_TS + 1];
-    const int lane = threadIdx.x, row0 = blockIdx.x * NOTCH_ROWS, rows = p.B * p.M;
-    const int my = row0 + lane;
+// FilterDcNotch16 (ds_ops.hpp td_dcnotch is the definition; same arithmetic, same order).  The recursion is serial in time, so one
+// lane owns one (utterance, channel) row and the rows are the only parallelism the arithmetic has: a workgroup takes 32 rows, and
+// its four wavefronts split the work by role.  All 256 lanes move 32 x 256-sample tiles between HBM and LDS as 16-byte accesses
+// (1 KB row segments per wave instruction, the next tile's loads in flight behind the current tile); wave 0 runs the recursion of
+// its 32 rows in place in LDS, 16 samples per register chunk with the next chunk already loading.
+constexpr int NOTCH_ROWS = 32, NOTCH_TS = 256, NOTCH_NT = 256, NOTCH_LD = NOTCH_TS + 4, NOTCH_RPT = NOTCH_ROWS * NOTCH_TS / 4 / NOTCH_NT;
+template <bool VEC> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kernel(TdParams p) {
+    __shared__ __attribute__((aligned(16))) float tile[2][NOTCH_ROWS][NOTCH_LD];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, row0 = blockIdx.x * NOTCH_ROWS, rows = p.B * p.M;
     const float r = p.radius;
     const float den2 = fma_(r, r, 0.7f * (1.0f - r) * (1.0f - r));
+    const bool rec = wv == 0 && lane < NOTCH_ROWS && row0 + lane < rows;      // this lane runs the recursion of row `lane`
     float m0 = 0.0f, m1 = 0.0f;
-    if (my < rows) { m0 = p.mem[(long long)my * 2]; m1 = p.mem[(long long)my * 2 + 1]; }
-    // row c of the block starts at xr[c] (computed once; lane c holds it, read back through LDS-free shuffles is not needed:
-    // every lane recomputes the 64 bases from (b, m) arithmetic only once per call)
-    const float* base[NOTCH_ROWS / 16][16];
+    if (rec) { m0 = p.mem[(long long)(row0 + lane) * 2]; m1 = p.mem[(long long)(row0 + lane) * 2 + 1]; }
+    // the NOTCH_RPT rows this lane moves: wv, wv + 4, ...; column 4 * lane
+    const float* src[NOTCH_RPT];
+    float* dst[NOTCH_RPT];
 #pragma unroll
-    for (int g = 0; g < NOTCH_ROWS / 16; ++g)
+    for (int j = 0; j < NOTCH_RPT; ++j) {
+        const int rr = row0 + wv + 4 * j < rows ? row0 + wv + 4 * j : rows - 1;
+        const int b = rr / p.M, m = rr - b * p.M;
+        src[j] = (p.x_bstride ? p.x + (long long)b * p.x_bstride + (long long)m * p.x_cstride : p.x + (long long)rr * p.n) + 4 * lane;
+        dst[j] = p.y + (long long)rr * p.n + 4 * lane;
+    }
+    vec4 v[NOTCH_RPT];
+    auto fetch = [&](int s0) {
+        const int left = p.n - s0 - 4 * lane;                                 // samples of the row at or after this lane's column
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int rr = row0 + g * 16 + u < rows ? row0 + g * 16 + u : rows - 1;
-            const int b = rr / p.M, m = rr - b * p.M;
-            base[g][u] = p.x_bstride ? p.x + (long long)b * p.x_bstride + (long long)m * p.x_cstride : p.x + (long long)rr * p.n;
+        for (int j = 0; j < NOTCH_RPT; ++j) {
+            if (VEC) {
+                v[j] = left > 0 ? *reinterpret_cast<const vec4*>(src[j] + s0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            } else {
+                v[j].x = left > 0 ? src[j][s0] : 0.0f; v[j].y = left > 1 ? src[j][s0 + 1] : 0.0f;
+                v[j].z = left > 2 ? src[j][s0 + 2] : 0.0f; v[j].w = left > 3 ? src[j][s0 + 3] : 0.0f;
+            }
         }
-    float v[NOTCH_ROWS];
-    auto fetch = [&](int s0) {                                              // all 64 row segments of a tile in flight at once
-        const bool on = s0 + lane < p.n;
-#pragma unroll
-        for (int g = 0; g < NOTCH_ROWS / 16; ++g)
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[g * 16 + u] = on ? base[g][u][s0 + lane] : 0.0f;
     };
     fetch(0);
     int cur = 0;
     for (int s0 = 0; s0 < p.n; s0 += NOTCH_TS, cur ^= 1) {
         const int ns = p.n - s0 < NOTCH_TS ? p.n - s0 : NOTCH_TS;
 #pragma unroll
-        for (int c = 0; c < NOTCH_ROWS; ++c) tile[cur][c][lane] = v[c];
+        for (int j = 0; j < NOTCH_RPT; ++j) *reinterpret_cast<vec4*>(&tile[cur][wv + 4 * j][4 * lane]) = v[j];
         __syncthreads();
-        if (s0 + NOTCH_TS < p.n) fetch(s0 + NOTCH_TS);                       // next tile's loads fly behind this tile's recursion
-        if (my < rows)
-            for (int i = 0; i < ns; ++i) {
-                const float vin = tile[cur][lane][i];
+        if (s0 + NOTCH_TS < p.n) fetch(s0 + NOTCH_TS);                         // next tile's loads fly behind this tile's recursion
+        if (rec) {
+            float* row = tile[cur][lane];
+            auto step = [&](float vin) {
                 const float vout = m0 + vin;
                 m0 = m1 + 2.0f * (-vin + r * vout);
                 m1 = vin - den2 * vout;
-                tile[cur][lane][i] = r * vout;
+                return r * vout;
+            };
+            const int nfull = ns & ~15;
+            vec4 a[4], nx[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nx[q] = a[q] = *reinterpret_cast<const vec4*>(row + 4 * q);
+            for (int i = 0; i < nfull; i += 16) {
+                if (i + 16 < nfull) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) nx[q] = *reinterpret_cast<const vec4*>(row + i + 16 + 4 * q);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a[q].x = step(a[q].x); a[q].y = step(a[q].y); a[q].z = step(a[q].z); a[q].w = step(a[q].w); }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { *reinterpret_cast<vec4*>(row + i + 4 * q) = a[q]; a[q] = nx[q]; }
             }
+            for (int i = nfull; i < ns; ++i) row[i] = step(row[i]);
+        }
         __syncthreads();
-        for (int c = 0; c < NOTCH_ROWS && row0 + c < rows; ++c)
-            if (lane < ns) p.y[(long long)(row0 + c) * p.n + s0 + lane] = tile[cur][c][lane];
+        const int left = ns - 4 * lane;
+#pragma unroll
+        for (int j = 0; j < NOTCH_RPT; ++j) {
+            if (row0 + wv + 4 * j >= rows || left <= 0) continue;
+            const vec4 o = *reinterpret_cast<const vec4*>(&tile[cur][wv + 4 * j][4 * lane]);
+            if (VEC) {
+                *reinterpret_cast<vec4*>(dst[j] + s0) = o;
+            } else {
+                dst[j][s0] = o.x;
+                if (left > 1) dst[j][s0 + 1] = o.y;
+                if (left > 2) dst[j][s0 + 2] = o.z;
+                if (left > 3) dst[j][s0 + 3] = o.w;
+            }
+        }
     }
-    if (my < rows) { p.mem[(long long)my * 2] = m0; p.mem[(long long)my * 2 + 1] = m1; }
+    if (rec) { p.mem[(long long)(row0 + lane) * 2] = m0; p.mem[(long long)(row0 + lane) * 2 + 1] = m1; }
 }
 
 // TimeAlignment FIR bank (td_fir is the definition).  One block = one utterance x FIR_TS consecutive outputs, a lane = 4 consecutive
@@ -212,7 +247,12 @@ __global__ void __launch_bounds__(256) ds_fir_cache_kernel(TdParams p) {
 }
 
 hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(ds_dcnotch_kernel, dim3((p.B * p.M + NOTCH_ROWS - 1) / NOTCH_ROWS), dim3(NOTCH_ROWS), 0, stream, p);
+    const dim3 grid((p.B * p.M + NOTCH_ROWS - 1) / NOTCH_ROWS);
+    // 16-byte accesses when every row of x and y starts on a 16-byte boundary and holds a multiple of 4 samples
+    const bool vec = p.n % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.y)) % 16 == 0 &&
+                     (p.x_bstride ? (p.x_bstride % 4 == 0 && p.x_cstride % 4 == 0) : true);
+    if (vec) hipLaunchKernelGGL(ds_dcnotch_kernel<true>, grid, dim3(NOTCH_NT), 0, stream, p);
+    else hipLaunchKernelGGL(ds_dcnotch_kernel<false>, grid, dim3(NOTCH_NT), 0, stream, p);
     return hipGetLastError();
 }
 hipError_t launch_fir(const TdParams& p, hipStream_t stream) {

@@ -285,6 +285,25 @@ def test_frontend_mirrors(ds):
     assert np.allclose(out[25:], z[:-25]) and np.all(out[:25] == 0)
 
 
+def test_dcnotch_shapes(ds):
+    """The notch kernel's tiling (32-row workgroups, 256-sample tiles, 16-sample register chunks) over ragged shapes: rows that do not
+    fill a workgroup, lengths that are not multiples of 16 or 4 (the scalar-access variant), several tiles, chunked == one call."""
+    from oracle import ds_oracle as O
+    from distantspeech_amd.engine import BatchEngine
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(11)
+    for B, M, n in [(5, 3, 1000), (11, 6, 777), (1, 1, 3), (40, 2, 530)]:
+        x = (rng.standard_normal((B, M, n)) * 0.1 + 0.05).astype(np.float32)
+        e1 = BatchEngine(L.ALGO_FRONTEND, M, 512, batch=B, filt_alpha=0.97)
+        y = e1.dcnotch(x)
+        ref = np.stack([[O.OracleDcNotch(0.97).filter(x[b, m].astype(np.float64)) for m in range(M)] for b in range(B)])
+        assert np.max(np.abs(y - ref)) < 2e-5, (B, M, n)
+        e2 = BatchEngine(L.ALGO_FRONTEND, M, 512, batch=B, filt_alpha=0.97)
+        cuts = [0, n // 3, n // 3 + 1, n]
+        yc = np.concatenate([e2.dcnotch(x[:, :, a:b]) for a, b in zip(cuts[:-1], cuts[1:]) if b > a], axis=2)
+        assert np.array_equal(y, yc), (B, M, n)
+
+
 def test_td_filters(ds):
     """BaseFilter.update / Rls.update (sample-wise definitions) vs the reference."""
     g = load("g13_tdfilters")
