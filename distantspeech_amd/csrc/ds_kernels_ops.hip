@@ -51,10 +51,11 @@ KernelInfo lookup_istft(int nfft, int M) {
 }
 
 template <int OP, int M> __global__ void __launch_bounds__(256) ds_binop_kernel(OpParams p) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
     const int b = (int)(i / p.KP), k = (int)(i - (long long)b * p.KP);
     if (b >= p.B || k >= p.K) return;
-    run_op_t<OP, M>(p, b, k);
+    const OpCtx c = make_op_ctx(p, i0);
+    run_op_t<OP, M>(c, b, k);
 }
 
 hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream) {
@@ -158,92 +159,139 @@ template <bool VEC> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kerne
     if (rec) { p.mem[(long long)(row0 + lane) * 2] = m0; p.mem[(long long)(row0 + lane) * 2 + 1] = m1; }
 }
 
-// TimeAlignment FIR bank (td_fir is the definition).  One block = one utterance x FIR_TS consecutive outputs, a lane = 4 consecutive
-// outputs of every channel.  The input window (history from the cache, then x) sits in LDS split into 4 phase arrays (sample 4q + c at
-// [c][q]) so that the lanes' reads are consecutive words for any tap; the taps slide through registers: one LDS read of x and one
-// (broadcast) read of a coefficient per 4 multiply-adds.  Every output accumulates its taps in the order j = 0 .. L-1, like td_fir.
-constexpr int FIR_TS = 512, FIR_NT = FIR_TS / 4, FIR_MMAX = 16, FIR_LMAX = 120, FIR_PAD = 8;
-__global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdParams p) {
-    extern __shared__ float lds[];
-    const int M = p.M, L = p.L, b = blockIdx.y, i0 = blockIdx.x * FIR_TS;
-    const int nt = p.n - i0 < FIR_TS ? p.n - i0 : FIR_TS;                 // outputs of this tile
-    const int W = FIR_TS + FIR_LMAX + FIR_PAD;                             // window samples kept per channel (4 phases x W / 4)
-    float* xs = lds;                                                       // [M][4][W / 4]
-    float* cs = lds + (size_t)M * W;                                       // [L][M]
-    const int tid = threadIdx.x;
-    for (int i = tid; i < L * M; i += FIR_NT) cs[i] = p.coef[i];
-    for (int i = tid; i < M * FIR_PAD; i += FIR_NT) {                      // zero entries in front of the window: taps past L read them
-        const int m = i / FIR_PAD, w = i - m * FIR_PAD;
-        xs[(size_t)m * W + (w & 3) * (W / 4) + (w >> 2)] = 0.0f;
+// TimeAlignment FIR bank (td_fir is the definition).  One single-wave block = one utterance x 64 * OPL consecutive outputs, a lane =
+// OPL consecutive outputs of every channel (OPL = 8, or 4 for calls of one 256-sample block).  The input window (history from the
+// cache, then x) sits in LDS split into OPL phase rows (sample w at [w % OPL][w / OPL]) so that the lanes' reads are consecutive words
+// for any tap; the coefficients sit transposed ([M][L], zero-padded to a multiple of OPL) and are read 16 bytes at a time.  Taps go in
+// blocks of OPL: a block needs the 2 * OPL - 1 samples x[o0 - jb - OPL + 1 .. o0 - jb + OPL - 1], kept as two register rows that swap
+// roles from block to block (OPL new LDS words and OPL coefficients per OPL * OPL multiply-adds, no register shuffling).  Every
+// output accumulates its taps in the order j = 0 .. L-1, like td_fir.  The block of the last tile also leaves the last L - 1 input
+// samples in the other half of the history ping-pong (td_fir_cache).
+constexpr int FIR_NT = 64, FIR_MMAX = 16, FIR_LMAX = 120;
+template <int OPL> struct FirShape {
+    static constexpr int TS = FIR_NT * OPL, PAD = OPL;                      // PAD zero entries in front: taps past L read them
+    static constexpr int RMIN = (TS + FIR_LMAX - 1 + PAD + OPL - 1) / OPL;  // words per phase row
+    static constexpr int UNIT = 64 / OPL;                                   // row length = UNIT x odd: staging stores are conflict-free
+    static constexpr int RL = ((RMIN + UNIT - 1) / UNIT | 1) * UNIT;
+    static constexpr int LOG = OPL == 8 ? 3 : 2;
+};
+template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdParams p) {
+    typedef FirShape<OPL> S;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int M = p.M, L = p.L, Lp = (L + OPL - 1) / OPL * OPL, b = blockIdx.y, i0 = blockIdx.x * S::TS, tid = threadIdx.x;
+    const int nt = p.n - i0 < S::TS ? p.n - i0 : S::TS;                    // outputs of this tile
+    float* xs = lds;                                                       // [M][OPL][RL]
+    float* cs = lds + (size_t)M * OPL * S::RL;                             // [M][Lp]
+    auto at = [&](int m, int w) { return m * (OPL * S::RL) + (w & (OPL - 1)) * S::RL + (w >> S::LOG); };   // w counts from the first pad entry
+    for (int i = tid; i < M * Lp; i += FIR_NT) {
+        const int m = i / Lp, j = i - m * Lp;
+        cs[i] = j < L ? p.coef[j * M + m] : 0.0f;
     }
-    const long long xs_s = p.x_chan_major ? 1 : M, xs_c = p.x_chan_major ? p.n : 1;
+    for (int i = tid; i < M * OPL; i += FIR_NT) xs[at(i >> S::LOG, i & (OPL - 1))] = 0.0f;
     const float* xb = p.x + (long long)b * p.n * M;
-    const float* cache = p.cache_in + (long long)b * (L - 1) * M;
-    // window index w = 0 .. nt + L - 2  <->  sample s = i0 + w - (L - 1)
-    const int nw = nt + L - 1, total = M * nw;
-    for (int base = 0; base < total; base += 8 * FIR_NT) {                 // 8 loads in flight per lane
-        float v[8];
-        int at[8];
+    // window entry w = 0 .. nt + L - 2  <->  sample s = i0 + w - (L - 1); s < 0 (first tile only: a tile is longer than the history)
+    // comes from the cache, which is sample-major like the window walk below
+    const int nw = nt + L - 1, hist = i0 == 0 ? L - 1 : 0;
+    {
+        const float* cache = p.cache_in + (long long)b * (L - 1) * M;
+        for (int idx = tid; idx < hist * M; idx += FIR_NT) {
+            const int w = idx / M, m = idx - w * M;
+            xs[at(m, w + S::PAD)] = cache[idx];
+        }
+    }
+    if (p.x_chan_major) {
+        for (int m = 0; m < M; ++m) {
+            const float* xm = xb + (long long)m * p.n + (i0 - (L - 1));
+            for (int w0 = hist; w0 < nw; w0 += 8 * FIR_NT) {               // 8 loads in flight per lane
+                float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = base + u * FIR_NT + tid;
-            at[u] = -1;
-            v[u] = 0.0f;
-            if (idx < total) {
-                const int m = idx / nw, w = idx - m * nw;
-                const int s = i0 + w - (L - 1);
-                v[u] = s >= 0 ? xb[(long long)s * xs_s + m * xs_c] : cache[(long long)(L - 1 + s) * M + m];
-                at[u] = m * W + ((w + FIR_PAD) & 3) * (W / 4) + ((w + FIR_PAD) >> 2);
+                for (int u = 0; u < 8; ++u) { const int w = w0 + u * FIR_NT + tid; v[u] = w < nw ? xm[w] : 0.0f; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int w = w0 + u * FIR_NT + tid; if (w < nw) xs[at(m, w + S::PAD)] = v[u]; }
             }
         }
+    } else {
+        const float* xw = xb + (long long)(i0 + hist - (L - 1)) * M;       // [nw - hist][M], contiguous
+        const int total = (nw - hist) * M;
+        for (int base = 0; base < total; base += 8 * FIR_NT) {
+            float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (at[u] >= 0) xs[at[u]] = v[u];
+            for (int u = 0; u < 8; ++u) { const int idx = base + u * FIR_NT + tid; v[u] = idx < total ? xw[idx] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * FIR_NT + tid;
+                if (idx < total) { const int w = idx / M, m = idx - w * M; xs[at(m, w + hist + S::PAD)] = v[u]; }
+            }
+        }
     }
     __syncthreads();
-    const int o0 = 4 * tid;                                                // first output of this lane within the tile
+    if (p.cache_out != nullptr && L > 1 && blockIdx.x == gridDim.x - 1) {  // history for the next call: the last L - 1 samples
+        float* co = p.cache_out + (long long)b * (L - 1) * M;
+        for (int idx = tid; idx < (L - 1) * M; idx += FIR_NT) {
+            const int i = idx / M, m = idx - i * M;
+            co[idx] = xs[at(m, i + nt + S::PAD)];
+        }
+    }
+    const int o0 = OPL * tid;                                              // first output of this lane within the tile
     if (o0 >= nt) return;
-    float mean[4] = {0.0f, 0.0f, 0.0f, 0.0f}, prev[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool vec = p.y_chan_major && p.n % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0;
+    float mean[OPL], prev[OPL];
+#pragma unroll
+    for (int o = 0; o < OPL; ++o) { mean[o] = 0.0f; prev[o] = 0.0f; }
     for (int m = 0; m < M; ++m) {
-        const float* xm = xs + (size_t)m * W;
-        auto X = [&](int e) {                                              // x[i0 + o0 + e]; window index (+ FIR_PAD zero entries in front)
-            const int w = o0 + e + (L - 1) + FIR_PAD;
-            return xm[(w & 3) * (W / 4) + (w >> 2)];
+        const float* xm = xs + m * (OPL * S::RL) + tid;
+        const float* cm = cs + m * Lp;
+        // row k of the window: H_k[i] = x[i0 + o0 - OPL * k + i]
+        auto row = [&](int k, float* h) {
+            const int w = (L - 1) + S::PAD - OPL * k;                      // + o0 = OPL * tid: same phase, word offset tid
+#pragma unroll
+            for (int i = 0; i < OPL; ++i) h[i] = xm[((w + i) & (OPL - 1)) * S::RL + ((w + i) >> S::LOG)];
         };
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        // taps in blocks of 4: outputs o = 0..3 take tap jb + u from x[o - u - jb]: 7 window values per block, 3 of them carried over
-        float xw[7];                                                       // xw[e + 3] = x[o0 - jb + e], e = -3 .. 3
-        xw[4] = X(1); xw[5] = X(2); xw[6] = X(3);
-        xw[3] = X(0);
-        for (int jb = 0; jb < L; jb += 4) {
-            xw[0] = X(-jb - 3); xw[1] = X(-jb - 2); xw[2] = X(-jb - 1);
-            float cj[4];
+        float acc[OPL];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) cj[u] = jb + u < L ? cs[(jb + u) * M + m] : 0.0f;
+        for (int o = 0; o < OPL; ++o) acc[o] = 0.0f;
+        auto block = [&](int jb, const float* hi, const float* lo) {       // taps jb .. jb + OPL - 1: x[o - u] = hi[o - u] or lo[OPL + o - u]
+            float c[OPL];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)                                    // tap order j = jb + u ascending for every output
+            for (int q = 0; q < OPL / 4; ++q) {
+                const vec4 c4 = *reinterpret_cast<const vec4*>(cm + jb + 4 * q);
+                c[4 * q] = c4.x; c[4 * q + 1] = c4.y; c[4 * q + 2] = c4.z; c[4 * q + 3] = c4.w;
+            }
 #pragma unroll
-                for (int o = 0; o < 4; ++o) acc[o] = fma_(cj[u], xw[o - u + 3], acc[o]);
-            xw[6] = xw[2]; xw[5] = xw[1]; xw[4] = xw[0];                   // next block: base moves 4 samples back
-            xw[3] = X(-jb - 4);
+            for (int u = 0; u < OPL; ++u)                                  // tap order ascending for every output
+#pragma unroll
+                for (int o = 0; o < OPL; ++o) acc[o] = fma_(c[u], o >= u ? hi[o - u] : lo[OPL + o - u], acc[o]);
+        };
+        float P[OPL], Q[OPL];
+        row(0, P); row(1, Q);
+        for (int jb = 0, k = 0; jb < Lp; jb += 2 * OPL, k += 2) {
+            block(jb, P, Q);
+            if (jb + OPL < Lp) {
+                row(k + 2, P);
+                block(jb + OPL, Q, P);
+                if (jb + 2 * OPL < Lp) row(k + 3, Q);
+            }
+        }
+        if (vec && o0 + OPL <= nt) {
+            float* dst = p.y + ((long long)b * M + m) * p.n + i0 + o0;
+#pragma unroll
+            for (int q = 0; q < OPL / 4; ++q) *reinterpret_cast<vec4*>(dst + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
         }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
+        for (int o = 0; o < OPL; ++o) {
             const int i = i0 + o0 + o;
             if (o0 + o >= nt) break;
-            if (p.y_chan_major) p.y[((long long)b * M + m) * p.n + i] = acc[o];
-            else p.y[((long long)b * p.n + i) * M + m] = acc[o];
+            if (!(vec && o0 + OPL <= nt)) {
+                if (p.y_chan_major) p.y[((long long)b * M + m) * p.n + i] = acc[o];
+                else p.y[((long long)b * p.n + i) * M + m] = acc[o];
+            }
             mean[o] += acc[o];
             if (p.diff && m > 0) p.diff[((long long)b * p.n + i) * (M - 1) + m - 1] = prev[o] - acc[o];
             prev[o] = acc[o];
         }
     }
     if (p.mean)
-        for (int o = 0; o < 4 && o0 + o < nt; ++o) p.mean[(long long)b * p.n + i0 + o0 + o] = mean[o] / (float)M;
-}
-__global__ void __launch_bounds__(256) ds_fir_cache_kernel(TdParams p) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (long long)p.B * (p.L - 1)) td_fir_cache(p, (int)(i / (p.L - 1)), (int)(i % (p.L - 1)));
+        for (int o = 0; o < OPL && o0 + o < nt; ++o) p.mean[(long long)b * p.n + i0 + o0 + o] = mean[o] / (float)M;
 }
 
 hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream) {
@@ -255,12 +303,15 @@ hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream) {
     else hipLaunchKernelGGL(ds_dcnotch_kernel<false>, grid, dim3(NOTCH_NT), 0, stream, p);
     return hipGetLastError();
 }
+template <int OPL> static void launch_fir_t(const TdParams& p, hipStream_t stream) {
+    typedef FirShape<OPL> S;
+    const int Lp = (p.L + OPL - 1) / OPL * OPL;
+    const size_t lds = ((size_t)p.M * OPL * S::RL + (size_t)p.M * Lp) * sizeof(float);
+    hipLaunchKernelGGL(ds_fir_kernel<OPL>, dim3((unsigned)((p.n + S::TS - 1) / S::TS), (unsigned)p.B), dim3(FIR_NT), lds, stream, p);
+}
 hipError_t launch_fir(const TdParams& p, hipStream_t stream) {
     if (p.M > FIR_MMAX || p.L > FIR_LMAX || p.L < 1) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)p.M * (FIR_TS + FIR_LMAX + FIR_PAD) + (size_t)p.L * p.M) * sizeof(float);
-    hipLaunchKernelGGL(ds_fir_kernel, dim3((unsigned)((p.n + FIR_TS - 1) / FIR_TS), (unsigned)p.B), dim3(FIR_NT), lds, stream, p);
-    if (p.L > 1)
-        hipLaunchKernelGGL(ds_fir_cache_kernel, dim3((unsigned)(((long long)p.B * (p.L - 1) + 255) / 256)), dim3(256), 0, stream, p);
+    if (p.n > 256) launch_fir_t<8>(p, stream); else launch_fir_t<4>(p, stream);
     return hipGetLastError();
 }
 

@@ -50,7 +50,40 @@ struct OpParams {
     float alpha_v, gate, diag;   // OP_ADAPTIVE: adaptivebeamformer.py:66,94,89
 };
 
-DS_HD float& st_at(const OpParams& p, int b, int f, int k) { return p.st[((long long)b * p.NF + f) * p.KP + k]; }
+// Per-bin state access st_at(p, b, plane, k).  On the GPU it is a buffer access: the descriptor starts at the state of the first utterance
+// of the workgroup (wave-uniform), the lane contributes ONE 32-bit offset and the plane offset travels in an SGPR — one address register
+// per lane instead of a 64-bit pointer per plane kept live from the loads to the stores (150 registers for the 75 planes of a 6-mic McSpp).
+#if defined(__HIP_DEVICE_COMPILE__)
+struct OpCtx : OpParams {
+    __amdgpu_buffer_rsrc_t rs;    // state from utterance b0 on
+    int b0;
+};
+struct StRef {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff, soff;
+    __device__ operator float() const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0)); }
+    __device__ void operator=(float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0); }
+    __device__ void operator=(const StRef& o) const { *this = (float)o; }       // st_at(..) = st_at(..) moves the value, not the reference
+    StRef(const StRef&) = default;
+    __device__ StRef(__amdgpu_buffer_rsrc_t rs_, unsigned v, unsigned s) : rs(rs_), voff(v), soff(s) {}
+};
+__device__ inline OpCtx make_op_ctx(const OpParams& p0, long long first_lane) {       // first_lane: flat (b, k) index of the workgroup's lane 0
+    OpCtx c;
+    static_cast<OpParams&>(c) = p0;
+    c.b0 = (int)(first_lane / p0.KP);
+    const long long off = (long long)c.b0 * p0.NF * p0.KP;
+    const long long left = ((long long)p0.B * p0.NF * p0.KP - off) * 4;
+    c.rs = __builtin_amdgcn_make_buffer_rsrc(p0.st + off, 0, (int)(unsigned)(left > 0xffffffffLL ? 0xffffffffLL : (left > 0 ? left : 0)), 0x00020000);
+    return c;
+}
+__device__ inline StRef st_at(const OpCtx& p, int b, int f, int k) {
+    return StRef(p.rs, (unsigned)(((b - p.b0) * p.NF * p.KP + k) * 4), (unsigned)(f * p.KP * 4));
+}
+#else
+typedef OpParams OpCtx;
+DS_HD OpCtx make_op_ctx(const OpParams& p0, long long) { return p0; }
+DS_HD float& st_at(const OpCtx& p, int b, int f, int k) { return p.st[((long long)b * p.NF + f) * p.KP + k]; }
+#endif
 
 // advance the uniform MCRA counters by one frame (mcra.py:52-56,72-74); returns `reset` for this frame
 DS_HD bool mcra_tick(int& frm, int& ell, int L) {
@@ -67,7 +100,7 @@ DS_HD float mcra_in(const OpParams& p, long long base, int k) {
     return p.in0[base + k];
 }
 
-DS_HD void op_mcra(const OpParams& p, int b, int k) {
+DS_HD void op_mcra(const OpCtx& p, int b, int k) {
     float st[5];
 #pragma unroll
     for (int f = 0; f < 5; ++f) st[f] = st_at(p, b, f, k);
@@ -91,7 +124,7 @@ DS_HD void op_mcra(const OpParams& p, int b, int k) {
 // McMcra: in0 = y complex [B][T][K][M]; out0 = p, out1 = G [B][T][K].
 // state: Phi_yy, Phi_vv (packed symmetric), then xi, gamma, p, G of the last frame (attributes users read)
 // ------------------------------------------------------------------------------------------------
-template <int M> DS_HD void op_mcmcra(const OpParams& p, int b, int k) {
+template <int M> DS_HD void op_mcmcra(const OpCtx& p, int b, int k) {
     constexpr int NS = M * (M + 1) / 2;
     float pyy[NS], pvv[NS];
 #pragma unroll
@@ -125,7 +158,7 @@ template <int M> DS_HD void op_mcmcra(const OpParams& p, int b, int k) {
 // ------------------------------------------------------------------------------------------------
 DS_HD int omlsa_nf(int M) { return 5 * M + (M - 1) + 8; }
 
-DS_HD void op_omlsa(const OpParams& p, int b, int k) {
+DS_HD void op_omlsa(const OpCtx& p, int b, int k) {
     const int M = p.M, K = p.K, R = M - 1;
     const int o_zy = 5 * M, o_zu = 5 * M + 1, o_s = 5 * M + 1 + R;   // o_s: lambda_d, gamma, G_H1, G, p, xi_hat, q_hat
     int frm = p.frm_cnt, ell = p.ell, first = p.first_frame;
@@ -227,7 +260,7 @@ DS_HD cf subband_d(const OpParams& p, int b, int t, int k) {
     else i = ((long long)b * p.T + t) * p.K + k;
     return mk(p.in1[2 * i], p.in1[2 * i + 1]);
 }
-DS_HD void subband_d_carry(const OpParams& p, int b, int k) {        // after the T frames: keep the last frame of in1 for the next call
+DS_HD void subband_d_carry(const OpCtx& p, int b, int k) {        // after the T frames: keep the last frame of in1 for the next call
     if (p.d_prev && p.T > 0) {
         const long long i = ((long long)b * p.T + p.T - 1) * p.K + k;
         p.d_prev[2 * ((long long)b * p.K + k)] = p.in1[2 * i];
@@ -235,7 +268,7 @@ DS_HD void subband_d_carry(const OpParams& p, int b, int k) {        // after th
     }
 }
 
-DS_HD void op_sublms_generic(const OpParams& p, int b, int k) {
+DS_HD void op_sublms_generic(const OpCtx& p, int b, int k) {
     const int N = p.N, C = p.M, NC2 = 2 * N * C;
     for (int t = 0; t < p.T; ++t) {
         const long long fb = ((long long)b * p.T + t) * p.K + k;
@@ -279,7 +312,7 @@ DS_HD void op_sublms_generic(const OpParams& p, int b, int k) {
 }
 
 // the same recursion with W, the tap buffer and P held in registers for the T frames of the call (state read once, written once)
-template <int N, int C> DS_HD void op_sublms_t(const OpParams& p, int b, int k) {
+template <int N, int C> DS_HD void op_sublms_t(const OpCtx& p, int b, int k) {
     constexpr int NC = N * C, NC2 = 2 * NC;
     cf W[NC], X[NC];
 #pragma unroll
@@ -327,7 +360,7 @@ template <int N, int C> DS_HD void op_sublms_t(const OpParams& p, int b, int k) 
     if (p.norm) st_at(p, b, 2 * NC2, k) = P;
 }
 
-DS_HD void op_sublms(const OpParams& p, int b, int k) {
+DS_HD void op_sublms(const OpCtx& p, int b, int k) {
     if (p.N == 2) {                                   // the reference's tap count everywhere it builds these filters
         switch (p.M) {
             case 1: return op_sublms_t<2, 1>(p, b, k);
@@ -347,7 +380,7 @@ DS_HD void op_sublms(const OpParams& p, int b, int k) {
 constexpr int RLS_NMAX = 4;
 DS_HD int subrls_nf(int N) { return 4 * N + 2 * N * N; }
 
-template <int N> DS_HD void op_subrls_t(const OpParams& p, int b, int k) {
+template <int N> DS_HD void op_subrls_t(const OpCtx& p, int b, int k) {
     constexpr int oX = 2 * N, oP = 4 * N;
     const float lam_inv = 1.0f / p.lam;
     cf W[N], X[N], P[N][N];                              // in registers for the T frames of the call
@@ -402,7 +435,7 @@ template <int N> DS_HD void op_subrls_t(const OpParams& p, int b, int k) {
     }
 }
 
-DS_HD void op_subrls(const OpParams& p, int b, int k) {
+DS_HD void op_subrls(const OpCtx& p, int b, int k) {
     switch (p.N) {
         case 1: return op_subrls_t<1>(p, b, k);
         case 2: return op_subrls_t<2>(p, b, k);
@@ -418,7 +451,7 @@ DS_HD void op_subrls(const OpParams& p, int b, int k) {
 // ------------------------------------------------------------------------------------------------
 DS_HD int mcsppbase_nf(int M) { return 2 * M * M + 5 + 3 + 2 * M; }
 
-template <int M> DS_HD void op_mcsppbase(const OpParams& p, int b, int k) {
+template <int M> DS_HD void op_mcsppbase(const OpCtx& p, int b, int k) {
     constexpr int NS = M * (M + 1) / 2, NO = M * (M - 1) / 2;
     float yd[M], yo[2 * NO + 1], vd[M], vo[2 * NO + 1], mc[5];
 #pragma unroll
@@ -689,7 +722,7 @@ template <int M> DS_HD void herm_unpack(const float* d, const float* o, cf (&A)[
 // in0 = y complex [B][T][K][M], in1 = Fn [K] (diffuse coherence of the pair); out0 = Gamma [B][T][K].
 // state floats: Pxii_1, Pxii_2, Re/Im Pxij_12, MCRA(5)
 // ------------------------------------------------------------------------------------------------
-DS_HD void op_mccdr(const OpParams& p, int b, int k) {
+DS_HD void op_mccdr(const OpCtx& p, int b, int k) {
     const int M = p.M;
     float p1 = st_at(p, b, 0, k), p2 = st_at(p, b, 1, k);
     cf x12 = mk(st_at(p, b, 2, k), st_at(p, b, 3, k));
@@ -747,7 +780,7 @@ DS_HD float mcspp_qavg(const float* gamma_frame, int fmin, int fmax) {
     return qsum / (float)(fmax - fmin);
 }
 
-template <int M, bool LEAN = false> DS_HD void op_mcspp(const OpParams& p, int b, int k) {
+template <int M, bool LEAN = false> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
     const int o0 = p.N;                                                            // state row offset of the McSpp part
     float yd[M], yo[2 * NO + 1], vd[M], vo[2 * NO + 1];
@@ -885,7 +918,7 @@ template <int M, bool LEAN = false> DS_HD void op_mcspp(const OpParams& p, int b
 // McSpp without the notebook-MVDR / matrix outputs (OP_MCSPP_LEAN, the SubbandGSC chain): the same estimation_core, but nothing here
 // needs inv(Phi_vv + dv I) as a matrix — tr(A^-1 Phi_yy), A^-1 y and the PMWF column are Cholesky solves on the Hermitian-packed state,
 // which is less work and fewer live registers than forming the explicit inverse (the kernel still sits at one wave per SIMD at M = 6).
-template <int M> DS_HD void op_mcspp_lean(const OpParams& p, int b, int k) {
+template <int M> DS_HD void op_mcspp_lean(const OpCtx& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
     const int o0 = p.N;
     float yd[M], yo[2 * NO + 1], vd[M], vo[2 * NO + 1];
@@ -972,7 +1005,7 @@ template <int M> DS_HD void op_mcspp_lean(const OpParams& p, int b, int k) {
 }
 
 // stateless: steering(XXs) — in0 = XX complex [B][K][M][M] -> out0 = v complex [B][K][M]
-template <int M> DS_HD void op_steering(const OpParams& p, int b, int k) {
+template <int M> DS_HD void op_steering(const OpCtx& p, int b, int k) {
     cf A[M][M], v[M];
     const long long base = ((long long)b * p.K + k) * M * M;
 #pragma unroll
@@ -992,7 +1025,7 @@ template <int M> DS_HD void op_steering(const OpParams& p, int b, int k) {
 }
 
 // stateless: compute_mvdr_weight — in0 = steer complex [B][K][M], in1 = Rvv_inv complex [B][K][M][M] -> out0 = w [B][K][M]
-template <int M> DS_HD void op_mvdrw(const OpParams& p, int b, int k) {
+template <int M> DS_HD void op_mvdrw(const OpCtx& p, int b, int k) {
     cf R[M][M], a[M], w[M];
     const long long rb = ((long long)b * p.K + k) * M * M, ab = ((long long)b * p.K + k) * M;
 #pragma unroll
@@ -1014,7 +1047,7 @@ template <int M> DS_HD void op_mvdrw(const OpParams& p, int b, int k) {
 // in0 = Z complex [B][T][K][M], in1 = optional post-filter gain [B][T][K] (has_p); out0 = Y complex [B][T][K] (= w^H Z * gain).
 // state floats: Rvv Hermitian-packed (M diagonal reals, M(M-1)/2 complex upper entries), MCRA S,Smin,Stmp,p,lambda_d
 // ------------------------------------------------------------------------------------------------
-template <int M> DS_HD void op_adaptive(const OpParams& p, int b, int k) {
+template <int M> DS_HD void op_adaptive(const OpCtx& p, int b, int k) {
     typedef StateLayout<M, ALGO_ADAPTIVE, false> SL;
     float st[SL::NF];
 #pragma unroll
@@ -1046,7 +1079,7 @@ template <int M> DS_HD void op_adaptive(const OpParams& p, int b, int k) {
     for (int f = 0; f < SL::NF; ++f) st_at(p, b, f, k) = st[f];
 }
 
-template <int OP, int M> DS_HD void run_op_t(const OpParams& p, int b, int k) {
+template <int OP, int M> DS_HD void run_op_t(const OpCtx& p, int b, int k) {
     if constexpr (OP == OP_MCRA) op_mcra(p, b, k);
     else if constexpr (OP == OP_OMLSA) op_omlsa(p, b, k);
     else if constexpr (OP == OP_SUBLMS) op_sublms(p, b, k);
@@ -1078,7 +1111,7 @@ inline bool op_supported(int op, int M) {
     DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_MCSPP_LEAN) DS_OP_M3_LIST(X, OP_STEERING) DS_OP_M3_LIST(X, OP_MVDRW)
 
 // runtime dispatch for the serial CPU run in tests/emul (the GPU launches one specialised kernel per (OP, M))
-inline void run_op(int op, const OpParams& p, int b, int k) {
+inline void run_op(int op, const OpCtx& p, int b, int k) {
 #define X(OP_, M_) if (op == OP_ && (!op_is_matrix(OP_) || p.M == M_)) { run_op_t<OP_, M_>(p, b, k); return; }
     DS_FOR_EACH_OP(X)
 #undef X
