@@ -160,86 +160,75 @@ template <bool VEC> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kerne
 }
 
 // TimeAlignment FIR bank (td_fir is the definition).  One single-wave block = one utterance x 64 * OPL consecutive outputs, a lane =
-// OPL consecutive outputs of every channel (OPL = 8, or 4 for calls of one 256-sample block).  The input window (history from the
-// cache, then x) sits in LDS split into OPL phase rows (sample w at [w % OPL][w / OPL]) so that the lanes' reads are consecutive words
-// for any tap; the coefficients sit transposed ([M][L], zero-padded to a multiple of OPL) and are read 16 bytes at a time.  Taps go in
-// blocks of OPL: a block needs the 2 * OPL - 1 samples x[o0 - jb - OPL + 1 .. o0 - jb + OPL - 1], kept as two register rows that swap
-// roles from block to block (OPL new LDS words and OPL coefficients per OPL * OPL multiply-adds, no register shuffling).  Every
-// output accumulates its taps in the order j = 0 .. L-1, like td_fir.  The block of the last tile also leaves the last L - 1 input
-// samples in the other half of the history ping-pong (td_fir_cache).
+// OPL consecutive outputs of every channel (OPL = 8, or 4 for calls of one 256-sample block).  Channels go through the block one at a
+// time: the input window of channel m (history from the cache, then x) sits in LDS while the window of channel m + 1 is already on
+// its way from memory into registers, so a block holds two windows (5 KB) instead of M and a CU keeps all its wave slots busy.  The
+// window is split into OPL phase rows (sample w at [w % OPL][w / OPL]) so that the lanes' reads are consecutive words for any tap; the
+// coefficients sit transposed ([M][L], zero-padded to a multiple of 3 * OPL) and are read 16 bytes at a time.  Taps go in blocks of OPL:
+// a block needs the 2 * OPL - 1 samples x[o0 - jb - OPL + 1 .. o0 - jb + OPL - 1], kept as register rows of OPL samples; three rows and
+// three coefficient blocks rotate so that the LDS reads of the next block are in flight behind the multiply-adds of this one.
+// Every output accumulates its taps in the order j = 0 .. L-1, like
+// td_fir.  The block of the last tile also leaves the last L - 1 input samples in the other half of the history ping-pong
+// (td_fir_cache).
 constexpr int FIR_NT = 64, FIR_MMAX = 16, FIR_LMAX = 120;
 template <int OPL> struct FirShape {
-    static constexpr int TS = FIR_NT * OPL, PAD = OPL;                      // PAD zero entries in front: taps past L read them
+    static constexpr int TS = FIR_NT * OPL, PAD = 4 * OPL;                  // zero entries in front: the zero-padded taps past L and the row prefetch read them
     static constexpr int RMIN = (TS + FIR_LMAX - 1 + PAD + OPL - 1) / OPL;  // words per phase row
     static constexpr int UNIT = 64 / OPL;                                   // row length = UNIT x odd: staging stores are conflict-free
     static constexpr int RL = ((RMIN + UNIT - 1) / UNIT | 1) * UNIT;
     static constexpr int LOG = OPL == 8 ? 3 : 2;
+    static constexpr int NB = (TS + FIR_LMAX - 1 + FIR_NT - 1) / FIR_NT;    // window entries per lane
 };
 template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdParams p) {
     typedef FirShape<OPL> S;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int M = p.M, L = p.L, Lp = (L + OPL - 1) / OPL * OPL, b = blockIdx.y, i0 = blockIdx.x * S::TS, tid = threadIdx.x;
+    const int M = p.M, L = p.L, Lp = (L + 3 * OPL - 1) / (3 * OPL) * (3 * OPL), b = blockIdx.y, i0 = blockIdx.x * S::TS, tid = threadIdx.x;
     const int nt = p.n - i0 < S::TS ? p.n - i0 : S::TS;                    // outputs of this tile
-    float* xs = lds;                                                       // [M][OPL][RL]
-    float* cs = lds + (size_t)M * OPL * S::RL;                             // [M][Lp]
-    auto at = [&](int m, int w) { return m * (OPL * S::RL) + (w & (OPL - 1)) * S::RL + (w >> S::LOG); };   // w counts from the first pad entry
+    float* cs = lds + 2 * OPL * S::RL;                                     // [M][Lp] (+ OPL slack for the prefetch) behind the two windows [2][OPL][RL]
+    auto at = [&](int w) { return (w & (OPL - 1)) * S::RL + (w >> S::LOG); };   // w counts from the first pad entry
     for (int i = tid; i < M * Lp; i += FIR_NT) {
         const int m = i / Lp, j = i - m * Lp;
         cs[i] = j < L ? p.coef[j * M + m] : 0.0f;
     }
-    for (int i = tid; i < M * OPL; i += FIR_NT) xs[at(i >> S::LOG, i & (OPL - 1))] = 0.0f;
+    for (int i = tid; i < 2 * S::PAD; i += FIR_NT) lds[(i / S::PAD) * OPL * S::RL + at(i % S::PAD)] = 0.0f;
+    if (tid < OPL) cs[M * Lp + tid] = 0.0f;
     const float* xb = p.x + (long long)b * p.n * M;
+    const float* cache = p.cache_in + (long long)b * (L - 1) * M;
+    const long long xs_s = p.x_chan_major ? 1 : M, xs_c = p.x_chan_major ? p.n : 1;
     // window entry w = 0 .. nt + L - 2  <->  sample s = i0 + w - (L - 1); s < 0 (first tile only: a tile is longer than the history)
-    // comes from the cache, which is sample-major like the window walk below
-    const int nw = nt + L - 1, hist = i0 == 0 ? L - 1 : 0;
-    {
-        const float* cache = p.cache_in + (long long)b * (L - 1) * M;
-        for (int idx = tid; idx < hist * M; idx += FIR_NT) {
-            const int w = idx / M, m = idx - w * M;
-            xs[at(m, w + S::PAD)] = cache[idx];
-        }
-    }
-    if (p.x_chan_major) {
-        for (int m = 0; m < M; ++m) {
-            const float* xm = xb + (long long)m * p.n + (i0 - (L - 1));
-            for (int w0 = hist; w0 < nw; w0 += 8 * FIR_NT) {               // 8 loads in flight per lane
-                float v[8];
+    // comes from the cache
+    const int nw = nt + L - 1;
+    float v[S::NB];
+    // branch-free: entries past the window re-read its last entry (and are not stored), history entries select the cache address
+    auto fetch = [&](int m) {
+        const float* xm_ = xb + (long long)m * xs_c;
+        const float* cm_ = cache + m;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int w = w0 + u * FIR_NT + tid; v[u] = w < nw ? xm[w] : 0.0f; }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const int w = w0 + u * FIR_NT + tid; if (w < nw) xs[at(m, w + S::PAD)] = v[u]; }
-            }
+        for (int u = 0; u < S::NB; ++u) {
+            const int w0 = u * FIR_NT + tid, w = w0 < nw ? w0 : nw - 1, s_ = i0 + w - (L - 1);
+            const float* src = s_ >= 0 ? xm_ + (long long)s_ * xs_s : cm_ + (long long)(L - 1 + s_) * M;
+            v[u] = *src;
         }
-    } else {
-        const float* xw = xb + (long long)(i0 + hist - (L - 1)) * M;       // [nw - hist][M], contiguous
-        const int total = (nw - hist) * M;
-        for (int base = 0; base < total; base += 8 * FIR_NT) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int idx = base + u * FIR_NT + tid; v[u] = idx < total ? xw[idx] : 0.0f; }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * FIR_NT + tid;
-                if (idx < total) { const int w = idx / M, m = idx - w * M; xs[at(m, w + hist + S::PAD)] = v[u]; }
-            }
-        }
-    }
-    __syncthreads();
-    if (p.cache_out != nullptr && L > 1 && blockIdx.x == gridDim.x - 1) {  // history for the next call: the last L - 1 samples
-        float* co = p.cache_out + (long long)b * (L - 1) * M;
-        for (int idx = tid; idx < (L - 1) * M; idx += FIR_NT) {
-            const int i = idx / M, m = idx - i * M;
-            co[idx] = xs[at(m, i + nt + S::PAD)];
-        }
-    }
+    };
     const int o0 = OPL * tid;                                              // first output of this lane within the tile
-    if (o0 >= nt) return;
-    const bool vec = p.y_chan_major && p.n % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0;
+    const bool live = o0 < nt, vec = p.y_chan_major && p.n % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0 && o0 + OPL <= nt;
+    const bool keep = p.cache_out != nullptr && L > 1 && blockIdx.x == gridDim.x - 1;
     float mean[OPL], prev[OPL];
 #pragma unroll
     for (int o = 0; o < OPL; ++o) { mean[o] = 0.0f; prev[o] = 0.0f; }
+    fetch(0);
     for (int m = 0; m < M; ++m) {
-        const float* xm = xs + m * (OPL * S::RL) + tid;
+        float* xs = lds + (m & 1) * OPL * S::RL;
+#pragma unroll
+        for (int u = 0; u < S::NB; ++u) xs[at(u * FIR_NT + tid + S::PAD)] = v[u];   // entries past the window are never used
+        __syncthreads();
+        if (m + 1 < M) fetch(m + 1);                                       // next channel's window flies behind this channel's taps
+        if (keep) {                                                        // history for the next call: the last L - 1 samples
+            float* co = p.cache_out + (long long)b * (L - 1) * M + m;
+            for (int i = tid; i < L - 1; i += FIR_NT) co[(long long)i * M] = xs[at(i + nt + S::PAD)];
+        }
+        if (!live) continue;
+        const float* xm = xs + tid;
         const float* cm = cs + m * Lp;
         // row k of the window: H_k[i] = x[i0 + o0 - OPL * k + i]
         auto row = [&](int k, float* h) {
@@ -250,47 +239,53 @@ template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdPar
         float acc[OPL];
 #pragma unroll
         for (int o = 0; o < OPL; ++o) acc[o] = 0.0f;
-        auto block = [&](int jb, const float* hi, const float* lo) {       // taps jb .. jb + OPL - 1: x[o - u] = hi[o - u] or lo[OPL + o - u]
-            float c[OPL];
+        auto coef = [&](int jb, float* c) {
 #pragma unroll
             for (int q = 0; q < OPL / 4; ++q) {
                 const vec4 c4 = *reinterpret_cast<const vec4*>(cm + jb + 4 * q);
                 c[4 * q] = c4.x; c[4 * q + 1] = c4.y; c[4 * q + 2] = c4.z; c[4 * q + 3] = c4.w;
             }
+        };
+        auto block = [&](const float* c, const float* hi, const float* lo) {   // OPL taps: x[o - u] = hi[o - u] or lo[OPL + o - u]
 #pragma unroll
             for (int u = 0; u < OPL; ++u)                                  // tap order ascending for every output
 #pragma unroll
                 for (int o = 0; o < OPL; ++o) acc[o] = fma_(c[u], o >= u ? hi[o - u] : lo[OPL + o - u], acc[o]);
         };
-        float P[OPL], Q[OPL];
-        row(0, P); row(1, Q);
-        for (int jb = 0, k = 0; jb < Lp; jb += 2 * OPL, k += 2) {
-            block(jb, P, Q);
-            if (jb + OPL < Lp) {
-                row(k + 2, P);
-                block(jb + OPL, Q, P);
-                if (jb + 2 * OPL < Lp) row(k + 3, Q);
-            }
+        // three rows and three coefficient blocks rotate: block k works on (H_k, H_k+1, c_k) while H_k+2 and c_k+1 are on their way from LDS
+        float A[OPL], B[OPL], C[OPL], cA[OPL], cB[OPL], cC[OPL];
+        row(0, A); row(1, B); coef(0, cA);
+        for (int jb = 0, k = 0; jb < Lp; jb += 3 * OPL, k += 3) {
+            row(k + 2, C); coef(jb + OPL, cB);
+            block(cA, A, B);
+            row(k + 3, A); coef(jb + 2 * OPL, cC);
+            block(cB, B, C);
+            row(k + 4, B); coef(jb + 3 * OPL, cA);
+            block(cC, C, A);
         }
-        if (vec && o0 + OPL <= nt) {
+        const int nv = nt - o0;                                            // valid outputs of this lane (>= OPL: all)
+        if (vec) {
             float* dst = p.y + ((long long)b * M + m) * p.n + i0 + o0;
 #pragma unroll
             for (int q = 0; q < OPL / 4; ++q) *reinterpret_cast<vec4*>(dst + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        } else if (p.y_chan_major) {
+            float* dst = p.y + ((long long)b * M + m) * p.n + i0 + o0;
+#pragma unroll
+            for (int o = 0; o < OPL; ++o) if (o < nv) dst[o] = acc[o];
+        } else {
+            float* dst = p.y + ((long long)b * p.n + i0 + o0) * M + m;
+#pragma unroll
+            for (int o = 0; o < OPL; ++o) if (o < nv) dst[(long long)o * M] = acc[o];
+        }
+        if (p.diff && m > 0) {
+            float* dd = p.diff + ((long long)b * p.n + i0 + o0) * (M - 1) + m - 1;
+#pragma unroll
+            for (int o = 0; o < OPL; ++o) if (o < nv) dd[(long long)o * (M - 1)] = prev[o] - acc[o];
         }
 #pragma unroll
-        for (int o = 0; o < OPL; ++o) {
-            const int i = i0 + o0 + o;
-            if (o0 + o >= nt) break;
-            if (!(vec && o0 + OPL <= nt)) {
-                if (p.y_chan_major) p.y[((long long)b * M + m) * p.n + i] = acc[o];
-                else p.y[((long long)b * p.n + i) * M + m] = acc[o];
-            }
-            mean[o] += acc[o];
-            if (p.diff && m > 0) p.diff[((long long)b * p.n + i) * (M - 1) + m - 1] = prev[o] - acc[o];
-            prev[o] = acc[o];
-        }
+        for (int o = 0; o < OPL; ++o) { mean[o] += acc[o]; prev[o] = acc[o]; }
     }
-    if (p.mean)
+    if (p.mean && live)
         for (int o = 0; o < OPL && o0 + o < nt; ++o) p.mean[(long long)b * p.n + i0 + o0 + o] = mean[o] / (float)M;
 }
 
@@ -305,8 +300,8 @@ hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream) {
 }
 template <int OPL> static void launch_fir_t(const TdParams& p, hipStream_t stream) {
     typedef FirShape<OPL> S;
-    const int Lp = (p.L + OPL - 1) / OPL * OPL;
-    const size_t lds = ((size_t)p.M * OPL * S::RL + (size_t)p.M * Lp) * sizeof(float);
+    const int Lp = (p.L + 3 * OPL - 1) / (3 * OPL) * (3 * OPL);
+    const size_t lds = ((size_t)2 * OPL * S::RL + (size_t)p.M * Lp + OPL) * sizeof(float);
     hipLaunchKernelGGL(ds_fir_kernel<OPL>, dim3((unsigned)((p.n + S::TS - 1) / S::TS), (unsigned)p.B), dim3(FIR_NT), lds, stream, p);
 }
 hipError_t launch_fir(const TdParams& p, hipStream_t stream) {
