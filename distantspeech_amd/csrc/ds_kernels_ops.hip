@@ -161,8 +161,8 @@ template <bool VEC> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kerne
 
 // TimeAlignment FIR bank (td_fir is the definition).  One single-wave block = one utterance x 64 * OPL consecutive outputs, a lane =
 // OPL consecutive outputs of every channel (OPL = 8, or 4 for calls of one 256-sample block).  Channels go through the block one at a
-// time: the input window of channel m (history from the cache, then x) sits in LDS while the window of channel m + 1 is already on
-// its way from memory into registers, so a block holds two windows (5 KB) instead of M and a CU keeps all its wave slots busy.  The
+// time: the input window of channel m (history from the cache, then x) sits in LDS while the windows of the next two or three channels
+// are already on their way from memory into registers, so a block holds two windows (5 KB) instead of M and a CU keeps all its wave slots busy.  The
 // window is split into OPL phase rows (sample w at [w % OPL][w / OPL]) so that the lanes' reads are consecutive words for any tap; the
 // coefficients sit transposed ([M][L], zero-padded to a multiple of 3 * OPL) and are read 16 bytes at a time.  Taps go in blocks of OPL:
 // a block needs the 2 * OPL - 1 samples x[o0 - jb - OPL + 1 .. o0 - jb + OPL - 1], kept as register rows of OPL samples; three rows and
@@ -178,6 +178,7 @@ template <int OPL> struct FirShape {
     static constexpr int RL = ((RMIN + UNIT - 1) / UNIT | 1) * UNIT;
     static constexpr int LOG = OPL == 8 ? 3 : 2;
     static constexpr int NB = (TS + FIR_LMAX - 1 + FIR_NT - 1) / FIR_NT;    // window entries per lane
+    static constexpr int D = OPL == 4 ? 3 : 2;                              // channel windows in flight (registers) ahead of the one in LDS
 };
 template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdParams p) {
     typedef FirShape<OPL> S;
@@ -198,9 +199,9 @@ template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdPar
     // window entry w = 0 .. nt + L - 2  <->  sample s = i0 + w - (L - 1); s < 0 (first tile only: a tile is longer than the history)
     // comes from the cache
     const int nw = nt + L - 1;
-    float v[S::NB];
+    float vr[S::D][S::NB];
     // branch-free: entries past the window re-read its last entry (and are not stored), history entries select the cache address
-    auto fetch = [&](int m) {
+    auto fetch = [&](int m, float* v) {
         const float* xm_ = xb + (long long)m * xs_c;
         const float* cm_ = cache + m;
 #pragma unroll
@@ -214,27 +215,32 @@ template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdPar
     const bool live = o0 < nt, vec = p.y_chan_major && p.n % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0 && o0 + OPL <= nt;
     const bool keep = p.cache_out != nullptr && L > 1 && blockIdx.x == gridDim.x - 1;
     float mean[OPL], prev[OPL];
+    int ridx[OPL];                                                         // word index of x[i0 + o0 + i] in a window: entry o0 + i + L - 1 + PAD
 #pragma unroll
-    for (int o = 0; o < OPL; ++o) { mean[o] = 0.0f; prev[o] = 0.0f; }
-    fetch(0);
-    for (int m = 0; m < M; ++m) {
+    for (int o = 0; o < OPL; ++o) { mean[o] = 0.0f; prev[o] = 0.0f; ridx[o] = at(L - 1 + S::PAD + o) + tid; }
+#pragma unroll
+    for (int d = 0; d < S::D; ++d)
+        if (d < M) fetch(d, vr[d]);
+    auto channel = [&](int m, float* v) {
         float* xs = lds + (m & 1) * OPL * S::RL;
 #pragma unroll
         for (int u = 0; u < S::NB; ++u) xs[at(u * FIR_NT + tid + S::PAD)] = v[u];   // entries past the window are never used
         __syncthreads();
-        if (m + 1 < M) fetch(m + 1);                                       // next channel's window flies behind this channel's taps
+        if (m + S::D < M) fetch(m + S::D, v);                              // D channel windows fly behind this channel's taps
         if (keep) {                                                        // history for the next call: the last L - 1 samples
             float* co = p.cache_out + (long long)b * (L - 1) * M + m;
             for (int i = tid; i < L - 1; i += FIR_NT) co[(long long)i * M] = xs[at(i + nt + S::PAD)];
         }
-        if (!live) continue;
-        const float* xm = xs + tid;
+        if (!live) return;
         const float* cm = cs + m * Lp;
-        // row k of the window: H_k[i] = x[i0 + o0 - OPL * k + i]
-        auto row = [&](int k, float* h) {
-            const int w = (L - 1) + S::PAD - OPL * k;                      // + o0 = OPL * tid: same phase, word offset tid
+        // row k of the window: H_k[i] = x[i0 + o0 - OPL * k + i] = q[i][4 - k]: the phase of entry i does not depend on k, so a lane keeps
+        // one pointer per entry and walks it back by three words per loop iteration (the reads below are pointer + immediate offset)
+        const float* q[OPL];
 #pragma unroll
-            for (int i = 0; i < OPL; ++i) h[i] = xm[((w + i) & (OPL - 1)) * S::RL + ((w + i) >> S::LOG)];
+        for (int i = 0; i < OPL; ++i) q[i] = xs + ridx[i] - 4;
+        auto row = [&](int back, float* h) {                               // back = 4 - (k - k0), k0 = the row q points 4 words below
+#pragma unroll
+            for (int i = 0; i < OPL; ++i) h[i] = q[i][back];
         };
         float acc[OPL];
 #pragma unroll
@@ -254,14 +260,16 @@ template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdPar
         };
         // three rows and three coefficient blocks rotate: block k works on (H_k, H_k+1, c_k) while H_k+2 and c_k+1 are on their way from LDS
         float A[OPL], B[OPL], C[OPL], cA[OPL], cB[OPL], cC[OPL];
-        row(0, A); row(1, B); coef(0, cA);
-        for (int jb = 0, k = 0; jb < Lp; jb += 3 * OPL, k += 3) {
-            row(k + 2, C); coef(jb + OPL, cB);
+        row(4, A); row(3, B); coef(0, cA);
+        for (int jb = 0; jb < Lp; jb += 3 * OPL) {
+            row(2, C); coef(jb + OPL, cB);
             block(cA, A, B);
-            row(k + 3, A); coef(jb + 2 * OPL, cC);
+            row(1, A); coef(jb + 2 * OPL, cC);
             block(cB, B, C);
-            row(k + 4, B); coef(jb + 3 * OPL, cA);
+            row(0, B); coef(jb + 3 * OPL, cA);
             block(cC, C, A);
+#pragma unroll
+            for (int i = 0; i < OPL; ++i) q[i] -= 3;
         }
         const int nv = nt - o0;                                            // valid outputs of this lane (>= OPL: all)
         if (vec) {
@@ -284,6 +292,11 @@ template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdPar
         }
 #pragma unroll
         for (int o = 0; o < OPL; ++o) { mean[o] += acc[o]; prev[o] = acc[o]; }
+    };
+    for (int m0 = 0; m0 < M; m0 += S::D) {
+#pragma unroll
+        for (int d = 0; d < S::D; ++d)
+            if (m0 + d < M) channel(m0 + d, vr[d]);
     }
     if (p.mean && live)
         for (int o = 0; o < OPL && o0 + o < nt; ++o) p.mean[(long long)b * p.n + i0 + o0 + o] = mean[o] / (float)M;
