@@ -348,14 +348,25 @@ hipError_t launch_wpe(const WpeParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// McSpp's band-averaged prior np.mean(q[fmin:fmax]) (mcspp.py:258-260) once per (utterance, frame) instead of once per bin
-__global__ void __launch_bounds__(64) ds_mcspp_qavg_kernel(const float* gamma, float* out, int rows, int K, int fmin, int fmax) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < rows) out[r] = mcspp_qavg(gamma + (long long)r * K, fmin, fmax);
+// McSpp's band-averaged prior np.mean(q[fmin:fmax]) (mcspp.py:258-260) once per (utterance, frame) instead of once per bin.  One wave
+// per row: the lanes fetch the band in one go, lane 0 adds it up in bin order (mcspp_qavg's order, so the value is the same bit for bit).
+constexpr int QAVG_MAX = 256;
+__global__ void __launch_bounds__(256) ds_mcspp_qavg_kernel(const float* gamma, float* out, int rows, int K, int fmin, int fmax) {
+    __shared__ float q[4][QAVG_MAX];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = blockIdx.x * 4 + wv, n = fmax - fmin;
+    if (r < rows)
+        for (int j = lane; j < n; j += 64) q[wv][j] = 1.0f - gamma[(long long)r * K + fmin + j];
+    __syncthreads();
+    if (r < rows && lane == 0) {
+        float qsum = 0.0f;
+        for (int j = 0; j < n; ++j) qsum += q[wv][j];
+        out[r] = qsum / (float)n;
+    }
 }
 hipError_t launch_mcspp_qavg(const float* gamma, float* out, int rows, int K, hipStream_t stream) {
     const int fmin = (int)(500.0 * (2 * (K - 1)) / 16000.0), fmax = (int)(2000.0 * (2 * (K - 1)) / 16000.0);
-    hipLaunchKernelGGL(ds_mcspp_qavg_kernel, dim3((rows + 63) / 64), dim3(64), 0, stream, gamma, out, rows, K, fmin, fmax);
+    if (fmax - fmin > QAVG_MAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ds_mcspp_qavg_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, gamma, out, rows, K, fmin, fmax);
     return hipGetLastError();
 }
 
