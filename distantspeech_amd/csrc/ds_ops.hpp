@@ -435,6 +435,81 @@ template <int N> DS_HD void op_subrls_t(const OpCtx& p, int b, int k) {
     }
 }
 
+// The F = x_fan instances of an utterance (SubbandGSC's blocking filters) take the same reference input, so their tap buffers, their
+// inverse correlation matrices P and their gain vectors are the same numbers: one thread per (utterance, bin) runs that common part once
+// and the F error / weight updates after it — the arithmetic of every instance is exactly op_subrls_t's, in the same order.  X and P
+// live in the first instance's planes only: the X / P planes of the other F - 1 instances are not maintained (this kernel is their only
+// reader; the chain exports and imports the raw state, so checkpoints round-trip).
+// Needs d_interleaved (the desired signals are the channels of one spectrum) and no d_prev.
+template <int N, int F> DS_HD void op_subrls_fan(const OpCtx& p, int u, int k) {
+    constexpr int oX = 2 * N, oP = 4 * N;
+    const float lam_inv = 1.0f / p.lam;
+    const int b0 = u * F;
+    cf W[F][N], X[N], P[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        X[i] = mk(st_at(p, b0, oX + 2 * i, k), st_at(p, b0, oX + 2 * i + 1, k));
+#pragma unroll
+        for (int j = 0; j < N; ++j) P[i][j] = mk(st_at(p, b0, oP + 2 * (i * N + j), k), st_at(p, b0, oP + 2 * (i * N + j) + 1, k));
+#pragma unroll
+        for (int m = 0; m < F; ++m) W[m][i] = mk(st_at(p, b0 + m, 2 * i, k), st_at(p, b0 + m, 2 * i + 1, k));
+    }
+    for (int t = 0; t < p.T; ++t) {
+        const long long fx = ((long long)u * p.T + t) * p.K + k;
+#pragma unroll
+        for (int n = N - 1; n > 0; --n) X[n] = X[n - 1];
+        X[0] = mk(p.in0[2 * fx], p.in0[2 * fx + 1]);
+        cf d[F];
+#pragma unroll
+        for (int m = 0; m < F; ++m) d[m] = mk(p.in1[2 * (fx * F + m)], p.in1[2 * (fx * F + m) + 1]);
+        cf num[N], xhP[N], kn[N];
+        cf den = mk(p.lam, 0.0f);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            cf a = mk(0.0f, 0.0f), r = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                a = cfma(a, P[i][j], X[j]);
+                r = cfmac(r, P[j][i], X[j]);
+            }
+            num[i] = a; xhP[i] = r;
+            den = cfmac(den, a, X[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            kn[i] = cdiv(num[i], den);
+#pragma unroll
+            for (int j = 0; j < N; ++j) P[i][j] = cscale(cfnma(P[i][j], kn[i], xhP[j]), lam_inv);
+        }
+#pragma unroll
+        for (int m = 0; m < F; ++m) {
+            cf out = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int i = 0; i < N; ++i) out = cfmac(out, X[i], W[m][i]);
+            const cf err = csub(d[m], out);
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const cf g = cmulc(kn[i], err);
+                W[m][i] = mk(fma_(2.0f * p.mu, g.x, W[m][i].x), fma_(2.0f * p.mu, g.y, W[m][i].y));
+            }
+            const long long fb = ((long long)(b0 + m) * p.T + t) * p.K + k;
+            p.out0[2 * fb] = err.x; p.out0[2 * fb + 1] = err.y;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int m = 0; m < F; ++m) { st_at(p, b0 + m, 2 * i, k) = W[m][i].x; st_at(p, b0 + m, 2 * i + 1, k) = W[m][i].y; }
+        st_at(p, b0, oX + 2 * i, k) = X[i].x; st_at(p, b0, oX + 2 * i + 1, k) = X[i].y;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { st_at(p, b0, oP + 2 * (i * N + j), k) = P[i][j].x; st_at(p, b0, oP + 2 * (i * N + j) + 1, k) = P[i][j].y; }
+    }
+}
+// can a SubbandRLS call run as op_subrls_fan?
+inline bool subrls_fan_ok(const OpParams& p) {
+    return p.N == 2 && p.d_interleaved && p.d_prev == nullptr && p.B % (p.x_fan > 0 ? p.x_fan : 1) == 0 && (p.x_fan == 2 || p.x_fan == 4 || p.x_fan == 6 || p.x_fan == 8);
+}
+
 DS_HD void op_subrls(const OpCtx& p, int b, int k) {
     switch (p.N) {
         case 1: return op_subrls_t<1>(p, b, k);

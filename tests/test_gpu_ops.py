@@ -239,6 +239,27 @@ def test_steering_and_mvdr_weight_random(ds):
         assert np.max(np.abs(compute_mvdr_weight(ref, Rinv) - O.compute_mvdr_weight(ref, Rinv))) < 1e-4
 
 
+def test_subband_gsc_rls_fan_equals_instances(ds):
+    """The chain runs the M RLS blocking filters of an utterance as ONE thread per bin (shared tap buffer, P and gain: op_subrls_fan);
+    M independent SubbandRLS objects driven on the chain's own aligned / fixed-beamformer signals must give the same bm_output bit for bit."""
+    rng = np.random.default_rng(21)
+    M, FL, T = 6, 256, 12
+    x = (rng.standard_normal((M, T * FL)) * 0.05).astype(np.float32)
+    x[1:] += 0.5 * x[:1]
+    mic = ds.MicArray(arrayType="circular", r=0.032, M=M, n_fft=512)
+    sg = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], bm_filter="rls")
+    _, fix, bm, _, al = sg.process(x)
+    n = (T - 1) * FL
+    fixed = fix[FL:]                                                     # fix_output is the fixed beamformer one block late
+    F = ds.Transform(channel=1, n_fft=512, hop_length=FL).stft(fixed.astype(np.float32))              # [K, T-1, 1]
+    D = ds.Transform(channel=M, n_fft=512, hop_length=FL).stft(al[:n].astype(np.float32))             # [K, T-1, M]
+    for m in range(M):
+        r = ds.SubbandRLS(filter_len=2, num_bands=512)
+        E = np.stack([r.update(F[:, t, 0], D[:, t, m])[0] for t in range(T - 1)], axis=1)             # [K, T-1]
+        y = ds.Transform(channel=1, n_fft=512, hop_length=FL).istft(E[:, :, None])
+        assert np.array_equal(np.asarray(y, dtype=np.float32), bm[:n, m].astype(np.float32)), m
+
+
 @pytest.mark.parametrize("name", ["rec1", "synth_m6", "synth_m6_rls"])
 def test_subband_gsc(ds, name):
     """SubbandGSC.process (config-5 structure; `_rls` = the SubbandRLS blocking-filter composition) vs the reference."""
