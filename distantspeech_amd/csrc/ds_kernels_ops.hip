@@ -66,7 +66,25 @@ template <int F> __global__ void __launch_bounds__(256) ds_subrls_fan_kernel(OpP
     op_subrls_fan<2, F>(c, u, k);
 }
 
+template <int F> __global__ void __launch_bounds__(256) ds_sublms_fan_kernel(OpParams p) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
+    const int u = (int)(i / p.KP), k = (int)(i - (long long)u * p.KP);
+    if (u >= p.B / F || k >= p.K) return;
+    const OpCtx c = make_op_ctx(p, (i0 / p.KP) * F * p.KP);
+    op_sublms_fan<2, F>(c, u, k);
+}
+
 hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream) {
+    if (op == OP_SUBLMS && sublms_fan_ok(p)) {
+        const int blocks = (int)(((long long)(p.B / p.x_fan) * p.KP + 255) / 256);
+        switch (p.x_fan) {
+            case 2: hipLaunchKernelGGL(ds_sublms_fan_kernel<2>, dim3(blocks), dim3(256), 0, stream, p); break;
+            case 4: hipLaunchKernelGGL(ds_sublms_fan_kernel<4>, dim3(blocks), dim3(256), 0, stream, p); break;
+            case 6: hipLaunchKernelGGL(ds_sublms_fan_kernel<6>, dim3(blocks), dim3(256), 0, stream, p); break;
+            default: hipLaunchKernelGGL(ds_sublms_fan_kernel<8>, dim3(blocks), dim3(256), 0, stream, p); break;
+        }
+        return hipGetLastError();
+    }
     if (op == OP_SUBRLS && subrls_fan_ok(p)) {                             // the instances of an utterance as one thread (see op_subrls_fan)
         const int blocks = (int)(((long long)(p.B / p.x_fan) * p.KP + 255) / 256);
         switch (p.x_fan) {

@@ -360,6 +360,67 @@ template <int N, int C> DS_HD void op_sublms_t(const OpCtx& p, int b, int k) {
     if (p.norm) st_at(p, b, 2 * NC2, k) = P;
 }
 
+// The fan form of the single-channel subband LMS (see op_subrls_fan further down for the idea): the F instances of an utterance share
+// the reference input, hence the tap buffer, the smoothed input power and the step size; only the error and the weights are per instance.
+// Same arithmetic per instance as op_sublms_t<N, 1>.  X and P live in the first instance's planes.  Needs d_interleaved, no d_prev.
+template <int N, int F> DS_HD void op_sublms_fan(const OpCtx& p, int u, int k) {
+    constexpr int NC2 = 2 * N;
+    const int b0 = u * F;
+    cf W[F][N], X[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        X[i] = mk(st_at(p, b0, NC2 + 2 * i, k), st_at(p, b0, NC2 + 2 * i + 1, k));
+#pragma unroll
+        for (int m = 0; m < F; ++m) W[m][i] = mk(st_at(p, b0 + m, 2 * i, k), st_at(p, b0 + m, 2 * i + 1, k));
+    }
+    float P = st_at(p, b0, 2 * NC2, k);
+    for (int t = 0; t < p.T; ++t) {
+        const long long fx = ((long long)u * p.T + t) * p.K + k;
+#pragma unroll
+        for (int n = N - 1; n > 0; --n) X[n] = X[n - 1];
+        X[0] = mk(p.in0[2 * fx], p.in0[2 * fx + 1]);
+        cf d[F];
+#pragma unroll
+        for (int m = 0; m < F; ++m) d[m] = mk(p.in1[2 * (fx * F + m)], p.in1[2 * (fx * F + m) + 1]);
+        float pw = 0.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) pw += cabs2(X[i]);
+        float pk = p.has_p ? p.in2[fx] : 1.0f;
+        if (p.p_complement) pk = 1.0f - pk;
+        float scale = 1.0f;
+        if (p.norm) {
+            P = fma_(p.alpha, P, (1.0f - p.alpha) * pw);                        // one channel: pw / C = pw
+            scale = 1.0f / (P + p.reg);
+        }
+        const float g = 2.0f * p.mu * pk * scale;
+#pragma unroll
+        for (int m = 0; m < F; ++m) {
+            cf out = mk(0.0f, 0.0f);
+#pragma unroll
+            for (int i = 0; i < N; ++i) out = cfmac(out, X[i], W[m][i]);
+            const cf err = mk(fma_(-out.x, pk, d[m].x), fma_(-out.y, pk, d[m].y));
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const cf gr = cmulc(X[i], err);
+                W[m][i] = mk(fma_(g, gr.x, W[m][i].x), fma_(g, gr.y, W[m][i].y));
+            }
+            const long long fb = ((long long)(b0 + m) * p.T + t) * p.K + k;
+            p.out0[2 * fb] = err.x; p.out0[2 * fb + 1] = err.y;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int m = 0; m < F; ++m) { st_at(p, b0 + m, 2 * i, k) = W[m][i].x; st_at(p, b0 + m, 2 * i + 1, k) = W[m][i].y; }
+        st_at(p, b0, NC2 + 2 * i, k) = X[i].x; st_at(p, b0, NC2 + 2 * i + 1, k) = X[i].y;
+    }
+    if (p.norm) st_at(p, b0, 2 * NC2, k) = P;
+}
+// can a SubbandLMS call run as op_sublms_fan?
+inline bool sublms_fan_ok(const OpParams& p) {
+    return p.N == 2 && p.M == 1 && p.d_interleaved && p.d_prev == nullptr && (p.x_fan == 2 || p.x_fan == 4 || p.x_fan == 6 || p.x_fan == 8) && p.B % p.x_fan == 0;
+}
+
 DS_HD void op_sublms(const OpCtx& p, int b, int k) {
     if (p.N == 2) {                                   // the reference's tap count everywhere it builds these filters
         switch (p.M) {

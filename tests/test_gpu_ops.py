@@ -239,23 +239,29 @@ def test_steering_and_mvdr_weight_random(ds):
         assert np.max(np.abs(compute_mvdr_weight(ref, Rinv) - O.compute_mvdr_weight(ref, Rinv))) < 1e-4
 
 
-def test_subband_gsc_rls_fan_equals_instances(ds):
-    """The chain runs the M RLS blocking filters of an utterance as ONE thread per bin (shared tap buffer, P and gain: op_subrls_fan);
-    M independent SubbandRLS objects driven on the chain's own aligned / fixed-beamformer signals must give the same bm_output bit for bit."""
+@pytest.mark.parametrize("kind", ["rls", "lms"])
+def test_subband_gsc_fan_equals_instances(ds, kind):
+    """The chain runs the M blocking filters of an utterance as ONE thread per bin (shared tap buffer, P / input power and gain:
+    op_subrls_fan, op_sublms_fan); M independent SubbandRLS / SubbandLMS objects driven on the chain's own aligned / fixed-beamformer
+    signals (and its p) must give the same bm_output bit for bit."""
     rng = np.random.default_rng(21)
     M, FL, T = 6, 256, 12
     x = (rng.standard_normal((M, T * FL)) * 0.05).astype(np.float32)
     x[1:] += 0.5 * x[:1]
     mic = ds.MicArray(arrayType="circular", r=0.032, M=M, n_fft=512)
-    sg = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], bm_filter="rls")
-    _, fix, bm, _, al = sg.process(x)
+    sg = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], bm_filter=kind)
+    _, fix, bm, p, al = sg.process(x)
     n = (T - 1) * FL
     fixed = fix[FL:]                                                     # fix_output is the fixed beamformer one block late
     F = ds.Transform(channel=1, n_fft=512, hop_length=FL).stft(fixed.astype(np.float32))              # [K, T-1, 1]
     D = ds.Transform(channel=M, n_fft=512, hop_length=FL).stft(al[:n].astype(np.float32))             # [K, T-1, M]
     for m in range(M):
-        r = ds.SubbandRLS(filter_len=2, num_bands=512)
-        E = np.stack([r.update(F[:, t, 0], D[:, t, m])[0] for t in range(T - 1)], axis=1)             # [K, T-1]
+        if kind == "rls":
+            r = ds.SubbandRLS(filter_len=2, num_bands=512)
+            E = np.stack([r.update(F[:, t, 0], D[:, t, m])[0] for t in range(T - 1)], axis=1)         # [K, T-1]
+        else:
+            r = ds.SubbandLMS(filter_len=2, num_bands=512, mu=0.1)
+            E = np.stack([r.update(F[:, t, 0], D[:, t, m], p=p[:, t].astype(np.float32))[0] for t in range(T - 1)], axis=1)
         y = ds.Transform(channel=1, n_fft=512, hop_length=FL).istft(E[:, :, None])
         assert np.array_equal(np.asarray(y, dtype=np.float32), bm[:n, m].astype(np.float32)), m
 
