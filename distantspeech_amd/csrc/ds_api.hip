@@ -345,15 +345,16 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             h->sub[i]->stream = h->stream; h->sub[i]->owns_stream = false;
         }
         if (rls) {
-            // the RLS blocking filters do not take the speech presence probability, so the McSpp stage (register-bound, one wave per SIMD)
-            // runs on a side stream next to the blocking-filter stages (HBM-bound) and joins in front of the canceller
+            // the RLS blocking filters do not take the speech presence probability, so the blocking-filter stages (HBM-bound) run on a side
+            // stream next to the McSpp stage (register-bound, one wave per SIMD) and join in front of the canceller.  McSpp is the longer
+            // branch and stays on the chain's own stream: the cross-stream hand-offs (~10 us each) then sit on the branch that has slack
             if (hipStreamCreateWithFlags(&h->side[0], hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming) != hipSuccess) {
                 ds_destroy(h);
                 return fail(nullptr, DS_EHIP, "ds_create(DS_ALGO_SUBBAND_GSC): side stream");
             }
-            h->sub[2]->stream = h->side[0];
+            for (int i = 3; i <= 6; ++i) h->sub[i]->stream = h->side[0];
         }
         h->sub[5]->x_fan = M;                 // the M blocking filters of an utterance share its fixed-beamformer spectrum and p ...
         h->sub[5]->d_interleaved = 1;         // ... and take their desired signals straight from the M-channel STFT of the aligned channels

@@ -94,7 +94,7 @@ static int chain_stft(ds_handle* h, ds_handle* t, const float* x, int n, float* 
     p.x_batch_stride = (long long)C * n; p.x_sample_stride = 1; p.x_chan_stride = n;
     p.y_batch_stride = (long long)T * t->K * C * 2;
     p.T = T; p.batch0 = 0;
-    DS_HIP(h, t->ki.launch(p, t->cfg.batch, h->stream));
+    DS_HIP(h, t->ki.launch(p, t->cfg.batch, t->stream));
     return DS_OK;
 }
 static int chain_istft(ds_handle* h, ds_handle* t, const float* Y, int T, float* y, long long y_batch_stride) {
@@ -104,7 +104,7 @@ static int chain_istft(ds_handle* h, ds_handle* t, const float* Y, int T, float*
     p.x_batch_stride = (long long)T * t->K * 2;
     p.y_batch_stride = y_batch_stride;
     p.T = T; p.batch0 = 0; p.method = 1;
-    DS_HIP(h, t->ki_istft.launch(p, t->cfg.batch, h->stream));
+    DS_HIP(h, t->ki_istft.launch(p, t->cfg.batch, t->stream));
     return DS_OK;
 }
 
@@ -143,13 +143,12 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         fe->td_cur ^= 1;
     }
     rc = chain_stft(h, h->sub[1], cb[G_XA], n, cb[G_D]); if (rc) return rc;                                   // :204  D
-    const bool fork = h->sub[2]->stream != h->stream;                       // McSpp on the side stream (RLS blocking filters, see ds_create)
+    const bool fork = h->sub[5]->stream != h->stream;                       // blocking-filter branch on the side stream (RLS filters, see ds_create)
     if (fork) {
         DS_HIP(h, hipEventRecord(h->ev_fork, h->stream));
-        DS_HIP(h, hipStreamWaitEvent(h->sub[2]->stream, h->ev_fork, 0));
+        DS_HIP(h, hipStreamWaitEvent(h->sub[5]->stream, h->ev_fork, 0));
     }
     DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[G_D], T, cb[G_P], nullptr, nullptr, nullptr, nullptr, DS_MEM_DEVICE));   // :208  p
-    if (fork) DS_HIP(h, hipEventRecord(h->ev_join[0], h->sub[2]->stream));
     rc = chain_stft(h, h->sub[3], cb[G_FIXED], n, cb[G_F]); if (rc) return rc;                                   // bm[m].transform_x: F
     // :217-223 the M blocking filters: reference input F (shared), desired signal = channel m of D (bm[m].transform_d's analysis of the
     // aligned channel is the same spectrum), update probability p
@@ -157,10 +156,13 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     else DS_SUB(5, ds_sublms_update(h->sub[5], cb[G_F], cb[G_D], cb[G_P], T, cb[G_E], DS_MEM_DEVICE));
     rc = chain_istft(h, h->sub[4], cb[G_E], T, cb[G_BM], n); if (rc) return rc;                               // bm outputs, [B*M][n] = [B][M][n]
     rc = chain_stft(h, h->sub[6], cb[G_BM], n, cb[G_XAIC]); if (rc) return rc;                                  // :230-234  aic transform_x
+    if (fork) {
+        DS_HIP(h, hipEventRecord(h->ev_join[0], h->sub[5]->stream));
+        DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[0], 0));
+    }
     // :226 delay_fbf: the canceller's desired signal is the fixed output one block late = F one frame late; the operator keeps the
     // carried frame in cb[G_FPREV] itself
     h->sub[7]->d_prev = cb[G_FPREV];
-    if (fork) DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[0], 0));
     DS_SUB(7, ds_sublms_update(h->sub[7], cb[G_XAIC], cb[G_F], cb[G_P], T, cb[G_E2], DS_MEM_DEVICE));
     rc = chain_istft(h, h->sub[8], cb[G_E2], T, y_dev, y_bstride); if (rc) return rc;
     {   // fix_output = fixed beamformer output delayed by one block (:226,255); the carried block is state either way
