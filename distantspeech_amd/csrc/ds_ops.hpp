@@ -1098,23 +1098,31 @@ template <int M> DS_HD void op_mcspp_lean(const OpCtx& p, int b, int k) {
         };
         ch.factor(vd, vo, dv);
         float tr = trace_with_pyy();
-        if (tr - (float)M < 0.0f) {                                                // :219-228: fall back to A = Phi_yy (+ dv I early on)
+        // :219-228: where xi < 0 the reference falls back to A = Phi_yy (+ dv I in the first five frames).  From frame 5 on that makes
+        // A^-1 Phi_yy the identity: tr - M and y^H A^-1 Phi_yy A^-1 y - y^H A^-1 y are zero up to rounding (1e-14 in the reference's
+        // doubles), so both clamp to their floor 1e-6 (:230,236) — taken here as exactly that, without a second factorisation and trace
+        // whose fp32 rounding would only land somewhere in 1e-6 .. 1e-5.  The PMWF weights (out1) still need A^-1.
+        const bool fell = tr - (float)M < 0.0f, ident = fell && frm >= 5;
+        if (fell && (!ident || p.out1)) {
             ch.factor(yd, yo, frm < 5 ? dv : 0.0f);
-            tr = trace_with_pyy();
+            if (!ident) tr = trace_with_pyy();
         }
-        xi = fminf_(fmaxf_(tr - (float)M, 1e-6f), 1e8f);                           // :230
-        cf v[M];
-        ch.solve(Z, v);                                                            // v = A^-1 y
-        float yv = 0.0f, vPv = 0.0f;
+        xi = ident ? 1e-6f : fminf_(fmaxf_(tr - (float)M, 1e-6f), 1e8f);           // :230
+        gam = 1e-6f;
+        if (!ident) {
+            cf v[M];
+            ch.solve(Z, v);                                                        // v = A^-1 y
+            float yv = 0.0f, vPv = 0.0f;
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-            yv = fma_(Z[i].x, v[i].x, fma_(Z[i].y, v[i].y, yv));                    // Re(conj(y_i) v_i)
-            cf acc = mk(0.0f, 0.0f);
+            for (int i = 0; i < M; ++i) {
+                yv = fma_(Z[i].x, v[i].x, fma_(Z[i].y, v[i].y, yv));                // Re(conj(y_i) v_i)
+                cf acc = mk(0.0f, 0.0f);
 #pragma unroll
-            for (int j = 0; j < M; ++j) acc = cfma(acc, herm_get<M>(yd, yo, i, j), v[j]);
-            vPv = fma_(v[i].x, acc.x, fma_(v[i].y, acc.y, vPv));                    // Re(conj(v_i) (Phi_yy v)_i)
+                for (int j = 0; j < M; ++j) acc = cfma(acc, herm_get<M>(yd, yo, i, j), v[j]);
+                vPv = fma_(v[i].x, acc.x, fma_(v[i].y, acc.y, vPv));                // Re(conj(v_i) (Phi_yy v)_i)
+            }
+            gam = fminf_(fmaxf_(vPv - yv, 1e-6f), 1e8f);                           // :232-236
         }
-        gam = fminf_(fmaxf_(vPv - yv, 1e-6f), 1e8f);                               // :232-236
         pp = 1.0f / (1.0f + q / (1.0f - q) * (1.0f + xi) * expf(-1.0f * (gam / (1.0f + xi))));   // compute_p :75-92
         pp = fminf_(fmaxf_(pp, 0.0f), 1.0f);
         const long long ob = fb + k;
