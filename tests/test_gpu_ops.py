@@ -312,6 +312,41 @@ def test_frontend_mirrors(ds):
     assert np.allclose(out[25:], z[:-25]) and np.all(out[:25] == 0)
 
 
+@pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
+def test_chain_full_batch_properties(ds, cfg):
+    """The chain handles at BASELINE.json's full per-GPU batch (cfg4: 1024 x 8 mics x 1024-FFT, cfg5: 2048 x 6 mics x 512 bands):
+    size-independent properties instead of an oracle run — utterances that repeat in the batch give identical outputs wherever they sit,
+    the full batch equals a batch of one (bitwise), and chunked calls equal one call."""
+    from oracle import ds_oracle as O
+    from _cases import ANGLE, oracle_mic
+    if cfg == "cfg4":
+        B, M, nfft, T = 1024, 8, 1024, 6
+        make = lambda mic, b: ds.WpeMvdrPostfilter(mic, frameLen=nfft, hop=nfft // 2, batch=b)
+        run = lambda o, x: o.process(x, ANGLE)["data"]
+    else:
+        B, M, nfft, T = 2048, 6, 512, 8
+        make = lambda mic, b: ds.SubbandGSC(mic, frameLen=nfft // 2, angle=[197, 0], batch=b, bm_filter="rls")
+        run = lambda o, x: o.process(x)[0]
+    hop = nfft // 2
+    omic = oracle_mic(M, nfft)
+    mic = ds.MicArray(arrayType="circular", r=omic.r, M=M, n_fft=nfft)
+    base = np.stack([O.synth_utterance(40 + u, T * hop, omic) for u in range(4)]).astype(np.float32)   # 4 distinct utterances
+    idx = (np.arange(B) * 7 + np.arange(B) // 5) % 4
+    x = base[idx]                                                          # [B, M, L]
+    full = make(mic, B)
+    y = np.asarray(run(full, x))
+    assert y.shape == (B, T * hop) and np.all(np.isfinite(y)) and np.any(y != 0)
+    for u in range(4):                                                     # position in the batch does not matter
+        rows = y[idx == u]
+        assert np.array_equal(rows, np.broadcast_to(rows[0], rows.shape))
+    one = make(mic, 1)
+    assert np.array_equal(np.asarray(run(one, x[3])), y[3])                # batch of one, same numbers
+    chunked = make(mic, B)
+    cut = 3 * hop
+    yc = np.concatenate([np.asarray(run(chunked, x[:, :, :cut])), np.asarray(run(chunked, x[:, :, cut:]))], axis=1)
+    assert np.array_equal(yc, y)                                           # state carried across calls, bitwise
+
+
 def test_dcnotch_shapes(ds):
     """The notch kernel's tiling (32-row workgroups, 256-sample tiles, 16-sample register chunks) over ragged shapes: rows that do not
     fill a workgroup, lengths that are not multiples of 16 or 4 (the scalar-access variant), several tiles, chunked == one call."""
