@@ -118,6 +118,15 @@ template <int NFFT> int run_tf(int M, bool inverse, const ds::Params& p, int bat
 
 }  // namespace
 
+// the F blocking filters of an utterance: per-instance operators (fan_form = 0) or the fan form (one (utterance, bin) at a time)
+template <int F> static void fan_rows(int op, const ds::OpParams& p) {
+    for (int u = 0; u < p.B / F; ++u)
+        for (int k = 0; k < p.K; ++k) {
+            if (op == ds::OP_SUBRLS) ds::op_subrls_fan<2, F>(p, u, k);
+            else ds::op_sublms_fan<2, F>(p, u, k);
+        }
+}
+
 extern "C" {
 
 // Transform.stft: x -> Y complex [B][T][K][M]; tail_in [B][M][hop] carried
@@ -163,6 +172,24 @@ int emul_op(int op, int B, int K, int T, float* st, int NF, const float* in0, co
     return 0;
 }
 
+
+int emul_fan(int op, int fan_form, int F, int B, int K, int T, float* st, int NF, const float* in0, const float* in1, const float* in2,
+             float* out0, int has_p, int norm, float mu, float alpha, float reg, float lam) {
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = st; p.NF = NF;
+    p.in0 = in0; p.in1 = in1; p.in2 = in2; p.out0 = out0;
+    p.M = 1; p.N = 2; p.has_p = has_p; p.norm = norm; p.mu = mu; p.alpha = alpha; p.reg = reg; p.lam = lam;
+    p.x_fan = F; p.d_interleaved = 1;
+    if (!fan_form) {
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < K; ++k) ds::run_op(op, p, b, k);
+        return 0;
+    }
+    if (!(op == ds::OP_SUBRLS ? ds::subrls_fan_ok(p) : ds::sublms_fan_ok(p))) return -1;
+    switch (F) { case 2: fan_rows<2>(op, p); break; case 4: fan_rows<4>(op, p); break; case 6: fan_rows<6>(op, p); break; default: fan_rows<8>(op, p); }
+    return 0;
+}
 
 int emul_adaptive_frames(int B, int K, int T, int M, float* st, int NF, const float* Z, const float* gain, float* Y, const float* steer,
                          int frm_cnt, int ell, int L, int method, float alpha_v, float gate, float diag) {

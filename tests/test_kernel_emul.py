@@ -334,3 +334,41 @@ def test_emul_adaptive_frames(M, nfft):
     g = np.linspace(0.2, 1.0, T * (nfft // 2 + 1)).reshape(1, T, -1).astype(np.float32)
     Ye = np.concatenate([em.run(Z[:, :20], g[:, :20]), em.run(Z[:, 20:], g[:, 20:])], axis=1)[0]
     assert rms(Ye - Yo * g[0]) < 1e-4 * rms(Yo)
+
+
+@pytest.mark.parametrize("op,F", [("subrls", 6), ("subrls", 4), ("sublms", 6), ("sublms", 2)])
+def test_fan_form_equals_instances(op, F):
+    """op_subrls_fan / op_sublms_fan (the F blocking filters of an utterance as one (utterance, bin) program: shared tap buffer, P / input
+    power and gain) against F per-instance operators with x_fan = F: errors and weights bit for bit, shared state equal to instance 0's."""
+    import ctypes
+    from emul import emul as E
+    lib = E.lib()
+    rng = np.random.default_rng(17)
+    U, K, N = 3, 129, 2
+    B, KP = U * F, (K + 3) & ~3
+    opid = {"sublms": 3, "subrls": 4}[op]
+    NF = 4 * N + 2 * N * N if op == "subrls" else 4 * N + 1
+    def fresh():
+        st = np.zeros((B, NF, KP), dtype=np.float32)
+        if op == "subrls":
+            for i in range(N):
+                st[:, 4 * N + 2 * (i * N + i), :] = 1000.0
+        return st
+    sts = [fresh(), fresh()]
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    f32 = ctypes.c_float
+    for T in (3, 1, 4):                                                     # three calls, state carried
+        x = (rng.standard_normal((U, T, K)) + 1j * rng.standard_normal((U, T, K))).astype(np.complex64)
+        d = (rng.standard_normal((U, T, K, F)) + 1j * rng.standard_normal((U, T, K, F))).astype(np.complex64)
+        pk = rng.uniform(0, 1, (U, T, K)).astype(np.float32)
+        outs = []
+        for form in (0, 1):
+            e = np.zeros((B, T, K), dtype=np.complex64)
+            rc = lib.emul_fan(opid, form, F, B, K, T, vp(sts[form]), NF, vp(x), vp(d), vp(pk) if op == "sublms" else None, vp(e),
+                              int(op == "sublms"), 1, f32(0.5 if op == "subrls" else 0.1), f32(0.9), f32(1e-4), f32(0.998))
+            assert rc == 0
+            outs.append(e)
+        assert np.array_equal(outs[0], outs[1])
+    a, b = sts
+    assert np.array_equal(a[:, : 2 * N, :K], b[:, : 2 * N, :K])                # every instance's weights
+    assert np.array_equal(a[::F, :, :K], b[::F, :, :K])                        # instance 0 of every utterance: all planes (W, taps, P)
