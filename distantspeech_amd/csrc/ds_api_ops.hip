@@ -205,7 +205,10 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, 
     DS_HIP(h, ds::launch_mcspp_qavg(h->dev_buf[3], h->dev_buf[3] + n, (int)nbt, h->K, h->stream));
     p.in1 = h->dev_buf[3]; p.in2 = h->dev_buf[3] + n; p.N = 9;
     p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
-    DS_HIP(h, ds::launch_binop((yout || phi_xx) ? ds::OP_MCSPP : ds::OP_MCSPP_LEAN, p, h->stream));
+    // three builds of the same estimation: with the notebook-MVDR / matrix outputs, lean (p and the optional PMWF weights), and the lean
+    // one for calls that start at frame 5 or later without weights (no second factorisation in the kernel: two waves per SIMD at 6 mics)
+    const int op = (yout || phi_xx) ? ds::OP_MCSPP : (w_pmwf || h->op_frm < 5) ? ds::OP_MCSPP_LEAN : ds::OP_MCSPP_STEADY;
+    DS_HIP(h, ds::launch_binop(op, p, h->stream));
     for (int t = 0; t < n_frames; ++t) {
         if (h->op_frm != 0 && h->op_ell % 65 == 0) h->op_ell = 0;
         h->op_frm += 1; h->op_ell += 1;

@@ -39,6 +39,15 @@ typedef float4 vec4;
 struct alignas(16) vec4 { float x, y, z, w; };
 #endif
 
+// keeps the compiler from forwarding values across it (used around a deliberate round trip through LDS); no instruction emitted
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DS_COMPILER_FENCE() asm volatile("" ::: "memory")
+#define DS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DS_COMPILER_FENCE() ((void)0)
+#define DS_SCHED_FENCE() ((void)0)
+#endif
+
 struct cf { float x, y; };
 
 // All floating-point contraction is explicit: the library is compiled with -ffp-contract=off and every

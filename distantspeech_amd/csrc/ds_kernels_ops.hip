@@ -54,7 +54,11 @@ template <int OP, int M> __global__ void __launch_bounds__(256) ds_binop_kernel(
     const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
     const int b = (int)(i / p.KP), k = (int)(i - (long long)b * p.KP);
     if (b >= p.B || k >= p.K) return;
-    const OpCtx c = make_op_ctx(p, i0);
+    OpCtx c = make_op_ctx(p, i0);
+    if constexpr (OP == OP_MCSPP_STEADY && M >= 5) {                        // parking space for Phi_vv (op_mcspp_lean): 235 registers instead of 256
+        __shared__ float park[(M * M + 1) * 256];
+        c.spill = park + threadIdx.x; c.spill_stride = 256;
+    }
     run_op_t<OP, M>(c, b, k);
 }
 

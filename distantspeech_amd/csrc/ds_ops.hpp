@@ -15,7 +15,8 @@
 namespace ds {
 
 enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4, OP_MCSPPBASE = 5, OP_WPE = 6, OP_MCCDR = 7, OP_MCSPP = 8, OP_STEERING = 9,
-       OP_MVDRW = 10, OP_ADAPTIVE = 11, OP_MCSPP_LEAN = 12 };   // LEAN: McSpp without the MVDR / matrix outputs (the SubbandGSC chain)
+       OP_MVDRW = 10, OP_ADAPTIVE = 11, OP_MCSPP_LEAN = 12,      // LEAN: McSpp without the MVDR / matrix outputs (the SubbandGSC chain)
+       OP_MCSPP_STEADY = 13 };                                   // ... and its variant for calls from frame 5 on without PMWF weights
 
 struct OpParams {
     int B, K, KP, T;          // utterances, bins, padded plane length, frames in this call
@@ -48,6 +49,8 @@ struct OpParams {
     long long steer_batch_stride;
     int method;               // OP_ADAPTIVE: METHOD_SRC / DS / MVDR
     float alpha_v, gate, diag;   // OP_ADAPTIVE: adaptivebeamformer.py:66,94,89
+    float* spill;             // lean McSpp at 6 microphones: per-lane parking space (LDS on the GPU) for Phi_vv while the solves run; element f of
+    int spill_stride;         // this lane at spill[f * spill_stride]; null = keep everything in registers
 };
 
 // Per-bin state access st_at(p, b, plane, k).  On the GPU it is a buffer access: the descriptor starts at the state of the first utterance
@@ -1054,7 +1057,7 @@ template <int M, bool LEAN = false> DS_HD void op_mcspp(const OpCtx& p, int b, i
 // McSpp without the notebook-MVDR / matrix outputs (OP_MCSPP_LEAN, the SubbandGSC chain): the same estimation_core, but nothing here
 // needs inv(Phi_vv + dv I) as a matrix — tr(A^-1 Phi_yy), A^-1 y and the PMWF column are Cholesky solves on the Hermitian-packed state,
 // which is less work and fewer live registers than forming the explicit inverse (the kernel still sits at one wave per SIMD at M = 6).
-template <int M> DS_HD void op_mcspp_lean(const OpCtx& p, int b, int k) {
+template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
     const int o0 = p.N;
     float yd[M], yo[2 * NO + 1], vd[M], vo[2 * NO + 1];
@@ -1093,19 +1096,33 @@ template <int M> DS_HD void op_mcspp_lean(const OpCtx& p, int b, int k) {
                 for (int i = 0; i < M; ++i) col[i] = herm_get<M>(yd, yo, i, j);
                 ch.solve(col, sol);
                 tr += sol[j].x;
+                DS_SCHED_FENCE();
             }
             return tr;
         };
         ch.factor(vd, vo, dv);
+        // Phi_vv is not needed again before the noise update at the end of the frame: parked (LDS) while the solves run, which is what
+        // lets two waves share a SIMD at 6 microphones
+        if (p.spill) {
+#pragma unroll
+            for (int f = 0; f < M; ++f) p.spill[f * p.spill_stride] = vd[f];
+#pragma unroll
+            for (int f = 0; f < 2 * NO; ++f) p.spill[(M + f) * p.spill_stride] = vo[f];
+            DS_COMPILER_FENCE();
+        }
         float tr = trace_with_pyy();
         // :219-228: where xi < 0 the reference falls back to A = Phi_yy (+ dv I in the first five frames).  From frame 5 on that makes
         // A^-1 Phi_yy the identity: tr - M and y^H A^-1 Phi_yy A^-1 y - y^H A^-1 y are zero up to rounding (1e-14 in the reference's
         // doubles), so both clamp to their floor 1e-6 (:230,236) — taken here as exactly that, without a second factorisation and trace
         // whose fp32 rounding would only land somewhere in 1e-6 .. 1e-5.  The PMWF weights (out1) still need A^-1.
-        const bool fell = tr - (float)M < 0.0f, ident = fell && frm >= 5;
-        if (fell && (!ident || p.out1)) {
-            ch.factor(yd, yo, frm < 5 ? dv : 0.0f);
-            if (!ident) tr = trace_with_pyy();
+        // STEADY: the variant for calls that start at frame 5 or later and do not ask for the PMWF weights — the second factorisation does
+        // not exist in it, which is what brings the 6-microphone kernel under 256 registers (two waves per SIMD)
+        const bool fell = tr - (float)M < 0.0f, ident = fell && (STEADY || frm >= 5);
+        if constexpr (!STEADY) {
+            if (fell && (!ident || p.out1)) {
+                ch.factor(yd, yo, frm < 5 ? dv : 0.0f);
+                if (!ident) tr = trace_with_pyy();
+            }
         }
         xi = ident ? 1e-6f : fminf_(fmaxf_(tr - (float)M, 1e-6f), 1e8f);           // :230
         gam = 1e-6f;
@@ -1126,14 +1143,23 @@ template <int M> DS_HD void op_mcspp_lean(const OpCtx& p, int b, int k) {
         pp = 1.0f / (1.0f + q / (1.0f - q) * (1.0f + xi) * expf(-1.0f * (gam / (1.0f + xi))));   // compute_p :75-92
         pp = fminf_(fmaxf_(pp, 0.0f), 1.0f);
         const long long ob = fb + k;
-        if (p.out1) {                                                              // compute_pmwf_weight beta = 10 :283, Phi_xx before the noise update
-            const float wsc = 1.0f / (10.0f + xi);
-            cf col[M], w[M];
+        if (p.spill) {
+            DS_COMPILER_FENCE();
 #pragma unroll
-            for (int i = 0; i < M; ++i) col[i] = csub(herm_get<M>(yd, yo, i, 0), herm_get<M>(vd, vo, i, 0));
-            ch.solve(col, w);
+            for (int f = 0; f < M; ++f) vd[f] = p.spill[f * p.spill_stride];
 #pragma unroll
-            for (int i = 0; i < M; ++i) { p.out1[2 * (ob * M + i)] = w[i].x * wsc; p.out1[2 * (ob * M + i) + 1] = w[i].y * wsc; }
+            for (int f = 0; f < 2 * NO; ++f) vo[f] = p.spill[(M + f) * p.spill_stride];
+        }
+        if constexpr (!STEADY) {
+            if (p.out1) {                                                          // compute_pmwf_weight beta = 10 :283, Phi_xx before the noise update
+                const float wsc = 1.0f / (10.0f + xi);
+                cf col[M], w[M];
+#pragma unroll
+                for (int i = 0; i < M; ++i) col[i] = csub(herm_get<M>(yd, yo, i, 0), herm_get<M>(vd, vo, i, 0));
+                ch.solve(col, w);
+#pragma unroll
+                for (int i = 0; i < M; ++i) { p.out1[2 * (ob * M + i)] = w[i].x * wsc; p.out1[2 * (ob * M + i) + 1] = w[i].y * wsc; }
+            }
         }
         const float at = fma_((float)(1.0 - 0.92), pp, 0.92f);                     // update_noise_psd (alpha_d = 0.92)
         herm_rank1<M>(vd, vo, Z, at, 1.0f - at);
@@ -1233,17 +1259,18 @@ template <int OP, int M> DS_HD void run_op_t(const OpCtx& p, int b, int k) {
     else if constexpr (OP == OP_MCSPPBASE) op_mcsppbase<M>(p, b, k);
     else if constexpr (OP == OP_MCSPP) op_mcspp<M>(p, b, k);
     else if constexpr (OP == OP_MCSPP_LEAN) op_mcspp_lean<M>(p, b, k);
+    else if constexpr (OP == OP_MCSPP_STEADY) op_mcspp_lean<M, true>(p, b, k);
     else if constexpr (OP == OP_STEERING) op_steering<M>(p, b, k);
     else if constexpr (OP == OP_MVDRW) op_mvdrw<M>(p, b, k);
     else if constexpr (OP == OP_ADAPTIVE) op_adaptive<M>(p, b, k);
 }
 
-inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_MCSPP || op == OP_STEERING || op == OP_MVDRW || op == OP_ADAPTIVE || op == OP_MCSPP_LEAN; }
+inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_MCSPP || op == OP_STEERING || op == OP_MVDRW || op == OP_ADAPTIVE || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY; }
 
 // is (op, M) a supported combination?  (matrix operators: M in {2, 4, 6, 8}; McSpp / steering / mvdr weight: {2, 4, 6})
 inline bool op_supported(int op, int M) {
     if (op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_ADAPTIVE) return M == 2 || M == 4 || M == 6 || M == 8;
-    if (op == OP_MCSPP || op == OP_MCSPP_LEAN || op == OP_STEERING || op == OP_MVDRW) return M == 2 || M == 4 || M == 6;
+    if (op == OP_MCSPP || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY || op == OP_STEERING || op == OP_MVDRW) return M == 2 || M == 4 || M == 6;
     return true;
 }
 
@@ -1252,7 +1279,7 @@ inline bool op_supported(int op, int M) {
 #define DS_FOR_EACH_OP(X) \
     X(OP_MCRA, 1) X(OP_OMLSA, 1) X(OP_SUBLMS, 1) X(OP_SUBRLS, 1) X(OP_MCCDR, 1) \
     DS_OP_M_LIST(X, OP_MCMCRA) DS_OP_M_LIST(X, OP_MCSPPBASE) DS_OP_M_LIST(X, OP_ADAPTIVE) \
-    DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_MCSPP_LEAN) DS_OP_M3_LIST(X, OP_STEERING) DS_OP_M3_LIST(X, OP_MVDRW)
+    DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_MCSPP_LEAN) DS_OP_M3_LIST(X, OP_MCSPP_STEADY) DS_OP_M3_LIST(X, OP_STEERING) DS_OP_M3_LIST(X, OP_MVDRW)
 
 // runtime dispatch for the serial CPU run in tests/emul (the GPU launches one specialised kernel per (OP, M))
 inline void run_op(int op, const OpCtx& p, int b, int k) {

@@ -158,13 +158,16 @@ class EmulOp:
             self.first = 0
         return outs
 
-    def run_mcspp(self, y, Fn, want_yout=True, want_matrices=False):
-        """McSpp handle: McCDR pass (L = 65) then McSpp pass, like ds_mcspp_estimate()."""
+    def run_mcspp(self, y, Fn, want_yout=True, want_matrices=False, variant=8):
+        """McSpp handle: McCDR pass (L = 65) then McSpp pass, like ds_mcspp_estimate().  variant: 8 = OP_MCSPP (all outputs),
+        12 = OP_MCSPP_LEAN, 13 = OP_MCSPP_STEADY (p only)."""
         y = np.ascontiguousarray(y, dtype=np.complex64)
         B, T, K, M = y.shape
         self.op_override, self.L_override, self.hold_counters = 7, 65, True
         gamma = self.run(y, np.ascontiguousarray(Fn, dtype=np.float32))[0]
-        self.op_override, self.N_override, self.hold_counters = 8, 9, False
+        self.op_override, self.N_override, self.hold_counters = variant, 9, False
+        if variant != 8:
+            return self.run(y, gamma, out_shapes=[((), np.float32)])
         shapes = [((), np.float32), ((M,), np.complex64)]
         shapes.append(((), np.complex64))
         if want_matrices:

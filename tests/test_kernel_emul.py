@@ -230,6 +230,25 @@ def test_emul_mcspp_notebook_mvdr(name):
     assert np.median(rel) < 1e-2
 
 
+@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+def test_emul_mcspp_lean_and_steady(name):
+    """The SubbandGSC chain's McSpp builds: OP_MCSPP_LEAN (Cholesky solves, p only) against the reference's p like the full operator, and
+    OP_MCSPP_STEADY (calls from frame 5 on: no second factorisation in the kernel) == OP_MCSPP_LEAN bit for bit."""
+    from oracle import ds_oracle as O
+    g = load("g11_mcspp_" + name)
+    M, nfft, hop = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    D = EmulTransform(nfft, M).stft(np.ascontiguousarray(x.T)[None], 0)
+    Fn = O.gen_noise_msc(O.OracleMicArray(arrayType="circular", r=0.032, M=M), nfft)[:, 1, 2]
+    p_lean = EmulOp("mcspp", nfft, M=M).run_mcspp(D, Fn, variant=12)[0]
+    assert np.all(np.isfinite(p_lean))
+    assert np.median(np.abs(p_lean[0] - g["p"])) < 1e-3 and np.mean(np.abs(p_lean[0] - g["p"]) > 0.05) < 0.05
+    op = EmulOp("mcspp", nfft, M=M)
+    head = op.run_mcspp(D[:, :8], Fn, variant=12)[0]
+    tail = op.run_mcspp(D[:, 8:], Fn, variant=13)[0]
+    assert np.array_equal(np.concatenate([head, tail], axis=1), p_lean)
+
+
 def test_emul_steering_and_mvdr_weight():
     from oracle import ds_oracle as O
     rng = np.random.default_rng(4)
