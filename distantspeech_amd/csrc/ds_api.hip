@@ -84,6 +84,15 @@ int zero_state(ds_handle* h) {
     return DS_OK;
 }
 
+hipError_t launch_transform_stft(const ds_handle* t, const Params& p, int batch, hipStream_t stream) {
+    if (t->cfg.n_mics == 1 && t->ki_rows.launch && p.batch0 == 0) return t->ki_rows.launch(p, batch, stream);
+    return t->ki.launch(p, batch, stream);
+}
+hipError_t launch_transform_istft(const ds_handle* t, const Params& p, int batch, hipStream_t stream) {
+    if (t->cfg.n_mics == 1 && t->ki_rows_istft.launch && p.batch0 == 0 && p.method == 1) return t->ki_rows_istft.launch(p, batch, stream);
+    return t->ki_istft.launch(p, batch, stream);
+}
+
 void fill_params(const ds_handle* h, Params& p) {
     std::memset(&p, 0, sizeof(p));
     p.bins = h->bins;
@@ -239,7 +248,10 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->graph_exec = nullptr; h->graph_valid = false;
     h->split = 1; h->ev_fork = nullptr;
     for (int i = 0; i < 7; ++i) { h->side[i] = nullptr; h->ev_join[i] = nullptr; }
-    h->ki_istft = ki_istft; h->op = op; h->opst = nullptr; h->NF = NF;
+    h->ki_istft = ki_istft; h->op = op;
+    h->ki_rows = KernelInfo{nullptr, 0, 0, 0}; h->ki_rows_istft = h->ki_rows;
+    if (cfg->algo == DS_ALGO_TRANSFORM && cfg->n_mics == 1) { h->ki_rows = ds::lookup_stft_rows(cfg->nfft); h->ki_rows_istft = ds::lookup_istft_rows(cfg->nfft); }
+ h->opst = nullptr; h->NF = NF;
     h->op_frm = 0; h->op_ell = 1; h->op_first = 1;
     h->filter_len = flen; h->norm = cfg->no_norm ? 0 : 1;
     h->filt_mu = cfg->filt_mu > 0 ? cfg->filt_mu : (cfg->algo == DS_ALGO_SUBRLS ? 0.5f : 0.1f);

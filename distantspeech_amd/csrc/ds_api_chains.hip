@@ -59,7 +59,7 @@ int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long
         p.x_batch_stride = (long long)T * K * 2;
         p.y_batch_stride = y_batch_stride;
         p.T = T; p.batch0 = 0; p.method = 1;
-        DS_HIP(h, t->ki_istft.launch(p, B, h->stream));
+        DS_HIP(h, launch_transform_istft(t, p, B, h->stream));
     }
 #undef DS_SUB
     return DS_OK;
@@ -94,7 +94,7 @@ static int chain_stft(ds_handle* h, ds_handle* t, const float* x, int n, float* 
     p.x_batch_stride = (long long)C * n; p.x_sample_stride = 1; p.x_chan_stride = n;
     p.y_batch_stride = (long long)T * t->K * C * 2;
     p.T = T; p.batch0 = 0;
-    DS_HIP(h, t->ki.launch(p, t->cfg.batch, t->stream));
+    DS_HIP(h, launch_transform_stft(t, p, t->cfg.batch, t->stream));
     return DS_OK;
 }
 static int chain_istft(ds_handle* h, ds_handle* t, const float* Y, int T, float* y, long long y_batch_stride) {
@@ -104,7 +104,7 @@ static int chain_istft(ds_handle* h, ds_handle* t, const float* Y, int T, float*
     p.x_batch_stride = (long long)T * t->K * 2;
     p.y_batch_stride = y_batch_stride;
     p.T = T; p.batch0 = 0; p.method = 1;
-    DS_HIP(h, t->ki_istft.launch(p, t->cfg.batch, t->stream));
+    DS_HIP(h, launch_transform_istft(t, p, t->cfg.batch, t->stream));
     return DS_OK;
 }
 

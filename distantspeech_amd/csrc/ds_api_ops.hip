@@ -120,7 +120,7 @@ int ds_stft(ds_handle* h, const float* x, int layout, int n_samples, float* Y, i
     if (layout == DS_LAYOUT_CHANNELS_SAMPLES) { p.x_sample_stride = 1; p.x_chan_stride = n_samples; }
     else { p.x_sample_stride = (long long)M; p.x_chan_stride = 1; }
     p.T = (int)T; p.batch0 = 0;
-    DS_HIP(h, h->ki.launch(p, h->cfg.batch, h->stream));
+    DS_HIP(h, launch_transform_stft(h, p, h->cfg.batch, h->stream));
     return io_end(h, mem, io, dout);
 }
 
@@ -142,7 +142,7 @@ int ds_istft(ds_handle* h, const float* Y, int n_frames, int n_channels, float* 
     p.x_batch_stride = (long long)(T * h->K * C * 2);
     p.y_batch_stride = (long long)(T * h->cfg.hop * C);
     p.T = (int)T; p.batch0 = 0; p.method = n_channels;
-    DS_HIP(h, h->ki_istft.launch(p, h->cfg.batch, h->stream));
+    DS_HIP(h, launch_transform_istft(h, p, h->cfg.batch, h->stream));
     return io_end(h, mem, io, dout);
 }
 

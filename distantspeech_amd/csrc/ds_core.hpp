@@ -112,6 +112,7 @@ struct Params {
     float diag;               // adaptivebeamformer.py:89
     float gate;               // adaptivebeamformer.py:94
     float mu;                 // GSC.py:202
+    int rows;                 // single-channel transforms run one row per wavefront (StftRowsEngine / IstftRowsEngine): number of rows
 };
 
 // number of per-bin state floats / planes
@@ -1053,6 +1054,190 @@ template <int NFFT, int M> struct IstftEngine {
                 const int m = i / (HOP / 4), q = i - m * (HOP / 4);
                 t4[i] = *reinterpret_cast<const vec4*>(&sh.tail[m][4 * q]);
             }
+        });
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Single-channel transforms, one row (utterance) per WAVEFRONT: the 64 lanes of a wave run every phase of their row's transform
+// (2 or 4 points per lane in the split / merge phases, NC / 256 butterflies per lane in the FFT stages), so nothing inside the
+// hop loop needs a workgroup barrier and no lane idles while "its" channel is in another wave's hands.  Four rows per workgroup
+// share the tables.  Same per-element arithmetic as StftEngine<NFFT, 1> / IstftEngine<NFFT, 1>.
+//   STFT : x rows (p.x + row * x_batch_stride, contiguous samples)  ->  Y complex [row][T][K]  (p.y + row * y_batch_stride floats)
+//   ISTFT: Y complex [row][T][K] (p.x + row * x_batch_stride floats) -> y rows (p.y + row * y_batch_stride)
+// ---------------------------------------------------------------------------------------------
+template <int NFFT> struct SharedRows {
+    static constexpr int N = NFFT, NC = NFFT / 2, HOP = NFFT / 2, NCP = NC + NC / 4, ROWS = 4;
+    alignas(16) Tables<NFFT> tb;
+    alignas(16) float xrow[ROWS][N];      // STFT: [old hop | new hop] per row
+    cf fa[ROWS][NCP];
+    cf fb[ROWS][NCP];
+    alignas(16) float tail[ROWS][HOP];    // ISTFT: overlap-add tail per row
+};
+template <int NFFT> struct RowView {         // what fft_stage sees of one row
+    static constexpr int NCP = NFFT / 2 + NFFT / 8;
+    const Tables<NFFT>& tb;
+    float (*xbuf)[NFFT];
+};
+struct RowRegs { vec4 pre[2]; };
+
+template <int NFFT> struct StftRowsEngine {
+    static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2, ROWS = 4, NT = 64 * ROWS, NV = HOP / 256;
+    static_assert(HOP % 256 == 0, "a lane carries whole 16-byte pieces of a hop");
+    typedef SharedRows<NFFT> Sh;
+    typedef RowRegs Rg;
+
+    template <class Exec> static DS_HD void run(Exec& ex, const Params& p, int blk, Sh& sh) {
+        auto where = [&](int tid, int& w, int& lane, int& row) { w = tid >> 6; lane = tid & 63; row = blk * ROWS + w; return row < p.rows; };
+        ex.phase([&](int tid, Rg& r) {
+            vec4* tb4 = reinterpret_cast<vec4*>(&sh.tb);
+            for (int i = tid; i < Tables<NFFT>::NV4; i += NT) tb4[i] = p.tables[i];
+            int w, lane, row;
+            if (!where(tid, w, lane, row)) return;
+            const vec4* tin4 = reinterpret_cast<const vec4*>(p.tail_in + (long long)row * HOP);
+            const vec4* x4 = reinterpret_cast<const vec4*>(p.x + (long long)row * p.x_batch_stride);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                *reinterpret_cast<vec4*>(&sh.xrow[w][4 * (lane + 64 * i)]) = tin4[lane + 64 * i];
+                r.pre[i] = x4[lane + 64 * i];
+            }
+        });
+        int old_half = 0;
+        for (int t = 0; t < p.T; ++t) {
+            const int new_half = old_half ^ 1;
+            ex.phase_wave([&](int tid, Rg& r) {
+                int w, lane, row;
+                if (!where(tid, w, lane, row)) return;
+                const vec4* x4 = reinterpret_cast<const vec4*>(p.x + (long long)row * p.x_batch_stride + (long long)(t + 1) * HOP);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    *reinterpret_cast<vec4*>(&sh.xrow[w][new_half * HOP + 4 * (lane + 64 * i)]) = r.pre[i];
+                    if (t + 1 < p.T) r.pre[i] = x4[lane + 64 * i];
+                }
+            });
+            auto stage = [&](auto f) {
+                ex.phase_wave([&](int tid, Rg&) {
+                    int w, lane, row;
+                    if (!where(tid, w, lane, row)) return;
+                    RowView<NFFT> rv = {sh.tb, &sh.xrow[w]};
+                    f(lane, rv, &sh.fa[w][0], &sh.fb[w][0]);
+                });
+            };
+            stage([&](int l, RowView<NFFT>& rv, cf* fa, cf* fb) { fft_stage<NFFT, 1, 4, -1, true, 0, 1>(l, 64, rv, nullptr, fa, 1, old_half, 1); });
+            stage([&](int l, RowView<NFFT>& rv, cf* fa, cf* fb) { fft_stage<NFFT, 1, 4, -1, false, 1, 2>(l, 64, rv, fa, fb, 4, 0, 1); });
+            stage([&](int l, RowView<NFFT>& rv, cf* fa, cf* fb) { fft_stage<NFFT, 1, 4, -1, false, 2, 0>(l, 64, rv, fb, fa, 16, 0, 1); });
+            stage([&](int l, RowView<NFFT>& rv, cf* fa, cf* fb) { fft_stage<NFFT, 1, 4, -1, false, 0, 0>(l, 64, rv, fa, fb, 64, 0, 1); });
+            if (NC == 512)
+                stage([&](int l, RowView<NFFT>& rv, cf* fa, cf* fb) { fft_stage<NFFT, 1, 2, -1, false, 0, 0>(l, 64, rv, fb, fa, 256, 0, 1); });
+            ex.phase_wave([&](int tid, Rg&) {
+                int w, lane, row;
+                if (!where(tid, w, lane, row)) return;
+                const cf* F = NC == 512 ? &sh.fa[w][0] : &sh.fb[w][0];
+                cf* Yt = reinterpret_cast<cf*>(p.y + (long long)row * p.y_batch_stride) + (long long)t * K;
+                for (int k = lane; k < NC; k += 64) {
+                    const int k2 = (NC - k) & (NC - 1);
+                    const cf wk = sh.tb.tw[k];
+                    const cf A = F[k], Bc = cconj(F[k2]);
+                    const cf E = cscale(cadd(A, Bc), 0.5f);
+                    const cf D = csub(A, Bc);
+                    const cf O = mk(0.5f * D.y, -0.5f * D.x);
+                    cf Z = cfma(E, wk, O);
+                    if (k == 0) Z.y = 0.0f;
+                    Yt[k] = Z;
+                }
+                if (lane == 0) { const cf F0 = F[0]; Yt[NC] = mk(F0.x - F0.y, 0.0f); }      // Nyquist bin
+            });
+            old_half = new_half;
+        }
+        ex.phase([&](int tid, Rg&) {
+            int w, lane, row;
+            if (!where(tid, w, lane, row)) return;
+            vec4* tin4 = reinterpret_cast<vec4*>(p.tail_in + (long long)row * HOP);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) tin4[lane + 64 * i] = *reinterpret_cast<const vec4*>(&sh.xrow[w][old_half * HOP + 4 * (lane + 64 * i)]);
+        });
+    }
+};
+
+template <int NFFT> struct IstftRowsEngine {
+    static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2, ROWS = 4, NT = 64 * ROWS, NV = HOP / 256, NPL = NC / 64;
+    typedef SharedRows<NFFT> Sh;
+    struct Rg { cf a[NPL], b[NPL]; };        // the next frame's Y[k] and Y[NC - k] of this lane's bins, in flight behind the current frame
+
+    template <class Exec> static DS_HD void run(Exec& ex, const Params& p, int blk, Sh& sh) {
+        auto where = [&](int tid, int& w, int& lane, int& row) { w = tid >> 6; lane = tid & 63; row = blk * ROWS + w; return row < p.rows; };
+        ex.phase([&](int tid, Rg&) {
+            vec4* tb4 = reinterpret_cast<vec4*>(&sh.tb);
+            for (int i = tid; i < Tables<NFFT>::NV4; i += NT) tb4[i] = p.tables[i];
+            int w, lane, row;
+            if (!where(tid, w, lane, row)) return;
+            const vec4* t4 = reinterpret_cast<const vec4*>(p.tail_out + (long long)row * HOP);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) *reinterpret_cast<vec4*>(&sh.tail[w][4 * (lane + 64 * i)]) = t4[lane + 64 * i];
+        });
+        auto fetch = [&](int row, int lane, int t, Rg& r) {
+            const cf* Yt = reinterpret_cast<const cf*>(p.x + (long long)row * p.x_batch_stride) + (long long)t * K;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) { const int k = lane + 64 * j; r.a[j] = Yt[k]; r.b[j] = Yt[NC - k]; }
+        };
+        ex.phase_wave([&](int tid, Rg& r) {
+            int w, lane, row;
+            if (where(tid, w, lane, row) && p.T > 0) fetch(row, lane, 0, r);
+        });
+        for (int t = 0; t < p.T; ++t) {
+            ex.phase_wave([&](int tid, Rg& r) {
+                int w, lane, row;
+                if (!where(tid, w, lane, row)) return;
+                cf* fa = &sh.fa[w][0];
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const int k = lane + 64 * j;
+                    const cf wk = cconj(sh.tb.tw[k]);
+                    cf A = r.a[j], B = r.b[j];
+                    if (k == 0) { A.y = 0.0f; B.y = 0.0f; }     // irfft ignores Im Y[0], Im Y[N/2]
+                    const cf Bc = cconj(B);
+                    const cf E = cscale(cadd(A, Bc), 0.5f);
+                    const cf O = cmul(cscale(csub(A, Bc), 0.5f), wk);
+                    fa[k] = mk(E.x - O.y, E.y + O.x);
+                }
+                if (t + 1 < p.T) fetch(row, lane, t + 1, r);
+            });
+            auto stage = [&](auto f) {
+                ex.phase_wave([&](int tid, Rg&) {
+                    int w, lane, row;
+                    if (!where(tid, w, lane, row)) return;
+                    RowView<NFFT> rv = {sh.tb, &sh.xrow[w]};
+                    f(lane, rv, &sh.fa[w][0], &sh.fb[w][0]);
+                });
+            };
+            stage([&](int l, RowView<NFFT>& rv, cf* fa, cf* fb) { fft_stage<NFFT, 1, 4, +1, false, 0, 1>(l, 64, rv, fa, fb, 1, 0, 1); });
+            stage([&](int l, RowView<NFFT>& rv, cf* fa, cf* fb) { fft_stage<NFFT, 1, 4, +1, false, 1, 2>(l, 64, rv, fb, fa, 4, 0, 1); });
+            stage([&](int l, RowView<NFFT>& rv, cf* fa, cf* fb) { fft_stage<NFFT, 1, 4, +1, false, 2, 0>(l, 64, rv, fa, fb, 16, 0, 1); });
+            stage([&](int l, RowView<NFFT>& rv, cf* fa, cf* fb) { fft_stage<NFFT, 1, 4, +1, false, 0, 0>(l, 64, rv, fb, fa, 64, 0, 1); });
+            if (NC == 512)
+                stage([&](int l, RowView<NFFT>& rv, cf* fa, cf* fb) { fft_stage<NFFT, 1, 2, +1, false, 0, 0>(l, 64, rv, fa, fb, 256, 0, 1); });
+            ex.phase_wave([&](int tid, Rg&) {
+                int w, lane, row;
+                if (!where(tid, w, lane, row)) return;
+                const cf* Zi = NC == 512 ? &sh.fb[w][0] : &sh.fa[w][0];
+                float* yrow = p.y + (long long)row * p.y_batch_stride + (long long)t * HOP;
+                const float sc = 1.0f / (float)NC;
+                for (int i = lane; i < NC / 2; i += 64) {
+                    const cf z1 = Zi[i], z2 = Zi[i + NC / 2];
+                    const float y0 = sh.tb.win[2 * i] * (z1.x * sc), y1 = sh.tb.win[2 * i + 1] * (z1.y * sc);
+                    const float o0 = (y0 + sh.tail[w][2 * i]) * p.out_scale, o1 = (y1 + sh.tail[w][2 * i + 1]) * p.out_scale;
+                    sh.tail[w][2 * i] = sh.tb.win[HOP + 2 * i] * (z2.x * sc);
+                    sh.tail[w][2 * i + 1] = sh.tb.win[HOP + 2 * i + 1] * (z2.y * sc);
+                    yrow[2 * i] = o0; yrow[2 * i + 1] = o1;
+                }
+            });
+        }
+        ex.phase([&](int tid, Rg&) {
+            int w, lane, row;
+            if (!where(tid, w, lane, row)) return;
+            vec4* t4 = reinterpret_cast<vec4*>(p.tail_out + (long long)row * HOP);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) t4[lane + 64 * i] = *reinterpret_cast<const vec4*>(&sh.tail[w][4 * (lane + 64 * i)]);
         });
     }
 };

@@ -41,6 +41,7 @@ struct ds_handle {
     // staging for host-pointer calls
     // frame-level objects (DS_ALGO_TRANSFORM .. DS_ALGO_SUBRLS)
     KernelInfo ki_istft;
+    KernelInfo ki_rows, ki_rows_istft;   // single-channel transform handles: the one-row-per-wavefront kernels (null launch = not available)
     int op;                     // ds::OP_* or -1
     float* opst;                // operator state [B][NF][KP]
     int NF;
@@ -101,6 +102,10 @@ size_t counters_bytes(const ds_handle* h);
 int set_device(ds_handle* h);
 int zero_state(ds_handle* h);
 void fill_params(const ds_handle* h, Params& p);
+// launch the analysis / synthesis of a transform handle (Params set up for one utterance per workgroup; p.method = channels of an
+// ISTFT): single-channel work goes to the one-row-per-wavefront kernels where they exist
+hipError_t launch_transform_stft(const ds_handle* t, const Params& p, int batch, hipStream_t stream);
+hipError_t launch_transform_istft(const ds_handle* t, const Params& p, int batch, hipStream_t stream);
 
 // staging for host-pointer calls of the frame-level objects (ds_api_ops.hip)
 struct IoSpec { const float* in[3]; size_t in_bytes[3]; float* out[5]; size_t out_bytes[5]; };

@@ -22,6 +22,8 @@ KernelInfo lookup_adaptive_ryy(int nfft, int M);
 KernelInfo lookup_gsc(int nfft, int M);
 KernelInfo lookup_stft(int nfft, int M);      // ds_kernels_ops.hip
 KernelInfo lookup_istft(int nfft, int M);
+KernelInfo lookup_stft_rows(int nfft);      // single-channel handles: one row per wavefront (nfft 512 / 1024), launch(p, rows, stream)
+KernelInfo lookup_istft_rows(int nfft);
 struct OpParams;
 hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream);
 struct TdParams;

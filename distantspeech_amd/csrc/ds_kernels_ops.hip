@@ -30,6 +30,44 @@ template <int NFFT, int M> hipError_t launch_istft(const Params& p, int nblocks,
     return hipGetLastError();
 }
 
+// single-channel transforms: one row per wavefront, four rows per workgroup (StftRowsEngine / IstftRowsEngine)
+template <int NFFT> __global__ void __launch_bounds__(256) ds_stft_rows_kernel(Params p) {
+    typedef StftRowsEngine<NFFT> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+template <int NFFT> __global__ void __launch_bounds__(256) ds_istft_rows_kernel(Params p) {
+    typedef IstftRowsEngine<NFFT> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+template <int NFFT> hipError_t launch_stft_rows(const Params& p0, int rows, hipStream_t stream) {
+    Params p = p0;
+    p.rows = rows;
+    hipLaunchKernelGGL((ds_stft_rows_kernel<NFFT>), dim3((rows + 3) / 4), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+template <int NFFT> hipError_t launch_istft_rows(const Params& p0, int rows, hipStream_t stream) {
+    Params p = p0;
+    p.rows = rows;
+    hipLaunchKernelGGL((ds_istft_rows_kernel<NFFT>), dim3((rows + 3) / 4), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+KernelInfo lookup_stft_rows(int nfft) {
+    KernelInfo ki = {nullptr, 0, 0, 0};
+    if (nfft == 512) ki = KernelInfo{&launch_stft_rows<512>, 0, (512 / 2 + 4) & ~3, 256};
+    if (nfft == 1024) ki = KernelInfo{&launch_stft_rows<1024>, 0, (1024 / 2 + 4) & ~3, 256};
+    return ki;
+}
+KernelInfo lookup_istft_rows(int nfft) {
+    KernelInfo ki = {nullptr, 0, 0, 0};
+    if (nfft == 512) ki = KernelInfo{&launch_istft_rows<512>, 0, (512 / 2 + 4) & ~3, 256};
+    if (nfft == 1024) ki = KernelInfo{&launch_istft_rows<1024>, 0, (1024 / 2 + 4) & ~3, 256};
+    return ki;
+}
+
 #define DS_FOR_EACH_TSHAPE(X) \
     X(256, 1) X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) X(256, 7) X(256, 8) \
     X(512, 1) X(512, 2) X(512, 3) X(512, 4) X(512, 5) X(512, 6) X(512, 7) X(512, 8) \

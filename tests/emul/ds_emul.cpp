@@ -109,7 +109,16 @@ template <int LPB> int run_wpe(const ds::WpeParams& p) {
     return 0;
 }
 
+// single-channel transforms at nfft 512 / 1024 run one row per wavefront in the product (launch_transform_stft / _istft): same route here
+template <class E> int run_rows(ds::Params p, int rows, int nfft) {
+    p.rows = rows;
+    return run_engine<E>(p, (rows + 3) / 4, nfft);
+}
 template <int NFFT> int run_tf(int M, bool inverse, const ds::Params& p, int batch) {
+    if constexpr (NFFT >= 512) {
+        if (M == 1 && (!inverse || p.method == 1))
+            return inverse ? run_rows<ds::IstftRowsEngine<NFFT>>(p, batch, NFFT) : run_rows<ds::StftRowsEngine<NFFT>>(p, batch, NFFT);
+    }
 #define TF(M_) if (M == M_) return inverse ? run_engine<ds::IstftEngine<NFFT, M_>>(p, batch, NFFT) : run_engine<ds::StftEngine<NFFT, M_>>(p, batch, NFFT);
     TF(1) TF(2) TF(3) TF(4) TF(5) TF(6) TF(7) TF(8)
 #undef TF

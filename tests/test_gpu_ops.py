@@ -347,6 +347,27 @@ def test_chain_full_batch_properties(ds, cfg):
     assert np.array_equal(yc, y)                                           # state carried across calls, bitwise
 
 
+@pytest.mark.parametrize("nfft", [512, 1024])
+def test_single_channel_rows_kernels(ds, nfft):
+    """Single-channel Transform objects run one row per wavefront (four rows per workgroup); multi-channel objects keep one utterance
+    per workgroup.  6 single-channel rows against the same signals as both channels of 2-channel objects: bit for bit, state carried."""
+    rng = np.random.default_rng(31)
+    hop, B, T = nfft // 2, 6, 5
+    x = (rng.standard_normal((B, 2 * T * hop)) * 0.1).astype(np.float32)
+    tb = ds.Transform(channel=1, n_fft=nfft, hop_length=hop, batch=B)
+    ib = ds.Transform(channel=1, n_fft=nfft, hop_length=hop, batch=B)
+    ts = [ds.Transform(channel=2, n_fft=nfft, hop_length=hop) for _ in range(B)]
+    is_ = [ds.Transform(channel=2, n_fft=nfft, hop_length=hop) for _ in range(B)]
+    for a in (0, T * hop):
+        Yb = tb.stft(x[:, a:a + T * hop, None])                                     # [B, K, T, 1]
+        Ys = np.stack([t.stft(np.repeat(x[b, a:a + T * hop, None], 2, axis=1)) for b, t in enumerate(ts)])   # [B, K, T, 2]
+        assert np.array_equal(Yb[..., 0], Ys[..., 0]) and np.array_equal(Yb[..., 0], Ys[..., 1])
+        yb = ib.istft(Yb)                                                           # [B, L, 1]
+        ys = np.stack([t.istft(Ys[b]) for b, t in enumerate(is_)])                  # [B, L, 2]
+        assert np.array_equal(np.squeeze(yb), ys[..., 0])
+    assert rms(np.squeeze(yb)[:, hop:] - x[:, T * hop: 2 * T * hop - hop]) < 1e-5   # perfect reconstruction, one hop late
+
+
 def test_dcnotch_shapes(ds):
     """The notch kernel's tiling (32-row workgroups, 256-sample tiles, 16-sample register chunks) over ragged shapes: rows that do not
     fill a workgroup, lengths that are not multiples of 16 or 4 (the scalar-access variant), several tiles, chunked == one call."""

@@ -391,3 +391,24 @@ def test_fan_form_equals_instances(op, F):
     a, b = sts
     assert np.array_equal(a[:, : 2 * N, :K], b[:, : 2 * N, :K])                # every instance's weights
     assert np.array_equal(a[::F, :, :K], b[::F, :, :K])                        # instance 0 of every utterance: all planes (W, taps, P)
+
+
+@pytest.mark.parametrize("nfft", [512, 1024])
+def test_single_channel_rows_engine_equals_block_engine(nfft):
+    """Single-channel transforms run one row per wavefront, four rows per workgroup (StftRowsEngine / IstftRowsEngine); the
+    multi-channel engines keep one utterance per workgroup.  A batch of 6 single-channel rows (two workgroups, the second half full)
+    against the same signals as the two channels of 2-channel objects: bit for bit, analysis and synthesis, state carried."""
+    rng = np.random.default_rng(23)
+    hop, B, T = nfft // 2, 6, 4
+    x = (rng.standard_normal((B, 2 * T * hop)) * 0.1).astype(np.float32)
+    rows, rows_i = EmulTransform(nfft, 1, batch=B), EmulTransform(nfft, 1, batch=B)
+    blk = [EmulTransform(nfft, 2) for _ in range(B)]
+    blk_i = [EmulTransform(nfft, 2) for _ in range(B)]
+    for a in (0, T * hop):
+        Yr = rows.stft(x[:, a:a + T * hop, None])                               # [B, T, K, 1]
+        Yb = np.stack([t.stft(np.repeat(x[b, a:a + T * hop, None], 2, axis=1)[None])[0] for b, t in enumerate(blk)])   # [B, T, K, 2]
+        assert np.array_equal(Yr[..., 0], Yb[..., 0]) and np.array_equal(Yr[..., 0], Yb[..., 1])
+        yr = rows_i.istft(Yr)                                                   # [B, L, 1]
+        yb = np.stack([t.istft(Yb[b][None])[0] for b, t in enumerate(blk_i)])   # [B, L, 2]
+        assert np.array_equal(yr[..., 0], yb[..., 0])
+    assert rms(yr[:, hop:, 0] - x[:, T * hop: 2 * T * hop - hop]) < 1e-5 * 10    # perfect reconstruction, one hop late
