@@ -162,7 +162,8 @@ template <int NFFT, int M, int NYQF = 4> struct Shared {
     float pw[K + 3];      // |Z_0|^2 for the MCRA frequency stencil
     cf Y[K + 1];          // beamformer output spectrum
     alignas(16) float tail[HOP];      // overlap-add tail
-    alignas(16) float nyq[NYQF];      // per-bin state of the Nyquist bin (k = N/2), processed by thread 0 in a second pass
+    alignas(16) float nyq[NYQF];      // per-bin state of the Nyquist bin (k = N/2)
+    float zn[M];                      // ... and its input Z[N/2][m] (real)
 };
 
 template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
@@ -628,7 +629,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
     // 512-point frames: every stage is radix-4 with exactly 64 butterflies per channel, so a channel's transform never leaves its
     // wavefront (the 128- and 512-point plans end in a radix-2 stage with a different butterfly-to-lane map and keep their barriers)
     static constexpr bool WAVE_FFT = NC == 256;
-    static constexpr int NYQ_TID = NT > 64 ? 64 : 0;         // thread (wave 1) that also runs the Nyquist bin k = NC
+    static constexpr int NYQ_TID = 0;                        // lane (wave 0, idle during the inverse FFT stages) that runs the Nyquist bin k = NC
     static constexpr int INV_T0 = NT / 2;                    // inverse-FFT butterflies run on threads [NT/2, NT)
     static constexpr int KP = (K + 3) & ~3;                  // padded plane length
     typedef StateLayout<M, ALGO, RYY> SL;
@@ -811,29 +812,39 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt);
                 if (tid == 0) Yk.y = 0.0f;                              // irfft ignores Im Y[0] and Im Y[N/2]
                 sh.Y[tid] = Yk;
-                if (tid == NYQ_TID) {                                   // second pass: the Nyquist bin, state in LDS
-                    cf Zn[M];
+                if (tid == NYQ_TID) {                                   // the Nyquist bin's inputs, before the inverse transform reuses the buffer
 #pragma unroll
-                    for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; Zn[m] = mk(F0.x - F0.y, 0.0f); }
-                    cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_cnt, reset, spp_cnt);
-                    Yn.y = 0.0f;
-                    sh.Y[NC] = Yn;
+                    for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; sh.zn[m] = F0.x - F0.y; }
                 }
             });
+            const int frm_nyq = frm_cnt, spp_nyq = spp_cnt;
             if (ALGO == ALGO_ADAPTIVE) {
                 if (reset) ell = 0;
                 frm_cnt += 1; ell += 1;
             }
             if (ALGO == ALGO_GSC) spp_cnt += 1;
             // ---- inverse packed real FFT -----------------------------------------------------------
+            // The Nyquist bin k = NC is the 257th bin of 256 lanes: its per-bin program (state in LDS) runs on lane NYQ_TID while another
+            // wave runs the inverse FFT stages, instead of as a second pass that the whole workgroup waits for.  The transform is linear,
+            // so it is taken with Y[NC] = 0 and the bin's contribution — the constant (Y[NC] / 2) (1 - j) on every packed point, i.e.
+            // +- Y[NC] / 2 on even / odd samples — is added in the overlap-add phase.
             ex.phase([&](int tid, Rg&) {
                 const int k = tid;
-                const cf A = sh.Y[k], Bc = cconj(sh.Y[NC - k]);
+                const cf A = sh.Y[k], Bc = k == 0 ? mk(0.0f, 0.0f) : cconj(sh.Y[NC - k]);
                 const cf E = cscale(cadd(A, Bc), 0.5f);
                 const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tb.tw[k]));
                 fa[k] = mk(E.x - O.y, E.y + O.x);                       // E + j O
             });
-            ph(WAVE_FFT, [&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 0, 1>(tid - INV_T0, NT, sh, fa, fb, 1, 0, 1); });
+            ph(WAVE_FFT, [&](int tid, Rg&) {
+                if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 0, 1>(tid - INV_T0, NT, sh, fa, fb, 1, 0, 1);
+                else if (tid == NYQ_TID) {
+                    cf Zn[M];
+#pragma unroll
+                    for (int m = 0; m < M; ++m) Zn[m] = mk(sh.zn[m], 0.0f);
+                    const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_nyq, reset, spp_nyq);
+                    sh.Y[NC] = mk(Yn.x, 0.0f);                          // irfft ignores Im Y[N/2]
+                }
+            });
             ph(WAVE_FFT, [&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 1, 2>(tid - INV_T0, NT, sh, fb, fa, 4, 0, 1); });
             ph(WAVE_FFT, [&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 2, 0>(tid - INV_T0, NT, sh, fa, fb, 16, 0, 1); });
             if (NC == 128) {
@@ -849,7 +860,9 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 if (tid < NC / 2) {
                     const int i = tid;
                     const float sc = 1.0f / (float)NC;
-                    const cf z1 = Zi[i], z2 = Zi[i + NC / 2];
+                    const float hn = 0.5f * sh.Y[NC].x;                 // the Nyquist bin's share of every even (+) / odd (-) sample
+                    cf z1 = Zi[i], z2 = Zi[i + NC / 2];
+                    z1.x += hn; z1.y -= hn; z2.x += hn; z2.y -= hn;
                     const float y0 = sh.tb.win[2 * i] * (z1.x * sc), y1 = sh.tb.win[2 * i + 1] * (z1.y * sc);
                     const float o0 = (y0 + sh.tail[2 * i]) * p.out_scale, o1 = (y1 + sh.tail[2 * i + 1]) * p.out_scale;
                     sh.tail[2 * i] = sh.tb.win[HOP + 2 * i] * (z2.x * sc);
