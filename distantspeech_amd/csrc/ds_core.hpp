@@ -223,9 +223,12 @@ template <int PAD> DS_HD int padi(int i) {
     else return i;
 }
 
-// in/out: [MCH][NCP].  FROM_X: read windowed real samples packed as (x[2n], x[2n+1]) from xbuf.
-template <int NFFT, int M, int R, int SIGN, bool FROM_X, int PIN, int POUT, class ShT>
+// in/out: [MCH][NCP].  FROM = 1: read windowed real samples packed as (x[2n], x[2n+1]) from xbuf.  FROM = 2 (inverse, one channel): form
+// point n of the packed spectrum from the output bins sh.Y[n], sh.Y[NC - n] on the fly (E + j O of the real-transform merge, with
+// the Nyquist bin taken as zero: see Engine::run).
+template <int NFFT, int M, int R, int SIGN, int FROM, int PIN, int POUT, class ShT>
 DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, int old_half, int MCH) {
+    constexpr bool FROM_X = FROM == 1;
     constexpr int NC = NFFT / 2, NB = NC / R, HOP = NFFT / 2, NCP = ShT::NCP;
     for (int idx = tid; idx < MCH * NB; idx += nt) {
         const int ch = idx / NB, j = idx - ch * NB;
@@ -238,6 +241,11 @@ DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, in
                 const int s = 2 * n;
                 const int pos = s < HOP ? old_half * HOP + s : (old_half ^ 1) * HOP + (s - HOP);
                 v[r] = mk(sh.tb.win[s] * sh.xbuf[ch][pos], sh.tb.win[s + 1] * sh.xbuf[ch][pos + 1]);
+            } else if constexpr (FROM == 2) {
+                const cf A = sh.Y[n], Bc = n == 0 ? mk(0.0f, 0.0f) : cconj(sh.Y[NC - n]);
+                const cf E = cscale(cadd(A, Bc), 0.5f);
+                const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tb.tw[n]));
+                v[r] = mk(E.x - O.y, E.y + O.x);                        // E + j O
             } else {
                 v[r] = in[ch * NCP + padi<PIN>(n)];
             }
@@ -828,15 +836,9 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // wave runs the inverse FFT stages, instead of as a second pass that the whole workgroup waits for.  The transform is linear,
             // so it is taken with Y[NC] = 0 and the bin's contribution — the constant (Y[NC] / 2) (1 - j) on every packed point, i.e.
             // +- Y[NC] / 2 on even / odd samples — is added in the overlap-add phase.
-            ex.phase([&](int tid, Rg&) {
-                const int k = tid;
-                const cf A = sh.Y[k], Bc = k == 0 ? mk(0.0f, 0.0f) : cconj(sh.Y[NC - k]);
-                const cf E = cscale(cadd(A, Bc), 0.5f);
-                const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tb.tw[k]));
-                fa[k] = mk(E.x - O.y, E.y + O.x);                       // E + j O
-            });
+            // The merge of the packed real transform (Y[k], Y[NC - k] -> point k) is formed inside the first inverse stage.
             ph(WAVE_FFT, [&](int tid, Rg&) {
-                if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 0, 1>(tid - INV_T0, NT, sh, fa, fb, 1, 0, 1);
+                if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, 2, 0, 1>(tid - INV_T0, NT, sh, nullptr, fb, 1, 0, 1);
                 else if (tid == NYQ_TID) {
                     cf Zn[M];
 #pragma unroll
