@@ -71,7 +71,7 @@ int zero_state(ds_handle* h) {
             for (int b = 0; b < h->cfg.batch; ++b)
                 for (int k = 0; k < h->K; ++k)
                     for (int i = 0; i < CN; ++i)
-                        st[(size_t)b * h->NF * h->KP + (size_t)k * SB + 2 * (i * CN + i)] = 1e-3f;
+                        st[(size_t)b * h->NF * h->KP + (size_t)k * SB + 2 * (i * (i + 1) / 2 + i)] = 1e-3f;   // diagonal of the packed upper triangle
         }
         if (h->op == ds::OP_SUBRLS) {                      // SubbandRLS.py:40-42: P = I / 1e-3
             const int N = h->filter_len;

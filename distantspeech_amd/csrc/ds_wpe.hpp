@@ -2,10 +2,17 @@
 //   x_delayed complex [B][T][K][C] (the frame from `delay` hops ago), d complex [B][T][K][C] (current frame)
 //   -> err complex [B][T][K][C] (dereverberated frame, all channels)
 // One (utterance, bin) is a CN x CN complex RLS (CN = C * N taps-by-channels, <= 16).  CN lanes share a bin: lane i keeps row i
-// of P, column i of W and tap i of the input buffer in registers for all T frames of the call; the three reductions of a frame
-// (W^H X, X^H P X, X^H P) go through LDS in a fixed order.  A workgroup of 128 lanes carries 128 / LPB bins (LPB = CN rounded up
-// to 4, 8 or 16).  State per bin is one contiguous block laid out slot-major, lane-minor, so that the CN lanes of a bin read
-// consecutive 8-byte words: every state access is a fully used 128-byte segment (CN = 16), once in and once out per call.
+// of P, column i of W and tap i of the input buffer in registers for all T frames of the call.  A workgroup of 128 lanes carries
+// 128 / LPB bins (LPB = CN rounded up to 4, 8 or 16).
+//
+// P, the inverse correlation matrix, is Hermitian, and the recursion is written so that it stays Hermitian bit for bit: with
+// g = P x the update is P <- (P - g g^H / den) / lambda, den = lambda var + Re(x^H g) — the reference's (P - k x^H P) / lambda with
+// x^H P replaced by (P x)^H and the rounding-level imaginary part of den dropped (awpe.py:174-185; equal in exact arithmetic).  That
+// buys three things: the third reduction of a frame (x^H P, a 16 x 16 exchange through LDS, more than half of the kernel's LDS)
+// is gone; only the upper triangle of P is state (1.1 KB instead of 2 KB per bin in HBM, read and written once per call: the
+// kernel is HBM-bound at one frame per call); and P cannot drift away from Hermitian over a long stream.
+// State per bin is one contiguous block; every lane reads the words it needs straight from it (its row above the diagonal, and
+// its column above the diagonal for the part of the row below it — no exchange), once in and once out per call.
 // Written against the Exec policy (tests/emul runs it serially on the CPU).
 #pragma once
 #include "ds_core.hpp"
@@ -14,10 +21,10 @@ namespace ds {
 
 constexpr int WPE_CNMAX = 16, WPE_CMAX = 8, WPE_NT = 128;
 
-// per-bin block: NQ = CN + C + 1 slots of CN complex, element (slot q, lane i) at 2 * (q * CN + i):
-//   q < CN: P[i][q]      CN <= q < CN + C: W[q - CN][i]      q = CN + C: input_buffer tap i      then var (1 float), padded to 16 B
-DS_HD constexpr int wpe_slots(int C, int N) { return C * N + C + 1; }
-DS_HD constexpr int wpe_bin_floats(int C, int N) { return (wpe_slots(C, N) * C * N * 2 + 1 + 3) & ~3; }
+// per-bin block, complex words: P upper triangle by columns, P[i][q] (i <= q) at q (q + 1) / 2 + i; then W[c][i] at NPK + c CN + i;
+// then input_buffer tap i at NPK + C CN + i; then var (1 float); padded to 16 B
+DS_HD constexpr int wpe_packed(int CN) { return CN * (CN + 1) / 2; }
+DS_HD constexpr int wpe_bin_floats(int C, int N) { return (2 * (wpe_packed(C * N) + C * C * N + C * N) + 1 + 3) & ~3; }
 DS_HD constexpr int wpe_lanes_per_bin(int CN) { return CN <= 4 ? 4 : CN <= 8 ? 8 : 16; }
 
 struct WpeParams {
@@ -40,9 +47,8 @@ template <int LPB> struct WpeShared {
     cf X[2][BPW][LPB];               // input buffer, double-buffered across frames (tap shift reads the neighbour lane)
     cf d[BPW][CM];
     cf part[BPW][CM][LPB + 1];       // conj(W[c][i]) X_i
-    cf dpart[BPW][LPB];              // conj(X_i) (P X)_i
-    cf xhp[BPW][LPB][LPB + 1];       // [j][i] = conj(X_i) P[i][j]
-    cf xh[BPW][LPB];                 // (X^H P)_j
+    cf num[BPW][LPB];                // g_i = (P X)_i
+    float dre[BPW][LPB];             // Re(conj(X_i) g_i)
     cf err[BPW][CM];
 };
 
@@ -94,18 +100,27 @@ template <int LPB> struct WpeEngine {
             if (!on) { if (i < LPB && s < BPW) sh.X[0][s][i] = mk(0.0f, 0.0f); return; }
             const float* stf = bin_state(g);
             const cf* st = reinterpret_cast<const cf*>(stf);
-#pragma unroll
-            for (int q = 0; q < LPB; ++q)
-                if (q < CN) r.P[q] = st[q * CN + i];
+            const int NPK = wpe_packed(CN);
+            cf* tri = &sh.part[s][0][0];                          // the packed triangle passes through LDS (the `part` tile, idle here):
+            for (int w = i; w < NPK; w += CN) tri[w] = st[w];     // consecutive lanes, consecutive words
 #pragma unroll
             for (int c = 0; c < CM; ++c)
-                if (c < C) r.W[c] = st[(CN + c) * CN + i];
-            sh.X[0][s][i] = st[(CN + C) * CN + i];
-            r.var = stf[2 * wpe_slots(C, N) * CN];
+                if (c < C) r.W[c] = st[NPK + c * CN + i];
+            sh.X[0][s][i] = st[NPK + C * CN + i];
+            r.var = stf[2 * (NPK + C * CN + CN)];
             const long long f0 = io_base(g, 0);
             const int c = i / N;
             if (i == c * N) r.xin = delayed(g, 0, c);
             if (i < C) r.din = mk(p.d[2 * (f0 + i)], p.d[2 * (f0 + i) + 1]);
+        });
+        ex.phase([&](int tid, Rg& r) {                            // row i of P: above the diagonal as stored, below it the conjugate of column i
+            int s, i; long long g; bool on;
+            slot(tid, s, i, g, on);
+            if (!on) return;
+            const cf* tri = &sh.part[s][0][0];
+#pragma unroll
+            for (int q = 0; q < LPB; ++q)
+                if (q < CN) r.P[q] = q >= i ? tri[q * (q + 1) / 2 + i] : cconj(tri[i * (i + 1) / 2 + q]);
         });
         int cur = 0;
         for (int t = 0; t < p.T; ++t) {
@@ -125,7 +140,7 @@ template <int LPB> struct WpeEngine {
                     }
                 }
             });
-            // ---- per-lane products: (P X)_i, conj(W[c][i]) X_i, conj(X_i) (P X)_i, conj(X_i) P[i][j]
+            // ---- per-lane products: g_i = (P X)_i, conj(W[c][i]) X_i, Re(conj(X_i) g_i)
             ex.phase([&](int tid, Rg& r) {
                 int s, i; long long g; bool on;
                 slot(tid, s, i, g, on);
@@ -134,12 +149,10 @@ template <int LPB> struct WpeEngine {
                 cf a = mk(0.0f, 0.0f);
 #pragma unroll
                 for (int j = 0; j < LPB; ++j)
-                    if (j < CN) {
-                        a = cfma(a, r.P[j], sh.X[nxt][s][j]);
-                        sh.xhp[s][j][i] = cmulc(r.P[j], Xi);
-                    }
+                    if (j < CN) a = cfma(a, r.P[j], sh.X[nxt][s][j]);
                 r.num = a;
-                sh.dpart[s][i] = cmulc(a, Xi);
+                sh.num[s][i] = a;
+                sh.dre[s][i] = fma_(Xi.x, a.x, Xi.y * a.y);
 #pragma unroll
                 for (int c = 0; c < CM; ++c)
                     if (c < C) sh.part[s][c][i] = cmulc(Xi, r.W[c]);
@@ -150,22 +163,17 @@ template <int LPB> struct WpeEngine {
                     if (i < C) r.din = mk(p.d[2 * (f1 + i)], p.d[2 * (f1 + i) + 1]);
                 }
             });
-            // ---- reductions in lane order: err_c = d_c - sum_i ..., (X^H P)_j = sum_i ...
+            // ---- err_c = d_c - sum_i conj(W[c][i]) X_i in lane order  (:158-161)
             ex.phase([&](int tid, Rg&) {
                 int s, i; long long g; bool on;
                 slot(tid, s, i, g, on);
-                if (!on) return;
-                cf acc = mk(0.0f, 0.0f);
-                for (int l = 0; l < CN; ++l) acc = cadd(acc, sh.xhp[s][i][l]);
-                sh.xh[s][i] = acc;
-                if (i < C) {                                       // err = d - W^H X  (:158-161)
-                    cf o = mk(0.0f, 0.0f);
-                    for (int l = 0; l < CN; ++l) o = cadd(o, sh.part[s][i][l]);
-                    const cf e = csub(sh.d[s][i], o);
-                    sh.err[s][i] = e;
-                    const long long f = io_base(g, t);
-                    p.err[2 * (f + i)] = e.x; p.err[2 * (f + i) + 1] = e.y;
-                }
+                if (!on || i >= C) return;
+                cf o = mk(0.0f, 0.0f);
+                for (int l = 0; l < CN; ++l) o = cadd(o, sh.part[s][i][l]);
+                const cf e = csub(sh.d[s][i], o);
+                sh.err[s][i] = e;
+                const long long f = io_base(g, t);
+                p.err[2 * (f + i)] = e.x; p.err[2 * (f + i) + 1] = e.y;
             });
             // ---- gain, P and W updates
             ex.phase([&](int tid, Rg& r) {
@@ -175,34 +183,51 @@ template <int LPB> struct WpeEngine {
                 float dpow = 0.0f;
                 for (int c = 0; c < C; ++c) dpow += cabs2(sh.d[s][c]);
                 r.var = fma_(0.98f, r.var, (float)(1.0 - 0.98) * (dpow / (float)C));       // :163-165
-                cf den = mk(lam * r.var, 0.0f);
-                for (int l = 0; l < CN; ++l) den = cadd(den, sh.dpart[s][l]);              // :174-180
+                float den = lam * r.var;
+                for (int l = 0; l < CN; ++l) den += sh.dre[s][l];                          // :174-180, real part (see the header)
                 // digital silence from the first frame on (var = 0, X = 0) makes the reference's gain 0 / 0 and its state NaN for good; the
-                // gain is 0 there instead — the only departure from awpe.py:174-180, and only where the reference has no finite value
-                const cf kn = (den.x == 0.0f && den.y == 0.0f) ? mk(0.0f, 0.0f) : cdiv(r.num, den);
+                // gain is 0 there instead — the only departure from awpe.py:174-180 where the reference has a finite value to depart from
+                const float dinv = den == 0.0f ? 0.0f : 1.0f / den;
+                const cf kn = cscale(r.num, dinv);
+                const cf gi = r.num;
 #pragma unroll
                 for (int j = 0; j < LPB; ++j)
-                    if (j < CN) r.P[j] = cscale(cfnma(r.P[j], kn, sh.xh[s][j]), lam_inv);    // P = (P - kn (X^H P)) / lambda  :183-185
+                    if (j < CN) {
+                        // P = (P - g g^H / den) / lambda (:183-185).  Every product is rounded on its own and the two of a sum are then added,
+                        // so that element (j, i), which lane j computes, is the exact conjugate of this one: P stays Hermitian bit for bit
+                        const cf gj = sh.num[s][j];
+                        const float tx = (gi.x * gj.x + gi.y * gj.y) * dinv, ty = (gi.y * gj.x - gi.x * gj.y) * dinv;
+                        r.P[j] = mk((r.P[j].x - tx) * lam_inv, j == i ? 0.0f : (r.P[j].y - ty) * lam_inv);
+                    }
 #pragma unroll
                 for (int c = 0; c < CM; ++c)
                     if (c < C) r.W[c] = cadd(r.W[c], cmulc(kn, sh.err[s][c]));             // W_c += conj(err_c) kn  :188-189
             });
             cur = nxt;
         }
+        ex.phase([&](int tid, Rg& r) {                            // the upper triangle back through the tile
+            int s, i; long long g; bool on;
+            slot(tid, s, i, g, on);
+            if (!on) return;
+            cf* tri = &sh.part[s][0][0];
+#pragma unroll
+            for (int q = 0; q < LPB; ++q)
+                if (q < CN && q >= i) tri[q * (q + 1) / 2 + i] = r.P[q];
+        });
         ex.phase([&](int tid, Rg& r) {
             int s, i; long long g; bool on;
             slot(tid, s, i, g, on);
             if (!on) return;
             float* stf = bin_state(g);
             cf* st = reinterpret_cast<cf*>(stf);
-#pragma unroll
-            for (int q = 0; q < LPB; ++q)
-                if (q < CN) st[q * CN + i] = r.P[q];
+            const int NPK = wpe_packed(CN);
+            const cf* tri = &sh.part[s][0][0];
+            for (int w = i; w < NPK; w += CN) st[w] = tri[w];
 #pragma unroll
             for (int c = 0; c < CM; ++c)
-                if (c < C) st[(CN + c) * CN + i] = r.W[c];
-            st[(CN + C) * CN + i] = sh.X[cur][s][i];
-            if (i == 0) stf[2 * wpe_slots(C, N) * CN] = r.var;
+                if (c < C) st[NPK + c * CN + i] = r.W[c];
+            st[NPK + C * CN + i] = sh.X[cur][s][i];
+            if (i == 0) stf[2 * (NPK + C * CN + CN)] = r.var;
         });
     }
 };

@@ -496,21 +496,31 @@ class Wpe(_SubbandBase):
         return self._sq(out), self.W
 
     def _blocks(self):
-        """per-bin state blocks [B, K, slots, CN] complex (layout of csrc/ds_wpe.hpp: slot q < CN: P[:, q]; then W[c, :]; then taps)."""
+        """per-bin state blocks [B, K, words] complex (layout of csrc/ds_wpe.hpp: the upper triangle of P by columns, P[i][q] (i <= q) at
+        q (q + 1) / 2 + i; then W[c, :]; then the taps)."""
         C, CN = self.channels, self.channels * self.filter_len
-        SB = ((CN + C + 1) * CN * 2 + 1 + 3) & ~3
+        nw = CN * (CN + 1) // 2 + C * CN + CN
+        SB = (2 * nw + 1 + 3) & ~3
         raw = self._eng.op_state_raw().reshape(self.batch, -1)[:, : self.half_band * SB].reshape(self.batch, self.half_band, SB)
-        return raw[:, :, : (CN + C + 1) * CN * 2].copy().view(np.complex64).reshape(self.batch, self.half_band, CN + C + 1, CN)
+        return raw[:, :, : 2 * nw].copy().view(np.complex64)
 
     @property
     def W(self):
         C, CN = self.channels, self.channels * self.filter_len
-        return self._sq(self._blocks()[:, :, CN:CN + C, :].astype(np.complex128))     # [half_band, C, C*N]
+        npk = CN * (CN + 1) // 2
+        w = self._blocks()[:, :, npk:npk + C * CN].reshape(self.batch, self.half_band, C, CN)
+        return self._sq(w.astype(np.complex128))                                       # [half_band, C, C*N]
 
     @property
     def P(self):
         CN = self.channels * self.filter_len
-        return self._sq(np.swapaxes(self._blocks()[:, :, :CN, :], 2, 3).astype(np.complex128))   # [half_band, CN, CN]
+        blk = self._blocks()
+        P = np.zeros((self.batch, self.half_band, CN, CN), dtype=np.complex128)
+        for q in range(CN):
+            for i in range(q + 1):
+                P[:, :, i, q] = blk[:, :, q * (q + 1) // 2 + i]
+                P[:, :, q, i] = np.conj(blk[:, :, q * (q + 1) // 2 + i])
+        return self._sq(P)                                                             # [half_band, CN, CN]
 
 
 class BaseFilter(_Base):

@@ -293,10 +293,10 @@ class EmulWpe:
     def __init__(self, nfft, C, N, batch=1, lam=0.998):
         self.B, self.K, self.C, self.N, self.lam = batch, nfft // 2 + 1, C, N, lam
         CN = C * N
-        self.SB = ((CN + C + 1) * CN * 2 + 1 + 3) & ~3
+        self.SB = (2 * (CN * (CN + 1) // 2 + C * CN + CN) + 1 + 3) & ~3
         self.state = np.zeros((batch, self.K, self.SB), np.float32)
         for i in range(CN):
-            self.state[:, :, 2 * (i * CN + i)] = 1e-3
+            self.state[:, :, 2 * (i * (i + 1) // 2 + i)] = 1e-3          # diagonal of the packed upper triangle
 
     def run(self, xd, d):
         xd = np.ascontiguousarray(xd, np.complex64); d = np.ascontiguousarray(d, np.complex64)
