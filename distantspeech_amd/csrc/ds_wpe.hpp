@@ -46,7 +46,7 @@ template <int LPB> struct WpeShared {
     static constexpr int BPW = WPE_NT / LPB, CM = LPB < WPE_CMAX ? LPB : WPE_CMAX;
     cf X[2][BPW][LPB];               // input buffer, double-buffered across frames (tap shift reads the neighbour lane)
     cf d[BPW][CM];
-    cf part[BPW][CM][LPB + 1];       // conj(W[c][i]) X_i
+    alignas(16) cf part[BPW][CM][LPB + 1];   // conj(W[c][i]) X_i; doubles as the tile the packed triangle of P passes through
     cf num[BPW][LPB];                // g_i = (P X)_i
     float dre[BPW][LPB];             // Re(conj(X_i) g_i)
     cf err[BPW][CM];
@@ -102,7 +102,12 @@ template <int LPB> struct WpeEngine {
             const cf* st = reinterpret_cast<const cf*>(stf);
             const int NPK = wpe_packed(CN);
             cf* tri = &sh.part[s][0][0];                          // the packed triangle passes through LDS (the `part` tile, idle here):
-            for (int w = i; w < NPK; w += CN) tri[w] = st[w];     // consecutive lanes, consecutive words
+            // consecutive lanes, consecutive 16-byte pieces (NPK is even for even CN; a block starts on a 16-byte boundary)
+            if ((NPK & 1) == 0) {
+                for (int w = 2 * i; w < NPK; w += 2 * CN) *reinterpret_cast<vec4*>(&tri[w]) = *reinterpret_cast<const vec4*>(&st[w]);
+            } else {
+                for (int w = i; w < NPK; w += CN) tri[w] = st[w];
+            }
 #pragma unroll
             for (int c = 0; c < CM; ++c)
                 if (c < C) r.W[c] = st[NPK + c * CN + i];
@@ -222,7 +227,11 @@ template <int LPB> struct WpeEngine {
             cf* st = reinterpret_cast<cf*>(stf);
             const int NPK = wpe_packed(CN);
             const cf* tri = &sh.part[s][0][0];
-            for (int w = i; w < NPK; w += CN) st[w] = tri[w];
+            if ((NPK & 1) == 0) {
+                for (int w = 2 * i; w < NPK; w += 2 * CN) *reinterpret_cast<vec4*>(&st[w]) = *reinterpret_cast<const vec4*>(&tri[w]);
+            } else {
+                for (int w = i; w < NPK; w += CN) st[w] = tri[w];
+            }
 #pragma unroll
             for (int c = 0; c < CM; ++c)
                 if (c < C) st[NPK + c * CN + i] = r.W[c];
