@@ -195,14 +195,16 @@ template <int LPB> struct WpeEngine {
                 const float dinv = den == 0.0f ? 0.0f : 1.0f / den;
                 const cf kn = cscale(r.num, dinv);
                 const cf gi = r.num;
+                const float dls = dinv * lam_inv;
 #pragma unroll
                 for (int j = 0; j < LPB; ++j)
                     if (j < CN) {
                         // P = (P - g g^H / den) / lambda (:183-185).  Every product is rounded on its own and the two of a sum are then added,
                         // so that element (j, i), which lane j computes, is the exact conjugate of this one: P stays Hermitian bit for bit
                         const cf gj = sh.num[s][j];
-                        const float tx = (gi.x * gj.x + gi.y * gj.y) * dinv, ty = (gi.y * gj.x - gi.x * gj.y) * dinv;
-                        r.P[j] = mk((r.P[j].x - tx) * lam_inv, j == i ? 0.0f : (r.P[j].y - ty) * lam_inv);
+                        const float tx = gi.x * gj.x + gi.y * gj.y, ty = gi.y * gj.x - gi.x * gj.y;      // g_i conj(g_j)
+                        // P / lambda - t (1 / (den lambda)): the fused multiply-add keeps the symmetry too (it commutes with negation)
+                        r.P[j] = mk(fma_(-tx, dls, r.P[j].x * lam_inv), j == i ? 0.0f : fma_(-ty, dls, r.P[j].y * lam_inv));
                     }
 #pragma unroll
                 for (int c = 0; c < CM; ++c)
