@@ -42,10 +42,12 @@ struct alignas(16) vec4 { float x, y, z, w; };
 // keeps the compiler from forwarding values across it (used around a deliberate round trip through LDS); no instruction emitted
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DS_COMPILER_FENCE() asm volatile("" ::: "memory")
+#define DS_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #define DS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define DS_COMPILER_FENCE() ((void)0)
 #define DS_SCHED_FENCE() ((void)0)
+#define DS_SETPRIO(n) ((void)0)
 #endif
 
 struct cf { float x, y; };
@@ -838,6 +840,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // +- Y[NC] / 2 on even / odd samples — is added in the overlap-add phase.
             // The merge of the packed real transform (Y[k], Y[NC - k] -> point k) is formed inside the first inverse stage.
             ph(WAVE_FFT, [&](int tid, Rg&) {
+                DS_SETPRIO(2);                                          // the serial part of a hop: ahead of other workgroups' wide phases
                 if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, 2, 0, 1>(tid - INV_T0, NT, sh, nullptr, fb, 1, 0, 1);
                 else if (tid == NYQ_TID) {
                     cf Zn[M];
@@ -878,6 +881,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     dst[0] = o0; dst[1] = o1;
 #endif
                 }
+                DS_SETPRIO(0);
             });
             old_half = new_half;
         }
