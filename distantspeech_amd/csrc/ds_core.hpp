@@ -43,11 +43,13 @@ struct alignas(16) vec4 { float x, y, z, w; };
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DS_COMPILER_FENCE() asm volatile("" ::: "memory")
 #define DS_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#define DS_GRID_BLOCKS() ((int)gridDim.x)
 #define DS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define DS_COMPILER_FENCE() ((void)0)
 #define DS_SCHED_FENCE() ((void)0)
 #define DS_SETPRIO(n) ((void)0)
+#define DS_GRID_BLOCKS() 0
 #endif
 
 struct cf { float x, y; };
@@ -737,6 +739,11 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         const cf* steer = p.steer + (long long)b * p.steer_batch_stride;
         int frm_cnt = cnt[0], ell = cnt[1], spp_cnt = cnt[2];
         int old_half = 0;
+        // Wave priorities.  The per-bin phase is wide and arithmetic-heavy, everything else in a hop is a chain of short LDS round trips.  When
+        // the whole grid is resident at once (<= 4 workgroups per CU) the chains run at raised priority from the start of a hop and the per-bin
+        // phase yields to them (+6..9 % at B = 1024, one hop per call; +8 % chunked); with more workgroups than that waiting for a slot only
+        // the serial tail of a hop (inverse stages, Nyquist bin, overlap-add) is raised (the full scheme costs 1.5 % there).
+        const bool one_round = DS_GRID_BLOCKS() <= 1024;
 
         // ---- prologue: tables, tails, per-bin state ---------------------------------------------
         ex.phase([&](int tid, Rg& r) {
@@ -775,6 +782,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // hand-offs need no workgroup barrier (the interleaved input layout scatters the staging across channels and keeps its barrier).
             auto ph = [&](bool wave_local, auto f) { if (wave_local) ex.phase_wave(f); else ex.phase(f); };
             ph(WAVE_FFT && p.x_sample_stride == 1, [&](int tid, Rg& r) {
+                if (one_round) DS_SETPRIO(2);
                 commit(p, sh, new_half, tid, r);
                 if (t + 1 < p.T) prefetch(p, xb, t + 1, tid, r);
             });
@@ -819,6 +827,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // ---- per-bin recursion -> Y[k] --------------------------------------------------------
             const bool reset = (frm_cnt != 0) && (ell % p.mcra_L == 0);
             ex.phase([&](int tid, Rg& r) {
+                DS_SETPRIO(0);                                          // the wide, arithmetic-heavy phase yields to other workgroups' latency-bound ones
                 cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt);
                 if (tid == 0) Yk.y = 0.0f;                              // irfft ignores Im Y[0] and Im Y[N/2]
                 sh.Y[tid] = Yk;
@@ -881,7 +890,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     dst[0] = o0; dst[1] = o1;
 #endif
                 }
-                DS_SETPRIO(0);
+                if (!one_round) DS_SETPRIO(0);
             });
             old_half = new_half;
         }

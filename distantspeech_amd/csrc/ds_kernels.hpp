@@ -65,9 +65,9 @@ template <class Rg> struct HipExec {
 
 // waves per SIMD the register allocator must leave room for.  The 4-microphone kernels live at the 128-VGPR step (4 waves / SIMD = 4
 // resident workgroups per CU for 512-point frames: the whole 1024-utterance batch in one wave of workgroups); the GSC kernel had
-// slipped to 130 VGPRs / 3 waves, so it is pinned.  The MVDR kernel reaches 128 by itself and schedules slightly better unpinned
-// (-1.5 % in the chunked regime with the pin); larger arrays keep the allocator's own choice.
-constexpr int frames_min_waves(int M, int algo) { return (M <= 4 && algo == ALGO_GSC) ? 4 : 1; }
+// slipped to 130 VGPRs / 3 waves, so it is pinned; the MVDR kernel sits on the same edge (two more registers and a workgroup per CU
+// is gone: -25 %) and is pinned too; larger arrays keep the allocator's own choice.
+constexpr int frames_min_waves(int M, int algo) { return (M <= 4 && (algo == ALGO_GSC || algo == ALGO_ADAPTIVE)) ? 4 : 1; }
 
 template <int NFFT, int M, int ALGO, bool RYY>
 __global__ void __launch_bounds__(NFFT / 2, frames_min_waves(M, ALGO)) ds_frames_kernel(Params p) {
