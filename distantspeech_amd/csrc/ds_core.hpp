@@ -246,7 +246,7 @@ DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, in
                 const int pos = s < HOP ? old_half * HOP + s : (old_half ^ 1) * HOP + (s - HOP);
                 v[r] = mk(sh.tb.win[s] * sh.xbuf[ch][pos], sh.tb.win[s + 1] * sh.xbuf[ch][pos + 1]);
             } else if constexpr (FROM == 2) {
-                const cf A = sh.Y[n], Bc = n == 0 ? mk(0.0f, 0.0f) : cconj(sh.Y[NC - n]);
+                const cf A = sh.Y[n], Bc = (n == 0 && NC == 256) ? mk(0.0f, 0.0f) : cconj(sh.Y[NC - n]);   // NC == 256: Nyquist bin added later
                 const cf E = cscale(cadd(A, Bc), 0.5f);
                 const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tb.tw[n]));
                 v[r] = mk(E.x - O.y, E.y + O.x);                        // E + j O
@@ -740,10 +740,12 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         int frm_cnt = cnt[0], ell = cnt[1], spp_cnt = cnt[2];
         int old_half = 0;
         // Wave priorities.  The per-bin phase is wide and arithmetic-heavy, everything else in a hop is a chain of short LDS round trips.  When
-        // the whole grid is resident at once (<= 4 workgroups per CU) the chains run at raised priority from the start of a hop and the per-bin
+        // the whole grid is resident at once (4 workgroups per CU for 4 microphones and 512-point frames) the chains run at raised priority from the start of a hop and the per-bin
         // phase yields to them (+6..9 % at B = 1024, one hop per call; +8 % chunked); with more workgroups than that waiting for a slot only
         // the serial tail of a hop (inverse stages, Nyquist bin, overlap-add) is raised (the full scheme costs 1.5 % there).
-        const bool one_round = DS_GRID_BLOCKS() <= 1024;
+        constexpr int by_lds = 160 * 1024 / (int)sizeof(Sh), by_threads = 2048 / NT;
+        constexpr int resident = 256 * (by_lds < by_threads ? by_lds : by_threads);      // workgroups the 256 CUs hold at once
+        const bool one_round = DS_GRID_BLOCKS() <= resident;
 
         // ---- prologue: tables, tails, per-bin state ---------------------------------------------
         ex.phase([&](int tid, Rg& r) {
@@ -831,9 +833,17 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt);
                 if (tid == 0) Yk.y = 0.0f;                              // irfft ignores Im Y[0] and Im Y[N/2]
                 sh.Y[tid] = Yk;
-                if (tid == NYQ_TID) {                                   // the Nyquist bin's inputs, before the inverse transform reuses the buffer
+                if (tid == NYQ_TID) {
+                    if constexpr (WAVE_FFT) {                           // the Nyquist bin's inputs, before the inverse transform reuses the buffer
 #pragma unroll
-                    for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; sh.zn[m] = F0.x - F0.y; }
+                        for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; sh.zn[m] = F0.x - F0.y; }
+                    } else {                                            // second pass: the Nyquist bin, state in LDS (see below)
+                        cf Zn[M];
+#pragma unroll
+                        for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; Zn[m] = mk(F0.x - F0.y, 0.0f); }
+                        const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_cnt, reset, spp_cnt);
+                        sh.Y[NC] = mk(Yn.x, 0.0f);
+                    }
                 }
             });
             const int frm_nyq = frm_cnt, spp_nyq = spp_cnt;
@@ -843,15 +853,16 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             }
             if (ALGO == ALGO_GSC) spp_cnt += 1;
             // ---- inverse packed real FFT -----------------------------------------------------------
-            // The Nyquist bin k = NC is the 257th bin of 256 lanes: its per-bin program (state in LDS) runs on lane NYQ_TID while another
-            // wave runs the inverse FFT stages, instead of as a second pass that the whole workgroup waits for.  The transform is linear,
+            // The Nyquist bin k = NC is the 257th bin of 256 lanes.  In 512-point frames (wave-local inverse stages) its per-bin program
+            // (state in LDS) runs on lane NYQ_TID while another wave runs the inverse FFT stages, instead of as a second pass of the per-bin
+            // phase that the whole workgroup waits for (which is what the other frame sizes, with a barrier behind every stage, keep doing).  The transform is linear,
             // so it is taken with Y[NC] = 0 and the bin's contribution — the constant (Y[NC] / 2) (1 - j) on every packed point, i.e.
             // +- Y[NC] / 2 on even / odd samples — is added in the overlap-add phase.
             // The merge of the packed real transform (Y[k], Y[NC - k] -> point k) is formed inside the first inverse stage.
             ph(WAVE_FFT, [&](int tid, Rg&) {
                 DS_SETPRIO(2);                                          // the serial part of a hop: ahead of other workgroups' wide phases
                 if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, 2, 0, 1>(tid - INV_T0, NT, sh, nullptr, fb, 1, 0, 1);
-                else if (tid == NYQ_TID) {
+                else if (WAVE_FFT && tid == NYQ_TID) {
                     cf Zn[M];
 #pragma unroll
                     for (int m = 0; m < M; ++m) Zn[m] = mk(sh.zn[m], 0.0f);
@@ -874,7 +885,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 if (tid < NC / 2) {
                     const int i = tid;
                     const float sc = 1.0f / (float)NC;
-                    const float hn = 0.5f * sh.Y[NC].x;                 // the Nyquist bin's share of every even (+) / odd (-) sample
+                    const float hn = WAVE_FFT ? 0.5f * sh.Y[NC].x : 0.0f;   // the Nyquist bin's share of every even (+) / odd (-) sample
                     cf z1 = Zi[i], z2 = Zi[i + NC / 2];
                     z1.x += hn; z1.y -= hn; z2.x += hn; z2.y -= hn;
                     const float y0 = sh.tb.win[2 * i] * (z1.x * sc), y1 = sh.tb.win[2 * i + 1] * (z1.y * sc);
