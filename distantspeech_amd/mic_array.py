@@ -55,32 +55,24 @@ class MicArray(object):
 
 
 def compute_tau(mic_array, incident_angle):
-    incident_angle = np.asarray(incident_angle, dtype=float)
-    az = incident_angle[0]
-    el = incident_angle[1] if incident_angle.ndim > 0 and incident_angle.size > 1 else 0
-    x0, y0, z0 = sph2cart(az, el, 1)
-    p0 = -1 * np.array([x0, y0, z0])
-    tau = np.zeros((mic_array.M, 1))
-    for m in range(mic_array.M):
-        mic_loc_m = -1 * mic_array.mic_loc[m, :]
-        nrm = np.linalg.norm(mic_loc_m)
-        cos_theta = np.sum(mic_loc_m * p0) / (np.linalg.norm(p0) * nrm + 1e-12)
-        tau[m] = -1 * nrm * cos_theta / mic_array.c
-    return tau
+    """Far-field delays [M, 1]: the projection of every microphone position on the unit vector of the
+    impinging direction, over the speed of sound (reference MicArray.py:149-187, all microphones at once)."""
+    ang = np.atleast_1d(np.asarray(incident_angle, dtype=float))
+    direction = -np.array(sph2cart(ang[0], ang[1] if ang.size > 1 else 0.0, 1.0))      # unit vector towards the array
+    pos = -np.asarray(mic_array.mic_loc, dtype=float)                                    # [M, 3]
+    dist = np.linalg.norm(pos, axis=1)
+    cosine = (pos * direction).sum(axis=1) / (np.linalg.norm(direction) * dist + 1e-12)
+    return (-dist * cosine / mic_array.c)[:, None]
 
 
 def gen_noise_msc(mic, nfft=256, Fvv_max=0.9998):
-    """Diffuse-field coherence matrix [half_bin, M, M] (sinc model)."""
-    M, c, fs = mic.M, mic.c, mic.fs
+    """Diffuse-field coherence [half_bin, M, M]: sin(x) / x with x = 2 pi f d_ij / c off the diagonal,
+    Fvv_max on it (reference gen_noise_msc.py:7-28)."""
     half_bin = round(nfft / 2 + 1)
-    Fvv = np.zeros((half_bin, M, M))
-    f = np.linspace(0, fs / 2, half_bin)
+    f = np.linspace(0, mic.fs / 2, half_bin)
     f[0] = 1e-6
-    for i in range(M):
-        for j in range(M):
-            if i == j:
-                Fvv[:, i, j] = Fvv_max
-            else:
-                dij = np.sqrt(np.sum((mic.mic_loc[i, :] - mic.mic_loc[j, :]) ** 2))
-                Fvv[:, i, j] = np.sin(2 * np.pi * f * dij / c) / (2 * np.pi * f * dij / c)
-    return Fvv
+    loc = np.asarray(mic.mic_loc, dtype=float)
+    spacing = np.sqrt(((loc[:, None, :] - loc[None, :, :]) ** 2).sum(axis=2))            # [M, M]
+    eye = np.eye(mic.M, dtype=bool)
+    x = 2 * np.pi * f[:, None, None] * np.where(eye, 1.0, spacing)[None] / mic.c         # diagonal argument is a dummy
+    return np.where(eye[None], Fvv_max, np.sin(x) / x)

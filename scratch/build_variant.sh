@@ -1,7 +1,7 @@
 #!/bin/bash
 # build_variant.sh <git-rev|WORK> <name>: build libdsenh.so from a given revision into scratch/variants/ for A/B timing
 set -e
-REV=$1; NAME=$2; ROOT=/root/repo; TMP=/tmp/proto/var_$NAME
+REV=$1; NAME=$2; ROOT=$(cd "$(dirname "$0")/.." && pwd); TMP=/tmp/proto/var_$NAME
 rm -rf $TMP; mkdir -p $TMP/distantspeech_amd/csrc $TMP/include
 if [ "$REV" = "WORK" ]; then cp $ROOT/distantspeech_amd/csrc/*.h* $ROOT/distantspeech_amd/csrc/Makefile $TMP/distantspeech_amd/csrc/; cp $ROOT/include/dsenh.h $TMP/include/;
 else (cd $ROOT && git archive $REV distantspeech_amd/csrc include | tar -x -C $TMP); fi
