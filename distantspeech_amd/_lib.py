@@ -27,7 +27,7 @@ METHOD_SRC, METHOD_DS, METHOD_MVDR, METHOD_TFGSC = 0, 1, 2, 3
 LAYOUT_SAMPLES_CHANNELS, LAYOUT_CHANNELS_SAMPLES = 0, 1
 PARAM_METHOD, PARAM_MCRA_L, PARAM_ALPHA_Y, PARAM_ALPHA_V, PARAM_DIAG, PARAM_GATE, PARAM_MU, PARAM_SPLIT = 1, 2, 3, 4, 5, 6, 7, 8
 (FIELD_RVV, FIELD_RYY, FIELD_MCRA_S, FIELD_MCRA_SMIN, FIELD_MCRA_STMP, FIELD_MCRA_P, FIELD_MCRA_LAMBDA_D,
- FIELD_PHI_YY, FIELD_PHI_VV, FIELD_G_AIC, FIELD_STFT_TAIL, FIELD_OLA_TAIL, FIELD_COUNTERS, FIELD_OP_STATE) = range(1, 15)
+ FIELD_PHI_YY, FIELD_PHI_VV, FIELD_G_AIC, FIELD_STFT_TAIL, FIELD_OLA_TAIL, FIELD_COUNTERS, FIELD_OP_STATE, FIELD_NOTCH_MEM) = range(1, 16)
 
 
 class ds_config(ctypes.Structure):

@@ -424,6 +424,7 @@ int ds_set_steering(ds_handle* h, const float* steer, int per_utterance) {
         h->steer = nullptr;
         DS_HIP(h, hipMalloc((void**)&h->steer, need));
         h->steer_per_utt = per_utterance ? 1 : 0;
+        h->graph_valid = false;            // a captured graph holds the old buffer's address and batch stride
     }
     DS_HIP(h, hipMemcpyAsync(h->steer, steer, need, hipMemcpyHostToDevice, h->stream));
     DS_HIP(h, hipStreamSynchronize(h->stream));
@@ -708,6 +709,7 @@ size_t ds_field_bytes(const ds_handle* h, int field) {
         case DS_FIELD_OP_STATE:
             if (h->tdf_w) return (size_t)h->cfg.batch * h->cfg.filter_len * sizeof(float);
             return opst_bytes(h);
+        case DS_FIELD_NOTCH_MEM: return h->td_mem ? B * M * 2 * sizeof(float) : 0;
         default: return 0;
     }
 }
@@ -730,6 +732,7 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
         }
         return DS_OK;
     }
+    if (field == DS_FIELD_NOTCH_MEM) { DS_HIP(h, hipMemcpy(dst, h->td_mem, need, hipMemcpyDeviceToHost)); return DS_OK; }
     if (field == DS_FIELD_OP_STATE) {
         DS_HIP(h, hipMemcpy(dst, h->tdf_w ? (const void*)h->tdf_w : (const void*)h->opst, need, hipMemcpyDeviceToHost));
         return DS_OK;
@@ -806,9 +809,16 @@ static int extra_state(const ds_handle* h, ExtraState out[3]) {
     }
     return n;
 }
+// every handle's section of a checkpoint blob starts with this header; ds_import_state refuses a blob written for another configuration
+struct BlobHeader { uint32_t magic, version; int32_t algo, nfft, hop, n_mics, batch, filter_len, td_L, track_ryy; };
+static const uint32_t BLOB_MAGIC = 0x44534348u;      // "DSCH"
+static BlobHeader blob_header(const ds_handle* h) {
+    return BlobHeader{BLOB_MAGIC, (uint32_t)DS_VERSION, h->cfg.algo, h->cfg.nfft, h->cfg.hop, h->cfg.n_mics, h->cfg.batch, h->filter_len, h->td_L,
+                      h->cfg.track_ryy};
+}
 static size_t own_state_bytes(const ds_handle* h) {
     ExtraState ex[3];
-    size_t n = bins_bytes(h) + tail_in_bytes(h) + tail_out_bytes(h) + counters_bytes(h) + opst_bytes(h) + 4 * sizeof(int);
+    size_t n = sizeof(BlobHeader) + bins_bytes(h) + tail_in_bytes(h) + tail_out_bytes(h) + counters_bytes(h) + opst_bytes(h) + 4 * sizeof(int);
     for (int i = 0, k = extra_state(h, ex); i < k; ++i) n += ex[i].bytes;
     return n;
 }
@@ -831,6 +841,7 @@ int ds_export_state(ds_handle* h, void* dst, size_t bytes) {
     if (rc) return rc;
     DS_HIP(h, hipStreamSynchronize(h->stream));
     char* d = (char*)dst;
+    { const BlobHeader hd = blob_header(h); std::memcpy(d, &hd, sizeof hd); d += sizeof hd; }
     if (bins_bytes(h)) DS_HIP(h, hipMemcpy(d, h->bins, bins_bytes(h), hipMemcpyDeviceToHost));
     d += bins_bytes(h);
     DS_HIP(h, hipMemcpy(d, h->tail_in, tail_in_bytes(h), hipMemcpyDeviceToHost)); d += tail_in_bytes(h);
@@ -865,11 +876,27 @@ int ds_export_state(ds_handle* h, void* dst, size_t bytes) {
 
 int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
     if (!h || !src) return fail(h, DS_EINVAL, "ds_import_state: NULL argument");
-    if (bytes != ds_state_bytes(h)) return fail(h, DS_ESHAPE, "ds_import_state: byte size mismatch");
+    if (bytes < sizeof(BlobHeader)) return fail(h, DS_ESHAPE, "ds_import_state: byte size mismatch");
     int rc = set_device(h);
     if (rc) return rc;
     DS_HIP(h, hipStreamSynchronize(h->stream));
     const char* s = (const char*)src;
+    {
+        BlobHeader got;
+        const BlobHeader want = blob_header(h);
+        std::memcpy(&got, s, sizeof got);
+        if (got.magic != BLOB_MAGIC) return fail(h, DS_EINVAL, "ds_import_state: not a dsenh checkpoint (bad magic)");
+        if (std::memcmp(&got, &want, sizeof got) != 0) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "ds_import_state: checkpoint was written for version %u algo %d nfft %d hop %d mics %d batch %d taps %d fir %d ryy %d, "
+                     "this handle is version %u algo %d nfft %d hop %d mics %d batch %d taps %d fir %d ryy %d",
+                     got.version, got.algo, got.nfft, got.hop, got.n_mics, got.batch, got.filter_len, got.td_L, got.track_ryy,
+                     want.version, want.algo, want.nfft, want.hop, want.n_mics, want.batch, want.filter_len, want.td_L, want.track_ryy);
+            return fail(h, DS_ESHAPE, buf);
+        }
+        s += sizeof got;
+    }
+    if (bytes != ds_state_bytes(h)) return fail(h, DS_ESHAPE, "ds_import_state: byte size mismatch");
     if (bins_bytes(h)) DS_HIP(h, hipMemcpy(h->bins, s, bins_bytes(h), hipMemcpyHostToDevice));
     s += bins_bytes(h);
     DS_HIP(h, hipMemcpy(h->tail_in, s, tail_in_bytes(h), hipMemcpyHostToDevice)); s += tail_in_bytes(h);

@@ -126,16 +126,7 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         p.radius = fe->cfg.filt_alpha;
         DS_HIP(h, ds::launch_dcnotch(p, h->stream));
         const int Lt = (int)(fe->aux_floats / M);
-        if (fe->td_L != Lt) {
-            DS_HIP(h, hipStreamSynchronize(h->stream));
-            for (int i = 0; i < 2; ++i) {
-                (void)hipFree(fe->td_cache[i]); fe->td_cache[i] = nullptr;
-                const size_t cbytes = (size_t)B * (Lt > 1 ? Lt - 1 : 1) * M * sizeof(float);
-                DS_HIP(h, hipMalloc((void**)&fe->td_cache[i], cbytes));
-                DS_HIP(h, hipMemset(fe->td_cache[i], 0, cbytes));
-            }
-            fe->td_L = Lt; fe->td_cur = 0;
-        }
+        rc = frontend_set_taps(fe, Lt); if (rc) return fail(h, rc, fe->err);
         std::memset(&p, 0, sizeof p);
         p.B = B; p.M = M; p.n = n; p.L = Lt; p.x = cb[G_XN]; p.x_chan_major = 1; p.y = cb[G_XA]; p.y_chan_major = 1; p.mean = cb[G_FIXED];
         p.coef = fe->dev_buf[9]; p.cache_in = fe->td_cache[fe->td_cur]; p.cache_out = fe->td_cache[fe->td_cur ^ 1];

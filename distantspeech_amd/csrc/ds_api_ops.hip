@@ -7,6 +7,20 @@ using namespace dsi;
 namespace dsi {
 
 // make sure staging slot `i` holds at least `bytes`
+// FIR history of a front-end handle for an L-tap bank: two ping-pong buffers [B][L-1][M], zeroed; no-op when L is unchanged
+int frontend_set_taps(ds_handle* h, int Lt) {
+    if (h->td_L == Lt) return DS_OK;
+    DS_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t cb = (size_t)h->cfg.batch * (Lt > 1 ? Lt - 1 : 1) * h->cfg.n_mics * sizeof(float);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipFree(h->td_cache[i]); h->td_cache[i] = nullptr;
+        DS_HIP(h, hipMalloc((void**)&h->td_cache[i], cb));
+        DS_HIP(h, hipMemset(h->td_cache[i], 0, cb));
+    }
+    h->td_L = Lt; h->td_cur = 0;
+    return DS_OK;
+}
+
 int stage_reserve(ds_handle* h, int i, size_t bytes) {
     if (bytes <= h->dev_buf_bytes[i]) return DS_OK;
     DS_HIP(h, hipStreamSynchronize(h->stream));
@@ -177,6 +191,11 @@ int ds_set_aux(ds_handle* h, const float* table, size_t n_floats) {
     rc = stage_reserve(h, 9, n_floats * sizeof(float)); if (rc) return rc;
     DS_HIP(h, hipMemcpy(h->dev_buf[9], table, n_floats * sizeof(float), hipMemcpyHostToDevice));
     h->aux_floats = n_floats;
+    // a front-end handle's table is its FIR bank coef[L][M]: the history (and with it the size of the exported state) is fixed here, not
+    // at the first filtering call, so a blob exported from a running handle imports into a freshly configured one
+    if (h->cfg.algo == DS_ALGO_FRONTEND && n_floats % (size_t)h->cfg.n_mics == 0) {
+        rc = frontend_set_taps(h, (int)(n_floats / h->cfg.n_mics)); if (rc) return rc;
+    }
     return DS_OK;
 }
 
@@ -270,16 +289,7 @@ int ds_firbank_bm(ds_handle* h, const float* x, int n_samples, float* y, float* 
     if (n_samples < 0) return fail(h, DS_ESHAPE, "ds_firbank_bm: n_samples < 0");
     if (n_samples == 0) return DS_OK;
     int rc = set_device(h); if (rc) return rc;
-    if (h->td_L != Lt) {                                                      // (re)allocate the history for this tap count
-        DS_HIP(h, hipStreamSynchronize(h->stream));
-        for (int i = 0; i < 2; ++i) {
-            (void)hipFree(h->td_cache[i]); h->td_cache[i] = nullptr;
-            const size_t cb = (size_t)h->cfg.batch * (Lt > 1 ? Lt - 1 : 1) * M * sizeof(float);
-            DS_HIP(h, hipMalloc((void**)&h->td_cache[i], cb));
-            DS_HIP(h, hipMemset(h->td_cache[i], 0, cb));
-        }
-        h->td_L = Lt; h->td_cur = 0;
-    }
+    rc = frontend_set_taps(h, Lt); if (rc) return rc;
     const size_t n = (size_t)h->cfg.batch * n_samples;
     IoSpec io = {{x, nullptr, nullptr}, {n * M * 4, 0, 0}, {y, mean, bm, nullptr, nullptr}, {n * M * 4, mean ? n * 4 : 0, bm ? n * (M - 1) * 4 : 0, 0, 0}};
     const float* din[3]; float* dout[5];
@@ -368,12 +378,12 @@ int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames
 int ds_omlsa_postfilter(ds_handle* h, const float* Y, const float* U, int n_frames, float* G, float* Yout, int mem) {
     if (!h || !Y || !U || !G || !Yout) return fail(h, DS_EINVAL, "ds_omlsa_postfilter: NULL argument");
     const size_t n = (size_t)h->cfg.batch * (n_frames > 0 ? n_frames : 0) * h->K;
-    int rc = stage_reserve(h, 3, 2 * n * 4); if (rc) return rc;                 // lambda_d and p are not returned by this entry point
-    IoSpec io = {{Y, U, nullptr}, {n * 8, n * (h->cfg.n_mics - 1) * 8, 0}, {nullptr, G, nullptr, Yout, nullptr}, {0, n * 4, 0, n * 8, 0}};
     if (h->cfg.algo != DS_ALGO_OMLSA) return fail(h, DS_ESTATE, "ds_omlsa_postfilter: handle was created for a different algo");
     if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_omlsa_postfilter: n_frames < 0");
     if (n_frames == 0) return DS_OK;
-    rc = set_device(h); if (rc) return rc;
+    int rc = set_device(h); if (rc) return rc;
+    rc = stage_reserve(h, 3, 2 * n * 4); if (rc) return rc;                     // lambda_d and p are not returned by this entry point
+    IoSpec io = {{Y, U, nullptr}, {n * 8, n * (h->cfg.n_mics - 1) * 8, 0}, {nullptr, G, nullptr, Yout, nullptr}, {0, n * 4, 0, n * 8, 0}};
     const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
     ds::OpParams p;

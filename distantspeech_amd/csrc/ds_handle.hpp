@@ -110,6 +110,7 @@ hipError_t launch_transform_istft(const ds_handle* t, const Params& p, int batch
 // staging for host-pointer calls of the frame-level objects (ds_api_ops.hip)
 struct IoSpec { const float* in[3]; size_t in_bytes[3]; float* out[5]; size_t out_bytes[5]; };
 int stage_reserve(ds_handle* h, int i, size_t bytes);
+int frontend_set_taps(ds_handle* h, int Lt);
 int io_begin(ds_handle* h, int mem, const IoSpec& io, const float* din[3], float* dout[5]);
 int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[5]);
 int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int mem, const IoSpec& io, int is_complex, int has_p);

@@ -401,6 +401,8 @@ class BatchEngine:
             return out.reshape(B, self.hop)
         if field == L.FIELD_COUNTERS:
             return out
+        if field == L.FIELD_NOTCH_MEM:
+            return out.reshape(B, M, 2)
         return out.reshape(B, K)
 
     def export_state(self):

@@ -42,6 +42,7 @@ class FilterDcNotch16(object):
 
     def filter_dc_notch16(self, input):
         out = self._eng.dcnotch(np.asarray(input, dtype=np.float32)[None, None, :])[0, 0]
+        self.notch_mem[:] = self._eng.get_field(L.FIELD_NOTCH_MEM)[0, 0]     # the live filter memory, as the reference returns it
         return out.astype(np.float64), self.notch_mem
 
 

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DS_VERSION 100
+#define DS_VERSION 101
 
 /* error codes */
 #define DS_OK 0
@@ -162,6 +162,7 @@ typedef struct ds_config {
 #define DS_FIELD_OLA_TAIL 12  /* [B][hop]     Transform.previous_output */
 #define DS_FIELD_COUNTERS 13  /* int32 [B][4] {mcra.frm_cnt, mcra.ell, spp.frm_cnt, 0} */
 #define DS_FIELD_OP_STATE 14  /* frame-level objects: raw state [B][NF][KP] float32 (row map in distantspeech_amd/ops.py) */
+#define DS_FIELD_NOTCH_MEM 15 /* DS_ALGO_FRONTEND: [B][M][2] the DC notch memories (FilterDcNotch16.notch_mem, feature.py:34,47) */
 
 int ds_version(void);
 int ds_device_count(void);

@@ -586,6 +586,58 @@ def test_chain_handles_long_stream_drift(ds):
     assert max(rms(y[i:i + n] - ref[i:i + n]) / rms(ref[i:i + n]) for i in range(0, len(ref), n)) < 1e-4
 
 
+def test_checkpoint_imports_into_a_never_run_handle(ds):
+    """The process-restart case: a blob exported from a running handle goes into a freshly created and configured one that has not
+    processed anything (the FIR history is sized when the bank is set, not at the first call); a blob of another configuration is
+    refused by its header; the notch mirror returns the live filter memory (feature.py:36-47)."""
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(11)
+    coef = rng.standard_normal((30, 4)).astype(np.float32) * 0.1
+    xs = [rng.standard_normal((2, 4, 512)).astype(np.float32) * 0.1 for _ in range(2)]
+
+    def make(batch=2, taps=coef):
+        e = ds.BatchEngine(L.ALGO_FRONTEND, 4, 512, batch=batch, filt_alpha=0.98)
+        e.set_aux(taps)
+        return e
+
+    def step(e, i):
+        return (e.dcnotch(xs[i]),) + tuple(e.firbank(np.ascontiguousarray(np.swapaxes(xs[i], 1, 2))))
+    a = make(); fresh = make()
+    assert a.export_state().size == fresh.export_state().size          # size is fixed once the tables are set
+    step(a, 0)
+    blob = a.export_state()
+    ref = step(a, 1)
+    fresh.import_state(blob)
+    assert all(np.array_equal(u, v) for u, v in zip(ref, step(fresh, 1)))
+    with pytest.raises(Exception, match="checkpoint was written for"):
+        make(taps=coef[:20]).import_state(blob)                          # other FIR length
+    bad = blob.copy(); bad[:4] = 0
+    with pytest.raises(Exception, match="bad magic"):
+        make().import_state(bad)
+    # SubbandGSC chain: export from a running object, import into one that has never processed a block
+    g = load("g12_subbandgsc_rec1")
+    M, FL, rls = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    mic = ds.MicArray(arrayType="circular", r=float(g["r"]), M=M, n_fft=512)
+    s1 = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0])
+    s1.process(x[:, : 6 * FL])
+    blob = s1._eng.export_state()
+    tail = s1.process(x[:, 6 * FL: 12 * FL])
+    s2 = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0])
+    s2._eng.import_state(blob)
+    assert all(np.array_equal(u, v) for u, v in zip(tail, s2.process(x[:, 6 * FL: 12 * FL])))
+    # FilterDcNotch16 hands back its memory after every call
+    from distantspeech_amd.subband_gsc import FilterDcNotch16
+    from oracle import ds_oracle as O
+    nf = FilterDcNotch16(radius=0.98)
+    sig = rng.standard_normal(256) * 0.1
+    out, mem = nf.filter_dc_notch16(sig)
+    assert np.abs(mem).max() > 0 and mem is nf.notch_mem
+    vin, vout = sig[-1], out[-1] / 0.98                                   # feature.py:44-46: mem[1] = vin - den2 * vout
+    den2 = 0.98 * 0.98 + 0.7 * 0.02 * 0.02
+    assert abs(mem[1] - (vin - den2 * vout)) < 1e-5
+
+
 def test_checkpoint_of_block_level_objects(ds):
     """export_state / import_state cover the state that lives outside the per-bin planes: the front end's notch memories and FIR
     history, the sample-wise filters' weights / buffer / P, the FDAF blocks."""
