@@ -1,71 +1,289 @@
 #!/usr/bin/env python3
-"""bench.py — enhanced frames/s of the MVDR hot path (BASELINE.json configs[1]):
-adaptive MVDR, 4 mics, 16 kHz, 512-FFT / 256-hop, batch = 1024 synthetic utterances per GPU.
+"""bench.py — enhanced frames/s of the per-frame enhancement hot path on MI355X.
 
-A "step" is one pass of the hot path over the batch in the streaming-callback regime: ONE hop
-(256 samples x 4 channels) of every utterance in -> one hop of enhanced audio out, all carried
-state (STFT tail, OLA tail, Rvv, MCRA trackers) read from and written back to HBM (T = 1 in
-SURVEY.md section 8d).  Inputs are resident in HBM before the timed region starts.
+Headline = BASELINE.json configs[1]: adaptive MVDR, 4 mics, 16 kHz, 512-FFT / 256-hop, batch = 1024 synthetic utterances
+per GPU.  A "step" is one pass of the hot path over the batch in the streaming-callback regime: ONE hop (256 samples x M
+channels) of every utterance in -> one hop of enhanced audio out, all carried state read from and written back to HBM (T = 1
+in SURVEY.md section 8d).  Inputs are resident in HBM before the timed region starts.
 
-    python bench.py --gpus 1 --steps 625 --warmup 25
+    python bench.py                                   # 1 GPU, defaults finish within minutes
+    python bench.py --gpus 8 --steps K --warmup W     # starts 8 child ranks itself (one per GPU, RCCL), rank 0 prints the line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W        # or launched as ranks by torchrun (RANK / LOCAL_RANK / WORLD_SIZE in the env)
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`."""
+Timed region: W untimed warm-up steps, then R rounds of EXACTLY K steps each, enqueued back to back and bracketed ONCE by
+barrier + device synchronize on both sides; R is the smallest count that makes the region >= --min-region-ms (the same on
+every rank), so a short --steps still gives a region the driver's clock can see.  `value` = frames of all ranks / MAX-over-ranks
+wall time of the region; `ms_per_step` = that time / (R * K).  HIP events on the engine's stream give the per-launch duration
+the roofline uses.
+
+One JSON line on rank 0 (contract in the task statement) with `roofline` (+ `roofline_hbm`: the same kernel with the state
+working set outside the 256 MiB Infinity Cache), `cpu_baseline`, and `other_configs` (BASELINE cfg3 / cfg4 / cfg5 through the
+same code path).  A --gpus / rank-count mismatch exits non-zero."""
 import argparse
+import importlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-M, NFFT, HOP, BATCH, FS = 4, 512, 256, 1024, 16000
-ANGLE = np.array([197.0, 0.0]) / 180.0 * np.pi
-# SURVEY.md section 8(d), cfg2 (MVDR): algorithmic bytes per frame at T hops per call
-#   bytes(T) = M*hop*4 (in) + hop*4 (out) + 2*S/T,  S = 43 156 B of output-affecting state per utterance
-S_STATE = 4096 + 1024 + 257 * 16 * 8 + 5 * 257 * 4
-
-
-# cfg3 (GSC + McMcra gain): S = 5120 tails + G_aic 3*257*8 + Phi_yy, Phi_vv 2*16*257*4 = 44 184 B ; cfg1 (fixed): tails only
-S_STATE_BY_ALGO = {"mvdr": S_STATE, "gsc": 5120 + 3 * 257 * 8 + 2 * 16 * 257 * 4, "fixed": 5120}
-
-
-def algorithmic_bytes_per_frame(T, algo="mvdr"):
-    return M * HOP * 4 + HOP * 4 + 2.0 * S_STATE_BY_ALGO[algo] / T
-
-
+FS = 16000
+ANGLE_DEG = (197.0, 0.0)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+# SURVEY.md section 8(d): algorithmic bytes per frame at T hops per call
+#   bytes(T) = M*hop*4 (in) + hop*4 (out) + 2*S/T,   S = output-affecting persistent state per utterance (fp32 / complex64)
+WORKLOADS = {
+    # cfg2 (headline): S = STFT tail 4096 + OLA tail 1024 + Rvv 257*16*8 + MCRA 5*257*4 = 43 156
+    "cfg2": dict(algo="ADAPTIVE", M=4, nfft=512, hop=256, batch=1024, S=4096 + 1024 + 257 * 16 * 8 + 5 * 257 * 4, r=0.032,
+                 kernel="ds_frames_kernel<512,4,ADAPTIVE>", launches=1, graph=1,
+                 desc="adaptive MVDR (adaptivebeamfomer.process method=2), 4 mics, 16 kHz, 512-FFT/256-hop"),
+    # cfg3: S = 5120 tails + G_aic 3*257*8 + Phi_yy, Phi_vv 2*16*257*4 = 44 184
+    "cfg3": dict(algo="GSC", M=4, nfft=512, hop=256, batch=4096, S=5120 + 3 * 257 * 8 + 2 * 16 * 257 * 4, r=0.032,
+                 kernel="ds_frames_kernel<512,4,GSC>", launches=1, graph=1,
+                 desc="GSC + LMS canceller + McMcra gain (GSC.process method=2), 4 mics, 16 kHz, 512-FFT/256-hop"),
+    # cfg1 on the GPU (stateless apart from the tails)
+    "fixed": dict(algo="FIXED", M=4, nfft=512, hop=256, batch=1024, S=5120, r=0.032,
+                  kernel="ds_frames_kernel<512,4,FIXED>", launches=1, graph=1,
+                  desc="delay-and-sum (FixedBeamformer.process), 4 mics, 16 kHz, 512-FFT/256-hop"),
+    # cfg4: WPE (N = 2 taps, delay 4) -> adaptive MVDR -> SPP gain; 8 mics, 1024/512; 8192 utterances over 8 GPUs = 1024 per GPU
+    "cfg4": dict(algo="WPE_MVDR", M=8, nfft=1024, hop=512, batch=1024, S=2197656, r=0.05, filter_len=2,
+                 kernel="DS_ALGO_WPE_MVDR chain", launches=5, graph=0,
+                 desc="WPE dereverberation (2 taps) + adaptive MVDR + SPP gain chain, 8 mics, 16 kHz, 1024-FFT/512-hop"),
+    # cfg5: SubbandGSC structure with SubbandRLS blocking filters; 6 mics, 512 bands; 16384 utterances over 8 GPUs = 2048 per GPU
+    "cfg5": dict(algo="SUBBAND_GSC", M=6, nfft=512, hop=256, batch=2048, S=313440, r=0.05, filter_len=2, rls_lambda=0.998,
+                 kernel="DS_ALGO_SUBBAND_GSC chain", launches=14, graph=0,
+                 desc="Subband-RLS GSC chain (SubbandGSC.process with SubbandRLS blocking filters), 6 mics, 16 kHz, 512 bands / block 256"),
+}
 
-def synth_batch_torch(torch, B, L, device, seed):
-    """[B, M, L] float32 on `device`: white noise sigma=0.05 per mic + 0.5 s on/off band-limited
-    (300-3400 Hz) Gaussian source sigma=0.1 steered from 197 deg through the array delays
-    (BASELINE.md section 3), generated on the GPU."""
-    from distantspeech_amd.mic_array import MicArray, compute_tau
-    g = torch.Generator(device=device)
-    g.manual_seed(1234 + seed)
-    mic = MicArray(M=M, n_fft=NFFT)
-    tau = torch.tensor(compute_tau(mic, ANGLE)[:, 0], dtype=torch.float32, device=device)
-    x = torch.empty((B, M, L), dtype=torch.float32, device=device)
-    f = torch.fft.rfftfreq(L, 1.0 / FS).to(device)
-    band = ((f >= 300) & (f <= 3400)).to(torch.float32)
-    gate = ((torch.arange(L, device=device) // (FS // 2)) % 2 == 0).to(torch.float32)
-    chunk = 64
-    for b0 in range(0, B, chunk):
-        b1 = min(B, b0 + chunk)
-        S = torch.fft.rfft(torch.randn((b1 - b0, L), generator=g, device=device)) * band
-        for m in range(M):
-            ph = torch.exp(-2j * math.pi * f * tau[m])
-            s = torch.fft.irfft(S * ph, n=L)
-            s = s / (s.std(dim=1, keepdim=True) + 1e-12) * 0.1
-            x[b0:b1, m] = s * gate + 0.05 * torch.randn((b1 - b0, L), generator=g, device=device)
-    return x
+
+def algorithmic_bytes_per_frame(w, T=1):
+    return w["M"] * w["hop"] * 4 + w["hop"] * 4 + 2.0 * w["S"] / T
+
+
+# ------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no rank environment starts N child ranks, one per GPU.  The parent never imports
+# torch and never touches the GPU; the children are this same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set.
+# ------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    env0 = dict(os.environ)
+    env0.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), DS_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in pending:                     # one rank failed: stop exactly the ranks this process started
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU backend: device buffers through torch (plumbing), the hot path through libdsenh.so's C-ABI (BatchEngine)
+# ------------------------------------------------------------------------------------------------
+class GpuBackend:
+    name = "synthetic"
+    dist_backend = None              # dist.init picks nccl (= RCCL) on a GPU box
+
+    def __init__(self, local_rank, world):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("rank with LOCAL_RANK=%d but only %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        self.local_rank = local_rank
+        self.device = torch.device("cuda", local_rank)
+
+    def device_sync(self):
+        self.torch.cuda.synchronize()
+
+    def synth(self, w, B, L, seed):
+        """[B, M, L] float32 on the GPU: white noise sigma = 0.05 per mic + 0.5 s on/off band-limited (300-3400 Hz) Gaussian
+        source sigma = 0.1 steered from 197 deg through the array delays."""
+        import numpy as np
+        torch = self.torch
+        from distantspeech_amd.mic_array import MicArray, compute_tau
+        M = w["M"]
+        g = torch.Generator(device=self.device)
+        g.manual_seed(1234 + seed)
+        mic = MicArray(arrayType="circular", r=w["r"], M=M, n_fft=w["nfft"])
+        ang = np.array(ANGLE_DEG) / 180.0 * np.pi
+        tau = torch.tensor(compute_tau(mic, ang)[:, 0], dtype=torch.float32, device=self.device)
+        x = torch.empty((B, M, L), dtype=torch.float32, device=self.device)
+        f = torch.fft.rfftfreq(L, 1.0 / FS).to(self.device)
+        band = ((f >= 300) & (f <= 3400)).to(torch.float32)
+        gate = ((torch.arange(L, device=self.device) // (FS // 2)) % 2 == 0).to(torch.float32)
+        chunk = 64
+        for b0 in range(0, B, chunk):
+            b1 = min(B, b0 + chunk)
+            S = torch.fft.rfft(torch.randn((b1 - b0, L), generator=g, device=self.device)) * band
+            for m in range(M):
+                ph = torch.exp(-2j * math.pi * f * tau[m])
+                s = torch.fft.irfft(S * ph, n=L)
+                s = s / (s.std(dim=1, keepdim=True) + 1e-12) * 0.1
+                x[b0:b1, m] = s * gate + 0.05 * torch.randn((b1 - b0, L), generator=g, device=self.device)
+        return x
+
+    def make(self, w, B, T, K, W, seed, graph):
+        return GpuWorkload(self, w, B, T, K, W, seed, graph)
+
+
+class GpuWorkload:
+    """One engine handle + its resident input / output slabs; run(first_step, n) enqueues n successive steps."""
+
+    def __init__(self, be, w, B, T, K, W, seed, graph):
+        import numpy as np
+        from distantspeech_amd import BatchEngine, _lib as L
+        from distantspeech_amd.mic_array import MicArray, compute_tau
+        torch = be.torch
+        self.be, self.w, self.B, self.T, self.L = be, w, B, T, L
+        M, nfft, hop = w["M"], w["nfft"], w["hop"]
+        self.hop, self.M = hop, M
+        self.Ltot = (K + W) * T * hop
+        self.x = be.synth(w, B, self.Ltot, seed)
+        self.y = torch.empty((B, self.Ltot), dtype=torch.float32, device=be.device)
+        self.graph = graph
+        algo = getattr(L, "ALGO_" + w["algo"])
+        self.eng = BatchEngine(algo, M, nfft, hop, batch=B, device=be.local_rank, filter_len=w.get("filter_len", 0),
+                               rls_lambda=w.get("rls_lambda", 0.0))
+        mic = MicArray(arrayType="circular", r=w["r"], M=M, n_fft=nfft)
+        ang = np.array(ANGLE_DEG) / 180.0 * np.pi
+        if w["algo"] == "SUBBAND_GSC":
+            from distantspeech_amd.ops import McSpp
+            from distantspeech_amd.subband_gsc import fractional_delay_filter_bank
+            tau = compute_tau(mic, ang)
+            self.eng.chain_set_aux(L.CHAIN_AUX_FIR, fractional_delay_filter_bank(np.array(-(tau - np.max(tau)))[:, 0] * mic.fs))
+            self.eng.chain_set_aux(L.CHAIN_AUX_COHERENCE, McSpp.diffuse_coherence(M, nfft))
+        else:
+            tao = -1 * mic.r * np.cos(ang[1]) * np.cos(ang[0] - mic.gamma) / mic.c          # adaptivebeamformer.py:52
+            a = np.exp(-1j * (2 * np.pi * np.arange(nfft // 2 + 1) * FS / nfft)[:, None] * tao[None, :])
+            self.eng.set_steering(a / M if w["algo"] == "FIXED" else a)                    # fixed: delay-and-sum weights W = a / M
+            if w["algo"] != "FIXED":
+                self.eng.set_method(L.METHOD_MVDR)
+        be.device_sync()              # inputs resident before anything is launched on the engine's stream
+
+    def run(self, first_step, n):
+        L, T, hop, Ltot = self.L, self.T, self.hop, self.Ltot
+        off = 4 * first_step * T * hop
+        self.eng.process_device_seq(self.x.data_ptr() + off, L.LAYOUT_CHANNELS_SAMPLES, self.M * Ltot, Ltot, T * hop, T * hop, n,
+                                    self.y.data_ptr() + off, Ltot, T * hop, graph=self.graph)
+
+    def sync(self):
+        self.eng.synchronize()
+
+    def timing_begin(self):
+        self.eng.timing_begin()       # hipEvent on the stream the kernels are launched on
+
+    def timing_end(self):
+        return self.eng.timing_end()  # records the end event on that stream and waits for it
+
+    def check(self, first_step):
+        assert bool(self.be.torch.isfinite(self.y[:, first_step * self.T * self.hop:]).all()), "non-finite output"
+
+    def close(self):
+        self.eng.close()
+        del self.x, self.y
+        self.be.torch.cuda.empty_cache()
+
+
+def load_backend(local_rank, world):
+    spec = os.environ.get("DS_BENCH_BACKEND")            # test infrastructure only (tests/bench_stub.py): exercises the rank plumbing without a GPU
+    if spec:
+        mod, cls = spec.split(":")
+        return getattr(importlib.import_module(mod), cls)(local_rank, world)
+    return GpuBackend(local_rank, world)
+
+
+# ------------------------------------------------------------------------------------------------
+# the measurement of one workload: warm-up, probe, R rounds of exactly K steps in ONE bracketed region
+# ------------------------------------------------------------------------------------------------
+def measure(be, dsdist, w, B, T, K, W, rank, world, min_region_ms, graph=None, max_rounds=20000):
+    wl = be.make(w, B, T, K, W, seed=rank, graph=w["graph"] if graph is None else graph)
+    wl.run(0, W)
+    wl.run(W, K)                      # one more untimed round: builds the round's hipGraph where one is used
+    wl.sync()
+    be.device_sync()
+    t0 = time.perf_counter()          # probe round (untimed for the result): sizes R, the same on every rank
+    wl.run(W, K)
+    wl.sync()
+    probe = time.perf_counter() - t0
+    probe = dsdist.reduce_max(probe, device=getattr(be, "device", None))
+    R = int(min(max_rounds, max(1, math.ceil(1.3 * min_region_ms * 1e-3 / max(probe, 1e-7)))))   # 1.3: the probe also pays one sync
+    be.device_sync()
+    dsdist.barrier()
+    be.device_sync()
+    t0 = time.perf_counter()
+    wl.timing_begin()
+    for _ in range(R):
+        wl.run(W, K)                  # every round replays the same K resident hops; the carried state keeps evolving
+    dev_ms = wl.timing_end()
+    be.device_sync()
+    dsdist.barrier()
+    be.device_sync()
+    elapsed = time.perf_counter() - t0
+    wl.check(W)
+    frames_rank = B * K * T * R
+    frames, t_max, ranks = dsdist.reduce_throughput(frames_rank, elapsed, device=getattr(be, "device", None))
+    dev_ms = dsdist.reduce_max(dev_ms, device=getattr(be, "device", None))
+    wl.close()
+    launch_ms = dev_ms / (K * R)                               # average launch-to-launch duration on the kernel's stream (HIP events)
+    alg = algorithmic_bytes_per_frame(w, T)
+    achieved = alg * B * T / (launch_ms * 1e-3) / 1e9          # algorithmic GB/s of one GPU
+    return {
+        "value": round(frames / t_max, 1), "ms_per_step": round(t_max / (K * R) * 1e3, 5), "rounds": R, "timed_steps": K * R,
+        "region_ms": round(t_max * 1e3, 3), "ranks": ranks,
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": w["kernel"],
+                     "launches_per_step": w["launches"], "launch_ms": round(launch_ms, 5), "algorithmic_bytes_per_frame": alg,
+                     "algorithmic_bytes_per_launch": alg * B * T, "batch_per_gpu": B, "hops_per_call": T},
+    }
+
+
+def attach_traffic(roof, key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/traffic_latest.json: FETCH_SIZE /
+    WRITE_SIZE with the guide's gfx950 corrections).  PMC counters cannot be read inside this process, so the figure is the profile's,
+    labelled with its source; `frac_measured` = that traffic / this run's launch duration / peak."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as fh:
+            t = json.load(fh)
+        ent = t.get(key)
+        if not ent:
+            return
+        roof["traffic"] = ent["hbm_bytes_per_launch"]
+        roof["traffic_source"] = ent.get("source", "profiles/traffic_latest.json")
+        gbs = ent["hbm_bytes_per_launch"] / (roof["launch_ms"] * 1e-3) / 1e9
+        roof["achieved_measured"] = round(gbs, 1)
+        roof["frac_measured"] = round(gbs / HBM_PEAK_GBS, 4)
+    except Exception:
+        pass
 
 
 # ------------------------------------------------------------------------------------------------
@@ -73,13 +291,16 @@ def synth_batch_torch(torch, B, L, device, seed):
 # oracle/c/ds_oracle_mvdr.c, pinned to the reference's golden vectors) on the host cores, one thread per core
 # ------------------------------------------------------------------------------------------------
 def cpu_baseline(budget_s=10.0):
+    import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     from oracle import ds_oracle as O
     from oracle.c_oracle import COracleMVDR
+    M, NFFT, HOP = 4, 512, 256
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, 64))                   # threads actually used (reported as `cores`)
     mic = O.OracleMicArray(M=M, n_fft=NFFT)
-    tao = O.circular_tao(mic.r, mic.c, mic.gamma, ANGLE)
+    ang = np.array(ANGLE_DEG) / 180.0 * np.pi
+    tao = O.circular_tao(mic.r, mic.c, mic.gamma, ang)
     omega = 2 * np.pi * np.arange(NFFT // 2 + 1) * FS / NFFT
     steer = np.exp(-1j * omega[:, None] * tao[None, :])
     n_distinct = 8
@@ -91,8 +312,8 @@ def cpu_baseline(budget_s=10.0):
         eng.process(x)                               # hop-by-hop inside (one hop per reference call)
         return x.shape[1] // HOP, time.perf_counter() - t0
 
-    f0, t0 = work((O.synth_utterance(0, HOP * 200, mic),))      # calibrate on one core, then ~budget_s/4 of work per thread
-    frames = int(max(200, min(625 * 4, f0 / t0 * budget_s / 4)))
+    f0, t0 = work((O.synth_utterance(0, HOP * 200, mic),))      # calibrate on one core, then ~budget_s of work per thread
+    frames = int(max(200, min(625 * 16, f0 / t0 * budget_s)))
     xs = [O.synth_utterance(u, HOP * frames, mic) for u in range(n_distinct)]   # inputs built before the timed region
     t_start = time.perf_counter()
     with ThreadPoolExecutor(cores) as pool:
@@ -106,118 +327,93 @@ def cpu_baseline(budget_s=10.0):
             "per_core": round(total / busy / cores, 1)}
 
 
-def load_traffic():
-    """HBM bytes per launch from the committed PMC profile of this same command (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=625)
     ap.add_argument("--warmup", type=int, default=25)
-    ap.add_argument("--batch", type=int, default=BATCH, help="utterances per GPU (BASELINE cfg2: 1024)")
+    ap.add_argument("--config", default="cfg2", choices=sorted(WORKLOADS), help="BASELINE config measured as the headline (default cfg2)")
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the config's BASELINE batch)")
     ap.add_argument("--hops-per-step", type=int, default=1, help="T: hops per call (1 = streaming callback regime)")
+    ap.add_argument("--graph", type=int, default=-1, help="1 = replay a round as one hipGraph, 0 = plain launches (default: per config)")
+    ap.add_argument("--min-region-ms", type=float, default=250.0, help="rounds of --steps are repeated until the timed region is this long")
+    ap.add_argument("--hbm-batch", type=int, default=16384, help="batch of the roofline_hbm regime (state working set > the 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--algo", default="mvdr", choices=["mvdr", "gsc", "fixed"],
-                    help="mvdr = BASELINE cfg2 (the headline); gsc = cfg3 (use --batch 4096); fixed = cfg1 on the GPU")
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
-                    help="BASELINE config: cfg2 = the headline (default); cfg3 = --algo gsc --batch 4096; cfg4 / cfg5 = the chain handles "
-                         "(scripts/bench_cfg4.py, scripts/bench_cfg5.py: single GPU, one JSON line per regime)")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_hbm and other_configs (profiling runs)")
     args = ap.parse_args()
-    if args.config in ("cfg4", "cfg5"):
-        import runpy
-        sys.argv = [sys.argv[0]]
-        runpy.run_path(os.path.join(ROOT, "scripts", "bench_%s.py" % args.config), run_name="__main__")
-        return
-    if args.config == "cfg3":
-        args.algo = "gsc"
-        if args.batch == BATCH:
-            args.batch = 4096
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--gpus and --steps must be >= 1, --warmup >= 0")
 
-    import torch
-    from distantspeech_amd import BatchEngine, dist as dsdist
-    from distantspeech_amd import _lib as L
-    from distantspeech_amd.mic_array import MicArray
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))        # children only; nothing in this process has touched torch or the GPU
 
-    rank, local_rank, world = dsdist.init()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    from distantspeech_amd import dist as dsdist
+    rank, local_rank, world = dsdist.env_world()
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but %d rank(s) were launched (WORLD_SIZE)\n" % (args.gpus, world))
+        sys.exit(2)
+    be = load_backend(local_rank, world)
+    dsdist.init(backend=be.dist_backend)
 
-    B, K, W, T = args.batch, args.steps, args.warmup, args.hops_per_step
-    hops_total = (K + W) * T
-    Ltot = hops_total * HOP
-    x = synth_batch_torch(torch, B, Ltot, device, seed=rank)
-    y = torch.empty((B, Ltot), dtype=torch.float32, device=device)
+    w = WORKLOADS[args.config]
+    B = args.batch or w["batch"]
+    K, W, T = args.steps, args.warmup, args.hops_per_step
+    graph = None if args.graph < 0 else args.graph
+    res = measure(be, dsdist, w, B, T, K, W, rank, world, args.min_region_ms, graph=graph)
+    if res["ranks"] != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but %d rank(s) contributed to the result\n" % (args.gpus, res["ranks"]))
+        sys.exit(2)
+    out = None
+    if rank == 0:
+        regime = "streaming callback regime" if T == 1 else "chunked"
+        mics = {"cfg2": "4-mic, 512-FFT", "cfg3": "4-mic, 512-FFT", "fixed": "4-mic, 512-FFT", "cfg4": "8-mic, 1024-FFT", "cfg5": "6-mic, 512 bands"}[args.config]
+        out = {
+            "metric": "enhanced frames/sec (%s)" % mics, "value": res["value"], "unit": "frames/s",
+            "n_gpus": res["ranks"], "steps": K, "warmup": W, "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": be.name,
+            "rounds": res["rounds"], "timed_steps": res["timed_steps"], "region_ms": res["region_ms"],
+            "config": {"workload": "BASELINE %s: %s, batch=%d utterances per GPU, %d hop(s) per call (%s), state resident in HBM"
+                                   % (args.config, w["desc"], B, T, regime),
+                       "batch_per_gpu": B, "hops_per_call": T, "n_mics": w["M"], "nfft": w["nfft"], "hop": w["hop"],
+                       "launch": "hipGraph replay of each round" if (w["graph"] if graph is None else graph) else "plain launches"},
+            "roofline": res["roofline"],
+        }
+        if T == 1 and B == w["batch"]:
+            attach_traffic(out["roofline"], args.config)
 
-    algo_id = {"mvdr": L.ALGO_ADAPTIVE, "gsc": L.ALGO_GSC, "fixed": L.ALGO_FIXED}[args.algo]
-    eng = BatchEngine(algo_id, M, NFFT, HOP, batch=B, device=local_rank)
-    mic = MicArray(M=M, n_fft=NFFT)
-    tao = -1 * mic.r * np.cos(ANGLE[1]) * np.cos(ANGLE[0] - mic.gamma) / mic.c
-    omega = 2 * np.pi * np.arange(NFFT // 2 + 1) * FS / NFFT
-    a = np.exp(-1j * omega[:, None] * tao[None, :])
-    eng.set_steering(a / M if args.algo == "fixed" else a)          # fixed: delay-and-sum weights W = a / M
-    if args.algo != "fixed":
-        eng.set_method(L.METHOD_MVDR)
-
-    xp, yp = x.data_ptr(), y.data_ptr()
-    torch.cuda.synchronize()          # inputs resident before anything is launched on the engine's stream
-
-    def run_steps(first_step, n):
-        """n successive steps (one native call; launches go to the engine's own HIP stream)."""
-        off = first_step * T * HOP
-        eng.process_device_seq(xp + 4 * off, L.LAYOUT_CHANNELS_SAMPLES, M * Ltot, Ltot, T * HOP, T * HOP, n,
-                               yp + 4 * off, Ltot, T * HOP)
-
-    run_steps(0, W)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    dsdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    eng.timing_begin()                # hipEvent on the stream the kernels are launched on
-    run_steps(W, K)
-    dev_ms = eng.timing_end()         # records the end event and waits for it
-    torch.cuda.synchronize()
-    dsdist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-
-    frames_rank = B * K * T
-    frames, t_max = dsdist.reduce_throughput(frames_rank, elapsed, device=device)
-    assert bool(torch.isfinite(y[:, W * T * HOP:]).all()), "non-finite output"
+    if not args.no_extras:
+        # (1) the same kernel with the state working set outside the Infinity Cache: an HBM measurement of the HBM claim
+        if args.config in ("cfg2", "cfg3", "fixed") and T == 1 and args.hbm_batch > B:
+            Kh, Wh = min(K, 40), min(W, 5)
+            r2 = measure(be, dsdist, w, args.hbm_batch, 1, Kh, Wh, rank, world, min(args.min_region_ms, 150.0), graph=graph)
+            if rank == 0:
+                roof = r2["roofline"]
+                roof.update(value=r2["value"], steps=Kh, rounds=r2["rounds"], state_bytes_per_launch=w["S"] * args.hbm_batch,
+                            note="same kernel, batch %d per GPU: the carried state of one launch exceeds the 256 MiB Infinity Cache, so consecutive "
+                                 "launches are served by HBM" % args.hbm_batch)
+                attach_traffic(roof, args.config + "_hbm")
+                out["roofline_hbm"] = roof
+        # (2) the other BASELINE configs through the same path (same sharding, same bracketing)
+        others = {}
+        for name in ("cfg3", "cfg4", "cfg5"):
+            if name == args.config or T != 1:
+                continue
+            wo = WORKLOADS[name]
+            Ko, Wo = min(K, 40), min(W, 4)
+            ro = measure(be, dsdist, wo, wo["batch"], 1, Ko, max(Wo, 2), rank, world, min(args.min_region_ms, 120.0))
+            if rank == 0:
+                attach_traffic(ro["roofline"], name)
+                others[name] = {"workload": "BASELINE %s: %s, batch=%d per GPU, 1 hop per call" % (name, wo["desc"], wo["batch"]),
+                                "value": ro["value"], "unit": "frames/s", "n_gpus": ro["ranks"], "steps": Ko, "rounds": ro["rounds"],
+                                "ms_per_step": ro["ms_per_step"], "roofline": ro["roofline"]}
+        if rank == 0 and others:
+            out["other_configs"] = others
 
     if rank == 0:
-        launch_ms = dev_ms / K                                  # average launch duration (HIP events, same stream)
-        alg_bytes = algorithmic_bytes_per_frame(T, args.algo) * B * T      # per launch
-        achieved = alg_bytes / (launch_ms * 1e-3) / 1e9
-        out = {
-            "metric": "enhanced frames/sec (4-mic, 512-FFT)", "value": round(frames / t_max, 1), "unit": "frames/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(t_max / K * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, 4 mics, 16 kHz, 512-FFT/256-hop, "
-                                   "batch=%d utterances per GPU, %d hop(s) per call (streaming callback regime), "
-                                   "state resident in HBM" % (
-                                       {"mvdr": "adaptive MVDR (adaptivebeamfomer.process method=2)",
-                                        "gsc": "GSC + LMS canceller + McMcra gain (GSC.process method=2)",
-                                        "fixed": "delay-and-sum (FixedBeamformer.process)"}[args.algo], B, T),
-                       "batch_per_gpu": B, "hops_per_call": T, "n_mics": M, "nfft": NFFT, "hop": HOP},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": load_traffic() if (args.algo == "mvdr" and B == BATCH and T == 1) else None,
-                         "kernel": "ds_frames_kernel<512,4,%s>" % {"mvdr": "ADAPTIVE", "gsc": "GSC", "fixed": "FIXED"}[args.algo], "launch_ms": round(launch_ms, 5),
-                         "algorithmic_bytes_per_frame": algorithmic_bytes_per_frame(T, args.algo)},
-        }
-        if world == 1 and not args.no_cpu_baseline and args.algo == "mvdr":
+        if world == 1 and not args.no_cpu_baseline and args.config == "cfg2" and not os.environ.get("DS_BENCH_BACKEND"):
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    dsdist.finalize()
 
 
 if __name__ == "__main__":

@@ -10,6 +10,7 @@
 // Written single-source (DS_HD) so tests/emul can run the same code serially on the CPU.
 #pragma once
 #include "ds_core.hpp"
+#include "ds_linalg64.hpp"
 #include "ds_wpe.hpp"     // OP_WPE handles run the lane-parallel block program of ds_wpe.hpp, not a per-thread operator
 
 namespace ds {
@@ -726,129 +727,7 @@ template <int M> DS_HD void op_mcsppbase(const OpCtx& p, int b, int k) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Small complex-Hermitian linear algebra in registers (full M x M arrays; M <= 8)
-// ------------------------------------------------------------------------------------------------
-// inverse of the Hermitian positive-definite A (overwritten): Cholesky A = L L^H, Linv, inv = Linv^H Linv
-template <int M> DS_HD void herm_inverse(cf (&A)[M][M], cf (&inv)[M][M]) {
-    float invd[M];
-    cf L[M][M], Li[M][M];
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        float s = A[j][j].x;
-#pragma unroll
-        for (int q = 0; q < j; ++q) s = fma_(-L[j][q].x, L[j][q].x, fma_(-L[j][q].y, L[j][q].y, s));
-        s = fmaxf_(s, 1e-30f);
-        const float r = 1.0f / sqrtf(s);
-        invd[j] = r;
-#pragma unroll
-        for (int i = j + 1; i < M; ++i) {
-            cf a = A[i][j];
-#pragma unroll
-            for (int q = 0; q < j; ++q) a = cfnmac(a, L[i][q], L[j][q]);
-            L[i][j] = cscale(a, r);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < M; ++c)
-#pragma unroll
-        for (int i = c; i < M; ++i) {
-            cf t = (i == c) ? mk(1.0f, 0.0f) : mk(0.0f, 0.0f);
-#pragma unroll
-            for (int q = c; q < i; ++q) t = cfnma(t, L[i][q], Li[q][c]);
-            Li[i][c] = cscale(t, invd[i]);
-        }
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-        for (int j = i; j < M; ++j) {
-            cf t = mk(0.0f, 0.0f);
-#pragma unroll
-            for (int q = j; q < M; ++q) t = cfmac(t, Li[q][j], Li[q][i]);     // sum conj(Li_qi) Li_qj
-            inv[i][j] = t;
-            inv[j][i] = cconj(t);
-        }
-}
-
-// principal eigenvector (largest eigenvalue) of the Hermitian A by cyclic complex Jacobi, phase-normalised by
-// element 0 (beamformer/beamformer.py:10-31: np.linalg.eigh(...)[1][:, :, -1] / exp(j angle(v0)))
-template <int M> DS_HD void herm_principal(cf (&A)[M][M], cf* v) {
-    cf V[M][M];
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-        for (int j = 0; j < M; ++j) V[i][j] = mk(i == j ? 1.0f : 0.0f, 0.0f);
-    for (int sweep = 0; sweep < 8; ++sweep) {
-#pragma unroll
-        for (int p = 0; p < M - 1; ++p)
-#pragma unroll
-            for (int q = p + 1; q < M; ++q) {
-                const cf apq = A[p][q];
-                const float mag2 = cabs2(apq);
-                if (mag2 > 1e-37f) {
-                    const float mag = sqrtf(mag2);
-                    const cf e = cscale(apq, 1.0f / mag);
-                    const float app = A[p][p].x, aqq = A[q][q].x;
-                    const float tau = (aqq - app) / (2.0f * mag);
-                    const float t = (tau >= 0.0f ? 1.0f : -1.0f) / (fabsf(tau) + sqrtf(fma_(tau, tau, 1.0f)));
-                    const float c = 1.0f / sqrtf(fma_(t, t, 1.0f)), sn = t * c;
-                    const cf se = cscale(e, sn);                                   // s e^{j phi}
-#pragma unroll
-                    for (int k = 0; k < M; ++k) {
-                        if (k != p && k != q) {
-                            const cf akp = A[k][p], akq = A[k][q];
-                            const cf np_ = cfnmac(cscale(akp, c), akq, se);        // c akp - s conj(e) akq
-                            const cf nq_ = cfma(cscale(akq, c), se, akp);          // s e akp + c akq
-                            A[k][p] = np_; A[k][q] = nq_;
-                            A[p][k] = cconj(np_); A[q][k] = cconj(nq_);
-                        }
-                    }
-                    A[p][p] = mk(fma_(-t, mag, app), 0.0f);
-                    A[q][q] = mk(fma_(t, mag, aqq), 0.0f);
-                    A[p][q] = mk(0.0f, 0.0f); A[q][p] = mk(0.0f, 0.0f);
-#pragma unroll
-                    for (int k = 0; k < M; ++k) {
-                        const cf vkp = V[k][p], vkq = V[k][q];
-                        V[k][p] = cfnmac(cscale(vkp, c), vkq, se);
-                        V[k][q] = cfma(cscale(vkq, c), se, vkp);
-                    }
-                }
-            }
-    }
-    int best = 0;
-    float wmax = A[0][0].x;
-#pragma unroll
-    for (int i = 1; i < M; ++i) if (A[i][i].x >= wmax) { wmax = A[i][i].x; best = i; }   // ties: the last one, like eigh's ascending order
-    cf v0 = mk(1.0f, 0.0f);
-#pragma unroll
-    for (int i = 0; i < M; ++i) if (i == best) v0 = V[0][i];
-    const float n0 = sqrtf(cabs2(v0));
-    const cf ph = n0 > 0.0f ? cscale(cconj(v0), 1.0f / n0) : mk(1.0f, 0.0f);       // exp(-j angle(v0))
-#pragma unroll
-    for (int k = 0; k < M; ++k) {
-        cf vk = mk(0.0f, 0.0f);
-#pragma unroll
-        for (int i = 0; i < M; ++i) if (i == best) vk = V[k][i];
-        v[k] = cmul(vk, ph);
-    }
-}
-
-// w = R^-1 a / (a^H R^-1 a)   (beamformer/beamformer.py:133-155)
-template <int M> DS_HD void mvdr_weight(const cf (&Rinv)[M][M], const cf* a, cf* w) {
-    cf num[M];
-    cf den = mk(0.0f, 0.0f);
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-        cf t = mk(0.0f, 0.0f);
-#pragma unroll
-        for (int j = 0; j < M; ++j) t = cfma(t, Rinv[i][j], a[j]);
-        num[i] = t;
-        den = cfmac(den, t, a[i]);                                                 // + conj(a_i) num_i
-    }
-#pragma unroll
-    for (int i = 0; i < M; ++i) w[i] = cdiv(num[i], den);
-}
-
+// Small complex-Hermitian linear algebra in registers (inverse, principal eigenvector, MVDR weights): ds_linalg64.hpp (double)
 template <int M> DS_HD void herm_unpack(const float* d, const float* o, cf (&A)[M][M]) {
 #pragma unroll
     for (int i = 0; i < M; ++i)
@@ -869,7 +748,7 @@ DS_HD void op_mccdr(const OpCtx& p, int b, int k) {
 #pragma unroll
     for (int f = 0; f < 5; ++f) mc[f] = st_at(p, b, 4 + f, k);
     int frm = p.frm_cnt, ell = p.ell;
-    const float Fn = p.in1[k], Fn2 = Fn * Fn;
+    const float Fn = p.in1[k];
     for (int t = 0; t < p.T; ++t) {
         const long long fb = ((long long)b * p.T + t) * p.K;
         const long long base = (fb + k) * M;
@@ -880,14 +759,17 @@ DS_HD void op_mccdr(const OpCtx& p, int b, int k) {
         p2 = fma_(0.9f, p2, (float)(1.0 - 0.9) * cabs2(y2));
         const cf c12 = cmulc(y1, y2);
         x12 = mk(fma_(0.9f, x12.x, (float)(1.0 - 0.9) * c12.x), fma_(0.9f, x12.y, (float)(1.0 - 0.9) * c12.y));   // :55-61
-        const float rn = 1.0f / sqrtf(p1 * p2);
-        const cf Fx = cscale(x12, rn);                                             // updateMSC :28
-        const float Fx2 = cabs2(Fx);
-        const float rad = fma_(Fn2, Fx.x * Fx.x, -Fn2 * Fx2) + Fn2 - 2.0f * Fn * Fx.x + Fx2;
-        float G = (Fn * Fx.x - Fx2 - sqrtf(rad)) / fminf_(Fx2 - 1.0f, -1e-3f);     // mccdr.py:141-145
-        G = G * G;
-        if (G > 1.0f) G = 1.0f;                                                    // :160-161 (NaN stays NaN like numpy)
-        if (G < 0.0f) G = 1e-3f;
+        // coherent-to-diffuse ratio in double: with |Fx| -> 1 and Fn -> 1 (the lowest bins of a real recording) the radicand is the
+        // difference of nearly equal terms
+        const double rn = 1.0 / sqrt((double)p1 * (double)p2);
+        const double Fxr = (double)x12.x * rn, Fxi = (double)x12.y * rn;           // updateMSC :28
+        const double Fx2 = fmad_(Fxr, Fxr, Fxi * Fxi);
+        const double Fnd = (double)Fn, Fn2d = Fnd * Fnd;
+        const double rad = Fn2d * (Fxr * Fxr) - Fn2d * Fx2 + Fn2d - 2.0 * Fnd * Fxr + Fx2;
+        double Gd = (Fnd * Fxr - Fx2 - sqrt(rad)) / dmin_(Fx2 - 1.0, -1e-3);      // mccdr.py:141-145
+        Gd = Gd * Gd;
+        if (Gd > 1.0) Gd = 1.0;                                                    // :160-161 (NaN stays NaN like numpy)
+        if (Gd < 0.0) Gd = 1e-3;
         const bool reset = mcra_tick(frm, ell, p.L);
         const float pw0 = cabs2(y0);
         float ym = 0.0f, yp = 0.0f;
@@ -895,7 +777,7 @@ DS_HD void op_mccdr(const OpCtx& p, int b, int k) {
         if (k < p.K - 1) { const long long q = (fb + k + 1) * M; yp = cabs2(mk(p.in0[2 * q], p.in0[2 * q + 1])); }
         mcra_bin(mc, k, p.K, ym, pw0, yp, frm, reset, p.L);                        // :174 (L = 65)
         frm += 1; ell += 1;
-        p.out0[fb + k] = sqrtf(G * mc[3]);                                         // :175
+        p.out0[fb + k] = (float)sqrt(Gd * (double)mc[3]);                          // :175
     }
     st_at(p, b, 0, k) = p1; st_at(p, b, 1, k) = p2; st_at(p, b, 2, k) = x12.x; st_at(p, b, 3, k) = x12.y;
 #pragma unroll
@@ -919,7 +801,7 @@ DS_HD float mcspp_qavg(const float* gamma_frame, int fmin, int fmax) {
     return qsum / (float)(fmax - fmin);
 }
 
-template <int M, bool LEAN = false> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
+template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
     const int o0 = p.N;                                                            // state row offset of the McSpp part
     float yd[M], yo[2 * NO + 1], vd[M], vo[2 * NO + 1];
@@ -952,97 +834,100 @@ template <int M, bool LEAN = false> DS_HD void op_mcspp(const OpCtx& p, int b, i
             for (int f = 0; f < 2 * NO; ++f) vo[f] = yo[f];
             q = 0.99f;
         }
-        // estimation_core :201-242
-        cf Pyy[M][M], A[M][M], inv[M][M];
-        herm_unpack<M>(yd, yo, Pyy);
-        herm_unpack<M>(vd, vo, A);
+        // estimation_core :201-242 — in double like the reference's complex128 (ds_linalg64.hpp): inv(Phi_vv + dv I) of nearly rank-one
+        // matrices and the cancellation Phi_yy - Phi_vv are conditioning-limited; the carried state stays fp32
+        cd Pyy[M][M], A[M][M], inv[M][M], Zd[M];
+        herm_unpack_d<M>(yd, yo, Pyy);
+        herm_unpack_d<M>(vd, vo, A);
 #pragma unroll
-        for (int i = 0; i < M; ++i) A[i][i].x += dv;
-        herm_inverse<M>(A, inv);
-        float tr = 0.0f;
+        for (int m = 0; m < M; ++m) Zd[m] = to_cd(Z[m]);
+        cd Pxx[M][M];                                                              // Phi_xx = Phi_yy - Phi_vv (:212; exact in double)
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
-            for (int j = 0; j < M; ++j) tr = fma_(inv[i][j].x, Pyy[i][j].x, fma_(inv[i][j].y, Pyy[i][j].y, tr));   // Re(inv_ij Pyy_ji)
-        if (tr - (float)M < 0.0f) {                                                // :219-228
+            for (int j = 0; j < M; ++j) Pxx[i][j] = cdsub(Pyy[i][j], A[i][j]);
+        const double dvd = (double)dv;
+#pragma unroll
+        for (int i = 0; i < M; ++i) A[i][i].x += dvd;
+        herm_inverse_d<M>(A, inv);
+        double tr = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i)
+#pragma unroll
+            for (int j = 0; j < M; ++j) tr = fmad_(inv[i][j].x, Pyy[i][j].x, fmad_(inv[i][j].y, Pyy[i][j].y, tr));   // Re(inv_ij Pyy_ji)
+        if (tr - (double)M < 0.0) {                                                // :219-228
 #pragma unroll
             for (int i = 0; i < M; ++i)
 #pragma unroll
                 for (int j = 0; j < M; ++j) A[i][j] = Pyy[i][j];
             if (frm < 5) {
 #pragma unroll
-                for (int i = 0; i < M; ++i) A[i][i].x += dv;
+                for (int i = 0; i < M; ++i) A[i][i].x += dvd;
             }
-            herm_inverse<M>(A, inv);
-            tr = 0.0f;
+            herm_inverse_d<M>(A, inv);
+            tr = 0.0;
 #pragma unroll
             for (int i = 0; i < M; ++i)
 #pragma unroll
-                for (int j = 0; j < M; ++j) tr = fma_(inv[i][j].x, Pyy[i][j].x, fma_(inv[i][j].y, Pyy[i][j].y, tr));
+                for (int j = 0; j < M; ++j) tr = fmad_(inv[i][j].x, Pyy[i][j].x, fmad_(inv[i][j].y, Pyy[i][j].y, tr));
         }
-        xi = fminf_(fmaxf_(tr - (float)M, 1e-6f), 1e8f);                           // :230
-        cf v[M];
-        float yv = 0.0f;
+        const double xid = dmin_(dmax_(tr - (double)M, 1e-6), 1e8);                  // :230
+        cd v[M];
+        double yv = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            cf acc = mk(0.0f, 0.0f);
+            cd acc = mkd(0.0, 0.0);
 #pragma unroll
-            for (int j = 0; j < M; ++j) acc = cfma(acc, inv[i][j], Z[j]);
+            for (int j = 0; j < M; ++j) acc = cdfma(acc, inv[i][j], Zd[j]);
             v[i] = acc;
-            yv = fma_(Z[i].x, acc.x, fma_(Z[i].y, acc.y, yv));                      // Re(conj(y_i) v_i)
+            yv = fmad_(Zd[i].x, acc.x, fmad_(Zd[i].y, acc.y, yv));                  // Re(conj(y_i) v_i)
         }
-        float vPv = 0.0f;
+        double vPv = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            cf acc = mk(0.0f, 0.0f);
+            cd acc = mkd(0.0, 0.0);
 #pragma unroll
-            for (int j = 0; j < M; ++j) acc = cfma(acc, Pyy[i][j], v[j]);
-            vPv = fma_(v[i].x, acc.x, fma_(v[i].y, acc.y, vPv));                    // Re(conj(v_i) (Pyy v)_i)
+            for (int j = 0; j < M; ++j) acc = cdfma(acc, Pyy[i][j], v[j]);
+            vPv = fmad_(v[i].x, acc.x, fmad_(v[i].y, acc.y, vPv));                  // Re(conj(v_i) (Pyy v)_i)
         }
-        gam = fminf_(fmaxf_(vPv - yv, 1e-6f), 1e8f);                               // :232-236
-        pp = 1.0f / (1.0f + q / (1.0f - q) * (1.0f + xi) * expf(-1.0f * (gam / (1.0f + xi))));   // compute_p :75-92
-        pp = fminf_(fmaxf_(pp, 0.0f), 1.0f);
-        // Phi_xx = Phi_yy - Phi_vv (before the noise update)
-        cf Pxx[M][M];
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-#pragma unroll
-            for (int j = 0; j < M; ++j) Pxx[i][j] = csub(Pyy[i][j], herm_get<M>(vd, vo, i, j));
-        // update_noise_psd (alpha_d = 0.92)
+        const double gamd = dmin_(dmax_(vPv - yv, 1e-6), 1e8);                       // :232-236
+        const double qd = (double)q;
+        double ppd = 1.0 / (1.0 + qd / (1.0 - qd) * (1.0 + xid) * exp(-1.0 * (gamd / (1.0 + xid))));   // compute_p :75-92
+        ppd = dmin_(dmax_(ppd, 0.0), 1.0);
+        xi = (float)xid; gam = (float)gamd; pp = (float)ppd;
+        // update_noise_psd (alpha_d = 0.92) on the fp32 state
         const float at = fma_((float)(1.0 - 0.92), pp, 0.92f);
         herm_rank1<M>(vd, vo, Z, at, 1.0f - at);
         const long long ob = fb + k;
         p.out0[ob] = pp;
-        const float wsc = 1.0f / (10.0f + xi);                                     // compute_pmwf_weight beta = 10 :283
+        const double wsc = 1.0 / (10.0 + xid);                                     // compute_pmwf_weight beta = 10 :283
         if (p.out1) {
 #pragma unroll
             for (int i = 0; i < M; ++i) {
-                cf acc = mk(0.0f, 0.0f);
+                cd acc = mkd(0.0, 0.0);
 #pragma unroll
-                for (int j = 0; j < M; ++j) acc = cfma(acc, inv[i][j], Pxx[j][0]);
-                p.out1[2 * (ob * M + i)] = acc.x * wsc; p.out1[2 * (ob * M + i) + 1] = acc.y * wsc;
+                for (int j = 0; j < M; ++j) acc = cdfma(acc, inv[i][j], Pxx[j][0]);
+                p.out1[2 * (ob * M + i)] = (float)(acc.x * wsc); p.out1[2 * (ob * M + i) + 1] = (float)(acc.y * wsc);
             }
         }
-        if constexpr (!LEAN) {
         if (p.out3) {
 #pragma unroll
             for (int i = 0; i < M; ++i)
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
                     const long long q2 = 2 * ((ob * M + i) * M + j);
-                    p.out3[q2] = Pxx[i][j].x; p.out3[q2 + 1] = Pxx[i][j].y;
-                    p.out4[q2] = inv[i][j].x; p.out4[q2 + 1] = inv[i][j].y;
+                    p.out3[q2] = (float)Pxx[i][j].x; p.out3[q2 + 1] = (float)Pxx[i][j].y;
+                    p.out4[q2] = (float)inv[i][j].x; p.out4[q2 + 1] = (float)inv[i][j].y;
                 }
         }
         if (p.out2) {                                                              // mvdr.ipynb cell 4
-            cf sv[M], w[M];
-            herm_principal<M>(Pxx, sv);
-            mvdr_weight<M>(inv, sv, w);
-            cf Y = mk(0.0f, 0.0f);
+            cd sv[M], w[M];
+            herm_principal_d<M>(Pxx, sv);
+            mvdr_weight_d<M>(inv, sv, w);
+            cd Y = mkd(0.0, 0.0);
 #pragma unroll
-            for (int m = 0; m < M; ++m) Y = cfmac(Y, Z[m], w[m]);
-            p.out2[2 * ob] = Y.x; p.out2[2 * ob + 1] = Y.y;
-        }
+            for (int m = 0; m < M; ++m) Y = cdfmac(Y, Zd[m], w[m]);
+            p.out2[2 * ob] = (float)Y.x; p.out2[2 * ob + 1] = (float)Y.y;
         }
         frm += 1;
     }
@@ -1176,37 +1061,37 @@ template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, i
 
 // stateless: steering(XXs) — in0 = XX complex [B][K][M][M] -> out0 = v complex [B][K][M]
 template <int M> DS_HD void op_steering(const OpCtx& p, int b, int k) {
-    cf A[M][M], v[M];
+    cd A[M][M], v[M];
     const long long base = ((long long)b * p.K + k) * M * M;
 #pragma unroll
     for (int i = 0; i < M; ++i)
 #pragma unroll
-        for (int j = 0; j < M; ++j) A[i][j] = mk(p.in0[2 * (base + i * M + j)], p.in0[2 * (base + i * M + j) + 1]);
+        for (int j = 0; j < M; ++j) A[i][j] = mkd((double)p.in0[2 * (base + i * M + j)], (double)p.in0[2 * (base + i * M + j) + 1]);
 #pragma unroll
     for (int i = 0; i < M; ++i) {                        // eigh reads one triangle: use the lower one like LAPACK 'L'
-        A[i][i].y = 0.0f;
+        A[i][i].y = 0.0;
 #pragma unroll
-        for (int j = i + 1; j < M; ++j) A[i][j] = cconj(A[j][i]);
+        for (int j = i + 1; j < M; ++j) A[i][j] = cdconj(A[j][i]);
     }
-    herm_principal<M>(A, v);
+    herm_principal_d<M>(A, v);                           // in double: the eigenvector of a nearly degenerate pair is conditioning-limited
     const long long ob = ((long long)b * p.K + k) * M;
 #pragma unroll
-    for (int m = 0; m < M; ++m) { p.out0[2 * (ob + m)] = v[m].x; p.out0[2 * (ob + m) + 1] = v[m].y; }
+    for (int m = 0; m < M; ++m) { p.out0[2 * (ob + m)] = (float)v[m].x; p.out0[2 * (ob + m) + 1] = (float)v[m].y; }
 }
 
 // stateless: compute_mvdr_weight — in0 = steer complex [B][K][M], in1 = Rvv_inv complex [B][K][M][M] -> out0 = w [B][K][M]
 template <int M> DS_HD void op_mvdrw(const OpCtx& p, int b, int k) {
-    cf R[M][M], a[M], w[M];
+    cd R[M][M], a[M], w[M];
     const long long rb = ((long long)b * p.K + k) * M * M, ab = ((long long)b * p.K + k) * M;
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-        a[i] = mk(p.in0[2 * (ab + i)], p.in0[2 * (ab + i) + 1]);
+        a[i] = mkd((double)p.in0[2 * (ab + i)], (double)p.in0[2 * (ab + i) + 1]);
 #pragma unroll
-        for (int j = 0; j < M; ++j) R[i][j] = mk(p.in1[2 * (rb + i * M + j)], p.in1[2 * (rb + i * M + j) + 1]);
+        for (int j = 0; j < M; ++j) R[i][j] = mkd((double)p.in1[2 * (rb + i * M + j)], (double)p.in1[2 * (rb + i * M + j) + 1]);
     }
-    mvdr_weight<M>(R, a, w);
+    mvdr_weight_d<M>(R, a, w);
 #pragma unroll
-    for (int m = 0; m < M; ++m) { p.out0[2 * (ab + m)] = w[m].x; p.out0[2 * (ab + m) + 1] = w[m].y; }
+    for (int m = 0; m < M; ++m) { p.out0[2 * (ab + m)] = (float)w[m].x; p.out0[2 * (ab + m) + 1] = (float)w[m].y; }
 }
 
 // dispatch one (b, k) of an operator; OP and (for the matrix operators) M are compile-time so every operator

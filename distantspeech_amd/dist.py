@@ -51,14 +51,38 @@ def barrier():
             dist.barrier()
 
 
-def reduce_throughput(frames, elapsed_s, device=None):
-    """(total frames over ranks, max elapsed over ranks): the one collective of the job."""
-    import torch
+def _group():
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return int(frames), float(elapsed_s)
-    f = torch.tensor([float(frames)], dtype=torch.float64, device=device)
-    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def reduce_throughput(frames, elapsed_s, device=None):
+    """(total frames over ranks, max elapsed over ranks, ranks that contributed): the one collective of the job."""
+    dist = _group()
+    if dist is None:
+        return int(frames), float(elapsed_s), 1
+    import torch
+    dev = device if dist.get_backend() == "nccl" else None
+    f = torch.tensor([float(frames), 1.0], dtype=torch.float64, device=dev)
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=dev)
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return int(round(f.item())), float(t.item())
+    return int(round(f[0].item())), float(t.item()), int(round(f[1].item()))
+
+
+def reduce_max(value, device=None):
+    """MAX of a scalar over ranks (set-up decisions that every rank must take alike, and device timings)."""
+    dist = _group()
+    if dist is None:
+        return float(value)
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else None)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def finalize():
+    dist = _group()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()

@@ -1,0 +1,64 @@
+"""`bench.py --gpus N` starts its N ranks itself: end-to-end under gloo with the stub backend of
+tests/bench_stub.py — the one JSON line carries n_gpus = N and the frames of every rank; a rank-count mismatch exits non-zero."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(args, env_extra=None, timeout=300):
+    env = dict(os.environ, DS_BENCH_BACKEND="tests.bench_stub:StubBackend", PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_self_launch_two_ranks(tmp_path):
+    log = str(tmp_path / "steps")
+    r = run_bench(["--gpus", "2", "--steps", "20", "--warmup", "5", "--min-region-ms", "30"], {"DS_BENCH_STUB_LOG": log})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # rank 0 only, ONE line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["scaling"] == "weak"
+    assert out["data"].startswith("stub")
+    R = out["rounds"]
+    assert out["timed_steps"] == 20 * R and out["region_ms"] >= 30 * 0.8
+    # whole-job value: both ranks' frames over the slowest rank's region
+    frames = 2 * 1024 * 20 * R
+    assert abs(out["value"] - frames / (out["region_ms"] * 1e-3)) / out["value"] < 1e-3
+    assert abs(out["ms_per_step"] - out["region_ms"] / (20 * R)) < 1e-3
+    assert set(out["other_configs"]) == {"cfg3", "cfg4", "cfg5"} and all(v["n_gpus"] == 2 for v in out["other_configs"].values())
+    assert out["roofline"]["bound"] == "hbm" and out["roofline_hbm"]["batch_per_gpu"] == 16384
+    # both ranks ran the same step sequence (warm-up + graph-build round + probe + R rounds for the headline)
+    per_rank = [open("%s.%d" % (log, k)).read().split() for k in range(2)]
+    assert per_rank[0] == per_rank[1] and int(per_rank[0][0]) == 5 + 20 + 20 + 20 * R
+
+
+def test_single_rank_default_path():
+    r = run_bench(["--steps", "10", "--warmup", "2", "--min-region-ms", "10", "--no-extras"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and "other_configs" not in out and "cpu_baseline" not in out
+
+
+def test_rank_count_mismatch_is_an_error():
+    # launched as ONE rank (as torchrun would with nproc-per-node 1) but asked for 8 GPUs: must not bench one GPU and call it eight
+    r = run_bench(["--gpus", "8", "--steps", "5", "--warmup", "1"], {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert r.returncode != 0 and "--gpus 8" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_torchrun_style_launch(tmp_path):
+    # the other launch form of the contract: ranks started by torch.distributed.run
+    env = dict(os.environ, DS_BENCH_BACKEND="tests.bench_stub:StubBackend", PYTHONPATH=ROOT)
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
+                        "--min-region-ms", "10", "--no-extras"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2

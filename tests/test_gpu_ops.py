@@ -216,10 +216,12 @@ def test_mcspp_notebook_flow(ds, name):
         if n % 16 == 0 or n == T - 1:                             # the three separate calls of the notebook
             w = compute_mvdr_weight(ds.steering(est.Phi_xx), est.Phi_vv_inv)
             Ys[n] = np.einsum("ij,ij->i", w.conj(), D[:, n, :])
-            assert np.max(np.abs(Ys[n] - Yf[n])) < 1e-3 * (np.max(np.abs(Yf[n])) + 1e-6)
-    assert np.median(np.abs(p - g["p"])) < 1e-3 and np.mean(np.abs(p - g["p"]) > 0.05) < 0.05
+            assert np.max(np.abs(Ys[n] - Yf[n])) < 1e-3 * (np.max(np.abs(Yf[n])) + 1e-6)    # the separate calls pass complex64 matrices
+    assert np.median(np.abs(p - g["p"])) < 1e-6 and np.max(np.abs(p - g["p"])) < 5e-3
     y = tr.istft(Yf.T[:, :, None])
-    assert rms(y - g["y"]) < 5e-2 * rms(g["y"])
+    err = rms(y - g["y"])
+    print("G11 %s: notebook MVDR output rms error %.3e (signal rms %.3e), p max error %.2e" % (name, err, rms(g["y"]), np.max(np.abs(p - g["p"]))))
+    assert err < 1e-4                    # north star: 1e-4 RMS absolute.  CPU emulation of the same program: 2.7e-6 (rec1), 3.0e-5 (synth_m6)
     assert est.Phi_xx.shape == g["Phi_xx"].shape and est.Phi_vv_inv.shape == g["Phi_vv_inv"].shape
     assert est.w.shape == (nfft // 2 + 1, M)
 
@@ -234,9 +236,9 @@ def test_steering_and_mvdr_weight_random(ds):
         XX = Bm @ np.conj(np.swapaxes(Bm, 1, 2)) - 0.3 * np.eye(M)
         v = ds.steering(XX)
         ref = O.steering(XX)
-        assert np.max(np.abs(v - ref)) < 5e-4
+        assert np.max(np.abs(v - ref)) < 1e-6           # double inside, complex64 in / out
         Rinv = np.linalg.inv(Bm @ np.conj(np.swapaxes(Bm, 1, 2)) + np.eye(M))
-        assert np.max(np.abs(compute_mvdr_weight(ref, Rinv) - O.compute_mvdr_weight(ref, Rinv))) < 1e-4
+        assert np.max(np.abs(compute_mvdr_weight(ref, Rinv) - O.compute_mvdr_weight(ref, Rinv))) < 5e-6
 
 
 @pytest.mark.parametrize("kind", ["rls", "lms"])

@@ -220,11 +220,12 @@ def test_emul_mcspp_notebook_mvdr(name):
     op = EmulOp("mcspp", nfft, M=M)
     p, w, yout, pxx, pinv = op.run_mcspp(D, Fn, want_matrices=True)
     assert np.all(np.isfinite(p)) and np.all(np.isfinite(yout))
-    assert np.median(np.abs(p[0] - g["p"])) < 1e-3 and np.mean(np.abs(p[0] - g["p"]) > 0.05) < 0.05
-    # enhanced signal through the ISTFT: 1e-4 RMS bar of the north star is for well-conditioned paths; the eigenvector
-    # MVDR is conditioning-limited in fp32, so compare relative to the signal level
+    assert np.median(np.abs(p[0] - g["p"])) < 1e-6 and np.max(np.abs(p[0] - g["p"])) < 5e-3      # measured: max 1.1e-4 / 7.7e-4
+    # enhanced signal through the ISTFT against the north star's 1e-4 RMS (absolute; the signal's RMS is 0.15): the estimation core,
+    # the eigenvector and the weights run in double on the fp32 state (ds_linalg64.hpp).  Measured 2.7e-6 (rec1), 3.0e-5 (synth_m6:
+    # three bins whose fp32-rounded covariances differ from the reference's doubles; 7.7e-4 / 7.2e-5 with fp32 arithmetic)
     y = tf.istft(np.ascontiguousarray(yout[..., None]))[0, :, 0]
-    assert rms(y - g["y"]) < 5e-2 * rms(g["y"])
+    assert rms(y - g["y"]) < 1e-4
     ref = g["Phi_xx"]
     rel = np.abs(pxx[0, -1] - ref).sum(axis=(1, 2)) / (np.abs(ref).sum(axis=(1, 2)) + 1e-30)
     assert np.median(rel) < 1e-2
@@ -262,12 +263,12 @@ def test_emul_steering_and_mvdr_weight():
         o = EmulOp("steering", 64, M=M)
         vv = o.run(XX[None, None].astype(np.complex64).reshape(1, 1, K, M * M), out_shapes=[((M,), np.complex64)])[0][0, 0]
         ref = O.steering(XX)
-        assert np.max(np.abs(vv - ref)) < 2e-4
+        assert np.max(np.abs(vv - ref)) < 1e-6          # double inside, complex64 in / out (measured 3e-8 ... 1.1e-7)
         Rinv = np.linalg.inv(Bm @ np.conj(np.swapaxes(Bm, 1, 2)) + np.eye(M))
         o2 = EmulOp("mvdrw", 64, M=M)
         ww = o2.run(ref[None, None].astype(np.complex64), Rinv[None, None].astype(np.complex64).reshape(1, 1, K, M * M),
                     out_shapes=[((M,), np.complex64)])[0][0, 0]
-        assert np.max(np.abs(ww - O.compute_mvdr_weight(ref, Rinv))) < 1e-4
+        assert np.max(np.abs(ww - O.compute_mvdr_weight(ref, Rinv))) < 5e-6    # measured 2e-7 ... 7e-7
 
 
 def test_emul_frontend_ops():
