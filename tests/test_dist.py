@@ -28,10 +28,10 @@ def _worker(rank, world, port, q):
     r, lr, w = d.init(backend="gloo")
     lo, hi = d.shard_range(1025, r, w)
     d.barrier()
-    frames, t = d.reduce_throughput((hi - lo) * 10, 1.0 + r)      # rank 1 is "slower"
+    frames, t, ranks = d.reduce_throughput((hi - lo) * 10, 1.0 + r)      # rank 1 is "slower"
+    assert ranks == w and d.reduce_max(3.0 + r) == 4.0
     q.put((r, lo, hi, frames, t))
-    import torch.distributed as dist
-    dist.destroy_process_group()
+    d.finalize()
 
 
 def test_gloo_world2_reduce():
