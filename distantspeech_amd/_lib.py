@@ -18,6 +18,7 @@ ALGO_WPE_MVDR = 18
 ALGO_SUBBAND_GSC = 19
 CHAIN_AUX_FIR, CHAIN_AUX_COHERENCE = 0, 1
 PARAM_WPE_DELAY = 13
+PARAM_MCSPP_REPEAT = 14
 FDAF_PLAIN, FDAF_BM, FDAF_AIC = 0, 1, 2
 FDAF_P_NONE, FDAF_P_BLOCK, FDAF_P_BIN = 0, 1, 2
 FDAF_P_COMPLEMENT = 4

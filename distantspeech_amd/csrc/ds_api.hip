@@ -107,6 +107,8 @@ void fill_params(const ds_handle* h, Params& p) {
     p.out_scale = h->out_scale;
     p.alpha_y = h->alpha_y;
     p.alpha_v = h->alpha_v;
+    p.beta_y = ds::complement_of(h->alpha_y);
+    p.beta_v = ds::complement_of(h->alpha_v);
     p.diag = h->diag;
     p.gate = h->gate;
     p.mu = h->mu;
@@ -260,6 +262,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     for (int i = 0; i < 10; ++i) { h->dev_buf[i] = nullptr; h->dev_buf_bytes[i] = 0; }
     h->aux_floats = 0;
     h->tdf_w = h->tdf_buf = h->tdf_P = nullptr;
+    h->mcspp_repeat = 0;
     h->x_fan = 1; h->p_complement = 0; h->d_interleaved = 0; h->d_prev = nullptr;
     h->fdaf_kind = DS_FDAF_PLAIN; h->fdaf_constrain = 1; h->fdaf_non_causal = 0; h->fdaf_weight_norm = 0;
     for (int i = 0; i < 10; ++i) h->sub[i] = nullptr;
@@ -462,6 +465,10 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
         case DS_PARAM_FDAF_CONSTRAIN: h->fdaf_constrain = value != 0; return DS_OK;
         case DS_PARAM_FDAF_NON_CAUSAL: h->fdaf_non_causal = value != 0; return DS_OK;
         case DS_PARAM_FDAF_WEIGHT_NORM: h->fdaf_weight_norm = value != 0; return DS_OK;
+        case DS_PARAM_MCSPP_REPEAT:
+            if (h->cfg.algo != DS_ALGO_MCSPP) return fail(h, DS_EINVAL, "mcspp repeat: DS_ALGO_MCSPP handles only");
+            h->mcspp_repeat = value != 0;
+            return DS_OK;
         case DS_PARAM_SPLIT:
             if (value < 1 || value > 8) return fail(h, DS_EINVAL, "split must be 1..8");
             h->split = value; h->graph_valid = false;

@@ -80,7 +80,7 @@ int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int me
     p.mu = h->filt_mu; p.alpha = h->filt_alpha; p.reg = 1e-4f; p.lam = h->rls_lambda;
     p.x_fan = h->x_fan > 0 ? h->x_fan : 1; p.p_complement = h->p_complement; p.d_interleaved = h->d_interleaved; p.d_prev = h->d_prev;
     p.steer = h->steer; p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
-    p.method = h->method; p.alpha_v = h->alpha_v; p.gate = h->gate; p.diag = h->diag;
+    p.method = h->method; p.alpha_v = h->alpha_v; p.beta_v = ds::complement_of(h->alpha_v); p.gate = h->gate; p.diag = h->diag;
     DS_HIP(h, ds::launch_binop(h->op, p, h->stream));
     // advance the uniform counters exactly like the kernel did (mcra.py:52-56,72-74)
     for (int t = 0; t < n_frames; ++t) {
@@ -226,7 +226,8 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, 
     p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
     // three builds of the same estimation: with the notebook-MVDR / matrix outputs, lean (p and the optional PMWF weights), and the lean
     // one for calls that start at frame 5 or later without weights (no second factorisation in the kernel: two waves per SIMD at 6 mics)
-    const int op = (yout || phi_xx) ? ds::OP_MCSPP : (w_pmwf || h->op_frm < 5) ? ds::OP_MCSPP_LEAN : ds::OP_MCSPP_STEADY;
+    p.repeat = h->mcspp_repeat;
+    const int op = (yout || phi_xx || p.repeat) ? ds::OP_MCSPP : (w_pmwf || h->op_frm < 5) ? ds::OP_MCSPP_LEAN : ds::OP_MCSPP_STEADY;
     DS_HIP(h, ds::launch_binop(op, p, h->stream));
     for (int t = 0; t < n_frames; ++t) {
         if (h->op_frm != 0 && h->op_ell % 65 == 0) h->op_ell = 0;

@@ -84,6 +84,18 @@ DS_HD cf cdiv(cf a, cf b) {
     return mk(n.x * d, n.y * d);
 }
 
+// 1 - a for a smoothing constant given as a float: the complement is taken in double of the shortest decimal that rounds to `a`
+// (0.9998f stands for 0.9998, whose complement is 2e-4; 1.0f - 0.9998f = 1.99974e-4 scales a covariance recursion by 1 - 1.3e-4).
+// Host-side set-up helper (fill_params and the emulator's entry points).
+inline float complement_of(float a) {
+    const double d = (double)a;
+    for (double scale = 1e1; scale <= 1e8; scale *= 10.0) {
+        const double r = (double)(long long)(d * scale + 0.5) / scale;
+        if ((float)r == a) return (float)(1.0 - r);
+    }
+    return (float)(1.0 - d);
+}
+
 DS_HD float fminf_(float a, float b) { return a < b ? a : b; }
 DS_HD float fmaxf_(float a, float b) { return a > b ? a : b; }
 
@@ -113,6 +125,7 @@ struct Params {
     int mcra_L;               // MCRA minimum-search window (mcra.py:25)
     float out_scale;          // hop / W0 (transform.py:479)
     float alpha_y, alpha_v;   // adaptivebeamformer.py:65-66
+    float beta_y, beta_v;     // 1 - alpha as the reference's doubles give it (complement_of(): 1 - 0.9998f in fp32 is off by 1.3e-4 relative)
     float diag;               // adaptivebeamformer.py:89
     float gate;               // adaptivebeamformer.py:94
     float mu;                 // GSC.py:202
@@ -430,8 +443,8 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
     typedef StateLayout<M, ALGO_ADAPTIVE, RYY> SL;
     float* d = st + SL::R_DIAG;
     float* o = st + SL::R_OFF;
-    if (RYY) herm_rank1<M>(st + SL::RYY_DIAG, st + SL::RYY_OFF, Z, p.alpha_y, 1.0f - p.alpha_y);      // :86-88
-    if (st[SL::MC_S + 3] < p.gate) herm_rank1<M>(d, o, Z, p.alpha_v, 1.0f - p.alpha_v);               // :94-99
+    if (RYY) herm_rank1<M>(st + SL::RYY_DIAG, st + SL::RYY_OFF, Z, p.alpha_y, p.beta_y);      // :86-88
+    if (st[SL::MC_S + 3] < p.gate) herm_rank1<M>(d, o, Z, p.alpha_v, p.beta_v);               // :94-99
     cf acc = mk(0.0f, 0.0f);
     if (p.method == METHOD_SRC) {                              // beamformer.py:320-322
         acc = cmulc(Z[0], a[0]);

@@ -50,6 +50,8 @@ struct OpParams {
     long long steer_batch_stride;
     int method;               // OP_ADAPTIVE: METHOD_SRC / DS / MVDR
     float alpha_v, gate, diag;   // OP_ADAPTIVE: adaptivebeamformer.py:66,94,89
+    float beta_v;             // OP_ADAPTIVE: 1 - alpha_v (complement_of)
+    int repeat;               // McSpp: estimation(repeat=True), a second estimation_core after the noise update (mcspp.py:280-282)
     float* spill;             // lean McSpp at 6 microphones: per-lane parking space (LDS on the GPU) for Phi_vv while the solves run; element f of
     int spill_stride;         // this lane at spill[f * spill_stride]; null = keep everything in registers
 };
@@ -836,12 +838,18 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
         }
         // estimation_core :201-242 — in double like the reference's complex128 (ds_linalg64.hpp): inv(Phi_vv + dv I) of nearly rank-one
         // matrices and the cancellation Phi_yy - Phi_vv are conditioning-limited; the carried state stays fp32
-        cd Pyy[M][M], A[M][M], inv[M][M], Zd[M];
+        cd Pyy[M][M], inv[M][M], Zd[M], Pxx[M][M];
         herm_unpack_d<M>(yd, yo, Pyy);
-        herm_unpack_d<M>(vd, vo, A);
 #pragma unroll
         for (int m = 0; m < M; ++m) Zd[m] = to_cd(Z[m]);
-        cd Pxx[M][M];                                                              // Phi_xx = Phi_yy - Phi_vv (:212; exact in double)
+        double xid = 0.0;
+        for (int pass = 0; pass < (p.repeat ? 2 : 1); ++pass) {
+        if (pass == 1) {                                                           // update_noise_psd (alpha_d = 0.92) on the fp32 state, then the
+            const float at1 = fma_((float)(1.0 - 0.92), pp, 0.92f);                // second estimation_core of repeat=True (:280-282)
+            herm_rank1<M>(vd, vo, Z, at1, 1.0f - at1);
+        }
+        cd A[M][M];
+        herm_unpack_d<M>(vd, vo, A);                                                              // Phi_xx = Phi_yy - Phi_vv (:212; exact in double)
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
@@ -871,7 +879,7 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
 #pragma unroll
                 for (int j = 0; j < M; ++j) tr = fmad_(inv[i][j].x, Pyy[i][j].x, fmad_(inv[i][j].y, Pyy[i][j].y, tr));
         }
-        const double xid = dmin_(dmax_(tr - (double)M, 1e-6), 1e8);                  // :230
+        xid = dmin_(dmax_(tr - (double)M, 1e-6), 1e8);                  // :230
         cd v[M];
         double yv = 0.0;
 #pragma unroll
@@ -895,9 +903,11 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
         double ppd = 1.0 / (1.0 + qd / (1.0 - qd) * (1.0 + xid) * exp(-1.0 * (gamd / (1.0 + xid))));   // compute_p :75-92
         ppd = dmin_(dmax_(ppd, 0.0), 1.0);
         xi = (float)xid; gam = (float)gamd; pp = (float)ppd;
-        // update_noise_psd (alpha_d = 0.92) on the fp32 state
-        const float at = fma_((float)(1.0 - 0.92), pp, 0.92f);
-        herm_rank1<M>(vd, vo, Z, at, 1.0f - at);
+        }
+        if (!p.repeat) {                                                           // update_noise_psd (alpha_d = 0.92) on the fp32 state
+            const float at = fma_((float)(1.0 - 0.92), pp, 0.92f);
+            herm_rank1<M>(vd, vo, Z, at, 1.0f - at);
+        }
         const long long ob = fb + k;
         p.out0[ob] = pp;
         const double wsc = 1.0 / (10.0 + xid);                                     // compute_pmwf_weight beta = 10 :283
@@ -1112,7 +1122,7 @@ template <int M> DS_HD void op_adaptive(const OpCtx& p, int b, int k) {
 #pragma unroll
     for (int m = 0; m < M; ++m) a[m] = sv[m];
     Params q;
-    q.method = p.method; q.alpha_y = 0.8f; q.alpha_v = p.alpha_v; q.gate = p.gate; q.diag = p.diag;
+    q.method = p.method; q.alpha_y = 0.8f; q.beta_y = (float)(1.0 - 0.8); q.alpha_v = p.alpha_v; q.beta_v = p.beta_v; q.gate = p.gate; q.diag = p.diag;
     int frm = p.frm_cnt, ell = p.ell;
     for (int t = 0; t < p.T; ++t) {
         const long long fb = ((long long)b * p.T + t) * p.K;

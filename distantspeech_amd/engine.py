@@ -58,6 +58,10 @@ class BatchEngine:
         """prediction delay (frames) of a DS_ALGO_WPE_MVDR chain handle; before the first call."""
         L.check(self._lib.ds_set_param_i(self._h, L.PARAM_WPE_DELAY, int(frames)), self._h)
 
+    def set_mcspp_repeat(self, on):
+        """McSpp handles: estimation(repeat=True), a second estimation_core after the noise update (mcspp.py:280-282)."""
+        L.check(self._lib.ds_set_param_i(self._h, L.PARAM_MCSPP_REPEAT, int(bool(on))), self._h)
+
     def set_mcra_L(self, value):
         L.check(self._lib.ds_set_param_i(self._h, L.PARAM_MCRA_L, int(value)), self._h)
 

@@ -232,13 +232,15 @@ class McSpp(_Base):
         if mic_array is not None:
             self.steer_vector = mic_array.steering_vector(look_direction=30).T          # mcspp.py:64-66
         self._last = None
+        self._repeat = False
         self._o = 9 + 2 * channels * channels
         self.frm_cnt = 0
 
     def estimation(self, y, diag_value=1e-4, repeat=False):
         """y complex [half_bin, channels] -> p [half_bin]."""
-        if repeat:
-            raise NotImplementedError("repeat=True (a second estimation_core pass) is not built")
+        if bool(repeat) != self._repeat:                                     # mcspp.py:280-282: a second estimation_core after the noise update
+            self._repeat = bool(repeat)
+            self._eng.set_mcspp_repeat(self._repeat)
         y = self._add_batch(y, 2)
         self._last = self._eng.mcspp_estimate(y[:, None, :, :], want_yout=True, want_matrices=True)
         self.frm_cnt += 1

@@ -145,6 +145,7 @@ typedef struct ds_config {
 #define DS_PARAM_FDAF_NON_CAUSAL 11  /* int 0/1: delay the desired signal by filter_len / 2 (FastFreqLms.py:84-85,167-168); default 0 */
 #define DS_PARAM_FDAF_WEIGHT_NORM 12 /* int 0/1: norm limiter of the canceller (gsc_aic.py:81-88); default 0 */
 #define DS_PARAM_WPE_DELAY 13        /* int >= 0: prediction delay of the DS_ALGO_WPE_MVDR chain in frames (awpe.py:36, default 4); set before the first call */
+#define DS_PARAM_MCSPP_REPEAT 14     /* int 0/1: DS_ALGO_MCSPP handles run estimation(repeat=True): a second estimation_core after the noise update (mcspp.py:280-282); default 0 */
 #define DS_PARAM_SPLIT 8   /* int: utterance groups run as parallel hipGraph branches in ds_process_device_seq(graph=1); default 1 */
 
 /* ds_get_state fields; all arrays are float32, complex = interleaved (re, im) */

@@ -564,7 +564,7 @@ class OracleMcSpp:
         p = 1 / (1 + self.q / (1 - self.q) * (1 + self.xi) * np.exp(-1 * (self.gamma / (1 + self.xi))))   # compute_p
         self.p = np.minimum(np.maximum(p, 0.0), 1.0)
 
-    def estimation(self, y):
+    def estimation(self, y, repeat=False):
         M = self.M
         y = np.asarray(y, dtype=complex)
         self.q = 1 - self.mccdr.estimation(y)                                      # compute_q :113-116
@@ -580,6 +580,8 @@ class OracleMcSpp:
         self._core(y, diag_bin)
         at = (self.alpha_d + (1 - self.alpha_d) * self.p)[:, None, None]           # update_noise_psd
         self.Phi_vv = at * self.Phi_vv + (1 - at) * psd_yy
+        if repeat:                                                                 # :280-282
+            self._core(y, diag_bin)
         self.w = (self.Phi_vv_inv @ self.Phi_xx)[:, :, 0] / (10 + self.xi[:, None])    # compute_pmwf_weight beta=10 :283
         self.frm_cnt += 1
         return self.p

@@ -18,6 +18,25 @@ def rms(a):
     return float(np.sqrt(np.mean(np.abs(a) ** 2)))
 
 
+def measured(test, **values):
+    """Record the measured parity numbers of a GPU test (what the assertions bound): one JSON line per call appended to
+    $DS_PARITY_LOG (default gpurun_out/parity_measured.jsonl); the per-round copy is committed under profiles/."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.environ.get("DS_PARITY_LOG") or os.path.join(root, "gpurun_out", "parity_measured.jsonl")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as fh:
+            fh.write(json.dumps(dict(test=test, **{k: (float(v) if np.ndim(v) == 0 else [float(u) for u in v]) for k, v in values.items()})) + "\n")
+    except OSError:
+        pass
+
+
+def relmax(a, ref):
+    """max |a - ref| over max |ref|"""
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(ref))) / (np.max(np.abs(ref)) + 1e-300))
+
+
 def load(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 

@@ -165,6 +165,10 @@ int emul_istft(int nfft, int M, int batch, const float* Y, int T, int C, float* 
     return -1;
 }
 
+// OpParams fields outside emul_op's argument list (set before the call, sticky)
+static int g_repeat = 0;
+void emul_set_repeat(int on) { g_repeat = on; }
+
 // frame-level operators: serial loop over (b, k) of ds::run_op
 int emul_op(int op, int B, int K, int T, float* st, int NF, const float* in0, const float* in1, const float* in2, float* out0,
             float* out1, float* out2, float* out3, float* out4, int M, int N, int frm_cnt, int ell, int L, int first_frame, int in_complex, int has_p,
@@ -175,7 +179,7 @@ int emul_op(int op, int B, int K, int T, float* st, int NF, const float* in0, co
     p.in0 = in0; p.in1 = in1; p.in2 = in2; p.out0 = out0; p.out1 = out1; p.out2 = out2; p.out3 = out3; p.out4 = out4;
     p.M = M; p.N = N; p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.first_frame = first_frame;
     p.in_complex = in_complex; p.has_p = has_p; p.norm = norm; p.mu = mu; p.alpha = alpha; p.reg = reg; p.lam = lam;
-    p.x_fan = 1;
+    p.x_fan = 1; p.repeat = g_repeat;
     for (int b = 0; b < B; ++b)
         for (int k = 0; k < K; ++k) ds::run_op(op, p, b, k);
     return 0;
@@ -207,7 +211,7 @@ int emul_adaptive_frames(int B, int K, int T, int M, float* st, int NF, const fl
     p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = st; p.NF = NF; p.in0 = Z; p.in1 = gain; p.out0 = Y; p.M = M;
     p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.has_p = gain != nullptr;
     p.steer = reinterpret_cast<const ds::cf*>(steer); p.steer_batch_stride = 0;
-    p.method = method; p.alpha_v = alpha_v; p.gate = gate; p.diag = diag;
+    p.method = method; p.alpha_v = alpha_v; p.beta_v = ds::complement_of(alpha_v); p.gate = gate; p.diag = diag;
     if (!ds::op_supported(ds::OP_ADAPTIVE, M)) return -1;
     for (int b = 0; b < B; ++b)
         for (int k = 0; k < K; ++k) ds::run_op(ds::OP_ADAPTIVE, p, b, k);
@@ -255,7 +259,7 @@ int emul_run(int algo, int nfft, int M, int ryy, int batch, const float* x, int 
     p.steer_batch_stride = steer_per_utt ? (long long)K * M : 0;
     p.method = method;
     p.mcra_L = mcra_L;
-    p.alpha_y = alpha_y; p.alpha_v = alpha_v; p.diag = diag; p.gate = gate; p.mu = mu;
+    p.alpha_y = alpha_y; p.alpha_v = alpha_v; p.beta_y = ds::complement_of(alpha_y); p.beta_v = ds::complement_of(alpha_v); p.diag = diag; p.gate = gate; p.mu = mu;
     switch (nfft) {
         case 256: return run_n<256>(M, algo, ryy, p, batch);
         case 512: return run_n<512>(M, algo, ryy, p, batch);

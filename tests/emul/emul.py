@@ -159,7 +159,7 @@ class EmulOp:
             self.first = 0
         return outs
 
-    def run_mcspp(self, y, Fn, want_yout=True, want_matrices=False, variant=8):
+    def run_mcspp(self, y, Fn, want_yout=True, want_matrices=False, variant=8, repeat=False):
         """McSpp handle: McCDR pass (L = 65) then McSpp pass, like ds_mcspp_estimate().  variant: 8 = OP_MCSPP (all outputs),
         12 = OP_MCSPP_LEAN, 13 = OP_MCSPP_STEADY (p only)."""
         y = np.ascontiguousarray(y, dtype=np.complex64)
@@ -173,7 +173,11 @@ class EmulOp:
         shapes.append(((), np.complex64))
         if want_matrices:
             shapes += [((M, M), np.complex64), ((M, M), np.complex64)]
-        outs = self.run(y, gamma, out_shapes=shapes)
+        lib().emul_set_repeat(int(repeat))
+        try:
+            outs = self.run(y, gamma, out_shapes=shapes)
+        finally:
+            lib().emul_set_repeat(0)
         return outs
 
 

@@ -366,7 +366,8 @@ def g11_mcspp(x16):
     from DistantSpeech.noise_estimation.mccdr import McCDR
     from DistantSpeech.beamformer.beamformer import steering, compute_mvdr_weight
     x = x16.astype(np.float32) / 32768.0
-    for name, xx, M in (("rec1", x, 4), ("synth_m6", synth(81, 6, 256 * 70), 6)):
+    for name, xx, M in (("rec1", x, 4), ("synth_m6", synth(81, 6, 256 * 70), 6), ("rec1_repeat", x[:, : 256 * 100], 4)):
+        repeat = name.endswith("_repeat")                                                  # estimation(repeat=True), mcspp.py:280-282
         tr = Transform(n_fft=512, hop_length=256, channel=M)
         D = tr.stft(xx.T.astype(np.float64))
         with contextlib.redirect_stdout(io.StringIO()):
@@ -378,7 +379,7 @@ def g11_mcspp(x16):
         wp = np.zeros((T, 257, M), dtype=complex)
         with contextlib.redirect_stdout(io.StringIO()), np.errstate(all="ignore"):
             for n in range(T):
-                est.estimation(D[:, n, :])
+                est.estimation(D[:, n, :], repeat=repeat)
                 p[n], q[n], wp[n] = est.p, est.q, est.w
                 sv = steering(est.Phi_xx)
                 w = compute_mvdr_weight(sv, est.Phi_vv_inv)
@@ -386,8 +387,8 @@ def g11_mcspp(x16):
         y = tr.istft(Yout.T[:, :, None])
         save("g11_mcspp_%s" % name,
              "McSpp.estimation mcspp.py:244-305 + steering/compute_mvdr_weight beamformer.py:10-31,133-155 (mvdr.ipynb cell 4)"
-             + ("; R8 mccdr=McCDR(nfft, channels=M)" if M != 4 else ""),
-             x=(x16 if name == "rec1" else xx), p=p, q=q[::4], Yout=Yout.astype(np.complex64), y=y, w_pmwf=wp[::8].astype(np.complex64),
+             + ("; R8 mccdr=McCDR(nfft, channels=M)" if M != 4 else "") + ("; repeat=True" if repeat else ""),
+             x=(x16 if name == "rec1" else x16[:, : 256 * 100] if repeat else xx), p=p, q=q[::4], Yout=Yout.astype(np.complex64), y=y, w_pmwf=wp[::8].astype(np.complex64),
              steer_last=sv, w_last=w, Phi_xx=est.Phi_xx, Phi_vv_inv=est.Phi_vv_inv, Phi_vv=est.Phi_vv, params=np.array([M, 512, 256]))
 
 

@@ -207,7 +207,7 @@ def test_emul_wpe_golden(name):
     assert rms(y - g["y"]) < 2e-4 * max(rms(g["y"]), 1e-3)
 
 
-@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+@pytest.mark.parametrize("name", ["rec1", "synth_m6", "rec1_repeat"])
 def test_emul_mcspp_notebook_mvdr(name):
     """McSpp (McCDR prior) + steering + compute_mvdr_weight, the notebook's online MVDR (example/mvdr.ipynb cell 4)."""
     from oracle import ds_oracle as O
@@ -218,7 +218,7 @@ def test_emul_mcspp_notebook_mvdr(name):
     D = tf.stft(np.ascontiguousarray(x.T)[None], 0)
     Fn = O.gen_noise_msc(O.OracleMicArray(arrayType="circular", r=0.032, M=M), nfft)[:, 1, 2]
     op = EmulOp("mcspp", nfft, M=M)
-    p, w, yout, pxx, pinv = op.run_mcspp(D, Fn, want_matrices=True)
+    p, w, yout, pxx, pinv = op.run_mcspp(D, Fn, want_matrices=True, repeat=name.endswith("_repeat"))   # mcspp.py:280-282
     assert np.all(np.isfinite(p)) and np.all(np.isfinite(yout))
     assert np.median(np.abs(p[0] - g["p"])) < 1e-6 and np.max(np.abs(p[0] - g["p"])) < 5e-3      # measured: max 1.1e-4 / 7.7e-4
     # enhanced signal through the ISTFT against the north star's 1e-4 RMS (absolute; the signal's RMS is 0.15): the estimation core,
@@ -413,3 +413,60 @@ def test_single_channel_rows_engine_equals_block_engine(nfft):
         yb = np.stack([t.istft(Yb[b][None])[0] for b, t in enumerate(blk_i)])   # [B, L, 2]
         assert np.array_equal(yr[..., 0], yb[..., 0])
     assert rms(yr[:, hop:, 0] - x[:, T * hop: 2 * T * hop - hop]) < 1e-5 * 10    # perfect reconstruction, one hop late
+
+
+def emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, p_override=None):
+    """The DS_ALGO_SUBBAND_GSC chain composed from the emulated stage programs exactly as ds_api_chains.hip::chain2_run composes the
+    kernels (notch -> FIR bank + mean -> STFT -> McSpp (lean build, steady build from frame 5) -> fan-form blocking filters -> ISTFT ->
+    STFT -> multichannel canceller on 1 - p with the one-frame-late fixed spectrum -> ISTFT).
+    x [M, L] float32 -> (output [L], bm_output [L, M], p [K, T], aligned [L, M])."""
+    import ctypes
+    from emul import emul as E
+    from emul.emul import EmulFrontend
+    lib = E.lib()
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    f32 = ctypes.c_float
+    nfft, K = 2 * FL, FL + 1
+    T = x.shape[1] // FL
+    fe = EmulFrontend(M, coef=coef, radius=0.98)
+    xn = fe.dcnotch(x[None])
+    xa, fixed = fe.firbank(np.ascontiguousarray(np.swapaxes(xn, 1, 2)))          # [1, L, M], [1, L]
+    D = EmulTransform(nfft, M).stft(xa, 0)                                       # [1, T, K, M]
+    sp = EmulOp("mcspp", nfft, M=M)
+    p = np.concatenate([sp.run_mcspp(D[:, :5], Fn, variant=12)[0], sp.run_mcspp(D[:, 5:], Fn, variant=13)[0]], axis=1)   # [1, T, K]
+    if p_override is not None:
+        p = np.ascontiguousarray(p_override.T[None], dtype=np.float32)
+    F = EmulTransform(nfft, 1).stft(fixed[:, :, None], 0)[..., 0]                # [1, T, K]
+    N, KP = 2, (K + 3) & ~3
+    NF = 4 * N + 2 * N * N if rls else 4 * N + 1
+    st = np.zeros((M, NF, KP), dtype=np.float32)
+    if rls:
+        for i in range(N):
+            st[:, 4 * N + 2 * (i * N + i), :] = 1000.0
+    e = np.zeros((M, T, K), dtype=np.complex64)
+    rc = lib.emul_fan(4 if rls else 3, 1, M, M, K, T, vp(st), NF, vp(np.ascontiguousarray(F)), vp(np.ascontiguousarray(D)),
+                      None if rls else vp(p), vp(e), int(not rls), 1, f32(0.5 if rls else 0.1), f32(0.9), f32(1e-4), f32(0.998))
+    assert rc == 0
+    bm = EmulTransform(nfft, 1, batch=M).istft(e[..., None])[:, :, 0]            # [M, L]
+    Xaic = EmulTransform(nfft, M).stft(np.ascontiguousarray(bm.T)[None], 0)
+    aic = EmulOp("sublms", nfft, M=M, N=2, mu=0.01, alpha=0.8)
+    Fd = np.concatenate([np.zeros_like(F[:, :1]), F[:, :-1]], axis=1)            # delay_fbf (SubbandGSC.py:226) in the spectral domain
+    e2 = aic.run(Xaic, np.ascontiguousarray(Fd), np.ascontiguousarray(np.float32(1) - p), out_complex=True)[0]
+    out = EmulTransform(nfft, 1).istft(e2[..., None])[0, :, 0]
+    return out, bm.T, p[0].T, xa[0]
+
+
+@pytest.mark.parametrize("name", ["rec1", "synth_m6", "synth_m6_rls"])
+def test_emul_subband_gsc_chain(name):
+    """SubbandGSC.process (G12, incl. the config-5 Subband-RLS composition) through the chain's stage programs: every returned signal
+    within the north star's 1e-4 RMS (absolute) of the reference.  Measured: output 2e-7 / 4e-7 / 9e-6, bm_output 1.4e-6 / 1.2e-6 /
+    2.7e-6, aligned_output 1.4e-6, p max 4e-5 / 1.1e-4 / 9e-5."""
+    from oracle import ds_oracle as O
+    g = load("g12_subbandgsc_" + name)
+    M, FL, rls = [int(v) for v in g["params"]]
+    x = as_float(g["x"]).astype(np.float32)
+    coef = np.ascontiguousarray(g["delay_filter"], dtype=np.float32)
+    Fn = O.gen_noise_msc(O.OracleMicArray(arrayType="circular", r=0.032, M=M), 2 * FL)[:, 1, 2]
+    out, bm, p, al = emul_subband_gsc_chain(x, M, FL, coef, Fn, rls)
+    assert rms(out - g["output"]) < 2e-5 and rms(bm - g["bm_output"]) < 1e-5 and rms(al - g["aligned_output"]) < 1e-5
+    assert np.max(np.abs(p - g["p"])) < 1e-3 and np.median(np.abs(p - g["p"])) < 1e-6

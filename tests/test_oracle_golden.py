@@ -198,7 +198,7 @@ def test_wpe(golden, name):
     assert np.allclose(wpe.P, g["P"], rtol=1e-6, atol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["rec1", "synth_m6"])
+@pytest.mark.parametrize("name", ["rec1", "synth_m6", "rec1_repeat"])
 def test_mcspp_notebook_flow(golden, name):
     """McSpp + steering + compute_mvdr_weight, driven like example/mvdr.ipynb cell 4."""
     g = golden("g11_mcspp_" + name)
@@ -212,7 +212,7 @@ def test_mcspp_notebook_flow(golden, name):
     Y = np.zeros((T, nfft // 2 + 1), dtype=complex)
     with np.errstate(all="ignore"):
         for n in range(T):
-            p = est.estimation(D[:, n, :])
+            p = est.estimation(D[:, n, :], repeat=name.endswith("_repeat"))
             assert np.allclose(p, g["p"][n], rtol=1e-7, atol=1e-10), n
             w = O.compute_mvdr_weight(O.steering(est.Phi_xx), est.Phi_vv_inv)
             Y[n] = np.einsum("ij,ij->i", w.conj(), D[:, n, :])
