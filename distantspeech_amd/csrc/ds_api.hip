@@ -80,8 +80,48 @@ int zero_state(ds_handle* h) {
         DS_HIP(h, hipMemcpyAsync(h->opst, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
         h->op_frm = 0; h->op_ell = 1; h->op_first = 1;
     }
+    h->td_cur = 0;
+    { const int rc = sync_dev_cnt(h); if (rc) return rc; }
     DS_HIP(h, hipStreamSynchronize(h->stream));
     return DS_OK;
+}
+
+// host mirror of the uniform counters (and the aux word: FIR parity / WPE ring position) -> the device copy the kernels read
+int sync_dev_cnt(ds_handle* h) {
+    if (!h->dev_cnt) return DS_OK;
+    const int aux = h->cfg.algo == DS_ALGO_FRONTEND ? h->td_cur : h->cfg.algo == DS_ALGO_WPE_MVDR ? h->hist_cur : 0;
+    const int c[8] = {h->op_frm, h->op_ell, h->op_first, aux, 0, 0, 0, 0};
+    DS_HIP(h, hipMemcpyAsync(h->dev_cnt, c, sizeof c, hipMemcpyHostToDevice, h->stream));
+    DS_HIP(h, hipStreamSynchronize(h->stream));                      // c is a stack buffer
+    return DS_OK;
+}
+
+int post_tick(ds_handle* t, int* cnt, int frames, int L, int aux_add, int aux_mod, hipStream_t stream) {
+    ds_handle* o = t->owner ? t->owner : t;
+    if (o->pend_set) { const int rc = flush_tick(o); if (rc) return rc; }
+    o->pend = ds::TickArgs{cnt, frames, L > 0 ? L : 1, aux_add, aux_mod};
+    o->pend_stream = stream; o->pend_set = true;
+    if (!t->owner) return flush_tick(o);                             // a stand-alone stage has no next launch to count on
+    return DS_OK;
+}
+void take_tick(ds_handle* t, hipStream_t stream, ds::TickArgs& out) {
+    ds_handle* o = t->owner ? t->owner : t;
+    out = ds::TickArgs{nullptr, 0, 1, 0, 0};
+    if (o->pend_set && o->pend_stream == stream) { out = o->pend; o->pend_set = false; }
+}
+int flush_tick(ds_handle* o) {
+    if (!o->pend_set) return DS_OK;
+    o->pend_set = false;
+    DS_HIP(o, ds::launch_tick(o->pend.cnt, o->pend.frames, o->pend.L, o->pend.aux_add, o->pend.aux_mod, o->pend_stream));
+    return DS_OK;
+}
+
+void advance_host_counters(ds_handle* h, int frames, int L) {
+    for (int t = 0; t < frames; ++t) {
+        if (h->op_frm != 0 && h->op_ell % L == 0) h->op_ell = 0;
+        h->op_frm += 1; h->op_ell += 1;
+    }
+    if (frames > 0) h->op_first = 0;
 }
 
 hipError_t launch_transform_stft(const ds_handle* t, const Params& p, int batch, hipStream_t stream) {
@@ -112,6 +152,29 @@ void fill_params(const ds_handle* h, Params& p) {
     p.diag = h->diag;
     p.gate = h->gate;
     p.mu = h->mu;
+}
+
+// host mirrors of the uniform counters of a chain handle (index 10) and its stages (0..9)
+struct ChainMirrors { int frm[11], ell[11], first[11], td[11], hist; };
+static void mirrors_get(const ds_handle* h, ChainMirrors& m) {
+    for (int i = 0; i < 11; ++i) {
+        const ds_handle* t = i < 10 ? h->sub[i] : h;
+        m.frm[i] = t ? t->op_frm : 0; m.ell[i] = t ? t->op_ell : 0; m.first[i] = t ? t->op_first : 0; m.td[i] = t ? t->td_cur : 0;
+    }
+    m.hist = h->hist_cur;
+}
+static void mirrors_set(ds_handle* h, const ChainMirrors& m) {
+    for (int i = 0; i < 11; ++i) {
+        ds_handle* t = i < 10 ? h->sub[i] : h;
+        if (!t) continue;
+        t->op_frm = m.frm[i]; t->op_ell = m.ell[i]; t->op_first = m.first[i]; t->td_cur = m.td[i];
+    }
+    h->hist_cur = m.hist;
+}
+static void advance_host_counters_keep_first(ds_handle* h, int frames, int L) {
+    const int first = h->op_first;
+    advance_host_counters(h, frames, L);
+    if (h->cfg.algo == DS_ALGO_MCSPP) h->op_first = first;           // ds_mcspp_estimate leaves it alone
 }
 
 }  // namespace dsi
@@ -158,6 +221,10 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         case DS_ALGO_FIXED: ki = ds::lookup_fixed(cfg->nfft, cfg->n_mics); break;
         case DS_ALGO_ADAPTIVE:
             ki = cfg->track_ryy ? ds::lookup_adaptive_ryy(cfg->nfft, cfg->n_mics) : ds::lookup_adaptive_noryy(cfg->nfft, cfg->n_mics);
+            if (!cfg->track_ryy) {                          // 8 microphones: the quad-spread kernel (same state layout, same numbers)
+                const KernelInfo kq = ds::lookup_adaptive_quad(cfg->nfft, cfg->n_mics);
+                if (kq.launch) ki = kq;
+            }
             break;
         case DS_ALGO_GSC: ki = ds::lookup_gsc(cfg->nfft, cfg->n_mics); break;
         case DS_ALGO_TRANSFORM:
@@ -247,7 +314,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->tables = nullptr; h->steer = nullptr; h->x_stage = nullptr; h->y_stage = nullptr;
     h->x_stage_elems = h->y_stage_elems = 0;
     h->steer_per_utt = 0; h->steer_set = false;
-    h->graph_exec = nullptr; h->graph_valid = false;
+    h->graph_exec = nullptr; h->graph_valid = false; h->chain_warm_n = -1; h->adv_hist = 0;
+    for (int i = 0; i < 11; ++i) { h->adv_frames[i] = 0; h->adv_td[i] = 0; }
     h->split = 1; h->ev_fork = nullptr;
     for (int i = 0; i < 7; ++i) { h->side[i] = nullptr; h->ev_join[i] = nullptr; }
     h->ki_istft = ki_istft; h->op = op;
@@ -263,6 +331,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->aux_floats = 0;
     h->tdf_w = h->tdf_buf = h->tdf_P = nullptr;
     h->mcspp_repeat = 0;
+    h->dev_cnt = nullptr; h->use_dev_cnt = false;
+    h->owner = nullptr; h->pend_set = false; h->pend_stream = nullptr; h->pend = ds::TickArgs{nullptr, 0, 1, 0, 0};
     h->x_fan = 1; h->p_complement = 0; h->d_interleaved = 0; h->d_prev = nullptr;
     h->fdaf_kind = DS_FDAF_PLAIN; h->fdaf_constrain = 1; h->fdaf_non_causal = 0; h->fdaf_weight_norm = 0;
     for (int i = 0; i < 10; ++i) h->sub[i] = nullptr;
@@ -298,6 +368,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     DS_CRE(hipMalloc((void**)&h->tail_in, tail_in_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->tail_out, tail_out_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->counters, counters_bytes(h)));
+    DS_CRE(hipMalloc((void**)&h->dev_cnt, 8 * sizeof(int)));
     if (is_tdf) {
         const size_t Lf = cfg->filter_len;
         DS_CRE(hipMalloc((void**)&h->tdf_w, (size_t)cfg->batch * Lf * sizeof(float)));
@@ -332,6 +403,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             if (rc != DS_OK) { std::string m = g_err; ds_destroy(h); return fail(nullptr, rc, "ds_create(DS_ALGO_WPE_MVDR): stage " + std::to_string(i) + ": " + m); }
             (void)hipStreamDestroy(h->sub[i]->stream);          // every stage runs on the chain's stream
             h->sub[i]->stream = h->stream; h->sub[i]->owns_stream = false;
+            h->sub[i]->use_dev_cnt = true;                      // uniform counters read from the device: the chain replays as a hipGraph
+            h->sub[i]->owner = h;
         }
     }
     if (cfg->algo == DS_ALGO_SUBBAND_GSC) {
@@ -358,6 +431,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             if (rc != DS_OK) { std::string m = g_err; ds_destroy(h); return fail(nullptr, rc, "ds_create(DS_ALGO_SUBBAND_GSC): stage " + std::to_string(i) + ": " + m); }
             (void)hipStreamDestroy(h->sub[i]->stream);
             h->sub[i]->stream = h->stream; h->sub[i]->owns_stream = false;
+            h->sub[i]->use_dev_cnt = true;
+            h->sub[i]->owner = h;
         }
         if (rls) {
             // the RLS blocking filters do not take the speech presence probability, so the blocking-filter stages (HBM-bound) run on a side
@@ -386,7 +461,7 @@ int ds_destroy(ds_handle* h) {
     for (int i = 0; i < 10; ++i) if (h->sub[i]) (void)ds_destroy(h->sub[i]);
     for (int i = 0; i < 16; ++i) (void)hipFree(h->chain_buf[i]);
     (void)hipFree(h->bins); (void)hipFree(h->tail_in); (void)hipFree(h->tail_out); (void)hipFree(h->counters);
-    (void)hipFree(h->tables); (void)hipFree(h->steer);
+    (void)hipFree(h->tables); (void)hipFree(h->steer); (void)hipFree(h->dev_cnt);
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage); (void)hipFree(h->opst);
     for (int i = 0; i < 10; ++i) (void)hipFree(h->dev_buf[i]);
     (void)hipFree(h->tdf_w); (void)hipFree(h->tdf_buf); (void)hipFree(h->tdf_P);
@@ -549,9 +624,16 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
         return fail(h, DS_EINVAL, "ds_process_device_seq: bad n_calls / call strides (must be multiples of 4 elements)");
     if (n_calls == 0) return DS_OK;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    if (graph != 0 && (h->cfg.algo == DS_ALGO_WPE_MVDR || h->cfg.algo == DS_ALGO_SUBBAND_GSC))
-        return fail(h, DS_EUNSUPPORTED, "ds_process_device_seq: chain handles keep frame counters on the host; use graph = 0");
+    const bool chain = h->cfg.algo == DS_ALGO_WPE_MVDR || h->cfg.algo == DS_ALGO_SUBBAND_GSC;
+    if (chain && graph != 0) {
+        // a chain replays as a graph once this call shape has run with plain launches (every stage buffer sized, nothing left to
+        // allocate or synchronise inside the capture) and the stages' host-side start-up branches are behind (McSpp's first frames)
+        const bool ready = h->chain_warm_n == n_samples_per_call && (h->cfg.algo != DS_ALGO_SUBBAND_GSC || h->sub[2]->op_frm >= 5) &&
+                           (!stream || (hipStream_t)stream == h->stream);
+        if (!ready) { if (graph == 2) return DS_OK; graph = 0; }
+    }
     if (graph == 0) {
+        if (chain) h->chain_warm_n = n_samples_per_call;
         for (int i = 0; i < n_calls; ++i) {
             int rc = ds_process_device(h, x_dev + (long long)i * x_call_stride, layout, x_batch_stride, x_chan_stride,
                                        n_samples_per_call, y_dev + (long long)i * y_call_stride, y_batch_stride, first,
@@ -582,6 +664,8 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
                 if (!h->ev_join[i]) DS_HIP(h, hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
             }
         }
+        ChainMirrors before;
+        if (chain) mirrors_get(h, before);
         DS_HIP(h, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         int crc = DS_OK;
         if (ns > 1) {
@@ -604,6 +688,14 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
         }
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(cs, &g);
+        if (chain) {                                      // nothing ran: the mirrors go back, one replay advances them by what the capture did
+            ChainMirrors after;
+            mirrors_get(h, after);
+            for (int i = 0; i < 11; ++i) { h->adv_frames[i] = after.frm[i] - before.frm[i]; h->adv_td[i] = after.td[i] ^ before.td[i]; }
+            const int dl = h->wpe_delay > 0 ? h->wpe_delay : 1;
+            h->adv_hist = ((after.hist - before.hist) % dl + dl) % dl;
+            mirrors_set(h, before);
+        }
         if (crc != DS_OK) { if (g) (void)hipGraphDestroy(g); return crc; }
         if (e != hipSuccess) return fail(h, DS_EHIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         e = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
@@ -614,6 +706,15 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     }
     if (graph == 2) return DS_OK;
     DS_HIP(h, hipGraphLaunch(h->graph_exec, s));
+    if (chain) {
+        for (int i = 0; i < 11; ++i) {
+            ds_handle* t = i < 10 ? h->sub[i] : h;
+            if (!t) continue;
+            advance_host_counters_keep_first(t, h->adv_frames[i], t->cfg.algo == DS_ALGO_MCSPP ? 65 : t->mcra_L);
+            t->td_cur ^= h->adv_td[i];
+        }
+        h->hist_cur = (h->hist_cur + h->adv_hist) % (h->wpe_delay > 0 ? h->wpe_delay : 1);
+    }
     return DS_OK;
 }
 
@@ -919,6 +1020,8 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
         for (int i = 0, k = extra_state(h, ex); i < k; ++i) { DS_HIP(h, hipMemcpy(ex[i].ptr, s, ex[i].bytes, hipMemcpyHostToDevice)); s += ex[i].bytes; }
     }
     h->op_frm = uc[0]; h->op_ell = uc[1]; h->op_first = uc[2]; h->hist_cur = uc[3];
+    rc = sync_dev_cnt(h); if (rc) return rc;
+    h->graph_valid = false;
     for (int i = 0; i < 10; ++i)
         if (h->sub[i]) {
             const size_t n = ds_state_bytes(h->sub[i]);

@@ -15,6 +15,7 @@ int chain_reserve(ds_handle* h, int T) {
     for (int i = 0; i < 8; ++i) {
         if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
         DS_HIP(h, hipStreamSynchronize(h->stream));
+        h->graph_valid = false; h->chain_warm_n = -1;
         (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
         DS_HIP(h, hipMalloc((void**)&h->chain_buf[i], need[i]));
         h->chain_bytes[i] = need[i];
@@ -44,10 +45,12 @@ int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long
     }
     // delayed input of the prediction filter: a ring of the last wpe_delay analysis frames kept by the WPE kernel itself
     if (h->wpe_delay > 0) {
-        DS_SUB(1, wpe_run(h->sub[1], nullptr, D, T, E, DS_MEM_DEVICE, h->chain_buf[6], h->hist_cur, h->wpe_delay));
+        // the ring position is device-resident (dev_cnt[3], advanced by the tick behind the launch) so that the step replays as a hipGraph
+        DS_SUB(1, wpe_run(h->sub[1], nullptr, D, T, E, DS_MEM_DEVICE, h->chain_buf[6], h->hist_cur, h->wpe_delay, h->dev_cnt + 3));
+        rc = post_tick(h->sub[1], h->dev_cnt, 0, 1, T % h->wpe_delay, h->wpe_delay, h->stream); if (rc) return rc;   // rides in the McMcra launch
         h->hist_cur = (h->hist_cur + T) % h->wpe_delay;
     } else {
-        DS_SUB(1, wpe_run(h->sub[1], D, D, T, E, DS_MEM_DEVICE, nullptr, 0, 0));
+        DS_SUB(1, wpe_run(h->sub[1], D, D, T, E, DS_MEM_DEVICE, nullptr, 0, 0, nullptr));
     }
     DS_SUB(2, ds_mcmcra_estimate(h->sub[2], E, T, pp, G, DS_MEM_DEVICE));
     DS_SUB(3, ds_adaptive_frames(h->sub[3], E, G, T, Y, DS_MEM_DEVICE));
@@ -59,10 +62,11 @@ int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long
         p.x_batch_stride = (long long)T * K * 2;
         p.y_batch_stride = y_batch_stride;
         p.T = T; p.batch0 = 0; p.method = 1;
+        take_tick(t, h->stream, p.tick);                                // the adaptive frame loop's counter advance
         DS_HIP(h, launch_transform_istft(t, p, B, h->stream));
     }
 #undef DS_SUB
-    return DS_OK;
+    return flush_tick(h);
 }
 
 // ---- DS_ALGO_SUBBAND_GSC: SubbandGSC.process (SubbandGSC.py:170-262) as a device-resident chain ------------------------------
@@ -77,6 +81,7 @@ int chain2_reserve(ds_handle* h, int n) {
     for (int i = 0; i < G_COUNT; ++i) {
         if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
         DS_HIP(h, hipStreamSynchronize(h->stream));
+        h->graph_valid = false; h->chain_warm_n = -1;
         (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
         DS_HIP(h, hipMalloc((void**)&h->chain_buf[i], need[i]));
         h->chain_bytes[i] = need[i];
@@ -94,6 +99,7 @@ static int chain_stft(ds_handle* h, ds_handle* t, const float* x, int n, float* 
     p.x_batch_stride = (long long)C * n; p.x_sample_stride = 1; p.x_chan_stride = n;
     p.y_batch_stride = (long long)T * t->K * C * 2;
     p.T = T; p.batch0 = 0;
+    take_tick(t, t->stream, p.tick);
     DS_HIP(h, launch_transform_stft(t, p, t->cfg.batch, t->stream));
     return DS_OK;
 }
@@ -104,6 +110,7 @@ static int chain_istft(ds_handle* h, ds_handle* t, const float* Y, int T, float*
     p.x_batch_stride = (long long)T * t->K * 2;
     p.y_batch_stride = y_batch_stride;
     p.T = T; p.batch0 = 0; p.method = 1;
+    take_tick(t, t->stream, p.tick);
     DS_HIP(h, launch_transform_istft(t, p, t->cfg.batch, t->stream));
     return DS_OK;
 }
@@ -129,8 +136,10 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         rc = frontend_set_taps(fe, Lt); if (rc) return fail(h, rc, fe->err);
         std::memset(&p, 0, sizeof p);
         p.B = B; p.M = M; p.n = n; p.L = Lt; p.x = cb[G_XN]; p.x_chan_major = 1; p.y = cb[G_XA]; p.y_chan_major = 1; p.mean = cb[G_FIXED];
-        p.coef = fe->dev_buf[9]; p.cache_in = fe->td_cache[fe->td_cur]; p.cache_out = fe->td_cache[fe->td_cur ^ 1];
+        // the ping-pong parity of the FIR history is device-resident (dev_cnt[3], flipped by the tick behind the launch): graph replay
+        p.coef = fe->dev_buf[9]; p.cache_in = fe->td_cache[0]; p.cache_out = fe->td_cache[1]; p.dev_parity = fe->dev_cnt + 3;
         DS_HIP(h, ds::launch_fir(p, h->stream));
+        rc = post_tick(fe, fe->dev_cnt, 0, 1, 1, 2, h->stream); if (rc) return rc;     // rides in the analysis launch that follows
         fe->td_cur ^= 1;
     }
     rc = chain_stft(h, h->sub[1], cb[G_XA], n, cb[G_D]); if (rc) return rc;                                   // :204  D
@@ -169,7 +178,7 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     if (al_dev) DS_HIP(h, hipMemcpyAsync(al_dev, cb[G_XA], nb, hipMemcpyDeviceToDevice, h->stream));
     if (p_dev) DS_HIP(h, hipMemcpyAsync(p_dev, cb[G_P], (size_t)B * T * K * 4, hipMemcpyDeviceToDevice, h->stream));
 #undef DS_SUB
-    return DS_OK;
+    return flush_tick(h);
 }
 
 

@@ -18,7 +18,7 @@ int frontend_set_taps(ds_handle* h, int Lt) {
         DS_HIP(h, hipMemset(h->td_cache[i], 0, cb));
     }
     h->td_L = Lt; h->td_cur = 0;
-    return DS_OK;
+    return sync_dev_cnt(h);
 }
 
 int stage_reserve(ds_handle* h, int i, size_t bytes) {
@@ -81,17 +81,19 @@ int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int me
     p.x_fan = h->x_fan > 0 ? h->x_fan : 1; p.p_complement = h->p_complement; p.d_interleaved = h->d_interleaved; p.d_prev = h->d_prev;
     p.steer = h->steer; p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
     p.method = h->method; p.alpha_v = h->alpha_v; p.beta_v = ds::complement_of(h->alpha_v); p.gate = h->gate; p.diag = h->diag;
+    p.dev_cnt = h->use_dev_cnt ? h->dev_cnt : nullptr;
+    take_tick(h, h->stream, p.tick);                                   // an earlier stage's counter advance rides in this launch
     DS_HIP(h, ds::launch_binop(h->op, p, h->stream));
-    // advance the uniform counters exactly like the kernel did (mcra.py:52-56,72-74)
-    for (int t = 0; t < n_frames; ++t) {
-        if (h->op_frm != 0 && h->op_ell % h->mcra_L == 0) h->op_ell = 0;
-        h->op_frm += 1; h->op_ell += 1;
-    }
-    h->op_first = 0;
+    // advance the uniform counters exactly like the kernel did (mcra.py:52-56,72-74): the host mirror, and the device copy behind the launch
+    // (only the operators that read them: the subband filters keep no frame counters)
+    const bool counts = h->op != ds::OP_SUBLMS && h->op != ds::OP_SUBRLS;
+    if (h->use_dev_cnt && counts) { rc = post_tick(h, h->dev_cnt, n_frames, h->mcra_L, 0, 0, h->stream); if (rc) return rc; }
+    advance_host_counters(h, n_frames, h->mcra_L);
     return io_end(h, mem, io, dout);
 }
 
-int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len) {
+int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len,
+            const int* dev_ring_pos) {
     if (!h || (!x_delayed && !ring) || !d || !err) return fail(h, DS_EINVAL, "ds_wpe_update: NULL argument");
     if (h->cfg.algo != DS_ALGO_WPE) return fail(h, DS_ESTATE, "ds_wpe_update: handle was created for a different algo");
     if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_wpe_update: n_frames < 0");
@@ -106,7 +108,7 @@ int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, 
     p.B = h->cfg.batch; p.K = h->K; p.T = n_frames; p.C = h->cfg.n_mics; p.N = h->filter_len;
     p.xd = din[0]; p.d = din[1]; p.err = dout[0]; p.state = h->opst; p.lam = h->rls_lambda;
     p.ustride = (long long)h->NF * h->KP;
-    p.ring = ring; p.ring_pos = ring_pos; p.ring_len = ring_len;
+    p.ring = ring; p.ring_pos = ring_pos; p.ring_len = ring_len; p.dev_ring_pos = dev_ring_pos;
     DS_HIP(h, ds::launch_wpe(p, h->stream));
     return io_end(h, mem, io, dout);
 }
@@ -219,20 +221,25 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, 
     std::memset(&p, 0, sizeof p);
     p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames; p.st = h->opst; p.NF = h->NF; p.M = h->cfg.n_mics;
     p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = 65;                      // mccdr.py:60-61
+    p.dev_cnt = h->use_dev_cnt ? h->dev_cnt : nullptr;
     p.in0 = din[0]; p.in1 = h->dev_buf[9]; p.out0 = h->dev_buf[3];
+    take_tick(h, h->stream, p.tick);
     DS_HIP(h, ds::launch_binop(ds::OP_MCCDR, p, h->stream));
-    DS_HIP(h, ds::launch_mcspp_qavg(h->dev_buf[3], h->dev_buf[3] + n, (int)nbt, h->K, h->stream));
-    p.in1 = h->dev_buf[3]; p.in2 = h->dev_buf[3] + n; p.N = 9;
+    p.tick = ds::TickArgs{nullptr, 0, 1, 0, 0};
+    // the band average of the prior, one value per (utterance, frame): formed inside the McSpp kernel's own prologue for short calls
+    // (ds_binop_kernel), by a launch of its own otherwise
+    const int band_n = (int)(2000.0 * (2 * (h->K - 1)) / 16000.0) - (int)(500.0 * (2 * (h->K - 1)) / 16000.0);
+    const bool qavg_in_kernel = n_frames <= 64 && band_n > 0 && band_n <= 64;
+    if (!qavg_in_kernel) DS_HIP(h, ds::launch_mcspp_qavg(h->dev_buf[3], h->dev_buf[3] + n, (int)nbt, h->K, h->stream));
+    p.in1 = h->dev_buf[3]; p.in2 = qavg_in_kernel ? nullptr : h->dev_buf[3] + n; p.N = 9;
     p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
     // three builds of the same estimation: with the notebook-MVDR / matrix outputs, lean (p and the optional PMWF weights), and the lean
     // one for calls that start at frame 5 or later without weights (no second factorisation in the kernel: two waves per SIMD at 6 mics)
     p.repeat = h->mcspp_repeat;
     const int op = (yout || phi_xx || p.repeat) ? ds::OP_MCSPP : (w_pmwf || h->op_frm < 5) ? ds::OP_MCSPP_LEAN : ds::OP_MCSPP_STEADY;
     DS_HIP(h, ds::launch_binop(op, p, h->stream));
-    for (int t = 0; t < n_frames; ++t) {
-        if (h->op_frm != 0 && h->op_ell % 65 == 0) h->op_ell = 0;
-        h->op_frm += 1; h->op_ell += 1;
-    }
+    if (h->use_dev_cnt) { rc = post_tick(h, h->dev_cnt, n_frames, 65, 0, 0, h->stream); if (rc) return rc; }
+    { const int first = h->op_first; advance_host_counters(h, n_frames, 65); h->op_first = first; }
     return io_end(h, mem, io, dout);
 }
 
@@ -392,12 +399,11 @@ int ds_omlsa_postfilter(ds_handle* h, const float* Y, const float* U, int n_fram
     p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames; p.st = h->opst; p.NF = h->NF; p.M = h->cfg.n_mics;
     p.in0 = din[0]; p.in1 = din[1]; p.out0 = h->dev_buf[3]; p.out1 = dout[1]; p.out2 = h->dev_buf[3] + n; p.out3 = dout[3];
     p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = h->mcra_L; p.first_frame = h->op_first; p.in_complex = 1; p.x_fan = 1;
+    p.dev_cnt = h->use_dev_cnt ? h->dev_cnt : nullptr;
+    take_tick(h, h->stream, p.tick);
     DS_HIP(h, ds::launch_binop(ds::OP_OMLSA, p, h->stream));
-    for (int t = 0; t < n_frames; ++t) {
-        if (h->op_frm != 0 && h->op_ell % h->mcra_L == 0) h->op_ell = 0;
-        h->op_frm += 1; h->op_ell += 1;
-    }
-    h->op_first = 0;
+    if (h->use_dev_cnt) { rc = post_tick(h, h->dev_cnt, n_frames, h->mcra_L, 0, 0, h->stream); if (rc) return rc; }
+    advance_host_counters(h, n_frames, h->mcra_L);
     return io_end(h, mem, io, dout);
 }
 
@@ -418,7 +424,7 @@ int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames,
 
 int ds_wpe_update(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem) {
     if (!x_delayed) return fail(h, DS_EINVAL, "ds_wpe_update: NULL argument");
-    return wpe_run(h, x_delayed, d, n_frames, err, mem, nullptr, 0, 0);
+    return wpe_run(h, x_delayed, d, n_frames, err, mem, nullptr, 0, 0, nullptr);
 }
 
 }  // extern "C"

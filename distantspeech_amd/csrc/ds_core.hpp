@@ -102,6 +102,22 @@ DS_HD float fmaxf_(float a, float b) { return a > b ? a : b; }
 enum { ALGO_FIXED = 0, ALGO_ADAPTIVE = 1, ALGO_GSC = 2 };
 enum { METHOD_SRC = 0, METHOD_DS = 1, METHOD_MVDR = 2, METHOD_TFGSC = 3 };
 
+// Device-resident uniform counters of a chain stage, cnt = {frm_cnt, ell, first_frame, aux}: a later kernel of the same stream carries
+// the advance in its arguments (thread 0 of block 0 applies it) instead of a launch of its own.  frames: frames to advance by (MCRA
+// window L, mcra.py:52-56,72-74); aux moves by aux_add modulo aux_mod (FIR ping-pong parity, WPE delay-ring position).
+struct TickArgs { int* cnt; int frames, L, aux_add, aux_mod; };
+DS_HD void apply_tick(const TickArgs& t) {
+    if (!t.cnt) return;
+    int frm = t.cnt[0], ell = t.cnt[1];
+    for (int i = 0; i < t.frames; ++i) {
+        if (frm != 0 && ell % t.L == 0) ell = 0;
+        frm += 1; ell += 1;
+    }
+    t.cnt[0] = frm; t.cnt[1] = ell;
+    if (t.frames > 0) t.cnt[2] = 0;
+    if (t.aux_mod > 0) t.cnt[3] = (t.cnt[3] + t.aux_add) % t.aux_mod;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Launch parameters (plain data; passed to the kernel by value)
 // ---------------------------------------------------------------------------------------------
@@ -130,6 +146,7 @@ struct Params {
     float gate;               // adaptivebeamformer.py:94
     float mu;                 // GSC.py:202
     int rows;                 // single-channel transforms run one row per wavefront (StftRowsEngine / IstftRowsEngine): number of rows
+    TickArgs tick;            // counters of an EARLIER stage of the chain to advance (stand-alone transform kernels only; cnt null = none)
 };
 
 // number of per-bin state floats / planes
@@ -444,7 +461,9 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
     float* d = st + SL::R_DIAG;
     float* o = st + SL::R_OFF;
     if (RYY) herm_rank1<M>(st + SL::RYY_DIAG, st + SL::RYY_OFF, Z, p.alpha_y, p.beta_y);      // :86-88
+#ifndef DS_ABLATE_NORANK1      // timing experiment only (scratch/build_variant.sh): the frame program without the covariance accumulate
     if (st[SL::MC_S + 3] < p.gate) herm_rank1<M>(d, o, Z, p.alpha_v, p.beta_v);               // :94-99
+#endif
     cf acc = mk(0.0f, 0.0f);
     if (p.method == METHOD_SRC) {                              // beamformer.py:320-322
         acc = cmulc(Z[0], a[0]);
@@ -453,7 +472,11 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
         for (int m = 0; m < M; ++m) acc = cfmac(acc, Z[m], a[m]);
         acc = cscale(acc, 1.0f / M);
     } else if (p.method == METHOD_MVDR) {                      // beamformer.py:325-326, :103-104
+#ifdef DS_ABLATE_NOSOLVE       // timing experiment only: the frame program without the Hermitian solve
+        acc = cmulc(Z[0], a[0]);
+#else
         acc = mvdr_output<M>(d, o, p.diag, a, Z);
+#endif
     } else if (RYY) {                                          // TFGSC, beamformer.py:327-333
         Chol<M> ch;
         ch.factor(d, o, p.diag);

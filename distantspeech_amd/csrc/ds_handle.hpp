@@ -45,7 +45,10 @@ struct ds_handle {
     int op;                     // ds::OP_* or -1
     float* opst;                // operator state [B][NF][KP]
     int NF;
-    int op_frm, op_ell, op_first;   // uniform counters of the operator handle
+    int op_frm, op_ell, op_first;   // uniform counters of the operator handle (host mirror; authoritative for host-side decisions)
+    int* dev_cnt;               // device copy {frm, ell, first, aux}: aux = FIR ping-pong parity (front end) / WPE ring position (chain)
+    bool use_dev_cnt;           // kernels read the counters from dev_cnt and a tick kernel follows every launch (stages of a chain handle: the
+                                // launches then replay as a hipGraph)
     int filter_len, norm;
     float filt_mu, filt_alpha, rls_lambda;
     float* dev_buf[10];         // staging for host-pointer frame-level calls (3 in, 1 scratch, 5 out, 1 aux table)
@@ -73,6 +76,14 @@ struct ds_handle {
     hipEvent_t ev_fork, ev_join[7];
     long long graph_key[16];
     bool graph_valid;
+    // chain handles under graph replay: the shape (samples per call) that has run once with plain launches (buffers sized, start-up
+    // branches behind), and what one replay of the captured sequence does to the host mirrors of the stages' uniform counters
+    ds_handle* owner;           // the chain handle this stage belongs to (null: stand-alone)
+    ds::TickArgs pend;          // chain handle: the counter advance of the stage launched last, waiting for the next launch on pend_stream
+    hipStream_t pend_stream;    // to carry it in its kernel arguments (a tick kernel of its own only if nothing follows)
+    bool pend_set;
+    int chain_warm_n;
+    int adv_frames[11], adv_td[11], adv_hist;
     float* x_stage;
     float* y_stage;
     size_t x_stage_elems, y_stage_elems;
@@ -112,10 +123,17 @@ hipError_t launch_transform_istft(const ds_handle* t, const Params& p, int batch
 struct IoSpec { const float* in[3]; size_t in_bytes[3]; float* out[5]; size_t out_bytes[5]; };
 int stage_reserve(ds_handle* h, int i, size_t bytes);
 int frontend_set_taps(ds_handle* h, int Lt);
+int sync_dev_cnt(ds_handle* h);                 // host mirror of the uniform counters -> device copy
+void advance_host_counters(ds_handle* h, int frames, int L);
+// device-side counter advance behind a launch of stage t: handed to the next kernel launched on the same stream of the chain (take_tick)
+int post_tick(ds_handle* t, int* cnt, int frames, int L, int aux_add, int aux_mod, hipStream_t stream);
+void take_tick(ds_handle* t, hipStream_t stream, ds::TickArgs& out);
+int flush_tick(ds_handle* chain);
 int io_begin(ds_handle* h, int mem, const IoSpec& io, const float* din[3], float* dout[5]);
 int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[5]);
 int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int mem, const IoSpec& io, int is_complex, int has_p);
-int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len);
+int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len,
+            const int* dev_ring_pos);
 
 // chain handles (ds_api_chains.hip)
 // DS_ALGO_SUBBAND_GSC: device buffers of the chain (indices into ds_handle::chain_buf; "c" = complex64)

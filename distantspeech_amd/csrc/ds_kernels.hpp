@@ -19,6 +19,7 @@ struct KernelInfo {
 KernelInfo lookup_fixed(int nfft, int M);
 KernelInfo lookup_adaptive_noryy(int nfft, int M);
 KernelInfo lookup_adaptive_ryy(int nfft, int M);
+KernelInfo lookup_adaptive_quad(int nfft, int M);   // 8 microphones, no Ryy: the per-bin program spread over quads (ds_quad.hpp); null launch = n/a
 KernelInfo lookup_gsc(int nfft, int M);
 KernelInfo lookup_stft(int nfft, int M);      // ds_kernels_ops.hip
 KernelInfo lookup_istft(int nfft, int M);
@@ -33,6 +34,10 @@ hipError_t launch_pcm16_to_float(const short* pcm, float* x, long long n, int Ct
 hipError_t launch_float_to_pcm16(const float* y, short* pcm, long long n, hipStream_t stream);
 struct TdfParams;
 hipError_t launch_tdfilter(const TdfParams& p, hipStream_t stream);
+// device-resident uniform counters of an operator / front-end / chain handle: cnt = {frm_cnt, ell, first_frame, aux}; advances them by
+// `frames` frames (MCRA window L; mcra.py:52-56,72-74), clears first_frame, and moves aux by aux_add modulo aux_mod (FIR ping-pong parity:
+// +1 mod 2 per call; WPE delay ring: +T mod ring_len)
+hipError_t launch_tick(int* cnt, int frames, int L, int aux_add, int aux_mod, hipStream_t stream);
 hipError_t launch_mcspp_qavg(const float* gamma, float* out, int rows, int K, hipStream_t stream);
 struct WpeParams;
 hipError_t launch_wpe(const WpeParams& p, hipStream_t stream);

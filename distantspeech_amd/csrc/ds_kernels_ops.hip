@@ -8,6 +8,7 @@
 namespace ds {
 
 template <int NFFT, int M> __global__ void __launch_bounds__(NFFT / 2) ds_stft_kernel(Params p) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
     typedef StftEngine<NFFT, M> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
@@ -15,6 +16,7 @@ template <int NFFT, int M> __global__ void __launch_bounds__(NFFT / 2) ds_stft_k
 }
 
 template <int NFFT, int M> __global__ void __launch_bounds__(NFFT / 2) ds_istft_kernel(Params p) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
     typedef IstftEngine<NFFT, M> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
@@ -32,12 +34,14 @@ template <int NFFT, int M> hipError_t launch_istft(const Params& p, int nblocks,
 
 // single-channel transforms: one row per wavefront, four rows per workgroup (StftRowsEngine / IstftRowsEngine)
 template <int NFFT> __global__ void __launch_bounds__(256) ds_stft_rows_kernel(Params p) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
     typedef StftRowsEngine<NFFT> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
     E::run(ex, p, (int)blockIdx.x, sh);
 }
 template <int NFFT> __global__ void __launch_bounds__(256) ds_istft_rows_kernel(Params p) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
     typedef IstftRowsEngine<NFFT> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
@@ -88,9 +92,45 @@ KernelInfo lookup_istft(int nfft, int M) {
     return none;
 }
 
+// McSpp's band-averaged prior np.mean(q[fmin:fmax]) (mcspp.py:258-260), q = 1 - Gamma: one value per (utterance, frame), needed by every
+// bin.  A workgroup of the flat (utterance, bin) grid touches at most two utterances (KP > 256): one wave per (utterance, frame) fetches
+// the band in one go and lane 0 adds it up in bin order — the order of mcspp_qavg(), so the value is the same bit for bit.
+constexpr int QAVG_BAND = 64, QAVG_TMAX = 64;
+__device__ inline void mcspp_qavg_block(const OpParams& p, int b0, float (*band)[QAVG_BAND], float* qa) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int fmin = (int)(500.0 * (2 * (p.K - 1)) / 16000.0), fmax = (int)(2000.0 * (2 * (p.K - 1)) / 16000.0), n = fmax - fmin;
+    for (int job = wv; job < 2 * p.T; job += 4) {                          // job = (u, t)
+        const int u = job / p.T, t = job - u * p.T, b = b0 + u;
+        if (b < p.B) {
+            if (lane < n) band[wv][lane] = 1.0f - p.in1[((long long)b * p.T + t) * p.K + fmin + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == 0) {
+                float qsum = 0.0f;
+                for (int j = 0; j < n; ++j) qsum += band[wv][j];
+                qa[u * p.T + t] = qsum / (float)n;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 template <int OP, int M> __global__ void __launch_bounds__(256) ds_binop_kernel(OpParams p) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
     const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
     const int b = (int)(i / p.KP), k = (int)(i - (long long)b * p.KP);
+    if constexpr (OP == OP_MCSPP || OP == OP_MCSPP_LEAN || OP == OP_MCSPP_STEADY) {
+        const int band_n = (int)(2000.0 * (2 * (p.K - 1)) / 16000.0) - (int)(500.0 * (2 * (p.K - 1)) / 16000.0);
+        if (!p.in2 && p.T <= QAVG_TMAX && band_n > 0 && band_n <= QAVG_BAND) {   // otherwise the operator sums the band per bin itself
+            __shared__ float band[4][QAVG_BAND];
+            __shared__ float qa[2 * QAVG_TMAX];
+            const int b0 = (int)(i0 / p.KP);
+            mcspp_qavg_block(p, b0, band, qa);
+            __syncthreads();
+            p.in2 = qa; p.in2_b0 = b0;                                    // the operator reads in2[(b - in2_b0) * T + t]
+        }
+    }
     if (b >= p.B || k >= p.K) return;
     OpCtx c = make_op_ctx(p, i0);
     if constexpr (OP == OP_MCSPP_STEADY && M >= 5) {                        // parking space for Phi_vv (op_mcspp_lean): 235 registers instead of 256
@@ -101,6 +141,7 @@ template <int OP, int M> __global__ void __launch_bounds__(256) ds_binop_kernel(
 }
 
 template <int F> __global__ void __launch_bounds__(256) ds_subrls_fan_kernel(OpParams p) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
     const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
     const int u = (int)(i / p.KP), k = (int)(i - (long long)u * p.KP);
     if (u >= p.B / F || k >= p.K) return;
@@ -109,6 +150,7 @@ template <int F> __global__ void __launch_bounds__(256) ds_subrls_fan_kernel(OpP
 }
 
 template <int F> __global__ void __launch_bounds__(256) ds_sublms_fan_kernel(OpParams p) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
     const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
     const int u = (int)(i / p.KP), k = (int)(i - (long long)u * p.KP);
     if (u >= p.B / F || k >= p.K) return;
@@ -272,7 +314,10 @@ template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdPar
     for (int i = tid; i < 2 * S::PAD; i += FIR_NT) lds[(i / S::PAD) * OPL * S::RL + at(i % S::PAD)] = 0.0f;
     if (tid < OPL) cs[M * Lp + tid] = 0.0f;
     const float* xb = p.x + (long long)b * p.n * M;
-    const float* cache = p.cache_in + (long long)b * (L - 1) * M;
+    const bool swapped = p.dev_parity != nullptr && (p.dev_parity[0] & 1);           // device-resident ping-pong parity (graph replay)
+    const float* cache_in = swapped ? p.cache_out : p.cache_in;
+    float* cache_out = swapped ? const_cast<float*>(p.cache_in) : p.cache_out;
+    const float* cache = cache_in + (long long)b * (L - 1) * M;
     const long long xs_s = p.x_chan_major ? 1 : M, xs_c = p.x_chan_major ? p.n : 1;
     // window entry w = 0 .. nt + L - 2  <->  sample s = i0 + w - (L - 1); s < 0 (first tile only: a tile is longer than the history)
     // comes from the cache
@@ -291,7 +336,7 @@ template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdPar
     };
     const int o0 = OPL * tid;                                              // first output of this lane within the tile
     const bool live = o0 < nt, vec = p.y_chan_major && p.n % 4 == 0 && reinterpret_cast<uintptr_t>(p.y) % 16 == 0 && o0 + OPL <= nt;
-    const bool keep = p.cache_out != nullptr && L > 1 && blockIdx.x == gridDim.x - 1;
+    const bool keep = cache_out != nullptr && L > 1 && blockIdx.x == gridDim.x - 1;
     float mean[OPL], prev[OPL];
     int ridx[OPL];                                                         // word index of x[i0 + o0 + i] in a window: entry o0 + i + L - 1 + PAD
 #pragma unroll
@@ -306,7 +351,7 @@ template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdPar
         __syncthreads();
         if (m + S::D < M) fetch(m + S::D, v);                              // D channel windows fly behind this channel's taps
         if (keep) {                                                        // history for the next call: the last L - 1 samples
-            float* co = p.cache_out + (long long)b * (L - 1) * M + m;
+            float* co = cache_out + (long long)b * (L - 1) * M + m;
             for (int i = tid; i < L - 1; i += FIR_NT) co[(long long)i * M] = xs[at(i + nt + S::PAD)];
         }
         if (!live) return;
@@ -423,6 +468,15 @@ hipError_t launch_wpe(const WpeParams& p, hipStream_t stream) {
     if (lpb == 4) hipLaunchKernelGGL(ds_wpe_kernel<4>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
     else if (lpb == 8) hipLaunchKernelGGL(ds_wpe_kernel<8>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
     else hipLaunchKernelGGL(ds_wpe_kernel<16>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(64) ds_tick_kernel(TickArgs t) {
+    if (threadIdx.x == 0) apply_tick(t);
+}
+hipError_t launch_tick(int* cnt, int frames, int L, int aux_add, int aux_mod, hipStream_t stream) {
+    const TickArgs t = {cnt, frames, L > 0 ? L : 1, aux_add, aux_mod};
+    hipLaunchKernelGGL(ds_tick_kernel, dim3(1), dim3(64), 0, stream, t);
     return hipGetLastError();
 }
 

@@ -51,6 +51,11 @@ struct OpParams {
     int method;               // OP_ADAPTIVE: METHOD_SRC / DS / MVDR
     float alpha_v, gate, diag;   // OP_ADAPTIVE: adaptivebeamformer.py:66,94,89
     float beta_v;             // OP_ADAPTIVE: 1 - alpha_v (complement_of)
+    const int* dev_cnt;       // optional device-resident {frm_cnt, ell, first_frame}: when set, the kernel takes the uniform counters from there instead
+                              // of from this struct, so that a captured hipGraph of the launch stays valid as the stream advances (ds_tick_kernel
+                              // advances them behind every launch)
+    int in2_b0;               // McSpp: in2 (the band average per (utterance, frame)) starts at this utterance (the kernel's own LDS copy)
+    TickArgs tick;            // counters of an EARLIER stage of the chain to advance (thread 0 of block 0; cnt null = none)
     int repeat;               // McSpp: estimation(repeat=True), a second estimation_core after the noise update (mcspp.py:280-282)
     float* spill;             // lean McSpp at 6 microphones: per-lane parking space (LDS on the GPU) for Phi_vv while the solves run; element f of
     int spill_stride;         // this lane at spill[f * spill_stride]; null = keep everything in registers
@@ -76,6 +81,7 @@ struct StRef {
 __device__ inline OpCtx make_op_ctx(const OpParams& p0, long long first_lane) {       // first_lane: flat (b, k) index of the workgroup's lane 0
     OpCtx c;
     static_cast<OpParams&>(c) = p0;
+    if (p0.dev_cnt) { c.frm_cnt = p0.dev_cnt[0]; c.ell = p0.dev_cnt[1]; c.first_frame = p0.dev_cnt[2]; }
     c.b0 = (int)(first_lane / p0.KP);
     const long long off = (long long)c.b0 * p0.NF * p0.KP;
     const long long left = ((long long)p0.B * p0.NF * p0.KP - off) * 4;
@@ -823,7 +829,7 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
         float q = 1.0f - p.in1[fb + k];                                            // compute_q :113-116
         float q_avg;
         if (p.in2) {
-            q_avg = p.in2[(long long)b * p.T + t];                                 // mcspp_qavg() ran once per (utterance, frame)
+            q_avg = p.in2[(long long)(b - p.in2_b0) * p.T + t];                    // mcspp_qavg() ran once per (utterance, frame)
         } else {
             q_avg = mcspp_qavg(p.in1 + fb, fmin, fmax);
         }
@@ -970,7 +976,7 @@ template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, i
 #pragma unroll
         for (int m = 0; m < M; ++m) Z[m] = mk(p.in0[2 * (base + m)], p.in0[2 * (base + m) + 1]);
         float q = 1.0f - p.in1[fb + k];                                            // compute_q :113-116
-        const float q_avg = p.in2 ? p.in2[(long long)b * p.T + t] : mcspp_qavg(p.in1 + fb, fmin, fmax);
+        const float q_avg = p.in2 ? p.in2[(long long)(b - p.in2_b0) * p.T + t] : mcspp_qavg(p.in1 + fb, fmin, fmax);
         const float dv = fma_(q_avg, 1e-1f, (1.0f - q_avg) * 1e-4f);               // :254-262
         herm_rank1<M>(yd, yo, Z, 0.92f, (float)(1.0 - 0.92));                      // :264-266
         if (frm < 10) {                                                            // :273-275
@@ -1201,6 +1207,7 @@ struct TdParams {
     const float* coef;         // FIR: [L][M]
     const float* cache_in;     // FIR: [B][L-1][M]
     float* cache_out;          // FIR: [B][L-1][M] (the other half of a ping-pong pair)
+    const int* dev_parity;     // FIR: optional device-resident call parity (dev_cnt[3] of the handle): odd = the two halves swap roles
     float radius;
 };
 

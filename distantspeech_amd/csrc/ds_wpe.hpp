@@ -40,6 +40,7 @@ struct WpeParams {
     // ring_len frames of d are left in the ring (the caller advances ring_pos by T)
     float* ring;         // complex [B][ring_len][K][C]
     int ring_pos, ring_len;
+    const int* dev_ring_pos;   // optional device-resident ring position (graph replay); overrides ring_pos
 };
 
 template <int LPB> struct WpeShared {
@@ -70,6 +71,7 @@ template <int LPB> struct WpeEngine {
         const int SB = wpe_bin_floats(C, N);
         const long long nbins = (long long)p.B * p.K;
         const float lam = p.lam, lam_inv = 1.0f / p.lam;
+        const int ring_pos = p.dev_ring_pos ? p.dev_ring_pos[0] : p.ring_pos;
         // lane -> (bin slot s, lane i of the bin); g = global bin
         auto slot = [&](int tid, int& s, int& i, long long& g, bool& on) {
             s = tid / LPB; i = tid - s * LPB;
@@ -90,7 +92,7 @@ template <int LPB> struct WpeEngine {
         };
         auto delayed = [&](long long g, int t, int c) {           // x_delayed[c] of frame t
             if (p.ring == nullptr) { const long long f = io_base(g, t); return mk(p.xd[2 * (f + c)], p.xd[2 * (f + c) + 1]); }
-            if (t < p.ring_len) { const long long f = ring_at(g, (p.ring_pos + t) % p.ring_len); return mk(p.ring[2 * (f + c)], p.ring[2 * (f + c) + 1]); }
+            if (t < p.ring_len) { const long long f = ring_at(g, (ring_pos + t) % p.ring_len); return mk(p.ring[2 * (f + c)], p.ring[2 * (f + c) + 1]); }
             const long long f = io_base(g, t - p.ring_len);
             return mk(p.d[2 * (f + c)], p.d[2 * (f + c) + 1]);
         };
@@ -140,7 +142,7 @@ template <int LPB> struct WpeEngine {
                 if (i < C) {
                     sh.d[s][i] = r.din;
                     if (p.ring != nullptr && t >= p.T - p.ring_len) {             // this frame is one of the last ring_len: keep it
-                        const long long f = ring_at(g, (p.ring_pos + t) % p.ring_len);
+                        const long long f = ring_at(g, (ring_pos + t) % p.ring_len);
                         p.ring[2 * (f + i)] = r.din.x; p.ring[2 * (f + i) + 1] = r.din.y;
                     }
                 }

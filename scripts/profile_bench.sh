@@ -9,6 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export DS_BENCH_SYNTH=white      # white-noise input: same traffic, no torch FFT kernels in the trace
 cd /tmp
 ARGS="--steps 50 --warmup 5 --min-region-ms 20 --no-cpu-baseline --no-extras $*"
 echo "bench.py $ARGS" > "$OUT/command.txt"

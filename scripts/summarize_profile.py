@@ -20,7 +20,7 @@ def find(sub, pat):
 
 
 def ours(name):
-    return "ds::" in name or "ds_" in name
+    return "ds::" in name
 
 
 rows = defaultdict(list)

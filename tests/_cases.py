@@ -58,3 +58,43 @@ def steering(M, nfft, r, angle=ANGLE):
 
 ADAPTIVE_CASES = ["rec1", "synth", "synth_ds", "synth_src", "synth_tfgsc", "synth_m6", "synth_m8_1024"]
 GSC_CASES = ["rec1", "synth_m6", "synth_m4", "synth_m0"]
+
+
+class DeviceBuffers:
+    """Raw device allocations for the tests that drive the device-pointer entry points (hipMalloc / hipMemcpy through ctypes on the HIP
+    runtime libdsenh.so is linked against — no second runtime in the process)."""
+
+    def __init__(self):
+        import ctypes
+        self.ct = ctypes
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.ptrs = []
+
+    def _ok(self, rc, what):
+        assert rc == 0, "%s failed with hipError %d" % (what, rc)
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        p = self.ct.c_void_p()
+        self._ok(self.hip.hipMalloc(self.ct.byref(p), self.ct.c_size_t(a.nbytes)), "hipMalloc")
+        self._ok(self.hip.hipMemcpy(p, a.ctypes.data_as(self.ct.c_void_p), self.ct.c_size_t(a.nbytes), 1), "hipMemcpy H2D")
+        self.ptrs.append(p)
+        return p.value
+
+    def zeros(self, nbytes):
+        p = self.ct.c_void_p()
+        self._ok(self.hip.hipMalloc(self.ct.byref(p), self.ct.c_size_t(nbytes)), "hipMalloc")
+        self._ok(self.hip.hipMemset(p, 0, self.ct.c_size_t(nbytes)), "hipMemset")
+        self.ptrs.append(p)
+        return p.value
+
+    def download(self, ptr, shape, dtype=np.float32):
+        out = np.empty(shape, dtype=dtype)
+        self._ok(self.hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
+        self._ok(self.hip.hipMemcpy(out.ctypes.data_as(self.ct.c_void_p), self.ct.c_void_p(ptr), self.ct.c_size_t(out.nbytes), 2), "hipMemcpy D2H")
+        return out
+
+    def free(self):
+        for p in self.ptrs:
+            self.hip.hipFree(p)
+        self.ptrs = []

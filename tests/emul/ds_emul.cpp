@@ -7,6 +7,7 @@
 
 #include "../../distantspeech_amd/csrc/ds_core.hpp"
 #include "../../distantspeech_amd/csrc/ds_ops.hpp"
+#include "../../distantspeech_amd/csrc/ds_quad.hpp"
 #include "../../distantspeech_amd/csrc/ds_tables.hpp"
 #include "../../distantspeech_amd/csrc/ds_tdfilter.hpp"
 #include "../../distantspeech_amd/csrc/ds_fdaf.hpp"
@@ -225,6 +226,40 @@ int emul_wpe(int B, int K, int T, int C, int N, const float* xd, const float* d,
     p.ustride = (long long)K * ds::wpe_bin_floats(C, N); p.lam = lam;
     const int lpb = ds::wpe_lanes_per_bin(C * N);
     return lpb == 4 ? run_wpe<4>(p) : lpb == 8 ? run_wpe<8>(p) : run_wpe<16>(p);
+}
+
+// the quad-spread 8-microphone MVDR bin program (ds_quad.hpp) in its CPU policy (the four lanes of a quad side by side) next to the
+// one-thread program it restates: packed state st[64] (updated in place when gate != 0), a[8], z[8] complex -> Y complex, both ways
+int emul_quad_mvdr(float* st_quad, float* st_ref, const float* a, const float* z, int gate, float alpha, float diag, float* Y_quad, float* Y_ref) {
+    using namespace ds;
+    cf A[8], Z[8];
+    for (int m = 0; m < 8; ++m) { A[m] = mk(a[2 * m], a[2 * m + 1]); Z[m] = mk(z[2 * m], z[2 * m + 1]); }
+    const float beta = complement_of(alpha);
+    if (gate) herm_rank1<8>(st_ref, st_ref + 8, Z, alpha, beta);
+    const cf yr = mvdr_output<8>(st_ref, st_ref + 8, diag, A, Z);
+    Y_ref[0] = yr.x; Y_ref[1] = yr.y;
+    QuadRows<float> rows[4];
+    for (int l = 0; l < 4; ++l) quad_unpack(l, [&](int f) { return st_quad[f]; }, rows[l]);
+    QuadRows<Q4> R;
+    auto gather = [&](auto pick) { Q4 v; for (int l = 0; l < 4; ++l) v.v[l] = pick(rows[l]); return v; };
+    R.d0 = gather([](const QuadRows<float>& r) { return r.d0; });
+    R.d1 = gather([](const QuadRows<float>& r) { return r.d1; });
+    for (int k = 0; k < 3; ++k) { R.r0[k].x = gather([k](const QuadRows<float>& r) { return r.r0[k].x; }); R.r0[k].y = gather([k](const QuadRows<float>& r) { return r.r0[k].y; }); }
+    for (int k = 0; k < 7; ++k) { R.r1[k].x = gather([k](const QuadRows<float>& r) { return r.r1[k].x; }); R.r1[k].y = gather([k](const QuadRows<float>& r) { return r.r1[k].y; }); }
+    cq<Q4> Aq[8], Zq[8];
+    for (int m = 0; m < 8; ++m) { Aq[m] = qmk<Q4>(QuadCpu::splat(A[m].x), QuadCpu::splat(A[m].y)); Zq[m] = qmk<Q4>(QuadCpu::splat(Z[m].x), QuadCpu::splat(Z[m].y)); }
+    QuadCpu q;
+    if (gate) quad_rank1(q, R, Zq, alpha, beta);
+    const cq<Q4> y = quad_mvdr_output(q, R, diag, Aq, Zq);
+    for (int l = 0; l < 4; ++l) { Y_quad[2 * l] = y.x.v[l]; Y_quad[2 * l + 1] = y.y.v[l]; }
+    for (int l = 0; l < 4; ++l) {
+        QuadRows<float> o;
+        o.d0 = R.d0.v[l]; o.d1 = R.d1.v[l];
+        for (int k = 0; k < 3; ++k) o.r0[k] = qmk<float>(R.r0[k].x.v[l], R.r0[k].y.v[l]);
+        for (int k = 0; k < 7; ++k) o.r1[k] = qmk<float>(R.r1[k].x.v[l], R.r1[k].y.v[l]);
+        quad_pack(l, o, [&](int f, float v) { st_quad[f] = v; });
+    }
+    return 0;
 }
 
 // sizes of the per-bin plane storage for (algo, M, ryy): returns NP, writes KP

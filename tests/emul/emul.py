@@ -16,7 +16,7 @@ SRCS = [os.path.join(HERE, "ds_emul.cpp"), os.path.join(ROOT, "distantspeech_amd
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_ops.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tables.hpp"),
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tdfilter.hpp"),
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_fdaf.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_wpe.hpp"),
-        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_linalg64.hpp")]
+        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_linalg64.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_quad.hpp")]
 
 
 def build(force=False):

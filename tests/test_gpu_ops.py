@@ -219,7 +219,7 @@ def test_mcspp_notebook_flow(ds, name):
         if n % 16 == 0 or n == T - 1:                             # the three separate calls of the notebook
             w = compute_mvdr_weight(ds.steering(est.Phi_xx), est.Phi_vv_inv)
             Ys[n] = np.einsum("ij,ij->i", w.conj(), D[:, n, :])
-            assert np.max(np.abs(Ys[n] - Yf[n])) < 1e-3 * (np.max(np.abs(Yf[n])) + 1e-6)    # the separate calls pass complex64 matrices
+            assert np.max(np.abs(Ys[n] - Yf[n])) < 1e-3 * np.max(np.abs(Yf[n])) + 2e-6      # the separate calls pass complex64 matrices
     assert np.median(np.abs(p - g["p"])) < 1e-6 and np.max(np.abs(p - g["p"])) < 5e-3
     y = tr.istft(Yf.T[:, :, None])
     err = rms(y - g["y"])
@@ -535,7 +535,7 @@ def test_wpe_mvdr_postfilter(ds, M, nfft):
 
 def test_chain_handles_error_behaviour(ds):
     """the two chain handles refuse what they cannot do, loudly: missing tables / steering, ragged lengths, wrong layout,
-    partial batches, graph replay; an empty call is a no-op."""
+    partial batches; an empty call is a no-op."""
     from distantspeech_amd import _lib as L
     from distantspeech_amd._lib import DsError
     eng = ds.BatchEngine(L.ALGO_SUBBAND_GSC, 4, 512, 256, batch=2, filter_len=2)
@@ -564,8 +564,8 @@ def test_chain_handles_error_behaviour(ds):
     fake_x, fake_y = 0x100000, 0x200000           # never dereferenced: both calls must be refused during validation
     with pytest.raises(DsError, match="whole batch"):
         ch.process_device_seq(fake_x, 1, 4 * 512, 512, 256, 256, 1, fake_y, 512, 256, first=0, count=1, graph=0)
-    with pytest.raises(DsError, match="graph"):
-        ch.process_device_seq(fake_x, 1, 4 * 512, 512, 256, 256, 2, fake_y, 512, 256, graph=1)
+    # graph replay of a chain needs the call shape to have run once with plain launches: a build-only request before that is a no-op
+    ch.process_device_seq(fake_x, 1, 4 * 512, 512, 256, 256, 2, fake_y, 512, 256, graph=2)
     with pytest.raises(DsError):
         ds.BatchEngine(L.ALGO_WPE_MVDR, 8, 1024, 512, batch=1, filter_len=3)   # C * N = 24 > 16 lanes per bin
 
@@ -593,6 +593,87 @@ def test_chain_handles_long_stream_drift(ds):
     y = np.concatenate([sg.process(x[:, a:a + 100 * FL])[0] for a in range(0, T * FL, 100 * FL)])
     n = 100 * FL
     assert max(rms(y[i:i + n] - ref[i:i + n]) / rms(ref[i:i + n]) for i in range(0, len(ref), n)) < 1e-4
+
+
+@pytest.mark.parametrize("chain", ["cfg4_m8_1024", "cfg5_rls", "cfg5_lms"])
+def test_chains_at_baseline_chunk_length(ds, chain):
+    """BASELINE's streaming shape for the two chain configs — 10 s chunks (312 hops of 512 for cfg4, 625 blocks of 256 for cfg5), three
+    chunks with the state carried — at a reduced batch against the fp64 oracle: every 100-frame segment of every utterance within the
+    north star's 1e-4 (relative to the segment's RMS); the LMS blocking filters and the 8-microphone 1024-point WPE + MVDR + gain chain
+    included (the long-stream check covered the RLS variant and M = 4 / 512 only)."""
+    from oracle import ds_oracle as O
+    from _cases import ANGLE, oracle_mic
+    if chain == "cfg4_m8_1024":
+        M, nfft, hop, T, B = 8, 1024, 512, 312, 2
+        omic = oracle_mic(M, nfft)
+        x = np.stack([O.synth_utterance(40 + b, 3 * T * hop, omic) for b in range(B)])
+        obj = ds.WpeMvdrPostfilter(ds.MicArray(arrayType="circular", r=omic.r, M=M, n_fft=nfft), frameLen=nfft, hop=hop, batch=B)
+        y = np.concatenate([obj.process(x[:, :, c * T * hop:(c + 1) * T * hop], ANGLE)["data"] for c in range(3)], axis=1)
+        ref = np.stack([O.OracleWpeMvdrPostfilter(omic, nfft=nfft, hop=hop).process(x[b], ANGLE) for b in range(B)])
+    else:
+        M, FL, T, B = 6, 256, 625, 1
+        hop = FL
+        omic = oracle_mic(M, 512)
+        x = np.stack([O.synth_utterance(50 + b, 3 * T * FL, omic) * 0.1 for b in range(B)])
+        sg = ds.SubbandGSC(ds.MicArray(arrayType="circular", r=omic.r, M=M, n_fft=512), frameLen=FL, bm_filter=chain[5:])
+        y = np.concatenate([sg.process(x[0][:, c * T * FL:(c + 1) * T * FL])[0] for c in range(3)])[None]
+        with np.errstate(all="ignore"):
+            ref = O.OracleSubbandGSC(omic, frameLen=FL, rls_bm=chain.endswith("rls")).process(x[0])[0][None]
+    n = 100 * hop
+    worst = max(rms(y[b, i:i + n] - ref[b, i:i + n]) / rms(ref[b, i:i + n]) for b in range(B) for i in range(0, ref.shape[1] - n + 1, n))
+    measured("chain_baseline_chunks_" + chain, worst_segment_rel_rms=worst, total_abs_rms=rms(y - ref), ref_rms=rms(ref))
+    assert worst < 1e-4
+
+
+@pytest.mark.parametrize("chain", ["cfg4", "cfg5_rls", "cfg5_lms"])
+def test_chain_graph_replay_equals_plain_launches(ds, chain):
+    """The chain handles keep their uniform counters (frame counts, MCRA window phase, FIR ping-pong parity, WPE ring position) on the
+    device, so ds_process_device_seq(graph=1) replays a captured sequence of calls: same samples and same exported state, bit for bit, as
+    plain launches — across several replays, with plain calls in between, one hop per call and several hops per call."""
+    from _cases import DeviceBuffers
+    from distantspeech_amd import _lib as L
+    from distantspeech_amd.mic_array import compute_tau
+    from distantspeech_amd.ops import McSpp
+    from distantspeech_amd.subband_gsc import fractional_delay_filter_bank
+    if chain == "cfg4":
+        algo, M, nfft, hop, kw = L.ALGO_WPE_MVDR, 8, 1024, 512, dict(filter_len=2)
+    else:
+        algo, M, nfft, hop, kw = L.ALGO_SUBBAND_GSC, 6, 512, 256, dict(filter_len=2, rls_lambda=0.998 if chain == "cfg5_rls" else 0.0)
+    B, T, n_calls, rounds = 3, 2, 5, 4
+    Ltot = T * hop * n_calls * (rounds + 2)
+    dv = DeviceBuffers()
+    xd = dv.upload((np.random.default_rng(9).standard_normal((B, M, Ltot)) * 0.05).astype(np.float32))
+    mic = ds.MicArray(arrayType="circular", r=0.05, M=M, n_fft=nfft)
+    ang = np.array([197.0, 0.0]) / 180 * np.pi
+
+    def make():
+        e = ds.BatchEngine(algo, M, nfft, hop, batch=B, device=0, **kw)
+        if algo == L.ALGO_SUBBAND_GSC:
+            tau = compute_tau(mic, ang)
+            e.chain_set_aux(L.CHAIN_AUX_FIR, fractional_delay_filter_bank(np.array(-(tau - np.max(tau)))[:, 0] * mic.fs))
+            e.chain_set_aux(L.CHAIN_AUX_COHERENCE, McSpp.diffuse_coherence(M, nfft))
+        else:
+            tao = -1 * mic.r * np.cos(ang[1]) * np.cos(ang[0] - mic.gamma) / mic.c
+            e.set_steering(np.exp(-1j * (2 * np.pi * np.arange(nfft // 2 + 1) * 16000 / nfft)[:, None] * tao[None, :]))
+            e.set_method(L.METHOD_MVDR)
+        return e
+
+    outs = []
+    for graph in (0, 1):
+        e = make()
+        yd = dv.zeros(B * Ltot * 4)
+        seg = T * hop * n_calls
+        for i, r in enumerate(list(range(rounds + 2)) + [rounds + 1] * 2):       # the last call three times: replays of the cached graph
+            off = 4 * r * seg
+            mode = graph if i not in (2,) else 0                 # a plain sequence in the middle of the replays
+            e.process_device_seq(xd + off, L.LAYOUT_CHANNELS_SAMPLES, M * Ltot, Ltot, T * hop, T * hop, n_calls,
+                                 yd + off, Ltot, T * hop, graph=mode)
+        e.synchronize()
+        outs.append((dv.download(yd, (B, Ltot)), e.export_state()))
+    dv.free()
+    assert np.all(np.isfinite(outs[0][0])) and np.abs(outs[0][0]).max() > 0
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
 
 
 def test_checkpoint_imports_into_a_never_run_handle(ds):

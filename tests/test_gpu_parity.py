@@ -112,6 +112,45 @@ def test_gsc_batch_vs_oracle(ds):
         assert rms(y[b] - ref) < TOL_RMS
 
 
+@pytest.mark.parametrize("nfft", [256, 512, 1024])
+def test_quad_kernel_equals_one_thread_kernel(ds, nfft):
+    """8 microphones: the frame kernel whose per-bin program is spread over quads of lanes (ds_quad.hpp: rows l and 7 - l of the
+    covariance per lane, Cholesky column sweep over DPP quad broadcasts; no scratch) against the one-thread-per-bin
+    kernel it replaces (DS_M8_ONE_THREAD=1): same samples and the same exported state, bit for bit, for MVDR / DS / src, one call and
+    hop by hop; and against the fp64 oracle."""
+    from distantspeech_amd import _lib as L
+    M, hop, B, T = 8, nfft // 2, 5, 24
+    omic = oracle_mic(M, nfft, 0.05)
+    xs = np.stack([O.synth_utterance(60 + b, hop * T, omic) for b in range(B)])
+    a = steering(M, nfft, 0.05)
+
+    def run(one_thread, method, chunked):
+        if one_thread:
+            os.environ["DS_M8_ONE_THREAD"] = "1"
+        try:
+            eng = ds.BatchEngine(L.ALGO_ADAPTIVE, M, nfft, batch=B)
+        finally:
+            os.environ.pop("DS_M8_ONE_THREAD", None)
+        eng.set_steering(a); eng.set_method(method)
+        if chunked:
+            y = np.concatenate([eng.process(xs[:, :, t * hop:(t + 1) * hop], L.LAYOUT_CHANNELS_SAMPLES) for t in range(T)], axis=1)
+        else:
+            y = eng.process(xs, L.LAYOUT_CHANNELS_SAMPLES)
+        return y, eng.export_state(), eng.get_field(L.FIELD_RVV)
+
+    for method in (L.METHOD_MVDR, L.METHOD_DS, L.METHOD_SRC):
+        yq, sq, Rq = run(False, method, False)
+        y1, s1, R1 = run(True, method, False)
+        assert np.all(np.isfinite(yq)) and np.abs(yq).max() > 0
+        assert np.array_equal(yq, y1) and np.array_equal(sq, s1) and np.array_equal(Rq, R1), method
+    yc, sc, _ = run(False, L.METHOD_MVDR, True)
+    yq, sq, _ = run(False, L.METHOD_MVDR, False)
+    assert np.array_equal(yc, yq) and np.array_equal(sc, sq)                  # hop by hop == one call
+    for b in (0, B - 1):
+        ref = O.OracleAdaptiveMVDR(omic, nfft, hop, nfft).process(xs[b], ANGLE, 2)
+        assert rms(yq[b] - ref) < 1e-5
+
+
 def test_per_utterance_look_directions(ds):
     """one look direction per utterance (set_steering [B, K, M]) == B single-direction objects."""
     from distantspeech_amd import _lib as L
