@@ -16,6 +16,9 @@ ALGO_FDAF = 16
 ALGO_ADAPTIVE_FRAMES = 17
 ALGO_WPE_MVDR = 18
 ALGO_SUBBAND_GSC = 19
+ALGO_TDGSC = 20
+ALGO_FDGSC = 21
+PARAM_POSTFILTER = 15
 CHAIN_AUX_FIR, CHAIN_AUX_COHERENCE = 0, 1
 PARAM_WPE_DELAY = 13
 PARAM_MCSPP_REPEAT = 14
@@ -56,7 +59,7 @@ EXPORTS = [
     "ds_version", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
     "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_pcm16", "ds_process_device",
     "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcra_estimate_p", "ds_mcmcra_estimate", "ds_mcsppbase_estimate", "ds_set_aux", "ds_mcspp_estimate", "ds_steering",
-    "ds_mvdr_weight", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process",
+    "ds_mvdr_weight", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process", "ds_tdgsc_process", "ds_fdgsc_process",
     "ds_omlsa_estimate", "ds_omlsa_postfilter",
     "ds_sublms_update", "ds_subrls_update", "ds_wpe_update", "ds_synchronize",
     "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_export_state",
@@ -137,6 +140,10 @@ def load():
     lib.ds_chain_set_aux.argtypes = [vp, ci, vp, csz]
     lib.ds_subband_gsc_process.restype = ci
     lib.ds_subband_gsc_process.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, ci]
+    lib.ds_tdgsc_process.restype = ci
+    lib.ds_tdgsc_process.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, ci]
+    lib.ds_fdgsc_process.restype = ci
+    lib.ds_fdgsc_process.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci]
     lib.ds_adaptive_frames.restype = ci
     lib.ds_adaptive_frames.argtypes = [vp, vp, vp, ci, vp, ci]
     lib.ds_fdaf_update.restype = ci

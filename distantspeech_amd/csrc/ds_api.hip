@@ -260,6 +260,10 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         case DS_ALGO_SUBBAND_GSC:
             if (ds::op_supported(ds::OP_MCSPP, cfg->n_mics) && cfg->n_mics >= 3 && cfg->hop * 2 == cfg->nfft && flen <= ds::RLS_NMAX) { op = 105; NF = 0; }
             break;
+        case DS_ALGO_TDGSC: case DS_ALGO_FDGSC:
+            if (cfg->n_mics >= 2 && cfg->n_mics <= 8 && cfg->hop * 2 == cfg->nfft &&
+                (cfg->nfft == 128 || cfg->nfft == 256 || cfg->nfft == 512 || cfg->nfft == 1024)) { op = 106; NF = 0; }
+            break;
         case DS_ALGO_WPE_MVDR:
             if (ds::op_supported(ds::OP_ADAPTIVE, cfg->n_mics) && cfg->hop * 2 == cfg->nfft && cfg->n_mics * flen <= ds::WPE_CNMAX) { op = 104; NF = 0; }
             break;
@@ -336,7 +340,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->x_fan = 1; h->p_complement = 0; h->d_interleaved = 0; h->d_prev = nullptr;
     h->fdaf_kind = DS_FDAF_PLAIN; h->fdaf_constrain = 1; h->fdaf_non_causal = 0; h->fdaf_weight_norm = 0;
     for (int i = 0; i < 10; ++i) h->sub[i] = nullptr;
-    for (int i = 0; i < 16; ++i) { h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0; }
+    for (int i = 0; i < 24; ++i) { h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0; }
+    h->postfilter = 0;
     h->owns_stream = true; h->wpe_delay = 4; h->hist_cur = 0;
     h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
@@ -407,6 +412,10 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             h->sub[i]->owner = h;
         }
     }
+    if (cfg->algo == DS_ALGO_TDGSC || cfg->algo == DS_ALGO_FDGSC) {
+        rc = gsc_chain_create(h);
+        if (rc != DS_OK) { std::string m = h->err.empty() ? g_err : h->err; ds_destroy(h); return fail(nullptr, rc, m); }
+    }
     if (cfg->algo == DS_ALGO_SUBBAND_GSC) {
         // stages of SubbandGSC.__init__ (SubbandGSC.py:85-124): 0 front end (notch radius 0.98 + TimeAlignment), 1 transform (M),
         // 2 McSpp, 3 bm[m].transform_x (identical for all m: one 1-channel transform), 4 bm[m].transform_d (B * M 1-channel
@@ -459,7 +468,7 @@ int ds_destroy(ds_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 10; ++i) if (h->sub[i]) (void)ds_destroy(h->sub[i]);
-    for (int i = 0; i < 16; ++i) (void)hipFree(h->chain_buf[i]);
+    for (int i = 0; i < 24; ++i) (void)hipFree(h->chain_buf[i]);
     (void)hipFree(h->bins); (void)hipFree(h->tail_in); (void)hipFree(h->tail_out); (void)hipFree(h->counters);
     (void)hipFree(h->tables); (void)hipFree(h->steer); (void)hipFree(h->dev_cnt);
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage); (void)hipFree(h->opst);
@@ -485,6 +494,9 @@ int ds_reset(ds_handle* h) {
     if (h->cfg.algo == DS_ALGO_WPE_MVDR && h->chain_buf[6]) DS_HIP(h, hipMemsetAsync(h->chain_buf[6], 0, h->chain_bytes[6], h->stream));
     if (h->cfg.algo == DS_ALGO_SUBBAND_GSC)
         for (int i = G_FPREV; i <= G_FIXPREV; ++i)
+            if (h->chain_buf[i]) DS_HIP(h, hipMemsetAsync(h->chain_buf[i], 0, h->chain_bytes[i], h->stream));
+    if (h->cfg.algo == DS_ALGO_FDGSC)
+        for (int i = 16; i <= 18; ++i)                                  // delay_aligned, delay_fbf, last bm_output block (ds_api_gsc_chains.hip)
             if (h->chain_buf[i]) DS_HIP(h, hipMemsetAsync(h->chain_buf[i], 0, h->chain_bytes[i], h->stream));
     h->hist_cur = 0;
     return zero_state(h);
@@ -540,6 +552,10 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
         case DS_PARAM_FDAF_CONSTRAIN: h->fdaf_constrain = value != 0; return DS_OK;
         case DS_PARAM_FDAF_NON_CAUSAL: h->fdaf_non_causal = value != 0; return DS_OK;
         case DS_PARAM_FDAF_WEIGHT_NORM: h->fdaf_weight_norm = value != 0; return DS_OK;
+        case DS_PARAM_POSTFILTER:
+            if (h->cfg.algo != DS_ALGO_TDGSC && h->cfg.algo != DS_ALGO_FDGSC) return fail(h, DS_EINVAL, "postfilter: TDGSC / FDGSC chain handles only");
+            h->postfilter = value != 0;
+            return DS_OK;
         case DS_PARAM_MCSPP_REPEAT:
             if (h->cfg.algo != DS_ALGO_MCSPP) return fail(h, DS_EINVAL, "mcspp repeat: DS_ALGO_MCSPP handles only");
             h->mcspp_repeat = value != 0;
@@ -577,6 +593,17 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
         if (n_samples == 0) return DS_OK;
         return chain2_run(h, x_dev, x_batch_stride, x_chan_stride > 0 ? x_chan_stride : n_samples, n_samples, y_dev, y_batch_stride,
                           nullptr, nullptr, nullptr, nullptr);
+    }
+    if (h->cfg.algo == DS_ALGO_TDGSC || h->cfg.algo == DS_ALGO_FDGSC) {
+        if (first != 0 || count != h->cfg.batch) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle processes its whole batch");
+        if (stream && (hipStream_t)stream != h->stream) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle runs on its own stream (pass NULL)");
+        if (layout != DS_LAYOUT_CHANNELS_SAMPLES) return fail(h, DS_EUNSUPPORTED, "ds_process_device: the TDGSC / FDGSC chains take [B][M][n] input");
+        if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_process_device: n_samples must be a multiple of hop");
+        if (n_samples == 0) return DS_OK;
+        const long long cs = x_chan_stride > 0 ? x_chan_stride : n_samples;
+        if (h->cfg.algo == DS_ALGO_TDGSC) return tdgsc_run(h, x_dev, x_batch_stride, cs, n_samples, h->postfilter, y_dev, y_batch_stride, nullptr, nullptr, nullptr);
+        return fdgsc_run(h, x_dev, x_batch_stride, cs, n_samples, h->postfilter, 1, y_dev, y_batch_stride, nullptr, nullptr, nullptr, nullptr, nullptr,
+                         nullptr, nullptr, nullptr);
     }
     if (h->cfg.algo == DS_ALGO_WPE_MVDR) {
         if (first != 0 || count != h->cfg.batch) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle processes its whole batch");
@@ -625,6 +652,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     if (n_calls == 0) return DS_OK;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const bool chain = h->cfg.algo == DS_ALGO_WPE_MVDR || h->cfg.algo == DS_ALGO_SUBBAND_GSC;
+    if (h->cfg.algo == DS_ALGO_TDGSC || h->cfg.algo == DS_ALGO_FDGSC) graph = 0;      // their stages keep the frame counters on the host
     if (chain && graph != 0) {
         // a chain replays as a graph once this call shape has run with plain launches (every stage buffer sized, nothing left to
         // allocate or synchronise inside the capture) and the stages' host-side start-up branches are behind (McSpp's first frames)
@@ -930,7 +958,12 @@ static size_t own_state_bytes(const ds_handle* h) {
     for (int i = 0, k = extra_state(h, ex); i < k; ++i) n += ex[i].bytes;
     return n;
 }
+static size_t fdgsc_slot_bytes(const ds_handle* h, int i) {            // chain_buf[16 + i]: delay_aligned [B][M][hop/2], delay_fbf [B][hop], bm_last [B][M][hop]
+    const size_t B = h->cfg.batch, M = h->cfg.n_mics, FL = h->cfg.hop;
+    return i == 0 ? B * M * (FL / 2) * 4 : i == 1 ? B * FL * 4 : B * M * FL * 4;
+}
 static size_t chain_hist_bytes(const ds_handle* h) {
+    if (h->cfg.algo == DS_ALGO_FDGSC) return fdgsc_slot_bytes(h, 0) + fdgsc_slot_bytes(h, 1) + fdgsc_slot_bytes(h, 2);
     if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) return (size_t)h->cfg.batch * (h->K * 8 + h->cfg.hop * 4);
     return h->cfg.algo == DS_ALGO_WPE_MVDR ? (size_t)h->cfg.batch * (h->wpe_delay > 0 ? h->wpe_delay : 1) * h->K * h->cfg.n_mics * 8 : 0;
 }
@@ -970,7 +1003,14 @@ int ds_export_state(ds_handle* h, void* dst, size_t bytes) {
             rc = ds_export_state(h->sub[i], d, n); if (rc) return fail(h, rc, h->sub[i]->err);
             d += n;
         }
-    if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) {
+    if (h->cfg.algo == DS_ALGO_FDGSC) {
+        for (int i = 0; i < 3; ++i) {                                   // never-run handle: the delays are silence
+            const size_t nb = fdgsc_slot_bytes(h, i);
+            if (h->chain_buf[16 + i]) DS_HIP(h, hipMemcpy(d, h->chain_buf[16 + i], nb, hipMemcpyDeviceToHost));
+            else std::memset(d, 0, nb);
+            d += nb;
+        }
+    } else if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) {
         rc = chain2_reserve(h, h->cfg.hop); if (rc) return rc;
         const size_t n13 = (size_t)h->cfg.batch * h->K * 8, n14 = (size_t)h->cfg.batch * h->cfg.hop * 4;
         DS_HIP(h, hipMemcpy(d, h->chain_buf[G_FPREV], n13, hipMemcpyDeviceToHost));
@@ -1028,7 +1068,14 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
             rc = ds_import_state(h->sub[i], s, n); if (rc) return fail(h, rc, h->sub[i]->err);
             s += n;
         }
-    if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) {
+    if (h->cfg.algo == DS_ALGO_FDGSC) {
+        for (int i = 0; i < 3; ++i) {
+            const size_t nb = fdgsc_slot_bytes(h, i);
+            if (!h->chain_buf[16 + i]) { DS_HIP(h, hipMalloc((void**)&h->chain_buf[16 + i], nb)); h->chain_bytes[16 + i] = nb; }
+            DS_HIP(h, hipMemcpy(h->chain_buf[16 + i], s, nb, hipMemcpyHostToDevice));
+            s += nb;
+        }
+    } else if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) {
         rc = chain2_reserve(h, h->cfg.hop); if (rc) return rc;
         const size_t n13 = (size_t)h->cfg.batch * h->K * 8, n14 = (size_t)h->cfg.batch * h->cfg.hop * 4;
         DS_HIP(h, hipMemcpy(h->chain_buf[G_FPREV], s, n13, hipMemcpyHostToDevice));

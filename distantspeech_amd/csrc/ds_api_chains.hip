@@ -187,8 +187,9 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
 extern "C" {
 int ds_chain_set_aux(ds_handle* h, int which, const float* table, size_t n_floats) {
     if (!h || !table) return fail(h, DS_EINVAL, "ds_chain_set_aux: NULL argument");
-    if (h->cfg.algo != DS_ALGO_SUBBAND_GSC) return fail(h, DS_ESTATE, "ds_chain_set_aux: handle is not a DS_ALGO_SUBBAND_GSC object");
-    ds_handle* t = which == DS_CHAIN_AUX_FIR ? h->sub[0] : which == DS_CHAIN_AUX_COHERENCE ? h->sub[2] : nullptr;
+    const bool gsc = h->cfg.algo == DS_ALGO_TDGSC || h->cfg.algo == DS_ALGO_FDGSC;
+    if (h->cfg.algo != DS_ALGO_SUBBAND_GSC && !gsc) return fail(h, DS_ESTATE, "ds_chain_set_aux: handle is not a SubbandGSC / TDGSC / FDGSC chain");
+    ds_handle* t = which == DS_CHAIN_AUX_FIR ? h->sub[0] : (which == DS_CHAIN_AUX_COHERENCE && !gsc) ? h->sub[2] : nullptr;
     if (!t) return fail(h, DS_EINVAL, "ds_chain_set_aux: unknown table id");
     const int rc = ds_set_aux(t, table, n_floats);
     return rc ? fail(h, rc, t->err) : DS_OK;

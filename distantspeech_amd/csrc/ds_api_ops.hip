@@ -21,6 +21,22 @@ int frontend_set_taps(ds_handle* h, int Lt) {
     return sync_dev_cnt(h);
 }
 
+int fdaf_run_dev(ds_handle* h, const float* x, const float* d, const float* pp, int p_mode, int n_blocks, int fir_truncate, float* err,
+                 float* w_out, int x_fan, long long x_inst_stride, long long x_sample_stride, long long x_chan_stride) {
+    ds::FdafParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.T = n_blocks; p.C = h->cfg.n_mics;
+    p.kind = h->fdaf_kind; p.constrain = h->fdaf_constrain; p.non_causal = h->fdaf_non_causal; p.weight_norm = h->fdaf_weight_norm;
+    p.trunc = fir_truncate < 0 ? -1 : fir_truncate; p.p_mode = p_mode & 3; p.p_complement = (p_mode & DS_FDAF_P_COMPLEMENT) ? 1 : 0;
+    p.mu = h->filt_mu; p.alpha = h->filt_alpha;
+    p.x = x; p.d = d; p.p = pp; p.err = err; p.w_out = w_out;
+    p.x_fan = x_fan; p.x_inst_stride = x_inst_stride; p.x_sample_stride = x_sample_stride; p.x_chan_stride = x_chan_stride;
+    p.state = h->opst; p.state_stride = (long long)h->NF * h->KP;
+    p.tables = h->tables;
+    DS_HIP(h, ds::launch_fdaf(p, h->cfg.nfft, h->stream));
+    return DS_OK;
+}
+
 int stage_reserve(ds_handle* h, int i, size_t bytes) {
     if (bytes <= h->dev_buf_bytes[i]) return DS_OK;
     DS_HIP(h, hipStreamSynchronize(h->stream));
@@ -363,16 +379,8 @@ int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* pp
                  {err, w_out, nullptr, nullptr, nullptr}, {n * 4, w_out ? (size_t)h->cfg.batch * L * C * 4 : 0, 0, 0, 0}};
     const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    ds::FdafParams p;
-    std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.T = n_blocks; p.C = C;
-    p.kind = h->fdaf_kind; p.constrain = h->fdaf_constrain; p.non_causal = h->fdaf_non_causal; p.weight_norm = h->fdaf_weight_norm;
-    p.trunc = fir_truncate < 0 ? -1 : fir_truncate; p.p_mode = p_mode & 3; p.p_complement = (p_mode & DS_FDAF_P_COMPLEMENT) ? 1 : 0;
-    p.mu = h->filt_mu; p.alpha = h->filt_alpha;
-    p.x = din[0]; p.d = din[1]; p.p = din[2]; p.err = dout[0]; p.w_out = w_out ? dout[1] : nullptr;
-    p.state = h->opst; p.state_stride = (long long)h->NF * h->KP;
-    p.tables = h->tables;
-    DS_HIP(h, ds::launch_fdaf(p, h->cfg.nfft, h->stream));
+    rc = fdaf_run_dev(h, din[0], din[1], din[2], p_mode, n_blocks, fir_truncate, dout[0], w_out ? dout[1] : nullptr, 0, 0, 0, 0);
+    if (rc) return rc;
     return io_end(h, mem, io, dout);
 }
 

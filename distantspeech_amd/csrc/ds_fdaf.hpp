@@ -21,7 +21,12 @@ struct FdafParams {
     int p_mode;               // 0: p = 1, 1: one p per block [B][T], 2: per bin [B][T][K]
     int p_complement;         // use 1 - p (TDGSC.py:154 hands the canceller p = 1 - p)
     float mu, alpha;
-    const float* x;           // [B][T * HOP][C]
+    const float* x;           // [B][T * HOP][C] by default; see the x_* fields
+    // input addressing for device-resident chains (all 0 = the dense default): instance b reads the input of instance-group b / x_fan
+    // (FDGSC: the M blocking filters of an utterance share the fixed-beamformer output), element (sample s, channel c) of that
+    // group at x + group * x_inst_stride + s * x_sample_stride + c * x_chan_stride (channel-major spectra-free hand-offs between stages)
+    int x_fan;
+    long long x_inst_stride, x_sample_stride, x_chan_stride;
     const float* d;           // [B][T * HOP]
     const float* p;
     float* err;               // [B][T * HOP]
@@ -127,7 +132,8 @@ template <int NFFT, int CMAX> struct FdafEngine {
 
     template <class Exec> static DS_HD void run(Exec& ex, const FdafParams& p, int b, Sh& sh) {
         const int C = p.C;
-        const float* xg = p.x + (long long)b * p.T * HOP * C;
+        const long long xs_s = p.x_sample_stride > 0 ? p.x_sample_stride : C, xs_c = p.x_sample_stride > 0 ? p.x_chan_stride : 1;
+        const float* xg = p.x + (long long)(b / (p.x_fan > 0 ? p.x_fan : 1)) * (p.x_inst_stride > 0 ? p.x_inst_stride : (long long)p.T * HOP * C);
         const float* dg = p.d + (long long)b * p.T * HOP;
         float* eg = p.err + (long long)b * p.T * HOP;
         float* st = p.state + (long long)b * p.state_stride;
@@ -159,7 +165,7 @@ template <int NFFT, int CMAX> struct FdafEngine {
         });
 
         for (int t = 0; t < p.T; ++t) {
-            const float* xt = xg + (long long)t * HOP * C;
+            const float* xt = xg + (long long)t * HOP * xs_s;
             const float* dt = dg + (long long)t * HOP;
             const bool last = t + 1 == p.T;
             const bool want_w = last && p.w_out != nullptr;
@@ -170,7 +176,7 @@ template <int NFFT, int CMAX> struct FdafEngine {
                 for (int idx = tid; idx < C * (NC / 2); idx += NT) {
                     const int n = idx / C, c = idx - n * C;
                     const float o0 = sh.xold[c][2 * n], o1 = sh.xold[c][2 * n + 1];
-                    const float n0 = xt[(long long)(2 * n) * C + c], n1 = xt[(long long)(2 * n + 1) * C + c];
+                    const float n0 = xt[(long long)(2 * n) * xs_s + c * xs_c], n1 = xt[(long long)(2 * n + 1) * xs_s + c * xs_c];
                     fa[c * Sh::NCP + n] = mk(o0, o1);
                     fa[c * Sh::NCP + n + NC / 2] = mk(n0, n1);
                     sh.xold[c][2 * n] = n0; sh.xold[c][2 * n + 1] = n1;

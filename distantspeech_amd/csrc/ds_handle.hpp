@@ -66,8 +66,9 @@ struct ds_handle {
     ds_handle* sub[10];         // WPE_MVDR: analysis transform, WPE, McMcra, adaptive frame loop, synthesis transform; SUBBAND_GSC: see chain2_*
     bool owns_stream;
     int wpe_delay;
-    float* chain_buf[16];       // WPE_MVDR: D, -, E, p, G, Y, ring of the last wpe_delay analysis frames; SUBBAND_GSC: see chain2_reserve
-    size_t chain_bytes[16];
+    float* chain_buf[24];       // WPE_MVDR: D, -, E, p, G, Y, ring of the last wpe_delay analysis frames; SUBBAND_GSC: see chain2_reserve
+    size_t chain_bytes[24];
+    int postfilter;             // DS_PARAM_POSTFILTER (TDGSC / FDGSC chains behind ds_process_device)
     int hist_cur;               // ring slot of the oldest frame
     // cached hipGraph of a ds_process_device_seq() sequence
     hipGraphExec_t graph_exec;
@@ -156,6 +157,16 @@ int chain_reserve(ds_handle* h, int T);
 int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
                          int n_samples, float* y_dev, long long y_batch_stride);
 int chain2_reserve(ds_handle* h, int n);
+// DS_ALGO_TDGSC / DS_ALGO_FDGSC (ds_api_gsc_chains.hip)
+int gsc_chain_create(ds_handle* h);
+int tdgsc_run(ds_handle* h, const float* x, long long x_bstride, long long x_cstride, int n, int postfilter, float* out, long long out_bstride,
+              float* p_dev, float* bm_dev, float* w_dev);
+int fdgsc_run(ds_handle* h, const float* x, long long x_bstride, long long x_cstride, int n, int postfilter, int dc_notch, float* out,
+              long long out_bstride, float* p_dev, float* fix_dev, float* fixd_dev, float* bm_dev, float* al_dev, float* ald_dev,
+              float* waic_dev, float* wbm_dev);
+// overlap-save FDAF launch on device pointers with the chain addressing options (x_fan / strides; 0 = dense)
+int fdaf_run_dev(ds_handle* h, const float* x, const float* d, const float* pp, int p_mode, int n_blocks, int fir_truncate, float* err,
+                 float* w_out, int x_fan, long long x_inst_stride, long long x_sample_stride, long long x_chan_stride);
 int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
                float* fix_dev, float* bm_dev, float* p_dev, float* al_dev);
 

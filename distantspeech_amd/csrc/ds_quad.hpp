@@ -119,7 +119,6 @@ template <class Put> DS_HD void quad_pack(int l, const QuadRows<float>& R, Put p
 
 // own-row picks of a vector every lane holds in full: z[l] and z[7 - l]
 template <class Q> DS_HD void quad_pick(const Q& q, const cq<typename Q::V>* z, cq<typename Q::V>& z0, cq<typename Q::V>& z1) {
-    typedef typename Q::V V;
     z0 = z[0]; z1 = z[7];
 #pragma unroll
     for (int c = 1; c < 4; ++c) {

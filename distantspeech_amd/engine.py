@@ -242,6 +242,35 @@ class BatchEngine:
         L.check(self._lib.ds_subband_gsc_process(self._h, self._p(x), int(n), self._p(y), q(fix), q(bm), q(p), q(al), L.MEM_HOST), self._h)
         return y, fix, bm, p, al
 
+    def tdgsc_process(self, x, postfilter=False):
+        """DS_ALGO_TDGSC: x [B, M, n] -> (out [B, n], p [B, T, K], bm [B, n, M-1], w [B, frameLen, M-1])."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 3 or x.shape[0] != self.batch or x.shape[1] != self.M:
+            raise ValueError("x must be [B=%d, M=%d, n]" % (self.batch, self.M))
+        n = x.shape[2]
+        out = np.empty((self.batch, n), dtype=np.float32)
+        p = np.empty((self.batch, n // self.hop, self.K), dtype=np.float32)
+        bm = np.empty((self.batch, n, self.M - 1), dtype=np.float32)
+        w = np.empty((self.batch, self.hop, self.M - 1), dtype=np.float32)
+        L.check(self._lib.ds_tdgsc_process(self._h, self._p(x), int(n), int(bool(postfilter)), self._p(out), self._p(p), self._p(bm), self._p(w),
+                                           L.MEM_HOST), self._h)
+        return out, p, bm, w
+
+    def fdgsc_process(self, x, postfilter=False, dc_notch=True):
+        """DS_ALGO_FDGSC: x [B, M, n] -> dict(out [B, n], p [B, T, K], fix, fix_d [B, n], bm, al, al_d [B, M, n], w_aic [B, frameLen, M],
+        w_bm [B * M, frameLen])."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 3 or x.shape[0] != self.batch or x.shape[1] != self.M:
+            raise ValueError("x must be [B=%d, M=%d, n]" % (self.batch, self.M))
+        B, M, n = x.shape
+        f32 = np.float32
+        r = dict(out=np.empty((B, n), f32), p=np.empty((B, n // self.hop, self.K), f32), fix=np.empty((B, n), f32), fix_d=np.empty((B, n), f32),
+                 bm=np.empty((B, M, n), f32), al=np.empty((B, M, n), f32), al_d=np.empty((B, M, n), f32),
+                 w_aic=np.empty((B, self.hop, M), f32), w_bm=np.empty((B * M, self.hop), f32))
+        L.check(self._lib.ds_fdgsc_process(self._h, self._p(x), int(n), int(bool(postfilter)), int(bool(dc_notch)), *[self._p(r[k]) for k in
+                                           ("out", "p", "fix", "fix_d", "bm", "al", "al_d", "w_aic", "w_bm")], L.MEM_HOST), self._h)
+        return r
+
     def adaptive_frames(self, Z, gain=None):
         """Z complex [B, T, K, M] STFT frames, gain [B, T, K] or None -> Y complex [B, T, K]: the adaptivebeamfomer frame loop
         (MCRA-gated Rvv, src/DS/MVDR weights) as a frame-level operator, times the optional post-filter gain."""

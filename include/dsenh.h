@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DS_VERSION 101
+#define DS_VERSION 102
 
 /* error codes */
 #define DS_OK 0
@@ -85,6 +85,15 @@ extern "C" {
                                  batched subband LMS, or RLS when ds_config.rls_lambda > 0) -> ISTFT/STFT -> multichannel subband-LMS canceller
                                  -> ISTFT, device-resident between the stages; nfft = 2 * frameLen, hop = frameLen, n_mics in {2,4,6},
                                  filter_len taps (0 -> 2).  Needs ds_chain_set_aux() for the FIR bank and the McCDR coherence first */
+#define DS_ALGO_TDGSC 20       /* TDGSC.process (beamformer/TDGSC.py:110-175) as ONE handle: DC notch -> TimeAlignment FIR bank + channel mean +
+                                  pairwise-difference blocking matrix -> STFT -> MCRA (L = 65) -> multichannel overlap-save canceller
+                                  (FastFreqLms, non-causal, p = 1 - p, fir_truncate 30) -> optional OMLSA post-filter; ds_tdgsc_process,
+                                  ds_process_device (post-filter per DS_PARAM_POSTFILTER); FIR table via ds_chain_set_aux(DS_CHAIN_AUX_FIR) */
+#define DS_ALGO_FDGSC 21       /* FDGSC.process (beamformer/FDGSC.py:201-317, blocking-matrix mode 3) as ONE handle: DC notch -> FIR bank + mean ->
+                                  MCRA (L = 60) on channel 0 + the :248-255 adaptation control -> M clamped adaptive blocking filters (one
+                                  batched launch, shared fixed-beamformer input, half-block-delayed aligned channels as desired signals) ->
+                                  norm-limited multichannel canceller on the one-block-delayed fixed output -> optional OMLSA post-filter
+                                  (block-sequential like the reference: its two signals share one Transform); ds_fdgsc_process */
 
 /* `mem` argument of the frame-level entry points */
 #define DS_MEM_HOST 0
@@ -146,6 +155,7 @@ typedef struct ds_config {
 #define DS_PARAM_FDAF_WEIGHT_NORM 12 /* int 0/1: norm limiter of the canceller (gsc_aic.py:81-88); default 0 */
 #define DS_PARAM_WPE_DELAY 13        /* int >= 0: prediction delay of the DS_ALGO_WPE_MVDR chain in frames (awpe.py:36, default 4); set before the first call */
 #define DS_PARAM_MCSPP_REPEAT 14     /* int 0/1: DS_ALGO_MCSPP handles run estimation(repeat=True): a second estimation_core after the noise update (mcspp.py:280-282); default 0 */
+#define DS_PARAM_POSTFILTER 15       /* int 0/1: DS_ALGO_TDGSC / DS_ALGO_FDGSC handles apply the OMLSA post-filter in ds_process_device; default 0 */
 #define DS_PARAM_SPLIT 8   /* int: utterance groups run as parallel hipGraph branches in ds_process_device_seq(graph=1); default 1 */
 
 /* ds_get_state fields; all arrays are float32, complex = interleaved (re, im) */
@@ -269,6 +279,14 @@ int ds_chain_set_aux(ds_handle* h, int which, const float* table, size_t n_float
  * output delayed by one block), bm_output [B][M][n], p [B][T][K], aligned [B][M][n] — the tuple SubbandGSC.process returns */
 int ds_subband_gsc_process(ds_handle* h, const float* x, int n_samples, float* y, float* fix_output, float* bm_output, float* p,
                            float* aligned, int mem);
+/* DS_ALGO_TDGSC: x [B][M][n] channel-major (n a multiple of frameLen = hop) -> out [B][n]; optional (NULL to skip) p [B][T][K] (MCRA speech
+ * presence probability per block), bm [B][n][M-1] (blocking-matrix outputs), w [B][frameLen][M-1] (canceller coefficients after the
+ * last block) — TDGSC.process's tuple (+ aic_filter.w) */
+int ds_tdgsc_process(ds_handle* h, const float* x, int n_samples, int postfilter, float* out, float* p, float* bm, float* w, int mem);
+/* DS_ALGO_FDGSC: x [B][M][n] channel-major -> out [B][n]; optional p [B][T][K], fix_output [B][n], fix_output_delayed [B][n], bm_output
+ * [B][M][n], aligned [B][M][n], aligned_delayed [B][M][n] (channel-major), w_aic [B][frameLen][M], w_bm [B*M][frameLen] — FDGSC.process's tuple */
+int ds_fdgsc_process(ds_handle* h, const float* x, int n_samples, int postfilter, int dc_notch, float* out, float* p, float* fix_output,
+                     float* fix_delayed, float* bm_output, float* aligned, float* aligned_delayed, float* w_aic, float* w_bm, int mem);
 int ds_adaptive_frames(ds_handle* h, const float* Z, const float* gain, int n_frames, float* Y, int mem);
 int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* p, int p_mode, int n_blocks, int fir_truncate,
                    float* err, float* w_out, int mem);

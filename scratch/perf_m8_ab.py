@@ -1,4 +1,4 @@
-"""8-microphone adaptive MVDR frame kernel: quad-spread per-bin program (default) vs one thread per bin (DS_M8_ONE_THREAD=1), B = 1024,
+"""8-microphone adaptive MVDR frame kernel: quad-spread per-bin program (DS_M8_QUAD=1) vs one thread per bin (default), B = 1024,
 white-noise input, one hop per call and 40 hops per call.  python scratch/perf_m8_ab.py [nfft ...]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,6 +26,6 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         del x, y, eng
     print(" | ".join(out)); sys.exit(0)
 for nfft in (sys.argv[1:] or ["512", "1024"]):
-    for name, env in (("quad", {}), ("one-thread", {"DS_M8_ONE_THREAD": "1"})):
+    for name, env in (("quad", {"DS_M8_QUAD": "1"}), ("one-thread", {})):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", nfft], env=dict(os.environ, **env), capture_output=True, text=True)
         print("M=8 nfft=%4s %-10s %s" % (nfft, name, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:]), flush=True)

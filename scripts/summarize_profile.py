@@ -51,7 +51,6 @@ def pmc(sub):
 
 fe, wr = pmc("pmc_fetch"), pmc("pmc_write")
 traffic = {"tag": tag, "note": "HBM bytes = FETCH_SIZE*1024*2 (gfx950 wide-read correction) + WRITE_SIZE*1024; mean over the launches of the run", "kernels": {}}
-steps = None
 for k in fe:
     f = fe[k].get("FETCH_SIZE", [])
     w = wr.get(k, {}).get("WRITE_SIZE", [])
@@ -60,8 +59,9 @@ for k in fe:
     fb = sum(f) / len(f) * 1024 * 2
     wb = (sum(w) / len(w) * 1024) if w else 0.0
     traffic["kernels"][k[:100]] = {"launches": len(f), "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes_per_launch": fb + wb}
-    steps = len(f) if steps is None else min(steps, len(f))
 if traffic["kernels"]:
+    from collections import Counter
+    steps = Counter(v["launches"] for v in traffic["kernels"].values()).most_common(1)[0][0]      # the once-per-step kernels
     traffic["steps"] = steps
     traffic["hbm_bytes_per_step"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in traffic["kernels"].values()) / steps
     print("== HBM traffic (PMC), %d steps" % steps)

@@ -497,6 +497,47 @@ def test_fdgsc(ds, name):
     assert rms(out - g["output"]) < 1e-3 * rms(g["output"])
 
 
+@pytest.mark.parametrize("kind", ["tdgsc", "fdgsc"])
+def test_block_gsc_chain_handles(ds, kind):
+    """TDGSC / FDGSC run behind ONE native chain handle (DS_ALGO_TDGSC / DS_ALGO_FDGSC: nothing returns to the host between the stages):
+    batch rows == the same utterance alone, chunked == one call (bitwise, with and without the post-filter), checkpoint / resume into a
+    never-run object, reset, and the device-pointer entry point ds_process_device == the host entry point."""
+    from _cases import DeviceBuffers
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(31)
+    M, FL, T, B = 4, 256, 12, 3
+    x = (rng.standard_normal((B, T * FL, M)) * 0.05).astype(np.float32)
+    x[:, :, 1:] += 0.6 * x[:, :, :1]
+    mic = ds.MicArray(arrayType="circular", r=0.032, M=M, n_fft=512)
+    cls = ds.TDGSC if kind == "tdgsc" else ds.FDGSC
+    for pf in (False, True):
+        full = cls(mic, frameLen=FL, batch=B).process(x, postfilter=pf)
+        assert all(np.all(np.isfinite(a)) for a in full) and np.abs(full[0]).max() > 0
+        one = cls(mic, frameLen=FL).process(x[1], postfilter=pf)
+        assert all(np.array_equal(a, b[1]) for a, b in zip(one, full))                       # batch independence
+        obj = cls(mic, frameLen=FL, batch=B)
+        cut = 5 * FL
+        a1 = obj.process(x[:, :cut], postfilter=pf)
+        blob = obj._eng.export_state()
+        a2 = obj.process(x[:, cut:], postfilter=pf)
+        assert np.array_equal(np.concatenate([a1[0], a2[0]], axis=1), full[0])                # chunked == one call
+        fresh = cls(mic, frameLen=FL, batch=B)
+        fresh._eng.import_state(blob)                                                        # into an object that never ran
+        assert all(np.array_equal(u, v) for u, v in zip(a2, fresh.process(x[:, cut:], postfilter=pf)))
+        obj._eng.reset()
+        assert np.array_equal(obj.process(x, postfilter=pf)[0], full[0])
+    # device-pointer path (what bench.py drives): [B][M][n] in, [B][n] out
+    dv = DeviceBuffers()
+    xc = np.ascontiguousarray(np.swapaxes(x, 1, 2))
+    xd, yd = dv.upload(xc), dv.zeros(B * T * FL * 4)
+    e = cls(mic, frameLen=FL, batch=B)._eng
+    e.process_device(xd, L.LAYOUT_CHANNELS_SAMPLES, M * T * FL, T * FL, yd, T * FL)
+    e.synchronize()
+    ref = cls(mic, frameLen=FL, batch=B).process(x)[0]
+    assert np.array_equal(dv.download(yd, (B, T * FL)).astype(np.float64), ref)
+    dv.free()
+
+
 @pytest.mark.parametrize("M,nfft", [(8, 1024), (4, 512)])
 def test_wpe_mvdr_postfilter(ds, M, nfft):
     """BASELINE config 4 (8-mic, 1024-FFT: WPE dereverberation -> adaptive MVDR -> SPP gain) vs the oracle's composition of the

@@ -115,9 +115,9 @@ def test_gsc_batch_vs_oracle(ds):
 @pytest.mark.parametrize("nfft", [256, 512, 1024])
 def test_quad_kernel_equals_one_thread_kernel(ds, nfft):
     """8 microphones: the frame kernel whose per-bin program is spread over quads of lanes (ds_quad.hpp: rows l and 7 - l of the
-    covariance per lane, Cholesky column sweep over DPP quad broadcasts; no scratch) against the one-thread-per-bin
-    kernel it replaces (DS_M8_ONE_THREAD=1): same samples and the same exported state, bit for bit, for MVDR / DS / src, one call and
-    hop by hop; and against the fp64 oracle."""
+    covariance per lane, Cholesky column sweep over DPP quad broadcasts; no scratch; opt-in with DS_M8_QUAD=1
+    because it measured slower, see ds_kernels_adaptive_q.hip) against the one-thread-per-bin default: same samples and the same
+    exported state, bit for bit, for MVDR / DS / src, one call and hop by hop; and against the fp64 oracle."""
     from distantspeech_amd import _lib as L
     M, hop, B, T = 8, nfft // 2, 5, 24
     omic = oracle_mic(M, nfft, 0.05)
@@ -125,12 +125,12 @@ def test_quad_kernel_equals_one_thread_kernel(ds, nfft):
     a = steering(M, nfft, 0.05)
 
     def run(one_thread, method, chunked):
-        if one_thread:
-            os.environ["DS_M8_ONE_THREAD"] = "1"
+        if not one_thread:
+            os.environ["DS_M8_QUAD"] = "1"
         try:
             eng = ds.BatchEngine(L.ALGO_ADAPTIVE, M, nfft, batch=B)
         finally:
-            os.environ.pop("DS_M8_ONE_THREAD", None)
+            os.environ.pop("DS_M8_QUAD", None)
         eng.set_steering(a); eng.set_method(method)
         if chunked:
             y = np.concatenate([eng.process(xs[:, :, t * hop:(t + 1) * hop], L.LAYOUT_CHANNELS_SAMPLES) for t in range(T)], axis=1)
