@@ -61,6 +61,14 @@ WORKLOADS = {
     "cfg5": dict(algo="SUBBAND_GSC", M=6, nfft=512, hop=256, batch=2048, S=313440, r=0.05, filter_len=2, rls_lambda=0.998,
                  kernel="DS_ALGO_SUBBAND_GSC chain", launches=14, graph=1,
                  desc="Subband-RLS GSC chain (SubbandGSC.process with SubbandRLS blocking filters), 6 mics, 16 kHz, 512 bands / block 256"),
+    # the two overlap-save GSCs as chain handles, 4 mics, block 256; not BASELINE configs (--config tdgsc / fdgsc).
+    # S (fp32): TDGSC = canceller W 3*257*8 + P 257*4 + previous input block 3*256*4 + non-causal delay 128*4, MCRA 5*257*4, analysis tail
+    # 1024, FIR history 83*4*4, notch 32 = 18 304; FDGSC = 4 blocking filters (257*8 + 257*4 + 1024) + canceller (4*257*8 + 257*4 + 4096),
+    # MCRA 5140, analysis tails 2*1024, FIR history 1328, notch 32, delays 4*128*4 + 1024 = 39 316
+    "tdgsc": dict(algo="TDGSC", M=4, nfft=512, hop=256, batch=1024, S=18304, r=0.032, kernel="DS_ALGO_TDGSC chain", launches=6, graph=0,
+                  desc="TDGSC chain (TDGSC.process: FIR bank + blocking matrix + MCRA-controlled overlap-save canceller), 4 mics, 16 kHz, block 256"),
+    "fdgsc": dict(algo="FDGSC", M=4, nfft=512, hop=256, batch=1024, S=39316, r=0.032, kernel="DS_ALGO_FDGSC chain", launches=14, graph=0,
+                  desc="FDGSC chain (FDGSC.process: adaptive blocking filters + norm-limited canceller), 4 mics, 16 kHz, block 256"),
 }
 
 
@@ -180,12 +188,13 @@ class GpuWorkload:
                                rls_lambda=w.get("rls_lambda", 0.0))
         mic = MicArray(arrayType="circular", r=w["r"], M=M, n_fft=nfft)
         ang = np.array(ANGLE_DEG) / 180.0 * np.pi
-        if w["algo"] == "SUBBAND_GSC":
+        if w["algo"] in ("SUBBAND_GSC", "TDGSC", "FDGSC"):
             from distantspeech_amd.ops import McSpp
             from distantspeech_amd.subband_gsc import fractional_delay_filter_bank
             tau = compute_tau(mic, ang)
             self.eng.chain_set_aux(L.CHAIN_AUX_FIR, fractional_delay_filter_bank(np.array(-(tau - np.max(tau)))[:, 0] * mic.fs))
-            self.eng.chain_set_aux(L.CHAIN_AUX_COHERENCE, McSpp.diffuse_coherence(M, nfft))
+            if w["algo"] == "SUBBAND_GSC":
+                self.eng.chain_set_aux(L.CHAIN_AUX_COHERENCE, McSpp.diffuse_coherence(M, nfft))
         else:
             tao = -1 * mic.r * np.cos(ang[1]) * np.cos(ang[0] - mic.gamma) / mic.c          # adaptivebeamformer.py:52
             a = np.exp(-1j * (2 * np.pi * np.arange(nfft // 2 + 1) * FS / nfft)[:, None] * tao[None, :])
@@ -370,14 +379,15 @@ def main():
     out = None
     if rank == 0:
         regime = "streaming callback regime" if T == 1 else "chunked"
-        mics = {"cfg2": "4-mic, 512-FFT", "cfg3": "4-mic, 512-FFT", "fixed": "4-mic, 512-FFT", "cfg4": "8-mic, 1024-FFT", "cfg5": "6-mic, 512 bands"}[args.config]
+        mics = {"cfg2": "4-mic, 512-FFT", "cfg3": "4-mic, 512-FFT", "fixed": "4-mic, 512-FFT", "cfg4": "8-mic, 1024-FFT", "cfg5": "6-mic, 512 bands",
+                "tdgsc": "4-mic, block 256", "fdgsc": "4-mic, block 256"}[args.config]
         out = {
             "metric": "enhanced frames/sec (%s)" % mics, "value": res["value"], "unit": "frames/s",
             "n_gpus": res["ranks"], "steps": K, "warmup": W, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": be.name,
             "rounds": res["rounds"], "timed_steps": res["timed_steps"], "region_ms": res["region_ms"],
-            "config": {"workload": "BASELINE %s: %s, batch=%d utterances per GPU, %d hop(s) per call (%s), state resident in HBM"
-                                   % (args.config, w["desc"], B, T, regime),
+            "config": {"workload": "%s: %s, batch=%d utterances per GPU, %d hop(s) per call (%s), state resident in HBM"
+                                   % (("BASELINE " + args.config) if args.config.startswith("cfg") else args.config, w["desc"], B, T, regime),
                        "batch_per_gpu": B, "hops_per_call": T, "n_mics": w["M"], "nfft": w["nfft"], "hop": w["hop"],
                        "launch": "hipGraph replay of each round" if (w["graph"] if graph is None else graph) else "plain launches"},
             "roofline": res["roofline"],

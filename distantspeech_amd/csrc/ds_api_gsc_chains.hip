@@ -159,10 +159,11 @@ static int front_end(ds_handle* h, const float* x, long long x_bstride, long lon
 
 // OMLSA post-filter of a signal of T blocks against reference spectra U (TDGSC.py:158-170 / FDGSC.py:286-298): analysis and synthesis on
 // the shared transform_fbf `tf`; U_frames = T (one reference frame per block) or 1 (the same frame for every block)
-static int postfilter_blocks(ds_handle* h, ds_handle* tf, ds_handle* om, const float* sig, int n, const float* U, float* out, long long out_bstride) {
+static int postfilter_blocks(ds_handle* h, ds_handle* tf, ds_handle* om, const float* sig, long long sig_bstride, int n, const float* U, float* out,
+                             long long out_bstride) {
     float** cb = h->chain_buf;
     const int T = n / h->cfg.hop;
-    int rc = tf_stft(h, tf, sig, n, 1, n, n, cb[Q_Y]); if (rc) return rc;
+    int rc = tf_stft(h, tf, sig, sig_bstride, 1, sig_bstride, n, cb[Q_Y]); if (rc) return rc;
     rc = ds_omlsa_postfilter(om, cb[Q_Y], U, T, cb[Q_G], cb[Q_Y2], DS_MEM_DEVICE); if (rc) return fail(h, rc, om->err);
     return tf_istft(h, tf, cb[Q_Y2], T, out, out_bstride);
 }
@@ -185,7 +186,7 @@ int tdgsc_run(ds_handle* h, const float* x, long long x_bstride, long long x_cst
     GS_SUB(3, fdaf_run_dev(h->sub[3], cb[Q_BM], cb[Q_FIXED], cb[Q_P], DS_FDAF_P_BIN | DS_FDAF_P_COMPLEMENT, (int)T, 30, o1, w_dev, 0, 0, 0, 0));
     if (postfilter) {                                                                                        // :158-170
         rc = tf_stft(h, h->sub[5], cb[Q_BM], (long long)n * (M - 1), (long long)(M - 1), 1, n, cb[Q_U]); if (rc) return rc;
-        rc = postfilter_blocks(h, h->sub[4], h->sub[6], cb[Q_OUT], n, cb[Q_U], out, out_bstride); if (rc) return rc;
+        rc = postfilter_blocks(h, h->sub[4], h->sub[6], cb[Q_OUT], (long long)N, n, cb[Q_U], out, out_bstride); if (rc) return rc;
     } else if (o1 != out) {
         DS_HIP(h, hipMemcpy2DAsync(out, (size_t)out_bstride * 4, o1, N * 4, N * 4, B, hipMemcpyDeviceToDevice, h->stream));
     }
@@ -241,7 +242,7 @@ int fdgsc_run(ds_handle* h, const float* x, long long x_bstride, long long x_cst
                 rc = tf_stft(h, tu, prev, (long long)(M * FL), 1, (long long)FL, (int)FL, cb[Q_U]); if (rc) return rc;
                 rc = tf_stft(h, tu, cb[Q_BM], (long long)(M * N), 1, (long long)N, (int)FL, cb[Q_U]); if (rc) return rc;   // channels 0 .. M-2 of block 0
             }
-            rc = postfilter_blocks(h, tf, om, cb[Q_OUT] + blk * FL, (int)FL, cb[Q_U], out + blk * FL, out_bstride);
+            rc = postfilter_blocks(h, tf, om, cb[Q_OUT] + blk * FL, (long long)N, (int)FL, cb[Q_U], out + blk * FL, out_bstride);
             if (rc) return rc;
         }
         DS_HIP(h, hipMemcpy2DAsync(cb[Q_BMLAST], FL * 4, (char*)cb[Q_BM] + (N - FL) * 4, N * 4, FL * 4, B * M, hipMemcpyDeviceToDevice, h->stream));

@@ -3,14 +3,15 @@
 //   Rls.update                 adaptivefilter/RLS.py:26-42
 // One workgroup per utterance walks the samples of the call in order; taps are spread over the lanes, the two
 // inner products of a sample are reduced through LDS in a fixed order (bitwise reproducible, and identical in the
-// serial CPU run of tests/emul).  NLMS: up to 1024 taps; RLS: up to 64 taps (P = L x L lives in LDS).
+// serial CPU run of tests/emul).  NLMS: up to 1024 taps; RLS: up to 64 taps with P = L x L in LDS, up to 256 taps (the reference's
+// example/RLS.ipynb) with P left in device memory (256 KB per utterance: L2-resident while the workgroup walks the samples).
 #pragma once
 #include "ds_core.hpp"
 
 namespace ds {
 
 enum { TDF_NLMS = 0, TDF_RLS = 1 };
-constexpr int TDF_NT = 256, TDF_LMAX = 1024, TDF_RLS_LMAX = 64;
+constexpr int TDF_NT = 256, TDF_LMAX = 1024, TDF_RLS_LDS = 64, TDF_RLS_LMAX = 256;
 
 struct TdfParams {
     int B, n, L, mode;
@@ -29,7 +30,7 @@ struct TdfShared {
     float w[TDF_LMAX];
     float part[2][TDF_NT];
     float part2[2][16];
-    float P[TDF_RLS_LMAX][TDF_RLS_LMAX + 1];
+    float P[TDF_RLS_LDS][TDF_RLS_LDS + 1];
     float num[TDF_RLS_LMAX], xtp[TDF_RLS_LMAX], kn[TDF_RLS_LMAX];
     int pos;
 };
@@ -49,9 +50,11 @@ struct TdfEngine {
         const float* x = p.x + (long long)b * p.n;
         const float* d = p.d + (long long)b * p.n;
         float* e = p.err + (long long)b * p.n;
+        const bool p_lds = L <= TDF_RLS_LDS;                         // P in LDS, else in place in device memory
+        auto Pat = [&](int r, int c) -> float& { return p_lds ? sh.P[r][c] : Pg[(long long)r * L + c]; };
         ex.phase([&](int tid, Rg&) {
             for (int i = tid; i < L; i += NT) { sh.buf[i] = bg[i]; sh.w[i] = wg[i]; }
-            if (p.mode == TDF_RLS)
+            if (p.mode == TDF_RLS && p_lds)
                 for (int i = tid; i < L * L; i += NT) sh.P[i / L][i % L] = Pg[i];
             if (tid == 0) sh.pos = 0;
         });
@@ -90,8 +93,8 @@ struct TdfEngine {
                         float a = 0.0f, r = 0.0f;
                         for (int j = 0; j < L; ++j) {
                             const float v = sh.buf[(np + j) % L];
-                            a = fma_(sh.P[tid][j], v, a);
-                            r = fma_(v, sh.P[j][tid], r);
+                            a = fma_(Pat(tid, j), v, a);
+                            r = fma_(v, Pat(j, tid), r);
                         }
                         sh.num[tid] = a; sh.xtp[tid] = r;
                     }
@@ -116,7 +119,7 @@ struct TdfEngine {
                     const float li = 1.0f / p.lam;
                     for (int i = tid; i < L * L; i += NT) {
                         const int r = i / L, c = i % L;
-                        sh.P[r][c] = fma_(-sh.kn[r], sh.xtp[c], sh.P[r][c]) * li;
+                        Pat(r, c) = fma_(-sh.kn[r], sh.xtp[c], Pat(r, c)) * li;
                     }
                 });
             }
@@ -125,7 +128,7 @@ struct TdfEngine {
             // store the shift register back in logical order (tap 0 first)
             const int fin = (L - (p.n % L)) % L;
             for (int j = tid; j < L; j += NT) { bg[j] = sh.buf[(fin + j) % L]; wg[j] = sh.w[j]; }
-            if (p.mode == TDF_RLS)
+            if (p.mode == TDF_RLS && p_lds)
                 for (int i = tid; i < L * L; i += NT) Pg[i] = sh.P[i / L][i % L];
         });
     }

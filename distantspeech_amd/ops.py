@@ -552,7 +552,7 @@ class BaseFilter(_Base):
 
 
 class Rls(BaseFilter):
-    """Sample-wise time-domain RLS — adaptivefilter/RLS.py:14-42 (filter_len <= 64 on the GPU: P lives in LDS)."""
+    """Sample-wise time-domain RLS — adaptivefilter/RLS.py:14-42 (filter_len <= 256: P lives in LDS up to 64 taps, in device memory beyond)."""
 
     def __init__(self, filter_len=1024, mu=0.5, forgetting_factor=0.9998, delta=1e-3, normalization=True, batch=1, device=-1):
         if delta != 1e-3:

@@ -70,7 +70,7 @@ extern "C" {
 #define DS_ALGO_LINALG 12    /* stateless per-bin helpers: steering(), compute_mvdr_weight()   beamformer/beamformer.py:10-31,133-155 */
 #define DS_ALGO_FRONTEND 13  /* time-domain conditioning: FilterDcNotch16 (feature.py:32-49), TimeAlignment FIR bank (fixedbeamformer.py:13-93) */
 #define DS_ALGO_TDNLMS 14     /* BaseFilter.update (sample-wise NLMS)  adaptivefilter/BaseFilter.py:52-85; filter_len <= 1024 */
-#define DS_ALGO_TDRLS 15      /* Rls.update (sample-wise RLS)         adaptivefilter/RLS.py:26-42; filter_len <= 64 */
+#define DS_ALGO_TDRLS 15      /* Rls.update (sample-wise RLS)         adaptivefilter/RLS.py:26-42; filter_len <= 256 (P in LDS up to 64 taps, in device memory beyond) */
 #define DS_ALGO_FDAF 16       /* overlap-save FDAF block filters: FastFreqLms.update (adaptivefilter/FastFreqLms.py:204-245),
                                  AdaptiveBlockingMatrixFilter.update (beamformer/gsc_bm.py:61-122), AdaptiveInterferenceCancellation.update
                                  (beamformer/gsc_aic.py:53-108); nfft = 2 * filter_len in {128,256,512,1024}, n_mics = input channels <= 8 */

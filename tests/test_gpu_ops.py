@@ -413,7 +413,19 @@ def test_td_filters(ds):
     assert rms(rl.w[:, 0] - g["w_rls"]) < 2e-2 * rms(g["w_rls"])
     from distantspeech_amd import _lib as L
     with pytest.raises(L.DsError):
-        ds.Rls(filter_len=1024)                                                   # P = 1024 x 1024 does not fit the LDS design
+        ds.Rls(filter_len=1024)                                                   # beyond the 256 taps the kernel is built for
+    # more than 64 taps: P stays in device memory; 128 taps against the fp64 oracle
+    from oracle import ds_oracle as O
+    rng = np.random.default_rng(5)
+    Lr, n = 128, 600
+    hh = rng.standard_normal(Lr) * np.exp(-np.arange(Lr) / 25.0)
+    xr = rng.standard_normal(n)
+    dr = np.convolve(xr, hh)[:n] + 1e-3 * rng.standard_normal(n)
+    o = O.OracleRls(filter_len=Lr)
+    ref = np.array([o.update(xr[i], dr[i])[0] for i in range(n)])
+    big = ds.Rls(filter_len=Lr)
+    e = np.array([big.update(xr[i], dr[i])[0] for i in range(n)]).reshape(-1)
+    assert rms(e - ref) < 2e-2 * rms(ref) and rms(big.w[:, 0] - o.w) < 2e-2 * rms(o.w)
 
 
 def _fdaf_obj(ds, case, g, batch=1):

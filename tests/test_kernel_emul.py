@@ -311,6 +311,23 @@ def test_emul_td_filters_golden():
     assert rms(rl.w[0] - g["w_rls"]) < 2e-2 * rms(g["w_rls"])
 
 
+def test_emul_rls_beyond_the_lds_matrix():
+    """Rls with more than 64 taps keeps P in device memory instead of LDS (ds_tdfilter.hpp): 96 taps against the fp64 oracle."""
+    from emul.emul import EmulTdFilter
+    from oracle import ds_oracle as O
+    rng = np.random.default_rng(5)
+    L, n = 96, 400
+    h = rng.standard_normal(L) * np.exp(-np.arange(L) / 20.0)
+    x = rng.standard_normal(n)
+    d = np.convolve(x, h)[:n] + 1e-3 * rng.standard_normal(n)
+    o = O.OracleRls(filter_len=L)
+    ref = np.array([o.update(x[i], d[i])[0] for i in range(n)])
+    f = EmulTdFilter(1, L, 0.5, lam=0.9998)
+    e = f.update(x[None].astype(np.float32), d[None].astype(np.float32))[0]
+    assert rms(e - ref) < 2e-2 * rms(ref)
+    assert rms(f.w[0] - o.w) < 2e-2 * rms(o.w)
+
+
 @pytest.mark.parametrize("case,kind", [("a", 0), ("b", 0), ("c", 1), ("d", 2)])
 def test_emul_fdaf_golden(case, kind):
     """overlap-save FDAF block program (ds_fdaf.hpp: plain / clamped blocking filter / norm-limited canceller) vs the
