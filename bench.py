@@ -340,6 +340,48 @@ def cpu_baseline(budget_s=10.0):
             "per_core": round(total / busy / cores, 1)}
 
 
+# CPU baseline of the chain / GSC configs: the NumPy restatements of oracle/ds_oracle.py (fp64, pinned to the reference's golden vectors),
+# one worker process per host core, each on its own synthetic utterance, one hop per call like the reference's loop
+def _cpu_oracle_worker(args):
+    name, seed, frames = args
+    import numpy as np
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from oracle import ds_oracle as O
+    w = WORKLOADS[name]
+    M, nfft, hop = w["M"], w["nfft"], w["hop"]
+    mic = O.OracleMicArray(arrayType="circular", r=w["r"], M=M, n_fft=nfft)
+    ang = np.array(ANGLE_DEG) / 180.0 * np.pi
+    x = O.synth_utterance(seed, hop * frames, mic) * (0.2 if name != "cfg4" else 1.0)
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        if name == "cfg3":
+            O.OracleGSC(mic, nfft, with_dead_state=False).process(x, ang, 2)
+        elif name == "cfg4":
+            O.OracleWpeMvdrPostfilter(mic, nfft=nfft, hop=hop).process(x, ang)
+        else:
+            O.OracleSubbandGSC(mic, frameLen=hop, rls_bm=True).process(x)
+    return frames, time.perf_counter() - t0
+
+
+def cpu_baseline_oracle(name, budget_s=3.0):
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    f0, t0 = _cpu_oracle_worker((name, 0, 24))                      # calibrate on one core (includes the first-frame branches)
+    frames = int(max(24, min(2000, f0 / t0 * budget_s)))
+    t_start = time.perf_counter()
+    with ProcessPoolExecutor(cores, mp_context=mp.get_context("spawn")) as pool:
+        res = list(pool.map(_cpu_oracle_worker, [(name, 1 + u, frames) for u in range(cores)]))
+    wall = time.perf_counter() - t_start
+    busy = max(r[1] for r in res)
+    total = sum(r[0] for r in res)
+    return {"value": round(total / busy, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d processes x %d hops (one synthetic utterance each), oracle/ds_oracle.py (NumPy, fp64), one process per core; %.1f s wall incl. start-up"
+                      % (cores, frames, wall),
+            "per_core": round(total / busy / cores, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -365,6 +407,11 @@ def main():
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but %d rank(s) were launched (WORLD_SIZE)\n" % (args.gpus, world))
         sys.exit(2)
+    # the NumPy-oracle CPU baselines of the other configs run in worker processes: started here, before this process touches the GPU
+    cpu_pre = {}
+    if world == 1 and not args.no_cpu_baseline and not args.no_extras and args.config == "cfg2" and not os.environ.get("DS_BENCH_BACKEND"):
+        for name in ("cfg3", "cfg4", "cfg5"):
+            cpu_pre[name] = cpu_baseline_oracle(name)
     be = load_backend(local_rank, world)
     dsdist.init(backend=be.dist_backend)
 
@@ -426,6 +473,9 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2" and not os.environ.get("DS_BENCH_BACKEND"):
             out["cpu_baseline"] = cpu_baseline()
+            for name in out.get("other_configs", {}):
+                if name in cpu_pre:
+                    out["other_configs"][name]["cpu_baseline"] = cpu_pre[name]
         print(json.dumps(out), flush=True)
     dsdist.finalize()
 

@@ -10,18 +10,29 @@ using namespace dsi;
 
 namespace ds {
 // FDGSC.py:248-255,282 per (utterance, block): if the mean speech presence probability over bins 32 .. 127 exceeds 0.8, the bins below 32
-// are raised to at least 0.8; pa = 1 - mean over all bins of the (modified) row.  One wave per row, sums in double in bin order.
+// are raised to at least 0.8; pa = 1 - mean over all bins of the (modified) row.  One wave per row: every lane adds its bins (stride 64)
+// in double, the lanes' sums meet in a fixed butterfly order.
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 __global__ void __launch_bounds__(256) ds_fdgsc_control_kernel(float* p, float* pa, int rows, int K) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = blockIdx.x * 4 + wv;
-    if (r >= rows || lane != 0) return;
+    if (r >= rows) return;
     float* row = p + (long long)r * K;
-    double mid = 0.0;
-    for (int k = 32; k < 128 && k < K; ++k) mid += (double)row[k];
-    if (mid / 96.0 > 0.8)
-        for (int k = 0; k < 32; ++k) if (row[k] < 0.8f) row[k] = 0.8f;
-    double all = 0.0;
-    for (int k = 0; k < K; ++k) all += (double)row[k];
-    pa[r] = (float)(1.0 - all / (double)K);
+    double mid = 0.0, all = 0.0;
+    float first = 0.0f;                                                 // this lane's bin `lane` (the only one the threshold can change)
+    for (int k = lane; k < K; k += 64) {
+        const float v = row[k];
+        if (k == lane) first = v; else all += (double)v;
+        if (k >= 32 && k < 128) mid += (double)v;
+    }
+    mid = wave_sum(mid);
+    if (mid / 96.0 > 0.8 && lane < 32 && first < 0.8f) { first = 0.8f; row[lane] = 0.8f; }
+    if (lane < K) all += (double)first;
+    all = wave_sum(all);
+    if (lane == 0) pa[r] = (float)(1.0 - all / (double)K);
 }
 }  // namespace ds
 

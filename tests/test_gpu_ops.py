@@ -92,7 +92,7 @@ def test_mcmcra(ds, name):
     assert np.mean(np.abs(p - g["p"]) > 2e-2) < 0.02
     assert np.median(np.abs(G - g["G"])) < 1e-4 and np.mean(np.abs(G - g["G"]) > 2e-2) < 0.02
     assert est.Phi_vv.shape == (M, M, nfft // 2 + 1)
-    assert rms(est.Phi_vv - ref) < 2e-2 * rms(ref)
+    assert rms(est.Phi_vv - ref) < 2e-3 * rms(ref)                          # measured 2e-4 ... 3e-4
 
 
 def test_omlsa(ds):

@@ -51,7 +51,7 @@ def test_adaptive_vs_reference_golden(ds, name):
     assert m["Rvv_relmax"] < 5e-5 and m["Ryy_relmax"] < 5e-5           # state read-back (measured: see profiles/r02_parity_measured.jsonl)
     assert np.mean(dp > 1e-3) < 0.02
     if method == 2:
-        assert m["H_rel_rms"] < 1e-2
+        assert m["H_rel_rms"] < 5e-4                                       # measured 4e-5 ... 9e-5
     # whole recording in one call on a fresh object == hop-by-hop
     ab2 = ds.adaptivebeamfomer(_mic(ds, M, nfft, float(g["r"])), frameLen=nfft, hop=hop, nfft=nfft)
     y2 = ab2.process(x, ANGLE, method=method)["data"]
@@ -82,7 +82,7 @@ def test_gsc_vs_reference_golden(ds, name):
     measured("G6_gsc_" + name, **m)
     assert m["y_rms"] < TOL_RMS
     if method != 0:
-        assert m["G_aic_rel_rms"] < 2e-2
+        assert m["G_aic_rel_rms"] < 1e-2                                   # measured 2e-4 ... 4e-3 (the weights integrate fp32 p errors)
 
 
 # ------------------------------------------------------------------------------------------------
