@@ -124,11 +124,18 @@ class GpuBackend:
         self.torch = torch
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-        if torch.cuda.device_count() <= local_rank:
-            raise SystemExit("rank with LOCAL_RANK=%d but only %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
-        torch.cuda.set_device(local_rank)
-        self.local_rank = local_rank
-        self.device = torch.device("cuda", local_rank)
+        # DS_FORCE_DEVICE=<ordinal> (with DS_DIST_BACKEND=gloo): every rank on that one GPU — exercises the real rank path (sharding, barrier,
+        # reduce, one JSON line) on a single-GPU box; the line then says so in `config.note` and is not a scaling measurement
+        forced = os.environ.get("DS_FORCE_DEVICE")
+        dev = int(forced) if forced is not None else local_rank
+        if torch.cuda.device_count() <= dev:
+            raise SystemExit("rank with LOCAL_RANK=%d needs GPU %d but only %d GPU(s) are visible" % (local_rank, dev, torch.cuda.device_count()))
+        torch.cuda.set_device(dev)
+        self.local_rank = dev
+        self.shared_device = forced is not None and world > 1
+        self.device = torch.device("cuda", dev)
+        if self.shared_device:
+            self.dist_backend = "gloo"
 
     def device_sync(self):
         self.torch.cuda.synchronize()
@@ -439,6 +446,8 @@ def main():
                        "launch": "hipGraph replay of each round" if (w["graph"] if graph is None else graph) else "plain launches"},
             "roofline": res["roofline"],
         }
+        if getattr(be, "shared_device", False):
+            out["config"]["note"] = "all %d ranks share GPU %d (DS_FORCE_DEVICE, gloo): rank-path check, not a scaling measurement" % (world, be.local_rank)
         if T == 1 and B == w["batch"]:
             attach_traffic(out["roofline"], args.config)
 

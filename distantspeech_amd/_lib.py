@@ -19,6 +19,7 @@ ALGO_SUBBAND_GSC = 19
 ALGO_TDGSC = 20
 ALGO_FDGSC = 21
 PARAM_POSTFILTER = 15
+PARAM_FDAF_TWO_PATH = 16
 CHAIN_AUX_FIR, CHAIN_AUX_COHERENCE = 0, 1
 PARAM_WPE_DELAY = 13
 PARAM_MCSPP_REPEAT = 14
@@ -57,7 +58,7 @@ _lib = None
 # every symbol include/dsenh.h declares (tests check that the built library exports all of them)
 EXPORTS = [
     "ds_version", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
-    "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_process", "ds_process_pcm16", "ds_process_device",
+    "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_set_window", "ds_process", "ds_process_pcm16", "ds_process_device",
     "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcra_estimate_p", "ds_mcmcra_estimate", "ds_mcsppbase_estimate", "ds_set_aux", "ds_mcspp_estimate", "ds_steering",
     "ds_mvdr_weight", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process", "ds_tdgsc_process", "ds_fdgsc_process",
     "ds_omlsa_estimate", "ds_omlsa_postfilter",
@@ -140,6 +141,8 @@ def load():
     lib.ds_chain_set_aux.argtypes = [vp, ci, vp, csz]
     lib.ds_subband_gsc_process.restype = ci
     lib.ds_subband_gsc_process.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, ci]
+    lib.ds_set_window.restype = ci
+    lib.ds_set_window.argtypes = [vp, vp, ci]
     lib.ds_tdgsc_process.restype = ci
     lib.ds_tdgsc_process.argtypes = [vp, vp, ci, ci, vp, vp, vp, vp, ci]
     lib.ds_fdgsc_process.restype = ci

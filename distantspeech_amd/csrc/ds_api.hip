@@ -338,7 +338,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->dev_cnt = nullptr; h->use_dev_cnt = false;
     h->owner = nullptr; h->pend_set = false; h->pend_stream = nullptr; h->pend = ds::TickArgs{nullptr, 0, 1, 0, 0};
     h->x_fan = 1; h->p_complement = 0; h->d_interleaved = 0; h->d_prev = nullptr;
-    h->fdaf_kind = DS_FDAF_PLAIN; h->fdaf_constrain = 1; h->fdaf_non_causal = 0; h->fdaf_weight_norm = 0;
+    h->fdaf_kind = DS_FDAF_PLAIN; h->fdaf_constrain = 1; h->fdaf_non_causal = 0; h->fdaf_weight_norm = 0; h->fdaf_two_path = 0;
     for (int i = 0; i < 10; ++i) h->sub[i] = nullptr;
     for (int i = 0; i < 24; ++i) { h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0; }
     h->postfilter = 0;
@@ -552,6 +552,7 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
         case DS_PARAM_FDAF_CONSTRAIN: h->fdaf_constrain = value != 0; return DS_OK;
         case DS_PARAM_FDAF_NON_CAUSAL: h->fdaf_non_causal = value != 0; return DS_OK;
         case DS_PARAM_FDAF_WEIGHT_NORM: h->fdaf_weight_norm = value != 0; return DS_OK;
+        case DS_PARAM_FDAF_TWO_PATH: h->fdaf_two_path = value != 0; return DS_OK;
         case DS_PARAM_POSTFILTER:
             if (h->cfg.algo != DS_ALGO_TDGSC && h->cfg.algo != DS_ALGO_FDGSC) return fail(h, DS_EINVAL, "postfilter: TDGSC / FDGSC chain handles only");
             h->postfilter = value != 0;
@@ -566,6 +567,22 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
             return DS_OK;
         default: return fail(h, DS_EINVAL, "unknown int parameter id");
     }
+}
+
+int ds_set_window(ds_handle* h, const float* window, int n) {
+    if (!h || !window) return fail(h, DS_EINVAL, "ds_set_window: NULL argument");
+    if (h->cfg.algo != DS_ALGO_TRANSFORM) return fail(h, DS_ESTATE, "ds_set_window: handle is not a DS_ALGO_TRANSFORM object");
+    if (n != h->cfg.nfft) return fail(h, DS_ESHAPE, "ds_set_window: the window must have nfft samples");
+    int rc = set_device(h); if (rc) return rc;
+    const int N = h->cfg.nfft, NC = N / 2, NSTW = NC == 512 ? 512 : 128;
+    double W0 = 0.0;
+    for (int i = 0; i < N; ++i) W0 += (double)window[i] * (double)window[i];
+    if (!(W0 > 0.0)) return fail(h, DS_EINVAL, "ds_set_window: the window has no energy");
+    DS_HIP(h, hipStreamSynchronize(h->stream));
+    float* win_dev = reinterpret_cast<float*>(h->tables) + (size_t)(NC + 2) * 2 + (size_t)NSTW * 4;      // Tables<NFFT>::win (ds_tables.hpp)
+    DS_HIP(h, hipMemcpy(win_dev, window, (size_t)N * sizeof(float), hipMemcpyHostToDevice));
+    h->out_scale = (float)((double)h->cfg.hop / W0);                                                   // transform.py:428,479
+    return DS_OK;
 }
 
 int ds_set_param_f(ds_handle* h, int id, float value) {

@@ -27,6 +27,7 @@ int fdaf_run_dev(ds_handle* h, const float* x, const float* d, const float* pp, 
     std::memset(&p, 0, sizeof p);
     p.B = h->cfg.batch; p.T = n_blocks; p.C = h->cfg.n_mics;
     p.kind = h->fdaf_kind; p.constrain = h->fdaf_constrain; p.non_causal = h->fdaf_non_causal; p.weight_norm = h->fdaf_weight_norm;
+    p.two_path = h->fdaf_two_path && h->fdaf_kind == DS_FDAF_PLAIN;
     p.trunc = fir_truncate < 0 ? -1 : fir_truncate; p.p_mode = p_mode & 3; p.p_complement = (p_mode & DS_FDAF_P_COMPLEMENT) ? 1 : 0;
     p.mu = h->filt_mu; p.alpha = h->filt_alpha;
     p.x = x; p.d = d; p.p = pp; p.err = err; p.w_out = w_out;

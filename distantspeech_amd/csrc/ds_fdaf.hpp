@@ -20,6 +20,9 @@ struct FdafParams {
     int trunc;                // fir_truncate, < 0 = None
     int p_mode;               // 0: p = 1, 1: one p per block [B][T], 2: per bin [B][T][K]
     int p_complement;         // use 1 - p (TDGSC.py:154 hands the canceller p = 1 - p)
+    int two_path;             // FastFreqLms(two_path=True), plain kind only: a foreground copy of the filter produces the output, the adapting
+                              // (background) filter is copied into it whenever the foreground error exceeds the background error by 3 dB
+                              // (FastFreqLms.py:94-104,162-176)
     float mu, alpha;
     const float* x;           // [B][T * HOP][C] by default; see the x_* fields
     // input addressing for device-resident chains (all 0 = the dense default): instance b reads the input of instance-group b / x_fan
@@ -31,14 +34,14 @@ struct FdafParams {
     const float* p;
     float* err;               // [B][T * HOP]
     float* w_out;             // [B][HOP][C] time-domain coefficients after the last block, or null
-    float* state;             // per instance: W [C][K] cf | P [K] | previous input block [C][HOP] | tail of d [HOP / 2]
+    float* state;             // per instance: W [C][K] cf | P [K] | previous input block [C][HOP] | tail of d [HOP / 2] | foreground [C][K] cf
     long long state_stride;   // floats between instances (>= fdaf_state_floats)
     const vec4* tables;
 };
 
 // floats of state per filter instance (dold: the non_causal delay of filter_len / 2 samples, FastFreqLms.py:85)
 DS_HD constexpr long long fdaf_state_floats(int nfft, int C) {
-    return 2LL * C * (nfft / 2 + 1) + (nfft / 2 + 1) + (long long)C * (nfft / 2) + nfft / 4;
+    return 2LL * C * (nfft / 2 + 1) + (nfft / 2 + 1) + (long long)C * (nfft / 2) + nfft / 4 + 2LL * C * (nfft / 2 + 1);
 }
 
 template <int NFFT, int CMAX> struct FdafShared {
@@ -52,6 +55,7 @@ template <int NFFT, int CMAX> struct FdafShared {
     cf nyqS[CMAX];            // Nyquist bin of the spectra handed to a synthesis transform
     cf nyqW[CMAX];            // Nyquist bin of W, X (real-valued; kept as cf for uniform code), P
     cf nyqX[CMAX];
+    cf nyqF[CMAX];            // Nyquist bin of the foreground filter (two_path)
     float nyqP;
     float red[NC];
     float red2[16];
@@ -60,6 +64,7 @@ template <int NFFT, int CMAX> struct FdafShared {
 template <int CMAX> struct FdafRegs {
     cf W[CMAX];
     cf X[CMAX];
+    cf F[CMAX];               // foreground filter (two_path)
     float P;
 };
 
@@ -141,6 +146,8 @@ template <int NFFT, int CMAX> struct FdafEngine {
         float* Pg = st + 2 * C * K;
         float* xog = Pg + K;
         float* dog = xog + C * HOP;
+        cf* Fg = reinterpret_cast<cf*>(dog + HOP / 2);
+        const bool two_path = p.two_path && p.kind == FDAF_PLAIN && CMAX >= 2;
         cf* fa = &sh.fa[0][0];
         cf* fb = &sh.fb[0][0];
         cf* const res = RES_IS_FB ? fb : fa;       // result of a transform
@@ -158,8 +165,14 @@ template <int NFFT, int CMAX> struct FdafEngine {
             for (int c = 0; c < CMAX; ++c)
                 if (c < C) r.W[c] = Wg[c * K + tid];
             r.P = Pg[tid];
+            if (two_path) {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) r.F[c] = Fg[c * K + tid];
+            }
             if (tid == 0) {
                 for (int c = 0; c < C; ++c) sh.nyqW[c] = Wg[c * K + NC];
+                if (two_path) for (int c = 0; c < C; ++c) sh.nyqF[c] = Fg[c * K + NC];
                 sh.nyqP = Pg[NC];
             }
         });
@@ -187,7 +200,7 @@ template <int NFFT, int CMAX> struct FdafEngine {
             ex.phase([&](int tid, Rg& r) {
                 const int k = tid;
                 float pw = 0.0f;
-                cf y = mk(0.0f, 0.0f);
+                cf y = mk(0.0f, 0.0f), yf = mk(0.0f, 0.0f);
 #pragma unroll
                 for (int c = 0; c < CMAX; ++c)
                     if (c < C) {
@@ -195,29 +208,81 @@ template <int NFFT, int CMAX> struct FdafEngine {
                         r.X[c] = X;
                         pw += cabs2(X);
                         y = cadd(y, cmul(X, r.W[c]));
+                        if (two_path) yf = cadd(yf, cmul(X, r.F[c]));
                     }
                 r.P = fma_(p.alpha, r.P, (1.0f - p.alpha) * pw);
                 oth[k] = y;
+                if (two_path) oth[Sh::NCP + k] = yf;                          // the foreground filter's output spectrum: a second "channel"
                 if (k == 0) {
                     float pn = 0.0f;
-                    cf yn = mk(0.0f, 0.0f);
+                    cf yn = mk(0.0f, 0.0f), yfn = mk(0.0f, 0.0f);
                     for (int c = 0; c < C; ++c) {
                         const cf F0 = res[c * Sh::NCP];
                         const cf X = mk(F0.x - F0.y, 0.0f);
                         sh.nyqX[c] = X;
                         pn += cabs2(X);
                         yn = cadd(yn, cmul(X, sh.nyqW[c]));
+                        if (two_path) yfn = cadd(yfn, cmul(X, sh.nyqF[c]));
                     }
                     sh.nyqP = fma_(p.alpha, sh.nyqP, (1.0f - p.alpha) * pn);
                     sh.nyqS[0] = yn;
+                    if (two_path) sh.nyqS[1] = yfn;
                 }
             });
-            ex.phase([&](int tid, Rg&) { merge_pairs(tid, sh, oth, 1); });
-            fft<+1>(ex, sh, 1);
+            const int ny = two_path ? 2 : 1;
+            ex.phase([&](int tid, Rg&) { merge_pairs(tid, sh, oth, ny); });
+            fft<+1>(ex, sh, ny);
+            if (two_path) {
+                // ---- transfer logic (FastFreqLms.py:99-104): sum |e_f| against sum |e_b| over the block
+                ex.phase([&](int tid, Rg&) {
+                    if (tid < NC / 2) {
+                        const cf zb = res[tid + NC / 2], zf = res[Sh::NCP + tid + NC / 2];
+                        const int s0 = 2 * tid, D = HOP / 2;
+                        float d0, d1;
+                        if (p.non_causal) {
+                            d0 = s0 < D ? sh.dold[s0] : dt[s0 - D];
+                            d1 = s0 + 1 < D ? sh.dold[s0 + 1] : dt[s0 + 1 - D];
+                        } else {
+                            d0 = dt[s0]; d1 = dt[s0 + 1];
+                        }
+                        sh.red[tid] = fabsf(d0 - zf.x * inv_nc) + fabsf(d1 - zf.y * inv_nc);
+                        sh.red[tid + NC / 2] = fabsf(d0 - zb.x * inv_nc) + fabsf(d1 - zb.y * inv_nc);
+                    }
+                });
+                ex.phase([&](int tid, Rg&) {
+                    if (tid < 16) {                                               // 8 partial sums each of e_f (0..7) and e_b (8..15), fixed order
+                        float a = 0.0f;
+                        for (int i = 0; i < NC / 16; ++i) a += sh.red[tid * (NC / 16) + i];
+                        sh.red2[tid] = a;
+                    }
+                });
+            }
             // ---- e = d (delayed when non_causal) - last hop of y; E = rfft([0 | e])       :160-172,183-185
-            ex.phase([&](int tid, Rg&) {
+            ex.phase([&](int tid, Rg& r) {
+                bool transfer = false;
+                if (two_path) {
+                    float ef = 0.0f, eb = 0.0f;
+                    for (int i = 0; i < 8; ++i) { ef += sh.red2[i]; eb += sh.red2[8 + i]; }
+                    transfer = 10.0f * log10f(ef / (eb + 1e-6f) + 1e-6f) > 3.0f;    // :101
+                    if (transfer) {                                               // foreground <- background (:102)
+#pragma unroll
+                        for (int c = 0; c < CMAX; ++c)
+                            if (c < C) r.F[c] = r.W[c];
+                        if (tid == 0) for (int c = 0; c < C; ++c) sh.nyqF[c] = sh.nyqW[c];
+                    }
+                }
                 if (tid < NC / 2) {
-                    const cf z = res[tid + NC / 2];
+                    cf z = res[tid + NC / 2];
+                    if (two_path) {                                               // the output is the foreground's; cross-faded on a transfer (:104)
+                        const cf zf = res[Sh::NCP + tid + NC / 2];
+                        if (transfer) {
+                            const float wa0 = sh.tb.win[HOP + 2 * tid], wa1 = sh.tb.win[HOP + 2 * tid + 1];      // sqrt-Hann: window = win^2
+                            const float wb0 = sh.tb.win[2 * tid], wb1 = sh.tb.win[2 * tid + 1];
+                            z = mk(fma_(wa0 * wa0, zf.x, (wb0 * wb0) * z.x), fma_(wa1 * wa1, zf.y, (wb1 * wb1) * z.y));
+                        } else {
+                            z = zf;
+                        }
+                    }
                     const int s0 = 2 * tid, D = HOP / 2;
                     float d0, d1;
                     if (p.non_causal) {
@@ -390,8 +455,14 @@ template <int NFFT, int CMAX> struct FdafEngine {
             for (int c = 0; c < CMAX; ++c)
                 if (c < C) Wg[c * K + tid] = r.W[c];
             Pg[tid] = r.P;
+            if (two_path) {
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c)
+                    if (c < C) Fg[c * K + tid] = r.F[c];
+            }
             if (tid == 0) {
                 for (int c = 0; c < C; ++c) Wg[c * K + NC] = sh.nyqW[c];
+                if (two_path) for (int c = 0; c < C; ++c) Fg[c * K + NC] = sh.nyqF[c];
                 Pg[NC] = sh.nyqP;
             }
         });

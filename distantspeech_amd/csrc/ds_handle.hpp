@@ -58,7 +58,7 @@ struct ds_handle {
     float* td_cache[2];         // FIR history ping-pong [B][L-1][M]
     int td_L, td_cur;
     float* tdf_w; float* tdf_buf; float* tdf_P;     // DS_ALGO_TDNLMS / TDRLS state
-    int fdaf_kind, fdaf_constrain, fdaf_non_causal, fdaf_weight_norm;   // DS_ALGO_FDAF (state lives in opst)
+    int fdaf_kind, fdaf_constrain, fdaf_non_causal, fdaf_weight_norm, fdaf_two_path;   // DS_ALGO_FDAF (state lives in opst)
     int mcspp_repeat;           // DS_PARAM_MCSPP_REPEAT
     int x_fan, p_complement, d_interleaved;   // subband LMS / RLS inside a chain: shared reference input, 1 - p, channel-interleaved d (OpParams)
     float* d_prev;              // ... and the one-frame delay line of the desired signal (owned by the chain)

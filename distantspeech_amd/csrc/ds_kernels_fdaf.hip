@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(NFFT / 2) ds_fdaf_kernel(FdafParams p) {
 
 hipError_t launch_fdaf(const FdafParams& p, int nfft, hipStream_t stream) {
 #define X(N_, C_)                                                                                            \
-    if (nfft == N_ && p.C <= C_) {                                                                             \
+    if (nfft == N_ && p.C <= C_ && !(p.two_path && C_ < 2)) {   /* two_path runs the foreground output as a second transform channel */                                                                           \
         hipLaunchKernelGGL((ds_fdaf_kernel<N_, C_>), dim3(p.B), dim3(N_ / 2), 0, stream, p);                   \
         return hipGetLastError();                                                                              \
     }

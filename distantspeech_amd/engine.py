@@ -58,6 +58,11 @@ class BatchEngine:
         """prediction delay (frames) of a DS_ALGO_WPE_MVDR chain handle; before the first call."""
         L.check(self._lib.ds_set_param_i(self._h, L.PARAM_WPE_DELAY, int(frames)), self._h)
 
+    def set_window(self, window):
+        """Transform handles: analysis / synthesis window [nfft] instead of the default sqrt-Hann (transform.py:415-419)."""
+        w = np.ascontiguousarray(window, dtype=np.float32)
+        L.check(self._lib.ds_set_window(self._h, self._p(w), int(w.size)), self._h)
+
     def set_mcspp_repeat(self, on):
         """McSpp handles: estimation(repeat=True), a second estimation_core after the noise update (mcspp.py:280-282)."""
         L.check(self._lib.ds_set_param_i(self._h, L.PARAM_MCSPP_REPEAT, int(bool(on))), self._h)
@@ -281,10 +286,10 @@ class BatchEngine:
                                              self._p(Y), L.MEM_HOST), self._h)
         return Y
 
-    def set_fdaf(self, kind=0, constrain=True, non_causal=False, weight_norm=False):
+    def set_fdaf(self, kind=0, constrain=True, non_causal=False, weight_norm=False, two_path=False):
         """select the overlap-save FDAF variant of a DS_ALGO_FDAF handle (plain / clamped blocking filter / norm-limited canceller)."""
         for pid, v in ((L.PARAM_FDAF_KIND, kind), (L.PARAM_FDAF_CONSTRAIN, constrain), (L.PARAM_FDAF_NON_CAUSAL, non_causal),
-                       (L.PARAM_FDAF_WEIGHT_NORM, weight_norm)):
+                       (L.PARAM_FDAF_WEIGHT_NORM, weight_norm), (L.PARAM_FDAF_TWO_PATH, two_path)):
             L.check(self._lib.ds_set_param_i(self._h, pid, int(v)), self._h)
 
     def fdaf_update(self, x, d, p=None, fir_truncate=None, want_w=True, p_complement=False):
@@ -324,6 +329,16 @@ class BatchEngine:
         C, K = self.M, self.K
         W = st[:, : 2 * C * K].copy().view(np.complex64).reshape(self.batch, C, K)
         return W, st[:, 2 * C * K: 2 * C * K + K].copy()
+
+    def fdaf_foreground(self):
+        """foreground filter [B, C, K] complex of a two-path DS_ALGO_FDAF handle (FastFreqLms.foreground)."""
+        nbytes = self._lib.ds_field_bytes(self._h, L.FIELD_OP_STATE)
+        out = np.empty(nbytes // 4, dtype=np.float32)
+        L.check(self._lib.ds_get_state(self._h, L.FIELD_OP_STATE, out.ctypes.data_as(ctypes.c_void_p), nbytes), self._h)
+        st = out.reshape(self.batch, -1)
+        C, K, Lb = self.M, self.K, self.nfft // 2
+        o = 2 * C * K + K + C * Lb + Lb // 2
+        return st[:, o: o + 2 * C * K].copy().view(np.complex64).reshape(self.batch, C, K)
 
     def tdfilter_weights(self):
         nbytes = self._lib.ds_field_bytes(self._h, L.FIELD_OP_STATE)

@@ -36,16 +36,18 @@ class Transform(_Base):
     """Streaming multichannel STFT / ISTFT with carried overlap — transform/transform.py:407-496."""
 
     def __init__(self, channel=1, n_fft=256, hop_length=128, window=None, batch=1, device=-1):
-        if window is not None:
-            raise NotImplementedError("only the default sqrt-Hann window is built into the kernels")
+        if window is not None and np.asarray(window).shape != (n_fft,):
+            raise NotImplementedError("a custom window must have n_fft samples (win_len == n_fft is what the kernels frame)")
         self.channel, self.n_fft, self.frame_length, self.hop_length = channel, n_fft, n_fft, hop_length
         self.half_bin = int(n_fft / 2 + 1)
-        self.window = np.sqrt(0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft))
+        self.window = np.sqrt(0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft)) if window is None else np.asarray(window, dtype=np.float64)
         self.win_len = n_fft
         self.overlap = n_fft - hop_length
         self.W0 = np.sum(self.window ** 2)
         self.batch = int(batch)
         self._eng = BatchEngine(L.ALGO_TRANSFORM, channel, n_fft, hop_length, batch=batch, device=device)
+        if window is not None:
+            self._eng.set_window(self.window)                              # transform.py:415-416
 
     def stft(self, x):
         """x [samples, channels] or [samples] -> [half_bin, frames, channels] complex128."""
@@ -575,8 +577,9 @@ class FastFreqLms(_Base):
 
     def __init__(self, filter_len=128, hop_len=None, win_len=None, mu=0.01, constrain=True, n_channels=1, alpha=0.9,
                  non_causal=False, two_path=False, batch=1, device=-1, weight_norm=False):
-        if two_path:
-            raise NotImplementedError("two_path (foreground/background filters, FastFreqLms.py:99-104) is not built")
+        if two_path and self._KIND != L.FDAF_PLAIN:
+            raise NotImplementedError("two_path belongs to the plain FastFreqLms (the GSC filters of the reference never set it)")
+        self.two_path = bool(two_path)
         if (hop_len is not None and hop_len != filter_len) or (win_len is not None and win_len != 2 * filter_len):
             raise NotImplementedError("only the default framing hop_len = filter_len, win_len = 2 * filter_len is built")
         self.filter_len, self.hop_len, self.win_len, self.mu = filter_len, filter_len, 2 * filter_len, mu
@@ -587,7 +590,7 @@ class FastFreqLms(_Base):
         self.overlap = self.win_len - self.hop_len
         self.batch = int(batch)
         self._eng = BatchEngine(L.ALGO_FDAF, n_channels, self.n_fft, batch=batch, device=device, filt_mu=mu, filt_alpha=alpha)
-        self._eng.set_fdaf(self._KIND, constrain=constrain, non_causal=non_causal, weight_norm=weight_norm)
+        self._eng.set_fdaf(self._KIND, constrain=constrain, non_causal=non_causal, weight_norm=weight_norm, two_path=two_path)
         self._w = np.zeros((self.batch, filter_len, n_channels))
 
     def update(self, x_n_vec, d_n_vec, update=True, p=1.0, fir_truncate=None, filter_p=False):
@@ -638,6 +641,14 @@ class FastFreqLms(_Base):
     def P(self):
         _, P = self._eng.fdaf_state()
         return self._sq(P.astype(np.float64)[:, :, None])
+
+
+    @property
+    def foreground(self):
+        """foreground filter [n_fft / 2 + 1, n_channels] of a two-path filter (FastFreqLms.py:95-96)."""
+        F = self._eng.fdaf_foreground().astype(np.complex128)                 # [B, C, K]
+        F = np.swapaxes(F, 1, 2)
+        return F[0] if self.batch == 1 else F
 
 
 class AdaptiveBlockingMatrixFilter(FastFreqLms):

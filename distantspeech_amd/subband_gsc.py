@@ -123,10 +123,9 @@ class SubbandGSC(object):
     def process(self, x, postfilter=False):
         """x [n_chs, n_samples] (or [B, n_chs, n_samples]) ->
         (output [L], fix_output [L], bm_output [L, M], p [half_bin, blocks], aligned_output [L, M])."""
-        if postfilter:
-            # the reference's post-filter branch re-analyses the WHOLE bm_output array every block (SubbandGSC.py:238)
-            # and never feeds its gain back into the returned signal (:248 commented out)
-            raise NotImplementedError("postfilter=True does not change the reference's output and is not built")
+        # postfilter=True: the reference's branch (SubbandGSC.py:236-249) analyses the canceller output, runs NsOmlsaMulti on it and scales a
+        # spectrum Y that is then dropped (the synthesis at :248 is commented out) — nothing it computes reaches the five returned arrays or
+        # any state they depend on, so the flag is accepted and the branch's dead work is not done
         x = np.asarray(x)
         single = x.ndim == 2
         if single:

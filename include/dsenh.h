@@ -155,6 +155,8 @@ typedef struct ds_config {
 #define DS_PARAM_FDAF_WEIGHT_NORM 12 /* int 0/1: norm limiter of the canceller (gsc_aic.py:81-88); default 0 */
 #define DS_PARAM_WPE_DELAY 13        /* int >= 0: prediction delay of the DS_ALGO_WPE_MVDR chain in frames (awpe.py:36, default 4); set before the first call */
 #define DS_PARAM_MCSPP_REPEAT 14     /* int 0/1: DS_ALGO_MCSPP handles run estimation(repeat=True): a second estimation_core after the noise update (mcspp.py:280-282); default 0 */
+#define DS_PARAM_FDAF_TWO_PATH 16     /* int 0/1: FastFreqLms(two_path=True) — foreground / background filters with the 3 dB transfer rule
+                                         (FastFreqLms.py:94-104,162-176); plain kind only; default 0 */
 #define DS_PARAM_POSTFILTER 15       /* int 0/1: DS_ALGO_TDGSC / DS_ALGO_FDGSC handles apply the OMLSA post-filter in ds_process_device; default 0 */
 #define DS_PARAM_SPLIT 8   /* int: utterance groups run as parallel hipGraph branches in ds_process_device_seq(graph=1); default 1 */
 
@@ -190,6 +192,9 @@ const char* ds_last_error(const ds_handle* h);
 int ds_set_steering(ds_handle* h, const float* steer, int per_utterance);
 
 int ds_set_param_i(ds_handle* h, int id, int value);
+/* DS_ALGO_TRANSFORM handles: analysis / synthesis window of n = nfft samples instead of the default sqrt-Hann (Transform(window=...),
+ * transform/transform.py:415-419); the synthesis scale hop / sum(window^2) (:428,479) follows */
+int ds_set_window(ds_handle* h, const float* window, int n);
 int ds_set_param_f(ds_handle* h, int id, float value);
 
 /* Host-buffer call (the realtime-callback form): x is [B] x layout, y is [B][n_samples];

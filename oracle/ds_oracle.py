@@ -48,11 +48,11 @@ def sqrt_hann(n_fft):
 class OracleTransform:
     """Streaming STFT/ISTFT with carried overlap — transform/transform.py:407-481."""
 
-    def __init__(self, channel=1, n_fft=256, hop_length=128, dtype=np.float64):
+    def __init__(self, channel=1, n_fft=256, hop_length=128, dtype=np.float64, window=None):
         self.channel = channel
         self.n_fft = n_fft
         self.hop_length = hop_length
-        self.window = sqrt_hann(n_fft)                      # :418-419
+        self.window = sqrt_hann(n_fft) if window is None else np.asarray(window, dtype=np.float64)   # :415-419
         self.half_bin = int(n_fft / 2 + 1)                  # :420
         self.overlap = n_fft - hop_length                   # :424
         self.previous_input = np.zeros((self.overlap, channel))   # :425
@@ -1052,18 +1052,21 @@ class OracleSubbandGSC:
 # overlap-save frequency-domain adaptive filters and the two GSCs built on them
 # --------------------------------------------------------------------------------------------
 class OracleFastFreqLms:
-    """Overlap-save FDAF — adaptivefilter/FastFreqLms.py:48-245 (two_path=False).
+    """Overlap-save FDAF — adaptivefilter/FastFreqLms.py:48-245 (two_path: the foreground / background pair of :94-104,162-176).
     kind "plain" = FastFreqLms.update (:204-245); "bm" = AdaptiveBlockingMatrixFilter.update (gsc_bm.py:61-122,
     coefficient-clamped); "aic" = AdaptiveInterferenceCancellation.update (gsc_aic.py:53-108, norm-limited)."""
 
     def __init__(self, filter_len=128, mu=0.01, constrain=True, n_channels=1, alpha=0.9, non_causal=False,
-                 kind="plain", weight_norm=False):
+                 kind="plain", weight_norm=False, two_path=False):
         self.filter_len, self.mu, self.constrain, self.n_channels, self.alpha = filter_len, mu, constrain, n_channels, alpha
+        self.two_path = two_path
         self.hop_len, self.win_len = filter_len, 2 * filter_len                      # :62-63
         self.input_buffer = np.zeros((self.win_len, n_channels))                     # :65
         self.n_fft = 2 ** (int(np.log2(self.hop_len + filter_len - 1)) + 1)           # :70-71
         self.overlap = self.win_len - self.hop_len
         self.W = np.zeros((self.n_fft // 2 + 1, n_channels), dtype=complex)           # :76
+        self.foreground = np.zeros_like(self.W)                                       # :95-96
+        self.window = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(self.n_fft) / self.n_fft))[:, None]   # :91-92
         self.w = np.zeros((filter_len, n_channels))
         self.P = np.zeros((self.n_fft // 2 + 1, 1))                                   # :78
         self.non_causal = non_causal
@@ -1093,6 +1096,13 @@ class OracleFastFreqLms:
         if d.ndim == 1:
             d = d[:, None]
         e = d - y                                                                     # :172
+        if self.two_path:                                                             # :162-164,174-176
+            y_f = np.sum(np.fft.irfft(X * self.foreground, axis=0)[-self.filter_len:, :], axis=1, keepdims=True)
+            e_f = d - y_f
+            if 10 * np.log10(np.sum(np.abs(e_f)) / (np.sum(np.abs(e)) + 1e-6) + 1e-6) > 3:      # transfer_logic :99-104
+                self.foreground[:] = self.W
+                y_f = self.window[self.filter_len:] * y_f + self.window[: self.filter_len] * y
+            e = d - y_f
         E = np.fft.rfft(np.concatenate((np.zeros((self.overlap, 1)), e), axis=0), n=n, axis=0)   # :183-185
         self.P[self.P < 1e-4] = 1e-4                                                  # :187
         grad = X.conj() * E / self.P                                                  # :188

@@ -167,8 +167,9 @@ int emul_istft(int nfft, int M, int batch, const float* Y, int T, int C, float* 
 }
 
 // OpParams fields outside emul_op's argument list (set before the call, sticky)
-static int g_repeat = 0;
+static int g_repeat = 0, g_two_path = 0;
 void emul_set_repeat(int on) { g_repeat = on; }
+void emul_set_two_path(int on) { g_two_path = on; }
 
 // frame-level operators: serial loop over (b, k) of ds::run_op
 int emul_op(int op, int B, int K, int T, float* st, int NF, const float* in0, const float* in1, const float* in2, float* out0,
@@ -348,8 +349,8 @@ int emul_fdaf(int nfft, int B, int T, int C, int kind, int constrain, int non_ca
     std::memset(&p, 0, sizeof p);
     p.B = B; p.T = T; p.C = C; p.kind = kind; p.constrain = constrain; p.non_causal = non_causal; p.weight_norm = weight_norm;
     p.trunc = trunc; p.p_mode = p_mode; p.mu = mu; p.alpha = alpha; p.x = x; p.d = d; p.p = pp; p.err = err; p.w_out = w_out;
-    p.state = state; p.state_stride = ds::fdaf_state_floats(nfft, C);
-#define FD(N_) if (nfft == N_) { if (C == 1) return run_fdaf<N_, 1>(p); if (C <= 4) return run_fdaf<N_, 4>(p); if (C <= 8) return run_fdaf<N_, 8>(p); }
+    p.state = state; p.state_stride = ds::fdaf_state_floats(nfft, C); p.two_path = g_two_path && kind == 0;
+#define FD(N_) if (nfft == N_) { if (C == 1 && !p.two_path) return run_fdaf<N_, 1>(p); if (C <= 4) return run_fdaf<N_, 4>(p); if (C <= 8) return run_fdaf<N_, 8>(p); }
     FD(128) FD(256) FD(512) FD(1024)
 #undef FD
     return -1;

@@ -236,7 +236,8 @@ class EmulFdaf:
         self.constrain, self.non_causal, self.weight_norm = int(constrain), int(non_causal), int(weight_norm)
         K, C, L = filter_len + 1, n_channels, filter_len
         self.K = K
-        self.state = np.zeros((batch, 2 * C * K + K + C * L + L // 2), np.float32)
+        self.two_path = False
+        self.state = np.zeros((batch, 2 * C * K + K + C * L + L // 2 + 2 * C * K), np.float32)     # ... | foreground [C][K] (two_path)
 
     @property
     def W(self):
@@ -257,9 +258,11 @@ class EmulFdaf:
         pm = 0 if p is None else (1 if np.ndim(p) == 2 else 2)
         pp = np.zeros(1, np.float32) if p is None else np.ascontiguousarray(p, np.float32)
         f = ctypes.c_float
+        lib().emul_set_two_path(int(self.two_path))
         rc = lib().emul_fdaf(2 * self.L, self.B, T, self.C, self.kind, self.constrain, self.non_causal, self.weight_norm,
                              -1 if fir_truncate is None else int(fir_truncate), pm, f(self.mu), f(self.alpha), _vp(x), _vp(d), _vp(pp),
                              _vp(err), _vp(w) if want_w else None, _vp(self.state))
+        lib().emul_set_two_path(0)
         assert rc == 0
         return err, w
 

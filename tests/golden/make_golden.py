@@ -158,6 +158,21 @@ def g1_transform():
              y_chunk=y_chunk, params=np.array([nfft, hop, M]))
 
 
+def g1b_transform_window():
+    """Transform(window=...) (transform.py:415-416): a caller-supplied window of n_fft samples (here a Hamming window, which is not
+    power-complementary, so the round trip is not the identity) through analysis and synthesis."""
+    rng = np.random.default_rng(12)
+    nfft, hop, M = 512, 256, 2
+    L = hop * 10
+    x = (rng.standard_normal((L, M)) * 0.1).astype(np.float32)
+    win = 0.54 - 0.46 * np.cos(2 * np.pi * np.arange(nfft) / nfft)
+    t = Transform(n_fft=nfft, hop_length=hop, channel=M, window=win)
+    Y = t.stft(x.astype(np.float64))
+    y = t.istft(Y)
+    save("g1b_transform_window", "Transform(window=hamming).stft/istft transform.py:415-416,430-481",
+         x=x, window=win, Y=Y.astype(np.complex64), y=np.asarray(y).reshape(L, -1), params=np.array([nfft, hop, M]))
+
+
 def g2_weights():
     for (atype, M, r, nfft, ang) in [("circular", 4, 0.032, 512, (197, 0)), ("linear", 6, 0.05, 512, (60, 0)),
                                       ("circular", 8, 0.05, 1024, (197, 10))]:
@@ -503,6 +518,35 @@ def g14_fdaf():
          "non_causal, fir_truncate(-1 = None)]", **out)
 
 
+def g14b_fdaf_two_path():
+    """FastFreqLms(two_path=True) (FastFreqLms.py:94-104,162-176): foreground / background filters with the 3 dB transfer rule; the
+    system changes half way so that transfers happen at the start and after the change."""
+    from DistantSpeech.adaptivefilter.FastFreqLms import FastFreqLms
+    rng = np.random.default_rng(142)
+    out = {}
+    for tag, L, nb, C in (("e", 128, 60, 1), ("f", 64, 50, 2)):
+        x = rng.standard_normal((L * nb, C)) * 0.3
+        d = np.zeros(L * nb)
+        half = L * nb // 2
+        for c in range(C):
+            h1 = rng.standard_normal(40) * np.exp(-np.arange(40) / 8.0)
+            h2 = rng.standard_normal(40) * np.exp(-np.arange(40) / 6.0)
+            d[:half] += np.convolve(x[:, c], h1)[:half]
+            d[half:] += np.convolve(x[:, c], h2)[half: L * nb]
+        d += 0.01 * rng.standard_normal(L * nb)
+        f = FastFreqLms(filter_len=L, mu=0.05, n_channels=C, two_path=True)
+        e = np.zeros(L * nb)
+        transfers = []
+        for n in range(nb):
+            fg0 = f.foreground.copy()
+            en, w = f.update(x[n * L:(n + 1) * L] if C > 1 else x[n * L:(n + 1) * L, 0], d[n * L:(n + 1) * L])
+            e[n * L:(n + 1) * L] = en[:, 0]
+            transfers.append(int(not np.array_equal(fg0, f.foreground)))
+        out.update({tag + "_x": x, tag + "_d": d, tag + "_e": e, tag + "_w": np.array(w), tag + "_W": np.array(f.W),
+                    tag + "_F": np.array(f.foreground), tag + "_transfers": np.array(transfers), tag + "_params": np.array([L, C, 0.05, 0.9])})
+    save("g14b_fdaf_two_path", "FastFreqLms(two_path=True).update FastFreqLms.py:94-104,162-176,204-245", **out)
+
+
 def g15_tdgsc(x16):
     from DistantSpeech.beamformer.TDGSC import TDGSC
     x = x16.astype(np.float32) / 32768.0
@@ -548,6 +592,7 @@ def main():
 
     x16 = rec1_int16(3.0, 3.0)
     if want("g1"): g1_transform()
+    if want("g1b"): g1b_transform_window()
     if want("g2"): g2_weights()
     if want("g2b"): g2b_fixed(x16)
     if want("g3"): g3_mcra(x16)
@@ -562,6 +607,7 @@ def main():
     if want("g12"): g12_subbandgsc(x16)
     if want("g13"): g13_tdfilters()
     if want("g14"): g14_fdaf()
+    if want("g14b"): g14b_fdaf_two_path()
     if want("g15"): g15_tdgsc(x16)
     if want("g16"): g16_fdgsc(x16)
 

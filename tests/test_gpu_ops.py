@@ -57,6 +57,25 @@ def test_transform(ds, name):
         assert np.allclose(y1, y[:hop], atol=1e-6)
 
 
+def test_transform_custom_window(ds):
+    """Transform(window=...): a Hamming window of n_fft samples through ds_set_window; analysis and synthesis against
+    the reference's fixture, chunked == one call."""
+    g = load("g1b_transform_window")
+    nfft, hop, M = [int(v) for v in g["params"]]
+    x = g["x"]
+    t = ds.Transform(channel=M, n_fft=nfft, hop_length=hop, window=g["window"])
+    assert abs(t.W0 - np.sum(g["window"] ** 2)) < 1e-9
+    Y = t.stft(x)
+    assert rms(Y - g["Y"]) < 1e-6 * rms(g["Y"])
+    y = t.istft(Y)
+    assert rms(y - g["y"]) < 1e-6 * rms(g["y"])
+    t2 = ds.Transform(channel=M, n_fft=nfft, hop_length=hop, window=g["window"])
+    yc = np.concatenate([t2.istft(t2.stft(x[a:a + 2 * hop])) for a in range(0, x.shape[0], 2 * hop)])
+    assert np.array_equal(yc, y)
+    with pytest.raises(NotImplementedError):
+        ds.Transform(channel=M, n_fft=nfft, hop_length=hop, window=np.ones(300))
+
+
 @pytest.mark.parametrize("L", [15, 10])
 def test_mcra(ds, L):
     g = load("g3_mcra_L%d" % L)
@@ -292,8 +311,10 @@ def test_subband_gsc(ds, name):
     # test_emul_subband_gsc_chain): output 2e-7 / 4e-7 / 9e-6 (LMS rec1, LMS M = 6, RLS M = 6), bm_output 1e-6 ... 3e-6
     assert e_al < 1e-5 and e_bm < 2e-5 and e_out < 5e-5
     assert e_p < 1e-3 and np.median(np.abs(p - g["p"])) < 1e-6
-    with pytest.raises(NotImplementedError):
-        sg.process(x[:, :FL], postfilter=True)
+    # postfilter=True is output-dead in the reference (SubbandGSC.py:236-249): accepted, same results
+    pf_a = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], bm_filter="rls" if rls else "lms").process(x[:, : 4 * FL], postfilter=True)
+    pf_b = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], bm_filter="rls" if rls else "lms").process(x[:, : 4 * FL])
+    assert all(np.array_equal(u, v) for u, v in zip(pf_a, pf_b))
     # checkpoint / resume of the chain: every stage's state plus the two block delays
     a = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], bm_filter="rls" if rls else "lms")
     a.process(x[:, : 10 * FL])
@@ -426,6 +447,26 @@ def test_td_filters(ds):
     big = ds.Rls(filter_len=Lr)
     e = np.array([big.update(xr[i], dr[i])[0] for i in range(n)]).reshape(-1)
     assert rms(e - ref) < 2e-2 * rms(ref) and rms(big.w[:, 0] - o.w) < 2e-2 * rms(o.w)
+
+
+@pytest.mark.parametrize("tag", ["e", "f"])
+def test_fdaf_two_path(ds, tag):
+    """FastFreqLms(two_path=True): block by block like the reference's loop and the whole signal in one launch (bitwise
+    equal), against the reference's error signal and foreground filter."""
+    g = load("g14b_fdaf_two_path")
+    Lf, C, mu, alpha = g[tag + "_params"]
+    Lf, C = int(Lf), int(C)
+    x, d = g[tag + "_x"], g[tag + "_d"]
+    f = ds.FastFreqLms(filter_len=Lf, mu=float(mu), n_channels=C, alpha=float(alpha), two_path=True)
+    e = np.concatenate([f.update(x[n * Lf:(n + 1) * Lf], d[n * Lf:(n + 1) * Lf])[0][:, 0] for n in range(d.size // Lf)])
+    assert rms(e - g[tag + "_e"]) < 1e-4 * rms(g[tag + "_e"])
+    assert rms(f.foreground - g[tag + "_F"]) < 1e-4 * rms(g[tag + "_F"])
+    assert rms(f.w - g[tag + "_w"]) < 1e-3 * rms(g[tag + "_w"])
+    f2 = ds.FastFreqLms(filter_len=Lf, mu=float(mu), n_channels=C, alpha=float(alpha), two_path=True)
+    e2, _ = f2._eng.fdaf_update(x[None].astype(np.float32).reshape(1, -1, C), d[None].astype(np.float32))
+    assert np.array_equal(e2[0].astype(np.float64), e)
+    with pytest.raises(NotImplementedError):
+        ds.AdaptiveBlockingMatrixFilter(filter_len=64, two_path=True)
 
 
 def _fdaf_obj(ds, case, g, batch=1):

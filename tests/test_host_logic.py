@@ -57,13 +57,13 @@ def test_unsupported_configurations_fail_before_touching_the_device():
     """argument errors are raised by the mirrors themselves (no GPU needed to see them)."""
     import distantspeech_amd as ds
     with pytest.raises(NotImplementedError):
-        ds.FastFreqLms(filter_len=64, two_path=True)
+        ds.AdaptiveBlockingMatrixFilter(filter_len=64, two_path=True)           # two_path belongs to the plain FastFreqLms
     with pytest.raises(NotImplementedError):
         ds.FastFreqLms(filter_len=100)
     with pytest.raises(NotImplementedError):
         ds.FastFreqLms(filter_len=64, hop_len=32)
     with pytest.raises(NotImplementedError):
-        ds.Transform(channel=2, n_fft=512, hop_length=256, window=np.ones(512))
+        ds.Transform(channel=2, n_fft=512, hop_length=256, window=np.ones(300))   # a custom window must have n_fft samples
 
 
 def test_wav_helpers_roundtrip(tmp_path):

@@ -311,6 +311,27 @@ def test_emul_td_filters_golden():
     assert rms(rl.w[0] - g["w_rls"]) < 2e-2 * rms(g["w_rls"])
 
 
+@pytest.mark.parametrize("tag", ["e", "f"])
+def test_emul_fdaf_two_path(tag):
+    """FastFreqLms(two_path=True) through the FDAF block program: the foreground output, the transfers (the fixture has them at the start and
+    after the system change) and the foreground filter; chunked calls, state carried."""
+    from emul.emul import EmulFdaf
+    g = load("g14b_fdaf_two_path")
+    L, C, mu, alpha = g[tag + "_params"]
+    L, C = int(L), int(C)
+    f = EmulFdaf(L, n_channels=C, mu=float(mu), alpha=float(alpha))
+    f.two_path = True
+    x = g[tag + "_x"].astype(np.float32)[None]
+    d = g[tag + "_d"].astype(np.float32)[None]
+    cut = (d.shape[1] // L // 3) * L
+    e = np.concatenate([f.update(x[:, :cut], d[:, :cut])[0], f.update(x[:, cut:], d[:, cut:])[0]], axis=1)[0]
+    assert rms(e - g[tag + "_e"]) < 1e-4 * rms(g[tag + "_e"])
+    K = L + 1
+    o = 2 * C * K + K + C * L + L // 2
+    F = f.state[0, o: o + 2 * C * K].copy().view(np.complex64).reshape(C, K).T
+    assert rms(F - g[tag + "_F"]) < 1e-4 * rms(g[tag + "_F"])
+
+
 def test_emul_rls_beyond_the_lds_matrix():
     """Rls with more than 64 taps keeps P in device memory instead of LDS (ds_tdfilter.hpp): 96 taps against the fp64 oracle."""
     from emul.emul import EmulTdFilter

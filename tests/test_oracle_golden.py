@@ -301,3 +301,32 @@ def test_fdgsc(golden, name):
     assert rms(al_d - g["aligned_output_delayed"]) < 1e-6 * rms(g["aligned_output_delayed"])
     assert rms(out - g["output"]) < 1e-7 * rms(g["output"])
     assert np.allclose(o.bm[0].w, g["w_bm0"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("tag", ["e", "f"])
+def test_fdaf_two_path(golden, tag):
+    """FastFreqLms(two_path=True): foreground / background filters with the 3 dB transfer rule (FastFreqLms.py:94-104,162-176)."""
+    g = golden("g14b_fdaf_two_path")
+    L, C, mu, alpha = g[tag + "_params"]
+    L, C = int(L), int(C)
+    f = O.OracleFastFreqLms(filter_len=L, mu=float(mu), n_channels=C, alpha=float(alpha), two_path=True)
+    x, d = g[tag + "_x"], g[tag + "_d"]
+    e = np.zeros_like(d)
+    transfers = []
+    for n in range(d.size // L):
+        fg0 = f.foreground.copy()
+        en, w = f.update(x[n * L:(n + 1) * L], d[n * L:(n + 1) * L])
+        e[n * L:(n + 1) * L] = en[:, 0]
+        transfers.append(int(not np.array_equal(fg0, f.foreground)))
+    assert np.array_equal(transfers, g[tag + "_transfers"])
+    assert rms(e - g[tag + "_e"]) < 1e-9 * rms(g[tag + "_e"]) and rms(f.foreground - g[tag + "_F"]) < 1e-9 * rms(g[tag + "_F"])
+
+
+def test_transform_custom_window(golden):
+    """Transform(window=...) with a window of n_fft samples (transform.py:415-416)."""
+    g = golden("g1b_transform_window")
+    nfft, hop, M = [int(v) for v in g["params"]]
+    t = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop, window=g["window"])
+    Y = t.stft(g["x"])
+    assert np.array_equal(Y.astype(np.complex64), g["Y"])
+    assert np.allclose(t.istft(Y), g["y"], rtol=1e-7, atol=1e-9)
