@@ -1,5 +1,7 @@
 // ds_api.hip — handle management and the C-ABI of libdsenh.so (see include/dsenh.h).
 // No CPU compute path lives here: every ds_process* call launches the gfx950 kernels.
+#include <cstdlib>
+
 #include "ds_handle.hpp"
 
 using namespace dsi;
@@ -443,7 +445,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             h->sub[i]->use_dev_cnt = true;
             h->sub[i]->owner = h;
         }
-        if (rls) {
+        const char* no_fork = std::getenv("DS_CHAIN_NO_FORK");               // A/B switch: every stage on the chain's own stream
+        if (rls && !(no_fork && no_fork[0] == '1')) {
             // the RLS blocking filters do not take the speech presence probability, so the blocking-filter stages (HBM-bound) run on a side
             // stream next to the McSpp stage (register-bound, one wave per SIMD) and join in front of the canceller.  McSpp is the longer
             // branch and stays on the chain's own stream: the cross-stream hand-offs (~10 us each) then sit on the branch that has slack
