@@ -323,6 +323,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->graph_exec = nullptr; h->graph_valid = false; h->chain_warm_n = -1; h->adv_hist = 0;
     for (int i = 0; i < 11; ++i) { h->adv_frames[i] = 0; h->adv_td[i] = 0; }
     h->split = 1; h->ev_fork = nullptr;
+    h->parts = 1; h->pipe_stream = nullptr; h->ev_pipe = nullptr;
+    for (int i = 0; i < 8; ++i) h->ev_part[i] = nullptr;
     for (int i = 0; i < 7; ++i) { h->side[i] = nullptr; h->ev_join[i] = nullptr; }
     h->ki_istft = ki_istft; h->op = op;
     h->ki_rows = KernelInfo{nullptr, 0, 0, 0}; h->ki_rows_istft = h->ki_rows;
@@ -413,6 +415,10 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             h->sub[i]->use_dev_cnt = true;                      // uniform counters read from the device: the chain replays as a hipGraph
             h->sub[i]->owner = h;
         }
+        // utterance groups pipelined through the stages: the HBM-bound WPE kernel of one group next to the arithmetic-bound McMcra / MVDR
+        // operators of the previous one (DS_PARAM_SPLIT; DS_CHAIN_PARTS in the environment overrides the default for A/B runs)
+        h->parts = 1;
+        if (const char* e = std::getenv("DS_CHAIN_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) h->parts = v; }
     }
     if (cfg->algo == DS_ALGO_TDGSC || cfg->algo == DS_ALGO_FDGSC) {
         rc = gsc_chain_create(h);
@@ -481,6 +487,9 @@ int ds_destroy(ds_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     for (int i = 0; i < 7; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int i = 0; i < 8; ++i) if (h->ev_part[i]) (void)hipEventDestroy(h->ev_part[i]);
+    if (h->ev_pipe) (void)hipEventDestroy(h->ev_pipe);
+    if (h->pipe_stream) (void)hipStreamDestroy(h->pipe_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
@@ -566,6 +575,7 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
             return DS_OK;
         case DS_PARAM_SPLIT:
             if (value < 1 || value > 8) return fail(h, DS_EINVAL, "split must be 1..8");
+            if (h->cfg.algo == DS_ALGO_WPE_MVDR) { h->parts = value; h->graph_valid = false; return DS_OK; }
             h->split = value; h->graph_valid = false;
             return DS_OK;
         default: return fail(h, DS_EINVAL, "unknown int parameter id");
@@ -698,13 +708,13 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     const long long key[16] = {(long long)(uintptr_t)x_dev, (long long)(uintptr_t)y_dev, layout, x_batch_stride, x_chan_stride,
                                x_call_stride, n_samples_per_call, n_calls, y_batch_stride, y_call_stride,
                                ((long long)first << 32) | (unsigned)count, ((long long)h->method << 32) | (unsigned)h->mcra_L,
-                               fbits[0], fbits[1], fbits[2] ^ ((long long)h->split << 40), (long long)(uintptr_t)h->steer};
+                               fbits[0], fbits[1], fbits[2] ^ ((long long)h->split << 40) ^ ((long long)h->parts << 44), (long long)(uintptr_t)h->steer};
     if (!h->graph_valid || std::memcmp(key, h->graph_key, sizeof key) != 0) {
         if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
         h->graph_valid = false;
         hipStream_t cs = h->stream;                       // capture on the handle's own stream
         DS_HIP(h, hipStreamSynchronize(cs));
-        const int ns = h->split < count ? h->split : (count > 0 ? count : 1);
+        const int ns = chain ? 1 : h->split < count ? h->split : (count > 0 ? count : 1);
         if (ns > 1) {
             if (!h->ev_fork) DS_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             for (int i = 0; i < ns - 1; ++i) {

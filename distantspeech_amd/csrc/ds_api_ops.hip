@@ -77,6 +77,31 @@ int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[5]) {
     return DS_OK;
 }
 
+// one launch of the operator over utterances [b0, b0 + nb) of the handle's batch; the io pointers already point at utterance b0.
+// Touches no counter: the caller advances the host mirrors and posts the device tick once the whole batch has been launched.
+int binop_launch(ds_handle* h, int b0, int nb, int n_frames, const float* const din[3], float* const dout[5], int is_complex, int has_p,
+                 hipStream_t stream, const ds::TickArgs& tick) {
+    if (b0 != 0 && h->d_prev) return fail(h, DS_EUNSUPPORTED, "binop_launch: utterance sub-ranges are not available with a delayed desired signal");
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = nb; p.K = h->K; p.KP = h->KP; p.T = n_frames;
+    p.st = h->opst + (size_t)b0 * h->NF * h->KP; p.NF = h->NF;
+    p.in0 = din[0]; p.in1 = din[1]; p.in2 = din[2];
+    p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
+    p.M = h->cfg.n_mics; p.N = h->filter_len;
+    p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = h->mcra_L; p.first_frame = h->op_first;
+    p.in_complex = is_complex; p.has_p = has_p; p.norm = h->norm;
+    p.mu = h->filt_mu; p.alpha = h->filt_alpha; p.reg = 1e-4f; p.lam = h->rls_lambda;
+    p.x_fan = h->x_fan > 0 ? h->x_fan : 1; p.p_complement = h->p_complement; p.d_interleaved = h->d_interleaved; p.d_prev = h->d_prev;
+    p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
+    p.steer = h->steer ? h->steer + (size_t)b0 * p.steer_batch_stride : nullptr;
+    p.method = h->method; p.alpha_v = h->alpha_v; p.beta_v = ds::complement_of(h->alpha_v); p.gate = h->gate; p.diag = h->diag;
+    p.dev_cnt = h->use_dev_cnt ? h->dev_cnt : nullptr;
+    p.tick = tick;
+    DS_HIP(h, ds::launch_binop(h->op, p, stream));
+    return DS_OK;
+}
+
 int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int mem, const IoSpec& io, int is_complex, int has_p) {
     if (!h) return DS_EINVAL;
     if (h->cfg.algo != want_algo) return fail(h, DS_ESTATE, std::string(who) + ": handle was created for a different algo");
@@ -85,28 +110,29 @@ int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int me
     int rc = set_device(h); if (rc) return rc;
     const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    ds::OpParams p;
-    std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames;
-    p.st = h->opst; p.NF = h->NF;
-    p.in0 = din[0]; p.in1 = din[1]; p.in2 = din[2];
-    p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
-    p.M = h->cfg.n_mics; p.N = h->filter_len;
-    p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = h->mcra_L; p.first_frame = h->op_first;
-    p.in_complex = is_complex; p.has_p = has_p; p.norm = h->norm;
-    p.mu = h->filt_mu; p.alpha = h->filt_alpha; p.reg = 1e-4f; p.lam = h->rls_lambda;
-    p.x_fan = h->x_fan > 0 ? h->x_fan : 1; p.p_complement = h->p_complement; p.d_interleaved = h->d_interleaved; p.d_prev = h->d_prev;
-    p.steer = h->steer; p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
-    p.method = h->method; p.alpha_v = h->alpha_v; p.beta_v = ds::complement_of(h->alpha_v); p.gate = h->gate; p.diag = h->diag;
-    p.dev_cnt = h->use_dev_cnt ? h->dev_cnt : nullptr;
-    take_tick(h, h->stream, p.tick);                                   // an earlier stage's counter advance rides in this launch
-    DS_HIP(h, ds::launch_binop(h->op, p, h->stream));
+    ds::TickArgs tick;
+    take_tick(h, h->stream, tick);                                     // an earlier stage's counter advance rides in this launch
+    rc = binop_launch(h, 0, h->cfg.batch, n_frames, din, dout, is_complex, has_p, h->stream, tick); if (rc) return rc;
     // advance the uniform counters exactly like the kernel did (mcra.py:52-56,72-74): the host mirror, and the device copy behind the launch
     // (only the operators that read them: the subband filters keep no frame counters)
     const bool counts = h->op != ds::OP_SUBLMS && h->op != ds::OP_SUBRLS;
     if (h->use_dev_cnt && counts) { rc = post_tick(h, h->dev_cnt, n_frames, h->mcra_L, 0, 0, h->stream); if (rc) return rc; }
     advance_host_counters(h, n_frames, h->mcra_L);
     return io_end(h, mem, io, dout);
+}
+
+// the WPE kernel over utterances [b0, b0 + nb) (device pointers at utterance b0; ring = the chain's delay line at utterance b0 or null)
+int wpe_launch(ds_handle* h, int b0, int nb, const float* x_delayed, const float* d, int n_frames, float* err, float* ring, int ring_pos,
+               int ring_len, const int* dev_ring_pos, hipStream_t stream) {
+    ds::WpeParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = nb; p.K = h->K; p.T = n_frames; p.C = h->cfg.n_mics; p.N = h->filter_len;
+    p.xd = x_delayed; p.d = d; p.err = err; p.lam = h->rls_lambda;
+    p.ustride = (long long)h->NF * h->KP;
+    p.state = h->opst + (size_t)b0 * p.ustride;
+    p.ring = ring; p.ring_pos = ring_pos; p.ring_len = ring_len; p.dev_ring_pos = dev_ring_pos;
+    DS_HIP(h, ds::launch_wpe(p, stream));
+    return DS_OK;
 }
 
 int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len,
@@ -120,13 +146,7 @@ int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, 
     IoSpec io = {{x_delayed, d, nullptr}, {x_delayed ? n : 0, n, 0}, {err, nullptr, nullptr}, {n, 0, 0}};
     const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    ds::WpeParams p;
-    std::memset(&p, 0, sizeof p);
-    p.B = h->cfg.batch; p.K = h->K; p.T = n_frames; p.C = h->cfg.n_mics; p.N = h->filter_len;
-    p.xd = din[0]; p.d = din[1]; p.err = dout[0]; p.state = h->opst; p.lam = h->rls_lambda;
-    p.ustride = (long long)h->NF * h->KP;
-    p.ring = ring; p.ring_pos = ring_pos; p.ring_len = ring_len; p.dev_ring_pos = dev_ring_pos;
-    DS_HIP(h, ds::launch_wpe(p, h->stream));
+    rc = wpe_launch(h, 0, h->cfg.batch, din[0], din[1], n_frames, dout[0], ring, ring_pos, ring_len, dev_ring_pos, h->stream); if (rc) return rc;
     return io_end(h, mem, io, dout);
 }
 

@@ -77,6 +77,11 @@ struct ds_handle {
     hipEvent_t ev_fork, ev_join[7];
     long long graph_key[16];
     bool graph_valid;
+    // DS_ALGO_WPE_MVDR: utterance groups pipelined through the stages (group g + 1 in the WPE kernel on `stream` while group g runs the
+    // McMcra / MVDR / synthesis stages on `pipe_stream`); parts = 1: every stage over the whole batch on `stream`
+    int parts;
+    hipStream_t pipe_stream;
+    hipEvent_t ev_part[8], ev_pipe;
     // chain handles under graph replay: the shape (samples per call) that has run once with plain launches (buffers sized, start-up
     // branches behind), and what one replay of the captured sequence does to the host mirrors of the stages' uniform counters
     ds_handle* owner;           // the chain handle this stage belongs to (null: stand-alone)
@@ -133,6 +138,11 @@ int flush_tick(ds_handle* chain);
 int io_begin(ds_handle* h, int mem, const IoSpec& io, const float* din[3], float* dout[5]);
 int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[5]);
 int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int mem, const IoSpec& io, int is_complex, int has_p);
+// sub-range launches (utterances [b0, b0 + nb), device pointers at utterance b0) that touch no counter: the stages of a pipelined chain
+int binop_launch(ds_handle* h, int b0, int nb, int n_frames, const float* const din[3], float* const dout[5], int is_complex, int has_p,
+                 hipStream_t stream, const ds::TickArgs& tick);
+int wpe_launch(ds_handle* h, int b0, int nb, const float* x_delayed, const float* d, int n_frames, float* err, float* ring, int ring_pos,
+               int ring_len, const int* dev_ring_pos, hipStream_t stream);
 int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len,
             const int* dev_ring_pos);
 

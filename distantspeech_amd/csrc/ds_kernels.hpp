@@ -38,6 +38,7 @@ hipError_t launch_tdfilter(const TdfParams& p, hipStream_t stream);
 // `frames` frames (MCRA window L; mcra.py:52-56,72-74), clears first_frame, and moves aux by aux_add modulo aux_mod (FIR ping-pong parity:
 // +1 mod 2 per call; WPE delay ring: +T mod ring_len)
 hipError_t launch_tick(int* cnt, int frames, int L, int aux_add, int aux_mod, hipStream_t stream);
+hipError_t launch_tick3(const TickArgs& a, const TickArgs& b, const TickArgs& c, hipStream_t stream);   // three handles' counters in one launch
 hipError_t launch_mcspp_qavg(const float* gamma, float* out, int rows, int K, hipStream_t stream);
 struct WpeParams;
 hipError_t launch_wpe(const WpeParams& p, hipStream_t stream);

@@ -474,6 +474,13 @@ hipError_t launch_wpe(const WpeParams& p, hipStream_t stream) {
 __global__ void __launch_bounds__(64) ds_tick_kernel(TickArgs t) {
     if (threadIdx.x == 0) apply_tick(t);
 }
+__global__ void __launch_bounds__(64) ds_tick3_kernel(TickArgs a, TickArgs b, TickArgs c) {
+    if (threadIdx.x == 0) { apply_tick(a); apply_tick(b); apply_tick(c); }
+}
+hipError_t launch_tick3(const TickArgs& a, const TickArgs& b, const TickArgs& c, hipStream_t stream) {
+    hipLaunchKernelGGL(ds_tick3_kernel, dim3(1), dim3(64), 0, stream, a, b, c);
+    return hipGetLastError();
+}
 hipError_t launch_tick(int* cnt, int frames, int L, int aux_add, int aux_mod, hipStream_t stream) {
     const TickArgs t = {cnt, frames, L > 0 ? L : 1, aux_add, aux_mod};
     hipLaunchKernelGGL(ds_tick_kernel, dim3(1), dim3(64), 0, stream, t);

@@ -51,7 +51,8 @@ class BatchEngine:
         L.check(self._lib.ds_set_param_i(self._h, L.PARAM_METHOD, int(method)), self._h)
 
     def set_split(self, n):
-        """graph mode of process_device_seq: run n utterance groups as parallel branches (memory/compute overlap)."""
+        """fused frame kernels: n utterance groups as parallel hipGraph branches of process_device_seq(graph=1); DS_ALGO_WPE_MVDR chain:
+        n utterance groups pipelined through the stages (default 4 from 256 utterances up, 1 = every stage over the whole batch)."""
         L.check(self._lib.ds_set_param_i(self._h, L.PARAM_SPLIT, int(n)), self._h)
 
     def set_wpe_delay(self, frames):

@@ -158,7 +158,9 @@ typedef struct ds_config {
 #define DS_PARAM_FDAF_TWO_PATH 16     /* int 0/1: FastFreqLms(two_path=True) — foreground / background filters with the 3 dB transfer rule
                                          (FastFreqLms.py:94-104,162-176); plain kind only; default 0 */
 #define DS_PARAM_POSTFILTER 15       /* int 0/1: DS_ALGO_TDGSC / DS_ALGO_FDGSC handles apply the OMLSA post-filter in ds_process_device; default 0 */
-#define DS_PARAM_SPLIT 8   /* int: utterance groups run as parallel hipGraph branches in ds_process_device_seq(graph=1); default 1 */
+#define DS_PARAM_SPLIT 8   /* int 1..8: utterance groups run as parallel hipGraph branches in ds_process_device_seq(graph=1), default 1;
+                              DS_ALGO_WPE_MVDR: utterance groups pipelined through the chain's stages on two streams (WPE of one group next to
+                              the McMcra / MVDR / synthesis stages of the previous one), default 4 from 256 utterances up */
 
 /* ds_get_state fields; all arrays are float32, complex = interleaved (re, im) */
 #define DS_FIELD_RVV 1        /* [B][K][M][M][2]  */

@@ -770,6 +770,43 @@ def test_chain_graph_replay_equals_plain_launches(ds, chain):
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("parts", [2, 3, 5])
+def test_wpe_mvdr_chain_pipelined_groups_equal_the_whole_batch(ds, parts):
+    """DS_ALGO_WPE_MVDR moves utterance groups through its stages as a pipeline (WPE of group g + 1 next to McMcra / MVDR / synthesis of
+    group g, two streams).  Utterances never interact, so any grouping gives the samples and the state of the one-group chain bit for bit —
+    uneven groups, plain launches and hipGraph replays, one hop and several hops per call, a non-zero WPE delay ring."""
+    from _cases import DeviceBuffers
+    from distantspeech_amd import _lib as L
+    M, nfft, hop, B, T, n_calls, rounds = 8, 1024, 512, 5, 2, 3, 4
+    Ltot = T * hop * n_calls * rounds
+    dv = DeviceBuffers()
+    xd = dv.upload((np.random.default_rng(21).standard_normal((B, M, Ltot)) * 0.05).astype(np.float32))
+    mic = ds.MicArray(arrayType="circular", r=0.05, M=M, n_fft=nfft)
+    ang = np.array([197.0, 0.0]) / 180 * np.pi
+    tao = -1 * mic.r * np.cos(ang[1]) * np.cos(ang[0] - mic.gamma) / mic.c
+    steer = np.exp(-1j * (2 * np.pi * np.arange(nfft // 2 + 1) * 16000 / nfft)[:, None] * tao[None, :])
+    outs = []
+    for n_parts, graph in ((1, 0), (parts, 0), (parts, 1)):
+        e = ds.BatchEngine(L.ALGO_WPE_MVDR, M, nfft, hop, batch=B, device=0, filter_len=2)
+        e.set_steering(steer)
+        e.set_method(L.METHOD_MVDR)
+        e.set_wpe_delay(3)
+        e.set_split(n_parts)
+        yd = dv.zeros(B * Ltot * 4)
+        seg = T * hop * n_calls
+        for r in range(rounds):
+            e.process_device_seq(xd + 4 * r * seg, L.LAYOUT_CHANNELS_SAMPLES, M * Ltot, Ltot, T * hop, T * hop, n_calls,
+                                 yd + 4 * r * seg, Ltot, T * hop, graph=graph)
+        e.synchronize()
+        outs.append((dv.download(yd, (B, Ltot)), e.export_state()))
+        e.close()
+    dv.free()
+    assert np.all(np.isfinite(outs[0][0])) and np.abs(outs[0][0]).max() > 0
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0])
+        assert np.array_equal(outs[0][1], o[1])
+
+
 def test_checkpoint_imports_into_a_never_run_handle(ds):
     """The process-restart case: a blob exported from a running handle goes into a freshly created and configured one that has not
     processed anything (the FIR history is sized when the bank is set, not at the first call); a blob of another configuration is
