@@ -28,6 +28,9 @@ size_t counters_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * 4 * si
 
 int set_device(ds_handle* h) {
     DS_HIP(h, hipSetDevice(h->device));
+    // every entry point comes through here before it touches the handle; the utterance groups of a chain are brought back onto the
+    // chain's stream first (the chain's own launch path selects the device without this: select_device)
+    if (h->groups_open) return join_groups(h);
     return DS_OK;
 }
 
@@ -92,7 +95,8 @@ int zero_state(ds_handle* h) {
 int sync_dev_cnt(ds_handle* h) {
     if (!h->dev_cnt) return DS_OK;
     const int aux = h->cfg.algo == DS_ALGO_FRONTEND ? h->td_cur : h->cfg.algo == DS_ALGO_WPE_MVDR ? h->hist_cur : 0;
-    const int c[8] = {h->op_frm, h->op_ell, h->op_first, aux, 0, 0, 0, 0};
+    int c[8 * DS_GROUPS];                                          // one copy per utterance group of a chain (groups run at their own pace)
+    for (int g = 0; g < DS_GROUPS; ++g) { int* q = c + 8 * g; q[0] = h->op_frm; q[1] = h->op_ell; q[2] = h->op_first; q[3] = aux; q[4] = q[5] = q[6] = q[7] = 0; }
     DS_HIP(h, hipMemcpyAsync(h->dev_cnt, c, sizeof c, hipMemcpyHostToDevice, h->stream));
     DS_HIP(h, hipStreamSynchronize(h->stream));                      // c is a stack buffer
     return DS_OK;
@@ -115,6 +119,19 @@ int flush_tick(ds_handle* o) {
     if (!o->pend_set) return DS_OK;
     o->pend_set = false;
     DS_HIP(o, ds::launch_tick(o->pend.cnt, o->pend.frames, o->pend.L, o->pend.aux_add, o->pend.aux_mod, o->pend_stream));
+    return DS_OK;
+}
+
+// utterance groups of a chain run on their own streams between calls; anything else that touches the handle first orders the chain's
+// stream behind them
+int join_groups(ds_handle* h) {
+    if (!h || !h->groups_open) return DS_OK;
+    h->groups_open = false;
+    for (int g = 0; g < 7; ++g) {
+        if (!h->side[g] || !h->ev_join[g]) continue;
+        DS_HIP(h, hipEventRecord(h->ev_join[g], h->side[g]));
+        DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[g], 0));
+    }
     return DS_OK;
 }
 
@@ -323,8 +340,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->graph_exec = nullptr; h->graph_valid = false; h->chain_warm_n = -1; h->adv_hist = 0;
     for (int i = 0; i < 11; ++i) { h->adv_frames[i] = 0; h->adv_td[i] = 0; }
     h->split = 1; h->ev_fork = nullptr;
-    h->parts = 1; h->pipe_stream = nullptr; h->ev_pipe = nullptr;
-    for (int i = 0; i < 8; ++i) h->ev_part[i] = nullptr;
+    h->parts = 1; h->groups_open = false;
     for (int i = 0; i < 7; ++i) { h->side[i] = nullptr; h->ev_join[i] = nullptr; }
     h->ki_istft = ki_istft; h->op = op;
     h->ki_rows = KernelInfo{nullptr, 0, 0, 0}; h->ki_rows_istft = h->ki_rows;
@@ -377,7 +393,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     DS_CRE(hipMalloc((void**)&h->tail_in, tail_in_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->tail_out, tail_out_bytes(h)));
     DS_CRE(hipMalloc((void**)&h->counters, counters_bytes(h)));
-    DS_CRE(hipMalloc((void**)&h->dev_cnt, 8 * sizeof(int)));
+    DS_CRE(hipMalloc((void**)&h->dev_cnt, 8 * DS_GROUPS * sizeof(int)));
     if (is_tdf) {
         const size_t Lf = cfg->filter_len;
         DS_CRE(hipMalloc((void**)&h->tdf_w, (size_t)cfg->batch * Lf * sizeof(float)));
@@ -415,9 +431,10 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             h->sub[i]->use_dev_cnt = true;                      // uniform counters read from the device: the chain replays as a hipGraph
             h->sub[i]->owner = h;
         }
-        // utterance groups pipelined through the stages: the HBM-bound WPE kernel of one group next to the arithmetic-bound McMcra / MVDR
-        // operators of the previous one (DS_PARAM_SPLIT; DS_CHAIN_PARTS in the environment overrides the default for A/B runs)
-        h->parts = 1;
+        // utterance groups: the batch as `parts` independent chains on their own streams (DS_PARAM_SPLIT; DS_CHAIN_PARTS in the environment
+        // overrides the default for A/B runs).  Two groups from 512 utterances up: one group's HBM-bound WPE kernel runs next to the other
+        // group's analysis, McMcra, MVDR and synthesis stages (+10 % at 1024 utterances); more groups cost the WPE kernel its grid
+        h->parts = cfg->batch >= 512 ? 2 : 1;
         if (const char* e = std::getenv("DS_CHAIN_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) h->parts = v; }
     }
     if (cfg->algo == DS_ALGO_TDGSC || cfg->algo == DS_ALGO_FDGSC) {
@@ -475,6 +492,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
 int ds_destroy(ds_handle* h) {
     if (!h) return DS_EINVAL;
     (void)hipSetDevice(h->device);
+    for (int i = 0; i < 7; ++i) if (h->side[i]) (void)hipStreamSynchronize(h->side[i]);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int i = 0; i < 10; ++i) if (h->sub[i]) (void)ds_destroy(h->sub[i]);
     for (int i = 0; i < 24; ++i) (void)hipFree(h->chain_buf[i]);
@@ -487,9 +505,6 @@ int ds_destroy(ds_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     for (int i = 0; i < 7; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (int i = 0; i < 8; ++i) if (h->ev_part[i]) (void)hipEventDestroy(h->ev_part[i]);
-    if (h->ev_pipe) (void)hipEventDestroy(h->ev_pipe);
-    if (h->pipe_stream) (void)hipStreamDestroy(h->pipe_stream);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
@@ -575,7 +590,15 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
             return DS_OK;
         case DS_PARAM_SPLIT:
             if (value < 1 || value > 8) return fail(h, DS_EINVAL, "split must be 1..8");
-            if (h->cfg.algo == DS_ALGO_WPE_MVDR) { h->parts = value; h->graph_valid = false; return DS_OK; }
+            if (h->cfg.algo == DS_ALGO_WPE_MVDR) {
+                // the groups' copies of the device counters start again from the host mirrors (copies of groups that did not run are stale)
+                int rc = set_device(h); if (rc) return rc;
+                DS_HIP(h, hipStreamSynchronize(h->stream));
+                h->parts = value; h->graph_valid = false;
+                rc = sync_dev_cnt(h); if (rc) return rc;
+                for (int i = 0; i < 10; ++i) if (h->sub[i]) { rc = sync_dev_cnt(h->sub[i]); if (rc) return fail(h, rc, h->sub[i]->err); }
+                return DS_OK;
+            }
             h->split = value; h->graph_valid = false;
             return DS_OK;
         default: return fail(h, DS_EINVAL, "unknown int parameter id");
@@ -723,7 +746,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
             }
         }
         ChainMirrors before;
-        if (chain) mirrors_get(h, before);
+        if (chain) { mirrors_get(h, before); const int jr = join_groups(h); if (jr) return jr; }
         DS_HIP(h, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         int crc = DS_OK;
         if (ns > 1) {
@@ -744,6 +767,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
                 if (hipEventRecord(h->ev_join[g2 - 1], bs) != hipSuccess || hipStreamWaitEvent(cs, h->ev_join[g2 - 1], 0) != hipSuccess) crc = DS_EHIP;
             }
         }
+        if (chain && crc == DS_OK) crc = join_groups(h);    // utterance groups of a chain: the side streams come back before the capture ends
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(cs, &g);
         if (chain) {                                      // nothing ran: the mirrors go back, one replay advances them by what the capture did
@@ -763,6 +787,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
         h->graph_valid = true;
     }
     if (graph == 2) return DS_OK;
+    if (chain) { const int jr = join_groups(h); if (jr) return jr; }
     DS_HIP(h, hipGraphLaunch(h->graph_exec, s));
     if (chain) {
         for (int i = 0; i < 11; ++i) {
@@ -801,6 +826,7 @@ int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y
     rc = ds_process_device(h, h->x_stage, layout, (long long)(M * (size_t)n_samples), 0, n_samples, h->y_stage,
                            (long long)n_samples, 0, h->cfg.batch, nullptr);
     if (rc) return rc;
+    rc = join_groups(h); if (rc) return rc;
     DS_HIP(h, hipMemcpyAsync(y, h->y_stage, ye * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     DS_HIP(h, hipStreamSynchronize(h->stream));
     return DS_OK;

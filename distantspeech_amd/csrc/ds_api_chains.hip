@@ -14,6 +14,7 @@ int chain_reserve(ds_handle* h, int T) {
     const size_t need[8] = {B * T * K * M * 8, 0, B * T * K * M * 8, B * T * K * 4, B * T * K * 4, B * T * K * 8, B * d * K * M * 8, 0};
     for (int i = 0; i < 8; ++i) {
         if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
+        { const int jr = join_groups(h); if (jr) return jr; }
         DS_HIP(h, hipStreamSynchronize(h->stream));
         h->graph_valid = false; h->chain_warm_n = -1;
         (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
@@ -24,23 +25,31 @@ int chain_reserve(ds_handle* h, int T) {
     return DS_OK;
 }
 
-// The same chain with the batch cut into `S` utterance groups that move through the stages as a two-stage pipeline: analysis + WPE of
-// group g + 1 on the chain's stream next to McMcra -> MVDR -> synthesis of group g on pipe_stream.  The WPE kernel is bound by HBM, the
-// 8-microphone operators by arithmetic, so the two overlap instead of queueing (utterances never interact; every kernel gets the
-// sub-range through its pointers).  All groups of a call read the same uniform counters; they advance once, behind the join.
-static int chain_process_pipelined(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
-                                   int n_samples, float* y_dev, long long y_batch_stride, int S) {
+// The same chain with the batch cut into `S` utterance groups, each running the whole chain on its own stream at its own pace: nothing
+// joins the groups between calls (join_groups() does when anything else touches the handle), so one group's HBM-bound WPE kernel runs
+// next to the other groups' analysis / McMcra / MVDR / synthesis stages, whichever step those are in.  Utterances never interact and
+// every kernel gets its sub-range through its pointers; each group reads and advances its own copy of the device counters.
+static int chain_process_groups(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
+                                int n_samples, float* y_dev, long long y_batch_stride, int S) {
     const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, T = n_samples / h->cfg.hop, dl = h->wpe_delay;
     float *D = h->chain_buf[0], *E = h->chain_buf[2], *pp = h->chain_buf[3], *G = h->chain_buf[4], *Y = h->chain_buf[5];
-    if (!h->pipe_stream) DS_HIP(h, hipStreamCreateWithFlags(&h->pipe_stream, hipStreamNonBlocking));
-    if (!h->ev_pipe) DS_HIP(h, hipEventCreateWithFlags(&h->ev_pipe, hipEventDisableTiming));
-    for (int g = 0; g < S; ++g) if (!h->ev_part[g]) DS_HIP(h, hipEventCreateWithFlags(&h->ev_part[g], hipEventDisableTiming));
+    if (!h->ev_fork) DS_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int g = 0; g < S - 1; ++g) {
+        if (!h->side[g]) DS_HIP(h, hipStreamCreateWithFlags(&h->side[g], hipStreamNonBlocking));
+        if (!h->ev_join[g]) DS_HIP(h, hipEventCreateWithFlags(&h->ev_join[g], hipEventDisableTiming));
+    }
     int rc = flush_tick(h); if (rc) return rc;
-    hipStream_t sa = h->stream, sb = h->pipe_stream;
+    if (!h->groups_open) {
+        // first call since the groups were joined: whatever is on the chain's stream (state imports, input uploads, a replayed graph) comes
+        // first for every group; from here on the groups only follow their own streams
+        DS_HIP(h, hipEventRecord(h->ev_fork, h->stream));
+        for (int g = 1; g < S; ++g) DS_HIP(h, hipStreamWaitEvent(h->side[g - 1], h->ev_fork, 0));
+    }
     const ds::TickArgs none = {nullptr, 0, 1, 0, 0};
     for (int g = 0; g < S; ++g) {
         const int lo = (int)((long long)B * g / S), nb = (int)((long long)B * (g + 1) / S) - lo;
         if (nb == 0) continue;
+        hipStream_t sg = g == 0 ? h->stream : h->side[g - 1];
         const size_t oz = (size_t)lo * T * K * M * 2, o1 = (size_t)lo * T * K;
         {   // analysis of the group's utterances (io through the pointers, the carried tails through batch0)
             ds_handle* t = h->sub[0];
@@ -52,24 +61,23 @@ static int chain_process_pipelined(ds_handle* h, const float* x_dev, int layout,
             if (layout == DS_LAYOUT_CHANNELS_SAMPLES) { p.x_sample_stride = 1; p.x_chan_stride = x_chan_stride > 0 ? x_chan_stride : n_samples; }
             else { p.x_sample_stride = M; p.x_chan_stride = 1; }
             p.T = T; p.batch0 = lo;
-            DS_HIP(h, t->ki.launch(p, nb, sa));
+            DS_HIP(h, t->ki.launch(p, nb, sg));
         }
-        if (dl > 0) rc = wpe_launch(h->sub[1], lo, nb, nullptr, D + oz, T, E + oz, h->chain_buf[6] + (size_t)lo * dl * K * M * 2, h->hist_cur, dl, h->dev_cnt + 3, sa);
-        else rc = wpe_launch(h->sub[1], lo, nb, D + oz, D + oz, T, E + oz, nullptr, 0, 0, nullptr, sa);
+        if (dl > 0) rc = wpe_launch(h->sub[1], lo, nb, nullptr, D + oz, T, E + oz, h->chain_buf[6] + (size_t)lo * dl * K * M * 2, h->hist_cur, dl, h->dev_cnt + 8 * g + 3, sg);
+        else rc = wpe_launch(h->sub[1], lo, nb, D + oz, D + oz, T, E + oz, nullptr, 0, 0, nullptr, sg);
         if (rc) return fail(h, rc, h->sub[1]->err);
-        DS_HIP(h, hipEventRecord(h->ev_part[g], sa));
-        DS_HIP(h, hipStreamWaitEvent(sb, h->ev_part[g], 0));
         {
             const float* in[3] = {E + oz, nullptr, nullptr};
             float* out[5] = {pp + o1, G + o1, nullptr, nullptr, nullptr};
-            rc = binop_launch(h->sub[2], lo, nb, T, in, out, 0, 0, sb, none); if (rc) return fail(h, rc, h->sub[2]->err);
+            rc = binop_launch(h->sub[2], lo, nb, T, in, out, 0, 0, sg, none, g); if (rc) return fail(h, rc, h->sub[2]->err);
         }
         {
             const float* in[3] = {E + oz, G + o1, nullptr};
             float* out[5] = {Y + o1 * 2, nullptr, nullptr, nullptr, nullptr};
-            rc = binop_launch(h->sub[3], lo, nb, T, in, out, 0, 1, sb, none); if (rc) return fail(h, rc, h->sub[3]->err);
+            rc = binop_launch(h->sub[3], lo, nb, T, in, out, 0, 1, sg, none, g); if (rc) return fail(h, rc, h->sub[3]->err);
         }
-        {   // synthesis into the caller's rows; the group is addressed through the pointers so that the one-row-per-wavefront kernel applies
+        {   // synthesis into the caller's rows; the group is addressed through the pointers so that the one-row-per-wavefront kernel applies,
+            // and the launch carries the advance of the McMcra counters (the operator that read them is behind it on this stream)
             ds_handle* t = h->sub[4];
             Params p;
             fill_params(t, p);
@@ -78,16 +86,15 @@ static int chain_process_pipelined(ds_handle* h, const float* x_dev, int layout,
             p.x_batch_stride = (long long)T * K * 2;
             p.y_batch_stride = y_batch_stride;
             p.T = T; p.batch0 = 0; p.method = 1;
-            DS_HIP(h, launch_transform_istft(t, p, nb, sb));
+            p.tick = ds::TickArgs{h->sub[2]->dev_cnt + 8 * g, T, h->sub[2]->mcra_L > 0 ? h->sub[2]->mcra_L : 1, 0, 0};
+            DS_HIP(h, launch_transform_istft(t, p, nb, sg));
         }
+        // the group's other counters: the WPE ring position and the frame loop's frame counter
+        const ds::TickArgs t0 = dl > 0 ? ds::TickArgs{h->dev_cnt + 8 * g, 0, 1, T % dl, dl} : none;
+        const ds::TickArgs t2 = {h->sub[3]->dev_cnt + 8 * g, T, h->sub[3]->mcra_L > 0 ? h->sub[3]->mcra_L : 1, 0, 0};
+        DS_HIP(h, ds::launch_tick3(t0, t2, none, sg));
     }
-    DS_HIP(h, hipEventRecord(h->ev_pipe, sb));
-    DS_HIP(h, hipStreamWaitEvent(sa, h->ev_pipe, 0));
-    // the uniform counters move once for the whole batch: the WPE ring position, McMcra's and the frame loop's frame counters
-    const ds::TickArgs t0 = dl > 0 ? ds::TickArgs{h->dev_cnt, 0, 1, T % dl, dl} : none;
-    const ds::TickArgs t1 = {h->sub[2]->dev_cnt, T, h->sub[2]->mcra_L > 0 ? h->sub[2]->mcra_L : 1, 0, 0};
-    const ds::TickArgs t2 = {h->sub[3]->dev_cnt, T, h->sub[3]->mcra_L > 0 ? h->sub[3]->mcra_L : 1, 0, 0};
-    DS_HIP(h, ds::launch_tick3(t0, t1, t2, sa));
+    h->groups_open = true;                                  // (a capture joins them before it ends: ds_process_device_seq)
     if (dl > 0) h->hist_cur = (h->hist_cur + T) % dl;
     advance_host_counters(h->sub[2], T, h->sub[2]->mcra_L);
     advance_host_counters(h->sub[3], T, h->sub[3]->mcra_L);
@@ -96,11 +103,12 @@ static int chain_process_pipelined(ds_handle* h, const float* x_dev, int layout,
 
 int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
                                 int n_samples, float* y_dev, long long y_batch_stride) {
-    int rc = set_device(h); if (rc) return rc;
+    DS_HIP(h, hipSetDevice(h->device));                       // not set_device(): the utterance groups stay on their own streams between calls
     const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, T = n_samples / h->cfg.hop;
-    rc = chain_reserve(h, T); if (rc) return rc;
+    int rc = chain_reserve(h, T); if (rc) return rc;
     const int S = h->parts < B ? h->parts : B;
-    if (S > 1) return chain_process_pipelined(h, x_dev, layout, x_batch_stride, x_chan_stride, n_samples, y_dev, y_batch_stride, S);
+    if (S <= 1) { rc = join_groups(h); if (rc) return rc; }
+    if (S > 1) return chain_process_groups(h, x_dev, layout, x_batch_stride, x_chan_stride, n_samples, y_dev, y_batch_stride, S);
     float *D = h->chain_buf[0], *E = h->chain_buf[2], *pp = h->chain_buf[3], *G = h->chain_buf[4], *Y = h->chain_buf[5];
 #define DS_SUB(i, call) do { int rc_ = (call); if (rc_) return fail(h, rc_, h->sub[i]->err); } while (0)
     {   // analysis, strided input like the fused kernels take it

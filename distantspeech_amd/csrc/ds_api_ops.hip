@@ -80,7 +80,7 @@ int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[5]) {
 // one launch of the operator over utterances [b0, b0 + nb) of the handle's batch; the io pointers already point at utterance b0.
 // Touches no counter: the caller advances the host mirrors and posts the device tick once the whole batch has been launched.
 int binop_launch(ds_handle* h, int b0, int nb, int n_frames, const float* const din[3], float* const dout[5], int is_complex, int has_p,
-                 hipStream_t stream, const ds::TickArgs& tick) {
+                 hipStream_t stream, const ds::TickArgs& tick, int group) {
     if (b0 != 0 && h->d_prev) return fail(h, DS_EUNSUPPORTED, "binop_launch: utterance sub-ranges are not available with a delayed desired signal");
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
@@ -96,7 +96,7 @@ int binop_launch(ds_handle* h, int b0, int nb, int n_frames, const float* const 
     p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
     p.steer = h->steer ? h->steer + (size_t)b0 * p.steer_batch_stride : nullptr;
     p.method = h->method; p.alpha_v = h->alpha_v; p.beta_v = ds::complement_of(h->alpha_v); p.gate = h->gate; p.diag = h->diag;
-    p.dev_cnt = h->use_dev_cnt ? h->dev_cnt : nullptr;
+    p.dev_cnt = h->use_dev_cnt ? h->dev_cnt + 8 * group : nullptr;
     p.tick = tick;
     DS_HIP(h, ds::launch_binop(h->op, p, stream));
     return DS_OK;

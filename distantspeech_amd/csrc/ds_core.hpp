@@ -410,6 +410,50 @@ template <int M> struct Chol {
 // (adaptivebeamformer.py:103-112,119-120 + beamformer.py:325-326).  Right-looking Cholesky on a working
 // copy of A with both forward substitutions fused into the column sweep: no back-substitution,
 // no stored factor, real denominator.
+#ifdef DS_SOLVE_FP64
+// Measured variant (scratch/build_variant.sh WORK fp64 "-DDS_SOLVE_FP64"): the same fused sweep in double on the
+// fp32 state, the reference's complex128 arithmetic (adaptivebeamformer.py:103-104).  Not the default: the fp32 sweep is already inside
+// the 1e-4 RMS bar and this one costs registers (occupancy) and the fp64 vector rate.
+template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag, const cf* a, const cf* z) {
+    struct dc { double x, y; };
+    auto F = [](double p, double q, double r) { return __builtin_fma(p, q, r); };
+    double Ad[M];
+    dc Al[M * (M - 1) / 2 + 1], u[M], t[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) { Ad[i] = (double)d[i] + (double)diag; u[i] = dc{a[i].x, a[i].y}; t[i] = dc{z[i].x, z[i].y}; }
+#pragma unroll
+    for (int q = 0; q < M * (M - 1) / 2; ++q) Al[q] = dc{o[2 * q], -(double)o[2 * q + 1]};
+    double nu = 0.0, utx = 0.0, uty = 0.0;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        const double sj = Ad[j] > 1e-30 ? Ad[j] : 1e-30;
+        const double r = 1.0 / __builtin_sqrt(sj);
+        const dc uj = dc{u[j].x * r, u[j].y * r}, tj = dc{t[j].x * r, t[j].y * r};
+        nu = F(uj.x, uj.x, F(uj.y, uj.y, nu));
+        utx = F(tj.x, uj.x, F(tj.y, uj.y, utx));                 // += conj(u_j) t_j
+        uty = F(tj.y, uj.x, F(-tj.x, uj.y, uty));
+        dc Lc[M];
+#pragma unroll
+        for (int i = j + 1; i < M; ++i) {
+            const dc A = Al[off_index(j, i, M)];
+            Lc[i] = dc{A.x * r, A.y * r};
+            u[i] = dc{F(-Lc[i].x, uj.x, F(Lc[i].y, uj.y, u[i].x)), F(-Lc[i].x, uj.y, F(-Lc[i].y, uj.x, u[i].y))};
+            t[i] = dc{F(-Lc[i].x, tj.x, F(Lc[i].y, tj.y, t[i].x)), F(-Lc[i].x, tj.y, F(-Lc[i].y, tj.x, t[i].y))};
+        }
+#pragma unroll
+        for (int i = j + 1; i < M; ++i) {
+            Ad[i] = F(-Lc[i].x, Lc[i].x, F(-Lc[i].y, Lc[i].y, Ad[i]));
+#pragma unroll
+            for (int k = j + 1; k < i; ++k) {
+                const int q = off_index(k, i, M);                // A_ik -= L_ij conj(L_kj)
+                Al[q] = dc{F(-Lc[i].x, Lc[k].x, F(-Lc[i].y, Lc[k].y, Al[q].x)), F(-Lc[i].y, Lc[k].x, F(Lc[i].x, Lc[k].y, Al[q].y))};
+            }
+        }
+    }
+    const double inv = 1.0 / nu;
+    return mk((float)(utx * inv), (float)(uty * inv));
+}
+#else
 template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag, const cf* a, const cf* z) {
     float Ad[M];
     cf Al[M * (M - 1) / 2 + 1];          // strictly-lower A_ij (i>j) at off_index(j, i)
@@ -451,6 +495,7 @@ template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag
     const float inv = 1.0f / nu;
     return mk(ut.x * inv, ut.y * inv);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Per-bin algorithms.  Return the beamformer output Y[k].

@@ -22,6 +22,8 @@ using ds::cf;
 using ds::KernelInfo;
 using ds::Params;
 
+constexpr int DS_GROUPS = 8;     // copies of a handle's device counters (one per utterance group of a chain)
+
 struct ds_handle {
     ds_config cfg;
     int K, KP, NP, NT;
@@ -77,11 +79,11 @@ struct ds_handle {
     hipEvent_t ev_fork, ev_join[7];
     long long graph_key[16];
     bool graph_valid;
-    // DS_ALGO_WPE_MVDR: utterance groups pipelined through the stages (group g + 1 in the WPE kernel on `stream` while group g runs the
-    // McMcra / MVDR / synthesis stages on `pipe_stream`); parts = 1: every stage over the whole batch on `stream`
+    // DS_ALGO_WPE_MVDR: the batch as `parts` utterance groups, each running the whole chain on its own stream (group 0: `stream`, group g:
+    // side[g - 1]) at its own pace between calls — one group's WPE kernel next to the other groups' remaining stages.  Every group has
+    // its own copy of the device counters (dev_cnt + 8 g); groups_open: side streams hold work the chain's stream has not joined yet
     int parts;
-    hipStream_t pipe_stream;
-    hipEvent_t ev_part[8], ev_pipe;
+    bool groups_open;
     // chain handles under graph replay: the shape (samples per call) that has run once with plain launches (buffers sized, start-up
     // branches behind), and what one replay of the captured sequence does to the host mirrors of the stages' uniform counters
     ds_handle* owner;           // the chain handle this stage belongs to (null: stand-alone)
@@ -135,12 +137,13 @@ void advance_host_counters(ds_handle* h, int frames, int L);
 int post_tick(ds_handle* t, int* cnt, int frames, int L, int aux_add, int aux_mod, hipStream_t stream);
 void take_tick(ds_handle* t, hipStream_t stream, ds::TickArgs& out);
 int flush_tick(ds_handle* chain);
+int join_groups(ds_handle* chain);
 int io_begin(ds_handle* h, int mem, const IoSpec& io, const float* din[3], float* dout[5]);
 int io_end(ds_handle* h, int mem, const IoSpec& io, float* dout[5]);
 int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int mem, const IoSpec& io, int is_complex, int has_p);
 // sub-range launches (utterances [b0, b0 + nb), device pointers at utterance b0) that touch no counter: the stages of a pipelined chain
 int binop_launch(ds_handle* h, int b0, int nb, int n_frames, const float* const din[3], float* const dout[5], int is_complex, int has_p,
-                 hipStream_t stream, const ds::TickArgs& tick);
+                 hipStream_t stream, const ds::TickArgs& tick, int group = 0);
 int wpe_launch(ds_handle* h, int b0, int nb, const float* x_delayed, const float* d, int n_frames, float* err, float* ring, int ring_pos,
                int ring_len, const int* dev_ring_pos, hipStream_t stream);
 int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len,

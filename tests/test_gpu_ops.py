@@ -771,10 +771,11 @@ def test_chain_graph_replay_equals_plain_launches(ds, chain):
 
 
 @pytest.mark.parametrize("parts", [2, 3, 5])
-def test_wpe_mvdr_chain_pipelined_groups_equal_the_whole_batch(ds, parts):
-    """DS_ALGO_WPE_MVDR moves utterance groups through its stages as a pipeline (WPE of group g + 1 next to McMcra / MVDR / synthesis of
-    group g, two streams).  Utterances never interact, so any grouping gives the samples and the state of the one-group chain bit for bit —
-    uneven groups, plain launches and hipGraph replays, one hop and several hops per call, a non-zero WPE delay ring."""
+def test_wpe_mvdr_chain_utterance_groups_equal_the_whole_batch(ds, parts):
+    """DS_ALGO_WPE_MVDR runs its batch as utterance groups, each the whole chain on its own stream at its own pace (one group's WPE kernel
+    next to the other groups' remaining stages; every group has its own copy of the device counters).  Utterances never interact, so any
+    grouping gives the samples and the state of the one-group chain bit for bit — uneven groups, plain launches and hipGraph replays,
+    several hops per call, a non-zero WPE delay ring, state exported while the groups are still running."""
     from _cases import DeviceBuffers
     from distantspeech_amd import _lib as L
     M, nfft, hop, B, T, n_calls, rounds = 8, 1024, 512, 5, 2, 3, 4
