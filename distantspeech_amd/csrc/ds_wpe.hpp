@@ -13,6 +13,8 @@
 // kernel is HBM-bound at one frame per call); and P cannot drift away from Hermitian over a long stream.
 // State per bin is one contiguous block; every lane reads the words it needs straight from it (its row above the diagonal, and
 // its column above the diagonal for the part of the row below it — no exchange), once in and once out per call.
+// A bin's lanes never leave their wavefront (LPB divides 64) and every LDS hand-off is between the lanes of one bin, so no phase needs a
+// workgroup barrier: they are wave-local phases (Exec::phase_wave), which is what the kernel lives on when a call carries many frames.
 // Written against the Exec policy (tests/emul runs it serially on the CPU).
 #pragma once
 #include "ds_core.hpp"
@@ -96,7 +98,7 @@ template <int LPB> struct WpeEngine {
             const long long f = io_base(g, t - p.ring_len);
             return mk(p.d[2 * (f + c)], p.d[2 * (f + c) + 1]);
         };
-        ex.phase([&](int tid, Rg& r) {
+        ex.phase_wave([&](int tid, Rg& r) {
             int s, i; long long g; bool on;
             slot(tid, s, i, g, on);
             if (!on) { if (i < LPB && s < BPW) sh.X[0][s][i] = mk(0.0f, 0.0f); return; }
@@ -120,7 +122,7 @@ template <int LPB> struct WpeEngine {
             if (i == c * N) r.xin = delayed(g, 0, c);
             if (i < C) r.din = mk(p.d[2 * (f0 + i)], p.d[2 * (f0 + i) + 1]);
         });
-        ex.phase([&](int tid, Rg& r) {                            // row i of P: above the diagonal as stored, below it the conjugate of column i
+        ex.phase_wave([&](int tid, Rg& r) {                            // row i of P: above the diagonal as stored, below it the conjugate of column i
             int s, i; long long g; bool on;
             slot(tid, s, i, g, on);
             if (!on) return;
@@ -133,7 +135,7 @@ template <int LPB> struct WpeEngine {
         for (int t = 0; t < p.T; ++t) {
             const int nxt = cur ^ 1;
             // ---- buffer_input (:80-102): per channel shift along the taps, newest delayed frame at tap 0
-            ex.phase([&](int tid, Rg& r) {
+            ex.phase_wave([&](int tid, Rg& r) {
                 int s, i; long long g; bool on;
                 slot(tid, s, i, g, on);
                 if (!on) return;
@@ -148,7 +150,7 @@ template <int LPB> struct WpeEngine {
                 }
             });
             // ---- per-lane products: g_i = (P X)_i, conj(W[c][i]) X_i, Re(conj(X_i) g_i)
-            ex.phase([&](int tid, Rg& r) {
+            ex.phase_wave([&](int tid, Rg& r) {
                 int s, i; long long g; bool on;
                 slot(tid, s, i, g, on);
                 if (!on) return;
@@ -171,7 +173,7 @@ template <int LPB> struct WpeEngine {
                 }
             });
             // ---- err_c = d_c - sum_i conj(W[c][i]) X_i in lane order  (:158-161)
-            ex.phase([&](int tid, Rg&) {
+            ex.phase_wave([&](int tid, Rg&) {
                 int s, i; long long g; bool on;
                 slot(tid, s, i, g, on);
                 if (!on || i >= C) return;
@@ -183,7 +185,7 @@ template <int LPB> struct WpeEngine {
                 p.err[2 * (f + i)] = e.x; p.err[2 * (f + i) + 1] = e.y;
             });
             // ---- gain, P and W updates
-            ex.phase([&](int tid, Rg& r) {
+            ex.phase_wave([&](int tid, Rg& r) {
                 int s, i; long long g; bool on;
                 slot(tid, s, i, g, on);
                 if (!on) return;
@@ -214,7 +216,7 @@ template <int LPB> struct WpeEngine {
             });
             cur = nxt;
         }
-        ex.phase([&](int tid, Rg& r) {                            // the upper triangle back through the tile
+        ex.phase_wave([&](int tid, Rg& r) {                            // the upper triangle back through the tile
             int s, i; long long g; bool on;
             slot(tid, s, i, g, on);
             if (!on) return;
@@ -223,7 +225,7 @@ template <int LPB> struct WpeEngine {
             for (int q = 0; q < LPB; ++q)
                 if (q < CN && q >= i) tri[q * (q + 1) / 2 + i] = r.P[q];
         });
-        ex.phase([&](int tid, Rg& r) {
+        ex.phase_wave([&](int tid, Rg& r) {
             int s, i; long long g; bool on;
             slot(tid, s, i, g, on);
             if (!on) return;
