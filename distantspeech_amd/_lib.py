@@ -7,6 +7,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# The chain handles spread their stages over up to five HIP streams; the runtime's default of 4 hardware queues per device makes two of
+# them share a queue (false serialisation).  Only effective if nothing in the process has initialised HIP yet.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 LIB_PATH = os.environ.get("DSENH_LIB", os.path.join(_HERE, "libdsenh.so"))   # DSENH_LIB: A/B of kernel builds
 
 DS_OK = 0

@@ -341,9 +341,11 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     for (int i = 0; i < 11; ++i) { h->adv_frames[i] = 0; h->adv_td[i] = 0; }
     h->split = 1; h->ev_fork = nullptr;
     h->parts = 1; h->groups_open = false;
+    h->front_async = false; h->tail_async = false; h->front_open = false; h->fr_valid[0] = h->fr_valid[1] = false; h->tf_valid[0] = h->tf_valid[1] = false; h->front_set = 0;
+    for (int i = 0; i < 8; ++i) h->ev_fr[i] = nullptr;
     for (int i = 0; i < 7; ++i) { h->side[i] = nullptr; h->ev_join[i] = nullptr; }
     h->ki_istft = ki_istft; h->op = op;
-    h->ki_rows = KernelInfo{nullptr, 0, 0, 0}; h->ki_rows_istft = h->ki_rows;
+    h->ki_rows = KernelInfo{nullptr, 0, 0, 0}; h->ki_rows_istft = h->ki_rows; h->ki_aic = h->ki_rows;
     if (cfg->algo == DS_ALGO_TRANSFORM && cfg->n_mics == 1) { h->ki_rows = ds::lookup_stft_rows(cfg->nfft); h->ki_rows_istft = ds::lookup_istft_rows(cfg->nfft); }
  h->opst = nullptr; h->NF = NF;
     h->op_frm = 0; h->op_ell = 1; h->op_first = 1;
@@ -481,9 +483,34 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             }
             for (int i = 3; i <= 6; ++i) h->sub[i]->stream = h->side[0];
         }
+        // the front end (notch, FIR bank, M-channel analysis: latency-bound) on a stream of its own, double-buffered: block t + 1's front end
+        // next to block t's HBM-bound stages (DS_CHAIN_SERIAL_FRONT=1: on the chain's stream, A/B runs)
+        const char* serial = std::getenv("DS_CHAIN_SERIAL_FRONT");
+        if (!(serial && serial[0] == '1')) {
+            bool ok = hipStreamCreateWithFlags(&h->side[1], hipStreamNonBlocking) == hipSuccess;
+            for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreateWithFlags(&h->ev_fr[i], hipEventDisableTiming) == hipSuccess;
+            // the tail on a stream of its own needs a hardware queue of its own: with the runtime's default of 4 queues per device the fourth
+            // and fifth stream of the process share one and the front end would queue behind the previous block's tail (measured: 0.31 ms per
+            // block instead of 0.28).  The application raises the limit before the first HIP call (GPU_MAX_HW_QUEUES=8; bench.py and the
+            // Python binding do); without that the tail stays on the chain's stream
+            const char* hwq = std::getenv("GPU_MAX_HW_QUEUES");
+            if (ok && hwq && std::atoi(hwq) >= 6) {
+                ok = hipStreamCreateWithFlags(&h->side[2], hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&h->ev_join[2], hipEventDisableTiming) == hipSuccess;
+                h->tail_async = ok;
+            }
+            if (ok && !h->ev_fork) ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+            if (!ok) { ds_destroy(h); return fail(nullptr, DS_EHIP, "ds_create(DS_ALGO_SUBBAND_GSC): front-end stream"); }
+            h->front_async = true;
+            h->sub[0]->stream = h->side[1]; h->sub[1]->stream = h->side[1];
+        }
         h->sub[5]->x_fan = M;                 // the M blocking filters of an utterance share its fixed-beamformer spectrum and p ...
         h->sub[5]->d_interleaved = 1;         // ... and take their desired signals straight from the M-channel STFT of the aligned channels
         h->sub[7]->p_complement = 1;          // SubbandGSC.py:232: p = 1 - p
+        // the chain's tail (re-analysis of the blocking-matrix outputs -> canceller -> synthesis) as one frame kernel on the stages' own
+        // state; DS_CHAIN_UNFUSED=1 keeps the three separate kernels (A/B runs, and the reference point of the parity test)
+        const char* unf = std::getenv("DS_CHAIN_UNFUSED");
+        if (flen == 2 && h->sub[7]->NF == 8 * M + 1 && !(unf && unf[0] == '1')) h->ki_aic = ds::lookup_aic(cfg->nfft, M);
     }
     *out = h;
     return DS_OK;
@@ -505,6 +532,7 @@ int ds_destroy(ds_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     for (int i = 0; i < 7; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int i = 0; i < 8; ++i) if (h->ev_fr[i]) (void)hipEventDestroy(h->ev_fr[i]);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);
@@ -747,6 +775,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
         }
         ChainMirrors before;
         if (chain) { mirrors_get(h, before); const int jr = join_groups(h); if (jr) return jr; }
+        h->front_open = false;                              // a chain's front-end stream joins the capture from the chain's stream
         DS_HIP(h, hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         int crc = DS_OK;
         if (ns > 1) {
@@ -770,6 +799,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
         if (chain && crc == DS_OK) crc = join_groups(h);    // utterance groups of a chain: the side streams come back before the capture ends
         hipGraph_t g = nullptr;
         hipError_t e = hipStreamEndCapture(cs, &g);
+        h->front_open = false;
         if (chain) {                                      // nothing ran: the mirrors go back, one replay advances them by what the capture did
             ChainMirrors after;
             mirrors_get(h, after);
@@ -789,6 +819,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     if (graph == 2) return DS_OK;
     if (chain) { const int jr = join_groups(h); if (jr) return jr; }
     DS_HIP(h, hipGraphLaunch(h->graph_exec, s));
+    h->front_open = false;                                  // whatever follows on the front-end stream follows the replay
     if (chain) {
         for (int i = 0; i < 11; ++i) {
             ds_handle* t = i < 10 ? h->sub[i] : h;
@@ -823,6 +854,7 @@ int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y
         h->y_stage_elems = ye;
     }
     DS_HIP(h, hipMemcpyAsync(h->x_stage, x, xe * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    h->front_open = false;                                  // a chain's front-end stream follows the upload
     rc = ds_process_device(h, h->x_stage, layout, (long long)(M * (size_t)n_samples), 0, n_samples, h->y_stage,
                            (long long)n_samples, 0, h->cfg.batch, nullptr);
     if (rc) return rc;

@@ -158,8 +158,17 @@ int chain2_reserve(ds_handle* h, int n) {
     need[G_D] = need[G_XAIC] = B * T * K * M * 8; need[G_P] = B * T * K * 4;
     need[G_F] = need[G_E2] = B * T * K * 8; need[G_E] = B * M * T * K * 8;
     need[G_FPREV] = B * K * 8; need[G_FIXPREV] = B * hop * 4;
+    if (h->ki_aic.launch) need[G_XAIC] = need[G_E2] = 0;                      // the fused tail keeps both in registers / LDS
+    // second set of the front end's buffers: block t + 1's front end next to block t's later stages (not for very long calls, where the
+    // front end is a small share of a call anyway and the set would cost gigabytes)
+    const size_t second = 2 * need[G_XN] + need[G_FIXED] + need[G_D];
+    if (h->front_async && second <= ((size_t)4 << 30)) {
+        need[G_XN2] = need[G_XA2] = need[G_XN]; need[G_FIXED2] = need[G_FIXED]; need[G_D2] = need[G_D];
+        if (h->ki_aic.launch && h->tail_async) { need[G_P2] = need[G_P]; need[G_F2] = need[G_F]; need[G_BM2] = need[G_BM]; }
+    }
     for (int i = 0; i < G_COUNT; ++i) {
         if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
+        { const int jr = join_groups(h); if (jr) return jr; }
         DS_HIP(h, hipStreamSynchronize(h->stream));
         h->graph_valid = false; h->chain_warm_n = -1;
         (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
@@ -198,31 +207,59 @@ static int chain_istft(ds_handle* h, ds_handle* t, const float* Y, int T, float*
 // x_dev: [B][M][n] with element strides (x_bstride, x_cstride); y_dev [B] rows of n with stride y_bstride; the optional outputs dense
 int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
                       float* fix_dev, float* bm_dev, float* p_dev, float* al_dev) {
-    int rc = set_device(h); if (rc) return rc;
+    DS_HIP(h, hipSetDevice(h->device));                      // not set_device(): the tail of the previous block stays on its own stream
+    int rc = DS_OK;
     ds_handle* fe = h->sub[0];
     const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, hop = h->cfg.hop, T = n / hop;
     if (fe->aux_floats == 0 || fe->aux_floats % M != 0 || h->sub[2]->aux_floats < (size_t)K)
         return fail(h, DS_ESTATE, "SubbandGSC chain: call ds_chain_set_aux(DS_CHAIN_AUX_FIR) and (DS_CHAIN_AUX_COHERENCE) first");
     rc = chain2_reserve(h, n); if (rc) return rc;
-    float** cb = h->chain_buf;
+    float* cb[G_COUNT];
+    for (int i = 0; i < G_COUNT; ++i) cb[i] = h->chain_buf[i];
+    // the front end's stream and buffer set.  With a second set, block t + 1's front end only waits for the set to be free (block t - 1
+    // behind it); otherwise it is ordered behind the whole of block t
+    hipStream_t fs = h->front_async ? h->side[1] : h->stream;
+    int set = 0;
+    if (h->front_async) {
+        const bool two = h->chain_buf[G_D2] != nullptr;
+        if (!h->front_open) {                               // first block since something else used the chain's stream: start from there
+            DS_HIP(h, hipEventRecord(h->ev_fork, h->stream));
+            DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fork, 0));
+            h->front_open = true; h->fr_valid[0] = h->fr_valid[1] = false; h->tf_valid[0] = h->tf_valid[1] = false;
+        }
+        set = two ? h->front_set : 0;
+        h->front_set ^= 1;
+        if (h->fr_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[2 + set], 0));
+        if (set) {
+            cb[G_XN] = cb[G_XN2]; cb[G_XA] = cb[G_XA2]; cb[G_FIXED] = cb[G_FIXED2]; cb[G_D] = cb[G_D2];
+            if (h->chain_buf[G_P2]) { cb[G_P] = cb[G_P2]; cb[G_F] = cb[G_F2]; cb[G_BM] = cb[G_BM2]; }
+        }
+    }
+    const bool tail_async = h->tail_async && h->ki_aic.launch != nullptr;    // the tail on its own stream (side[2])
 #define DS_SUB(i, call) do { int rc_ = (call); if (rc_) return fail(h, rc_, h->sub[i]->err); } while (0)
     {   // :177-178 DC notch per channel, then :201,206 TimeAlignment FIR bank + channel mean (the fixed beamformer)
         ds::TdParams p;
         std::memset(&p, 0, sizeof p);
         p.B = B; p.M = M; p.n = n; p.x = x_dev; p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.y = cb[G_XN]; p.mem = fe->td_mem;
         p.radius = fe->cfg.filt_alpha;
-        DS_HIP(h, ds::launch_dcnotch(p, h->stream));
+        DS_HIP(h, ds::launch_dcnotch(p, fs));
         const int Lt = (int)(fe->aux_floats / M);
         rc = frontend_set_taps(fe, Lt); if (rc) return fail(h, rc, fe->err);
         std::memset(&p, 0, sizeof p);
         p.B = B; p.M = M; p.n = n; p.L = Lt; p.x = cb[G_XN]; p.x_chan_major = 1; p.y = cb[G_XA]; p.y_chan_major = 1; p.mean = cb[G_FIXED];
         // the ping-pong parity of the FIR history is device-resident (dev_cnt[3], flipped by the tick behind the launch): graph replay
         p.coef = fe->dev_buf[9]; p.cache_in = fe->td_cache[0]; p.cache_out = fe->td_cache[1]; p.dev_parity = fe->dev_cnt + 3;
-        DS_HIP(h, ds::launch_fir(p, h->stream));
-        rc = post_tick(fe, fe->dev_cnt, 0, 1, 1, 2, h->stream); if (rc) return rc;     // rides in the analysis launch that follows
+        DS_HIP(h, ds::launch_fir(p, fs));
+        rc = post_tick(fe, fe->dev_cnt, 0, 1, 1, 2, fs); if (rc) return rc;            // rides in the analysis launch that follows
         fe->td_cur ^= 1;
     }
     rc = chain_stft(h, h->sub[1], cb[G_XA], n, cb[G_D]); if (rc) return rc;                                   // :204  D
+    if (h->front_async) {
+        DS_HIP(h, hipEventRecord(h->ev_fr[set], fs));
+        DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_fr[set], 0));
+        // the middle stages write p, F and the blocking-matrix outputs of this set: the tail that read them last comes first
+        if (tail_async && h->tf_valid[set]) DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_fr[6 + set], 0));
+    }
     const bool fork = h->sub[5]->stream != h->stream;                       // blocking-filter branch on the side stream (RLS filters, see ds_create)
     if (fork) {
         DS_HIP(h, hipEventRecord(h->ev_fork, h->stream));
@@ -235,16 +272,46 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[G_F], cb[G_D], T, cb[G_E], DS_MEM_DEVICE));
     else DS_SUB(5, ds_sublms_update(h->sub[5], cb[G_F], cb[G_D], cb[G_P], T, cb[G_E], DS_MEM_DEVICE));
     rc = chain_istft(h, h->sub[4], cb[G_E], T, cb[G_BM], n); if (rc) return rc;                               // bm outputs, [B*M][n] = [B][M][n]
-    rc = chain_stft(h, h->sub[6], cb[G_BM], n, cb[G_XAIC]); if (rc) return rc;                                  // :230-234  aic transform_x
+    const bool fused_tail = h->ki_aic.launch != nullptr;
+    if (!fused_tail) { rc = chain_stft(h, h->sub[6], cb[G_BM], n, cb[G_XAIC]); if (rc) return rc; }             // :230-234  aic transform_x
     if (fork) {
         DS_HIP(h, hipEventRecord(h->ev_join[0], h->sub[5]->stream));
         DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[0], 0));
     }
     // :226 delay_fbf: the canceller's desired signal is the fixed output one block late = F one frame late; the operator keeps the
     // carried frame in cb[G_FPREV] itself
-    h->sub[7]->d_prev = cb[G_FPREV];
-    DS_SUB(7, ds_sublms_update(h->sub[7], cb[G_XAIC], cb[G_F], cb[G_P], T, cb[G_E2], DS_MEM_DEVICE));
-    rc = chain_istft(h, h->sub[8], cb[G_E2], T, y_dev, y_bstride); if (rc) return rc;
+    if (fused_tail) {
+        // :230-262 as ONE frame kernel: analysis of the M blocking-matrix outputs, the canceller as the per-bin program (state where the
+        // subband-LMS stage keeps it), synthesis into the caller's rows — X_aic and the error spectrum never leave the workgroup
+        ds_handle *ta = h->sub[6], *op = h->sub[7], *ts = h->sub[8];
+        Params p;
+        fill_params(ta, p);
+        p.x = cb[G_BM]; p.y = y_dev;
+        p.x_batch_stride = (long long)M * n; p.x_sample_stride = 1; p.x_chan_stride = n;
+        p.y_batch_stride = y_bstride;
+        p.T = T; p.batch0 = 0;
+        p.tail_out = ts->tail_out; p.out_scale = ts->out_scale;
+        p.aic_st = op->opst; p.aic_NF = op->NF; p.aic_d = cb[G_F]; p.aic_dprev = cb[G_FPREV]; p.aic_p = cb[G_P];
+        p.aic_pc = op->p_complement; p.aic_norm = op->norm; p.aic_mu = op->filt_mu; p.aic_alpha = op->filt_alpha; p.aic_reg = 1e-4f;
+        if (tail_async) {
+            // McSpp's counter advance stays on the chain's stream (the next block's McSpp follows it there); the tail follows the middle stages
+            // on its own stream, the next block's middle stages do not wait for it
+            rc = flush_tick(h); if (rc) return rc;
+            DS_HIP(h, hipEventRecord(h->ev_fr[4 + set], h->stream));
+            DS_HIP(h, hipStreamWaitEvent(h->side[2], h->ev_fr[4 + set], 0));
+            DS_HIP(h, h->ki_aic.launch(p, B, h->side[2]));
+            DS_HIP(h, hipEventRecord(h->ev_fr[6 + set], h->side[2]));
+            h->tf_valid[set] = true;
+            h->groups_open = true;                                          // join_groups(): side[2] comes back before anything else touches the handle
+        } else {
+            take_tick(op, h->stream, p.tick);                               // McSpp's counter advance
+            DS_HIP(h, h->ki_aic.launch(p, B, h->stream));
+        }
+    } else {
+        h->sub[7]->d_prev = cb[G_FPREV];
+        DS_SUB(7, ds_sublms_update(h->sub[7], cb[G_XAIC], cb[G_F], cb[G_P], T, cb[G_E2], DS_MEM_DEVICE));
+        rc = chain_istft(h, h->sub[8], cb[G_E2], T, y_dev, y_bstride); if (rc) return rc;
+    }
     {   // fix_output = fixed beamformer output delayed by one block (:226,255); the carried block is state either way
         const size_t blk = (size_t)hop * 4, row = (size_t)n * 4;
         if (fix_dev) {
@@ -258,7 +325,12 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     if (al_dev) DS_HIP(h, hipMemcpyAsync(al_dev, cb[G_XA], nb, hipMemcpyDeviceToDevice, h->stream));
     if (p_dev) DS_HIP(h, hipMemcpyAsync(p_dev, cb[G_P], (size_t)B * T * K * 4, hipMemcpyDeviceToDevice, h->stream));
 #undef DS_SUB
-    return flush_tick(h);
+    rc = flush_tick(h); if (rc) return rc;
+    if (h->front_async) {                                   // everything that reads this block's front-end buffers is on the chain's stream by now
+        DS_HIP(h, hipEventRecord(h->ev_fr[2 + set], h->stream));
+        h->fr_valid[set] = true;
+    }
+    return DS_OK;
 }
 
 
@@ -287,9 +359,11 @@ int ds_subband_gsc_process(ds_handle* h, const float* x, int n_samples, float* y
                  {B * n * 4, fix_output ? B * n * 4 : 0, bm_output ? B * M * n * 4 : 0, pp ? B * T * h->K * 4 : 0, aligned ? B * M * n * 4 : 0}};
     const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    if (mem == DS_MEM_HOST) h->front_open = false;          // the input was just staged on the chain's stream: the front-end stream follows it
     rc = chain2_run(h, din[0], (long long)(M * n), (long long)n, n_samples, dout[0], (long long)n, fix_output ? dout[1] : nullptr,
                     bm_output ? dout[2] : nullptr, pp ? dout[3] : nullptr, aligned ? dout[4] : nullptr);
     if (rc) return rc;
+    rc = join_groups(h); if (rc) return rc;                 // the tail's stream, before the outputs are copied back
     return io_end(h, mem, io, dout);
 }
 

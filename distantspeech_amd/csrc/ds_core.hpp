@@ -99,7 +99,7 @@ inline float complement_of(float a) {
 DS_HD float fminf_(float a, float b) { return a < b ? a : b; }
 DS_HD float fmaxf_(float a, float b) { return a > b ? a : b; }
 
-enum { ALGO_FIXED = 0, ALGO_ADAPTIVE = 1, ALGO_GSC = 2 };
+enum { ALGO_FIXED = 0, ALGO_ADAPTIVE = 1, ALGO_GSC = 2, ALGO_AIC = 3 };   // ALGO_AIC: the SubbandGSC chain's tail (see aic_bin)
 enum { METHOD_SRC = 0, METHOD_DS = 1, METHOD_MVDR = 2, METHOD_TFGSC = 3 };
 
 // Device-resident uniform counters of a chain stage, cnt = {frm_cnt, ell, first_frame, aux}: a later kernel of the same stream carries
@@ -147,6 +147,15 @@ struct Params {
     float mu;                 // GSC.py:202
     int rows;                 // single-channel transforms run one row per wavefront (StftRowsEngine / IstftRowsEngine): number of rows
     TickArgs tick;            // counters of an EARLIER stage of the chain to advance (stand-alone transform kernels only; cnt null = none)
+    // ALGO_AIC, the SubbandGSC chain's tail as one frame kernel: re-analysis of the M blocking-matrix outputs (x) -> multi-channel subband
+    // NLMS canceller (SubbandLmsMc, 2 taps) -> synthesis (y).  The canceller's state stays where the DS_ALGO_SUBLMS operator keeps it.
+    float* aic_st;            // [B][aic_NF][KP] planes: W (2 N M), tap buffer X (2 N M), smoothed input power P
+    int aic_NF;
+    const float* aic_d;       // desired-signal spectra, complex [B][T][K]; the canceller takes them one frame late (SubbandGSC.py:226) ...
+    float* aic_dprev;         // ... complex [B][K]: the frame carried from the previous call
+    const float* aic_p;       // update probability [B][T][K]
+    int aic_pc, aic_norm;     // p -> 1 - p (SubbandGSC.py:232); normalised step (SubbandLmsMc.py:174-180)
+    float aic_mu, aic_alpha, aic_reg;
 };
 
 // number of per-bin state floats / planes
@@ -154,6 +163,7 @@ template <int M, int ALGO, bool RYY> struct StateLayout {
     static constexpr int NF =
         ALGO == ALGO_ADAPTIVE ? (M * M + 5 + (RYY ? M * M : 0))
         : ALGO == ALGO_GSC    ? (M * (M + 1) + 2 * (M - 1))
+        : ALGO == ALGO_AIC    ? (8 * M + 1)            // 2-tap M-channel canceller: W, X (2 M complex each), P
                               : 0;
     static constexpr int NP = (NF + 3) / 4;
     // ADAPTIVE float map
@@ -206,6 +216,8 @@ template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
     vec4 pre[NPRE];
     const vec4* xp[NPRE];     // this lane's read position in the input stream (advanced one hop per frame)
     vec4 nyq;                 // prologue: plane `tid` of the Nyquist bin on its way to LDS
+    cf ad, adn;               // ALGO_AIC: desired-signal sample of this frame for this lane's bin / for the Nyquist bin (lane NYQ_TID)
+    float apk, apkn;          // ... and the update probability
 };
 
 // state-plane accessors.  Every state line is read once and written once per launch and is next touched by the following launch,
@@ -713,6 +725,65 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
     return cscale(Yk, G);                                                                   // GSC.py:286
 }
 
+// The SubbandGSC canceller for one bin: SubbandLmsMc.update with 2 taps on M channels (SubbandLmsMc.py:62-63,150-190 through
+// SubbandGSC.py:230-236), the arithmetic of op_sublms_t<2, M> (ds_ops.hpp) word for word.  st = [W (2 M complex) | X (2 M complex) | P].
+template <int M> DS_HD cf aic_bin(float* st, const cf* Xin, cf d, float pk, const Params& p) {
+    constexpr int NC = 2 * M, NC2 = 2 * NC;
+    float* W = st;
+    float* X = st + NC2;
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+        X[2 * (M + c)] = X[2 * c]; X[2 * (M + c) + 1] = X[2 * c + 1];            // tap 1 <- tap 0
+        X[2 * c] = Xin[c].x; X[2 * c + 1] = Xin[c].y;                              // tap 0 <- this frame
+    }
+    cf out = mk(0.0f, 0.0f);
+    float pw = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const cf x = mk(X[2 * i], X[2 * i + 1]);
+        out = cfmac(out, x, mk(W[2 * i], W[2 * i + 1]));                           // conj(W) X
+        pw += cabs2(x);
+    }
+    if (p.aic_pc) pk = 1.0f - pk;
+    const cf err = mk(fma_(-out.x, pk, d.x), fma_(-out.y, pk, d.y));             // d - out * p
+    float scale = 1.0f;
+    if (p.aic_norm) {
+        float P = st[2 * NC2];
+        P = fma_(p.aic_alpha, P, (1.0f - p.aic_alpha) * (pw / (float)M));
+        st[2 * NC2] = P;
+        scale = 1.0f / (P + p.aic_reg);
+    }
+    const float g = 2.0f * p.aic_mu * pk * scale;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const cf gr = cmulc(mk(X[2 * i], X[2 * i + 1]), err);                     // X conj(err)
+        W[2 * i] = fma_(g, gr.x, W[2 * i]);
+        W[2 * i + 1] = fma_(g, gr.y, W[2 * i + 1]);
+    }
+    return err;
+}
+// plane f of the canceller's state at bin k of utterance b.  On the device one buffer descriptor per utterance, the lane's bin as the
+// 32-bit offset and the plane in the scalar offset (the addressing of the operator kernels, ds_ops.hpp)
+#if defined(__HIP_DEVICE_COMPILE__)
+struct AicState {
+    __amdgpu_buffer_rsrc_t rs;
+    int KP;
+    __device__ AicState(const Params& p, int b, int KP_) : KP(KP_) {
+        rs = __builtin_amdgcn_make_buffer_rsrc(p.aic_st + (long long)b * p.aic_NF * KP_, 0, p.aic_NF * KP_ * 4, 0x00020000);
+    }
+    __device__ float ld(int f, int k) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(k * 4), (unsigned)(f * KP * 4), 0)); }
+    __device__ void st(int f, int k, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (unsigned)(k * 4), (unsigned)(f * KP * 4), 0); }
+};
+#else
+struct AicState {
+    float* base;
+    int KP;
+    AicState(const Params& p, int b, int KP_) : base(p.aic_st ? p.aic_st + (long long)b * p.aic_NF * KP_ : nullptr), KP(KP_) {}
+    float ld(int f, int k) const { return base[(long long)f * KP + k]; }
+    void st(int f, int k, float v) const { base[(long long)f * KP + k] = v; }
+};
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // The block program
 // ---------------------------------------------------------------------------------------------
@@ -793,7 +864,8 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
 
     // one frequency bin: MCRA / covariance recursion / solve -> Y[k]
     static DS_HD cf bin_program(float* st, const cf* Z, const cf* steer, int k, const Sh& sh, const Params& p,
-                                int frm_cnt, bool reset, int spp_cnt) {
+                                int frm_cnt, bool reset, int spp_cnt, cf ad = cf{0.0f, 0.0f}, float apk = 0.0f) {
+        if constexpr (ALGO == ALGO_AIC) return aic_bin<M>(st, Z, ad, apk, p);
         cf a[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) a[m] = steer[k * M + m];
@@ -845,13 +917,32 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             prefetch(p, xb, 0, tid, r);
             // state planes are issued LAST and consumed first in the per-bin phase: they stay in flight while the
             // forward FFT of the first hop runs (loads retire in order, so nothing above waits for them)
+            if constexpr (ALGO == ALGO_AIC) {                           // the canceller's planes, where the subband-LMS operator keeps them
+                const AicState as(p, b, KP);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                const vec4 v = load_state(&bins[q * KP + tid]);
-                r.st[4 * q] = v.x; r.st[4 * q + 1] = v.y; r.st[4 * q + 2] = v.z; r.st[4 * q + 3] = v.w;
+                for (int f = 0; f < SL::NF; ++f) r.st[f] = as.ld(f, tid);
+                r.nyq.x = as.ld(tid < SL::NF ? tid : 0, NC);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const vec4 v = load_state(&bins[q * KP + tid]);
+                    r.st[4 * q] = v.x; r.st[4 * q + 1] = v.y; r.st[4 * q + 2] = v.z; r.st[4 * q + 3] = v.w;
+                }
+                if constexpr (NP > 0) r.nyq = bins[(tid < NP ? tid : 0) * KP + NC];   // Nyquist planes: parked in a register until the split phase
             }
-            if constexpr (NP > 0) r.nyq = bins[(tid < NP ? tid : 0) * KP + NC];   // Nyquist planes: parked in a register until the split phase
         });
+        // ALGO_AIC: this frame's desired-signal sample (the spectrum one frame back; frame 0 takes the carried one) and update
+        // probability for the lane's bin, and for the Nyquist bin on the lane that runs it; issued at the start of a frame, consumed
+        // behind the forward transforms
+        auto aic_fetch = [&](int t, int tid, Rg& r) {
+            auto dsamp = [&](int k) {
+                const float* q = t == 0 ? p.aic_dprev + 2 * ((long long)b * K + k) : p.aic_d + 2 * (((long long)b * p.T + (t - 1)) * K + k);
+                return mk(q[0], q[1]);
+            };
+            auto prob = [&](int k) { return p.aic_p ? p.aic_p[((long long)b * p.T + t) * K + k] : 1.0f; };
+            r.ad = dsamp(tid); r.apk = prob(tid);
+            if (tid == NYQ_TID) { r.adn = dsamp(NC); r.apkn = prob(NC); }
+        };
 
 #ifdef DS_ABLATE_NOFRAMES     // timing experiment only: state movement without the frame program
         const int T_run = 0;
@@ -868,6 +959,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 if (one_round) DS_SETPRIO(2);
                 commit(p, sh, new_half, tid, r);
                 if (t + 1 < p.T) prefetch(p, xb, t + 1, tid, r);
+                if constexpr (ALGO == ALGO_AIC) aic_fetch(t, tid, r);
             });
             // ---- forward FFT: M packed real transforms -------------------------------------------
             cf* fa = &sh.fa[0][0];
@@ -885,7 +977,9 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             const cf* F = FWD_FINAL_IS_FB ? fb : fa;
             // ---- split packed spectrum -> Z[k][m]; publish |Z_0|^2 for the MCRA stencil ----------
             ex.phase([&](int tid, Rg& r) {
-                if (t == 0 && tid < NP) {                               // Nyquist planes -> LDS (loaded in the prologue)
+                if constexpr (ALGO == ALGO_AIC) {
+                    if (t == 0 && tid < SL::NF) sh.nyq[tid] = r.nyq.x;
+                } else if (t == 0 && tid < NP) {                        // Nyquist planes -> LDS (loaded in the prologue)
                     sh.nyq[4 * tid] = r.nyq.x; sh.nyq[4 * tid + 1] = r.nyq.y; sh.nyq[4 * tid + 2] = r.nyq.z; sh.nyq[4 * tid + 3] = r.nyq.w;
                 }
                 const int k = tid, k2 = (NC - k) & (NC - 1);
@@ -911,7 +1005,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             const bool reset = (frm_cnt != 0) && (ell % p.mcra_L == 0);
             ex.phase([&](int tid, Rg& r) {
                 DS_SETPRIO(0);                                          // the wide, arithmetic-heavy phase yields to other workgroups' latency-bound ones
-                cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt);
+                cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt, r.ad, r.apk);
                 if (tid == 0) Yk.y = 0.0f;                              // irfft ignores Im Y[0] and Im Y[N/2]
                 sh.Y[tid] = Yk;
                 if (tid == NYQ_TID) {
@@ -922,7 +1016,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                         cf Zn[M];
 #pragma unroll
                         for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; Zn[m] = mk(F0.x - F0.y, 0.0f); }
-                        const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_cnt, reset, spp_cnt);
+                        const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_cnt, reset, spp_cnt, r.adn, r.apkn);
                         sh.Y[NC] = mk(Yn.x, 0.0f);
                     }
                 }
@@ -940,14 +1034,14 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // so it is taken with Y[NC] = 0 and the bin's contribution — the constant (Y[NC] / 2) (1 - j) on every packed point, i.e.
             // +- Y[NC] / 2 on even / odd samples — is added in the overlap-add phase.
             // The merge of the packed real transform (Y[k], Y[NC - k] -> point k) is formed inside the first inverse stage.
-            ph(WAVE_FFT, [&](int tid, Rg&) {
+            ph(WAVE_FFT, [&](int tid, Rg& r) {
                 DS_SETPRIO(2);                                          // the serial part of a hop: ahead of other workgroups' wide phases
                 if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, 2, 0, 1>(tid - INV_T0, NT, sh, nullptr, fb, 1, 0, 1);
                 else if (WAVE_FFT && tid == NYQ_TID) {
                     cf Zn[M];
 #pragma unroll
                     for (int m = 0; m < M; ++m) Zn[m] = mk(sh.zn[m], 0.0f);
-                    const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_nyq, reset, spp_nyq);
+                    const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_nyq, reset, spp_nyq, r.adn, r.apkn);
                     sh.Y[NC] = mk(Yn.x, 0.0f);                          // irfft ignores Im Y[N/2]
                 }
             });
@@ -998,14 +1092,27 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 vec4* tout4 = reinterpret_cast<vec4*>(tout);
                 for (int i = tid; i < HOP / 4; i += NT) store_state(&tout4[i], *reinterpret_cast<const vec4*>(&sh.tail[4 * i]));
             }
+            if constexpr (ALGO == ALGO_AIC) {
+                const AicState as(p, b, KP);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                vec4 v; v.x = r.st[4 * q]; v.y = r.st[4 * q + 1]; v.z = r.st[4 * q + 2]; v.w = r.st[4 * q + 3];
-                store_state(&bins[q * KP + tid], v);
-            }
-            if (tid < NP) {
-                vec4 v; v.x = sh.nyq[4 * tid]; v.y = sh.nyq[4 * tid + 1]; v.z = sh.nyq[4 * tid + 2]; v.w = sh.nyq[4 * tid + 3];
-                bins[tid * KP + NC] = v;
+                for (int f = 0; f < SL::NF; ++f) as.st(f, tid, r.st[f]);
+                if (tid < SL::NF) as.st(tid, NC, sh.nyq[tid]);
+                if (p.T > 0) {                                          // the desired-signal frame the next call starts with
+                    const float* last = p.aic_d + 2 * (((long long)b * p.T + (p.T - 1)) * K);
+                    float* keep = p.aic_dprev + 2 * (long long)b * K;
+                    keep[2 * tid] = last[2 * tid]; keep[2 * tid + 1] = last[2 * tid + 1];
+                    if (tid == NYQ_TID) { keep[2 * NC] = last[2 * NC]; keep[2 * NC + 1] = last[2 * NC + 1]; }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    vec4 v; v.x = r.st[4 * q]; v.y = r.st[4 * q + 1]; v.z = r.st[4 * q + 2]; v.w = r.st[4 * q + 3];
+                    store_state(&bins[q * KP + tid], v);
+                }
+                if (tid < NP) {
+                    vec4 v; v.x = sh.nyq[4 * tid]; v.y = sh.nyq[4 * tid + 1]; v.z = sh.nyq[4 * tid + 2]; v.w = sh.nyq[4 * tid + 3];
+                    bins[tid * KP + NC] = v;
+                }
             }
             if (tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }
         });

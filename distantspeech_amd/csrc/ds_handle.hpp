@@ -43,6 +43,7 @@ struct ds_handle {
     // staging for host-pointer calls
     // frame-level objects (DS_ALGO_TRANSFORM .. DS_ALGO_SUBRLS)
     KernelInfo ki_istft;
+    KernelInfo ki_aic;          // DS_ALGO_SUBBAND_GSC: the chain's tail as one frame kernel (null launch: separate kernels)
     KernelInfo ki_rows, ki_rows_istft;   // single-channel transform handles: the one-row-per-wavefront kernels (null launch = not available)
     int op;                     // ds::OP_* or -1
     float* opst;                // operator state [B][NF][KP]
@@ -84,6 +85,15 @@ struct ds_handle {
     // its own copy of the device counters (dev_cnt + 8 g); groups_open: side streams hold work the chain's stream has not joined yet
     int parts;
     bool groups_open;
+    // DS_ALGO_SUBBAND_GSC: the front end of a block (notch -> FIR bank -> analysis; latency-bound kernels) runs on its own stream
+    // (side[1]) into one of two buffer sets, so that the front end of block t + 1 overlaps the HBM-bound stages of block t whenever the
+    // caller has block t + 1 enqueued by then.  ev_fr: {front of set 0 / 1 done, set 0 / 1 free again}
+    // ... and, with the tail as one frame kernel, the tail runs on side[2] out of one of two sets of the middle stages' outputs (p, F, the
+    // blocking-matrix outputs): a three-stage pipeline front(t + 1) | McSpp + blocking filters(t) | tail(t - 1) across the blocks the caller
+    // has enqueued.  ev_fr + 4: {middle of set 0 / 1 done, tail of set 0 / 1 done}
+    bool front_async, tail_async, front_open, fr_valid[2], tf_valid[2];
+    int front_set;
+    hipEvent_t ev_fr[8];
     // chain handles under graph replay: the shape (samples per call) that has run once with plain launches (buffers sized, start-up
     // branches behind), and what one replay of the captured sequence does to the host mirrors of the stages' uniform counters
     ds_handle* owner;           // the chain handle this stage belongs to (null: stand-alone)
@@ -164,7 +174,9 @@ enum {
     G_E2 = 12,       // c[B][T][K]       canceller error = output spectrum
     G_FPREV = 13,    // c[B][K]          state: F of the previous block (delay_fbf in the spectral domain)
     G_FIXPREV = 14,  // [B][hop]         state: fixed beamformer output of the previous block
-    G_COUNT = 15
+    G_XN2 = 15, G_XA2 = 16, G_FIXED2 = 17, G_D2 = 18,   // second set of the front end's buffers (front_async)
+    G_P2 = 19, G_F2 = 20, G_BM2 = 21,                   // ... and of what the tail reads
+    G_COUNT = 22
 };
 int chain_reserve(ds_handle* h, int T);
 int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,

@@ -21,6 +21,7 @@ KernelInfo lookup_adaptive_noryy(int nfft, int M);
 KernelInfo lookup_adaptive_ryy(int nfft, int M);
 KernelInfo lookup_adaptive_quad(int nfft, int M);   // 8 microphones, no Ryy: the per-bin program spread over quads (ds_quad.hpp); null launch = n/a
 KernelInfo lookup_gsc(int nfft, int M);
+KernelInfo lookup_aic(int nfft, int M);     // ALGO_AIC: the SubbandGSC chain's tail (ds_kernels_aic.hip)
 KernelInfo lookup_stft(int nfft, int M);      // ds_kernels_ops.hip
 KernelInfo lookup_istft(int nfft, int M);
 KernelInfo lookup_stft_rows(int nfft);      // single-channel handles: one row per wavefront (nfft 512 / 1024), launch(p, rows, stream)
@@ -80,6 +81,9 @@ __global__ void __launch_bounds__(NFFT / 2, frames_min_waves(M, ALGO)) ds_frames
     typedef Engine<NFFT, M, ALGO, RYY> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
+    if constexpr (ALGO == ALGO_AIC) {                    // a stage of a chain: an earlier stage's counter advance rides in this launch
+        if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
+    }
     E::run(ex, p, (int)blockIdx.x, sh);
 }
 

@@ -47,6 +47,7 @@ template <int NFFT, int M> int run_nm(int algo, int ryy, const ds::Params& p, in
     if (algo == ds::ALGO_ADAPTIVE && !ryy) return run_t<NFFT, M, ds::ALGO_ADAPTIVE, false>(p, batch);
     if (algo == ds::ALGO_ADAPTIVE && ryy) return run_t<NFFT, M, ds::ALGO_ADAPTIVE, true>(p, batch);
     if (algo == ds::ALGO_GSC) return run_t<NFFT, M, ds::ALGO_GSC, false>(p, batch);
+    if (algo == ds::ALGO_AIC) return run_t<NFFT, M, ds::ALGO_AIC, false>(p, batch);
     return -1;
 }
 
@@ -300,6 +301,29 @@ int emul_run(int algo, int nfft, int M, int ryy, int batch, const float* x, int 
         case 256: return run_n<256>(M, algo, ryy, p, batch);
         case 512: return run_n<512>(M, algo, ryy, p, batch);
         case 1024: return run_n<1024>(M, algo, ryy, p, batch);
+    }
+    return -1;
+}
+
+// the SubbandGSC chain's tail as one frame program (Engine<.., ALGO_AIC>): blocking-matrix outputs x [B][M][n] -> y [B][n]; st = the
+// canceller's planes [B][NF][KP] (the DS_ALGO_SUBLMS operator's layout), d [B][T][K] complex taken one frame late through dprev [B][K]
+int emul_aic(int nfft, int M, int batch, const float* x, int n_samples, float* y, float* tail_in, float* tail_out, int* counters,
+             float* st, int NF, const float* d, float* dprev, const float* pk, int pc, int norm, float mu, float alpha, float reg) {
+    ds::Params p;
+    std::memset(&p, 0, sizeof p);
+    const int hop = nfft / 2;
+    p.x = x; p.y = y;
+    p.x_batch_stride = (long long)M * n_samples; p.y_batch_stride = n_samples;
+    p.x_sample_stride = 1; p.x_chan_stride = n_samples;
+    p.T = n_samples / hop;
+    p.tail_in = tail_in; p.tail_out = tail_out; p.counters = counters;
+    p.mcra_L = 1;
+    p.aic_st = st; p.aic_NF = NF; p.aic_d = d; p.aic_dprev = dprev; p.aic_p = pk; p.aic_pc = pc; p.aic_norm = norm;
+    p.aic_mu = mu; p.aic_alpha = alpha; p.aic_reg = reg;
+    switch (nfft) {
+        case 256: return run_n<256>(M, ds::ALGO_AIC, 0, p, batch);
+        case 512: return run_n<512>(M, ds::ALGO_AIC, 0, p, batch);
+        case 1024: return run_n<1024>(M, ds::ALGO_AIC, 0, p, batch);
     }
     return -1;
 }

@@ -798,14 +798,68 @@ def test_wpe_mvdr_chain_utterance_groups_equal_the_whole_batch(ds, parts):
         for r in range(rounds):
             e.process_device_seq(xd + 4 * r * seg, L.LAYOUT_CHANNELS_SAMPLES, M * Ltot, Ltot, T * hop, T * hop, n_calls,
                                  yd + 4 * r * seg, Ltot, T * hop, graph=graph)
-        e.synchronize()
-        outs.append((dv.download(yd, (B, Ltot)), e.export_state()))
+        blob = e.export_state()                                  # no synchronize first: the export itself brings the groups back
+        outs.append((dv.download(yd, (B, Ltot)), blob))
         e.close()
     dv.free()
     assert np.all(np.isfinite(outs[0][0])) and np.abs(outs[0][0]).max() > 0
     for o in outs[1:]:
         assert np.array_equal(outs[0][0], o[0])
         assert np.array_equal(outs[0][1], o[1])
+
+
+@pytest.mark.parametrize("rls", [False, True])
+def test_subband_gsc_fused_tail_and_pipelined_stages_equal_separate_kernels(ds, rls, monkeypatch):
+    """The SubbandGSC chain's tail (re-analysis of the blocking-matrix outputs -> canceller -> synthesis) runs as ONE frame kernel by
+    default (ds_frames_kernel<.., ALGO_AIC>), and the chain is a three-stage pipeline over the blocks the caller has enqueued: front end
+    of block t + 1 | McSpp + blocking filters of block t | tail of block t - 1, each on its own stream, double-buffered.
+    DS_CHAIN_UNFUSED=1 keeps the three kernels the tail replaces, DS_CHAIN_SERIAL_FRONT=1 keeps every stage behind the previous one, and
+    with fewer than 6 hardware queues (GPU_MAX_HW_QUEUES) the tail stays on the chain's stream.  Same transforms, same per-bin
+    arithmetic: every fused variant gives the same samples and the same state bit for bit; against the separate kernels the canceller's
+    weights, tap buffer and power are bit-identical and the samples agree to the rounding of the two synthesis paths (the fused kernel
+    adds the Nyquist bin by linearity)."""
+    from oracle import ds_oracle as O
+    from _cases import oracle_mic
+    M, FL, B = 6, 256, 3
+    omic = oracle_mic(M, 2 * FL)
+    mic = ds.MicArray(arrayType="circular", r=omic.r, M=M, n_fft=2 * FL)
+    x = np.stack([O.synth_utterance(70 + u, 40 * FL, omic) for u in range(B)]).astype(np.float32)
+    cuts = [0, 7 * FL, 8 * FL, 9 * FL, 10 * FL, 11 * FL, 40 * FL]               # several blocks, single blocks back to back, many
+    res = {}
+    for name, env in (("separate", dict(DS_CHAIN_UNFUSED="1", DS_CHAIN_SERIAL_FRONT="1")),
+                      ("fused_serial", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="1")),
+                      ("fused_front", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", GPU_MAX_HW_QUEUES="4")),
+                      ("fused_pipeline", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", GPU_MAX_HW_QUEUES="8"))):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], batch=B, bm_filter="rls" if rls else "lms")
+        outs = [g.process(x[:, :, a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        y = np.concatenate([np.asarray(o[0]) for o in outs], axis=-1)
+        bm = np.concatenate([np.asarray(o[2]) for o in outs], axis=1)                                       # [B, L, M]
+        # the device-pointer route (no staging, no synchronisation between the calls): blocks enqueued back to back
+        from _cases import DeviceBuffers
+        from distantspeech_amd import _lib as L
+        dv = DeviceBuffers()
+        xd, yd = dv.upload(x), dv.zeros(B * 40 * FL * 4)
+        g2 = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], batch=B, bm_filter="rls" if rls else "lms")
+        g2._eng.process_device_seq(xd, L.LAYOUT_CHANNELS_SAMPLES, M * 40 * FL, 40 * FL, FL, FL, 40, yd, 40 * FL, FL, graph=0)
+        y_dev = dv.download(yd, (B, 40 * FL))
+        dv.free()
+        res[name] = (y, bm, np.frombuffer(g._eng.export_state(), dtype=np.float32).copy(), y_dev,
+                     np.frombuffer(g2._eng.export_state(), dtype=np.float32).copy())
+    y0, bm0, s0 = res["separate"][:3]
+    assert np.all(np.isfinite(y0)) and np.abs(y0).max() > 0
+    for name in ("fused_serial", "fused_front", "fused_pipeline"):
+        y1, bm1, s1, yd1, sd1 = res[name]
+        assert np.array_equal(bm0, bm1)                                      # everything in front of the tail is the same launch sequence
+        assert np.array_equal(y1, res["fused_serial"][0]) and np.array_equal(s1, res["fused_serial"][2])      # scheduling changes nothing
+        assert np.array_equal(yd1, res["fused_serial"][3]) and np.array_equal(sd1, res["fused_serial"][4])
+        assert np.allclose(yd1, y1, rtol=0, atol=2e-6)                       # one block per call == blocks per call as processed above
+        measured("fused_tail_%s_rls%d" % (name, int(rls)), y_max_abs_diff=float(np.max(np.abs(y1 - y0))), y_absmax=float(np.abs(y0).max()))
+        assert np.max(np.abs(y1 - y0)) < 2e-6 * max(1.0, np.abs(y0).max())
+        diff = np.flatnonzero(s0 != s1)
+        # the only state words that may differ are the synthesis overlap tail (B x hop floats, rounding of the synthesis path)
+        assert diff.size <= B * FL and (diff.size == 0 or np.max(np.abs(s0[diff] - s1[diff])) < 2e-6)
 
 
 def test_checkpoint_imports_into_a_never_run_handle(ds):

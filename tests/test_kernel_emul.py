@@ -453,7 +453,7 @@ def test_single_channel_rows_engine_equals_block_engine(nfft):
     assert rms(yr[:, hop:, 0] - x[:, T * hop: 2 * T * hop - hop]) < 1e-5 * 10    # perfect reconstruction, one hop late
 
 
-def emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, p_override=None):
+def emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, p_override=None, fused_tail=False, tail_state=None):
     """The DS_ALGO_SUBBAND_GSC chain composed from the emulated stage programs exactly as ds_api_chains.hip::chain2_run composes the
     kernels (notch -> FIR bank + mean -> STFT -> McSpp (lean build, steady build from frame 5) -> fan-form blocking filters -> ISTFT ->
     STFT -> multichannel canceller on 1 - p with the one-frame-late fixed spectrum -> ISTFT).
@@ -486,11 +486,27 @@ def emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, p_override=None):
                       None if rls else vp(p), vp(e), int(not rls), 1, f32(0.5 if rls else 0.1), f32(0.9), f32(1e-4), f32(0.998))
     assert rc == 0
     bm = EmulTransform(nfft, 1, batch=M).istft(e[..., None])[:, :, 0]            # [M, L]
-    Xaic = EmulTransform(nfft, M).stft(np.ascontiguousarray(bm.T)[None], 0)
     aic = EmulOp("sublms", nfft, M=M, N=2, mu=0.01, alpha=0.8)
+    if fused_tail:
+        # the chain's tail as ONE frame program (Engine<nfft, M, ALGO_AIC>, the product's default): re-analysis -> canceller -> synthesis
+        L = bm.shape[1]
+        out = np.zeros((1, L), np.float32)
+        tin, tout, cnt = np.zeros((1, M, FL), np.float32), np.zeros((1, FL), np.float32), np.zeros((1, 4), np.int32)
+        dprev = np.zeros((1, K), np.complex64)
+        Fc, pc = np.ascontiguousarray(F), np.ascontiguousarray(p, dtype=np.float32)
+        rc = lib.emul_aic(nfft, M, 1, vp(np.ascontiguousarray(bm[None])), L, vp(out), vp(tin), vp(tout), vp(cnt), vp(aic.st), aic.NF,
+                          vp(Fc), vp(dprev), vp(pc), 1, 1, f32(0.01), f32(0.8), f32(1e-4))
+        assert rc == 0
+        if tail_state is not None:
+            tail_state.update(st=aic.st.copy(), dprev=dprev.copy(), tin=tin.copy())
+        return out[0], bm.T, p[0].T, xa[0]
+    tx = EmulTransform(nfft, M)
+    Xaic = tx.stft(np.ascontiguousarray(bm.T)[None], 0)
     Fd = np.concatenate([np.zeros_like(F[:, :1]), F[:, :-1]], axis=1)            # delay_fbf (SubbandGSC.py:226) in the spectral domain
     e2 = aic.run(Xaic, np.ascontiguousarray(Fd), np.ascontiguousarray(np.float32(1) - p), out_complex=True)[0]
     out = EmulTransform(nfft, 1).istft(e2[..., None])[0, :, 0]
+    if tail_state is not None:
+        tail_state.update(st=aic.st.copy(), dprev=F[:, -1].copy(), tin=tx.tail_in.copy())
     return out, bm.T, p[0].T, xa[0]
 
 
@@ -505,6 +521,12 @@ def test_emul_subband_gsc_chain(name):
     x = as_float(g["x"]).astype(np.float32)
     coef = np.ascontiguousarray(g["delay_filter"], dtype=np.float32)
     Fn = O.gen_noise_msc(O.OracleMicArray(arrayType="circular", r=0.032, M=M), 2 * FL)[:, 1, 2]
-    out, bm, p, al = emul_subband_gsc_chain(x, M, FL, coef, Fn, rls)
+    sa, sb = {}, {}
+    out, bm, p, al = emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, tail_state=sa)
     assert rms(out - g["output"]) < 2e-5 and rms(bm - g["bm_output"]) < 1e-5 and rms(al - g["aligned_output"]) < 1e-5
     assert np.max(np.abs(p - g["p"])) < 1e-3 and np.median(np.abs(p - g["p"])) < 1e-6
+    # the tail as one frame program (what the product launches): the same canceller state bit for bit (same transforms, same per-bin
+    # arithmetic), the same samples up to the rounding of the two synthesis paths, and the reference's output to the same bar
+    out2 = emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, fused_tail=True, tail_state=sb)[0]
+    assert np.array_equal(sa["st"][:, :, :FL + 1], sb["st"][:, :, :FL + 1]) and np.array_equal(sa["dprev"], sb["dprev"]) and np.array_equal(sa["tin"], sb["tin"])
+    assert rms(out2 - out) < 1e-7 and rms(out2 - g["output"]) < 2e-5
