@@ -734,6 +734,10 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const bool chain = h->cfg.algo == DS_ALGO_WPE_MVDR || h->cfg.algo == DS_ALGO_SUBBAND_GSC;
     if (h->cfg.algo == DS_ALGO_TDGSC || h->cfg.algo == DS_ALGO_FDGSC) graph = 0;      // their stages keep the frame counters on the host
+    // the SubbandGSC chain pipelines its stages over the enqueued blocks on up to five streams; replayed as ONE hipGraph the branches are
+    // serialised by the graph executor (measured 0.34-0.50 ms per block against 0.26 ms with plain launches), so the sequence is launched
+    // plainly.  DS_CHAIN_SERIAL_FRONT=1 (every stage behind the previous one) keeps the replay path
+    if (h->cfg.algo == DS_ALGO_SUBBAND_GSC && h->front_async && graph == 1) graph = 0;
     if (chain && graph != 0) {
         // a chain replays as a graph once this call shape has run with plain launches (every stage buffer sized, nothing left to
         // allocate or synchronise inside the capture) and the stages' host-side start-up branches are behind (McSpp's first frames)

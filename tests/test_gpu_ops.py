@@ -720,7 +720,7 @@ def test_chains_at_baseline_chunk_length(ds, chain):
 
 
 @pytest.mark.parametrize("chain", ["cfg4", "cfg5_rls", "cfg5_lms"])
-def test_chain_graph_replay_equals_plain_launches(ds, chain):
+def test_chain_graph_replay_equals_plain_launches(ds, chain, monkeypatch):
     """The chain handles keep their uniform counters (frame counts, MCRA window phase, FIR ping-pong parity, WPE ring position) on the
     device, so ds_process_device_seq(graph=1) replays a captured sequence of calls: same samples and same exported state, bit for bit, as
     plain launches — across several replays, with plain calls in between, one hop per call and several hops per call."""
@@ -729,6 +729,9 @@ def test_chain_graph_replay_equals_plain_launches(ds, chain):
     from distantspeech_amd.mic_array import compute_tau
     from distantspeech_amd.ops import McSpp
     from distantspeech_amd.subband_gsc import fractional_delay_filter_bank
+    # the SubbandGSC chain launches a sequence plainly when its stages are pipelined over streams (the default); the replay path is the
+    # serial chain's
+    monkeypatch.setenv("DS_CHAIN_SERIAL_FRONT", "1")
     if chain == "cfg4":
         algo, M, nfft, hop, kw = L.ALGO_WPE_MVDR, 8, 1024, 512, dict(filter_len=2)
     else:
