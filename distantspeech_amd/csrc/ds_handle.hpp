@@ -75,6 +75,7 @@ struct ds_handle {
     int hist_cur;               // ring slot of the oldest frame
     // cached hipGraph of a ds_process_device_seq() sequence
     hipGraphExec_t graph_exec;
+    hipGraphExec_t group_exec[8];   // fused frame kernels with DS_PARAM_SPLIT > 1: one graph per free-running utterance group
     int split;                  // DS_PARAM_SPLIT: utterance groups captured as parallel graph branches
     hipStream_t side[7];        // side streams for the extra branches
     hipEvent_t ev_fork, ev_join[7];

@@ -158,9 +158,10 @@ typedef struct ds_config {
 #define DS_PARAM_FDAF_TWO_PATH 16     /* int 0/1: FastFreqLms(two_path=True) — foreground / background filters with the 3 dB transfer rule
                                          (FastFreqLms.py:94-104,162-176); plain kind only; default 0 */
 #define DS_PARAM_POSTFILTER 15       /* int 0/1: DS_ALGO_TDGSC / DS_ALGO_FDGSC handles apply the OMLSA post-filter in ds_process_device; default 0 */
-#define DS_PARAM_SPLIT 8   /* int 1..8: utterance groups run as parallel hipGraph branches in ds_process_device_seq(graph=1), default 1;
-                              DS_ALGO_WPE_MVDR: utterance groups pipelined through the chain's stages on two streams (WPE of one group next to
-                              the McMcra / MVDR / synthesis stages of the previous one), default 4 from 256 utterances up */
+#define DS_PARAM_SPLIT 8   /* int 1..8: utterance groups.  Fused frame kernels: ds_process_device_seq runs the utterance range as that many groups,
+                              each on its own stream at its own pace (its own hipGraph with graph=1); default 2 from 2048 utterances up, else 1.
+                              DS_ALGO_WPE_MVDR: the batch as that many independent chains on their own streams; default 2 from 512 utterances up.
+                              Results are complete after ds_synchronize (every other entry point joins the groups first) */
 
 /* ds_get_state fields; all arrays are float32, complex = interleaved (re, im) */
 #define DS_FIELD_RVV 1        /* [B][K][M][M][2]  */

@@ -8,7 +8,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "cfg5"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 w = bench.WORKLOADS[name]
 be = bench.load_backend(0, 1)
-B = w["batch"]
+B = int(os.environ.get("BATCH", w["batch"]))
 for S in [int(v) for v in os.environ.get('SPLITS', '1,2,4,8,1').split(',')]:
     wls = [be.make(w, B // S, 1, K, 5, seed=s, graph=w["graph"]) for s in range(S)]
     for wl in wls: wl.run(0, 5)

@@ -56,7 +56,7 @@ class StubBackend:
         for wl in self.made:
             wl._drain()
 
-    def make(self, w, B, T, K, W, seed, graph):
+    def make(self, w, B, T, K, W, seed, graph, split=None):
         wl = StubWorkload(w, B, T, K, W)
         self.made = [wl]
         return wl

@@ -865,6 +865,49 @@ def test_subband_gsc_fused_tail_and_pipelined_stages_equal_separate_kernels(ds, 
         assert diff.size <= B * FL and (diff.size == 0 or np.max(np.abs(s0[diff] - s1[diff])) < 2e-6)
 
 
+@pytest.mark.parametrize("algo", ["ADAPTIVE", "GSC"])
+def test_frame_kernel_sequences_graphs_and_utterance_groups(ds, algo):
+    """ds_process_device_seq on the fused frame kernels (what bench.py times): a sequence of calls launched plainly, replayed as a hipGraph,
+    and with the batch as free-running utterance groups on their own streams (DS_PARAM_SPLIT, each group its own graph) gives the samples
+    and the exported state of hop-by-hop ds_process calls bit for bit — uneven groups, a sub-range of the batch, replays of a cached
+    graph, state exported while the groups are still running."""
+    from _cases import DeviceBuffers
+    from distantspeech_amd import _lib as L
+    M, nfft, hop, B, T, n_calls, rounds = 4, 512, 256, 7, 2, 3, 4
+    Ltot = T * hop * n_calls * rounds
+    x = (np.random.default_rng(31).standard_normal((B, M, Ltot)) * 0.05).astype(np.float32)
+    mic = ds.MicArray(arrayType="circular", r=0.032, M=M, n_fft=nfft)
+    ang = np.array([197.0, 0.0]) / 180 * np.pi
+    tao = -1 * mic.r * np.cos(ang[1]) * np.cos(ang[0] - mic.gamma) / mic.c
+    steer = np.exp(-1j * (2 * np.pi * np.arange(nfft // 2 + 1) * 16000 / nfft)[:, None] * tao[None, :])
+
+    def make():
+        e = ds.BatchEngine(getattr(L, "ALGO_" + algo), M, nfft, hop, batch=B, device=0)
+        e.set_steering(steer)
+        e.set_method(L.METHOD_MVDR if algo == "ADAPTIVE" else 1)
+        return e
+
+    ref = make()
+    y_ref = np.concatenate([ref.process(x[:, :, a:a + hop], L.LAYOUT_CHANNELS_SAMPLES) for a in range(0, Ltot, hop)], axis=1)
+    s_ref = ref.export_state()
+    dv = DeviceBuffers()
+    xd = dv.upload(x)
+    for split, graph in ((1, 0), (1, 1), (2, 0), (3, 1), (7, 1)):
+        e = make()
+        e.set_split(split)
+        yd = dv.zeros(B * Ltot * 4)
+        seg = T * hop * n_calls
+        for r in range(rounds):
+            e.process_device_seq(xd + 4 * r * seg, L.LAYOUT_CHANNELS_SAMPLES, M * Ltot, Ltot, T * hop, T * hop, n_calls,
+                                 yd + 4 * r * seg, Ltot, T * hop, graph=graph)
+        blob = e.export_state()                                  # joins the groups itself
+        y = dv.download(yd, (B, Ltot))
+        assert np.array_equal(y, y_ref), (split, graph)
+        assert np.array_equal(blob, s_ref), (split, graph)
+        e.close()
+    dv.free()
+
+
 def test_checkpoint_imports_into_a_never_run_handle(ds):
     """The process-restart case: a blob exported from a running handle goes into a freshly created and configured one that has not
     processed anything (the FIR history is sized when the bank is set, not at the first call); a blob of another configuration is
