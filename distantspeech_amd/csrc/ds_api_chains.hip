@@ -343,6 +343,8 @@ int ds_chain_set_aux(ds_handle* h, int which, const float* table, size_t n_float
     if (h->cfg.algo != DS_ALGO_SUBBAND_GSC && !gsc) return fail(h, DS_ESTATE, "ds_chain_set_aux: handle is not a SubbandGSC / TDGSC / FDGSC chain");
     ds_handle* t = which == DS_CHAIN_AUX_FIR ? h->sub[0] : (which == DS_CHAIN_AUX_COHERENCE && !gsc) ? h->sub[2] : nullptr;
     if (!t) return fail(h, DS_EINVAL, "ds_chain_set_aux: unknown table id");
+    { const int jr = set_device(h); if (jr) return jr; }    // stages still running on their own streams come back first
+    DS_HIP(h, hipStreamSynchronize(h->stream));
     const int rc = ds_set_aux(t, table, n_floats);
     return rc ? fail(h, rc, t->err) : DS_OK;
 }
