@@ -158,13 +158,13 @@ int chain2_reserve(ds_handle* h, int n) {
     need[G_D] = need[G_XAIC] = B * T * K * M * 8; need[G_P] = B * T * K * 4;
     need[G_F] = need[G_E2] = B * T * K * 8; need[G_E] = B * M * T * K * 8;
     need[G_FPREV] = B * K * 8; need[G_FIXPREV] = B * hop * 4;
-    if (h->ki_aic.launch) need[G_XAIC] = need[G_E2] = 0;                      // the fused tail keeps both in registers / LDS
+    if (h->ki_aic.launch) need[G_XAIC] = need[G_E2] = need[G_BM] = 0;         // the fused tail keeps all three in registers / LDS
     // second set of the front end's buffers: block t + 1's front end next to block t's later stages (not for very long calls, where the
     // front end is a small share of a call anyway and the set would cost gigabytes)
     const size_t second = 2 * need[G_XN] + need[G_FIXED] + need[G_D];
     if (h->front_async && second <= ((size_t)4 << 30)) {
         need[G_XN2] = need[G_XA2] = need[G_XN]; need[G_FIXED2] = need[G_FIXED]; need[G_D2] = need[G_D];
-        if (h->ki_aic.launch && h->tail_async) { need[G_P2] = need[G_P]; need[G_F2] = need[G_F]; need[G_BM2] = need[G_BM]; }
+        if (h->ki_aic.launch && h->tail_async) { need[G_P2] = need[G_P]; need[G_F2] = need[G_F]; need[G_EB2] = need[G_E]; }
     }
     for (int i = 0; i < G_COUNT; ++i) {
         if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
@@ -232,7 +232,7 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         if (h->fr_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[2 + set], 0));
         if (set) {
             cb[G_XN] = cb[G_XN2]; cb[G_XA] = cb[G_XA2]; cb[G_FIXED] = cb[G_FIXED2]; cb[G_D] = cb[G_D2];
-            if (h->chain_buf[G_P2]) { cb[G_P] = cb[G_P2]; cb[G_F] = cb[G_F2]; cb[G_BM] = cb[G_BM2]; }
+            if (h->chain_buf[G_P2]) { cb[G_P] = cb[G_P2]; cb[G_F] = cb[G_F2]; cb[G_E] = cb[G_EB2]; }
         }
     }
     const bool tail_async = h->tail_async && h->ki_aic.launch != nullptr;    // the tail on its own stream (side[2])
@@ -271,9 +271,11 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     // aligned channel is the same spectrum), update probability p
     if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[G_F], cb[G_D], T, cb[G_E], DS_MEM_DEVICE));
     else DS_SUB(5, ds_sublms_update(h->sub[5], cb[G_F], cb[G_D], cb[G_P], T, cb[G_E], DS_MEM_DEVICE));
-    rc = chain_istft(h, h->sub[4], cb[G_E], T, cb[G_BM], n); if (rc) return rc;                               // bm outputs, [B*M][n] = [B][M][n]
     const bool fused_tail = h->ki_aic.launch != nullptr;
-    if (!fused_tail) { rc = chain_stft(h, h->sub[6], cb[G_BM], n, cb[G_XAIC]); if (rc) return rc; }             // :230-234  aic transform_x
+    if (!fused_tail) {
+        rc = chain_istft(h, h->sub[4], cb[G_E], T, cb[G_BM], n); if (rc) return rc;                           // bm outputs, [B*M][n] = [B][M][n]
+        rc = chain_stft(h, h->sub[6], cb[G_BM], n, cb[G_XAIC]); if (rc) return rc;                              // :230-234  aic transform_x
+    }
     if (fork) {
         DS_HIP(h, hipEventRecord(h->ev_join[0], h->sub[5]->stream));
         DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[0], 0));
@@ -281,12 +283,14 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     // :226 delay_fbf: the canceller's desired signal is the fixed output one block late = F one frame late; the operator keeps the
     // carried frame in cb[G_FPREV] itself
     if (fused_tail) {
-        // :230-262 as ONE frame kernel: analysis of the M blocking-matrix outputs, the canceller as the per-bin program (state where the
-        // subband-LMS stage keeps it), synthesis into the caller's rows — X_aic and the error spectrum never leave the workgroup
+        // :224-262 as ONE frame kernel: synthesis of the M blocking-matrix outputs from the blocking filters' error spectra, their
+        // re-analysis, the canceller as the per-bin program (state where the subband-LMS stage keeps it), synthesis into the caller's
+        // rows — the blocking-matrix outputs (unless the caller asks for them), X_aic and the error spectrum never leave the workgroup
         ds_handle *ta = h->sub[6], *op = h->sub[7], *ts = h->sub[8];
         Params p;
         fill_params(ta, p);
-        p.x = cb[G_BM]; p.y = y_dev;
+        p.x = nullptr; p.y = y_dev;
+        p.aic_e = cb[G_E]; p.aic_bmtail = h->sub[4]->tail_out; p.aic_bm = bm_dev;
         p.x_batch_stride = (long long)M * n; p.x_sample_stride = 1; p.x_chan_stride = n;
         p.y_batch_stride = y_bstride;
         p.T = T; p.batch0 = 0;
@@ -321,7 +325,7 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         DS_HIP(h, hipMemcpy2DAsync(cb[G_FIXPREV], blk, (char*)cb[G_FIXED] + (row - blk), row, blk, B, hipMemcpyDeviceToDevice, h->stream));
     }
     const size_t nb = (size_t)B * M * n * 4;
-    if (bm_dev) DS_HIP(h, hipMemcpyAsync(bm_dev, cb[G_BM], nb, hipMemcpyDeviceToDevice, h->stream));
+    if (bm_dev && !fused_tail) DS_HIP(h, hipMemcpyAsync(bm_dev, cb[G_BM], nb, hipMemcpyDeviceToDevice, h->stream));   // (the fused tail writes them itself)
     if (al_dev) DS_HIP(h, hipMemcpyAsync(al_dev, cb[G_XA], nb, hipMemcpyDeviceToDevice, h->stream));
     if (p_dev) DS_HIP(h, hipMemcpyAsync(p_dev, cb[G_P], (size_t)B * T * K * 4, hipMemcpyDeviceToDevice, h->stream));
 #undef DS_SUB

@@ -156,6 +156,12 @@ struct Params {
     const float* aic_p;       // update probability [B][T][K]
     int aic_pc, aic_norm;     // p -> 1 - p (SubbandGSC.py:232); normalised step (SubbandLmsMc.py:174-180)
     float aic_mu, aic_alpha, aic_reg;
+    // ... with the synthesis of the blocking-matrix outputs in front of it: when aic_e is set the kernel takes the blocking filters' error
+    // spectra instead of time samples (x unused), synthesises the M outputs itself (IstftEngine's arithmetic, overlap tails in aic_bmtail)
+    // and hands them to the re-analysis through LDS; aic_bm (optional) receives the time-domain outputs
+    const float* aic_e;       // complex [B * M][T][K]
+    float* aic_bmtail;        // [B][M][hop]
+    float* aic_bm;            // [B][M][T * hop] or null
 };
 
 // number of per-bin state floats / planes
@@ -218,6 +224,7 @@ template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
     vec4 nyq;                 // prologue: plane `tid` of the Nyquist bin on its way to LDS
     cf ad, adn;               // ALGO_AIC: desired-signal sample of this frame for this lane's bin / for the Nyquist bin (lane NYQ_TID)
     float apk, apkn;          // ... and the update probability
+    float bmt[2 * M];         // ... and this lane's two samples of the M blocking-matrix overlap tails (lanes < NC / 2; aic_e mode)
 };
 
 // state-plane accessors.  Every state line is read once and written once per launch and is next touched by the following launch,
@@ -913,8 +920,16 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 const vec4* tout4 = reinterpret_cast<const vec4*>(tout);
                 for (int i = tid; i < HOP / 4; i += NT) *reinterpret_cast<vec4*>(&sh.tail[4 * i]) = tout4[i];
             }
-            prefetch_init(p, xb, tid, r);
-            prefetch(p, xb, 0, tid, r);
+            bool spectra_in = false;
+            if constexpr (ALGO == ALGO_AIC) spectra_in = p.aic_e != nullptr;
+            if (!spectra_in) {
+                prefetch_init(p, xb, tid, r);
+                prefetch(p, xb, 0, tid, r);
+            } else if (tid < NC / 2) {                                  // this lane's samples of the blocking-matrix overlap tails
+                const float* bt = p.aic_bmtail + (long long)b * M * HOP;
+#pragma unroll
+                for (int c = 0; c < M; ++c) { r.bmt[2 * c] = bt[c * HOP + 2 * tid]; r.bmt[2 * c + 1] = bt[c * HOP + 2 * tid + 1]; }
+            }
             // state planes are issued LAST and consumed first in the per-bin phase: they stay in flight while the
             // forward FFT of the first hop runs (loads retire in order, so nothing above waits for them)
             if constexpr (ALGO == ALGO_AIC) {                           // the canceller's planes, where the subband-LMS operator keeps them
@@ -955,15 +970,69 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // WAVE_FFT: a channel's transform lives inside one wavefront from the staging of its samples to the last stage, so those
             // hand-offs need no workgroup barrier (the interleaved input layout scatters the staging across channels and keeps its barrier).
             auto ph = [&](bool wave_local, auto f) { if (wave_local) ex.phase_wave(f); else ex.phase(f); };
-            ph(WAVE_FFT && p.x_sample_stride == 1, [&](int tid, Rg& r) {
-                if (one_round) DS_SETPRIO(2);
-                commit(p, sh, new_half, tid, r);
-                if (t + 1 < p.T) prefetch(p, xb, t + 1, tid, r);
-                if constexpr (ALGO == ALGO_AIC) aic_fetch(t, tid, r);
-            });
-            // ---- forward FFT: M packed real transforms -------------------------------------------
             cf* fa = &sh.fa[0][0];
             cf* fb = &sh.fb[0][0];
+            bool spectra_in = false;
+            if constexpr (ALGO == ALGO_AIC) spectra_in = p.aic_e != nullptr;
+            if (spectra_in) {
+                // ---- hop t of the M blocking-matrix outputs from the error spectra: IstftEngine's program (merge, inverse stages, window,
+                // overlap-add) with the new samples going to the re-analysis through LDS instead of HBM ------------------------------------
+                ex.phase([&](int tid, Rg& r) {
+                    if (one_round) DS_SETPRIO(2);
+                    if constexpr (ALGO == ALGO_AIC) aic_fetch(t, tid, r);
+                    const int k = tid;
+                    const cf w = cconj(sh.tb.tw[k]);
+#pragma unroll
+                    for (int c = 0; c < M; ++c) {
+                        const cf* Yt = reinterpret_cast<const cf*>(p.aic_e) + (((long long)b * M + c) * p.T + t) * K;
+                        cf A = Yt[k], B = Yt[NC - k];
+                        if (k == 0) { A.y = 0.0f; B.y = 0.0f; }          // irfft ignores Im Y[0], Im Y[N/2]
+                        const cf Bc = cconj(B);
+                        const cf E = cscale(cadd(A, Bc), 0.5f);
+                        const cf O = cmul(cscale(csub(A, Bc), 0.5f), w);
+                        fa[c * Sh::NCP + k] = mk(E.x - O.y, E.y + O.x);
+                    }
+                });
+                ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 0, 1>(tid, NT, sh, fa, fb, 1, 0, M); });
+                ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 1, 2>(tid, NT, sh, fb, fa, 4, 0, M); });
+                ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 2, 0>(tid, NT, sh, fa, fb, 16, 0, M); });
+                if (NC == 128) {
+                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid, NT, sh, fb, fa, 64, 0, M); });
+                } else {
+                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 0, 0>(tid, NT, sh, fb, fa, 64, 0, M); });
+                    if (NC == 512)
+                        ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid, NT, sh, fa, fb, 256, 0, M); });
+                }
+                const cf* Zb = (NC != 512) ? fa : fb;
+                ex.phase([&](int tid, Rg& r) {
+                    if (tid < NC / 2) {
+                        const int i = tid;
+                        const float sc = 1.0f / (float)NC;
+#pragma unroll
+                        for (int c = 0; c < M; ++c) {
+                            const cf z1 = Zb[c * Sh::NCP + i], z2 = Zb[c * Sh::NCP + i + NC / 2];
+                            const float y0 = sh.tb.win[2 * i] * (z1.x * sc), y1 = sh.tb.win[2 * i + 1] * (z1.y * sc);
+                            const float o0 = (y0 + r.bmt[2 * c]) * p.out_scale, o1 = (y1 + r.bmt[2 * c + 1]) * p.out_scale;
+                            r.bmt[2 * c] = sh.tb.win[HOP + 2 * i] * (z2.x * sc);
+                            r.bmt[2 * c + 1] = sh.tb.win[HOP + 2 * i + 1] * (z2.y * sc);
+                            sh.xbuf[c][new_half * HOP + 2 * i] = o0;
+                            sh.xbuf[c][new_half * HOP + 2 * i + 1] = o1;
+                            if (p.aic_bm) {
+                                float* dst = p.aic_bm + ((long long)b * M + c) * p.T * HOP + (long long)t * HOP + 2 * i;
+                                dst[0] = o0; dst[1] = o1;
+                            }
+                        }
+                    }
+                });
+            } else {
+                ph(WAVE_FFT && p.x_sample_stride == 1, [&](int tid, Rg& r) {
+                    if (one_round) DS_SETPRIO(2);
+                    commit(p, sh, new_half, tid, r);
+                    if (t + 1 < p.T) prefetch(p, xb, t + 1, tid, r);
+                    if constexpr (ALGO == ALGO_AIC) aic_fetch(t, tid, r);
+                });
+            }
+            // ---- forward FFT: M packed real transforms -------------------------------------------
             ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half, M); });
             ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0, M); });
             ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0, M); });
@@ -1097,6 +1166,11 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
 #pragma unroll
                 for (int f = 0; f < SL::NF; ++f) as.st(f, tid, r.st[f]);
                 if (tid < SL::NF) as.st(tid, NC, sh.nyq[tid]);
+                if (p.aic_e != nullptr && tid < NC / 2) {               // overlap tails of the blocking-matrix synthesis
+                    float* bt = p.aic_bmtail + (long long)b * M * HOP;
+#pragma unroll
+                    for (int c = 0; c < M; ++c) { bt[c * HOP + 2 * tid] = r.bmt[2 * c]; bt[c * HOP + 2 * tid + 1] = r.bmt[2 * c + 1]; }
+                }
                 if (p.T > 0) {                                          // the desired-signal frame the next call starts with
                     const float* last = p.aic_d + 2 * (((long long)b * p.T + (p.T - 1)) * K);
                     float* keep = p.aic_dprev + 2 * (long long)b * K;

@@ -176,7 +176,7 @@ enum {
     G_FPREV = 13,    // c[B][K]          state: F of the previous block (delay_fbf in the spectral domain)
     G_FIXPREV = 14,  // [B][hop]         state: fixed beamformer output of the previous block
     G_XN2 = 15, G_XA2 = 16, G_FIXED2 = 17, G_D2 = 18,   // second set of the front end's buffers (front_async)
-    G_P2 = 19, G_F2 = 20, G_BM2 = 21,                   // ... and of what the tail reads
+    G_P2 = 19, G_F2 = 20, G_EB2 = 21,                   // ... and of what the tail reads (p, F, the blocking filters' error spectra)
     G_COUNT = 22
 };
 int chain_reserve(ds_handle* h, int T);

@@ -308,7 +308,8 @@ int emul_run(int algo, int nfft, int M, int ryy, int batch, const float* x, int 
 // the SubbandGSC chain's tail as one frame program (Engine<.., ALGO_AIC>): blocking-matrix outputs x [B][M][n] -> y [B][n]; st = the
 // canceller's planes [B][NF][KP] (the DS_ALGO_SUBLMS operator's layout), d [B][T][K] complex taken one frame late through dprev [B][K]
 int emul_aic(int nfft, int M, int batch, const float* x, int n_samples, float* y, float* tail_in, float* tail_out, int* counters,
-             float* st, int NF, const float* d, float* dprev, const float* pk, int pc, int norm, float mu, float alpha, float reg) {
+             float* st, int NF, const float* d, float* dprev, const float* pk, int pc, int norm, float mu, float alpha, float reg,
+             const float* e_spectra, float* bmtail, float* bm_out) {
     ds::Params p;
     std::memset(&p, 0, sizeof p);
     const int hop = nfft / 2;
@@ -320,6 +321,7 @@ int emul_aic(int nfft, int M, int batch, const float* x, int n_samples, float* y
     p.mcra_L = 1;
     p.aic_st = st; p.aic_NF = NF; p.aic_d = d; p.aic_dprev = dprev; p.aic_p = pk; p.aic_pc = pc; p.aic_norm = norm;
     p.aic_mu = mu; p.aic_alpha = alpha; p.aic_reg = reg;
+    p.aic_e = e_spectra; p.aic_bmtail = bmtail; p.aic_bm = bm_out;     // e_spectra set: the blocking-matrix synthesis runs inside the program
     switch (nfft) {
         case 256: return run_n<256>(M, ds::ALGO_AIC, 0, p, batch);
         case 512: return run_n<512>(M, ds::ALGO_AIC, 0, p, batch);

@@ -494,8 +494,15 @@ def emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, p_override=None, fused_tail=
         tin, tout, cnt = np.zeros((1, M, FL), np.float32), np.zeros((1, FL), np.float32), np.zeros((1, 4), np.int32)
         dprev = np.zeros((1, K), np.complex64)
         Fc, pc = np.ascontiguousarray(F), np.ascontiguousarray(p, dtype=np.float32)
-        rc = lib.emul_aic(nfft, M, 1, vp(np.ascontiguousarray(bm[None])), L, vp(out), vp(tin), vp(tout), vp(cnt), vp(aic.st), aic.NF,
-                          vp(Fc), vp(dprev), vp(pc), 1, 1, f32(0.01), f32(0.8), f32(1e-4))
+        if fused_tail == "spectra":
+            # ... and the synthesis of the blocking-matrix outputs inside the same program (error spectra in, tails carried by the kernel)
+            bmtail, bm2 = np.zeros((1, M, FL), np.float32), np.zeros((1, M, L), np.float32)
+            rc = lib.emul_aic(nfft, M, 1, None, L, vp(out), vp(tin), vp(tout), vp(cnt), vp(aic.st), aic.NF,
+                              vp(Fc), vp(dprev), vp(pc), 1, 1, f32(0.01), f32(0.8), f32(1e-4), vp(np.ascontiguousarray(e)), vp(bmtail), vp(bm2))
+            assert rc == 0 and np.array_equal(bm2[0], bm)                        # the same blocking-matrix samples as the synthesis kernel
+        else:
+            rc = lib.emul_aic(nfft, M, 1, vp(np.ascontiguousarray(bm[None])), L, vp(out), vp(tin), vp(tout), vp(cnt), vp(aic.st), aic.NF,
+                              vp(Fc), vp(dprev), vp(pc), 1, 1, f32(0.01), f32(0.8), f32(1e-4), None, None, None)
         assert rc == 0
         if tail_state is not None:
             tail_state.update(st=aic.st.copy(), dprev=dprev.copy(), tin=tin.copy())
@@ -530,3 +537,6 @@ def test_emul_subband_gsc_chain(name):
     out2 = emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, fused_tail=True, tail_state=sb)[0]
     assert np.array_equal(sa["st"][:, :, :FL + 1], sb["st"][:, :, :FL + 1]) and np.array_equal(sa["dprev"], sb["dprev"]) and np.array_equal(sa["tin"], sb["tin"])
     assert rms(out2 - out) < 1e-7 and rms(out2 - g["output"]) < 2e-5
+    sc = {}
+    out3 = emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, fused_tail="spectra", tail_state=sc)[0]
+    assert np.array_equal(out3, out2) and all(np.array_equal(sb[k], sc[k]) for k in sb)     # bit for bit the tail fed with time samples
