@@ -162,8 +162,9 @@ int chain2_reserve(ds_handle* h, int n) {
     // second set of the front end's buffers: block t + 1's front end next to block t's later stages (not for very long calls, where the
     // front end is a small share of a call anyway and the set would cost gigabytes)
     const size_t second = 2 * need[G_XN] + need[G_FIXED] + need[G_D];
+    if (h->ki_cdr.launch) need[G_GAM] = B * T * K * 4 + B * T * 4;
     if (h->front_async && second <= ((size_t)4 << 30)) {
-        need[G_XN2] = need[G_XA2] = need[G_XN]; need[G_FIXED2] = need[G_FIXED]; need[G_D2] = need[G_D];
+        need[G_XN2] = need[G_XA2] = need[G_XN]; need[G_FIXED2] = need[G_FIXED]; need[G_D2] = need[G_D]; need[G_GAM2] = need[G_GAM];
         if (h->ki_aic.launch && h->tail_async) { need[G_P2] = need[G_P]; need[G_F2] = need[G_F]; need[G_EB2] = need[G_E]; }
     }
     for (int i = 0; i < G_COUNT; ++i) {
@@ -231,7 +232,7 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         h->front_set ^= 1;
         if (h->fr_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[2 + set], 0));
         if (set) {
-            cb[G_XN] = cb[G_XN2]; cb[G_XA] = cb[G_XA2]; cb[G_FIXED] = cb[G_FIXED2]; cb[G_D] = cb[G_D2];
+            cb[G_XN] = cb[G_XN2]; cb[G_XA] = cb[G_XA2]; cb[G_FIXED] = cb[G_FIXED2]; cb[G_D] = cb[G_D2]; cb[G_GAM] = cb[G_GAM2];
             if (h->chain_buf[G_P2]) { cb[G_P] = cb[G_P2]; cb[G_F] = cb[G_F2]; cb[G_E] = cb[G_EB2]; }
         }
     }
@@ -253,7 +254,24 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         rc = post_tick(fe, fe->dev_cnt, 0, 1, 1, 2, fs); if (rc) return rc;            // rides in the analysis launch that follows
         fe->td_cur ^= 1;
     }
-    rc = chain_stft(h, h->sub[1], cb[G_XA], n, cb[G_D]); if (rc) return rc;                                   // :204  D
+    const bool cdr_in_front = h->ki_cdr.launch != nullptr;
+    if (cdr_in_front) {
+        // :204 D, and McCDR (mcspp.py:250: the prior of McSpp) in the same kernel: thread k has bin k of microphones 0..2 in registers, the
+        // MCRA stencil and the band mean of 1 - Gamma come from LDS; the counters go in by value (the host mirror of the McSpp stage)
+        ds_handle *t = h->sub[1], *sp = h->sub[2];
+        Params p;
+        fill_params(t, p);
+        p.x = cb[G_XA]; p.y = cb[G_D];
+        p.x_batch_stride = (long long)M * n; p.x_sample_stride = 1; p.x_chan_stride = n;
+        p.y_batch_stride = (long long)T * K * M * 2;
+        p.T = T; p.batch0 = 0;
+        p.cdr_st = sp->opst; p.cdr_NF = sp->NF; p.cdr_frm = sp->op_frm; p.cdr_ell = sp->op_ell; p.cdr_L = 65; p.cdr_fn = sp->dev_buf[9];
+        p.cdr_gamma = cb[G_GAM]; p.cdr_qavg = cb[G_GAM] + (size_t)B * T * K;
+        take_tick(t, fs, p.tick);
+        DS_HIP(h, h->ki_cdr.launch(p, B, fs));
+    } else {
+        rc = chain_stft(h, h->sub[1], cb[G_XA], n, cb[G_D]); if (rc) return rc;                               // :204  D
+    }
     if (h->front_async) {
         DS_HIP(h, hipEventRecord(h->ev_fr[set], fs));
         DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_fr[set], 0));
@@ -265,7 +283,8 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         DS_HIP(h, hipEventRecord(h->ev_fork, h->stream));
         DS_HIP(h, hipStreamWaitEvent(h->sub[5]->stream, h->ev_fork, 0));
     }
-    DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[G_D], T, cb[G_P], nullptr, nullptr, nullptr, nullptr, DS_MEM_DEVICE));   // :208  p
+    if (cdr_in_front) DS_SUB(2, mcspp_from_gamma(h->sub[2], cb[G_D], T, cb[G_GAM], cb[G_GAM] + (size_t)B * T * K, cb[G_P]));   // :208  p
+    else DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[G_D], T, cb[G_P], nullptr, nullptr, nullptr, nullptr, DS_MEM_DEVICE));
     rc = chain_stft(h, h->sub[3], cb[G_FIXED], n, cb[G_F]); if (rc) return rc;                                   // bm[m].transform_x: F
     // :217-223 the M blocking filters: reference input F (shared), desired signal = channel m of D (bm[m].transform_d's analysis of the
     // aligned channel is the same spectrum), update probability p

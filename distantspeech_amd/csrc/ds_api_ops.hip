@@ -280,6 +280,27 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, 
     return io_end(h, mem, io, dout);
 }
 
+}  // extern "C"
+namespace dsi {
+int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* gamma, const float* qavg, float* p_out) {
+    ds::OpParams p;
+    std::memset(&p, 0, sizeof p);
+    p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames; p.st = h->opst; p.NF = h->NF; p.M = h->cfg.n_mics;
+    p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = 65;
+    p.dev_cnt = h->use_dev_cnt ? h->dev_cnt : nullptr;
+    p.in0 = y; p.in1 = gamma; p.in2 = qavg; p.N = 9;
+    p.out0 = p_out;
+    p.repeat = h->mcspp_repeat;
+    take_tick(h, h->stream, p.tick);
+    const int op = p.repeat ? ds::OP_MCSPP : h->op_frm < 5 ? ds::OP_MCSPP_LEAN : ds::OP_MCSPP_STEADY;
+    DS_HIP(h, ds::launch_binop(op, p, h->stream));
+    if (h->use_dev_cnt) { const int rc = post_tick(h, h->dev_cnt, n_frames, 65, 0, 0, h->stream); if (rc) return rc; }
+    { const int first = h->op_first; advance_host_counters(h, n_frames, 65); h->op_first = first; }
+    return DS_OK;
+}
+}  // namespace dsi
+extern "C" {
+
 static int run_linalg(ds_handle* h, int op, const char* who, const IoSpec& io, int mem) {
     if (h->cfg.algo != DS_ALGO_LINALG) return fail(h, DS_ESTATE, std::string(who) + ": handle is not a DS_ALGO_LINALG object");
     int rc = set_device(h); if (rc) return rc;

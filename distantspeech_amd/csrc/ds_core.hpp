@@ -162,6 +162,14 @@ struct Params {
     const float* aic_e;       // complex [B * M][T][K]
     float* aic_bmtail;        // [B][M][hop]
     float* aic_bm;            // [B][M][T * hop] or null
+    // StftEngine<.., CDR = true>, the analysis of the SubbandGSC chain's front end with McCDR (mccdr_frame) as its per-bin program: the
+    // workgroup holds the utterance, so the MCRA stencil comes from LDS and McSpp's band average of 1 - Gamma is a sum over LDS
+    float* cdr_st;            // the DS_ALGO_MCSPP stage's planes [B][cdr_NF][KP]; rows 0..8 are McCDR's (p1, p2, x12, MCRA S..lambda_d)
+    int cdr_NF;
+    int cdr_frm, cdr_ell, cdr_L;   // the stage's uniform counters before this call (host mirror; the launch is never part of a replayed graph)
+    const float* cdr_fn;      // diffuse coherence of the microphone pair, [K]
+    float* cdr_gamma;         // out: Gamma [B][T][K]
+    float* cdr_qavg;          // out: mean of 1 - Gamma over the 500-2000 Hz band, [B][T]  (mcspp.py:258-260)
 };
 
 // number of per-bin state floats / planes
@@ -225,6 +233,7 @@ template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
     cf ad, adn;               // ALGO_AIC: desired-signal sample of this frame for this lane's bin / for the Nyquist bin (lane NYQ_TID)
     float apk, apkn;          // ... and the update probability
     float bmt[2 * M];         // ... and this lane's two samples of the M blocking-matrix overlap tails (lanes < NC / 2; aic_e mode)
+    float cdr[9], cdrn[9];    // StftEngine<.., CDR>: McCDR's state of this lane's bin / of the Nyquist bin (lane 0)
 };
 
 // state-plane accessors.  Every state line is read once and written once per launch and is next touched by the following launch,
@@ -351,6 +360,31 @@ DS_HD void mcra_bin(float* st, int k, int K, float Ykm1, float Yk, float Ykp1, i
     const float at = fma_(one_m_alpha_d, p, alpha_d);                                     // Base :57
     lam = fma_(at, lam, (1.0f - at) * Yk);                                                // Base :60
     st[0] = S; st[1] = Smin; st[2] = Stmp; st[3] = p; st[4] = lam;
+}
+
+// McCDR for one bin and frame (noise_estimation/mccdr.py:120-175 with BinauralEnhancement.py:28-61): recursive auto / cross spectra of
+// microphones 1 and 2, the coherent-to-diffuse ratio against the diffuse coherence Fn, and the MCRA speech presence probability of
+// microphone 0 (stencil ym, y0, yp = |Y0|^2 at bins k - 1, k, k + 1); returns Gamma = sqrt(CDR^2 p).  State: p1, p2, x12, mc[5].
+DS_HD float mccdr_frame(float& p1, float& p2, cf& x12, float* mc, cf y1, cf y2, float Fn, float ym, float y0, float yp, int k, int K,
+                        int frm, bool reset, int L) {
+    p1 = fma_(0.9f, p1, (float)(1.0 - 0.9) * cabs2(y1));                           // BinauralEnhancement.py:49-52
+    p2 = fma_(0.9f, p2, (float)(1.0 - 0.9) * cabs2(y2));
+    const cf c12 = cmulc(y1, y2);
+    x12 = mk(fma_(0.9f, x12.x, (float)(1.0 - 0.9) * c12.x), fma_(0.9f, x12.y, (float)(1.0 - 0.9) * c12.y));   // :55-61
+    // coherent-to-diffuse ratio in double: with |Fx| -> 1 and Fn -> 1 (the lowest bins of a real recording) the radicand is the
+    // difference of nearly equal terms
+    const double rn = 1.0 / sqrt((double)p1 * (double)p2);
+    const double Fxr = (double)x12.x * rn, Fxi = (double)x12.y * rn;               // updateMSC :28
+    const double Fx2 = __builtin_fma(Fxr, Fxr, Fxi * Fxi);
+    const double Fnd = (double)Fn, Fn2d = Fnd * Fnd;
+    const double rad = Fn2d * (Fxr * Fxr) - Fn2d * Fx2 + Fn2d - 2.0 * Fnd * Fxr + Fx2;
+    const double den = Fx2 - 1.0 < -1e-3 ? Fx2 - 1.0 : -1e-3;
+    double Gd = (Fnd * Fxr - Fx2 - sqrt(rad)) / den;                               // mccdr.py:141-145
+    Gd = Gd * Gd;
+    if (Gd > 1.0) Gd = 1.0;                                                        // :160-161 (NaN stays NaN like numpy)
+    if (Gd < 0.0) Gd = 1e-3;
+    mcra_bin(mc, k, K, ym, y0, yp, frm, reset, L);                                 // :174 (L = 65)
+    return (float)sqrt(Gd * (double)mc[3]);                                        // :175
 }
 
 // Hermitian packed (diag reals d[M], strictly-upper complex o[]) helpers ------------------------
@@ -1200,11 +1234,12 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
 //   STFT : x [B][..layout..]  ->  Y complex [B][T][K][M]   (p.y, p.y_batch_stride in floats)
 //   ISTFT: Y complex [B][T][K][C] (p.x, p.x_batch_stride in floats) -> y [B][T*hop][C]   (C = p.method <= M)
 // ---------------------------------------------------------------------------------------------
-template <int NFFT, int M> struct StftEngine {
+template <int NFFT, int M, bool CDR = false> struct StftEngine {
     typedef Engine<NFFT, M, ALGO_FIXED, false> EB;
     static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2, NT = NC;
     typedef typename EB::Sh Sh;
     typedef typename EB::Rg Rg;
+    static_assert(!CDR || M >= 3, "McCDR takes microphones 0, 1 and 2");
 
     template <class Exec> static DS_HD void run(Exec& ex, const Params& p, int blk, Sh& sh) {
         const int b = p.batch0 + blk;
@@ -1212,6 +1247,18 @@ template <int NFFT, int M> struct StftEngine {
         float* tin = p.tail_in + (long long)b * M * HOP;
         cf* Yout = reinterpret_cast<cf*>(p.y + (long long)blk * p.y_batch_stride);
         int old_half = 0;
+        constexpr int KP = (K + 3) & ~3;
+        // McCDR's planes of this utterance (rows 0..8 of the McSpp stage's state), bin `tid` in registers for the call, the Nyquist bin on lane 0
+        auto cdr_plane = [&](int f, int k) -> float& { return p.cdr_st[((long long)b * p.cdr_NF + f) * KP + k]; };
+        int frm = 0, ell = 0;
+        if constexpr (CDR) { frm = p.cdr_frm; ell = p.cdr_ell; }
+        const int fmin = (int)(500.0 * (2 * (K - 1)) / 16000.0), fmax = (int)(2000.0 * (2 * (K - 1)) / 16000.0);   // mcspp.py:258-259
+        // band mean of 1 - Gamma of frame t (Gamma in sh.tail), summed in bin order by one lane like mcspp_qavg()
+        auto band_mean = [&](int t) {
+            float qsum = 0.0f;
+            for (int j = fmin; j < fmax; ++j) qsum += 1.0f - sh.tail[j];
+            p.cdr_qavg[(long long)b * p.T + t] = qsum / (float)(fmax - fmin);
+        };
         ex.phase([&](int tid, Rg& r) {
             vec4* tb4 = reinterpret_cast<vec4*>(&sh.tb);
             for (int i = tid; i < Tables<NFFT>::NV4; i += NT) tb4[i] = p.tables[i];
@@ -1222,6 +1269,14 @@ template <int NFFT, int M> struct StftEngine {
             }
             EB::prefetch_init(p, xb, tid, r);
             EB::prefetch(p, xb, 0, tid, r);
+            if constexpr (CDR) {
+#pragma unroll
+                for (int f = 0; f < 9; ++f) r.cdr[f] = cdr_plane(f, tid);
+                if (tid == 0) {
+#pragma unroll
+                    for (int f = 0; f < 9; ++f) r.cdrn[f] = cdr_plane(f, NC);
+                }
+            }
         });
         for (int t = 0; t < p.T; ++t) {
             const int new_half = old_half ^ 1;
@@ -1229,6 +1284,7 @@ template <int NFFT, int M> struct StftEngine {
             ph(EB::WAVE_FFT && p.x_sample_stride == 1, [&](int tid, Rg& r) {
                 EB::commit(p, sh, new_half, tid, r);
                 if (t + 1 < p.T) EB::prefetch(p, xb, t + 1, tid, r);
+                if constexpr (CDR) { if (t > 0 && tid == NT - 1) band_mean(t - 1); }      // Gamma of the previous frame is behind a barrier by now
             });
             cf* fa = &sh.fa[0][0];
             cf* fb = &sh.fb[0][0];
@@ -1243,7 +1299,7 @@ template <int NFFT, int M> struct StftEngine {
                     ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, -1, false, 0, 0>(tid, NT, sh, fb, fa, 256, 0, M); });
             }
             const cf* F = EB::FWD_FINAL_IS_FB ? fb : fa;
-            ex.phase([&](int tid, Rg&) {
+            ex.phase([&](int tid, Rg& r) {
                 const int k = tid, k2 = (NC - k) & (NC - 1);
                 const cf w = sh.tb.tw[k];
                 cf* dst = Yout + ((long long)t * K + k) * M;
@@ -1256,20 +1312,58 @@ template <int NFFT, int M> struct StftEngine {
                     cf Z = cfma(E, w, O);
                     if (k == 0) Z.y = 0.0f;
                     dst[m] = Z;
+                    if constexpr (CDR) { if (m < 3) r.Z[m] = Z; }
                 }
                 if (k == 0) {                                  // Nyquist bin
                     cf* dn = Yout + ((long long)t * K + NC) * M;
 #pragma unroll
-                    for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; dn[m] = mk(F0.x - F0.y, 0.0f); }
+                    for (int m = 0; m < M; ++m) {
+                        const cf F0 = F[m * Sh::NCP];
+                        dn[m] = mk(F0.x - F0.y, 0.0f);
+                        if constexpr (CDR) { if (m < 3) sh.zn[m] = F0.x - F0.y; }
+                    }
+                    if constexpr (CDR) sh.pw[NC] = sh.zn[0] * sh.zn[0];
                 }
+                if constexpr (CDR) sh.pw[k] = cabs2(r.Z[0]);
             });
+            if constexpr (CDR) {
+                // ---- McCDR of frame t: Gamma to HBM (McSpp's input) and to LDS (the band mean) ----------------------------------------
+                const bool reset = (frm != 0) && (ell % p.cdr_L == 0);
+                ex.phase([&](int tid, Rg& r) {
+                    const int k = tid;
+                    cf x12 = mk(r.cdr[2], r.cdr[3]);
+                    const float g = mccdr_frame(r.cdr[0], r.cdr[1], x12, r.cdr + 4, r.Z[1], r.Z[2], p.cdr_fn[k], k > 0 ? sh.pw[k - 1] : 0.0f,
+                                                sh.pw[k], sh.pw[k + 1], k, K, frm, reset, p.cdr_L);
+                    r.cdr[2] = x12.x; r.cdr[3] = x12.y;
+                    float* gout = p.cdr_gamma + ((long long)b * p.T + t) * K;
+                    gout[k] = g;
+                    sh.tail[k] = g;
+                    if (k == 0) {                              // ... and of the Nyquist bin
+                        cf xn = mk(r.cdrn[2], r.cdrn[3]);
+                        gout[NC] = mccdr_frame(r.cdrn[0], r.cdrn[1], xn, r.cdrn + 4, mk(sh.zn[1], 0.0f), mk(sh.zn[2], 0.0f), p.cdr_fn[NC],
+                                               sh.pw[NC - 1], sh.pw[NC], 0.0f, NC, K, frm, reset, p.cdr_L);
+                        r.cdrn[2] = xn.x; r.cdrn[3] = xn.y;
+                    }
+                });
+                if (reset) ell = 0;
+                frm += 1; ell += 1;
+            }
             old_half = new_half;
         }
-        ex.phase([&](int tid, Rg&) {
+        ex.phase([&](int tid, Rg& r) {
             vec4* tin4 = reinterpret_cast<vec4*>(tin);
             for (int i = tid; i < M * HOP / 4; i += NT) {
                 const int m = i / (HOP / 4), q = i - m * (HOP / 4);
                 tin4[i] = *reinterpret_cast<const vec4*>(&sh.xbuf[m][old_half * HOP + 4 * q]);
+            }
+            if constexpr (CDR) {
+                if (p.T > 0 && tid == NT - 1) band_mean(p.T - 1);
+#pragma unroll
+                for (int f = 0; f < 9; ++f) cdr_plane(f, tid) = r.cdr[f];
+                if (tid == 0) {
+#pragma unroll
+                    for (int f = 0; f < 9; ++f) cdr_plane(f, NC) = r.cdrn[f];
+                }
             }
         });
     }

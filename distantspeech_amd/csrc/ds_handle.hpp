@@ -43,6 +43,7 @@ struct ds_handle {
     // staging for host-pointer calls
     // frame-level objects (DS_ALGO_TRANSFORM .. DS_ALGO_SUBRLS)
     KernelInfo ki_istft;
+    KernelInfo ki_cdr;          // DS_ALGO_SUBBAND_GSC, pipelined: the front end's analysis with McCDR as its per-bin program (null: separate kernels)
     KernelInfo ki_aic;          // DS_ALGO_SUBBAND_GSC: the chain's tail as one frame kernel (null launch: separate kernels)
     KernelInfo ki_rows, ki_rows_istft;   // single-channel transform handles: the one-row-per-wavefront kernels (null launch = not available)
     int op;                     // ds::OP_* or -1
@@ -157,6 +158,8 @@ int binop_launch(ds_handle* h, int b0, int nb, int n_frames, const float* const 
                  hipStream_t stream, const ds::TickArgs& tick, int group = 0);
 int wpe_launch(ds_handle* h, int b0, int nb, const float* x_delayed, const float* d, int n_frames, float* err, float* ring, int ring_pos,
                int ring_len, const int* dev_ring_pos, hipStream_t stream);
+// the McSpp half of ds_mcspp_estimate on device buffers: Gamma and its band mean come from the caller (the chain's front end computes them)
+int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* gamma, const float* qavg, float* p_out);
 int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len,
             const int* dev_ring_pos);
 
@@ -177,7 +180,8 @@ enum {
     G_FIXPREV = 14,  // [B][hop]         state: fixed beamformer output of the previous block
     G_XN2 = 15, G_XA2 = 16, G_FIXED2 = 17, G_D2 = 18,   // second set of the front end's buffers (front_async)
     G_P2 = 19, G_F2 = 20, G_EB2 = 21,                   // ... and of what the tail reads (p, F, the blocking filters' error spectra)
-    G_COUNT = 22
+    G_GAM = 22, G_GAM2 = 23,                            // McCDR's Gamma [B][T][K] + its band mean [B][T] when the front end computes them (ki_cdr), two sets
+    G_COUNT = 24
 };
 int chain_reserve(ds_handle* h, int T);
 int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,

@@ -24,6 +24,7 @@ KernelInfo lookup_gsc(int nfft, int M);
 KernelInfo lookup_aic(int nfft, int M);     // ALGO_AIC: the SubbandGSC chain's tail (ds_kernels_aic.hip)
 KernelInfo lookup_stft(int nfft, int M);      // ds_kernels_ops.hip
 KernelInfo lookup_istft(int nfft, int M);
+KernelInfo lookup_stft_cdr(int nfft, int M);   // analysis + McCDR (the SubbandGSC chain's front end); M in {4, 6, 8}
 KernelInfo lookup_stft_rows(int nfft);      // single-channel handles: one row per wavefront (nfft 512 / 1024), launch(p, rows, stream)
 KernelInfo lookup_istft_rows(int nfft);
 struct OpParams;

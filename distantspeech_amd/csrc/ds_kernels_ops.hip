@@ -23,6 +23,19 @@ template <int NFFT, int M> __global__ void __launch_bounds__(NFFT / 2) ds_istft_
     E::run(ex, p, (int)blockIdx.x, sh);
 }
 
+// the analysis of the SubbandGSC chain's front end with McCDR as its per-bin program (StftEngine<.., CDR = true>)
+template <int NFFT, int M> __global__ void __launch_bounds__(NFFT / 2) ds_stft_cdr_kernel(Params p) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
+    typedef StftEngine<NFFT, M, true> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+template <int NFFT, int M> hipError_t launch_stft_cdr(const Params& p, int nblocks, hipStream_t stream) {
+    hipLaunchKernelGGL((ds_stft_cdr_kernel<NFFT, M>), dim3(nblocks), dim3(NFFT / 2), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <int NFFT, int M> hipError_t launch_stft(const Params& p, int nblocks, hipStream_t stream) {
     hipLaunchKernelGGL((ds_stft_kernel<NFFT, M>), dim3(nblocks), dim3(NFFT / 2), 0, stream, p);
     return hipGetLastError();
@@ -80,6 +93,13 @@ KernelInfo lookup_istft_rows(int nfft) {
 KernelInfo lookup_stft(int nfft, int M) {
 #define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {&launch_stft<NFFT_, M_>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
     DS_FOR_EACH_TSHAPE(X)
+#undef X
+    KernelInfo none = {nullptr, 0, 0, 0};
+    return none;
+}
+KernelInfo lookup_stft_cdr(int nfft, int M) {
+#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {&launch_stft_cdr<NFFT_, M_>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
+    X(256, 4) X(256, 6) X(256, 8) X(512, 4) X(512, 6) X(512, 8) X(1024, 4) X(1024, 6) X(1024, 8)
 #undef X
     KernelInfo none = {nullptr, 0, 0, 0};
     return none;

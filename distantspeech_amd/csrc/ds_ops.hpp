@@ -763,29 +763,14 @@ DS_HD void op_mccdr(const OpCtx& p, int b, int k) {
         const cf y0 = mk(p.in0[2 * base], p.in0[2 * base + 1]);
         const cf y1 = mk(p.in0[2 * (base + 1)], p.in0[2 * (base + 1) + 1]);
         const cf y2 = mk(p.in0[2 * (base + 2)], p.in0[2 * (base + 2) + 1]);
-        p1 = fma_(0.9f, p1, (float)(1.0 - 0.9) * cabs2(y1));                       // BinauralEnhancement.py:49-52
-        p2 = fma_(0.9f, p2, (float)(1.0 - 0.9) * cabs2(y2));
-        const cf c12 = cmulc(y1, y2);
-        x12 = mk(fma_(0.9f, x12.x, (float)(1.0 - 0.9) * c12.x), fma_(0.9f, x12.y, (float)(1.0 - 0.9) * c12.y));   // :55-61
-        // coherent-to-diffuse ratio in double: with |Fx| -> 1 and Fn -> 1 (the lowest bins of a real recording) the radicand is the
-        // difference of nearly equal terms
-        const double rn = 1.0 / sqrt((double)p1 * (double)p2);
-        const double Fxr = (double)x12.x * rn, Fxi = (double)x12.y * rn;           // updateMSC :28
-        const double Fx2 = fmad_(Fxr, Fxr, Fxi * Fxi);
-        const double Fnd = (double)Fn, Fn2d = Fnd * Fnd;
-        const double rad = Fn2d * (Fxr * Fxr) - Fn2d * Fx2 + Fn2d - 2.0 * Fnd * Fxr + Fx2;
-        double Gd = (Fnd * Fxr - Fx2 - sqrt(rad)) / dmin_(Fx2 - 1.0, -1e-3);      // mccdr.py:141-145
-        Gd = Gd * Gd;
-        if (Gd > 1.0) Gd = 1.0;                                                    // :160-161 (NaN stays NaN like numpy)
-        if (Gd < 0.0) Gd = 1e-3;
         const bool reset = mcra_tick(frm, ell, p.L);
         const float pw0 = cabs2(y0);
         float ym = 0.0f, yp = 0.0f;
         if (k > 0) { const long long q = (fb + k - 1) * M; ym = cabs2(mk(p.in0[2 * q], p.in0[2 * q + 1])); }
         if (k < p.K - 1) { const long long q = (fb + k + 1) * M; yp = cabs2(mk(p.in0[2 * q], p.in0[2 * q + 1])); }
-        mcra_bin(mc, k, p.K, ym, pw0, yp, frm, reset, p.L);                        // :174 (L = 65)
+        const float g = mccdr_frame(p1, p2, x12, mc, y1, y2, Fn, ym, pw0, yp, k, p.K, frm, reset, p.L);
         frm += 1; ell += 1;
-        p.out0[fb + k] = (float)sqrt(Gd * (double)mc[3]);                          // :175
+        p.out0[fb + k] = g;
     }
     st_at(p, b, 0, k) = p1; st_at(p, b, 1, k) = p2; st_at(p, b, 2, k) = x12.x; st_at(p, b, 3, k) = x12.y;
 #pragma unroll

@@ -138,6 +138,13 @@ template <int F> static void fan_rows(int op, const ds::OpParams& p) {
         }
 }
 
+template <int NFFT> static int run_stft_cdr(int M, const ds::Params& p, int batch) {
+    if (M == 4) return run_engine<ds::StftEngine<NFFT, 4, true>>(p, batch, NFFT);
+    if (M == 6) return run_engine<ds::StftEngine<NFFT, 6, true>>(p, batch, NFFT);
+    if (M == 8) return run_engine<ds::StftEngine<NFFT, 8, true>>(p, batch, NFFT);
+    return -1;
+}
+
 extern "C" {
 
 // Transform.stft: x -> Y complex [B][T][K][M]; tail_in [B][M][hop] carried
@@ -301,6 +308,27 @@ int emul_run(int algo, int nfft, int M, int ryy, int batch, const float* x, int 
         case 256: return run_n<256>(M, algo, ryy, p, batch);
         case 512: return run_n<512>(M, algo, ryy, p, batch);
         case 1024: return run_n<1024>(M, algo, ryy, p, batch);
+    }
+    return -1;
+}
+
+// the analysis of the SubbandGSC chain's front end with McCDR as its per-bin program (StftEngine<.., CDR = true>): x [B][M][n] -> Y complex
+// [B][T][K][M], Gamma [B][T][K], band mean of 1 - Gamma [B][T]; st = the McSpp stage's planes [B][NF][KP] (rows 0..8 McCDR's)
+int emul_stft_cdr(int nfft, int M, int batch, const float* x, int n_samples, float* Y, float* tail_in, float* st, int NF, int frm, int ell,
+                  const float* Fn, float* gamma, float* qavg) {
+    ds::Params p;
+    std::memset(&p, 0, sizeof p);
+    const int hop = nfft / 2, K = nfft / 2 + 1;
+    p.x = x; p.y = Y;
+    p.x_batch_stride = (long long)M * n_samples; p.x_sample_stride = 1; p.x_chan_stride = n_samples;
+    p.T = n_samples / hop;
+    p.y_batch_stride = (long long)p.T * K * M * 2;
+    p.tail_in = tail_in;
+    p.cdr_st = st; p.cdr_NF = NF; p.cdr_frm = frm; p.cdr_ell = ell; p.cdr_L = 65; p.cdr_fn = Fn; p.cdr_gamma = gamma; p.cdr_qavg = qavg;
+    switch (nfft) {
+        case 256: return run_stft_cdr<256>(M, p, batch);
+        case 512: return run_stft_cdr<512>(M, p, batch);
+        case 1024: return run_stft_cdr<1024>(M, p, batch);
     }
     return -1;
 }

@@ -517,6 +517,43 @@ def emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, p_override=None, fused_tail=
     return out, bm.T, p[0].T, xa[0]
 
 
+@pytest.mark.parametrize("M,nfft", [(6, 512), (4, 256), (4, 1024)])
+def test_emul_analysis_with_mccdr_equals_separate_programs(M, nfft):
+    """The SubbandGSC chain's front-end analysis with McCDR as its per-bin program (StftEngine<.., CDR>: stencil and band mean from LDS)
+    against the analysis program followed by the McCDR operator: spectra, Gamma, the band mean of 1 - Gamma and McCDR's state bit for bit,
+    over several calls (state and MCRA counters carried), including a call that crosses the 65-frame MCRA window."""
+    import ctypes
+    from emul import emul as E
+    from oracle import ds_oracle as O
+    lib = E.lib()
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    hop, K = nfft // 2, nfft // 2 + 1
+    rng = np.random.default_rng(17)
+    Fn = np.ascontiguousarray(O.gen_noise_msc(O.OracleMicArray(arrayType="circular", r=0.032, M=M), nfft)[:, 1, 2], dtype=np.float32)
+    tx = EmulTransform(nfft, M)
+    op = EmulOp("mcspp", nfft, M=M)
+    st2 = op.st.copy()
+    tin2 = np.zeros((1, M, hop), np.float32)
+    frm, ell = 0, 1
+    for T in (3, 1, 70, 2):
+        x = (rng.standard_normal((1, M, T * hop)) * 0.1).astype(np.float32)
+        D = tx.stft(x, 1)                                                           # [1, T, K, M]
+        op.op_override, op.L_override, op.hold_counters = 7, 65, False
+        gamma = op.run(D, Fn)[0]                                                    # advances op.frm / op.ell like the handle does
+        qavg = np.array([[np.float32(sum((np.float32(1) - gamma[0, t, j] for j in range(int(500.0 * nfft / 16000.0), int(2000.0 * nfft / 16000.0))), np.float32(0))
+                                     / np.float32(int(2000.0 * nfft / 16000.0) - int(500.0 * nfft / 16000.0))) for t in range(T)]], np.float32)
+        D2 = np.zeros_like(D); g2 = np.zeros((1, T, K), np.float32); q2 = np.zeros((1, T), np.float32)
+        rc = lib.emul_stft_cdr(nfft, M, 1, vp(x), T * hop, vp(D2), vp(tin2), vp(st2), op.NF, frm, ell, vp(Fn), vp(g2), vp(q2))
+        assert rc == 0
+        for _ in range(T):                                                          # the host mirror of the counters (advance_host_counters, L = 65)
+            if frm != 0 and ell % 65 == 0:
+                ell = 0
+            frm += 1; ell += 1
+        assert np.array_equal(D2, D) and np.array_equal(g2, gamma) and np.array_equal(q2, qavg)
+        assert np.array_equal(st2[:, :9, :K], op.st[:, :9, :K]) and np.array_equal(tin2, tx.tail_in)
+    assert (frm, ell) == (op.frm, op.ell)
+
+
 @pytest.mark.parametrize("name", ["rec1", "synth_m6", "synth_m6_rls"])
 def test_emul_subband_gsc_chain(name):
     """SubbandGSC.process (G12, incl. the config-5 Subband-RLS composition) through the chain's stage programs: every returned signal
