@@ -343,8 +343,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     // fused frame kernels: two free-running utterance groups from 2048 utterances up (more than one round of workgroups per launch)
     h->split = (cfg->algo <= DS_ALGO_GSC && cfg->batch >= 2048) ? 2 : 1; h->ev_fork = nullptr;
     h->parts = 1; h->groups_open = false;
-    h->front_async = false; h->tail_async = false; h->front_open = false; h->fr_valid[0] = h->fr_valid[1] = false; h->tf_valid[0] = h->tf_valid[1] = false; h->front_set = 0;
-    for (int i = 0; i < 8; ++i) h->ev_fr[i] = nullptr;
+    h->front_async = false; h->tail_async = false; h->front_open = false; h->fr_valid[0] = h->fr_valid[1] = false; h->tf_valid[0] = h->tf_valid[1] = false; h->bf_valid[0] = h->bf_valid[1] = false; h->al_read[0] = h->al_read[1] = false; h->fr_mid[0] = h->fr_mid[1] = false; h->front_set = 0; h->lean_main = false;
+    for (int i = 0; i < 10; ++i) h->ev_fr[i] = nullptr;
     for (int i = 0; i < 7; ++i) { h->side[i] = nullptr; h->ev_join[i] = nullptr; }
     h->ki_istft = ki_istft; h->op = op;
     h->ki_rows = KernelInfo{nullptr, 0, 0, 0}; h->ki_rows_istft = h->ki_rows; h->ki_aic = h->ki_rows; h->ki_cdr = h->ki_rows;
@@ -490,7 +490,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         const char* serial = std::getenv("DS_CHAIN_SERIAL_FRONT");
         if (!(serial && serial[0] == '1')) {
             bool ok = hipStreamCreateWithFlags(&h->side[1], hipStreamNonBlocking) == hipSuccess;
-            for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreateWithFlags(&h->ev_fr[i], hipEventDisableTiming) == hipSuccess;
+            for (int i = 0; i < 10 && ok; ++i) ok = hipEventCreateWithFlags(&h->ev_fr[i], hipEventDisableTiming) == hipSuccess;
             // the tail on a stream of its own needs a hardware queue of its own: with the runtime's default of 4 queues per device the fourth
             // and fifth stream of the process share one and the front end would queue behind the previous block's tail (measured: 0.31 ms per
             // block instead of 0.28).  The application raises the limit before the first HIP call (GPU_MAX_HW_QUEUES=8; bench.py and the
@@ -505,6 +505,12 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             if (!ok) { ds_destroy(h); return fail(nullptr, DS_EHIP, "ds_create(DS_ALGO_SUBBAND_GSC): front-end stream"); }
             h->front_async = true;
             h->sub[0]->stream = h->side[1]; h->sub[1]->stream = h->side[1];
+            // a pipelined chain is never replayed as a graph, so McSpp takes its frame counters by value (the host mirror): no
+            // counter-advance launch between two McSpp launches, which are the chain's critical loop (DS_CHAIN_MAIN_JOIN=1: the older
+            // arrangement, A/B runs)
+            const char* mj = std::getenv("DS_CHAIN_MAIN_JOIN");
+            h->lean_main = !(mj && mj[0] == '1');
+            if (h->lean_main) h->sub[2]->use_dev_cnt = false;
             // ... with McCDR as the per-bin program of the analysis kernel (the workgroup holds the utterance: MCRA stencil and band mean from
             // LDS); counters by value, so only where nothing is replayed as a graph.  DS_CHAIN_UNFUSED=1: the separate McCDR launch
             const char* unf2 = std::getenv("DS_CHAIN_UNFUSED");
@@ -539,7 +545,7 @@ int ds_destroy(ds_handle* h) {
     for (int i = 0; i < 8; ++i) if (h->group_exec[i]) (void)hipGraphExecDestroy(h->group_exec[i]);
     for (int i = 0; i < 7; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    for (int i = 0; i < 8; ++i) if (h->ev_fr[i]) (void)hipEventDestroy(h->ev_fr[i]);
+    for (int i = 0; i < 10; ++i) if (h->ev_fr[i]) (void)hipEventDestroy(h->ev_fr[i]);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream && h->owns_stream) (void)hipStreamDestroy(h->stream);

@@ -221,16 +221,27 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     // behind it); otherwise it is ordered behind the whole of block t
     hipStream_t fs = h->front_async ? h->side[1] : h->stream;
     int set = 0;
+    bool early = false;
     if (h->front_async) {
         const bool two = h->chain_buf[G_D2] != nullptr;
         if (!h->front_open) {                               // first block since something else used the chain's stream: start from there
             DS_HIP(h, hipEventRecord(h->ev_fork, h->stream));
             DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fork, 0));
             h->front_open = true; h->fr_valid[0] = h->fr_valid[1] = false; h->tf_valid[0] = h->tf_valid[1] = false;
+            h->bf_valid[0] = h->bf_valid[1] = false;
         }
         set = two ? h->front_set : 0;
         h->front_set ^= 1;
-        if (h->fr_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[2 + set], 0));
+        // who read this set last: the analysis outputs (D, Gamma) are read by the middle stages, the fixed-beamformer block by the
+        // blocking-filter branch, the notch / FIR outputs only by the front end itself (and by the copy of `aligned`, if the caller asked for
+        // it).  When the branch joins at the tail (below) each front-end kernel waits for its own readers only, so that the notch and the
+        // FIR bank of block t + 2 run next to the middle stages of block t and only the analysis waits for them
+        static const bool no_early = [] { const char* e = std::getenv("DS_CHAIN_NO_EARLY"); return e && e[0] == '1'; }();     // A/B switch
+        early = !no_early && two && h->lean_main && h->tail_async && h->ki_aic.launch && h->sub[5]->stream != h->stream && !h->al_read[set];
+        if (!early) {
+            if (h->fr_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[(h->fr_mid[set] ? 4 : 2) + set], 0));
+            if (h->bf_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[8 + set], 0));     // ... and its blocking-filter branch (lean_main)
+        }
         if (set) {
             cb[G_XN] = cb[G_XN2]; cb[G_XA] = cb[G_XA2]; cb[G_FIXED] = cb[G_FIXED2]; cb[G_D] = cb[G_D2]; cb[G_GAM] = cb[G_GAM2];
             if (h->chain_buf[G_P2]) { cb[G_P] = cb[G_P2]; cb[G_F] = cb[G_F2]; cb[G_E] = cb[G_EB2]; }
@@ -244,6 +255,7 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         p.B = B; p.M = M; p.n = n; p.x = x_dev; p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.y = cb[G_XN]; p.mem = fe->td_mem;
         p.radius = fe->cfg.filt_alpha;
         DS_HIP(h, ds::launch_dcnotch(p, fs));
+        if (early && h->bf_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[8 + set], 0));    // the FIR bank writes the fixed-beamformer block
         const int Lt = (int)(fe->aux_floats / M);
         rc = frontend_set_taps(fe, Lt); if (rc) return fail(h, rc, fe->err);
         std::memset(&p, 0, sizeof p);
@@ -255,6 +267,7 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         fe->td_cur ^= 1;
     }
     const bool cdr_in_front = h->ki_cdr.launch != nullptr;
+    if (early && h->fr_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[(h->fr_mid[set] ? 4 : 2) + set], 0));        // the analysis writes D and Gamma
     if (cdr_in_front) {
         // :204 D, and McCDR (mcspp.py:250: the prior of McSpp) in the same kernel: thread k has bin k of microphones 0..2 in registers, the
         // MCRA stencil and the band mean of 1 - Gamma come from LDS; the counters go in by value (the host mirror of the McSpp stage)
@@ -272,16 +285,26 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     } else {
         rc = chain_stft(h, h->sub[1], cb[G_XA], n, cb[G_D]); if (rc) return rc;                               // :204  D
     }
+    const bool fork = h->sub[5]->stream != h->stream;                       // blocking-filter branch on the side stream (RLS filters, see ds_create)
+    const bool fused_tail = h->ki_aic.launch != nullptr;
+    // with the tail on its own stream the blocking-filter branch joins THERE, and forks from the front end, not from the chain's stream:
+    // every record / wait on the chain's stream is a barrier packet (~5 us) between two McSpp launches, which are the chain's critical
+    // loop — that stream then carries one wait per dependency and one record per block, no join, no counter advance, no copy
+    const bool join_at_tail = h->front_async && fork && fused_tail && tail_async && h->lean_main;
     if (h->front_async) {
         DS_HIP(h, hipEventRecord(h->ev_fr[set], fs));
         DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_fr[set], 0));
         // the middle stages write p, F and the blocking-matrix outputs of this set: the tail that read them last comes first
         if (tail_async && h->tf_valid[set]) DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_fr[6 + set], 0));
     }
-    const bool fork = h->sub[5]->stream != h->stream;                       // blocking-filter branch on the side stream (RLS filters, see ds_create)
     if (fork) {
-        DS_HIP(h, hipEventRecord(h->ev_fork, h->stream));
-        DS_HIP(h, hipStreamWaitEvent(h->sub[5]->stream, h->ev_fork, 0));
+        if (join_at_tail) {                                                  // the RLS filters do not take p: the branch follows the front end and the
+            DS_HIP(h, hipStreamWaitEvent(h->sub[5]->stream, h->ev_fr[set], 0));                       // last tail of this set directly
+            if (h->tf_valid[set]) DS_HIP(h, hipStreamWaitEvent(h->sub[5]->stream, h->ev_fr[6 + set], 0));
+        } else {
+            DS_HIP(h, hipEventRecord(h->ev_fork, h->stream));
+            DS_HIP(h, hipStreamWaitEvent(h->sub[5]->stream, h->ev_fork, 0));
+        }
     }
     if (cdr_in_front) DS_SUB(2, mcspp_from_gamma(h->sub[2], cb[G_D], T, cb[G_GAM], cb[G_GAM] + (size_t)B * T * K, cb[G_P]));   // :208  p
     else DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[G_D], T, cb[G_P], nullptr, nullptr, nullptr, nullptr, DS_MEM_DEVICE));
@@ -290,14 +313,27 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     // aligned channel is the same spectrum), update probability p
     if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[G_F], cb[G_D], T, cb[G_E], DS_MEM_DEVICE));
     else DS_SUB(5, ds_sublms_update(h->sub[5], cb[G_F], cb[G_D], cb[G_P], T, cb[G_E], DS_MEM_DEVICE));
-    const bool fused_tail = h->ki_aic.launch != nullptr;
     if (!fused_tail) {
         rc = chain_istft(h, h->sub[4], cb[G_E], T, cb[G_BM], n); if (rc) return rc;                           // bm outputs, [B*M][n] = [B][M][n]
         rc = chain_stft(h, h->sub[6], cb[G_BM], n, cb[G_XAIC]); if (rc) return rc;                              // :230-234  aic transform_x
     }
-    if (fork) {
-        DS_HIP(h, hipEventRecord(h->ev_join[0], h->sub[5]->stream));
-        DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[0], 0));
+    hipStream_t cs = join_at_tail ? h->sub[5]->stream : h->stream;             // the stream of the carried-block copies below
+    {   // fix_output = fixed beamformer output delayed by one block (:226,255); the carried block is state either way
+        const size_t blk = (size_t)hop * 4, row = (size_t)n * 4;
+        if (fork && !join_at_tail) {
+            DS_HIP(h, hipEventRecord(h->ev_join[0], h->sub[5]->stream));
+            DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[0], 0));
+        }
+        if (fix_dev) {
+            if (T > 1) DS_HIP(h, hipMemcpy2DAsync((char*)fix_dev + blk, row, cb[G_FIXED], row, row - blk, B, hipMemcpyDeviceToDevice, cs));
+            DS_HIP(h, hipMemcpy2DAsync(fix_dev, row, cb[G_FIXPREV], blk, blk, B, hipMemcpyDeviceToDevice, cs));
+        }
+        DS_HIP(h, hipMemcpy2DAsync(cb[G_FIXPREV], blk, (char*)cb[G_FIXED] + (row - blk), row, blk, B, hipMemcpyDeviceToDevice, cs));
+        if (join_at_tail) {
+            DS_HIP(h, hipEventRecord(h->ev_fr[8 + set], h->sub[5]->stream));
+            h->bf_valid[set] = true;
+            h->groups_open = true;                                              // join_groups(): the branch comes back before anything else touches the handle
+        }
     }
     // :226 delay_fbf: the canceller's desired signal is the fixed output one block late = F one frame late; the operator keeps the
     // carried frame in cb[G_FPREV] itself
@@ -322,6 +358,7 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
             rc = flush_tick(h); if (rc) return rc;
             DS_HIP(h, hipEventRecord(h->ev_fr[4 + set], h->stream));
             DS_HIP(h, hipStreamWaitEvent(h->side[2], h->ev_fr[4 + set], 0));
+            if (join_at_tail) DS_HIP(h, hipStreamWaitEvent(h->side[2], h->ev_fr[8 + set], 0));
             DS_HIP(h, h->ki_aic.launch(p, B, h->side[2]));
             DS_HIP(h, hipEventRecord(h->ev_fr[6 + set], h->side[2]));
             h->tf_valid[set] = true;
@@ -335,22 +372,17 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         DS_SUB(7, ds_sublms_update(h->sub[7], cb[G_XAIC], cb[G_F], cb[G_P], T, cb[G_E2], DS_MEM_DEVICE));
         rc = chain_istft(h, h->sub[8], cb[G_E2], T, y_dev, y_bstride); if (rc) return rc;
     }
-    {   // fix_output = fixed beamformer output delayed by one block (:226,255); the carried block is state either way
-        const size_t blk = (size_t)hop * 4, row = (size_t)n * 4;
-        if (fix_dev) {
-            if (T > 1) DS_HIP(h, hipMemcpy2DAsync((char*)fix_dev + blk, row, cb[G_FIXED], row, row - blk, B, hipMemcpyDeviceToDevice, h->stream));
-            DS_HIP(h, hipMemcpy2DAsync(fix_dev, row, cb[G_FIXPREV], blk, blk, B, hipMemcpyDeviceToDevice, h->stream));
-        }
-        DS_HIP(h, hipMemcpy2DAsync(cb[G_FIXPREV], blk, (char*)cb[G_FIXED] + (row - blk), row, blk, B, hipMemcpyDeviceToDevice, h->stream));
-    }
     const size_t nb = (size_t)B * M * n * 4;
     if (bm_dev && !fused_tail) DS_HIP(h, hipMemcpyAsync(bm_dev, cb[G_BM], nb, hipMemcpyDeviceToDevice, h->stream));   // (the fused tail writes them itself)
     if (al_dev) DS_HIP(h, hipMemcpyAsync(al_dev, cb[G_XA], nb, hipMemcpyDeviceToDevice, h->stream));
+    h->al_read[set] = al_dev != nullptr;
     if (p_dev) DS_HIP(h, hipMemcpyAsync(p_dev, cb[G_P], (size_t)B * T * K * 4, hipMemcpyDeviceToDevice, h->stream));
 #undef DS_SUB
     rc = flush_tick(h); if (rc) return rc;
     if (h->front_async) {                                   // everything that reads this block's front-end buffers is on the chain's stream by now
-        DS_HIP(h, hipEventRecord(h->ev_fr[2 + set], h->stream));
+        // (or on the blocking-filter branch, ev_fr[8 + set]).  Nothing enqueued there since the tail's fork: that event says the same
+        h->fr_mid[set] = join_at_tail && !(al_dev || p_dev);
+        if (!h->fr_mid[set]) DS_HIP(h, hipEventRecord(h->ev_fr[2 + set], h->stream));
         h->fr_valid[set] = true;
     }
     return DS_OK;

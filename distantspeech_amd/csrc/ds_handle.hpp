@@ -92,10 +92,12 @@ struct ds_handle {
     // caller has block t + 1 enqueued by then.  ev_fr: {front of set 0 / 1 done, set 0 / 1 free again}
     // ... and, with the tail as one frame kernel, the tail runs on side[2] out of one of two sets of the middle stages' outputs (p, F, the
     // blocking-matrix outputs): a three-stage pipeline front(t + 1) | McSpp + blocking filters(t) | tail(t - 1) across the blocks the caller
-    // has enqueued.  ev_fr + 4: {middle of set 0 / 1 done, tail of set 0 / 1 done}
-    bool front_async, tail_async, front_open, fr_valid[2], tf_valid[2];
+    // has enqueued.  ev_fr + 4: {middle of set 0 / 1 done, tail of set 0 / 1 done}; ev_fr + 8: {blocking-filter branch of set 0 / 1 done}
+    // (with the tail on its own stream the branch joins there, not on the chain's stream: nothing but McSpp sits between two McSpp launches)
+    bool front_async, tail_async, front_open, fr_valid[2], tf_valid[2], bf_valid[2], al_read[2], fr_mid[2];
+    bool lean_main;             // pipelined chain: McSpp's counters by value (no counter-advance launch), the blocking-filter branch joins on the tail's stream
     int front_set;
-    hipEvent_t ev_fr[8];
+    hipEvent_t ev_fr[10];
     // chain handles under graph replay: the shape (samples per call) that has run once with plain launches (buffers sized, start-up
     // branches behind), and what one replay of the captured sequence does to the host mirrors of the stages' uniform counters
     ds_handle* owner;           // the chain handle this stage belongs to (null: stand-alone)
