@@ -63,7 +63,7 @@ WORKLOADS = {
                  desc="WPE dereverberation (2 taps) + adaptive MVDR + SPP gain chain, 8 mics, 16 kHz, 1024-FFT/512-hop"),
     # cfg5: SubbandGSC structure with SubbandRLS blocking filters; 6 mics, 512 bands; 16384 utterances over 8 GPUs = 2048 per GPU
     "cfg5": dict(algo="SUBBAND_GSC", M=6, nfft=512, hop=256, batch=2048, S=313440, r=0.05, filter_len=2, rls_lambda=0.998,
-                 kernel="DS_ALGO_SUBBAND_GSC chain", launches=8, graph=0,     # plain launches: hipGraph replay serialises the chain's streams
+                 kernel="DS_ALGO_SUBBAND_GSC chain", launches=7, graph=0,     # plain launches: hipGraph replay serialises the chain's streams
                  desc="Subband-RLS GSC chain (SubbandGSC.process with SubbandRLS blocking filters), 6 mics, 16 kHz, 512 bands / block 256"),
     # the two overlap-save GSCs as chain handles, 4 mics, block 256; not BASELINE configs (--config tdgsc / fdgsc).
     # S (fp32): TDGSC = canceller W 3*257*8 + P 257*4 + previous input block 3*256*4 + non-causal delay 128*4, MCRA 5*257*4, analysis tail
