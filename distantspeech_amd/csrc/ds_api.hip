@@ -343,7 +343,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     // fused frame kernels: two free-running utterance groups from 2048 utterances up (more than one round of workgroups per launch)
     h->split = (cfg->algo <= DS_ALGO_GSC && cfg->batch >= 2048) ? 2 : 1; h->ev_fork = nullptr;
     h->parts = 1; h->groups_open = false;
-    h->front_async = false; h->tail_async = false; h->front_open = false; h->fr_valid[0] = h->fr_valid[1] = false; h->tf_valid[0] = h->tf_valid[1] = false; h->bf_valid[0] = h->bf_valid[1] = false; h->al_read[0] = h->al_read[1] = false; h->fr_mid[0] = h->fr_mid[1] = false; h->front_set = 0; h->lean_main = false;
+    h->front_async = false; h->tail_async = false; h->front_open = false; h->fr_valid[0] = h->fr_valid[1] = false; h->tf_valid[0] = h->tf_valid[1] = false; h->bf_valid[0] = h->bf_valid[1] = false; h->al_read[0] = h->al_read[1] = false; h->fr_mid[0] = h->fr_mid[1] = false; h->front_set = 0; h->lean_main = false; h->early_front = false;
     for (int i = 0; i < 10; ++i) h->ev_fr[i] = nullptr;
     for (int i = 0; i < 7; ++i) { h->side[i] = nullptr; h->ev_join[i] = nullptr; }
     h->ki_istft = ki_istft; h->op = op;
@@ -511,6 +511,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             const char* mj = std::getenv("DS_CHAIN_MAIN_JOIN");
             h->lean_main = !(mj && mj[0] == '1');
             if (h->lean_main) h->sub[2]->use_dev_cnt = false;
+            const char* ne = std::getenv("DS_CHAIN_NO_EARLY");
+            h->early_front = !(ne && ne[0] == '1');
             // ... with McCDR as the per-bin program of the analysis kernel (the workgroup holds the utterance: MCRA stencil and band mean from
             // LDS); counters by value, so only where nothing is replayed as a graph.  DS_CHAIN_UNFUSED=1: the separate McCDR launch
             const char* unf2 = std::getenv("DS_CHAIN_UNFUSED");

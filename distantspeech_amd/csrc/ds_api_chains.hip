@@ -236,8 +236,7 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
         // blocking-filter branch, the notch / FIR outputs only by the front end itself (and by the copy of `aligned`, if the caller asked for
         // it).  When the branch joins at the tail (below) each front-end kernel waits for its own readers only, so that the notch and the
         // FIR bank of block t + 2 run next to the middle stages of block t and only the analysis waits for them
-        static const bool no_early = [] { const char* e = std::getenv("DS_CHAIN_NO_EARLY"); return e && e[0] == '1'; }();     // A/B switch
-        early = !no_early && two && h->lean_main && h->tail_async && h->ki_aic.launch && h->sub[5]->stream != h->stream && !h->al_read[set];
+        early = h->early_front && two && h->lean_main && h->tail_async && h->ki_aic.launch && h->sub[5]->stream != h->stream && !h->al_read[set];
         if (!early) {
             if (h->fr_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[(h->fr_mid[set] ? 4 : 2) + set], 0));
             if (h->bf_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[8 + set], 0));     // ... and its blocking-filter branch (lean_main)

@@ -95,6 +95,7 @@ struct ds_handle {
     // has enqueued.  ev_fr + 4: {middle of set 0 / 1 done, tail of set 0 / 1 done}; ev_fr + 8: {blocking-filter branch of set 0 / 1 done}
     // (with the tail on its own stream the branch joins there, not on the chain's stream: nothing but McSpp sits between two McSpp launches)
     bool front_async, tail_async, front_open, fr_valid[2], tf_valid[2], bf_valid[2], al_read[2], fr_mid[2];
+    bool early_front;           // ... and the notch / FIR bank of block t + 2 wait for their own readers only (DS_CHAIN_NO_EARLY=1: off, A/B runs)
     bool lean_main;             // pipelined chain: McSpp's counters by value (no counter-advance launch), the blocking-filter branch joins on the tail's stream
     int front_set;
     hipEvent_t ev_fr[10];

@@ -832,7 +832,13 @@ def test_subband_gsc_fused_tail_and_pipelined_stages_equal_separate_kernels(ds, 
     for name, env in (("separate", dict(DS_CHAIN_UNFUSED="1", DS_CHAIN_SERIAL_FRONT="1")),
                       ("fused_serial", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="1")),
                       ("fused_front", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", GPU_MAX_HW_QUEUES="4")),
+                      # the pipeline as first built: joins, counter advance and the carried-block copy on the chain's own stream
+                      ("fused_pipeline_main_join", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", GPU_MAX_HW_QUEUES="8", DS_CHAIN_MAIN_JOIN="1")),
+                      # lean chain stream, but the whole front end of block t + 2 behind the middle stages of block t
+                      ("fused_pipeline_no_early", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", GPU_MAX_HW_QUEUES="8", DS_CHAIN_NO_EARLY="1")),
                       ("fused_pipeline", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", GPU_MAX_HW_QUEUES="8"))):
+        for k in ("DS_CHAIN_MAIN_JOIN", "DS_CHAIN_NO_EARLY"):
+            monkeypatch.setenv(k, "0")
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         g = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], batch=B, bm_filter="rls" if rls else "lms")
@@ -852,7 +858,7 @@ def test_subband_gsc_fused_tail_and_pipelined_stages_equal_separate_kernels(ds, 
                      np.frombuffer(g2._eng.export_state(), dtype=np.float32).copy())
     y0, bm0, s0 = res["separate"][:3]
     assert np.all(np.isfinite(y0)) and np.abs(y0).max() > 0
-    for name in ("fused_serial", "fused_front", "fused_pipeline"):
+    for name in ("fused_serial", "fused_front", "fused_pipeline_main_join", "fused_pipeline_no_early", "fused_pipeline"):
         y1, bm1, s1, yd1, sd1 = res[name]
         assert np.array_equal(bm0, bm1)                                      # everything in front of the tail is the same launch sequence
         assert np.array_equal(y1, res["fused_serial"][0]) and np.array_equal(s1, res["fused_serial"][2])      # scheduling changes nothing
