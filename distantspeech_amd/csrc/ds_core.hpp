@@ -45,7 +45,13 @@ struct alignas(16) vec4 { float x, y, z, w; };
 #define DS_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
 #define DS_GRID_BLOCKS() ((int)gridDim.x)
 #define DS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// orders arithmetic the optimiser would otherwise hoist: the values come out of an (empty) volatile asm, and volatile asms keep their
+// program order — what is computed from a pinned value starts after everything that feeds an earlier pin.  No instruction emitted
+#define DS_PIN(a) asm volatile("" : "+v"(a))
+#define DS_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #else
+#define DS_PIN(a) ((void)0)
+#define DS_PIN2(a, b) ((void)0)
 #define DS_COMPILER_FENCE() ((void)0)
 #define DS_SCHED_FENCE() ((void)0)
 #define DS_SETPRIO(n) ((void)0)
@@ -454,6 +460,67 @@ template <int M> struct Chol {
             for (int k = i + 1; k < M; ++k) a = cfnmac(a, v[k], L(k, i));
             v[i] = cscale(a, inv[i]);
         }
+    }
+    // L -> L^-1 in place (lower triangular, real diagonal inv[]): column by column, entry (i, j) from row i of L to the right of column j
+    // (not overwritten yet) and the finished part of column j.  After this L(i, j) reads L^-1 and solve() must not be used; apply() and
+    // trace_with() take its place — one triangular inverse (M (M^2 - 1) / 6 complex multiply-adds) instead of a substitution pair per
+    // right-hand side, and nothing but the factor itself stays live between the right-hand sides
+    DS_HD void invert() {
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) {
+                cf a = cscale(L(i, j), inv[j]);
+#pragma unroll
+                for (int k = j + 1; k < i; ++k) a = cfma(a, L(i, k), L(k, j));
+                lo[off_index(j, i, M)] = cscale(a, -inv[i]);
+            }
+    }
+    // after invert(): v = A^-1 b = L^-H (L^-1 b)
+    DS_HD void apply(const cf* b, cf* v) const {
+        cf u[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            cf a = cscale(b[i], inv[i]);
+#pragma unroll
+            for (int j = 0; j < i; ++j) a = cfma(a, L(i, j), b[j]);
+            u[i] = a;
+        }
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            cf a = cscale(u[j], inv[j]);
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) a = cfma(a, cconj(L(i, j)), u[i]);
+            v[j] = a;
+        }
+    }
+    // after invert(): Re tr(A^-1 R) for a Hermitian-packed R = sum over the rows r_i of L^-1 of the quadratic forms r_i R r_i^H
+    DS_HD float trace_with(const float* d, const float* o) const {
+        float tr = 0.0f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            // row by row (the products of all rows at once are ~100 live registers): row i's entries go through a pin behind row i - 1's sum
+            if (i >= 2) {
+                DS_PIN(tr);
+#pragma unroll
+                for (int j = 0; j < i; ++j) { cf& l = const_cast<cf&>(lo[off_index(j, i, M)]); DS_PIN2(l.x, l.y); }
+            }
+            float q = inv[i] * inv[i] * d[i], c2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                const cf rj = L(i, j);
+                q = fma_(cabs2(rj), d[j], q);
+                { const int w = off_index(j, i, M); c2 = fma_(rj.x * inv[i], o[2 * w], fma_(-(rj.y * inv[i]), o[2 * w + 1], c2)); }   // Re(r_ij R_ji... ) with r_ii real
+#pragma unroll
+                for (int k = j + 1; k < i; ++k) {
+                    const cf c = cmulc(rj, L(i, k));                       // r_ij conj(r_ik)
+                    const int w = off_index(j, k, M);
+                    c2 = fma_(c.x, o[2 * w], fma_(-c.y, o[2 * w + 1], c2));   // Re(r_ij R_jk conj(r_ik))
+                }
+            }
+            tr += fma_(2.0f, c2, q);
+        }
+        return tr;
     }
 };
 

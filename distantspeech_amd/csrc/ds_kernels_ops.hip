@@ -153,7 +153,7 @@ template <int OP, int M> __global__ void __launch_bounds__(256) ds_binop_kernel(
     }
     if (b >= p.B || k >= p.K) return;
     OpCtx c = make_op_ctx(p, i0);
-    if constexpr (OP == OP_MCSPP_STEADY && M >= 5) {                        // parking space for Phi_vv (op_mcspp_lean): 235 registers instead of 256
+    if constexpr (OP == OP_MCSPP_STEADY && M >= 5) {                        // parking space for Phi_vv (op_mcspp_lean): two waves per SIMD at 6 microphones
         __shared__ float park[(M * M + 1) * 256];
         c.spill = park + threadIdx.x; c.spill_stride = 256;
     }

@@ -941,8 +941,9 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
 }
 
 // McSpp without the notebook-MVDR / matrix outputs (OP_MCSPP_LEAN, the SubbandGSC chain): the same estimation_core, but nothing here
-// needs inv(Phi_vv + dv I) as a matrix — tr(A^-1 Phi_yy), A^-1 y and the PMWF column are Cholesky solves on the Hermitian-packed state,
-// which is less work and fewer live registers than forming the explicit inverse (the kernel still sits at one wave per SIMD at M = 6).
+// needs inv(Phi_vv + dv I) as a matrix — tr(A^-1 Phi_yy), A^-1 y and the PMWF column come from the inverse of the Cholesky factor of the
+// Hermitian-packed state (Chol::invert / trace_with / apply), which is less work and fewer live registers than forming the explicit
+// inverse, and less than a pair of substitutions per column of Phi_yy (the first form of this operator: 233 registers, 211 now at M = 6).
 template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
     const int o0 = p.N;
@@ -971,24 +972,13 @@ template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, i
             for (int f = 0; f < 2 * NO; ++f) vo[f] = yo[f];
             q = 0.99f;
         }
-        // estimation_core :201-242 with A = Phi_vv + dv I = L L^H
+        // estimation_core :201-242 with A = Phi_vv + dv I = L L^H, through L^-1 (Chol::invert): Re tr(A^-1 Phi_yy) is the sum of the quadratic
+        // forms of Phi_yy in the rows of L^-1 and A^-1 y two triangular products — one triangular inverse instead of a substitution pair per
+        // column of Phi_yy, and no right-hand side or solution vector live next to the factor (the six solves held the kernel at two waves
+        // per SIMD and were half of its arithmetic)
         Chol<M> ch;
-        auto trace_with_pyy = [&]() {                                              // Re tr(A^-1 Phi_yy) = sum_j Re (A^-1 Phi_yy[:, j])_j
-            float tr = 0.0f;
-#pragma unroll
-            for (int j = 0; j < M; ++j) {
-                cf col[M], sol[M];
-#pragma unroll
-                for (int i = 0; i < M; ++i) col[i] = herm_get<M>(yd, yo, i, j);
-                ch.solve(col, sol);
-                tr += sol[j].x;
-                DS_SCHED_FENCE();
-            }
-            return tr;
-        };
         ch.factor(vd, vo, dv);
-        // Phi_vv is not needed again before the noise update at the end of the frame: parked (LDS) while the solves run, which is what
-        // lets two waves share a SIMD at 6 microphones
+        // Phi_vv is not needed again before the noise update at the end of the frame: parked (LDS) while the rest of the frame runs
         if (p.spill) {
 #pragma unroll
             for (int f = 0; f < M; ++f) p.spill[f * p.spill_stride] = vd[f];
@@ -996,7 +986,10 @@ template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, i
             for (int f = 0; f < 2 * NO; ++f) p.spill[(M + f) * p.spill_stride] = vo[f];
             DS_COMPILER_FENCE();
         }
-        float tr = trace_with_pyy();
+        ch.invert();
+        DS_SCHED_FENCE();
+        float tr = ch.trace_with(yd, yo);
+        DS_SCHED_FENCE();
         // :219-228: where xi < 0 the reference falls back to A = Phi_yy (+ dv I in the first five frames).  From frame 5 on that makes
         // A^-1 Phi_yy the identity: tr - M and y^H A^-1 Phi_yy A^-1 y - y^H A^-1 y are zero up to rounding (1e-14 in the reference's
         // doubles), so both clamp to their floor 1e-6 (:230,236) — taken here as exactly that, without a second factorisation and trace
@@ -1007,14 +1000,15 @@ template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, i
         if constexpr (!STEADY) {
             if (fell && (!ident || p.out1)) {
                 ch.factor(yd, yo, frm < 5 ? dv : 0.0f);
-                if (!ident) tr = trace_with_pyy();
+                ch.invert();
+                if (!ident) tr = ch.trace_with(yd, yo);
             }
         }
         xi = ident ? 1e-6f : fminf_(fmaxf_(tr - (float)M, 1e-6f), 1e8f);           // :230
         gam = 1e-6f;
         if (!ident) {
             cf v[M];
-            ch.solve(Z, v);                                                        // v = A^-1 y
+            ch.apply(Z, v);                                                        // v = A^-1 y
             float yv = 0.0f, vPv = 0.0f;
 #pragma unroll
             for (int i = 0; i < M; ++i) {
@@ -1042,7 +1036,7 @@ template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, i
                 cf col[M], w[M];
 #pragma unroll
                 for (int i = 0; i < M; ++i) col[i] = csub(herm_get<M>(yd, yo, i, 0), herm_get<M>(vd, vo, i, 0));
-                ch.solve(col, w);
+                ch.apply(col, w);
 #pragma unroll
                 for (int i = 0; i < M; ++i) { p.out1[2 * (ob * M + i)] = w[i].x * wsc; p.out1[2 * (ob * M + i) + 1] = w[i].y * wsc; }
             }
