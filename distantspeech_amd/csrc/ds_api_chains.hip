@@ -206,8 +206,33 @@ static int chain_istft(ds_handle* h, ds_handle* t, const float* Y, int T, float*
 }
 
 // x_dev: [B][M][n] with element strides (x_bstride, x_cstride); y_dev [B] rows of n with stride y_bstride; the optional outputs dense
+static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
+                        float* fix_dev, float* bm_dev, float* p_dev, float* al_dev);
+
+// A long call (BASELINE config 5's 10 s chunk = 625 blocks) runs as pieces of at most DS_CHAIN2_PIECE blocks: the stages' intermediate
+// spectra are sized by a piece, not by the call (1.6 GB instead of 16 GB at 2048 utterances), the second buffer set exists, and the
+// stage pipeline runs across the pieces — 62 blocks per piece was the best of {4 ... 125} (24.3 M frames/s against 22.1 M as one piece).
+// A call of T blocks is T one-block calls by definition, so the pieces change nothing in the samples or the state.
+constexpr int DS_CHAIN2_PIECE = 62;
 int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
-                      float* fix_dev, float* bm_dev, float* p_dev, float* al_dev) {
+               float* fix_dev, float* bm_dev, float* p_dev, float* al_dev) {
+    const int hop = h->cfg.hop, T = n / hop;
+    // (the optional outputs are dense arrays whose rows are as long as the call: a call that asks for them runs as one piece)
+    if (T <= DS_CHAIN2_PIECE + DS_CHAIN2_PIECE / 2 || !h->front_async || fix_dev || bm_dev || p_dev || al_dev)
+        return chain2_block(h, x_dev, x_bstride, x_cstride, n, y_dev, y_bstride, fix_dev, bm_dev, p_dev, al_dev);
+    const int pieces = (T + DS_CHAIN2_PIECE - 1) / DS_CHAIN2_PIECE;
+    for (int i = 0, t0 = 0; i < pieces; ++i) {
+        const int tn = T / pieces + (i < T % pieces ? 1 : 0);                 // the longer pieces first: the buffers are sized once
+        const int rc = chain2_block(h, x_dev + (size_t)t0 * hop, x_bstride, x_cstride, tn * hop, y_dev + (size_t)t0 * hop, y_bstride,
+                                    nullptr, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        t0 += tn;
+    }
+    return DS_OK;
+}
+
+static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
+                        float* fix_dev, float* bm_dev, float* p_dev, float* al_dev) {
     DS_HIP(h, hipSetDevice(h->device));                      // not set_device(): the tail of the previous block stays on its own stream
     int rc = DS_OK;
     ds_handle* fe = h->sub[0];

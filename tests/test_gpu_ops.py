@@ -871,6 +871,40 @@ def test_subband_gsc_fused_tail_and_pipelined_stages_equal_separate_kernels(ds, 
         assert diff.size <= B * FL and (diff.size == 0 or np.max(np.abs(s0[diff] - s1[diff])) < 2e-6)
 
 
+@pytest.mark.parametrize("rls", [True, False])
+def test_subband_gsc_long_call_runs_as_pieces(ds, rls):
+    """A device call of more than 93 blocks (BASELINE config 5's 10 s chunk is 625) is cut into pieces of at most 62 blocks inside the
+    library (chain2_run: intermediate buffers sized by a piece, the stage pipeline across the pieces).  A call of T blocks is T one-block
+    calls by definition: one 130-block call, the same stream as 130 one-block calls and as calls of 50 + 80 blocks (one piece each) give
+    the same samples and the same exported state bit for bit."""
+    from oracle import ds_oracle as O
+    from _cases import oracle_mic, DeviceBuffers
+    from distantspeech_amd import _lib as L
+    M, FL, B, T = 6, 256, 2, 130
+    omic = oracle_mic(M, 2 * FL)
+    mic = ds.MicArray(arrayType="circular", r=omic.r, M=M, n_fft=2 * FL)
+    x = np.stack([O.synth_utterance(90 + u, T * FL, omic) for u in range(B)]).astype(np.float32)
+    n = T * FL
+    res = []
+    for plan in ([T], [1] * T, [50, 80]):
+        dv = DeviceBuffers()
+        xd, yd = dv.upload(x), dv.zeros(B * n * 4)
+        g = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], batch=B, bm_filter="rls" if rls else "lms")
+        if len(plan) == T:
+            g._eng.process_device_seq(xd, L.LAYOUT_CHANNELS_SAMPLES, M * n, n, FL, FL, T, yd, n, FL, graph=0)
+        else:
+            t0 = 0
+            for tn in plan:
+                g._eng.process_device(xd + 4 * t0 * FL, L.LAYOUT_CHANNELS_SAMPLES, M * n, tn * FL, yd + 4 * t0 * FL, n, x_chan_stride=n)
+                t0 += tn
+        y = dv.download(yd, (B, n))
+        res.append((y, np.frombuffer(g._eng.export_state(), dtype=np.float32).copy()))
+        dv.free()
+    assert np.all(np.isfinite(res[0][0])) and np.abs(res[0][0]).max() > 0
+    for y, st in res[1:]:
+        assert np.array_equal(y, res[0][0]) and np.array_equal(st, res[0][1])
+
+
 @pytest.mark.parametrize("algo", ["ADAPTIVE", "GSC"])
 def test_frame_kernel_sequences_graphs_and_utterance_groups(ds, algo):
     """ds_process_device_seq on the fused frame kernels (what bench.py times): a sequence of calls launched plainly, replayed as a hipGraph,
