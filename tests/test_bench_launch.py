@@ -31,7 +31,7 @@ def test_self_launch_two_ranks(tmp_path):
     frames = 2 * 1024 * 20 * R
     assert abs(out["value"] - frames / (out["region_ms"] * 1e-3)) / out["value"] < 1e-3
     assert abs(out["ms_per_step"] - out["region_ms"] / (20 * R)) < 1e-3
-    assert set(out["other_configs"]) == {"cfg3", "cfg4", "cfg5", "cfg5_10s_chunks"} and all(v["n_gpus"] == 2 for v in out["other_configs"].values())
+    assert set(out["other_configs"]) == {"cfg3", "cfg4", "cfg5", "cfg2_10s_chunks", "cfg3_10s_chunks", "cfg4_10s_chunks", "cfg5_10s_chunks"} and all(v["n_gpus"] == 2 for v in out["other_configs"].values())
     assert out["roofline"]["bound"] == "hbm" and out["roofline_hbm"]["batch_per_gpu"] == 16384
     # both ranks ran the same step sequence (warm-up + graph-build round + probe + R rounds for the headline)
     per_rank = [open("%s.%d" % (log, k)).read().split() for k in range(2)]
