@@ -349,15 +349,41 @@ def test_wav_files_end_to_end(ds, tmp_path):
         wavfile.write(str(d / ("ch%d.wav" % m)), 16000, x16[m])
     x, sr = load_wav(str(d))
     assert sr == 16000 and x.shape == x16.shape
-    order = [int(os.path.basename(n)[2]) for n in __import__("distantspeech_amd.utils", fromlist=["find_files"]).find_files(str(d), ".wav")]
+    names = __import__("distantspeech_amd.utils", fromlist=["find_files"]).find_files(str(d), ".wav")
+    order = [int(os.path.basename(n)[2]) for n in names]
     assert np.array_equal(x, x16[order].astype(np.float32) / 32768.0)          # librosa-style scaling, os.listdir order
-    if order == [0, 1, 2, 3]:
+    # the reference takes the channels in os.listdir order (utils.py:83-110), which is the file system's business: put microphone j into
+    # the j-th file of that order (rewriting a file does not move its directory entry) so that the drivers below see microphones 0..3
+    for j, n in enumerate(names):
+        wavfile.write(n, 16000, x16[j])
+    assert np.array_equal(load_wav(str(d))[0], x16.astype(np.float32) / 32768.0)
+    if True:
         out = tmp_path / "out.wav"
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         subprocess.check_call([sys.executable, os.path.join(root, "examples", "run_GSC.py"), "--input", str(d), "--save", str(out)])
         _, y16 = wavfile.read(str(out))
         ref16 = (g["y"] * 32767).astype(np.int16)
         assert np.max(np.abs(y16.astype(np.int32) - ref16.astype(np.int32))) <= 2          # within int16 quantisation of 1e-4
+        # the same recording through the other two file-level drivers (BASELINE configs 1 and 2): run_MVDRbeamformer.py against the
+        # reference's adaptivebeamfomer output (G4), run_fixedbeamformer.py against the reference's FixedBeamformer output (G2b, which
+        # holds the first 25 600 samples of the recording)
+        out = tmp_path / "out_mvdr.wav"
+        subprocess.check_call([sys.executable, os.path.join(root, "examples", "run_MVDRbeamformer.py"), "--input", str(d), "--save", str(out)])
+        _, y16 = wavfile.read(str(out))
+        g4 = load("g4_adaptive_rec1")
+        assert np.array_equal(g4["x"], x16)
+        ref16 = (g4["y"] * 32767).astype(np.int16)
+        assert np.max(np.abs(y16.astype(np.int32) - ref16.astype(np.int32))) <= 2
+        for wt in ("DS", "SD"):
+            g2 = load("g2b_fixed_" + wt)
+            n2 = g2["x"].shape[1]
+            assert np.array_equal(g2["x"], x16[:, :n2])
+            out = tmp_path / ("out_fixed_%s.wav" % wt)
+            subprocess.check_call([sys.executable, os.path.join(root, "examples", "run_fixedbeamformer.py"), "--input", str(d), "--save", str(out),
+                                   "--weights", wt])
+            _, y16 = wavfile.read(str(out))
+            ref16 = (g2["y"] * 32767).astype(np.int16)
+            assert np.max(np.abs(y16[:n2].astype(np.int32) - ref16.astype(np.int32))) <= 2
 
 
 def test_plain_c_caller(tmp_path):
