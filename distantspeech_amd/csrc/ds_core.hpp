@@ -294,29 +294,45 @@ template <int PAD> DS_HD int padi(int i) {
 // in/out: [MCH][NCP].  FROM = 1: read windowed real samples packed as (x[2n], x[2n+1]) from xbuf.  FROM = 2 (inverse, one channel): form
 // point n of the packed spectrum from the output bins sh.Y[n], sh.Y[NC - n] on the fly (E + j O of the real-transform merge, with
 // the Nyquist bin taken as zero: see Engine::run).
+// offset of entry i + d from entry i in a padded buffer, for the displacements a stage uses: a multiple of 16 moves the padding term by a
+// constant; a displacement that stays inside i's own run of 16 leaves it alone (the caller guarantees which case holds)
+template <int PAD> DS_HD constexpr int pad_step16(int d) { return PAD == 1 ? d + (d >> 4) : PAD == 2 ? d + ((d >> 4) << 2) : d; }
+
 template <int NFFT, int M, int R, int SIGN, int FROM, int PIN, int POUT, class ShT>
 DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, int old_half, int MCH) {
     constexpr bool FROM_X = FROM == 1;
     constexpr int NC = NFFT / 2, NB = NC / R, HOP = NFFT / 2, NCP = ShT::NCP;
+    static_assert(NB % 16 == 0, "the inputs of a butterfly are NB apart: a constant step in a padded buffer");
+    constexpr int RSTEP = pad_step16<PIN>(NB);
     for (int idx = tid; idx < MCH * NB; idx += nt) {
-        const int ch = idx / NB, j = idx - ch * NB;
+        // (unsigned: the split into channel and butterfly is a shift and a mask, and j's range is known to the compiler)
+        const int ch = (int)((unsigned)idx / (unsigned)NB), j = (int)((unsigned)idx % (unsigned)NB);
         const int k = j & (Ns - 1);
         cf v[R];
+        // the R inputs of butterfly j sit at n = j + r NB: one address, constant steps
+        if constexpr (FROM_X) {
+            static_assert(R == 4 || R == 2, "radix");
+            const int s0 = 2 * j;                                               // s = s0 + r * 2 NB; 2 NB = HOP / 2 (R = 4) or HOP (R = 2)
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int n = j + r * NB;
-            if constexpr (FROM_X) {
-                const int s = 2 * n;
-                const int pos = s < HOP ? old_half * HOP + s : (old_half ^ 1) * HOP + (s - HOP);
+            for (int r = 0; r < R; ++r) {
+                const int s = s0 + r * 2 * NB;
+                const bool first = r * 2 * NB + 2 * NB <= HOP;                  // compile-time: the whole range of s for this r is below HOP
+                const int pos = first ? old_half * HOP + s : (old_half ^ 1) * HOP + (s - HOP);
                 v[r] = mk(sh.tb.win[s] * sh.xbuf[ch][pos], sh.tb.win[s + 1] * sh.xbuf[ch][pos + 1]);
-            } else if constexpr (FROM == 2) {
+            }
+        } else if constexpr (FROM == 2) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int n = j + r * NB;
                 const cf A = sh.Y[n], Bc = (n == 0 && NC == 256) ? mk(0.0f, 0.0f) : cconj(sh.Y[NC - n]);   // NC == 256: Nyquist bin added later
                 const cf E = cscale(cadd(A, Bc), 0.5f);
                 const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tb.tw[n]));
                 v[r] = mk(E.x - O.y, E.y + O.x);                        // E + j O
-            } else {
-                v[r] = in[ch * NCP + padi<PIN>(n)];
             }
+        } else {
+            const cf* rp = in + ch * NCP + padi<PIN>(j);
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = rp[r * RSTEP];
         }
         if (Ns > 1) {
             const vec4 wv = sh.tb.stw[Ns + k];                  // consecutive lanes -> consecutive k: conflict-free
@@ -332,9 +348,20 @@ DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, in
             }
         }
         butterfly<R, SIGN>(v);
+        // the R outputs sit at j0 + r Ns, j0 = (j - k) R + k: Ns a multiple of 16 is a constant step in a padded buffer; for Ns R <= 16 the
+        // R outputs share j0's run of 16 (j0 - k is a multiple of Ns R, which divides 16), so the padding term does not move
         const int j0 = (j - k) * R + k;
+        cf* wp = out + ch * NCP + padi<POUT>(j0);
+        if (POUT == 0 || (Ns & 15) == 0) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) out[ch * NCP + padi<POUT>(j0 + r * Ns)] = v[r];
+            for (int r = 0; r < R; ++r) wp[pad_step16<POUT>(r * Ns)] = v[r];
+        } else if (Ns * R <= 16) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) wp[r * Ns] = v[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) out[ch * NCP + padi<POUT>(j0 + r * Ns)] = v[r];
+        }
     }
 }
 
