@@ -47,9 +47,11 @@ struct alignas(16) vec4 { float x, y, z, w; };
 #define DS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // orders arithmetic the optimiser would otherwise hoist: the values come out of an (empty) volatile asm, and volatile asms keep their
 // program order — what is computed from a pinned value starts after everything that feeds an earlier pin.  No instruction emitted
+#define DS_ASSUME(c) __builtin_assume(c)
 #define DS_PIN(a) asm volatile("" : "+v"(a))
 #define DS_PIN2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 #else
+#define DS_ASSUME(c) do { if (!(c)) __builtin_trap(); } while (0)      // the CPU emulator checks what the device build assumes
 #define DS_PIN(a) ((void)0)
 #define DS_PIN2(a, b) ((void)0)
 #define DS_COMPILER_FENCE() ((void)0)
@@ -304,6 +306,7 @@ DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, in
     constexpr int NC = NFFT / 2, NB = NC / R, HOP = NFFT / 2, NCP = ShT::NCP;
     static_assert(NB % 16 == 0, "the inputs of a butterfly are NB apart: a constant step in a padded buffer");
     constexpr int RSTEP = pad_step16<PIN>(NB);
+    DS_ASSUME(tid >= 0 && tid < nt);                                     // a one-trip loop where MCH * NB <= nt: no loop-carried addresses
     for (int idx = tid; idx < MCH * NB; idx += nt) {
         // (unsigned: the split into channel and butterfly is a shift and a mask, and j's range is known to the compiler)
         const int ch = (int)((unsigned)idx / (unsigned)NB), j = (int)((unsigned)idx % (unsigned)NB);
