@@ -69,23 +69,78 @@ DS_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DS_HD cf mk(float a, float b) { cf r; r.x = a; r.y = b; return r; }
 DS_HD cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
 DS_HD cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
-DS_HD cf cmul(cf a, cf b) { return mk(fma_(a.x, b.x, -(a.y * b.y)), fma_(a.x, b.y, a.y * b.x)); }
-DS_HD cf cmulc(cf a, cf b) { return mk(fma_(a.x, b.x, a.y * b.y), fma_(a.y, b.x, -(a.x * b.y))); }   // a * conj(b)
+// The complex products, as the scalar expressions that DEFINE their rounding (every product and every fused multiply-add below is one
+// rounding, in this nesting) ...
+DS_HD cf cmul_s(cf a, cf b) { return mk(fma_(a.x, b.x, -(a.y * b.y)), fma_(a.x, b.y, a.y * b.x)); }
+DS_HD cf cmulc_s(cf a, cf b) { return mk(fma_(a.x, b.x, a.y * b.y), fma_(a.y, b.x, -(a.x * b.y))); }   // a * conj(b)
+DS_HD cf cfma_s(cf acc, cf a, cf b) {        // acc + a * b
+    return mk(fma_(a.x, b.x, fma_(-a.y, b.y, acc.x)), fma_(a.x, b.y, fma_(a.y, b.x, acc.y)));
+}
+DS_HD cf cfmac_s(cf acc, cf a, cf b) {       // acc + a * conj(b)
+    return mk(fma_(a.x, b.x, fma_(a.y, b.y, acc.x)), fma_(a.y, b.x, fma_(-a.x, b.y, acc.y)));
+}
+DS_HD cf cfnma_s(cf acc, cf a, cf b) {       // acc - a * b
+    return mk(fma_(-a.x, b.x, fma_(a.y, b.y, acc.x)), fma_(-a.x, b.y, fma_(-a.y, b.x, acc.y)));
+}
+DS_HD cf cfnmac_s(cf acc, cf a, cf b) {      // acc - a * conj(b)
+    return mk(fma_(-a.x, b.x, fma_(-a.y, b.y, acc.x)), fma_(-a.y, b.x, fma_(a.x, b.y, acc.y)));
+}
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_SCALAR_COMPLEX)
+// ... and on the device as TWO packed instructions each (v_pk_mul_f32 / v_pk_fma_f32): the half selects (op_sel / op_sel_hi: which half of
+// a source feeds the low / the high result) and the per-half negations (neg_lo / neg_hi) do the swaps and sign changes of a complex product
+// for free.  The compiler's own vectoriser packs the scalar expressions too, but pays a v_mov / v_xor for every swap or one-sided negation
+// (38 instructions where these forms take 26 in a mix of six a*conj(b) and six multiply-adds).  Same products, same nesting, same single
+// roundings as the scalar forms: bit-identical (tests/test_gpu_ops.py::test_packed_complex_helpers_equal_their_scalar_definitions).
+typedef float cf2_t __attribute__((ext_vector_type(2)));
+DS_HD cf2_t cf_pk(cf a) { return __builtin_bit_cast(cf2_t, a); }
+DS_HD cf pk_cf(cf2_t a) { return __builtin_bit_cast(cf, a); }
+DS_HD cf cmul(cf a, cf b) {
+    cf2_t t, r;                                  // t = (-(a.y b.y), a.y b.x);  r = (a.x b.x + t.lo, a.x b.y + t.hi)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(cf_pk(a)), "v"(cf_pk(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(t));
+    return pk_cf(r);
+}
+DS_HD cf cmulc(cf a, cf b) {
+    cf2_t t, r;                                  // t = (a.y b.y, -(a.x b.y));  r = (a.x b.x + t.lo, a.y b.x + t.hi)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(cf_pk(a)), "v"(cf_pk(b)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(t));
+    return pk_cf(r);
+}
+DS_HD cf cfma(cf acc, cf a, cf b) {
+    cf2_t t, r;                                  // t = (-a.y b.y + acc.x, a.y b.x + acc.y);  r = (a.x b.x + t.lo, a.x b.y + t.hi)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(t) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(cf_pk(acc)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(t));
+    return pk_cf(r);
+}
+DS_HD cf cfmac(cf acc, cf a, cf b) {
+    cf2_t t, r;                                  // t = (a.y b.y + acc.x, -a.x b.y + acc.y);  r = (a.x b.x + t.lo, a.y b.x + t.hi)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(t) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(cf_pk(acc)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(t));
+    return pk_cf(r);
+}
+DS_HD cf cfnma(cf acc, cf a, cf b) {
+    cf2_t t, r;                                  // t = (a.y b.y + acc.x, -a.y b.x + acc.y);  r = (-a.x b.x + t.lo, -a.x b.y + t.hi)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(t) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(cf_pk(acc)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(t));
+    return pk_cf(r);
+}
+DS_HD cf cfnmac(cf acc, cf a, cf b) {
+    cf2_t t, r;                                  // t = (-a.y b.y + acc.x, a.x b.y + acc.y);  r = (-a.x b.x + t.lo, -a.y b.x + t.hi)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(t) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(cf_pk(acc)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(t));
+    return pk_cf(r);
+}
+#else
+DS_HD cf cmul(cf a, cf b) { return cmul_s(a, b); }
+DS_HD cf cmulc(cf a, cf b) { return cmulc_s(a, b); }
+DS_HD cf cfma(cf acc, cf a, cf b) { return cfma_s(acc, a, b); }
+DS_HD cf cfmac(cf acc, cf a, cf b) { return cfmac_s(acc, a, b); }
+DS_HD cf cfnma(cf acc, cf a, cf b) { return cfnma_s(acc, a, b); }
+DS_HD cf cfnmac(cf acc, cf a, cf b) { return cfnmac_s(acc, a, b); }
+#endif
 DS_HD cf cconj(cf a) { return mk(a.x, -a.y); }
 DS_HD cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
 DS_HD float cabs2(cf a) { return fma_(a.x, a.x, a.y * a.y); }
-DS_HD cf cfma(cf acc, cf a, cf b) {        // acc + a * b
-    return mk(fma_(a.x, b.x, fma_(-a.y, b.y, acc.x)), fma_(a.x, b.y, fma_(a.y, b.x, acc.y)));
-}
-DS_HD cf cfmac(cf acc, cf a, cf b) {       // acc + a * conj(b)
-    return mk(fma_(a.x, b.x, fma_(a.y, b.y, acc.x)), fma_(a.y, b.x, fma_(-a.x, b.y, acc.y)));
-}
-DS_HD cf cfnma(cf acc, cf a, cf b) {       // acc - a * b
-    return mk(fma_(-a.x, b.x, fma_(a.y, b.y, acc.x)), fma_(-a.x, b.y, fma_(-a.y, b.x, acc.y)));
-}
-DS_HD cf cfnmac(cf acc, cf a, cf b) {      // acc - a * conj(b)
-    return mk(fma_(-a.x, b.x, fma_(-a.y, b.y, acc.x)), fma_(-a.y, b.x, fma_(a.x, b.y, acc.y)));
-}
 DS_HD cf cdiv(cf a, cf b) {
     const float d = 1.0f / cabs2(b);
     const cf n = cmulc(a, b);

@@ -871,6 +871,21 @@ def test_subband_gsc_fused_tail_and_pipelined_stages_equal_separate_kernels(ds, 
         assert diff.size <= B * FL and (diff.size == 0 or np.max(np.abs(s0[diff] - s1[diff])) < 2e-6)
 
 
+def test_packed_complex_helpers_equal_their_scalar_definitions(tmp_path):
+    """ds_core.hpp's complex products run on the device as two packed instructions each (v_pk_mul_f32 / v_pk_fma_f32 with half selects and
+    per-half negations, inline asm); the scalar expressions beside them define the rounding.  tests/hip/complex_helpers_check.hip evaluates
+    both on a million random operand triples and on signed zeros, denormals, huge / tiny magnitudes and infinities: bit for bit the same."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "complex_helpers_check")
+    subprocess.check_call([hipcc, "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", "-I", os.path.join(root, "distantspeech_amd", "csrc"),
+                           "-I", os.path.join(root, "include"), os.path.join(root, "tests", "hip", "complex_helpers_check.hip"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("rls", [True, False])
 def test_subband_gsc_long_call_runs_as_pieces(ds, rls):
     """A device call of more than 93 blocks (BASELINE config 5's 10 s chunk is 625) is cut into pieces of at most 62 blocks inside the
