@@ -326,12 +326,55 @@ DS_HD vec4 load_state(const vec4* src) {
 // ---------------------------------------------------------------------------------------------
 // FFT stages (Stockham autosort, radix 4 / radix 2), all channels of the block at once
 // ---------------------------------------------------------------------------------------------
+// a + j d and a - j d: the quarter turn is a half swap with one negated half — one packed add each on the device (the compiler forms
+// both full sums and then picks halves with v_mov); the same additions either way
+template <int SIGN> DS_HD cf cadd_jd(cf a, cf d) {        // a + SIGN * j * d
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_SCALAR_COMPLEX)
+    cf2_t r;
+    if constexpr (SIGN > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(d)));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(d)));
+    return pk_cf(r);
+#else
+    return SIGN > 0 ? mk(a.x - d.y, a.y + d.x) : mk(a.x + d.y, a.y - d.x);
+#endif
+}
+
+// a + conj(b), a - conj(b), d / (2j): the merge / split of the packed real transform; one packed instruction each on the device
+DS_HD cf cadd_c(cf a, cf b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_SCALAR_COMPLEX)
+    cf2_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(b)));
+    return pk_cf(r);
+#else
+    return mk(a.x + b.x, a.y + (-b.y));
+#endif
+}
+DS_HD cf csub_c(cf a, cf b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_SCALAR_COMPLEX)
+    cf2_t r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(b)));
+    return pk_cf(r);
+#else
+    return mk(a.x - b.x, a.y - (-b.y));
+#endif
+}
+DS_HD cf cdiv_2j(cf d) {                         // (0.5 d.y, -0.5 d.x)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_SCALAR_COMPLEX)
+    cf2_t r;
+    const cf2_t h = {0.5f, -0.5f};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(cf_pk(d)), "v"(h));
+    return pk_cf(r);
+#else
+    return mk(0.5f * d.y, -0.5f * d.x);
+#endif
+}
+
 template <int R, int SIGN> DS_HD void butterfly(cf* v) {
     if constexpr (R == 4) {
         cf t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]);
         cf d = csub(v[1], v[3]);
-        cf t3 = SIGN < 0 ? mk(d.y, -d.x) : mk(-d.y, d.x);   // (-/+ j) * d
-        v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
+        // t3 = (-/+ j) d;  v1 = t1 + t3, v3 = t1 - t3
+        v[0] = cadd(t0, t2); v[1] = cadd_jd<(SIGN < 0 ? -1 : +1)>(t1, d); v[2] = csub(t0, t2); v[3] = cadd_jd<(SIGN < 0 ? +1 : -1)>(t1, d);
     } else {
         cf a = v[0], b = v[1];
         v[0] = cadd(a, b); v[1] = csub(a, b);
@@ -382,10 +425,18 @@ DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, in
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int n = j + r * NB;
-                const cf A = sh.Y[n], Bc = (n == 0 && NC == 256) ? mk(0.0f, 0.0f) : cconj(sh.Y[NC - n]);   // NC == 256: Nyquist bin added later
-                const cf E = cscale(cadd(A, Bc), 0.5f);
-                const cf O = cmul(cscale(csub(A, Bc), 0.5f), cconj(sh.tb.tw[n]));
-                v[r] = mk(E.x - O.y, E.y + O.x);                        // E + j O
+                const cf A = sh.Y[n];
+                cf S, Dm;                                               // A + conj(B), A - conj(B), B = Y[NC - n]
+                if (NC == 256 && r == 0) {                              // NC == 256: the Nyquist bin (n = 0's partner) is added later: B = 0 there
+                    const cf Bc = n == 0 ? mk(0.0f, 0.0f) : cconj(sh.Y[NC - n]);
+                    S = cadd(A, Bc); Dm = csub(A, Bc);
+                } else {
+                    const cf B = sh.Y[NC - n];
+                    S = cadd_c(A, B); Dm = csub_c(A, B);
+                }
+                const cf E = cscale(S, 0.5f);
+                const cf O = cmul(cscale(Dm, 0.5f), cconj(sh.tb.tw[n]));
+                v[r] = cadd_jd<+1>(E, O);                               // E + j O
             }
         } else {
             const cf* rp = in + ch * NCP + padi<PIN>(j);
@@ -1173,10 +1224,9 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                         const cf* Yt = reinterpret_cast<const cf*>(p.aic_e) + (((long long)b * M + c) * p.T + t) * K;
                         cf A = Yt[k], B = Yt[NC - k];
                         if (k == 0) { A.y = 0.0f; B.y = 0.0f; }          // irfft ignores Im Y[0], Im Y[N/2]
-                        const cf Bc = cconj(B);
-                        const cf E = cscale(cadd(A, Bc), 0.5f);
-                        const cf O = cmul(cscale(csub(A, Bc), 0.5f), w);
-                        fa[c * Sh::NCP + k] = mk(E.x - O.y, E.y + O.x);
+                        const cf E = cscale(cadd_c(A, B), 0.5f);
+                        const cf O = cmul(cscale(csub_c(A, B), 0.5f), w);
+                        fa[c * Sh::NCP + k] = cadd_jd<+1>(E, O);
                     }
                 });
                 ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, +1, false, 0, 1>(tid, NT, sh, fa, fb, 1, 0, M); });
@@ -1241,10 +1291,10 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 const cf w = sh.tb.tw[k];
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const cf A = F[m * Sh::NCP + k], Bc = cconj(F[m * Sh::NCP + k2]);
-                    const cf E = cscale(cadd(A, Bc), 0.5f);
-                    const cf D = csub(A, Bc);
-                    const cf O = mk(0.5f * D.y, -0.5f * D.x);          // D / (2j)
+                    const cf A = F[m * Sh::NCP + k], B = F[m * Sh::NCP + k2];
+                    const cf E = cscale(cadd_c(A, B), 0.5f);
+                    const cf D = csub_c(A, B);
+                    const cf O = cdiv_2j(D);          // D / (2j)
                     r.Z[m] = cfma(E, w, O);
                 }
                 if (k == 0) {
@@ -1457,10 +1507,10 @@ template <int NFFT, int M, bool CDR = false> struct StftEngine {
                 cf* dst = Yout + ((long long)t * K + k) * M;
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const cf A = F[m * Sh::NCP + k], Bc = cconj(F[m * Sh::NCP + k2]);
-                    const cf E = cscale(cadd(A, Bc), 0.5f);
-                    const cf D = csub(A, Bc);
-                    const cf O = mk(0.5f * D.y, -0.5f * D.x);
+                    const cf A = F[m * Sh::NCP + k], B = F[m * Sh::NCP + k2];
+                    const cf E = cscale(cadd_c(A, B), 0.5f);
+                    const cf D = csub_c(A, B);
+                    const cf O = cdiv_2j(D);
                     cf Z = cfma(E, w, O);
                     if (k == 0) Z.y = 0.0f;
                     dst[m] = Z;
@@ -1560,10 +1610,9 @@ template <int NFFT, int M> struct IstftEngine {
                 for (int c = 0; c < C; ++c) {
                     cf A = Yt[(long long)k * C + c], B = Yt[(long long)(NC - k) * C + c];
                     if (k == 0) { A.y = 0.0f; B.y = 0.0f; }     // irfft ignores Im Y[0], Im Y[N/2]
-                    const cf Bc = cconj(B);
-                    const cf E = cscale(cadd(A, Bc), 0.5f);
-                    const cf O = cmul(cscale(csub(A, Bc), 0.5f), w);
-                    fa[c * Sh::NCP + k] = mk(E.x - O.y, E.y + O.x);
+                    const cf E = cscale(cadd_c(A, B), 0.5f);
+                    const cf O = cmul(cscale(csub_c(A, B), 0.5f), w);
+                    fa[c * Sh::NCP + k] = cadd_jd<+1>(E, O);
                 }
             });
             auto ph = [&](bool wave_local, auto f) { if (wave_local) ex.phase_wave(f); else ex.phase(f); };   // see Engine::run
@@ -1684,10 +1733,10 @@ template <int NFFT> struct StftRowsEngine {
                 for (int k = lane; k < NC; k += 64) {
                     const int k2 = (NC - k) & (NC - 1);
                     const cf wk = sh.tb.tw[k];
-                    const cf A = F[k], Bc = cconj(F[k2]);
-                    const cf E = cscale(cadd(A, Bc), 0.5f);
-                    const cf D = csub(A, Bc);
-                    const cf O = mk(0.5f * D.y, -0.5f * D.x);
+                    const cf A = F[k], B = F[k2];
+                    const cf E = cscale(cadd_c(A, B), 0.5f);
+                    const cf D = csub_c(A, B);
+                    const cf O = cdiv_2j(D);
                     cf Z = cfma(E, wk, O);
                     if (k == 0) Z.y = 0.0f;
                     Yt[k] = Z;
@@ -1742,10 +1791,9 @@ template <int NFFT> struct IstftRowsEngine {
                     const cf wk = cconj(sh.tb.tw[k]);
                     cf A = r.a[j], B = r.b[j];
                     if (k == 0) { A.y = 0.0f; B.y = 0.0f; }     // irfft ignores Im Y[0], Im Y[N/2]
-                    const cf Bc = cconj(B);
-                    const cf E = cscale(cadd(A, Bc), 0.5f);
-                    const cf O = cmul(cscale(csub(A, Bc), 0.5f), wk);
-                    fa[k] = mk(E.x - O.y, E.y + O.x);
+                    const cf E = cscale(cadd_c(A, B), 0.5f);
+                    const cf O = cmul(cscale(csub_c(A, B), 0.5f), wk);
+                    fa[k] = cadd_jd<+1>(E, O);
                 }
                 if (t + 1 < p.T) fetch(row, lane, t + 1, r);
             });
