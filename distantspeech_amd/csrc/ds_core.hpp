@@ -482,21 +482,24 @@ DS_HD void mcra_bin(float* st, int k, int K, float Ykm1, float Yk, float Ykp1, i
     const float alpha_s = 0.8f, one_m_alpha_s = (float)(1.0 - 0.8), delta_s = 5.0f;
     const float alpha_p = 0.2f, one_m_alpha_p = (float)(1.0 - 0.2), alpha_d = 0.95f, one_m_alpha_d = (float)(1.0 - 0.95);
     const float p_max = 0.999f, p_min = 1e-3f;
-    float S = st[0], Smin = st[1], Stmp = st[2], p = st[3], lam = st[4];
-    if (frm_cnt == 0) {
-        if (k < K - 1) { Smin = Yk; Stmp = Yk; lam = Yk; p = 0.0f; }                 // :38-41,68-69
-    } else if (k == 0) {
-        p = 0.0f;                                                                     // :43-45
-    } else if (k < K - 1) {
-        const float Sf = fma_(Ykp1, 0.25f, fma_(Yk, 0.5f, Ykm1 * 0.25f));           // :46
-        S = fma_(alpha_s, S, one_m_alpha_s * Sf);                                         // :47
-        Smin = fminf_(Smin, S); Stmp = fminf_(Stmp, S);                               // :49-50
-        if (reset) { Smin = fminf_(Stmp, S); Stmp = S; }                              // :52-56
-        const float Sr = S / (Smin + 1e-6f);                                          // :58
-        const float I = Sr > delta_s ? 1.0f : 0.0f;                                   // :60-63
-        p = fma_(alpha_p, p, one_m_alpha_p * I);                                          // :65-67
-        if (frm_cnt < 2 * L) p = 0.0f;                                                // :68-69
-    }
+    const float S0 = st[0], Smin0 = st[1], Stmp0 = st[2], p0 = st[3], lam0 = st[4];
+    // the recursion of an interior bin, evaluated by every lane and selected below: as branches the three cases cost more in copies of
+    // the state between the paths than the few lanes that take the short ones save
+    const float Sf = fma_(Ykp1, 0.25f, fma_(Yk, 0.5f, Ykm1 * 0.25f));               // :46
+    const float S1 = fma_(alpha_s, S0, one_m_alpha_s * Sf);                          // :47
+    const float Smin_a = fminf_(Smin0, S1), Stmp_a = fminf_(Stmp0, S1);             // :49-50
+    const float Smin1 = reset ? fminf_(Stmp_a, S1) : Smin_a, Stmp1 = reset ? S1 : Stmp_a;   // :52-56
+    const float Sr = S1 / (Smin1 + 1e-6f);                                          // :58
+    const float I = Sr > delta_s ? 1.0f : 0.0f;                                     // :60-63
+    float p1 = fma_(alpha_p, p0, one_m_alpha_p * I);                                // :65-67
+    if (frm_cnt < 2 * L) p1 = 0.0f;                                                 // :68-69
+    const bool first = frm_cnt == 0, init = first && k < K - 1;                     // :38-41,68-69
+    const bool upd = !first && k > 0 && k < K - 1;
+    const float S = upd ? S1 : S0;
+    const float Smin = upd ? Smin1 : init ? Yk : Smin0;
+    const float Stmp = upd ? Stmp1 : init ? Yk : Stmp0;
+    float lam = init ? Yk : lam0;
+    float p = upd ? p1 : (init || (!first && k == 0)) ? 0.0f : p0;                  // :43-45
     p = fmaxf_(fminf_(p, p_max), p_min);                                              // :70
     if (k == K - 1) lam = 1e-8f;                                                      // :73
     const float at = fma_(one_m_alpha_d, p, alpha_d);                                     // Base :57
