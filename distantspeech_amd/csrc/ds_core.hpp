@@ -67,6 +67,24 @@ struct cf { float x, y; };
 // an unrolled / peeled loop the compiler happened to emit (chunked calls == one long call, bit for bit).
 DS_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DS_HD cf mk(float a, float b) { cf r; r.x = a; r.y = b; return r; }
+// Reciprocal, reciprocal square root, 2^x and log2 x as the hardware's one-instruction forms (1 ulp) on the device, where the correctly
+// rounded division / square root / libm call is 10-20 instructions each: used in the post-filter arithmetic of the McMcra / GSC bin
+// program (a dozen of them per bin and frame), whose parity bar is 1e-4 against a float64 reference.  The CPU build keeps the exact forms.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_EXACT_DIV)
+DS_HD float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+DS_HD float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
+DS_HD float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+DS_HD float exp2_(float x) { return __builtin_amdgcn_exp2f(x); }
+DS_HD float log2_(float x) { return __builtin_amdgcn_logf(x); }
+DS_HD float exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+#else
+DS_HD float rcp_(float x) { return 1.0f / x; }
+DS_HD float rsq_(float x) { return 1.0f / sqrtf(x); }
+DS_HD float div_(float a, float b) { return a / b; }
+DS_HD float exp2_(float x) { return exp2f(x); }
+DS_HD float log2_(float x) { return log2f(x); }
+DS_HD float exp_(float x) { return expf(x); }
+#endif
 DS_HD cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
 DS_HD cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
 // The complex products, as the scalar expressions that DEFINE their rounding (every product and every fused multiply-add below is one
@@ -849,7 +867,7 @@ DS_HD void mcmcra_bin(float* pyy, float* pvv, const cf* Z, int k, int spp_frm_cn
 #pragma unroll
         for (int q = 0; q < j; ++q) s = fma_(-Lm[j][q], Lm[j][q], s);
         s = fmaxf_(s, 1e-30f);
-        const float r = 1.0f / sqrtf(s);
+        const float r = rsq_(s);
         inv_d[j] = r;
         Lm[j][j] = s * r;
 #pragma unroll
@@ -923,9 +941,10 @@ DS_HD void mcmcra_bin(float* pyy, float* pvv, const cf* Z, int k, int spp_frm_cn
     float q;
     if (psi >= psi0 || tr > psi0) q = q_min;
     else if (tr < (float)M) q = q_max;
-    else q = fminf_(fmaxf_((psi0 - tr) / (psi0 - (float)M), q_min), q_max);
+    else q = fminf_(fmaxf_(div_(psi0 - tr, psi0 - (float)M), q_min), q_max);
     // p :143-151
-    float pp = 1.0f / (1.0f + q / (1.0f - q) * (1.0f + xi) * expf(-1.0f * (gam / (1.0f + xi))));
+    const float r1xi = rcp_(1.0f + xi);
+    float pp = rcp_(1.0f + div_(q, 1.0f - q) * (1.0f + xi) * exp_(-1.0f * (gam * r1xi)));
     pp = fminf_(fmaxf_(pp, 0.01f), 0.99f);
     // noise PSD update :210-224
     const float at = 0.95f + (float)(1.0 - 0.95) * pp;
@@ -933,8 +952,8 @@ DS_HD void mcmcra_bin(float* pyy, float* pvv, const cf* Z, int k, int spp_frm_cn
     for (int q2 = 0; q2 < NS; ++q2) pvv[q2] = fma_(at, pvv[q2], (1.0f - at) * yy[q2]);
     // gain :153-157
     const float Gmin = 0.0631f;
-    const float gh1 = xi / (1.0f + xi);
-    float G = exp2f(fma_(pp, log2f(gh1), (1.0f - pp) * log2f(Gmin)));                      // G_H1^p Gmin^(1-p)
+    const float gh1 = xi * r1xi;
+    float G = exp2_(fma_(pp, log2_(gh1), (1.0f - pp) * log2f(Gmin)));                      // G_H1^p Gmin^(1-p)
     G = fmaxf_(fminf_(G, 1.0f), Gmin);
     if (k < 2) G = 0.0f;
     p_out = pp; G_out = G; xi_out = xi; gamma_out = gam;
@@ -953,7 +972,7 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
     cf yf = mk(0.0f, 0.0f);
 #pragma unroll
     for (int m = 0; m < M; ++m) { aa += cabs2(a[m]); yf = cfmac(yf, Z[m], a[m]); }
-    yf = cscale(yf, 1.0f / aa);
+    yf = cscale(yf, rcp_(aa));
     const cf u0 = cmulc(Z[0], a[0]);
     cf U[M - 1];
     cf Yk = yf;
