@@ -769,7 +769,7 @@ template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag
             }
         }
     }
-    const float inv = 1.0f / nu;
+    const float inv = rcp_(nu);
     return mk(ut.x * inv, ut.y * inv);
 }
 #endif

@@ -1020,7 +1020,7 @@ template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, i
             }
             gam = fminf_(fmaxf_(vPv - yv, 1e-6f), 1e8f);                           // :232-236
         }
-        pp = 1.0f / (1.0f + q / (1.0f - q) * (1.0f + xi) * expf(-1.0f * (gam / (1.0f + xi))));   // compute_p :75-92
+        pp = rcp_(1.0f + div_(q, 1.0f - q) * (1.0f + xi) * exp_(-1.0f * div_(gam, 1.0f + xi)));   // compute_p :75-92
         pp = fminf_(fmaxf_(pp, 0.0f), 1.0f);
         const long long ob = fb + k;
         if (p.spill) {

@@ -34,7 +34,7 @@ struct QuadHip {
     }
     __device__ static V sel(B m, V a, V b) { return m ? a : b; }
     __device__ static V rsq(V x) { return rsqrtf(x); }
-    __device__ static V rcp(V x) { return 1.0f / x; }
+    __device__ static V rcp(V x) { return rcp_(x); }                          // as mvdr_output<M> does
     __device__ static V vmax(V a, float c) { return a > c ? a : c; }
     __device__ static V splat(float c) { return c; }
 };
