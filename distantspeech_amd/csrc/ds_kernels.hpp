@@ -75,7 +75,11 @@ template <class Rg> struct HipExec {
 // resident workgroups per CU for 512-point frames: the whole 1024-utterance batch in one wave of workgroups); the GSC kernel had
 // slipped to 130 VGPRs / 3 waves, so it is pinned; the MVDR kernel sits on the same edge (two more registers and a workgroup per CU
 // is gone: -25 %) and is pinned too; larger arrays keep the allocator's own choice.
-constexpr int frames_min_waves(int M, int algo) { return (M <= 4 && (algo == ALGO_GSC || algo == ALGO_ADAPTIVE)) ? 4 : 1; }
+// The 6-microphone SubbandGSC tail (ALGO_AIC) holds three workgroups per CU by its LDS; with the packed complex products the allocator
+// took 172 registers (two waves per SIMD) where 168 keep the third: pinned as well.
+constexpr int frames_min_waves(int M, int algo) {
+    return (M <= 4 && (algo == ALGO_GSC || algo == ALGO_ADAPTIVE)) ? 4 : (M == 6 && algo == ALGO_AIC) ? 3 : 1;
+}
 
 template <int NFFT, int M, int ALGO, bool RYY>
 __global__ void __launch_bounds__(NFFT / 2, frames_min_waves(M, ALGO)) ds_frames_kernel(Params p) {
