@@ -61,6 +61,7 @@ template <int LPB> struct WpeRegs {
     cf W[CM];
     cf num, xin, din;
     float var;
+    long long io0, ring0;          // channel 0 of frame 0 / of ring slot 0 of this lane's bin in the [B][T][K][C] / [B][ring_len][K][C] arrays
 };
 
 template <int LPB> struct WpeEngine {
@@ -92,10 +93,15 @@ template <int LPB> struct WpeEngine {
             const long long b = g / p.K, k = g - b * p.K;
             return ((b * p.ring_len + slot_) * p.K + k) * C;
         };
-        auto delayed = [&](long long g, int t, int c) {           // x_delayed[c] of frame t
-            if (p.ring == nullptr) { const long long f = io_base(g, t); return mk(p.xd[2 * (f + c)], p.xd[2 * (f + c) + 1]); }
-            if (t < p.ring_len) { const long long f = ring_at(g, (ring_pos + t) % p.ring_len); return mk(p.ring[2 * (f + c)], p.ring[2 * (f + c) + 1]); }
-            const long long f = io_base(g, t - p.ring_len);
+        // the split of a bin index into (utterance, bin) is a 64-bit division by a run-time K: done once per lane (first phase), the frame
+        // loop then steps through the arrays from the lane's frame-0 / slot-0 offsets (r.io0, r.ring0) by the uniform frame stride
+        const long long fstride = (long long)p.K * C;
+        auto io_at = [&](const Rg& r, int t) { return r.io0 + (long long)t * fstride; };
+        auto ring_slot = [&](const Rg& r, int slot_) { return r.ring0 + (long long)slot_ * fstride; };
+        auto delayed = [&](const Rg& r, int t, int c) {           // x_delayed[c] of frame t
+            if (p.ring == nullptr) { const long long f = io_at(r, t); return mk(p.xd[2 * (f + c)], p.xd[2 * (f + c) + 1]); }
+            if (t < p.ring_len) { const long long f = ring_slot(r, (ring_pos + t) % p.ring_len); return mk(p.ring[2 * (f + c)], p.ring[2 * (f + c) + 1]); }
+            const long long f = io_at(r, t - p.ring_len);
             return mk(p.d[2 * (f + c)], p.d[2 * (f + c) + 1]);
         };
         ex.phase_wave([&](int tid, Rg& r) {
@@ -117,9 +123,11 @@ template <int LPB> struct WpeEngine {
                 if (c < C) r.W[c] = st[NPK + c * CN + i];
             sh.X[0][s][i] = st[NPK + C * CN + i];
             r.var = stf[2 * (NPK + C * CN + CN)];
-            const long long f0 = io_base(g, 0);
+            r.io0 = io_base(g, 0);
+            r.ring0 = p.ring != nullptr ? ring_at(g, 0) : 0;
+            const long long f0 = r.io0;
             const int c = i / N;
-            if (i == c * N) r.xin = delayed(g, 0, c);
+            if (i == c * N) r.xin = delayed(r, 0, c);
             if (i < C) r.din = mk(p.d[2 * (f0 + i)], p.d[2 * (f0 + i) + 1]);
         });
         ex.phase_wave([&](int tid, Rg& r) {                            // row i of P: above the diagonal as stored, below it the conjugate of column i
@@ -144,7 +152,7 @@ template <int LPB> struct WpeEngine {
                 if (i < C) {
                     sh.d[s][i] = r.din;
                     if (p.ring != nullptr && t >= p.T - p.ring_len) {             // this frame is one of the last ring_len: keep it
-                        const long long f = ring_at(g, (ring_pos + t) % p.ring_len);
+                        const long long f = ring_slot(r, (ring_pos + t) % p.ring_len);
                         p.ring[2 * (f + i)] = r.din.x; p.ring[2 * (f + i) + 1] = r.din.y;
                     }
                 }
@@ -166,14 +174,14 @@ template <int LPB> struct WpeEngine {
                 for (int c = 0; c < CM; ++c)
                     if (c < C) sh.part[s][c][i] = cmulc(Xi, r.W[c]);
                 if (t + 1 < p.T) {                                 // next frame's inputs: in flight behind this frame's arithmetic
-                    const long long f1 = io_base(g, t + 1);
+                    const long long f1 = io_at(r, t + 1);
                     const int c = i / N;
-                    if (i == c * N) r.xin = delayed(g, t + 1, c);
+                    if (i == c * N) r.xin = delayed(r, t + 1, c);
                     if (i < C) r.din = mk(p.d[2 * (f1 + i)], p.d[2 * (f1 + i) + 1]);
                 }
             });
             // ---- err_c = d_c - sum_i conj(W[c][i]) X_i in lane order  (:158-161)
-            ex.phase_wave([&](int tid, Rg&) {
+            ex.phase_wave([&](int tid, Rg& r) {
                 int s, i; long long g; bool on;
                 slot(tid, s, i, g, on);
                 if (!on || i >= C) return;
@@ -181,7 +189,7 @@ template <int LPB> struct WpeEngine {
                 for (int l = 0; l < CN; ++l) o = cadd(o, sh.part[s][i][l]);
                 const cf e = csub(sh.d[s][i], o);
                 sh.err[s][i] = e;
-                const long long f = io_base(g, t);
+                const long long f = io_at(r, t);
                 p.err[2 * (f + i)] = e.x; p.err[2 * (f + i) + 1] = e.y;
             });
             // ---- gain, P and W updates
