@@ -289,7 +289,10 @@ def measure(be, dsdist, w, B, T, K, W, rank, world, min_region_ms, graph=None, m
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": w["kernel"],
                      "launches_per_step": w["launches"], "launch_ms": round(launch_ms, 5), "algorithmic_bytes_per_frame": alg,
-                     "algorithmic_bytes_per_launch": alg * B * T, "batch_per_gpu": B, "hops_per_call": T},
+                     "algorithmic_bytes_per_launch": alg * B * T, "batch_per_gpu": B, "hops_per_call": T,
+                     "accounting": "frac = SURVEY 8(d)'s algorithmic bytes (the carried state counted in fp32 / complex64, full matrices) over this "
+                                   "run's launch duration; the kernels keep Hermitian / symmetric state packed, so the bytes they move are fewer and "
+                                   "frac can pass 1 — frac_measured (PMC bytes of the same command over the same duration) is the physical figure"},
     }
 
 
