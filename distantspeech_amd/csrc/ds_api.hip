@@ -17,7 +17,9 @@ int fail(ds_handle* h, int code, const std::string& msg) {
 }
 
 
-size_t bins_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * h->NP * h->KP * sizeof(ds::vec4); }
+// StateLayout::ust(): NF KP floats per utterance, rounded up to a 128-byte line
+static size_t bins_ust(const ds_handle* h) { return ((size_t)h->ki.NF * h->KP + 31) & ~(size_t)31; }
+size_t bins_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * bins_ust(h) * sizeof(float); }
 size_t tail_in_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * h->cfg.n_mics * h->cfg.hop * sizeof(float); }
 size_t tail_out_bytes(const ds_handle* h) {
     const size_t ch = h->cfg.algo == DS_ALGO_TRANSFORM ? (size_t)h->cfg.n_mics : 1;   // Transform keeps one OLA tail per channel
@@ -1029,9 +1031,10 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
     // per-bin fields: pull the raw planes and unpack on the host
     std::vector<float> raw(bins_bytes(h) / sizeof(float));
     DS_HIP(h, hipMemcpy(raw.data(), h->bins, bins_bytes(h), hipMemcpyDeviceToHost));
-    const int B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, KP = h->KP, NP = h->NP;
-    auto at = [&](int b, int k, int f) -> float {   // float f of bin k of utterance b
-        return raw[(((size_t)b * NP + f / 4) * KP + k) * 4 + (f % 4)];
+    const int B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, KP = h->KP, NF = h->ki.NF, NPF = NF / 4, RT = NF % 4;
+    auto at = [&](int b, int k, int f) -> float {   // float f of bin k of utterance b: NPF float4 planes, then the narrow plane [KP][RT]
+        const size_t u = (size_t)b * bins_ust(h);
+        return f < 4 * NPF ? raw[u + ((size_t)(f / 4) * KP + k) * 4 + (f % 4)] : raw[u + (size_t)NPF * KP * 4 + (size_t)k * RT + (f - 4 * NPF)];
     };
     float* out = (float*)dst;
     auto herm = [&](int d0, int o0) {

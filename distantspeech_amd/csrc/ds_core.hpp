@@ -211,7 +211,7 @@ struct Params {
     long long y_batch_stride;
     int T;                    // hops in this call
     int batch0;               // first utterance handled by block 0 (state / io index offset)
-    vec4* bins;               // per-bin state planes [B][NP][KP]
+    vec4* bins;               // per-bin state [B][NF KP floats]: NF / 4 float4 planes [KP], then NF % 4 floats per bin as a narrow plane (StateLayout)
     float* tail_in;           // STFT overlap [B][M][hop]
     float* tail_out;          // OLA overlap  [B][hop]
     int* counters;            // [B][4]  {mcra frm_cnt, mcra ell, spp frm_cnt, reserved}
@@ -261,6 +261,12 @@ template <int M, int ALGO, bool RYY> struct StateLayout {
         : ALGO == ALGO_AIC    ? (8 * M + 1)            // 2-tap M-channel canceller: W, X (2 M complex each), P
                               : 0;
     static constexpr int NP = (NF + 3) / 4;
+    // in memory: NPF full 16-byte planes [NPF][KP] of float4, then the NF % 4 floats that are left as ONE narrow plane [KP][RT] — not a
+    // sixth / seventh float4 plane with spare words: the adaptive kernel's 21 floats per bin are 84 bytes each way instead of 96
+    // (one hop per call moves the whole state, and the launch is bound by exactly those bytes); ust(KP) floats per utterance
+    static constexpr int NPF = NF / 4, RT = NF % 4;
+    // floats between utterances: NF KP rounded up to a 128-byte line, so that every utterance's planes start on a line like the first one's
+    static constexpr long long ust(int KP) { return ((long long)NF * KP + 31) & ~31LL; }
     // ADAPTIVE float map
     static constexpr int R_DIAG = 0;                 // M reals
     static constexpr int R_OFF = M;                  // M(M-1)/2 complex, (i<j) row-major
@@ -1151,7 +1157,9 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         const int b = p.batch0 + blk;
         const long long xb = (long long)blk * p.x_batch_stride;
         const long long yb = (long long)blk * p.y_batch_stride;
-        vec4* bins = p.bins + (long long)b * NP * KP;
+        float* const ubase = reinterpret_cast<float*>(p.bins) + (long long)b * SL::ust(KP);      // this utterance's state
+        vec4* bins = reinterpret_cast<vec4*>(ubase);                                            // its NPF full planes ...
+        float* const btail = ubase + (long long)SL::NPF * KP * 4;                               // ... and the narrow one, [KP][RT]
         float* tin = p.tail_in + (long long)b * M * HOP;
         float* tout = p.tail_out + (long long)b * HOP;
         int* cnt = p.counters + (long long)b * 4;
@@ -1198,11 +1206,27 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 r.nyq.x = as.ld(tid < SL::NF ? tid : 0, NC);
             } else {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
+                for (int q = 0; q < SL::NPF; ++q) {
                     const vec4 v = load_state(&bins[q * KP + tid]);
                     r.st[4 * q] = v.x; r.st[4 * q + 1] = v.y; r.st[4 * q + 2] = v.z; r.st[4 * q + 3] = v.w;
                 }
-                if constexpr (NP > 0) r.nyq = bins[(tid < NP ? tid : 0) * KP + NC];   // Nyquist planes: parked in a register until the split phase
+#pragma unroll
+                for (int j = 0; j < SL::RT; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DS_NT_TAIL)
+                    r.st[4 * SL::NPF + j] = __builtin_nontemporal_load(&btail[tid * SL::RT + j]);
+#else
+                    r.st[4 * SL::NPF + j] = btail[tid * SL::RT + j];
+#endif
+                }
+                if constexpr (NP > 0) {                                     // Nyquist planes: parked in a register until the split phase
+                    r.nyq = bins[(tid < SL::NPF ? tid : 0) * KP + NC];
+                    if (SL::RT > 0 && tid == SL::NPF) {
+                        float w[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int j = 0; j < SL::RT; ++j) w[j] = btail[NC * SL::RT + j];
+                        r.nyq.x = w[0]; r.nyq.y = w[1]; r.nyq.z = w[2]; r.nyq.w = w[3];
+                    }
+                }
             }
         });
         // ALGO_AIC: this frame's desired-signal sample (the spectrum one frame back; frame 0 takes the carried one) and update
@@ -1437,13 +1461,24 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 }
             } else {
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
+                for (int q = 0; q < SL::NPF; ++q) {
                     vec4 v; v.x = r.st[4 * q]; v.y = r.st[4 * q + 1]; v.z = r.st[4 * q + 2]; v.w = r.st[4 * q + 3];
                     store_state(&bins[q * KP + tid], v);
                 }
-                if (tid < NP) {
+#pragma unroll
+                for (int j = 0; j < SL::RT; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DS_NT_TAIL)
+                    __builtin_nontemporal_store(r.st[4 * SL::NPF + j], &btail[tid * SL::RT + j]);
+#else
+                    btail[tid * SL::RT + j] = r.st[4 * SL::NPF + j];
+#endif
+                }
+                if (tid < SL::NPF) {
                     vec4 v; v.x = sh.nyq[4 * tid]; v.y = sh.nyq[4 * tid + 1]; v.z = sh.nyq[4 * tid + 2]; v.w = sh.nyq[4 * tid + 3];
                     bins[tid * KP + NC] = v;
+                } else if (SL::RT > 0 && tid == SL::NPF) {
+#pragma unroll
+                    for (int j = 0; j < SL::RT; ++j) btail[NC * SL::RT + j] = sh.nyq[4 * SL::NPF + j];
                 }
             }
             if (tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }

@@ -10,9 +10,10 @@ typedef hipError_t (*launch_fn)(const Params& p, int nblocks, hipStream_t stream
 
 struct KernelInfo {
     launch_fn launch;
-    int NP;   // float4 state planes per bin
+    int NP;   // float4 state planes per bin (the last one partly filled when NF % 4 != 0)
     int KP;   // padded plane length
     int NT;   // threads per block
+    int NF = 0;   // state floats per bin (in memory: NF KP floats per utterance, see StateLayout)
 };
 
 // lookups implemented in ds_kernels_*.hip; launch == nullptr when the combination is not compiled
@@ -103,7 +104,7 @@ template <int NFFT, int M, int ALGO, bool RYY> KernelInfo make_info() {
     typedef Engine<NFFT, M, ALGO, RYY> E;
     KernelInfo ki;
     ki.launch = &launch_frames<NFFT, M, ALGO, RYY>;
-    ki.NP = E::NP; ki.KP = E::KP; ki.NT = E::NT;
+    ki.NP = E::NP; ki.NF = E::SL::NF; ki.KP = E::KP; ki.NT = E::NT;
     return ki;
 }
 

@@ -27,7 +27,7 @@ template <int NFFT> static KernelInfo quad_info() {
     typedef EngineQ<NFFT> E;
     KernelInfo ki;
     ki.launch = &launch_frames_quad<NFFT>;
-    ki.NP = E::NP; ki.KP = E::KP; ki.NT = E::NT;
+    ki.NP = E::NP; ki.KP = E::KP; ki.NT = E::NT; ki.NF = E::EB::SL::NF;       // the state layout is the one-thread kernel's
     return ki;
 }
 

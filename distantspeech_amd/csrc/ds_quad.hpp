@@ -293,7 +293,12 @@ template <int NFFT> struct EngineQ {
         const int b = p.batch0 + blk;
         const long long xb = (long long)blk * p.x_batch_stride;
         const long long yb = (long long)blk * p.y_batch_stride;
-        vec4* bins = p.bins + (long long)b * NP * KP;
+        // this utterance's state as Engine lays it out (StateLayout): 17 full planes, then float 68 (lambda_d) as a narrow plane [KP]
+        typedef typename EB::SL SLq;
+        static_assert(SLq::NPF == 17 && SLq::RT == 1, "8 microphones, no Ryy: 64 covariance floats + 5 MCRA floats");
+        float* const ubase = reinterpret_cast<float*>(p.bins) + (long long)b * SLq::ust(KP);
+        vec4* bins = reinterpret_cast<vec4*>(ubase);
+        float* const btail = ubase + (long long)SLq::NPF * KP * 4;
         float* tin = p.tail_in + (long long)b * M * HOP;
         float* tout = p.tail_out + (long long)b * HOP;
         int* cnt = p.counters + (long long)b * 4;
@@ -318,11 +323,13 @@ template <int NFFT> struct EngineQ {
             EB::prefetch_init(p, xb, tid, r.b);
             EB::prefetch(p, xb, 0, tid, r.b);
             // MCRA floats 64 .. 68 of bin tid (planes 16, 17); the Nyquist bin's packed state (all 18 planes) -> LDS
-            const vec4 m0 = load_state(&bins[16 * KP + tid]), m1 = load_state(&bins[17 * KP + tid]);
-            r.mc[0] = m0.x; r.mc[1] = m0.y; r.mc[2] = m0.z; r.mc[3] = m0.w; r.mc[4] = m1.x;
-            if (tid < NP) {
+            const vec4 m0 = load_state(&bins[16 * KP + tid]);
+            r.mc[0] = m0.x; r.mc[1] = m0.y; r.mc[2] = m0.z; r.mc[3] = m0.w; r.mc[4] = btail[tid];
+            if (tid < SLq::NPF) {
                 const vec4 v = bins[tid * KP + NC];
                 sh.nyq[4 * tid] = v.x; sh.nyq[4 * tid + 1] = v.y; sh.nyq[4 * tid + 2] = v.z; sh.nyq[4 * tid + 3] = v.w;
+            } else if (tid == SLq::NPF) {
+                sh.nyq[4 * tid] = btail[NC]; sh.nyq[4 * tid + 1] = 0.0f; sh.nyq[4 * tid + 2] = 0.0f; sh.nyq[4 * tid + 3] = 0.0f;
             }
         });
 #pragma unroll
@@ -456,12 +463,14 @@ template <int NFFT> struct EngineQ {
             }
             vec4* tout4 = reinterpret_cast<vec4*>(tout);
             for (int i = tid; i < HOP / 4; i += NT) store_state(&tout4[i], *reinterpret_cast<const vec4*>(&sh.tail[4 * i]));
-            vec4 m0, m1;
-            m0.x = r.mc[0]; m0.y = r.mc[1]; m0.z = r.mc[2]; m0.w = r.mc[3]; m1.x = r.mc[4]; m1.y = 0.0f; m1.z = 0.0f; m1.w = 0.0f;
-            store_state(&bins[16 * KP + tid], m0); store_state(&bins[17 * KP + tid], m1);
-            if (tid < NP) {
+            vec4 m0;
+            m0.x = r.mc[0]; m0.y = r.mc[1]; m0.z = r.mc[2]; m0.w = r.mc[3];
+            store_state(&bins[16 * KP + tid], m0); btail[tid] = r.mc[4];
+            if (tid < SLq::NPF) {
                 vec4 v; v.x = sh.nyq[4 * tid]; v.y = sh.nyq[4 * tid + 1]; v.z = sh.nyq[4 * tid + 2]; v.w = sh.nyq[4 * tid + 3];
                 bins[tid * KP + NC] = v;
+            } else if (tid == SLq::NPF) {
+                btail[NC] = sh.nyq[4 * tid];
             }
             if (tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; }
         });

@@ -271,14 +271,15 @@ int emul_quad_mvdr(float* st_quad, float* st_ref, const float* a, const float* z
     return 0;
 }
 
-// sizes of the per-bin plane storage for (algo, M, ryy): returns NP, writes KP
+// sizes of the per-bin state storage for (algo, M, ryy): returns NF (floats per bin; NF KP floats per utterance: NF / 4 float4 planes
+// [KP], then NF % 4 floats per bin as a narrow plane, the utterance stride rounded up to 32 floats — ds_core.hpp StateLayout), writes KP
 int emul_layout(int algo, int nfft, int M, int ryy, int* kp) {
     const int K = nfft / 2 + 1;
     *kp = (K + 3) & ~3;
     int nf = 0;
     if (algo == ds::ALGO_ADAPTIVE) nf = M * M + 5 + (ryy ? M * M : 0);
     if (algo == ds::ALGO_GSC) nf = M * (M + 1) + 2 * (M - 1);
-    return (nf + 3) / 4;
+    return nf;
 }
 
 int emul_run(int algo, int nfft, int M, int ryy, int batch, const float* x, int layout, int n_samples, float* y,

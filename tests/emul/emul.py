@@ -45,9 +45,10 @@ class EmulEngine:
         self.algo, self.nfft, self.M, self.batch, self.ryy = algo, nfft, M, batch, int(ryy)
         self.hop, self.K = nfft // 2, nfft // 2 + 1
         kp = ctypes.c_int(0)
-        self.NP = lib().emul_layout(algo, nfft, M, self.ryy, ctypes.byref(kp))
+        self.NF = lib().emul_layout(algo, nfft, M, self.ryy, ctypes.byref(kp))
         self.KP = kp.value
-        self.bins = np.zeros((batch, max(self.NP, 1), self.KP, 4), dtype=np.float32)
+        self.ust = (max(self.NF, 1) * self.KP + 31) & ~31                          # StateLayout::ust(): floats between utterances
+        self.bins = np.zeros((batch, self.ust), dtype=np.float32)                    # per utterance: NF // 4 float4 planes [KP], then [KP][NF % 4]
         self.tail_in = np.zeros((batch, M, self.hop), dtype=np.float32)
         self.tail_out = np.zeros((batch, self.hop), dtype=np.float32)
         self.counters = np.zeros((batch, 4), dtype=np.int32)
@@ -78,7 +79,10 @@ class EmulEngine:
 
     def field(self, f):
         """float index f of every bin -> [B, K]"""
-        return self.bins[:, f // 4, : self.K, f % 4]
+        npf, rt = self.NF // 4, self.NF % 4
+        if f < 4 * npf:
+            return self.bins[:, : npf * self.KP * 4].reshape(self.batch, npf, self.KP, 4)[:, f // 4, : self.K, f % 4]
+        return self.bins[:, npf * self.KP * 4: self.NF * self.KP].reshape(self.batch, self.KP, rt)[:, : self.K, f - 4 * npf]
 
 
 def _vp(a):
