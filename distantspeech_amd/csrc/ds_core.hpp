@@ -42,7 +42,11 @@ struct alignas(16) vec4 { float x, y, z, w; };
 // keeps the compiler from forwarding values across it (used around a deliberate round trip through LDS); no instruction emitted
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DS_COMPILER_FENCE() asm volatile("" ::: "memory")
+#if defined(DS_NO_SETPRIO)
+#define DS_SETPRIO(n) ((void)0)
+#else
 #define DS_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
 #define DS_GRID_BLOCKS() ((int)gridDim.x)
 #define DS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // orders arithmetic the optimiser would otherwise hoist: the values come out of an (empty) volatile asm, and volatile asms keep their
