@@ -92,6 +92,15 @@ def free_port():
     return port
 
 
+def under_profiler():
+    """True when a GPU profiler's tool library is preloaded into this process (rocprofv3 / rocprof): the tool initialises the GPU before
+    main() runs, so this process must not start another program — no child ranks, no CPU-baseline worker processes."""
+    env = os.environ
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_TOOL", "ROCTRACER_")) for k in env):
+        return True
+    return any(t in env.get("LD_PRELOAD", "") for t in ("rocprofiler", "roctracer", "rocprof"))
+
+
 def launch_ranks(n, argv):
     env0 = dict(os.environ)
     env0.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
@@ -415,7 +424,12 @@ def main():
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         raise SystemExit("--gpus and --steps must be >= 1, --warmup >= 0")
 
+    profiled = under_profiler()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if profiled:
+            sys.stderr.write("bench.py: --gpus %d under a GPU profiler refused: the profiled process has initialised the GPU and must not start "
+                             "child ranks (profile one GPU: scripts/profile_bench.sh)\n" % args.gpus)
+            sys.exit(2)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))        # children only; nothing in this process has touched torch or the GPU
 
     from distantspeech_amd import dist as dsdist
@@ -425,7 +439,8 @@ def main():
         sys.exit(2)
     # the NumPy-oracle CPU baselines of the other configs run in worker processes: started here, before this process touches the GPU
     cpu_pre = {}
-    if world == 1 and not args.no_cpu_baseline and not args.no_extras and args.config == "cfg2" and not os.environ.get("DS_BENCH_BACKEND"):
+    if world == 1 and not args.no_cpu_baseline and not args.no_extras and args.config == "cfg2" and not os.environ.get("DS_BENCH_BACKEND") \
+            and not profiled:                            # worker processes: never from a profiled (GPU-initialised) process
         for name in ("cfg3", "cfg4", "cfg5"):
             cpu_pre[name] = cpu_baseline_oracle(name)
     be = load_backend(local_rank, world)

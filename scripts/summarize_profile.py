@@ -69,7 +69,7 @@ if traffic["kernels"]:
         print("%-70s x%5.1f/step  fetch %9.2f MB  write %9.2f MB  total %9.2f MB" % (k[:70], v["launches"] / steps, v["fetch_bytes"] / 1e6, v["write_bytes"] / 1e6, v["hbm_bytes_per_launch"] / 1e6))
     print("per step: %.2f MB" % (traffic["hbm_bytes_per_step"] / 1e6))
 json.dump(traffic, open(os.path.join(d, "traffic.json"), "w"), indent=1)
-for sub in ("pmc_sq", "pmc_lds"):
+for sub in ("pmc_sq", "pmc_lds", "pmc_sq2"):
     acc = pmc(sub)
     for k, cs in acc.items():
         print("== %s: %s" % (sub, k[:90]))

@@ -584,6 +584,110 @@ def g16_fdgsc(x16):
              r=np.array(mic.r))
 
 
+def an101_int16():
+    """[8, L] int16: the reference's 8-channel recording (example/test_audio/an101-mtms-arrA, 2.85 s), whole hops of 512."""
+    files = sorted(glob.glob(os.path.join(_ref_shim.REFERENCE_ROOT, "example/test_audio/an101-mtms-arrA/*.wav")))
+    assert len(files) == 8
+    chans = []
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for f in files:
+            sr, d = wavfile.read(f)
+            assert sr == 16000 and d.dtype == np.int16
+            chans.append(d)
+    x = np.stack(chans)
+    return x[:, : (x.shape[1] // 512) * 512]
+
+
+SNAP_FRAMES = (1, 500, 1000)
+
+
+def g17_long():
+    """The reference's WHOLE test recording (rec1: 26.7 s = 1 670 hops of 256) through the three frame loops whose gate / VAD decisions
+    accumulate over a long run: adaptivebeamfomer.process, GSC.process, SubbandGSC.process.  The input is stored once
+    (int16, g17_rec1_full); each output fixture holds float32 samples (the ISTFT's own storage type, transform.py:243,359) and state
+    snapshots at frames {1, 500, 1000, last}."""
+    import DistantSpeech.beamformer.FDGSC as FD
+    FD.DelayObj = object                                                                   # R9
+    from DistantSpeech.beamformer.SubbandGSC import SubbandGSC
+    x16 = rec1_int16(0.0, 1e9)
+    x = x16.astype(np.float32) / 32768.0
+    T = x.shape[1] // 256
+    save("g17_rec1_full", "example/test_audio/rec1, all %d hops of 256 samples, 4 channels, int16" % T, x=x16)
+    mic = MicArray(arrayType="circular", r=0.032, M=4, n_fft=512)                          # R2
+    # -- adaptive MVDR
+    ab = make_adaptive(mic, 512, 256)                                                      # R1
+    ys, snap = [], {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        for t in range(T):                                                                 # R3
+            ys.append(np.atleast_1d(ab.process(x[:, t * 256:(t + 1) * 256].astype(np.float64), ANGLE, method=2)["data"]))
+            if t in SNAP_FRAMES:
+                snap["Rvv_t%d" % t] = ab.Rvv.astype(np.complex64)
+                snap["p_t%d" % t] = ab.mcra.p.astype(np.float32)
+    save("g17_adaptive_rec1_full", "adaptivebeamfomer.process(method=2) adaptivebeamformer.py:44-128 hop-by-hop over the whole recording; "
+         "R1 R2 R3; angle=197deg; snapshots after frames %s and the last" % (SNAP_FRAMES,),
+         y=np.concatenate(ys).astype(np.float32), Rvv=ab.Rvv, H=ab.H, mcra_p=ab.mcra.p, mcra_lambda_d=ab.mcra.lambda_d,
+         params=np.array([4, 512, 256, 2]), r=np.array(mic.r), **snap)
+    # -- GSC
+    with contextlib.redirect_stdout(io.StringIO()):                                        # R5
+        g = GSC(mic, frameLen=512, angle=[197, 0])
+    ys, snap = [], {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        for t in range(T):                                                                 # R3
+            ys.append(np.atleast_1d(g.process(x[:, t * 256:(t + 1) * 256].astype(np.float64), ANGLE, method=2)["data"]))
+            if t in SNAP_FRAMES:
+                snap["G_t%d" % t] = g.G.astype(np.complex64)
+                snap["spp_p_t%d" % t] = g.spp.p.astype(np.float32)
+    save("g17_gsc_rec1_full", "GSC.process(method=2) GSC.py:174-294 hop-by-hop over the whole recording; R2 R3 R5; angle=197deg",
+         y=np.concatenate(ys).astype(np.float32), G=g.G, spp_G=g.spp.G, spp_p=g.spp.p, params=np.array([4, 512, 256, 2]), r=np.array(mic.r), **snap)
+    # -- SubbandGSC (one call over the whole recording, as example/run_GSC.py feeds it)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sg = SubbandGSC(mic, frameLen=256, angle=[197, 0])
+        with np.errstate(all="ignore"):
+            out, fix, bm, p, al = sg.process(x.astype(np.float64).copy())
+    save("g17_subbandgsc_rec1_full", "SubbandGSC.process(postfilter=False) SubbandGSC.py:170-262 over the whole recording; R9",
+         output=out.astype(np.float32), fix_output=fix.astype(np.float32), bm_output=bm[:, ::4].astype(np.float32), p=p.astype(np.float32),
+         params=np.array([4, 256, 0]), r=np.array(mic.r))
+
+
+def g18_an101():
+    """The reference's real 8-channel recording (an101-mtms-arrA, 8 x 2.85 s; example/run_postfilter.py builds its array as
+    MicArray('linear', r=0.032, M=8)) through adaptivebeamfomer at 1024 / 512 and through the patched Wpe (R6, R7) on the same grid."""
+    from DistantSpeech.dereverberation import awpe
+    x16 = an101_int16()
+    x = x16.astype(np.float32) / 32768.0
+    M, nfft, hop = 8, 1024, 512
+    T = x.shape[1] // hop
+    mic = MicArray(arrayType="linear", r=0.032, M=M, n_fft=nfft)                           # R2
+    ab = make_adaptive(mic, nfft, hop)                                                     # R1
+    ys = []
+    with contextlib.redirect_stdout(io.StringIO()):
+        for t in range(T):                                                                 # R3
+            ys.append(np.atleast_1d(ab.process(x[:, t * hop:(t + 1) * hop].astype(np.float64), ANGLE, method=2)["data"]))
+    save("g18_adaptive_an101", "adaptivebeamfomer.process(method=2) adaptivebeamformer.py:44-128 hop-by-hop on an101-mtms-arrA "
+         "(8 channels, 1024/512, MicArray linear r=0.032 as example/run_postfilter.py); R1 R2 R3; angle=197deg",
+         x=x16, y=np.concatenate(ys), Rvv=ab.Rvv, H=ab.H, mcra_p=ab.mcra.p, params=np.array([M, nfft, hop, 2]), r=np.array(mic.r))
+    awpe.Subband = Transform                                                               # R6
+
+    def check_input_data(self, xd, xx):                                                    # R7
+        self.return_td = True
+        return np.squeeze(self.transform_x.analysis(xd)), np.squeeze(self.transform_d.analysis(xx))
+
+    awpe.Wpe.check_input_data = check_input_data
+    C, N, D = 8, 2, 4
+    with contextlib.redirect_stdout(io.StringIO()):
+        wpe = awpe.Wpe(filter_len=N, delay=D, channels=C, num_bands=nfft, hop_length=hop)
+    outs = []
+    xt = x.T.astype(np.float64)
+    for n in range(T):
+        out, _ = wpe.update(xt[n * hop:(n + 1) * hop])
+        outs.append(np.atleast_1d(out))
+    save("g18_wpe_an101", "Wpe.update awpe.py:129-192 hop-by-hop on an101-mtms-arrA, 8 channels x 2 taps, delay 4, STFT grid 1024/512 "
+         "(BASELINE config 4's shape); R6 R7 (PARITY UNPINNED by the reference as shipped)",
+         y=np.concatenate(outs), W=wpe.W.astype(np.complex64), var=wpe.var, params=np.array([C, N, D, nfft, hop]))
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -610,6 +714,8 @@ def main():
     if want("g14b"): g14b_fdaf_two_path()
     if want("g15"): g15_tdgsc(x16)
     if want("g16"): g16_fdgsc(x16)
+    if want("g17"): g17_long()
+    if want("g18"): g18_an101()
 
 
 if __name__ == "__main__":

@@ -62,3 +62,11 @@ def test_torchrun_style_launch(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 2
+
+
+def test_profiled_process_never_starts_child_ranks():
+    # under rocprofv3 the preloaded tool has initialised the GPU before main(): bench.py must refuse to self-launch ranks
+    r = run_bench(["--gpus", "2", "--steps", "5", "--warmup", "1"], {"ROCPROF_OUTPUT_PATH": "/tmp/x", "ROCPROFILER_LIBRARY_CTOR": "1"})
+    assert r.returncode == 2 and "profiler" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    r = subprocess.run(["bash", os.path.join(ROOT, "scripts", "profile_bench.sh"), "t", "--gpus", "8"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "refused" in r.stderr

@@ -375,6 +375,17 @@ def test_chain_full_batch_properties(ds, cfg):
     cut = 3 * hop
     yc = np.concatenate([np.asarray(run(chunked, x[:, :, :cut])), np.asarray(run(chunked, x[:, :, cut:]))], axis=1)
     assert np.array_equal(yc, y)                                           # state carried across calls, bitwise
+    # rows of the full batch against the oracle: the first two distinct utterances, wherever they first sit
+    for u in (0, 3):
+        b = int(np.flatnonzero(idx == u)[0])
+        with np.errstate(all="ignore"):
+            if cfg == "cfg4":
+                ref = O.OracleWpeMvdrPostfilter(omic, nfft=nfft, hop=hop).process(base[u], ANGLE)
+            else:
+                ref = O.OracleSubbandGSC(omic, frameLen=hop, angle_deg=(197, 0), rls_bm=True).process(base[u])[0]
+        err = rms(y[b] - ref)
+        measured("chain_full_batch_%s_row%d" % (cfg, b), y_rms=err, y_ref_rms=rms(ref))
+        assert err < 1e-4, (cfg, b, err)
 
 
 @pytest.mark.parametrize("nfft", [512, 1024])

@@ -308,6 +308,78 @@ def test_long_utterance_drift(ds):
         assert rms(y[b, -hop * 200:] - ref[-hop * 200:]) < TOL_RMS          # no growth at the end of the stream
 
 
+# ------------------------------------------------------------------------------------------------
+# the reference's WHOLE recording (rec1, 26.7 s = 1 670 hops) and its real 8-channel recording (an101-mtms-arrA): fixtures generated by
+# the reference itself (make_golden.py g17 / g18) — long-run gate / VAD decisions and the last 200 hops on their own
+# ------------------------------------------------------------------------------------------------
+def _tail(a, hops=200, hop=256):
+    return a[-hops * hop:]
+
+
+def test_long_recording_adaptive_mvdr(ds):
+    g, x = load("g17_adaptive_rec1_full"), as_float(load("g17_rec1_full")["x"])
+    hop = 256
+    ab = ds.adaptivebeamfomer(_mic(ds, 4, 512, 0.032), frameLen=512, hop=hop, nfft=512)
+    cuts = [0, 2, 501, 1001, x.shape[1] // hop]                        # state snapshots after frames 1, 500, 1000 (and the last)
+    ys, m = [], {}
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        ys.append(ab.process(x[:, a * hop:b * hop], ANGLE, method=2)["data"])
+        if b - 1 in (1, 500, 1000):
+            m["Rvv_relmax_t%d" % (b - 1)] = relmax(ab.Rvv, g["Rvv_t%d" % (b - 1)])
+            m["p_max_t%d" % (b - 1)] = np.max(np.abs(ab.mcra.p - g["p_t%d" % (b - 1)]))
+    y = np.concatenate(ys)
+    dp = np.abs(ab.mcra.p - g["mcra_p"])
+    m.update(y_rms=rms(y - g["y"]), y_tail_rms=rms(_tail(y - g["y"])), y_ref_rms=rms(g["y"]), Rvv_relmax=relmax(ab.Rvv, g["Rvv"]),
+             H_rel_rms=rms(ab.H - g["H"]) / rms(g["H"]), mcra_p_max=dp.max(), mcra_p_frac_gt_1e3=np.mean(dp > 1e-3))
+    measured("G17_adaptive_rec1_full", **m)
+    assert m["y_rms"] < TOL_RMS and m["y_tail_rms"] < TOL_RMS
+    assert m["y_rms"] < 1e-5 and m["y_tail_rms"] < 1e-5
+    assert max(m["Rvv_relmax"], m["Rvv_relmax_t1"], m["Rvv_relmax_t500"], m["Rvv_relmax_t1000"]) < 5e-5
+    assert m["mcra_p_frac_gt_1e3"] < 0.002
+
+
+def test_long_recording_gsc(ds):
+    g, x = load("g17_gsc_rec1_full"), as_float(load("g17_rec1_full")["x"])
+    gsc = ds.GSC(_mic(ds, 4, 512, 0.032), frameLen=512, angle=[197, 0])
+    y = gsc.process(x, ANGLE, method=2)["data"]
+    m = dict(y_rms=rms(y - g["y"]), y_tail_rms=rms(_tail(y - g["y"])), y_ref_rms=rms(g["y"]),
+             G_aic_rel_rms=rms(gsc.G - g["G"]) / rms(g["G"]))
+    measured("G17_gsc_rec1_full", **m)
+    assert m["y_rms"] < TOL_RMS and m["y_tail_rms"] < TOL_RMS
+    assert m["G_aic_rel_rms"] < 1e-2
+
+
+def test_long_recording_subband_gsc(ds):
+    g, x = load("g17_subbandgsc_rec1_full"), as_float(load("g17_rec1_full")["x"])
+    sg = ds.SubbandGSC(ds.MicArray(arrayType="circular", r=0.032, M=4, n_fft=512), frameLen=256, angle=[197, 0])
+    out, fix, bm, p, al = sg.process(x)
+    m = dict(output_rms=rms(out - g["output"]), output_tail_rms=rms(_tail(out - g["output"])), output_ref_rms=rms(g["output"]),
+             fix_rms=rms(fix - g["fix_output"]), bm_rms=rms(bm[:, ::4] - g["bm_output"]), p_max=np.max(np.abs(p - g["p"])))
+    measured("G17_subbandgsc_rec1_full", **m)
+    assert m["output_rms"] < TOL_RMS and m["output_tail_rms"] < TOL_RMS and m["fix_rms"] < TOL_RMS and m["bm_rms"] < TOL_RMS
+
+
+def test_an101_eight_channel_recording(ds):
+    """the reference's 8-microphone recording through adaptivebeamfomer at 1024 / 512 (BASELINE config 4's array size on real audio;
+    the array is built as example/run_postfilter.py builds it) and through the Wpe mirror on the same grid (patched reference: R6, R7)."""
+    g = load("g18_adaptive_an101")
+    M, nfft, hop, method = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    mic = ds.MicArray(arrayType="linear", r=float(g["r"]), M=M, n_fft=nfft)
+    ab = ds.adaptivebeamfomer(mic, frameLen=nfft, hop=hop, nfft=nfft)
+    y = np.concatenate([ab.process(x[:, t * hop:(t + 1) * hop], ANGLE, method=method)["data"] for t in range(x.shape[1] // hop)])
+    m = dict(y_rms=rms(y - g["y"]), y_ref_rms=rms(g["y"]), Rvv_relmax=relmax(ab.Rvv, g["Rvv"]), H_rel_rms=rms(ab.H - g["H"]) / rms(g["H"]))
+    gw = load("g18_wpe_an101")
+    C, N, D, nb, whop = [int(v) for v in gw["params"]]
+    wpe = ds.Wpe(channels=C, filter_len=N, num_bands=nb, delay=D, hop_length=whop)
+    xt = x.T
+    yw = np.concatenate([wpe.update(xt[n:n + whop])[0] for n in range(0, xt.shape[0], whop)])
+    m.update(wpe_y_rms=rms(yw - gw["y"]), wpe_y_ref_rms=rms(gw["y"]), wpe_W_rel_rms=rms(wpe.W - gw["W"]) / rms(gw["W"]))
+    measured("G18_an101", **m)
+    assert m["y_rms"] < TOL_RMS and m["Rvv_relmax"] < 5e-5
+    assert m["wpe_y_rms"] < TOL_RMS and m["wpe_W_rel_rms"] < 1e-3
+
+
 def test_realtime_pcm16_wire_format(ds):
     """the realtime shell's chunk format (realtime/realtime_processing.py:113-136): int16 interleaved 6-channel frames,
     microphones in channels 1..4, chunk = 1024 samples; GPU-side conversion == the shell's numpy conversion + process()."""

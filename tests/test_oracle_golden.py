@@ -330,3 +330,61 @@ def test_transform_custom_window(golden):
     Y = t.stft(g["x"])
     assert np.array_equal(Y.astype(np.complex64), g["Y"])
     assert np.allclose(t.istft(Y), g["y"], rtol=1e-7, atol=1e-9)
+
+
+# ---- the reference's whole recording (26.7 s, 1 670 hops) and its real 8-channel recording ----------------------
+def _last(a, hops, hop=256):
+    return a[-hops * hop:]
+
+
+def test_long_adaptive_mvdr(golden):
+    g, x = golden("g17_adaptive_rec1_full"), golden("g17_rec1_full")["x"].astype(np.float32) / 32768.0
+    ab = O.OracleAdaptiveMVDR(_mic(4, 512), frameLen=512, hop=256, nfft=512)
+    T = x.shape[1] // 256
+    ys = []
+    for t in range(T):                                        # hop by hop, for the state snapshots
+        ys.append(ab.process(x[:, t * 256:(t + 1) * 256], ANGLE, method=2))
+        if t in (1, 500, 1000):
+            assert np.allclose(ab.Rvv, g["Rvv_t%d" % t], rtol=2e-6, atol=1e-12), t          # fixture stores complex64
+            assert np.allclose(ab.mcra.p, g["p_t%d" % t], rtol=1e-6, atol=1e-9), t
+    y = np.concatenate(ys)
+    assert rms(y - g["y"]) < 2e-7 * rms(g["y"]) and rms(_last(y - g["y"], 200)) < 2e-7 * rms(_last(g["y"], 200))   # float32 storage
+    assert np.allclose(ab.Rvv, g["Rvv"], rtol=1e-9, atol=1e-14) and np.allclose(ab.mcra.p, g["mcra_p"], rtol=1e-10, atol=1e-14)
+
+
+def test_long_gsc(golden):
+    g, x = golden("g17_gsc_rec1_full"), golden("g17_rec1_full")["x"].astype(np.float32) / 32768.0
+    gsc = O.OracleGSC(_mic(4, 512), frameLen=512)
+    y = gsc.process(x, ANGLE, method=2)
+    assert rms(y - g["y"]) < 2e-7 * rms(g["y"]) and rms(_last(y - g["y"], 200)) < 2e-7 * rms(_last(g["y"], 200))
+    assert np.allclose(gsc.G, g["G"], rtol=1e-7, atol=1e-10) and np.allclose(gsc.spp.p, g["spp_p"], rtol=1e-6, atol=1e-9)
+
+
+def test_long_subband_gsc(golden):
+    g, x = golden("g17_subbandgsc_rec1_full"), golden("g17_rec1_full")["x"].astype(np.float32) / 32768.0
+    sg = O.OracleSubbandGSC(_mic(4, 512), 256, (197, 0))
+    out, fix, bm, p, al = sg.process(x)
+    assert rms(out - g["output"]) < 1e-6 * rms(g["output"]) and rms(_last(out - g["output"], 200)) < 1e-6 * rms(_last(g["output"], 200))
+    assert rms(fix - g["fix_output"]) < 1e-6 * rms(g["fix_output"]) and rms(bm[:, ::4] - g["bm_output"]) < 1e-6 * rms(g["bm_output"])
+    assert np.max(np.abs(p - g["p"])) < 1e-5
+
+
+def test_an101_adaptive_mvdr_8_channels(golden):
+    g = golden("g18_adaptive_an101")
+    M, nfft, hop, method = [int(v) for v in g["params"]]
+    x = g["x"].astype(np.float32) / 32768.0
+    ab = O.OracleAdaptiveMVDR(_mic(M, nfft, r=float(g["r"]), atype="linear"), frameLen=nfft, hop=hop, nfft=nfft)
+    y = ab.process(x, ANGLE, method=method)
+    assert rms(y - g["y"]) < 1e-7 * rms(g["y"])
+    assert np.allclose(ab.Rvv, g["Rvv"], rtol=1e-9, atol=1e-14) and np.allclose(ab.H, g["H"], rtol=1e-5, atol=1e-7)
+
+
+def test_an101_wpe_8_channels(golden):
+    """BASELINE config 4's WPE shape (8 channels x 2 taps, 1024/512) on the real recording, against the *patched* reference (R6, R7)."""
+    g, x = golden("g18_wpe_an101"), golden("g18_adaptive_an101")["x"].astype(np.float32) / 32768.0
+    C, N, D, nb, hop = [int(v) for v in g["params"]]
+    wpe = O.OracleWpe(channels=C, filter_len=N, num_bands=nb, delay=D, hop_length=hop)
+    xt = x.T
+    y = np.concatenate([wpe.update(xt[n:n + hop])[0] for n in range(0, xt.shape[0], hop)])
+    assert rms(y - g["y"]) < 1e-7 * rms(g["y"])
+    assert np.allclose(wpe.W, g["W"], rtol=2e-6, atol=1e-9)
