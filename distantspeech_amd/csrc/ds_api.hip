@@ -372,6 +372,13 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
+    {   // DS_PIPE_MIN_T=<hops>: calls of at least that many hops take the hop-pipelined frame kernel (ds_pipe.hpp).  Off by default: it is
+        // bit-identical and measured SLOWER (cfg2, 625 hops per call: 193 against 216 M frames/s; profiles/r03b/pipe_ab.txt and
+        // DESIGN.md section 3, "Hop-level software pipeline") — kept as an opt-in experiment with its tests
+        const char* e = getenv("DS_PIPE_MIN_T");
+        const int v = e ? atoi(e) : 0;
+        h->pipe_min_T = v > 0 ? v : 0x7fffffff;
+    }
     h->alpha_y = cfg->alpha_y > 0 ? cfg->alpha_y : 0.8f;
     h->alpha_v = cfg->alpha_v > 0 ? cfg->alpha_v : 0.9998f;
     h->diag = cfg->diag > 0 ? cfg->diag : 1e-6f;
@@ -736,7 +743,9 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
     p.T = n_samples / h->cfg.hop;
     p.batch0 = first;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    DS_HIP(h, h->ki.launch(p, count, s));
+    // calls of several hops: the hop-pipelined kernel (same results bit for bit; at one or two hops per call it has nothing to overlap)
+    const ds::launch_fn launch = (h->ki.launch_pipe && p.T >= h->pipe_min_T) ? h->ki.launch_pipe : h->ki.launch;
+    DS_HIP(h, launch(p, count, s));
     return DS_OK;
 }
 

@@ -426,79 +426,100 @@ template <int PAD> DS_HD int padi(int i) {
 // constant; a displacement that stays inside i's own run of 16 leaves it alone (the caller guarantees which case holds)
 template <int PAD> DS_HD constexpr int pad_step16(int d) { return PAD == 1 ? d + (d >> 4) : PAD == 2 ? d + ((d >> 4) << 2) : d; }
 
-template <int NFFT, int M, int R, int SIGN, int FROM, int PIN, int POUT, class ShT>
-DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, int old_half, int MCH) {
+// One butterfly job of a stage = (channel ch, butterfly j).  fft_load brings its R inputs and the stage's twiddle pair into registers;
+// fft_finish applies the twiddles and the butterfly and writes the R outputs.  fft_stage runs the two back to back for every job of a
+// thread; the hop-pipelined engine (ds_pipe.hpp) runs other work between them and transforms in place (the whole channel is in its
+// wave's registers between the two halves).
+template <int NFFT, int R, int SIGN, int FROM, int PIN, class ShT>
+DS_HD void fft_load(ShT& sh, const cf* in, int ch, int j, int Ns, int old_half, cf* v, vec4& wv) {
     constexpr bool FROM_X = FROM == 1;
     constexpr int NC = NFFT / 2, NB = NC / R, HOP = NFFT / 2, NCP = ShT::NCP;
     static_assert(NB % 16 == 0, "the inputs of a butterfly are NB apart: a constant step in a padded buffer");
     constexpr int RSTEP = pad_step16<PIN>(NB);
+    // the R inputs of butterfly j sit at n = j + r NB: one address, constant steps
+    if constexpr (FROM_X) {
+        static_assert(R == 4 || R == 2, "radix");
+        const int s0 = 2 * j;                                               // s = s0 + r * 2 NB; 2 NB = HOP / 2 (R = 4) or HOP (R = 2)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int s = s0 + r * 2 * NB;
+            const bool first = r * 2 * NB + 2 * NB <= HOP;                  // compile-time: the whole range of s for this r is below HOP
+            const int pos = first ? old_half * HOP + s : (old_half ^ 1) * HOP + (s - HOP);
+            v[r] = mk(sh.tb.win[s] * sh.xbuf[ch][pos], sh.tb.win[s + 1] * sh.xbuf[ch][pos + 1]);
+        }
+    } else if constexpr (FROM == 2) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int n = j + r * NB;
+            const cf* Yb = in;                                          // the output spectrum Y[0 .. NC]
+            const cf A = Yb[n];
+            cf S, Dm;                                               // A + conj(B), A - conj(B), B = Y[NC - n]
+            if (NC == 256 && r == 0) {                              // NC == 256: the Nyquist bin (n = 0's partner) is added later: B = 0 there
+                const cf Bc = n == 0 ? mk(0.0f, 0.0f) : cconj(Yb[NC - n]);
+                S = cadd(A, Bc); Dm = csub(A, Bc);
+            } else {
+                const cf B = Yb[NC - n];
+                S = cadd_c(A, B); Dm = csub_c(A, B);
+            }
+            const cf E = cscale(S, 0.5f);
+            const cf O = cmul(cscale(Dm, 0.5f), cconj(sh.tb.tw[n]));
+            v[r] = cadd_jd<+1>(E, O);                               // E + j O
+        }
+    } else {
+        const cf* rp = in + ch * NCP + padi<PIN>(j);
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = rp[r * RSTEP];
+    }
+    if (Ns > 1) wv = sh.tb.stw[Ns + (j & (Ns - 1))];        // consecutive lanes -> consecutive k: conflict-free
+}
+
+template <int NFFT, int R, int SIGN, int POUT, class ShT>
+DS_HD void fft_finish(ShT&, cf* out, int ch, int j, int Ns, cf* v, const vec4& wv) {
+    constexpr int NCP = ShT::NCP;
+    const int k = j & (Ns - 1);
+    if (Ns > 1) {
+        cf w1 = mk(wv.x, wv.y);
+        if (SIGN > 0) w1 = cconj(w1);
+        if constexpr (R == 4) {
+            cf w2 = mk(wv.z, wv.w);
+            if (SIGN > 0) w2 = cconj(w2);
+            cf w3 = cmul(w1, w2);
+            v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3);
+        } else {
+            v[1] = cmul(v[1], w1);
+        }
+    }
+    butterfly<R, SIGN>(v);
+    // the R outputs sit at j0 + r Ns, j0 = (j - k) R + k: Ns a multiple of 16 is a constant step in a padded buffer; for Ns R <= 16 the
+    // R outputs share j0's run of 16 (j0 - k is a multiple of Ns R, which divides 16), so the padding term does not move
+    const int j0 = (j - k) * R + k;
+    cf* wp = out + ch * NCP + padi<POUT>(j0);
+    if (POUT == 0 || (Ns & 15) == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) wp[pad_step16<POUT>(r * Ns)] = v[r];
+    } else if (Ns * R <= 16) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) wp[r * Ns] = v[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[ch * NCP + padi<POUT>(j0 + r * Ns)] = v[r];
+    }
+}
+
+template <int NFFT, int M, int R, int SIGN, int FROM, int PIN, int POUT, class ShT>
+DS_HD void fft_stage(int tid, int nt, ShT& sh, const cf* in, cf* out, int Ns, int old_half, int MCH) {
+    constexpr int NC = NFFT / 2, NB = NC / R;
     DS_ASSUME(tid >= 0 && tid < nt);                                     // a one-trip loop where MCH * NB <= nt: no loop-carried addresses
     for (int idx = tid; idx < MCH * NB; idx += nt) {
         // (unsigned: the split into channel and butterfly is a shift and a mask, and j's range is known to the compiler)
         const int ch = (int)((unsigned)idx / (unsigned)NB), j = (int)((unsigned)idx % (unsigned)NB);
-        const int k = j & (Ns - 1);
         cf v[R];
-        // the R inputs of butterfly j sit at n = j + r NB: one address, constant steps
-        if constexpr (FROM_X) {
-            static_assert(R == 4 || R == 2, "radix");
-            const int s0 = 2 * j;                                               // s = s0 + r * 2 NB; 2 NB = HOP / 2 (R = 4) or HOP (R = 2)
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int s = s0 + r * 2 * NB;
-                const bool first = r * 2 * NB + 2 * NB <= HOP;                  // compile-time: the whole range of s for this r is below HOP
-                const int pos = first ? old_half * HOP + s : (old_half ^ 1) * HOP + (s - HOP);
-                v[r] = mk(sh.tb.win[s] * sh.xbuf[ch][pos], sh.tb.win[s + 1] * sh.xbuf[ch][pos + 1]);
-            }
-        } else if constexpr (FROM == 2) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int n = j + r * NB;
-                const cf A = sh.Y[n];
-                cf S, Dm;                                               // A + conj(B), A - conj(B), B = Y[NC - n]
-                if (NC == 256 && r == 0) {                              // NC == 256: the Nyquist bin (n = 0's partner) is added later: B = 0 there
-                    const cf Bc = n == 0 ? mk(0.0f, 0.0f) : cconj(sh.Y[NC - n]);
-                    S = cadd(A, Bc); Dm = csub(A, Bc);
-                } else {
-                    const cf B = sh.Y[NC - n];
-                    S = cadd_c(A, B); Dm = csub_c(A, B);
-                }
-                const cf E = cscale(S, 0.5f);
-                const cf O = cmul(cscale(Dm, 0.5f), cconj(sh.tb.tw[n]));
-                v[r] = cadd_jd<+1>(E, O);                               // E + j O
-            }
-        } else {
-            const cf* rp = in + ch * NCP + padi<PIN>(j);
-#pragma unroll
-            for (int r = 0; r < R; ++r) v[r] = rp[r * RSTEP];
-        }
-        if (Ns > 1) {
-            const vec4 wv = sh.tb.stw[Ns + k];                  // consecutive lanes -> consecutive k: conflict-free
-            cf w1 = mk(wv.x, wv.y);
-            if (SIGN > 0) w1 = cconj(w1);
-            if constexpr (R == 4) {
-                cf w2 = mk(wv.z, wv.w);
-                if (SIGN > 0) w2 = cconj(w2);
-                cf w3 = cmul(w1, w2);
-                v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3);
-            } else {
-                v[1] = cmul(v[1], w1);
-            }
-        }
-        butterfly<R, SIGN>(v);
-        // the R outputs sit at j0 + r Ns, j0 = (j - k) R + k: Ns a multiple of 16 is a constant step in a padded buffer; for Ns R <= 16 the
-        // R outputs share j0's run of 16 (j0 - k is a multiple of Ns R, which divides 16), so the padding term does not move
-        const int j0 = (j - k) * R + k;
-        cf* wp = out + ch * NCP + padi<POUT>(j0);
-        if (POUT == 0 || (Ns & 15) == 0) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) wp[pad_step16<POUT>(r * Ns)] = v[r];
-        } else if (Ns * R <= 16) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) wp[r * Ns] = v[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; ++r) out[ch * NCP + padi<POUT>(j0 + r * Ns)] = v[r];
-        }
+        vec4 wv;
+        wv.x = wv.y = wv.z = wv.w = 0.0f;
+        const cf* src = in;
+        if constexpr (FROM == 2) src = reinterpret_cast<const cf*>(&sh.Y[0]);       // the inverse merge reads the output spectrum
+        fft_load<NFFT, R, SIGN, FROM, PIN>(sh, src, ch, j, Ns, old_half, v, wv);
+        fft_finish<NFFT, R, SIGN, POUT>(sh, out, ch, j, Ns, v, wv);
     }
 }
 
@@ -741,6 +762,61 @@ template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag
     return mk((float)(utx * inv), (float)(uty * inv));
 }
 #else
+// The same sweep as a resumable object (init, one column at a time, finish) for the hop-pipelined engine (ds_pipe.hpp), which runs the
+// columns between the stages of the neighbouring hops' transforms.  The operations and their order are mvdr_output()'s, word for word
+// (bit-identical results: tests/test_kernel_emul.py::test_emul_pipelined_engine_equals_the_frame_engine and its GPU twin).
+template <int M> struct MvdrSweep {
+    float Ad[M];
+    cf Al[M * (M - 1) / 2 + 1];          // strictly-lower A_ij (i>j) at off_index(j, i)
+    cf u[M], t[M];
+    float nu;
+    cf ut;
+    DS_HD void init(const float* d, const float* o, float diag, const cf* a, const cf* z) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) { Ad[i] = d[i] + diag; u[i] = a[i]; t[i] = z[i]; }
+#pragma unroll
+        for (int q = 0; q < M * (M - 1) / 2; ++q) Al[q] = mk(o[2 * q], -o[2 * q + 1]);   // A_ij = conj(R_ji)
+        nu = 0.0f;
+        ut = mk(0.0f, 0.0f);
+    }
+    DS_HD void column(int j) {
+        const float sj = fmaxf_(Ad[j], 1e-30f);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const float r = rsqrtf(sj);
+#else
+        const float r = 1.0f / sqrtf(sj);
+#endif
+        const cf uj = cscale(u[j], r), tj = cscale(t[j], r);
+        nu = fma_(uj.x, uj.x, fma_(uj.y, uj.y, nu));
+        ut = cfmac(ut, tj, uj);                                  // += conj(u_j) t_j
+        cf Lc[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            if (i > j) {
+                Lc[i] = cscale(Al[off_index(j, i, M)], r);
+                u[i] = cfnma(u[i], Lc[i], uj);
+                t[i] = cfnma(t[i], Lc[i], tj);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            if (i > j) {
+                Ad[i] = fma_(-Lc[i].x, Lc[i].x, fma_(-Lc[i].y, Lc[i].y, Ad[i]));
+#pragma unroll
+                for (int k = 0; k < M; ++k) {
+                    if (k > j && k < i) {
+                        const int q = off_index(k, i, M);
+                        Al[q] = cfnmac(Al[q], Lc[i], Lc[k]);             // A_ik -= L_ij conj(L_kj)
+                    }
+                }
+            }
+        }
+    }
+    DS_HD cf finish() const {
+        const float inv = rcp_(nu);
+        return mk(ut.x * inv, ut.y * inv);
+    }
+};
 template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag, const cf* a, const cf* z) {
     float Ad[M];
     cf Al[M * (M - 1) / 2 + 1];          // strictly-lower A_ij (i>j) at off_index(j, i)

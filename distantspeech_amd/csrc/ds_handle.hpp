@@ -111,6 +111,7 @@ struct ds_handle {
     float* y_stage;
     size_t x_stage_elems, y_stage_elems;
     // params
+    int pipe_min_T;             // fused frame kernels: calls of at least this many hops run the hop-pipelined kernel (ds_pipe.hpp) where one exists
     int method;
     int mcra_L;
     float alpha_y, alpha_v, diag, gate, mu, out_scale;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ds_core.hpp"
+#include "ds_pipe.hpp"
 
 namespace ds {
 
@@ -14,6 +15,7 @@ struct KernelInfo {
     int KP;   // padded plane length
     int NT;   // threads per block
     int NF = 0;   // state floats per bin (in memory: NF KP floats per utterance, see StateLayout)
+    launch_fn launch_pipe = nullptr;   // the same frame program as a hop-level software pipeline (ds_pipe.hpp; 512-point frames): calls of several hops
 };
 
 // lookups implemented in ds_kernels_*.hip; launch == nullptr when the combination is not compiled
@@ -49,14 +51,17 @@ struct FdafParams;
 hipError_t launch_fdaf(const FdafParams& p, int nfft, hipStream_t stream);   // ds_kernels_fdaf.hip
 
 #if defined(__HIPCC__)
-template <class Rg> struct HipExec {
+// HOIST = false: the thread id is laundered through an empty asm at the start of every phase, so that per-thread LDS addresses are
+// recomputed inside each phase instead of being hoisted out of the frame loop and kept live in VGPRs for the whole kernel.  HOIST = true
+// leaves the id alone: the compiler hoists the loop-invariant address arithmetic of every phase out of the hop loop (4-microphone MVDR
+// kernel: 809 -> 622 vector instructions per hop, 94 -> 127 registers — still four waves per SIMD; +8 % with 10 s per call, +4 % at one
+// hop per call, profiles/r03b/hoist_ab.txt).  Which kernels can afford the registers: frames_hoist() below.
+#define DS_LAUNDER(tid) do { if constexpr (!HOIST) asm volatile("" : "+v"(tid)); } while (0)
+template <class Rg, bool HOIST = false> struct HipExec {
     Rg r;
     template <class F> __device__ __forceinline__ void phase(F f) {
-        // The thread id is laundered through an empty asm so that per-thread LDS addresses are recomputed
-        // inside each phase instead of being hoisted out of the frame loop and kept live in VGPRs for the
-        // whole kernel (that hoisting cost ~60 VGPRs and a block of occupancy).
         int tid = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid));
+        DS_LAUNDER(tid);
         f(tid, r);
         __syncthreads();
     }
@@ -64,12 +69,33 @@ template <class Rg> struct HipExec {
     // executes one wave's accesses in order, the fence keeps the compiler from moving them across the phase boundary
     template <class F> __device__ __forceinline__ void phase_wave(F f) {
         int tid = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid));
+        DS_LAUNDER(tid);
         f(tid, r);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // a wave-local phase in two halves: `load` reads LDS into registers, `rest` computes and writes — possibly over what other lanes of the
+    // same wave have just read (in-place transform stages: the LDS executes a wave's accesses in order, and the stores depend on the
+    // loads).  Here the halves simply follow each other, so the scheduler can run `rest`'s independent arithmetic under the loads' latency;
+    // the CPU emulator runs `load` for every thread before `rest` for any.
+    template <class FL, class FR> __device__ __forceinline__ void phase_wave2(FL fl, FR fr) {
+        int tid = (int)threadIdx.x;
+        DS_LAUNDER(tid);
+        fl(tid, r);
+        fr(tid, r);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    template <class FL, class FR> __device__ __forceinline__ void phase2(FL fl, FR fr) {      // the same, ending in a workgroup barrier
+        int tid = (int)threadIdx.x;
+        DS_LAUNDER(tid);
+        fl(tid, r);
+        fr(tid, r);
+        __syncthreads();
+    }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
 };
 
 // waves per SIMD the register allocator must leave room for.  The 4-microphone kernels live at the 128-VGPR step (4 waves / SIMD = 4
@@ -78,6 +104,15 @@ template <class Rg> struct HipExec {
 // is gone: -25 %) and is pinned too; larger arrays keep the allocator's own choice.
 // The 6-microphone SubbandGSC tail (ALGO_AIC) holds three workgroups per CU by its LDS; with the packed complex products the allocator
 // took 172 registers (two waves per SIMD) where 168 keep the third: pinned as well.
+// frame kernels whose register budget has room for the hoisted addresses at unchanged occupancy (measured per shape with
+// -Rpass-analysis=kernel-resource-usage: the GSC kernel spills, the 6- and 8-microphone kernels lose a wave per SIMD)
+constexpr bool frames_hoist(int nfft, int M, int algo, bool ryy) {
+#if defined(DS_NO_HOIST)
+    return false;
+#else
+    return nfft <= 512 && M <= 4 && ((algo == ALGO_ADAPTIVE && !ryy) || algo == ALGO_FIXED);
+#endif
+}
 constexpr int frames_min_waves(int M, int algo) {
     return (M <= 4 && (algo == ALGO_GSC || algo == ALGO_ADAPTIVE)) ? 4 : (M == 6 && algo == ALGO_AIC) ? 3 : 1;
 }
@@ -86,7 +121,7 @@ template <int NFFT, int M, int ALGO, bool RYY>
 __global__ void __launch_bounds__(NFFT / 2, frames_min_waves(M, ALGO)) ds_frames_kernel(Params p) {
     typedef Engine<NFFT, M, ALGO, RYY> E;
     __shared__ typename E::Sh sh;
-    HipExec<typename E::Rg> ex;
+    HipExec<typename E::Rg, frames_hoist(NFFT, M, ALGO, RYY)> ex;
     if constexpr (ALGO == ALGO_AIC) {                    // a stage of a chain: an earlier stage's counter advance rides in this launch
         if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
     }
@@ -100,11 +135,29 @@ hipError_t launch_frames(const Params& p, int nblocks, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// the hop-pipelined form of the same program (ds_pipe.hpp): same state, same arguments, same results bit for bit
+template <int NFFT, int M, int ALGO, bool RYY>
+__global__ void __launch_bounds__(NFFT / 2, frames_min_waves(M, ALGO)) ds_frames_pipe_kernel(Params p) {
+    typedef PipeEngine<NFFT, M, ALGO, RYY> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+
+template <int NFFT, int M, int ALGO, bool RYY>
+hipError_t launch_frames_pipe(const Params& p, int nblocks, hipStream_t stream) {
+    typedef PipeEngine<NFFT, M, ALGO, RYY> E;
+    hipLaunchKernelGGL((ds_frames_pipe_kernel<NFFT, M, ALGO, RYY>), dim3(nblocks), dim3(E::NT), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <int NFFT, int M, int ALGO, bool RYY> KernelInfo make_info() {
     typedef Engine<NFFT, M, ALGO, RYY> E;
     KernelInfo ki;
     ki.launch = &launch_frames<NFFT, M, ALGO, RYY>;
     ki.NP = E::NP; ki.NF = E::SL::NF; ki.KP = E::KP; ki.NT = E::NT;
+    if constexpr (NFFT == 512 && (ALGO == ALGO_FIXED || ALGO == ALGO_ADAPTIVE || ALGO == ALGO_GSC) && M <= 4)
+        ki.launch_pipe = &launch_frames_pipe<NFFT, M, ALGO, RYY>;
     return ki;
 }
 

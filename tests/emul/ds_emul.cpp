@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../distantspeech_amd/csrc/ds_core.hpp"
+#include "../../distantspeech_amd/csrc/ds_pipe.hpp"
 #include "../../distantspeech_amd/csrc/ds_ops.hpp"
 #include "../../distantspeech_amd/csrc/ds_quad.hpp"
 #include "../../distantspeech_amd/csrc/ds_tables.hpp"
@@ -21,12 +22,42 @@ template <class Rg> struct CpuExec {
         for (int t = 0; t < nt; ++t) f(t, R[t]);
     }
     template <class F> void phase_wave(F f) { phase(f); }       // wave-local hand-off: the same thing when run serially
+    // two-part phases (in-place transform stages of the hop-pipelined engine): every thread's loads before any thread's stores
+    template <class FL, class FR> void phase_wave2(FL fl, FR fr) { phase(fl); phase(fr); }
+    template <class FL, class FR> void phase2(FL fl, FR fr) { phase(fl); phase(fr); }
+    void sync() {}
 };
 
+static int g_pipe_runs = 0;  // calls served by ds::PipeEngine (the test checks that the switch took effect)
+static int g_pipe = 0;       // emul_set_pipe(1): 512-point frame programs run as ds::PipeEngine (ds_pipe.hpp) instead of ds::Engine
+
+
+template <class E> int run_engine_blob(ds::Params p, int batch, int nfft);
 template <int NFFT, int M, int ALGO, bool RYY> int run_t(ds::Params p, int batch) {
+    if constexpr (NFFT == 512 && ALGO != ds::ALGO_AIC) {
+        if (g_pipe) { ++g_pipe_runs; return run_engine_blob<ds::PipeEngine<NFFT, M, ALGO, RYY>>(p, batch, NFFT); }
+    }
     typedef ds::Engine<NFFT, M, ALGO, RYY> E;
     std::vector<float> blob;
     ds::make_table_blob(NFFT, NFFT / 2, blob, p.out_scale);
+    std::vector<ds::vec4> blob4(blob.size() / 4);
+    std::memcpy((void*)blob4.data(), blob.data(), blob.size() * sizeof(float));
+    p.tables = blob4.data();
+    typename E::Sh* sh = new typename E::Sh();
+    for (int b = 0; b < batch; ++b) {
+        CpuExec<typename E::Rg> ex;
+        ex.nt = E::NT;
+        ex.R.resize(E::NT);
+        std::memset((void*)ex.R.data(), 0, sizeof(typename E::Rg) * E::NT);
+        E::run(ex, p, b, *sh);
+    }
+    delete sh;
+    return 0;
+}
+
+template <class E> int run_engine_blob(ds::Params p, int batch, int nfft) {
+    std::vector<float> blob;
+    ds::make_table_blob(nfft, nfft / 2, blob, p.out_scale);
     std::vector<ds::vec4> blob4(blob.size() / 4);
     std::memcpy((void*)blob4.data(), blob.data(), blob.size() * sizeof(float));
     p.tables = blob4.data();
@@ -177,6 +208,8 @@ int emul_istft(int nfft, int M, int batch, const float* Y, int T, int C, float* 
 // OpParams fields outside emul_op's argument list (set before the call, sticky)
 static int g_repeat = 0, g_two_path = 0;
 void emul_set_repeat(int on) { g_repeat = on; }
+void emul_set_pipe(int on) { g_pipe = on; }
+int emul_pipe_runs() { return g_pipe_runs; }
 void emul_set_two_path(int on) { g_two_path = on; }
 
 // frame-level operators: serial loop over (b, k) of ds::run_op

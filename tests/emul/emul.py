@@ -16,7 +16,8 @@ SRCS = [os.path.join(HERE, "ds_emul.cpp"), os.path.join(ROOT, "distantspeech_amd
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_ops.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tables.hpp"),
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tdfilter.hpp"),
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_fdaf.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_wpe.hpp"),
-        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_linalg64.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_quad.hpp")]
+        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_linalg64.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_quad.hpp"),
+        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_pipe.hpp")]
 
 
 def build(force=False):
@@ -36,6 +37,11 @@ def lib():
         _lib.emul_layout.restype = ctypes.c_int
         _lib.emul_run.restype = ctypes.c_int
     return _lib
+
+
+def set_pipe(on):
+    """512-point frame programs as the hop-pipelined engine (ds_pipe.hpp) instead of the phase-by-phase one (ds_core.hpp)."""
+    lib().emul_set_pipe(int(bool(on)))
 
 
 class EmulEngine:

@@ -167,6 +167,43 @@ def test_per_utterance_look_directions(ds):
         assert rms(y[b] - ref) < 1e-5
 
 
+@pytest.mark.parametrize("algo_name,M,method,ryy", [("ADAPTIVE", 4, 2, False), ("ADAPTIVE", 4, 3, True), ("ADAPTIVE", 4, 1, False),
+                                                   ("ADAPTIVE", 2, 2, False), ("GSC", 4, 2, False), ("FIXED", 4, 2, False)])
+def test_pipelined_kernel_equals_frame_kernel(ds, monkeypatch, algo_name, M, method, ryy):
+    """Calls of several hops run the hop-pipelined form of the frame program (ds_pipe.hpp: the forward transforms of hop s + 1, the per-bin
+    program of hop s in four parts, the inverse transform of hop s - 1 and the overlap-add of hop s - 2 in the same wave-local phases,
+    transforms in place).  DS_PIPE_MIN_T (read at ds_create) moves the switch: the pipelined kernel for EVERY call (1) against never
+    (a huge value) — the same samples and the same exported state bit for bit, one call and chunked (1, 2, 3 hops and the rest), both
+    input layouts."""
+    from distantspeech_amd import _lib as L
+    nfft, hop, B, T = 512, 256, 6, 37
+    algo = getattr(L, "ALGO_" + algo_name)
+    omic = oracle_mic(M, nfft)
+    x = np.stack([O.synth_utterance(90 + b, hop * T, omic) * (0.2 if algo_name == "GSC" else 1.0) for b in range(B)]).astype(np.float32)
+    a = steering(M, nfft, omic.r)
+
+    def run(min_t, cuts, layout):
+        monkeypatch.setenv("DS_PIPE_MIN_T", str(min_t))
+        eng = ds.BatchEngine(algo, M, nfft, batch=B, track_ryy=ryy) if algo_name == "ADAPTIVE" else ds.BatchEngine(algo, M, nfft, batch=B)
+        eng.set_steering(a / M if algo_name == "FIXED" else a)
+        if algo_name != "FIXED":
+            eng.set_method(method)
+        xs = x if layout == L.LAYOUT_CHANNELS_SAMPLES else np.ascontiguousarray(x.transpose(0, 2, 1))
+        ys = [eng.process(xs[:, :, c0 * hop:c1 * hop] if layout == L.LAYOUT_CHANNELS_SAMPLES else xs[:, c0 * hop:c1 * hop], layout)
+              for c0, c1 in zip(cuts[:-1], cuts[1:])]
+        return np.concatenate(ys, axis=1), eng.export_state()
+
+    y0, s0 = run(1 << 30, [0, T], L.LAYOUT_CHANNELS_SAMPLES)
+    assert np.all(np.isfinite(y0)) and np.abs(y0).max() > 0
+    for cuts, layout in (([0, T], L.LAYOUT_CHANNELS_SAMPLES), ([0, 1, 3, 6, T], L.LAYOUT_CHANNELS_SAMPLES), ([0, T], L.LAYOUT_SAMPLES_CHANNELS),
+                         ([0, 2, T], L.LAYOUT_SAMPLES_CHANNELS)):
+        y1, s1 = run(1, cuts, layout)
+        assert np.array_equal(y1, y0) and np.array_equal(s1, s0), (cuts, layout)
+    if algo_name == "ADAPTIVE" and method == 2 and M == 4:                # and against the fp64 oracle
+        ref = O.OracleAdaptiveMVDR(omic, nfft).process(x[1], ANGLE, 2)
+        assert rms(y0[1] - ref) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------
 # edge cases and error behaviour
 # ------------------------------------------------------------------------------------------------

@@ -577,3 +577,41 @@ def test_emul_subband_gsc_chain(name):
     sc = {}
     out3 = emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, fused_tail="spectra", tail_state=sc)[0]
     assert np.array_equal(out3, out2) and all(np.array_equal(sb[k], sc[k]) for k in sb)     # bit for bit the tail fed with time samples
+
+
+@pytest.mark.parametrize("algo,M,method,ryy", [(1, 4, 2, False), (1, 4, 3, True), (1, 4, 1, False), (1, 2, 2, False), (1, 6, 2, False), (1, 8, 2, False),
+                                              (2, 4, 2, False), (2, 6, 2, False), (0, 4, 2, False)])
+def test_emul_pipelined_engine_equals_the_frame_engine(algo, M, method, ryy):
+    """ds_pipe.hpp (hop-level software pipeline: forward transforms of hop s + 1, per-bin program of hop s in four parts, inverse transform
+    of hop s - 1 and overlap-add of hop s - 2 in the same wave-local phases; in-place transforms) against ds_core.hpp's Engine: the same
+    samples and the same carried state bit for bit, for one long call, for chunked calls (1, 2, 3 hops and the rest) and for both
+    input layouts — the emulator runs a two-part phase as "every thread's loads, then every thread's stores", which is what makes the
+    in-place stages meaningful when run serially."""
+    from emul import emul
+    from oracle import ds_oracle as O
+    from _cases import oracle_mic
+    nfft, hop, T, B = 512, 256, 23, 2
+    omic = oracle_mic(M, nfft)
+    x = np.stack([O.synth_utterance(70 + b, hop * T, omic) * (0.2 if algo == 2 else 1.0) for b in range(B)]).astype(np.float32)
+    a = steering(M, nfft, omic.r)
+
+    def run(pipe, cuts, layout=1):
+        emul.set_pipe(pipe)
+        try:
+            e = EmulEngine(algo, nfft, M, B, ryy=ryy)
+            e.set_steering(a / M if algo == 0 else a)
+            e.method = method
+            xs = x if layout == 1 else np.ascontiguousarray(x.transpose(0, 2, 1))
+            ys = [e.process(xs[:, :, c0 * hop:c1 * hop] if layout == 1 else xs[:, c0 * hop:c1 * hop], layout) for c0, c1 in zip(cuts[:-1], cuts[1:])]
+        finally:
+            emul.set_pipe(0)
+        return np.concatenate(ys, axis=1), e.bins.copy(), e.tail_in.copy(), e.tail_out.copy(), e.counters.copy()
+
+    n0 = emul.lib().emul_pipe_runs()
+    ref = run(0, [0, T])
+    assert np.all(np.isfinite(ref[0])) and np.abs(ref[0]).max() > 0 and emul.lib().emul_pipe_runs() == n0
+    for cuts, layout in (([0, T], 1), ([0, 1, 3, 6, T], 1), ([0, T], 0), ([0, 2, T], 0)):
+        got = run(1, cuts, layout)
+        for u, v in zip(got, ref):
+            assert np.array_equal(u, v), (cuts, layout)
+    assert emul.lib().emul_pipe_runs() == n0 + 1 + 4 + 1 + 2         # every call above went through the pipelined engine
