@@ -187,6 +187,58 @@ class GpuBackend:
     def make(self, w, B, T, K, W, seed, graph, split=None):
         return GpuWorkload(self, w, B, T, K, W, seed, graph, split)
 
+    def latency(self, n_chunks=1500, warm=100):
+        """The reference's only service-level figure: the realtime shell must finish one 1024-sample chunk within its 64 ms
+        (realtime/realtime_processing.py:113-136, CHUNK = 1024 at 16 kHz).  ONE stream (B = 1), 4 microphones, 512 / 256, adaptive MVDR:
+        the shell's wire format through ds_process_pcm16 (int16 interleaved 6-channel frames in host memory, int16 out: PCIe both ways and
+        two synchronisations inside the timed call) and the same chunk through ds_process_device (device-resident float chunk; timed with
+        the stream synchronisation).  Median and p99 of the wall time per chunk."""
+        import numpy as np
+        import ctypes
+        from distantspeech_amd import BatchEngine, _lib as L
+        from distantspeech_amd.mic_array import MicArray
+        torch = self.torch
+        w = WORKLOADS["cfg2"]
+        M, nfft, hop, CH = w["M"], w["nfft"], w["hop"], 1024
+        mic = MicArray(arrayType="circular", r=w["r"], M=M, n_fft=nfft)
+        ang = np.array(ANGLE_DEG) / 180.0 * np.pi
+        tao = -1 * mic.r * np.cos(ang[1]) * np.cos(ang[0] - mic.gamma) / mic.c
+        a = np.exp(-1j * (2 * np.pi * np.arange(nfft // 2 + 1) * FS / nfft)[:, None] * tao[None, :])
+        rng = np.random.default_rng(7)
+        n = n_chunks + warm
+        pcm = (rng.standard_normal((n, CH, 6)) * 1500).astype("<i2")                  # [chunk][sample][6 channels], microphones in 1..4
+        out = {}
+        eng = BatchEngine(L.ALGO_ADAPTIVE, M, nfft, hop, batch=1, device=self.local_rank)
+        eng.set_steering(a); eng.set_method(L.METHOD_MVDR)
+        t = np.empty(n)
+        for i in range(n):
+            t0 = time.perf_counter()
+            eng.process_pcm16(pcm[i][None], first_channel=1)
+            t[i] = time.perf_counter() - t0
+        out["pcm16_host"] = t[warm:] * 1e6
+        eng.close()
+        eng = BatchEngine(L.ALGO_ADAPTIVE, M, nfft, hop, batch=1, device=self.local_rank)
+        eng.set_steering(a); eng.set_method(L.METHOD_MVDR)
+        xd = torch.tensor((pcm[:, :, 1:5].astype(np.float32) / 32768.0).transpose(0, 2, 1).copy(), device=self.device)   # [chunk][M][CH]
+        yd = torch.empty((n, CH), dtype=torch.float32, device=self.device)
+        self.device_sync()
+        for i in range(n):
+            t0 = time.perf_counter()
+            eng.process_device(xd[i].data_ptr(), L.LAYOUT_CHANNELS_SAMPLES, M * CH, CH, yd[i].data_ptr(), CH)
+            eng.synchronize()
+            t[i] = time.perf_counter() - t0
+        out["device"] = t[warm:] * 1e6
+        eng.close()
+        res = {"workload": "ONE stream (batch 1), adaptive MVDR, 4 mics, 512-FFT/256-hop, one 1024-sample chunk (4 hops) per call — the realtime "
+                           "shell's callback (realtime/realtime_processing.py:113-136)", "chunk_samples": CH, "chunk_ms_budget": CH / FS * 1e3,
+               "chunks_timed": n_chunks, "unit": "us per chunk (host wall clock around the call)"}
+        for k, v in out.items():
+            res[k] = {"median_us": round(float(np.median(v)), 1), "p99_us": round(float(np.percentile(v, 99)), 1), "max_us": round(float(v.max()), 1)}
+        res["pcm16_host"]["path"] = "ds_process_pcm16: int16 interleaved 6-channel frames in host memory in, int16 out (H2D, conversion kernel, frame kernel, conversion kernel, D2H)"
+        res["device"]["path"] = "ds_process_device + ds_synchronize: float chunk resident in HBM, output left in HBM"
+        res["realtime_factor_p99"] = round(res["chunk_ms_budget"] * 1e3 / res["pcm16_host"]["p99_us"], 1)
+        return res
+
 
 class GpuWorkload:
     """One engine handle + its resident input / output slabs; run(first_step, n) enqueues n successive steps."""
@@ -224,6 +276,10 @@ class GpuWorkload:
             if w["algo"] != "FIXED":
                 self.eng.set_method(L.METHOD_MVDR)
         be.device_sync()              # inputs resident before anything is launched on the engine's stream
+
+    def state_bytes(self):
+        """carried state of the handle as the library packs it (Hermitian / symmetric matrices as triangles), without the blob's header words"""
+        return self.eng.state_bytes()
 
     def run(self, first_step, n):
         L, T, hop, Ltot = self.L, self.T, self.hop, self.Ltot
@@ -285,23 +341,31 @@ def measure(be, dsdist, w, B, T, K, W, rank, world, min_region_ms, graph=None, m
     be.device_sync()
     elapsed = time.perf_counter() - t0
     wl.check(W)
+    state_bytes = wl.state_bytes() if hasattr(wl, "state_bytes") else 0
     frames_rank = B * K * T * R
     frames, t_max, ranks = dsdist.reduce_throughput(frames_rank, elapsed, device=getattr(be, "device", None))
     dev_ms = dsdist.reduce_max(dev_ms, device=getattr(be, "device", None))
     wl.close()
     launch_ms = dev_ms / (K * R)                               # average launch-to-launch duration on the kernel's stream (HIP events)
-    alg = algorithmic_bytes_per_frame(w, T)
-    achieved = alg * B * T / (launch_ms * 1e-3) / 1e9          # algorithmic GB/s of one GPU
+    # bytes one step moves at the least: the carried state as the library packs it, once in and once out, plus the step's samples in and out
+    io = (w["M"] + 1) * w["hop"] * 4
+    phys = 2.0 * state_bytes + float(B) * T * io
+    achieved = phys / (launch_ms * 1e-3) / 1e9                 # GB/s of one GPU
+    alg = algorithmic_bytes_per_frame(w, T)                    # the state counted unpacked
+    survey = alg * B * T / (launch_ms * 1e-3) / 1e9
     return {
         "value": round(frames / t_max, 1), "ms_per_step": round(t_max / (K * R) * 1e3, 5), "rounds": R, "timed_steps": K * R,
         "region_ms": round(t_max * 1e3, 3), "ranks": ranks,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": w["kernel"],
-                     "launches_per_step": w["launches"], "launch_ms": round(launch_ms, 5), "algorithmic_bytes_per_frame": alg,
-                     "algorithmic_bytes_per_launch": alg * B * T, "batch_per_gpu": B, "hops_per_call": T,
-                     "accounting": "frac = SURVEY 8(d)'s algorithmic bytes (the carried state counted in fp32 / complex64, full matrices) over this "
-                                   "run's launch duration; the kernels keep Hermitian / symmetric state packed, so the bytes they move are fewer and "
-                                   "frac can pass 1 — frac_measured (PMC bytes of the same command over the same duration) is the physical figure"},
+                     "launches_per_step": w["launches"], "launch_ms": round(launch_ms, 5), "bytes_per_launch": phys,
+                     "state_bytes_per_gpu": state_bytes, "batch_per_gpu": B, "hops_per_call": T,
+                     "achieved_survey_bytes": round(survey, 1), "frac_survey_bytes": round(survey / HBM_PEAK_GBS, 4),
+                     "algorithmic_bytes_per_frame": alg, "algorithmic_bytes_per_launch": alg * B * T,
+                     "accounting": "achieved / frac = the bytes a step must move (the carried state as the library packs it — Hermitian and symmetric "
+                                   "matrices as triangles — once in and once out, plus the step's samples in and out) over this run's launch "
+                                   "duration; frac_survey_bytes = SURVEY 8(d)'s figure, which counts the same state unpacked and is therefore "
+                                   "not a physical fraction; traffic / frac_measured = PMC bytes of the same command (committed profile)"},
     }
 
 
@@ -320,6 +384,46 @@ def attach_traffic(roof, key):
         gbs = ent["hbm_bytes_per_launch"] / (roof["launch_ms"] * 1e-3) / 1e9
         roof["achieved_measured"] = round(gbs, 1)
         roof["frac_measured"] = round(gbs / HBM_PEAK_GBS, 4)
+        if roof.get("launches_per_step", 1) > 2:
+            # chain handles: the allocated state of the stages is not what a step moves (the blocking filters' fan form keeps the shared
+            # tap buffer and RLS matrix once per utterance; the stages also hand spectra to each other through HBM), so the physical
+            # figure of a chain is the measured traffic, not a state-size formula
+            roof["achieved_state_bytes"], roof["frac_state_bytes"] = roof["achieved"], roof["frac"]
+            roof["achieved"], roof["frac"] = roof["achieved_measured"], roof["frac_measured"]
+            roof["accounting"] = ("achieved / frac = PMC bytes of the same command (FETCH_SIZE / WRITE_SIZE passes, committed profile: traffic_source) "
+                                  "over this run's step duration — a chain of kernels moves its stages' state AND the spectra they hand each other; "
+                                  "frac_survey_bytes = SURVEY 8(d)'s state-only figure (state counted unpacked: not a physical fraction); "
+                                  "frac_state_bytes = 2 x the stages' allocated state + samples (an upper bound of the state traffic: the fan "
+                                  "form of the blocking filters moves shared matrices once per utterance, not once per filter)")
+    except Exception:
+        pass
+
+
+def attach_compute(entry, key, frames_per_s_per_gpu):
+    """The 10 s-per-call regime moves the carried state once per 625 / 312 hops: it is bound by the vector pipes, not by HBM.
+    Its roofline is the share of every SIMD's cycles that ISSUING the measured vector instructions takes at the measured frame rate:
+    vector instructions per frame from the SQ counter passes of the same command (profiles/compute_latest.json, committed; PMC counters
+    cannot be read inside this process), each priced at its kernel's mix-weighted issue cost (scripts/kernel_mix.py; costs measured by
+    scratch/micro/valu_rate.hip), over the 2.4 GHz peak clock.  The HBM figure measure() computed stays in the entry as roofline_hbm_bytes."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "compute_latest.json")) as fh:
+            t = json.load(fh)
+        ent = t.get(key)
+        if not ent:
+            return
+        clk = t.get("clock_ghz_peak", 2.4) * 1e9
+        vc, lc = ent["valu_issue_cycles_per_frame"], ent["lds_cycles_per_frame"]
+        entry["roofline_hbm_bytes"] = entry["roofline"]
+        entry["roofline"] = {
+            "bound": "valu", "achieved": round(frames_per_s_per_gpu * vc / 1e9, 4), "peak": round(clk / 1e9, 3),
+            "unit": "G vector-issue cycles/s per SIMD", "frac": round(frames_per_s_per_gpu * vc / clk, 4),
+            "frac_lds": round(frames_per_s_per_gpu * lc / clk, 4), "valu_instructions_per_frame": round(ent["valu_instructions_per_frame"], 1),
+            "valu_issue_cycles_per_frame_per_simd": round(vc, 3), "lds_cycles_per_frame_per_cu": round(lc, 3),
+            "source": "profiles/compute_latest.json <- " + ent.get("profile", "?") + " (SQ_INSTS_VALU, SQ_LDS_IDX_ACTIVE of the same command; "
+                      "issue cost per instruction from the shipped kernels' instruction mix, scripts/kernel_mix.py)",
+            "note": "frac = share of each SIMD's cycles spent issuing vector instructions at this frame rate (peak clock 2.4 GHz; the chip "
+                    "holds 2.2-2.3 GHz in these kernels); frac_lds = the LDS pipes' busy share.  What keeps it from 1: a lone wave issues one "
+                    "vector instruction per 5.5-8 cycles, so a SIMD needs two or more of its four waves ready at once (profiles/r03b/bsweep.txt)"}
     except Exception:
         pass
 
@@ -359,10 +463,19 @@ def cpu_baseline(budget_s=10.0):
     wall = time.perf_counter() - t_start
     busy = max(r[1] for r in res)
     total = sum(r[0] for r in res)
+    # one 1024-sample chunk (4 hops) of ONE stream on ONE core: the C port's figure beside the `latency` block
+    eng = COracleMVDR(steer, NFFT, HOP)
+    xc = O.synth_utterance(99, 1024 * 300, mic)
+    tc = []
+    for i in range(300):
+        t1 = time.perf_counter()
+        eng.process(xc[:, i * 1024:(i + 1) * 1024])
+        tc.append(time.perf_counter() - t1)
     return {"value": round(total / busy, 1), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d streams x %d hops (one hop per call; %d distinct synthetic utterances), oracle/c/ds_oracle_mvdr.c "
                       "(plain C, fp64), one thread per core; %.1f s wall" % (cores, frames, n_distinct, wall),
-            "per_core": round(total / busy / cores, 1)}
+            "per_core": round(total / busy / cores, 1),
+            "chunk_1024_one_core_us": {"median_us": round(float(np.median(tc)) * 1e6, 1), "p99_us": round(float(np.percentile(tc, 99)) * 1e6, 1)}}
 
 
 # CPU baseline of the chain / GSC configs: the NumPy restatements of oracle/ds_oracle.py (fp64, pinned to the reference's golden vectors),
@@ -474,6 +587,13 @@ def main():
             out["config"]["note"] = "all %d ranks share GPU %d (DS_FORCE_DEVICE, gloo): rank-path check, not a scaling measurement" % (world, be.local_rank)
         if T == 1 and B == w["batch"]:
             attach_traffic(out["roofline"], args.config)
+            if args.config == "cfg2":
+                out["roofline"]["note"] = ("at 1024 utterances the launch is ONE resident round of 1024 workgroups (4 per CU) walking their phases in "
+                                           "step over a state that stays in the 256 MiB Infinity Cache: the duration is the dependent chain of one "
+                                           "workgroup (3.1 us alone on a CU, profiles/r03b/bsweep.txt) as much as a bandwidth figure; roofline_hbm "
+                                           "(same kernel, 16 384 utterances) is the HBM measurement")
+        if T > 1:
+            attach_compute(out, "%s_10s_chunks" % args.config if T >= 300 else "none", out["value"] / max(1, res["ranks"]))
 
     if not args.no_extras:
         # (1) the same kernel with the state working set outside the Infinity Cache: an HBM measurement of the HBM claim
@@ -510,19 +630,22 @@ def main():
                 wo = WORKLOADS[name]
                 ro = measure(be, dsdist, wo, wo["batch"], Tc, 2, 1, rank, world, min(args.min_region_ms, 120.0))
                 if rank == 0:
-                    ro["roofline"]["note"] = ("chunked regime: the carried state moves once per %d hops; bound by the per-hop arithmetic and LDS "
-                                              "work of the kernels, not by HBM" % Tc)
-                    others[name + "_10s_chunks"] = {"workload": "BASELINE %s: %s, batch=%d per GPU, 10 s per call (%d hops)"
-                                                                % (name, wo["desc"], wo["batch"], Tc),
-                                                    "value": ro["value"], "unit": "frames/s", "n_gpus": ro["ranks"], "steps": 2,
-                                                    "rounds": ro["rounds"], "ms_per_step": ro["ms_per_step"], "hops_per_call": Tc,
-                                                    "roofline": ro["roofline"]}
+                    ro["roofline"]["note"] = ("the carried state moves once per %d hops: HBM is not the limiter of this regime (see roofline)" % Tc)
+                    ent = {"workload": "BASELINE %s: %s, batch=%d per GPU, 10 s per call (%d hops)" % (name, wo["desc"], wo["batch"], Tc),
+                           "value": ro["value"], "unit": "frames/s", "n_gpus": ro["ranks"], "steps": 2, "rounds": ro["rounds"],
+                           "ms_per_step": ro["ms_per_step"], "hops_per_call": Tc, "roofline": ro["roofline"]}
+                    attach_compute(ent, name + "_10s_chunks", ro["value"] / max(1, ro["ranks"]))
+                    others[name + "_10s_chunks"] = ent
         if rank == 0 and others:
             out["other_configs"] = others
 
+    if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg2" and hasattr(be, "latency"):
+        out["latency"] = be.latency()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2" and not os.environ.get("DS_BENCH_BACKEND"):
             out["cpu_baseline"] = cpu_baseline()
+            if "latency" in out:
+                out["latency"]["cpu_port_one_core"] = out["cpu_baseline"]["chunk_1024_one_core_us"]
             for name in out.get("other_configs", {}):
                 if name in cpu_pre:
                     out["other_configs"][name]["cpu_baseline"] = cpu_pre[name]

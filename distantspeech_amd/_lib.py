@@ -5,11 +5,23 @@ module.  If the shared library is missing (not built) or no HIP device is visibl
 point fails loudly."""
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # The chain handles spread their stages over up to five HIP streams; the runtime's default of 4 hardware queues per device makes two of
 # them share a queue (false serialisation).  Only effective if nothing in the process has initialised HIP yet.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+def _hip_already_initialised():
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+# (the library reads the variable as a statement about the running HIP runtime: set it only where it can still take effect.  A process
+# whose HIP runtime is already up — e.g. torch has made a CUDA call — keeps its 4 queues, and the chains then keep their serial tail)
+if "GPU_MAX_HW_QUEUES" not in os.environ and not _hip_already_initialised():
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 LIB_PATH = os.environ.get("DSENH_LIB", os.path.join(_HERE, "libdsenh.so"))   # DSENH_LIB: A/B of kernel builds
 
 DS_OK = 0
@@ -66,7 +78,7 @@ EXPORTS = [
     "ds_mvdr_weight", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process", "ds_tdgsc_process", "ds_fdgsc_process",
     "ds_omlsa_estimate", "ds_omlsa_postfilter",
     "ds_sublms_update", "ds_subrls_update", "ds_wpe_update", "ds_synchronize",
-    "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_export_state",
+    "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_state_payload_bytes", "ds_export_state",
     "ds_import_state",
 ]
 
@@ -172,6 +184,8 @@ def load():
     lib.ds_field_bytes.argtypes = [vp, ci]
     lib.ds_state_bytes.restype = csz
     lib.ds_state_bytes.argtypes = [vp]
+    lib.ds_state_payload_bytes.restype = csz
+    lib.ds_state_payload_bytes.argtypes = [vp]
     lib.ds_export_state.restype = ci
     lib.ds_export_state.argtypes = [vp, vp, csz]
     lib.ds_import_state.restype = ci

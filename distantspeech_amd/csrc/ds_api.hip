@@ -32,7 +32,7 @@ int set_device(ds_handle* h) {
     DS_HIP(h, hipSetDevice(h->device));
     // every entry point comes through here before it touches the handle; the utterance groups of a chain are brought back onto the
     // chain's stream first (the chain's own launch path selects the device without this: select_device)
-    if (h->groups_open) return join_groups(h);
+    if (h->groups_open && !h->group_enqueue) return join_groups(h);
     return DS_OK;
 }
 
@@ -368,7 +368,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     for (int i = 0; i < 10; ++i) h->sub[i] = nullptr;
     for (int i = 0; i < 24; ++i) { h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0; }
     h->postfilter = 0;
-    h->owns_stream = true; h->wpe_delay = 4; h->hist_cur = 0;
+    h->owns_stream = true; h->wpe_delay = 4; h->hist_cur = 0; h->group_enqueue = false;
     h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
@@ -789,13 +789,14 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
         auto enqueue = [&](int g, hipStream_t sg) {         // the n_calls launches of group g
             int lo, hi;
             range(g, lo, hi);
-            for (int i = 0; i < n_calls; ++i) {
-                const int rc = ds_process_device(h, x_dev + (long long)i * x_call_stride + (long long)lo * x_batch_stride, layout, x_batch_stride,
-                                                 x_chan_stride, n_samples_per_call, y_dev + (long long)i * y_call_stride + (long long)lo * y_batch_stride,
-                                                 y_batch_stride, first + lo, hi - lo, (void*)sg);
-                if (rc) return rc;
-            }
-            return (int)DS_OK;
+            h->group_enqueue = true;                        // ds_process_device -> set_device() would join the very groups being launched
+            int rc = DS_OK;
+            for (int i = 0; i < n_calls && rc == DS_OK; ++i)
+                rc = ds_process_device(h, x_dev + (long long)i * x_call_stride + (long long)lo * x_batch_stride, layout, x_batch_stride,
+                                       x_chan_stride, n_samples_per_call, y_dev + (long long)i * y_call_stride + (long long)lo * y_batch_stride,
+                                       y_batch_stride, first + lo, hi - lo, (void*)sg);
+            h->group_enqueue = false;
+            return rc;
         };
         if (graph != 0) {
             float fl[6] = {h->alpha_y, h->alpha_v, h->diag, h->gate, h->mu, 0.0f};
@@ -1111,11 +1112,18 @@ static int extra_state(const ds_handle* h, ExtraState out[3]) {
     return n;
 }
 // every handle's section of a checkpoint blob starts with this header; ds_import_state refuses a blob written for another configuration
-struct BlobHeader { uint32_t magic, version; int32_t algo, nfft, hop, n_mics, batch, filter_len, td_L, track_ryy; };
+// layout: bumped whenever the serialised arrangement of the state changes (2 = per-bin planes without spare words, 128-byte utterance
+// stride, foreground filter in the FDAF state); modes: the settings that shape the state or its meaning (two-path FDAF, McSpp repeat,
+// shared-reference / complemented-p subband filters); out_scale_bits: hop / sum(window^2), which moves with a caller-supplied window
+struct BlobHeader { uint32_t magic, version; int32_t algo, nfft, hop, n_mics, batch, filter_len, td_L, track_ryy, layout, modes, wpe_delay; uint32_t out_scale_bits; };
 static const uint32_t BLOB_MAGIC = 0x44534348u;      // "DSCH"
+static const int32_t BLOB_LAYOUT = 2;
 static BlobHeader blob_header(const ds_handle* h) {
+    uint32_t osb;
+    std::memcpy(&osb, &h->out_scale, sizeof osb);
+    const int32_t modes = (h->fdaf_two_path ? 1 : 0) | (h->mcspp_repeat ? 2 : 0) | (h->x_fan > 1 ? 4 : 0) | (h->p_complement ? 8 : 0);
     return BlobHeader{BLOB_MAGIC, (uint32_t)DS_VERSION, h->cfg.algo, h->cfg.nfft, h->cfg.hop, h->cfg.n_mics, h->cfg.batch, h->filter_len, h->td_L,
-                      h->cfg.track_ryy};
+                      h->cfg.track_ryy, BLOB_LAYOUT, modes, h->wpe_delay, osb};
 }
 static size_t own_state_bytes(const ds_handle* h) {
     ExtraState ex[3];
@@ -1137,6 +1145,14 @@ size_t ds_state_bytes(const ds_handle* h) {
     if (!h) return 0;
     size_t n = own_state_bytes(h) + chain_hist_bytes(h);
     for (int i = 0; i < 10; ++i) if (h->sub[i]) n += ds_state_bytes(h->sub[i]);
+    return n;
+}
+
+// the same without the blob's framing (header + uniform counters of every handle in it): the bytes of carried state one call moves each way
+size_t ds_state_payload_bytes(const ds_handle* h) {
+    if (!h) return 0;
+    size_t n = own_state_bytes(h) - sizeof(BlobHeader) - 4 * sizeof(int) + chain_hist_bytes(h);
+    for (int i = 0; i < 10; ++i) if (h->sub[i]) n += ds_state_payload_bytes(h->sub[i]);
     return n;
 }
 
@@ -1201,10 +1217,13 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
         if (got.magic != BLOB_MAGIC) return fail(h, DS_EINVAL, "ds_import_state: not a dsenh checkpoint (bad magic)");
         if (std::memcmp(&got, &want, sizeof got) != 0) {
             char buf[256];
-            snprintf(buf, sizeof buf, "ds_import_state: checkpoint was written for version %u algo %d nfft %d hop %d mics %d batch %d taps %d fir %d ryy %d, "
-                     "this handle is version %u algo %d nfft %d hop %d mics %d batch %d taps %d fir %d ryy %d",
-                     got.version, got.algo, got.nfft, got.hop, got.n_mics, got.batch, got.filter_len, got.td_L, got.track_ryy,
-                     want.version, want.algo, want.nfft, want.hop, want.n_mics, want.batch, want.filter_len, want.td_L, want.track_ryy);
+            snprintf(buf, sizeof buf, "ds_import_state: checkpoint was written for version %u algo %d nfft %d hop %d mics %d batch %d taps %d fir %d ryy %d "
+                     "layout %d modes %d wpe_delay %d window-scale %08x, this handle is version %u algo %d nfft %d hop %d mics %d batch %d taps %d fir %d "
+                     "ryy %d layout %d modes %d wpe_delay %d window-scale %08x",
+                     got.version, got.algo, got.nfft, got.hop, got.n_mics, got.batch, got.filter_len, got.td_L, got.track_ryy, got.layout, got.modes,
+                     got.wpe_delay, got.out_scale_bits,
+                     want.version, want.algo, want.nfft, want.hop, want.n_mics, want.batch, want.filter_len, want.td_L, want.track_ryy, want.layout,
+                     want.modes, want.wpe_delay, want.out_scale_bits);
             return fail(h, DS_ESHAPE, buf);
         }
         s += sizeof got;

@@ -29,7 +29,8 @@ __global__ void __launch_bounds__(256) ds_fdgsc_control_kernel(float* p, float* 
         if (k >= 32 && k < 128) mid += (double)v;
     }
     mid = wave_sum(mid);
-    if (mid / 96.0 > 0.8 && lane < 32 && first < 0.8f) { first = 0.8f; row[lane] = 0.8f; }
+    const int nmid = (K < 128 ? K : 128) - 32;                          // np.mean(p_bm[32:128]) is over the bins that exist (frameLen 64: 33 of them)
+    if (nmid > 0 && mid / (double)nmid > 0.8 && lane < 32 && first < 0.8f) { first = 0.8f; row[lane] = 0.8f; }
     if (lane < K) all += (double)first;
     all = wave_sum(all);
     if (lane == 0) pa[r] = (float)(1.0 - all / (double)K);

@@ -1333,6 +1333,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // WAVE_FFT: a channel's transform lives inside one wavefront from the staging of its samples to the last stage, so those
             // hand-offs need no workgroup barrier (the interleaved input layout scatters the staging across channels and keeps its barrier).
             auto ph = [&](bool wave_local, auto f) { if (wave_local) ex.phase_wave(f); else ex.phase(f); };
+            auto phs = [&](bool wave_local, auto f) { if (wave_local) ex.stage_wave(f); else ex.stage(f); };     // transform stages
             cf* fa = &sh.fa[0][0];
             cf* fb = &sh.fb[0][0];
             bool spectra_in = false;
@@ -1395,15 +1396,15 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 });
             }
             // ---- forward FFT: M packed real transforms -------------------------------------------
-            ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half, M); });
-            ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0, M); });
-            ph(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0, M); });
+            phs(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half, M); });
+            phs(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0, M); });
+            phs(WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0, M); });
             if (NC == 128) {
-                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0, M); });
+                ex.stage([&](int tid, Rg&) { fft_stage<NFFT, M, 2, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0, M); });
             } else {
-                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0, M); });
+                ex.stage([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 0, 0>(tid, NT, sh, fa, fb, 64, 0, M); });
                 if (NC == 512)
-                    ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, -1, false, 0, 0>(tid, NT, sh, fb, fa, 256, 0, M); });
+                    ex.stage([&](int tid, Rg&) { fft_stage<NFFT, M, 2, -1, false, 0, 0>(tid, NT, sh, fb, fa, 256, 0, M); });
             }
             const cf* F = FWD_FINAL_IS_FB ? fb : fa;
             // ---- split packed spectrum -> Z[k][m]; publish |Z_0|^2 for the MCRA stencil ----------
@@ -1465,7 +1466,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // so it is taken with Y[NC] = 0 and the bin's contribution — the constant (Y[NC] / 2) (1 - j) on every packed point, i.e.
             // +- Y[NC] / 2 on even / odd samples — is added in the overlap-add phase.
             // The merge of the packed real transform (Y[k], Y[NC - k] -> point k) is formed inside the first inverse stage.
-            ph(WAVE_FFT, [&](int tid, Rg& r) {
+            phs(WAVE_FFT, [&](int tid, Rg& r) {
                 DS_SETPRIO(2);                                          // the serial part of a hop: ahead of other workgroups' wide phases
                 if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, 2, 0, 1>(tid - INV_T0, NT, sh, nullptr, fb, 1, 0, 1);
                 else if (WAVE_FFT && tid == NYQ_TID) {
@@ -1476,14 +1477,14 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     sh.Y[NC] = mk(Yn.x, 0.0f);                          // irfft ignores Im Y[N/2]
                 }
             });
-            ph(WAVE_FFT, [&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 1, 2>(tid - INV_T0, NT, sh, fb, fa, 4, 0, 1); });
-            ph(WAVE_FFT, [&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 2, 0>(tid - INV_T0, NT, sh, fa, fb, 16, 0, 1); });
+            phs(WAVE_FFT, [&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 1, 2>(tid - INV_T0, NT, sh, fb, fa, 4, 0, 1); });
+            phs(WAVE_FFT, [&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 2, 0>(tid - INV_T0, NT, sh, fa, fb, 16, 0, 1); });
             if (NC == 128) {
-                ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid - INV_T0, NT, sh, fb, fa, 64, 0, 1); });
+                ex.stage([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid - INV_T0, NT, sh, fb, fa, 64, 0, 1); });
             } else {
-                ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 0, 0>(tid - INV_T0, NT, sh, fb, fa, 64, 0, 1); });
+                ex.stage([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, false, 0, 0>(tid - INV_T0, NT, sh, fb, fa, 64, 0, 1); });
                 if (NC == 512)
-                    ex.phase([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid - INV_T0, NT, sh, fa, fb, 256, 0, 1); });
+                    ex.stage([&](int tid, Rg&) { if (tid >= INV_T0) fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid - INV_T0, NT, sh, fa, fb, 256, 0, 1); });
             }
             const cf* Zi = INV_FINAL_IS_FA ? fa : fb;
             // ---- window, overlap-add, emit hop t ---------------------------------------------------

@@ -87,6 +87,7 @@ struct ds_handle {
     // its own copy of the device counters (dev_cnt + 8 g); groups_open: side streams hold work the chain's stream has not joined yet
     int parts;
     bool groups_open;
+    bool group_enqueue;         // inside ds_process_device_seq's per-group launches: set_device() must not join the groups it is launching
     // DS_ALGO_SUBBAND_GSC: the front end of a block (notch -> FIR bank -> analysis; latency-bound kernels) runs on its own stream
     // (side[1]) into one of two buffer sets, so that the front end of block t + 1 overlaps the HBM-bound stages of block t whenever the
     // caller has block t + 1 enqueued by then.  ev_fr: {front of set 0 / 1 done, set 0 / 1 free again}

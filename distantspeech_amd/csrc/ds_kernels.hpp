@@ -56,8 +56,10 @@ hipError_t launch_fdaf(const FdafParams& p, int nfft, hipStream_t stream);   // 
 // leaves the id alone: the compiler hoists the loop-invariant address arithmetic of every phase out of the hop loop (4-microphone MVDR
 // kernel: 809 -> 622 vector instructions per hop, 94 -> 127 registers — still four waves per SIMD; +8 % with 10 s per call, +4 % at one
 // hop per call, profiles/r03b/hoist_ab.txt).  Which kernels can afford the registers: frames_hoist() below.
-#define DS_LAUNDER(tid) do { if constexpr (!HOIST) asm volatile("" : "+v"(tid)); } while (0)
-template <class Rg, bool HOIST = false> struct HipExec {
+// HOIST = 1 hoists in the transform-stage phases only (stage / stage_wave), 2 in every phase.
+#define DS_LAUNDER(tid) do { if constexpr (HOIST < 2) asm volatile("" : "+v"(tid)); } while (0)
+#define DS_LAUNDER_STAGE(tid) do { if constexpr (HOIST < 1) asm volatile("" : "+v"(tid)); } while (0)
+template <class Rg, int HOIST = 0> struct HipExec {
     Rg r;
     template <class F> __device__ __forceinline__ void phase(F f) {
         int tid = (int)threadIdx.x;
@@ -70,6 +72,21 @@ template <class Rg, bool HOIST = false> struct HipExec {
     template <class F> __device__ __forceinline__ void phase_wave(F f) {
         int tid = (int)threadIdx.x;
         DS_LAUNDER(tid);
+        f(tid, r);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // the transform stages' phases (workgroup barrier / wave-local): the same, with their own hoisting level
+    template <class F> __device__ __forceinline__ void stage(F f) {
+        int tid = (int)threadIdx.x;
+        DS_LAUNDER_STAGE(tid);
+        f(tid, r);
+        __syncthreads();
+    }
+    template <class F> __device__ __forceinline__ void stage_wave(F f) {
+        int tid = (int)threadIdx.x;
+        DS_LAUNDER_STAGE(tid);
         f(tid, r);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -104,13 +121,18 @@ template <class Rg, bool HOIST = false> struct HipExec {
 // is gone: -25 %) and is pinned too; larger arrays keep the allocator's own choice.
 // The 6-microphone SubbandGSC tail (ALGO_AIC) holds three workgroups per CU by its LDS; with the packed complex products the allocator
 // took 172 registers (two waves per SIMD) where 168 keep the third: pinned as well.
+#ifndef DS_GSC_HOIST
+#define DS_GSC_HOIST 0
+#endif
 // frame kernels whose register budget has room for the hoisted addresses at unchanged occupancy (measured per shape with
 // -Rpass-analysis=kernel-resource-usage: the GSC kernel spills, the 6- and 8-microphone kernels lose a wave per SIMD)
-constexpr bool frames_hoist(int nfft, int M, int algo, bool ryy) {
+constexpr int frames_hoist(int nfft, int M, int algo, bool ryy) {
 #if defined(DS_NO_HOIST)
-    return false;
+    return 0;
 #else
-    return nfft <= 512 && M <= 4 && ((algo == ALGO_ADAPTIVE && !ryy) || algo == ALGO_FIXED);
+    if (nfft <= 512 && M <= 4 && ((algo == ALGO_ADAPTIVE && !ryy) || algo == ALGO_FIXED)) return 2;
+    if (nfft <= 512 && M <= 4 && algo == ALGO_GSC) return DS_GSC_HOIST;
+    return 0;
 #endif
 }
 constexpr int frames_min_waves(int M, int algo) {

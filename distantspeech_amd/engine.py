@@ -454,6 +454,10 @@ class BatchEngine:
             return out.reshape(B, M, 2)
         return out.reshape(B, K)
 
+    def state_bytes(self):
+        """bytes of the carried state as the library packs it (without the checkpoint's framing): what one call reads and writes back"""
+        return int(self._lib.ds_state_payload_bytes(self._h))
+
     def export_state(self):
         n = self._lib.ds_state_bytes(self._h)
         buf = np.empty(n, dtype=np.uint8)

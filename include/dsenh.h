@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DS_VERSION 102
+#define DS_VERSION 103
 
 /* error codes */
 #define DS_OK 0
@@ -316,6 +316,8 @@ size_t ds_field_bytes(const ds_handle* h, int field);
 
 /* opaque checkpoint of all carried state (the reference never serialises its state) */
 size_t ds_state_bytes(const ds_handle* h);
+/* the carried state alone, without the checkpoint's framing: the bytes one call reads and writes back (bench.py's byte accounting) */
+size_t ds_state_payload_bytes(const ds_handle* h);
 int ds_export_state(ds_handle* h, void* dst, size_t bytes);
 int ds_import_state(ds_handle* h, const void* src, size_t bytes);
 

@@ -69,12 +69,20 @@ if traffic["kernels"]:
         print("%-70s x%5.1f/step  fetch %9.2f MB  write %9.2f MB  total %9.2f MB" % (k[:70], v["launches"] / steps, v["fetch_bytes"] / 1e6, v["write_bytes"] / 1e6, v["hbm_bytes_per_launch"] / 1e6))
     print("per step: %.2f MB" % (traffic["hbm_bytes_per_step"] / 1e6))
 json.dump(traffic, open(os.path.join(d, "traffic.json"), "w"), indent=1)
+compute = {"tag": tag, "note": "SQ / GRBM counters, mean per launch of each kernel (rocprofv3 --pmc passes of scripts/profile_bench.sh with PROFILE_SQ=1; "
+           "kernels run one at a time under counter collection); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles, "
+           "GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_LDS_IDX_ACTIVE over the 256 CUs", "kernels": {}}
 for sub in ("pmc_sq", "pmc_lds", "pmc_sq2"):
     acc = pmc(sub)
     for k, cs in acc.items():
         print("== %s: %s" % (sub, k[:90]))
         for c, v in sorted(cs.items()):
             print("   %-28s mean %16.1f  min %16.1f  max %16.1f  n %d" % (c, sum(v) / len(v), min(v), max(v), len(v)))
+            ent = compute["kernels"].setdefault(k[:100], {})
+            ent[c] = sum(v) / len(v)
+            ent["launches"] = len(v)
+if compute["kernels"]:
+    json.dump(compute, open(os.path.join(d, "compute.json"), "w"), indent=1)
 for name in ("trace.log",):
     p = os.path.join(d, name)
     if os.path.exists(p):

@@ -22,6 +22,8 @@ template <class Rg> struct CpuExec {
         for (int t = 0; t < nt; ++t) f(t, R[t]);
     }
     template <class F> void phase_wave(F f) { phase(f); }       // wave-local hand-off: the same thing when run serially
+    template <class F> void stage(F f) { phase(f); }
+    template <class F> void stage_wave(F f) { phase(f); }
     // two-part phases (in-place transform stages of the hop-pipelined engine): every thread's loads before any thread's stores
     template <class FL, class FR> void phase_wave2(FL fl, FR fr) { phase(fl); phase(fr); }
     template <class FL, class FR> void phase2(FL fl, FR fr) { phase(fl); phase(fr); }

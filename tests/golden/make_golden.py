@@ -571,16 +571,24 @@ def g16_fdgsc(x16):
     s[: 256 * 135] = 0
     s[256 * 160:] = 0
     burst = (burst + s[None, :]).astype(np.float32)
-    for name, xx, M, pf in (("rec1", x[:, : 256 * 150], 4, False), ("rec1_pf", x[:, : 256 * 150], 4, True),
-                            ("synth_m6_pf", synth(161, 6, 256 * 80), 6, True), ("burst", burst, 4, False)):
-        mic = MicArray(arrayType="circular", r=0.032 if M == 4 else 0.05, M=M, n_fft=512)
+    # the same with frameLen 64 (K = 65): np.mean(p_bm[32:128]) then averages the 33 bins that exist (FDGSC.py:248)
+    rng = np.random.default_rng(163)
+    burst64 = rng.standard_normal((4, 64 * 400)) * 0.01
+    s = rng.standard_normal(64 * 400) * 0.3
+    s[: 64 * 300] = 0
+    s[64 * 360:] = 0
+    burst64 = (burst64 + s[None, :]).astype(np.float32)
+    for name, xx, M, pf, FL in (("rec1", x[:, : 256 * 150], 4, False, 256), ("rec1_pf", x[:, : 256 * 150], 4, True, 256),
+                                ("synth_m6_pf", synth(161, 6, 256 * 80), 6, True, 256), ("burst", burst, 4, False, 256),
+                                ("burst64", burst64, 4, False, 64)):
+        mic = MicArray(arrayType="circular", r=0.032 if M == 4 else 0.05, M=M, n_fft=2 * FL)
         with contextlib.redirect_stdout(io.StringIO()):
-            g = FDGSC(mic, frameLen=256, angle=[197, 0])
+            g = FDGSC(mic, frameLen=FL, angle=[197, 0])
             r = g.process(xx.T.astype(np.float64).copy(), postfilter=pf)
-        save("g16_fdgsc_%s" % name, "FDGSC.process(postfilter=%s, dc_notch=True) FDGSC.py:201-317 (blocking-matrix mode 3)" % pf,
+        save("g16_fdgsc_%s" % name, "FDGSC.process(postfilter=%s, dc_notch=True) FDGSC.py:201-317 (blocking-matrix mode 3), frameLen %d" % (pf, FL),
              x=(x16[:, : 256 * 150] if name.startswith("rec1") else xx), output=r[0], p=r[1], fix_output=r[2],
              fix_output_delayed=r[3], bm_output=r[4].astype(np.float32), aligned_output_delayed=r[6].astype(np.float32),
-             w_aic=np.array(g.aic_filter.w).astype(np.float32), w_bm0=np.array(g.bm[0].w), params=np.array([M, 256, int(pf)]),
+             w_aic=np.array(g.aic_filter.w).astype(np.float32), w_bm0=np.array(g.bm[0].w), params=np.array([M, FL, int(pf)]),
              r=np.array(mic.r))
 
 

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_strerror():
     lib = L.load()
-    assert lib.ds_version() == 102
+    assert lib.ds_version() == 103
     assert lib.ds_strerror(-2).decode().startswith("shape")
 
 

@@ -217,8 +217,8 @@ def test_wpe(ds, name):
     x = g["x"]
     y = np.concatenate([wpe.update(x[n:n + hop])[0] for n in range(0, x.shape[0], hop)])
     measured("G10_wpe_" + name, y_rms=rms(y - g["y"]), y_ref_rms=rms(g["y"]), W_rel_rms=rms(wpe.W - g["W"]) / rms(g["W"]))
-    assert rms(y - g["y"]) < 2e-4 * max(rms(g["y"]), 1e-3)
-    assert wpe.W.shape == g["W"].shape and rms(wpe.W - g["W"]) < 2e-2 * rms(g["W"])
+    assert rms(y - g["y"]) < 5e-7 * rms(g["y"])                                    # measured 1.5e-7 relative
+    assert wpe.W.shape == g["W"].shape and rms(wpe.W - g["W"]) < 1e-6 * rms(g["W"])   # measured 2.7e-7
     assert wpe.P.shape == g["P"].shape
 
 
@@ -311,7 +311,7 @@ def test_subband_gsc(ds, name):
     measured("G12_subbandgsc_" + name, output_rms=e_out, output_ref_rms=rms(g["output"]), bm_rms=e_bm, bm_ref_rms=rms(g["bm_output"]), aligned_rms=e_al, p_max=e_p)
     # north star: 1e-4 RMS absolute on every returned signal.  CPU emulation of the same stage programs (tests/test_kernel_emul.py::
     # test_emul_subband_gsc_chain): output 2e-7 / 4e-7 / 9e-6 (LMS rec1, LMS M = 6, RLS M = 6), bm_output 1e-6 ... 3e-6
-    assert e_al < 1e-5 and e_bm < 2e-5 and e_out < 5e-5
+    assert e_al < 4e-6 and e_bm < 8e-6 and e_out < 3e-5                         # measured <= 1.4e-6, 2.7e-6, 9.4e-6
     assert e_p < 1e-3 and np.median(np.abs(p - g["p"])) < 1e-6
     # postfilter=True is output-dead in the reference (SubbandGSC.py:236-249): accepted, same results
     pf_a = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0], bm_filter="rls" if rls else "lms").process(x[:, : 4 * FL], postfilter=True)
@@ -385,7 +385,7 @@ def test_chain_full_batch_properties(ds, cfg):
                 ref = O.OracleSubbandGSC(omic, frameLen=hop, angle_deg=(197, 0), rls_bm=True).process(base[u])[0]
         err = rms(y[b] - ref)
         measured("chain_full_batch_%s_row%d" % (cfg, b), y_rms=err, y_ref_rms=rms(ref))
-        assert err < 1e-4, (cfg, b, err)
+        assert err < 2e-6, (cfg, b, err)                                          # measured 2e-7 ... 6e-7
 
 
 @pytest.mark.parametrize("nfft", [512, 1024])
@@ -540,16 +540,24 @@ def test_tdgsc(ds, name):
     assert rms(bm - g["output_bm"]) < 1e-4 * rms(g["output_bm"])
     measured("G15_tdgsc_" + name, output_rms=rms(out - g["output"]), output_ref_rms=rms(g["output"]), w_rel_rms=rms(tg.aic_filter.w - g["w"]) / rms(g["w"]))
     assert rms(out - g["output"]) < 1e-3 * rms(g["output"])
-    assert rms(tg.aic_filter.w - g["w"]) < 1e-3 * rms(g["w"])
+    assert rms(tg.aic_filter.w - g["w"]) < 7e-4 * rms(g["w"])                    # measured 1.0e-4 ... 2.3e-4
 
 
-@pytest.mark.parametrize("name", ["rec1", "rec1_pf", "synth_m6_pf", "burst"])
+@pytest.mark.parametrize("name", ["rec1", "rec1_pf", "synth_m6_pf", "burst", "burst64"])
 def test_fdgsc(ds, name):
-    """FDGSC.process (adaptive blocking matrix mode 3 + norm-limited canceller + OMLSA gain) vs the reference."""
+    """FDGSC.process (adaptive blocking matrix mode 3 + norm-limited canceller + OMLSA gain) vs the reference; `burst64`: frameLen 64,
+    where the adaptation control's np.mean(p_bm[32:128]) averages the 33 bins that exist (FDGSC.py:248)."""
     g = load("g16_fdgsc_" + name)
     M, FL, pf = [int(v) for v in g["params"]]
     x = as_float(g["x"]).T
-    mic = ds.MicArray(arrayType="circular", r=float(g["r"]), M=M, n_fft=512)
+    mic = ds.MicArray(arrayType="circular", r=float(g["r"]), M=M, n_fft=2 * FL)
+    if 2 * FL < 256:
+        # 128-point frames have no transform kernel: the chain refuses at ds_create (the smallest FDGSC block is 128 samples, where
+        # p_bm[32:128] still has all its 96 bins; the fixture pins the oracle's handling of the shorter mean, tests/test_oracle_golden.py)
+        from distantspeech_amd import _lib as L
+        with pytest.raises(L.DsError):
+            ds.FDGSC(mic, frameLen=FL, angle=[197, 0])
+        return
     fg = ds.FDGSC(mic, frameLen=FL, angle=[197, 0])
     out, p, fix, fix_d, bm, al, al_d = fg.process(x, postfilter=bool(pf))
     assert np.median(np.abs(p - g["p"])) < 1e-3
@@ -557,8 +565,8 @@ def test_fdgsc(ds, name):
     assert rms(fix_d - g["fix_output_delayed"]) < 1e-4 * rms(g["fix_output_delayed"])
     assert rms(al_d - g["aligned_output_delayed"]) < 1e-4 * rms(g["aligned_output_delayed"])
     measured("G16_fdgsc_" + name, output_rms=rms(out - g["output"]), output_ref_rms=rms(g["output"]), bm_rms=rms(bm - g["bm_output"]), bm_ref_rms=rms(g["bm_output"]))
-    assert rms(bm - g["bm_output"]) < 1e-3 * rms(g["bm_output"])
-    assert rms(out - g["output"]) < 1e-3 * rms(g["output"])
+    assert rms(bm - g["bm_output"]) < 1.5e-4 * rms(g["bm_output"])               # measured <= 4.1e-5 relative
+    assert rms(out - g["output"]) < 2e-4 * rms(g["output"])                      # measured <= 6.0e-5 relative
 
 
 @pytest.mark.parametrize("kind", ["tdgsc", "fdgsc"])

@@ -48,10 +48,11 @@ def test_adaptive_vs_reference_golden(ds, name):
     if method == 2:
         m["H_rel_rms"] = rms(ab.H - g["H"]) / rms(g["H"])
     measured("G4_adaptive_" + name, **m)
-    assert m["Rvv_relmax"] < 5e-5 and m["Ryy_relmax"] < 5e-5           # state read-back (measured: see profiles/r02_parity_measured.jsonl)
-    assert np.mean(dp > 1e-3) < 0.02
+    # bars = at most 3x what profiles/r03_parity_measured.jsonl records (Rvv 2.1e-6, Ryy 3.1e-7, no p flips, H 5e-5 ... 8.8e-5)
+    assert m["Rvv_relmax"] < 7e-6 and m["Ryy_relmax"] < 1e-6
+    assert np.mean(dp > 1e-3) < 0.002
     if method == 2:
-        assert m["H_rel_rms"] < 5e-4                                       # measured 4e-5 ... 9e-5
+        assert m["H_rel_rms"] < 3e-4
     # whole recording in one call on a fresh object == hop-by-hop
     ab2 = ds.adaptivebeamfomer(_mic(ds, M, nfft, float(g["r"])), frameLen=nfft, hop=hop, nfft=nfft)
     y2 = ab2.process(x, ANGLE, method=method)["data"]
@@ -80,9 +81,9 @@ def test_gsc_vs_reference_golden(ds, name):
     if method != 0:
         m["G_aic_rel_rms"] = rms(gsc.G - g["G"]) / max(rms(g["G"]), 1e-6)
     measured("G6_gsc_" + name, **m)
-    assert m["y_rms"] < TOL_RMS
+    assert m["y_rms"] < TOL_RMS and m["y_rms"] < 1.5e-5                   # measured 2.4e-6 ... 4.9e-6
     if method != 0:
-        assert m["G_aic_rel_rms"] < 1e-2                                   # measured 2e-4 ... 4e-3 (the weights integrate fp32 p errors)
+        assert m["G_aic_rel_rms"] < 2e-3                                   # measured 2.5e-4 ... 5.8e-4 (the weights integrate fp32 p errors)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -370,9 +371,9 @@ def test_long_recording_adaptive_mvdr(ds):
              H_rel_rms=rms(ab.H - g["H"]) / rms(g["H"]), mcra_p_max=dp.max(), mcra_p_frac_gt_1e3=np.mean(dp > 1e-3))
     measured("G17_adaptive_rec1_full", **m)
     assert m["y_rms"] < TOL_RMS and m["y_tail_rms"] < TOL_RMS
-    assert m["y_rms"] < 1e-5 and m["y_tail_rms"] < 1e-5
-    assert max(m["Rvv_relmax"], m["Rvv_relmax_t1"], m["Rvv_relmax_t500"], m["Rvv_relmax_t1000"]) < 5e-5
-    assert m["mcra_p_frac_gt_1e3"] < 0.002
+    assert m["y_rms"] < 1e-5 and m["y_tail_rms"] < 1.2e-5                  # measured 3.9e-6 / 4.9e-6
+    assert max(m["Rvv_relmax"], m["Rvv_relmax_t1"], m["Rvv_relmax_t500"], m["Rvv_relmax_t1000"]) < 5e-5     # measured 2.0e-5 after 1 670 hops
+    assert m["mcra_p_frac_gt_1e3"] < 0.002 and m["H_rel_rms"] < 4e-4       # measured 0 / 1.4e-4
 
 
 def test_long_recording_gsc(ds):
@@ -382,8 +383,8 @@ def test_long_recording_gsc(ds):
     m = dict(y_rms=rms(y - g["y"]), y_tail_rms=rms(_tail(y - g["y"])), y_ref_rms=rms(g["y"]),
              G_aic_rel_rms=rms(gsc.G - g["G"]) / rms(g["G"]))
     measured("G17_gsc_rec1_full", **m)
-    assert m["y_rms"] < TOL_RMS and m["y_tail_rms"] < TOL_RMS
-    assert m["G_aic_rel_rms"] < 1e-2
+    assert m["y_rms"] < 3e-6 and m["y_tail_rms"] < 3e-6                   # measured 7.8e-7 / 1.2e-7 (north star: 1e-4)
+    assert m["G_aic_rel_rms"] < 2e-5                                       # measured 3.7e-6
 
 
 def test_long_recording_subband_gsc(ds):
@@ -393,7 +394,8 @@ def test_long_recording_subband_gsc(ds):
     m = dict(output_rms=rms(out - g["output"]), output_tail_rms=rms(_tail(out - g["output"])), output_ref_rms=rms(g["output"]),
              fix_rms=rms(fix - g["fix_output"]), bm_rms=rms(bm[:, ::4] - g["bm_output"]), p_max=np.max(np.abs(p - g["p"])))
     measured("G17_subbandgsc_rec1_full", **m)
-    assert m["output_rms"] < TOL_RMS and m["output_tail_rms"] < TOL_RMS and m["fix_rms"] < TOL_RMS and m["bm_rms"] < TOL_RMS
+    # measured 8.8e-7 / 3.2e-7 / 9.8e-7 / 1.6e-6 (north star: 1e-4)
+    assert m["output_rms"] < 3e-6 and m["output_tail_rms"] < 3e-6 and m["fix_rms"] < 3e-6 and m["bm_rms"] < 5e-6 and m["p_max"] < 2e-3
 
 
 def test_an101_eight_channel_recording(ds):
@@ -413,8 +415,8 @@ def test_an101_eight_channel_recording(ds):
     yw = np.concatenate([wpe.update(xt[n:n + whop])[0] for n in range(0, xt.shape[0], whop)])
     m.update(wpe_y_rms=rms(yw - gw["y"]), wpe_y_ref_rms=rms(gw["y"]), wpe_W_rel_rms=rms(wpe.W - gw["W"]) / rms(gw["W"]))
     measured("G18_an101", **m)
-    assert m["y_rms"] < TOL_RMS and m["Rvv_relmax"] < 5e-5
-    assert m["wpe_y_rms"] < TOL_RMS and m["wpe_W_rel_rms"] < 1e-3
+    assert m["y_rms"] < 2e-6 and m["Rvv_relmax"] < 4e-6 and m["H_rel_rms"] < 3e-4     # measured 5.4e-7, 1.1e-6, 9.0e-5
+    assert m["wpe_y_rms"] < 5e-8 and m["wpe_W_rel_rms"] < 5e-6                        # measured 6.5e-9, 1.3e-6
 
 
 def test_realtime_pcm16_wire_format(ds):
@@ -513,3 +515,41 @@ def test_plain_c_caller(tmp_path):
     bf = ds.adaptivebeamfomer(ds.MicArray(arrayType="circular", r=0.032, M=4, n_fft=512), frameLen=512, hop=256, nfft=512, track_ryy=False)
     y_py = np.concatenate([bf.process(x[:, s:s + 256], ANGLE, method=2)["data"] for s in range(0, n, 256)])
     assert np.array_equal(y_c.astype(np.float64), y_py)
+
+
+# ------------------------------------------------------------------------------------------------
+# measurement plumbing: the committed PMC traffic against the state layout of THIS build; the realtime budget
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,algo_name,B", [("cfg2", "ADAPTIVE", 1024), ("cfg3", "GSC", 4096)])
+def test_committed_traffic_matches_this_builds_state_layout(ds, cfg, algo_name, B):
+    """bench.py reports `roofline.traffic` from the committed rocprofv3 PMC passes (profiles/traffic_latest.json): a layout change that
+    moved more or fewer bytes would leave a stale number there.  The bytes a one-hop step must move follow from the library's own state
+    size (ds_state_bytes: every plane, tail and counter once in and once out) plus the hop's samples; the PMC figure must be within 2 %."""
+    import json
+    from distantspeech_amd import _lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pmc = json.load(open(os.path.join(root, "profiles", "traffic_latest.json")))[cfg]["hbm_bytes_per_launch"]
+    M, nfft, hop = 4, 512, 256
+    eng = ds.BatchEngine(getattr(L, "ALGO_" + algo_name), M, nfft, batch=B, track_ryy=False) if algo_name == "ADAPTIVE" else ds.BatchEngine(L.ALGO_GSC, M, nfft, batch=B)
+    analytic = 2 * eng.state_bytes() + B * (M + 1) * hop * 4
+    measured("traffic_vs_layout_" + cfg, pmc_bytes=pmc, analytic_bytes=analytic, ratio=pmc / analytic)
+    assert abs(pmc / analytic - 1.0) < 0.02, (pmc, analytic)
+
+
+def test_realtime_chunk_latency_within_budget(ds):
+    """the reference's realtime contract (realtime/realtime_processing.py:113-136): one 1024-sample chunk of the 6-channel int16 stream
+    must be done within its own duration (64 ms).  One stream through ds_process_pcm16 (host buffers, PCIe included): p99 over 400 chunks."""
+    import time
+    from distantspeech_amd import _lib as L
+    eng = ds.BatchEngine(L.ALGO_ADAPTIVE, 4, 512, batch=1)
+    eng.set_steering(steering(4, 512, 0.032)); eng.set_method(2)
+    rng = np.random.default_rng(5)
+    pcm = (rng.standard_normal((450, 1024, 6)) * 1500).astype("<i2")
+    t = []
+    for i in range(450):
+        t0 = time.perf_counter()
+        y = eng.process_pcm16(pcm[i][None], first_channel=1)
+        t.append(time.perf_counter() - t0)
+    t = np.array(t[50:]) * 1e3
+    measured("realtime_chunk_latency", median_ms=np.median(t), p99_ms=np.percentile(t, 99), budget_ms=64.0)
+    assert y.shape == (1, 1024) and np.percentile(t, 99) < 64.0

@@ -287,12 +287,12 @@ def test_tdgsc(golden, name):
     assert np.allclose(o.aic_filter.w, g["w"], rtol=1e-7, atol=1e-10)
 
 
-@pytest.mark.parametrize("name", ["rec1", "rec1_pf", "synth_m6_pf", "burst"])
+@pytest.mark.parametrize("name", ["rec1", "rec1_pf", "synth_m6_pf", "burst", "burst64"])
 def test_fdgsc(golden, name):
     g = golden("g16_fdgsc_" + name)
     M, FL, pf = [int(v) for v in g["params"]]
     x = g["x"].astype(np.float32) / 32768.0 if g["x"].dtype == np.int16 else g["x"]
-    o = O.OracleFDGSC(_mic(M, 512, r=float(g["r"])), frameLen=FL, angle_deg=(197, 0))
+    o = O.OracleFDGSC(_mic(M, 2 * FL, r=float(g["r"])), frameLen=FL, angle_deg=(197, 0))
     out, p, fix, fix_d, bm, al, al_d = o.process(x.T.astype(np.float64), postfilter=bool(pf))
     assert np.allclose(p, g["p"], atol=1e-12)
     assert rms(fix - g["fix_output"]) < 1e-9 * rms(g["fix_output"])
