@@ -75,7 +75,7 @@ EXPORTS = [
     "ds_version", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
     "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_set_window", "ds_process", "ds_process_pcm16", "ds_process_device",
     "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcra_estimate_p", "ds_mcmcra_estimate", "ds_mcsppbase_estimate", "ds_set_aux", "ds_mcspp_estimate", "ds_steering",
-    "ds_mvdr_weight", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process", "ds_tdgsc_process", "ds_fdgsc_process",
+    "ds_mvdr_weight", "ds_pmwf_weight", "ds_gev_vector", "ds_blind_analytic_normalization", "ds_phase_correction", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process", "ds_tdgsc_process", "ds_fdgsc_process",
     "ds_omlsa_estimate", "ds_omlsa_postfilter",
     "ds_sublms_update", "ds_subrls_update", "ds_wpe_update", "ds_synchronize",
     "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_state_payload_bytes", "ds_export_state",
@@ -146,6 +146,14 @@ def load():
     lib.ds_steering.argtypes = [vp, vp, vp, ci]
     lib.ds_mvdr_weight.restype = ci
     lib.ds_mvdr_weight.argtypes = [vp, vp, vp, vp, ci]
+    lib.ds_pmwf_weight.restype = ci
+    lib.ds_pmwf_weight.argtypes = [vp, vp, vp, vp, ctypes.c_float, vp, ci]
+    lib.ds_gev_vector.restype = ci
+    lib.ds_gev_vector.argtypes = [vp, vp, vp, vp, ci]
+    lib.ds_blind_analytic_normalization.restype = ci
+    lib.ds_blind_analytic_normalization.argtypes = [vp, vp, vp, ctypes.c_float, vp, ci]
+    lib.ds_phase_correction.restype = ci
+    lib.ds_phase_correction.argtypes = [vp, vp, vp, ci]
     lib.ds_mcra_estimate_p.restype = ci
     lib.ds_mcra_estimate_p.argtypes = [vp, vp, ci, ci, vp, vp, ci]
     lib.ds_omlsa_postfilter.restype = ci

@@ -301,7 +301,7 @@ int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* ga
 }  // namespace dsi
 extern "C" {
 
-static int run_linalg(ds_handle* h, int op, const char* who, const IoSpec& io, int mem) {
+static int run_linalg(ds_handle* h, int op, const char* who, const IoSpec& io, int mem, float mu = 0.0f, float reg = 0.0f) {
     if (h->cfg.algo != DS_ALGO_LINALG) return fail(h, DS_ESTATE, std::string(who) + ": handle is not a DS_ALGO_LINALG object");
     int rc = set_device(h); if (rc) return rc;
     const float* din[3]; float* dout[5];
@@ -309,7 +309,8 @@ static int run_linalg(ds_handle* h, int op, const char* who, const IoSpec& io, i
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
     p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = 1; p.M = h->cfg.n_mics;
-    p.in0 = din[0]; p.in1 = din[1]; p.out0 = dout[0];
+    p.in0 = din[0]; p.in1 = din[1]; p.in2 = din[2]; p.out0 = dout[0];
+    p.mu = mu; p.reg = reg;
     DS_HIP(h, ds::launch_binop(op, p, h->stream));
     return io_end(h, mem, io, dout);
 }
@@ -326,6 +327,34 @@ int ds_mvdr_weight(ds_handle* h, const float* steer, const float* Rinv, float* w
     const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
     IoSpec io = {{steer, Rinv, nullptr}, {n * M * 8, n * M * M * 8, 0}, {w, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
     return run_linalg(h, ds::OP_MVDRW, "ds_mvdr_weight", io, mem);
+}
+
+int ds_pmwf_weight(ds_handle* h, const float* xi, const float* Rxx, const float* Rvv_inv, float beta, float* w, int mem) {
+    if (!h || !xi || !Rxx || !Rvv_inv || !w) return fail(h, DS_EINVAL, "ds_pmwf_weight: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
+    IoSpec io = {{xi, Rxx, Rvv_inv}, {n * 4, n * M * M * 8, n * M * M * 8}, {w, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
+    return run_linalg(h, ds::OP_PMWFW, "ds_pmwf_weight", io, mem, beta, 0.0f);
+}
+
+int ds_gev_vector(ds_handle* h, const float* target, const float* noise, float* v, int mem) {
+    if (!h || !target || !noise || !v) return fail(h, DS_EINVAL, "ds_gev_vector: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
+    IoSpec io = {{target, noise, nullptr}, {n * M * M * 8, n * M * M * 8, 0}, {v, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
+    return run_linalg(h, ds::OP_GEV, "ds_gev_vector", io, mem);
+}
+
+int ds_blind_analytic_normalization(ds_handle* h, const float* vector, const float* noise, float eps, float* out, int mem) {
+    if (!h || !vector || !noise || !out) return fail(h, DS_EINVAL, "ds_blind_analytic_normalization: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
+    IoSpec io = {{vector, noise, nullptr}, {n * M * 8, n * M * M * 8, 0}, {out, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
+    return run_linalg(h, ds::OP_BAN, "ds_blind_analytic_normalization", io, mem, 0.0f, eps);
+}
+
+int ds_phase_correction(ds_handle* h, const float* vector, float* out, int mem) {
+    if (!h || !vector || !out) return fail(h, DS_EINVAL, "ds_phase_correction: NULL argument");
+    const size_t n = (size_t)h->cfg.batch * h->K, M = h->cfg.n_mics;
+    IoSpec io = {{vector, nullptr, nullptr}, {n * M * 8, 0, 0}, {out, nullptr, nullptr, nullptr, nullptr}, {n * M * 8, 0, 0, 0, 0}};
+    return run_linalg(h, ds::OP_PHASECORR, "ds_phase_correction", io, mem);
 }
 
 int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem) {

@@ -178,4 +178,74 @@ template <int M> DS_HD void mvdr_weight_d(const cd (&Rinv)[M][M], const cd* a, c
     for (int i = 0; i < M; ++i) w[i] = cddiv(num[i], den);
 }
 
+// Generalised Hermitian eigenproblem A v = lambda B v, B positive definite: the eigenvector of the LARGEST eigenvalue, normalised to
+// v^H B v = 1 like scipy.linalg.eigh(a, b)[1][:, -1] (beamformer/beamformer.py:79-97, get_gev_vector).  Cholesky whitening B = L L^H,
+// C = L^-1 A L^-H, Jacobi on C (herm_principal_d: unit-norm y, phase fixed by y_0 real and positive), v = L^-H y.  The PHASE of an
+// eigenvector is LAPACK's business in the reference (the caller's phase_correction removes it from bin to bin and leaves the first
+// bin's): here the whitened vector's first component is real and positive, and the tests compare up to that phase.
+// Returns false where B is not positive definite (the reference's LinAlgError branch: ones / trace(B) * M).
+template <int M> DS_HD bool herm_gev_principal_d(const cd (&A)[M][M], const cd (&Bm)[M][M], cd* v) {
+    double invd[M];
+    cd L[M][M], Li[M][M];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        double s = Bm[j][j].x;
+#pragma unroll
+        for (int q = 0; q < j; ++q) s = fmad_(-L[j][q].x, L[j][q].x, fmad_(-L[j][q].y, L[j][q].y, s));
+        if (!(s > 0.0)) { ok = false; s = 1e-300; }
+        const double r = 1.0 / sqrt(s);
+        invd[j] = r;
+#pragma unroll
+        for (int i = j + 1; i < M; ++i) {
+            cd a = Bm[i][j];
+#pragma unroll
+            for (int q = 0; q < j; ++q) a = cdfnmac(a, L[i][q], L[j][q]);
+            L[i][j] = cdscale(a, r);
+        }
+    }
+    if (!ok) return false;
+#pragma unroll
+    for (int c = 0; c < M; ++c)                                   // Li = L^-1 (lower)
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            if (i < c) { Li[i][c] = mkd(0.0, 0.0); continue; }
+            cd t = (i == c) ? mkd(1.0, 0.0) : mkd(0.0, 0.0);
+#pragma unroll
+            for (int q = c; q < i; ++q) t = cdfnma(t, L[i][q], Li[q][c]);
+            Li[i][c] = cdscale(t, invd[i]);
+        }
+    cd T[M][M], C[M][M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)                                   // T = Li A
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            cd t = mkd(0.0, 0.0);
+#pragma unroll
+            for (int q = 0; q <= i; ++q) t = cdfma(t, Li[i][q], A[q][j]);
+            T[i][j] = t;
+        }
+#pragma unroll
+    for (int i = 0; i < M; ++i)                                   // C = T Li^H (Hermitian: the upper triangle mirrors the lower one)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            cd t = mkd(0.0, 0.0);
+#pragma unroll
+            for (int q = 0; q <= j; ++q) t = cdfmac(t, T[i][q], Li[j][q]);
+            if (i == j) t.y = 0.0;
+            C[i][j] = t;
+            C[j][i] = cdconj(t);
+        }
+    cd y[M];
+    herm_principal_d<M>(C, y);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {                                 // v = Li^H y
+        cd t = mkd(0.0, 0.0);
+#pragma unroll
+        for (int q = i; q < M; ++q) t = cdfma(t, cdconj(Li[q][i]), y[q]);
+        v[i] = t;
+    }
+    return true;
+}
+
 }  // namespace ds

@@ -17,7 +17,8 @@ namespace ds {
 
 enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4, OP_MCSPPBASE = 5, OP_WPE = 6, OP_MCCDR = 7, OP_MCSPP = 8, OP_STEERING = 9,
        OP_MVDRW = 10, OP_ADAPTIVE = 11, OP_MCSPP_LEAN = 12,      // LEAN: McSpp without the MVDR / matrix outputs (the SubbandGSC chain)
-       OP_MCSPP_STEADY = 13 };                                   // ... and its variant for calls from frame 5 on without PMWF weights
+       OP_MCSPP_STEADY = 13,                                     // ... and its variant for calls from frame 5 on without PMWF weights
+       OP_PMWFW = 14, OP_GEV = 15, OP_BAN = 16, OP_PHASECORR = 17 };   // the free functions of beamformer/beamformer.py:34-130 (mvdr.ipynb's GEV flow)
 
 struct OpParams {
     int B, K, KP, T;          // utterances, bins, padded plane length, frames in this call
@@ -1089,6 +1090,112 @@ template <int M> DS_HD void op_mvdrw(const OpCtx& p, int b, int k) {
     for (int m = 0; m < M; ++m) { p.out0[2 * (ab + m)] = (float)w[m].x; p.out0[2 * (ab + m) + 1] = (float)w[m].y; }
 }
 
+
+// stateless: compute_pmwf_weight(xi, Rxx, Rvv_inv, beta) — beamformer/beamformer.py:100-130: w = (Rvv_inv Rxx)[:, 0] / (beta + xi).
+// in0 = xi [B][K], in1 = Rxx complex [B][K][M][M], in2 = Rvv_inv complex [B][K][M][M]; beta in p.mu -> out0 = w complex [B][K][M]
+template <int M> DS_HD void op_pmwfw(const OpCtx& p, int b, int k) {
+    const long long rb = ((long long)b * p.K + k) * M * M, ob = ((long long)b * p.K + k) * M;
+    cd x0[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) x0[i] = mkd((double)p.in1[2 * (rb + i * M)], (double)p.in1[2 * (rb + i * M) + 1]);     // column 0 of Rxx
+    const double den = 1.0 / ((double)p.mu + (double)p.in0[(long long)b * p.K + k]);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        cd t = mkd(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < M; ++j) t = cdfma(t, mkd((double)p.in2[2 * (rb + i * M + j)], (double)p.in2[2 * (rb + i * M + j) + 1]), x0[j]);
+        p.out0[2 * (ob + i)] = (float)(t.x * den); p.out0[2 * (ob + i) + 1] = (float)(t.y * den);
+    }
+}
+
+// stateless: get_gev_vector(target_psd_matrix, noise_psd_matrix) — beamformer/beamformer.py:79-97.  in0 = target complex [B][K][M][M],
+// in1 = noise complex [B][K][M][M] -> out0 = v complex [B][K][M] (principal generalised eigenvector, v^H N v = 1; phase: ds_linalg64.hpp)
+template <int M> DS_HD void op_gev(const OpCtx& p, int b, int k) {
+    cd A[M][M], N[M][M], v[M];
+    const long long base = ((long long)b * p.K + k) * M * M, ob = ((long long)b * p.K + k) * M;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            A[i][j] = mkd((double)p.in0[2 * (base + i * M + j)], (double)p.in0[2 * (base + i * M + j) + 1]);
+            N[i][j] = mkd((double)p.in1[2 * (base + i * M + j)], (double)p.in1[2 * (base + i * M + j) + 1]);
+        }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {                        // scipy's eigh reads the lower triangles
+        A[i][i].y = 0.0; N[i][i].y = 0.0;
+#pragma unroll
+        for (int j = i + 1; j < M; ++j) { A[i][j] = cdconj(A[j][i]); N[i][j] = cdconj(N[j][i]); }
+    }
+    if (!herm_gev_principal_d<M>(A, N, v)) {             // :94-96: ones / trace(noise) * sensors
+        double tr = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) tr += N[i][i].x;
+#pragma unroll
+        for (int i = 0; i < M; ++i) v[i] = mkd((double)M / tr, 0.0);
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) { p.out0[2 * (ob + m)] = (float)v[m].x; p.out0[2 * (ob + m) + 1] = (float)v[m].y; }
+}
+
+// stateless: blind_analytic_normalization(vector, noise_psd_matrix, eps) — beamformer/beamformer.py:34-63:
+// w * |sqrt(w^H N N w)| / (|w^H N w| + eps).  in0 = vector complex [B][K][M], in1 = noise complex [B][K][M][M]; eps in p.reg -> out0
+template <int M> DS_HD void op_ban(const OpCtx& p, int b, int k) {
+    const long long rb = ((long long)b * p.K + k) * M * M, ob = ((long long)b * p.K + k) * M;
+    cd w[M], Nw[M], NNw[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) w[i] = mkd((double)p.in0[2 * (ob + i)], (double)p.in0[2 * (ob + i) + 1]);
+    auto Nat = [&](int i, int j) { return mkd((double)p.in1[2 * (rb + i * M + j)], (double)p.in1[2 * (rb + i * M + j) + 1]); };
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        cd t = mkd(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < M; ++j) t = cdfma(t, Nat(i, j), w[j]);
+        Nw[i] = t;
+    }
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        cd t = mkd(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < M; ++j) t = cdfma(t, Nat(i, j), Nw[j]);
+        NNw[i] = t;
+    }
+    cd nom = mkd(0.0, 0.0), den = mkd(0.0, 0.0);
+#pragma unroll
+    for (int i = 0; i < M; ++i) { nom = cdfmac(nom, NNw[i], w[i]); den = cdfmac(den, Nw[i], w[i]); }    // sum conj(w_i) (..)_i
+    const double scale = sqrt(sqrt(cdabs2(nom))) / (sqrt(cdabs2(den)) + (double)p.reg);                // |sqrt(z)| = sqrt(|z|)
+#pragma unroll
+    for (int m = 0; m < M; ++m) { p.out0[2 * (ob + m)] = (float)(w[m].x * scale); p.out0[2 * (ob + m) + 1] = (float)(w[m].y * scale); }
+}
+
+// stateless: phase_correction(vector) — beamformer/beamformer.py:66-76: bin f is rotated by exp(-j angle(sum_m w[f, m] conj(w[f - 1, m])))
+// with w[f - 1] already corrected: a serial walk over the bins of one utterance (the thread of bin 0 does it).  in0 -> out0, complex [B][K][M]
+template <int M> DS_HD void op_phasecorr(const OpCtx& p, int b, int k) {
+    if (k != 0) return;
+    const long long ub = (long long)b * p.K * M;
+    cd prev[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        prev[m] = mkd((double)p.in0[2 * (ub + m)], (double)p.in0[2 * (ub + m) + 1]);
+        p.out0[2 * (ub + m)] = (float)prev[m].x; p.out0[2 * (ub + m) + 1] = (float)prev[m].y;
+    }
+    for (int f = 1; f < p.K; ++f) {
+        cd cur[M];
+        cd s = mkd(0.0, 0.0);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            cur[m] = mkd((double)p.in0[2 * (ub + (long long)f * M + m)], (double)p.in0[2 * (ub + (long long)f * M + m) + 1]);
+            s = cdfmac(s, cur[m], prev[m]);
+        }
+        const double n = sqrt(cdabs2(s));
+        const cd rot = n > 0.0 ? cdscale(cdconj(s), 1.0 / n) : mkd(1.0, 0.0);     // exp(-j angle(s)); angle(0) = 0
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            prev[m] = cdmul(cur[m], rot);
+            p.out0[2 * (ub + (long long)f * M + m)] = (float)prev[m].x; p.out0[2 * (ub + (long long)f * M + m) + 1] = (float)prev[m].y;
+        }
+    }
+}
+
 // dispatch one (b, k) of an operator; OP and (for the matrix operators) M are compile-time so every operator
 // gets its own register allocation
 // ------------------------------------------------------------------------------------------------
@@ -1142,15 +1249,20 @@ template <int OP, int M> DS_HD void run_op_t(const OpCtx& p, int b, int k) {
     else if constexpr (OP == OP_MCSPP_STEADY) op_mcspp_lean<M, true>(p, b, k);
     else if constexpr (OP == OP_STEERING) op_steering<M>(p, b, k);
     else if constexpr (OP == OP_MVDRW) op_mvdrw<M>(p, b, k);
+    else if constexpr (OP == OP_PMWFW) op_pmwfw<M>(p, b, k);
+    else if constexpr (OP == OP_GEV) op_gev<M>(p, b, k);
+    else if constexpr (OP == OP_BAN) op_ban<M>(p, b, k);
+    else if constexpr (OP == OP_PHASECORR) op_phasecorr<M>(p, b, k);
     else if constexpr (OP == OP_ADAPTIVE) op_adaptive<M>(p, b, k);
 }
 
-inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_MCSPP || op == OP_STEERING || op == OP_MVDRW || op == OP_ADAPTIVE || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY; }
+inline bool op_is_linalg(int op) { return op == OP_STEERING || op == OP_MVDRW || op == OP_PMWFW || op == OP_GEV || op == OP_BAN || op == OP_PHASECORR; }
+inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_MCSPP || op == OP_ADAPTIVE || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY || op_is_linalg(op); }
 
 // is (op, M) a supported combination?  (matrix operators: M in {2, 4, 6, 8}; McSpp / steering / mvdr weight: {2, 4, 6})
 inline bool op_supported(int op, int M) {
     if (op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_ADAPTIVE) return M == 2 || M == 4 || M == 6 || M == 8;
-    if (op == OP_MCSPP || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY || op == OP_STEERING || op == OP_MVDRW) return M == 2 || M == 4 || M == 6;
+    if (op == OP_MCSPP || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY || op_is_linalg(op)) return M == 2 || M == 4 || M == 6;
     return true;
 }
 
@@ -1159,7 +1271,8 @@ inline bool op_supported(int op, int M) {
 #define DS_FOR_EACH_OP(X) \
     X(OP_MCRA, 1) X(OP_OMLSA, 1) X(OP_SUBLMS, 1) X(OP_SUBRLS, 1) X(OP_MCCDR, 1) \
     DS_OP_M_LIST(X, OP_MCMCRA) DS_OP_M_LIST(X, OP_MCSPPBASE) DS_OP_M_LIST(X, OP_ADAPTIVE) \
-    DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_MCSPP_LEAN) DS_OP_M3_LIST(X, OP_MCSPP_STEADY) DS_OP_M3_LIST(X, OP_STEERING) DS_OP_M3_LIST(X, OP_MVDRW)
+    DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_MCSPP_LEAN) DS_OP_M3_LIST(X, OP_MCSPP_STEADY) DS_OP_M3_LIST(X, OP_STEERING) DS_OP_M3_LIST(X, OP_MVDRW) \
+    DS_OP_M3_LIST(X, OP_PMWFW) DS_OP_M3_LIST(X, OP_GEV) DS_OP_M3_LIST(X, OP_BAN) DS_OP_M3_LIST(X, OP_PHASECORR)
 
 // runtime dispatch for the serial CPU run in tests/emul (the GPU launches one specialised kernel per (OP, M))
 inline void run_op(int op, const OpCtx& p, int b, int k) {

@@ -216,6 +216,34 @@ class BatchEngine:
         L.check(self._lib.ds_mvdr_weight(self._h, self._p(steer), self._p(Rinv), self._p(w), L.MEM_HOST), self._h)
         return w
 
+    def pmwf_weight(self, xi, Rxx, Rvv_inv, beta=1.0):
+        xi = np.ascontiguousarray(xi, dtype=np.float32)
+        Rxx = np.ascontiguousarray(Rxx, dtype=np.complex64)
+        Rvv_inv = np.ascontiguousarray(Rvv_inv, dtype=np.complex64)
+        w = np.empty(Rxx.shape[:3], dtype=np.complex64)
+        L.check(self._lib.ds_pmwf_weight(self._h, self._p(xi), self._p(Rxx), self._p(Rvv_inv), float(beta), self._p(w), L.MEM_HOST), self._h)
+        return w
+
+    def gev_vector(self, target, noise):
+        target = np.ascontiguousarray(target, dtype=np.complex64)
+        noise = np.ascontiguousarray(noise, dtype=np.complex64)
+        v = np.empty(target.shape[:3], dtype=np.complex64)
+        L.check(self._lib.ds_gev_vector(self._h, self._p(target), self._p(noise), self._p(v), L.MEM_HOST), self._h)
+        return v
+
+    def blind_analytic_normalization(self, vector, noise, eps=0.0):
+        vector = np.ascontiguousarray(vector, dtype=np.complex64)
+        noise = np.ascontiguousarray(noise, dtype=np.complex64)
+        out = np.empty(vector.shape, dtype=np.complex64)
+        L.check(self._lib.ds_blind_analytic_normalization(self._h, self._p(vector), self._p(noise), float(eps), self._p(out), L.MEM_HOST), self._h)
+        return out
+
+    def phase_correction(self, vector):
+        vector = np.ascontiguousarray(vector, dtype=np.complex64)
+        out = np.empty(vector.shape, dtype=np.complex64)
+        L.check(self._lib.ds_phase_correction(self._h, self._p(vector), self._p(out), L.MEM_HOST), self._h)
+        return out
+
     def tdfilter_update(self, x, d, p=1.0):
         """x, d [B, n] samples -> err [B, n]  (n successive sample-wise NLMS / RLS updates)."""
         x = np.ascontiguousarray(x, dtype=np.float32)

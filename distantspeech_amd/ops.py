@@ -292,6 +292,51 @@ def compute_mvdr_weight(steer_vector, Rvv_inv, Gmin=0.0631, beta=1):
     return w[0] if single else w
 
 
+def compute_pmwf_weight(xi, Rxx, Rvv_inv, Gmin=0.0631, beta=1):
+    """parameterised multichannel Wiener filter w = (Rvv_inv Rxx) e_0 / (beta + xi) — beamformer/beamformer.py:100-130, with the
+    matrices as [bins, M, M] (the reference's docstring says [M, M, bins] but its batched `Rvv_inv @ Rxx @ u` needs [bins, M, M], and
+    its `channels = Rxx.shape[0]` only works where M == bins: here channels = Rxx.shape[1]).  xi [bins] -> w [bins, M] (GPU)."""
+    xi, Rxx, Rvv_inv = np.asarray(xi), np.asarray(Rxx), np.asarray(Rvv_inv)
+    single = Rxx.ndim == 3
+    if single:
+        xi, Rxx, Rvv_inv = xi[None], Rxx[None], Rvv_inv[None]
+    w = _linalg(Rxx.shape[1], Rxx.shape[2], Rxx.shape[0]).pmwf_weight(xi, Rxx, Rvv_inv, beta).astype(np.complex128)
+    return w[0] if single else w
+
+
+def get_gev_vector(target_psd_matrix, noise_psd_matrix):
+    """GEV beamforming vector: the principal generalised eigenvector of (target, noise) per bin, v^H N v = 1 —
+    beamformer/beamformer.py:79-97 (scipy.linalg.eigh(a, b)[1][:, -1]).  An eigenvector's phase is the eigen-solver's business
+    (LAPACK's in the reference; phase_correction removes it from bin to bin): here the first component of the whitened vector is real
+    and positive.  [bins, M, M] -> [bins, M] (Cholesky whitening + complex Jacobi in double on the GPU)."""
+    A, N = np.asarray(target_psd_matrix), np.asarray(noise_psd_matrix)
+    single = A.ndim == 3
+    if single:
+        A, N = A[None], N[None]
+    v = _linalg(A.shape[1], A.shape[2], A.shape[0]).gev_vector(A, N).astype(np.complex128)
+    return v[0] if single else v
+
+
+def blind_analytic_normalization(vector, noise_psd_matrix, eps=0):
+    """vector * |sqrt(v^H N N v)| / (|v^H N v| + eps) — beamformer/beamformer.py:34-63.  [bins, M], [bins, M, M] -> [bins, M] (GPU)."""
+    v, N = np.asarray(vector), np.asarray(noise_psd_matrix)
+    single = v.ndim == 2
+    if single:
+        v, N = v[None], N[None]
+    out = _linalg(v.shape[1], v.shape[2], v.shape[0]).blind_analytic_normalization(v, N, eps).astype(np.complex128)
+    return out[0] if single else out
+
+
+def phase_correction(vector):
+    """bin f rotated by exp(-j angle(sum_m w[f, m] conj(w[f - 1, m]))), bins in order — beamformer/beamformer.py:66-76.  [bins, M] (GPU)."""
+    v = np.asarray(vector)
+    single = v.ndim == 2
+    if single:
+        v = v[None]
+    out = _linalg(v.shape[1], v.shape[2], v.shape[0]).phase_correction(v).astype(np.complex128)
+    return out[0] if single else out
+
+
 class NsOmlsaMulti(_Base):
     """Multichannel (TBRR) OMLSA noise estimate and gain — noise_estimation/omlsa_multi.py:27-156."""
 

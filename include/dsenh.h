@@ -276,6 +276,18 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p, floa
                       float* phi_vv_inv, int mem);
 int ds_steering(ds_handle* h, const float* XX, float* v, int mem);
 int ds_mvdr_weight(ds_handle* h, const float* steer, const float* Rinv, float* w, int mem);
+/* The other free functions of beamformer/beamformer.py the notebook flows use (mvdr.ipynb: get_gev_vector -> phase_correction ->
+ * blind_analytic_normalization; beamformer.py:34-130), on a DS_ALGO_LINALG handle, double arithmetic inside, complex64 in / out:
+ *   ds_pmwf_weight                    xi [B][K], Rxx / Rvv_inv complex [B][K][M][M], beta -> w complex [B][K][M] = (Rvv_inv Rxx)[:, 0] / (beta + xi)
+ *                                     (beamformer.py:100-130; its `channels = Rxx.shape[0]` only works for M == bins: [bins, M, M] matrices here)
+ *   ds_gev_vector                     target / noise complex [B][K][M][M] -> principal generalised eigenvector [B][K][M], v^H N v = 1
+ *                                     (beamformer.py:79-97 = scipy.linalg.eigh(a, b)[1][:, -1]; phase: first whitened component real positive)
+ *   ds_blind_analytic_normalization   vector [B][K][M], noise [B][K][M][M], eps -> vector * |sqrt(v^H N N v)| / (|v^H N v| + eps)   (:34-63)
+ *   ds_phase_correction               vector [B][K][M] -> bin f rotated onto bin f - 1 (serial over the bins of an utterance)      (:66-76) */
+int ds_pmwf_weight(ds_handle* h, const float* xi, const float* Rxx, const float* Rvv_inv, float beta, float* w, int mem);
+int ds_gev_vector(ds_handle* h, const float* target, const float* noise, float* v, int mem);
+int ds_blind_analytic_normalization(ds_handle* h, const float* vector, const float* noise, float eps, float* out, int mem);
+int ds_phase_correction(ds_handle* h, const float* vector, float* out, int mem);
 int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem);
 int ds_firbank(ds_handle* h, const float* x, int n_samples, float* y, float* mean, int mem);
 int ds_firbank_bm(ds_handle* h, const float* x, int n_samples, float* y, float* mean, float* bm, int mem);

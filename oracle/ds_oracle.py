@@ -528,6 +528,46 @@ def compute_mvdr_weight(steer_vector, Rvv_inv):
     return (num / (steer_vector[:, None, :].conj() @ num))[..., 0]
 
 
+def compute_pmwf_weight(xi, Rxx, Rvv_inv, beta=1):
+    """parameterised multichannel Wiener filter w = (Rvv_inv Rxx) u / (beta + xi), u = e_0 — beamformer/beamformer.py:100-130 with the
+    matrices as [bins, M, M] (the batched `Rvv_inv @ Rxx @ u` of :128 needs that layout; the reference's `channels = Rxx.shape[0]`, :124,
+    only works where M == bins — repaired to Rxx.shape[1], make_golden.py R10)."""
+    half_bin, channels = xi.shape[0], Rxx.shape[1]
+    u = np.zeros((half_bin, channels, 1))
+    u[:, 0, 0] = 1                                                                  # :125-127
+    return (Rvv_inv @ Rxx @ u).squeeze() / (beta + xi[:, None])                     # :128
+
+
+def get_gev_vector(target_psd_matrix, noise_psd_matrix):
+    """principal generalised eigenvector per bin, scipy.linalg.eigh(a, b)[1][:, -1] — beamformer/beamformer.py:79-97.  Third-party
+    arithmetic (scipy.linalg.eigh -> LAPACK zhegvd): the eigenvector's phase is LAPACK's."""
+    from scipy.linalg import eigh
+    bins, sensors, _ = target_psd_matrix.shape
+    out = np.empty((bins, sensors), dtype=complex)
+    for f in range(bins):
+        try:
+            out[f, :] = eigh(target_psd_matrix[f], noise_psd_matrix[f])[1][:, -1]  # :91-92
+        except np.linalg.LinAlgError:
+            out[f, :] = np.ones((sensors,)) / np.trace(noise_psd_matrix[f]) * sensors   # :95
+    return out
+
+
+def blind_analytic_normalization(vector, noise_psd_matrix, eps=0):
+    """vector * |sqrt(v^H N N v)| / (|v^H N v| + eps) — beamformer/beamformer.py:34-63."""
+    nominator = np.einsum('...a,...ab,...bc,...c->...', vector.conj(), noise_psd_matrix, noise_psd_matrix, vector)   # :55
+    nominator = np.abs(np.sqrt(nominator))                                          # :56
+    denominator = np.abs(np.einsum('...a,...ab,...b->...', vector.conj(), noise_psd_matrix, vector))                # :58-59
+    return vector * (nominator / (denominator + eps))[..., np.newaxis]              # :61-62
+
+
+def phase_correction(vector):
+    """bin f rotated by exp(-j angle(sum_m w[f, m] conj(w[f - 1, m]))), in bin order — beamformer/beamformer.py:66-76."""
+    w = vector.copy()
+    for f in range(1, w.shape[0]):
+        w[f, :] *= np.exp(-1j * np.angle(np.sum(w[f, :] * w[f - 1, :].conj(), axis=-1, keepdims=True)))              # :75
+    return w
+
+
 class OracleMcSpp:
     """McSpp.estimation — noise_estimation/mcspp.py:46-305 (q from McCDR, complex covariances, PMWF beta = 10)."""
 

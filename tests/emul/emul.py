@@ -120,14 +120,15 @@ class EmulTransform:
 
 class EmulOp:
     """One frame-level operator handle (state + uniform counters), mirrors run_binop() in ds_api.hip."""
-    OPS = {"mcra": 0, "mcmcra": 1, "omlsa": 2, "sublms": 3, "subrls": 4, "mcsppbase": 5, "wpe": 6, "mccdr": 7, "mcspp": 8, "steering": 9, "mvdrw": 10}
+    OPS = {"mcra": 0, "mcmcra": 1, "omlsa": 2, "sublms": 3, "subrls": 4, "mcsppbase": 5, "wpe": 6, "mccdr": 7, "mcspp": 8, "steering": 9, "mvdrw": 10,
+           "pmwfw": 14, "gev": 15, "ban": 16, "phasecorr": 17}
 
     def __init__(self, op, nfft, M=1, N=2, batch=1, mu=None, alpha=0.9, lam=0.998, norm=1, L=15):
         self.op, self.B, self.K, self.M, self.N = self.OPS[op], batch, nfft // 2 + 1, M, N
         self.KP = (self.K + 3) & ~3
         self.NF = {0: 5, 1: M * (M + 1) + 4, 2: 5 * M + (M - 1) + 8, 3: 4 * N * M + 1, 4: 4 * N + 2 * N * N,
                    5: 2 * M * M + 8 + 2 * M,
-                   6: 2 * M * M * N + 2 * M * N + 2 * (M * N) ** 2 + 1, 7: 9, 8: 9 + 2 * M * M + 3, 9: 1, 10: 1}[self.op]
+                   6: 2 * M * M * N + 2 * M * N + 2 * (M * N) ** 2 + 1, 7: 9, 8: 9 + 2 * M * M + 3, 9: 1, 10: 1, 14: 1, 15: 1, 16: 1, 17: 1}[self.op]
         self.st = np.zeros((batch, self.NF, self.KP), dtype=np.float32)
         if self.op == 2:
             o = 5 * M + 1 + (M - 1)
@@ -143,6 +144,7 @@ class EmulOp:
         self.frm, self.ell, self.first, self.L = 0, 1, 1, L
         self.mu = mu if mu is not None else (0.5 if self.op == 4 else 0.1)
         self.alpha, self.lam, self.norm = alpha, lam, norm
+        self.reg = 1e-4
 
     def run(self, in0, in1=None, in2=None, n_out=1, out_complex=False, in_complex=0, out_shapes=None):
         in0 = np.ascontiguousarray(in0)
@@ -158,7 +160,7 @@ class EmulOp:
         rc = lib().emul_op(getattr(self, "op_override", self.op), self.B, self.K, T, _vp(self.st), self.NF, _vp(in0), _vp(in1),
                            _vp(in2), _vp(o[0]), _vp(o[1]), _vp(o[2]), _vp(o[3]), _vp(o[4]), self.M, getattr(self, "N_override", self.N),
                            self.frm, self.ell, L, self.first, int(in_complex), int(in2 is not None), self.norm, f(self.mu),
-                           f(self.alpha), f(1e-4), f(self.lam))
+                           f(self.alpha), f(self.reg), f(self.lam))
         assert rc == 0
         if not getattr(self, "hold_counters", False):
             for _ in range(T):

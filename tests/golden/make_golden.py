@@ -26,6 +26,8 @@ Repairs applied to broken reference entry points, each recorded
       (SubbandGSC.py:23 imports a DelayObj that FDGSC.py does not define).
   R7  Wpe (g10 only): `Wpe.check_input_data(xd, x)` is undefined at HEAD (awpe.py:150); defined here as the
       analogue of SubbandAF.update_input_data (SubbandAF.py:53-60): analyse both signals, set return_td = True.
+  R10 compute_pmwf_weight (g19 only): the free function's `channels = Rxx.shape[0]` (beamformer.py:124) makes `u` [bins, bins, 1], which
+      only multiplies with [bins, M, M] matrices where M == bins; the fixture replays its body with channels = Rxx.shape[1].
 Third-party versions at generation time are recorded in every fixture.
 """
 import contextlib
@@ -696,6 +698,35 @@ def g18_an101():
          y=np.concatenate(outs), W=wpe.W.astype(np.complex64), var=wpe.var, params=np.array([C, N, D, nfft, hop]))
 
 
+def g19_gev(x16):
+    """The notebook's GEV flow (example/mvdr.ipynb: get_gev_vector -> phase_correction -> blind_analytic_normalization -> output) and the
+    free compute_pmwf_weight, on PSD matrices of the reference's recording: target = average of all frames, noise = average of the
+    frames whose power is below the median (plus 1e-6 of its trace on the diagonal)."""
+    from DistantSpeech.beamformer.beamformer import get_gev_vector, phase_correction, blind_analytic_normalization
+    x = x16.astype(np.float32) / 32768.0
+    M = 4
+    tr = Transform(n_fft=512, hop_length=256, channel=M)
+    D = tr.stft(x.T.astype(np.float64))                                                    # [K, T, M]
+    pw = np.mean(np.abs(D) ** 2, axis=(0, 2))
+    quiet = pw < np.median(pw)
+    Phi_yy = np.einsum("ktm,ktn->kmn", D, D.conj()) / D.shape[1]
+    Phi_vv = np.einsum("ktm,ktn->kmn", D[:, quiet], D[:, quiet].conj()) / quiet.sum()
+    Phi_vv = Phi_vv + 1e-6 * np.real(np.trace(Phi_vv, axis1=1, axis2=2))[:, None, None] * np.eye(M)[None]
+    Phi_xx = Phi_yy - Phi_vv
+    W = get_gev_vector(Phi_xx, Phi_vv)
+    Wp = phase_correction(W)
+    Wb = blind_analytic_normalization(Wp, Phi_vv)
+    Yout = np.einsum("inj,ij->in", D, Wb.conj())
+    y = tr.istft(Yout[:, :, None])
+    xi = np.real(np.trace(np.linalg.inv(Phi_vv) @ Phi_xx, axis1=1, axis2=2))
+    Rvv_inv = np.linalg.inv(Phi_vv)
+    u = np.zeros((257, M, 1)); u[:, 0, 0] = 1                                              # R10: compute_pmwf_weight's body with channels = M
+    w_pmwf = {b: (Rvv_inv @ Phi_xx @ u).squeeze() / (b + xi[:, None]) for b in (1, 10)}
+    save("g19_gev", "get_gev_vector / phase_correction / blind_analytic_normalization beamformer/beamformer.py:34-97 as example/mvdr.ipynb "
+         "chains them, and compute_pmwf_weight :100-130 (R10) on PSD matrices of rec1", x=x16, Phi_xx=Phi_xx, Phi_vv=Phi_vv, W_gev=W, W_pc=Wp,
+         W_ban=Wb, Yout=Yout.astype(np.complex64), y=np.asarray(y), xi=xi, w_pmwf_b1=w_pmwf[1], w_pmwf_b10=w_pmwf[10])
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -724,6 +755,7 @@ def main():
     if want("g16"): g16_fdgsc(x16)
     if want("g17"): g17_long()
     if want("g18"): g18_an101()
+    if want("g19"): g19_gev(x16)
 
 
 if __name__ == "__main__":

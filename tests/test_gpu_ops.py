@@ -265,6 +265,41 @@ def test_steering_and_mvdr_weight_random(ds):
         assert np.max(np.abs(compute_mvdr_weight(ref, Rinv) - O.compute_mvdr_weight(ref, Rinv))) < 5e-6
 
 
+def test_gev_flow_and_pmwf_weight(ds):
+    """mvdr.ipynb's GEV flow through the mirrors of the free functions of beamformer/beamformer.py:34-130 (get_gev_vector ->
+    phase_correction -> blind_analytic_normalization -> output; compute_pmwf_weight with R10) against the reference-generated g19.
+    An eigenvector's phase is the solver's (LAPACK's in the reference): single vectors are compared per bin up to a unit phase, the
+    chained output up to ONE global phase (bin 0's matrices are real, so that phase is a sign)."""
+    g = load("g19_gev")
+    A, N = g["Phi_xx"], g["Phi_vv"]
+    v = ds.get_gev_vector(A, N)
+    ref = g["W_gev"]
+    nrm = np.real(np.einsum("ka,kab,kb->k", v.conj(), N, v))
+    c = np.sum(v * ref.conj(), axis=-1, keepdims=True)
+    rel = np.linalg.norm(v * np.exp(-1j * np.angle(c)) - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    pc = ds.phase_correction(ref)
+    bn = ds.blind_analytic_normalization(g["W_pc"], N)
+    w = ds.blind_analytic_normalization(ds.phase_correction(v), N)
+    gc = np.vdot(g["W_ban"], w); gc = gc / abs(gc)
+    x = as_float(g["x"])
+    tr = ds.Transform(channel=4, n_fft=512, hop_length=256)
+    D = tr.stft(x.T)
+    y = np.asarray(tr.istft(np.einsum("inj,ij->in", D, (w * np.conj(gc)).conj())[:, :, None])).reshape(-1)
+    yref = np.asarray(g["y"]).reshape(-1)
+    m = dict(gev_norm_err=np.max(np.abs(nrm - 1.0)), gev_rel_median=np.median(rel), gev_rel_max=np.max(rel),
+             pc_relmax=np.max(np.abs(pc - g["W_pc"])) / np.max(np.abs(g["W_pc"])), ban_relmax=np.max(np.abs(bn - g["W_ban"])) / np.max(np.abs(g["W_ban"])),
+             chain_w_rel_rms=rms(w * np.conj(gc) - g["W_ban"]) / rms(g["W_ban"]), y_rms=rms(y - yref), y_ref_rms=rms(yref))
+    for beta in (1, 10):
+        ww = ds.compute_pmwf_weight(g["xi"], A, np.linalg.inv(N), beta=beta)
+        m["pmwf_rel_rms_b%d" % beta] = rms(ww - g["w_pmwf_b%d" % beta]) / rms(g["w_pmwf_b%d" % beta])
+    measured("G19_gev", **m)
+    assert m["gev_norm_err"] < 1e-3 and m["gev_rel_median"] < 1e-5 and m["gev_rel_max"] < 5e-3
+    assert m["pc_relmax"] < 2e-6 and m["ban_relmax"] < 1e-5
+    assert abs(abs(gc.real) - 1.0) < 1e-4 and m["chain_w_rel_rms"] < 1e-4
+    assert m["y_rms"] < 1e-4                                                  # north star, absolute (signal RMS in y_ref_rms)
+    assert m["pmwf_rel_rms_b1"] < 1e-4 and m["pmwf_rel_rms_b10"] < 1e-4
+
+
 @pytest.mark.parametrize("kind", ["rls", "lms"])
 def test_subband_gsc_fan_equals_instances(ds, kind):
     """The chain runs the M blocking filters of an utterance as ONE thread per bin (shared tap buffer, P / input power and gain:

@@ -271,6 +271,48 @@ def test_emul_steering_and_mvdr_weight():
         assert np.max(np.abs(ww - O.compute_mvdr_weight(ref, Rinv))) < 5e-6    # measured 2e-7 ... 7e-7
 
 
+def _align_phase(v, ref):
+    """rotate every row of v onto ref (an eigenvector's phase is the solver's business)"""
+    c = np.sum(v * ref.conj(), axis=-1, keepdims=True)
+    return v * np.exp(-1j * np.angle(c))
+
+
+def test_emul_gev_flow_and_pmwf_weight():
+    """the operator programs behind ds_gev_vector / ds_phase_correction / ds_blind_analytic_normalization / ds_pmwf_weight (Cholesky
+    whitening + complex Jacobi in double) against the reference-generated fixture g19 (mvdr.ipynb's GEV flow; beamformer.py:34-130)."""
+    g = load("g19_gev")
+    K, M = 257, 4
+    A, N = g["Phi_xx"].astype(np.complex64), g["Phi_vv"].astype(np.complex64)
+    r4 = lambda a: a[None, None].reshape(1, 1, K, -1)
+    v = EmulOp("gev", 512, M=M).run(r4(A), r4(N), out_shapes=[((M,), np.complex64)])[0][0, 0]
+    ref = g["W_gev"]
+    # same vector up to a unit phase per bin, normalised to v^H N v = 1
+    nrm = np.real(np.einsum("ka,kab,kb->k", v.conj(), g["Phi_vv"], v))
+    assert np.max(np.abs(nrm - 1.0)) < 1e-3
+    rel = np.linalg.norm(_align_phase(v, ref) - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert np.median(rel) < 1e-5 and np.max(rel) < 5e-3, (np.median(rel), np.max(rel))      # complex64 matrices in; worst bin = smallest eigen-gap
+    # phase correction and normalisation on the reference's own vectors: exact operations
+    pc = EmulOp("phasecorr", 512, M=M).run(r4(ref.astype(np.complex64)), out_shapes=[((M,), np.complex64)])[0][0, 0]
+    assert np.max(np.abs(pc - g["W_pc"])) < 2e-6 * np.max(np.abs(g["W_pc"]))
+    op = EmulOp("ban", 512, M=M); op.reg = 0.0
+    bn = op.run(r4(g["W_pc"].astype(np.complex64)), r4(N), out_shapes=[((M,), np.complex64)])[0][0, 0]
+    assert np.max(np.abs(bn - g["W_ban"])) < 1e-5 * np.max(np.abs(g["W_ban"]))
+    # the whole chain on the operator's own eigenvectors: the output spectrum up to one global phase (bin 0's eigenvector is real: a sign)
+    pc2 = EmulOp("phasecorr", 512, M=M).run(r4(v), out_shapes=[((M,), np.complex64)])[0][0, 0]
+    op2 = EmulOp("ban", 512, M=M); op2.reg = 0.0
+    w = op2.run(r4(pc2), r4(N), out_shapes=[((M,), np.complex64)])[0][0, 0]
+    c = np.vdot(g["W_ban"], w)
+    c = c / abs(c)
+    assert abs(abs(c.real) - 1.0) < 1e-4
+    assert rms(w * np.conj(c) - g["W_ban"]) < 1e-4 * rms(g["W_ban"])
+    for beta in (1.0, 10.0):
+        opw = EmulOp("pmwfw", 512, M=M); opw.mu = beta
+        ww = opw.run(g["xi"].astype(np.float32)[None, None], r4(A), r4(np.linalg.inv(g["Phi_vv"]).astype(np.complex64)),
+                     out_shapes=[((M,), np.complex64)])[0][0, 0]
+        refw = g["w_pmwf_b%d" % int(beta)]
+        assert rms(ww - refw) < 1e-4 * rms(refw)
+
+
 def test_emul_frontend_ops():
     """FilterDcNotch16 and the TimeAlignment FIR bank against the oracle restatements (chunked, state carried)."""
     from emul.emul import EmulFrontend

@@ -388,3 +388,22 @@ def test_an101_wpe_8_channels(golden):
     y = np.concatenate([wpe.update(xt[n:n + hop])[0] for n in range(0, xt.shape[0], hop)])
     assert rms(y - g["y"]) < 1e-7 * rms(g["y"])
     assert np.allclose(wpe.W, g["W"], rtol=2e-6, atol=1e-9)
+
+
+def test_gev_flow_and_pmwf_weight(golden):
+    """mvdr.ipynb's GEV flow (get_gev_vector -> phase_correction -> blind_analytic_normalization) and the free compute_pmwf_weight
+    (beamformer/beamformer.py:34-130; R10) — scipy's eigh is the same third-party routine the fixture was made with."""
+    g = golden("g19_gev")
+    W = O.get_gev_vector(g["Phi_xx"], g["Phi_vv"])
+    assert np.allclose(W, g["W_gev"], rtol=1e-9, atol=1e-12)
+    Wp = O.phase_correction(W)
+    assert np.allclose(Wp, g["W_pc"], rtol=1e-9, atol=1e-12)
+    Wb = O.blind_analytic_normalization(Wp, g["Phi_vv"])
+    assert np.allclose(Wb, g["W_ban"], rtol=1e-9, atol=1e-12)
+    x = g["x"].astype(np.float32) / 32768.0
+    tr = O.OracleTransform(channel=4, n_fft=512, hop_length=256)
+    D = tr.stft(x.T)
+    y = tr.istft(np.einsum("inj,ij->in", D, Wb.conj())[:, :, None])
+    assert rms(np.asarray(y).reshape(-1) - np.asarray(g["y"]).reshape(-1)) < 1e-7 * rms(g["y"])
+    for beta in (1, 10):
+        assert np.allclose(O.compute_pmwf_weight(g["xi"], g["Phi_xx"], np.linalg.inv(g["Phi_vv"]), beta), g["w_pmwf_b%d" % beta], rtol=1e-9, atol=1e-12)
