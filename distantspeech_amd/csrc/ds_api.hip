@@ -25,7 +25,7 @@ size_t tail_out_bytes(const ds_handle* h) {
     const size_t ch = h->cfg.algo == DS_ALGO_TRANSFORM ? (size_t)h->cfg.n_mics : 1;   // Transform keeps one OLA tail per channel
     return (size_t)h->cfg.batch * ch * h->cfg.hop * sizeof(float);
 }
-size_t opst_bytes(const ds_handle* h) { return h->op >= 0 ? (size_t)h->cfg.batch * h->NF * h->KP * sizeof(float) : 0; }
+size_t opst_bytes(const ds_handle* h) { return h->op >= 0 ? (size_t)h->cfg.batch * op_ust(h) * sizeof(float) : 0; }
 size_t counters_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * 4 * sizeof(int); }
 
 int set_device(ds_handle* h) {
@@ -63,10 +63,10 @@ int zero_state(ds_handle* h) {
     }
     if (h->op >= 0 && h->NF > 0) {
         // operator state: zeros, except the rows the reference initialises to non-zero values
-        std::vector<float> st((size_t)h->cfg.batch * h->NF * h->KP, 0.0f);
-        auto fill_row = [&](int f, float v) {
+        std::vector<float> st((size_t)h->cfg.batch * op_ust(h), 0.0f);
+        auto fill_row = [&](int f, float v) {                // row f of every bin (float4 planes: ds_ops.hpp st_index)
             for (int b = 0; b < h->cfg.batch; ++b)
-                for (int k = 0; k < h->KP; ++k) st[((size_t)b * h->NF + f) * h->KP + k] = v;
+                for (int k = 0; k < h->KP; ++k) st[(size_t)ds::st_index(b, f, k, h->NF, h->KP)] = v;
         };
         if (h->op == ds::OP_OMLSA) {                       // omlsa_multi.py:33-58: gamma, G_H1, G, xi_hat, q_hat = 1
             const int o_s = 5 * h->cfg.n_mics + 1 + (h->cfg.n_mics - 1);
@@ -78,7 +78,7 @@ int zero_state(ds_handle* h) {
             for (int b = 0; b < h->cfg.batch; ++b)
                 for (int k = 0; k < h->K; ++k)
                     for (int i = 0; i < CN; ++i)
-                        st[(size_t)b * h->NF * h->KP + (size_t)k * SB + 2 * (i * (i + 1) / 2 + i)] = 1e-3f;   // diagonal of the packed upper triangle
+                        st[(size_t)b * op_ust(h) + (size_t)k * SB + 2 * (i * (i + 1) / 2 + i)] = 1e-3f;   // diagonal of the packed upper triangle
         }
         if (h->op == ds::OP_SUBRLS) {                      // SubbandRLS.py:40-42: P = I / 1e-3
             const int N = h->filter_len;
@@ -419,7 +419,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         DS_CRE(hipMalloc((void**)&h->td_mem, (size_t)cfg->batch * cfg->n_mics * 2 * sizeof(float)));
         DS_CRE(hipMemset(h->td_mem, 0, (size_t)cfg->batch * cfg->n_mics * 2 * sizeof(float)));
     }
-    if (h->op >= 0 && h->NF > 0) DS_CRE(hipMalloc((void**)&h->opst, (size_t)cfg->batch * h->NF * h->KP * sizeof(float)));
+    if (h->op >= 0 && h->NF > 0) DS_CRE(hipMalloc((void**)&h->opst, (size_t)cfg->batch * op_ust(h) * sizeof(float)));
     const int N = cfg->nfft, NC = N / 2;
     DS_CRE(hipMalloc((void**)&h->steer, (size_t)h->K * cfg->n_mics * sizeof(cf)));
     {
@@ -1117,7 +1117,7 @@ static int extra_state(const ds_handle* h, ExtraState out[3]) {
 // shared-reference / complemented-p subband filters); out_scale_bits: hop / sum(window^2), which moves with a caller-supplied window
 struct BlobHeader { uint32_t magic, version; int32_t algo, nfft, hop, n_mics, batch, filter_len, td_L, track_ryy, layout, modes, wpe_delay; uint32_t out_scale_bits; };
 static const uint32_t BLOB_MAGIC = 0x44534348u;      // "DSCH"
-static const int32_t BLOB_LAYOUT = 2;
+static const int32_t BLOB_LAYOUT = 3;      // 3: operator state as float4 planes [b][f / 4][k][f % 4]
 static BlobHeader blob_header(const ds_handle* h) {
     uint32_t osb;
     std::memcpy(&osb, &h->out_scale, sizeof osb);

@@ -32,7 +32,7 @@ int fdaf_run_dev(ds_handle* h, const float* x, const float* d, const float* pp, 
     p.mu = h->filt_mu; p.alpha = h->filt_alpha;
     p.x = x; p.d = d; p.p = pp; p.err = err; p.w_out = w_out;
     p.x_fan = x_fan; p.x_inst_stride = x_inst_stride; p.x_sample_stride = x_sample_stride; p.x_chan_stride = x_chan_stride;
-    p.state = h->opst; p.state_stride = (long long)h->NF * h->KP;
+    p.state = h->opst; p.state_stride = (long long)op_ust(h);
     p.tables = h->tables;
     DS_HIP(h, ds::launch_fdaf(p, h->cfg.nfft, h->stream));
     return DS_OK;
@@ -85,7 +85,7 @@ int binop_launch(ds_handle* h, int b0, int nb, int n_frames, const float* const 
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
     p.B = nb; p.K = h->K; p.KP = h->KP; p.T = n_frames;
-    p.st = h->opst + (size_t)b0 * h->NF * h->KP; p.NF = h->NF;
+    p.st = h->opst + (size_t)b0 * op_ust(h); p.NF = h->NF;
     p.in0 = din[0]; p.in1 = din[1]; p.in2 = din[2];
     p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
     p.M = h->cfg.n_mics; p.N = h->filter_len;
@@ -128,7 +128,7 @@ int wpe_launch(ds_handle* h, int b0, int nb, const float* x_delayed, const float
     std::memset(&p, 0, sizeof p);
     p.B = nb; p.K = h->K; p.T = n_frames; p.C = h->cfg.n_mics; p.N = h->filter_len;
     p.xd = x_delayed; p.d = d; p.err = err; p.lam = h->rls_lambda;
-    p.ustride = (long long)h->NF * h->KP;
+    p.ustride = (long long)op_ust(h);
     p.state = h->opst + (size_t)b0 * p.ustride;
     p.ring = ring; p.ring_pos = ring_pos; p.ring_len = ring_len; p.dev_ring_pos = dev_ring_pos;
     DS_HIP(h, ds::launch_wpe(p, stream));

@@ -437,7 +437,16 @@ DS_HD void fft_load(ShT& sh, const cf* in, int ch, int j, int Ns, int old_half, 
     static_assert(NB % 16 == 0, "the inputs of a butterfly are NB apart: a constant step in a padded buffer");
     constexpr int RSTEP = pad_step16<PIN>(NB);
     // the R inputs of butterfly j sit at n = j + r NB: one address, constant steps
-    if constexpr (FROM_X) {
+    if constexpr (FROM == 3) {
+        // hop = NFFT / 4 (Transform with 75 % overlap): xbuf is a ring of four quarter-frames and `old_half` the slot of the oldest;
+        // the r-th input of a radix-4 butterfly of the first stage lies in the r-th quarter of the frame
+        static_assert(R == 4 && 2 * NB == NFFT / 4, "first stage of the quarter-hop transform");
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int s = 2 * j + r * 2 * NB, pos = ((old_half + r) & 3) * (NFFT / 4) + 2 * j;
+            v[r] = mk(sh.tb.win[s] * sh.xbuf[ch][pos], sh.tb.win[s + 1] * sh.xbuf[ch][pos + 1]);
+        }
+    } else if constexpr (FROM_X) {
         static_assert(R == 4 || R == 2, "radix");
         const int s0 = 2 * j;                                               // s = s0 + r * 2 NB; 2 NB = HOP / 2 (R = 4) or HOP (R = 2)
 #pragma unroll
@@ -1116,23 +1125,25 @@ template <int M> DS_HD cf aic_bin(float* st, const cf* Xin, cf d, float pk, cons
 }
 // plane f of the canceller's state at bin k of utterance b.  On the device one buffer descriptor per utterance, the lane's bin as the
 // 32-bit offset and the plane in the scalar offset (the addressing of the operator kernels, ds_ops.hpp)
+// (the operator kernels' layout, ds_ops.hpp st_index: float f of bin k at [f / 4][k][f % 4], NF rounded up to whole float4 planes)
+DS_HD constexpr int aic_floats_per_bin(int NF) { return (NF + 3) & ~3; }
 #if defined(__HIP_DEVICE_COMPILE__)
 struct AicState {
     __amdgpu_buffer_rsrc_t rs;
     int KP;
     __device__ AicState(const Params& p, int b, int KP_) : KP(KP_) {
-        rs = __builtin_amdgcn_make_buffer_rsrc(p.aic_st + (long long)b * p.aic_NF * KP_, 0, p.aic_NF * KP_ * 4, 0x00020000);
+        rs = __builtin_amdgcn_make_buffer_rsrc(p.aic_st + (long long)b * aic_floats_per_bin(p.aic_NF) * KP_, 0, aic_floats_per_bin(p.aic_NF) * KP_ * 4, 0x00020000);
     }
-    __device__ float ld(int f, int k) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(k * 4), (unsigned)(f * KP * 4), 0)); }
-    __device__ void st(int f, int k, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (unsigned)(k * 4), (unsigned)(f * KP * 4), 0); }
+    __device__ float ld(int f, int k) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)((k * 4 + (f & 3)) * 4), (unsigned)((f >> 2) * KP * 16), 0)); }
+    __device__ void st(int f, int k, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (unsigned)((k * 4 + (f & 3)) * 4), (unsigned)((f >> 2) * KP * 16), 0); }
 };
 #else
 struct AicState {
     float* base;
     int KP;
-    AicState(const Params& p, int b, int KP_) : base(p.aic_st ? p.aic_st + (long long)b * p.aic_NF * KP_ : nullptr), KP(KP_) {}
-    float ld(int f, int k) const { return base[(long long)f * KP + k]; }
-    void st(int f, int k, float v) const { base[(long long)f * KP + k] = v; }
+    AicState(const Params& p, int b, int KP_) : base(p.aic_st ? p.aic_st + (long long)b * aic_floats_per_bin(p.aic_NF) * KP_ : nullptr), KP(KP_) {}
+    float ld(int f, int k) const { return base[((long long)(f >> 2) * KP + k) * 4 + (f & 3)]; }
+    void st(int f, int k, float v) const { base[((long long)(f >> 2) * KP + k) * 4 + (f & 3)] = v; }
 };
 #endif
 
@@ -1574,22 +1585,28 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
 //   STFT : x [B][..layout..]  ->  Y complex [B][T][K][M]   (p.y, p.y_batch_stride in floats)
 //   ISTFT: Y complex [B][T][K][C] (p.x, p.x_batch_stride in floats) -> y [B][T*hop][C]   (C = p.method <= M)
 // ---------------------------------------------------------------------------------------------
-template <int NFFT, int M, bool CDR = false> struct StftEngine {
+// OV = NFFT / hop: 2 (the half-overlap every beamformer object uses), or 4 for Transform(n_fft, hop_length = n_fft / 4)
+// (transform.py:407-428 takes any hop; wpe.ipynb runs 75 % overlap): the LDS sample buffer becomes a ring of four quarter-frames.
+template <int NFFT, int M, bool CDR = false, int OV = 2> struct StftEngine {
     typedef Engine<NFFT, M, ALGO_FIXED, false> EB;
     static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2, NT = NC;
     typedef typename EB::Sh Sh;
     typedef typename EB::Rg Rg;
+    static constexpr int HOPX = NFFT / OV, OVL = NFFT - HOPX;        // hop and carried overlap of this transform
     static_assert(!CDR || M >= 3, "McCDR takes microphones 0, 1 and 2");
+    static_assert(OV == 2 || (OV == 4 && !CDR), "overlap");
 
     template <class Exec> static DS_HD void run(Exec& ex, const Params& p, int blk, Sh& sh) {
         const int b = p.batch0 + blk;
         const long long xb = (long long)blk * p.x_batch_stride;
-        float* tin = p.tail_in + (long long)b * M * HOP;
+        float* tin = p.tail_in + (long long)b * M * OVL;
         cf* Yout = reinterpret_cast<cf*>(p.y + (long long)blk * p.y_batch_stride);
         int old_half = 0;
         constexpr int KP = (K + 3) & ~3;
         // McCDR's planes of this utterance (rows 0..8 of the McSpp stage's state), bin `tid` in registers for the call, the Nyquist bin on lane 0
-        auto cdr_plane = [&](int f, int k) -> float& { return p.cdr_st[((long long)b * p.cdr_NF + f) * KP + k]; };
+        auto cdr_plane = [&](int f, int k) -> float& {                 // ds_ops.hpp st_index
+            return p.cdr_st[(((long long)b * (aic_floats_per_bin(p.cdr_NF) >> 2) + (f >> 2)) * KP + k) * 4 + (f & 3)];
+        };
         int frm = 0, ell = 0;
         if constexpr (CDR) { frm = p.cdr_frm; ell = p.cdr_ell; }
         const int fmin = (int)(500.0 * (2 * (K - 1)) / 16000.0), fmax = (int)(2000.0 * (2 * (K - 1)) / 16000.0);   // mcspp.py:258-259
@@ -1603,12 +1620,14 @@ template <int NFFT, int M, bool CDR = false> struct StftEngine {
             vec4* tb4 = reinterpret_cast<vec4*>(&sh.tb);
             for (int i = tid; i < Tables<NFFT>::NV4; i += NT) tb4[i] = p.tables[i];
             const vec4* tin4 = reinterpret_cast<const vec4*>(tin);
-            for (int i = tid; i < M * HOP / 4; i += NT) {
-                const int m = i / (HOP / 4), q = i - m * (HOP / 4);
+            for (int i = tid; i < M * OVL / 4; i += NT) {                      // OV = 4: the three carried quarters fill slots 0..2
+                const int m = i / (OVL / 4), q = i - m * (OVL / 4);
                 *reinterpret_cast<vec4*>(&sh.xbuf[m][4 * q]) = tin4[i];
             }
-            EB::prefetch_init(p, xb, tid, r);
-            EB::prefetch(p, xb, 0, tid, r);
+            if constexpr (OV == 2) {
+                EB::prefetch_init(p, xb, tid, r);
+                EB::prefetch(p, xb, 0, tid, r);
+            }
             if constexpr (CDR) {
 #pragma unroll
                 for (int f = 0; f < 9; ++f) r.cdr[f] = cdr_plane(f, tid);
@@ -1621,14 +1640,28 @@ template <int NFFT, int M, bool CDR = false> struct StftEngine {
         for (int t = 0; t < p.T; ++t) {
             const int new_half = old_half ^ 1;
             auto ph = [&](bool wave_local, auto f) { if (wave_local) ex.phase_wave(f); else ex.phase(f); };   // see Engine::run
+            cf* fa = &sh.fa[0][0];
+            cf* fb = &sh.fb[0][0];
+            if constexpr (OV == 4) {
+                const int slot = (t + 3) & 3;                                  // the new quarter replaces the oldest one
+                ex.phase([&](int tid, Rg&) {
+                    for (int i = tid; i < M * HOPX; i += NT) {
+                        int m, n;
+                        long long off;
+                        if (p.x_sample_stride == 1) { m = i / HOPX; n = i - m * HOPX; off = (long long)m * p.x_chan_stride + (long long)t * HOPX + n; }
+                        else { n = i / M; m = i - n * M; off = ((long long)t * HOPX + n) * M + m; }
+                        sh.xbuf[m][slot * HOPX + n] = p.x[xb + off];
+                    }
+                });
+                ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, 3, 0, 1>(tid, NT, sh, nullptr, fa, 1, (slot + 1) & 3, M); });
+            } else {
             ph(EB::WAVE_FFT && p.x_sample_stride == 1, [&](int tid, Rg& r) {
                 EB::commit(p, sh, new_half, tid, r);
                 if (t + 1 < p.T) EB::prefetch(p, xb, t + 1, tid, r);
                 if constexpr (CDR) { if (t > 0 && tid == NT - 1) band_mean(t - 1); }      // Gamma of the previous frame is behind a barrier by now
             });
-            cf* fa = &sh.fa[0][0];
-            cf* fb = &sh.fb[0][0];
             ph(EB::WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half, M); });
+            }
             ph(EB::WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 1, 2>(tid, NT, sh, fa, fb, 4, 0, M); });
             ph(EB::WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, false, 2, 0>(tid, NT, sh, fb, fa, 16, 0, M); });
             if (NC == 128) {
@@ -1692,9 +1725,17 @@ template <int NFFT, int M, bool CDR = false> struct StftEngine {
         }
         ex.phase([&](int tid, Rg& r) {
             vec4* tin4 = reinterpret_cast<vec4*>(tin);
+            if constexpr (OV == 4) {                                           // the three newest quarters, oldest first
+                const int first = p.T & 3;                                     // = (slot of the last hop + 2) & 3; 0 for an empty call
+                for (int i = tid; i < M * OVL / 4; i += NT) {
+                    const int m = i / (OVL / 4), q = i - m * (OVL / 4), qq = q / (HOPX / 4), e = q - qq * (HOPX / 4);
+                    tin4[i] = *reinterpret_cast<const vec4*>(&sh.xbuf[m][((first + qq) & 3) * HOPX + 4 * e]);
+                }
+            } else {
             for (int i = tid; i < M * HOP / 4; i += NT) {
                 const int m = i / (HOP / 4), q = i - m * (HOP / 4);
                 tin4[i] = *reinterpret_cast<const vec4*>(&sh.xbuf[m][old_half * HOP + 4 * q]);
+            }
             }
             if constexpr (CDR) {
                 if (p.T > 0 && tid == NT - 1) band_mean(p.T - 1);

@@ -135,6 +135,8 @@ size_t bins_bytes(const ds_handle* h);
 size_t tail_in_bytes(const ds_handle* h);
 size_t tail_out_bytes(const ds_handle* h);
 size_t opst_bytes(const ds_handle* h);
+// floats between the utterances of an operator handle's state: NF rounded up to whole float4 planes (ds_ops.hpp: st_index) times KP
+inline size_t op_ust(const ds_handle* h) { return (size_t)ds::st_floats_per_bin(h->NF) * h->KP; }
 size_t counters_bytes(const ds_handle* h);
 int set_device(ds_handle* h);
 int zero_state(ds_handle* h);

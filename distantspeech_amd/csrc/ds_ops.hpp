@@ -62,6 +62,18 @@ struct OpParams {
     int spill_stride;         // this lane at spill[f * spill_stride]; null = keep everything in registers
 };
 
+// State of the per-thread operators in memory: float f of bin k of utterance b at [b][f / 4][k][f % 4] — planes of float4, so that a lane
+// reads and writes its bin's state as 16-byte accesses (the frame kernels' planes reach 6.2 TB/s that way, 4-byte planes 4.85:
+// scratch/micro/planes_bw.hip); NF is rounded up to a multiple of 4 per utterance.  (Round 2 kept [b][f][k] planes of single floats.)
+DS_HD constexpr int st_floats_per_bin(int NF) { return (NF + 3) & ~3; }
+DS_HD long long st_index(int b, int f, int k, int NF, int KP) {
+#ifdef DS_OLD_OPSTATE      // bisection builds only: round 2's [b][f][k] planes (the chain tail / CDR kernels keep the new layout: do not mix)
+    return ((long long)b * st_floats_per_bin(NF) + f) * KP + k;
+#else
+    return (((long long)b * (st_floats_per_bin(NF) >> 2) + (f >> 2)) * KP + k) * 4 + (f & 3);
+#endif
+}
+
 // Per-bin state access st_at(p, b, plane, k).  On the GPU it is a buffer access: the descriptor starts at the state of the first utterance
 // of the workgroup (wave-uniform), the lane contributes ONE 32-bit offset and the plane offset travels in an SGPR — one address register
 // per lane instead of a 64-bit pointer per plane kept live from the loads to the stores (150 registers for the 75 planes of a 6-mic McSpp).
@@ -84,19 +96,58 @@ __device__ inline OpCtx make_op_ctx(const OpParams& p0, long long first_lane) { 
     static_cast<OpParams&>(c) = p0;
     if (p0.dev_cnt) { c.frm_cnt = p0.dev_cnt[0]; c.ell = p0.dev_cnt[1]; c.first_frame = p0.dev_cnt[2]; }
     c.b0 = (int)(first_lane / p0.KP);
-    const long long off = (long long)c.b0 * p0.NF * p0.KP;
-    const long long left = ((long long)p0.B * p0.NF * p0.KP - off) * 4;
+    const long long off = (long long)c.b0 * st_floats_per_bin(p0.NF) * p0.KP;
+    const long long left = ((long long)p0.B * st_floats_per_bin(p0.NF) * p0.KP - off) * 4;
     c.rs = __builtin_amdgcn_make_buffer_rsrc(p0.st + off, 0, (int)(unsigned)(left > 0xffffffffLL ? 0xffffffffLL : (left > 0 ? left : 0)), 0x00020000);
     return c;
 }
 __device__ inline StRef st_at(const OpCtx& p, int b, int f, int k) {
-    return StRef(p.rs, (unsigned)(((b - p.b0) * p.NF * p.KP + k) * 4), (unsigned)(f * p.KP * 4));
+    // [b][f / 4][k][f % 4]: the lane offset addresses the bin's 16-byte group, the plane group travels in the SGPR offset and f % 4 is an
+    // immediate — four neighbouring floats of a bin merge into one 16-byte access per lane
+#ifdef DS_OLD_OPSTATE
+    return StRef(p.rs, (unsigned)(((b - p.b0) * st_floats_per_bin(p.NF) * p.KP + k) * 4), (unsigned)(f * p.KP * 4));
+#else
+    return StRef(p.rs, (unsigned)((((b - p.b0) * st_floats_per_bin(p.NF) * p.KP + k * 4) + (f & 3)) * 4), (unsigned)((f >> 2) * p.KP * 16));
+#endif
+}
+// one whole float4 plane group q (floats 4 q .. 4 q + 3) of bin k as ONE 16-byte access
+// (four dword loads at consecutive immediate offsets: the backend merges them into one buffer_load_dwordx4.  ROCm 7.2's
+// __builtin_amdgcn_raw_buffer_load_b128 is lowered to a ONE-dword load — three result words undefined — so it is not used; the b128
+// STORE builtin below is lowered correctly, and single-dword stores are not merged reliably)
+__device__ inline void st_load4(const OpCtx& p, int b, int q, int k, float* d) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = st_at(p, b, 4 * q + j, k);
+}
+// (four dword stores at consecutive immediate offsets, which the backend merges (dwordx3 + dword in ROCm 7.2).  The b128 STORE builtin
+// was tried as well: single-stream results were right, but with two utterance groups of a chain running on two streams the outputs
+// carried NaNs at random — scratch/dbg_groups.py, DESIGN.md "Operator state as float4 planes" — so neither b128 builtin is used)
+__device__ inline void st_store4(const OpCtx& p, int b, int q, int k, const float* s) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st_at(p, b, 4 * q + j, k) = s[j];
 }
 #else
 typedef OpParams OpCtx;
 DS_HD OpCtx make_op_ctx(const OpParams& p0, long long) { return p0; }
-DS_HD float& st_at(const OpCtx& p, int b, int f, int k) { return p.st[((long long)b * p.NF + f) * p.KP + k]; }
+DS_HD float& st_at(const OpCtx& p, int b, int f, int k) { return p.st[st_index(b, f, k, p.NF, p.KP)]; }
+DS_HD void st_load4(const OpCtx& p, int b, int q, int k, float* d) { for (int j = 0; j < 4; ++j) d[j] = st_at(p, b, 4 * q + j, k); }
+DS_HD void st_store4(const OpCtx& p, int b, int q, int k, const float* s) { for (int j = 0; j < 4; ++j) st_at(p, b, 4 * q + j, k) = s[j]; }
 #endif
+// floats F0 .. F0 + N - 1 of a bin into / out of registers: whole float4 groups as 16-byte accesses, the ragged ends float by float
+// (compile-time recursion: every register index is a constant)
+template <int F, int END, int F0> DS_HD void st_load_from(const OpCtx& p, int b, int k, float* d) {
+    if constexpr (F < END) {
+        if constexpr ((F & 3) == 0 && F + 4 <= END) { st_load4(p, b, F >> 2, k, d + (F - F0)); st_load_from<F + 4, END, F0>(p, b, k, d); }
+        else { d[F - F0] = st_at(p, b, F, k); st_load_from<F + 1, END, F0>(p, b, k, d); }
+    }
+}
+template <int F, int END, int F0> DS_HD void st_store_from(const OpCtx& p, int b, int k, const float* s) {
+    if constexpr (F < END) {
+        if constexpr ((F & 3) == 0 && F + 4 <= END) { st_store4(p, b, F >> 2, k, s + (F - F0)); st_store_from<F + 4, END, F0>(p, b, k, s); }
+        else { st_at(p, b, F, k) = s[F - F0]; st_store_from<F + 1, END, F0>(p, b, k, s); }
+    }
+}
+template <int F0, int N> DS_HD void st_load_span(const OpCtx& p, int b, int k, float* d) { st_load_from<F0, F0 + N, F0>(p, b, k, d); }
+template <int F0, int N> DS_HD void st_store_span(const OpCtx& p, int b, int k, const float* s) { st_store_from<F0, F0 + N, F0>(p, b, k, s); }
 
 // advance the uniform MCRA counters by one frame (mcra.py:52-56,72-74); returns `reset` for this frame
 DS_HD bool mcra_tick(int& frm, int& ell, int L) {
@@ -139,9 +190,10 @@ DS_HD void op_mcra(const OpCtx& p, int b, int k) {
 // ------------------------------------------------------------------------------------------------
 template <int M> DS_HD void op_mcmcra(const OpCtx& p, int b, int k) {
     constexpr int NS = M * (M + 1) / 2;
-    float pyy[NS], pvv[NS];
-#pragma unroll
-    for (int f = 0; f < NS; ++f) { pyy[f] = st_at(p, b, f, k); pvv[f] = st_at(p, b, NS + f, k); }
+    float both[2 * NS + 4];                                  // Phi_yy, Phi_vv (packed symmetric), then xi, gamma, p, G: the bin's whole state
+    float* pyy = both;
+    float* pvv = both + NS;
+    st_load_span<0, 2 * NS>(p, b, k, both);
     float pp = 0, G = 0, xi = 0, gam = 0;
     int frm = p.frm_cnt;
     for (int t = 0; t < p.T; ++t) {
@@ -155,11 +207,11 @@ template <int M> DS_HD void op_mcmcra(const OpCtx& p, int b, int k) {
         p.out0[ob] = pp;
         p.out1[ob] = G;
     }
-#pragma unroll
-    for (int f = 0; f < NS; ++f) { st_at(p, b, f, k) = pyy[f]; st_at(p, b, NS + f, k) = pvv[f]; }
     if (p.T > 0) {
-        st_at(p, b, 2 * NS + 0, k) = xi; st_at(p, b, 2 * NS + 1, k) = gam;
-        st_at(p, b, 2 * NS + 2, k) = pp; st_at(p, b, 2 * NS + 3, k) = G;
+        both[2 * NS + 0] = xi; both[2 * NS + 1] = gam; both[2 * NS + 2] = pp; both[2 * NS + 3] = G;
+        st_store_span<0, 2 * NS + 4>(p, b, k, both);
+    } else {
+        st_store_span<0, 2 * NS>(p, b, k, both);
     }
 }
 
@@ -520,14 +572,11 @@ template <int N, int F> DS_HD void op_subrls_fan(const OpCtx& p, int u, int k) {
     const float lam_inv = 1.0f / p.lam;
     const int b0 = u * F;
     cf W[F][N], X[N], P[N][N];
+    // rows 2 i, 2 i + 1 of an instance are (Re, Im) of tap i: a cf array IS the run of rows it mirrors — whole float4 groups per access
+    st_load_span<oX, 2 * N>(p, b0, k, reinterpret_cast<float*>(&X[0]));
+    st_load_span<oP, 2 * N * N>(p, b0, k, reinterpret_cast<float*>(&P[0][0]));
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        X[i] = mk(st_at(p, b0, oX + 2 * i, k), st_at(p, b0, oX + 2 * i + 1, k));
-#pragma unroll
-        for (int j = 0; j < N; ++j) P[i][j] = mk(st_at(p, b0, oP + 2 * (i * N + j), k), st_at(p, b0, oP + 2 * (i * N + j) + 1, k));
-#pragma unroll
-        for (int m = 0; m < F; ++m) W[m][i] = mk(st_at(p, b0 + m, 2 * i, k), st_at(p, b0 + m, 2 * i + 1, k));
-    }
+    for (int m = 0; m < F; ++m) st_load_span<0, 2 * N>(p, b0 + m, k, reinterpret_cast<float*>(&W[m][0]));
     for (int t = 0; t < p.T; ++t) {
         const long long fx = ((long long)u * p.T + t) * p.K + k;
 #pragma unroll
@@ -571,13 +620,9 @@ template <int N, int F> DS_HD void op_subrls_fan(const OpCtx& p, int u, int k) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-#pragma unroll
-        for (int m = 0; m < F; ++m) { st_at(p, b0 + m, 2 * i, k) = W[m][i].x; st_at(p, b0 + m, 2 * i + 1, k) = W[m][i].y; }
-        st_at(p, b0, oX + 2 * i, k) = X[i].x; st_at(p, b0, oX + 2 * i + 1, k) = X[i].y;
-#pragma unroll
-        for (int j = 0; j < N; ++j) { st_at(p, b0, oP + 2 * (i * N + j), k) = P[i][j].x; st_at(p, b0, oP + 2 * (i * N + j) + 1, k) = P[i][j].y; }
-    }
+    for (int m = 0; m < F; ++m) st_store_span<0, 2 * N>(p, b0 + m, k, reinterpret_cast<const float*>(&W[m][0]));
+    st_store_span<oX, 2 * N>(p, b0, k, reinterpret_cast<const float*>(&X[0]));
+    st_store_span<oP, 2 * N * N>(p, b0, k, reinterpret_cast<const float*>(&P[0][0]));
 }
 // can a SubbandRLS call run as op_subrls_fan?
 inline bool subrls_fan_ok(const OpParams& p) {
@@ -784,9 +829,11 @@ DS_HD void op_mccdr(const OpCtx& p, int b, int k) {
 // in0 = y complex [B][T][K][M], in1 = Gamma [B][T][K] (op_mccdr);
 // out0 = p [B][T][K], out1 = w_pmwf complex [B][T][K][M], out2 = Yout complex [B][T][K] (optional),
 // out3 = Phi_xx, out4 = Phi_vv_inv complex [B][T][K][M][M] (optional).
-// state floats (row offset p.N): Phi_yy, Phi_vv Hermitian packed (M*M each), xi, gamma, p
+// state floats: rows 0 .. 8 McCDR's, 9 .. 11 unused (the matrices start on a float4 plane, so that their 16-byte groups are known at compile
+// time: MCSPP_ROW0), then Phi_yy, Phi_vv Hermitian packed (M*M each), xi, gamma, p
 // ------------------------------------------------------------------------------------------------
-DS_HD int mcspp_nf(int M) { return 9 + 2 * M * M + 3; }
+constexpr int MCSPP_ROW0 = 12;
+DS_HD int mcspp_nf(int M) { return MCSPP_ROW0 + 2 * M * M + 3; }
 
 // np.mean(q[fmin:fmax]) of one frame (mcspp.py:260), q = 1 - Gamma; summed in bin order
 DS_HD float mcspp_qavg(const float* gamma_frame, int fmin, int fmax) {
@@ -797,12 +844,15 @@ DS_HD float mcspp_qavg(const float* gamma_frame, int fmin, int fmax) {
 
 template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
-    const int o0 = p.N;                                                            // state row offset of the McSpp part
-    float yd[M], yo[2 * NO + 1], vd[M], vo[2 * NO + 1];
-#pragma unroll
-    for (int f = 0; f < M; ++f) { yd[f] = st_at(p, b, o0 + f, k); vd[f] = st_at(p, b, o0 + M * M + f, k); }
-#pragma unroll
-    for (int f = 0; f < 2 * NO; ++f) { yo[f] = st_at(p, b, o0 + M + f, k); vo[f] = st_at(p, b, o0 + M * M + M + f, k); }
+    constexpr int o0 = MCSPP_ROW0;                                                 // state row offset of the McSpp part
+    // rows o0 .. o0 + 2 M M - 1 = Phi_yy (diagonal, upper triangle), Phi_vv (the same), then xi, gamma, p: one register block, moved as
+    // whole float4 groups (o0 is a multiple of 4)
+    float mat[2 * M * M + 4];
+    float* yd = mat;
+    float* yo = mat + M;
+    float* vd = mat + M * M;
+    float* vo = mat + M * M + M;
+    st_load_span<o0, 2 * M * M>(p, b, k, mat);
     int frm = p.frm_cnt;
     const int fmin = (int)(500.0 * (2 * (p.K - 1)) / 16000.0), fmax = (int)(2000.0 * (2 * (p.K - 1)) / 16000.0);   // :258-259
     float xi = 0, gam = 0, pp = 0;
@@ -933,12 +983,12 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
         }
         frm += 1;
     }
-    const int ks = k;
-#pragma unroll
-    for (int f = 0; f < M; ++f) { st_at(p, b, o0 + f, ks) = yd[f]; st_at(p, b, o0 + M * M + f, ks) = vd[f]; }
-#pragma unroll
-    for (int f = 0; f < 2 * NO; ++f) { st_at(p, b, o0 + M + f, ks) = yo[f]; st_at(p, b, o0 + M * M + M + f, ks) = vo[f]; }
-    if (p.T > 0) { st_at(p, b, o0 + 2 * M * M, ks) = xi; st_at(p, b, o0 + 2 * M * M + 1, ks) = gam; st_at(p, b, o0 + 2 * M * M + 2, ks) = pp; }
+    if (p.T > 0) {
+        mat[2 * M * M] = xi; mat[2 * M * M + 1] = gam; mat[2 * M * M + 2] = pp;
+        st_store_span<o0, 2 * M * M + 3>(p, b, k, mat);
+    } else {
+        st_store_span<o0, 2 * M * M>(p, b, k, mat);
+    }
 }
 
 // McSpp without the notebook-MVDR / matrix outputs (OP_MCSPP_LEAN, the SubbandGSC chain): the same estimation_core, but nothing here
@@ -947,12 +997,15 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
 // inverse, and less than a pair of substitutions per column of Phi_yy (the first form of this operator: 233 registers, 211 now at M = 6).
 template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
-    const int o0 = p.N;
-    float yd[M], yo[2 * NO + 1], vd[M], vo[2 * NO + 1];
-#pragma unroll
-    for (int f = 0; f < M; ++f) { yd[f] = st_at(p, b, o0 + f, k); vd[f] = st_at(p, b, o0 + M * M + f, k); }
-#pragma unroll
-    for (int f = 0; f < 2 * NO; ++f) { yo[f] = st_at(p, b, o0 + M + f, k); vo[f] = st_at(p, b, o0 + M * M + M + f, k); }
+    constexpr int o0 = MCSPP_ROW0;
+    // rows o0 .. o0 + 2 M M - 1 = Phi_yy (diagonal, upper triangle), Phi_vv (the same), then xi, gamma, p: one register block, moved as
+    // whole float4 groups (o0 is a multiple of 4)
+    float mat[2 * M * M + 4];
+    float* yd = mat;
+    float* yo = mat + M;
+    float* vd = mat + M * M;
+    float* vo = mat + M * M + M;
+    st_load_span<o0, 2 * M * M>(p, b, k, mat);
     int frm = p.frm_cnt;
     const int fmin = (int)(500.0 * (2 * (p.K - 1)) / 16000.0), fmax = (int)(2000.0 * (2 * (p.K - 1)) / 16000.0);   // :258-259
     float xi = 0, gam = 0, pp = 0;
@@ -1047,12 +1100,12 @@ template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, i
         p.out0[ob] = pp;
         frm += 1;
     }
-    const int ks = k;
-#pragma unroll
-    for (int f = 0; f < M; ++f) { st_at(p, b, o0 + f, ks) = yd[f]; st_at(p, b, o0 + M * M + f, ks) = vd[f]; }
-#pragma unroll
-    for (int f = 0; f < 2 * NO; ++f) { st_at(p, b, o0 + M + f, ks) = yo[f]; st_at(p, b, o0 + M * M + M + f, ks) = vo[f]; }
-    if (p.T > 0) { st_at(p, b, o0 + 2 * M * M, ks) = xi; st_at(p, b, o0 + 2 * M * M + 1, ks) = gam; st_at(p, b, o0 + 2 * M * M + 2, ks) = pp; }
+    if (p.T > 0) {
+        mat[2 * M * M] = xi; mat[2 * M * M + 1] = gam; mat[2 * M * M + 2] = pp;
+        st_store_span<o0, 2 * M * M + 3>(p, b, k, mat);
+    } else {
+        st_store_span<o0, 2 * M * M>(p, b, k, mat);
+    }
 }
 
 // stateless: steering(XXs) — in0 = XX complex [B][K][M][M] -> out0 = v complex [B][K][M]
@@ -1207,8 +1260,7 @@ template <int M> DS_HD void op_phasecorr(const OpCtx& p, int b, int k) {
 template <int M> DS_HD void op_adaptive(const OpCtx& p, int b, int k) {
     typedef StateLayout<M, ALGO_ADAPTIVE, false> SL;
     float st[SL::NF];
-#pragma unroll
-    for (int f = 0; f < SL::NF; ++f) st[f] = st_at(p, b, f, k);
+    st_load_span<0, SL::NF>(p, b, k, st);
     cf a[M];
     const cf* sv = p.steer + (long long)b * p.steer_batch_stride + (long long)k * M;
 #pragma unroll
@@ -1232,8 +1284,7 @@ template <int M> DS_HD void op_adaptive(const OpCtx& p, int b, int k) {
         if (p.has_p) Y = cscale(Y, p.in1[fb + k]);
         p.out0[2 * (fb + k)] = Y.x; p.out0[2 * (fb + k) + 1] = Y.y;
     }
-#pragma unroll
-    for (int f = 0; f < SL::NF; ++f) st_at(p, b, f, k) = st[f];
+    st_store_span<0, SL::NF>(p, b, k, st);
 }
 
 template <int OP, int M> DS_HD void run_op_t(const OpCtx& p, int b, int k) {

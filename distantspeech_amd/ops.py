@@ -235,7 +235,7 @@ class McSpp(_Base):
             self.steer_vector = mic_array.steering_vector(look_direction=30).T          # mcspp.py:64-66
         self._last = None
         self._repeat = False
-        self._o = 9 + 2 * channels * channels
+        self._o = 12 + 2 * channels * channels              # ds_ops.hpp MCSPP_ROW0: rows 0..8 McCDR, 9..11 unused, then the two matrices
         self.frm_cnt = 0
 
     def estimation(self, y, diag_value=1e-4, repeat=False):

@@ -30,6 +30,24 @@ template <class Rg> struct CpuExec {
     void sync() {}
 };
 
+// The Python side of the emulator keeps operator state as logical planes [B][NF][KP]; the kernels keep it as float4 planes
+// [B][ceil(NF / 4)][KP][4] (ds_ops.hpp st_index).  StPlanes packs on entry and unpacks on exit.
+struct StPlanes {
+    float* logical; int B, NF, KP; std::vector<float> phys;
+    StPlanes(float* st, int B_, int NF_, int KP_) : logical(st), B(B_), NF(NF_), KP(KP_) {
+        if (!st) return;
+        phys.assign((size_t)B * ds::st_floats_per_bin(NF) * KP, 0.0f);
+        for (int b = 0; b < B; ++b) for (int f = 0; f < NF; ++f) for (int k = 0; k < KP; ++k)
+            phys[(size_t)ds::st_index(b, f, k, NF, KP)] = st[((size_t)b * NF + f) * KP + k];
+    }
+    float* data() { return logical ? phys.data() : nullptr; }
+    ~StPlanes() {
+        if (!logical) return;
+        for (int b = 0; b < B; ++b) for (int f = 0; f < NF; ++f) for (int k = 0; k < KP; ++k)
+            logical[((size_t)b * NF + f) * KP + k] = phys[(size_t)ds::st_index(b, f, k, NF, KP)];
+    }
+};
+
 static int g_pipe_runs = 0;  // calls served by ds::PipeEngine (the test checks that the switch took effect)
 static int g_pipe = 0;       // emul_set_pipe(1): 512-point frame programs run as ds::PipeEngine (ds_pipe.hpp) instead of ds::Engine
 
@@ -220,7 +238,8 @@ int emul_op(int op, int B, int K, int T, float* st, int NF, const float* in0, co
             int norm, float mu, float alpha, float reg, float lam) {
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
-    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = st; p.NF = NF;
+    StPlanes planes(st, B, NF, (K + 3) & ~3);
+    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = planes.data(); p.NF = NF;
     p.in0 = in0; p.in1 = in1; p.in2 = in2; p.out0 = out0; p.out1 = out1; p.out2 = out2; p.out3 = out3; p.out4 = out4;
     p.M = M; p.N = N; p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.first_frame = first_frame;
     p.in_complex = in_complex; p.has_p = has_p; p.norm = norm; p.mu = mu; p.alpha = alpha; p.reg = reg; p.lam = lam;
@@ -235,7 +254,8 @@ int emul_fan(int op, int fan_form, int F, int B, int K, int T, float* st, int NF
              float* out0, int has_p, int norm, float mu, float alpha, float reg, float lam) {
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
-    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = st; p.NF = NF;
+    StPlanes planes(st, B, NF, (K + 3) & ~3);
+    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = planes.data(); p.NF = NF;
     p.in0 = in0; p.in1 = in1; p.in2 = in2; p.out0 = out0;
     p.M = 1; p.N = 2; p.has_p = has_p; p.norm = norm; p.mu = mu; p.alpha = alpha; p.reg = reg; p.lam = lam;
     p.x_fan = F; p.d_interleaved = 1;
@@ -253,7 +273,8 @@ int emul_adaptive_frames(int B, int K, int T, int M, float* st, int NF, const fl
                          int frm_cnt, int ell, int L, int method, float alpha_v, float gate, float diag) {
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
-    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = st; p.NF = NF; p.in0 = Z; p.in1 = gain; p.out0 = Y; p.M = M;
+    StPlanes planes(st, B, NF, (K + 3) & ~3);
+    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = planes.data(); p.NF = NF; p.in0 = Z; p.in1 = gain; p.out0 = Y; p.M = M;
     p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.has_p = gain != nullptr;
     p.steer = reinterpret_cast<const ds::cf*>(steer); p.steer_batch_stride = 0;
     p.method = method; p.alpha_v = alpha_v; p.beta_v = ds::complement_of(alpha_v); p.gate = gate; p.diag = diag;
@@ -360,7 +381,8 @@ int emul_stft_cdr(int nfft, int M, int batch, const float* x, int n_samples, flo
     p.T = n_samples / hop;
     p.y_batch_stride = (long long)p.T * K * M * 2;
     p.tail_in = tail_in;
-    p.cdr_st = st; p.cdr_NF = NF; p.cdr_frm = frm; p.cdr_ell = ell; p.cdr_L = 65; p.cdr_fn = Fn; p.cdr_gamma = gamma; p.cdr_qavg = qavg;
+    StPlanes planes(st, batch, NF, (nfft / 2 + 1 + 3) & ~3);
+    p.cdr_st = planes.data(); p.cdr_NF = NF; p.cdr_frm = frm; p.cdr_ell = ell; p.cdr_L = 65; p.cdr_fn = Fn; p.cdr_gamma = gamma; p.cdr_qavg = qavg;
     switch (nfft) {
         case 256: return run_stft_cdr<256>(M, p, batch);
         case 512: return run_stft_cdr<512>(M, p, batch);
@@ -383,7 +405,8 @@ int emul_aic(int nfft, int M, int batch, const float* x, int n_samples, float* y
     p.T = n_samples / hop;
     p.tail_in = tail_in; p.tail_out = tail_out; p.counters = counters;
     p.mcra_L = 1;
-    p.aic_st = st; p.aic_NF = NF; p.aic_d = d; p.aic_dprev = dprev; p.aic_p = pk; p.aic_pc = pc; p.aic_norm = norm;
+    StPlanes planes(st, batch, NF, (nfft / 2 + 1 + 3) & ~3);
+    p.aic_st = planes.data(); p.aic_NF = NF; p.aic_d = d; p.aic_dprev = dprev; p.aic_p = pk; p.aic_pc = pc; p.aic_norm = norm;
     p.aic_mu = mu; p.aic_alpha = alpha; p.aic_reg = reg;
     p.aic_e = e_spectra; p.aic_bmtail = bmtail; p.aic_bm = bm_out;     // e_spectra set: the blocking-matrix synthesis runs inside the program
     switch (nfft) {

@@ -128,7 +128,7 @@ class EmulOp:
         self.KP = (self.K + 3) & ~3
         self.NF = {0: 5, 1: M * (M + 1) + 4, 2: 5 * M + (M - 1) + 8, 3: 4 * N * M + 1, 4: 4 * N + 2 * N * N,
                    5: 2 * M * M + 8 + 2 * M,
-                   6: 2 * M * M * N + 2 * M * N + 2 * (M * N) ** 2 + 1, 7: 9, 8: 9 + 2 * M * M + 3, 9: 1, 10: 1, 14: 1, 15: 1, 16: 1, 17: 1}[self.op]
+                   6: 2 * M * M * N + 2 * M * N + 2 * (M * N) ** 2 + 1, 7: 9, 8: 12 + 2 * M * M + 3, 9: 1, 10: 1, 14: 1, 15: 1, 16: 1, 17: 1}[self.op]
         self.st = np.zeros((batch, self.NF, self.KP), dtype=np.float32)
         if self.op == 2:
             o = 5 * M + 1 + (M - 1)
