@@ -20,10 +20,11 @@ int fail(ds_handle* h, int code, const std::string& msg) {
 // StateLayout::ust(): NF KP floats per utterance, rounded up to a 128-byte line
 static size_t bins_ust(const ds_handle* h) { return ((size_t)h->ki.NF * h->KP + 31) & ~(size_t)31; }
 size_t bins_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * bins_ust(h) * sizeof(float); }
-size_t tail_in_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * h->cfg.n_mics * h->cfg.hop * sizeof(float); }
+// Transform.previous_input / previous_output hold n_fft - hop samples per channel (transform.py:424-426): one hop, or three for hop = n_fft / 4
+size_t tail_in_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * h->cfg.n_mics * (h->cfg.nfft - h->cfg.hop) * sizeof(float); }
 size_t tail_out_bytes(const ds_handle* h) {
     const size_t ch = h->cfg.algo == DS_ALGO_TRANSFORM ? (size_t)h->cfg.n_mics : 1;   // Transform keeps one OLA tail per channel
-    return (size_t)h->cfg.batch * ch * h->cfg.hop * sizeof(float);
+    return (size_t)h->cfg.batch * ch * (h->cfg.nfft - h->cfg.hop) * sizeof(float);
 }
 size_t opst_bytes(const ds_handle* h) { return h->op >= 0 ? (size_t)h->cfg.batch * op_ust(h) * sizeof(float) : 0; }
 size_t counters_bytes(const ds_handle* h) { return (size_t)h->cfg.batch * 4 * sizeof(int); }
@@ -230,8 +231,10 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     if (cfg->struct_size != (int32_t)sizeof(ds_config)) return fail(nullptr, DS_EINVAL, "ds_create: struct_size mismatch");
     *out = nullptr;
     if (cfg->batch <= 0) return fail(nullptr, DS_EINVAL, "ds_create: batch must be > 0");
-    if (cfg->algo <= DS_ALGO_TRANSFORM && cfg->hop * 2 != cfg->nfft)
-        return fail(nullptr, DS_EUNSUPPORTED, "ds_create: only hop == nfft/2 is supported");
+    if (cfg->algo < DS_ALGO_TRANSFORM && cfg->hop * 2 != cfg->nfft)
+        return fail(nullptr, DS_EUNSUPPORTED, "ds_create: the beamformer objects take hop == nfft/2 (the only overlap their reference callers use)");
+    if (cfg->algo == DS_ALGO_TRANSFORM && cfg->hop * 2 != cfg->nfft && cfg->hop * 4 != cfg->nfft)
+        return fail(nullptr, DS_EUNSUPPORTED, "ds_create: Transform takes hop == nfft/2 or hop == nfft/4");
     KernelInfo ki = {nullptr, 0, 0, 0};
     KernelInfo ki_istft = {nullptr, 0, 0, 0};
     int op = -1, NF = 0;
@@ -249,8 +252,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             break;
         case DS_ALGO_GSC: ki = ds::lookup_gsc(cfg->nfft, cfg->n_mics); break;
         case DS_ALGO_TRANSFORM:
-            ki = ds::lookup_stft(cfg->nfft, cfg->n_mics);
-            ki_istft = ds::lookup_istft(cfg->nfft, cfg->n_mics);
+            ki = ds::lookup_stft(cfg->nfft, cfg->n_mics, cfg->nfft / cfg->hop);
+            ki_istft = ds::lookup_istft(cfg->nfft, cfg->n_mics, cfg->nfft / cfg->hop);
             break;
         case DS_ALGO_MCRA: op = ds::OP_MCRA; NF = 5; break;
         case DS_ALGO_MCMCRA:
@@ -350,7 +353,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     for (int i = 0; i < 7; ++i) { h->side[i] = nullptr; h->ev_join[i] = nullptr; }
     h->ki_istft = ki_istft; h->op = op;
     h->ki_rows = KernelInfo{nullptr, 0, 0, 0}; h->ki_rows_istft = h->ki_rows; h->ki_aic = h->ki_rows; h->ki_cdr = h->ki_rows;
-    if (cfg->algo == DS_ALGO_TRANSFORM && cfg->n_mics == 1) { h->ki_rows = ds::lookup_stft_rows(cfg->nfft); h->ki_rows_istft = ds::lookup_istft_rows(cfg->nfft); }
+    if (cfg->algo == DS_ALGO_TRANSFORM && cfg->n_mics == 1 && cfg->hop * 2 == cfg->nfft) { h->ki_rows = ds::lookup_stft_rows(cfg->nfft); h->ki_rows_istft = ds::lookup_istft_rows(cfg->nfft); }
  h->opst = nullptr; h->NF = NF;
     h->op_frm = 0; h->op_ell = 1; h->op_first = 1;
     h->filter_len = flen; h->norm = cfg->no_norm ? 0 : 1;

@@ -1750,8 +1750,8 @@ template <int NFFT, int M, bool CDR = false, int OV = 2> struct StftEngine {
     }
 };
 
-template <int NFFT, int M> struct SharedIstft {
-    static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2;
+template <int NFFT, int M, int OV = 2> struct SharedIstft {
+    static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = OV == 2 ? NFFT / 2 : NFFT;   // OV = 4: a ring of four quarter-frames
     static constexpr int NCP = NC + NC / 4;
     cf fa[M][NCP];
     cf fb[M][NCP];
@@ -1759,9 +1759,13 @@ template <int NFFT, int M> struct SharedIstft {
     alignas(16) float tail[M][HOP];
 };
 
-template <int NFFT, int M> struct IstftEngine {
-    static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2, NT = NC;
-    typedef SharedIstft<NFFT, M> Sh;
+// OV = 4 (hop = NFFT / 4): the overlap-add accumulator is a ring of four quarter-frames in LDS; a frame adds its r-th quarter to slot
+// (head + r) & 3, the head slot leaves as this hop's output and is cleared for the frame after next's last quarter.  Between calls the
+// three carried quarters (Transform.previous_output, transform.py:476-477) are kept oldest first, so a chunked run repeats the
+// single-call arithmetic step for step.
+template <int NFFT, int M, int OV = 2> struct IstftEngine {
+    static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2, NT = NC, HOPX = NFFT / OV, OVL = NFFT - HOPX;
+    typedef SharedIstft<NFFT, M, OV> Sh;
     struct Rg { int unused; };
 
     template <class Exec> static DS_HD void run(Exec& ex, const Params& p, int blk, Sh& sh) {
@@ -1769,14 +1773,17 @@ template <int NFFT, int M> struct IstftEngine {
         const int C = p.method;                                // channels in this call (<= M)
         const cf* Yin = reinterpret_cast<const cf*>(p.x + (long long)blk * p.x_batch_stride);
         float* yout = p.y + (long long)blk * p.y_batch_stride;
-        float* tout = p.tail_out + (long long)b * M * HOP;
+        float* tout = p.tail_out + (long long)b * M * OVL;
         ex.phase([&](int tid, Rg&) {
             vec4* tb4 = reinterpret_cast<vec4*>(&sh.tb);
             for (int i = tid; i < Tables<NFFT>::NV4; i += NT) tb4[i] = p.tables[i];
             const vec4* t4 = reinterpret_cast<const vec4*>(tout);
-            for (int i = tid; i < M * HOP / 4; i += NT) {
-                const int m = i / (HOP / 4), q = i - m * (HOP / 4);
+            for (int i = tid; i < M * OVL / 4; i += NT) {
+                const int m = i / (OVL / 4), q = i - m * (OVL / 4);
                 *reinterpret_cast<vec4*>(&sh.tail[m][4 * q]) = t4[i];
+            }
+            if constexpr (OV == 4) {
+                for (int i = tid; i < M * HOPX; i += NT) sh.tail[i / HOPX][OVL + i % HOPX] = 0.0f;     // slot 3: nothing accumulated yet
             }
         });
         cf* fa = &sh.fa[0][0];
@@ -1807,6 +1814,24 @@ template <int NFFT, int M> struct IstftEngine {
                     ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 2, +1, false, 0, 0>(tid, NT, sh, fa, fb, 256, 0, C); });
             }
             const cf* Zi = (NC != 512) ? fa : fb;
+            if constexpr (OV == 4) {
+                const int head = t & 3;
+                ex.phase([&](int tid, Rg&) {
+                    const int i = tid, qr = (2 * i) / HOPX, e = 2 * i - qr * HOPX, at = ((head + qr) & 3) * HOPX + e;
+                    const float sc = 1.0f / (float)NC;
+                    for (int c = 0; c < C; ++c) {
+                        const cf z = Zi[c * Sh::NCP + i];
+                        const float a0 = sh.tail[c][at] + sh.tb.win[2 * i] * (z.x * sc), a1 = sh.tail[c][at + 1] + sh.tb.win[2 * i + 1] * (z.y * sc);
+                        if (qr == 0) {
+                            yout[((long long)t * HOPX + e) * C + c] = a0 * p.out_scale;
+                            yout[((long long)t * HOPX + e + 1) * C + c] = a1 * p.out_scale;
+                            sh.tail[c][at] = 0.0f; sh.tail[c][at + 1] = 0.0f;
+                        } else {
+                            sh.tail[c][at] = a0; sh.tail[c][at + 1] = a1;
+                        }
+                    }
+                });
+            } else
             ex.phase([&](int tid, Rg&) {
                 if (tid < NC / 2) {
                     const int i = tid;
@@ -1825,6 +1850,13 @@ template <int NFFT, int M> struct IstftEngine {
         }
         ex.phase([&](int tid, Rg&) {
             vec4* t4 = reinterpret_cast<vec4*>(tout);
+            if constexpr (OV == 4) {
+                const int head = p.T & 3;                                     // the slot the next frame's first quarter goes to
+                for (int i = tid; i < M * OVL / 4; i += NT) {
+                    const int m = i / (OVL / 4), q = i - m * (OVL / 4), qq = q / (HOPX / 4), e = q - qq * (HOPX / 4);
+                    t4[i] = *reinterpret_cast<const vec4*>(&sh.tail[m][((head + qq) & 3) * HOPX + 4 * e]);
+                }
+            } else
             for (int i = tid; i < M * HOP / 4; i += NT) {
                 const int m = i / (HOP / 4), q = i - m * (HOP / 4);
                 t4[i] = *reinterpret_cast<const vec4*>(&sh.tail[m][4 * q]);

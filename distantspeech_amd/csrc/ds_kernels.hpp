@@ -25,8 +25,8 @@ KernelInfo lookup_adaptive_ryy(int nfft, int M);
 KernelInfo lookup_adaptive_quad(int nfft, int M);   // 8 microphones, no Ryy: the per-bin program spread over quads (ds_quad.hpp); null launch = n/a
 KernelInfo lookup_gsc(int nfft, int M);
 KernelInfo lookup_aic(int nfft, int M);     // ALGO_AIC: the SubbandGSC chain's tail (ds_kernels_aic.hip)
-KernelInfo lookup_stft(int nfft, int M);      // ds_kernels_ops.hip
-KernelInfo lookup_istft(int nfft, int M);
+KernelInfo lookup_stft(int nfft, int M, int ov = 2);      // ds_kernels_ops.hip; ov = nfft / hop: 2 or 4
+KernelInfo lookup_istft(int nfft, int M, int ov = 2);
 KernelInfo lookup_stft_cdr(int nfft, int M);   // analysis + McCDR (the SubbandGSC chain's front end); M in {4, 6, 8}
 KernelInfo lookup_stft_rows(int nfft);      // single-channel handles: one row per wavefront (nfft 512 / 1024), launch(p, rows, stream)
 KernelInfo lookup_istft_rows(int nfft);
@@ -184,9 +184,9 @@ template <int NFFT, int M, int ALGO, bool RYY> KernelInfo make_info() {
 }
 
 #define DS_FOR_EACH_SHAPE(X) \
-    X(256, 2) X(256, 4) X(256, 6) X(256, 8) \
-    X(512, 2) X(512, 4) X(512, 6) X(512, 8) \
-    X(1024, 2) X(1024, 4) X(1024, 6) X(1024, 8)
+    X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) X(256, 8) \
+    X(512, 2) X(512, 3) X(512, 4) X(512, 5) X(512, 6) X(512, 8) \
+    X(1024, 2) X(1024, 3) X(1024, 4) X(1024, 5) X(1024, 6) X(1024, 8)
 #endif
 
 }  // namespace ds

@@ -7,17 +7,17 @@
 
 namespace ds {
 
-template <int NFFT, int M> __global__ void __launch_bounds__(NFFT / 2) ds_stft_kernel(Params p) {
+template <int NFFT, int M, int OV> __global__ void __launch_bounds__(NFFT / 2) ds_stft_kernel(Params p) {
     if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
-    typedef StftEngine<NFFT, M> E;
+    typedef StftEngine<NFFT, M, false, OV> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
     E::run(ex, p, (int)blockIdx.x, sh);
 }
 
-template <int NFFT, int M> __global__ void __launch_bounds__(NFFT / 2) ds_istft_kernel(Params p) {
+template <int NFFT, int M, int OV> __global__ void __launch_bounds__(NFFT / 2) ds_istft_kernel(Params p) {
     if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
-    typedef IstftEngine<NFFT, M> E;
+    typedef IstftEngine<NFFT, M, OV> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
     E::run(ex, p, (int)blockIdx.x, sh);
@@ -36,12 +36,12 @@ template <int NFFT, int M> hipError_t launch_stft_cdr(const Params& p, int nbloc
     return hipGetLastError();
 }
 
-template <int NFFT, int M> hipError_t launch_stft(const Params& p, int nblocks, hipStream_t stream) {
-    hipLaunchKernelGGL((ds_stft_kernel<NFFT, M>), dim3(nblocks), dim3(NFFT / 2), 0, stream, p);
+template <int NFFT, int M, int OV> hipError_t launch_stft(const Params& p, int nblocks, hipStream_t stream) {
+    hipLaunchKernelGGL((ds_stft_kernel<NFFT, M, OV>), dim3(nblocks), dim3(NFFT / 2), 0, stream, p);
     return hipGetLastError();
 }
-template <int NFFT, int M> hipError_t launch_istft(const Params& p, int nblocks, hipStream_t stream) {
-    hipLaunchKernelGGL((ds_istft_kernel<NFFT, M>), dim3(nblocks), dim3(NFFT / 2), 0, stream, p);
+template <int NFFT, int M, int OV> hipError_t launch_istft(const Params& p, int nblocks, hipStream_t stream) {
+    hipLaunchKernelGGL((ds_istft_kernel<NFFT, M, OV>), dim3(nblocks), dim3(NFFT / 2), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -90,8 +90,8 @@ KernelInfo lookup_istft_rows(int nfft) {
     X(512, 1) X(512, 2) X(512, 3) X(512, 4) X(512, 5) X(512, 6) X(512, 7) X(512, 8) \
     X(1024, 1) X(1024, 2) X(1024, 3) X(1024, 4) X(1024, 5) X(1024, 6) X(1024, 7) X(1024, 8)
 
-KernelInfo lookup_stft(int nfft, int M) {
-#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {&launch_stft<NFFT_, M_>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
+KernelInfo lookup_stft(int nfft, int M, int ov) {
+#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {ov == 4 ? &launch_stft<NFFT_, M_, 4> : &launch_stft<NFFT_, M_, 2>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
     DS_FOR_EACH_TSHAPE(X)
 #undef X
     KernelInfo none = {nullptr, 0, 0, 0};
@@ -104,8 +104,8 @@ KernelInfo lookup_stft_cdr(int nfft, int M) {
     KernelInfo none = {nullptr, 0, 0, 0};
     return none;
 }
-KernelInfo lookup_istft(int nfft, int M) {
-#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {&launch_istft<NFFT_, M_>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
+KernelInfo lookup_istft(int nfft, int M, int ov) {
+#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {ov == 4 ? &launch_istft<NFFT_, M_, 4> : &launch_istft<NFFT_, M_, 2>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
     DS_FOR_EACH_TSHAPE(X)
 #undef X
     KernelInfo none = {nullptr, 0, 0, 0};

@@ -474,9 +474,9 @@ class BatchEngine:
         if field == L.FIELD_G_AIC:
             return out.view(np.complex64).reshape(B, K, M - 1)
         if field == L.FIELD_STFT_TAIL:
-            return out.reshape(B, M, self.hop)
+            return out.reshape(B, M, self.nfft - self.hop)
         if field == L.FIELD_OLA_TAIL:
-            return out.reshape(B, self.hop)
+            return out.reshape(B, M, self.nfft - self.hop) if self.algo == L.ALGO_TRANSFORM else out.reshape(B, self.hop)
         if field == L.FIELD_COUNTERS:
             return out
         if field == L.FIELD_NOTCH_MEM:

@@ -114,9 +114,9 @@ typedef struct ds_handle ds_handle;
 typedef struct ds_config {
     int32_t struct_size; /* = sizeof(ds_config) */
     int32_t algo;
-    int32_t n_mics;      /* M: 2, 4, 6 or 8 */
+    int32_t n_mics;      /* M: 2..6 or 8 for the beamformer objects (7 has no array geometry in MicArray.py), 1..8 for Transform */
     int32_t nfft;        /* 256, 512 or 1024 */
-    int32_t hop;         /* must equal nfft / 2 (the only overlap the reference's callers use) */
+    int32_t hop;         /* nfft / 2 (the only overlap the reference's beamformer callers use); DS_ALGO_TRANSFORM also takes nfft / 4 */
     int32_t batch;       /* independent utterances resident on this device */
     int32_t track_ryy;   /* adaptive: also keep Ryy like the reference (needed by TFGSC) */
     int32_t mcra_L;      /* 0 -> 15 (mcra.py:25) */
@@ -174,8 +174,8 @@ typedef struct ds_config {
 #define DS_FIELD_PHI_YY 8     /* [B][K][M][M] real */
 #define DS_FIELD_PHI_VV 9
 #define DS_FIELD_G_AIC 10     /* [B][K][M-1][2] */
-#define DS_FIELD_STFT_TAIL 11 /* [B][M][hop]  Transform.previous_input  */
-#define DS_FIELD_OLA_TAIL 12  /* [B][hop]     Transform.previous_output */
+#define DS_FIELD_STFT_TAIL 11 /* [B][M][nfft - hop]  Transform.previous_input (transform.py:424-425)  */
+#define DS_FIELD_OLA_TAIL 12  /* [B][hop] of a beamformer object; [B][M][nfft - hop] of a DS_ALGO_TRANSFORM handle: Transform.previous_output */
 #define DS_FIELD_COUNTERS 13  /* int32 [B][4] {mcra.frm_cnt, mcra.ell, spp.frm_cnt, 0} */
 #define DS_FIELD_OP_STATE 14  /* frame-level objects: raw state [B][NF][KP] float32 (row map in distantspeech_amd/ops.py) */
 #define DS_FIELD_NOTCH_MEM 15 /* DS_ALGO_FRONTEND: [B][M][2] the DC notch memories (FilterDcNotch16.notch_mem, feature.py:34,47) */

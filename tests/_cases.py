@@ -56,8 +56,8 @@ def steering(M, nfft, r, angle=ANGLE):
     return np.exp(-1j * omega[:, None] * tao[None, :])
 
 
-ADAPTIVE_CASES = ["rec1", "synth", "synth_ds", "synth_src", "synth_tfgsc", "synth_m6", "synth_m8_1024"]
-GSC_CASES = ["rec1", "synth_m6", "synth_m4", "synth_m0"]
+ADAPTIVE_CASES = ["rec1", "synth", "synth_ds", "synth_src", "synth_tfgsc", "synth_m6", "synth_m8_1024", "synth_m3", "synth_m5"]
+GSC_CASES = ["rec1", "synth_m6", "synth_m4", "synth_m0", "synth_m3", "synth_m5"]
 
 
 class DeviceBuffers:

@@ -103,6 +103,10 @@ template <int NFFT, int M> int run_nm(int algo, int ryy, const ds::Params& p, in
 }
 
 template <int NFFT> int run_n(int M, int algo, int ryy, const ds::Params& p, int batch) {
+    if constexpr (NFFT == 512) {                 // odd channel counts: the 512-point programs only (build time of this library)
+        if (M == 3) return run_nm<NFFT, 3>(algo, ryy, p, batch);
+        if (M == 5) return run_nm<NFFT, 5>(algo, ryy, p, batch);
+    }
     switch (M) {
         case 2: return run_nm<NFFT, 2>(algo, ryy, p, batch);
         case 4: return run_nm<NFFT, 4>(algo, ryy, p, batch);
@@ -112,9 +116,9 @@ template <int NFFT> int run_n(int M, int algo, int ryy, const ds::Params& p, int
     return -1;
 }
 
-template <class E> int run_engine(ds::Params p, int batch, int nfft) {
+template <class E> int run_engine(ds::Params p, int batch, int nfft, int hop = 0) {
     std::vector<float> blob;
-    ds::make_table_blob(nfft, nfft / 2, blob, p.out_scale);
+    ds::make_table_blob(nfft, hop ? hop : nfft / 2, blob, p.out_scale);
     std::vector<ds::vec4> blob4(blob.size() / 4);
     std::memcpy((void*)blob4.data(), blob.data(), blob.size() * sizeof(float));
     p.tables = blob4.data();
@@ -177,6 +181,13 @@ template <int NFFT> int run_tf(int M, bool inverse, const ds::Params& p, int bat
 #undef TF
     return -1;
 }
+// Transform(n_fft, hop_length = n_fft / 4): the quarter-hop engines
+template <int NFFT> int run_tf4(int M, bool inverse, const ds::Params& p, int batch) {
+#define TF(M_) if (M == M_) return inverse ? run_engine<ds::IstftEngine<NFFT, M_, 4>>(p, batch, NFFT, NFFT / 4) : run_engine<ds::StftEngine<NFFT, M_, false, 4>>(p, batch, NFFT, NFFT / 4);
+    TF(1) TF(2) TF(4) TF(5)
+#undef TF
+    return -1;
+}
 
 }  // namespace
 
@@ -199,30 +210,38 @@ template <int NFFT> static int run_stft_cdr(int M, const ds::Params& p, int batc
 extern "C" {
 
 // Transform.stft: x -> Y complex [B][T][K][M]; tail_in [B][M][hop] carried
-int emul_stft(int nfft, int M, int batch, const float* x, int layout, int n_samples, float* Y, float* tail_in) {
+int emul_stft_ov(int nfft, int ov, int M, int batch, const float* x, int layout, int n_samples, float* Y, float* tail_in) {
     ds::Params p;
     std::memset(&p, 0, sizeof p);
-    const int hop = nfft / 2, K = nfft / 2 + 1, T = n_samples / hop;
+    const int hop = nfft / ov, K = nfft / 2 + 1, T = n_samples / hop;
     p.x = x; p.y = Y;
     p.x_batch_stride = (long long)M * n_samples;
     p.y_batch_stride = (long long)T * K * M * 2;
     if (layout == 1) { p.x_sample_stride = 1; p.x_chan_stride = n_samples; } else { p.x_sample_stride = M; p.x_chan_stride = 1; }
     p.T = T; p.tail_in = tail_in;
-    switch (nfft) { case 256: return run_tf<256>(M, false, p, batch); case 512: return run_tf<512>(M, false, p, batch); case 1024: return run_tf<1024>(M, false, p, batch); }
+    if (ov == 4) switch (nfft) { case 256: return run_tf4<256>(M, false, p, batch); case 512: return run_tf4<512>(M, false, p, batch); case 1024: return run_tf4<1024>(M, false, p, batch); }
+    if (ov == 2) switch (nfft) { case 256: return run_tf<256>(M, false, p, batch); case 512: return run_tf<512>(M, false, p, batch); case 1024: return run_tf<1024>(M, false, p, batch); }
     return -1;
+}
+int emul_stft(int nfft, int M, int batch, const float* x, int layout, int n_samples, float* Y, float* tail_in) {
+    return emul_stft_ov(nfft, 2, M, batch, x, layout, n_samples, Y, tail_in);
 }
 
 // Transform.istft: Y complex [B][T][K][C] -> y [B][T*hop][C]; tail_out [B][M][hop] carried
-int emul_istft(int nfft, int M, int batch, const float* Y, int T, int C, float* y, float* tail_out) {
+int emul_istft_ov(int nfft, int ov, int M, int batch, const float* Y, int T, int C, float* y, float* tail_out) {
     ds::Params p;
     std::memset(&p, 0, sizeof p);
-    const int hop = nfft / 2, K = nfft / 2 + 1;
+    const int hop = nfft / ov, K = nfft / 2 + 1;
     p.x = Y; p.y = y;
     p.x_batch_stride = (long long)T * K * C * 2;
     p.y_batch_stride = (long long)T * hop * C;
     p.T = T; p.method = C; p.tail_out = tail_out;
-    switch (nfft) { case 256: return run_tf<256>(M, true, p, batch); case 512: return run_tf<512>(M, true, p, batch); case 1024: return run_tf<1024>(M, true, p, batch); }
+    if (ov == 4) switch (nfft) { case 256: return run_tf4<256>(M, true, p, batch); case 512: return run_tf4<512>(M, true, p, batch); case 1024: return run_tf4<1024>(M, true, p, batch); }
+    if (ov == 2) switch (nfft) { case 256: return run_tf<256>(M, true, p, batch); case 512: return run_tf<512>(M, true, p, batch); case 1024: return run_tf<1024>(M, true, p, batch); }
     return -1;
+}
+int emul_istft(int nfft, int M, int batch, const float* Y, int T, int C, float* y, float* tail_out) {
+    return emul_istft_ov(nfft, 2, M, batch, Y, T, C, y, tail_out);
 }
 
 // OpParams fields outside emul_op's argument list (set before the call, sticky)

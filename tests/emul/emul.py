@@ -23,7 +23,10 @@ SRCS = [os.path.join(HERE, "ds_emul.cpp"), os.path.join(ROOT, "distantspeech_amd
 def build(force=False):
     if not force and os.path.exists(SO) and all(os.path.getmtime(SO) >= os.path.getmtime(s) for s in SRCS):
         return SO
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", SRCS[0], "-o", SO])
+    # -fno-strict-aliasing: the block programs fill LDS structures sixteen bytes at a time (vec4 stores over cf / float arrays) and read
+    # them back by element in a LATER phase; on the device a workgroup barrier (with its fence) lies between the two, here the phases
+    # are inlined loops and g++ -O2 has been seen moving the element loads above the vec4 stores (StftEngine<512, 5, false, 4>: all-zero output)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-mfma", "-fno-strict-aliasing", SRCS[0], "-o", SO])
     return SO
 
 
@@ -98,23 +101,24 @@ def _vp(a):
 class EmulTransform:
     """Transform.stft / istft through the kernel block programs (StftEngine / IstftEngine)."""
 
-    def __init__(self, nfft, M, batch=1):
-        self.nfft, self.M, self.batch, self.hop, self.K = nfft, M, batch, nfft // 2, nfft // 2 + 1
-        self.tail_in = np.zeros((batch, M, self.hop), dtype=np.float32)
-        self.tail_out = np.zeros((batch, M, self.hop), dtype=np.float32)
+    def __init__(self, nfft, M, batch=1, hop=None):
+        self.nfft, self.M, self.batch, self.hop, self.K = nfft, M, batch, hop or nfft // 2, nfft // 2 + 1
+        self.ov = nfft // self.hop
+        self.tail_in = np.zeros((batch, M, nfft - self.hop), dtype=np.float32)
+        self.tail_out = np.zeros((batch, M, nfft - self.hop), dtype=np.float32)
 
     def stft(self, x, layout=0):
         x = np.ascontiguousarray(x, dtype=np.float32)
         n = x.shape[1] if layout == 0 else x.shape[2]
         Y = np.zeros((self.batch, n // self.hop, self.K, self.M), dtype=np.complex64)
-        assert lib().emul_stft(self.nfft, self.M, self.batch, _vp(x), layout, n, _vp(Y), _vp(self.tail_in)) == 0
+        assert lib().emul_stft_ov(self.nfft, self.ov, self.M, self.batch, _vp(x), layout, n, _vp(Y), _vp(self.tail_in)) == 0
         return Y
 
     def istft(self, Y):
         Y = np.ascontiguousarray(Y, dtype=np.complex64)
         B, T, K, C = Y.shape
         y = np.zeros((B, T * self.hop, C), dtype=np.float32)
-        assert lib().emul_istft(self.nfft, self.M, self.batch, _vp(Y), T, C, _vp(y), _vp(self.tail_out)) == 0
+        assert lib().emul_istft_ov(self.nfft, self.ov, self.M, self.batch, _vp(Y), T, C, _vp(y), _vp(self.tail_out)) == 0
         return y
 
 

@@ -160,6 +160,30 @@ def g1_transform():
              y_chunk=y_chunk, params=np.array([nfft, hop, M]))
 
 
+def g1c_transform_quarter_hop():
+    """Transform(n_fft, hop_length = n_fft / 4) (transform.py:407-428 takes any hop; the overlap carried between calls is then three
+    hops): same checks as g1, for 1, 2, 4 and 5 channels."""
+    rng = np.random.default_rng(13)
+    for (nfft, hop, M) in [(512, 128, 2), (256, 64, 4), (1024, 256, 1), (512, 128, 5)]:
+        L = hop * 21
+        x = (rng.standard_normal((L, M)) * 0.1).astype(np.float32)
+        t1 = Transform(n_fft=nfft, hop_length=hop, channel=M)
+        Y_one = t1.stft(x.astype(np.float64))
+        y_one = t1.istft(Y_one)
+        t2 = Transform(n_fft=nfft, hop_length=hop, channel=M)
+        cuts = [0, hop, 3 * hop, 10 * hop, L]                      # 1 hop (shorter than the overlap), 2, 7 and 11 hops
+        Ys, ys = [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            Yc = t2.stft(x[a:b].astype(np.float64))
+            Ys.append(Yc)
+            ys.append(np.atleast_2d(t2.istft(Yc).T).T.reshape(b - a, -1))
+        assert np.array_equal(Y_one, np.concatenate(Ys, axis=1))
+        save("g1c_transform_%d_%d_%d" % (nfft, hop, M),
+             "Transform.stft/istft with hop = n_fft/4, transform.py:407-481; chunked stft == one-shot verified bit-for-bit at generation",
+             x=x, Y=Y_one.astype(np.complex64), y=np.asarray(y_one).reshape(L, -1), y_chunk=np.concatenate(ys, axis=0),
+             params=np.array([nfft, hop, M]))
+
+
 def g1b_transform_window():
     """Transform(window=...) (transform.py:415-416): a caller-supplied window of n_fft samples (here a Hamming window, which is not
     power-complementary, so the round trip is not the identity) through analysis and synthesis."""
@@ -727,6 +751,35 @@ def g19_gev(x16):
          W_ban=Wb, Yout=Yout.astype(np.complex64), y=np.asarray(y), xi=xi, w_pmwf_b1=w_pmwf[1], w_pmwf_b10=w_pmwf[10])
 
 
+def g20_odd_m():
+    """Odd channel counts through the beamformer objects: the adaptive MVDR (method 2) and the GSC hop by hop with 3 and 5 microphones.
+    (7 cannot be built: MicArray.gamma = arange(0, 360, int(360 / M)) has 8 entries for M = 7, MicArray.py:33, and the steering vector
+    beamformer.py:267-289 takes one entry per element of gamma for linear arrays too — getweights fails with a shape mismatch.)"""
+    for name, M, atype, seed in (("m3", 3, "circular", 71), ("m5", 5, "circular", 72)):
+        x = synth(seed, M, 256 * 50)
+        mic = MicArray(arrayType=atype, r=0.05, M=M, n_fft=512)                            # R2
+        ab = make_adaptive(mic, 512, 256)                                                  # R1
+        ys = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for t in range(x.shape[1] // 256):                                             # R3
+                ys.append(np.atleast_1d(ab.process(x[:, t * 256:(t + 1) * 256].astype(np.float64), ANGLE, method=2)["data"]))
+        save("g4_adaptive_synth_%s" % name, "adaptivebeamfomer.process(method=2) adaptivebeamformer.py:44-128 hop-by-hop, %d microphones (%s); R1 R2 R3; "
+             "angle=197deg" % (M, atype), x=x, y=np.concatenate(ys), Rvv=ab.Rvv, Rvv_inv=ab.Rvv_inv, Ryy=ab.Ryy, H=ab.H, mcra_p=ab.mcra.p,
+             mcra_lambda_d=ab.mcra.lambda_d, params=np.array([M, 512, 256, 2]), r=np.array(mic.r))
+    for name, M, seed in (("m3", 3, 74), ("m5", 5, 75)):
+        xx = synth(seed, M, 256 * 50) * np.float32(0.1)
+        mic = MicArray(arrayType="circular", r=0.05, M=M, n_fft=512)                       # R2
+        with contextlib.redirect_stdout(io.StringIO()):                                    # R5
+            g = GSC(mic, frameLen=512, angle=[197, 0])
+        ys = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for t in range(xx.shape[1] // 256):                                            # R3
+                ys.append(np.atleast_1d(g.process(xx[:, t * 256:(t + 1) * 256].astype(np.float64), ANGLE, method=2)["data"]))
+        save("g6_gsc_synth_%s" % name, "GSC.process(method=2) GSC.py:174-294 hop-by-hop, %d microphones; R2 R3 R5; angle=197deg" % M,
+             x=xx, y=np.concatenate(ys), G=g.G, spp_G=g.spp.G, spp_p=g.spp.p, omlsa_G=g.omlsa_multi.G, omlsa_p=g.omlsa_multi.p,
+             omlsa_lambda_d=np.asarray(g.omlsa_multi.lambda_d), mcra_p=g.mcra.p, params=np.array([M, 512, 256, 2]), r=np.array(mic.r))
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -736,6 +789,7 @@ def main():
     x16 = rec1_int16(3.0, 3.0)
     if want("g1"): g1_transform()
     if want("g1b"): g1b_transform_window()
+    if want("g1c"): g1c_transform_quarter_hop()
     if want("g2"): g2_weights()
     if want("g2b"): g2b_fixed(x16)
     if want("g3"): g3_mcra(x16)
@@ -756,6 +810,7 @@ def main():
     if want("g17"): g17_long()
     if want("g18"): g18_an101()
     if want("g19"): g19_gev(x16)
+    if want("g20"): g20_odd_m()
 
 
 if __name__ == "__main__":

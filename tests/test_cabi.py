@@ -48,8 +48,11 @@ def test_create_rejects_bad_configs_before_touching_the_gpu():
     bad_taps = L.ds_config(ctypes.sizeof(L.ds_config), L.ALGO_SUBRLS, 1, 512, 256, 1, 0, 0, -1, 0, 0, 0, 0, 0, 9)
     assert lib.ds_create(ctypes.byref(bad_taps), ctypes.byref(h)) == -3
     assert lib.ds_create(ctypes.byref(bad_hop), ctypes.byref(h)) == -3          # DS_EUNSUPPORTED
-    bad_m = L.ds_config(ctypes.sizeof(L.ds_config), L.ALGO_ADAPTIVE, 5, 512, 256, 1, 0, 0, -1, 0, 0, 0, 0, 0)
-    assert lib.ds_create(ctypes.byref(bad_m), ctypes.byref(h)) == -3
+    for m in (1, 7, 9):                     # 2..6 and 8 microphones have kernels (7: no array geometry in the reference, MicArray.py:33)
+        bad_m = L.ds_config(ctypes.sizeof(L.ds_config), L.ALGO_ADAPTIVE, m, 512, 256, 1, 0, 0, -1, 0, 0, 0, 0, 0)
+        assert lib.ds_create(ctypes.byref(bad_m), ctypes.byref(h)) == -3
+    bad_ov = L.ds_config(ctypes.sizeof(L.ds_config), L.ALGO_TRANSFORM, 2, 512, 64, 1, 0, 0, -1, 0, 0, 0, 0, 0)      # Transform: hop = nfft/2 or nfft/4
+    assert lib.ds_create(ctypes.byref(bad_ov), ctypes.byref(h)) == -3
     bad_size = L.ds_config(8, L.ALGO_ADAPTIVE, 4, 512, 256, 1, 0, 0, -1, 0, 0, 0, 0, 0)
     assert lib.ds_create(ctypes.byref(bad_size), ctypes.byref(h)) == -1         # DS_EINVAL
     assert lib.ds_create(None, ctypes.byref(h)) == -1

@@ -32,7 +32,8 @@ def test_transform_odd_channel_counts(ds, M):
     assert np.max(np.abs(np.asarray(t.istft(Y)) - np.asarray(o.istft(Yo)))) < 5e-6
 
 
-@pytest.mark.parametrize("name", ["g1_transform_512_256_4", "g1_transform_1024_512_2", "g1_transform_256_128_1"])
+@pytest.mark.parametrize("name", ["g1_transform_512_256_4", "g1_transform_1024_512_2", "g1_transform_256_128_1",
+                                  "g1c_transform_512_128_2", "g1c_transform_256_64_4", "g1c_transform_1024_256_1", "g1c_transform_512_128_5"])
 def test_transform(ds, name):
     g = load(name)
     nfft, hop, M = [int(v) for v in g["params"]]
@@ -76,6 +77,39 @@ def test_transform_custom_window(ds):
     assert np.array_equal(yc, y)
     with pytest.raises(NotImplementedError):
         ds.Transform(channel=M, n_fft=nfft, hop_length=hop, window=np.ones(300))
+
+
+def test_transform_quarter_hop_batch_state_and_refusals(ds):
+    """Transform(n_fft, hop_length = n_fft / 4) as a batch of three: every row against the oracle, the carried input overlap is the last
+    three hops (transform.py:424-425,451), a checkpoint taken mid-stream resumes bit for bit on a fresh handle, other overlaps are refused."""
+    from distantspeech_amd._lib import DsError
+    from oracle import ds_oracle as O
+    nfft, hop, M, B = 512, 128, 3, 3
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((B, hop * 13, M)) * 0.1).astype(np.float32)
+    t = ds.Transform(channel=M, n_fft=nfft, hop_length=hop, batch=B)
+    Y = t.stft(x)                                                           # [B, K, T, M]
+    y = t.istft(Y)
+    for b in range(B):
+        o = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop)
+        Yo = o.stft(x[b])
+        assert rms(Y[b] - Yo) < 2e-6 * rms(Yo)
+        assert np.max(np.abs(y[b] - np.asarray(o.istft(Yo)))) < 5e-6
+    assert np.array_equal(t.previous_input, x[:, -3 * hop:, :].astype(np.float64))
+    # sqrt-Hann at 75 % overlap: analysis -> synthesis returns the input n_fft - hop samples late (hop / W0 = 1 / 2 of the window power sum)
+    assert np.max(np.abs(y[:, nfft - hop:, :] - x[:, : -(nfft - hop), :])) < 5e-6
+    t1 = ds.Transform(channel=M, n_fft=nfft, hop_length=hop, batch=B)
+    ya = t1.istft(t1.stft(x[:, : 5 * hop]))
+    blob = t1._eng.export_state()
+    t2 = ds.Transform(channel=M, n_fft=nfft, hop_length=hop, batch=B)
+    t2._eng.import_state(blob)
+    yb = t2.istft(t2.stft(x[:, 5 * hop:]))
+    assert np.array_equal(np.concatenate([ya, yb], axis=1), y)
+    for bad in (64, 192, 512):
+        with pytest.raises(DsError):
+            ds.Transform(channel=M, n_fft=nfft, hop_length=bad)
+    with pytest.raises(DsError):                                            # the beamformer objects keep hop = n_fft / 2
+        ds.adaptivebeamfomer(ds.MicArray(arrayType="circular", r=0.05, M=4, n_fft=512), frameLen=512, hop=128, nfft=512)
 
 
 @pytest.mark.parametrize("L", [15, 10])

@@ -100,24 +100,25 @@ def test_emul_transform_roundtrip(nfft, M):
 from emul.emul import EmulOp, EmulTransform  # noqa: E402
 
 
-@pytest.mark.parametrize("name", ["g1_transform_512_256_4", "g1_transform_1024_512_2", "g1_transform_256_128_1"])
+@pytest.mark.parametrize("name", ["g1_transform_512_256_4", "g1_transform_1024_512_2", "g1_transform_256_128_1",
+                                  "g1c_transform_512_128_2", "g1c_transform_256_64_4", "g1c_transform_1024_256_1", "g1c_transform_512_128_5"])
 def test_emul_transform_golden(name):
     g = load(name)
     nfft, hop, M = [int(v) for v in g["params"]]
     x = g["x"]
-    t = EmulTransform(nfft, M)
+    t = EmulTransform(nfft, M, hop=hop)
     Y = t.stft(x[None], 0)[0]                                    # [T, K, M]
     ref = np.transpose(g["Y"], (1, 0, 2))
     assert rms(Y - ref) < 2e-6 * rms(ref)
     y = t.istft(Y[None])[0]
     assert np.max(np.abs(y - g["y"])) < 5e-6
     # chunked == one-shot bit for bit
-    t2 = EmulTransform(nfft, M)
-    cuts = [0, hop, 4 * hop, x.shape[0]]
+    t2 = EmulTransform(nfft, M, hop=hop)
+    cuts = [0, hop, 4 * hop, 6 * hop, x.shape[0]]
     ys = [t2.istft(t2.stft(x[None, a:b], 0))[0] for a, b in zip(cuts[:-1], cuts[1:])]
     assert np.array_equal(np.concatenate(ys), y)
     # istft of fewer channels than the Transform was built with (transform.py:466)
-    t3 = EmulTransform(nfft, M)
+    t3 = EmulTransform(nfft, M, hop=hop)
     y1 = t3.istft(np.ascontiguousarray(Y[None, :, :, :1]))[0]
     assert np.array_equal(y1[:, 0], y[:, 0])
 

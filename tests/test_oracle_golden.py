@@ -13,7 +13,8 @@ def _mic(M, nfft, r=None, atype="circular"):
     return O.OracleMicArray(arrayType=atype, r=(0.032 if M == 4 else 0.05) if r is None else r, M=M, n_fft=nfft)
 
 
-@pytest.mark.parametrize("name", ["g1_transform_512_256_4", "g1_transform_1024_512_2", "g1_transform_256_128_1"])
+@pytest.mark.parametrize("name", ["g1_transform_512_256_4", "g1_transform_1024_512_2", "g1_transform_256_128_1",
+                                  "g1c_transform_512_128_2", "g1c_transform_256_64_4", "g1c_transform_1024_256_1", "g1c_transform_512_128_5"])
 def test_transform(golden, name):
     g = golden(name)
     nfft, hop, M = [int(v) for v in g["params"]]
@@ -25,7 +26,7 @@ def test_transform(golden, name):
     assert np.max(np.abs(y - g["y"])) < 1e-7
     # chunked == one-shot
     t2 = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop)
-    cuts = [0, hop, 4 * hop, x.shape[0]]
+    cuts = [0, hop, 3 * hop, 10 * hop, x.shape[0]] if name.startswith("g1c") else [0, hop, 4 * hop, x.shape[0]]   # as make_golden.py cut them
     ys = [np.asarray(t2.istft(t2.stft(x[a:b]))).reshape(b - a, -1) for a, b in zip(cuts[:-1], cuts[1:])]
     assert np.max(np.abs(np.concatenate(ys) - g["y_chunk"])) < 1e-7
 
@@ -68,7 +69,7 @@ def test_mcra(golden, L):
             assert np.allclose(est.Smin, g["Smin"][n // 8], rtol=1e-12, atol=1e-18)
 
 
-@pytest.mark.parametrize("name", ["rec1", "synth", "synth_ds", "synth_src", "synth_tfgsc", "synth_m6", "synth_m8_1024"])
+@pytest.mark.parametrize("name", ["rec1", "synth", "synth_ds", "synth_src", "synth_tfgsc", "synth_m6", "synth_m8_1024", "synth_m3", "synth_m5"])
 def test_adaptive_mvdr(golden, name):
     g = golden("g4_adaptive_" + name)
     M, nfft, hop, method = [int(v) for v in g["params"]]
@@ -117,7 +118,7 @@ def test_mcmcra(golden, name):
     assert np.allclose(est.Phi_yy, g["Phi_yy"], rtol=1e-9, atol=1e-14)
 
 
-@pytest.mark.parametrize("name", ["rec1", "synth_m6", "synth_m4", "synth_m0"])
+@pytest.mark.parametrize("name", ["rec1", "synth_m6", "synth_m4", "synth_m0", "synth_m3", "synth_m5"])
 def test_gsc(golden, name):
     g = golden("g6_gsc_" + name)
     M, nfft, hop, method = [int(v) for v in g["params"]]
