@@ -1120,7 +1120,7 @@ static int extra_state(const ds_handle* h, ExtraState out[3]) {
 // shared-reference / complemented-p subband filters); out_scale_bits: hop / sum(window^2), which moves with a caller-supplied window
 struct BlobHeader { uint32_t magic, version; int32_t algo, nfft, hop, n_mics, batch, filter_len, td_L, track_ryy, layout, modes, wpe_delay; uint32_t out_scale_bits; };
 static const uint32_t BLOB_MAGIC = 0x44534348u;      // "DSCH"
-static const int32_t BLOB_LAYOUT = 3;      // 3: operator state as float4 planes [b][f / 4][k][f % 4]
+static const int32_t BLOB_LAYOUT = 3;      // 3: operator state as float4 planes [b][f / 4][k][f % 4], FIR history channel-major [b][m][L - 1]
 static BlobHeader blob_header(const ds_handle* h) {
     uint32_t osb;
     std::memcpy(&osb, &h->out_scale, sizeof osb);
@@ -1157,6 +1157,16 @@ size_t ds_state_payload_bytes(const ds_handle* h) {
     size_t n = own_state_bytes(h) - sizeof(BlobHeader) - 4 * sizeof(int) + chain_hist_bytes(h);
     for (int i = 0; i < 10; ++i) if (h->sub[i]) n += ds_state_payload_bytes(h->sub[i]);
     return n;
+}
+
+int ds_chain_stage_info(const ds_handle* h, int i, int32_t* algo, int32_t* n_mics, int32_t* batch, size_t* payload_bytes) {
+    if (!h || i < 0 || i >= 10 || !h->sub[i]) return DS_EINVAL;
+    const ds_handle* s = h->sub[i];
+    if (algo) *algo = s->cfg.algo;
+    if (n_mics) *n_mics = s->cfg.n_mics;
+    if (batch) *batch = s->cfg.batch;
+    if (payload_bytes) *payload_bytes = ds_state_payload_bytes(s);
+    return DS_OK;
 }
 
 int ds_export_state(ds_handle* h, void* dst, size_t bytes) {

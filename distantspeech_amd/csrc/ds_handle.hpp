@@ -59,7 +59,7 @@ struct ds_handle {
     size_t dev_buf_bytes[10];
     size_t aux_floats;
     float* td_mem;              // DS_ALGO_FRONTEND: notch memories [B][M][2]
-    float* td_cache[2];         // FIR history ping-pong [B][L-1][M]
+    float* td_cache[2];         // FIR history ping-pong [B][M][L-1]
     int td_L, td_cur;
     float* tdf_w; float* tdf_buf; float* tdf_P;     // DS_ALGO_TDNLMS / TDRLS state
     int fdaf_kind, fdaf_constrain, fdaf_non_causal, fdaf_weight_norm, fdaf_two_path;   // DS_ALGO_FDAF (state lives in opst)

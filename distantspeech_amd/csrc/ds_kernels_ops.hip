@@ -346,11 +346,11 @@ template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdPar
     // branch-free: entries past the window re-read its last entry (and are not stored), history entries select the cache address
     auto fetch = [&](int m, float* v) {
         const float* xm_ = xb + (long long)m * xs_c;
-        const float* cm_ = cache + m;
+        const float* cm_ = cache + (long long)m * (L - 1);
 #pragma unroll
         for (int u = 0; u < S::NB; ++u) {
             const int w0 = u * FIR_NT + tid, w = w0 < nw ? w0 : nw - 1, s_ = i0 + w - (L - 1);
-            const float* src = s_ >= 0 ? xm_ + (long long)s_ * xs_s : cm_ + (long long)(L - 1 + s_) * M;
+            const float* src = s_ >= 0 ? xm_ + (long long)s_ * xs_s : cm_ + (L - 1 + s_);
             v[u] = *src;
         }
     };
@@ -371,8 +371,8 @@ template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdPar
         __syncthreads();
         if (m + S::D < M) fetch(m + S::D, v);                              // D channel windows fly behind this channel's taps
         if (keep) {                                                        // history for the next call: the last L - 1 samples
-            float* co = cache_out + (long long)b * (L - 1) * M + m;
-            for (int i = tid; i < L - 1; i += FIR_NT) co[(long long)i * M] = xs[at(i + nt + S::PAD)];
+            float* co = cache_out + ((long long)b * M + m) * (L - 1);      // one contiguous row per channel (see TdParams::cache_in)
+            for (int i = tid; i < L - 1; i += FIR_NT) co[i] = xs[at(i + nt + S::PAD)];
         }
         if (!live) return;
         const float* cm = cs + m * Lp;

@@ -1348,8 +1348,10 @@ struct TdParams {
     long long x_bstride, x_cstride;   // notch: element strides of x between utterances / channels (0 = dense [B][M][n])
     float* mem;                // notch: [B][M][2]
     const float* coef;         // FIR: [L][M]
-    const float* cache_in;     // FIR: [B][L-1][M]
-    float* cache_out;          // FIR: [B][L-1][M] (the other half of a ping-pong pair)
+    const float* cache_in;     // FIR: [B][M][L-1], channel-major: a channel's history is one contiguous row.  (Interleaved [L-1][M] rows made
+                               // every channel pass of the kernel a stride-M partial write of the same lines: 1.3x the history in extra HBM
+                               // reads AND writes, profiles/r03e/cfg5_stage_budget.md)
+    float* cache_out;          // FIR: [B][M][L-1] (the other half of a ping-pong pair)
     const int* dev_parity;     // FIR: optional device-resident call parity (dev_cnt[3] of the handle): odd = the two halves swap roles
     float radius;
 };
@@ -1381,7 +1383,7 @@ DS_HD void td_fir(const TdParams& p, int b, int i) {
         float acc = 0.0f;
         for (int j = 0; j < L; ++j) {
             const int s = i - j;                                        // sample index relative to this call
-            const float v = s >= 0 ? x[(long long)s * xs + m * xc] : cache[(long long)(L - 1 + s) * M + m];
+            const float v = s >= 0 ? x[(long long)s * xs + m * xc] : cache[(long long)m * (L - 1) + (L - 1 + s)];
             acc = fma_(p.coef[(long long)j * M + m], v, acc);
         }
         if (p.y_chan_major) p.y[((long long)b * M + m) * p.n + i] = acc;
@@ -1399,8 +1401,8 @@ DS_HD void td_fir_cache(const TdParams& p, int b, int i) {
     const int s = i + p.n - (L - 1);                                    // position in x of history slot i (may be negative)
     for (int m = 0; m < M; ++m) {
         const float v = s >= 0 ? (p.x_chan_major ? p.x[((long long)b * M + m) * p.n + s] : p.x[((long long)b * p.n + s) * M + m])
-                               : p.cache_in[((long long)b * (L - 1) + (i + p.n)) * M + m];
-        p.cache_out[((long long)b * (L - 1) + i) * M + m] = v;
+                               : p.cache_in[((long long)b * M + m) * (L - 1) + (i + p.n)];
+        p.cache_out[((long long)b * M + m) * (L - 1) + i] = v;
     }
 }
 

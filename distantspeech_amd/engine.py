@@ -487,6 +487,15 @@ class BatchEngine:
         """bytes of the carried state as the library packs it (without the checkpoint's framing): what one call reads and writes back"""
         return int(self._lib.ds_state_payload_bytes(self._h))
 
+    def chain_stages(self):
+        """[(stage index, DS_ALGO_*, channels, batch, carried-state bytes)] of a chain handle (ds_chain_stage_info); [] for a plain handle"""
+        out = []
+        a, m, b, n = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_size_t()
+        for i in range(10):
+            if self._lib.ds_chain_stage_info(self._h, i, ctypes.byref(a), ctypes.byref(m), ctypes.byref(b), ctypes.byref(n)) == 0:
+                out.append((i, a.value, m.value, b.value, int(n.value)))
+        return out
+
     def export_state(self):
         n = self._lib.ds_state_bytes(self._h)
         buf = np.empty(n, dtype=np.uint8)

@@ -330,6 +330,10 @@ size_t ds_field_bytes(const ds_handle* h, int field);
 size_t ds_state_bytes(const ds_handle* h);
 /* the carried state alone, without the checkpoint's framing: the bytes one call reads and writes back (bench.py's byte accounting) */
 size_t ds_state_payload_bytes(const ds_handle* h);
+/* a chain handle's stage i (0-based; the order of the reference object's members, see DS_ALGO_* above): its DS_ALGO_*, channel count,
+   batch and carried-state bytes (ds_state_payload_bytes of that stage).  DS_EINVAL when the handle has no stage i.  Read-only
+   introspection for byte accounting (scripts/stage_budget.py) and for mapping a checkpoint to the reference object's members. */
+int ds_chain_stage_info(const ds_handle* h, int i, int32_t* algo, int32_t* n_mics, int32_t* batch, size_t* payload_bytes);
 int ds_export_state(ds_handle* h, void* dst, size_t bytes);
 int ds_import_state(ds_handle* h, const void* src, size_t bytes);
 

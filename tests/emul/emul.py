@@ -206,7 +206,7 @@ class EmulFrontend:
         self.coef = None if coef is None else np.ascontiguousarray(coef, dtype=np.float32)
         if coef is not None:
             self.L = self.coef.shape[0]
-            self.cache = [np.zeros((batch, self.L - 1, M), dtype=np.float32) for _ in range(2)]
+            self.cache = [np.zeros((batch, M, self.L - 1), dtype=np.float32) for _ in range(2)]
             self.cur = 0
 
     def dcnotch(self, x):
