@@ -377,7 +377,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
     {   // DS_PIPE_MIN_T=<hops>: calls of at least that many hops take the hop-pipelined frame kernel (ds_pipe.hpp).  Off by default: it is
         // bit-identical and measured SLOWER (cfg2, 625 hops per call: 193 against 216 M frames/s; profiles/r03b/pipe_ab.txt and
-        // DESIGN.md section 3, "Hop-level software pipeline") — kept as an opt-in experiment with its tests
+        // DESIGN.md section 4.4) — kept as an opt-in experiment with its tests
         const char* e = getenv("DS_PIPE_MIN_T");
         const int v = e ? atoi(e) : 0;
         h->pipe_min_T = v > 0 ? v : 0x7fffffff;

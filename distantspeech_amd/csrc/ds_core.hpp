@@ -728,7 +728,7 @@ template <int M> struct Chol {
 // copy of A with both forward substitutions fused into the column sweep: no back-substitution,
 // no stored factor, real denominator.
 #ifdef DS_SOLVE_FP64
-// Measured variant (scratch/build_variant.sh WORK fp64 "-DDS_SOLVE_FP64"): the same fused sweep in double on the
+// Measured variant (scratch/build_variant.sh WORK fp64 "-DDS_SOLVE_FP64"; docs/DESIGN_rounds_1_2.md section 3): the same fused sweep in double on the
 // fp32 state, the reference's complex128 arithmetic (adaptivebeamformer.py:103-104).  Not the default: the fp32 sweep is already inside
 // the 1e-4 RMS bar and this one costs registers (occupancy) and the fp64 vector rate.
 template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag, const cf* a, const cf* z) {

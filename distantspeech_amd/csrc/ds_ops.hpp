@@ -120,7 +120,7 @@ __device__ inline void st_load4(const OpCtx& p, int b, int q, int k, float* d) {
 }
 // (four dword stores at consecutive immediate offsets, which the backend merges (dwordx3 + dword in ROCm 7.2).  The b128 STORE builtin
 // was tried as well: single-stream results were right, but with two utterance groups of a chain running on two streams the outputs
-// carried NaNs at random — scratch/dbg_groups.py, DESIGN.md "Operator state as float4 planes" — so neither b128 builtin is used)
+// carried NaNs at random — scratch/dbg_groups.py, DESIGN.md section 3.5 — so neither b128 builtin is used)
 __device__ inline void st_store4(const OpCtx& p, int b, int q, int k, const float* s) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) st_at(p, b, 4 * q + j, k) = s[j];
