@@ -107,6 +107,12 @@ DS_HD cf cfnma_s(cf acc, cf a, cf b) {       // acc - a * b
 DS_HD cf cfnmac_s(cf acc, cf a, cf b) {      // acc - a * conj(b)
     return mk(fma_(-a.x, b.x, fma_(-a.y, b.y, acc.x)), fma_(-a.y, b.x, fma_(a.x, b.y, acc.y)));
 }
+// P / lambda - (g_i conj(g_j)) dls, the element update of the RLS-WPE recursion (ds_wpe.hpp): every product of g_i conj(g_j) is rounded on its
+// own and the two of a sum are then added, so that the element lane j computes for (j, i) is the exact conjugate of this one
+DS_HD cf herm_downdate_s(cf P, cf gi, cf gj, float lam_inv, float dls) {
+    const float tx = gi.x * gj.x + gi.y * gj.y, ty = gi.y * gj.x - gi.x * gj.y;
+    return mk(fma_(-tx, dls, P.x * lam_inv), fma_(-ty, dls, P.y * lam_inv));
+}
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_SCALAR_COMPLEX)
 // ... and on the device as TWO packed instructions each (v_pk_mul_f32 / v_pk_fma_f32): the half selects (op_sel / op_sel_hi: which half of
 // a source feeds the low / the high result) and the per-half negations (neg_lo / neg_hi) do the swaps and sign changes of a complex product
@@ -152,7 +158,18 @@ DS_HD cf cfnmac(cf acc, cf a, cf b) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(t));
     return pk_cf(r);
 }
+DS_HD cf herm_downdate(cf P, cf gi, cf gj, float lam_inv, float dls) {     // five packed instructions for the eleven of the scalar form
+    cf2_t p1, p2, t, q, r;
+    const cf2_t sc = {lam_inv, dls};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p1) : "v"(cf_pk(gi)), "v"(cf_pk(gj)));      // (gi.x gj.x, gi.y gj.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(p2) : "v"(cf_pk(gi)), "v"(cf_pk(gj)));      // (gi.y gj.y, gi.x gj.y)
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(t) : "v"(p1), "v"(p2));                                     // (tx, ty)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(q) : "v"(cf_pk(P)), "v"(sc));               // P lam_inv
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(t), "v"(sc), "v"(q));   // -t dls + q
+    return pk_cf(r);
+}
 #else
+DS_HD cf herm_downdate(cf P, cf gi, cf gj, float lam_inv, float dls) { return herm_downdate_s(P, gi, gj, lam_inv, dls); }
 DS_HD cf cmul(cf a, cf b) { return cmul_s(a, b); }
 DS_HD cf cmulc(cf a, cf b) { return cmulc_s(a, b); }
 DS_HD cf cfma(cf acc, cf a, cf b) { return cfma_s(acc, a, b); }

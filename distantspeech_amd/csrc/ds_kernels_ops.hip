@@ -476,8 +476,8 @@ hipError_t launch_tdfilter(const TdfParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int LPB> __global__ void __launch_bounds__(WPE_NT) ds_wpe_kernel(WpeParams p) {
-    typedef WpeEngine<LPB> E;
+template <int LPB, int CT = 0, int NTAPS = 0> __global__ void __launch_bounds__(WPE_NT) ds_wpe_kernel(WpeParams p) {
+    typedef WpeEngine<LPB, CT, NTAPS> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
     E::run(ex, p, (int)blockIdx.x, sh);
@@ -485,7 +485,14 @@ template <int LPB> __global__ void __launch_bounds__(WPE_NT) ds_wpe_kernel(WpePa
 hipError_t launch_wpe(const WpeParams& p, hipStream_t stream) {
     const int lpb = wpe_lanes_per_bin(p.C * p.N), bpw = WPE_NT / lpb;
     const unsigned blocks = (unsigned)(((long long)p.B * p.K + bpw - 1) / bpw);
-    if (lpb == 4) hipLaunchKernelGGL(ds_wpe_kernel<4>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
+    // the shapes of the BASELINE config (8 channels x 2 taps), of the reference's notebooks and tests (4 x 2, 2 x 3, 4 x 4, 8 x 1) as
+    // compile-time shapes; anything else through the generic kernels
+    if (p.C == 8 && p.N == 2) hipLaunchKernelGGL((ds_wpe_kernel<16, 8, 2>), dim3(blocks), dim3(WPE_NT), 0, stream, p);
+    else if (p.C == 4 && p.N == 2) hipLaunchKernelGGL((ds_wpe_kernel<8, 4, 2>), dim3(blocks), dim3(WPE_NT), 0, stream, p);
+    else if (p.C == 4 && p.N == 4) hipLaunchKernelGGL((ds_wpe_kernel<16, 4, 4>), dim3(blocks), dim3(WPE_NT), 0, stream, p);
+    else if (p.C == 8 && p.N == 1) hipLaunchKernelGGL((ds_wpe_kernel<8, 8, 1>), dim3(blocks), dim3(WPE_NT), 0, stream, p);
+    else if (p.C == 2 && p.N == 3) hipLaunchKernelGGL((ds_wpe_kernel<8, 2, 3>), dim3(blocks), dim3(WPE_NT), 0, stream, p);
+    else if (lpb == 4) hipLaunchKernelGGL(ds_wpe_kernel<4>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
     else if (lpb == 8) hipLaunchKernelGGL(ds_wpe_kernel<8>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
     else hipLaunchKernelGGL(ds_wpe_kernel<16>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
     return hipGetLastError();

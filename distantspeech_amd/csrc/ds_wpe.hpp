@@ -64,13 +64,17 @@ template <int LPB> struct WpeRegs {
     long long io0, ring0;          // channel 0 of frame 0 / of ring slot 0 of this lane's bin in the [B][T][K][C] / [B][ring_len][K][C] arrays
 };
 
-template <int LPB> struct WpeEngine {
+// CT, NTAPS > 0: the channel and tap counts as compile-time constants (the shapes the launcher knows: launch_wpe) — the `c < C`, `j < CN`
+// guards of the generic program fold away with their scalar branches (29 % of the generic kernel's instruction stream at 8 x 2), the loops
+// unroll to the live entries only.  Same statements, same order: bit-identical to the generic instantiation (test_wpe_*).
+template <int LPB, int CT = 0, int NTAPS = 0> struct WpeEngine {
     static constexpr int NT = WPE_NT, BPW = WPE_NT / LPB, CM = LPB < WPE_CMAX ? LPB : WPE_CMAX;
     typedef WpeShared<LPB> Sh;
     typedef WpeRegs<LPB> Rg;
+    static_assert(CT * NTAPS <= LPB && CT <= CM, "shape");
 
     template <class Exec> static DS_HD void run(Exec& ex, const WpeParams& p, int blk, Sh& sh) {
-        const int C = p.C, N = p.N, CN = C * N;
+        const int C = CT > 0 ? CT : p.C, N = NTAPS > 0 ? NTAPS : p.N, CN = C * N;
         const int SB = wpe_bin_floats(C, N);
         const long long nbins = (long long)p.B * p.K;
         const float lam = p.lam, lam_inv = 1.0f / p.lam;
@@ -213,10 +217,10 @@ template <int LPB> struct WpeEngine {
                     if (j < CN) {
                         // P = (P - g g^H / den) / lambda (:183-185).  Every product is rounded on its own and the two of a sum are then added,
                         // so that element (j, i), which lane j computes, is the exact conjugate of this one: P stays Hermitian bit for bit
-                        const cf gj = sh.num[s][j];
-                        const float tx = gi.x * gj.x + gi.y * gj.y, ty = gi.y * gj.x - gi.x * gj.y;      // g_i conj(g_j)
-                        // P / lambda - t (1 / (den lambda)): the fused multiply-add keeps the symmetry too (it commutes with negation)
-                        r.P[j] = mk(fma_(-tx, dls, r.P[j].x * lam_inv), j == i ? 0.0f : fma_(-ty, dls, r.P[j].y * lam_inv));
+                        // P / lambda - g_i conj(g_j) (1 / (den lambda)): the fused multiply-add keeps the symmetry too (it commutes with
+                        // negation).  On the diagonal g_i conj(g_i) has the imaginary part x y - x y = +0 exactly and P_ii's is 0 from the
+                        // initial state on (a real multiple of the identity), so it stays +0 without a per-lane select
+                        r.P[j] = herm_downdate(r.P[j], gi, sh.num[s][j], lam_inv, dls);
                     }
 #pragma unroll
                 for (int c = 0; c < CM; ++c)

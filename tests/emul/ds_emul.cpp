@@ -152,8 +152,8 @@ template <int NFFT, int CMAX> int run_fdaf(ds::FdafParams p) {
     return 0;
 }
 
-template <int LPB> int run_wpe(const ds::WpeParams& p) {
-    typedef ds::WpeEngine<LPB> E;
+template <int LPB, int CT = 0, int NTAPS = 0> int run_wpe(const ds::WpeParams& p) {
+    typedef ds::WpeEngine<LPB, CT, NTAPS> E;
     typename E::Sh* sh = new typename E::Sh();
     const int blocks = (int)(((long long)p.B * p.K + E::BPW - 1) / E::BPW);
     for (int b = 0; b < blocks; ++b) {
@@ -246,7 +246,9 @@ int emul_istft(int nfft, int M, int batch, const float* Y, int T, int C, float* 
 
 // OpParams fields outside emul_op's argument list (set before the call, sticky)
 static int g_repeat = 0, g_two_path = 0;
+static int g_wpe_generic = 0;     // emul_set_wpe_generic(1): every WPE shape through the run-time-shape program (the A side of an A/B)
 void emul_set_repeat(int on) { g_repeat = on; }
+void emul_set_wpe_generic(int on) { g_wpe_generic = on; }
 void emul_set_pipe(int on) { g_pipe = on; }
 int emul_pipe_runs() { return g_pipe_runs; }
 void emul_set_two_path(int on) { g_two_path = on; }
@@ -309,6 +311,13 @@ int emul_wpe(int B, int K, int T, int C, int N, const float* xd, const float* d,
     p.B = B; p.K = K; p.T = T; p.C = C; p.N = N; p.xd = xd; p.d = d; p.err = err; p.state = state;
     p.ustride = (long long)K * ds::wpe_bin_floats(C, N); p.lam = lam;
     const int lpb = ds::wpe_lanes_per_bin(C * N);
+    if (!g_wpe_generic) {                                        // the compile-time shapes of launch_wpe (ds_kernels_ops.hip)
+        if (C == 8 && N == 2) return run_wpe<16, 8, 2>(p);
+        if (C == 4 && N == 2) return run_wpe<8, 4, 2>(p);
+        if (C == 4 && N == 4) return run_wpe<16, 4, 4>(p);
+        if (C == 8 && N == 1) return run_wpe<8, 8, 1>(p);
+        if (C == 2 && N == 3) return run_wpe<8, 2, 3>(p);
+    }
     return lpb == 4 ? run_wpe<4>(p) : lpb == 8 ? run_wpe<8>(p) : run_wpe<16>(p);
 }
 

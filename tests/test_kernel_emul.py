@@ -208,6 +208,30 @@ def test_emul_wpe_golden(name):
     assert rms(y - g["y"]) < 2e-4 * max(rms(g["y"]), 1e-3)
 
 
+@pytest.mark.parametrize("C,N", [(8, 2), (4, 2), (4, 4), (8, 1), (2, 3)])
+def test_emul_wpe_compile_time_shapes_equal_the_generic_program(C, N):
+    """launch_wpe runs the BASELINE shape (8 channels x 2 taps) and the reference's notebook / test shapes as instantiations with the
+    channel and tap counts as compile-time constants (WpeEngine<LPB, CT, NTAPS>): the same statements with their guards folded — errors
+    and state bit for bit what the run-time-shape program gives, over two calls."""
+    from emul import emul as E
+    from emul.emul import EmulWpe
+    rng = np.random.default_rng(100 * C + N)
+    nfft, T = 256, 9
+    d = (rng.standard_normal((2, T, nfft // 2 + 1, C)) + 1j * rng.standard_normal((2, T, nfft // 2 + 1, C))).astype(np.complex64)
+    xd = np.concatenate([np.zeros_like(d[:, :2]), d[:, :-2]], axis=1)
+    res = []
+    for generic in (1, 0):
+        E.lib().emul_set_wpe_generic(generic)
+        try:
+            op = EmulWpe(nfft, C, N, batch=2)
+            err = np.concatenate([op.run(xd[:, :4], d[:, :4]), op.run(xd[:, 4:], d[:, 4:])], axis=1)
+        finally:
+            E.lib().emul_set_wpe_generic(0)
+        res.append((err, op.state.copy()))
+    assert np.all(np.isfinite(res[0][0])) and np.abs(res[0][0]).max() > 0
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("name", ["rec1", "synth_m6", "rec1_repeat"])
 def test_emul_mcspp_notebook_mvdr(name):
     """McSpp (McCDR prior) + steering + compute_mvdr_weight, the notebook's online MVDR (example/mvdr.ipynb cell 4)."""
