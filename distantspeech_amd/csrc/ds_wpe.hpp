@@ -102,11 +102,17 @@ template <int LPB, int CT = 0, int NTAPS = 0> struct WpeEngine {
         const long long fstride = (long long)p.K * C;
         auto io_at = [&](const Rg& r, int t) { return r.io0 + (long long)t * fstride; };
         auto ring_slot = [&](const Rg& r, int slot_) { return r.ring0 + (long long)slot_ * fstride; };
+        // (one load from a selected address, not a load per source: three returns made the compiler keep the value in scratch and wait
+        // for the load on the spot — the prefetch of the next frame's input was a stall)
         auto delayed = [&](const Rg& r, int t, int c) {           // x_delayed[c] of frame t
-            if (p.ring == nullptr) { const long long f = io_at(r, t); return mk(p.xd[2 * (f + c)], p.xd[2 * (f + c) + 1]); }
-            if (t < p.ring_len) { const long long f = ring_slot(r, (ring_pos + t) % p.ring_len); return mk(p.ring[2 * (f + c)], p.ring[2 * (f + c) + 1]); }
-            const long long f = io_at(r, t - p.ring_len);
-            return mk(p.d[2 * (f + c)], p.d[2 * (f + c) + 1]);
+            const float* src = p.xd;
+            long long f = io_at(r, t);
+            if (p.ring != nullptr) {
+                const bool in_ring = t < p.ring_len;
+                src = in_ring ? p.ring : p.d;
+                f = in_ring ? ring_slot(r, (ring_pos + t) % p.ring_len) : io_at(r, t - p.ring_len);
+            }
+            return mk(src[2 * (f + c)], src[2 * (f + c) + 1]);
         };
         ex.phase_wave([&](int tid, Rg& r) {
             int s, i; long long g; bool on;
@@ -130,8 +136,8 @@ template <int LPB, int CT = 0, int NTAPS = 0> struct WpeEngine {
             r.io0 = io_base(g, 0);
             r.ring0 = p.ring != nullptr ? ring_at(g, 0) : 0;
             const long long f0 = r.io0;
-            const int c = i / N;
-            if (i == c * N) r.xin = delayed(r, 0, c);
+            r.xin = delayed(r, 0, i / N);          // every lane of a channel (only tap 0 uses it: the others would need a guarded assignment,
+                                                   // which the compiler turns into a scratch slot and a wait on the load)
             if (i < C) r.din = mk(p.d[2 * (f0 + i)], p.d[2 * (f0 + i) + 1]);
         });
         ex.phase_wave([&](int tid, Rg& r) {                            // row i of P: above the diagonal as stored, below it the conjugate of column i
@@ -151,8 +157,11 @@ template <int LPB, int CT = 0, int NTAPS = 0> struct WpeEngine {
                 int s, i; long long g; bool on;
                 slot(tid, s, i, g, on);
                 if (!on) return;
-                const int c = i / N;
-                sh.X[nxt][s][i] = (i == c * N) ? r.xin : sh.X[cur][s][i - 1];
+                // (both candidates as values, then a select: `cond ? r.xin : sh.X[..]` on the structs became a select of ADDRESSES — a flat load
+                // from either scratch or LDS, with r.xin parked in scratch and the prefetch waited for on the spot)
+                const bool tap0 = i == (i / N) * N;
+                const cf prev = sh.X[cur][s][i > 0 ? i - 1 : 0], xin = r.xin;
+                sh.X[nxt][s][i] = mk(tap0 ? xin.x : prev.x, tap0 ? xin.y : prev.y);
                 if (i < C) {
                     sh.d[s][i] = r.din;
                     if (p.ring != nullptr && t >= p.T - p.ring_len) {             // this frame is one of the last ring_len: keep it
@@ -167,10 +176,14 @@ template <int LPB, int CT = 0, int NTAPS = 0> struct WpeEngine {
                 slot(tid, s, i, g, on);
                 if (!on) return;
                 const cf Xi = sh.X[nxt][s][i];
-                cf a = mk(0.0f, 0.0f);
+                // two partial sums (even and odd taps) added at the end: half the dependent chain of multiply-adds per lane
+                cf a0 = mk(0.0f, 0.0f), a1 = mk(0.0f, 0.0f);
 #pragma unroll
-                for (int j = 0; j < LPB; ++j)
-                    if (j < CN) a = cfma(a, r.P[j], sh.X[nxt][s][j]);
+                for (int j = 0; j < LPB; j += 2) {
+                    if (j < CN) a0 = cfma(a0, r.P[j], sh.X[nxt][s][j]);
+                    if (j + 1 < CN) a1 = cfma(a1, r.P[j + 1], sh.X[nxt][s][j + 1]);
+                }
+                const cf a = cadd(a0, a1);
                 r.num = a;
                 sh.num[s][i] = a;
                 sh.dre[s][i] = fma_(Xi.x, a.x, Xi.y * a.y);
@@ -179,8 +192,7 @@ template <int LPB, int CT = 0, int NTAPS = 0> struct WpeEngine {
                     if (c < C) sh.part[s][c][i] = cmulc(Xi, r.W[c]);
                 if (t + 1 < p.T) {                                 // next frame's inputs: in flight behind this frame's arithmetic
                     const long long f1 = io_at(r, t + 1);
-                    const int c = i / N;
-                    if (i == c * N) r.xin = delayed(r, t + 1, c);
+                    r.xin = delayed(r, t + 1, i / N);
                     if (i < C) r.din = mk(p.d[2 * (f1 + i)], p.d[2 * (f1 + i) + 1]);
                 }
             });
