@@ -577,6 +577,10 @@ def main():
             "n_gpus": res["ranks"], "steps": K, "warmup": W, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": be.name,
             "rounds": res["rounds"], "timed_steps": res["timed_steps"], "region_ms": res["region_ms"],
+            "data_note": "BASELINE.md section 3's recipe in both legs (white noise sigma 0.05 per microphone + a 0.5 s on / off 300-3400 Hz Gaussian source sigma "
+                         "0.1 steered from 197 degrees, seed 1234 + utterance): the GPU leg draws it on the device with torch's generator "
+                         "(GpuBackend.synth), the cpu_baseline legs with NumPy's (oracle.synth_utterance) — the same statistics, different random "
+                         "streams; neither leg's arithmetic per frame depends on the sample values",
             "config": {"workload": "%s: %s, batch=%d utterances per GPU, %d hop(s) per call (%s), state resident in HBM"
                                    % (("BASELINE " + args.config) if args.config.startswith("cfg") else args.config, w["desc"], B, T, regime),
                        "batch_per_gpu": B, "hops_per_call": T, "n_mics": w["M"], "nfft": w["nfft"], "hop": w["hop"],
