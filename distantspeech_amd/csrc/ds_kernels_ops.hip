@@ -1,6 +1,7 @@
 // ds_kernels_ops.hip — stand-alone STFT / ISTFT kernels and the frame-level (utterance, bin) operator
 // kernel (MCRA, McMcra, NsOmlsaMulti, subband LMS / RLS) for gfx950.
 #include <cstdint>
+#include <cstdlib>
 #include "ds_kernels.hpp"
 #include "ds_ops.hpp"
 #include "ds_tdfilter.hpp"
@@ -486,13 +487,15 @@ hipError_t launch_wpe(const WpeParams& p, hipStream_t stream) {
     const int lpb = wpe_lanes_per_bin(p.C * p.N), bpw = WPE_NT / lpb;
     const unsigned blocks = (unsigned)(((long long)p.B * p.K + bpw - 1) / bpw);
     // the shapes of the BASELINE config (8 channels x 2 taps), of the reference's notebooks and tests (4 x 2, 2 x 3, 4 x 4, 8 x 1) as
-    // compile-time shapes; anything else through the generic kernels
-    if (p.C == 8 && p.N == 2) hipLaunchKernelGGL((ds_wpe_kernel<16, 8, 2>), dim3(blocks), dim3(WPE_NT), 0, stream, p);
-    else if (p.C == 4 && p.N == 2) hipLaunchKernelGGL((ds_wpe_kernel<8, 4, 2>), dim3(blocks), dim3(WPE_NT), 0, stream, p);
-    else if (p.C == 4 && p.N == 4) hipLaunchKernelGGL((ds_wpe_kernel<16, 4, 4>), dim3(blocks), dim3(WPE_NT), 0, stream, p);
-    else if (p.C == 8 && p.N == 1) hipLaunchKernelGGL((ds_wpe_kernel<8, 8, 1>), dim3(blocks), dim3(WPE_NT), 0, stream, p);
-    else if (p.C == 2 && p.N == 3) hipLaunchKernelGGL((ds_wpe_kernel<8, 2, 3>), dim3(blocks), dim3(WPE_NT), 0, stream, p);
-    else if (lpb == 4) hipLaunchKernelGGL(ds_wpe_kernel<4>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
+    // compile-time shapes; anything else — and everything under DS_WPE_GENERIC=1, the A/B and test switch — through the generic kernels
+    const char* e = std::getenv("DS_WPE_GENERIC");
+    if (!(e && e[0] == '1')) {
+#define DS_WPE_SHAPE(LPB_, C_, N_) \
+        if (p.C == C_ && p.N == N_) { hipLaunchKernelGGL((ds_wpe_kernel<LPB_, C_, N_>), dim3(blocks), dim3(WPE_NT), 0, stream, p); return hipGetLastError(); }
+        DS_WPE_SHAPE(16, 8, 2) DS_WPE_SHAPE(8, 4, 2) DS_WPE_SHAPE(16, 4, 4) DS_WPE_SHAPE(8, 8, 1) DS_WPE_SHAPE(8, 2, 3)
+#undef DS_WPE_SHAPE
+    }
+    if (lpb == 4) hipLaunchKernelGGL(ds_wpe_kernel<4>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
     else if (lpb == 8) hipLaunchKernelGGL(ds_wpe_kernel<8>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
     else hipLaunchKernelGGL(ds_wpe_kernel<16>, dim3(blocks), dim3(WPE_NT), 0, stream, p);
     return hipGetLastError();

@@ -5,7 +5,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
-g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -mfma -fsanitize=address,undefined -fno-omit-frame-pointer \
+g++ -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -mfma -fsanitize=address,undefined -fno-omit-frame-pointer -fno-strict-aliasing \
     tests/emul/ds_emul.cpp -o /tmp/libds_emul_asan.so
 cp tests/emul/libds_emul.so /tmp/libds_emul_plain.so 2>/dev/null || true
 cp /tmp/libds_emul_asan.so tests/emul/libds_emul.so; touch tests/emul/libds_emul.so

@@ -1208,6 +1208,52 @@ def test_wpe_shapes(ds, C, N):
     assert rms(err[0] - ref) < 2e-4 * rms(ref)
 
 
+@pytest.mark.parametrize("C,N", [(8, 2), (4, 2), (4, 4), (8, 1), (2, 3)])
+def test_wpe_compile_time_shapes_equal_the_generic_kernel(ds, C, N, monkeypatch):
+    """launch_wpe runs these shapes as kernels with the channel and tap counts as compile-time constants (ds_wpe.hpp WpeEngine<LPB, CT,
+    NTAPS>); DS_WPE_GENERIC=1 sends them through the run-time-shape kernel: same errors and the same exported state bit for bit, also
+    against the oracle core."""
+    from oracle import ds_oracle as O
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(1000 + 10 * C + N)
+    K, T, B = 129, 24, 3
+    D = ((rng.standard_normal((B, T, K, C)) + 1j * rng.standard_normal((B, T, K, C))) * 0.3).astype(np.complex64)
+    Xd = np.concatenate([np.zeros((B, 2, K, C), np.complex64), D[:, :-2]], axis=1)
+    out = []
+    for generic in ("1", "0"):
+        monkeypatch.setenv("DS_WPE_GENERIC", generic)
+        eng = ds.BatchEngine(L.ALGO_WPE, C, 256, batch=B, filter_len=N, rls_lambda=0.998)
+        err = np.concatenate([eng.wpe_update(Xd[:, :9], D[:, :9]), eng.wpe_update(Xd[:, 9:], D[:, 9:])], axis=1)
+        out.append((err, eng.export_state()))
+    monkeypatch.delenv("DS_WPE_GENERIC")
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    o = O.OracleWpe(channels=C, filter_len=N, num_bands=256, delay=2)
+    ref = np.stack([o.update_fd(Xd[1, t], D[1, t]) for t in range(T)])
+    assert rms(out[1][0][1] - ref) < 2e-4 * rms(ref)
+
+
+def test_chain_stage_info_adds_up(ds):
+    """ds_chain_stage_info: the stages of the two BASELINE chains in the order of the reference object's members; their carried-state
+    bytes + the chain's own delay lines (+ the overlaps and counters every handle allocates) = ds_state_payload_bytes of the chain; a plain
+    handle has no stages."""
+    from distantspeech_amd import _lib as L
+    e = ds.BatchEngine(L.ALGO_WPE_MVDR, 8, 1024, 512, batch=4, filter_len=2)
+    st = e.chain_stages()
+    assert [a for _, a, _, _, _ in st] == [L.ALGO_TRANSFORM, L.ALGO_WPE, L.ALGO_MCMCRA, L.ALGO_ADAPTIVE_FRAMES, L.ALGO_TRANSFORM]
+    assert [m for _, _, m, _, _ in st] == [8, 8, 8, 8, 1] and all(b == 4 for _, _, _, b, _ in st)
+    hist = 4 * 4 * 513 * 8 * 8                                  # the delay line: batch x delay (4 frames) x K x channels complex64
+    own = e.state_bytes() - sum(n for *_, n in st) - hist         # the chain handle's own (idle) overlaps and counters
+    assert 0 <= own <= 4 * (9 * 512 * 4 + 64)
+    g = ds.BatchEngine(L.ALGO_SUBBAND_GSC, 6, 512, 256, batch=2, filter_len=2, rls_lambda=0.998)
+    sg = g.chain_stages()
+    assert [a for _, a, _, _, _ in sg] == [L.ALGO_FRONTEND, L.ALGO_TRANSFORM, L.ALGO_MCSPP, L.ALGO_TRANSFORM, L.ALGO_TRANSFORM, L.ALGO_SUBRLS,
+                                           L.ALGO_TRANSFORM, L.ALGO_SUBLMS, L.ALGO_TRANSFORM]
+    assert [b for _, _, _, b, _ in sg][4:6] == [12, 12]          # the M blocking filters and their transforms: one batch of B * M
+    own = g.state_bytes() - sum(n for *_, n in sg) - 2 * (257 * 8 + 256 * 4)     # - the delayed fixed spectrum and fixed-beamformer block
+    assert 0 <= own <= 2 * (7 * 256 * 4 + 64)
+    assert ds.BatchEngine(L.ALGO_ADAPTIVE, 4, 512, batch=1).chain_stages() == []
+
+
 @pytest.mark.parametrize("N,C", [(2, 1), (2, 2), (2, 4), (2, 6), (2, 8), (3, 3), (1, 5), (4, 2)])
 def test_subband_lms_shapes(ds, N, C):
     """the register-resident specialisations of the subband LMS operator (2 taps x 1/2/4/6/8 channels) and its generic path vs the
