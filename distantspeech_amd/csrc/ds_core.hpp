@@ -1274,6 +1274,22 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         const cf* steer = p.steer + (long long)b * p.steer_batch_stride;
         int frm_cnt = cnt[0], ell = cnt[1], spp_cnt = cnt[2];
         int old_half = 0;
+        auto store_lane_state = [&](int tid, Rg& r) {              // bin `tid`'s planes back to HBM
+            DS_PIN(tid);                                           // addresses formed here, not hoisted out of the hop loop (registers)
+#pragma unroll
+            for (int q = 0; q < SL::NPF; ++q) {
+                vec4 v; v.x = r.st[4 * q]; v.y = r.st[4 * q + 1]; v.z = r.st[4 * q + 2]; v.w = r.st[4 * q + 3];
+                store_state(&bins[q * KP + tid], v);
+            }
+#pragma unroll
+            for (int j = 0; j < SL::RT; ++j) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DS_NT_TAIL)
+                __builtin_nontemporal_store(r.st[4 * SL::NPF + j], &btail[tid * SL::RT + j]);
+#else
+                btail[tid * SL::RT + j] = r.st[4 * SL::NPF + j];
+#endif
+            }
+        };
         // Wave priorities.  The per-bin phase is wide and arithmetic-heavy, everything else in a hop is a chain of short LDS round trips.  When
         // the whole grid is resident at once (4 workgroups per CU for 4 microphones and 512-point frames) the chains run at raised priority from the start of a hop and the per-bin
         // phase yields to them (+6..9 % at B = 1024, one hop per call; +8 % chunked); with more workgroups than that waiting for a slot only
@@ -1468,6 +1484,13 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt, r.ad, r.apk);
                 if (tid == 0) Yk.y = 0.0f;                              // irfft ignores Im Y[0] and Im Y[N/2]
                 sh.Y[tid] = Yk;
+#if !defined(DS_LATE_STATE_STORE)
+                if constexpr (ALGO != ALGO_AIC) {
+                    // the call's last hop: this lane's state is final here — on its way to HBM while the inverse transform and the
+                    // overlap-add run, instead of behind them (at one hop per call every launch ends on this)
+                    if (t == p.T - 1) store_lane_state(tid, r);
+                }
+#endif
                 if (tid == NYQ_TID) {
                     if constexpr (WAVE_FFT) {                           // the Nyquist bin's inputs, before the inverse transform reuses the buffer
 #pragma unroll
@@ -1569,19 +1592,11 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     if (tid == NYQ_TID) { keep[2 * NC] = last[2 * NC]; keep[2 * NC + 1] = last[2 * NC + 1]; }
                 }
             } else {
-#pragma unroll
-                for (int q = 0; q < SL::NPF; ++q) {
-                    vec4 v; v.x = r.st[4 * q]; v.y = r.st[4 * q + 1]; v.z = r.st[4 * q + 2]; v.w = r.st[4 * q + 3];
-                    store_state(&bins[q * KP + tid], v);
-                }
-#pragma unroll
-                for (int j = 0; j < SL::RT; ++j) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(DS_NT_TAIL)
-                    __builtin_nontemporal_store(r.st[4 * SL::NPF + j], &btail[tid * SL::RT + j]);
+#if defined(DS_LATE_STATE_STORE)
+                store_lane_state(tid, r);
 #else
-                    btail[tid * SL::RT + j] = r.st[4 * SL::NPF + j];
+                if (p.T == 0) store_lane_state(tid, r);                 // (otherwise stored in the last hop's per-bin phase)
 #endif
-                }
                 if (tid < SL::NPF) {
                     vec4 v; v.x = sh.nyq[4 * tid]; v.y = sh.nyq[4 * tid + 1]; v.z = sh.nyq[4 * tid + 2]; v.w = sh.nyq[4 * tid + 3];
                     bins[tid * KP + NC] = v;

@@ -84,7 +84,14 @@ class Transform(_Base):
 
     @property
     def previous_input(self):
+        """[overlap, channel] (transform.py:425,451): the last n_fft - hop input samples"""
         return self._sq(np.swapaxes(self._eng.get_field(L.FIELD_STFT_TAIL), 1, 2).astype(np.float64))
+
+    @property
+    def previous_output(self):
+        """[overlap, channel] (transform.py:426,477): the synthesis frames' overlap still to be added to the next hops (before the
+        hop / W0 scaling of :479, like the reference's attribute)"""
+        return self._sq(np.swapaxes(self._eng.get_field(L.FIELD_OLA_TAIL), 1, 2).astype(np.float64))
 
 
 class NoiseEstimationMCRA(_Base):

@@ -96,6 +96,9 @@ def test_transform_quarter_hop_batch_state_and_refusals(ds):
         assert rms(Y[b] - Yo) < 2e-6 * rms(Yo)
         assert np.max(np.abs(y[b] - np.asarray(o.istft(Yo)))) < 5e-6
     assert np.array_equal(t.previous_input, x[:, -3 * hop:, :].astype(np.float64))
+    o = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop)
+    o.istft(o.stft(x[0]))
+    assert t.previous_output.shape == (B, nfft - hop, M) and np.max(np.abs(t.previous_output[0] - o.previous_output)) < 5e-6
     # sqrt-Hann at 75 % overlap: analysis -> synthesis returns the input n_fft - hop samples late (hop / W0 = 1 / 2 of the window power sum)
     assert np.max(np.abs(y[:, nfft - hop:, :] - x[:, : -(nfft - hop), :])) < 5e-6
     t1 = ds.Transform(channel=M, n_fft=nfft, hop_length=hop, batch=B)
