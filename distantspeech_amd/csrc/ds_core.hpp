@@ -1274,6 +1274,21 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         const cf* steer = p.steer + (long long)b * p.steer_batch_stride;
         int frm_cnt = cnt[0], ell = cnt[1], spp_cnt = cnt[2];
         int old_half = 0;
+#if defined(DS_LATE_STATE_STORE)
+        constexpr bool EARLY_STORE = false;                        // A/B switch: everything in the epilogue, as before round 3
+#else
+        constexpr bool EARLY_STORE = ALGO != ALGO_AIC;
+#endif
+        auto store_nyquist_state = [&](int tid) {                  // the Nyquist bin's planes (kept in LDS during the call)
+            DS_PIN(tid);
+            if (tid < SL::NPF) {
+                vec4 v; v.x = sh.nyq[4 * tid]; v.y = sh.nyq[4 * tid + 1]; v.z = sh.nyq[4 * tid + 2]; v.w = sh.nyq[4 * tid + 3];
+                bins[tid * KP + NC] = v;
+            } else if (SL::RT > 0 && tid == SL::NPF) {
+#pragma unroll
+                for (int j = 0; j < SL::RT; ++j) btail[NC * SL::RT + j] = sh.nyq[4 * SL::NPF + j];
+            }
+        };
         auto store_lane_state = [&](int tid, Rg& r) {              // bin `tid`'s planes back to HBM
             DS_PIN(tid);                                           // addresses formed here, not hoisted out of the hop loop (registers)
 #pragma unroll
@@ -1484,13 +1499,18 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt, r.ad, r.apk);
                 if (tid == 0) Yk.y = 0.0f;                              // irfft ignores Im Y[0] and Im Y[N/2]
                 sh.Y[tid] = Yk;
-#if !defined(DS_LATE_STATE_STORE)
-                if constexpr (ALGO != ALGO_AIC) {
-                    // the call's last hop: this lane's state is final here — on its way to HBM while the inverse transform and the
-                    // overlap-add run, instead of behind them (at one hop per call every launch ends on this)
-                    if (t == p.T - 1) store_lane_state(tid, r);
+                if constexpr (EARLY_STORE) {
+                    // the call's last hop: this lane's state and the analysis overlap are final here — on their way to HBM while the inverse
+                    // transform and the overlap-add run, instead of behind them (at one hop per call every launch ends on this)
+                    if (t == p.T - 1) {
+                        store_lane_state(tid, r);
+                        vec4* tin4 = reinterpret_cast<vec4*>(tin);
+                        for (int i = tid; i < M * HOP / 4; i += NT) {
+                            const int m = i / (HOP / 4), q = i - m * (HOP / 4);
+                            store_state(&tin4[i], *reinterpret_cast<const vec4*>(&sh.xbuf[m][new_half * HOP + 4 * q]));
+                        }
+                    }
                 }
-#endif
                 if (tid == NYQ_TID) {
                     if constexpr (WAVE_FFT) {                           // the Nyquist bin's inputs, before the inverse transform reuses the buffer
 #pragma unroll
@@ -1548,8 +1568,12 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     z1.x += hn; z1.y -= hn; z2.x += hn; z2.y -= hn;
                     const float y0 = sh.tb.win[2 * i] * (z1.x * sc), y1 = sh.tb.win[2 * i + 1] * (z1.y * sc);
                     const float o0 = (y0 + sh.tail[2 * i]) * p.out_scale, o1 = (y1 + sh.tail[2 * i + 1]) * p.out_scale;
-                    sh.tail[2 * i] = sh.tb.win[HOP + 2 * i] * (z2.x * sc);
-                    sh.tail[2 * i + 1] = sh.tb.win[HOP + 2 * i + 1] * (z2.y * sc);
+                    const float t0 = sh.tb.win[HOP + 2 * i] * (z2.x * sc), t1 = sh.tb.win[HOP + 2 * i + 1] * (z2.y * sc);
+                    sh.tail[2 * i] = t0;
+                    sh.tail[2 * i + 1] = t1;
+                    if constexpr (EARLY_STORE) {
+                        if (t == p.T - 1) { tout[2 * i] = t0; tout[2 * i + 1] = t1; }      // the synthesis overlap the next call starts with
+                    }
                     float* dst = p.y + yb + (long long)t * HOP + 2 * i;
 #if defined(__HIP_DEVICE_COMPILE__)
                     typedef float f2_t __attribute__((ext_vector_type(2)));
@@ -1559,12 +1583,19 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     dst[0] = o0; dst[1] = o1;
 #endif
                 }
+                if constexpr (EARLY_STORE) {
+                    if (t == p.T - 1) {                                 // the Nyquist bin's state (final since its pass, two barriers back) and the counters
+                        store_nyquist_state(tid);
+                        if (tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }
+                    }
+                }
                 if (!one_round) DS_SETPRIO(0);
             });
             old_half = new_half;
         }
 
-        // ---- epilogue: state back to HBM -----------------------------------------------------------
+        // ---- epilogue: state back to HBM (the chain tail; a call without hops) -----------------------
+        if (!EARLY_STORE || p.T == 0)
         ex.phase([&](int tid, Rg& r) {
             {
                 vec4* tin4 = reinterpret_cast<vec4*>(tin);
@@ -1592,18 +1623,8 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     if (tid == NYQ_TID) { keep[2 * NC] = last[2 * NC]; keep[2 * NC + 1] = last[2 * NC + 1]; }
                 }
             } else {
-#if defined(DS_LATE_STATE_STORE)
                 store_lane_state(tid, r);
-#else
-                if (p.T == 0) store_lane_state(tid, r);                 // (otherwise stored in the last hop's per-bin phase)
-#endif
-                if (tid < SL::NPF) {
-                    vec4 v; v.x = sh.nyq[4 * tid]; v.y = sh.nyq[4 * tid + 1]; v.z = sh.nyq[4 * tid + 2]; v.w = sh.nyq[4 * tid + 3];
-                    bins[tid * KP + NC] = v;
-                } else if (SL::RT > 0 && tid == SL::NPF) {
-#pragma unroll
-                    for (int j = 0; j < SL::RT; ++j) btail[NC * SL::RT + j] = sh.nyq[4 * SL::NPF + j];
-                }
+                store_nyquist_state(tid);
             }
             if (tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }
         });
