@@ -1502,7 +1502,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 if constexpr (EARLY_STORE) {
                     // the call's last hop: this lane's state and the analysis overlap are final here — on their way to HBM while the inverse
                     // transform and the overlap-add run, instead of behind them (at one hop per call every launch ends on this)
-                    if (t == p.T - 1) {
+                    if (t == T_run - 1) {
                         store_lane_state(tid, r);
                         vec4* tin4 = reinterpret_cast<vec4*>(tin);
                         for (int i = tid; i < M * HOP / 4; i += NT) {
@@ -1572,7 +1572,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     sh.tail[2 * i] = t0;
                     sh.tail[2 * i + 1] = t1;
                     if constexpr (EARLY_STORE) {
-                        if (t == p.T - 1) { tout[2 * i] = t0; tout[2 * i + 1] = t1; }      // the synthesis overlap the next call starts with
+                        if (t == T_run - 1) { tout[2 * i] = t0; tout[2 * i + 1] = t1; }      // the synthesis overlap the next call starts with
                     }
                     float* dst = p.y + yb + (long long)t * HOP + 2 * i;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1584,7 +1584,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
 #endif
                 }
                 if constexpr (EARLY_STORE) {
-                    if (t == p.T - 1) {                                 // the Nyquist bin's state (final since its pass, two barriers back) and the counters
+                    if (t == T_run - 1) {                               // the Nyquist bin's state (final since its pass, two barriers back) and the counters
                         store_nyquist_state(tid);
                         if (tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }
                     }
@@ -1595,7 +1595,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         }
 
         // ---- epilogue: state back to HBM (the chain tail; a call without hops) -----------------------
-        if (!EARLY_STORE || p.T == 0)
+        if (!EARLY_STORE || T_run == 0)
         ex.phase([&](int tid, Rg& r) {
             {
                 vec4* tin4 = reinterpret_cast<vec4*>(tin);

@@ -122,8 +122,8 @@ template <class Rg, int HOIST = 0> struct HipExec {
 // The 6-microphone SubbandGSC tail (ALGO_AIC) holds three workgroups per CU by its LDS; with the packed complex products the allocator
 // took 172 registers (two waves per SIMD) where 168 keep the third: pinned as well.
 #ifndef DS_GSC_HOIST
-#define DS_GSC_HOIST 0
-#endif
+#define DS_GSC_HOIST 1      // the transform stages only: 128 registers without scratch (level 2 spills 52 B); +4 % with 10 s per call, neutral at one hop
+#endif                      // per call (profiles/r03f/wpe_gschoist_ab.txt: before the state went back inside the last hop this level spilled too and lost 13 %)
 // frame kernels whose register budget has room for the hoisted addresses at unchanged occupancy (measured per shape with
 // -Rpass-analysis=kernel-resource-usage: the GSC kernel spills, the 6- and 8-microphone kernels lose a wave per SIMD)
 constexpr int frames_hoist(int nfft, int M, int algo, bool ryy) {
