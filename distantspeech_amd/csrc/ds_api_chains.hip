@@ -87,12 +87,12 @@ static int chain_process_groups(ds_handle* h, const float* x_dev, int layout, lo
             p.y_batch_stride = y_batch_stride;
             p.T = T; p.batch0 = 0; p.method = 1;
             p.tick = ds::TickArgs{h->sub[2]->dev_cnt + 8 * g, T, h->sub[2]->mcra_L > 0 ? h->sub[2]->mcra_L : 1, 0, 0};
+            // ... and of the group's other counters, the WPE ring position and the frame loop's frame counter (their readers are behind this
+            // launch on the stream as well): no counter kernel of its own at the end of a group's step (it was 6 us of each 390 us)
+            p.tick2 = dl > 0 ? ds::TickArgs{h->dev_cnt + 8 * g, 0, 1, T % dl, dl} : none;
+            p.tick3 = ds::TickArgs{h->sub[3]->dev_cnt + 8 * g, T, h->sub[3]->mcra_L > 0 ? h->sub[3]->mcra_L : 1, 0, 0};
             DS_HIP(h, launch_transform_istft(t, p, nb, sg));
         }
-        // the group's other counters: the WPE ring position and the frame loop's frame counter
-        const ds::TickArgs t0 = dl > 0 ? ds::TickArgs{h->dev_cnt + 8 * g, 0, 1, T % dl, dl} : none;
-        const ds::TickArgs t2 = {h->sub[3]->dev_cnt + 8 * g, T, h->sub[3]->mcra_L > 0 ? h->sub[3]->mcra_L : 1, 0, 0};
-        DS_HIP(h, ds::launch_tick3(t0, t2, none, sg));
     }
     h->groups_open = true;                                  // (a capture joins them before it ends: ds_process_device_seq)
     if (dl > 0) h->hist_cur = (h->hist_cur + T) % dl;

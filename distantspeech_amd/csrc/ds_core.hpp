@@ -249,6 +249,7 @@ struct Params {
     float mu;                 // GSC.py:202
     int rows;                 // single-channel transforms run one row per wavefront (StftRowsEngine / IstftRowsEngine): number of rows
     TickArgs tick;            // counters of an EARLIER stage of the chain to advance (stand-alone transform kernels only; cnt null = none)
+    TickArgs tick2, tick3;    // two more (synthesis kernels only: the last launch of a DS_ALGO_WPE_MVDR group advances every counter of its step)
     // ALGO_AIC, the SubbandGSC chain's tail as one frame kernel: re-analysis of the M blocking-matrix outputs (x) -> multi-channel subband
     // NLMS canceller (SubbandLmsMc, 2 taps) -> synthesis (y).  The canceller's state stays where the DS_ALGO_SUBLMS operator keeps it.
     float* aic_st;            // [B][aic_NF][KP] planes: W (2 N M), tap buffer X (2 N M), smoothed input power P

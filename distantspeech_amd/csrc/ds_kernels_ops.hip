@@ -17,7 +17,7 @@ template <int NFFT, int M, int OV> __global__ void __launch_bounds__(NFFT / 2) d
 }
 
 template <int NFFT, int M, int OV> __global__ void __launch_bounds__(NFFT / 2) ds_istft_kernel(Params p) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { apply_tick(p.tick); apply_tick(p.tick2); apply_tick(p.tick3); }
     typedef IstftEngine<NFFT, M, OV> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
@@ -55,7 +55,7 @@ template <int NFFT> __global__ void __launch_bounds__(256) ds_stft_rows_kernel(P
     E::run(ex, p, (int)blockIdx.x, sh);
 }
 template <int NFFT> __global__ void __launch_bounds__(256) ds_istft_rows_kernel(Params p) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { apply_tick(p.tick); apply_tick(p.tick2); apply_tick(p.tick3); }
     typedef IstftRowsEngine<NFFT> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
