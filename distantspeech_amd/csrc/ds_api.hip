@@ -226,6 +226,20 @@ const char* ds_strerror(int code) {
 
 const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
+// Which streams of a SubbandGSC chain run at the device's greatest priority (DS_CHAIN_PRIO=<mask> for A/B runs: 1 the chain's own (McSpp), 2 the
+// tail's, 4 the front end's, 8 the blocking filters').  Default 2: the tail kernel of block t shares the chip with McSpp of block t + 1 for
+// its whole length; dispatched first, it finishes earlier and the next block's stages find their buffers free sooner — +2.0 .. +3.7 % at one
+// block per call in every one of eleven interleaved pairs, -1.2 % with 10 s per call (profiles/r03f/chain_prio_ab.txt).  McSpp's own stream
+// first is -2 %, every other combination worse
+static hipError_t chain_stream(hipStream_t* s, int bit) {
+    const char* pr = std::getenv("DS_CHAIN_PRIO");
+    const int mask = pr ? std::atoi(pr) : 2;
+    int lo = 0, hi = 0;
+    if ((mask & bit) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 int ds_create(const ds_config* cfg, ds_handle** out) {
     if (!cfg || !out) return fail(nullptr, DS_EINVAL, "ds_create: NULL argument");
     if (cfg->struct_size != (int32_t)sizeof(ds_config)) return fail(nullptr, DS_EINVAL, "ds_create: struct_size mismatch");
@@ -402,7 +416,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     } while (0)
 
     DS_CRE(hipSetDevice(h->device));
-    DS_CRE(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    DS_CRE(cfg->algo == DS_ALGO_SUBBAND_GSC ? chain_stream(&h->stream, 1) : hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     DS_CRE(hipEventCreate(&h->ev0));
     DS_CRE(hipEventCreate(&h->ev1));
     if (bins_bytes(h)) DS_CRE(hipMalloc((void**)&h->bins, bins_bytes(h)));
@@ -489,7 +503,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             // the RLS blocking filters do not take the speech presence probability, so the blocking-filter stages (HBM-bound) run on a side
             // stream next to the McSpp stage (register-bound, one wave per SIMD) and join in front of the canceller.  McSpp is the longer
             // branch and stays on the chain's own stream: the cross-stream hand-offs (~10 us each) then sit on the branch that has slack
-            if (hipStreamCreateWithFlags(&h->side[0], hipStreamNonBlocking) != hipSuccess ||
+            if (chain_stream(&h->side[0], 8) != hipSuccess ||
                 hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&h->ev_join[0], hipEventDisableTiming) != hipSuccess) {
                 ds_destroy(h);
@@ -501,7 +515,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         // next to block t's HBM-bound stages (DS_CHAIN_SERIAL_FRONT=1: on the chain's stream, A/B runs)
         const char* serial = std::getenv("DS_CHAIN_SERIAL_FRONT");
         if (!(serial && serial[0] == '1')) {
-            bool ok = hipStreamCreateWithFlags(&h->side[1], hipStreamNonBlocking) == hipSuccess;
+            bool ok = chain_stream(&h->side[1], 4) == hipSuccess;
             for (int i = 0; i < 10 && ok; ++i) ok = hipEventCreateWithFlags(&h->ev_fr[i], hipEventDisableTiming) == hipSuccess;
             // the tail on a stream of its own needs a hardware queue of its own: with the runtime's default of 4 queues per device the fourth
             // and fifth stream of the process share one and the front end would queue behind the previous block's tail (measured: 0.31 ms per
@@ -509,7 +523,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             // Python binding do); without that the tail stays on the chain's stream
             const char* hwq = std::getenv("GPU_MAX_HW_QUEUES");
             if (ok && hwq && std::atoi(hwq) >= 6) {
-                ok = hipStreamCreateWithFlags(&h->side[2], hipStreamNonBlocking) == hipSuccess &&
+                ok = chain_stream(&h->side[2], 2) == hipSuccess &&
                      hipEventCreateWithFlags(&h->ev_join[2], hipEventDisableTiming) == hipSuccess;
                 h->tail_async = ok;
             }
