@@ -226,14 +226,13 @@ const char* ds_strerror(int code) {
 
 const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
 
-// Which streams of a SubbandGSC chain run at the device's greatest priority (DS_CHAIN_PRIO=<mask> for A/B runs: 1 the chain's own (McSpp), 2 the
-// tail's, 4 the front end's, 8 the blocking filters').  Default 2: the tail kernel of block t shares the chip with McSpp of block t + 1 for
-// its whole length; dispatched first, it finishes earlier and the next block's stages find their buffers free sooner — +2.0 .. +3.7 % at one
-// block per call in every one of eleven interleaved pairs, -1.2 % with 10 s per call (profiles/r03f/chain_prio_ab.txt).  McSpp's own stream
-// first is -2 %, every other combination worse
+// DS_CHAIN_PRIO=<mask> (A/B runs; default 0 = none): which streams of a SubbandGSC chain run at the device's greatest priority — 1 the chain's own
+// (McSpp), 2 the tail's, 4 the front end's, 8 the blocking filters'.  The tail's stream first was +2.0 .. +3.7 % at one block per call in eleven
+// interleaved pairs on three boxes and -4 .. -7 % in the second half of a fourth session (the chain's rate is bistable, 8.3 - 8.7 against 9.3 - 9.6 M
+// frames/s, and the priority moves the odds, not the levels): not the default (profiles/r03f/chain_prio_ab.txt)
 static hipError_t chain_stream(hipStream_t* s, int bit) {
     const char* pr = std::getenv("DS_CHAIN_PRIO");
-    const int mask = pr ? std::atoi(pr) : 2;
+    const int mask = pr ? std::atoi(pr) : 0;
     int lo = 0, hi = 0;
     if ((mask & bit) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
         return hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi);
