@@ -228,8 +228,9 @@ const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_er
 
 // DS_CHAIN_PRIO=<mask> (A/B runs; default 0 = none): which streams of a SubbandGSC chain run at the device's greatest priority — 1 the chain's own
 // (McSpp), 2 the tail's, 4 the front end's, 8 the blocking filters'.  The tail's stream first was +2.0 .. +3.7 % at one block per call in eleven
-// interleaved pairs on three boxes and -4 .. -7 % in the second half of a fourth session (the chain's rate is bistable, 8.3 - 8.7 against 9.3 - 9.6 M
-// frames/s, and the priority moves the odds, not the levels): not the default (profiles/r03f/chain_prio_ab.txt)
+// interleaved pairs on three boxes and -4 .. -7 % in the second half of a fourth session: inside the run-to-run spread of the chain itself (a run lands
+// on one of two levels, 8.3 - 8.7 or 9.3 - 9.6 M frames/s, with every kernel of the step scaled alike: the device's clock state,
+// profiles/r03f/cfg5_step_length.txt) — not the default (profiles/r03f/chain_prio_ab.txt)
 static hipError_t chain_stream(hipStream_t* s, int bit) {
     const char* pr = std::getenv("DS_CHAIN_PRIO");
     const int mask = pr ? std::atoi(pr) : 0;
