@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 from distantspeech_amd import BatchEngine, _lib as L
 dev = torch.device("cuda", 0)
 for algo, name in ((1, "mvdr"), (2, "gsc")):
-    for M, NFFT in ((4, 512), (6, 512), (8, 512), (4, 1024), (8, 1024)):
+    for M, NFFT in ((4, 256), (4, 512), (6, 512), (4, 1024), (6, 1024), (8, 1024)):
         HOP, B = NFFT // 2, 1024
         for T in (1, 40):
             K = 80 // T; Ltot = (K + 2) * T * HOP
