@@ -130,7 +130,8 @@ constexpr int frames_hoist(int nfft, int M, int algo, bool ryy) {
 #if defined(DS_NO_HOIST)
     return 0;
 #else
-    if (nfft <= 512 && M <= 4 && ((algo == ALGO_ADAPTIVE && !ryy) || algo == ALGO_FIXED)) return 2;
+    if (nfft <= 512 && M <= 5 && ((algo == ALGO_ADAPTIVE && !ryy) || algo == ALGO_FIXED)) return 2;      // 5 microphones: 134 -> 168 registers, still three waves
+                                                                                                          // per SIMD; +3 .. 11 % with 40 hops per call (r03f/m5_hoist_ab.txt)
     if (nfft <= 512 && M <= 4 && algo == ALGO_GSC) return DS_GSC_HOIST;
     return 0;
 #endif
