@@ -102,6 +102,34 @@ def test_adaptive_batch_vs_oracle(ds, M, nfft):
         assert rms(y[b] - ref) < 1e-5, (b, rms(y[b] - ref))
 
 
+@pytest.mark.parametrize("M,nfft", [(2, 512), (3, 512), (4, 256), (5, 256), (5, 512), (6, 512)])
+def test_mvdr_kernel_without_ryy_vs_oracle(ds, M, nfft):
+    """The adaptive MVDR frame kernel WITHOUT the Ryy recursion (track_ryy = 0: what bench.py runs; the Python adaptivebeamfomer keeps Ryy for
+    TFGSC) — the instantiations with hoisted addresses (M <= 5 at 256 / 512 points) and the ones without: rows of a batch against the
+    oracle, hop by hop == one call bit for bit (samples and exported state)."""
+    from distantspeech_amd import _lib as L
+    hop, B, T = nfft // 2, 4, 40
+    omic = oracle_mic(M, nfft, 0.05)
+    xs = np.stack([O.synth_utterance(300 + b, hop * T, omic) for b in range(B)])
+    a = steering(M, nfft, 0.05)
+
+    def run(chunked):
+        eng = ds.BatchEngine(L.ALGO_ADAPTIVE, M, nfft, batch=B)             # track_ryy defaults to 0 at this level
+        eng.set_steering(a); eng.set_method(L.METHOD_MVDR)
+        if chunked:
+            y = np.concatenate([eng.process(xs[:, :, t * hop:(t + 1) * hop], L.LAYOUT_CHANNELS_SAMPLES) for t in range(T)], axis=1)
+        else:
+            y = eng.process(xs, L.LAYOUT_CHANNELS_SAMPLES)
+        return y, eng.export_state()
+
+    y1, s1 = run(False)
+    yc, sc = run(True)
+    assert np.array_equal(y1, yc) and np.array_equal(s1, sc)
+    for b in (0, B - 1):
+        ref = O.OracleAdaptiveMVDR(omic, nfft, hop, nfft).process(xs[b], ANGLE, 2)
+        assert rms(y1[b] - ref) < 1e-5, (b, rms(y1[b] - ref))
+
+
 @pytest.mark.parametrize("M,nfft", [(4, 512), (3, 256), (5, 1024)])
 def test_gsc_batch_vs_oracle(ds, M, nfft):
     hop, B, T = nfft // 2, 4, 40
