@@ -17,9 +17,12 @@ every rank), so a short --steps still gives a region the driver's clock can see.
 wall time of the region; `ms_per_step` = that time / (R * K).  HIP events on the engine's stream give the per-launch duration
 the roofline uses.
 
-One JSON line on rank 0 (contract in the task statement) with `roofline` (+ `roofline_hbm`: the same kernel with the state
-working set outside the 256 MiB Infinity Cache), `cpu_baseline`, and `other_configs` (BASELINE cfg3 / cfg4 / cfg5 — one hop per call, and every config with 10 s of signal per call — through the
-same code path).  A --gpus / rank-count mismatch exits non-zero."""
+ONE JSON line of at most 4 KB on rank 0 (contract in the task statement): the contract keys, a numeric `roofline` (+ `roofline_hbm`: the
+same kernel with the state working set outside the 256 MiB Infinity Cache), `cpu_baseline`, and per other BASELINE config (cfg3 / cfg4 /
+cfg5 at one hop per call, every config with 10 s of signal per call, the wide-tap WPE) `{value, ms_per_step, bound, frac}`.  Everything
+else — accounting prose, per-config CPU legs, the latency block, sources of the profile-derived figures — goes to the side file the line
+names in `detail` (default bench_detail.json next to this script; DS_BENCH_DETAIL=<path> overrides).  A --gpus / rank-count mismatch exits
+non-zero."""
 import argparse
 import importlib
 import json
@@ -29,10 +32,6 @@ import socket
 import subprocess
 import sys
 import time
-
-# hardware queues per device for the HIP runtime (default 4): the chain handles run their stages on up to five streams and two streams that
-# share a queue serialise; must be in the environment before the first HIP call of the process (the child ranks inherit it)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -74,6 +73,14 @@ WORKLOADS = {
     "fdgsc": dict(algo="FDGSC", M=4, nfft=512, hop=256, batch=1024, S=39316, r=0.032, kernel="DS_ALGO_FDGSC chain", launches=14, graph=0,
                   desc="FDGSC chain (FDGSC.process: adaptive blocking filters + norm-limited canceller), 4 mics, 16 kHz, block 256"),
 }
+
+
+EXTRA_T1 = ("cfg3", "cfg4", "cfg5")                                                  # other_configs at one hop per call
+EXTRA_CHUNKED = (("cfg2", 625), ("cfg3", 625), ("cfg4", 312), ("cfg5", 625))         # ... and with 10 s per call
+DATA_NOTE = ("BASELINE.md section 3's recipe in both legs (white noise sigma 0.05 per microphone + a 0.5 s on / off 300-3400 Hz Gaussian source sigma "
+             "0.1 steered from 197 degrees, seed 1234 + utterance): the GPU leg draws it on the device with torch's generator (GpuBackend.synth), the "
+             "cpu_baseline legs with NumPy's (oracle.synth_utterance) — the same statistics, different random streams; neither leg's arithmetic per "
+             "frame depends on the sample values")
 
 
 def algorithmic_bytes_per_frame(w, T=1):
@@ -281,6 +288,18 @@ class GpuWorkload:
         """carried state of the handle as the library packs it (Hermitian / symmetric matrices as triangles), without the blob's header words"""
         return self.eng.state_bytes()
 
+    def chain_min_bytes(self):
+        """per-kernel byte budget of one step of a chain handle (cfg4 / cfg5), 0 for single-kernel workloads"""
+        key = {"WPE_MVDR": "cfg4", "SUBBAND_GSC": "cfg5"}.get(self.w["algo"])
+        if key is None or self.w is not WORKLOADS[key]:
+            return 0
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        try:
+            import stage_budget
+        finally:
+            sys.path.pop(0)
+        return stage_budget.minimal_step_bytes(key, self.w, self.eng, self.B)
+
     def run(self, first_step, n):
         L, T, hop, Ltot = self.L, self.T, self.hop, self.Ltot
         off = 4 * first_step * T * hop
@@ -316,8 +335,8 @@ def load_backend(local_rank, world):
 # ------------------------------------------------------------------------------------------------
 # the measurement of one workload: warm-up, probe, R rounds of exactly K steps in ONE bracketed region
 # ------------------------------------------------------------------------------------------------
-def measure(be, dsdist, w, B, T, K, W, rank, world, min_region_ms, graph=None, max_rounds=20000, split=None):
-    wl = be.make(w, B, T, K, W, seed=rank, graph=w["graph"] if graph is None else graph, split=split)
+def measure(be, dsdist, w, B, T, K, W, rank, world, min_region_ms, graph=None, max_rounds=20000, split=None, seed=None):
+    wl = be.make(w, B, T, K, W, seed=rank if seed is None else seed, graph=w["graph"] if graph is None else graph, split=split)
     wl.run(0, W)
     wl.run(W, K)                      # one more untimed round: builds the round's hipGraph where one is used
     wl.sync()
@@ -342,6 +361,7 @@ def measure(be, dsdist, w, B, T, K, W, rank, world, min_region_ms, graph=None, m
     elapsed = time.perf_counter() - t0
     wl.check(W)
     state_bytes = wl.state_bytes() if hasattr(wl, "state_bytes") else 0
+    chain_min = wl.chain_min_bytes() if hasattr(wl, "chain_min_bytes") else 0
     frames_rank = B * K * T * R
     frames, t_max, ranks = dsdist.reduce_throughput(frames_rank, elapsed, device=getattr(be, "device", None))
     dev_ms = dsdist.reduce_max(dev_ms, device=getattr(be, "device", None))
@@ -350,6 +370,11 @@ def measure(be, dsdist, w, B, T, K, W, rank, world, min_region_ms, graph=None, m
     # bytes one step moves at the least: the carried state as the library packs it, once in and once out, plus the step's samples in and out
     io = (w["M"] + 1) * w["hop"] * 4
     phys = 2.0 * state_bytes + float(B) * T * io
+    basis = "state"
+    if chain_min and T == 1:
+        # a chain of kernels: some allocated state is shared between filters (fan form) and the stages hand spectra to each other through
+        # HBM, so the step's bytes are the per-kernel budget (scripts/stage_budget.py: state touched once in and once out + stage arrays)
+        phys, basis = float(chain_min), "stage_budget"
     achieved = phys / (launch_ms * 1e-3) / 1e9                 # GB/s of one GPU
     alg = algorithmic_bytes_per_frame(w, T)                    # the state counted unpacked
     survey = alg * B * T / (launch_ms * 1e-3) / 1e9
@@ -358,74 +383,113 @@ def measure(be, dsdist, w, B, T, K, W, rank, world, min_region_ms, graph=None, m
         "region_ms": round(t_max * 1e3, 3), "ranks": ranks,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": w["kernel"],
-                     "launches_per_step": w["launches"], "launch_ms": round(launch_ms, 5), "bytes_per_launch": phys,
+                     "launches_per_step": w["launches"], "launch_ms": round(launch_ms, 5), "bytes_per_launch": phys, "bytes_basis": basis,
                      "state_bytes_per_gpu": state_bytes, "batch_per_gpu": B, "hops_per_call": T,
                      "achieved_survey_bytes": round(survey, 1), "frac_survey_bytes": round(survey / HBM_PEAK_GBS, 4),
-                     "algorithmic_bytes_per_frame": alg, "algorithmic_bytes_per_launch": alg * B * T,
-                     "accounting": "achieved / frac = the bytes a step must move (the carried state as the library packs it — Hermitian and symmetric "
-                                   "matrices as triangles — once in and once out, plus the step's samples in and out) over this run's launch "
-                                   "duration; frac_survey_bytes = SURVEY 8(d)'s figure, which counts the same state unpacked and is therefore "
-                                   "not a physical fraction; traffic / frac_measured = PMC bytes of the same command (committed profile)"},
+                     "algorithmic_bytes_per_frame": alg, "algorithmic_bytes_per_launch": alg * B * T},
     }
 
 
-def attach_traffic(roof, key):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (profiles/traffic_latest.json: FETCH_SIZE /
-    WRITE_SIZE with the guide's gfx950 corrections).  PMC counters cannot be read inside this process, so the figure is the profile's,
-    labelled with its source; `frac_measured` = that traffic / this run's launch duration / peak."""
+ACCOUNTING = {
+    "state": "achieved / frac = the bytes a step must move (the carried state as the library packs it — Hermitian and symmetric matrices as "
+             "triangles — once in and once out, plus the step's samples in and out) over THIS run's launch duration (HIP events on the kernel's stream)",
+    "stage_budget": "achieved / frac = the per-kernel byte budget of one step (scripts/stage_budget.py: every kernel's share of the chain's state "
+                    "once in and once out + the arrays its stage reads and writes; sizes from ds_chain_stage_info of this handle) over THIS run's "
+                    "step duration",
+    "frac_survey_bytes": "SURVEY 8(d)'s figure, which counts the same state unpacked (full complex covariance): a throughput figure in the contract's "
+                         "own unit, not a physical fraction (it can exceed 1)",
+    "frac_measured": "traffic = HBM bytes per step from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, "
+                     "separate runs: traffic_profile); frac_measured = that / this run's launch duration / peak.  Profile-derived: tied to the build "
+                     "by tests (state layout / stage budgets within 3 % of it)",
+    "frac_valu_issue": "10 s-per-call regime (state moves once per 625 / 312 hops: vector-issue bound, SURVEY 8d): share of each SIMD's cycles spent "
+                       "issuing the SQ_INSTS_VALU of the committed counter passes (valu_profile) at their kernels' instruction-mix cost "
+                       "(scripts/kernel_mix.py) at this run's frame rate, 2.4 GHz peak clock",
+}
+
+
+def _profile_json(name):
+    """a committed profile-derived table (profiles/<name>); a missing or malformed file is reported on stderr, never silently skipped"""
+    path = os.path.join(ROOT, "profiles", name)
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as fh:
-            t = json.load(fh)
-        ent = t.get(key)
-        if not ent:
-            return
-        roof["traffic"] = ent["hbm_bytes_per_launch"]
-        roof["traffic_source"] = ent.get("source", "profiles/traffic_latest.json")
-        gbs = ent["hbm_bytes_per_launch"] / (roof["launch_ms"] * 1e-3) / 1e9
-        roof["achieved_measured"] = round(gbs, 1)
-        roof["frac_measured"] = round(gbs / HBM_PEAK_GBS, 4)
-        if roof.get("launches_per_step", 1) > 2:
-            # chain handles: the allocated state of the stages is not what a step moves (the blocking filters' fan form keeps the shared
-            # tap buffer and RLS matrix once per utterance; the stages also hand spectra to each other through HBM), so the physical
-            # figure of a chain is the measured traffic, not a state-size formula
-            roof["achieved_state_bytes"], roof["frac_state_bytes"] = roof["achieved"], roof["frac"]
-            roof["achieved"], roof["frac"] = roof["achieved_measured"], roof["frac_measured"]
-            roof["accounting"] = ("achieved / frac = PMC bytes of the same command (FETCH_SIZE / WRITE_SIZE passes, committed profile: traffic_source) "
-                                  "over this run's step duration — a chain of kernels moves its stages' state AND the spectra they hand each other; "
-                                  "frac_survey_bytes = SURVEY 8(d)'s state-only figure (state counted unpacked: not a physical fraction); "
-                                  "frac_state_bytes = 2 x the stages' allocated state + samples (an upper bound of the state traffic: the fan "
-                                  "form of the blocking filters moves shared matrices once per utterance, not once per filter)")
-    except Exception:
-        pass
+        with open(path) as fh:
+            return json.load(fh)
+    except (OSError, ValueError) as e:
+        sys.stderr.write("bench.py: profiles/%s unusable (%s): profile-derived figures omitted\n" % (name, e))
+        return None
+
+
+def attach_traffic(roof, key):
+    """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (profiles/traffic_latest.json).  PMC counters cannot be
+    read inside this process, so the figure is the profile's, under its own keys (`traffic`, `frac_measured`, `traffic_profile`): the live
+    `achieved` / `frac` are never replaced by it."""
+    t = _profile_json("traffic_latest.json")
+    ent = (t or {}).get(key)
+    if not ent:
+        return
+    roof["traffic"] = round(ent["hbm_bytes_per_launch"])
+    roof["traffic_profile"] = ent.get("source", "profiles/traffic_latest.json").split(":")[0]
+    gbs = ent["hbm_bytes_per_launch"] / (roof["launch_ms"] * 1e-3) / 1e9
+    roof["frac_measured"] = round(gbs / HBM_PEAK_GBS, 4)
+    roof["traffic_over_bytes"] = round(ent["hbm_bytes_per_launch"] / roof["bytes_per_launch"], 4)
+    if abs(roof["traffic_over_bytes"] - 1.0) > 0.05 and not os.environ.get("DS_BENCH_BACKEND"):
+        sys.stderr.write("bench.py: %s: committed PMC traffic is %.3f x this build's byte budget — profiles/traffic_latest.json is stale for "
+                         "this build or the kernel moves bytes it should not\n" % (key, roof["traffic_over_bytes"]))
 
 
 def attach_compute(entry, key, frames_per_s_per_gpu):
-    """The 10 s-per-call regime moves the carried state once per 625 / 312 hops: it is bound by the vector pipes, not by HBM.
-    Its roofline is the share of every SIMD's cycles that ISSUING the measured vector instructions takes at the measured frame rate:
-    vector instructions per frame from the SQ counter passes of the same command (profiles/compute_latest.json, committed; PMC counters
-    cannot be read inside this process), each priced at its kernel's mix-weighted issue cost (scripts/kernel_mix.py; costs measured by
-    scratch/micro/valu_rate.hip), over the 2.4 GHz peak clock.  The HBM figure measure() computed stays in the entry as roofline_hbm_bytes."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "compute_latest.json")) as fh:
-            t = json.load(fh)
-        ent = t.get(key)
-        if not ent:
-            return
-        clk = t.get("clock_ghz_peak", 2.4) * 1e9
-        vc, lc = ent["valu_issue_cycles_per_frame"], ent["lds_cycles_per_frame"]
-        entry["roofline_hbm_bytes"] = entry["roofline"]
-        entry["roofline"] = {
-            "bound": "valu", "achieved": round(frames_per_s_per_gpu * vc / 1e9, 4), "peak": round(clk / 1e9, 3),
-            "unit": "G vector-issue cycles/s per SIMD", "frac": round(frames_per_s_per_gpu * vc / clk, 4),
-            "frac_lds": round(frames_per_s_per_gpu * lc / clk, 4), "valu_instructions_per_frame": round(ent["valu_instructions_per_frame"], 1),
-            "valu_issue_cycles_per_frame_per_simd": round(vc, 3), "lds_cycles_per_frame_per_cu": round(lc, 3),
-            "source": "profiles/compute_latest.json <- " + ent.get("profile", "?") + " (SQ_INSTS_VALU, SQ_LDS_IDX_ACTIVE of the same command; "
-                      "issue cost per instruction from the shipped kernels' instruction mix, scripts/kernel_mix.py)",
-            "note": "frac = share of each SIMD's cycles spent issuing vector instructions at this frame rate (peak clock 2.4 GHz; the chip "
-                    "holds 2.2-2.3 GHz in these kernels); frac_lds = the LDS pipes' busy share.  What keeps it from 1: a lone wave issues one "
-                    "vector instruction per 5.5-8 cycles, so a SIMD needs two or more of its four waves ready at once (profiles/r03b/bsweep.txt)"}
-    except Exception:
-        pass
+    """The 10 s-per-call regime is bound by the vector pipes, not by HBM: `valu` = the share of every SIMD's cycles that ISSUING
+    the measured vector instructions takes at this run's frame rate (profiles/compute_latest.json, committed SQ counter passes).  A separate
+    object beside the live HBM `roofline`, which stays as measured."""
+    t = _profile_json("compute_latest.json")
+    ent = (t or {}).get(key)
+    if not ent:
+        return
+    clk = t.get("clock_ghz_peak", 2.4) * 1e9
+    vc, lc = ent["valu_issue_cycles_per_frame"], ent["lds_cycles_per_frame"]
+    entry["valu"] = {"bound": "valu", "frac_valu_issue": round(frames_per_s_per_gpu * vc / clk, 4), "frac_lds": round(frames_per_s_per_gpu * lc / clk, 4),
+                     "peak_ghz": round(clk / 1e9, 3), "valu_instructions_per_frame": round(ent["valu_instructions_per_frame"], 1),
+                     "valu_issue_cycles_per_frame_per_simd": round(vc, 3), "lds_cycles_per_frame_per_cu": round(lc, 3),
+                     "valu_profile": ent.get("profile", "?")}
+
+
+def compact_roofline(r):
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "bytes_per_launch", "bytes_basis", "batch_per_gpu",
+            "frac_survey_bytes", "frac_measured", "traffic_profile", "value")
+    return {k: r[k] for k in keep if k in r}
+
+
+def compact_line(out, detail_path):
+    """the ONE line the driver parses: contract keys + numeric roofline objects + per other config {value, ms_per_step, bound, frac}"""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                "dtype", "data", "rounds", "timed_steps", "region_ms") if k in out}
+    line["config"] = out["config"]
+    line["roofline"] = compact_roofline(out["roofline"])
+    if "valu" in out:
+        line["valu"] = {k: out["valu"][k] for k in ("bound", "frac_valu_issue", "frac_lds", "valu_profile")}
+    if "roofline_hbm" in out:
+        line["roofline_hbm"] = compact_roofline(out["roofline_hbm"])
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = {k: out["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample", "per_core") if k in out["cpu_baseline"]}
+    oc = {}
+    for name, e in out.get("other_configs", {}).items():
+        c = {"value": e["value"], "ms_per_step": e["ms_per_step"]}
+        if "valu" in e:
+            c.update(bound="valu", frac=e["valu"]["frac_valu_issue"], frac_hbm=e["roofline"]["frac"])
+        else:
+            c.update(bound="hbm", frac=e["roofline"]["frac"])
+            if "frac_measured" in e["roofline"]:
+                c["frac_measured"] = e["roofline"]["frac_measured"]
+        if "cpu_baseline" in e:
+            c["cpu"] = e["cpu_baseline"]["value"]
+        oc[name] = c
+    if oc:
+        line["other_configs"] = oc
+    if "latency" in out:
+        la = out["latency"]
+        line["latency_us"] = {"chunk_ms_budget": la["chunk_ms_budget"], "pcm16_host_median": la["pcm16_host"]["median_us"], "pcm16_host_p99": la["pcm16_host"]["p99_us"],
+                              "device_median": la["device"]["median_us"]}
+    line["detail"] = detail_path
+    return line
 
 
 # ------------------------------------------------------------------------------------------------
@@ -527,6 +591,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=25)
     ap.add_argument("--config", default="cfg2", choices=sorted(WORKLOADS), help="BASELINE config measured as the headline (default cfg2)")
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the config's BASELINE batch)")
+    ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: this many utterances in all, sharded contiguously over the ranks "
+                                                               "(dist.shard_range), e.g. cfg4's 8192 over 8 GPUs; default 0 = weak scaling")
     ap.add_argument("--hops-per-step", type=int, default=1, help="T: hops per call (1 = streaming callback regime)")
     ap.add_argument("--graph", type=int, default=-1, help="1 = replay a round as one hipGraph, 0 = plain launches (default: per config)")
     ap.add_argument("--min-region-ms", type=float, default=250.0, help="rounds of --steps are repeated until the timed region is this long")
@@ -538,6 +604,11 @@ def main():
         raise SystemExit("--gpus and --steps must be >= 1, --warmup >= 0")
 
     profiled = under_profiler()
+    if not profiled:
+        # this PROCESS is the application: hardware queues per device for the HIP runtime (default 4) — the chain handles run their stages on
+        # up to five streams and two streams that share a queue serialise.  Must be in the environment before the first HIP call (the child
+        # ranks inherit it); under a profiler the runtime is already up and the variable is left alone (DS_PARAM_TAIL_ASYNC follows it)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if profiled:
             sys.stderr.write("bench.py: --gpus %d under a GPU profiler refused: the profiled process has initialised the GPU and must not start "
@@ -561,9 +632,15 @@ def main():
 
     w = WORKLOADS[args.config]
     B = args.batch or w["batch"]
+    seed = None
+    if args.total_batch:
+        lo, hi = dsdist.shard_range(args.total_batch, rank, world)     # utterances [lo, hi) of the job live on this rank's GPU
+        B, seed = hi - lo, lo
+        if B < 1:
+            raise SystemExit("--total-batch %d leaves rank %d without an utterance" % (args.total_batch, rank))
     K, W, T = args.steps, args.warmup, args.hops_per_step
     graph = None if args.graph < 0 else args.graph
-    res = measure(be, dsdist, w, B, T, K, W, rank, world, args.min_region_ms, graph=graph)
+    res = measure(be, dsdist, w, B, T, K, W, rank, world, args.min_region_ms, graph=graph, seed=seed)
     if res["ranks"] != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but %d rank(s) contributed to the result\n" % (args.gpus, res["ranks"]))
         sys.exit(2)
@@ -575,33 +652,29 @@ def main():
         out = {
             "metric": "enhanced frames/sec (%s)" % mics, "value": res["value"], "unit": "frames/s",
             "n_gpus": res["ranks"], "steps": K, "warmup": W, "ms_per_step": res["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": be.name,
+            "higher_is_better": True, "scaling": "weak" if not args.total_batch else "strong", "vs_baseline": None, "dtype": "f32", "data": be.name,
             "rounds": res["rounds"], "timed_steps": res["timed_steps"], "region_ms": res["region_ms"],
-            "data_note": "BASELINE.md section 3's recipe in both legs (white noise sigma 0.05 per microphone + a 0.5 s on / off 300-3400 Hz Gaussian source sigma "
-                         "0.1 steered from 197 degrees, seed 1234 + utterance): the GPU leg draws it on the device with torch's generator "
-                         "(GpuBackend.synth), the cpu_baseline legs with NumPy's (oracle.synth_utterance) — the same statistics, different random "
-                         "streams; neither leg's arithmetic per frame depends on the sample values",
-            "config": {"workload": "%s: %s, batch=%d utterances per GPU, %d hop(s) per call (%s), state resident in HBM"
+            "config": {"workload": "%s: %s, batch=%d per GPU, %d hop(s) per call (%s)"
                                    % (("BASELINE " + args.config) if args.config.startswith("cfg") else args.config, w["desc"], B, T, regime),
                        "batch_per_gpu": B, "hops_per_call": T, "n_mics": w["M"], "nfft": w["nfft"], "hop": w["hop"],
-                       "launch": "hipGraph replay of each round" if (w["graph"] if graph is None else graph) else "plain launches"},
+                       "launch": "hipGraph" if (w["graph"] if graph is None else graph) else "plain",
+                       "timed_hops": "each round replays resident hops %d..%d of every utterance (inside the recipe's first 0.5 s source-on "
+                                     "segment when < 31); state keeps evolving" % (W * T, (W + K) * T - 1)},
             "roofline": res["roofline"],
         }
+        if args.total_batch:
+            out["config"]["total_batch"] = args.total_batch
         if getattr(be, "shared_device", False):
             out["config"]["note"] = "all %d ranks share GPU %d (DS_FORCE_DEVICE, gloo): rank-path check, not a scaling measurement" % (world, be.local_rank)
         if T == 1 and B == w["batch"]:
             attach_traffic(out["roofline"], args.config)
-            if args.config == "cfg2":
-                out["roofline"]["note"] = ("at 1024 utterances the launch is ONE resident round of 1024 workgroups (4 per CU) walking their phases in "
-                                           "step over a state that stays in the 256 MiB Infinity Cache: the duration is the dependent chain of one "
-                                           "workgroup (3.1 us alone on a CU, profiles/r03b/bsweep.txt) as much as a bandwidth figure; roofline_hbm "
-                                           "(same kernel, 16 384 utterances) is the HBM measurement")
         if T > 1:
             attach_compute(out, "%s_10s_chunks" % args.config if T >= 300 else "none", out["value"] / max(1, res["ranks"]))
 
+    detail = {}
     if not args.no_extras:
         # (1) the same kernel with the state working set outside the Infinity Cache: an HBM measurement of the HBM claim
-        if args.config in ("cfg2", "cfg3", "fixed") and T == 1 and args.hbm_batch > B:
+        if args.config in ("cfg2", "cfg3", "fixed") and T == 1 and args.hbm_batch > B and not args.total_batch:
             Kh, Wh = min(K, 40), min(W, 5)
             # one launch per step (split = 1), so that the launch duration is the kernel's: the library's default at this batch is two
             # utterance groups on two streams (+3 % here)
@@ -615,27 +688,26 @@ def main():
                 out["roofline_hbm"] = roof
         # (2) the other BASELINE configs through the same path (same sharding, same bracketing)
         others = {}
-        for name in ("cfg3", "cfg4", "cfg5"):
-            if name == args.config or T != 1:
+        for name in EXTRA_T1:
+            if name == args.config or T != 1 or args.total_batch:
                 continue
             wo = WORKLOADS[name]
             Ko, Wo = min(K, 40), min(W, 4)
             ro = measure(be, dsdist, wo, wo["batch"], 1, Ko, max(Wo, 2), rank, world, min(args.min_region_ms, 120.0))
             if rank == 0:
                 attach_traffic(ro["roofline"], name)
-                others[name] = {"workload": "BASELINE %s: %s, batch=%d per GPU, 1 hop per call" % (name, wo["desc"], wo["batch"]),
+                others[name] = {"workload": "%s: %s, batch=%d per GPU, 1 hop per call" % (name, wo["desc"], wo["batch"]),
                                 "value": ro["value"], "unit": "frames/s", "n_gpus": ro["ranks"], "steps": Ko, "rounds": ro["rounds"],
                                 "ms_per_step": ro["ms_per_step"], "roofline": ro["roofline"]}
         # (3) the BASELINE configs as SURVEY 8(d) words their inputs: 10 s per utterance in ONE call (625 hops at hop 256, 312 at hop 512;
         # cfg5's "10 s streaming chunks").  The carried state then moves once per chunk and the step is bound by the per-hop arithmetic /
         # LDS work of the kernels — the HBM fraction is reported for completeness, not as the limiter
-        if args.config == "cfg2" and T == 1:
-            for name, Tc in (("cfg2", 625), ("cfg3", 625), ("cfg4", 312), ("cfg5", 625)):
+        if args.config == "cfg2" and T == 1 and not args.total_batch:
+            for name, Tc in EXTRA_CHUNKED:
                 wo = WORKLOADS[name]
                 ro = measure(be, dsdist, wo, wo["batch"], Tc, 2, 1, rank, world, min(args.min_region_ms, 120.0))
                 if rank == 0:
-                    ro["roofline"]["note"] = ("the carried state moves once per %d hops: HBM is not the limiter of this regime (see roofline)" % Tc)
-                    ent = {"workload": "BASELINE %s: %s, batch=%d per GPU, 10 s per call (%d hops)" % (name, wo["desc"], wo["batch"], Tc),
+                    ent = {"workload": "%s: %s, batch=%d per GPU, 10 s per call (%d hops)" % (name, wo["desc"], wo["batch"], Tc),
                            "value": ro["value"], "unit": "frames/s", "n_gpus": ro["ranks"], "steps": 2, "rounds": ro["rounds"],
                            "ms_per_step": ro["ms_per_step"], "hops_per_call": Tc, "roofline": ro["roofline"]}
                     attach_compute(ent, name + "_10s_chunks", ro["value"] / max(1, ro["ranks"]))
@@ -653,7 +725,20 @@ def main():
             for name in out.get("other_configs", {}):
                 if name in cpu_pre:
                     out["other_configs"][name]["cpu_baseline"] = cpu_pre[name]
-        print(json.dumps(out), flush=True)
+        # the side file: everything, with the prose; the line: numbers only (the driver keeps an 8 KB tail of stdout)
+        detail_path = os.environ.get("DS_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+        out["accounting"] = ACCOUNTING
+        out["data_note"] = DATA_NOTE
+        try:
+            with open(detail_path, "w") as fh:
+                json.dump(out, fh, indent=1)
+            shown = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path
+        except OSError as e:
+            sys.stderr.write("bench.py: could not write %s (%s)\n" % (detail_path, e))
+            shown = None
+        line = json.dumps(compact_line(out, shown), separators=(",", ":"))
+        assert len(line) <= 4096, "bench line is %d bytes (> 4 KB): the driver's tail would cut it" % len(line)
+        print(line, flush=True)
     dsdist.finalize()
 
 

@@ -21,20 +21,12 @@ def planes(nf):
     return (nf + 3) // 4
 
 
-def main():
-    cfg, traffic_path = sys.argv[1], sys.argv[2]
-    w = bench.WORKLOADS[cfg]
-    B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else w["batch"]
-    from distantspeech_amd import BatchEngine, _lib as L
-    eng = BatchEngine(getattr(L, "ALGO_" + w["algo"]), w["M"], w["nfft"], w["hop"], batch=B, filter_len=w.get("filter_len", 0),
-                      rls_lambda=w.get("rls_lambda", 0.0))
-    stages = {i: dict(algo=a, mics=m, batch=b, bytes=n) for i, a, m, b, n in eng.chain_stages()}
-    total_state = eng.state_bytes()
-    parts = int(os.environ.get("DS_CHAIN_PARTS", "2" if (cfg == "cfg4" and B >= 512) else "1"))
-    eng.close()
+def budget_rows(cfg, w, stages, B):
+    """(kernel substring, stage label, what it touches, state bytes per utterance one way, in bytes, out bytes) per kernel of one step of the
+    chain `cfg` (bench.WORKLOADS key), from the stage table the library reports (BatchEngine.chain_stages())."""
     M, K, hop, N = w["M"], w["nfft"] // 2 + 1, w["hop"], w.get("filter_len", 2)
     P16 = K * 16                       # one float4 plane of one utterance as the K lanes move it
-    rows = []                          # (kernel substring, stage label, what it touches, state bytes per utterance (one way), in bytes, out bytes)
+    rows = []
     if cfg == "cfg5":
         # taps of the alignment FIR bank the bench hands the chain (bench.py GpuWorkload: fractional_delay_filter_bank of the look direction)
         import numpy as np
@@ -73,6 +65,29 @@ def main():
             ("ds_binop_kernel<11", "adaptive MVDR + SPP gain on frames (stage 3)", "the whole covariance / MCRA state", mvdr_state * K // ((K + 3) & ~3), K * M * 8 + K * 4 + K * 4, K * 8),
             ("ds_istft_rows_kernel", "synthesis (stage 4)", "synthesis overlap, one channel", hop * 4, K * 8, hop * 4),
         ]
+    return rows
+
+
+def minimal_step_bytes(cfg, w, eng, B):
+    """bytes ONE step (one block of every utterance) of the chain must move: every kernel's share of the state once in and once out + the
+    arrays its stage reads and writes (bench.py quotes it as the chains' live `roofline.achieved`)."""
+    stages = {i: dict(algo=a, mics=m, batch=b, bytes=n) for i, a, m, b, n in eng.chain_stages()}
+    return float(sum(B * (2 * st + bi + bo) for _, _, _, st, bi, bo in budget_rows(cfg, w, stages, B)))
+
+
+def main():
+    cfg, traffic_path = sys.argv[1], sys.argv[2]
+    w = bench.WORKLOADS[cfg]
+    B = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else w["batch"]
+    from distantspeech_amd import BatchEngine, _lib as L
+    eng = BatchEngine(getattr(L, "ALGO_" + w["algo"]), w["M"], w["nfft"], w["hop"], batch=B, filter_len=w.get("filter_len", 0),
+                      rls_lambda=w.get("rls_lambda", 0.0))
+    stages = {i: dict(algo=a, mics=m, batch=b, bytes=n) for i, a, m, b, n in eng.chain_stages()}
+    total_state = eng.state_bytes()
+    parts = int(os.environ.get("DS_CHAIN_PARTS", "2" if (cfg == "cfg4" and B >= 512) else "1"))
+    eng.close()
+    M, K, hop, N = w["M"], w["nfft"] // 2 + 1, w["hop"], w.get("filter_len", 2)
+    rows = budget_rows(cfg, w, stages, B)
     tr = json.load(open(traffic_path))
     print("# %s at one block per call: bytes per launch, minimal against measured" % cfg)
     print()
