@@ -64,6 +64,17 @@ WORKLOADS = {
     "cfg5": dict(algo="SUBBAND_GSC", M=6, nfft=512, hop=256, batch=2048, S=313440, r=0.05, filter_len=2, rls_lambda=0.998,
                  kernel="DS_ALGO_SUBBAND_GSC chain", launches=7, graph=0,     # plain launches: hipGraph replay serialises the chain's streams
                  desc="Subband-RLS GSC chain (SubbandGSC.process with SubbandRLS blocking filters), 6 mics, 16 kHz, 512 bands / block 256"),
+    # the reference's maintained use of Wpe (example/wpe.ipynb cell 2): Wpe(channels=4, filter_len=20, delay=4, num_bands=256, hop_length=64),
+    # ONE call per hop (DS_ALGO_WPE_TD: analysis -> delay line -> RLS-WPE, one wavefront per (utterance, bin) -> synthesis of channel 0).
+    # S = K (CN (CN + 1) / 2 + C CN + CN) 8 B (P as its Hermitian triangle, W, taps) = 129 * 3640 * 8 + the delay line 4 * 129 * 4 * 8 + tails
+    "wpe_nb": dict(algo="WPE_TD", M=4, nfft=256, hop=64, batch=1024, S=129 * 3640 * 8 + 4 * 129 * 4 * 8 + 4 * 192 * 4 + 192 * 4, r=0.032, filter_len=20,
+                   rls_lambda=0.998, kernel="ds_wpe_wide_kernel<80,2,4,20> (+ analysis, synthesis)", launches=3, graph=1,
+                   desc="Wpe.update at the notebook's operating point (4 channels x 20 taps, delay 4, 256 bands / hop 64), dereverberated channel 0"),
+    # SURVEY 8(d)'s 10-tap sizing of BASELINE config 4: the cfg4 chain with 8 x 10 = 80 taps-by-channels (S per the survey's formula with the
+    # covariance unpacked: 513 (80^2 + 8 * 80 + 80) 8 B = 29.2 MB + the cfg4 rest); 256 utterances per GPU = 4.3 GB of state
+    "cfg4_n10": dict(algo="WPE_MVDR", M=8, nfft=1024, hop=512, batch=256, S=513 * (6400 + 640 + 80) * 8 + 18432 + 262656 * 2 + 10260, r=0.05, filter_len=10,
+                     kernel="DS_ALGO_WPE_MVDR chain, ds_wpe_wide_kernel<80,2,8,10>", launches=5, graph=1,
+                     desc="WPE dereverberation (10 taps) + adaptive MVDR + SPP gain chain, 8 mics, 16 kHz, 1024-FFT/512-hop"),
     # the two overlap-save GSCs as chain handles, 4 mics, block 256; not BASELINE configs (--config tdgsc / fdgsc).
     # S (fp32): TDGSC = canceller W 3*257*8 + P 257*4 + previous input block 3*256*4 + non-causal delay 128*4, MCRA 5*257*4, analysis tail
     # 1024, FIR history 83*4*4, notch 32 = 18 304; FDGSC = 4 blocking filters (257*8 + 257*4 + 1024) + canceller (4*257*8 + 257*4 + 4096),
@@ -75,8 +86,8 @@ WORKLOADS = {
 }
 
 
-EXTRA_T1 = ("cfg3", "cfg4", "cfg5")                                                  # other_configs at one hop per call
-EXTRA_CHUNKED = (("cfg2", 625), ("cfg3", 625), ("cfg4", 312), ("cfg5", 625))         # ... and with 10 s per call
+EXTRA_T1 = ("cfg3", "cfg4", "cfg5", "wpe_nb")                                                  # other_configs at one hop per call
+EXTRA_CHUNKED = (("cfg2", 625), ("cfg3", 625), ("cfg4", 312), ("cfg5", 625), ("wpe_nb", 2500))         # ... and with 10 s per call
 DATA_NOTE = ("BASELINE.md section 3's recipe in both legs (white noise sigma 0.05 per microphone + a 0.5 s on / off 300-3400 Hz Gaussian source sigma "
              "0.1 steered from 197 degrees, seed 1234 + utterance): the GPU leg draws it on the device with torch's generator (GpuBackend.synth), the "
              "cpu_baseline legs with NumPy's (oracle.synth_utterance) — the same statistics, different random streams; neither leg's arithmetic per "
@@ -269,7 +280,9 @@ class GpuWorkload:
             self.eng.set_split(split)         # utterance groups of the fused frame kernels (default: 2 from 2048 utterances up)
         mic = MicArray(arrayType="circular", r=w["r"], M=M, n_fft=nfft)
         ang = np.array(ANGLE_DEG) / 180.0 * np.pi
-        if w["algo"] in ("SUBBAND_GSC", "TDGSC", "FDGSC"):
+        if w["algo"] == "WPE_TD":
+            self.eng.set_wpe_delay(4)                                                       # awpe.py:36 / wpe.ipynb cell 2: delay=4
+        elif w["algo"] in ("SUBBAND_GSC", "TDGSC", "FDGSC"):
             from distantspeech_amd.ops import McSpp
             from distantspeech_amd.subband_gsc import fractional_delay_filter_bank
             tau = compute_tau(mic, ang)
@@ -647,7 +660,7 @@ def main():
     out = None
     if rank == 0:
         regime = "streaming callback regime" if T == 1 else "chunked"
-        mics = {"cfg2": "4-mic, 512-FFT", "cfg3": "4-mic, 512-FFT", "fixed": "4-mic, 512-FFT", "cfg4": "8-mic, 1024-FFT", "cfg5": "6-mic, 512 bands",
+        mics = {"cfg2": "4-mic, 512-FFT", "cfg3": "4-mic, 512-FFT", "fixed": "4-mic, 512-FFT", "cfg4": "8-mic, 1024-FFT", "cfg5": "6-mic, 512 bands", "wpe_nb": "4-ch WPE, 256 bands", "cfg4_n10": "8-mic, 1024-FFT, 10-tap WPE",
                 "tdgsc": "4-mic, block 256", "fdgsc": "4-mic, block 256"}[args.config]
         out = {
             "metric": "enhanced frames/sec (%s)" % mics, "value": res["value"], "unit": "frames/s",

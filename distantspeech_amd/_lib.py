@@ -33,6 +33,7 @@ ALGO_WPE_MVDR = 18
 ALGO_SUBBAND_GSC = 19
 ALGO_TDGSC = 20
 ALGO_FDGSC = 21
+ALGO_WPE_TD = 22
 PARAM_POSTFILTER = 15
 PARAM_FDAF_TWO_PATH = 16
 CHAIN_AUX_FIR, CHAIN_AUX_COHERENCE = 0, 1
@@ -78,7 +79,7 @@ EXPORTS = [
     "ds_mvdr_weight", "ds_pmwf_weight", "ds_gev_vector", "ds_blind_analytic_normalization", "ds_phase_correction", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process", "ds_tdgsc_process", "ds_fdgsc_process",
     "ds_omlsa_estimate", "ds_omlsa_postfilter",
     "ds_sublms_update", "ds_subrls_update", "ds_wpe_update", "ds_synchronize",
-    "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_state_payload_bytes", "ds_chain_stage_info", "ds_export_state",
+    "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_state_payload_bytes", "ds_chain_stage_info", "ds_chain_stage_field_bytes", "ds_chain_stage_state", "ds_export_state",
     "ds_import_state",
 ]
 
@@ -194,6 +195,10 @@ def load():
     lib.ds_state_bytes.argtypes = [vp]
     lib.ds_state_payload_bytes.restype = csz
     lib.ds_state_payload_bytes.argtypes = [vp]
+    lib.ds_chain_stage_field_bytes.restype = csz
+    lib.ds_chain_stage_field_bytes.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.ds_chain_stage_state.restype = ctypes.c_int
+    lib.ds_chain_stage_state.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, csz]
     lib.ds_chain_stage_info.restype = ctypes.c_int
     lib.ds_chain_stage_info.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(csz)]
     lib.ds_export_state.restype = ci

@@ -62,7 +62,12 @@ int zero_state(ds_handle* h) {
         for (int i = 0; i < 2; ++i)
             if (h->td_cache[i]) DS_HIP(h, hipMemsetAsync(h->td_cache[i], 0, (size_t)h->cfg.batch * (h->td_L > 1 ? h->td_L - 1 : 1) * h->cfg.n_mics * sizeof(float), h->stream));
     }
-    if (h->op >= 0 && h->NF > 0) {
+    if (h->op == ds::OP_WPE && h->NF > 0) {
+        // awpe.py:58-77: P = I * 1e-3, everything else zero — on the device (the state of a wide filter is gigabytes: 3.8 MB per utterance
+        // at 4 channels x 20 taps, 129 bins)
+        DS_HIP(h, ds::launch_wpe_init(h->opst, h->cfg.batch, h->K, (long long)op_ust(h), h->cfg.n_mics, h->filter_len, h->stream));
+        h->op_frm = 0; h->op_ell = 1; h->op_first = 1;
+    } else if (h->op >= 0 && h->NF > 0) {
         // operator state: zeros, except the rows the reference initialises to non-zero values
         std::vector<float> st((size_t)h->cfg.batch * op_ust(h), 0.0f);
         auto fill_row = [&](int f, float v) {                // row f of every bin (float4 planes: ds_ops.hpp st_index)
@@ -73,13 +78,6 @@ int zero_state(ds_handle* h) {
             const int o_s = 5 * h->cfg.n_mics + 1 + (h->cfg.n_mics - 1);
             fill_row(o_s + 1, 1.0f); fill_row(o_s + 2, 1.0f); fill_row(o_s + 3, 1.0f); fill_row(o_s + 5, 1.0f); fill_row(o_s + 6, 1.0f);
             fill_row(5 * h->cfg.n_mics, 1.0f);             // zeta_Y = 1
-        }
-        if (h->op == ds::OP_WPE) {                         // awpe.py:69-73: P = I * 1e-3 (bin blocks of ds_wpe.hpp)
-            const int C = h->cfg.n_mics, N = h->filter_len, CN = C * N, SB = ds::wpe_bin_floats(C, N);
-            for (int b = 0; b < h->cfg.batch; ++b)
-                for (int k = 0; k < h->K; ++k)
-                    for (int i = 0; i < CN; ++i)
-                        st[(size_t)b * op_ust(h) + (size_t)k * SB + 2 * (i * (i + 1) / 2 + i)] = 1e-3f;   // diagonal of the packed upper triangle
         }
         if (h->op == ds::OP_SUBRLS) {                      // SubbandRLS.py:40-42: P = I / 1e-3
             const int N = h->filter_len;
@@ -97,7 +95,7 @@ int zero_state(ds_handle* h) {
 // host mirror of the uniform counters (and the aux word: FIR parity / WPE ring position) -> the device copy the kernels read
 int sync_dev_cnt(ds_handle* h) {
     if (!h->dev_cnt) return DS_OK;
-    const int aux = h->cfg.algo == DS_ALGO_FRONTEND ? h->td_cur : h->cfg.algo == DS_ALGO_WPE_MVDR ? h->hist_cur : 0;
+    const int aux = h->cfg.algo == DS_ALGO_FRONTEND ? h->td_cur : wpe_chain(h) ? h->hist_cur : 0;
     int c[8 * DS_GROUPS];                                          // one copy per utterance group of a chain (groups run at their own pace)
     for (int g = 0; g < DS_GROUPS; ++g) { int* q = c + 8 * g; q[0] = h->op_frm; q[1] = h->op_ell; q[2] = h->op_first; q[3] = aux; q[4] = q[5] = q[6] = q[7] = 0; }
     DS_HIP(h, hipMemcpyAsync(h->dev_cnt, c, sizeof c, hipMemcpyHostToDevice, h->stream));
@@ -303,7 +301,11 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
                 (cfg->nfft == 128 || cfg->nfft == 256 || cfg->nfft == 512 || cfg->nfft == 1024)) { op = 106; NF = 0; }
             break;
         case DS_ALGO_WPE_MVDR:
-            if (ds::op_supported(ds::OP_ADAPTIVE, cfg->n_mics) && cfg->hop * 2 == cfg->nfft && cfg->n_mics * flen <= ds::WPE_CNMAX) { op = 104; NF = 0; }
+            if (ds::op_supported(ds::OP_ADAPTIVE, cfg->n_mics) && cfg->hop * 2 == cfg->nfft && cfg->n_mics * flen <= ds::WPEW_CNMAX) { op = 104; NF = 0; }
+            break;
+        case DS_ALGO_WPE_TD:
+            if (cfg->n_mics >= 1 && cfg->n_mics <= ds::WPE_CMAX && cfg->n_mics * flen <= ds::WPEW_CNMAX &&
+                (cfg->hop * 2 == cfg->nfft || cfg->hop * 4 == cfg->nfft)) { op = 107; NF = 0; }
             break;
         case DS_ALGO_FDAF:
             if ((cfg->nfft == 128 || cfg->nfft == 256 || cfg->nfft == 512 || cfg->nfft == 1024) && cfg->n_mics >= 1 && cfg->n_mics <= 8) {
@@ -324,7 +326,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             if (flen <= ds::RLS_NMAX) { op = ds::OP_SUBRLS; NF = ds::subrls_nf(flen); }
             break;
         case DS_ALGO_WPE:
-            if (cfg->n_mics >= 1 && cfg->n_mics <= ds::WPE_CMAX && cfg->n_mics * flen <= ds::WPE_CNMAX) {
+            if (cfg->n_mics >= 1 && cfg->n_mics <= ds::WPE_CMAX && cfg->n_mics * flen <= ds::WPEW_CNMAX) {
                 op = ds::OP_WPE;
                 NF = (int)(((long long)(cfg->nfft / 2 + 1) * ds::wpe_bin_floats(cfg->n_mics, flen) + KPo - 1) / KPo);   // [B][K][bin block]
             }
@@ -386,6 +388,9 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     for (int i = 0; i < 24; ++i) { h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0; }
     h->postfilter = 0;
     h->owns_stream = true; h->wpe_delay = 4; h->hist_cur = 0; h->group_enqueue = false;
+    h->wpe_only = cfg->algo == DS_ALGO_WPE_TD;
+    { const char* e = getenv("DS_WPE_GENERIC"); h->wpe_generic = (e && e[0] == '1') ? 1 : 0; }
+    { const char* e = getenv("DS_WPE_WIDE_NCH"); if (e && e[0] == '1') h->wpe_generic |= 2; }
     h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
@@ -448,14 +453,15 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
 #undef DS_CRE
     int rc = zero_state(h);
     if (rc != DS_OK) { std::string m = h->err; ds_destroy(h); return fail(nullptr, rc, m); }
-    if (cfg->algo == DS_ALGO_WPE_MVDR) {
+    if (cfg->algo == DS_ALGO_WPE_MVDR || cfg->algo == DS_ALGO_WPE_TD) {
         const int algos[5] = {DS_ALGO_TRANSFORM, DS_ALGO_WPE, DS_ALGO_MCMCRA, DS_ALGO_ADAPTIVE_FRAMES, DS_ALGO_TRANSFORM};
         for (int i = 0; i < 5; ++i) {
+            if (h->wpe_only && (i == 2 || i == 3)) continue;            // Wpe.update alone: no speech-presence / beamformer stages
             ds_config c = *cfg;
             c.algo = algos[i]; c.device = h->device;
             if (i == 4) c.n_mics = 1;
             rc = ds_create(&c, &h->sub[i]);
-            if (rc != DS_OK) { std::string m = g_err; ds_destroy(h); return fail(nullptr, rc, "ds_create(DS_ALGO_WPE_MVDR): stage " + std::to_string(i) + ": " + m); }
+            if (rc != DS_OK) { std::string m = g_err; ds_destroy(h); return fail(nullptr, rc, "ds_create(WPE chain): stage " + std::to_string(i) + ": " + m); }
             (void)hipStreamDestroy(h->sub[i]->stream);          // every stage runs on the chain's stream
             h->sub[i]->stream = h->stream; h->sub[i]->owns_stream = false;
             h->sub[i]->use_dev_cnt = true;                      // uniform counters read from the device: the chain replays as a hipGraph
@@ -587,7 +593,7 @@ int ds_reset(ds_handle* h) {
     if (rc) return rc;
     for (int i = 0; i < 10; ++i)
         if (h->sub[i]) { rc = ds_reset(h->sub[i]); if (rc) return fail(h, rc, h->sub[i]->err); }
-    if (h->cfg.algo == DS_ALGO_WPE_MVDR && h->chain_buf[6]) DS_HIP(h, hipMemsetAsync(h->chain_buf[6], 0, h->chain_bytes[6], h->stream));
+    if (wpe_chain(h) && h->chain_buf[6]) DS_HIP(h, hipMemsetAsync(h->chain_buf[6], 0, h->chain_bytes[6], h->stream));
     if (h->cfg.algo == DS_ALGO_SUBBAND_GSC)
         for (int i = G_FPREV; i <= G_FIXPREV; ++i)
             if (h->chain_buf[i]) DS_HIP(h, hipMemsetAsync(h->chain_buf[i], 0, h->chain_bytes[i], h->stream));
@@ -627,7 +633,7 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
     }
     switch (id) {
         case DS_PARAM_WPE_DELAY:
-            if (h->cfg.algo != DS_ALGO_WPE_MVDR || value < 0 || value > 64) return fail(h, DS_EINVAL, "wpe delay: chain handles only, 0..64 frames");
+            if (!wpe_chain(h) || value < 0 || value > 64) return fail(h, DS_EINVAL, "wpe delay: chain handles only, 0..64 frames");
             if (h->chain_buf[6]) return fail(h, DS_ESTATE, "wpe delay must be set before the first call");
             h->wpe_delay = value;
             return DS_OK;
@@ -659,7 +665,7 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
             return DS_OK;
         case DS_PARAM_SPLIT:
             if (value < 1 || value > 8) return fail(h, DS_EINVAL, "split must be 1..8");
-            if (h->cfg.algo == DS_ALGO_WPE_MVDR) {
+            if (wpe_chain(h)) {
                 // the groups' copies of the device counters start again from the host mirrors (copies of groups that did not run are stale)
                 int rc = set_device(h); if (rc) return rc;
                 DS_HIP(h, hipStreamSynchronize(h->stream));
@@ -727,10 +733,10 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
         return fdgsc_run(h, x_dev, x_batch_stride, cs, n_samples, h->postfilter, 1, y_dev, y_batch_stride, nullptr, nullptr, nullptr, nullptr, nullptr,
                          nullptr, nullptr, nullptr);
     }
-    if (h->cfg.algo == DS_ALGO_WPE_MVDR) {
+    if (wpe_chain(h)) {
         if (first != 0 || count != h->cfg.batch) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle processes its whole batch");
         if (stream && (hipStream_t)stream != h->stream) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle runs on its own stream (pass NULL)");
-        if (!h->steer_set) return fail(h, DS_ESTATE, "ds_process_device: call ds_set_steering first");
+        if (!h->steer_set && !h->wpe_only) return fail(h, DS_ESTATE, "ds_process_device: call ds_set_steering first");
         if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_process_device: n_samples must be a multiple of hop");
         if (layout != DS_LAYOUT_SAMPLES_CHANNELS && layout != DS_LAYOUT_CHANNELS_SAMPLES) return fail(h, DS_EINVAL, "ds_process_device: unknown layout");
         if (n_samples == 0) return DS_OK;
@@ -775,7 +781,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
         return fail(h, DS_EINVAL, "ds_process_device_seq: bad n_calls / call strides (must be multiples of 4 elements)");
     if (n_calls == 0) return DS_OK;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    const bool chain = h->cfg.algo == DS_ALGO_WPE_MVDR || h->cfg.algo == DS_ALGO_SUBBAND_GSC;
+    const bool chain = wpe_chain(h) || h->cfg.algo == DS_ALGO_SUBBAND_GSC;
     if (h->cfg.algo == DS_ALGO_TDGSC || h->cfg.algo == DS_ALGO_FDGSC) graph = 0;      // their stages keep the frame counters on the host
     // the SubbandGSC chain pipelines its stages over the enqueued blocks on up to five streams; replayed as ONE hipGraph the branches are
     // serialised by the graph executor (measured 0.34-0.50 ms per block against 0.26 ms with plain launches), so the sequence is launched
@@ -1155,7 +1161,7 @@ static size_t fdgsc_slot_bytes(const ds_handle* h, int i) {            // chain_
 static size_t chain_hist_bytes(const ds_handle* h) {
     if (h->cfg.algo == DS_ALGO_FDGSC) return fdgsc_slot_bytes(h, 0) + fdgsc_slot_bytes(h, 1) + fdgsc_slot_bytes(h, 2);
     if (h->cfg.algo == DS_ALGO_SUBBAND_GSC) return (size_t)h->cfg.batch * (h->K * 8 + h->cfg.hop * 4);
-    return h->cfg.algo == DS_ALGO_WPE_MVDR ? (size_t)h->cfg.batch * (h->wpe_delay > 0 ? h->wpe_delay : 1) * h->K * h->cfg.n_mics * 8 : 0;
+    return wpe_chain(h) ? (size_t)h->cfg.batch * (h->wpe_delay > 0 ? h->wpe_delay : 1) * h->K * h->cfg.n_mics * 8 : 0;
 }
 
 size_t ds_state_bytes(const ds_handle* h) {
@@ -1181,6 +1187,19 @@ int ds_chain_stage_info(const ds_handle* h, int i, int32_t* algo, int32_t* n_mic
     if (batch) *batch = s->cfg.batch;
     if (payload_bytes) *payload_bytes = ds_state_payload_bytes(s);
     return DS_OK;
+}
+
+size_t ds_chain_stage_field_bytes(const ds_handle* h, int i, int field) {
+    if (!h || i < 0 || i >= 10 || !h->sub[i]) return 0;
+    return ds_field_bytes(h->sub[i], field);
+}
+
+int ds_chain_stage_state(ds_handle* h, int i, int field, void* dst, size_t bytes) {
+    if (!h || i < 0 || i >= 10 || !h->sub[i]) return fail(h, DS_EINVAL, "ds_chain_stage_state: the handle has no such stage");
+    int rc = set_device(h); if (rc) return rc;                          // (joins the chain's utterance groups)
+    DS_HIP(h, hipStreamSynchronize(h->stream));
+    rc = ds_get_state(h->sub[i], field, dst, bytes);
+    return rc ? fail(h, rc, h->sub[i]->err) : DS_OK;
 }
 
 int ds_export_state(ds_handle* h, void* dst, size_t bytes) {

@@ -11,7 +11,8 @@ namespace dsi {
 // kernel on h->stream reading the previous stage's device buffer (nothing returns to the host between the stages)
 int chain_reserve(ds_handle* h, int T) {
     const size_t B = h->cfg.batch, K = h->K, M = h->cfg.n_mics, d = h->wpe_delay > 0 ? h->wpe_delay : 1;
-    const size_t need[8] = {B * T * K * M * 8, 0, B * T * K * M * 8, B * T * K * 4, B * T * K * 4, B * T * K * 8, B * d * K * M * 8, 0};
+    const size_t pg = h->wpe_only ? 0 : B * T * K * 4;              // Wpe.update alone: no speech-presence / gain arrays; [5] = channel 0 of E
+    const size_t need[8] = {B * T * K * M * 8, 0, B * T * K * M * 8, pg, pg, B * T * K * 8, B * d * K * M * 8, 0};
     for (int i = 0; i < 8; ++i) {
         if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
         { const int jr = join_groups(h); if (jr) return jr; }
@@ -106,7 +107,7 @@ int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long
     DS_HIP(h, hipSetDevice(h->device));                       // not set_device(): the utterance groups stay on their own streams between calls
     const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, T = n_samples / h->cfg.hop;
     int rc = chain_reserve(h, T); if (rc) return rc;
-    const int S = h->parts < B ? h->parts : B;
+    const int S = h->wpe_only ? 1 : (h->parts < B ? h->parts : B);
     if (S <= 1) { rc = join_groups(h); if (rc) return rc; }
     if (S > 1) return chain_process_groups(h, x_dev, layout, x_batch_stride, x_chan_stride, n_samples, y_dev, y_batch_stride, S);
     float *D = h->chain_buf[0], *E = h->chain_buf[2], *pp = h->chain_buf[3], *G = h->chain_buf[4], *Y = h->chain_buf[5];
@@ -126,14 +127,16 @@ int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long
     // delayed input of the prediction filter: a ring of the last wpe_delay analysis frames kept by the WPE kernel itself
     if (h->wpe_delay > 0) {
         // the ring position is device-resident (dev_cnt[3], advanced by the tick behind the launch) so that the step replays as a hipGraph
-        DS_SUB(1, wpe_run(h->sub[1], nullptr, D, T, E, DS_MEM_DEVICE, h->chain_buf[6], h->hist_cur, h->wpe_delay, h->dev_cnt + 3));
+        DS_SUB(1, wpe_run(h->sub[1], nullptr, D, T, E, DS_MEM_DEVICE, h->chain_buf[6], h->hist_cur, h->wpe_delay, h->dev_cnt + 3, h->wpe_only ? Y : nullptr));
         rc = post_tick(h->sub[1], h->dev_cnt, 0, 1, T % h->wpe_delay, h->wpe_delay, h->stream); if (rc) return rc;   // rides in the McMcra launch
         h->hist_cur = (h->hist_cur + T) % h->wpe_delay;
     } else {
-        DS_SUB(1, wpe_run(h->sub[1], D, D, T, E, DS_MEM_DEVICE, nullptr, 0, 0, nullptr));
+        DS_SUB(1, wpe_run(h->sub[1], D, D, T, E, DS_MEM_DEVICE, nullptr, 0, 0, nullptr, h->wpe_only ? Y : nullptr));
     }
-    DS_SUB(2, ds_mcmcra_estimate(h->sub[2], E, T, pp, G, DS_MEM_DEVICE));
-    DS_SUB(3, ds_adaptive_frames(h->sub[3], E, G, T, Y, DS_MEM_DEVICE));
+    if (!h->wpe_only) {
+        DS_SUB(2, ds_mcmcra_estimate(h->sub[2], E, T, pp, G, DS_MEM_DEVICE));
+        DS_SUB(3, ds_adaptive_frames(h->sub[3], E, G, T, Y, DS_MEM_DEVICE));
+    }
     {   // synthesis straight into the caller's (strided) output
         ds_handle* t = h->sub[4];
         Params p;
@@ -142,7 +145,7 @@ int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long
         p.x_batch_stride = (long long)T * K * 2;
         p.y_batch_stride = y_batch_stride;
         p.T = T; p.batch0 = 0; p.method = 1;
-        take_tick(t, h->stream, p.tick);                                // the adaptive frame loop's counter advance
+        take_tick(t, h->stream, p.tick);                                // the adaptive frame loop's counter advance (Wpe.update alone: the delay line's)
         DS_HIP(h, launch_transform_istft(t, p, B, h->stream));
     }
 #undef DS_SUB

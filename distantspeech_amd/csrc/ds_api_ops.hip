@@ -123,20 +123,21 @@ int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int me
 
 // the WPE kernel over utterances [b0, b0 + nb) (device pointers at utterance b0; ring = the chain's delay line at utterance b0 or null)
 int wpe_launch(ds_handle* h, int b0, int nb, const float* x_delayed, const float* d, int n_frames, float* err, float* ring, int ring_pos,
-               int ring_len, const int* dev_ring_pos, hipStream_t stream) {
+               int ring_len, const int* dev_ring_pos, hipStream_t stream, float* err0) {
     ds::WpeParams p;
     std::memset(&p, 0, sizeof p);
     p.B = nb; p.K = h->K; p.T = n_frames; p.C = h->cfg.n_mics; p.N = h->filter_len;
     p.xd = x_delayed; p.d = d; p.err = err; p.lam = h->rls_lambda;
     p.ustride = (long long)op_ust(h);
     p.state = h->opst + (size_t)b0 * p.ustride;
-    p.ring = ring; p.ring_pos = ring_pos; p.ring_len = ring_len; p.dev_ring_pos = dev_ring_pos;
-    DS_HIP(h, ds::launch_wpe(p, stream));
+    p.ring = ring; p.ring_pos = ring_pos; p.ring_len = ring_len; p.dev_ring_pos = dev_ring_pos; p.err0 = err0;
+    if (p.C * p.N > ds::WPE_CNMAX) DS_HIP(h, ds::launch_wpe_wide(p, h->wpe_generic, stream));     // wide prediction filters: one wavefront per bin
+    else DS_HIP(h, ds::launch_wpe(p, h->wpe_generic, stream));
     return DS_OK;
 }
 
 int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len,
-            const int* dev_ring_pos) {
+            const int* dev_ring_pos, float* err0) {
     if (!h || (!x_delayed && !ring) || !d || !err) return fail(h, DS_EINVAL, "ds_wpe_update: NULL argument");
     if (h->cfg.algo != DS_ALGO_WPE) return fail(h, DS_ESTATE, "ds_wpe_update: handle was created for a different algo");
     if (n_frames < 0) return fail(h, DS_ESHAPE, "ds_wpe_update: n_frames < 0");
@@ -146,7 +147,7 @@ int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, 
     IoSpec io = {{x_delayed, d, nullptr}, {x_delayed ? n : 0, n, 0}, {err, nullptr, nullptr}, {n, 0, 0}};
     const float* din[3]; float* dout[5];
     rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
-    rc = wpe_launch(h, 0, h->cfg.batch, din[0], din[1], n_frames, dout[0], ring, ring_pos, ring_len, dev_ring_pos, h->stream); if (rc) return rc;
+    rc = wpe_launch(h, 0, h->cfg.batch, din[0], din[1], n_frames, dout[0], ring, ring_pos, ring_len, dev_ring_pos, h->stream, err0); if (rc) return rc;
     return io_end(h, mem, io, dout);
 }
 

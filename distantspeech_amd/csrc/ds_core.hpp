@@ -77,6 +77,7 @@ DS_HD cf mk(float a, float b) { cf r; r.x = a; r.y = b; return r; }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_EXACT_DIV)
 DS_HD float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 DS_HD float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
+DS_HD float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
 DS_HD float div_(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 DS_HD float exp2_(float x) { return __builtin_amdgcn_exp2f(x); }
 DS_HD float log2_(float x) { return __builtin_amdgcn_logf(x); }
@@ -84,6 +85,7 @@ DS_HD float exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634
 #else
 DS_HD float rcp_(float x) { return 1.0f / x; }
 DS_HD float rsq_(float x) { return 1.0f / sqrtf(x); }
+DS_HD float sqrt_(float x) { return sqrtf(x); }
 DS_HD float div_(float a, float b) { return a / b; }
 DS_HD float exp2_(float x) { return exp2f(x); }
 DS_HD float log2_(float x) { return log2f(x); }
@@ -112,6 +114,12 @@ DS_HD cf cfnmac_s(cf acc, cf a, cf b) {      // acc - a * conj(b)
 DS_HD cf herm_downdate_s(cf P, cf gi, cf gj, float lam_inv, float dls) {
     const float tx = gi.x * gj.x + gi.y * gj.y, ty = gi.y * gj.x - gi.x * gj.y;
     return mk(fma_(-tx, dls, P.x * lam_inv), fma_(-ty, dls, P.y * lam_inv));
+}
+// the same update with the scale folded into the vectors: P / lambda - h_i conj(h_j), h = g sqrt(1 / (den lambda)) (ds_wpe_wide.hpp).  Same
+// symmetry: both products of a sum are rounded on their own, so (j, i) comes out as the exact conjugate of (i, j)
+DS_HD cf herm_downdate_h_s(cf P, cf hi, cf hj, float lam_inv) {
+    const float tx = hi.x * hj.x + hi.y * hj.y, ty = hi.y * hj.x - hi.x * hj.y;
+    return mk(fma_(P.x, lam_inv, -tx), fma_(P.y, lam_inv, -ty));
 }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_SCALAR_COMPLEX)
 // ... and on the device as TWO packed instructions each (v_pk_mul_f32 / v_pk_fma_f32): the half selects (op_sel / op_sel_hi: which half of
@@ -168,7 +176,17 @@ DS_HD cf herm_downdate(cf P, cf gi, cf gj, float lam_inv, float dls) {     // fi
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(t), "v"(sc), "v"(q));   // -t dls + q
     return pk_cf(r);
 }
+DS_HD cf herm_downdate_h(cf P, cf hi, cf hj, float lam_inv) {               // four packed instructions
+    cf2_t p1, p2, t, r;
+    const cf2_t sc = {lam_inv, lam_inv};
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(p1) : "v"(cf_pk(hi)), "v"(cf_pk(hj)));      // (hi.x hj.x, hi.y hj.x)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1]" : "=v"(p2) : "v"(cf_pk(hi)), "v"(cf_pk(hj)));      // (hi.y hj.y, hi.x hj.y)
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(t) : "v"(p1), "v"(p2));                                     // (tx, ty)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(cf_pk(P)), "v"(sc), "v"(t));  // P lam_inv - t
+    return pk_cf(r);
+}
 #else
+DS_HD cf herm_downdate_h(cf P, cf hi, cf hj, float lam_inv) { return herm_downdate_h_s(P, hi, hj, lam_inv); }
 DS_HD cf herm_downdate(cf P, cf gi, cf gj, float lam_inv, float dls) { return herm_downdate_s(P, gi, gj, lam_inv, dls); }
 DS_HD cf cmul(cf a, cf b) { return cmul_s(a, b); }
 DS_HD cf cmulc(cf a, cf b) { return cmulc_s(a, b); }

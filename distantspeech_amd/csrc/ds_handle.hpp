@@ -70,6 +70,8 @@ struct ds_handle {
     ds_handle* sub[10];         // WPE_MVDR: analysis transform, WPE, McMcra, adaptive frame loop, synthesis transform; SUBBAND_GSC: see chain2_*
     bool owns_stream;
     int wpe_delay;
+    bool wpe_only;              // DS_ALGO_WPE_TD: analysis -> delay line -> WPE -> synthesis of channel 0 (no McMcra / MVDR stages)
+    int wpe_generic;            // DS_WPE_GENERIC=1 at ds_create: every WPE shape through the run-time-shape kernels (A/B and tests)
     float* chain_buf[24];       // WPE_MVDR: D, -, E, p, G, Y, ring of the last wpe_delay analysis frames; SUBBAND_GSC: see chain2_reserve
     size_t chain_bytes[24];
     int postfilter;             // DS_PARAM_POSTFILTER (TDGSC / FDGSC chains behind ds_process_device)
@@ -136,6 +138,7 @@ size_t tail_in_bytes(const ds_handle* h);
 size_t tail_out_bytes(const ds_handle* h);
 size_t opst_bytes(const ds_handle* h);
 // floats between the utterances of an operator handle's state: NF rounded up to whole float4 planes (ds_ops.hpp: st_index) times KP
+inline bool wpe_chain(const ds_handle* h) { return h->cfg.algo == DS_ALGO_WPE_MVDR || h->cfg.algo == DS_ALGO_WPE_TD; }
 inline size_t op_ust(const ds_handle* h) { return (size_t)ds::st_floats_per_bin(h->NF) * h->KP; }
 size_t counters_bytes(const ds_handle* h);
 int set_device(ds_handle* h);
@@ -164,11 +167,11 @@ int run_binop(ds_handle* h, int want_algo, const char* who, int n_frames, int me
 int binop_launch(ds_handle* h, int b0, int nb, int n_frames, const float* const din[3], float* const dout[5], int is_complex, int has_p,
                  hipStream_t stream, const ds::TickArgs& tick, int group = 0);
 int wpe_launch(ds_handle* h, int b0, int nb, const float* x_delayed, const float* d, int n_frames, float* err, float* ring, int ring_pos,
-               int ring_len, const int* dev_ring_pos, hipStream_t stream);
+               int ring_len, const int* dev_ring_pos, hipStream_t stream, float* err0 = nullptr);
 // the McSpp half of ds_mcspp_estimate on device buffers: Gamma and its band mean come from the caller (the chain's front end computes them)
 int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* gamma, const float* qavg, float* p_out);
 int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len,
-            const int* dev_ring_pos);
+            const int* dev_ring_pos, float* err0 = nullptr);
 
 // chain handles (ds_api_chains.hip)
 // DS_ALGO_SUBBAND_GSC: device buffers of the chain (indices into ds_handle::chain_buf; "c" = complex64)

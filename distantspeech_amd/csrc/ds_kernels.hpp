@@ -46,7 +46,9 @@ hipError_t launch_tick(int* cnt, int frames, int L, int aux_add, int aux_mod, hi
 hipError_t launch_tick3(const TickArgs& a, const TickArgs& b, const TickArgs& c, hipStream_t stream);   // three handles' counters in one launch
 hipError_t launch_mcspp_qavg(const float* gamma, float* out, int rows, int K, hipStream_t stream);
 struct WpeParams;
-hipError_t launch_wpe(const WpeParams& p, hipStream_t stream);
+hipError_t launch_wpe(const WpeParams& p, int generic, hipStream_t stream);          // C N <= 16 (ds_wpe.hpp)
+hipError_t launch_wpe_wide(const WpeParams& p, int generic, hipStream_t stream);     // 16 < C N <= 80: one wavefront per bin (ds_kernels_wpe.hip)
+hipError_t launch_wpe_init(float* state, int B, int K, long long ustride, int C, int N, hipStream_t stream);   // P = 1e-3 I, the rest zero (awpe.py:58-77)
 struct FdafParams;
 hipError_t launch_fdaf(const FdafParams& p, int nfft, hipStream_t stream);   // ds_kernels_fdaf.hip
 
@@ -96,6 +98,14 @@ template <class Rg, int HOIST = 0> struct HipExec {
     // same wave have just read (in-place transform stages: the LDS executes a wave's accesses in order, and the stores depend on the
     // loads).  Here the halves simply follow each other, so the scheduler can run `rest`'s independent arithmetic under the loads' latency;
     // the CPU emulator runs `load` for every thread before `rest` for any.
+    // asynchronous 16-byte copy global -> LDS with no register in between (global_load_lds_dwordx4): lane `lane` of the wavefront lands at
+    // lds_piece + 16 * lane (the hardware's rule: wave-uniform base + lane x size), from its own global address.  Every piece of a tile can
+    // be in flight at once; lds_load_wait() before the phase ends retires them
+    __device__ __forceinline__ void lds_load16(void* lds_piece, int lane, const void* src) {
+        (void)lane;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+    }
+    __device__ __forceinline__ void lds_load_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     template <class FL, class FR> __device__ __forceinline__ void phase_wave2(FL fl, FR fr) {
         int tid = (int)threadIdx.x;
         DS_LAUNDER(tid);

@@ -483,13 +483,12 @@ template <int LPB, int CT = 0, int NTAPS = 0> __global__ void __launch_bounds__(
     HipExec<typename E::Rg> ex;
     E::run(ex, p, (int)blockIdx.x, sh);
 }
-hipError_t launch_wpe(const WpeParams& p, hipStream_t stream) {
+hipError_t launch_wpe(const WpeParams& p, int generic, hipStream_t stream) {
     const int lpb = wpe_lanes_per_bin(p.C * p.N), bpw = WPE_NT / lpb;
     const unsigned blocks = (unsigned)(((long long)p.B * p.K + bpw - 1) / bpw);
     // the shapes of the BASELINE config (8 channels x 2 taps), of the reference's notebooks and tests (4 x 2, 2 x 3, 4 x 4, 8 x 1) as
-    // compile-time shapes; anything else — and everything under DS_WPE_GENERIC=1, the A/B and test switch — through the generic kernels
-    const char* e = std::getenv("DS_WPE_GENERIC");
-    if (!(e && e[0] == '1')) {
+    // compile-time shapes; anything else — and everything with `generic` (DS_WPE_GENERIC=1 at ds_create, the A/B and test switch) — through the generic kernels
+    if (!(generic & 1)) {
 #define DS_WPE_SHAPE(LPB_, C_, N_) \
         if (p.C == C_ && p.N == N_) { hipLaunchKernelGGL((ds_wpe_kernel<LPB_, C_, N_>), dim3(blocks), dim3(WPE_NT), 0, stream, p); return hipGetLastError(); }
         DS_WPE_SHAPE(16, 8, 2) DS_WPE_SHAPE(8, 4, 2) DS_WPE_SHAPE(16, 4, 4) DS_WPE_SHAPE(8, 8, 1) DS_WPE_SHAPE(8, 2, 3)

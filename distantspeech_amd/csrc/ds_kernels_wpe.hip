@@ -1,0 +1,55 @@
+// ds_kernels_wpe.hip — the wide-tap RLS-WPE kernels (ds_wpe_wide.hpp) for gfx950: one wavefront per (utterance, bin), 16 < C N <= 80.
+// Two wavefronts per SIMD (eight per CU): the 80 x 80 matrix is 200 registers per lane, the tile 13 KB of LDS per wavefront.
+#include "ds_kernels.hpp"
+#include "ds_wpe_wide.hpp"
+
+namespace ds {
+
+template <int CNP, int NCH, int CT = 0, int NTAPS = 0>
+__global__ void __launch_bounds__(WPEW_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) ds_wpe_wide_kernel(WpeParams p) {
+    typedef WpeWideEngine<CNP, NCH, CT, NTAPS> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+
+// the reference's notebook shape (4 channels x 20 taps, example/wpe.ipynb cell 2) and SURVEY 8(d)'s cfg4 sizing (8 x 10) with the channel
+// and tap counts as compile-time constants; any other 16 < C N <= 80 through the run-time-shape kernel of its padded size (32 / 64 / 80).
+// generic != 0 (DS_WPE_GENERIC=1, read once at ds_create): every shape through the run-time-shape kernels (A/B and tests)
+hipError_t launch_wpe_wide(const WpeParams& p, int generic, hipStream_t stream) {
+    const int CN = p.C * p.N;
+    if (CN <= WPE_CNMAX || CN > WPEW_CNMAX || p.C > WPE_CMAX) return hipErrorInvalidValue;
+    const long long blocks = (long long)p.B * p.K;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+#define DS_WPEW(...) do { hipLaunchKernelGGL((ds_wpe_wide_kernel<__VA_ARGS__>), dim3((unsigned)blocks), dim3(WPEW_NT), 0, stream, p); return hipGetLastError(); } while (0)
+    if (generic & 2) {                                   // DS_WPE_WIDE_NCH=1: the whole triangle through one 26 KB tile (five wavefronts per CU); A/B runs
+        if (p.C == 4 && p.N == 20) DS_WPEW(80, 1, 4, 20);
+        if (p.C == 8 && p.N == 10) DS_WPEW(80, 1, 8, 10);
+    }
+    if (!(generic & 1)) {
+        if (p.C == 4 && p.N == 20) DS_WPEW(80, 2, 4, 20);
+        if (p.C == 8 && p.N == 10) DS_WPEW(80, 2, 8, 10);
+    }
+    if (CN <= 32) DS_WPEW(32, 1);
+    if (CN <= 64) DS_WPEW(64, 2);
+    DS_WPEW(80, 2);
+#undef DS_WPEW
+}
+
+// P = 1e-3 I (the diagonal words of the packed triangle, awpe.py:69-73) on a zeroed state: one thread per (utterance, bin, tap)
+__global__ void __launch_bounds__(256) ds_wpe_init_kernel(float* state, long long n, int K, long long ustride, int SB, int CN) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    const int i = (int)(g % CN);
+    const long long bk = g / CN, b = bk / K, k = bk - b * K;
+    state[b * ustride + k * SB + 2 * (wpew_words(i) + i)] = 1e-3f;
+}
+hipError_t launch_wpe_init(float* state, int B, int K, long long ustride, int C, int N, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(state, 0, (size_t)B * (size_t)ustride * sizeof(float), stream);
+    if (e != hipSuccess) return e;
+    const long long n = (long long)B * K * C * N;
+    hipLaunchKernelGGL(ds_wpe_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, state, n, K, ustride, wpe_bin_floats(C, N), C * N);
+    return hipGetLastError();
+}
+
+}  // namespace ds

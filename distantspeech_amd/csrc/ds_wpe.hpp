@@ -22,6 +22,7 @@
 namespace ds {
 
 constexpr int WPE_CNMAX = 16, WPE_CMAX = 8, WPE_NT = 128;
+constexpr int WPEW_CNMAX = 80;          // ... and up to this many taps-by-channels through the wavefront-per-bin program (ds_wpe_wide.hpp)
 
 // per-bin block, complex words: P upper triangle by columns, P[i][q] (i <= q) at q (q + 1) / 2 + i; then W[c][i] at NPK + c CN + i;
 // then input_buffer tap i at NPK + C CN + i; then var (1 float); padded to 16 B
@@ -43,6 +44,7 @@ struct WpeParams {
     float* ring;         // complex [B][ring_len][K][C]
     int ring_pos, ring_len;
     const int* dev_ring_pos;   // optional device-resident ring position (graph replay); overrides ring_pos
+    float* err0;         // optional: channel 0 of err alone, complex [B][T][K] (the input of a single-channel synthesis; ds_wpe_wide.hpp)
 };
 
 template <int LPB> struct WpeShared {
@@ -207,6 +209,7 @@ template <int LPB, int CT = 0, int NTAPS = 0> struct WpeEngine {
                 sh.err[s][i] = e;
                 const long long f = io_at(r, t);
                 p.err[2 * (f + i)] = e.x; p.err[2 * (f + i) + 1] = e.y;
+                if (p.err0 != nullptr && i == 0) { const long long f0 = f / C; p.err0[2 * f0] = e.x; p.err0[2 * f0 + 1] = e.y; }   // [B][T][K]
             });
             // ---- gain, P and W updates
             ex.phase_wave([&](int tid, Rg& r) {

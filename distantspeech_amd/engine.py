@@ -496,6 +496,16 @@ class BatchEngine:
                 out.append((i, a.value, m.value, b.value, int(n.value)))
         return out
 
+    def stage_state_raw(self, i, field=None):
+        """state field of stage i of a chain handle exactly as it sits in HBM (flat float32 per utterance): ds_chain_stage_state"""
+        field = L.FIELD_OP_STATE if field is None else int(field)
+        nbytes = self._lib.ds_chain_stage_field_bytes(self._h, int(i), field)
+        if nbytes == 0:
+            raise AttributeError("stage %d has no state field %d" % (i, field))
+        out = np.empty(nbytes // 4, dtype=np.float32)
+        L.check(self._lib.ds_chain_stage_state(self._h, int(i), field, out.ctypes.data_as(ctypes.c_void_p), nbytes), self._h)
+        return out.reshape(self.batch, -1)
+
     def export_state(self):
         n = self._lib.ds_state_bytes(self._h)
         buf = np.empty(n, dtype=np.uint8)

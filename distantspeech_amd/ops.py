@@ -523,8 +523,11 @@ class Wpe(_SubbandBase):
 
     The reference's Wpe does not run at HEAD (undefined check_input_data, awpe.py:150) and sits on the
     Nyquist filterbank; this class implements the same equations on the STFT (Transform) grid with
-    check_input_data(xd, x) := (analysis(xd), analysis(x)) — the semantics the golden vectors g10 pin
-    (tests/golden/make_golden.py R6, R7).  update() returns the dereverberated channel 0 in the time domain."""
+    check_input_data(xd, x) := (analysis(xd), analysis(x)) — the semantics the golden vectors g10 / g20 pin
+    (tests/golden/make_golden.py R6, R7).  update() is ONE native call (DS_ALGO_WPE_TD: analysis -> delay line of `delay`
+    frames on the device -> RLS-WPE -> synthesis of channel 0) and returns the dereverberated channel 0 in the time domain.
+    channels * filter_len <= 80 (the maintained use, example/wpe.ipynb cell 2: channels=4, filter_len=20, num_bands=256,
+    hop_length=64); hop_length = num_bands / 2 or num_bands / 4."""
 
     def __init__(self, channels=2, filter_len=2, num_bands=512, forgetting_factor=0.998, delay=4, mu=0.5,
                  normalization=True, alpha=0.9, m=2, hop_length=None, input_td=False, batch=1, device=-1):
@@ -532,24 +535,18 @@ class Wpe(_SubbandBase):
         self.hop_length = int(num_bands / 2) if hop_length is None else hop_length
         self.D = delay
         self.forgetting_factor = forgetting_factor
-        self._eng = BatchEngine(L.ALGO_WPE, channels, num_bands, batch=batch, device=device, filter_len=filter_len,
-                                rls_lambda=forgetting_factor)
-        self.transform_d = Transform(channel=channels, n_fft=num_bands, hop_length=self.hop_length, batch=batch, device=device)
-        # x delayed by D*hop samples has the STFT frames of x from D calls ago (zero history before that)
-        self._ring = [np.zeros((self.batch, self.half_band, channels), dtype=np.complex64) for _ in range(delay)]
+        self._eng = BatchEngine(L.ALGO_WPE_TD, channels, num_bands, hop=self.hop_length, batch=batch, device=device,
+                                filter_len=filter_len, rls_lambda=forgetting_factor)
+        self._eng.set_wpe_delay(delay)
 
     def update(self, x_n, alpha=1e-4, p=None):
-        """x_n [hop, channels] float -> (dereverberated channel 0 [hop], W [half_band, channels, channels*filter_len])."""
+        """x_n [hop, channels] float (or any multiple of hop samples: successive hops, bit for bit the hop-by-hop result)
+        -> (dereverberated channel 0 [samples], W [half_band, channels, channels*filter_len])."""
         x = self._add_batch(x_n, 2)
-        if x.shape[1] != self.hop_length:
-            raise ValueError("Wpe.update takes one hop (%d samples) per call" % self.hop_length)
-        D = self.transform_d._eng.stft(x, L.LAYOUT_SAMPLES_CHANNELS)[:, 0]         # [B, K, C] current frame
-        self._ring.append(D)
-        Xd = self._ring.pop(0) if self.D > 0 else D
-        err = self._eng.wpe_update(Xd[:, None], D[:, None])                          # [B, 1, K, C]
-        y = self.transform_d._eng.istft(np.ascontiguousarray(err[:, :, :, :1]))      # channel 0 -> [B, hop, 1]
-        out = y[:, :, 0].astype(np.float64)
-        return self._sq(out), self.W
+        if x.shape[1] % self.hop_length != 0 or x.shape[2] != self.channels:
+            raise ValueError("Wpe.update takes [k * hop (%d), channels (%d)] samples per call" % (self.hop_length, self.channels))
+        y = self._eng.process(x, L.LAYOUT_SAMPLES_CHANNELS)
+        return self._sq(y.astype(np.float64)), self.W
 
     def _blocks(self):
         """per-bin state blocks [B, K, words] complex (layout of csrc/ds_wpe.hpp: the upper triangle of P by columns, P[i][q] (i <= q) at
@@ -557,7 +554,7 @@ class Wpe(_SubbandBase):
         C, CN = self.channels, self.channels * self.filter_len
         nw = CN * (CN + 1) // 2 + C * CN + CN
         SB = (2 * nw + 1 + 3) & ~3
-        raw = self._eng.op_state_raw().reshape(self.batch, -1)[:, : self.half_band * SB].reshape(self.batch, self.half_band, SB)
+        raw = self._eng.stage_state_raw(1).reshape(self.batch, -1)[:, : self.half_band * SB].reshape(self.batch, self.half_band, SB)
         return raw[:, :, : 2 * nw].copy().view(np.complex64)
 
     @property

@@ -65,7 +65,7 @@ extern "C" {
 #define DS_ALGO_SUBLMS 7     /* SubbandLMS (n_mics=1) / SubbandLmsMc (n_mics=C) .update   adaptivefilter/SubbandLMS.py, SubbandLmsMc.py */
 #define DS_ALGO_SUBRLS 8     /* SubbandRLS.update                    adaptivefilter/SubbandRLS.py:44-71 */
 #define DS_ALGO_MCSPPBASE 9  /* McSppBase.estimation + PMWF weights  noise_estimation/mcspp_base.py:220-324 */
-#define DS_ALGO_WPE 10       /* Wpe.update frequency-domain core (RLS-WPE on the STFT grid)  dereverberation/awpe.py:129-192 */
+#define DS_ALGO_WPE 10       /* Wpe.update frequency-domain core (RLS-WPE on the STFT grid)  dereverberation/awpe.py:129-192; n_mics <= 8, n_mics * filter_len <= 80 */
 #define DS_ALGO_MCSPP 11     /* McSpp.estimation (McCDR prior) + fused steering/MVDR   noise_estimation/mcspp.py:244-305, mccdr.py:122-177 */
 #define DS_ALGO_LINALG 12    /* stateless per-bin helpers: steering(), compute_mvdr_weight()   beamformer/beamformer.py:10-31,133-155 */
 #define DS_ALGO_FRONTEND 13  /* time-domain conditioning: FilterDcNotch16 (feature.py:32-49), TimeAlignment FIR bank (fixedbeamformer.py:13-93) */
@@ -79,7 +79,8 @@ extern "C" {
 #define DS_ALGO_WPE_MVDR 18    /* BASELINE config 4 as ONE handle behind ds_process / ds_process_device: STFT -> RLS-WPE on all channels
                                  (awpe.py:152-189; ds_config.filter_len taps, rls_lambda forgetting factor, prediction delay DS_PARAM_WPE_DELAY
                                  frames, default 4) -> McMcra gain (mc_mcra.py:179-224) -> adaptive MVDR frame loop (adaptivebeamformer.py:69-120)
-                                 x gain -> ISTFT; device-resident between the stages, all on the handle's stream; n_mics * filter_len <= 16 */
+                                 x gain -> ISTFT; device-resident between the stages, all on the handle's stream; n_mics * filter_len <= 80
+                                 (16 < n_mics * filter_len: the wavefront-per-bin kernel, csrc/ds_wpe_wide.hpp) */
 #define DS_ALGO_SUBBAND_GSC 19 /* SubbandGSC.process (beamformer/SubbandGSC.py:170-262; BASELINE config 5 with rls_lambda > 0) as ONE handle:
                                  DC notch -> TimeAlignment FIR bank + mean beamformer -> STFT -> McSpp -> M adaptive blocking filters (one
                                  batched subband LMS, or RLS when ds_config.rls_lambda > 0) -> ISTFT/STFT -> multichannel subband-LMS canceller
@@ -94,6 +95,14 @@ extern "C" {
                                   batched launch, shared fixed-beamformer input, half-block-delayed aligned channels as desired signals) ->
                                   norm-limited multichannel canceller on the one-block-delayed fixed output -> optional OMLSA post-filter
                                   (block-sequential like the reference: its two signals share one Transform); ds_fdgsc_process */
+
+#define DS_ALGO_WPE_TD 22      /* Wpe.update (dereverberation/awpe.py:129-192) as ONE call behind ds_process / ds_process_device: analysis of the
+                                  n_mics channels -> prediction delay line (DS_PARAM_WPE_DELAY frames, default 4: DelaySamples of delay * hop
+                                  samples, awpe.py:75-76,147) -> RLS-WPE on all channels (filter_len taps, rls_lambda forgetting factor) ->
+                                  synthesis of the dereverberated channel 0, all on the device.  hop = nfft / 2 or nfft / 4 (the reference's
+                                  maintained use is Wpe(channels=4, filter_len=20, delay=4, num_bands=256, hop_length=64), example/wpe.ipynb
+                                  cell 2); n_mics <= 8, n_mics * filter_len <= 80.  No steering vector.  State of the filter: the stage handle
+                                  of ds_chain_stage_info stage 1 (DS_FIELD_OP_STATE: per-bin blocks, csrc/ds_wpe.hpp) */
 
 /* `mem` argument of the frame-level entry points */
 #define DS_MEM_HOST 0
@@ -334,6 +343,10 @@ size_t ds_state_payload_bytes(const ds_handle* h);
    batch and carried-state bytes (ds_state_payload_bytes of that stage).  DS_EINVAL when the handle has no stage i.  Read-only
    introspection for byte accounting (scripts/stage_budget.py) and for mapping a checkpoint to the reference object's members. */
 int ds_chain_stage_info(const ds_handle* h, int i, int32_t* algo, int32_t* n_mics, int32_t* batch, size_t* payload_bytes);
+/* ds_field_bytes / ds_get_state of stage i of a chain handle: the attributes the reference leaves readable on the members of a composite
+   object (wpe.W / wpe.P of a Wpe: stage 1 of DS_ALGO_WPE_TD, DS_FIELD_OP_STATE; awpe.py:61-73) */
+size_t ds_chain_stage_field_bytes(const ds_handle* h, int i, int field);
+int ds_chain_stage_state(ds_handle* h, int i, int field, void* dst, size_t bytes);
 int ds_export_state(ds_handle* h, void* dst, size_t bytes);
 int ds_import_state(ds_handle* h, const void* src, size_t bytes);
 

@@ -891,7 +891,7 @@ class OracleWpe:
         self.var = 0.98 * self.var + (1 - 0.98) * var_n[:, None]                  # :163
         num = np.einsum('kij, kj->ki', self.P, X)                                 # :172
         kn = num / (self.lam * self.var + np.sum(X.conj() * num, axis=-1, keepdims=True))   # :173-178
-        self.P = (self.P - np.einsum('ij,il,ilk->ijk', kn, X.conj(), self.P)) * self.lam_inv   # :181-183
+        self.P = (self.P - np.einsum('ij,il,ilk->ijk', kn, X.conj(), self.P, optimize=True)) * self.lam_inv   # :181-183 (optimize=True as the reference: pairwise contraction)
         for ch in range(C):
             self.W[:, ch, :] = self.W[:, ch, :] + err[:, ch:ch + 1].conj() * kn   # :186-187
         return err

@@ -12,6 +12,7 @@
 #include "../../distantspeech_amd/csrc/ds_tables.hpp"
 #include "../../distantspeech_amd/csrc/ds_tdfilter.hpp"
 #include "../../distantspeech_amd/csrc/ds_fdaf.hpp"
+#include "../../distantspeech_amd/csrc/ds_wpe_wide.hpp"
 
 namespace {
 
@@ -28,6 +29,8 @@ template <class Rg> struct CpuExec {
     template <class FL, class FR> void phase_wave2(FL fl, FR fr) { phase(fl); phase(fr); }
     template <class FL, class FR> void phase2(FL fl, FR fr) { phase(fl); phase(fr); }
     void sync() {}
+    void lds_load16(void* lds_piece, int lane, const void* src) { std::memcpy((char*)lds_piece + 16 * lane, src, 16); }   // HipExec: global_load_lds
+    void lds_load_wait() {}
 };
 
 // The Python side of the emulator keeps operator state as logical planes [B][NF][KP]; the kernels keep it as float4 planes
@@ -147,6 +150,21 @@ template <int NFFT, int CMAX> int run_fdaf(ds::FdafParams p) {
         ex.nt = E::NT;
         ex.R.resize(E::NT);
         E::run(ex, p, b, *sh);
+    }
+    delete sh;
+    return 0;
+}
+
+// the wide-tap program (ds_wpe_wide.hpp): one 64-lane block per (utterance, bin)
+template <int CNP, int NCH, int CT = 0, int NTAPS = 0> int run_wpe_wide(const ds::WpeParams& p) {
+    typedef ds::WpeWideEngine<CNP, NCH, CT, NTAPS> E;
+    typename E::Sh* sh = new typename E::Sh();
+    const long long blocks = (long long)p.B * p.K;
+    for (long long b = 0; b < blocks; ++b) {
+        CpuExec<typename E::Rg> ex;
+        ex.nt = E::NT;
+        ex.R.resize(E::NT);
+        E::run(ex, p, (int)b, *sh);
     }
     delete sh;
     return 0;
@@ -310,6 +328,14 @@ int emul_wpe(int B, int K, int T, int C, int N, const float* xd, const float* d,
     std::memset(&p, 0, sizeof p);
     p.B = B; p.K = K; p.T = T; p.C = C; p.N = N; p.xd = xd; p.d = d; p.err = err; p.state = state;
     p.ustride = (long long)K * ds::wpe_bin_floats(C, N); p.lam = lam;
+    if (C * N > ds::WPE_CNMAX) {                                 // wide prediction filters: launch_wpe_wide's dispatch (ds_kernels_wpe.hip)
+        if (C * N > ds::WPEW_CNMAX || C > ds::WPE_CMAX) return -1;
+        if (!g_wpe_generic) {
+            if (C == 4 && N == 20) return run_wpe_wide<80, 2, 4, 20>(p);
+            if (C == 8 && N == 10) return run_wpe_wide<80, 2, 8, 10>(p);
+        }
+        return C * N <= 32 ? run_wpe_wide<32, 1>(p) : C * N <= 64 ? run_wpe_wide<64, 2>(p) : run_wpe_wide<80, 2>(p);
+    }
     const int lpb = ds::wpe_lanes_per_bin(C * N);
     if (!g_wpe_generic) {                                        // the compile-time shapes of launch_wpe (ds_kernels_ops.hip)
         if (C == 8 && N == 2) return run_wpe<16, 8, 2>(p);

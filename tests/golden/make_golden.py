@@ -18,13 +18,13 @@ Repairs applied to broken reference entry points, each recorded
   R4  SD weights at 512-FFT via the base class beamformer.compute_weights(weightType='SD')
       (FixedBeamformer.compute_weights calls gen_noise_msc with nfft=256: shape error).
   R5  stray prints silenced (fixedbeamformer.py:68-74).
-  R6  Wpe (g10 only): `awpe.Subband := Transform` — the reference builds Wpe on its Nyquist filterbank whose
+  R6  Wpe (g10, g18, g21): `awpe.Subband := Transform` — the reference builds Wpe on its Nyquist filterbank whose
       design does not terminate at the sizes of interest; the STFT grid is used instead.
   R8  McSpp with M != 4 (g11 synth_m6 only): `mcspp.mccdr = McCDR(nfft, channels=M)` — McSpp builds its McCDR with the
       default 4 channels (mcspp.py:54) and raises IndexError for other array sizes.
   R9  SubbandGSC (g12 only): `DistantSpeech.beamformer.FDGSC.DelayObj = object` before importing SubbandGSC
       (SubbandGSC.py:23 imports a DelayObj that FDGSC.py does not define).
-  R7  Wpe (g10 only): `Wpe.check_input_data(xd, x)` is undefined at HEAD (awpe.py:150); defined here as the
+  R7  Wpe (g10, g18, g21): `Wpe.check_input_data(xd, x)` is undefined at HEAD (awpe.py:150); defined here as the
       analogue of SubbandAF.update_input_data (SubbandAF.py:53-60): analyse both signals, set return_td = True.
   R10 compute_pmwf_weight (g19 only): the free function's `channels = Rxx.shape[0]` (beamformer.py:124) makes `u` [bins, bins, 1], which
       only multiplies with [bins, M, M] matrices where M == bins; the fixture replays its body with channels = Rxx.shape[1].
@@ -780,6 +780,41 @@ def g20_odd_m():
              omlsa_lambda_d=np.asarray(g.omlsa_multi.lambda_d), mcra_p=g.mcra.p, params=np.array([M, 512, 256, 2]), r=np.array(mic.r))
 
 
+def g21_wpe_wide():
+    """The reference's maintained use of Wpe: Wpe(channels=4, mu=1e-4, forgetting_factor=0.998, filter_len=20, delay=4, num_bands=256,
+    hop_length=64) driven one hop (64 samples) per update() call (example/wpe.ipynb cell 2) — on 4 s of the reference's own 4-channel
+    recording rec1 (the notebook's input files are not in the repository); and 8 channels x 10 taps on the 1024 / 512 grid (SURVEY 8d's
+    sizing of BASELINE config 4) on the reference's 8-channel recording an101.  Patched reference: R6, R7."""
+    from DistantSpeech.dereverberation import awpe
+    awpe.Subband = Transform                                                               # R6
+
+    def check_input_data(self, xd, xx):                                                    # R7
+        self.return_td = True
+        return np.squeeze(self.transform_x.analysis(xd)), np.squeeze(self.transform_d.analysis(xx))
+
+    awpe.Wpe.check_input_data = check_input_data
+    for name, x16, C, N, D, nb, hop, secs in (("nb_c4n20", rec1_int16(3.0, 4.0), 4, 20, 4, 256, 64, 4.0),
+                                              ("c8n10", an101_int16(), 8, 10, 4, 1024, 512, 2.8)):
+        T = min(int(secs * 16000) // hop, x16.shape[1] // hop)
+        x16 = np.ascontiguousarray(x16[:, : T * hop])
+        xt = (x16.astype(np.float32) / 32768.0).T.astype(np.float64)
+        with contextlib.redirect_stdout(io.StringIO()):
+            wpe = awpe.Wpe(channels=C, mu=1e-4, forgetting_factor=0.998, filter_len=N, delay=D, num_bands=nb, hop_length=hop)
+        outs, W_mid = [], None
+        for n in range(T):
+            out, _ = wpe.update(xt[n * hop:(n + 1) * hop])
+            outs.append(np.atleast_1d(out))
+            if n == T // 2 - 1:
+                W_mid = wpe.W[::8].astype(np.complex64)
+        kk = np.arange(0, nb // 2 + 1, 8)
+        kp = kk[:: max(1, len(kk) // 8)]                                                   # P (80 x 80 per bin) at a handful of bins
+        save("g21_wpe_%s" % name, "Wpe.update awpe.py:129-192 one hop per call, Wpe(channels=%d, filter_len=%d, delay=%d, num_bands=%d, hop_length=%d, "
+             "forgetting_factor=0.998) on the STFT grid (example/wpe.ipynb cell 2's operating point for nb_c4n20); W at every 8th bin, P at bins_P; "
+             "R6 R7 (PARITY UNPINNED by the reference as shipped)" % (C, N, D, nb, hop),
+             x=x16, y=np.concatenate(outs).astype(np.float32), W=wpe.W[kk].astype(np.complex64), W_mid=W_mid, P=wpe.P[kp].astype(np.complex64),
+             var=wpe.var, bins=kk, bins_P=kp, params=np.array([C, N, D, nb, hop]))
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -811,6 +846,7 @@ def main():
     if want("g18"): g18_an101()
     if want("g19"): g19_gev(x16)
     if want("g20"): g20_odd_m()
+    if want("g21"): g21_wpe_wide()
 
 
 if __name__ == "__main__":

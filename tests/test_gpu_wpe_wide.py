@@ -1,0 +1,179 @@
+"""GPU parity of the wide-tap RLS-WPE (csrc/ds_wpe_wide.hpp: one wavefront per (utterance, bin), 16 < channels * taps <= 80) through
+the C-ABI: the reference's maintained operating point Wpe(channels=4, filter_len=20, delay=4, num_bands=256, hop_length=64)
+(example/wpe.ipynb cell 2) and SURVEY 8(d)'s 8-channel x 10-tap sizing of BASELINE config 4, against the patched reference's golden
+vectors (G21; make_golden.py R6, R7 — parity otherwise unpinned: the shipped Wpe does not run) and against the oracle core.
+Tolerance: the north star's 1e-4 RMS, asserted at <= 3x what the committed build measured."""
+import numpy as np
+import pytest
+
+from _cases import as_float, load, measured, rms
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ds():
+    import distantspeech_amd as d
+    from distantspeech_amd import _lib as L
+    assert L.load().ds_device_count() > 0
+    return d
+
+
+def reverberant(seed, L, C, tail=3000, decay=600.0):
+    """[L, C] float32: a modulated noise source through C random exponentially decaying impulse responses + a little sensor noise"""
+    rng = np.random.default_rng(seed)
+    n = np.arange(L + tail)
+    s = rng.standard_normal(L + tail) * 0.1 * (0.25 + 0.75 * np.abs(np.sin(2 * np.pi * n / 16000 * 2.7))) * (np.sin(2 * np.pi * n / 16000 * 0.9) > -0.5)
+    x = np.empty((L, C))
+    for c in range(C):
+        h = rng.standard_normal(tail) * np.exp(-np.arange(tail) / decay) * 0.2
+        h[0] = 1.0
+        x[:, c] = np.convolve(s, h)[tail:tail + L]
+    return (x + 0.002 * rng.standard_normal(x.shape)).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["nb_c4n20", "c8n10"])
+def test_wpe_wide_against_the_patched_reference(ds, name):
+    """Wpe.update one hop per call, like the notebook's loop, on the reference's own recordings: output, W (mid-stream and final), P."""
+    g = load("g21_wpe_" + name)
+    C, N, D, nb, hop = [int(v) for v in g["params"]]
+    x = as_float(g["x"]).T
+    wpe = ds.Wpe(channels=C, mu=1e-4, forgetting_factor=0.998, filter_len=N, delay=D, num_bands=nb, hop_length=hop)
+    T = x.shape[0] // hop
+    ys, W_mid = [], None
+    for n in range(T):
+        y, _ = wpe.update(x[n * hop:(n + 1) * hop])
+        ys.append(y)
+        if n == T // 2 - 1:
+            W_mid = wpe.W[::8]
+    y = np.concatenate(ys)
+    kk, kp = g["bins"], g["bins_P"]
+    W, P = wpe.W, wpe.P
+    e_y, e_W, e_Wm, e_P = rms(y - g["y"]), rms(W[kk] - g["W"]) / rms(g["W"]), rms(W_mid - g["W_mid"]) / rms(g["W_mid"]), rms(P[kp] - g["P"]) / rms(g["P"])
+    measured("G21_wpe_" + name, y_rms=e_y, y_ref_rms=rms(g["y"]), W_rel_rms=e_W, W_mid_rel_rms=e_Wm, P_rel_rms=e_P)
+    assert e_y < 1e-4 and e_y < 3e-5 * rms(g["y"])
+    assert e_W < 1e-3 and e_Wm < 1e-3 and e_P < 1e-3
+    # the matrix the kernel carries is Hermitian bit for bit (only its upper triangle is state)
+    assert np.array_equal(P, np.conj(np.swapaxes(P, -1, -2)))
+
+
+def test_wpe_wide_one_call_equals_hop_by_hop(ds):
+    """a call of T hops is bit for bit T one-hop calls (output and the whole carried state), and utterances of a batch are independent"""
+    C, N, nb, hop = 4, 20, 256, 64
+    x = np.stack([reverberant(5, hop * 40, C), reverberant(6, hop * 40, C)])
+    a = ds.Wpe(channels=C, filter_len=N, delay=4, num_bands=nb, hop_length=hop, batch=2)
+    b = ds.Wpe(channels=C, filter_len=N, delay=4, num_bands=nb, hop_length=hop, batch=2)
+    ya = np.concatenate([a.update(x[:, n * hop:(n + 1) * hop])[0] for n in range(40)], axis=1)
+    yb = np.concatenate([b.update(x[:, : hop * 7])[0], b.update(x[:, hop * 7: hop * 8])[0], b.update(x[:, hop * 8:])[0]], axis=1)
+    assert np.array_equal(ya, yb)
+    assert np.array_equal(a._eng.export_state(), b._eng.export_state())
+    c = ds.Wpe(channels=C, filter_len=N, delay=4, num_bands=nb, hop_length=hop, batch=1)
+    yc = c.update(x[1])[0]
+    assert np.array_equal(yc, ya[1])
+    o_in = x[1]
+    from oracle import ds_oracle as O
+    o = O.OracleWpe(channels=C, filter_len=N, num_bands=nb, delay=4, hop_length=hop)
+    ref = np.concatenate([o.update(o_in[n * hop:(n + 1) * hop])[0] for n in range(40)])
+    assert rms(yc - ref) < 2e-5 * rms(ref)
+
+
+@pytest.mark.parametrize("C,N", [(4, 5), (3, 7), (4, 8), (6, 8), (8, 8), (8, 9), (2, 33), (1, 20), (5, 16), (8, 10), (4, 20)])
+def test_wpe_wide_shapes(ds, C, N):
+    """every padded size of the wide kernel (32 / 64 / 80 rows; strips of 8, 16, 32 or 64 lanes per channel; split rows part filled) vs
+    the oracle core, state carried across two calls, two identical utterances in a batch"""
+    from oracle import ds_oracle as O
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(100 * C + N)
+    K, T = 33, 18
+    D = (rng.standard_normal((T, K, C)) + 1j * rng.standard_normal((T, K, C))) * 0.3
+    for t in range(1, T):
+        D[t] += 0.6 * D[t - 1]
+    Xd = np.concatenate([np.zeros((2, K, C), complex), D[:-2]])
+    o = O.OracleWpe(channels=C, filter_len=N, num_bands=64, delay=2)
+    ref = np.stack([o.update_fd(Xd[t], D[t]) for t in range(T)])
+    eng = ds.BatchEngine(L.ALGO_WPE, C, 64, batch=2, filter_len=N, rls_lambda=0.998)
+    err = np.concatenate([eng.wpe_update(np.stack([Xd[:7], Xd[:7]]), np.stack([D[:7], D[:7]])),
+                          eng.wpe_update(np.stack([Xd[7:], Xd[7:]]), np.stack([D[7:], D[7:]]))], axis=1)
+    assert np.array_equal(err[0], err[1])
+    assert rms(err[0] - ref) < 1e-5 * rms(ref)
+
+
+@pytest.mark.parametrize("C,N", [(4, 20), (8, 10)])
+def test_wpe_wide_compile_time_shapes_equal_the_generic_kernel(ds, C, N, monkeypatch):
+    """the notebook's shape and the cfg4 sizing run as kernels with the channel and tap counts as compile-time constants; DS_WPE_GENERIC=1
+    (read at ds_create) sends them through the run-time-shape kernel of the same padded size: same errors, same exported state, bit for bit"""
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(7 + C)
+    K, T, B = 65, 12, 2
+    D = ((rng.standard_normal((B, T, K, C)) + 1j * rng.standard_normal((B, T, K, C))) * 0.3).astype(np.complex64)
+    Xd = np.concatenate([np.zeros((B, 2, K, C), np.complex64), D[:, :-2]], axis=1)
+    out = []
+    for generic in ("1", "0"):
+        monkeypatch.setenv("DS_WPE_GENERIC", generic)
+        eng = ds.BatchEngine(L.ALGO_WPE, C, 128, batch=B, filter_len=N, rls_lambda=0.998)
+        err = np.concatenate([eng.wpe_update(Xd[:, :5], D[:, :5]), eng.wpe_update(Xd[:, 5:], D[:, 5:])], axis=1)
+        out.append((err, eng.export_state()))
+    monkeypatch.delenv("DS_WPE_GENERIC")
+    assert np.abs(out[0][0]).max() > 0 and np.all(np.isfinite(out[0][0]))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_wpe_wide_30_s_stream(ds):
+    """32 s of a strongly reverberant, stationary 4-channel stream at the notebook's operating point (8000 frames at hop 64, 4 x 20 taps)
+    through the frequency-domain entry, 250 frames per call: 17 of the 129 bins against the fp64 oracle core, frame for frame.
+    The recursion carries P in fp32 (its Hermitian triangle): what bounds the error is eps x cond(P) — it grows while P converges
+    (cond(P) 10 -> 2.6e5 over the first 20 s of this input) and then stays put (7e-4 of the output's own RMS); it does not drift further
+    and P stays Hermitian bit for bit.  The bar is the north star's: 1e-4 RMS at WAV scale (the stream is scaled to 0.05 RMS; by Parseval
+    the error of the spectra relative to the input spectra is the error of the waveform relative to the input waveform)."""
+    from oracle import ds_oracle as O
+    from distantspeech_amd import _lib as L
+    C, N, nb, hop, dl = 4, 20, 256, 64, 4
+    x = reverberant(11, 16000 * 32, C)
+    x = x * (0.05 / rms(x))
+    Dn = O.OracleTransform(channel=C, n_fft=nb, hop_length=hop).stft(x)          # [K, T, C]
+    ks = np.linspace(1, nb // 2 - 1, 17).astype(int)
+    D = np.ascontiguousarray(Dn[ks].transpose(1, 0, 2))                          # [T, 17, C]
+    T = D.shape[0]
+    Xd = np.concatenate([np.zeros((dl, 17, C), complex), D[:-dl]])
+    eng = ds.BatchEngine(L.ALGO_WPE, C, 32, batch=1, filter_len=N, rls_lambda=0.998)    # 32-point grid = 17 bins
+    o = O.OracleWpe(channels=C, filter_len=N, num_bands=32, delay=dl)
+    rel, wav = [], []
+    for a in range(0, T, 250):
+        b = min(T, a + 250)
+        err = eng.wpe_update(Xd[None, a:b], D[None, a:b])[0]
+        ref = np.stack([o.update_fd(Xd[t], D[t]) for t in range(a, b)])
+        assert np.all(np.isfinite(err))
+        rel.append(rms(err - ref) / rms(ref))
+        wav.append(rms(err - ref) / rms(D[a:b, :, 0]) * rms(x[:, 0]))            # RMS error of the waveform at this input level
+    measured("wpe_wide_32s_stream", worst_segment_rel=max(rel), last_segment_rel=rel[-1], first_segment_rel=rel[0], worst_segment_wav_rms=max(wav),
+             last_segment_wav_rms=wav[-1], input_rms=rms(x[:, 0]), frames=T)
+    assert T >= 7500 and max(wav) < 1e-4 and max(rel) < 2.5e-3                     # measured: 2.5e-5 at 0.05 RMS input, 7.4e-4 relative
+    assert rel[-1] < 1.3 * max(rel[-8:-4])                                         # ... and level over the last 8 s: no drift
+
+
+def test_wpe_mvdr_chain_with_wide_taps(ds):
+    """the cfg4 chain (DS_ALGO_WPE_MVDR: STFT -> WPE -> McMcra -> MVDR x gain -> ISTFT) at SURVEY 8(d)'s 10-tap sizing (8 x 10 = 80):
+    the oracle's composition on one utterance; utterance groups on two streams equal the whole batch bit for bit"""
+    from oracle import ds_oracle as O
+    from distantspeech_amd import _lib as L
+    from distantspeech_amd.mic_array import MicArray
+    M, nfft, hop, T = 8, 1024, 512, 14
+    mic = MicArray(arrayType="circular", r=0.05, M=M, n_fft=nfft)
+    omic = O.OracleMicArray(arrayType="circular", r=0.05, M=M, n_fft=nfft)
+    ang = np.array([197, 0]) / 180 * np.pi
+    x = np.stack([O.synth_utterance(40 + b, hop * T, omic) for b in range(4)])
+    tao = -1 * mic.r * np.cos(ang[1]) * np.cos(ang[0] - mic.gamma) / mic.c
+    a = np.exp(-1j * (2 * np.pi * np.arange(nfft // 2 + 1) * 16000 / nfft)[:, None] * tao[None, :])
+    ys = []
+    for parts in (1, 2):
+        eng = ds.BatchEngine(L.ALGO_WPE_MVDR, M, nfft, hop, batch=4, filter_len=10, rls_lambda=0.998)
+        eng.set_split(parts)
+        eng.set_steering(a); eng.set_method(L.METHOD_MVDR)
+        ys.append(np.concatenate([eng.process(x[:, :, : hop * 5], L.LAYOUT_CHANNELS_SAMPLES), eng.process(x[:, :, hop * 5:], L.LAYOUT_CHANNELS_SAMPLES)], axis=1))
+        eng.close()
+    assert np.array_equal(ys[0], ys[1])
+    with np.errstate(all="ignore"):
+        ref = O.OracleWpeMvdrPostfilter(omic, nfft=nfft, hop=hop, taps=10).process(x[1], ang)
+    e = rms(ys[0][1] - ref)
+    measured("cfg4_chain_10_taps", y_rms=e, y_ref_rms=rms(ref))
+    assert e < 1e-4

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from _cases import ADAPTIVE_CASES, ANGLE, GSC_CASES, TOL_RMS, as_float, load, rms, steering
+from oracle import ds_oracle as O
 from emul.emul import EmulEngine
 
 
@@ -206,6 +207,62 @@ def test_emul_wpe_golden(name):
     err = np.concatenate([op.run(Xd[:, :7], Dn[:, :7]), op.run(Xd[:, 7:], Dn[:, 7:])], axis=1)     # state carried across calls
     y = tf.istft(np.ascontiguousarray(err[:, :, :, :1]))[0, :, 0]
     assert rms(y - g["y"]) < 2e-4 * max(rms(g["y"]), 1e-3)
+
+
+def test_emul_wpe_wide_golden():
+    """the wavefront-per-bin program (ds_wpe_wide.hpp) at the notebook's operating point, 4 channels x 20 taps on the 256 / 64 grid, on the
+    reference's recording: W and P of the patched reference after 1000 frames (G21), frames fed 97 per call"""
+    g = load("g21_wpe_nb_c4n20")
+    C, N, D, nb, hop = [int(v) for v in g["params"]]
+    x = (g["x"].astype(np.float32) / 32768.0).T
+    Dn = O.OracleTransform(channel=C, n_fft=nb, hop_length=hop).stft(x).transpose(1, 0, 2)[None].astype(np.complex64)    # [1, T, K, C]
+    T = Dn.shape[1]
+    Xd = np.concatenate([np.zeros((1, D) + Dn.shape[2:], np.complex64), Dn[:, : T - D]], axis=1)
+    from emul.emul import EmulWpe
+    op = EmulWpe(nb, C, N)
+    err = np.concatenate([op.run(Xd[:, a:a + 97], Dn[:, a:a + 97]) for a in range(0, T, 97)], axis=1)
+    assert np.all(np.isfinite(err))
+    CN = C * N
+    npk = CN * (CN + 1) // 2
+    blk = op.state[0, :, : 2 * (npk + C * CN + CN)].copy().view(np.complex64)
+    W = blk[:, npk:npk + C * CN].reshape(-1, C, CN)
+    assert rms(W[g["bins"]] - g["W"]) < 1e-4 * rms(g["W"])
+    P = np.zeros((len(g["bins_P"]), CN, CN), complex)
+    for q in range(CN):
+        for i in range(q + 1):
+            P[:, i, q] = blk[g["bins_P"], q * (q + 1) // 2 + i]
+            P[:, q, i] = np.conj(P[:, i, q])
+    assert rms(P - g["P"]) < 1e-4 * rms(g["P"])
+    y = O.OracleTransform(channel=1, n_fft=nb, hop_length=hop).istft(np.ascontiguousarray(err[0, :, :, :1].transpose(1, 0, 2)))
+    assert rms(np.asarray(y).ravel() - g["y"]) < 1e-4 * rms(g["y"])
+
+
+@pytest.mark.parametrize("C,N", [(4, 20), (8, 10), (4, 6), (6, 8), (8, 9), (3, 7), (2, 33), (1, 20)])
+def test_emul_wpe_wide_shapes(C, N):
+    """every padded size of the wide program (32 / 64 / 80; split rows part filled; strips of 8 .. 64 lanes per channel) against the
+    oracle core, state carried across two calls; the compile-time shapes equal the run-time-shape program bit for bit"""
+    from emul import emul as E
+    from emul.emul import EmulWpe
+    rng = np.random.default_rng(100 * C + N)
+    nfft, T = 32, 12
+    K = nfft // 2 + 1
+    d = ((rng.standard_normal((1, T, K, C)) + 1j * rng.standard_normal((1, T, K, C))) * 0.1).astype(np.complex64)
+    for t in range(1, T):
+        d[:, t] += 0.5 * d[:, t - 1]
+    xd = np.concatenate([np.zeros_like(d[:, :4]), d[:, :-4]], axis=1)
+    res = []
+    for generic in (1, 0):
+        E.lib().emul_set_wpe_generic(generic)
+        try:
+            op = EmulWpe(nfft, C, N)
+            err = np.concatenate([op.run(xd[:, :5], d[:, :5]), op.run(xd[:, 5:], d[:, 5:])], axis=1)
+        finally:
+            E.lib().emul_set_wpe_generic(0)
+        res.append((err, op.state.copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    o = O.OracleWpe(channels=C, filter_len=N, num_bands=nfft, delay=4)
+    ref = np.stack([o.update_fd(xd[0, t].astype(complex), d[0, t].astype(complex)) for t in range(T)])
+    assert rms(res[0][0][0] - ref) < 1e-6 * rms(ref)
 
 
 @pytest.mark.parametrize("C,N", [(8, 2), (4, 2), (4, 4), (8, 1), (2, 3)])

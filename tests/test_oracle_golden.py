@@ -391,6 +391,26 @@ def test_an101_wpe_8_channels(golden):
     assert np.allclose(wpe.W, g["W"], rtol=2e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("name", ["nb_c4n20", "c8n10"])
+def test_wpe_wide_taps(golden, name):
+    """the reference's maintained operating point Wpe(channels=4, filter_len=20, delay=4, num_bands=256, hop_length=64) (example/wpe.ipynb
+    cell 2) on rec1, and 8 channels x 10 taps at 1024 / 512 (SURVEY 8d's cfg4 sizing) on an101: against the *patched* reference (R6, R7)."""
+    g = golden("g21_wpe_" + name)
+    C, N, D, nb, hop = [int(v) for v in g["params"]]
+    x = (g["x"].astype(np.float32) / 32768.0).T
+    wpe = O.OracleWpe(channels=C, filter_len=N, num_bands=nb, delay=D, hop_length=hop)
+    T = x.shape[0] // hop
+    ys = []
+    for n in range(T):
+        ys.append(wpe.update(x[n * hop:(n + 1) * hop])[0])
+        if n == T // 2 - 1:
+            assert np.allclose(wpe.W[::8], g["W_mid"], rtol=1e-4, atol=1e-7)
+    y = np.concatenate(ys)
+    assert rms(y - g["y"]) < 1e-6 * rms(g["y"])                       # (the fixture stores y as float32)
+    assert np.allclose(wpe.W[g["bins"]], g["W"], rtol=1e-4, atol=1e-7)
+    assert np.allclose(wpe.P[g["bins_P"]], g["P"], rtol=1e-4, atol=1e-9)
+
+
 def test_gev_flow_and_pmwf_weight(golden):
     """mvdr.ipynb's GEV flow (get_gev_vector -> phase_correction -> blind_analytic_normalization) and the free compute_pmwf_weight
     (beamformer/beamformer.py:34-130; R10) — scipy's eigh is the same third-party routine the fixture was made with."""
