@@ -289,6 +289,10 @@ class GpuWorkload:
             self.eng.chain_set_aux(L.CHAIN_AUX_FIR, fractional_delay_filter_bank(np.array(-(tau - np.max(tau)))[:, 0] * mic.fs))
             if w["algo"] == "SUBBAND_GSC":
                 self.eng.chain_set_aux(L.CHAIN_AUX_COHERENCE, McSpp.diffuse_coherence(M, nfft))
+                # the chain's tail on its own stream: only where this process raised the runtime's hardware-queue limit itself (main());
+                # under a profiler the runtime was up before main() with its default 4 queues, and the tail stays on the chain's stream
+                self.tail_async = int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 6 and not under_profiler()
+                self.eng.set_param_i(L.PARAM_TAIL_ASYNC, int(self.tail_async))
         else:
             tao = -1 * mic.r * np.cos(ang[1]) * np.cos(ang[0] - mic.gamma) / mic.c          # adaptivebeamformer.py:52
             a = np.exp(-1j * (2 * np.pi * np.arange(nfft // 2 + 1) * FS / nfft)[:, None] * tao[None, :])

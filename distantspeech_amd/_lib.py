@@ -8,20 +8,9 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# The chain handles spread their stages over up to five HIP streams; the runtime's default of 4 hardware queues per device makes two of
-# them share a queue (false serialisation).  Only effective if nothing in the process has initialised HIP yet.
-def _hip_already_initialised():
-    t = sys.modules.get("torch")
-    try:
-        return bool(t is not None and t.cuda.is_initialized())
-    except Exception:
-        return False
-
-
-# (the library reads the variable as a statement about the running HIP runtime: set it only where it can still take effect.  A process
-# whose HIP runtime is already up — e.g. torch has made a CUDA call — keeps its 4 queues, and the chains then keep their serial tail)
-if "GPU_MAX_HW_QUEUES" not in os.environ and not _hip_already_initialised():
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+# (the package does not touch the process environment.  An application that runs the SubbandGSC chain with its tail on a stream of its
+# own raises the HIP runtime's hardware-queue limit itself — GPU_MAX_HW_QUEUES=8 before its first HIP call — and then says so with
+# PARAM_TAIL_ASYNC: see INTEGRATION.md)
 LIB_PATH = os.environ.get("DSENH_LIB", os.path.join(_HERE, "libdsenh.so"))   # DSENH_LIB: A/B of kernel builds
 
 DS_OK = 0
@@ -35,6 +24,7 @@ ALGO_TDGSC = 20
 ALGO_FDGSC = 21
 ALGO_WPE_TD = 22
 PARAM_POSTFILTER = 15
+PARAM_TAIL_ASYNC = 17
 PARAM_FDAF_TWO_PATH = 16
 CHAIN_AUX_FIR, CHAIN_AUX_COHERENCE = 0, 1
 PARAM_WPE_DELAY = 13
@@ -49,6 +39,7 @@ LAYOUT_SAMPLES_CHANNELS, LAYOUT_CHANNELS_SAMPLES = 0, 1
 PARAM_METHOD, PARAM_MCRA_L, PARAM_ALPHA_Y, PARAM_ALPHA_V, PARAM_DIAG, PARAM_GATE, PARAM_MU, PARAM_SPLIT = 1, 2, 3, 4, 5, 6, 7, 8
 (FIELD_RVV, FIELD_RYY, FIELD_MCRA_S, FIELD_MCRA_SMIN, FIELD_MCRA_STMP, FIELD_MCRA_P, FIELD_MCRA_LAMBDA_D,
  FIELD_PHI_YY, FIELD_PHI_VV, FIELD_G_AIC, FIELD_STFT_TAIL, FIELD_OLA_TAIL, FIELD_COUNTERS, FIELD_OP_STATE, FIELD_NOTCH_MEM) = range(1, 16)
+FIELD_H = 16
 
 
 class ds_config(ctypes.Structure):
@@ -73,7 +64,7 @@ _lib = None
 
 # every symbol include/dsenh.h declares (tests check that the built library exports all of them)
 EXPORTS = [
-    "ds_version", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
+    "ds_version", "ds_build_info", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
     "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_set_window", "ds_process", "ds_process_pcm16", "ds_process_device",
     "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcra_estimate_p", "ds_mcmcra_estimate", "ds_mcsppbase_estimate", "ds_set_aux", "ds_mcspp_estimate", "ds_steering",
     "ds_mvdr_weight", "ds_pmwf_weight", "ds_gev_vector", "ds_blind_analytic_normalization", "ds_phase_correction", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process", "ds_tdgsc_process", "ds_fdgsc_process",
@@ -82,6 +73,12 @@ EXPORTS = [
     "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_state_payload_bytes", "ds_chain_stage_info", "ds_chain_stage_field_bytes", "ds_chain_stage_state", "ds_export_state",
     "ds_import_state",
 ]
+
+
+def build_info():
+    """{'version': '104', 'state_layout': '3', 'arch': 'gfx950', 'shelved': '0'}: ds_build_info() parsed"""
+    txt = load().ds_build_info().decode()
+    return dict(kv.split("=", 1) for kv in txt.split()[1:])
 
 
 def load():
@@ -107,6 +104,8 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, cf_, cll, csz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong, ctypes.c_size_t
     lib.ds_version.restype = ci
+    lib.ds_build_info.restype = ctypes.c_char_p
+    lib.ds_build_info.argtypes = []
     lib.ds_device_count.restype = ci
     lib.ds_strerror.restype = ctypes.c_char_p
     lib.ds_strerror.argtypes = [ci]

@@ -231,6 +231,15 @@ class adaptivebeamfomer(_AdaptiveBase):
         return self._squeeze(np.swapaxes(w, 1, 2))
 
 
+    @property
+    def H_kernel(self):
+        """the weights [M, half_bin] the frame kernel applies to the next frame, from the kernel's own fused Cholesky solve on the resident
+        Rvv (ds_get_state DS_FIELD_H: a read-only probe running mvdr_output() with unit frames) — what `H` derives on the host with NumPy's
+        inverse; methods src / DS / MVDR."""
+        w = self._eng.get_field(L.FIELD_H)
+        return self._squeeze(np.swapaxes(w.astype(np.complex128), 1, 2))
+
+
 class GSC(_AdaptiveBase):
     """Frequency-domain GSC with SPP-controlled LMS canceller and McMcra gain — beamformer/GSC.py:26-294."""
 

@@ -199,9 +199,20 @@ static void advance_host_counters_keep_first(ds_handle* h, int frames, int L) {
 
 }  // namespace dsi
 
+#define DS_STR2(x) #x
+#define DS_STR(x) DS_STR2(x)
+
 extern "C" {
 
 int ds_version(void) { return DS_VERSION; }
+
+const char* ds_build_info(void) {
+#if defined(DS_WITH_SHELVED)
+    return "libdsenh version=" DS_STR(DS_VERSION) " state_layout=" DS_STR(DS_STATE_LAYOUT) " arch=gfx950 shelved=1";
+#else
+    return "libdsenh version=" DS_STR(DS_VERSION) " state_layout=" DS_STR(DS_STATE_LAYOUT) " arch=gfx950 shelved=0";
+#endif
+}
 
 int ds_device_count(void) {
     int n = 0;
@@ -257,10 +268,12 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         case DS_ALGO_FIXED: ki = ds::lookup_fixed(cfg->nfft, cfg->n_mics); break;
         case DS_ALGO_ADAPTIVE:
             ki = cfg->track_ryy ? ds::lookup_adaptive_ryy(cfg->nfft, cfg->n_mics) : ds::lookup_adaptive_noryy(cfg->nfft, cfg->n_mics);
-            if (!cfg->track_ryy) {                          // 8 microphones: the quad-spread kernel (same state layout, same numbers)
+#if defined(DS_WITH_SHELVED)
+            if (!cfg->track_ryy) {                          // 8 microphones, DS_M8_QUAD=1: the quad-spread kernel (same state layout, same numbers)
                 const KernelInfo kq = ds::lookup_adaptive_quad(cfg->nfft, cfg->n_mics);
                 if (kq.launch) ki = kq;
             }
+#endif
             break;
         case DS_ALGO_GSC: ki = ds::lookup_gsc(cfg->nfft, cfg->n_mics); break;
         case DS_ALGO_TRANSFORM:
@@ -523,16 +536,15 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         if (!(serial && serial[0] == '1')) {
             bool ok = chain_stream(&h->side[1], 4) == hipSuccess;
             for (int i = 0; i < 10 && ok; ++i) ok = hipEventCreateWithFlags(&h->ev_fr[i], hipEventDisableTiming) == hipSuccess;
-            // the tail on a stream of its own needs a hardware queue of its own: with the runtime's default of 4 queues per device the fourth
-            // and fifth stream of the process share one and the front end would queue behind the previous block's tail (measured: 0.31 ms per
-            // block instead of 0.28).  The application raises the limit before the first HIP call (GPU_MAX_HW_QUEUES=8; bench.py and the
-            // Python binding do); without that the tail stays on the chain's stream
-            const char* hwq = std::getenv("GPU_MAX_HW_QUEUES");
-            if (ok && hwq && std::atoi(hwq) >= 6) {
-                ok = chain_stream(&h->side[2], 2) == hipSuccess &&
-                     hipEventCreateWithFlags(&h->ev_join[2], hipEventDisableTiming) == hipSuccess;
-                h->tail_async = ok;
-            }
+            // the tail on a stream of its own (side[2]) pays only when that stream gets a hardware queue of its own: with the HIP runtime's
+            // default of 4 queues per device the fourth and fifth stream of the process share one and the front end queues behind the
+            // previous block's tail (measured: 0.31 ms per block instead of 0.28).  The library cannot see how many queues the running
+            // runtime has, so the APPLICATION says so: DS_PARAM_TAIL_ASYNC = 1 before the first call (or DS_CHAIN_TAIL_ASYNC=1 in the
+            // environment at ds_create) after it has raised the limit itself before its first HIP call (GPU_MAX_HW_QUEUES=8; bench.py
+            // does).  Default 0: the tail stays on the chain's stream
+            if (ok) ok = chain_stream(&h->side[2], 2) == hipSuccess && hipEventCreateWithFlags(&h->ev_join[2], hipEventDisableTiming) == hipSuccess;
+            const char* ta = std::getenv("DS_CHAIN_TAIL_ASYNC");
+            h->tail_async = ok && ta && ta[0] == '1';
             if (ok && !h->ev_fork) ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
             if (!ok) { ds_destroy(h); return fail(nullptr, DS_EHIP, "ds_create(DS_ALGO_SUBBAND_GSC): front-end stream"); }
             h->front_async = true;
@@ -655,6 +667,12 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
         case DS_PARAM_FDAF_NON_CAUSAL: h->fdaf_non_causal = value != 0; return DS_OK;
         case DS_PARAM_FDAF_WEIGHT_NORM: h->fdaf_weight_norm = value != 0; return DS_OK;
         case DS_PARAM_FDAF_TWO_PATH: h->fdaf_two_path = value != 0; return DS_OK;
+        case DS_PARAM_TAIL_ASYNC: {
+            if (h->cfg.algo != DS_ALGO_SUBBAND_GSC || !h->side[2]) return fail(h, DS_EINVAL, "tail async: pipelined DS_ALGO_SUBBAND_GSC chain handles only");
+            for (int i = 0; i < 24; ++i) if (h->chain_bytes[i]) return fail(h, DS_ESTATE, "tail async must be set before the first call");
+            h->tail_async = value != 0;
+            return DS_OK;
+        }
         case DS_PARAM_POSTFILTER:
             if (h->cfg.algo != DS_ALGO_TDGSC && h->cfg.algo != DS_ALGO_FDGSC) return fail(h, DS_EINVAL, "postfilter: TDGSC / FDGSC chain handles only");
             h->postfilter = value != 0;
@@ -1034,6 +1052,7 @@ size_t ds_field_bytes(const ds_handle* h, int field) {
             if (h->tdf_w) return (size_t)h->cfg.batch * h->cfg.filter_len * sizeof(float);
             return opst_bytes(h);
         case DS_FIELD_NOTCH_MEM: return h->td_mem ? B * M * 2 * sizeof(float) : 0;
+        case DS_FIELD_H: return (ad && h->method != DS_METHOD_TFGSC) ? B * K * M * 2 * sizeof(float) : 0;
         default: return 0;
     }
 }
@@ -1059,6 +1078,18 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
     if (field == DS_FIELD_NOTCH_MEM) { DS_HIP(h, hipMemcpy(dst, h->td_mem, need, hipMemcpyDeviceToHost)); return DS_OK; }
     if (field == DS_FIELD_OP_STATE) {
         DS_HIP(h, hipMemcpy(dst, h->tdf_w ? (const void*)h->tdf_w : (const void*)h->opst, need, hipMemcpyDeviceToHost));
+        return DS_OK;
+    }
+    if (field == DS_FIELD_H) {
+        if (!h->steer_set) return fail(h, DS_ESTATE, "ds_get_state(DS_FIELD_H): call ds_set_steering first");
+        float* Hd = nullptr;
+        DS_HIP(h, hipMalloc((void**)&Hd, need));
+        hipError_t e = ds::launch_mvdr_probe(h->cfg.n_mics, reinterpret_cast<const float*>(h->bins), (long long)bins_ust(h), h->KP, h->ki.NF, h->cfg.batch, h->K,
+                                             reinterpret_cast<const float*>(h->steer), h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0, h->diag, h->method, Hd, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, Hd, need, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(Hd);
+        if (e != hipSuccess) return fail(h, DS_EHIP, std::string("ds_get_state(DS_FIELD_H): ") + hipGetErrorString(e));
         return DS_OK;
     }
     // per-bin fields: pull the raw planes and unpack on the host
@@ -1140,7 +1171,7 @@ static int extra_state(const ds_handle* h, ExtraState out[3]) {
 // shared-reference / complemented-p subband filters); out_scale_bits: hop / sum(window^2), which moves with a caller-supplied window
 struct BlobHeader { uint32_t magic, version; int32_t algo, nfft, hop, n_mics, batch, filter_len, td_L, track_ryy, layout, modes, wpe_delay; uint32_t out_scale_bits; };
 static const uint32_t BLOB_MAGIC = 0x44534348u;      // "DSCH"
-static const int32_t BLOB_LAYOUT = 3;      // 3: operator state as float4 planes [b][f / 4][k][f % 4], FIR history channel-major [b][m][L - 1]
+static const int32_t BLOB_LAYOUT = DS_STATE_LAYOUT;      // 3: operator state as float4 planes [b][f / 4][k][f % 4], FIR history channel-major [b][m][L - 1]
 static BlobHeader blob_header(const ds_handle* h) {
     uint32_t osb;
     std::memcpy(&osb, &h->out_scale, sizeof osb);

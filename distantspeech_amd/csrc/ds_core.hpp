@@ -195,6 +195,11 @@ DS_HD cf cfmac(cf acc, cf a, cf b) { return cfmac_s(acc, a, b); }
 DS_HD cf cfnma(cf acc, cf a, cf b) { return cfnma_s(acc, a, b); }
 DS_HD cf cfnmac(cf acc, cf a, cf b) { return cfnmac_s(acc, a, b); }
 #endif
+// Floor of a Cholesky pivot of A = R + delta I with R positive semi-definite: every pivot (a diagonal entry of a Schur complement of A)
+// is >= lambda_min(A) >= delta in exact arithmetic, so the floor changes nothing there.  In fp32 a rank-deficient R (fewer distinct frames
+// than microphones: a periodic input, the bench's replayed hops) leaves pivots of rounding-level size and either sign; floored at 1e-30
+// they became r = 1e15 and the solve overflowed to NaN (found by bench.py --total-batch on a three-hop round, round 4).
+DS_HD float pivot_floor(float delta) { return delta > 1e-30f ? delta : 1e-30f; }
 DS_HD cf cconj(cf a) { return mk(a.x, -a.y); }
 DS_HD cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
 DS_HD float cabs2(cf a) { return fma_(a.x, a.x, a.y * a.y); }
@@ -660,7 +665,7 @@ template <int M> struct Chol {
             float s = d[j] + diag;
 #pragma unroll
             for (int k = 0; k < j; ++k) { const cf l = L(j, k); s = fma_(-l.x, l.x, fma_(-l.y, l.y, s)); }
-            s = fmaxf_(s, 1e-30f);
+            s = fmaxf_(s, fmaxf_(diag, 1e-30f));     // a pivot of R + diag I (R >= 0) is >= diag in exact arithmetic: see pivot_floor()
 #if defined(__HIP_DEVICE_COMPILE__)
             const float r = rsqrtf(s);
 #else
@@ -811,6 +816,7 @@ template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag
 // columns between the stages of the neighbouring hops' transforms.  The operations and their order are mvdr_output()'s, word for word
 // (bit-identical results: tests/test_kernel_emul.py::test_emul_pipelined_engine_equals_the_frame_engine and its GPU twin).
 template <int M> struct MvdrSweep {
+    float dg;
     float Ad[M];
     cf Al[M * (M - 1) / 2 + 1];          // strictly-lower A_ij (i>j) at off_index(j, i)
     cf u[M], t[M];
@@ -823,9 +829,10 @@ template <int M> struct MvdrSweep {
         for (int q = 0; q < M * (M - 1) / 2; ++q) Al[q] = mk(o[2 * q], -o[2 * q + 1]);   // A_ij = conj(R_ji)
         nu = 0.0f;
         ut = mk(0.0f, 0.0f);
+        dg = diag;
     }
     DS_HD void column(int j) {
-        const float sj = fmaxf_(Ad[j], 1e-30f);
+        const float sj = fmaxf_(Ad[j], pivot_floor(dg));
 #if defined(__HIP_DEVICE_COMPILE__)
         const float r = rsqrtf(sj);
 #else
@@ -874,7 +881,7 @@ template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag
     cf ut = mk(0.0f, 0.0f);
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-        const float sj = fmaxf_(Ad[j], 1e-30f);
+        const float sj = fmaxf_(Ad[j], pivot_floor(diag));
 #if defined(__HIP_DEVICE_COMPILE__)
         const float r = rsqrtf(sj);
 #else
@@ -997,7 +1004,7 @@ DS_HD void mcmcra_bin(float* pyy, float* pvv, const cf* Z, int k, int spp_frm_cn
         float s = sym_get<M>(pvv, j, j) + 1e-6f;
 #pragma unroll
         for (int q = 0; q < j; ++q) s = fma_(-Lm[j][q], Lm[j][q], s);
-        s = fmaxf_(s, 1e-30f);
+        s = fmaxf_(s, pivot_floor(1e-6f));
         const float r = rsq_(s);
         inv_d[j] = r;
         Lm[j][j] = s * r;
@@ -1291,7 +1298,10 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         float* tout = p.tail_out + (long long)b * HOP;
         int* cnt = p.counters + (long long)b * 4;
         const cf* steer = p.steer + (long long)b * p.steer_batch_stride;
-        int frm_cnt = cnt[0], ell = cnt[1], spp_cnt = cnt[2];
+        // (the fixed beamformer and the chain tail have no frame counters: nothing to read, nothing to write back — as loaded-and-restored
+        // values they were three registers held across the whole kernel, spilled to scratch in the 6-microphone tail)
+        constexpr bool HAS_CNT = ALGO == ALGO_ADAPTIVE || ALGO == ALGO_GSC;
+        int frm_cnt = HAS_CNT ? cnt[0] : 0, ell = HAS_CNT ? cnt[1] : 1, spp_cnt = HAS_CNT ? cnt[2] : 0;
         int old_half = 0;
 #if defined(DS_LATE_STATE_STORE)
         constexpr bool EARLY_STORE = false;                        // A/B switch: everything in the epilogue, as before round 3
@@ -1605,7 +1615,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 if constexpr (EARLY_STORE) {
                     if (t == T_run - 1) {                               // the Nyquist bin's state (final since its pass, two barriers back) and the counters
                         store_nyquist_state(tid);
-                        if (tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }
+                        if (HAS_CNT && tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }
                     }
                 }
                 if (!one_round) DS_SETPRIO(0);
@@ -1645,7 +1655,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 store_lane_state(tid, r);
                 store_nyquist_state(tid);
             }
-            if (tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }
+            if (HAS_CNT && tid == 0) { cnt[0] = frm_cnt; cnt[1] = ell; cnt[2] = spp_cnt; }
         });
     }
 };
@@ -1958,13 +1968,13 @@ template <int NFFT> struct RowView {         // what fft_stage sees of one row
     const Tables<NFFT>& tb;
     float (*xbuf)[NFFT];
 };
-struct RowRegs { vec4 pre[2]; };
+template <int NV> struct RowRegs { vec4 pre[NV]; };     // (sized to the shape: with two slots for the one a 512-point row uses the struct stayed in scratch)
 
 template <int NFFT> struct StftRowsEngine {
     static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2, ROWS = 4, NT = 64 * ROWS, NV = HOP / 256;
     static_assert(HOP % 256 == 0, "a lane carries whole 16-byte pieces of a hop");
     typedef SharedRows<NFFT> Sh;
-    typedef RowRegs Rg;
+    typedef RowRegs<NV> Rg;
 
     template <class Exec> static DS_HD void run(Exec& ex, const Params& p, int blk, Sh& sh) {
         auto where = [&](int tid, int& w, int& lane, int& row) { w = tid >> 6; lane = tid & 63; row = blk * ROWS + w; return row < p.rows; };

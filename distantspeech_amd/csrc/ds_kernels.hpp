@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include "ds_core.hpp"
+#if defined(DS_WITH_SHELVED)      // make SHELVED=1: the hop-pipelined and quad-lane experiments (built, bit-identical, measured slower: DESIGN.md 4.4)
 #include "ds_pipe.hpp"
+#endif
 
 namespace ds {
 
@@ -49,6 +51,8 @@ struct WpeParams;
 hipError_t launch_wpe(const WpeParams& p, int generic, hipStream_t stream);          // C N <= 16 (ds_wpe.hpp)
 hipError_t launch_wpe_wide(const WpeParams& p, int generic, hipStream_t stream);     // 16 < C N <= 80: one wavefront per bin (ds_kernels_wpe.hip)
 hipError_t launch_wpe_init(float* state, int B, int K, long long ustride, int C, int N, hipStream_t stream);   // P = 1e-3 I, the rest zero (awpe.py:58-77)
+hipError_t launch_mvdr_probe(int M, const float* bins, long long ust, int KP, int NF, int B, int K, const float* steer, long long steer_batch_stride,
+                             float diag, int method, float* H, hipStream_t stream);   // DS_FIELD_H (ds_kernels_adaptive.hip)
 struct FdafParams;
 hipError_t launch_fdaf(const FdafParams& p, int nfft, hipStream_t stream);   // ds_kernels_fdaf.hip
 
@@ -168,6 +172,7 @@ hipError_t launch_frames(const Params& p, int nblocks, hipStream_t stream) {
     return hipGetLastError();
 }
 
+#if defined(DS_WITH_SHELVED)
 // the hop-pipelined form of the same program (ds_pipe.hpp): same state, same arguments, same results bit for bit
 template <int NFFT, int M, int ALGO, bool RYY>
 __global__ void __launch_bounds__(NFFT / 2, frames_min_waves(M, ALGO)) ds_frames_pipe_kernel(Params p) {
@@ -183,14 +188,17 @@ hipError_t launch_frames_pipe(const Params& p, int nblocks, hipStream_t stream) 
     hipLaunchKernelGGL((ds_frames_pipe_kernel<NFFT, M, ALGO, RYY>), dim3(nblocks), dim3(E::NT), 0, stream, p);
     return hipGetLastError();
 }
+#endif
 
 template <int NFFT, int M, int ALGO, bool RYY> KernelInfo make_info() {
     typedef Engine<NFFT, M, ALGO, RYY> E;
     KernelInfo ki;
     ki.launch = &launch_frames<NFFT, M, ALGO, RYY>;
     ki.NP = E::NP; ki.NF = E::SL::NF; ki.KP = E::KP; ki.NT = E::NT;
+#if defined(DS_WITH_SHELVED)
     if constexpr (NFFT == 512 && (ALGO == ALGO_FIXED || ALGO == ALGO_ADAPTIVE || ALGO == ALGO_GSC) && M <= 4)
         ki.launch_pipe = &launch_frames_pipe<NFFT, M, ALGO, RYY>;
+#endif
     return ki;
 }
 

@@ -187,7 +187,7 @@ template <class Q> DS_HD cq<typename Q::V> quad_mvdr_output(const Q& q, const Qu
             default: dj = Q::template bcast<3>(s1 ? d1 : d0); ujx = Q::template bcast<3>(s1 ? u1.x : u0.x); ujy = Q::template bcast<3>(s1 ? u1.y : u0.y);
                     tjx = Q::template bcast<3>(s1 ? t1.x : t0.x); tjy = Q::template bcast<3>(s1 ? t1.y : t0.y); break;
         }
-        const V r = Q::rsq(Q::vmax(dj, 1e-30f));
+        const V r = Q::rsq(Q::vmax(dj, pivot_floor(diag)));      // (mvdr_output()'s floor, word for word)
         const cq<V> uj = qmk<V>(ujx * r, ujy * r), tj = qmk<V>(tjx * r, tjy * r);
         nu = fma_(uj.x, uj.x, fma_(uj.y, uj.y, nu));
         ut = qfmac(ut, tj, uj);                                          // += conj(u_j) t_j

@@ -71,6 +71,9 @@ class BatchEngine:
     def set_mcra_L(self, value):
         L.check(self._lib.ds_set_param_i(self._h, L.PARAM_MCRA_L, int(value)), self._h)
 
+    def set_param_i(self, pid, value):
+        L.check(self._lib.ds_set_param_i(self._h, int(pid), int(value)), self._h)
+
     def set_param_f(self, pid, value):
         L.check(self._lib.ds_set_param_f(self._h, int(pid), float(value)), self._h)
 
@@ -473,6 +476,8 @@ class BatchEngine:
             return out.reshape(B, K, M, M)
         if field == L.FIELD_G_AIC:
             return out.view(np.complex64).reshape(B, K, M - 1)
+        if field == L.FIELD_H:
+            return out.view(np.complex64).reshape(B, K, M)
         if field == L.FIELD_STFT_TAIL:
             return out.reshape(B, M, self.nfft - self.hop)
         if field == L.FIELD_OLA_TAIL:

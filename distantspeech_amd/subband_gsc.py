@@ -47,22 +47,34 @@ class FilterDcNotch16(object):
 
 
 class DelaySamples(object):
-    """beamformer/utils.py:241-274 — pure buffering."""
+    """A delay line of `delay` samples fed `data_len` samples per call — the interface of beamformer/utils.py:241-274 (same constructor
+    arguments, `delay(x)` takes [samples] or [samples, channels] and returns [samples, channels]).  Kept as a ring: the write position
+    advances by the block length and the read position trails it by `delay`; nothing is shifted."""
 
     def __init__(self, data_len, delay, channel=1, dtype=np.float64):
-        self.data_len, self.n_delay = data_len, delay
-        self.buffer = np.zeros(((data_len + delay), channel), dtype=dtype)
+        self.data_len, self.n_delay = int(data_len), int(delay)
+        self._ring = np.zeros((self.data_len + self.n_delay, channel), dtype=dtype)
+        self._w = self.n_delay                      # next write position; the oldest sample still owed sits `delay` behind it
+
+    @property
+    def buffer(self):
+        """the line's content, oldest sample first (the reference object's `buffer` attribute after a call: its first `delay` rows)"""
+        return np.roll(self._ring, -(self._w - self.n_delay), axis=0)
 
     def delay(self, x):
-        if len(x.shape) == 1:
-            x = x[:, np.newaxis]
-        data_len = x.shape[0]
+        x = np.asarray(x)
+        if x.ndim == 1:
+            x = x[:, None]
         if self.n_delay == 0:
             return x
-        self.buffer[-data_len:, :] = x
-        output = self.buffer[:data_len, :].copy()
-        self.buffer[: self.n_delay, :] = self.buffer[-self.n_delay:, :]
-        return output
+        n, size = x.shape[0], self._ring.shape[0]
+        if n > self.data_len:
+            raise ValueError("DelaySamples was built for blocks of at most %d samples" % self.data_len)
+        w = (self._w + np.arange(n)) % size
+        self._ring[w] = x
+        out = self._ring[(w - self.n_delay) % size]
+        self._w = int((self._w + n) % size)
+        return out
 
 
 class TimeAlignment(object):

@@ -42,7 +42,8 @@
 extern "C" {
 #endif
 
-#define DS_VERSION 103
+#define DS_VERSION 104
+#define DS_STATE_LAYOUT 3   /* serialised arrangement of the carried state (checkpoint header; measurement records quote it) */
 
 /* error codes */
 #define DS_OK 0
@@ -166,6 +167,10 @@ typedef struct ds_config {
 #define DS_PARAM_MCSPP_REPEAT 14     /* int 0/1: DS_ALGO_MCSPP handles run estimation(repeat=True): a second estimation_core after the noise update (mcspp.py:280-282); default 0 */
 #define DS_PARAM_FDAF_TWO_PATH 16     /* int 0/1: FastFreqLms(two_path=True) — foreground / background filters with the 3 dB transfer rule
                                          (FastFreqLms.py:94-104,162-176); plain kind only; default 0 */
+#define DS_PARAM_TAIL_ASYNC 17        /* int 0/1, DS_ALGO_SUBBAND_GSC, before the first call: run the chain's tail kernel on a stream of its own.  Pays only
+                                         when the process's HIP runtime has >= 6 hardware queues per device (the APPLICATION sets GPU_MAX_HW_QUEUES=8
+                                         before its first HIP call; the runtime's default is 4 and the library cannot query it); default 0, or
+                                         DS_CHAIN_TAIL_ASYNC=1 in the environment at ds_create */
 #define DS_PARAM_POSTFILTER 15       /* int 0/1: DS_ALGO_TDGSC / DS_ALGO_FDGSC handles apply the OMLSA post-filter in ds_process_device; default 0 */
 #define DS_PARAM_SPLIT 8   /* int 1..8: utterance groups.  Fused frame kernels: ds_process_device_seq runs the utterance range as that many groups,
                               each on its own stream at its own pace (its own hipGraph with graph=1); default 2 from 2048 utterances up, else 1.
@@ -187,9 +192,15 @@ typedef struct ds_config {
 #define DS_FIELD_OLA_TAIL 12  /* [B][hop] of a beamformer object; [B][M][nfft - hop] of a DS_ALGO_TRANSFORM handle: Transform.previous_output */
 #define DS_FIELD_COUNTERS 13  /* int32 [B][4] {mcra.frm_cnt, mcra.ell, spp.frm_cnt, 0} */
 #define DS_FIELD_OP_STATE 14  /* frame-level objects: raw state [B][NF][KP] float32 (row map in distantspeech_amd/ops.py) */
+#define DS_FIELD_H 16          /* DS_ALGO_ADAPTIVE, methods src / DS / MVDR: [B][K][M][2] the weights the frame kernel applies to the next frame
+                                 (adaptivebeamformer.py:105-112: H[:, k]), computed by the kernel's own fused Cholesky solve on the handle's Rvv —
+                                 a read-only probe; needs ds_set_steering */
 #define DS_FIELD_NOTCH_MEM 15 /* DS_ALGO_FRONTEND: [B][M][2] the DC notch memories (FilterDcNotch16.notch_mem, feature.py:34,47) */
 
 int ds_version(void);
+/* one line identifying the build for measurement records and tests: version, state layout, optional kernel sets compiled in
+   ("shelved=1": the hop-pipelined and quad-lane experiment kernels, make SHELVED=1) */
+const char* ds_build_info(void);
 int ds_device_count(void);
 const char* ds_strerror(int code);
 

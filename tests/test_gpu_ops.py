@@ -908,7 +908,7 @@ def test_subband_gsc_fused_tail_and_pipelined_stages_equal_separate_kernels(ds, 
     default (ds_frames_kernel<.., ALGO_AIC>), and the chain is a three-stage pipeline over the blocks the caller has enqueued: front end
     of block t + 1 | McSpp + blocking filters of block t | tail of block t - 1, each on its own stream, double-buffered.
     DS_CHAIN_UNFUSED=1 keeps the three kernels the tail replaces, DS_CHAIN_SERIAL_FRONT=1 keeps every stage behind the previous one, and
-    with fewer than 6 hardware queues (GPU_MAX_HW_QUEUES) the tail stays on the chain's stream.  Same transforms, same per-bin
+    without DS_PARAM_TAIL_ASYNC / DS_CHAIN_TAIL_ASYNC=1 the tail stays on the chain's stream.  Same transforms, same per-bin
     arithmetic: every fused variant gives the same samples and the same state bit for bit; against the separate kernels the canceller's
     weights, tap buffer and power are bit-identical and the samples agree to the rounding of the two synthesis paths (the fused kernel
     adds the Nyquist bin by linearity)."""
@@ -922,14 +922,14 @@ def test_subband_gsc_fused_tail_and_pipelined_stages_equal_separate_kernels(ds, 
     res = {}
     for name, env in (("separate", dict(DS_CHAIN_UNFUSED="1", DS_CHAIN_SERIAL_FRONT="1")),
                       ("fused_serial", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="1")),
-                      ("fused_front", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", GPU_MAX_HW_QUEUES="4")),
+                      ("fused_front", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", DS_CHAIN_TAIL_ASYNC="0")),
                       # the pipeline as first built: joins, counter advance and the carried-block copy on the chain's own stream
-                      ("fused_pipeline_main_join", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", GPU_MAX_HW_QUEUES="8", DS_CHAIN_MAIN_JOIN="1")),
+                      ("fused_pipeline_main_join", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", DS_CHAIN_TAIL_ASYNC="1", DS_CHAIN_MAIN_JOIN="1")),
                       # lean chain stream, but the whole front end of block t + 2 behind the middle stages of block t
-                      ("fused_pipeline_no_early", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", GPU_MAX_HW_QUEUES="8", DS_CHAIN_NO_EARLY="1")),
+                      ("fused_pipeline_no_early", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", DS_CHAIN_TAIL_ASYNC="1", DS_CHAIN_NO_EARLY="1")),
                       # the tail's and the front end's streams at the greatest stream priority (the A/B switch of profiles/r03f/chain_prio_ab.txt)
-                      ("fused_pipeline_prio", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", GPU_MAX_HW_QUEUES="8", DS_CHAIN_PRIO="6")),
-                      ("fused_pipeline", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", GPU_MAX_HW_QUEUES="8"))):
+                      ("fused_pipeline_prio", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", DS_CHAIN_TAIL_ASYNC="1", DS_CHAIN_PRIO="6")),
+                      ("fused_pipeline", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", DS_CHAIN_TAIL_ASYNC="1"))):
         for k in ("DS_CHAIN_MAIN_JOIN", "DS_CHAIN_NO_EARLY", "DS_CHAIN_PRIO"):
             monkeypatch.setenv(k, "0")
         for k, v in env.items():

@@ -177,3 +177,33 @@ def test_wpe_mvdr_chain_with_wide_taps(ds):
     e = rms(ys[0][1] - ref)
     measured("cfg4_chain_10_taps", y_rms=e, y_ref_rms=rms(ref))
     assert e < 1e-4
+
+
+def test_chain_stays_finite_on_a_periodic_input(ds):
+    """fewer distinct frames than microphones (a period-3 frame sequence: three hops replayed, what a bench round of three steps feeds):
+    the noise covariance of the 8-microphone MVDR stage is rank 3 + 1e-6 I, cond 1e7 — fp32 Cholesky pivots of rounding-level size.
+    The pivots are floored at the diagonal loading (their lower bound in exact arithmetic): the chain's output stays finite and small
+    like the fp64 oracle's (found by bench.py --total-batch, round 4: NaN after ~200 replayed hops)."""
+    from oracle import ds_oracle as O
+    from distantspeech_amd import _lib as L
+    from distantspeech_amd.mic_array import MicArray
+    M, nfft, hop, B = 8, 1024, 512, 6
+    mic = MicArray(arrayType="circular", r=0.05, M=M, n_fft=nfft)
+    omic = O.OracleMicArray(arrayType="circular", r=0.05, M=M, n_fft=nfft)
+    ang = np.array([197, 0]) / 180 * np.pi
+    x = np.stack([O.synth_utterance(10 + b, hop * 4, omic) for b in range(B)])
+    tao = -1 * mic.r * np.cos(ang[1]) * np.cos(ang[0] - mic.gamma) / mic.c
+    a = np.exp(-1j * (2 * np.pi * np.arange(nfft // 2 + 1) * 16000 / nfft)[:, None] * tao[None, :])
+    eng = ds.BatchEngine(L.ALGO_WPE_MVDR, M, nfft, hop, batch=B, filter_len=2, rls_lambda=0.998)
+    eng.set_steering(a); eng.set_method(L.METHOD_MVDR)
+    eng.process(x[:, :, :hop], L.LAYOUT_CHANNELS_SAMPLES)
+    for r in range(110):
+        y = eng.process(x[:, :, hop:], L.LAYOUT_CHANNELS_SAMPLES)
+        assert np.all(np.isfinite(y)), r
+    o = O.OracleWpeMvdrPostfilter(omic, nfft=nfft, hop=hop, taps=2)
+    with np.errstate(all="ignore"):
+        o.process(x[0][:, :hop], ang)
+        for r in range(110):
+            ref = o.process(x[0][:, hop:], ang)
+    measured("cfg4_chain_periodic_input", y_rms=rms(y[0]), ref_rms=rms(ref), diff_rms=rms(y[0] - ref))
+    assert rms(y[0]) < 1e-3 and rms(y[0] - ref) < 1e-4
