@@ -403,7 +403,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->owns_stream = true; h->wpe_delay = 4; h->hist_cur = 0; h->group_enqueue = false;
     h->wpe_only = cfg->algo == DS_ALGO_WPE_TD;
     { const char* e = getenv("DS_WPE_GENERIC"); h->wpe_generic = (e && e[0] == '1') ? 1 : 0; }
-    { const char* e = getenv("DS_WPE_WIDE_NCH"); if (e && e[0] == '1') h->wpe_generic |= 2; }
+    { const char* e = getenv("DS_WPE_WIDE_NCH"); if (e && e[0] == '1') h->wpe_generic |= 2; if (e && e[0] == '2') h->wpe_generic |= 4; }
     h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;
@@ -1312,6 +1312,10 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
     DS_HIP(h, hipMemcpy(h->tail_out, s, tail_out_bytes(h), hipMemcpyHostToDevice)); s += tail_out_bytes(h);
     DS_HIP(h, hipMemcpy(h->counters, s, counters_bytes(h), hipMemcpyHostToDevice)); s += counters_bytes(h);
     if (opst_bytes(h)) DS_HIP(h, hipMemcpy(h->opst, s, opst_bytes(h), hipMemcpyHostToDevice));
+    // the WPE recursion never touches Im(P_ii) (it is +0 from the initial state on and the downdate keeps it there): a blob that carries
+    // anything else on the diagonal would keep it for good, so an imported state is cleaned once here, not every frame in the kernel
+    if (h->op == ds::OP_WPE && opst_bytes(h))
+        DS_HIP(h, ds::launch_wpe_fix_diag(h->opst, h->cfg.batch, h->K, (long long)op_ust(h), h->cfg.n_mics, h->filter_len, h->stream));
     s += opst_bytes(h);
     int uc[4];
     std::memcpy(uc, s, sizeof uc);

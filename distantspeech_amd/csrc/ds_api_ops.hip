@@ -269,7 +269,7 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, 
     const int band_n = (int)(2000.0 * (2 * (h->K - 1)) / 16000.0) - (int)(500.0 * (2 * (h->K - 1)) / 16000.0);
     const bool qavg_in_kernel = n_frames <= 64 && band_n > 0 && band_n <= 64;
     if (!qavg_in_kernel) DS_HIP(h, ds::launch_mcspp_qavg(h->dev_buf[3], h->dev_buf[3] + n, (int)nbt, h->K, h->stream));
-    p.in1 = h->dev_buf[3]; p.in2 = qavg_in_kernel ? nullptr : h->dev_buf[3] + n; p.N = 9;
+    p.in1 = h->dev_buf[3]; p.in2 = qavg_in_kernel ? nullptr : h->dev_buf[3] + n;      // (the McSpp rows start at the constexpr MCSPP_ROW0: nothing to pass)
     p.out0 = dout[0]; p.out1 = dout[1]; p.out2 = dout[2]; p.out3 = dout[3]; p.out4 = dout[4];
     // three builds of the same estimation: with the notebook-MVDR / matrix outputs, lean (p and the optional PMWF weights), and the lean
     // one for calls that start at frame 5 or later without weights (no second factorisation in the kernel: two waves per SIMD at 6 mics)
@@ -289,7 +289,7 @@ int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* ga
     p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames; p.st = h->opst; p.NF = h->NF; p.M = h->cfg.n_mics;
     p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = 65;
     p.dev_cnt = h->use_dev_cnt ? h->dev_cnt : nullptr;
-    p.in0 = y; p.in1 = gamma; p.in2 = qavg; p.N = 9;
+    p.in0 = y; p.in1 = gamma; p.in2 = qavg;
     p.out0 = p_out;
     p.repeat = h->mcspp_repeat;
     take_tick(h, h->stream, p.tick);

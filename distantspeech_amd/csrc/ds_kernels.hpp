@@ -50,7 +50,8 @@ hipError_t launch_mcspp_qavg(const float* gamma, float* out, int rows, int K, hi
 struct WpeParams;
 hipError_t launch_wpe(const WpeParams& p, int generic, hipStream_t stream);          // C N <= 16 (ds_wpe.hpp)
 hipError_t launch_wpe_wide(const WpeParams& p, int generic, hipStream_t stream);     // 16 < C N <= 80: one wavefront per bin (ds_kernels_wpe.hip)
-hipError_t launch_wpe_init(float* state, int B, int K, long long ustride, int C, int N, hipStream_t stream);   // P = 1e-3 I, the rest zero (awpe.py:58-77)
+hipError_t launch_wpe_init(float* state, int B, int K, long long ustride, int C, int N, hipStream_t stream);
+hipError_t launch_wpe_fix_diag(float* state, int B, int K, long long ustride, int C, int N, hipStream_t stream);   // Im(P_ii) = 0 (an imported state)   // P = 1e-3 I, the rest zero (awpe.py:58-77)
 hipError_t launch_mvdr_probe(int M, const float* bins, long long ust, int KP, int NF, int B, int K, const float* steer, long long steer_batch_stride,
                              float diag, int method, float* H, hipStream_t stream);   // DS_FIELD_H (ds_kernels_adaptive.hip)
 struct FdafParams;
@@ -110,6 +111,12 @@ template <class Rg, int HOIST = 0> struct HipExec {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
     }
     __device__ __forceinline__ void lds_load_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // ... all but the N youngest vector-memory operations of the wave (loads, stores and LDS-DMA count together, in issue order): a chunk
+    // is complete while the next one's N pieces are still in flight
+    template <int N> __device__ __forceinline__ void lds_load_wait_keep() {
+        if constexpr (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N < 63 ? N : 63) : "memory");
+    }
     template <class FL, class FR> __device__ __forceinline__ void phase_wave2(FL fl, FR fr) {
         int tid = (int)threadIdx.x;
         DS_LAUNDER(tid);
@@ -150,12 +157,13 @@ constexpr int frames_hoist(int nfft, int M, int algo, bool ryy) {
     return 0;
 #endif
 }
-constexpr int frames_min_waves(int M, int algo) {
-    return (M <= 4 && (algo == ALGO_GSC || algo == ALGO_ADAPTIVE)) ? 4 : (M == 6 && algo == ALGO_AIC) ? 3 : 1;
+// (with Ryy — the Python mirror's objects and TFGSC — the 4-microphone program does not fit 128 registers without scratch: three waves)
+constexpr int frames_min_waves(int M, int algo, bool ryy = false) {
+    return (M <= 4 && (algo == ALGO_GSC || algo == ALGO_ADAPTIVE)) ? (ryy && M == 4 ? 3 : 4) : (M == 6 && algo == ALGO_AIC) ? 3 : 1;
 }
 
 template <int NFFT, int M, int ALGO, bool RYY>
-__global__ void __launch_bounds__(NFFT / 2, frames_min_waves(M, ALGO)) ds_frames_kernel(Params p) {
+__global__ void __launch_bounds__(NFFT / 2, frames_min_waves(M, ALGO, RYY)) ds_frames_kernel(Params p) {
     typedef Engine<NFFT, M, ALGO, RYY> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg, frames_hoist(NFFT, M, ALGO, RYY)> ex;

@@ -5,9 +5,9 @@
 
 namespace ds {
 
-template <int CNP, int NCH, int CT = 0, int NTAPS = 0>
+template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false>
 __global__ void __launch_bounds__(WPEW_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) ds_wpe_wide_kernel(WpeParams p) {
-    typedef WpeWideEngine<CNP, NCH, CT, NTAPS> E;
+    typedef WpeWideEngine<CNP, NCH, CT, NTAPS, DB> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
     E::run(ex, p, (int)blockIdx.x, sh);
@@ -26,9 +26,13 @@ hipError_t launch_wpe_wide(const WpeParams& p, int generic, hipStream_t stream) 
         if (p.C == 4 && p.N == 20) DS_WPEW(80, 1, 4, 20);
         if (p.C == 8 && p.N == 10) DS_WPEW(80, 1, 8, 10);
     }
-    if (!(generic & 1)) {
+    if (generic & 4) {                                   // DS_WPE_WIDE_NCH=2: two chunks through one tile, one after the other (round 4's first form); A/B runs
         if (p.C == 4 && p.N == 20) DS_WPEW(80, 2, 4, 20);
         if (p.C == 8 && p.N == 10) DS_WPEW(80, 2, 8, 10);
+    }
+    if (!(generic & 1)) {                                // default: four chunks through two tile buffers as a pipeline
+        if (p.C == 4 && p.N == 20) DS_WPEW(80, 4, 4, 20, true);
+        if (p.C == 8 && p.N == 10) DS_WPEW(80, 4, 8, 10, true);
     }
     if (CN <= 32) DS_WPEW(32, 1);
     if (CN <= 64) DS_WPEW(64, 2);
@@ -37,18 +41,24 @@ hipError_t launch_wpe_wide(const WpeParams& p, int generic, hipStream_t stream) 
 }
 
 // P = 1e-3 I (the diagonal words of the packed triangle, awpe.py:69-73) on a zeroed state: one thread per (utterance, bin, tap)
-__global__ void __launch_bounds__(256) ds_wpe_init_kernel(float* state, long long n, int K, long long ustride, int SB, int CN) {
+template <bool INIT> __global__ void __launch_bounds__(256) ds_wpe_init_kernel(float* state, long long n, int K, long long ustride, int SB, int CN) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= n) return;
     const int i = (int)(g % CN);
     const long long bk = g / CN, b = bk / K, k = bk - b * K;
-    state[b * ustride + k * SB + 2 * (wpew_words(i) + i)] = 1e-3f;
+    float* pii = state + b * ustride + k * SB + 2 * (wpew_words(i) + i);
+    if (INIT) pii[0] = 1e-3f; else pii[1] = 0.0f;       // the diagonal word of the packed triangle: P_ii = 1e-3 / Im(P_ii) = 0
 }
 hipError_t launch_wpe_init(float* state, int B, int K, long long ustride, int C, int N, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(state, 0, (size_t)B * (size_t)ustride * sizeof(float), stream);
     if (e != hipSuccess) return e;
     const long long n = (long long)B * K * C * N;
-    hipLaunchKernelGGL(ds_wpe_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, state, n, K, ustride, wpe_bin_floats(C, N), C * N);
+    hipLaunchKernelGGL(ds_wpe_init_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, state, n, K, ustride, wpe_bin_floats(C, N), C * N);
+    return hipGetLastError();
+}
+hipError_t launch_wpe_fix_diag(float* state, int B, int K, long long ustride, int C, int N, hipStream_t stream) {
+    const long long n = (long long)B * K * C * N;
+    hipLaunchKernelGGL(ds_wpe_init_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, state, n, K, ustride, wpe_bin_floats(C, N), C * N);
     return hipGetLastError();
 }
 

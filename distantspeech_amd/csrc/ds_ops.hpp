@@ -112,8 +112,8 @@ __device__ inline StRef st_at(const OpCtx& p, int b, int f, int k) {
 }
 // one whole float4 plane group q (floats 4 q .. 4 q + 3) of bin k as ONE 16-byte access
 // (four dword loads at consecutive immediate offsets: the backend merges them into one buffer_load_dwordx4.  ROCm 7.2's
-// __builtin_amdgcn_raw_buffer_load_b128 is lowered to a ONE-dword load — three result words undefined — so it is not used; the b128
-// STORE builtin below is lowered correctly, and single-dword stores are not merged reliably)
+// __builtin_amdgcn_raw_buffer_load_b128 is lowered to a ONE-dword load — three result words undefined — so it is not used.  Neither is
+// the b128 STORE builtin: see st_store4)
 __device__ inline void st_load4(const OpCtx& p, int b, int q, int k, float* d) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) d[j] = st_at(p, b, 4 * q + j, k);
@@ -1179,12 +1179,13 @@ template <int M> DS_HD void op_gev(const OpCtx& p, int b, int k) {
 #pragma unroll
         for (int j = i + 1; j < M; ++j) { A[i][j] = cdconj(A[j][i]); N[i][j] = cdconj(N[j][i]); }
     }
-    if (!herm_gev_principal_d<M>(A, N, v)) {             // :94-96: ones / trace(noise) * sensors
-        double tr = 0.0;
+    if (!herm_gev_principal_d<M>(A, N, v)) {             // :94-96: ones / trace(noise) * sensors — the COMPLEX trace of the matrix as given
+        double trx = 0.0, try_ = 0.0;                    // (its diagonal's imaginary parts as they came in: np.trace does not symmetrise)
 #pragma unroll
-        for (int i = 0; i < M; ++i) tr += N[i][i].x;
+        for (int i = 0; i < M; ++i) { trx += (double)p.in1[2 * (base + i * M + i)]; try_ += (double)p.in1[2 * (base + i * M + i) + 1]; }
+        const double d = trx * trx + try_ * try_;
 #pragma unroll
-        for (int i = 0; i < M; ++i) v[i] = mkd((double)M / tr, 0.0);
+        for (int i = 0; i < M; ++i) v[i] = mkd((double)M * trx / d, -(double)M * try_ / d);
     }
 #pragma unroll
     for (int m = 0; m < M; ++m) { p.out0[2 * (ob + m)] = (float)v[m].x; p.out0[2 * (ob + m) + 1] = (float)v[m].y; }
@@ -1313,17 +1314,19 @@ inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE 
 // is (op, M) a supported combination?  (matrix operators: M in {2, 4, 6, 8}; McSpp / steering / mvdr weight: {2, 4, 6})
 inline bool op_supported(int op, int M) {
     if (op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_ADAPTIVE) return M == 2 || M == 4 || M == 6 || M == 8;
-    if (op == OP_MCSPP || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY || op_is_linalg(op)) return M == 2 || M == 4 || M == 6;
+    if (op == OP_MCSPP || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY) return M == 2 || M == 4 || M == 6;
+    if (op_is_linalg(op)) return M >= 2 && M <= 6;          // the stateless helpers also for the 3- and 5-microphone arrays the frame kernels take
     return true;
 }
 
 #define DS_OP_M_LIST(X, OP_) X(OP_, 2) X(OP_, 4) X(OP_, 6) X(OP_, 8)
 #define DS_OP_M3_LIST(X, OP_) X(OP_, 2) X(OP_, 4) X(OP_, 6)
+#define DS_OP_ML_LIST(X, OP_) X(OP_, 2) X(OP_, 3) X(OP_, 4) X(OP_, 5) X(OP_, 6)
 #define DS_FOR_EACH_OP(X) \
     X(OP_MCRA, 1) X(OP_OMLSA, 1) X(OP_SUBLMS, 1) X(OP_SUBRLS, 1) X(OP_MCCDR, 1) \
     DS_OP_M_LIST(X, OP_MCMCRA) DS_OP_M_LIST(X, OP_MCSPPBASE) DS_OP_M_LIST(X, OP_ADAPTIVE) \
-    DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_MCSPP_LEAN) DS_OP_M3_LIST(X, OP_MCSPP_STEADY) DS_OP_M3_LIST(X, OP_STEERING) DS_OP_M3_LIST(X, OP_MVDRW) \
-    DS_OP_M3_LIST(X, OP_PMWFW) DS_OP_M3_LIST(X, OP_GEV) DS_OP_M3_LIST(X, OP_BAN) DS_OP_M3_LIST(X, OP_PHASECORR)
+    DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_MCSPP_LEAN) DS_OP_M3_LIST(X, OP_MCSPP_STEADY) DS_OP_ML_LIST(X, OP_STEERING) DS_OP_ML_LIST(X, OP_MVDRW) \
+    DS_OP_ML_LIST(X, OP_PMWFW) DS_OP_ML_LIST(X, OP_GEV) DS_OP_ML_LIST(X, OP_BAN) DS_OP_ML_LIST(X, OP_PHASECORR)
 
 // runtime dispatch for the serial CPU run in tests/emul (the GPU launches one specialised kernel per (OP, M))
 inline void run_op(int op, const OpCtx& p, int b, int k) {

@@ -60,9 +60,12 @@ template <int CNP, int NCH> struct WpeWideDims {
     static constexpr int TILE = tile_words();
 };
 
-template <int CNP, int NCH> struct WpeWideShared {
+template <int CNP, int NCH, bool DB = false, bool GEO = true> struct WpeWideShared {
     typedef WpeWideDims<CNP, NCH> D;
-    alignas(16) cf tile[D::TILE + WPEW_NT];    // + a spare word per lane: where a lane stores what is not part of the packed triangle
+    // spare: a word per lane, where a lane stores what is not part of the packed triangle.
+    // DB: two buffers, chunk h + 2 lands while chunk h + 1 is taken apart
+    alignas(16) cf tile[DB ? 2 : 1][D::TILE];
+    alignas(16) cf spare[WPEW_NT];
     alignas(16) cf X[2][D::XP + WPE_CMAX];     // tap buffer, double-buffered; [XP + c] = the frame's delayed input of channel c
     alignas(16) cf g[D::XP];                   // g = P x
     alignas(16) cf red[WPEW_NT];               // a lane's share of the filter output of its channel
@@ -71,7 +74,7 @@ template <int CNP, int NCH> struct WpeWideShared {
     alignas(16) float p16[16];
     float ks;                                  // kn = h ks
     cf d[WPE_CMAX], err[WPE_CMAX];
-    int geo[4][WPEW_NT];                       // run-time shapes: a lane's tap sources and W strip (src0, src1, wc, wi0)
+    int geo[GEO ? 4 : 1][GEO ? WPEW_NT : 1];   // run-time shapes: a lane's tap sources and W strip (src0, src1, wc, wi0)
 };
 
 template <int CNP, int NCH> struct WpeWideRegs {
@@ -85,9 +88,13 @@ template <int CNP, int NCH> struct WpeWideRegs {
 };
 
 // CT > 0: the channel count as a compile-time constant (strip geometry and the channel loops fold); NTAPS with it
-template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
+// DB (compile-time shapes only): the chunks through two tile buffers as a pipeline — every load of the prologue (the strips of W, var, the
+// frame's inputs, the taps and the first TWO chunks) is in flight before the first wait, and chunk h + 2 is requested as soon as chunk h has
+// been taken apart: one exposed HBM latency per call instead of one per chunk plus one for the small parts.
+template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false> struct WpeWideEngine {
     typedef WpeWideDims<CNP, NCH> D;
-    typedef WpeWideShared<CNP, NCH> Sh;
+    typedef WpeWideShared<CNP, NCH, DB, CT == 0> Sh;
+    static_assert(!DB || (CT > 0 && NTAPS > 0), "the pipelined form counts its loads at compile time");
     typedef WpeWideRegs<CNP, NCH> Rg;
     static constexpr int NT = WPEW_NT, RL = D::RL, XR = D::XR, QW = D::QW, SLP = D::SLP, XP = D::XP;
     static_assert(CT * NTAPS <= CNP, "shape");
@@ -110,7 +117,10 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
         // wc, wi0: channel (or -1) and first tap of the lane's strip of W
         auto src0_of = [&](int l, const Rg&) { return CT > 0 ? src_of(l) : sh.geo[0][l]; };
         auto src1_of = [&](int l, const Rg&) { return CT > 0 ? src_of(64 + l) : sh.geo[1][l]; };
-        auto wc_of = [&](int l, const Rg&) { if (CT > 0) { const int c = l / LPC; return c < C ? c : -1; } return sh.geo[2][l]; };
+        // (ALLW: every lane has a strip — C a power of two and LPC SL == CN: no lane predicate around the strip's loads, whose results a
+        // predicate would make the compiler wait for on the spot)
+        constexpr bool ALLW = CT > 0 && (CT & (CT - 1)) == 0 && ((CT * NTAPS) % (NT / (CT > 0 ? CT : 1))) == 0;
+        auto wc_of = [&](int l, const Rg&) { if (ALLW) return l / LPC; if (CT > 0) { const int c = l / LPC; return c < C ? c : -1; } return sh.geo[2][l]; };
         auto wi0_of = [&](int l, const Rg&) { return CT > 0 ? (l % LPC) * SL : sh.geo[3][l]; };
         auto io_at = [&](const Rg& r, int t) { return r.io0 + (long long)t * fstride; };
         auto ring_slot = [&](const Rg& r, int s) { return r.ring0 + (long long)s * fstride; };
@@ -127,17 +137,17 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
         // global <-> tile, 16-byte pieces (two packed words), consecutive lanes on consecutive pieces; words [w0, w1), w0 even
         // (inbound as LDS-DMA: the 13 .. 26 one-KiB pieces of a chunk are all in flight at once and take no registers — with ordinary loads
         // the copy loop ran load, wait, store piece by piece: two HBM latencies per KiB, 39 us per bin at one frame per call)
-        auto tile_in = [&](int tid, int w0, int w1) {
+        auto tile_in = [&](int tid, int w0, int w1, int buf, bool wait) {
             const int we = w1 & ~1;
             for (int w = w0; w < we; w += 2 * NT)
-                if (w + 2 * tid < we) ex.lds_load16(&sh.tile[w - w0], tid, &st[w + 2 * tid]);
-            if ((w1 & 1) && tid == 0) sh.tile[w1 - 1 - w0] = st[w1 - 1];
-            ex.lds_load_wait();
+                if (w + 2 * tid < we) ex.lds_load16(&sh.tile[buf][w - w0], tid, &st[w + 2 * tid]);
+            if ((w1 & 1) && tid == 0) sh.tile[buf][w1 - 1 - w0] = st[w1 - 1];
+            if (wait) ex.lds_load_wait();
         };
-        auto tile_out = [&](int tid, int w0, int w1) {
+        auto tile_out = [&](int tid, int w0, int w1, int buf) {
             const int we = w1 & ~1;
-            for (int w = w0 + 2 * tid; w < we; w += 2 * NT) *reinterpret_cast<vec4*>(&st[w]) = *reinterpret_cast<const vec4*>(&sh.tile[w - w0]);
-            if ((w1 & 1) && tid == 0) st[w1 - 1] = sh.tile[w1 - 1 - w0];
+            for (int w = w0 + 2 * tid; w < we; w += 2 * NT) *reinterpret_cast<vec4*>(&st[w]) = *reinterpret_cast<const vec4*>(&sh.tile[buf][w - w0]);
+            if ((w1 & 1) && tid == 0) st[w1 - 1] = sh.tile[buf][w1 - 1 - w0];
         };
 
         // ---- prologue: registers and LDS to zero, geometry, first frame's inputs, the small parts of the state
@@ -149,23 +159,33 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
             for (int j = 0; j < QW; ++j) r.Pb[j] = z;
 #pragma unroll
             for (int s = 0; s < SLP; ++s) r.W[s] = z;
-            for (int i = l; i < XP + WPE_CMAX; i += NT) { sh.X[0][i] = z; sh.X[1][i] = z; }
+            for (int i = l; i < XP + WPE_CMAX; i += NT) { if (!DB || i >= CN) sh.X[0][i] = z; sh.X[1][i] = z; }
             for (int i = l; i < XP; i += NT) { sh.g[i] = z; sh.dre[i] = 0.0f; }
             sh.red[l] = z; sh.q[l] = z;
             const int c = l / LPC, sub = l - c * LPC;
-            const int wc = c < C ? c : -1, wi0 = sub * SL;
-            if (CT == 0) { sh.geo[0][l] = src_of(l); sh.geo[1][l] = XR > 0 ? src_of(64 + l) : -1; sh.geo[2][l] = wc; sh.geo[3][l] = wi0; }
-            if (wc >= 0) {
+            const int wc = (ALLW || c < C) ? c : -1, wi0 = sub * SL;
+            if constexpr (CT == 0) { sh.geo[0][l] = src_of(l); sh.geo[1][l] = XR > 0 ? src_of(64 + l) : -1; sh.geo[2][l] = wc; sh.geo[3][l] = wi0; }
+            if (ALLW || wc >= 0) {
 #pragma unroll
                 for (int s = 0; s < SLP; ++s)
-                    if (s < SL && wi0 + s < CN) r.W[s] = st[NPK + wc * CN + wi0 + s];
+                    if (s < SL && (ALLW || wi0 + s < CN)) r.W[s] = st[NPK + wc * CN + wi0 + s];
             }
             r.var = stf[2 * (NPK + C * CN + CN)];
             r.io0 = (ub * p.T * p.K + kb) * C;
             r.ring0 = p.ring != nullptr ? (ub * p.ring_len * p.K + kb) * C : 0;
             r.xin = z; r.din = z;
             if (l < C) { r.xin = delayed(r, 0, l); r.din = mk(p.d[2 * (r.io0 + l)], p.d[2 * (r.io0 + l) + 1]); }
+            if constexpr (DB) {
+                // the taps (CN words, contiguous, 16-byte aligned for these shapes) and the first two chunks: all requested here, behind the
+                // loads above; nothing of this phase is used before the first chunk's wait, which retires everything older than chunk 1
+                static_assert(((wpe_packed(CT * NTAPS) + CT * CT * NTAPS) & 1) == 0 && ((CT * NTAPS) & 1) == 0, "tap block alignment");
+                if (2 * l < CN) ex.lds_load16(&sh.X[0][0], l, &st[NPK + C * CN + 2 * l]);
+                constexpr int wa = wpew_words(D::col0(0)), wb = wpew_words(D::col0(1)), wc2 = wpew_words(D::col0(NCH > 1 ? 2 : 1));
+                tile_in(l, wa, wb, 0, false);
+                if constexpr (NCH > 1) tile_in(l, wb, wc2, 1, false);
+            }
         });
+        if constexpr (!DB)
         ex.phase_wave([&](int l, Rg&) {                               // (after the zero fill: the taps as stored)
             for (int i = l; i < CN; i += NT) sh.X[0][i] = st[NPK + C * CN + i];
         });
@@ -175,7 +195,14 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
             if (c0 >= CN) return;
             const int c1 = c1r < CN ? c1r : CN;                         // columns [c0, c1) of the CN the state has
             const int w1 = wpew_words(c1);
-            ex.phase_wave([&](int l, Rg&) { tile_in(l, w0, w1); });
+            constexpr int buf = DB ? (H & 1) : 0;
+            if constexpr (DB) {
+                // chunk H was requested two steps ago; only chunk H + 1's pieces (issued after it) may still be in flight
+                constexpr int younger = H + 1 < NCH ? (wpew_words(D::col0(H + 2 > NCH ? NCH : H + 2)) - wpew_words(D::col0(H + 1)) + 2 * NT - 1) / (2 * NT) : 0;
+                ex.phase_wave([&](int, Rg&) { ex.template lds_load_wait_keep<younger>(); });
+            } else {
+                ex.phase_wave([&](int l, Rg&) { tile_in(l, w0, w1, 0, true); });
+            }
             // a lane's predicate does not depend on the column: for the chunk's own columns q every row i < c1 takes exactly one word (its
             // stored (i, q) when i <= q, the conjugate of its own column's (q, i) otherwise: then c0 <= q < i < c1), and for the columns in
             // front of the chunk the rows inside it take the conjugates of their column — two straight-line loops under one lane mask each
@@ -188,12 +215,12 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
                     for (int q = c0; q < c1r; ++q)
                         if (q < c1) {                                   // (uniform; folds for the compile-time shapes)
                             const bool up = i <= q;
-                            const cf v = sh.tile[up ? wpew_words(q) - w0 + i : lowbase + q];
+                            const cf v = sh.tile[buf][up ? wpew_words(q) - w0 + i : lowbase + q];
                             r.Pa[q] = mk(v.x, up ? v.y : -v.y);
                         }
                     if (i >= c0) {
 #pragma unroll
-                        for (int q = 0; q < c0; ++q) r.Pa[q] = cconj(sh.tile[lowbase + q]);
+                        for (int q = 0; q < c0; ++q) r.Pa[q] = cconj(sh.tile[buf][lowbase + q]);
                     }
                 }
                 if constexpr (XR > 0 && c1r > 64) {                     // the split rows 64 .. : all in the chunks that reach beyond column 64
@@ -206,7 +233,7 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
                                 const int cq = cq0 + j;
                                 if (cq < CN) {
                                     const bool up = e <= cq;
-                                    const cf v = sh.tile[up ? wpew_words(cq) - w0 + e : ebase + cq];
+                                    const cf v = sh.tile[buf][up ? wpew_words(cq) - w0 + e : ebase + cq];
                                     r.Pb[j] = mk(v.x, up ? v.y : -v.y);
                                 }
                             }
@@ -219,13 +246,17 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
                             const bool up = e <= cq;
                             const bool ok = (up ? (cq >= c0 && cq < c1) : (ein && cq < CN)) && e < CN;
                             if (ok) {
-                                const cf v = sh.tile[up ? wpew_words(cq) - w0 + e : ebase + cq];
+                                const cf v = sh.tile[buf][up ? wpew_words(cq) - w0 + e : ebase + cq];
                                 r.Pb[j] = mk(v.x, up ? v.y : -v.y);
                             }
                         }
                     }
                 }
             });
+            if constexpr (DB && H + 2 < NCH) {                          // this buffer is free again (every lane has taken its words): the chunk after next
+                constexpr int wn0 = wpew_words(D::col0(H + 2)), wn1 = wpew_words(D::col0(H + 3));
+                ex.phase_wave([&](int l, Rg&) { tile_in(l, wn0, wn1, buf, false); });
+            }
         };
         load_chunk(std::integral_constant<int, 0>());
         if constexpr (NCH > 1) load_chunk(std::integral_constant<int, 1>());
@@ -387,21 +418,22 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
             if (c0 >= CN) return;
             const int c1 = c1r < CN ? c1r : CN;
             const int w1 = wpew_words(c1);
+            constexpr int buf = DB ? (H & 1) : 0;
             ex.phase_wave([&](int l, Rg& r) {
                 const int i = l;
 #pragma unroll
                 for (int q = c0; q < c1r; ++q)
-                    if (q < c1) sh.tile[i <= q ? wpew_words(q) - w0 + i : D::TILE + l] = r.Pa[q];     // rows below the diagonal: a spare word of the lane's own
+                    if (q < c1) *(i <= q ? &sh.tile[buf][wpew_words(q) - w0 + i] : &sh.spare[l]) = r.Pa[q];     // rows below the diagonal: a spare word of the lane's own
                 if constexpr (XR > 0 && c1r > 64) {
                     const int e = 64 + (l >> 2), cq0 = (l & 3) * QW;
 #pragma unroll
                     for (int j = 0; j < QW; ++j) {
                         const int cq = cq0 + j;
-                        sh.tile[(cq >= c0 && cq < c1 && e <= cq) ? wpew_words(cq) - w0 + e : D::TILE + l] = r.Pb[j];
+                        *((cq >= c0 && cq < c1 && e <= cq) ? &sh.tile[buf][wpew_words(cq) - w0 + e] : &sh.spare[l]) = r.Pb[j];
                     }
                 }
             });
-            ex.phase_wave([&](int l, Rg&) { tile_out(l, w0, w1); });
+            ex.phase_wave([&](int l, Rg&) { tile_out(l, w0, w1, buf); });
         };
         store_chunk(std::integral_constant<int, 0>());
         if constexpr (NCH > 1) store_chunk(std::integral_constant<int, 1>());

@@ -47,6 +47,7 @@ for spec in sys.argv[1:]:
         kl = v.get("SQ_LDS_IDX_ACTIVE", 0.0) * per_step
         valu += kv; lds += kl; insts += v["SQ_INSTS_VALU"] * per_step
         ent["kernels"][k] = {"launches_per_step": per_step, "SQ_INSTS_VALU": v["SQ_INSTS_VALU"], "cycles_per_valu": cpv,
+                             "static_valu": m["valu"] if m else None,     # vector instructions of the kernel in the library the profile was made with (tests/test_profiles_fresh.py)
                              "SQ_LDS_IDX_ACTIVE": v.get("SQ_LDS_IDX_ACTIVE"), "GRBM_GUI_ACTIVE_per_xcd": v.get("GRBM_GUI_ACTIVE", 0.0) / 8,
                              "SQ_WAIT_ANY_share_of_wave_cycles": (v.get("SQ_WAIT_ANY", 0.0) / v["SQ_WAVE_CYCLES"]) if v.get("SQ_WAVE_CYCLES") else None}
     ent["valu_instructions_per_frame"] = insts / frames

@@ -574,6 +574,32 @@ def test_committed_traffic_matches_this_builds_state_layout(ds, cfg, algo_name, 
     assert abs(pmc / analytic - 1.0) < 0.02, (pmc, analytic)
 
 
+@pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])
+def test_committed_traffic_matches_this_builds_stage_budgets(ds, cfg):
+    """the chains: bench.py's live `roofline.achieved` is the per-kernel byte budget of a step (scripts/stage_budget.py: every kernel's
+    share of the state once in and once out + the arrays its stage reads and writes, sizes from ds_chain_stage_info of a handle of the
+    bench's shape), `frac_measured` the committed PMC bytes (profiles/traffic_latest.json).  A stage that starts moving more bytes, or a
+    stale profile, shows here: the two must agree within 3 %."""
+    import json
+    import sys
+    from distantspeech_amd import _lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    try:
+        import stage_budget
+    finally:
+        sys.path.pop(0)
+    import bench
+    w = bench.WORKLOADS[cfg]
+    pmc = json.load(open(os.path.join(root, "profiles", "traffic_latest.json")))[cfg]["hbm_bytes_per_launch"]
+    eng = ds.BatchEngine(getattr(L, "ALGO_" + w["algo"]), w["M"], w["nfft"], w["hop"], batch=w["batch"], filter_len=w.get("filter_len", 0),
+                         rls_lambda=w.get("rls_lambda", 0.0))
+    budget = stage_budget.minimal_step_bytes(cfg, w, eng, w["batch"])
+    eng.close()
+    measured("traffic_vs_budget_" + cfg, pmc_bytes=pmc, budget_bytes=budget, ratio=pmc / budget)
+    assert abs(pmc / budget - 1.0) < 0.03, (pmc, budget)
+
+
 def test_realtime_chunk_latency_within_budget(ds):
     """the reference's realtime contract (realtime/realtime_processing.py:113-136): one 1024-sample chunk of the 6-channel int16 stream
     must be done within its own duration (64 ms).  One stream through ds_process_pcm16 (host buffers, PCIe included): p99 over 400 chunks."""
