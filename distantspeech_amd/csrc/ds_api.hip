@@ -403,7 +403,6 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->owns_stream = true; h->wpe_delay = 4; h->hist_cur = 0; h->group_enqueue = false;
     h->wpe_only = cfg->algo == DS_ALGO_WPE_TD;
     { const char* e = getenv("DS_WPE_GENERIC"); h->wpe_generic = (e && e[0] == '1') ? 1 : 0; }
-    { const char* e = getenv("DS_WPE_WIDE_NCH"); if (e && e[0] == '1') h->wpe_generic |= 2; if (e && e[0] == '2') h->wpe_generic |= 4; }
     h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
     h->mcra_L = cfg->mcra_L > 0 ? cfg->mcra_L : 15;

@@ -111,12 +111,6 @@ template <class Rg, int HOIST = 0> struct HipExec {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
     }
     __device__ __forceinline__ void lds_load_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    // ... all but the N youngest vector-memory operations of the wave (loads, stores and LDS-DMA count together, in issue order): a chunk
-    // is complete while the next one's N pieces are still in flight
-    template <int N> __device__ __forceinline__ void lds_load_wait_keep() {
-        if constexpr (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N < 63 ? N : 63) : "memory");
-    }
     template <class FL, class FR> __device__ __forceinline__ void phase_wave2(FL fl, FR fr) {
         int tid = (int)threadIdx.x;
         DS_LAUNDER(tid);

@@ -5,9 +5,9 @@
 
 namespace ds {
 
-template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false>
+template <int CNP, int NCH, int CT = 0, int NTAPS = 0>
 __global__ void __launch_bounds__(WPEW_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) ds_wpe_wide_kernel(WpeParams p) {
-    typedef WpeWideEngine<CNP, NCH, CT, NTAPS, DB> E;
+    typedef WpeWideEngine<CNP, NCH, CT, NTAPS> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg> ex;
     E::run(ex, p, (int)blockIdx.x, sh);
@@ -22,17 +22,9 @@ hipError_t launch_wpe_wide(const WpeParams& p, int generic, hipStream_t stream) 
     const long long blocks = (long long)p.B * p.K;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
 #define DS_WPEW(...) do { hipLaunchKernelGGL((ds_wpe_wide_kernel<__VA_ARGS__>), dim3((unsigned)blocks), dim3(WPEW_NT), 0, stream, p); return hipGetLastError(); } while (0)
-    if (generic & 2) {                                   // DS_WPE_WIDE_NCH=1: the whole triangle through one 26 KB tile (five wavefronts per CU); A/B runs
-        if (p.C == 4 && p.N == 20) DS_WPEW(80, 1, 4, 20);
-        if (p.C == 8 && p.N == 10) DS_WPEW(80, 1, 8, 10);
-    }
-    if (generic & 4) {                                   // DS_WPE_WIDE_NCH=2: two chunks through one tile, one after the other (round 4's first form); A/B runs
+    if (!(generic & 1)) {
         if (p.C == 4 && p.N == 20) DS_WPEW(80, 2, 4, 20);
         if (p.C == 8 && p.N == 10) DS_WPEW(80, 2, 8, 10);
-    }
-    if (!(generic & 1)) {                                // default: four chunks through two tile buffers as a pipeline
-        if (p.C == 4 && p.N == 20) DS_WPEW(80, 4, 4, 20, true);
-        if (p.C == 8 && p.N == 10) DS_WPEW(80, 4, 8, 10, true);
     }
     if (CN <= 32) DS_WPEW(32, 1);
     if (CN <= 64) DS_WPEW(64, 2);

@@ -60,11 +60,10 @@ template <int CNP, int NCH> struct WpeWideDims {
     static constexpr int TILE = tile_words();
 };
 
-template <int CNP, int NCH, bool DB = false, bool GEO = true> struct WpeWideShared {
+template <int CNP, int NCH, bool GEO = true> struct WpeWideShared {
     typedef WpeWideDims<CNP, NCH> D;
     // spare: a word per lane, where a lane stores what is not part of the packed triangle.
-    // DB: two buffers, chunk h + 2 lands while chunk h + 1 is taken apart
-    alignas(16) cf tile[DB ? 2 : 1][D::TILE];
+    alignas(16) cf tile[D::TILE];
     alignas(16) cf spare[WPEW_NT];
     alignas(16) cf X[2][D::XP + WPE_CMAX];     // tap buffer, double-buffered; [XP + c] = the frame's delayed input of channel c
     alignas(16) cf g[D::XP];                   // g = P x
@@ -88,13 +87,11 @@ template <int CNP, int NCH> struct WpeWideRegs {
 };
 
 // CT > 0: the channel count as a compile-time constant (strip geometry and the channel loops fold); NTAPS with it
-// DB (compile-time shapes only): the chunks through two tile buffers as a pipeline — every load of the prologue (the strips of W, var, the
-// frame's inputs, the taps and the first TWO chunks) is in flight before the first wait, and chunk h + 2 is requested as soon as chunk h has
-// been taken apart: one exposed HBM latency per call instead of one per chunk plus one for the small parts.
-template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false> struct WpeWideEngine {
+// (the chunks through two tile buffers as a load pipeline — everything of the prologue and the first two of four chunks in flight before the
+// first wait — was built and measured: no gain, profiles/r04a/wpe_wide_pipeline_ab.txt; the kernel is bound by its two waves per SIMD)
+template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
     typedef WpeWideDims<CNP, NCH> D;
-    typedef WpeWideShared<CNP, NCH, DB, CT == 0> Sh;
-    static_assert(!DB || (CT > 0 && NTAPS > 0), "the pipelined form counts its loads at compile time");
+    typedef WpeWideShared<CNP, NCH, CT == 0> Sh;
     typedef WpeWideRegs<CNP, NCH> Rg;
     static constexpr int NT = WPEW_NT, RL = D::RL, XR = D::XR, QW = D::QW, SLP = D::SLP, XP = D::XP;
     static_assert(CT * NTAPS <= CNP, "shape");
@@ -137,29 +134,31 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false> struct W
         // global <-> tile, 16-byte pieces (two packed words), consecutive lanes on consecutive pieces; words [w0, w1), w0 even
         // (inbound as LDS-DMA: the 13 .. 26 one-KiB pieces of a chunk are all in flight at once and take no registers — with ordinary loads
         // the copy loop ran load, wait, store piece by piece: two HBM latencies per KiB, 39 us per bin at one frame per call)
-        auto tile_in = [&](int tid, int w0, int w1, int buf, bool wait) {
+        auto tile_in = [&](int tid, int w0, int w1) {
             const int we = w1 & ~1;
             for (int w = w0; w < we; w += 2 * NT)
-                if (w + 2 * tid < we) ex.lds_load16(&sh.tile[buf][w - w0], tid, &st[w + 2 * tid]);
-            if ((w1 & 1) && tid == 0) sh.tile[buf][w1 - 1 - w0] = st[w1 - 1];
-            if (wait) ex.lds_load_wait();
+                if (w + 2 * tid < we) ex.lds_load16(&sh.tile[w - w0], tid, &st[w + 2 * tid]);
+            if ((w1 & 1) && tid == 0) sh.tile[w1 - 1 - w0] = st[w1 - 1];
+            ex.lds_load_wait();
         };
-        auto tile_out = [&](int tid, int w0, int w1, int buf) {
+        auto tile_out = [&](int tid, int w0, int w1) {
             const int we = w1 & ~1;
-            for (int w = w0 + 2 * tid; w < we; w += 2 * NT) *reinterpret_cast<vec4*>(&st[w]) = *reinterpret_cast<const vec4*>(&sh.tile[buf][w - w0]);
-            if ((w1 & 1) && tid == 0) st[w1 - 1] = sh.tile[buf][w1 - 1 - w0];
+            for (int w = w0 + 2 * tid; w < we; w += 2 * NT) *reinterpret_cast<vec4*>(&st[w]) = *reinterpret_cast<const vec4*>(&sh.tile[w - w0]);
+            if ((w1 & 1) && tid == 0) st[w1 - 1] = sh.tile[w1 - 1 - w0];
         };
 
         // ---- prologue: registers and LDS to zero, geometry, first frame's inputs, the small parts of the state
         ex.phase_wave([&](int l, Rg& r) {
             const cf z = mk(0.0f, 0.0f);
+            if constexpr (CT * NTAPS != CNP) {                          // exact shapes: every word of every lane's rows is loaded below
 #pragma unroll
-            for (int q = 0; q < CNP; ++q) r.Pa[q] = z;
+                for (int q = 0; q < CNP; ++q) r.Pa[q] = z;
 #pragma unroll
-            for (int j = 0; j < QW; ++j) r.Pb[j] = z;
+                for (int j = 0; j < QW; ++j) r.Pb[j] = z;
+            }
 #pragma unroll
             for (int s = 0; s < SLP; ++s) r.W[s] = z;
-            for (int i = l; i < XP + WPE_CMAX; i += NT) { if (!DB || i >= CN) sh.X[0][i] = z; sh.X[1][i] = z; }
+            for (int i = l; i < XP + WPE_CMAX; i += NT) { sh.X[0][i] = z; sh.X[1][i] = z; }
             for (int i = l; i < XP; i += NT) { sh.g[i] = z; sh.dre[i] = 0.0f; }
             sh.red[l] = z; sh.q[l] = z;
             const int c = l / LPC, sub = l - c * LPC;
@@ -175,17 +174,7 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false> struct W
             r.ring0 = p.ring != nullptr ? (ub * p.ring_len * p.K + kb) * C : 0;
             r.xin = z; r.din = z;
             if (l < C) { r.xin = delayed(r, 0, l); r.din = mk(p.d[2 * (r.io0 + l)], p.d[2 * (r.io0 + l) + 1]); }
-            if constexpr (DB) {
-                // the taps (CN words, contiguous, 16-byte aligned for these shapes) and the first two chunks: all requested here, behind the
-                // loads above; nothing of this phase is used before the first chunk's wait, which retires everything older than chunk 1
-                static_assert(((wpe_packed(CT * NTAPS) + CT * CT * NTAPS) & 1) == 0 && ((CT * NTAPS) & 1) == 0, "tap block alignment");
-                if (2 * l < CN) ex.lds_load16(&sh.X[0][0], l, &st[NPK + C * CN + 2 * l]);
-                constexpr int wa = wpew_words(D::col0(0)), wb = wpew_words(D::col0(1)), wc2 = wpew_words(D::col0(NCH > 1 ? 2 : 1));
-                tile_in(l, wa, wb, 0, false);
-                if constexpr (NCH > 1) tile_in(l, wb, wc2, 1, false);
-            }
         });
-        if constexpr (!DB)
         ex.phase_wave([&](int l, Rg&) {                               // (after the zero fill: the taps as stored)
             for (int i = l; i < CN; i += NT) sh.X[0][i] = st[NPK + C * CN + i];
         });
@@ -195,14 +184,7 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false> struct W
             if (c0 >= CN) return;
             const int c1 = c1r < CN ? c1r : CN;                         // columns [c0, c1) of the CN the state has
             const int w1 = wpew_words(c1);
-            constexpr int buf = DB ? (H & 1) : 0;
-            if constexpr (DB) {
-                // chunk H was requested two steps ago; only chunk H + 1's pieces (issued after it) may still be in flight
-                constexpr int younger = H + 1 < NCH ? (wpew_words(D::col0(H + 2 > NCH ? NCH : H + 2)) - wpew_words(D::col0(H + 1)) + 2 * NT - 1) / (2 * NT) : 0;
-                ex.phase_wave([&](int, Rg&) { ex.template lds_load_wait_keep<younger>(); });
-            } else {
-                ex.phase_wave([&](int l, Rg&) { tile_in(l, w0, w1, 0, true); });
-            }
+            ex.phase_wave([&](int l, Rg&) { tile_in(l, w0, w1); });
             // a lane's predicate does not depend on the column: for the chunk's own columns q every row i < c1 takes exactly one word (its
             // stored (i, q) when i <= q, the conjugate of its own column's (q, i) otherwise: then c0 <= q < i < c1), and for the columns in
             // front of the chunk the rows inside it take the conjugates of their column — two straight-line loops under one lane mask each
@@ -215,12 +197,12 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false> struct W
                     for (int q = c0; q < c1r; ++q)
                         if (q < c1) {                                   // (uniform; folds for the compile-time shapes)
                             const bool up = i <= q;
-                            const cf v = sh.tile[buf][up ? wpew_words(q) - w0 + i : lowbase + q];
+                            const cf v = sh.tile[up ? wpew_words(q) - w0 + i : lowbase + q];
                             r.Pa[q] = mk(v.x, up ? v.y : -v.y);
                         }
                     if (i >= c0) {
 #pragma unroll
-                        for (int q = 0; q < c0; ++q) r.Pa[q] = cconj(sh.tile[buf][lowbase + q]);
+                        for (int q = 0; q < c0; ++q) r.Pa[q] = cconj(sh.tile[lowbase + q]);
                     }
                 }
                 if constexpr (XR > 0 && c1r > 64) {                     // the split rows 64 .. : all in the chunks that reach beyond column 64
@@ -233,7 +215,7 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false> struct W
                                 const int cq = cq0 + j;
                                 if (cq < CN) {
                                     const bool up = e <= cq;
-                                    const cf v = sh.tile[buf][up ? wpew_words(cq) - w0 + e : ebase + cq];
+                                    const cf v = sh.tile[up ? wpew_words(cq) - w0 + e : ebase + cq];
                                     r.Pb[j] = mk(v.x, up ? v.y : -v.y);
                                 }
                             }
@@ -246,17 +228,13 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false> struct W
                             const bool up = e <= cq;
                             const bool ok = (up ? (cq >= c0 && cq < c1) : (ein && cq < CN)) && e < CN;
                             if (ok) {
-                                const cf v = sh.tile[buf][up ? wpew_words(cq) - w0 + e : ebase + cq];
+                                const cf v = sh.tile[up ? wpew_words(cq) - w0 + e : ebase + cq];
                                 r.Pb[j] = mk(v.x, up ? v.y : -v.y);
                             }
                         }
                     }
                 }
             });
-            if constexpr (DB && H + 2 < NCH) {                          // this buffer is free again (every lane has taken its words): the chunk after next
-                constexpr int wn0 = wpew_words(D::col0(H + 2)), wn1 = wpew_words(D::col0(H + 3));
-                ex.phase_wave([&](int l, Rg&) { tile_in(l, wn0, wn1, buf, false); });
-            }
         };
         load_chunk(std::integral_constant<int, 0>());
         if constexpr (NCH > 1) load_chunk(std::integral_constant<int, 1>());
@@ -286,14 +264,18 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false> struct W
             // ---- lane-local products: g_l = (P x)_l, the split rows' shares, the lane's share of its channel's filter output
             ex.phase_wave([&](int l, Rg& r) {
                 const cf* X = sh.X[nxt];
-                cf a0 = mk(0.0f, 0.0f), a1 = mk(0.0f, 0.0f);
+                // four partial sums (taps j mod 4): a complex multiply-add is two dependent packed instructions, and with two waves per SIMD
+                // the chain of a partial sum is what the row product waits on
+                cf a0 = mk(0.0f, 0.0f), a1 = mk(0.0f, 0.0f), a2 = mk(0.0f, 0.0f), a3 = mk(0.0f, 0.0f);
 #pragma unroll
-                for (int j = 0; j < CNP; j += 2) {
-                    const vec4 x2 = *reinterpret_cast<const vec4*>(&X[j]);
+                for (int j = 0; j < CNP; j += 4) {
+                    const vec4 x2 = *reinterpret_cast<const vec4*>(&X[j]), x3 = *reinterpret_cast<const vec4*>(&X[j + 2]);
                     a0 = cfma(a0, r.Pa[j], mk(x2.x, x2.y));
                     a1 = cfma(a1, r.Pa[j + 1], mk(x2.z, x2.w));
+                    a2 = cfma(a2, r.Pa[j + 2], mk(x3.x, x3.y));
+                    a3 = cfma(a3, r.Pa[j + 3], mk(x3.z, x3.w));
                 }
-                sh.g[l] = cadd(a0, a1);
+                sh.g[l] = cadd(cadd(a0, a1), cadd(a2, a3));
                 if constexpr (XR > 0) {
                     const int cq0 = (l & 3) * QW;
                     cf b0 = mk(0.0f, 0.0f), b1 = mk(0.0f, 0.0f);
@@ -418,22 +400,21 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false> struct W
             if (c0 >= CN) return;
             const int c1 = c1r < CN ? c1r : CN;
             const int w1 = wpew_words(c1);
-            constexpr int buf = DB ? (H & 1) : 0;
             ex.phase_wave([&](int l, Rg& r) {
                 const int i = l;
 #pragma unroll
                 for (int q = c0; q < c1r; ++q)
-                    if (q < c1) *(i <= q ? &sh.tile[buf][wpew_words(q) - w0 + i] : &sh.spare[l]) = r.Pa[q];     // rows below the diagonal: a spare word of the lane's own
+                    if (q < c1) *(i <= q ? &sh.tile[wpew_words(q) - w0 + i] : &sh.spare[l]) = r.Pa[q];     // rows below the diagonal: a spare word of the lane's own
                 if constexpr (XR > 0 && c1r > 64) {
                     const int e = 64 + (l >> 2), cq0 = (l & 3) * QW;
 #pragma unroll
                     for (int j = 0; j < QW; ++j) {
                         const int cq = cq0 + j;
-                        *((cq >= c0 && cq < c1 && e <= cq) ? &sh.tile[buf][wpew_words(cq) - w0 + e] : &sh.spare[l]) = r.Pb[j];
+                        *((cq >= c0 && cq < c1 && e <= cq) ? &sh.tile[wpew_words(cq) - w0 + e] : &sh.spare[l]) = r.Pb[j];
                     }
                 }
             });
-            ex.phase_wave([&](int l, Rg&) { tile_out(l, w0, w1, buf); });
+            ex.phase_wave([&](int l, Rg&) { tile_out(l, w0, w1); });
         };
         store_chunk(std::integral_constant<int, 0>());
         if constexpr (NCH > 1) store_chunk(std::integral_constant<int, 1>());

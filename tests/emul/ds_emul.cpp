@@ -31,7 +31,6 @@ template <class Rg> struct CpuExec {
     void sync() {}
     void lds_load16(void* lds_piece, int lane, const void* src) { std::memcpy((char*)lds_piece + 16 * lane, src, 16); }   // HipExec: global_load_lds
     void lds_load_wait() {}
-    template <int N> void lds_load_wait_keep() {}
 };
 
 // The Python side of the emulator keeps operator state as logical planes [B][NF][KP]; the kernels keep it as float4 planes
@@ -157,8 +156,8 @@ template <int NFFT, int CMAX> int run_fdaf(ds::FdafParams p) {
 }
 
 // the wide-tap program (ds_wpe_wide.hpp): one 64-lane block per (utterance, bin)
-template <int CNP, int NCH, int CT = 0, int NTAPS = 0, bool DB = false> int run_wpe_wide(const ds::WpeParams& p) {
-    typedef ds::WpeWideEngine<CNP, NCH, CT, NTAPS, DB> E;
+template <int CNP, int NCH, int CT = 0, int NTAPS = 0> int run_wpe_wide(const ds::WpeParams& p) {
+    typedef ds::WpeWideEngine<CNP, NCH, CT, NTAPS> E;
     typename E::Sh* sh = new typename E::Sh();
     const long long blocks = (long long)p.B * p.K;
     for (long long b = 0; b < blocks; ++b) {
@@ -332,8 +331,8 @@ int emul_wpe(int B, int K, int T, int C, int N, const float* xd, const float* d,
     if (C * N > ds::WPE_CNMAX) {                                 // wide prediction filters: launch_wpe_wide's dispatch (ds_kernels_wpe.hip)
         if (C * N > ds::WPEW_CNMAX || C > ds::WPE_CMAX) return -1;
         if (!g_wpe_generic) {
-            if (C == 4 && N == 20) return run_wpe_wide<80, 4, 4, 20, true>(p);      // four chunks through two tile buffers (the device's default)
-            if (C == 8 && N == 10) return run_wpe_wide<80, 4, 8, 10, true>(p);
+            if (C == 4 && N == 20) return run_wpe_wide<80, 2, 4, 20>(p);
+            if (C == 8 && N == 10) return run_wpe_wide<80, 2, 8, 10>(p);
         }
         return C * N <= 32 ? run_wpe_wide<32, 1>(p) : C * N <= 64 ? run_wpe_wide<64, 2>(p) : run_wpe_wide<80, 2>(p);
     }

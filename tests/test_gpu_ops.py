@@ -752,7 +752,7 @@ def test_chain_handles_error_behaviour(ds):
     # graph replay of a chain needs the call shape to have run once with plain launches: a build-only request before that is a no-op
     ch.process_device_seq(fake_x, 1, 4 * 512, 512, 256, 256, 2, fake_y, 512, 256, graph=2)
     with pytest.raises(DsError):
-        ds.BatchEngine(L.ALGO_WPE_MVDR, 8, 1024, 512, batch=1, filter_len=3)   # C * N = 24 > 16 lanes per bin
+        ds.BatchEngine(L.ALGO_WPE_MVDR, 8, 1024, 512, batch=1, filter_len=11)  # C * N = 88 > 80: beyond the wavefront-per-bin kernel
 
 
 def test_chain_handles_long_stream_drift(ds):
