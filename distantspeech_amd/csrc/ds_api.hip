@@ -381,7 +381,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     for (int i = 0; i < 10; ++i) h->ev_fr[i] = nullptr;
     for (int i = 0; i < 7; ++i) { h->side[i] = nullptr; h->ev_join[i] = nullptr; }
     h->ki_istft = ki_istft; h->op = op;
-    h->ki_rows = KernelInfo{nullptr, 0, 0, 0}; h->ki_rows_istft = h->ki_rows; h->ki_aic = h->ki_rows; h->ki_cdr = h->ki_rows;
+    h->ki_rows = KernelInfo{nullptr, 0, 0, 0}; h->ki_rows_istft = h->ki_rows; h->ki_aic = h->ki_rows; h->ki_cdr = h->ki_rows; h->front_fused = false;
     if (cfg->algo == DS_ALGO_TRANSFORM && cfg->n_mics == 1 && cfg->hop * 2 == cfg->nfft) { h->ki_rows = ds::lookup_stft_rows(cfg->nfft); h->ki_rows_istft = ds::lookup_istft_rows(cfg->nfft); }
  h->opst = nullptr; h->NF = NF;
     h->op_frm = 0; h->op_ell = 1; h->op_first = 1;
@@ -560,6 +560,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             // LDS); counters by value, so only where nothing is replayed as a graph.  DS_CHAIN_UNFUSED=1: the separate McCDR launch
             const char* unf2 = std::getenv("DS_CHAIN_UNFUSED");
             if (!(unf2 && unf2[0] == '1')) h->ki_cdr = ds::lookup_stft_cdr(cfg->nfft, M);
+            const char* ff = std::getenv("DS_CHAIN_FRONT_FUSED");        // shelved (make SHELVED=1): the front end as ONE kernel, measured slower
+            h->front_fused = h->ki_cdr.launch != nullptr && ff && ff[0] == '1';
         }
         h->sub[5]->x_fan = M;                 // the M blocking filters of an utterance share its fixed-beamformer spectrum and p ...
         h->sub[5]->d_interleaved = 1;         // ... and take their desired signals straight from the M-channel STFT of the aligned channels

@@ -276,6 +276,35 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
     }
     const bool tail_async = h->tail_async && h->ki_aic.launch != nullptr;    // the tail on its own stream (side[2])
 #define DS_SUB(i, call) do { int rc_ = (call); if (rc_) return fail(h, rc_, h->sub[i]->err); } while (0)
+    const int Lt = (int)(fe->aux_floats / M);
+    rc = frontend_set_taps(fe, Lt); if (rc) return fail(h, rc, fe->err);
+    const bool cdr_in_front = h->ki_cdr.launch != nullptr;
+    // the whole front end as ONE kernel (DC notch -> FIR bank + mean -> analysis + McCDR on the hop in LDS): where the shape can hold the
+    // bank's history and windows in the analysis kernel's LDS, and nobody asks for the aligned channels as an array of their own
+    const ds::KernelInfo kf = (h->front_fused && cdr_in_front && !al_dev) ? ds::lookup_front(h->cfg.nfft, M, Lt) : ds::KernelInfo{nullptr, 0, 0, 0};
+    if (kf.launch) {
+        if (early) {                                                    // one kernel: it waits for every reader of the set
+            if (h->fr_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[(h->fr_mid[set] ? 4 : 2) + set], 0));
+            if (h->bf_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[8 + set], 0));
+        }
+        ds_handle *t = h->sub[1], *sp = h->sub[2];
+        Params p;
+        fill_params(t, p);
+        p.x = x_dev; p.y = cb[G_D];
+        p.x_batch_stride = x_bstride ? x_bstride : (long long)M * n; p.x_sample_stride = 1; p.x_chan_stride = x_bstride ? x_cstride : n;
+        p.y_batch_stride = (long long)T * K * M * 2;
+        p.T = T; p.batch0 = 0;
+        p.cdr_st = sp->opst; p.cdr_NF = sp->NF; p.cdr_frm = sp->op_frm; p.cdr_ell = sp->op_ell; p.cdr_L = 65; p.cdr_fn = sp->dev_buf[9];
+        p.cdr_gamma = cb[G_GAM]; p.cdr_qavg = cb[G_GAM] + (size_t)B * T * K;
+        // the FIR history's ping-pong halves by value (the host mirror of the parity: a pipelined chain is never replayed as a graph); the
+        // device copy of the parity still flips, in this launch, so that the separate kernels could take over at any block
+        p.fe_coef = fe->dev_buf[9]; p.fe_L = Lt; p.fe_mem = fe->td_mem; p.fe_radius = fe->cfg.filt_alpha; p.fe_fixed = cb[G_FIXED];
+        p.fe_cache_in = fe->td_cache[fe->td_cur]; p.fe_cache_out = fe->td_cache[fe->td_cur ^ 1];
+        rc = post_tick(fe, fe->dev_cnt, 0, 1, 1, 2, fs); if (rc) return rc;
+        fe->td_cur ^= 1;
+        take_tick(t, fs, p.tick);
+        DS_HIP(h, kf.launch(p, B, fs));
+    } else {
     {   // :177-178 DC notch per channel, then :201,206 TimeAlignment FIR bank + channel mean (the fixed beamformer)
         ds::TdParams p;
         std::memset(&p, 0, sizeof p);
@@ -283,8 +312,6 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
         p.radius = fe->cfg.filt_alpha;
         DS_HIP(h, ds::launch_dcnotch(p, fs));
         if (early && h->bf_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[8 + set], 0));    // the FIR bank writes the fixed-beamformer block
-        const int Lt = (int)(fe->aux_floats / M);
-        rc = frontend_set_taps(fe, Lt); if (rc) return fail(h, rc, fe->err);
         std::memset(&p, 0, sizeof p);
         p.B = B; p.M = M; p.n = n; p.L = Lt; p.x = cb[G_XN]; p.x_chan_major = 1; p.y = cb[G_XA]; p.y_chan_major = 1; p.mean = cb[G_FIXED];
         // the ping-pong parity of the FIR history is device-resident (dev_cnt[3], flipped by the tick behind the launch): graph replay
@@ -293,7 +320,6 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
         rc = post_tick(fe, fe->dev_cnt, 0, 1, 1, 2, fs); if (rc) return rc;            // rides in the analysis launch that follows
         fe->td_cur ^= 1;
     }
-    const bool cdr_in_front = h->ki_cdr.launch != nullptr;
     if (early && h->fr_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[(h->fr_mid[set] ? 4 : 2) + set], 0));        // the analysis writes D and Gamma
     if (cdr_in_front) {
         // :204 D, and McCDR (mcspp.py:250: the prior of McSpp) in the same kernel: thread k has bin k of microphones 0..2 in registers, the
@@ -311,6 +337,7 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
         DS_HIP(h, h->ki_cdr.launch(p, B, fs));
     } else {
         rc = chain_stft(h, h->sub[1], cb[G_XA], n, cb[G_D]); if (rc) return rc;                               // :204  D
+    }
     }
     const bool fork = h->sub[5]->stream != h->stream;                       // blocking-filter branch on the side stream (RLS filters, see ds_create)
     const bool fused_tail = h->ki_aic.launch != nullptr;

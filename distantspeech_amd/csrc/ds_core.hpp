@@ -294,6 +294,16 @@ struct Params {
     int cdr_NF;
     int cdr_frm, cdr_ell, cdr_L;   // the stage's uniform counters before this call (host mirror; the launch is never part of a replayed graph)
     const float* cdr_fn;      // diffuse coherence of the microphone pair, [K]
+    // StftEngine<.., CDR, 2, FRONT = true>: the chain's WHOLE front end in that kernel — FilterDcNotch16 per channel (feature.py:32-49), the
+    // TimeAlignment FIR bank and the channel mean (fixedbeamformer.py:13-93, SubbandGSC.py:143) run on the hop in LDS, in front of the
+    // analysis: x is then the RAW input (strided [B][M][n]).  Same arithmetic, same order as ds_dcnotch_kernel / ds_fir_kernel
+    const float* fe_coef;     // FIR taps [L][M]
+    int fe_L;
+    float* fe_mem;            // notch memories [B][M][2]
+    const float* fe_cache_in; // FIR history [B][M][L-1] before this call ...
+    float* fe_cache_out;      // ... and after it (the other half of the ping-pong pair)
+    float* fe_fixed;          // channel mean of the aligned channels, [B][T * hop] (the fixed beamformer's block)
+    float fe_radius;
     float* cdr_gamma;         // out: Gamma [B][T][K]
     float* cdr_qavg;          // out: mean of 1 - Gamma over the 500-2000 Hz band, [B][T]  (mcspp.py:258-260)
 };
@@ -366,6 +376,7 @@ template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
     float apk, apkn;          // ... and the update probability
     float bmt[2 * M];         // ... and this lane's two samples of the M blocking-matrix overlap tails (lanes < NC / 2; aic_e mode)
     float cdr[9], cdrn[9];    // StftEngine<.., CDR>: McCDR's state of this lane's bin / of the Nyquist bin (lane 0)
+    float nm0, nm1;           // StftEngine<.., FRONT>: the DC notch memory of channel `tid` (lanes < M)
 };
 
 // state-plane accessors.  Every state line is read once and written once per launch and is next touched by the following launch,
@@ -1669,7 +1680,10 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
 // ---------------------------------------------------------------------------------------------
 // OV = NFFT / hop: 2 (the half-overlap every beamformer object uses), or 4 for Transform(n_fft, hop_length = n_fft / 4)
 // (transform.py:407-428 takes any hop; wpe.ipynb runs 75 % overlap): the LDS sample buffer becomes a ring of four quarter-frames.
-template <int NFFT, int M, bool CDR = false, int OV = 2> struct StftEngine {
+// FRONT (with CDR; the SubbandGSC chain's front end as ONE kernel): the hop goes raw input -> DC notch -> FIR bank + channel mean -> analysis
+// inside the workgroup.  The FIR windows (history + hop per channel) live in the second transform buffer and the taps in the first (both idle
+// until the forward stages start), the carried history in the spectrum row `Y` this engine never uses: no LDS beyond the plain analysis.
+template <int NFFT, int M, bool CDR = false, int OV = 2, bool FRONT = false> struct StftEngine {
     typedef Engine<NFFT, M, ALGO_FIXED, false> EB;
     static constexpr int N = NFFT, NC = NFFT / 2, K = NFFT / 2 + 1, HOP = NFFT / 2, NT = NC;
     typedef typename EB::Sh Sh;
@@ -1677,11 +1691,22 @@ template <int NFFT, int M, bool CDR = false, int OV = 2> struct StftEngine {
     static constexpr int HOPX = NFFT / OV, OVL = NFFT - HOPX;        // hop and carried overlap of this transform
     static_assert(!CDR || M >= 3, "McCDR takes microphones 0, 1 and 2");
     static_assert(OV == 2 || (OV == 4 && !CDR), "overlap");
+    static_assert(!FRONT || (CDR && OV == 2 && HOP == NT), "the fused front end: one thread per hop sample");
+    // can this shape keep the FIR history of an L-tap bank in LDS (the `Y` row) and its windows in the transform buffers?
+    static constexpr bool front_fits(int L) {
+        return L >= 1 && L <= 120 && (size_t)M * (L - 1) * sizeof(float) <= sizeof(Sh::Y) &&
+               (size_t)M * ((((L - 1) + 3) & ~3) + 4 + HOP) * sizeof(float) <= sizeof(Sh::fb) && (size_t)M * ((L + 3) & ~3) * sizeof(float) <= sizeof(Sh::fa);
+    }
 
     template <class Exec> static DS_HD void run(Exec& ex, const Params& p, int blk, Sh& sh) {
         const int b = p.batch0 + blk;
         const long long xb = (long long)blk * p.x_batch_stride;
         float* tin = p.tail_in + (long long)b * M * OVL;
+        // FRONT: window row m = W[m * WL ...]: four zeros (the zero-padded taps read them), L - 1 history samples ending at OFF, the hop at OFF
+        const int FL = FRONT ? p.fe_L : 1, FLp = (FL + 3) & ~3, OFF = (((FL - 1) + 3) & ~3) + 4, WL = OFF + HOP;
+        float* const W = reinterpret_cast<float*>(&sh.fb[0][0]);
+        float* const cs = reinterpret_cast<float*>(&sh.fa[0][0]);
+        float* const hist = reinterpret_cast<float*>(&sh.Y[0]);
         cf* Yout = reinterpret_cast<cf*>(p.y + (long long)blk * p.y_batch_stride);
         int old_half = 0;
         constexpr int KP = (K + 3) & ~3;
@@ -1710,6 +1735,12 @@ template <int NFFT, int M, bool CDR = false, int OV = 2> struct StftEngine {
                 EB::prefetch_init(p, xb, tid, r);
                 EB::prefetch(p, xb, 0, tid, r);
             }
+            if constexpr (FRONT) {
+                const float* cin = p.fe_cache_in + (long long)b * M * (FL - 1);
+                for (int i = tid; i < M * (FL - 1); i += NT) hist[i] = cin[i];
+                r.nm0 = r.nm1 = 0.0f;
+                if (tid < M) { r.nm0 = p.fe_mem[((long long)b * M + tid) * 2]; r.nm1 = p.fe_mem[((long long)b * M + tid) * 2 + 1]; }
+            }
             if constexpr (CDR) {
 #pragma unroll
                 for (int f = 0; f < 9; ++f) r.cdr[f] = cdr_plane(f, tid);
@@ -1736,6 +1767,59 @@ template <int NFFT, int M, bool CDR = false, int OV = 2> struct StftEngine {
                     }
                 });
                 ex.phase([&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, 3, 0, 1>(tid, NT, sh, nullptr, fa, 1, (slot + 1) & 3, M); });
+            } else if constexpr (FRONT) {
+                // ---- raw hop, history and taps into the windows (x is channel-major here: x_sample_stride == 1) --------------------------
+                ex.phase([&](int tid, Rg& r) {
+#pragma unroll
+                    for (int i = 0; i < EB::NPRE; ++i) {
+                        const int v = tid + i * NT;
+                        if (v < EB::NV4) { const int m = v / (HOP / 4), q = v - m * (HOP / 4); *reinterpret_cast<vec4*>(&W[m * WL + OFF + 4 * q]) = r.pre[i]; }
+                    }
+                    for (int m = 0; m < M; ++m) {
+                        for (int h = tid; h < FL - 1; h += NT) W[m * WL + OFF - (FL - 1) + h] = hist[m * (FL - 1) + h];
+                        if (tid < 4) W[m * WL + OFF - (FL - 1) - 4 + tid] = 0.0f;
+                        for (int j = tid; j < FLp; j += NT) cs[m * FLp + j] = j < FL ? p.fe_coef[(long long)j * M + m] : 0.0f;
+                    }
+                    if (t + 1 < p.T) EB::prefetch(p, xb, t + 1, tid, r);
+                    if (t > 0 && tid == NT - 1) band_mean(t - 1);
+                });
+                // ---- DC notch, in place: one lane per channel, serial in time (ds_ops.hpp td_dcnotch: same statements) ----------------------
+                ex.phase([&](int tid, Rg& r) {
+                    if (tid >= M) return;
+                    const float rr = p.fe_radius;
+                    const float den2 = fma_(rr, rr, 0.7f * (1.0f - rr) * (1.0f - rr));
+                    float* row = W + tid * WL + OFF;
+                    float m0 = r.nm0, m1 = r.nm1;
+                    for (int i = 0; i < HOP; ++i) {
+                        const float vin = row[i];
+                        const float vout = m0 + vin;
+                        m0 = m1 + 2.0f * (-vin + rr * vout);
+                        m1 = vin - den2 * vout;
+                        row[i] = rr * vout;
+                    }
+                    r.nm0 = m0; r.nm1 = m1;
+                });
+                // ---- FIR bank: thread o = output sample o of every channel, taps in ascending order (td_fir); channel mean; new history -----
+                ex.phase([&](int tid, Rg&) {
+                    float mean = 0.0f;
+                    for (int m = 0; m < M; ++m) {
+                        const float* w = W + m * WL + OFF + tid;
+                        const float* c = cs + m * FLp;
+                        float acc = 0.0f;
+                        for (int jb = 0; jb < FLp; jb += 4) {
+                            const vec4 c4 = *reinterpret_cast<const vec4*>(c + jb);
+                            acc = fma_(c4.x, w[-jb], acc);
+                            acc = fma_(c4.y, w[-jb - 1], acc);
+                            acc = fma_(c4.z, w[-jb - 2], acc);
+                            acc = fma_(c4.w, w[-jb - 3], acc);
+                        }
+                        sh.xbuf[m][new_half * HOP + tid] = acc;
+                        mean += acc;
+                        for (int h = tid; h < FL - 1; h += NT) hist[m * (FL - 1) + h] = W[m * WL + OFF + HOP - (FL - 1) + h];
+                    }
+                    p.fe_fixed[((long long)b * p.T + t) * HOP + tid] = mean / (float)M;
+                });
+                ph(EB::WAVE_FFT, [&](int tid, Rg&) { fft_stage<NFFT, M, 4, -1, true, 0, 1>(tid, NT, sh, nullptr, fa, 1, old_half, M); });
             } else {
             ph(EB::WAVE_FFT && p.x_sample_stride == 1, [&](int tid, Rg& r) {
                 EB::commit(p, sh, new_half, tid, r);
@@ -1818,6 +1902,11 @@ template <int NFFT, int M, bool CDR = false, int OV = 2> struct StftEngine {
                 const int m = i / (HOP / 4), q = i - m * (HOP / 4);
                 tin4[i] = *reinterpret_cast<const vec4*>(&sh.xbuf[m][old_half * HOP + 4 * q]);
             }
+            }
+            if constexpr (FRONT) {
+                float* cout = p.fe_cache_out + (long long)b * M * (FL - 1);
+                for (int i = tid; i < M * (FL - 1); i += NT) cout[i] = hist[i];
+                if (tid < M) { p.fe_mem[((long long)b * M + tid) * 2] = r.nm0; p.fe_mem[((long long)b * M + tid) * 2 + 1] = r.nm1; }
             }
             if constexpr (CDR) {
                 if (p.T > 0 && tid == NT - 1) band_mean(p.T - 1);

@@ -44,6 +44,7 @@ struct ds_handle {
     // frame-level objects (DS_ALGO_TRANSFORM .. DS_ALGO_SUBRLS)
     KernelInfo ki_istft;
     KernelInfo ki_cdr;          // DS_ALGO_SUBBAND_GSC, pipelined: the front end's analysis with McCDR as its per-bin program (null: separate kernels)
+    bool front_fused;           // ... and with the DC notch and the FIR bank in front of it, ONE kernel (ds_front_kernel: shelved, make SHELVED=1 + DS_CHAIN_FRONT_FUSED=1)
     KernelInfo ki_aic;          // DS_ALGO_SUBBAND_GSC: the chain's tail as one frame kernel (null launch: separate kernels)
     KernelInfo ki_rows, ki_rows_istft;   // single-channel transform handles: the one-row-per-wavefront kernels (null launch = not available)
     int op;                     // ds::OP_* or -1

@@ -29,7 +29,8 @@ KernelInfo lookup_gsc(int nfft, int M);
 KernelInfo lookup_aic(int nfft, int M);     // ALGO_AIC: the SubbandGSC chain's tail (ds_kernels_aic.hip)
 KernelInfo lookup_stft(int nfft, int M, int ov = 2);      // ds_kernels_ops.hip; ov = nfft / hop: 2 or 4
 KernelInfo lookup_istft(int nfft, int M, int ov = 2);
-KernelInfo lookup_stft_cdr(int nfft, int M);   // analysis + McCDR (the SubbandGSC chain's front end); M in {4, 6, 8}
+KernelInfo lookup_stft_cdr(int nfft, int M);
+KernelInfo lookup_front(int nfft, int M, int L);   // DC notch + L-tap FIR bank + analysis + McCDR as one kernel (the SubbandGSC chain's front end)   // analysis + McCDR (the SubbandGSC chain's front end); M in {4, 6, 8}
 KernelInfo lookup_stft_rows(int nfft);      // single-channel handles: one row per wavefront (nfft 512 / 1024), launch(p, rows, stream)
 KernelInfo lookup_istft_rows(int nfft);
 struct OpParams;

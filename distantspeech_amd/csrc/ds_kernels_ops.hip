@@ -37,6 +37,22 @@ template <int NFFT, int M> hipError_t launch_stft_cdr(const Params& p, int nbloc
     return hipGetLastError();
 }
 
+#if defined(DS_WITH_SHELVED)
+// ... and with the DC notch and the FIR bank in front of it: the chain's whole front end as one kernel (StftEngine<.., FRONT = true>).
+// Built, bit-identical to the three kernels it replaces, measured SLOWER (profiles/r04a/cfg5_front_fusion_ab.txt): shelved
+template <int NFFT, int M> __global__ void __launch_bounds__(NFFT / 2) ds_front_kernel(Params p) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
+    typedef StftEngine<NFFT, M, true, 2, true> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+template <int NFFT, int M> hipError_t launch_front(const Params& p, int nblocks, hipStream_t stream) {
+    hipLaunchKernelGGL((ds_front_kernel<NFFT, M>), dim3(nblocks), dim3(NFFT / 2), 0, stream, p);
+    return hipGetLastError();
+}
+#endif
+
 template <int NFFT, int M, int OV> hipError_t launch_stft(const Params& p, int nblocks, hipStream_t stream) {
     hipLaunchKernelGGL((ds_stft_kernel<NFFT, M, OV>), dim3(nblocks), dim3(NFFT / 2), 0, stream, p);
     return hipGetLastError();
@@ -102,6 +118,17 @@ KernelInfo lookup_stft_cdr(int nfft, int M) {
 #define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {&launch_stft_cdr<NFFT_, M_>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
     X(256, 4) X(256, 6) X(256, 8) X(512, 4) X(512, 6) X(512, 8) X(1024, 4) X(1024, 6) X(1024, 8)
 #undef X
+    KernelInfo none = {nullptr, 0, 0, 0};
+    return none;
+}
+// the fused front end: null launch where the shape has no kernel or cannot hold an L-tap bank's history and windows in its LDS
+KernelInfo lookup_front(int nfft, int M, int L) {
+#if defined(DS_WITH_SHELVED)
+#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_ && StftEngine<NFFT_, M_, true, 2, true>::front_fits(L)) { \
+        KernelInfo ki = {&launch_front<NFFT_, M_>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
+    X(512, 4) X(512, 6) X(1024, 4) X(1024, 6)
+#undef X
+#endif
     KernelInfo none = {nullptr, 0, 0, 0};
     return none;
 }

@@ -35,11 +35,20 @@ def budget_rows(cfg, w, stages, B):
         mic = MicArray(arrayType="circular", r=w["r"], M=M, n_fft=w["nfft"])
         tau = compute_tau(mic, np.array(bench.ANGLE_DEG) / 180.0 * np.pi)
         Lt = fractional_delay_filter_bank(np.array(-(tau - np.max(tau)))[:, 0] * mic.fs).shape[0]
-        rows = [
+        front3 = [
             ("ds_dcnotch_kernel", "DC notch (stage 0)", "notch memory (2 floats per channel)", M * 2 * 4, M * hop * 4, M * hop * 4),
             ("ds_fir_kernel", "FIR bank + channel mean (stage 0)", "FIR history, %d samples per channel" % (Lt - 1), (Lt - 1) * M * 4, M * hop * 4, M * hop * 4 + hop * 4),
             ("ds_stft_cdr_kernel", "analysis of M channels + McCDR (stages 1, 2)", "analysis overlap M x hop; McCDR rows 0..8 of the McSpp state = 3 planes",
              M * hop * 4 + 3 * P16, M * hop * 4, K * M * 8 + K * 4 + 4),
+        ]
+        # round 4's shelved experiment: the three as ONE kernel (ds_front_kernel; make SHELVED=1 + DS_CHAIN_FRONT_FUSED=1): the notched and
+        # the aligned channels never leave the workgroup
+        front1 = [
+            ("ds_front_kernel", "DC notch + FIR bank + channel mean + analysis of M channels + McCDR (stages 0, 1, 2)",
+             "notch memory, FIR history (%d samples per channel), analysis overlap M x hop, McCDR rows 0..8 of the McSpp state = 3 planes" % (Lt - 1),
+             M * 2 * 4 + (Lt - 1) * M * 4 + M * hop * 4 + 3 * P16, M * hop * 4, K * M * 8 + K * 4 + 4 + hop * 4),
+        ]
+        rows = (front1 if os.environ.get("DS_CHAIN_FRONT_FUSED") == "1" else front3) + [
             ("ds_binop_kernel<13", "McSpp, steady-state build (stage 2)", "rows 12.. of the McSpp state: %d planes" % (planes(12 + 2 * M * M + 3) - 3),
              (planes(12 + 2 * M * M + 3) - 3) * P16, K * M * 8 + K * 4 + 4, K * 4),
             ("ds_stft_rows_kernel", "analysis of the fixed beamformer output (stage 3)", "analysis overlap, one channel", hop * 4, hop * 4, K * 8),

@@ -218,6 +218,12 @@ template <int F> static void fan_rows(int op, const ds::OpParams& p) {
         }
 }
 
+template <int NFFT> static int run_front(int M, const ds::Params& p, int batch) {
+    if (M == 4 && ds::StftEngine<NFFT, 4, true, 2, true>::front_fits(p.fe_L)) return run_engine<ds::StftEngine<NFFT, 4, true, 2, true>>(p, batch, NFFT);
+    if (M == 6 && ds::StftEngine<NFFT, 6, true, 2, true>::front_fits(p.fe_L)) return run_engine<ds::StftEngine<NFFT, 6, true, 2, true>>(p, batch, NFFT);
+    return -1;
+}
+
 template <int NFFT> static int run_stft_cdr(int M, const ds::Params& p, int batch) {
     if (M == 4) return run_engine<ds::StftEngine<NFFT, 4, true>>(p, batch, NFFT);
     if (M == 6) return run_engine<ds::StftEngine<NFFT, 6, true>>(p, batch, NFFT);
@@ -441,6 +447,29 @@ int emul_stft_cdr(int nfft, int M, int batch, const float* x, int n_samples, flo
         case 256: return run_stft_cdr<256>(M, p, batch);
         case 512: return run_stft_cdr<512>(M, p, batch);
         case 1024: return run_stft_cdr<1024>(M, p, batch);
+    }
+    return -1;
+}
+
+// the chain's whole front end as one program (StftEngine<.., FRONT = true>): raw x [B][M][n] -> DC notch -> FIR bank + channel mean -> analysis
+// + McCDR; notch memories mem [B][M][2], FIR history cache_in -> cache_out [B][M][L - 1], fixed [B][n]
+int emul_front(int nfft, int M, int batch, const float* x, int n_samples, float* Y, float* tail_in, float* st, int NF, int frm, int ell,
+               const float* Fn, float* gamma, float* qavg, const float* coef, int L, float* mem, const float* cache_in, float* cache_out,
+               float* fixed, float radius) {
+    ds::Params p;
+    std::memset(&p, 0, sizeof p);
+    const int hop = nfft / 2, K = nfft / 2 + 1;
+    p.x = x; p.y = Y;
+    p.x_batch_stride = (long long)M * n_samples; p.x_sample_stride = 1; p.x_chan_stride = n_samples;
+    p.T = n_samples / hop;
+    p.y_batch_stride = (long long)p.T * K * M * 2;
+    p.tail_in = tail_in;
+    StPlanes planes(st, batch, NF, (nfft / 2 + 1 + 3) & ~3);
+    p.cdr_st = planes.data(); p.cdr_NF = NF; p.cdr_frm = frm; p.cdr_ell = ell; p.cdr_L = 65; p.cdr_fn = Fn; p.cdr_gamma = gamma; p.cdr_qavg = qavg;
+    p.fe_coef = coef; p.fe_L = L; p.fe_mem = mem; p.fe_cache_in = cache_in; p.fe_cache_out = cache_out; p.fe_fixed = fixed; p.fe_radius = radius;
+    switch (nfft) {
+        case 512: return run_front<512>(M, p, batch);
+        case 1024: return run_front<1024>(M, p, batch);
     }
     return -1;
 }

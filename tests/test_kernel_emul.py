@@ -678,6 +678,53 @@ def test_emul_analysis_with_mccdr_equals_separate_programs(M, nfft):
     assert (frm, ell) == (op.frm, op.ell)
 
 
+@pytest.mark.parametrize("M,nfft,L", [(6, 512, 83), (4, 512, 83), (4, 1024, 33), (6, 1024, 83)])
+def test_emul_fused_front_end_equals_separate_programs(M, nfft, L):
+    """The SubbandGSC chain's front end as ONE program (StftEngine<.., FRONT>: DC notch -> FIR bank + channel mean -> analysis + McCDR on the
+    hop in LDS) against the three programs it replaces (td_dcnotch, td_fir, the analysis with McCDR): spectra, Gamma, its band mean, the
+    fixed beamformer's block, the notch memories, the FIR history, the analysis overlap and McCDR's state, bit for bit over several calls."""
+    import ctypes
+    from emul import emul as E
+    from emul.emul import EmulFrontend
+    from oracle import ds_oracle as O
+    lib = E.lib()
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    hop, K = nfft // 2, nfft // 2 + 1
+    rng = np.random.default_rng(100 * M + L)
+    Fn = np.ascontiguousarray(O.gen_noise_msc(O.OracleMicArray(arrayType="circular", r=0.032, M=M), nfft)[:, 1, 2], dtype=np.float32)
+    coef = (rng.standard_normal((L, M)) * 0.2).astype(np.float32)
+    fe = EmulFrontend(M, coef=coef, radius=0.98)
+    op = EmulOp("mcspp", nfft, M=M)
+    st_a, st_b = op.st.copy(), op.st.copy()
+    tin_a, tin_b = np.zeros((1, M, hop), np.float32), np.zeros((1, M, hop), np.float32)
+    mem_b = np.zeros((1, M, 2), np.float32)
+    cache_b = [np.zeros((1, M, L - 1), np.float32) for _ in range(2)]
+    cur, frm, ell = 0, 0, 1
+    for T in (2, 1, 5):
+        x = (rng.standard_normal((1, M, T * hop)) * 0.1 + 0.03).astype(np.float32)
+        # A: the three programs
+        xn = fe.dcnotch(x)                                                          # [1, M, n]
+        xa_i, mean = fe.firbank(np.ascontiguousarray(xn.transpose(0, 2, 1)))        # [1, n, M], [1, n]
+        xa = np.ascontiguousarray(xa_i.transpose(0, 2, 1))
+        Da = np.zeros((1, T, K, M), np.complex64); ga = np.zeros((1, T, K), np.float32); qa = np.zeros((1, T), np.float32)
+        assert lib.emul_stft_cdr(nfft, M, 1, vp(xa), T * hop, vp(Da), vp(tin_a), vp(st_a), op.NF, frm, ell, vp(Fn), vp(ga), vp(qa)) == 0
+        # B: the fused program
+        Db = np.zeros_like(Da); gb = np.zeros_like(ga); qb = np.zeros_like(qa); fixed = np.zeros((1, T * hop), np.float32)
+        rc = lib.emul_front(nfft, M, 1, vp(x), T * hop, vp(Db), vp(tin_b), vp(st_b), op.NF, frm, ell, vp(Fn), vp(gb), vp(qb), vp(coef), L,
+                            vp(mem_b), vp(cache_b[cur]), vp(cache_b[cur ^ 1]), vp(fixed), ctypes.c_float(0.98))
+        assert rc == 0
+        cur ^= 1
+        for _ in range(T):
+            if frm != 0 and ell % 65 == 0:
+                ell = 0
+            frm += 1; ell += 1
+        assert np.abs(Da).max() > 0
+        assert np.array_equal(fixed, mean)
+        assert np.array_equal(Db, Da) and np.array_equal(gb, ga) and np.array_equal(qb, qa)
+        assert np.array_equal(mem_b, fe.mem) and np.array_equal(cache_b[cur], fe.cache[fe.cur])
+        assert np.array_equal(tin_b, tin_a) and np.array_equal(st_b[:, :9, :K], st_a[:, :9, :K])
+
+
 @pytest.mark.parametrize("name", ["rec1", "synth_m6", "synth_m6_rls"])
 def test_emul_subband_gsc_chain(name):
     """SubbandGSC.process (G12, incl. the config-5 Subband-RLS composition) through the chain's stage programs: every returned signal
