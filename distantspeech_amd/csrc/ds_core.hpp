@@ -200,6 +200,9 @@ DS_HD cf cfnmac(cf acc, cf a, cf b) { return cfnmac_s(acc, a, b); }
 // than microphones: a periodic input, the bench's replayed hops) leaves pivots of rounding-level size and either sign; floored at 1e-30
 // they became r = 1e15 and the solve overflowed to NaN (found by bench.py --total-batch on a three-hop round, round 4).
 DS_HD float pivot_floor(float delta) { return delta > 1e-30f ? delta : 1e-30f; }
+// max(s, floor) as ONE v_max_f32 (written as a compare and a select against a run-time floor it compiled to six instructions per pivot:
+// +8 % vector instructions in the MVDR frame kernel)
+DS_HD float pivot_max(float s, float floor) { return __builtin_fmaxf(s, floor); }
 DS_HD cf cconj(cf a) { return mk(a.x, -a.y); }
 DS_HD cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
 DS_HD float cabs2(cf a) { return fma_(a.x, a.x, a.y * a.y); }
@@ -676,9 +679,9 @@ template <int M> struct Chol {
             float s = d[j] + diag;
 #pragma unroll
             for (int k = 0; k < j; ++k) { const cf l = L(j, k); s = fma_(-l.x, l.x, fma_(-l.y, l.y, s)); }
-            s = fmaxf_(s, fmaxf_(diag, 1e-30f));     // a pivot of R + diag I (R >= 0) is >= diag in exact arithmetic: see pivot_floor()
+            s = pivot_max(s, pivot_floor(diag));     // a pivot of R + diag I (R >= 0) is >= diag in exact arithmetic: see pivot_floor()
 #if defined(__HIP_DEVICE_COMPILE__)
-            const float r = rsqrtf(s);
+            const float r = __builtin_amdgcn_rsqf(s);      // (s >= 1e-30: see mvdr_output)
 #else
             const float r = 1.0f / sqrtf(s);
 #endif
@@ -843,9 +846,10 @@ template <int M> struct MvdrSweep {
         dg = diag;
     }
     DS_HD void column(int j) {
-        const float sj = fmaxf_(Ad[j], pivot_floor(dg));
+        const float sj = pivot_max(Ad[j], pivot_floor(dg));
 #if defined(__HIP_DEVICE_COMPILE__)
-        const float r = rsqrtf(sj);
+        const float r = __builtin_amdgcn_rsqf(sj);     // sj >= 1e-30: a normal number, the bare instruction (what rsqrtf() compiled to while the
+                                                       // floor was a literal; against a run-time floor it grew a denormal-range rescale per pivot)
 #else
         const float r = 1.0f / sqrtf(sj);
 #endif
@@ -892,9 +896,10 @@ template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag
     cf ut = mk(0.0f, 0.0f);
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-        const float sj = fmaxf_(Ad[j], pivot_floor(diag));
+        const float sj = pivot_max(Ad[j], pivot_floor(diag));
 #if defined(__HIP_DEVICE_COMPILE__)
-        const float r = rsqrtf(sj);
+        const float r = __builtin_amdgcn_rsqf(sj);     // sj >= 1e-30: a normal number, the bare instruction (what rsqrtf() compiled to while the
+                                                       // floor was a literal; against a run-time floor it grew a denormal-range rescale per pivot)
 #else
         const float r = 1.0f / sqrtf(sj);
 #endif
@@ -1015,7 +1020,7 @@ DS_HD void mcmcra_bin(float* pyy, float* pvv, const cf* Z, int k, int spp_frm_cn
         float s = sym_get<M>(pvv, j, j) + 1e-6f;
 #pragma unroll
         for (int q = 0; q < j; ++q) s = fma_(-Lm[j][q], Lm[j][q], s);
-        s = fmaxf_(s, pivot_floor(1e-6f));
+        s = pivot_max(s, pivot_floor(1e-6f));
         const float r = rsq_(s);
         inv_d[j] = r;
         Lm[j][j] = s * r;

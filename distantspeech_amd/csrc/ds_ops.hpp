@@ -682,7 +682,7 @@ template <int M> DS_HD void op_mcsppbase(const OpCtx& p, int b, int k) {
             float s = sym_get<M>(sv, j, j) + 1e-6f;
 #pragma unroll
             for (int q = 0; q < j; ++q) s = fma_(-Lm[j][q], Lm[j][q], s);
-            s = fmaxf_(s, pivot_floor(1e-6f));
+            s = pivot_max(s, pivot_floor(1e-6f));
             const float r = 1.0f / sqrtf(s);
             inv_d[j] = r; Lm[j][j] = s * r;
 #pragma unroll

@@ -207,3 +207,46 @@ def test_chain_stays_finite_on_a_periodic_input(ds):
             ref = o.process(x[0][:, hop:], ang)
     measured("cfg4_chain_periodic_input", y_rms=rms(y[0]), ref_rms=rms(ref), diff_rms=rms(y[0] - ref))
     assert rms(y[0]) < 1e-3 and rms(y[0] - ref) < 1e-4
+
+
+def test_wpe_td_checkpoint_reset_and_errors(ds):
+    """the one-call Wpe handle (DS_ALGO_WPE_TD) like every other handle: a checkpoint taken mid-stream and imported into a fresh object
+    continues bit for bit; reset() returns to the initial state; delay = 0 and hop = nfft / 2 run; shapes beyond the kernels are refused
+    at construction, wrong chunk lengths at the call"""
+    from oracle import ds_oracle as O
+    from distantspeech_amd import _lib as L
+    from distantspeech_amd._lib import DsError
+    C, N, nb, hop = 4, 20, 256, 64
+    x = reverberant(21, hop * 30, C)
+    a = ds.Wpe(channels=C, filter_len=N, delay=4, num_bands=nb, hop_length=hop)
+    y1 = a.update(x[: hop * 12])[0]
+    blob = a._eng.export_state()
+    y2 = a.update(x[hop * 12:])[0]
+    b = ds.Wpe(channels=C, filter_len=N, delay=4, num_bands=nb, hop_length=hop)
+    b._eng.import_state(blob)
+    assert np.array_equal(b.update(x[hop * 12:])[0], y2)
+    assert np.array_equal(a._eng.export_state(), b._eng.export_state())
+    a._eng.reset()
+    assert np.array_equal(a.update(x[: hop * 12])[0], y1)
+    with pytest.raises(DsError):
+        b._eng.import_state(blob[:-8])                                           # a truncated blob
+    with pytest.raises(DsError):
+        ds.Wpe(channels=C, filter_len=N, delay=4, num_bands=512, hop_length=256)._eng.import_state(blob)   # another configuration
+    # delay 0 (the current frame predicts itself: awpe.py allows it) and hop = nfft / 2, against the oracle
+    for dl, nbb, hp, CC, NN in ((0, 256, 128, 4, 6), (2, 512, 256, 3, 11)):
+        xx = reverberant(22 + dl, hp * 20, CC)
+        w = ds.Wpe(channels=CC, filter_len=NN, delay=dl, num_bands=nbb, hop_length=hp)
+        o = O.OracleWpe(channels=CC, filter_len=NN, num_bands=nbb, delay=dl, hop_length=hp)
+        y = np.concatenate([w.update(xx[n * hp:(n + 1) * hp])[0] for n in range(20)])
+        ref = np.concatenate([o.update(xx[n * hp:(n + 1) * hp])[0] for n in range(20)])
+        assert rms(y - ref) < 1e-5 * rms(ref), (dl, rms(y - ref), rms(ref))
+    with pytest.raises(DsError):
+        ds.Wpe(channels=4, filter_len=21, num_bands=256, hop_length=64)            # 84 taps-by-channels > 80
+    with pytest.raises(DsError):
+        ds.Wpe(channels=9, filter_len=2, num_bands=256, hop_length=64)             # more than 8 channels
+    with pytest.raises(DsError):
+        ds.Wpe(channels=4, filter_len=2, num_bands=256, hop_length=32)             # hop = nfft / 8
+    with pytest.raises(ValueError):
+        a.update(x[: hop + 1])                                                     # not a multiple of the hop
+    with pytest.raises(ValueError):
+        a.update(x[: hop, :3])                                                     # wrong channel count
