@@ -387,7 +387,7 @@ template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
 // dirty in L2 until the end-of-kernel write-back (measured: +4 % at B = 1024 and +11 % at B = 4096, one hop per call).
 // DS_PLAIN_STATE restores ordinary loads / stores for A/B runs.
 DS_HD void store_state(vec4* dst, const vec4& v) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_PLAIN_STATE)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_PLAIN_STATE) && !defined(DS_PLAIN_STATE_STORE)
     typedef float f4_t __attribute__((ext_vector_type(4)));
     f4_t q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
     __builtin_nontemporal_store(q, reinterpret_cast<f4_t*>(dst));
@@ -396,7 +396,7 @@ DS_HD void store_state(vec4* dst, const vec4& v) {
 #endif
 }
 DS_HD vec4 load_state(const vec4* src) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_PLAIN_STATE)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_PLAIN_STATE) && !defined(DS_PLAIN_STATE_LOAD)
     typedef float f4_t __attribute__((ext_vector_type(4)));
     const f4_t q = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(src));
     vec4 v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;

@@ -109,9 +109,17 @@ template <class Rg, int HOIST = 0> struct HipExec {
     // be in flight at once; lds_load_wait() before the phase ends retires them
     __device__ __forceinline__ void lds_load16(void* lds_piece, int lane, const void* src) {
         (void)lane;
+        // (cache policy 2 = nt: state streams through once per launch, like load_state())
+#if defined(DS_PLAIN_STATE) || defined(DS_PLAIN_STATE_LOAD)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 0);
+#else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_piece, 16, 0, 2);
+#endif
     }
-    __device__ __forceinline__ void lds_load_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // s_waitcnt vmcnt(0) as the BUILTIN (0x0f70: vmcnt 0, expcnt and lgkmcnt untouched), not inline assembly: the compiler's wait-count
+    // pass reads a real S_WAITCNT and knows the copies have landed.  Behind an opaque asm it kept them "pending" for the rest of the
+    // kernel — every LDS access after any global store then waited for vmcnt(0), and every counted wait degraded to 0
+    __device__ __forceinline__ void lds_load_wait() { __builtin_amdgcn_s_waitcnt(0x0f70); asm volatile("" ::: "memory"); }
     template <class FL, class FR> __device__ __forceinline__ void phase_wave2(FL fl, FR fr) {
         int tid = (int)threadIdx.x;
         DS_LAUNDER(tid);

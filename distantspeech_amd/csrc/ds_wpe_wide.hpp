@@ -141,9 +141,12 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
             if ((w1 & 1) && tid == 0) sh.tile[w1 - 1 - w0] = st[w1 - 1];
             ex.lds_load_wait();
         };
+        // (the tile's traffic is non-temporal in both directions — one instruction covers whole 128-byte lines, streamed once per launch:
+        // +9 % at one hop per call.  The W strips and taps are 8-byte pieces at a lane stride: as non-temporal stores those cost 24 % at
+        // 8 channels, so they stay ordinary; profiles/r04a/wpe_nt_ab.txt)
         auto tile_out = [&](int tid, int w0, int w1) {
             const int we = w1 & ~1;
-            for (int w = w0 + 2 * tid; w < we; w += 2 * NT) *reinterpret_cast<vec4*>(&st[w]) = *reinterpret_cast<const vec4*>(&sh.tile[w - w0]);
+            for (int w = w0 + 2 * tid; w < we; w += 2 * NT) store_state(reinterpret_cast<vec4*>(&st[w]), *reinterpret_cast<const vec4*>(&sh.tile[w - w0]));
             if ((w1 & 1) && tid == 0) st[w1 - 1] = sh.tile[w1 - 1 - w0];
         };
 

@@ -1,0 +1,103 @@
+// block_rw.hip — what HBM gives the wide-tap WPE kernel's ACCESS PATTERN with no arithmetic in it: one wavefront per block of BLK bytes (the
+// state of one bin: 29 KB at C N = 80), read in CH-byte chunks through LDS-DMA into an LDS tile and written back from the tile, chunk
+// after chunk; LDSB bytes of LDS per wavefront set how many wavefronts a CU holds (160 KB / LDSB, at most 8 per SIMD).
+// hipcc -O3 --offload-arch=gfx950 scratch/micro/block_rw.hip -o scratch/micro/block_rw && scratch/micro/block_rw
+// Reported: (bytes read + bytes written) / kernel time — the number the kernel's roofline fraction is measured against 8 TB/s with.
+//   mode 0: read chunk, wait, write chunk back (the kernel's order with the frame loop taken out: chunks one after the other)
+//   mode 1: read every chunk of the block first (tile = the whole block), one wait, then write all
+//   mode 2: mode 0, and SPIN dependent v_fma per chunk between the read and the write (a stand-in for gather + update + scatter)
+// and the variants: nontemporal loads / stores, a second array to write to (ping-pong state), read only, write only
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); std::exit(1); } } while (0)
+
+// AUXL: cache-policy bits of the loads (0, or 2 = nt); NTS: nontemporal stores; OOP: write to a second array (ping-pong state)
+// WR: 0 = read + write, 1 = read only, 2 = write only
+template <int MODE, int AUXL = 0, bool NTS = false, bool OOP = false, int WR = 0>
+__global__ void __launch_bounds__(64) rw(float* state, float* state2, long long blk_floats, int chunk_floats, int spin, float seed) {
+    extern __shared__ float4 tile[];
+    const int l = threadIdx.x;
+    float* st = state + (long long)blockIdx.x * blk_floats;
+    float* so = (OOP ? state2 : state) + (long long)blockIdx.x * blk_floats;
+    auto put = [&](float* dst, float4 v) {
+        if constexpr (WR == 1) { if (v.x == 12345.678f) *reinterpret_cast<float4*>(dst) = v; }
+        else if constexpr (NTS) { typedef float v4 __attribute__((ext_vector_type(4))); v4 u = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(u, reinterpret_cast<v4*>(dst)); }
+        else *reinterpret_cast<float4*>(dst) = v;
+    };
+    const int nch = (int)((blk_floats + chunk_floats - 1) / chunk_floats);
+    float acc = seed + l;
+    if constexpr (MODE == 1) {
+        for (int w = 0; w < blk_floats; w += 256)
+            if (w + 4 * l < blk_floats)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st + w + 4 * l), (__attribute__((address_space(3))) void*)(tile + w / 4), 16, 0, AUXL);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < spin; ++i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(acc) : "v"(seed));
+        if (acc == 12345.678f) tile[l].x = acc;
+        for (int w = 0; w < blk_floats; w += 256)
+            if (w + 4 * l < blk_floats) put(so + w + 4 * l, tile[w / 4 + l]);
+    } else {
+        for (int c = 0; c < nch; ++c) {
+            const long long w0 = (long long)c * chunk_floats;
+            const long long w1 = w0 + chunk_floats < blk_floats ? w0 + chunk_floats : blk_floats;
+            for (long long w = w0; w < w1; w += 256)
+                if (WR != 2 && w + 4 * l < w1)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st + w + 4 * l), (__attribute__((address_space(3))) void*)(tile + (w - w0) / 4), 16, 0, AUXL);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (MODE == 2) {
+                for (int i = 0; i < spin; ++i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(acc) : "v"(seed));
+                if (acc == 12345.678f) tile[l].x = acc;
+            }
+            for (long long w = w0; w < w1; w += 256)
+                if (w + 4 * l < w1) put(so + w + 4 * l, tile[(w - w0) / 4 + l]);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+int main(int argc, char** argv) {
+    const long long blocks = argc > 1 ? atoll(argv[1]) : 132096;          // wpe_nb: 1024 utterances x 129 bins
+    const long long blk_bytes = 29120;                                     // wpe_bin_floats(4, 20) * 4 rounded to 16 B
+    const long long blk_floats = blk_bytes / 4;
+    float *state, *state2;
+    CK(hipMalloc(&state, blocks * blk_bytes));
+    CK(hipMalloc(&state2, blocks * blk_bytes));
+    CK(hipMemset(state, 0, blocks * blk_bytes));
+    CK(hipMemset(state2, 0, blocks * blk_bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    typedef void (*K)(float*, float*, long long, int, int, float);
+    struct Case { const char* name; K k; int chunk_bytes; int lds_bytes; int spin; double traffic; };
+    std::vector<Case> cases = {
+        {"chunks, in place", rw<0>, 13312, 20480, 0, 2}, {"chunks, in place", rw<0>, 13312, 14336, 0, 2},
+        {"chunks, in place", rw<0>, 6656, 20480, 0, 2}, {"chunks, in place", rw<0>, 6656, 6656, 0, 2}, {"chunks, in place", rw<0>, 4096, 5120, 0, 2},
+        {"whole block, in place", rw<1>, 29120, 32768, 0, 2},
+        {"chunks, nt loads", rw<0, 2>, 13312, 20480, 0, 2}, {"chunks, nt stores", rw<0, 0, true>, 13312, 20480, 0, 2},
+        {"chunks, nt loads+stores", rw<0, 2, true>, 13312, 20480, 0, 2}, {"whole block, nt loads+stores", rw<1, 2, true>, 29120, 32768, 0, 2},
+        {"chunks, out of place", rw<0, 0, false, true>, 13312, 20480, 0, 2}, {"chunks, out of place, nt", rw<0, 2, true, true>, 13312, 20480, 0, 2},
+        {"whole block, out of place", rw<1, 0, false, true>, 29120, 32768, 0, 2}, {"whole block, out of place, nt", rw<1, 2, true, true>, 29120, 32768, 0, 2},
+        {"chunks, read only", rw<0, 0, false, false, 1>, 13312, 20480, 0, 1}, {"chunks, read only nt", rw<0, 2, false, false, 1>, 13312, 20480, 0, 1},
+        {"chunks, write only", rw<0, 0, false, false, 2>, 13312, 20480, 0, 1}, {"chunks, write only nt", rw<0, 0, true, false, 2>, 13312, 20480, 0, 1},
+        {"chunks + 500 fma", rw<2>, 13312, 20480, 500, 2}, {"chunks + 250 fma", rw<2>, 13312, 20480, 250, 2},
+    };
+    std::printf("%lld blocks of %lld bytes (%.2f GB)\n%-32s chunk  lds/wave waves/CU spin   ms      TB/s\n", blocks, blk_bytes, blocks * blk_bytes / 1e9, "pattern");
+    for (const Case& c : cases) {
+        auto launch = [&]() { hipLaunchKernelGGL(c.k, dim3((unsigned)blocks), dim3(64), c.lds_bytes, 0, state, state2, blk_floats, c.chunk_bytes / 4, c.spin, 0.0f); };
+        launch(); launch();
+        CK(hipDeviceSynchronize());
+        const int reps = 10;
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) launch();
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        ms /= reps;
+        int wpc = 163840 / c.lds_bytes; if (wpc > 32) wpc = 32;
+        std::printf("%-32s %6d %6d   %3d      %5d  %7.3f  %6.3f\n", c.name, c.chunk_bytes, c.lds_bytes, wpc, c.spin, ms, c.traffic * blocks * blk_bytes / (ms * 1e-3) / 1e12);
+    }
+    return 0;
+}
