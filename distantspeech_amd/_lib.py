@@ -25,6 +25,7 @@ ALGO_FDGSC = 21
 ALGO_WPE_TD = 22
 PARAM_POSTFILTER = 15
 PARAM_TAIL_ASYNC = 17
+PARAM_REF_POWERS = 18
 PARAM_FDAF_TWO_PATH = 16
 CHAIN_AUX_FIR, CHAIN_AUX_COHERENCE = 0, 1
 PARAM_WPE_DELAY = 13
@@ -40,6 +41,7 @@ PARAM_METHOD, PARAM_MCRA_L, PARAM_ALPHA_Y, PARAM_ALPHA_V, PARAM_DIAG, PARAM_GATE
 (FIELD_RVV, FIELD_RYY, FIELD_MCRA_S, FIELD_MCRA_SMIN, FIELD_MCRA_STMP, FIELD_MCRA_P, FIELD_MCRA_LAMBDA_D,
  FIELD_PHI_YY, FIELD_PHI_VV, FIELD_G_AIC, FIELD_STFT_TAIL, FIELD_OLA_TAIL, FIELD_COUNTERS, FIELD_OP_STATE, FIELD_NOTCH_MEM) = range(1, 16)
 FIELD_H = 16
+FIELD_REF_POWERS = 17
 
 
 class ds_config(ctypes.Structure):
@@ -76,7 +78,7 @@ EXPORTS = [
 
 
 def build_info():
-    """{'version': '104', 'state_layout': '3', 'arch': 'gfx950', 'shelved': '0'}: ds_build_info() parsed"""
+    """{'version': '105', 'state_layout': '3', 'arch': 'gfx950', 'shelved': '0'}: ds_build_info() parsed"""
     txt = load().ds_build_info().decode()
     return dict(kv.split("=", 1) for kv in txt.split()[1:])
 

@@ -245,7 +245,11 @@ class GSC(_AdaptiveBase):
 
     _ALGO = L.ALGO_GSC
 
-    def __init__(self, mic_array: MicArray, frameLen=256, angle=[197, 0], batch=1, device=-1):
+    def __init__(self, mic_array: MicArray, frameLen=256, angle=[197, 0], batch=1, device=-1, track_omlsa_multi=False):
+        """track_omlsa_multi: also keep `self.omlsa_multi` (NsOmlsaMulti, GSC.py:78) up to date — the reference runs its estimation() on the
+        canceller output and the blocking-matrix outputs of every frame (GSC.py:281-283) and uses nothing of it, so it is off by default:
+        when on, the frame kernel writes those powers out per frame and bin (DS_PARAM_REF_POWERS) and an NsOmlsaMulti operator consumes
+        them after every process() call."""
         beamformer.__init__(self, mic_array, frame_len=frameLen, batch=batch, device=device)
         self.mic_array = mic_array
         self.angle = np.array(angle) / 180 * np.pi if isinstance(angle, list) else angle
@@ -255,10 +259,19 @@ class GSC(_AdaptiveBase):
         self._steer_angle = None
         self._make_engine()
         self._eng.set_method(0)
+        self._track_omlsa_multi = bool(track_omlsa_multi)
+        if self._track_omlsa_multi:
+            from .ops import NsOmlsaMulti
+            self.omlsa_multi = NsOmlsaMulti(nfft=self.nfft, M=self.M, cal_weights=True, batch=batch, device=device)   # GSC.py:78
+            self._eng.set_param_i(L.PARAM_REF_POWERS, 1)
 
     def process(self, x, angle, method=2, retH=False, retWNG=False, retDI=False):
         """x [M, samples] (or [B, M, samples]); angle in radians; method 0 passes channel 0 through."""
-        return self._run(x, angle, method, retH, retWNG, retDI)
+        out = self._run(x, angle, method, retH, retWNG, retDI)
+        if self._track_omlsa_multi and method != 0:                         # GSC.py:242-243: method 0 leaves the frame before :281
+            pw = self._eng.get_field(L.FIELD_REF_POWERS)                    # [B, T, K, M]: |Y|^2, |U_1|^2 .. |U_{M-1}|^2
+            self.omlsa_multi.estimation_frames(pw[..., 0], pw[..., 1:])
+        return out
 
     @property
     def G(self):

@@ -418,6 +418,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->diag = cfg->diag > 0 ? cfg->diag : 1e-6f;
     h->gate = cfg->gate > 0 ? cfg->gate : 0.4f;
     h->mu = cfg->mu > 0 ? cfg->mu : 0.01f;
+    h->ref_powers = false; h->ref_pow = nullptr; h->ref_pow_cap = 0; h->ref_pow_T = 0;
     if (cfg->device >= 0) h->device = cfg->device;
     else if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
     h->stream = nullptr; h->ev0 = nullptr; h->ev1 = nullptr;
@@ -584,6 +585,7 @@ int ds_destroy(ds_handle* h) {
     for (int i = 0; i < 24; ++i) (void)hipFree(h->chain_buf[i]);
     (void)hipFree(h->bins); (void)hipFree(h->tail_in); (void)hipFree(h->tail_out); (void)hipFree(h->counters);
     (void)hipFree(h->tables); (void)hipFree(h->steer); (void)hipFree(h->dev_cnt);
+    (void)hipFree(h->ref_pow);
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage); (void)hipFree(h->opst);
     for (int i = 0; i < 10; ++i) (void)hipFree(h->dev_buf[i]);
     (void)hipFree(h->tdf_w); (void)hipFree(h->tdf_buf); (void)hipFree(h->tdf_P);
@@ -674,6 +676,12 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
             h->tail_async = value != 0;
             return DS_OK;
         }
+        case DS_PARAM_REF_POWERS:
+            if (h->cfg.algo != DS_ALGO_GSC) return fail(h, DS_EINVAL, "ref powers: DS_ALGO_GSC handles only");
+            { const int jr = join_groups(h); if (jr) return jr; }
+            h->ref_powers = value != 0;
+            h->ref_pow_T = 0;
+            return DS_OK;
         case DS_PARAM_POSTFILTER:
             if (h->cfg.algo != DS_ALGO_TDGSC && h->cfg.algo != DS_ALGO_FDGSC) return fail(h, DS_EINVAL, "postfilter: TDGSC / FDGSC chain handles only");
             h->postfilter = value != 0;
@@ -785,8 +793,24 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
     p.T = n_samples / h->cfg.hop;
     p.batch0 = first;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    if (h->ref_powers) {                                    // DS_PARAM_REF_POWERS: [B][T][K][M] of this call, indexed by the handle's utterance numbers
+        if (h->group_enqueue) return fail(h, DS_ESTATE, "ds_process_device: DS_PARAM_REF_POWERS is on — no utterance groups");
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(h, DS_ESTATE, "ds_process_device: DS_PARAM_REF_POWERS is on — no hipGraph capture");
+        const size_t need = (size_t)h->cfg.batch * p.T * h->K * h->cfg.n_mics;
+        if (need > h->ref_pow_cap) {
+            DS_HIP(h, hipStreamSynchronize(s));
+            (void)hipFree(h->ref_pow); h->ref_pow = nullptr; h->ref_pow_cap = 0;
+            DS_HIP(h, hipMalloc((void**)&h->ref_pow, need * sizeof(float)));
+            h->ref_pow_cap = need;
+        }
+        if (count != h->cfg.batch) DS_HIP(h, hipMemsetAsync(h->ref_pow, 0, need * sizeof(float), s));   // utterances outside the range read as zeros
+        p.ref_pow = h->ref_pow;
+        h->ref_pow_T = p.T;
+    }
     // calls of several hops: the hop-pipelined kernel (same results bit for bit; at one or two hops per call it has nothing to overlap)
-    const ds::launch_fn launch = (h->ki.launch_pipe && p.T >= h->pipe_min_T) ? h->ki.launch_pipe : h->ki.launch;
+    const ds::launch_fn launch = (h->ki.launch_pipe && p.T >= h->pipe_min_T && !h->ref_powers) ? h->ki.launch_pipe : h->ki.launch;
     DS_HIP(h, launch(p, count, s));
     return DS_OK;
 }
@@ -799,6 +823,8 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     if (n_calls < 0 || (x_call_stride & 3) || (y_call_stride & 3))
         return fail(h, DS_EINVAL, "ds_process_device_seq: bad n_calls / call strides (must be multiples of 4 elements)");
     if (n_calls == 0) return DS_OK;
+    if (h->ref_powers && (n_calls > 1 || graph != 0))
+        return fail(h, DS_ESTATE, "ds_process_device_seq: DS_PARAM_REF_POWERS keeps the powers of ONE plain call (n_calls 1, graph 0)");
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const bool chain = wpe_chain(h) || h->cfg.algo == DS_ALGO_SUBBAND_GSC;
     if (h->cfg.algo == DS_ALGO_TDGSC || h->cfg.algo == DS_ALGO_FDGSC) graph = 0;      // their stages keep the frame counters on the host
@@ -819,7 +845,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     // or its last round of workgroups the other group's kernel fills the CUs: +12..15 % at 2048-4096 utterances per call, +3 % at 16 384,
     // nothing at 1024 (one round of workgroups).  A caller-provided stream keeps everything on that stream.
     const bool frames = h->cfg.algo <= DS_ALGO_GSC;
-    const int ng = (frames && !stream) ? (h->split < count ? h->split : (count > 0 ? count : 1)) : 1;
+    const int ng = (frames && !stream && !h->ref_powers) ? (h->split < count ? h->split : (count > 0 ? count : 1)) : 1;
     if (ng > 1) {
         DS_HIP(h, hipSetDevice(h->device));                 // not set_device(): the groups stay on their streams between calls
         if (!h->ev_fork) DS_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -1054,6 +1080,7 @@ size_t ds_field_bytes(const ds_handle* h, int field) {
             return opst_bytes(h);
         case DS_FIELD_NOTCH_MEM: return h->td_mem ? B * M * 2 * sizeof(float) : 0;
         case DS_FIELD_H: return (ad && h->method != DS_METHOD_TFGSC) ? B * K * M * 2 * sizeof(float) : 0;
+        case DS_FIELD_REF_POWERS: return (gsc && h->ref_powers) ? B * (size_t)h->ref_pow_T * K * M * sizeof(float) : 0;
         default: return 0;
     }
 }
@@ -1077,6 +1104,7 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
         return DS_OK;
     }
     if (field == DS_FIELD_NOTCH_MEM) { DS_HIP(h, hipMemcpy(dst, h->td_mem, need, hipMemcpyDeviceToHost)); return DS_OK; }
+    if (field == DS_FIELD_REF_POWERS) { DS_HIP(h, hipMemcpy(dst, h->ref_pow, need, hipMemcpyDeviceToHost)); return DS_OK; }
     if (field == DS_FIELD_OP_STATE) {
         DS_HIP(h, hipMemcpy(dst, h->tdf_w ? (const void*)h->tdf_w : (const void*)h->opst, need, hipMemcpyDeviceToHost));
         return DS_OK;

@@ -273,6 +273,9 @@ struct Params {
     float diag;               // adaptivebeamformer.py:89
     float gate;               // adaptivebeamformer.py:94
     float mu;                 // GSC.py:202
+    float* ref_pow;           // GSC, optional (null = off): [B][T][K][M] float, per frame and bin |Y|^2 of the canceller output in front of the
+                              // post-filter gain and |U_i|^2 of the M - 1 blocking-matrix outputs — what GSC.py:281-283 hands to
+                              // NsOmlsaMulti.estimation (DS_PARAM_REF_POWERS; utterance index = batch0 + block, as the state's)
     int rows;                 // single-channel transforms run one row per wavefront (StftRowsEngine / IstftRowsEngine): number of rows
     TickArgs tick;            // counters of an EARLIER stage of the chain to advance (stand-alone transform kernels only; cnt null = none)
     TickArgs tick2, tick3;    // two more (synthesis kernels only: the last launch of a DS_ALGO_WPE_MVDR group advances every counter of its step)
@@ -1115,7 +1118,7 @@ DS_HD void mcmcra_bin(float* pyy, float* pvv, const cf* Z, int k, int spp_frm_cn
 
 // GSC.process for one bin: McMcra SPP/gain (GSC.py:225) + FD-GSC with SPP-stepped LMS canceller (GSC.py:245-286).
 template <int M>
-DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, int spp_frm_cnt) {
+DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, int spp_frm_cnt, long long pw_row0 = -1) {
     typedef StateLayout<M, ALGO_GSC, false> SL;
     float* ga = st + SL::GA;
     float pp, G, xi, gam;
@@ -1134,6 +1137,12 @@ DS_HD cf gsc_bin(float* st, const cf* Z, const cf* a, const Params& p, int k, in
     for (int i = 0; i < M - 1; ++i) {
         U[i] = csub(u0, cmulc(Z[i + 1], a[i + 1]));
         Yk = cfnmac(Yk, U[i], mk(ga[2 * i], ga[2 * i + 1]));                           // conj(G_i) U_i
+    }
+    if (p.ref_pow != nullptr && pw_row0 >= 0) {                                             // GSC.py:281-283: the powers omlsa_multi.estimation is given
+        float* pw = p.ref_pow + (pw_row0 + k) * M;                                          // (a uniform branch; the address only inside it)
+        pw[0] = cabs2(Yk);
+#pragma unroll
+        for (int i = 0; i < M - 1; ++i) pw[1 + i] = cabs2(U[i]);
     }
     const float step = p.mu * (1.0f - pp);                                                  // GSC.py:270-274
 #pragma unroll
@@ -1286,7 +1295,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
 
     // one frequency bin: MCRA / covariance recursion / solve -> Y[k]
     static DS_HD cf bin_program(float* st, const cf* Z, const cf* steer, int k, const Sh& sh, const Params& p,
-                                int frm_cnt, bool reset, int spp_cnt, cf ad = cf{0.0f, 0.0f}, float apk = 0.0f) {
+                                int frm_cnt, bool reset, int spp_cnt, cf ad = cf{0.0f, 0.0f}, float apk = 0.0f, long long pw_row0 = -1) {
         if constexpr (ALGO == ALGO_AIC) return aic_bin<M>(st, Z, ad, apk, p);
         cf a[M];
 #pragma unroll
@@ -1298,7 +1307,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             mcra_bin(st + SL::MC_S, k, K, sh.pw[k > 0 ? k - 1 : 0], sh.pw[k], sh.pw[k + 1], frm_cnt, reset, p.mcra_L);
             Yk = adaptive_bin<M, RYY>(st, Z, a, p);
         } else {
-            Yk = gsc_bin<M>(st, Z, a, p, k, spp_cnt);
+            Yk = gsc_bin<M>(st, Z, a, p, k, spp_cnt, pw_row0);
         }
         return Yk;
     }
@@ -1319,6 +1328,8 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         constexpr bool HAS_CNT = ALGO == ALGO_ADAPTIVE || ALGO == ALGO_GSC;
         int frm_cnt = HAS_CNT ? cnt[0] : 0, ell = HAS_CNT ? cnt[1] : 1, spp_cnt = HAS_CNT ? cnt[2] : 0;
         int old_half = 0;
+        // Params::ref_pow: row of frame t, bin 0 of this utterance in [B][T][K] (GSC only; wave-uniform)
+        auto ref_pow_row = [&](int t) -> long long { return ALGO == ALGO_GSC ? ((long long)b * p.T + t) * K : -1; };
 #if defined(DS_LATE_STATE_STORE)
         constexpr bool EARLY_STORE = false;                        // A/B switch: everything in the epilogue, as before round 3
 #else
@@ -1541,7 +1552,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             const bool reset = (frm_cnt != 0) && (ell % p.mcra_L == 0);
             ex.phase([&](int tid, Rg& r) {
                 DS_SETPRIO(0);                                          // the wide, arithmetic-heavy phase yields to other workgroups' latency-bound ones
-                cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt, r.ad, r.apk);
+                cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt, r.ad, r.apk, ref_pow_row(t));
                 if (tid == 0) Yk.y = 0.0f;                              // irfft ignores Im Y[0] and Im Y[N/2]
                 sh.Y[tid] = Yk;
                 if constexpr (EARLY_STORE) {
@@ -1564,7 +1575,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                         cf Zn[M];
 #pragma unroll
                         for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; Zn[m] = mk(F0.x - F0.y, 0.0f); }
-                        const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_cnt, reset, spp_cnt, r.adn, r.apkn);
+                        const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_cnt, reset, spp_cnt, r.adn, r.apkn, ref_pow_row(t));
                         sh.Y[NC] = mk(Yn.x, 0.0f);
                     }
                 }
@@ -1589,7 +1600,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     cf Zn[M];
 #pragma unroll
                     for (int m = 0; m < M; ++m) Zn[m] = mk(sh.zn[m], 0.0f);
-                    const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_nyq, reset, spp_nyq, r.adn, r.apkn);
+                    const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_nyq, reset, spp_nyq, r.adn, r.apkn, ref_pow_row(t));
                     sh.Y[NC] = mk(Yn.x, 0.0f);                          // irfft ignores Im Y[N/2]
                 }
             });

@@ -119,6 +119,10 @@ struct ds_handle {
     int method;
     int mcra_L;
     float alpha_y, alpha_v, diag, gate, mu, out_scale;
+    bool ref_powers;            // DS_PARAM_REF_POWERS (DS_ALGO_GSC): the frame kernel also writes Params::ref_pow ...
+    float* ref_pow;             // ... [B][ref_pow_T][K][M] of the last call (grown on demand)
+    size_t ref_pow_cap;         // floats allocated
+    int ref_pow_T;              // hops of the last call (0: none yet)
     std::string err;
 };
 

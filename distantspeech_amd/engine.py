@@ -478,6 +478,8 @@ class BatchEngine:
             return out.view(np.complex64).reshape(B, K, M - 1)
         if field == L.FIELD_H:
             return out.view(np.complex64).reshape(B, K, M)
+        if field == L.FIELD_REF_POWERS:
+            return out.reshape(B, -1, K, M)                 # [B, T of the last call, K, M]
         if field == L.FIELD_STFT_TAIL:
             return out.reshape(B, M, self.nfft - self.hop)
         if field == L.FIELD_OLA_TAIL:

@@ -364,6 +364,16 @@ class NsOmlsaMulti(_Base):
             return None
         return self._sq(lam[:, 0, :].astype(np.float64))
 
+    def estimation_frames(self, y, u):
+        """T successive estimation() calls as one native call: y [B, T, half_bin], u [B, T, half_bin, M-1] powers (T may be 0)."""
+        y = np.asarray(y, dtype=np.float32)
+        u = np.asarray(u, dtype=np.float32)
+        assert y.ndim == 3 and u.ndim == 4 and y.shape[-1] == self.half_bin and u.shape[-1] == self.M - 1
+        if y.shape[1] == 0:
+            return
+        self._eng.omlsa_estimate(y, u)
+        self._first = False
+
     def _row(self, f):
         return self._sq(self._eng.op_state()[:, f, :].astype(np.float64))
 

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DS_VERSION 104
+#define DS_VERSION 105
 #define DS_STATE_LAYOUT 3   /* serialised arrangement of the carried state (checkpoint header; measurement records quote it) */
 
 /* error codes */
@@ -171,6 +171,11 @@ typedef struct ds_config {
                                          when the process's HIP runtime has >= 6 hardware queues per device (the APPLICATION sets GPU_MAX_HW_QUEUES=8
                                          before its first HIP call; the runtime's default is 4 and the library cannot query it); default 0, or
                                          DS_CHAIN_TAIL_ASYNC=1 in the environment at ds_create */
+#define DS_PARAM_REF_POWERS 18       /* int 0/1, DS_ALGO_GSC: every ds_process / ds_process_device call also keeps, per frame and bin, the power of the canceller
+                                         output in front of the post-filter gain and the powers of the M - 1 blocking-matrix outputs — the arguments of
+                                         omlsa_multi.estimation in GSC.process (GSC.py:281-283; the reference computes that estimate and uses nothing of
+                                         it).  Read with ds_get_state(DS_FIELD_REF_POWERS) after the call.  One plain call at a time: sequences of several
+                                         calls, hipGraph replays and utterance groups are refused while it is on; default 0 */
 #define DS_PARAM_POSTFILTER 15       /* int 0/1: DS_ALGO_TDGSC / DS_ALGO_FDGSC handles apply the OMLSA post-filter in ds_process_device; default 0 */
 #define DS_PARAM_SPLIT 8   /* int 1..8: utterance groups.  Fused frame kernels: ds_process_device_seq runs the utterance range as that many groups,
                               each on its own stream at its own pace (its own hipGraph with graph=1); default 2 from 2048 utterances up, else 1.
@@ -195,6 +200,7 @@ typedef struct ds_config {
 #define DS_FIELD_H 16          /* DS_ALGO_ADAPTIVE, methods src / DS / MVDR: [B][K][M][2] the weights the frame kernel applies to the next frame
                                  (adaptivebeamformer.py:105-112: H[:, k]), computed by the kernel's own fused Cholesky solve on the handle's Rvv —
                                  a read-only probe; needs ds_set_steering */
+#define DS_FIELD_REF_POWERS 17 /* DS_ALGO_GSC with DS_PARAM_REF_POWERS: [B][T][K][M] of the LAST call (T = its hops): [0] = |Y|^2, [1 + i] = |U_i|^2 */
 #define DS_FIELD_NOTCH_MEM 15 /* DS_ALGO_FRONTEND: [B][M][2] the DC notch memories (FilterDcNotch16.notch_mem, feature.py:34,47) */
 
 int ds_version(void);

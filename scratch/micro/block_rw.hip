@@ -59,6 +59,47 @@ __global__ void __launch_bounds__(64) rw(float* state, float* state2, long long 
     }
 }
 
+// mode 3: a workgroup of WV wavefronts, one block each, the read and the write phases of its wavefronts aligned by workgroup barriers
+// (chunks through LDS as in mode 0; LDS per workgroup = WV tiles)
+template <int WV, int AUXL, bool NTS>
+__global__ void __launch_bounds__(64 * WV) rw_aligned(float* state, float*, long long blk_floats, int chunk_floats, int, float) {
+    extern __shared__ float4 tile[];
+    const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float4* my = tile + (size_t)wv * (chunk_floats / 4);
+    float* st = state + ((long long)blockIdx.x * WV + wv) * blk_floats;
+    const int nch = (int)((blk_floats + chunk_floats - 1) / chunk_floats);
+    for (int c = 0; c < nch; ++c) {
+        const long long w0 = (long long)c * chunk_floats;
+        const long long w1 = w0 + chunk_floats < blk_floats ? w0 + chunk_floats : blk_floats;
+        __syncthreads();
+        for (long long w = w0; w < w1; w += 256)
+            if (w + 4 * l < w1)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st + w + 4 * l), (__attribute__((address_space(3))) void*)(my + (w - w0) / 4), 16, 0, AUXL);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        for (long long w = w0; w < w1; w += 256)
+            if (w + 4 * l < w1) {
+                const float4 v = my[(w - w0) / 4 + l];
+                if constexpr (NTS) { typedef float v4 __attribute__((ext_vector_type(4))); v4 u = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(u, reinterpret_cast<v4*>(st + w + 4 * l)); }
+                else *reinterpret_cast<float4*>(st + w + 4 * l) = v;
+            }
+    }
+}
+// mode 4: the frame kernels' pattern: a 256-thread workgroup reads NB consecutive blocks (NB x 29 KB) into REGISTERS in one burst of
+// 16-byte loads, one barrier, and writes them back in one burst
+template <int NV, bool NT>
+__global__ void __launch_bounds__(256) rw_burst(float* state, float*, long long blk_floats, int, int, float) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const long long burst = (long long)NV * 256 * 4;                                     // floats per workgroup
+    v4* st = reinterpret_cast<v4*>(state + (long long)blockIdx.x * burst);
+    v4 r[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = NT ? __builtin_nontemporal_load(st + i * 256 + threadIdx.x) : st[i * 256 + threadIdx.x];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { if (NT) __builtin_nontemporal_store(r[i], st + i * 256 + threadIdx.x); else st[i * 256 + threadIdx.x] = r[i]; }
+}
+
 int main(int argc, char** argv) {
     const long long blocks = argc > 1 ? atoll(argv[1]) : 132096;          // wpe_nb: 1024 utterances x 129 bins
     const long long blk_bytes = 29120;                                     // wpe_bin_floats(4, 20) * 4 rounded to 16 B
@@ -85,6 +126,34 @@ int main(int argc, char** argv) {
         {"chunks + 500 fma", rw<2>, 13312, 20480, 500, 2}, {"chunks + 250 fma", rw<2>, 13312, 20480, 250, 2},
     };
     std::printf("%lld blocks of %lld bytes (%.2f GB)\n%-32s chunk  lds/wave waves/CU spin   ms      TB/s\n", blocks, blk_bytes, blocks * blk_bytes / 1e9, "pattern");
+    {   // aligned workgroups and register bursts
+        struct Sp { const char* name; K k; int threads; long long grid; int lds; int chunk; };
+        const long long total = blocks * blk_bytes;
+        std::vector<Sp> sp = {
+            {"4 waves aligned, chunks", rw_aligned<4, 0, false>, 256, blocks / 4, 4 * 13312, 13312},
+            {"4 waves aligned, chunks, nt", rw_aligned<4, 2, true>, 256, blocks / 4, 4 * 13312, 13312},
+            {"2 waves aligned, chunks, nt", rw_aligned<2, 2, true>, 128, blocks / 2, 2 * 13312, 13312},
+            {"4 waves aligned, whole, nt", rw_aligned<4, 2, true>, 256, blocks / 4, 4 * 29120, 29120},
+            {"burst 28 KB / workgroup", rw_burst<7, false>, 256, total / (7 * 4096), 0, 0},
+            {"burst 28 KB / workgroup, nt", rw_burst<7, true>, 256, total / (7 * 4096), 0, 0},
+            {"burst 112 KB / workgroup", rw_burst<28, false>, 256, total / (28 * 4096), 0, 0},
+            {"burst 112 KB / workgroup, nt", rw_burst<28, true>, 256, total / (28 * 4096), 0, 0},
+        };
+        for (const Sp& c : sp) {
+            if (c.lds > 65536) CK(hipFuncSetAttribute((const void*)c.k, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds));
+            auto launch = [&]() { hipLaunchKernelGGL(c.k, dim3((unsigned)c.grid), dim3(c.threads), c.lds, 0, state, state2, blk_floats, c.chunk / 4, 0, 0.0f); };
+            launch(); launch();
+            CK(hipDeviceSynchronize());
+            const int reps = 10;
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; ++r) launch();
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            ms /= reps;
+            std::printf("%-32s %6d %6d                   %7.3f  %6.3f\n", c.name, c.chunk, c.lds, ms, 2.0 * blocks * blk_bytes / (ms * 1e-3) / 1e12);
+        }
+    }
     for (const Case& c : cases) {
         auto launch = [&]() { hipLaunchKernelGGL(c.k, dim3((unsigned)blocks), dim3(64), c.lds_bytes, 0, state, state2, blk_floats, c.chunk_bytes / 4, c.spin, 0.0f); };
         launch(); launch();

@@ -398,6 +398,10 @@ int emul_layout(int algo, int nfft, int M, int ryy, int* kp) {
     return nf;
 }
 
+// Params::ref_pow for the next emul_run calls (GSC: the powers GSC.py:281-283 hands to omlsa_multi.estimation), [B][T][K][M]; null = off
+static float* g_ref_pow = nullptr;
+void emul_set_ref_pow(float* ptr) { g_ref_pow = ptr; }
+
 int emul_run(int algo, int nfft, int M, int ryy, int batch, const float* x, int layout, int n_samples, float* y,
              float* bins, float* tail_in, float* tail_out, int* counters, const float* steer, int steer_per_utt,
              int method, int mcra_L, float alpha_y, float alpha_v, float diag, float gate, float mu) {
@@ -421,6 +425,7 @@ int emul_run(int algo, int nfft, int M, int ryy, int batch, const float* x, int 
     p.method = method;
     p.mcra_L = mcra_L;
     p.alpha_y = alpha_y; p.alpha_v = alpha_v; p.beta_y = ds::complement_of(alpha_y); p.beta_v = ds::complement_of(alpha_v); p.diag = diag; p.gate = gate; p.mu = mu;
+    p.ref_pow = g_ref_pow;
     switch (nfft) {
         case 256: return run_n<256>(M, algo, ryy, p, batch);
         case 512: return run_n<512>(M, algo, ryy, p, batch);

@@ -71,18 +71,22 @@ class EmulEngine:
         self.steer_per_utt = int(a.ndim == 3)
         self.steer = a
 
-    def process(self, x, layout):
-        """x [B, L, M] (layout 0) or [B, M, L] (layout 1) float32 -> y [B, L]"""
+    def process(self, x, layout, ref_pow=False):
+        """x [B, L, M] (layout 0) or [B, M, L] (layout 1) float32 -> y [B, L]; ref_pow (GSC): also self.ref_pow [B, T, K, M], the powers of
+        the canceller output and of the blocking-matrix outputs per frame and bin (Params::ref_pow)"""
         x = np.ascontiguousarray(x, dtype=np.float32)
         L = x.shape[1] if layout == 0 else x.shape[2]
         y = np.zeros((self.batch, L), dtype=np.float32)
         f = ctypes.c_float
+        self.ref_pow = np.zeros((self.batch, L // self.hop, self.K, self.M), dtype=np.float32) if ref_pow else None
+        lib().emul_set_ref_pow(_vp(self.ref_pow))
         rc = lib().emul_run(self.algo, self.nfft, self.M, self.ryy, self.batch, x.ctypes.data_as(ctypes.c_void_p), layout, L,
                             y.ctypes.data_as(ctypes.c_void_p), self.bins.ctypes.data_as(ctypes.c_void_p),
                             self.tail_in.ctypes.data_as(ctypes.c_void_p), self.tail_out.ctypes.data_as(ctypes.c_void_p),
                             self.counters.ctypes.data_as(ctypes.c_void_p), self.steer.ctypes.data_as(ctypes.c_void_p),
                             self.steer_per_utt, self.method, self.mcra_L, f(self.alpha_y), f(self.alpha_v), f(self.diag),
                             f(self.gate), f(self.mu))
+        lib().emul_set_ref_pow(None)
         assert rc == 0, rc
         return y
 

@@ -5,7 +5,7 @@ checked by tests/test_gpu_parity.py (-m gpu)."""
 import numpy as np
 import pytest
 
-from _cases import ADAPTIVE_CASES, ANGLE, GSC_CASES, TOL_RMS, as_float, load, rms, steering
+from _cases import ADAPTIVE_CASES, ANGLE, GSC_CASES, TOL_RMS, as_float, load, oracle_mic, rms, steering
 from oracle import ds_oracle as O
 from emul.emul import EmulEngine
 
@@ -77,6 +77,42 @@ def test_emul_gsc(name):
     e.method = method
     y = e.process(x[None], 1)[0]
     assert rms(y - g["y"]) < TOL_RMS
+
+
+@pytest.mark.parametrize("M,nfft", [(4, 512), (2, 256), (3, 512)])
+def test_emul_gsc_reference_powers(M, nfft):
+    """Params::ref_pow (DS_PARAM_REF_POWERS): the GSC frame program also writes, per frame and bin, |Y|^2 of the canceller output in front
+    of the post-filter gain and |U_i|^2 of the blocking-matrix outputs — the arguments of omlsa_multi.estimation at GSC.py:281-283.  Fed to
+    the oracle's NsOmlsaMulti they reproduce the state of the oracle GSC's own (output-dead) omlsa_multi; the samples do not change."""
+    hop, T = nfft // 2, 30
+    omic = oracle_mic(M, nfft, 0.032)
+    x = (O.synth_utterance(7, hop * T, omic) * 0.2).astype(np.float32)
+    a = steering(M, nfft, 0.032)
+    e = EmulEngine(2, nfft, M, 1)
+    e.set_steering(a)
+    y = e.process(x[None], 1, ref_pow=True)[0]
+    pw = e.ref_pow[0].astype(np.float64)                          # [T, K, M]
+    e2 = EmulEngine(2, nfft, M, 1)
+    e2.set_steering(a)
+    assert np.array_equal(e2.process(x[None], 1)[0], y)           # the export is write-only
+    ref = O.OracleGSC(omic, nfft)                                 # with_dead_state: its omlsa_multi runs
+    yr = ref.process(x, ANGLE, 2)
+    assert rms(y - yr) < TOL_RMS
+    om = O.OracleOmlsaMulti(nfft=nfft, cal_weights=True, M=M)
+    for t in range(T):
+        om.estimation(pw[t, :, 0], pw[t, :, 1:])
+    ro = ref.omlsa_multi
+    assert np.median(np.abs(om.G - ro.G)) < 1e-5 and np.mean(np.abs(om.G - ro.G) > 1e-2) < 0.01
+    assert np.median(np.abs(om.xi_hat - ro.xi_hat) / (np.abs(ro.xi_hat) + 1e-9)) < 1e-3
+    assert np.median(np.abs(om.lambda_d - ro.lambda_d) / (ro.lambda_d + 1e-12)) < 1e-3
+    # hop by hop == one call, for the powers too
+    e3 = EmulEngine(2, nfft, M, 1)
+    e3.set_steering(a)
+    rows = []
+    for t in range(T):
+        e3.process(x[None, :, t * hop:(t + 1) * hop], 1, ref_pow=True)
+        rows.append(e3.ref_pow[0, 0].copy())
+    assert np.array_equal(np.stack(rows), e.ref_pow[0])
 
 
 @pytest.mark.parametrize("nfft,M", [(256, 2), (1024, 2), (512, 8)])
