@@ -967,7 +967,19 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
         for (int j = 0; j < M; ++j) {
             cf b[M], v[M];
 #pragma unroll
-            for (int i = 0; i < M; ++i) b[i] = herm_get<M>(yd, yo, i, j);
+            for (int i = 0; i < M; ++i) {
+                // (element by element, each word pinned to a register of its own: read as (re, im) PAIRS the off-diagonal words — which start
+                // at an odd float of the state for even M — became 8-byte accesses across the 16-byte plane groups, and the Ryy planes
+                // stayed in private memory: 144 - 416 B of scratch in the 6- and 8-microphone kernels)
+                float re, im;
+                if (i == j) { re = yd[i]; im = 0.0f; }
+                else if (i < j) { const int q = off_index(i, j, M); re = yo[2 * q]; im = yo[2 * q + 1]; }
+                else { const int q = off_index(j, i, M); re = yo[2 * q]; im = -yo[2 * q + 1]; }
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(re), "+v"(im));
+#endif
+                b[i] = mk(re, im);
+            }
             ch.solve(b, v);                                    // column j of Rvv_inv @ Ryy
             tr = cadd(tr, v[j]);
             if (j == 0) {
