@@ -100,6 +100,25 @@ __global__ void __launch_bounds__(256) rw_burst(float* state, float*, long long 
     for (int i = 0; i < NV; ++i) { if (NT) __builtin_nontemporal_store(r[i], st + i * 256 + threadIdx.x); else st[i * 256 + threadIdx.x] = r[i]; }
 }
 
+// mode 5: mode 4 with SPIN dependent FMAs between the burst of loads and the burst of stores (the frame kernels' shape: read the state,
+// run the hop, write the state), dynamic LDS only to set the number of resident workgroups per CU
+template <int NV, bool NT>
+__global__ void __launch_bounds__(256) rw_burst_spin(float* state, float*, long long, int, int spin, float seed) {
+    extern __shared__ float4 tile[];
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const long long burst = (long long)NV * 256 * 4;
+    v4* st = reinterpret_cast<v4*>(state + (long long)blockIdx.x * burst);
+    v4 r[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r[i] = NT ? __builtin_nontemporal_load(st + i * 256 + threadIdx.x) : st[i * 256 + threadIdx.x];
+    float acc = r[0].x + seed;
+    for (int i = 0; i < spin; ++i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(acc) : "v"(seed));
+    if (acc == 12345.678f) tile[threadIdx.x].x = acc;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { if (NT) __builtin_nontemporal_store(r[i], st + i * 256 + threadIdx.x); else st[i * 256 + threadIdx.x] = r[i]; }
+}
+
 int main(int argc, char** argv) {
     const long long blocks = argc > 1 ? atoll(argv[1]) : 132096;          // wpe_nb: 1024 utterances x 129 bins
     const long long blk_bytes = 29120;                                     // wpe_bin_floats(4, 20) * 4 rounded to 16 B
@@ -139,6 +158,24 @@ int main(int argc, char** argv) {
             {"burst 112 KB / workgroup", rw_burst<28, false>, 256, total / (28 * 4096), 0, 0},
             {"burst 112 KB / workgroup, nt", rw_burst<28, true>, 256, total / (28 * 4096), 0, 0},
         };
+        if (argc > 2) {                                 // block_rw <blocks> spin: only the burst-with-arithmetic sweep
+            sp.clear();
+            std::printf("burst of 28 KB per 256-thread workgroup, nt, SPIN dependent FMAs between loads and stores; lds bytes set the workgroups per CU\n");
+            for (int lds : {4096, 20480, 40960}) for (int spin : {0, 250, 500, 1000, 2000, 4000}) {
+                auto launch = [&]() { hipLaunchKernelGGL((rw_burst_spin<7, true>), dim3((unsigned)(total / (7 * 4096))), dim3(256), lds, 0, state, state2, blk_floats, 0, spin, 0.0f); };
+                launch(); launch();
+                CK(hipDeviceSynchronize());
+                const int reps = 5;
+                CK(hipEventRecord(e0));
+                for (int r = 0; r < reps; ++r) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                ms /= reps;
+                std::printf("lds %6d (<= %2d workgroups / CU)  spin %5d   %7.3f ms  %6.3f TB/s\n", lds, 163840 / lds > 8 ? 8 : 163840 / lds, spin, ms, 2.0 * blocks * blk_bytes / (ms * 1e-3) / 1e12);
+            }
+            return 0;
+        }
         for (const Sp& c : sp) {
             if (c.lds > 65536) CK(hipFuncSetAttribute((const void*)c.k, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds));
             auto launch = [&]() { hipLaunchKernelGGL(c.k, dim3((unsigned)c.grid), dim3(c.threads), c.lds, 0, state, state2, blk_floats, c.chunk / 4, 0, 0.0f); };

@@ -75,16 +75,24 @@ def test_gsc_vs_reference_golden(ds, name):
     g = load("g6_gsc_" + name)
     M, nfft, hop, method = [int(v) for v in g["params"]]
     x = as_float(g["x"])
-    gsc = ds.GSC(_mic(ds, M, nfft, float(g["r"])), frameLen=nfft, angle=[197, 0])
+    gsc = ds.GSC(_mic(ds, M, nfft, float(g["r"])), frameLen=nfft, angle=[197, 0], track_omlsa_multi=True)
     ys = [gsc.process(x[:, t * hop:(t + 1) * hop], ANGLE, method=method)["data"] for t in range(x.shape[1] // hop)]
     y = np.concatenate(ys)
     m = dict(y_rms=rms(y - g["y"]), y_ref_rms=rms(g["y"]))
     if method != 0:
         m["G_aic_rel_rms"] = rms(gsc.G - g["G"]) / max(rms(g["G"]), 1e-6)
+        # the reference object's own (output-dead) omlsa_multi after the last hop (GSC.py:78,281-283), as the fixture holds it
+        om = gsc.omlsa_multi
+        m["omlsa_G_median_abs"] = float(np.median(np.abs(om.G - g["omlsa_G"])))
+        m["omlsa_G_outliers"] = float(np.mean(np.abs(om.G - g["omlsa_G"]) > 2e-2))
+        m["omlsa_p_median_abs"] = float(np.median(np.abs(om.p - g["omlsa_p"])))
+        m["omlsa_lambda_d_median_rel"] = float(np.median(np.abs(om.lambda_d - g["omlsa_lambda_d"]) / (g["omlsa_lambda_d"] + 1e-12)))
     measured("G6_gsc_" + name, **m)
     assert m["y_rms"] < TOL_RMS and m["y_rms"] < 1.5e-5                   # measured 2.4e-6 ... 4.9e-6
     if method != 0:
         assert m["G_aic_rel_rms"] < 2e-3                                   # measured 2.5e-4 ... 5.8e-4 (the weights integrate fp32 p errors)
+        assert m["omlsa_G_median_abs"] < 1e-4 and m["omlsa_G_outliers"] < 0.02
+        assert m["omlsa_p_median_abs"] < 1e-4 and m["omlsa_lambda_d_median_rel"] < 1e-3
 
 
 # ------------------------------------------------------------------------------------------------

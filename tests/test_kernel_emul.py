@@ -75,8 +75,17 @@ def test_emul_gsc(name):
     e = EmulEngine(2, nfft, M, 1)
     e.set_steering(steering(M, nfft, float(g["r"])))
     e.method = method
-    y = e.process(x[None], 1)[0]
+    y = e.process(x[None], 1, ref_pow=True)[0]
     assert rms(y - g["y"]) < TOL_RMS
+    if method != 0:
+        # the exported powers through the oracle's NsOmlsaMulti against the REFERENCE object's own omlsa_multi (the fixture's omlsa_*)
+        om = O.OracleOmlsaMulti(nfft=nfft, cal_weights=True, M=M)
+        pw = e.ref_pow[0].astype(np.float64)
+        for t in range(pw.shape[0]):
+            om.estimation(pw[t, :, 0], pw[t, :, 1:])
+        assert np.median(np.abs(om.G - g["omlsa_G"])) < 1e-4 and np.mean(np.abs(om.G - g["omlsa_G"]) > 2e-2) < 0.02
+        assert np.median(np.abs(om.p - g["omlsa_p"])) < 1e-4
+        assert np.median(np.abs(om.lambda_d - g["omlsa_lambda_d"]) / (g["omlsa_lambda_d"] + 1e-12)) < 1e-3
 
 
 @pytest.mark.parametrize("M,nfft", [(4, 512), (2, 256), (3, 512)])
