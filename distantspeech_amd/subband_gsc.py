@@ -115,6 +115,7 @@ class SubbandGSC(object):
 
     def __init__(self, mic_array: MicArray, frameLen=256, angle=[197, 0], batch=1, device=-1, bm_filter="lms"):
         self.M, self.frameLen, self.batch = mic_array.M, frameLen, int(batch)
+        self._device = device
         self.MicArray = mic_array
         self.nfft, self.hop, self.half_bin = 2 * frameLen, frameLen, frameLen + 1
         self.angle = np.array(angle) / 180 * np.pi if isinstance(angle, list) else angle
@@ -136,8 +137,8 @@ class SubbandGSC(object):
         """x [n_chs, n_samples] (or [B, n_chs, n_samples]) ->
         (output [L], fix_output [L], bm_output [L, M], p [half_bin, blocks], aligned_output [L, M])."""
         # postfilter=True: the reference's branch (SubbandGSC.py:236-249) analyses the canceller output, runs NsOmlsaMulti on it and scales a
-        # spectrum Y that is then dropped (the synthesis at :248 is commented out) — nothing it computes reaches the five returned arrays or
-        # any state they depend on, so the flag is accepted and the branch's dead work is not done
+        # spectrum Y that is then dropped (the synthesis at :249 is commented out) — nothing it computes reaches the five returned arrays or
+        # any state they depend on.  Its one trace is the object's omlsa_multi: _postfilter_trace() below keeps that, behind the chain
         x = np.asarray(x)
         single = x.ndim == 2
         if single:
@@ -147,6 +148,33 @@ class SubbandGSC(object):
         if x.shape[1] != self.M or x.shape[2] % self.frameLen != 0:
             raise ValueError("x must be [n_chs=%d, k * %d samples]" % (self.M, self.frameLen))
         y, fix, bm, p, al = self._eng.subband_gsc_process(x)
+        if postfilter:
+            self._postfilter_trace(y, bm)
         out = (y.astype(np.float64), fix.astype(np.float64), np.swapaxes(bm, 1, 2).astype(np.float64),
                np.swapaxes(p, 1, 2).astype(np.float64), np.swapaxes(al, 1, 2).astype(np.float64))
         return tuple(a[0] for a in out) if single else out
+
+    def _postfilter_trace(self, y, bm):
+        """self.omlsa_multi as SubbandGSC.process(postfilter=True) leaves it (SubbandGSC.py:127-129,236-249).  Per block n of the call the
+        reference analyses the block's output (transform_fbf, a streaming analysis) and the WHOLE bm_output array of the call as filled so
+        far (transform_bm: blocks behind n are still zero, and the transform's carried overlap becomes the array's last block every time),
+        takes frame 0 of that, and hands the two powers to NsOmlsaMulti.estimation — which reads the first M - 1 of the M blocking outputs.
+        Reproduced with the native Transform and NsOmlsaMulti operators, block by block like the reference (one block per call, the
+        realtime contract, is one analysis of each; a call of T blocks is T analyses of T frames).  y [B, L], bm [B, M, L] float32."""
+        from .ops import NsOmlsaMulti, Transform
+        if not hasattr(self, "omlsa_multi"):
+            dev = self._device
+            self.omlsa_multi = NsOmlsaMulti(nfft=self.nfft, M=self.M, cal_weights=True, batch=self.batch, device=dev)      # :127
+            self.transform_fbf = Transform(n_fft=self.nfft, hop_length=self.frameLen, channel=1, batch=self.batch, device=dev)   # :128
+            self.transform_bm = Transform(n_fft=self.nfft, hop_length=self.frameLen, channel=self.M, batch=self.batch, device=dev)   # :129
+        FL, B = self.frameLen, self.batch
+        T = y.shape[1] // FL
+        bm_t = np.ascontiguousarray(np.swapaxes(bm, 1, 2))                 # [B, L, M]
+        so_far = np.zeros_like(bm_t)
+        for n in range(T):
+            so_far[:, n * FL:(n + 1) * FL] = bm_t[:, n * FL:(n + 1) * FL]
+            Y = self.transform_fbf._eng.stft(np.ascontiguousarray(y[:, n * FL:(n + 1) * FL, None]), L.LAYOUT_SAMPLES_CHANNELS)   # [B, 1, K, 1]
+            U = self.transform_bm._eng.stft(so_far, L.LAYOUT_SAMPLES_CHANNELS)                                                   # [B, T, K, M]
+            yp = (Y[:, :1, :, 0].real.astype(np.float64) ** 2 + Y[:, :1, :, 0].imag.astype(np.float64) ** 2)
+            up = (U[:, :1, :, : self.M - 1].real.astype(np.float64) ** 2 + U[:, :1, :, : self.M - 1].imag.astype(np.float64) ** 2)
+            self.omlsa_multi.estimation_frames(yp, up)

@@ -672,7 +672,7 @@ class OracleOmlsaMulti:
             self.first_frame = 0
             self.lambda_d = y.copy()
             self.zeta_Y = y.copy()
-            self.zeta_U = u.T.copy()
+            self.zeta_U = u[:, : self.M - 1].T.copy()                       # :91-92 (the first M - 1 columns, whatever u carries)
             return None
         alpha = 0.921
         self.zeta_Y = smooth_psd(y, self.zeta_Y, self.win, self.alpha_s)    # :98
@@ -1029,7 +1029,7 @@ class OracleDelaySamples:
 
 
 class OracleSubbandGSC:
-    """SubbandGSC.process (postfilter=False) — beamformer/SubbandGSC.py:67-262.
+    """SubbandGSC.process — beamformer/SubbandGSC.py:67-262.
     `rls_bm=True` is the config-5 composition of SURVEY section 8a-19: the adaptive blocking filters are
     SubbandRLS(filter_len=2, num_bands=2*frameLen) instead of SubbandLMS (a composition we define)."""
 
@@ -1052,9 +1052,14 @@ class OracleSubbandGSC:
         self.spp = OracleMcSpp(nfft=nb, channels=M)                              # :115
         self.transform = OracleTransform(n_fft=nb, hop_length=hop, channel=M)    # :117
         self.dc_notch = [OracleDcNotch(radius=0.98) for _ in range(M)]           # :122-124
+        self.omlsa_multi = OracleOmlsaMulti(nfft=nb, cal_weights=True, M=M)      # :127 (touched by postfilter=True only; output-dead)
+        self.transform_fbf = OracleTransform(n_fft=nb, hop_length=hop)           # :128
+        self.transform_bm = OracleTransform(n_fft=nb, hop_length=hop, channel=M) # :129
 
-    def process(self, x):
-        """x [M, L] -> (output [L], fix_output [L], bm_output [L, M], p [K, blocks], aligned_output [L, M])."""
+    def process(self, x, postfilter=False):
+        """x [M, L] -> (output [L], fix_output [L], bm_output [L, M], p [K, blocks], aligned_output [L, M]).
+        postfilter=True (:236-249) changes none of the five: it analyses the block's output and — as the reference does — the WHOLE
+        bm_output array of the call as filled so far, takes frame 0 of that, and runs omlsa_multi.estimation on the two powers."""
         x = np.array(x, dtype=np.float64)
         M, FL = self.M, self.frameLen
         for m in range(M):
@@ -1085,6 +1090,10 @@ class OracleSubbandGSC:
             err, _ = self.aic.update(Xa[:, 0, :], Dd, p=1 - p[:, n])
             output[sl] = self.aic_td.istft(err)
             fix_output[sl] = fixed_d[:, 0]
+            if postfilter:                                                       # :236-249
+                Y = self.transform_fbf.stft(output[sl])                          # [K, 1, 1]
+                U = self.transform_bm.stft(bm_output)                            # the whole array, every block: [K, nblk, M]
+                self.omlsa_multi.estimation(np.real(Y[:, 0, 0] * np.conj(Y[:, 0, 0])), np.real(U[:, 0, :] * np.conj(U[:, 0, :])))
         return output, fix_output, bm_output, p, aligned
 
 

@@ -459,6 +459,30 @@ def g12_subbandgsc(x16):
              r=np.array(mic.r))
 
 
+def g22_subbandgsc_postfilter(x16):
+    """SubbandGSC.process(postfilter=True) (SubbandGSC.py:236-249): the five results are those of postfilter=False; the branch's only trace is
+    the object's omlsa_multi.  Driven one block per call (the realtime contract, where transform_bm sees a one-block array and behaves as
+    a streaming analysis) and in calls of several blocks (where the branch re-analyses the whole bm_output array in every block)."""
+    import DistantSpeech.beamformer.FDGSC as FD
+    FD.DelayObj = object                                                                   # R9
+    from DistantSpeech.beamformer.SubbandGSC import SubbandGSC
+    SCALE = 10.0       # the recording at ten times its level: at its own level the powers (1e-20) sit under the estimator's 1e-6 regularisers
+    x = x16.astype(np.float32) / 32768.0 * np.float32(SCALE)
+    for name, xx, M, blocks_per_call in (("rec1_1", x[:, : 256 * 60], 4, 1), ("rec1_5", x[:, : 256 * 60], 4, 5)):
+        mic = MicArray(arrayType="circular", r=0.032, M=M, n_fft=512)
+        with contextlib.redirect_stdout(io.StringIO()):
+            g = SubbandGSC(mic, frameLen=256, angle=[197, 0])
+            outs = []
+            with np.errstate(all="ignore"):
+                for a in range(0, xx.shape[1], 256 * blocks_per_call):
+                    outs.append(g.process(xx[:, a:a + 256 * blocks_per_call].astype(np.float64).copy(), postfilter=True)[0])
+        om = g.omlsa_multi
+        save("g22_subbandgsc_pf_%s" % name,
+             "SubbandGSC.process(postfilter=True) SubbandGSC.py:170-262, %d block(s) per call, x = int16 / 32768 * scale; R9; the object's omlsa_multi after the last call" % blocks_per_call,
+             x=x16[:, : 256 * 60], output=np.concatenate(outs), omlsa_G=om.G, omlsa_p=om.p, omlsa_lambda_d=np.asarray(om.lambda_d),
+             omlsa_xi_hat=om.xi_hat, omlsa_q_hat=om.q_hat, params=np.array([M, 256, blocks_per_call]), r=np.array(mic.r), scale=np.array(SCALE))
+
+
 def g13_tdfilters():
     from DistantSpeech.adaptivefilter.BaseFilter import BaseFilter
     from DistantSpeech.adaptivefilter.RLS import Rls
@@ -847,6 +871,7 @@ def main():
     if want("g19"): g19_gev(x16)
     if want("g20"): g20_odd_m()
     if want("g21"): g21_wpe_wide()
+    if want("g22"): g22_subbandgsc_postfilter(x16)
 
 
 if __name__ == "__main__":

@@ -236,6 +236,31 @@ def test_subband_gsc(golden, name):
     assert np.max(np.abs(p - g["p"])) < 1e-6
 
 
+@pytest.mark.parametrize("name", ["rec1_1", "rec1_5"])
+def test_subband_gsc_postfilter_branch(golden, name):
+    """SubbandGSC.process(postfilter=True) (SubbandGSC.py:236-249): same five results; the branch's trace is the object's omlsa_multi —
+    driven one block per call and five (where every block re-analyses the whole bm_output array of the call and takes its frame 0)."""
+    g = golden("g22_subbandgsc_pf_" + name)
+    M, FL, per_call = [int(v) for v in g["params"]]
+    x = g["x"].astype(np.float32) / 32768.0 * np.float32(g["scale"])
+    sg = O.OracleSubbandGSC(_mic(M, 512, r=float(g["r"])), FL, (197, 0))
+    outs = [sg.process(x[:, a:a + FL * per_call], postfilter=True)[0] for a in range(0, x.shape[1], FL * per_call)]
+    out = np.concatenate(outs)
+    assert rms(out - g["output"]) < 1e-6 * rms(g["output"])
+    om = sg.omlsa_multi
+    assert np.allclose(om.G, g["omlsa_G"], rtol=1e-6, atol=1e-8) and np.allclose(om.p, g["omlsa_p"], rtol=1e-6, atol=1e-9)
+    # lambda_d stays at the first frame's power here (p == 1 from the second frame on: alpha_tilde == 1): the power of an output block that
+    # is still all but zero, i.e. numbers at the transform's rounding floor (1e-22 .. 1e-14) — held at the bins that carry a value
+    ref = g["omlsa_lambda_d"]
+    rel = np.abs(om.lambda_d - ref) / ref
+    assert np.median(rel) < 1e-4 and np.max(rel[ref > 1e-3 * ref.max()]) < 2e-2
+    assert np.allclose(om.xi_hat, g["omlsa_xi_hat"], rtol=1e-4, atol=1e-9) and np.allclose(om.q_hat, g["omlsa_q_hat"], rtol=1e-5, atol=1e-6)
+    # and the five results are those of postfilter=False
+    sg0 = O.OracleSubbandGSC(_mic(M, 512, r=float(g["r"])), FL, (197, 0))
+    out0 = np.concatenate([sg0.process(x[:, a:a + FL * per_call])[0] for a in range(0, x.shape[1], FL * per_call)])
+    assert np.array_equal(out0, out)
+
+
 def test_td_filters(golden):
     g = golden("g13_tdfilters")
     x, d = g["x"], g["d"]
