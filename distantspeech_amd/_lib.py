@@ -78,7 +78,7 @@ EXPORTS = [
 
 
 def build_info():
-    """{'version': '105', 'state_layout': '3', 'arch': 'gfx950', 'shelved': '0'}: ds_build_info() parsed"""
+    """{'version': '106', 'state_layout': '4', 'arch': 'gfx950', 'shelved': '0'}: ds_build_info() parsed"""
     txt = load().ds_build_info().decode()
     return dict(kv.split("=", 1) for kv in txt.split()[1:])
 

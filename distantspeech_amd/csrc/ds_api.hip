@@ -1201,6 +1201,7 @@ static int extra_state(const ds_handle* h, ExtraState out[3]) {
 struct BlobHeader { uint32_t magic, version; int32_t algo, nfft, hop, n_mics, batch, filter_len, td_L, track_ryy, layout, modes, wpe_delay; uint32_t out_scale_bits; };
 static const uint32_t BLOB_MAGIC = 0x44534348u;      // "DSCH"
 static const int32_t BLOB_LAYOUT = DS_STATE_LAYOUT;      // 3: operator state as float4 planes [b][f / 4][k][f % 4], FIR history channel-major [b][m][L - 1]
+                                                         // 4: RLS-WPE blocks of 16 taps-by-channels on 128-byte lines (ds_wpe.hpp wpe_layout)
 static BlobHeader blob_header(const ds_handle* h) {
     uint32_t osb;
     std::memcpy(&osb, &h->out_scale, sizeof osb);

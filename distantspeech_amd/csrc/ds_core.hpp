@@ -408,6 +408,26 @@ DS_HD vec4 load_state(const vec4* src) {
     return *src;
 #endif
 }
+// the same for one complex word (rows of 16 of them: one line per instruction in the RLS-WPE blocks' line layout, ds_wpe.hpp)
+DS_HD void store_state(cf* dst, const cf& v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_PLAIN_STATE) && !defined(DS_PLAIN_STATE_STORE)
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    f2_t q; q.x = v.x; q.y = v.y;
+    __builtin_nontemporal_store(q, reinterpret_cast<f2_t*>(dst));
+#else
+    *dst = v;
+#endif
+}
+DS_HD cf load_state(const cf* src) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_PLAIN_STATE) && !defined(DS_PLAIN_STATE_LOAD)
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t q = __builtin_nontemporal_load(reinterpret_cast<const f2_t*>(src));
+    cf v; v.x = q.x; v.y = q.y;
+    return v;
+#else
+    return *src;
+#endif
+}
 
 // ---------------------------------------------------------------------------------------------
 // FFT stages (Stockham autosort, radix 4 / radix 2), all channels of the block at once

@@ -24,10 +24,24 @@ namespace ds {
 constexpr int WPE_CNMAX = 16, WPE_CMAX = 8, WPE_NT = 128;
 constexpr int WPEW_CNMAX = 80;          // ... and up to this many taps-by-channels through the wavefront-per-bin program (ds_wpe_wide.hpp)
 
-// per-bin block, complex words: P upper triangle by columns, P[i][q] (i <= q) at q (q + 1) / 2 + i; then W[c][i] at NPK + c CN + i;
-// then input_buffer tap i at NPK + C CN + i; then var (1 float); padded to 16 B
+// per-bin block, complex words: P upper triangle by columns, P[i][q] (i <= q) at q (q + 1) / 2 + i; then W[c][i] at w0 + c CN + i;
+// then input_buffer tap i at x0 + i; var (1 float) at float var_f.
+//   C N != 16: everything back to back (w0 = NPK, x0 = NPK + C CN, var behind the taps), padded to 16 B.
+//   C N == 16 — the 16-lane kernel's full shape: BASELINE config 4's 8 x 2, and 4 x 4 — every piece one instruction moves is whole
+//   128-byte lines: [P: 136 words][(var, 0)][7 words of padding] = 144 words = 9 lines, then C rows of W (16 words = one line each), then
+//   the taps (one line): 2304 B at 8 channels against 2244 B packed.  With the pieces on line boundaries the block's traffic can be
+//   non-temporal (on the packed block that policy COST 4 - 11 %: a line touched by two instructions was fetched twice): the same
+//   pieces moved with no arithmetic run 19 % faster (scratch/micro/block_rw.hip `narrow`, profiles/r04a/block_rw_narrow.txt).
 DS_HD constexpr int wpe_packed(int CN) { return CN * (CN + 1) / 2; }
-DS_HD constexpr int wpe_bin_floats(int C, int N) { return (2 * (wpe_packed(C * N) + C * C * N + C * N) + 1 + 3) & ~3; }
+struct WpeLayout { int w0, x0, var_f, floats, tri_words; bool lines; };
+DS_HD constexpr WpeLayout wpe_layout(int C, int N) {
+    const int CN = C * N, NPK = wpe_packed(CN);
+    if (CN == 16) return WpeLayout{144, 144 + C * 16, 2 * 136, 2 * (144 + C * 16 + 16), 144, true};
+    return WpeLayout{NPK, NPK + C * CN, 2 * (NPK + C * CN + CN), (2 * (NPK + C * CN + CN) + 1 + 3) & ~3, NPK, false};
+}
+DS_HD constexpr int wpe_bin_floats(int C, int N) { return wpe_layout(C, N).floats; }
+// the bytes of a block that carry state (what a launch must move once in and once out; the line layout's padding is not among them)
+DS_HD constexpr int wpe_bin_floats_packed(int C, int N) { return 2 * (wpe_packed(C * N) + C * C * N + C * N) + 1; }
 DS_HD constexpr int wpe_lanes_per_bin(int CN) { return CN <= 4 ? 4 : CN <= 8 ? 8 : 16; }
 
 struct WpeParams {
@@ -51,7 +65,7 @@ template <int LPB> struct WpeShared {
     static constexpr int BPW = WPE_NT / LPB, CM = LPB < WPE_CMAX ? LPB : WPE_CMAX;
     cf X[2][BPW][LPB];               // input buffer, double-buffered across frames (tap shift reads the neighbour lane)
     cf d[BPW][CM];
-    alignas(16) cf part[BPW][CM][LPB + 1];   // conj(W[c][i]) X_i; doubles as the tile the packed triangle of P passes through
+    alignas(16) cf part[BPW][CM][LPB + 2];   // conj(W[c][i]) X_i; doubles as the tile the packed triangle of P passes through (144 words at LPB = 16)
     cf num[BPW][LPB];                // g_i = (P X)_i
     float dre[BPW][LPB];             // Re(conj(X_i) g_i)
     cf err[BPW][CM];
@@ -122,19 +136,28 @@ template <int LPB, int CT = 0, int NTAPS = 0> struct WpeEngine {
             if (!on) { if (i < LPB && s < BPW) sh.X[0][s][i] = mk(0.0f, 0.0f); return; }
             const float* stf = bin_state(g);
             const cf* st = reinterpret_cast<const cf*>(stf);
-            const int NPK = wpe_packed(CN);
+            const WpeLayout Lb = wpe_layout(C, N);
             cf* tri = &sh.part[s][0][0];                          // the packed triangle passes through LDS (the `part` tile, idle here):
-            // consecutive lanes, consecutive 16-byte pieces (NPK is even for even CN; a block starts on a 16-byte boundary)
-            if ((NPK & 1) == 0) {
-                for (int w = 2 * i; w < NPK; w += 2 * CN) *reinterpret_cast<vec4*>(&tri[w]) = *reinterpret_cast<const vec4*>(&st[w]);
-            } else {
-                for (int w = i; w < NPK; w += CN) tri[w] = st[w];
-            }
+            // consecutive lanes, consecutive 16-byte pieces (an even word count; a block starts on a 16-byte boundary)
+            if (Lb.lines) {                                       // whole lines per instruction, streamed (see wpe_layout)
+                for (int w = 2 * i; w < Lb.tri_words; w += 2 * CN) *reinterpret_cast<vec4*>(&tri[w]) = load_state(reinterpret_cast<const vec4*>(&st[w]));
 #pragma unroll
-            for (int c = 0; c < CM; ++c)
-                if (c < C) r.W[c] = st[NPK + c * CN + i];
-            sh.X[0][s][i] = st[NPK + C * CN + i];
-            r.var = stf[2 * (NPK + C * CN + CN)];
+                for (int c = 0; c < CM; ++c)
+                    if (c < C) r.W[c] = load_state(&st[Lb.w0 + c * CN + i]);
+                sh.X[0][s][i] = load_state(&st[Lb.x0 + i]);
+                r.var = 0.0f;                                     // (arrives with the tile: taken in the next phase)
+            } else {
+                if ((Lb.tri_words & 1) == 0) {
+                    for (int w = 2 * i; w < Lb.tri_words; w += 2 * CN) *reinterpret_cast<vec4*>(&tri[w]) = *reinterpret_cast<const vec4*>(&st[w]);
+                } else {
+                    for (int w = i; w < Lb.tri_words; w += CN) tri[w] = st[w];
+                }
+#pragma unroll
+                for (int c = 0; c < CM; ++c)
+                    if (c < C) r.W[c] = st[Lb.w0 + c * CN + i];
+                sh.X[0][s][i] = st[Lb.x0 + i];
+                r.var = stf[Lb.var_f];
+            }
             r.io0 = io_base(g, 0);
             r.ring0 = p.ring != nullptr ? ring_at(g, 0) : 0;
             const long long f0 = r.io0;
@@ -150,6 +173,7 @@ template <int LPB, int CT = 0, int NTAPS = 0> struct WpeEngine {
 #pragma unroll
             for (int q = 0; q < LPB; ++q)
                 if (q < CN) r.P[q] = q >= i ? tri[q * (q + 1) / 2 + i] : cconj(tri[i * (i + 1) / 2 + q]);
+            if (CN == WPE_CNMAX) r.var = tri[wpe_packed(WPE_CNMAX)].x;     // the line layout keeps var behind the triangle (wpe_layout)
         });
         int cur = 0;
         for (int t = 0; t < p.T; ++t) {
@@ -251,6 +275,7 @@ template <int LPB, int CT = 0, int NTAPS = 0> struct WpeEngine {
 #pragma unroll
             for (int q = 0; q < LPB; ++q)
                 if (q < CN && q >= i) tri[q * (q + 1) / 2 + i] = r.P[q];
+            if (CN == WPE_CNMAX && i < 8) tri[wpe_packed(WPE_CNMAX) + i] = mk(i == 0 ? r.var : 0.0f, 0.0f);   // (var, 0) and the line's padding
         });
         ex.phase_wave([&](int tid, Rg& r) {
             int s, i; long long g; bool on;
@@ -258,18 +283,26 @@ template <int LPB, int CT = 0, int NTAPS = 0> struct WpeEngine {
             if (!on) return;
             float* stf = bin_state(g);
             cf* st = reinterpret_cast<cf*>(stf);
-            const int NPK = wpe_packed(CN);
+            const WpeLayout Lb = wpe_layout(C, N);
             const cf* tri = &sh.part[s][0][0];
-            if ((NPK & 1) == 0) {
-                for (int w = 2 * i; w < NPK; w += 2 * CN) *reinterpret_cast<vec4*>(&st[w]) = *reinterpret_cast<const vec4*>(&tri[w]);
-            } else {
-                for (int w = i; w < NPK; w += CN) st[w] = tri[w];
-            }
+            if (Lb.lines) {                                       // (var went into the tile with the rows, one phase back)
+                for (int w = 2 * i; w < Lb.tri_words; w += 2 * CN) store_state(reinterpret_cast<vec4*>(&st[w]), *reinterpret_cast<const vec4*>(&tri[w]));
 #pragma unroll
-            for (int c = 0; c < CM; ++c)
-                if (c < C) st[NPK + c * CN + i] = r.W[c];
-            st[NPK + C * CN + i] = sh.X[cur][s][i];
-            if (i == 0) stf[2 * (NPK + C * CN + CN)] = r.var;
+                for (int c = 0; c < CM; ++c)
+                    if (c < C) store_state(&st[Lb.w0 + c * CN + i], r.W[c]);
+                store_state(&st[Lb.x0 + i], sh.X[cur][s][i]);
+            } else {
+                if ((Lb.tri_words & 1) == 0) {
+                    for (int w = 2 * i; w < Lb.tri_words; w += 2 * CN) *reinterpret_cast<vec4*>(&st[w]) = *reinterpret_cast<const vec4*>(&tri[w]);
+                } else {
+                    for (int w = i; w < Lb.tri_words; w += CN) st[w] = tri[w];
+                }
+#pragma unroll
+                for (int c = 0; c < CM; ++c)
+                    if (c < C) st[Lb.w0 + c * CN + i] = r.W[c];
+                st[Lb.x0 + i] = sh.X[cur][s][i];
+                if (i == 0) stf[Lb.var_f] = r.var;
+            }
         });
     }
 };

@@ -344,6 +344,17 @@ def phase_correction(vector):
     return out[0] if single else out
 
 
+def wpe_block_layout(C, N):
+    """The per-bin state block of the RLS-WPE kernels (csrc/ds_wpe.hpp wpe_layout()): complex-word offsets of W (w0) and of the taps (x0),
+    float offset of var, floats per block.  C N == 16 is laid out on 128-byte lines (the triangle's 136 words, (var, 0), 7 words of
+    padding; then C rows of W; then the taps); every other shape is packed back to back and padded to 16 bytes."""
+    CN = C * N
+    npk = CN * (CN + 1) // 2
+    if CN == 16:
+        return dict(w0=144, x0=144 + 16 * C, var_f=2 * 136, floats=2 * (144 + 16 * C + 16), npk=npk)
+    return dict(w0=npk, x0=npk + C * CN, var_f=2 * (npk + C * CN + CN), floats=(2 * (npk + C * CN + CN) + 1 + 3) & ~3, npk=npk)
+
+
 class NsOmlsaMulti(_Base):
     """Multichannel (TBRR) OMLSA noise estimate and gain — noise_estimation/omlsa_multi.py:27-156."""
 
@@ -559,19 +570,18 @@ class Wpe(_SubbandBase):
         return self._sq(y.astype(np.float64)), self.W
 
     def _blocks(self):
-        """per-bin state blocks [B, K, words] complex (layout of csrc/ds_wpe.hpp: the upper triangle of P by columns, P[i][q] (i <= q) at
-        q (q + 1) / 2 + i; then W[c, :]; then the taps)."""
-        C, CN = self.channels, self.channels * self.filter_len
-        nw = CN * (CN + 1) // 2 + C * CN + CN
-        SB = (2 * nw + 1 + 3) & ~3
+        """per-bin state blocks [B, K, words] complex (wpe_block_layout(): the upper triangle of P by columns, P[i][q] (i <= q) at
+        q (q + 1) / 2 + i; W[c, :] from word w0; the taps from word x0)."""
+        lay = wpe_block_layout(self.channels, self.filter_len)
+        SB = lay["floats"]
         raw = self._eng.stage_state_raw(1).reshape(self.batch, -1)[:, : self.half_band * SB].reshape(self.batch, self.half_band, SB)
-        return raw[:, :, : 2 * nw].copy().view(np.complex64)
+        return raw[:, :, : SB & ~1].copy().view(np.complex64)
 
     @property
     def W(self):
         C, CN = self.channels, self.channels * self.filter_len
-        npk = CN * (CN + 1) // 2
-        w = self._blocks()[:, :, npk:npk + C * CN].reshape(self.batch, self.half_band, C, CN)
+        w0 = wpe_block_layout(C, self.filter_len)["w0"]
+        w = self._blocks()[:, :, w0:w0 + C * CN].reshape(self.batch, self.half_band, C, CN)
         return self._sq(w.astype(np.complex128))                                       # [half_band, C, C*N]
 
     @property

@@ -42,8 +42,8 @@
 extern "C" {
 #endif
 
-#define DS_VERSION 105
-#define DS_STATE_LAYOUT 3   /* serialised arrangement of the carried state (checkpoint header; measurement records quote it) */
+#define DS_VERSION 106
+#define DS_STATE_LAYOUT 4   /* serialised arrangement of the carried state (checkpoint header; measurement records quote it) */
 
 /* error codes */
 #define DS_OK 0

@@ -119,9 +119,28 @@ __global__ void __launch_bounds__(256) rw_burst_spin(float* state, float*, long 
     for (int i = 0; i < NV; ++i) { if (NT) __builtin_nontemporal_store(r[i], st + i * 256 + threadIdx.x); else st[i * 256 + threadIdx.x] = r[i]; }
 }
 
+// mode 6: the NARROW WPE kernel's shape (C N = 16): a wavefront holds four consecutive bins, 16 lanes each; every instruction moves one
+// 256-byte piece per bin (16 lanes x 16 B), i.e. four pieces SB bytes apart; pieces go straight to registers and back (no LDS).
+// SB = bytes per bin: 2244 (the kernel's block, pieces straddle 128-byte lines) or 2304 (padded to whole lines)
+template <bool NT>
+__global__ void __launch_bounds__(256) rw_narrow(float* state, float*, long long sb_floats, int, int, float) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 15, bin = threadIdx.x >> 4;                       // 16 bins per 256-thread workgroup
+    float* st = state + ((long long)blockIdx.x * 16 + bin) * sb_floats;
+    const int pieces = (int)(sb_floats * 4 / 256);                                   // whole 256-byte pieces of the bin's block (8 of them at 2244 / 9 at 2304)
+    v4 r[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        if (i < pieces) r[i] = NT ? __builtin_nontemporal_load(reinterpret_cast<v4*>(st + i * 64 + lane * 4)) : *reinterpret_cast<v4*>(st + i * 64 + lane * 4);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        if (i < pieces) { if (NT) __builtin_nontemporal_store(r[i], reinterpret_cast<v4*>(st + i * 64 + lane * 4)); else *reinterpret_cast<v4*>(st + i * 64 + lane * 4) = r[i]; }
+}
+
 int main(int argc, char** argv) {
     const long long blocks = argc > 1 ? atoll(argv[1]) : 132096;          // wpe_nb: 1024 utterances x 129 bins
-    const long long blk_bytes = 29120;                                     // wpe_bin_floats(4, 20) * 4 rounded to 16 B
+    const long long blk_bytes = (argc > 3 && argv[2][0] == 'b') ? atoll(argv[3]) : 29120;     // wpe_bin_floats(4, 20) * 4 rounded to 16 B; `block_rw <blocks> blk <bytes>`: another block size
     const long long blk_floats = blk_bytes / 4;
     float *state, *state2;
     CK(hipMalloc(&state, blocks * blk_bytes));
@@ -158,7 +177,29 @@ int main(int argc, char** argv) {
             {"burst 112 KB / workgroup", rw_burst<28, false>, 256, total / (28 * 4096), 0, 0},
             {"burst 112 KB / workgroup, nt", rw_burst<28, true>, 256, total / (28 * 4096), 0, 0},
         };
-        if (argc > 2) {                                 // block_rw <blocks> spin: only the burst-with-arithmetic sweep
+        if (argc > 2 && argv[2][0] == 'n') {            // block_rw <bins> narrow: the narrow WPE kernel's pieces, block size 2244 B against 2304 B, plain against nt
+            const long long bins = 1024LL * 513;
+            std::printf("narrow WPE pattern: %lld bins, four per wavefront, 256-byte pieces\n", bins);
+            for (int sb : {2244, 2304}) for (int nt = 0; nt < 2; ++nt) {
+                const long long sbf = sb / 4;
+                if (bins * sb > 2 * blocks * blk_bytes) { std::printf("buffer too small\n"); return 1; }
+                auto launch = [&]() { if (nt) hipLaunchKernelGGL((rw_narrow<true>), dim3((unsigned)(bins / 16)), dim3(256), 0, 0, state, state2, sbf, 0, 0, 0.0f);
+                                      else hipLaunchKernelGGL((rw_narrow<false>), dim3((unsigned)(bins / 16)), dim3(256), 0, 0, state, state2, sbf, 0, 0, 0.0f); };
+                launch(); launch();
+                CK(hipDeviceSynchronize());
+                const int reps = 10;
+                CK(hipEventRecord(e0));
+                for (int r = 0; r < reps; ++r) launch();
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                ms /= reps;
+                const double moved = 2.0 * bins * (sb / 256) * 256.0;
+                std::printf("block %4d B  %s   %7.3f ms   %6.3f TB/s of moved bytes   %8.1f k bins/ms\n", sb, nt ? "nt   " : "plain", ms, moved / (ms * 1e-3) / 1e12, bins / ms / 1e3);
+            }
+            return 0;
+        }
+        if (argc > 2 && argv[2][0] == 's') {            // block_rw <blocks> spin: only the burst-with-arithmetic sweep
             sp.clear();
             std::printf("burst of 28 KB per 256-thread workgroup, nt, SPIN dependent FMAs between loads and stores; lds bytes set the workgroups per CU\n");
             for (int lds : {4096, 20480, 40960}) for (int spin : {0, 250, 500, 1000, 2000, 4000}) {

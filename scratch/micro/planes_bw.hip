@@ -6,7 +6,10 @@
 #include <cstdio>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
-constexpr int NF = 72, KP = 260, K = 257;
+#ifndef KPV
+#define KPV 260          // -DKPV=264: plane rows on 128-byte lines (16-byte planes: 264 x 16 B = 33 lines; 260 x 16 B = 32.5)
+#endif
+constexpr int NF = 72, KP = KPV, K = 257;
 typedef float vf4 __attribute__((ext_vector_type(4)));
 
 template <int W, bool NT> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W)))

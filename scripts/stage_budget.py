@@ -63,6 +63,13 @@ def budget_rows(cfg, w, stages, B):
         # the operator kernels never touch them
         idle = (M + 1) * (w["nfft"] - hop) * 4
         wpe_state = stages[1]["bytes"] // B - idle
+        # ... minus the padding of the WPE blocks' 128-byte-line layout (C N = 16: 2304 B allocated per bin for 2256 B of state, ds_wpe.hpp
+        # wpe_layout): the budget counts the bytes that carry state, the padding shows up on the measured side
+        CN = M * N
+        nw = CN * (CN + 1) // 2 + M * CN + CN
+        packed = (2 * nw + 1 + 3) & ~3
+        alloc = 2 * (144 + 16 * M + 16) if CN == 16 else packed
+        wpe_state -= K * (alloc - packed) * 4
         mcmcra_state = stages[2]["bytes"] // B - idle
         mvdr_state = stages[3]["bytes"] // B - idle
         rows = [

@@ -321,7 +321,9 @@ class EmulWpe:
     def __init__(self, nfft, C, N, batch=1, lam=0.998):
         self.B, self.K, self.C, self.N, self.lam = batch, nfft // 2 + 1, C, N, lam
         CN = C * N
-        self.SB = (2 * (CN * (CN + 1) // 2 + C * CN + CN) + 1 + 3) & ~3
+        from distantspeech_amd.ops import wpe_block_layout
+        self.layout = wpe_block_layout(C, N)
+        self.SB = self.layout["floats"]
         self.state = np.zeros((batch, self.K, self.SB), np.float32)
         for i in range(CN):
             self.state[:, :, 2 * (i * (i + 1) // 2 + i)] = 1e-3          # diagonal of the packed upper triangle

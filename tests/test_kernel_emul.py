@@ -268,9 +268,9 @@ def test_emul_wpe_wide_golden():
     err = np.concatenate([op.run(Xd[:, a:a + 97], Dn[:, a:a + 97]) for a in range(0, T, 97)], axis=1)
     assert np.all(np.isfinite(err))
     CN = C * N
-    npk = CN * (CN + 1) // 2
-    blk = op.state[0, :, : 2 * (npk + C * CN + CN)].copy().view(np.complex64)
-    W = blk[:, npk:npk + C * CN].reshape(-1, C, CN)
+    w0 = op.layout["w0"]
+    blk = op.state[0, :, : op.SB & ~1].copy().view(np.complex64)
+    W = blk[:, w0:w0 + C * CN].reshape(-1, C, CN)
     assert rms(W[g["bins"]] - g["W"]) < 1e-4 * rms(g["W"])
     P = np.zeros((len(g["bins_P"]), CN, CN), complex)
     for q in range(CN):
