@@ -77,6 +77,11 @@ EXPORTS = [
 ]
 
 
+def plane_len(K):
+    """lanes per plane row of the per-bin state arrays (csrc/ds_core.hpp plane_len): K bins rounded up to 8 — whole 128-byte lines per row"""
+    return (int(K) + 7) & ~7
+
+
 def build_info():
     """{'version': '106', 'state_layout': '4', 'arch': 'gfx950', 'shelved': '0'}: ds_build_info() parsed"""
     txt = load().ds_build_info().decode()

@@ -261,7 +261,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     KernelInfo ki = {nullptr, 0, 0, 0};
     KernelInfo ki_istft = {nullptr, 0, 0, 0};
     int op = -1, NF = 0;
-    const int KPo = (cfg->nfft / 2 + 1 + 3) & ~3;
+    const int KPo = ds::plane_len(cfg->nfft / 2 + 1);
     const int flen = cfg->filter_len > 0 ? cfg->filter_len : 2;
     const bool is_tdf = cfg->algo == DS_ALGO_TDNLMS || cfg->algo == DS_ALGO_TDRLS;
     switch (cfg->algo) {
@@ -1201,7 +1201,7 @@ static int extra_state(const ds_handle* h, ExtraState out[3]) {
 struct BlobHeader { uint32_t magic, version; int32_t algo, nfft, hop, n_mics, batch, filter_len, td_L, track_ryy, layout, modes, wpe_delay; uint32_t out_scale_bits; };
 static const uint32_t BLOB_MAGIC = 0x44534348u;      // "DSCH"
 static const int32_t BLOB_LAYOUT = DS_STATE_LAYOUT;      // 3: operator state as float4 planes [b][f / 4][k][f % 4], FIR history channel-major [b][m][L - 1]
-                                                         // 4: RLS-WPE blocks of 16 taps-by-channels on 128-byte lines (ds_wpe.hpp wpe_layout)
+                                                         // 4: plane rows of K rounded up to 8 lanes (ds_core.hpp plane_len); RLS-WPE blocks on 128-byte lines (ds_wpe.hpp wpe_layout)
 static BlobHeader blob_header(const ds_handle* h) {
     uint32_t osb;
     std::memcpy(&osb, &h->out_scale, sizeof osb);
@@ -1232,10 +1232,23 @@ size_t ds_state_bytes(const ds_handle* h) {
     return n;
 }
 
-// the same without the blob's framing (header + uniform counters of every handle in it): the bytes of carried state one call moves each way
+// the same without the blob's framing (header + uniform counters of every handle in it) and without the padding of the plane arrays (the
+// lanes K .. KP - 1 of every row, the rounding of the floats per bin to whole float4 planes, the line padding of the RLS-WPE blocks): the
+// bytes that carry state — what one call must move each way
+static size_t plane_padding_bytes(const ds_handle* h) {
+    const size_t B = h->cfg.batch, K = h->K;
+    size_t pad = 0;
+    if (bins_bytes(h)) pad += bins_bytes(h) - B * (size_t)h->ki.NF * K * sizeof(float);
+    if (h->op >= 0 && h->NF > 0 && opst_bytes(h)) {
+        const size_t live = h->cfg.algo == DS_ALGO_WPE ? B * K * (size_t)ds::wpe_bin_floats_packed(h->cfg.n_mics, h->filter_len) * sizeof(float)
+                                                        : B * (size_t)h->NF * K * sizeof(float);
+        if (live < opst_bytes(h)) pad += opst_bytes(h) - live;
+    }
+    return pad;
+}
 size_t ds_state_payload_bytes(const ds_handle* h) {
     if (!h) return 0;
-    size_t n = own_state_bytes(h) - sizeof(BlobHeader) - 4 * sizeof(int) + chain_hist_bytes(h);
+    size_t n = own_state_bytes(h) - sizeof(BlobHeader) - 4 * sizeof(int) + chain_hist_bytes(h) - plane_padding_bytes(h);
     for (int i = 0; i < 10; ++i) if (h->sub[i]) n += ds_state_payload_bytes(h->sub[i]);
     return n;
 }

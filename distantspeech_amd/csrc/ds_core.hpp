@@ -315,6 +315,12 @@ struct Params {
 };
 
 // number of per-bin state floats / planes
+// lanes per plane row of the per-bin state arrays ([..][plane][KP] of float4 or float): K bins rounded up to 8, so that a row of 16-byte
+// words is a whole number of 128-byte lines (264 x 16 B = 33 lines at 257 bins; the 260 of rounds 1 - 3 were 32.5: every other row
+// started in the middle of a line, and a wavefront's 1 KB of a row was 7 whole lines and two halves.  With the frame kernels'
+// non-temporal state traffic the aligned rows are +4.5 % at 1024 utterances, +3 % at 4096; profiles/r04a/plane_rows_ab.txt)
+DS_HD constexpr int plane_len(int K) { return (K + 7) & ~7; }
+
 template <int M, int ALGO, bool RYY> struct StateLayout {
     static constexpr int NF =
         ALGO == ALGO_ADAPTIVE ? (M * M + 5 + (RYY ? M * M : 0))
@@ -1258,7 +1264,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
     static constexpr bool WAVE_FFT = NC == 256;
     static constexpr int NYQ_TID = 0;                        // lane (wave 0, idle during the inverse FFT stages) that runs the Nyquist bin k = NC
     static constexpr int INV_T0 = NT / 2;                    // inverse-FFT butterflies run on threads [NT/2, NT)
-    static constexpr int KP = (K + 3) & ~3;                  // padded plane length
+    static constexpr int KP = plane_len(K);                  // padded plane length
     typedef StateLayout<M, ALGO, RYY> SL;
     static constexpr int NP = SL::NP;
     static constexpr int NV4 = HOP * M / 4;                  // float4 per hop of input
@@ -1757,7 +1763,7 @@ template <int NFFT, int M, bool CDR = false, int OV = 2, bool FRONT = false> str
         float* const hist = reinterpret_cast<float*>(&sh.Y[0]);
         cf* Yout = reinterpret_cast<cf*>(p.y + (long long)blk * p.y_batch_stride);
         int old_half = 0;
-        constexpr int KP = (K + 3) & ~3;
+        constexpr int KP = plane_len(K);
         // McCDR's planes of this utterance (rows 0..8 of the McSpp stage's state), bin `tid` in registers for the call, the Nyquist bin on lane 0
         auto cdr_plane = [&](int f, int k) -> float& {                 // ds_ops.hpp st_index
             return p.cdr_st[(((long long)b * (aic_floats_per_bin(p.cdr_NF) >> 2) + (f >> 2)) * KP + k) * 4 + (f & 3)];

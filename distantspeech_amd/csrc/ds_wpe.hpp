@@ -26,7 +26,7 @@ constexpr int WPEW_CNMAX = 80;          // ... and up to this many taps-by-chann
 
 // per-bin block, complex words: P upper triangle by columns, P[i][q] (i <= q) at q (q + 1) / 2 + i; then W[c][i] at w0 + c CN + i;
 // then input_buffer tap i at x0 + i; var (1 float) at float var_f.
-//   C N != 16: everything back to back (w0 = NPK, x0 = NPK + C CN, var behind the taps), padded to 16 B.
+//   C N < 16: everything back to back (w0 = NPK, x0 = NPK + C CN, var behind the taps), padded to 16 B.  C N > 16: see below.
 //   C N == 16 — the 16-lane kernel's full shape: BASELINE config 4's 8 x 2, and 4 x 4 — every piece one instruction moves is whole
 //   128-byte lines: [P: 136 words][(var, 0)][7 words of padding] = 144 words = 9 lines, then C rows of W (16 words = one line each), then
 //   the taps (one line): 2304 B at 8 channels against 2244 B packed.  With the pieces on line boundaries the block's traffic can be
@@ -37,6 +37,10 @@ struct WpeLayout { int w0, x0, var_f, floats, tri_words; bool lines; };
 DS_HD constexpr WpeLayout wpe_layout(int C, int N) {
     const int CN = C * N, NPK = wpe_packed(CN);
     if (CN == 16) return WpeLayout{144, 144 + C * 16, 2 * 136, 2 * (144 + C * 16 + 16), 144, true};
+    // the wide kernel's blocks (ds_wpe_wide.hpp): the block and its W section start on 128-byte lines (29 184 B at 4 x 20 against 29 124 B
+    // packed) — the 1 KB pieces of the tile traffic are then whole lines in every block, not in every other one: +5 % for the access
+    // pattern alone (profiles/r04a/block_rw.txt, `blk 29184`)
+    if (CN > 16) { const int w0 = (NPK + 15) & ~15, x0 = w0 + C * CN; return WpeLayout{w0, x0, 2 * (x0 + CN), (2 * (x0 + CN) + 1 + 31) & ~31, NPK, false}; }
     return WpeLayout{NPK, NPK + C * CN, 2 * (NPK + C * CN + CN), (2 * (NPK + C * CN + CN) + 1 + 3) & ~3, NPK, false};
 }
 DS_HD constexpr int wpe_bin_floats(int C, int N) { return wpe_layout(C, N).floats; }

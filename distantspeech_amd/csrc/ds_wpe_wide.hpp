@@ -98,7 +98,8 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
 
     template <class Exec> static DS_HD void run(Exec& ex, const WpeParams& p, int blk, Sh& sh) {
         const int C = CT > 0 ? CT : p.C, N = NTAPS > 0 ? NTAPS : p.N, CN = C * N;
-        const int SB = wpe_bin_floats(C, N), NPK = wpe_packed(CN);
+        const WpeLayout Lb = wpe_layout(C, N);
+        const int SB = Lb.floats, NPK = wpe_packed(CN);
         const float lam = p.lam, lam_inv = 1.0f / p.lam;
         const int ring_pos = p.dev_ring_pos ? p.dev_ring_pos[0] : p.ring_pos;
         const long long gbin = blk;                                    // one workgroup (= one wavefront) per (utterance, bin)
@@ -170,16 +171,16 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
             if (ALLW || wc >= 0) {
 #pragma unroll
                 for (int s = 0; s < SLP; ++s)
-                    if (s < SL && (ALLW || wi0 + s < CN)) r.W[s] = st[NPK + wc * CN + wi0 + s];
+                    if (s < SL && (ALLW || wi0 + s < CN)) r.W[s] = st[Lb.w0 + wc * CN + wi0 + s];
             }
-            r.var = stf[2 * (NPK + C * CN + CN)];
+            r.var = stf[Lb.var_f];
             r.io0 = (ub * p.T * p.K + kb) * C;
             r.ring0 = p.ring != nullptr ? (ub * p.ring_len * p.K + kb) * C : 0;
             r.xin = z; r.din = z;
             if (l < C) { r.xin = delayed(r, 0, l); r.din = mk(p.d[2 * (r.io0 + l)], p.d[2 * (r.io0 + l) + 1]); }
         });
         ex.phase_wave([&](int l, Rg&) {                               // (after the zero fill: the taps as stored)
-            for (int i = l; i < CN; i += NT) sh.X[0][i] = st[NPK + C * CN + i];
+            for (int i = l; i < CN; i += NT) sh.X[0][i] = st[Lb.x0 + i];
         });
         // ---- the packed triangle of P, chunk by chunk: block -> tile -> rows
         auto load_chunk = [&](auto hc) {
@@ -393,10 +394,10 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> struct WpeWideEngine {
             if (wc >= 0) {
 #pragma unroll
                 for (int s = 0; s < SLP; ++s)
-                    if (s < SL && wi0 + s < CN) st[NPK + wc * CN + wi0 + s] = r.W[s];
+                    if (s < SL && wi0 + s < CN) st[Lb.w0 + wc * CN + wi0 + s] = r.W[s];
             }
-            for (int i = l; i < CN; i += NT) st[NPK + C * CN + i] = sh.X[cur][i];
-            if (l == 0) stf[2 * (NPK + C * CN + CN)] = r.var;
+            for (int i = l; i < CN; i += NT) st[Lb.x0 + i] = sh.X[cur][i];
+            if (l == 0) stf[Lb.var_f] = r.var;
         });
         auto store_chunk = [&](auto hc) {
             constexpr int H = decltype(hc)::value, c0 = D::col0(H), c1r = D::col0(H + 1), w0 = wpew_words(c0);

@@ -455,7 +455,7 @@ class BatchEngine:
         nbytes = self._lib.ds_field_bytes(self._h, L.FIELD_OP_STATE)
         out = np.empty(nbytes // 4, dtype=np.float32)
         L.check(self._lib.ds_get_state(self._h, L.FIELD_OP_STATE, out.ctypes.data_as(ctypes.c_void_p), nbytes), self._h)
-        KP = (self.K + 3) & ~3
+        KP = L.plane_len(self.K)
         # in HBM the operator kernels keep float f of bin k at [f // 4][k][f % 4] (float4 planes: 16-byte accesses per lane)
         return out.reshape(self.batch, -1, KP, 4).transpose(0, 1, 3, 2).reshape(self.batch, -1, KP)[:, :, : self.K]
 

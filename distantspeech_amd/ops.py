@@ -347,11 +347,16 @@ def phase_correction(vector):
 def wpe_block_layout(C, N):
     """The per-bin state block of the RLS-WPE kernels (csrc/ds_wpe.hpp wpe_layout()): complex-word offsets of W (w0) and of the taps (x0),
     float offset of var, floats per block.  C N == 16 is laid out on 128-byte lines (the triangle's 136 words, (var, 0), 7 words of
-    padding; then C rows of W; then the taps); every other shape is packed back to back and padded to 16 bytes."""
+    padding; then C rows of W; then the taps); C N > 16 (the wide kernel) starts the block and its W section on lines; smaller shapes are
+    packed back to back and padded to 16 bytes."""
     CN = C * N
     npk = CN * (CN + 1) // 2
     if CN == 16:
         return dict(w0=144, x0=144 + 16 * C, var_f=2 * 136, floats=2 * (144 + 16 * C + 16), npk=npk)
+    if CN > 16:                                             # the wide kernel: the block and its W section on 128-byte lines
+        w0 = (npk + 15) & ~15
+        x0 = w0 + C * CN
+        return dict(w0=w0, x0=x0, var_f=2 * (x0 + CN), floats=(2 * (x0 + CN) + 1 + 31) & ~31, npk=npk)
     return dict(w0=npk, x0=npk + C * CN, var_f=2 * (npk + C * CN + CN), floats=(2 * (npk + C * CN + CN) + 1 + 3) & ~3, npk=npk)
 
 

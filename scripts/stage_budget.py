@@ -63,13 +63,6 @@ def budget_rows(cfg, w, stages, B):
         # the operator kernels never touch them
         idle = (M + 1) * (w["nfft"] - hop) * 4
         wpe_state = stages[1]["bytes"] // B - idle
-        # ... minus the padding of the WPE blocks' 128-byte-line layout (C N = 16: 2304 B allocated per bin for 2256 B of state, ds_wpe.hpp
-        # wpe_layout): the budget counts the bytes that carry state, the padding shows up on the measured side
-        CN = M * N
-        nw = CN * (CN + 1) // 2 + M * CN + CN
-        packed = (2 * nw + 1 + 3) & ~3
-        alloc = 2 * (144 + 16 * M + 16) if CN == 16 else packed
-        wpe_state -= K * (alloc - packed) * 4
         mcmcra_state = stages[2]["bytes"] // B - idle
         mvdr_state = stages[3]["bytes"] // B - idle
         rows = [
@@ -77,8 +70,8 @@ def budget_rows(cfg, w, stages, B):
             ("ds_wpe_kernel", "WPE, %d taps (stage 1)" % N, "the whole WPE state (inverse covariance as a packed triangle, taps, tap buffer) + one frame in and "
              "one frame out of the delay line", wpe_state + K * M * 8, K * M * 8, K * M * 8),
             ("ds_binop_kernel<1,", "McMcra speech presence (stage 2)", "the whole McMcra state, %d planes" % planes(M * (M + 1) + 4),
-             mcmcra_state * K // ((K + 3) & ~3), K * M * 8, K * 4 + K * 4),
-            ("ds_binop_kernel<11", "adaptive MVDR + SPP gain on frames (stage 3)", "the whole covariance / MCRA state", mvdr_state * K // ((K + 3) & ~3), K * M * 8 + K * 4 + K * 4, K * 8),
+             mcmcra_state, K * M * 8, K * 4 + K * 4),
+            ("ds_binop_kernel<11", "adaptive MVDR + SPP gain on frames (stage 3)", "the whole covariance / MCRA state", mvdr_state, K * M * 8 + K * 4 + K * 4, K * 8),
             ("ds_istft_rows_kernel", "synthesis (stage 4)", "synthesis overlap, one channel", hop * 4, K * 8, hop * 4),
         ]
     return rows
@@ -113,7 +106,7 @@ def main():
     print("Measured = HBM bytes of the PMC passes (`%s`, FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024, mean over the launches of the run)."
           % os.path.relpath(traffic_path, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     print("Minimal = the kernel's share of the state once in and once out + the stage's input and output arrays; K = %d lanes of a %d-lane plane "
-          "row are live." % (K, (K + 3) & ~3))
+          "row are live." % (K, (K + 7) & ~7))
     print()
     print("| kernel | stage | state the kernel touches | state B/utt (one way) | in B/utt | out B/utt | minimal MB/launch | measured MB/launch | measured / minimal |")
     print("|---|---|---|---|---|---|---|---|---|")

@@ -283,8 +283,8 @@ int emul_op(int op, int B, int K, int T, float* st, int NF, const float* in0, co
             int norm, float mu, float alpha, float reg, float lam) {
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
-    StPlanes planes(st, B, NF, (K + 3) & ~3);
-    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = planes.data(); p.NF = NF;
+    StPlanes planes(st, B, NF, ds::plane_len(K));
+    p.B = B; p.K = K; p.KP = ds::plane_len(K); p.T = T; p.st = planes.data(); p.NF = NF;
     p.in0 = in0; p.in1 = in1; p.in2 = in2; p.out0 = out0; p.out1 = out1; p.out2 = out2; p.out3 = out3; p.out4 = out4;
     p.M = M; p.N = N; p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.first_frame = first_frame;
     p.in_complex = in_complex; p.has_p = has_p; p.norm = norm; p.mu = mu; p.alpha = alpha; p.reg = reg; p.lam = lam;
@@ -299,8 +299,8 @@ int emul_fan(int op, int fan_form, int F, int B, int K, int T, float* st, int NF
              float* out0, int has_p, int norm, float mu, float alpha, float reg, float lam) {
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
-    StPlanes planes(st, B, NF, (K + 3) & ~3);
-    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = planes.data(); p.NF = NF;
+    StPlanes planes(st, B, NF, ds::plane_len(K));
+    p.B = B; p.K = K; p.KP = ds::plane_len(K); p.T = T; p.st = planes.data(); p.NF = NF;
     p.in0 = in0; p.in1 = in1; p.in2 = in2; p.out0 = out0;
     p.M = 1; p.N = 2; p.has_p = has_p; p.norm = norm; p.mu = mu; p.alpha = alpha; p.reg = reg; p.lam = lam;
     p.x_fan = F; p.d_interleaved = 1;
@@ -318,8 +318,8 @@ int emul_adaptive_frames(int B, int K, int T, int M, float* st, int NF, const fl
                          int frm_cnt, int ell, int L, int method, float alpha_v, float gate, float diag) {
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
-    StPlanes planes(st, B, NF, (K + 3) & ~3);
-    p.B = B; p.K = K; p.KP = (K + 3) & ~3; p.T = T; p.st = planes.data(); p.NF = NF; p.in0 = Z; p.in1 = gain; p.out0 = Y; p.M = M;
+    StPlanes planes(st, B, NF, ds::plane_len(K));
+    p.B = B; p.K = K; p.KP = ds::plane_len(K); p.T = T; p.st = planes.data(); p.NF = NF; p.in0 = Z; p.in1 = gain; p.out0 = Y; p.M = M;
     p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.has_p = gain != nullptr;
     p.steer = reinterpret_cast<const ds::cf*>(steer); p.steer_batch_stride = 0;
     p.method = method; p.alpha_v = alpha_v; p.beta_v = ds::complement_of(alpha_v); p.gate = gate; p.diag = diag;
@@ -391,7 +391,7 @@ int emul_quad_mvdr(float* st_quad, float* st_ref, const float* a, const float* z
 // [KP], then NF % 4 floats per bin as a narrow plane, the utterance stride rounded up to 32 floats — ds_core.hpp StateLayout), writes KP
 int emul_layout(int algo, int nfft, int M, int ryy, int* kp) {
     const int K = nfft / 2 + 1;
-    *kp = (K + 3) & ~3;
+    *kp = ds::plane_len(K);
     int nf = 0;
     if (algo == ds::ALGO_ADAPTIVE) nf = M * M + 5 + (ryy ? M * M : 0);
     if (algo == ds::ALGO_GSC) nf = M * (M + 1) + 2 * (M - 1);
@@ -446,7 +446,7 @@ int emul_stft_cdr(int nfft, int M, int batch, const float* x, int n_samples, flo
     p.T = n_samples / hop;
     p.y_batch_stride = (long long)p.T * K * M * 2;
     p.tail_in = tail_in;
-    StPlanes planes(st, batch, NF, (nfft / 2 + 1 + 3) & ~3);
+    StPlanes planes(st, batch, NF, ds::plane_len(nfft / 2 + 1));
     p.cdr_st = planes.data(); p.cdr_NF = NF; p.cdr_frm = frm; p.cdr_ell = ell; p.cdr_L = 65; p.cdr_fn = Fn; p.cdr_gamma = gamma; p.cdr_qavg = qavg;
     switch (nfft) {
         case 256: return run_stft_cdr<256>(M, p, batch);
@@ -469,7 +469,7 @@ int emul_front(int nfft, int M, int batch, const float* x, int n_samples, float*
     p.T = n_samples / hop;
     p.y_batch_stride = (long long)p.T * K * M * 2;
     p.tail_in = tail_in;
-    StPlanes planes(st, batch, NF, (nfft / 2 + 1 + 3) & ~3);
+    StPlanes planes(st, batch, NF, ds::plane_len(nfft / 2 + 1));
     p.cdr_st = planes.data(); p.cdr_NF = NF; p.cdr_frm = frm; p.cdr_ell = ell; p.cdr_L = 65; p.cdr_fn = Fn; p.cdr_gamma = gamma; p.cdr_qavg = qavg;
     p.fe_coef = coef; p.fe_L = L; p.fe_mem = mem; p.fe_cache_in = cache_in; p.fe_cache_out = cache_out; p.fe_fixed = fixed; p.fe_radius = radius;
     switch (nfft) {
@@ -493,7 +493,7 @@ int emul_aic(int nfft, int M, int batch, const float* x, int n_samples, float* y
     p.T = n_samples / hop;
     p.tail_in = tail_in; p.tail_out = tail_out; p.counters = counters;
     p.mcra_L = 1;
-    StPlanes planes(st, batch, NF, (nfft / 2 + 1 + 3) & ~3);
+    StPlanes planes(st, batch, NF, ds::plane_len(nfft / 2 + 1));
     p.aic_st = planes.data(); p.aic_NF = NF; p.aic_d = d; p.aic_dprev = dprev; p.aic_p = pk; p.aic_pc = pc; p.aic_norm = norm;
     p.aic_mu = mu; p.aic_alpha = alpha; p.aic_reg = reg;
     p.aic_e = e_spectra; p.aic_bmtail = bmtail; p.aic_bm = bm_out;     // e_spectra set: the blocking-matrix synthesis runs inside the program

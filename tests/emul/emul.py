@@ -133,7 +133,7 @@ class EmulOp:
 
     def __init__(self, op, nfft, M=1, N=2, batch=1, mu=None, alpha=0.9, lam=0.998, norm=1, L=15):
         self.op, self.B, self.K, self.M, self.N = self.OPS[op], batch, nfft // 2 + 1, M, N
-        self.KP = (self.K + 3) & ~3
+        self.KP = (self.K + 7) & ~7                       # ds_core.hpp plane_len()
         self.NF = {0: 5, 1: M * (M + 1) + 4, 2: 5 * M + (M - 1) + 8, 3: 4 * N * M + 1, 4: 4 * N + 2 * N * N,
                    5: 2 * M * M + 8 + 2 * M,
                    6: 2 * M * M * N + 2 * M * N + 2 * (M * N) ** 2 + 1, 7: 9, 8: 12 + 2 * M * M + 3, 9: 1, 10: 1, 14: 1, 15: 1, 16: 1, 17: 1}[self.op]
@@ -292,7 +292,7 @@ class EmulAdaptiveFrames:
 
     def __init__(self, nfft, M, steer, batch=1, L=15, method=2):
         self.B, self.K, self.M, self.L, self.method = batch, nfft // 2 + 1, M, L, method
-        self.KP = (self.K + 3) & ~3
+        self.KP = (self.K + 7) & ~7                       # ds_core.hpp plane_len()
         self.NF = M * M + 5
         self.st = np.zeros((batch, self.NF, self.KP), dtype=np.float32)
         self.steer = np.ascontiguousarray(steer, dtype=np.complex64)

@@ -648,7 +648,9 @@ def test_plain_c_caller(tmp_path):
 def test_committed_traffic_matches_this_builds_state_layout(ds, cfg, algo_name, B):
     """bench.py reports `roofline.traffic` from the committed rocprofv3 PMC passes (profiles/traffic_latest.json): a layout change that
     moved more or fewer bytes would leave a stale number there.  The bytes a one-hop step must move follow from the library's own state
-    size (ds_state_bytes: every plane, tail and counter once in and once out) plus the hop's samples; the PMC figure must be within 2 %."""
+    size (ds_state_bytes: every plane, tail and counter once in and once out) plus the hop's samples.  The library counts the LIVE lanes
+    of a plane row (257 of 264); the memory system moves whole 128-byte lines (33 per row of float4 words for 32.1 lines of state), so the
+    PMC figure sits 2 % above the analytic one: held to [-1 %, +3.5 %]."""
     import json
     from distantspeech_amd import _lib as L
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -657,7 +659,7 @@ def test_committed_traffic_matches_this_builds_state_layout(ds, cfg, algo_name, 
     eng = ds.BatchEngine(getattr(L, "ALGO_" + algo_name), M, nfft, batch=B, track_ryy=False) if algo_name == "ADAPTIVE" else ds.BatchEngine(L.ALGO_GSC, M, nfft, batch=B)
     analytic = 2 * eng.state_bytes() + B * (M + 1) * hop * 4
     measured("traffic_vs_layout_" + cfg, pmc_bytes=pmc, analytic_bytes=analytic, ratio=pmc / analytic)
-    assert abs(pmc / analytic - 1.0) < 0.02, (pmc, analytic)
+    assert -0.01 < pmc / analytic - 1.0 < 0.035, (pmc, analytic)
 
 
 @pytest.mark.parametrize("cfg", ["cfg4", "cfg5"])

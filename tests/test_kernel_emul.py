@@ -572,7 +572,7 @@ def test_fan_form_equals_instances(op, F):
     lib = E.lib()
     rng = np.random.default_rng(17)
     U, K, N = 3, 129, 2
-    B, KP = U * F, (K + 3) & ~3
+    B, KP = U * F, (K + 7) & ~7
     opid = {"sublms": 3, "subrls": 4}[op]
     NF = 4 * N + 2 * N * N if op == "subrls" else 4 * N + 1
     def fresh():
@@ -644,7 +644,7 @@ def emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, p_override=None, fused_tail=
     if p_override is not None:
         p = np.ascontiguousarray(p_override.T[None], dtype=np.float32)
     F = EmulTransform(nfft, 1).stft(fixed[:, :, None], 0)[..., 0]                # [1, T, K]
-    N, KP = 2, (K + 3) & ~3
+    N, KP = 2, (K + 7) & ~7
     NF = 4 * N + 2 * N * N if rls else 4 * N + 1
     st = np.zeros((M, NF, KP), dtype=np.float32)
     if rls:
