@@ -82,15 +82,27 @@ struct OpCtx : OpParams {
     __amdgpu_buffer_rsrc_t rs;    // state from utterance b0 on
     int b0;
 };
-struct StRef {
+// cache policy of the operators' state accesses: 2 = nt.  An operator reads every state line once and writes it once per launch and the
+// next launch (possibly on another XCD) is the next to touch it: streamed, like the frame kernels' load_state / store_state.  It pays since
+// the plane rows are whole 128-byte lines (plane_len(): cfg5 +8.9 %, cfg4 +2.3 % at one hop per call, nothing lost at 10 s per call;
+// on the 260-lane rows of rounds 1 - 3 it had gained nothing: profiles/r04a/opstate_nt_lines_ab.txt, wpe_nt_ab.txt).  -DDS_OPSTATE_POLICY=0: A/B
+#if !defined(DS_OPSTATE_POLICY)
+#if defined(DS_PLAIN_STATE)
+#define DS_OPSTATE_POLICY 0
+#else
+#define DS_OPSTATE_POLICY 2
+#endif
+#endif
+template <int POL> struct StRefT {
     __amdgpu_buffer_rsrc_t rs;
     unsigned voff, soff;
-    __device__ operator float() const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0)); }
-    __device__ void operator=(float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0); }
-    __device__ void operator=(const StRef& o) const { *this = (float)o; }       // st_at(..) = st_at(..) moves the value, not the reference
-    StRef(const StRef&) = default;
-    __device__ StRef(__amdgpu_buffer_rsrc_t rs_, unsigned v, unsigned s) : rs(rs_), voff(v), soff(s) {}
+    __device__ operator float() const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, POL)); }
+    __device__ void operator=(float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, POL); }
+    __device__ void operator=(const StRefT& o) const { *this = (float)o; }       // st_at(..) = st_at(..) moves the value, not the reference
+    StRefT(const StRefT&) = default;
+    __device__ StRefT(__amdgpu_buffer_rsrc_t rs_, unsigned v, unsigned s) : rs(rs_), voff(v), soff(s) {}
 };
+typedef StRefT<DS_OPSTATE_POLICY> StRef;
 __device__ inline OpCtx make_op_ctx(const OpParams& p0, long long first_lane) {       // first_lane: flat (b, k) index of the workgroup's lane 0
     OpCtx c;
     static_cast<OpParams&>(c) = p0;
@@ -108,6 +120,17 @@ __device__ inline StRef st_at(const OpCtx& p, int b, int f, int k) {
     return StRef(p.rs, (unsigned)(((b - p.b0) * st_floats_per_bin(p.NF) * p.KP + k) * 4), (unsigned)(f * p.KP * 4));
 #else
     return StRef(p.rs, (unsigned)((((b - p.b0) * st_floats_per_bin(p.NF) * p.KP + k * 4) + (f & 3)) * 4), (unsigned)((f >> 2) * p.KP * 16));
+#endif
+}
+// the same word with the ordinary cache policy: for the operators that keep their state in memory and come back to it every frame of a
+// call (OMLSA, the run-time-shape subband LMS) — a streamed line would be fetched from HBM again one frame later
+__device__ inline StRefT<0> st_mem(const OpCtx& p, int b, int f, int k) {
+    // [b][f / 4][k][f % 4]: the lane offset addresses the bin's 16-byte group, the plane group travels in the SGPR offset and f % 4 is an
+    // immediate — four neighbouring floats of a bin merge into one 16-byte access per lane
+#ifdef DS_OLD_OPSTATE
+    return StRefT<0>(p.rs, (unsigned)(((b - p.b0) * st_floats_per_bin(p.NF) * p.KP + k) * 4), (unsigned)(f * p.KP * 4));
+#else
+    return StRefT<0>(p.rs, (unsigned)((((b - p.b0) * st_floats_per_bin(p.NF) * p.KP + k * 4) + (f & 3)) * 4), (unsigned)((f >> 2) * p.KP * 16));
 #endif
 }
 // one whole float4 plane group q (floats 4 q .. 4 q + 3) of bin k as ONE 16-byte access
@@ -129,6 +152,7 @@ __device__ inline void st_store4(const OpCtx& p, int b, int q, int k, const floa
 typedef OpParams OpCtx;
 DS_HD OpCtx make_op_ctx(const OpParams& p0, long long) { return p0; }
 DS_HD float& st_at(const OpCtx& p, int b, int f, int k) { return p.st[st_index(b, f, k, p.NF, p.KP)]; }
+DS_HD float& st_mem(const OpCtx& p, int b, int f, int k) { return st_at(p, b, f, k); }
 DS_HD void st_load4(const OpCtx& p, int b, int q, int k, float* d) { for (int j = 0; j < 4; ++j) d[j] = st_at(p, b, 4 * q + j, k); }
 DS_HD void st_store4(const OpCtx& p, int b, int q, int k, const float* s) { for (int j = 0; j < 4; ++j) st_at(p, b, 4 * q + j, k) = s[j]; }
 #endif
@@ -240,10 +264,10 @@ DS_HD void op_omlsa(const OpCtx& p, int b, int k) {
         // M minima-controlled noise trackers (:83-85)
         float mc[5];
 #pragma unroll
-        for (int f = 0; f < 5; ++f) mc[f] = st_at(p, b, f, k);
+        for (int f = 0; f < 5; ++f) mc[f] = st_mem(p, b, f, k);
         mcra_bin(mc, k, K, ym, y0, yp, frm, reset, p.L);
 #pragma unroll
-        for (int f = 0; f < 5; ++f) st_at(p, b, f, k) = mc[f];
+        for (int f = 0; f < 5; ++f) st_mem(p, b, f, k) = mc[f];
         const float MU_Y = mc[4];
         float zu_minus_mu_max = -3.0e38f;
         for (int ch = 0; ch < R; ++ch) {
@@ -251,31 +275,31 @@ DS_HD void op_omlsa(const OpCtx& p, int b, int k) {
             const float um = k > 0 ? pw(p.in1, ub + (long long)(k - 1) * R + ch) : 0.0f;
             const float up = k < K - 1 ? pw(p.in1, ub + (long long)(k + 1) * R + ch) : 0.0f;
 #pragma unroll
-            for (int f = 0; f < 5; ++f) mc[f] = st_at(p, b, 5 * (ch + 1) + f, k);
+            for (int f = 0; f < 5; ++f) mc[f] = st_mem(p, b, 5 * (ch + 1) + f, k);
             mcra_bin(mc, k, K, um, u0, up, frm, reset, p.L);
 #pragma unroll
-            for (int f = 0; f < 5; ++f) st_at(p, b, 5 * (ch + 1) + f, k) = mc[f];
+            for (int f = 0; f < 5; ++f) st_mem(p, b, 5 * (ch + 1) + f, k) = mc[f];
             float zu;
             if (first) zu = u0;                                                           // :92-93
-            else zu = fma_(0.8f, st_at(p, b, o_zu + ch, k), (float)(1.0 - 0.8) * fma_(up, 0.25f, fma_(u0, 0.5f, um * 0.25f)));   // :100
-            st_at(p, b, o_zu + ch, k) = zu;
+            else zu = fma_(0.8f, st_mem(p, b, o_zu + ch, k), (float)(1.0 - 0.8) * fma_(up, 0.25f, fma_(u0, 0.5f, um * 0.25f)));   // :100
+            st_mem(p, b, o_zu + ch, k) = zu;
             zu_minus_mu_max = fmaxf_(zu_minus_mu_max, zu - mc[4]);
         }
         frm += 1; ell += 1;
         const long long ob = yb + k;
         if (first) {                                                                       // :87-93
             first = 0;
-            st_at(p, b, o_s + 0, k) = y0;
-            st_at(p, b, o_zy, k) = y0;
-            p.out0[ob] = y0; p.out1[ob] = st_at(p, b, o_s + 3, k); p.out2[ob] = st_at(p, b, o_s + 4, k);
+            st_mem(p, b, o_s + 0, k) = y0;
+            st_mem(p, b, o_zy, k) = y0;
+            p.out0[ob] = y0; p.out1[ob] = st_mem(p, b, o_s + 3, k); p.out2[ob] = st_mem(p, b, o_s + 4, k);
             if (p.in_complex && p.out3) {
-                const float sg = sqrtf(st_at(p, b, o_s + 3, k));
+                const float sg = sqrtf(st_mem(p, b, o_s + 3, k));
                 p.out3[2 * ob] = p.in0[2 * ob] * sg; p.out3[2 * ob + 1] = p.in0[2 * ob + 1] * sg;
             }
             continue;
         }
-        const float zy = fma_(0.8f, st_at(p, b, o_zy, k), (float)(1.0 - 0.8) * fma_(yp, 0.25f, fma_(y0, 0.5f, ym * 0.25f)));   // :98
-        st_at(p, b, o_zy, k) = zy;
+        const float zy = fma_(0.8f, st_mem(p, b, o_zy, k), (float)(1.0 - 0.8) * fma_(yp, 0.25f, fma_(y0, 0.5f, ym * 0.25f)));   // :98
+        st_mem(p, b, o_zy, k) = zy;
         float Omega = fmaxf_(zy - MU_Y, 1e-6f) / (fmaxf_(zu_minus_mu_max, 0.01f * MU_Y) + 1e-6f);   // :107-109
         Omega = fminf_(fmaxf_(Omega, 0.1f), 100.0f);
         const float gamma_s = fminf_(y0 / fma_(MU_Y, 1.66f, 1e-6f), 100.0f);                     // :115
@@ -286,8 +310,8 @@ DS_HD void op_omlsa(const OpCtx& p, int b, int k) {
         else omq = fminf_((gamma_s - 1.0f) / (10.0f - 1.0f), (Omega - 0.3f) / (3.0f - 0.3f));
         omq = fminf_(fmaxf_(omq, 2e-7f), 1.0f - 1e-6f);
         const float q = 1.0f - omq;
-        float lam = st_at(p, b, o_s + 0, k);
-        const float gamma_pre = st_at(p, b, o_s + 1, k), gh1_pre = st_at(p, b, o_s + 2, k);
+        float lam = st_mem(p, b, o_s + 0, k);
+        const float gamma_pre = st_mem(p, b, o_s + 1, k), gh1_pre = st_mem(p, b, o_s + 2, k);
         const float gamma = y0 / fmaxf_(lam, 1e-10f);                                            // :134
         const float xi = fma_(0.921f * gh1_pre * gh1_pre, gamma_pre, (float)(1.0 - 0.921) * fmaxf_(gamma - 1.0f, 0.0f));   // :137
         const float nu = gamma * xi / (1.0f + xi);                                               // :140
@@ -297,8 +321,8 @@ DS_HD void op_omlsa(const OpCtx& p, int b, int k) {
         lam = fma_(at, lam, 1.47f * (1.0f - at) * y0);                                           // :149
         float G = powf(gh1, pp) * powf(Gmin, 1.0f - pp);                                         // :153
         G = fmaxf_(fminf_(G, 1.0f), Gmin);
-        st_at(p, b, o_s + 0, k) = lam; st_at(p, b, o_s + 1, k) = gamma; st_at(p, b, o_s + 2, k) = gh1;
-        st_at(p, b, o_s + 3, k) = G; st_at(p, b, o_s + 4, k) = pp; st_at(p, b, o_s + 5, k) = xi; st_at(p, b, o_s + 6, k) = q;
+        st_mem(p, b, o_s + 0, k) = lam; st_mem(p, b, o_s + 1, k) = gamma; st_mem(p, b, o_s + 2, k) = gh1;
+        st_mem(p, b, o_s + 3, k) = G; st_mem(p, b, o_s + 4, k) = pp; st_mem(p, b, o_s + 5, k) = xi; st_mem(p, b, o_s + 6, k) = q;
         p.out0[ob] = lam; p.out1[ob] = G; p.out2[ob] = pp;
         if (p.in_complex && p.out3) {
             const float sg = sqrtf(G);
@@ -340,16 +364,16 @@ DS_HD void op_sublms_generic(const OpCtx& p, int b, int k) {
         const long long fx = ((long long)(b / p.x_fan) * p.T + t) * p.K + k;
         // shift register (SubbandAF.py:50-51 / SubbandLmsMc.py:62-63)
         for (int n = N - 1; n > 0; --n)
-            for (int c = 0; c < 2 * C; ++c) st_at(p, b, NC2 + n * 2 * C + c, k) = st_at(p, b, NC2 + (n - 1) * 2 * C + c, k);
+            for (int c = 0; c < 2 * C; ++c) st_mem(p, b, NC2 + n * 2 * C + c, k) = st_mem(p, b, NC2 + (n - 1) * 2 * C + c, k);
         for (int c = 0; c < C; ++c) {
-            st_at(p, b, NC2 + 2 * c, k) = p.in0[2 * (fx * C + c)];
-            st_at(p, b, NC2 + 2 * c + 1, k) = p.in0[2 * (fx * C + c) + 1];
+            st_mem(p, b, NC2 + 2 * c, k) = p.in0[2 * (fx * C + c)];
+            st_mem(p, b, NC2 + 2 * c + 1, k) = p.in0[2 * (fx * C + c) + 1];
         }
         cf out = mk(0.0f, 0.0f);
         float pw = 0.0f;
         for (int i = 0; i < N * C; ++i) {
-            const cf w = mk(st_at(p, b, 2 * i, k), st_at(p, b, 2 * i + 1, k));
-            const cf x = mk(st_at(p, b, NC2 + 2 * i, k), st_at(p, b, NC2 + 2 * i + 1, k));
+            const cf w = mk(st_mem(p, b, 2 * i, k), st_mem(p, b, 2 * i + 1, k));
+            const cf x = mk(st_mem(p, b, NC2 + 2 * i, k), st_mem(p, b, NC2 + 2 * i + 1, k));
             out = cfmac(out, x, w);                        // conj(W) X  (SubbandAF.py:107)
             pw += cabs2(x);
         }
@@ -359,17 +383,17 @@ DS_HD void op_sublms_generic(const OpCtx& p, int b, int k) {
         const cf err = mk(fma_(-out.x, pk, d.x), fma_(-out.y, pk, d.y));      // d - out * p  (SubbandLMS.py:66-68)
         float scale = 1.0f;
         if (p.norm) {
-            float P = st_at(p, b, 2 * NC2, k);
+            float P = st_mem(p, b, 2 * NC2, k);
             P = fma_(p.alpha, P, (1.0f - p.alpha) * (pw / (float)C));           // SubbandLMS.py:72-75 ; /M in SubbandLmsMc.py:174-180
-            st_at(p, b, 2 * NC2, k) = P;
+            st_mem(p, b, 2 * NC2, k) = P;
             scale = 1.0f / (P + p.reg);
         }
         const float g = 2.0f * p.mu * pk * scale;                              // SubbandAF.py:86
         for (int i = 0; i < N * C; ++i) {
-            const cf x = mk(st_at(p, b, NC2 + 2 * i, k), st_at(p, b, NC2 + 2 * i + 1, k));
+            const cf x = mk(st_mem(p, b, NC2 + 2 * i, k), st_mem(p, b, NC2 + 2 * i + 1, k));
             const cf gr = cmulc(x, err);                                        // X conj(err)
-            st_at(p, b, 2 * i, k) = fma_(g, gr.x, st_at(p, b, 2 * i, k));
-            st_at(p, b, 2 * i + 1, k) = fma_(g, gr.y, st_at(p, b, 2 * i + 1, k));
+            st_mem(p, b, 2 * i, k) = fma_(g, gr.x, st_mem(p, b, 2 * i, k));
+            st_mem(p, b, 2 * i + 1, k) = fma_(g, gr.y, st_mem(p, b, 2 * i + 1, k));
         }
         p.out0[2 * fb] = err.x; p.out0[2 * fb + 1] = err.y;
     }
