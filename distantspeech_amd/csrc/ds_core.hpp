@@ -1242,6 +1242,14 @@ struct AicState {
     }
     __device__ float ld(int f, int k) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)((k * 4 + (f & 3)) * 4), (unsigned)((f >> 2) * KP * 16), 0)); }
     __device__ void st(int f, int k, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (unsigned)((k * 4 + (f & 3)) * 4), (unsigned)((f >> 2) * KP * 16), 0); }
+    // the lanes' own planes, once in and once out per launch: streamed (cache policy 2 = nt), like the operators' state (ds_ops.hpp)
+#if defined(DS_PLAIN_STATE) || defined(DS_AIC_PLAIN_STATE)
+    __device__ float ld_once(int f, int k) const { return ld(f, k); }
+    __device__ void st_once(int f, int k, float v) const { st(f, k, v); }
+#else
+    __device__ float ld_once(int f, int k) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)((k * 4 + (f & 3)) * 4), (unsigned)((f >> 2) * KP * 16), 2)); }
+    __device__ void st_once(int f, int k, float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (unsigned)((k * 4 + (f & 3)) * 4), (unsigned)((f >> 2) * KP * 16), 2); }
+#endif
 };
 #else
 struct AicState {
@@ -1250,6 +1258,8 @@ struct AicState {
     AicState(const Params& p, int b, int KP_) : base(p.aic_st ? p.aic_st + (long long)b * aic_floats_per_bin(p.aic_NF) * KP_ : nullptr), KP(KP_) {}
     float ld(int f, int k) const { return base[((long long)(f >> 2) * KP + k) * 4 + (f & 3)]; }
     void st(int f, int k, float v) const { base[((long long)(f >> 2) * KP + k) * 4 + (f & 3)] = v; }
+    float ld_once(int f, int k) const { return ld(f, k); }
+    void st_once(int f, int k, float v) const { st(f, k, v); }
 };
 #endif
 
@@ -1435,7 +1445,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             if constexpr (ALGO == ALGO_AIC) {                           // the canceller's planes, where the subband-LMS operator keeps them
                 const AicState as(p, b, KP);
 #pragma unroll
-                for (int f = 0; f < SL::NF; ++f) r.st[f] = as.ld(f, tid);
+                for (int f = 0; f < SL::NF; ++f) r.st[f] = as.ld_once(f, tid);
                 r.nyq.x = as.ld(tid < SL::NF ? tid : 0, NC);
             } else {
 #pragma unroll
@@ -1703,7 +1713,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             if constexpr (ALGO == ALGO_AIC) {
                 const AicState as(p, b, KP);
 #pragma unroll
-                for (int f = 0; f < SL::NF; ++f) as.st(f, tid, r.st[f]);
+                for (int f = 0; f < SL::NF; ++f) as.st_once(f, tid, r.st[f]);
                 if (tid < SL::NF) as.st(tid, NC, sh.nyq[tid]);
                 if (p.aic_e != nullptr && tid < NC / 2) {               // overlap tails of the blocking-matrix synthesis
                     float* bt = p.aic_bmtail + (long long)b * M * HOP;
