@@ -93,11 +93,14 @@ struct OpCtx : OpParams {
 #define DS_OPSTATE_POLICY 2
 #endif
 #endif
+#if !defined(DS_OPSTATE_STORE_POLICY)
+#define DS_OPSTATE_STORE_POLICY(pol) (pol)      // A/B: -DDS_OPSTATE_STORE_POLICY\(pol\)=0 keeps the stores ordinary while the loads stream
+#endif
 template <int POL> struct StRefT {
     __amdgpu_buffer_rsrc_t rs;
     unsigned voff, soff;
     __device__ operator float() const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, POL)); }
-    __device__ void operator=(float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, POL); }
+    __device__ void operator=(float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, DS_OPSTATE_STORE_POLICY(POL)); }
     __device__ void operator=(const StRefT& o) const { *this = (float)o; }       // st_at(..) = st_at(..) moves the value, not the reference
     StRefT(const StRefT&) = default;
     __device__ StRefT(__amdgpu_buffer_rsrc_t rs_, unsigned v, unsigned s) : rs(rs_), voff(v), soff(s) {}

@@ -43,7 +43,9 @@ extern "C" {
 #endif
 
 #define DS_VERSION 106
-#define DS_STATE_LAYOUT 4   /* serialised arrangement of the carried state (checkpoint header; measurement records quote it) */
+#define DS_STATE_LAYOUT 4   /* serialised arrangement of the carried state (checkpoint header; measurement records quote it).  4 (round 4): plane rows of
+                               KP = K rounded up to 8 lanes (whole 128-byte lines per row of float4 words), RLS-WPE blocks on 128-byte lines (csrc/ds_wpe.hpp
+                               wpe_layout); ds_import_state refuses blobs of another layout */
 
 /* error codes */
 #define DS_OK 0
@@ -196,7 +198,8 @@ typedef struct ds_config {
 #define DS_FIELD_STFT_TAIL 11 /* [B][M][nfft - hop]  Transform.previous_input (transform.py:424-425)  */
 #define DS_FIELD_OLA_TAIL 12  /* [B][hop] of a beamformer object; [B][M][nfft - hop] of a DS_ALGO_TRANSFORM handle: Transform.previous_output */
 #define DS_FIELD_COUNTERS 13  /* int32 [B][4] {mcra.frm_cnt, mcra.ell, spp.frm_cnt, 0} */
-#define DS_FIELD_OP_STATE 14  /* frame-level objects: raw state [B][NF][KP] float32 (row map in distantspeech_amd/ops.py) */
+#define DS_FIELD_OP_STATE 14  /* frame-level objects: raw state [B][NF / 4][KP][4] float32, KP = K rounded up to 8 (row map in distantspeech_amd/ops.py;
+                                 RLS-WPE objects: one block per (utterance, bin), distantspeech_amd/ops.py wpe_block_layout) */
 #define DS_FIELD_H 16          /* DS_ALGO_ADAPTIVE, methods src / DS / MVDR: [B][K][M][2] the weights the frame kernel applies to the next frame
                                  (adaptivebeamformer.py:105-112: H[:, k]), computed by the kernel's own fused Cholesky solve on the handle's Rvv —
                                  a read-only probe; needs ds_set_steering */
