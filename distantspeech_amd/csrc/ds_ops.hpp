@@ -147,9 +147,27 @@ __device__ inline void st_load4(const OpCtx& p, int b, int q, int k, float* d) {
 // (four dword stores at consecutive immediate offsets, which the backend merges (dwordx3 + dword in ROCm 7.2).  The b128 STORE builtin
 // was tried as well: single-stream results were right, but with two utterance groups of a chain running on two streams the outputs
 // carried NaNs at random — scratch/dbg_groups.py, DESIGN.md section 3.5 — so neither b128 builtin is used)
+// Round 4: ONE buffer_store_dwordx4 per group, written as inline assembly.  Left to the backend the four dword stores of a group came out
+// as a dword + a dwordx3 (the float-0 store's offset register is formed from another spelling of the same stride; three rewrites of the
+// expression each merged less): two partial writes per 16 bytes, which the L2 merged while the stores were ordinary and nothing merges now
+// that they are streamed (+30 % write bytes in the PMC passes, profiles/r04i).  The s_nop covers the hardware's wait state between a
+// store of more than 8 bytes and a vector write to its data registers, which the compiler cannot see inside an asm statement.
+// -DDS_OPSTATE_STORE4_BUILTIN: the four dword stores again (A/B)
 __device__ inline void st_store4(const OpCtx& p, int b, int q, int k, const float* s) {
+#if defined(DS_OPSTATE_STORE4_BUILTIN) || defined(DS_OLD_OPSTATE)
 #pragma unroll
     for (int j = 0; j < 4; ++j) st_at(p, b, 4 * q + j, k) = s[j];
+#else
+    typedef float v4_t __attribute__((ext_vector_type(4)));
+    v4_t v; v.x = s[0]; v.y = s[1]; v.z = s[2]; v.w = s[3];
+    const unsigned voff = (unsigned)(((b - p.b0) * st_floats_per_bin(p.NF) * p.KP + k * 4) * 4);
+    const unsigned soff = (unsigned)(q * p.KP * 16);
+#if DS_OPSTATE_POLICY == 2
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(p.rs), "s"(soff) : "memory");
+#else
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(p.rs), "s"(soff) : "memory");
+#endif
+#endif
 }
 #else
 typedef OpParams OpCtx;
