@@ -150,8 +150,9 @@ __device__ inline void st_load4(const OpCtx& p, int b, int q, int k, float* d) {
 // Round 4: ONE buffer_store_dwordx4 per group, written as inline assembly.  Left to the backend the four dword stores of a group came out
 // as a dword + a dwordx3 (the float-0 store's offset register is formed from another spelling of the same stride; three rewrites of the
 // expression each merged less): two partial writes per 16 bytes, which the L2 merged while the stores were ordinary and nothing merges now
-// that they are streamed (+30 % write bytes in the PMC passes, profiles/r04i).  The s_nop covers the hardware's wait state between a
-// store of more than 8 bytes and a vector write to its data registers, which the compiler cannot see inside an asm statement.
+// that they are streamed (+30 % write bytes in the PMC passes, profiles/r04i).  The trailing s_nop covers the hardware's two wait states
+// between a store of more than 8 bytes and a vector write to its data registers, the leading one the five between a vector write to an
+// SGPR (v_readfirstlane) and a memory instruction that reads it: hazards the compiler cannot see into an asm statement for.
 // -DDS_OPSTATE_STORE4_BUILTIN: the four dword stores again (A/B)
 __device__ inline void st_store4(const OpCtx& p, int b, int q, int k, const float* s) {
 #if defined(DS_OPSTATE_STORE4_BUILTIN) || defined(DS_OLD_OPSTATE)
@@ -163,9 +164,9 @@ __device__ inline void st_store4(const OpCtx& p, int b, int q, int k, const floa
     const unsigned voff = (unsigned)(((b - p.b0) * st_floats_per_bin(p.NF) * p.KP + k * 4) * 4);
     const unsigned soff = (unsigned)(q * p.KP * 16);
 #if DS_OPSTATE_POLICY == 2
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(p.rs), "s"(soff) : "memory");
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(p.rs), "s"(soff) : "memory");
 #else
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(p.rs), "s"(soff) : "memory");
+    asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(p.rs), "s"(soff) : "memory");
 #endif
 #endif
 }
