@@ -1623,7 +1623,11 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                         cf Zn[M];
 #pragma unroll
                         for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; Zn[m] = mk(F0.x - F0.y, 0.0f); }
+#ifdef DS_ABLATE_NYQUIST   // timing experiment only (profiles/r04a/nyquist_ablation.txt): the hop without the Nyquist bin's per-bin program
+                        const cf Yn = Zn[0];
+#else
                         const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_cnt, reset, spp_cnt, r.adn, r.apkn, ref_pow_row(t));
+#endif
                         sh.Y[NC] = mk(Yn.x, 0.0f);
                     }
                 }
@@ -1648,7 +1652,11 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     cf Zn[M];
 #pragma unroll
                     for (int m = 0; m < M; ++m) Zn[m] = mk(sh.zn[m], 0.0f);
+#ifdef DS_ABLATE_NYQUIST
+                    const cf Yn = Zn[0];
+#else
                     const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_nyq, reset, spp_nyq, r.adn, r.apkn, ref_pow_row(t));
+#endif
                     sh.Y[NC] = mk(Yn.x, 0.0f);                          // irfft ignores Im Y[N/2]
                 }
             });
