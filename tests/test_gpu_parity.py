@@ -685,10 +685,10 @@ def test_committed_traffic_matches_this_builds_stage_budgets(ds, cfg):
     budget = stage_budget.minimal_step_bytes(cfg, w, eng, w["batch"])
     eng.close()
     measured("traffic_vs_budget_" + cfg, pmc_bytes=pmc, budget_bytes=budget, ratio=pmc / budget)
-    # measured above minimal: whole 128-byte lines against live lanes (2 %), the line padding of the WPE blocks (cfg4: 2.7 % of them), and —
-    # since the operators' planes are streamed — their 16-byte groups leaving as a dword + a dwordx3 store each, two partial writes the L2
-    # no longer merges (cfg5: the operators' write bytes 1.3 x their state).  Held to [-3 %, +10 %]
-    assert -0.03 < pmc / budget - 1.0 < 0.10, (pmc, budget)
+    # measured above minimal: whole 128-byte lines against live lanes (2 %) and the line padding of the WPE blocks (cfg4: 2.7 % of them):
+    # 1.02 / 1.01 with the operators' state groups leaving as ONE 16-byte store each.  (As a dword + a dwordx3 per group — what the backend
+    # makes of four dword stores — the streamed operators wrote 1.3 x their state: 1.05 / 1.09 here)  Held to [-3 %, +4 %]
+    assert -0.03 < pmc / budget - 1.0 < 0.04, (pmc, budget)
 
 
 def test_realtime_chunk_latency_within_budget(ds):
