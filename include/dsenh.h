@@ -357,7 +357,9 @@ size_t ds_field_bytes(const ds_handle* h, int field);
 
 /* opaque checkpoint of all carried state (the reference never serialises its state) */
 size_t ds_state_bytes(const ds_handle* h);
-/* the carried state alone, without the checkpoint's framing: the bytes one call reads and writes back (bench.py's byte accounting) */
+/* the carried state alone, without the checkpoint's framing and without the padding of the arrays it lives in (the lanes K .. KP - 1 of a
+   plane row, the rounding of a bin's floats to float4 groups, the line padding of the RLS-WPE blocks): the bytes that carry state, which one
+   call must read and write back (bench.py's byte accounting).  Smaller than ds_state_bytes by the framing and that padding */
 size_t ds_state_payload_bytes(const ds_handle* h);
 /* a chain handle's stage i (0-based; the order of the reference object's members, see DS_ALGO_* above): its DS_ALGO_*, channel count,
    batch and carried-state bytes (ds_state_payload_bytes of that stage).  DS_EINVAL when the handle has no stage i.  Read-only
