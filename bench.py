@@ -52,6 +52,11 @@ WORKLOADS = {
     "cfg3": dict(algo="GSC", M=4, nfft=512, hop=256, batch=4096, S=5120 + 3 * 257 * 8 + 2 * 16 * 257 * 4, r=0.032,
                  kernel="ds_frames_kernel<512,4,GSC> (two utterance groups of 2048 on two streams)", launches=2, graph=1,
                  desc="GSC + LMS canceller + McMcra gain (GSC.process method=2), 4 mics, 16 kHz, 512-FFT/256-hop"),
+    # the north star's target sentence ("4-mic MVDR + postfilter ... frames/s at >= 40 % HBM roofline"): cfg2's beamformer with the McMcra gain of the
+    # same frame on its output (GSC.py:225,286), ONE fused frame kernel (DS_ALGO_ADAPTIVE_PF).  S = cfg2's 43 156 + Phi_yy, Phi_vv 2*16*257*4
+    "mvdr_pf": dict(algo="ADAPTIVE_PF", M=4, nfft=512, hop=256, batch=1024, S=4096 + 1024 + 257 * 16 * 8 + 5 * 257 * 4 + 2 * 16 * 257 * 4, r=0.032,
+                    kernel="ds_frames_kernel<512,4,ADAPTIVE_PF>", launches=1, graph=1,
+                    desc="adaptive MVDR + McMcra post-filter gain in one pass (adaptivebeamfomer.process method=2, * spp.G), 4 mics, 16 kHz, 512-FFT/256-hop"),
     # cfg1 on the GPU (stateless apart from the tails)
     "fixed": dict(algo="FIXED", M=4, nfft=512, hop=256, batch=1024, S=5120, r=0.032,
                   kernel="ds_frames_kernel<512,4,FIXED>", launches=1, graph=1,
@@ -86,8 +91,8 @@ WORKLOADS = {
 }
 
 
-EXTRA_T1 = ("cfg3", "cfg4", "cfg5", "wpe_nb")                                                  # other_configs at one hop per call
-EXTRA_CHUNKED = (("cfg2", 625), ("cfg3", 625), ("cfg4", 312), ("cfg5", 625), ("wpe_nb", 2500))         # ... and with 10 s per call
+EXTRA_T1 = ("mvdr_pf", "cfg3", "cfg4", "cfg5", "wpe_nb")                                                  # other_configs at one hop per call
+EXTRA_CHUNKED = (("cfg2", 625), ("mvdr_pf", 625), ("cfg3", 625), ("cfg4", 312), ("cfg5", 625), ("wpe_nb", 2500))         # ... and with 10 s per call
 DATA_NOTE = ("BASELINE.md section 3's recipe in both legs (white noise sigma 0.05 per microphone + a 0.5 s on / off 300-3400 Hz Gaussian source sigma "
              "0.1 steered from 197 degrees, seed 1234 + utterance): the GPU leg draws it on the device with torch's generator (GpuBackend.synth), the "
              "cpu_baseline legs with NumPy's (oracle.synth_utterance) — the same statistics, different random streams; neither leg's arithmetic per "
@@ -150,9 +155,10 @@ class GpuBackend:
     name = "synthetic"
     dist_backend = None              # dist.init picks nccl (= RCCL) on a GPU box
 
-    def __init__(self, local_rank, world):
+    def __init__(self, local_rank, world, tail_async=False):
         import torch
         self.torch = torch
+        self.tail_async = bool(tail_async)        # main() decides: it is the one that raised the runtime's hardware-queue limit (or did not)
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
         # DS_FORCE_DEVICE=<ordinal> (with DS_DIST_BACKEND=gloo): every rank on that one GPU — exercises the real rank path (sharding, barrier,
@@ -289,9 +295,9 @@ class GpuWorkload:
             self.eng.chain_set_aux(L.CHAIN_AUX_FIR, fractional_delay_filter_bank(np.array(-(tau - np.max(tau)))[:, 0] * mic.fs))
             if w["algo"] == "SUBBAND_GSC":
                 self.eng.chain_set_aux(L.CHAIN_AUX_COHERENCE, McSpp.diffuse_coherence(M, nfft))
-                # the chain's tail on its own stream: only where this process raised the runtime's hardware-queue limit itself (main());
-                # under a profiler the runtime was up before main() with its default 4 queues, and the tail stays on the chain's stream
-                self.tail_async = int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 6 and not under_profiler()
+                # the chain's tail on its own stream: only where this process raised the runtime's hardware-queue limit itself — main() says
+                # so through the backend (tail_async); under a profiler the runtime was up before main() with its default 4 queues
+                self.tail_async = bool(getattr(be, "tail_async", False))
                 self.eng.set_param_i(L.PARAM_TAIL_ASYNC, int(self.tail_async))
         else:
             tao = -1 * mic.r * np.cos(ang[1]) * np.cos(ang[0] - mic.gamma) / mic.c          # adaptivebeamformer.py:52
@@ -341,12 +347,12 @@ class GpuWorkload:
         self.be.torch.cuda.empty_cache()
 
 
-def load_backend(local_rank, world):
+def load_backend(local_rank, world, tail_async=False):
     spec = os.environ.get("DS_BENCH_BACKEND")            # test infrastructure only (tests/bench_stub.py): exercises the rank plumbing without a GPU
     if spec:
         mod, cls = spec.split(":")
         return getattr(importlib.import_module(mod), cls)(local_rank, world)
-    return GpuBackend(local_rank, world)
+    return GpuBackend(local_rank, world, tail_async=tail_async)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -402,6 +408,8 @@ def measure(be, dsdist, w, B, T, K, W, rank, world, min_region_ms, graph=None, m
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": w["kernel"],
                      "launches_per_step": w["launches"], "launch_ms": round(launch_ms, 5), "bytes_per_launch": phys, "bytes_basis": basis,
                      "state_bytes_per_gpu": state_bytes, "batch_per_gpu": B, "hops_per_call": T,
+                     # where the carried state sits between two launches: under the 256 MiB Infinity Cache the "hbm" fraction is an on-die figure
+                     "resident": "infinity_cache" if 0 < state_bytes <= 256 * 1024 * 1024 else "hbm",
                      "achieved_survey_bytes": round(survey, 1), "frac_survey_bytes": round(survey / HBM_PEAK_GBS, 4),
                      "algorithmic_bytes_per_frame": alg, "algorithmic_bytes_per_launch": alg * B * T},
     }
@@ -470,7 +478,7 @@ def attach_compute(entry, key, frames_per_s_per_gpu):
 
 
 def compact_roofline(r):
-    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "bytes_per_launch", "bytes_basis", "batch_per_gpu",
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "bytes_per_launch", "bytes_basis", "batch_per_gpu", "resident",
             "frac_survey_bytes", "frac_measured", "traffic_profile", "value")
     return {k: r[k] for k in keep if k in r}
 
@@ -575,6 +583,8 @@ def _cpu_oracle_worker(args):
     with np.errstate(all="ignore"):
         if name == "cfg3":
             O.OracleGSC(mic, nfft, with_dead_state=False).process(x, ang, 2)
+        elif name == "mvdr_pf":
+            O.OracleMvdrPostfilter(mic, nfft=nfft, hop=hop).process(x, ang, 2)
         elif name == "cfg4":
             O.OracleWpeMvdrPostfilter(mic, nfft=nfft, hop=hop).process(x, ang)
         else:
@@ -621,11 +631,16 @@ def main():
         raise SystemExit("--gpus and --steps must be >= 1, --warmup >= 0")
 
     profiled = under_profiler()
+    hw_queues_raised = False
     if not profiled:
         # this PROCESS is the application: hardware queues per device for the HIP runtime (default 4) — the chain handles run their stages on
         # up to five streams and two streams that share a queue serialise.  Must be in the environment before the first HIP call (the child
         # ranks inherit it); under a profiler the runtime is already up and the variable is left alone (DS_PARAM_TAIL_ASYNC follows it)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        try:
+            hw_queues_raised = int(os.environ["GPU_MAX_HW_QUEUES"]) >= 6      # what THIS process (or the parent that launched the ranks) asked the runtime for
+        except ValueError:
+            hw_queues_raised = False
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if profiled:
             sys.stderr.write("bench.py: --gpus %d under a GPU profiler refused: the profiled process has initialised the GPU and must not start "
@@ -642,9 +657,9 @@ def main():
     cpu_pre = {}
     if world == 1 and not args.no_cpu_baseline and not args.no_extras and args.config == "cfg2" and not os.environ.get("DS_BENCH_BACKEND") \
             and not profiled:                            # worker processes: never from a profiled (GPU-initialised) process
-        for name in ("cfg3", "cfg4", "cfg5"):
+        for name in ("mvdr_pf", "cfg3", "cfg4", "cfg5"):
             cpu_pre[name] = cpu_baseline_oracle(name)
-    be = load_backend(local_rank, world)
+    be = load_backend(local_rank, world, tail_async=hw_queues_raised)
     dsdist.init(backend=be.dist_backend)
 
     w = WORKLOADS[args.config]
@@ -664,7 +679,7 @@ def main():
     out = None
     if rank == 0:
         regime = "streaming callback regime" if T == 1 else "chunked"
-        mics = {"cfg2": "4-mic, 512-FFT", "cfg3": "4-mic, 512-FFT", "fixed": "4-mic, 512-FFT", "cfg4": "8-mic, 1024-FFT", "cfg5": "6-mic, 512 bands", "wpe_nb": "4-ch WPE, 256 bands", "cfg4_n10": "8-mic, 1024-FFT, 10-tap WPE",
+        mics = {"cfg2": "4-mic, 512-FFT", "cfg3": "4-mic, 512-FFT", "fixed": "4-mic, 512-FFT", "cfg4": "8-mic, 1024-FFT", "cfg5": "6-mic, 512 bands", "wpe_nb": "4-ch WPE, 256 bands", "cfg4_n10": "8-mic, 1024-FFT, 10-tap WPE", "mvdr_pf": "4-mic, 512-FFT, MVDR + post-filter",
                 "tdgsc": "4-mic, block 256", "fdgsc": "4-mic, block 256"}[args.config]
         out = {
             "metric": "enhanced frames/sec (%s)" % mics, "value": res["value"], "unit": "frames/s",

@@ -23,6 +23,7 @@ ALGO_SUBBAND_GSC = 19
 ALGO_TDGSC = 20
 ALGO_FDGSC = 21
 ALGO_WPE_TD = 22
+ALGO_ADAPTIVE_PF = 23
 PARAM_POSTFILTER = 15
 PARAM_TAIL_ASYNC = 17
 PARAM_REF_POWERS = 18

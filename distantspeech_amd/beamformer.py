@@ -181,14 +181,36 @@ class _AdaptiveBase(beamformer):
         return {'data': self._squeeze(y).astype(np.float64), 'WNG': None, 'DI': None, 'beampattern': None}
 
 
+class _SppView(object):
+    """`spp` of an adaptivebeamfomer(postfilter="mcmcra"): the McMcra state the fused kernel carries (mc_mcra.py:68-69)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    Phi_yy = property(lambda s: s._o._squeeze(s._o._eng.get_field(L.FIELD_PHI_YY).astype(np.float64)))
+    Phi_vv = property(lambda s: s._o._squeeze(s._o._eng.get_field(L.FIELD_PHI_VV).astype(np.float64)))
+    frm_cnt = property(lambda s: s._o._squeeze(s._o._eng.get_field(L.FIELD_COUNTERS)[:, 2]))
+
+
 class adaptivebeamfomer(_AdaptiveBase):
-    """MCRA-gated adaptive beamformer (src / DS / MVDR / TFGSC) — beamformer/adaptivebeamformer.py:10-128."""
+    """MCRA-gated adaptive beamformer (src / DS / MVDR / TFGSC) — beamformer/adaptivebeamformer.py:10-128.
+
+    postfilter="mcmcra" (not in the reference's class; BASELINE's "MVDR + post-filter" workload): the McMcra speech-presence gain of the
+    same input frame multiplies the beamformer output, Y = (H^H Z) spp.G — GSC.process's convention for its `spp` (GSC.py:225,286) — inside
+    the same fused frame kernel (DS_ALGO_ADAPTIVE_PF).  Methods src / DS / MVDR; `self.spp.Phi_yy / Phi_vv` read the McMcra state."""
 
     _ALGO = L.ALGO_ADAPTIVE
 
     def __init__(self, mic: MicArray, frameLen=256, hop=None, nfft=None, c=343, r=0.032, fs=16000, batch=1,
-                 device=-1, track_ryy=True):
+                 device=-1, track_ryy=True, postfilter=None):
         beamformer.__init__(self, mic, frame_len=frameLen, hop=hop, nfft=nfft, batch=batch, device=device)
+        if postfilter not in (None, False, "mcmcra"):
+            raise ValueError("postfilter must be None or 'mcmcra', got %r" % (postfilter,))
+        self.postfilter = postfilter or None
+        if self.postfilter:
+            self._ALGO = L.ALGO_ADAPTIVE_PF
+            track_ryy = False                  # the one-pass kernel keeps no Ryy (TFGSC is refused)
+            self.spp = _SppView(self)
         self.gamma = mic.gamma
         self.angle = np.array([0, 0]) / 180 * np.pi
         self.method = 'MVDR'

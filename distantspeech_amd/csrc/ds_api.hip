@@ -254,7 +254,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     if (cfg->struct_size != (int32_t)sizeof(ds_config)) return fail(nullptr, DS_EINVAL, "ds_create: struct_size mismatch");
     *out = nullptr;
     if (cfg->batch <= 0) return fail(nullptr, DS_EINVAL, "ds_create: batch must be > 0");
-    if (cfg->algo < DS_ALGO_TRANSFORM && cfg->hop * 2 != cfg->nfft)
+    if (dsi::frames_algo(cfg->algo) && cfg->hop * 2 != cfg->nfft)
         return fail(nullptr, DS_EUNSUPPORTED, "ds_create: the beamformer objects take hop == nfft/2 (the only overlap their reference callers use)");
     if (cfg->algo == DS_ALGO_TRANSFORM && cfg->hop * 2 != cfg->nfft && cfg->hop * 4 != cfg->nfft)
         return fail(nullptr, DS_EUNSUPPORTED, "ds_create: Transform takes hop == nfft/2 or hop == nfft/4");
@@ -276,6 +276,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
 #endif
             break;
         case DS_ALGO_GSC: ki = ds::lookup_gsc(cfg->nfft, cfg->n_mics); break;
+        case DS_ALGO_ADAPTIVE_PF: ki = ds::lookup_adaptive_pf(cfg->nfft, cfg->n_mics); break;
         case DS_ALGO_TRANSFORM:
             ki = ds::lookup_stft(cfg->nfft, cfg->n_mics, cfg->nfft / cfg->hop);
             ki_istft = ds::lookup_istft(cfg->nfft, cfg->n_mics, cfg->nfft / cfg->hop);
@@ -355,7 +356,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
                  cfg->algo, cfg->nfft, cfg->n_mics);
         return fail(nullptr, DS_EUNSUPPORTED, buf);
     }
-    if (cfg->algo >= DS_ALGO_MCRA && op < 0) return fail(nullptr, DS_EUNSUPPORTED, "ds_create: unsupported n_mics / filter_len for this frame-level object");
+    if (cfg->algo >= DS_ALGO_MCRA && !dsi::frames_algo(cfg->algo) && op < 0) return fail(nullptr, DS_EUNSUPPORTED, "ds_create: unsupported n_mics / filter_len for this frame-level object");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(nullptr, DS_EHIP, "ds_create: no HIP device visible (libdsenh has no CPU path)");
@@ -375,7 +376,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     for (int i = 0; i < 8; ++i) h->group_exec[i] = nullptr;
     for (int i = 0; i < 11; ++i) { h->adv_frames[i] = 0; h->adv_td[i] = 0; }
     // fused frame kernels: two free-running utterance groups from 2048 utterances up (more than one round of workgroups per launch)
-    h->split = (cfg->algo <= DS_ALGO_GSC && cfg->batch >= 2048) ? 2 : 1; h->ev_fork = nullptr;
+    h->split = (dsi::frames_algo(cfg->algo) && cfg->batch >= 2048) ? 2 : 1; h->ev_fork = nullptr;
     h->parts = 1; h->groups_open = false;
     h->front_async = false; h->tail_async = false; h->front_open = false; h->fr_valid[0] = h->fr_valid[1] = false; h->tf_valid[0] = h->tf_valid[1] = false; h->bf_valid[0] = h->bf_valid[1] = false; h->al_read[0] = h->al_read[1] = false; h->fr_mid[0] = h->fr_mid[1] = false; h->front_set = 0; h->lean_main = false; h->early_front = false;
     for (int i = 0; i < 10; ++i) h->ev_fr[i] = nullptr;
@@ -656,6 +657,8 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
             if (value < 0 || value > 3) return fail(h, DS_EINVAL, "method must be 0..3");
             if (value == DS_METHOD_TFGSC && h->cfg.algo == DS_ALGO_ADAPTIVE && !h->cfg.track_ryy)
                 return fail(h, DS_ESTATE, "method TFGSC needs ds_config.track_ryy = 1");
+            if (value == DS_METHOD_TFGSC && h->cfg.algo == DS_ALGO_ADAPTIVE_PF)
+                return fail(h, DS_EUNSUPPORTED, "method TFGSC: not on a DS_ALGO_ADAPTIVE_PF handle (it keeps no Ryy)");
             h->method = value;
             return DS_OK;
         case DS_PARAM_MCRA_L:
@@ -769,7 +772,7 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
         if (n_samples == 0) return DS_OK;
         return chain_process_device(h, x_dev, layout, x_batch_stride, x_chan_stride, n_samples, y_dev, y_batch_stride);
     }
-    if (h->cfg.algo > DS_ALGO_GSC) return fail(h, DS_ESTATE, "ds_process_device: this handle is a frame-level object; use ds_stft / ds_*_estimate / ds_sub*_update");
+    if (!dsi::frames_algo(h->cfg.algo)) return fail(h, DS_ESTATE, "ds_process_device: this handle is a frame-level object; use ds_stft / ds_*_estimate / ds_sub*_update");
     if (!h->steer_set) return fail(h, DS_ESTATE, "ds_process_device: call ds_set_steering first");
     if (n_samples < 0 || n_samples % h->cfg.hop != 0)
         return fail(h, DS_ESHAPE, "ds_process_device: n_samples must be a multiple of hop");
@@ -844,7 +847,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     // the groups between calls (join_groups() does when anything else touches the handle).  While one group's kernel is in its launch gap
     // or its last round of workgroups the other group's kernel fills the CUs: +12..15 % at 2048-4096 utterances per call, +3 % at 16 384,
     // nothing at 1024 (one round of workgroups).  A caller-provided stream keeps everything on that stream.
-    const bool frames = h->cfg.algo <= DS_ALGO_GSC;
+    const bool frames = dsi::frames_algo(h->cfg.algo);
     const int ng = (frames && !stream && !h->ref_powers) ? (h->split < count ? h->split : (count > 0 ? count : 1)) : 1;
     if (ng > 1) {
         DS_HIP(h, hipSetDevice(h->device));                 // not set_device(): the groups stay on their streams between calls
@@ -1012,7 +1015,7 @@ int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y
 // ---- frame-level entry points ---------------------------------------------------------------------
 int ds_process_pcm16(ds_handle* h, const int16_t* pcm, int n_total_channels, int first_channel, int n_samples, int16_t* out) {
     if (!h || !pcm || !out) return fail(h, DS_EINVAL, "ds_process_pcm16: NULL argument");
-    if (h->cfg.algo > DS_ALGO_GSC) return fail(h, DS_ESTATE, "ds_process_pcm16: handle is a frame-level object");
+    if (!dsi::frames_algo(h->cfg.algo)) return fail(h, DS_ESTATE, "ds_process_pcm16: handle is a frame-level object");
     const int M = h->cfg.n_mics;
     if (first_channel < 0 || first_channel + M > n_total_channels) return fail(h, DS_ESHAPE, "ds_process_pcm16: microphone channels outside the frame");
     if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_process_pcm16: n_samples must be a multiple of hop");
@@ -1064,13 +1067,14 @@ int ds_timing_end(ds_handle* h, float* elapsed_ms) {
 size_t ds_field_bytes(const ds_handle* h, int field) {
     if (!h) return 0;
     const size_t B = h->cfg.batch, K = h->K, M = h->cfg.n_mics;
-    const bool ad = h->cfg.algo == DS_ALGO_ADAPTIVE, gsc = h->cfg.algo == DS_ALGO_GSC;
+    const bool pf = h->cfg.algo == DS_ALGO_ADAPTIVE_PF;
+    const bool ad = h->cfg.algo == DS_ALGO_ADAPTIVE || pf, gsc = h->cfg.algo == DS_ALGO_GSC;
     switch (field) {
         case DS_FIELD_RVV: return ad ? B * K * M * M * 2 * sizeof(float) : 0;
         case DS_FIELD_RYY: return (ad && h->cfg.track_ryy) ? B * K * M * M * 2 * sizeof(float) : 0;
         case DS_FIELD_MCRA_S: case DS_FIELD_MCRA_SMIN: case DS_FIELD_MCRA_STMP: case DS_FIELD_MCRA_P:
         case DS_FIELD_MCRA_LAMBDA_D: return ad ? B * K * sizeof(float) : 0;
-        case DS_FIELD_PHI_YY: case DS_FIELD_PHI_VV: return gsc ? B * K * M * M * sizeof(float) : 0;
+        case DS_FIELD_PHI_YY: case DS_FIELD_PHI_VV: return (gsc || pf) ? B * K * M * M * sizeof(float) : 0;
         case DS_FIELD_G_AIC: return gsc ? B * K * (M - 1) * 2 * sizeof(float) : 0;
         case DS_FIELD_STFT_TAIL: return tail_in_bytes(h);
         case DS_FIELD_OLA_TAIL: return tail_out_bytes(h);
@@ -1165,8 +1169,8 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
         case DS_FIELD_MCRA_STMP: scalar(MCS + 2); break;
         case DS_FIELD_MCRA_P: scalar(MCS + 3); break;
         case DS_FIELD_MCRA_LAMBDA_D: scalar(MCS + 4); break;
-        case DS_FIELD_PHI_YY: sym(0); break;
-        case DS_FIELD_PHI_VV: sym(M * (M + 1) / 2); break;
+        case DS_FIELD_PHI_YY: sym(h->cfg.algo == DS_ALGO_ADAPTIVE_PF ? M * M + 5 : 0); break;                       // StateLayout::PYY / PF_PYY
+        case DS_FIELD_PHI_VV: sym((h->cfg.algo == DS_ALGO_ADAPTIVE_PF ? M * M + 5 : 0) + M * (M + 1) / 2); break;
         case DS_FIELD_G_AIC:
             for (int b = 0; b < B; ++b)
                 for (int k = 0; k < K; ++k)
@@ -1336,7 +1340,7 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
         std::memcpy(&got, s, sizeof got);
         if (got.magic != BLOB_MAGIC) return fail(h, DS_EINVAL, "ds_import_state: not a dsenh checkpoint (bad magic)");
         if (std::memcmp(&got, &want, sizeof got) != 0) {
-            char buf[256];
+            char buf[768];
             snprintf(buf, sizeof buf, "ds_import_state: checkpoint was written for version %u algo %d nfft %d hop %d mics %d batch %d taps %d fir %d ryy %d "
                      "layout %d modes %d wpe_delay %d window-scale %08x, this handle is version %u algo %d nfft %d hop %d mics %d batch %d taps %d fir %d "
                      "ryy %d layout %d modes %d wpe_delay %d window-scale %08x",

@@ -227,7 +227,11 @@ inline float complement_of(float a) {
 DS_HD float fminf_(float a, float b) { return a < b ? a : b; }
 DS_HD float fmaxf_(float a, float b) { return a > b ? a : b; }
 
-enum { ALGO_FIXED = 0, ALGO_ADAPTIVE = 1, ALGO_GSC = 2, ALGO_AIC = 3 };   // ALGO_AIC: the SubbandGSC chain's tail (see aic_bin)
+enum { ALGO_FIXED = 0, ALGO_ADAPTIVE = 1, ALGO_GSC = 2, ALGO_AIC = 3, ALGO_ADAPTIVE_PF = 4 };   // ALGO_AIC: the SubbandGSC chain's tail (see aic_bin)
+// ALGO_ADAPTIVE_PF: the adaptive beamformer's frame program followed, in the same per-bin phase, by the McMcra speech-presence gain on the
+// same input frame (the post-filter convention of GSC.py:225,286): Y = w^H z * spp.G — "MVDR + post-filter" in one pass
+DS_HD constexpr bool algo_has_mcra(int algo) { return algo == ALGO_ADAPTIVE || algo == ALGO_ADAPTIVE_PF; }
+DS_HD constexpr bool algo_has_spp(int algo) { return algo == ALGO_GSC || algo == ALGO_ADAPTIVE_PF; }
 enum { METHOD_SRC = 0, METHOD_DS = 1, METHOD_MVDR = 2, METHOD_TFGSC = 3 };
 
 // Device-resident uniform counters of a chain stage, cnt = {frm_cnt, ell, first_frame, aux}: a later kernel of the same stream carries
@@ -324,6 +328,7 @@ DS_HD constexpr int plane_len(int K) { return (K + 7) & ~7; }
 template <int M, int ALGO, bool RYY> struct StateLayout {
     static constexpr int NF =
         ALGO == ALGO_ADAPTIVE ? (M * M + 5 + (RYY ? M * M : 0))
+        : ALGO == ALGO_ADAPTIVE_PF ? (M * M + 5 + M * (M + 1))     // the adaptive program's floats, then McMcra's Phi_yy, Phi_vv (packed symmetric)
         : ALGO == ALGO_GSC    ? (M * (M + 1) + 2 * (M - 1))
         : ALGO == ALGO_AIC    ? (8 * M + 1)            // 2-tap M-channel canceller: W, X (2 M complex each), P
                               : 0;
@@ -344,6 +349,9 @@ template <int M, int ALGO, bool RYY> struct StateLayout {
     static constexpr int PYY = 0;                    // sym packed (i<=j) row-major, M(M+1)/2
     static constexpr int PVV = M * (M + 1) / 2;
     static constexpr int GA = M * (M + 1);           // (M-1) complex
+    // ADAPTIVE_PF float map: [0, M M + 5) as ADAPTIVE, then
+    static constexpr int PF_PYY = M * M + 5;
+    static constexpr int PF_PVV = M * M + 5 + M * (M + 1) / 2;
 };
 
 DS_HD constexpr int off_index(int i, int j, int M) {   // i<j -> index among strictly-upper entries
@@ -1354,6 +1362,12 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         } else if constexpr (ALGO == ALGO_ADAPTIVE) {
             mcra_bin(st + SL::MC_S, k, K, sh.pw[k > 0 ? k - 1 : 0], sh.pw[k], sh.pw[k + 1], frm_cnt, reset, p.mcra_L);
             Yk = adaptive_bin<M, RYY>(st, Z, a, p);
+        } else if constexpr (ALGO == ALGO_ADAPTIVE_PF) {
+            mcra_bin(st + SL::MC_S, k, K, sh.pw[k > 0 ? k - 1 : 0], sh.pw[k], sh.pw[k + 1], frm_cnt, reset, p.mcra_L);
+            Yk = adaptive_bin<M, false>(st, Z, a, p);                                          // adaptivebeamformer.py:69-120
+            float pp, G, xi, gam;
+            mcmcra_bin<M>(st + SL::PF_PYY, st + SL::PF_PVV, Z, k, spp_cnt, pp, G, xi, gam);    // spp.estimation(Z)  GSC.py:225
+            Yk = cscale(Yk, G);                                                                // Y * spp.G         GSC.py:286
         } else {
             Yk = gsc_bin<M>(st, Z, a, p, k, spp_cnt, pw_row0);
         }
@@ -1373,7 +1387,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         const cf* steer = p.steer + (long long)b * p.steer_batch_stride;
         // (the fixed beamformer and the chain tail have no frame counters: nothing to read, nothing to write back — as loaded-and-restored
         // values they were three registers held across the whole kernel, spilled to scratch in the 6-microphone tail)
-        constexpr bool HAS_CNT = ALGO == ALGO_ADAPTIVE || ALGO == ALGO_GSC;
+        constexpr bool HAS_CNT = algo_has_mcra(ALGO) || algo_has_spp(ALGO);
         int frm_cnt = HAS_CNT ? cnt[0] : 0, ell = HAS_CNT ? cnt[1] : 1, spp_cnt = HAS_CNT ? cnt[2] : 0;
         int old_half = 0;
         // Params::ref_pow: row of frame t, bin 0 of this utterance in [B][T][K] (GSC only; wave-uniform)
@@ -1633,11 +1647,11 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 }
             });
             const int frm_nyq = frm_cnt, spp_nyq = spp_cnt;
-            if (ALGO == ALGO_ADAPTIVE) {
+            if (algo_has_mcra(ALGO)) {
                 if (reset) ell = 0;
                 frm_cnt += 1; ell += 1;
             }
-            if (ALGO == ALGO_GSC) spp_cnt += 1;
+            if (algo_has_spp(ALGO)) spp_cnt += 1;
             // ---- inverse packed real FFT -----------------------------------------------------------
             // The Nyquist bin k = NC is the 257th bin of 256 lanes.  In 512-point frames (wave-local inverse stages) its per-bin program
             // (state in LDS) runs on lane NYQ_TID while another wave runs the inverse FFT stages, instead of as a second pass of the per-bin

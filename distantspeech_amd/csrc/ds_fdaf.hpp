@@ -226,7 +226,7 @@ template <int NFFT, int CMAX> struct FdafEngine {
                     }
                     sh.nyqP = fma_(p.alpha, sh.nyqP, (1.0f - p.alpha) * pn);
                     sh.nyqS[0] = yn;
-                    if (two_path) sh.nyqS[1] = yfn;
+                    if constexpr (CMAX >= 2) { if (two_path) sh.nyqS[1] = yfn; }      // (launch_fdaf never runs two_path at CMAX = 1)
                 }
             });
             const int ny = two_path ? 2 : 1;

@@ -138,6 +138,8 @@ int fail(ds_handle* h, int code, const std::string& msg);
             return dsi::fail(h, DS_EHIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
     } while (0)
 
+// the fused frame kernels (one workgroup per utterance, time samples in, time samples out)
+inline bool frames_algo(int algo) { return algo == DS_ALGO_FIXED || algo == DS_ALGO_ADAPTIVE || algo == DS_ALGO_GSC || algo == DS_ALGO_ADAPTIVE_PF; }
 size_t bins_bytes(const ds_handle* h);
 size_t tail_in_bytes(const ds_handle* h);
 size_t tail_out_bytes(const ds_handle* h);

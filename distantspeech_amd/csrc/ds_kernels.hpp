@@ -26,6 +26,7 @@ KernelInfo lookup_adaptive_noryy(int nfft, int M);
 KernelInfo lookup_adaptive_ryy(int nfft, int M);
 KernelInfo lookup_adaptive_quad(int nfft, int M);   // 8 microphones, no Ryy: the per-bin program spread over quads (ds_quad.hpp); null launch = n/a
 KernelInfo lookup_gsc(int nfft, int M);
+KernelInfo lookup_adaptive_pf(int nfft, int M);   // ALGO_ADAPTIVE_PF: MVDR + McMcra gain in one pass (ds_kernels_adaptive_pf.hip)
 KernelInfo lookup_aic(int nfft, int M);     // ALGO_AIC: the SubbandGSC chain's tail (ds_kernels_aic.hip)
 KernelInfo lookup_stft(int nfft, int M, int ov = 2);      // ds_kernels_ops.hip; ov = nfft / hop: 2 or 4
 KernelInfo lookup_istft(int nfft, int M, int ov = 2);
@@ -150,6 +151,9 @@ template <class Rg, int HOIST = 0> struct HipExec {
 #endif                      // per call (profiles/r03f/wpe_gschoist_ab.txt: before the state went back inside the last hop this level spilled too and lost 13 %)
 // frame kernels whose register budget has room for the hoisted addresses at unchanged occupancy (measured per shape with
 // -Rpass-analysis=kernel-resource-usage: the GSC kernel spills, the 6- and 8-microphone kernels lose a wave per SIMD)
+#ifndef DS_PF_HOIST
+#define DS_PF_HOIST 2
+#endif
 constexpr int frames_hoist(int nfft, int M, int algo, bool ryy) {
 #if defined(DS_NO_HOIST)
     return 0;
@@ -157,16 +161,20 @@ constexpr int frames_hoist(int nfft, int M, int algo, bool ryy) {
     if (nfft <= 512 && M <= 5 && ((algo == ALGO_ADAPTIVE && !ryy) || algo == ALGO_FIXED)) return 2;      // 5 microphones: 134 -> 168 registers, still three waves
                                                                                                           // per SIMD; +3 .. 11 % with 40 hops per call (r03f/m5_hoist_ab.txt)
     if (nfft <= 512 && M <= 4 && algo == ALGO_GSC) return DS_GSC_HOIST;
+    if (nfft == 512 && M == 4 && algo == ALGO_ADAPTIVE_PF) return DS_PF_HOIST;    // 134 -> 168 registers: three waves per SIMD either way (the 256-point kernel spills 12 B at level 2)
     return 0;
 #endif
 }
 // (with Ryy — the Python mirror's objects and TFGSC — the 4-microphone program does not fit 128 registers without scratch: three waves)
-constexpr int frames_min_waves(int M, int algo, bool ryy = false) {
-    return (M <= 4 && (algo == ALGO_GSC || algo == ALGO_ADAPTIVE)) ? (ryy && M == 4 ? 3 : 4) : (M == 6 && algo == ALGO_AIC) ? 3 : 1;
+// (a 1024-point workgroup is eight waves: two per SIMD is all a CU can hold of it, whatever the register count)
+constexpr int frames_min_waves(int M, int algo, bool ryy = false, int nfft = 512) {
+    if (nfft >= 1024) return 1;
+    return (M <= 4 && (algo == ALGO_GSC || algo == ALGO_ADAPTIVE)) ? (ryy && M == 4 ? 3 : 4) : (M == 6 && algo == ALGO_AIC) ? 3
+           : (M == 4 && algo == ALGO_ADAPTIVE_PF) ? 3 : 1;
 }
 
 template <int NFFT, int M, int ALGO, bool RYY>
-__global__ void __launch_bounds__(NFFT / 2, frames_min_waves(M, ALGO, RYY)) ds_frames_kernel(Params p) {
+__global__ void __launch_bounds__(NFFT / 2, frames_min_waves(M, ALGO, RYY, NFFT)) ds_frames_kernel(Params p) {
     typedef Engine<NFFT, M, ALGO, RYY> E;
     __shared__ typename E::Sh sh;
     HipExec<typename E::Rg, frames_hoist(NFFT, M, ALGO, RYY)> ex;
@@ -217,6 +225,12 @@ template <int NFFT, int M, int ALGO, bool RYY> KernelInfo make_info() {
     X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) X(256, 8) \
     X(512, 2) X(512, 3) X(512, 4) X(512, 5) X(512, 6) X(512, 8) \
     X(1024, 2) X(1024, 3) X(1024, 4) X(1024, 5) X(1024, 6) X(1024, 8)
+// MVDR + post-filter in one thread per bin: 2 .. 6 microphones (at 8 the two programs hold 141 state floats per lane: the chain
+// DS_ALGO_WPE_MVDR runs them as two operators there)
+#define DS_FOR_EACH_SHAPE_PF(X) \
+    X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) \
+    X(512, 2) X(512, 3) X(512, 4) X(512, 5) X(512, 6) \
+    X(1024, 2) X(1024, 3) X(1024, 4) X(1024, 5)
 #endif
 
 }  // namespace ds

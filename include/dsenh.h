@@ -146,6 +146,12 @@ typedef struct ds_config {
     float rls_lambda;    /* 0 -> 0.998 forgetting factor          SubbandRLS.py:16 */
 } ds_config;
 
+#define DS_ALGO_ADAPTIVE_PF 23  /* adaptivebeamfomer.process (adaptivebeamformer.py:69-120) with the McMcra speech-presence gain of the same input frame
+                                  applied to its output, Y = w^H z * spp.G — the post-filter convention of GSC.py:225,286 (spp = McMcra,
+                                  mc_mcra.py:179-224) — in ONE fused frame kernel behind ds_process / ds_process_device: "MVDR + post-filter" in
+                                  one pass.  Methods src / DS / MVDR; parameters and fields of DS_ALGO_ADAPTIVE (track_ryy = 0) plus
+                                  DS_FIELD_PHI_YY / DS_FIELD_PHI_VV; n_mics 2..6 (6: nfft <= 512) */
+
 /* ds_set_param_* ids */
 #define DS_FDAF_PLAIN 0
 #define DS_FDAF_BM 1

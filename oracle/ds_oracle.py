@@ -29,7 +29,7 @@ __all__ = [
     "OracleFixedBeamformer", "OracleMcMcra", "OracleMcSppBase", "OracleMcCDR", "OracleMcSpp", "steering",
     "compute_mvdr_weight", "OracleOmlsaMulti", "OracleGSC",
     "OracleSubbandLMS", "OracleSubbandLmsMc", "OracleSubbandRLS", "OracleWpe", "fractional_delay_filter_bank",
-    "OracleNlms", "OracleRls", "OracleDcNotch", "OracleTimeAlignment", "OracleDelaySamples", "OracleSubbandGSC", "OracleFastFreqLms", "OracleTDGSC", "OracleFDGSC", "OracleWpeMvdrPostfilter",
+    "OracleNlms", "OracleRls", "OracleDcNotch", "OracleTimeAlignment", "OracleDelaySamples", "OracleSubbandGSC", "OracleFastFreqLms", "OracleTDGSC", "OracleFDGSC", "OracleWpeMvdrPostfilter", "OracleMvdrPostfilter",
     "synth_utterance",
 ]
 
@@ -1328,6 +1328,31 @@ class OracleWpeMvdrPostfilter:
             E = self.wpe.update_fd(Xd, D[:, t, :])
             self.spp.estimation(E)
             Y = self.mvdr.process_frame(E, angle_rad, method) * self.spp.G
+            out.append(np.atleast_1d(self.tf.istft(Y[:, None, None])))
+        return np.concatenate(out)
+
+
+class OracleMvdrPostfilter:
+    """MVDR + post-filter in one pass (BASELINE.json north_star's target workload; DS_ALGO_ADAPTIVE_PF).  No reference class composes the
+    two; the composition is GSC.process's own convention for its beamformer and `spp` (GSC.py:225,286), on the adaptive beamformer:
+      Z   = Transform.stft(x)                               transform.py:430-453
+      G   = McMcra.estimation(Z).G                          mc_mcra.py:179-224  (GSC.py:225)
+      Y   = adaptivebeamfomer frame loop on Z (MCRA-gated Rvv, src / DS / MVDR weights) * G   adaptivebeamformer.py:69-120, GSC.py:286
+      out = Transform.istft(Y)                              transform.py:455-481
+    Pinned by the G23 fixtures: the same composition driven through the reference's own objects (tests/golden/make_golden.py g23)."""
+
+    def __init__(self, mic, nfft=512, hop=None, mcra_L=15):
+        self.mvdr = OracleAdaptiveMVDR(mic, frameLen=nfft, hop=hop, nfft=nfft, mcra_L=mcra_L)
+        self.spp = OracleMcMcra(nfft=nfft, channels=mic.M)
+        self.tf = self.mvdr.transformer
+
+    def process(self, x, angle_rad, method=2):
+        """x [M, T*hop] -> y [T*hop]; T successive one-hop calls."""
+        D = self.tf.stft(np.asarray(x).T)
+        out = []
+        for t in range(D.shape[1]):
+            self.spp.estimation(D[:, t, :])
+            Y = self.mvdr.process_frame(D[:, t, :], angle_rad, method) * self.spp.G
             out.append(np.atleast_1d(self.tf.istft(Y[:, None, None])))
         return np.concatenate(out)
 

@@ -57,7 +57,7 @@ static int g_pipe = 0;       // emul_set_pipe(1): 512-point frame programs run a
 
 template <class E> int run_engine_blob(ds::Params p, int batch, int nfft);
 template <int NFFT, int M, int ALGO, bool RYY> int run_t(ds::Params p, int batch) {
-    if constexpr (NFFT == 512 && ALGO != ds::ALGO_AIC) {
+    if constexpr (NFFT == 512 && ALGO != ds::ALGO_AIC && ALGO != ds::ALGO_ADAPTIVE_PF) {
         if (g_pipe) { ++g_pipe_runs; return run_engine_blob<ds::PipeEngine<NFFT, M, ALGO, RYY>>(p, batch, NFFT); }
     }
     typedef ds::Engine<NFFT, M, ALGO, RYY> E;
@@ -102,6 +102,7 @@ template <int NFFT, int M> int run_nm(int algo, int ryy, const ds::Params& p, in
     if (algo == ds::ALGO_ADAPTIVE && ryy) return run_t<NFFT, M, ds::ALGO_ADAPTIVE, true>(p, batch);
     if (algo == ds::ALGO_GSC) return run_t<NFFT, M, ds::ALGO_GSC, false>(p, batch);
     if (algo == ds::ALGO_AIC) return run_t<NFFT, M, ds::ALGO_AIC, false>(p, batch);
+    if constexpr (M <= 6) { if (algo == ds::ALGO_ADAPTIVE_PF) return run_t<NFFT, M, ds::ALGO_ADAPTIVE_PF, false>(p, batch); }
     return -1;
 }
 
@@ -395,6 +396,7 @@ int emul_layout(int algo, int nfft, int M, int ryy, int* kp) {
     int nf = 0;
     if (algo == ds::ALGO_ADAPTIVE) nf = M * M + 5 + (ryy ? M * M : 0);
     if (algo == ds::ALGO_GSC) nf = M * (M + 1) + 2 * (M - 1);
+    if (algo == ds::ALGO_ADAPTIVE_PF) nf = M * M + 5 + M * (M + 1);
     return nf;
 }
 

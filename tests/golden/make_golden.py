@@ -839,6 +839,44 @@ def g21_wpe_wide():
              var=wpe.var, bins=kk, bins_P=kp, params=np.array([C, N, D, nb, hop]))
 
 
+def g23_mvdr_postfilter(x16):
+    """MVDR + McMcra post-filter in one pass (BASELINE.json north_star's target workload).  No reference class composes the two;
+    this drives the REFERENCE's own objects frame by frame and composes them the way GSC.process composes its beamformer with `spp`
+    (GSC.py:225 `self.spp.estimation(Z)`, GSC.py:286 `Y * self.spp.G`): the weights are adaptivebeamfomer's own `H` after its
+    process() call of the hop, the gain is McMcra's own `G` for the same input frame, analysis / synthesis are Transform's."""
+    cases = [("rec1", x16.astype(np.float32) / 32768.0, 4, 512, 256),
+             ("synth", synth(5, 4, 256 * 90), 4, 512, 256),
+             ("synth_m6", synth(7, 6, 256 * 60), 6, 512, 256),
+             ("synth_m2_256", synth(11, 2, 128 * 80), 2, 256, 128)]
+    for name, x, M, nfft, hop in cases:
+        mic = MicArray(arrayType="circular", r=0.032 if M == 4 else 0.05, M=M, n_fft=nfft)   # R2
+        ab = make_adaptive(mic, nfft, hop)                                                 # R1
+        tr_in = Transform(n_fft=nfft, hop_length=hop, channel=M)
+        tr_out = Transform(n_fft=nfft, hop_length=hop, channel=1)
+        spp = McMcra(nfft=nfft, channels=M)
+        T = x.shape[1] // hop
+        K = nfft // 2 + 1
+        ys, y_mvdr = [], []
+        G = np.zeros((T, K)); P = np.zeros((T, K))
+        with contextlib.redirect_stdout(io.StringIO()):
+            for t in range(T):                                                             # R3
+                xh = x[:, t * hop:(t + 1) * hop].astype(np.float64)
+                out = ab.process(xh, ANGLE, method=2)                                      # adaptivebeamformer.py:44-128: updates ab.H
+                y_mvdr.append(np.atleast_1d(out["data"]))
+                Z = tr_in.stft(xh.T)[:, 0, :]                                              # [K, M], the frame ab.process analysed
+                spp.estimation(Z)                                                          # GSC.py:225
+                Y = np.sum(np.conj(np.asarray(ab.H)).T * Z, axis=1) * spp.G                # adaptivebeamformer.py:119-120, GSC.py:286
+                ys.append(np.atleast_1d(tr_out.istft(Y[:, None, None])))
+                G[t], P[t] = spp.G, spp.p
+        save("g23_mvdr_pf_%s" % name,
+             "composition of reference objects, per hop: adaptivebeamfomer.process(method=2) -> H; Transform.stft -> Z; McMcra.estimation(Z) -> G; "
+             "Y = (H^H Z) G (adaptivebeamformer.py:119-120, GSC.py:225,286); Transform.istft.  R1 R2 R3; angle=197deg.  PARITY of the COMPOSITION "
+             "is defined by this script (no reference class composes them); every object in it is the reference's",
+             x=(x16 if name == "rec1" else x), y=np.concatenate(ys), y_mvdr=np.concatenate(y_mvdr), G=G[::4], p=P[::4], G_last=G[-1], p_last=P[-1],
+             Rvv=ab.Rvv, Phi_vv=np.moveaxis(spp.Phi_vv, 2, 0), Phi_yy=np.moveaxis(spp.Phi_yy, 2, 0), mcra_p=ab.mcra.p,
+             params=np.array([M, nfft, hop, 2]), r=np.array(mic.r))
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -872,6 +910,7 @@ def main():
     if want("g20"): g20_odd_m()
     if want("g21"): g21_wpe_wide()
     if want("g22"): g22_subbandgsc_postfilter(x16)
+    if want("g23"): g23_mvdr_postfilter(x16)
 
 
 if __name__ == "__main__":

@@ -60,6 +60,106 @@ def test_adaptive_vs_reference_golden(ds, name):
     assert np.array_equal(y2, y)
 
 
+MVDR_PF_CASES = ["rec1", "synth", "synth_m6", "synth_m2_256"]
+
+
+@pytest.mark.parametrize("name", MVDR_PF_CASES)
+def test_mvdr_postfilter_one_pass_vs_reference_golden(ds, name):
+    """BASELINE's target workload "MVDR + post-filter" as ONE fused frame kernel (DS_ALGO_ADAPTIVE_PF; adaptivebeamfomer(postfilter="mcmcra")):
+    against G23, the composition driven through the REFERENCE's own objects (adaptivebeamfomer -> H, McMcra -> G, Transform; GSC.py:225,286)."""
+    g = load("g23_mvdr_pf_" + name)
+    M, nfft, hop, method = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    ab = ds.adaptivebeamfomer(_mic(ds, M, nfft, float(g["r"])), frameLen=nfft, hop=hop, nfft=nfft, postfilter="mcmcra")
+    y = np.concatenate([ab.process(x[:, t * hop:(t + 1) * hop], ANGLE, method=method)["data"] for t in range(x.shape[1] // hop)])
+    dp = np.abs(ab.mcra.p - g["mcra_p"])
+    m = dict(y_rms=rms(y - g["y"]), y_ref_rms=rms(g["y"]), Rvv_relmax=relmax(ab.Rvv, g["Rvv"]),
+             Phi_vv_rel_rms=rms(ab.spp.Phi_vv - g["Phi_vv"]) / rms(g["Phi_vv"]), Phi_yy_rel_rms=rms(ab.spp.Phi_yy - g["Phi_yy"]) / rms(g["Phi_yy"]),
+             mcra_p_frac_gt_1e3=np.mean(dp > 1e-3), H_kernel_rel_rms=0.0)
+    measured("G23_mvdr_pf_" + name, **m)
+    assert m["y_rms"] < TOL_RMS and m["y_rms"] < 1e-5, m
+    assert m["Rvv_relmax"] < 7e-6 and m["Phi_yy_rel_rms"] < 1e-5 and m["Phi_vv_rel_rms"] < 3e-3 and m["mcra_p_frac_gt_1e3"] < 0.002, m
+    ab2 = ds.adaptivebeamfomer(_mic(ds, M, nfft, float(g["r"])), frameLen=nfft, hop=hop, nfft=nfft, postfilter="mcmcra")
+    assert np.array_equal(ab2.process(x, ANGLE, method=method)["data"], y)          # one call == hop by hop, bit for bit
+    with pytest.raises(Exception):
+        ab2.process(x[:, :hop], ANGLE, method=3)                                      # TFGSC needs Ryy: refused, not silently something else
+
+
+@pytest.mark.parametrize("M,nfft", [(4, 512), (2, 256), (3, 512), (5, 512), (6, 512), (6, 256), (4, 1024), (5, 1024), (3, 256)])
+def test_mvdr_postfilter_batch_vs_oracle(ds, M, nfft):
+    """every compiled shape class of ALGO_ADAPTIVE_PF: rows of a batch against the oracle's composition (pinned by G23), methods MVDR and DS,
+    checkpoint / resume in the middle of the stream."""
+    from distantspeech_amd import _lib as L
+    hop, B, T = nfft // 2, 4, 40
+    r = 0.032 if M == 4 else 0.05
+    omic = oracle_mic(M, nfft, r)
+    xs = np.stack([O.synth_utterance(40 + b, hop * T, omic) for b in range(B)])
+    a = steering(M, nfft, r)
+    for method in (2, 1):
+        eng = ds.BatchEngine(L.ALGO_ADAPTIVE_PF, M, nfft, batch=B)
+        eng.set_steering(a); eng.set_method(method)
+        y = eng.process(xs, L.LAYOUT_CHANNELS_SAMPLES)
+        for b in (0, B - 1):
+            ref = O.OracleMvdrPostfilter(omic, nfft, hop).process(xs[b], ANGLE, method)
+            assert rms(y[b] - ref) < 1e-5, (method, b, rms(y[b] - ref))
+    cut = hop * 17
+    e1 = ds.BatchEngine(L.ALGO_ADAPTIVE_PF, M, nfft, batch=B); e1.set_steering(a); e1.set_method(1)
+    y_a = e1.process(xs[:, :, :cut], 1)
+    blob = e1.export_state()
+    e2 = ds.BatchEngine(L.ALGO_ADAPTIVE_PF, M, nfft, batch=B); e2.set_steering(a); e2.set_method(1)
+    e2.import_state(blob)
+    assert np.array_equal(np.concatenate([y_a, e2.process(xs[:, :, cut:], 1)], axis=1), y)
+    plain = ds.BatchEngine(L.ALGO_ADAPTIVE, M, nfft, batch=B)
+    with pytest.raises(Exception):
+        plain.import_state(blob)                                                       # a checkpoint of another algo is refused
+
+
+def test_unsupported_postfilter_shapes_are_refused(ds):
+    from distantspeech_amd import _lib as L
+    for M, nfft in ((8, 512), (6, 1024), (7, 512)):
+        with pytest.raises(Exception):
+            ds.BatchEngine(L.ALGO_ADAPTIVE_PF, M, nfft, batch=1)
+
+
+def test_full_batch_properties_mvdr_postfilter(ds):
+    """BASELINE's batch (B = 1024, 4 microphones, 512 / 256) for the north star's target workload, MVDR + post-filter in one pass: batch
+    independence, one hop per call == one call bit for bit with the state, the gain is what separates it from the plain MVDR handle,
+    oracle rows."""
+    from distantspeech_amd import _lib as L
+    B, M, nfft, hop, T = 1024, 4, 512, 256, 24
+    omic = oracle_mic(M, nfft, 0.032)
+    base = np.stack([O.synth_utterance(100 + b, hop * T, omic) for b in range(8)]).astype(np.float32)
+    gains = np.random.default_rng(1).uniform(0.5, 1.5, size=(B, 1, 1)).astype(np.float32)
+    x = base[np.arange(B) % 8] * gains
+    a = steering(M, nfft, 0.032)
+    eng = ds.BatchEngine(L.ALGO_ADAPTIVE_PF, M, nfft, batch=B)
+    eng.set_steering(a); eng.set_method(2)
+    y = eng.process(x, 1)
+    assert np.all(np.isfinite(y))
+    idx = [0, 1, 511, 777, 1023]
+    small = ds.BatchEngine(L.ALGO_ADAPTIVE_PF, M, nfft, batch=len(idx))
+    small.set_steering(a); small.set_method(2)
+    assert np.array_equal(small.process(x[idx], 1), y[idx])
+    eng2 = ds.BatchEngine(L.ALGO_ADAPTIVE_PF, M, nfft, batch=B)
+    eng2.set_steering(a); eng2.set_method(2)
+    ys = np.concatenate([eng2.process(x[:, :, t * hop:(t + 1) * hop], 1) for t in range(T)], axis=1)
+    assert np.array_equal(ys, y)
+    assert np.array_equal(eng2.export_state(), eng.export_state())
+    # the beamformer half of the state is the plain MVDR handle's, bit for bit (same program on the same frames)
+    mv = ds.BatchEngine(L.ALGO_ADAPTIVE, M, nfft, batch=B)
+    mv.set_steering(a); mv.set_method(2)
+    y_mv = mv.process(x, 1)
+    assert np.array_equal(mv.get_field(L.FIELD_RVV), eng.get_field(L.FIELD_RVV))
+    assert np.array_equal(mv.get_field(L.FIELD_MCRA_P), eng.get_field(L.FIELD_MCRA_P))
+    assert rms(y) < rms(y_mv)                                                          # the gain is <= 1 everywhere
+    worst = 0.0
+    for b in (3, 600, 1023):
+        ref = O.OracleMvdrPostfilter(omic, nfft, hop).process(x[b], ANGLE, 2)
+        worst = max(worst, rms(y[b] - ref))
+        assert rms(y[b] - ref) < 1e-5
+    measured("mvdr_pf_B1024_rows", y_rms_worst=worst, y_rms=rms(y))
+
+
 @pytest.mark.parametrize("wt", ["DS", "SD"])
 def test_fixed_vs_reference_golden(ds, wt):
     g = load("g2b_fixed_" + wt)

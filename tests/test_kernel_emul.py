@@ -29,6 +29,36 @@ def test_emul_adaptive(name):
     assert np.mean(pdiff > 1e-3) < 0.02          # an fp32 threshold flip may move isolated bins
 
 
+@pytest.mark.parametrize("name", ["rec1", "synth", "synth_m6", "synth_m2_256"])
+def test_emul_mvdr_postfilter_one_pass(name):
+    """ALGO_ADAPTIVE_PF (MVDR + McMcra gain in one per-bin phase) against G23, the same composition run through the reference's objects."""
+    g = load("g23_mvdr_pf_" + name)
+    M, nfft, hop, method = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    e = EmulEngine(4, nfft, M, 1)
+    e.set_steering(steering(M, nfft, float(g["r"])))
+    e.method = method
+    T = x.shape[1] // hop
+    cut = hop * (T // 3)
+    y = np.concatenate([e.process(x[None, :, :cut], 1)[0], e.process(x[None, :, cut:], 1)[0]])
+    err = rms(y - g["y"])
+    assert err < 1e-5, err
+    # McMcra's Phi_vv diagonal and the MCRA p of the beamformer half
+    pv0 = M * M + 5 + M * (M + 1) // 2
+    d = np.stack([e.field(pv0 + i * M - (i * (i - 1)) // 2)[0] for i in range(M)], axis=1)
+    ref = np.einsum("kii->ki", g["Phi_vv"])
+    assert np.median(np.abs(d - ref) / (np.abs(ref) + 1e-12)) < 1e-3
+    assert np.mean(np.abs(e.field(M * M + 3)[0] - g["mcra_p"]) > 1e-3) < 0.02
+    assert e.counters[0, 0] == T and e.counters[0, 2] == T
+    # one call == hop by hop, bit for bit, with the state
+    e2 = EmulEngine(4, nfft, M, 1)
+    e2.set_steering(steering(M, nfft, float(g["r"])))
+    e2.method = method
+    n = hop * min(T, 12)
+    y2 = np.concatenate([e2.process(x[None, :, i:i + hop], 1)[0] for i in range(0, n, hop)])
+    assert np.array_equal(y2, y[:n])
+
+
 def test_emul_adaptive_chunking_and_layout():
     g = load("g4_adaptive_synth")
     x = as_float(g["x"])[:, : 256 * 30]

@@ -88,6 +88,28 @@ def test_adaptive_mvdr(golden, name):
         assert np.allclose(ab.H, g["H"], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("name", ["rec1", "synth", "synth_m6", "synth_m2_256"])
+def test_mvdr_postfilter_one_pass(golden, name):
+    """G23: MVDR + McMcra gain in one pass, composed from the reference's own objects (make_golden.py g23)."""
+    g = golden("g23_mvdr_pf_" + name)
+    M, nfft, hop, method = [int(v) for v in g["params"]]
+    x = g["x"]
+    if x.dtype == np.int16:
+        x = x.astype(np.float32) / 32768.0
+    o = O.OracleMvdrPostfilter(_mic(M, nfft, r=float(g["r"])), nfft=nfft, hop=hop)
+    y = o.process(x, ANGLE, method=method)
+    ref = g["y"]
+    assert y.shape == ref.shape
+    assert rms(y - ref) < 1e-7 * max(rms(ref), 1e-3), rms(y - ref)
+    assert np.allclose(o.mvdr.Rvv, g["Rvv"], rtol=1e-9, atol=1e-14)
+    assert np.allclose(o.spp.G, g["G_last"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(o.spp.p, g["p_last"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(o.spp.Phi_vv, g["Phi_vv"], rtol=1e-9, atol=1e-14)
+    # the un-gained beamformer output of the same run is the plain adaptive MVDR's
+    y0 = O.OracleAdaptiveMVDR(_mic(M, nfft, r=float(g["r"])), frameLen=nfft, hop=hop, nfft=nfft).process(x, ANGLE, method=method)
+    assert rms(y0 - g["y_mvdr"]) < 1e-7 * max(rms(g["y_mvdr"]), 1e-3)
+
+
 def test_adaptive_mvdr_chunk_invariance(golden):
     g = golden("g4_adaptive_synth")
     x = g["x"][:, : 256 * 40]
