@@ -169,7 +169,7 @@ void fill_params(const ds_handle* h, Params& p) {
     p.alpha_v = h->alpha_v;
     p.beta_y = ds::complement_of(h->alpha_y);
     p.beta_v = ds::complement_of(h->alpha_v);
-    p.diag = h->diag;
+    p.diag = h->diag; p.diag_floor = ds::pivot_floor(h->diag);
     p.gate = h->gate;
     p.mu = h->mu;
 }

@@ -95,7 +95,7 @@ int binop_launch(ds_handle* h, int b0, int nb, int n_frames, const float* const 
     p.x_fan = h->x_fan > 0 ? h->x_fan : 1; p.p_complement = h->p_complement; p.d_interleaved = h->d_interleaved; p.d_prev = h->d_prev;
     p.steer_batch_stride = h->steer_per_utt ? (long long)h->K * h->cfg.n_mics : 0;
     p.steer = h->steer ? h->steer + (size_t)b0 * p.steer_batch_stride : nullptr;
-    p.method = h->method; p.alpha_v = h->alpha_v; p.beta_v = ds::complement_of(h->alpha_v); p.gate = h->gate; p.diag = h->diag;
+    p.method = h->method; p.alpha_v = h->alpha_v; p.beta_v = ds::complement_of(h->alpha_v); p.gate = h->gate; p.diag = h->diag; p.diag_floor = ds::pivot_floor(h->diag);
     p.dev_cnt = h->use_dev_cnt ? h->dev_cnt + 8 * group : nullptr;
     p.tick = tick;
     DS_HIP(h, ds::launch_binop(h->op, p, stream));

@@ -275,6 +275,9 @@ struct Params {
     float alpha_y, alpha_v;   // adaptivebeamformer.py:65-66
     float beta_y, beta_v;     // 1 - alpha as the reference's doubles give it (complement_of(): 1 - 0.9998f in fp32 is off by 1.3e-4 relative)
     float diag;               // adaptivebeamformer.py:89
+    float diag_floor;         // pivot_floor(diag), formed by whoever fills diag: a kernel ARGUMENT (scalar register) — formed in the kernel it was a
+                              // loop-invariant vector register held across the whole call (and the one value the one-pass MVDR + post-filter
+                              // kernel spilled at four waves per SIMD)
     float gate;               // adaptivebeamformer.py:94
     float mu;                 // GSC.py:202
     float* ref_pow;           // GSC, optional (null = off): [B][T][K][M] float, per frame and bin |Y|^2 of the canceller output in front of the
@@ -921,7 +924,7 @@ template <int M> struct MvdrSweep {
         return mk(ut.x * inv, ut.y * inv);
     }
 };
-template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag, const cf* a, const cf* z) {
+template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag, const cf* a, const cf* z, float floor_) {
     float Ad[M];
     cf Al[M * (M - 1) / 2 + 1];          // strictly-lower A_ij (i>j) at off_index(j, i)
     cf u[M], t[M];
@@ -933,7 +936,7 @@ template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag
     cf ut = mk(0.0f, 0.0f);
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-        const float sj = pivot_max(Ad[j], pivot_floor(diag));
+        const float sj = pivot_max(Ad[j], floor_);               // floor_ = pivot_floor(diag)
 #if defined(__HIP_DEVICE_COMPILE__)
         const float r = __builtin_amdgcn_rsqf(sj);     // sj >= 1e-30: a normal number, the bare instruction (what rsqrtf() compiled to while the
                                                        // floor was a literal; against a run-time floor it grew a denormal-range rescale per pivot)
@@ -963,6 +966,9 @@ template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag
     const float inv = rcp_(nu);
     return mk(ut.x * inv, ut.y * inv);
 }
+template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag, const cf* a, const cf* z) {
+    return mvdr_output<M>(d, o, diag, a, z, pivot_floor(diag));
+}
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -988,7 +994,11 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
 #ifdef DS_ABLATE_NOSOLVE       // timing experiment only: the frame program without the Hermitian solve
         acc = cmulc(Z[0], a[0]);
 #else
+#ifdef DS_SOLVE_FP64
         acc = mvdr_output<M>(d, o, p.diag, a, Z);
+#else
+        acc = mvdr_output<M>(d, o, p.diag, a, Z, p.diag_floor);
+#endif
 #endif
     } else if (RYY) {                                          // TFGSC, beamformer.py:327-333
         Chol<M> ch;

@@ -151,8 +151,12 @@ template <class Rg, int HOIST = 0> struct HipExec {
 #endif                      // per call (profiles/r03f/wpe_gschoist_ab.txt: before the state went back inside the last hop this level spilled too and lost 13 %)
 // frame kernels whose register budget has room for the hoisted addresses at unchanged occupancy (measured per shape with
 // -Rpass-analysis=kernel-resource-usage: the GSC kernel spills, the 6- and 8-microphone kernels lose a wave per SIMD)
+#ifndef DS_PF_WAVES
+#define DS_PF_WAVES 4
+#endif
 #ifndef DS_PF_HOIST
-#define DS_PF_HOIST 2
+#define DS_PF_HOIST 0      // level 2: 168 registers, three waves per SIMD = three workgroups per CU: 1024 utterances then need a second round of workgroups (20.1 us per
+                           // hop against the plain MVDR kernel's 10.4); level 0 fits 128 registers without scratch: four per CU, the batch in one round
 #endif
 constexpr int frames_hoist(int nfft, int M, int algo, bool ryy) {
 #if defined(DS_NO_HOIST)
@@ -170,7 +174,7 @@ constexpr int frames_hoist(int nfft, int M, int algo, bool ryy) {
 constexpr int frames_min_waves(int M, int algo, bool ryy = false, int nfft = 512) {
     if (nfft >= 1024) return 1;
     return (M <= 4 && (algo == ALGO_GSC || algo == ALGO_ADAPTIVE)) ? (ryy && M == 4 ? 3 : 4) : (M == 6 && algo == ALGO_AIC) ? 3
-           : (M == 4 && algo == ALGO_ADAPTIVE_PF) ? 3 : 1;
+           : (M == 4 && algo == ALGO_ADAPTIVE_PF) ? (nfft == 512 ? DS_PF_WAVES : 3) : 1;      // (the 256-point kernel spills 20 B at four)
 }
 
 template <int NFFT, int M, int ALGO, bool RYY>

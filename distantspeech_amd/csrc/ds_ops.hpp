@@ -51,6 +51,7 @@ struct OpParams {
     long long steer_batch_stride;
     int method;               // OP_ADAPTIVE: METHOD_SRC / DS / MVDR
     float alpha_v, gate, diag;   // OP_ADAPTIVE: adaptivebeamformer.py:66,94,89
+    float diag_floor;         // OP_ADAPTIVE: pivot_floor(diag), see Params::diag_floor
     float beta_v;             // OP_ADAPTIVE: 1 - alpha_v (complement_of)
     const int* dev_cnt;       // optional device-resident {frm_cnt, ell, first_frame}: when set, the kernel takes the uniform counters from there instead
                               // of from this struct, so that a captured hipGraph of the launch stays valid as the stream advances (ds_tick_kernel
@@ -1313,7 +1314,7 @@ template <int M> DS_HD void op_adaptive(const OpCtx& p, int b, int k) {
 #pragma unroll
     for (int m = 0; m < M; ++m) a[m] = sv[m];
     Params q;
-    q.method = p.method; q.alpha_y = 0.8f; q.beta_y = (float)(1.0 - 0.8); q.alpha_v = p.alpha_v; q.beta_v = p.beta_v; q.gate = p.gate; q.diag = p.diag;
+    q.method = p.method; q.alpha_y = 0.8f; q.beta_y = (float)(1.0 - 0.8); q.alpha_v = p.alpha_v; q.beta_v = p.beta_v; q.gate = p.gate; q.diag = p.diag; q.diag_floor = p.diag_floor;
     int frm = p.frm_cnt, ell = p.ell;
     for (int t = 0; t < p.T; ++t) {
         const long long fb = ((long long)b * p.T + t) * p.K;

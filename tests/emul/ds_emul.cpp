@@ -323,7 +323,7 @@ int emul_adaptive_frames(int B, int K, int T, int M, float* st, int NF, const fl
     p.B = B; p.K = K; p.KP = ds::plane_len(K); p.T = T; p.st = planes.data(); p.NF = NF; p.in0 = Z; p.in1 = gain; p.out0 = Y; p.M = M;
     p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.has_p = gain != nullptr;
     p.steer = reinterpret_cast<const ds::cf*>(steer); p.steer_batch_stride = 0;
-    p.method = method; p.alpha_v = alpha_v; p.beta_v = ds::complement_of(alpha_v); p.gate = gate; p.diag = diag;
+    p.method = method; p.alpha_v = alpha_v; p.beta_v = ds::complement_of(alpha_v); p.gate = gate; p.diag = diag; p.diag_floor = ds::pivot_floor(diag);
     if (!ds::op_supported(ds::OP_ADAPTIVE, M)) return -1;
     for (int b = 0; b < B; ++b)
         for (int k = 0; k < K; ++k) ds::run_op(ds::OP_ADAPTIVE, p, b, k);
@@ -426,7 +426,7 @@ int emul_run(int algo, int nfft, int M, int ryy, int batch, const float* x, int 
     p.steer_batch_stride = steer_per_utt ? (long long)K * M : 0;
     p.method = method;
     p.mcra_L = mcra_L;
-    p.alpha_y = alpha_y; p.alpha_v = alpha_v; p.beta_y = ds::complement_of(alpha_y); p.beta_v = ds::complement_of(alpha_v); p.diag = diag; p.gate = gate; p.mu = mu;
+    p.alpha_y = alpha_y; p.alpha_v = alpha_v; p.beta_y = ds::complement_of(alpha_y); p.beta_v = ds::complement_of(alpha_v); p.diag = diag; p.diag_floor = ds::pivot_floor(diag); p.gate = gate; p.mu = mu;
     p.ref_pow = g_ref_pow;
     switch (nfft) {
         case 256: return run_n<256>(M, algo, ryy, p, batch);
