@@ -486,7 +486,7 @@ def compact_roofline(r):
 def compact_line(out, detail_path):
     """the ONE line the driver parses: contract keys + numeric roofline objects + per other config {value, ms_per_step, bound, frac}"""
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                                "dtype", "data", "rounds", "timed_steps", "region_ms") if k in out}
+                                "dtype", "data", "rounds", "timed_steps", "region_ms", "collective") if k in out}
     line["config"] = out["config"]
     line["roofline"] = compact_roofline(out["roofline"])
     if "valu" in out:
@@ -686,6 +686,7 @@ def main():
             "n_gpus": res["ranks"], "steps": K, "warmup": W, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak" if not args.total_batch else "strong", "vs_baseline": None, "dtype": "f32", "data": be.name,
             "rounds": res["rounds"], "timed_steps": res["timed_steps"], "region_ms": res["region_ms"],
+            "collective": dsdist.collective_name(),       # what the barrier and the final reduce ran over: "nccl" (= RCCL), "gloo", or "none" (one process)
             "config": {"workload": "%s: %s, batch=%d per GPU, %d hop(s) per call (%s)"
                                    % (("BASELINE " + args.config) if args.config.startswith("cfg") else args.config, w["desc"], B, T, regime),
                        "batch_per_gpu": B, "hops_per_call": T, "n_mics": w["M"], "nfft": w["nfft"], "hop": w["hop"],

@@ -290,7 +290,7 @@ class GSC(_AdaptiveBase):
     def process(self, x, angle, method=2, retH=False, retWNG=False, retDI=False):
         """x [M, samples] (or [B, M, samples]); angle in radians; method 0 passes channel 0 through."""
         out = self._run(x, angle, method, retH, retWNG, retDI)
-        if self._track_omlsa_multi and method != 0:                         # GSC.py:242-243: method 0 leaves the frame before :281
+        if self._track_omlsa_multi and method != 0 and np.shape(x)[-1] >= self.hop:      # GSC.py:242-243: method 0 leaves the frame before :281; an empty block ran no frame
             pw = self._eng.get_field(L.FIELD_REF_POWERS)                    # [B, T, K, M]: |Y|^2, |U_1|^2 .. |U_{M-1}|^2
             self.omlsa_multi.estimation_frames(pw[..., 0], pw[..., 1:])
         return out

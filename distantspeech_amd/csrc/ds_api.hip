@@ -199,6 +199,9 @@ static void advance_host_counters_keep_first(ds_handle* h, int frames, int L) {
 
 }  // namespace dsi
 
+#ifndef DS_ARCH
+#define DS_ARCH gfx950
+#endif
 #define DS_STR2(x) #x
 #define DS_STR(x) DS_STR2(x)
 
@@ -208,9 +211,9 @@ int ds_version(void) { return DS_VERSION; }
 
 const char* ds_build_info(void) {
 #if defined(DS_WITH_SHELVED)
-    return "libdsenh version=" DS_STR(DS_VERSION) " state_layout=" DS_STR(DS_STATE_LAYOUT) " arch=gfx950 shelved=1";
+    return "libdsenh version=" DS_STR(DS_VERSION) " state_layout=" DS_STR(DS_STATE_LAYOUT) " arch=" DS_STR(DS_ARCH) " shelved=1";
 #else
-    return "libdsenh version=" DS_STR(DS_VERSION) " state_layout=" DS_STR(DS_STATE_LAYOUT) " arch=gfx950 shelved=0";
+    return "libdsenh version=" DS_STR(DS_VERSION) " state_layout=" DS_STR(DS_STATE_LAYOUT) " arch=" DS_STR(DS_ARCH) " shelved=0";
 #endif
 }
 
@@ -419,7 +422,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->diag = cfg->diag > 0 ? cfg->diag : 1e-6f;
     h->gate = cfg->gate > 0 ? cfg->gate : 0.4f;
     h->mu = cfg->mu > 0 ? cfg->mu : 0.01f;
-    h->ref_powers = false; h->ref_pow = nullptr; h->ref_pow_cap = 0; h->ref_pow_T = 0;
+    h->ref_powers = false; h->ref_pow = nullptr; h->ref_pow_cap = 0; h->ref_pow_T = 0; h->ref_pow_stream = nullptr;
     if (cfg->device >= 0) h->device = cfg->device;
     else if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
     h->stream = nullptr; h->ev0 = nullptr; h->ev1 = nullptr;
@@ -782,7 +785,7 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
         return fail(h, DS_EINVAL, "ds_process_device: unknown layout");
     if (((uintptr_t)x_dev & 15) || ((uintptr_t)y_dev & 15) || (x_batch_stride & 3) || (x_chan_stride & 3))
         return fail(h, DS_EINVAL, "ds_process_device: device buffers must be 16-byte aligned");
-    if (n_samples == 0 || count == 0) return DS_OK;
+    if (n_samples == 0 || count == 0) { if (h->ref_powers) h->ref_pow_T = 0; return DS_OK; }      // (no hop ran: no powers of a 'last call' to read)
     int rc = set_device(h);
     if (rc) return rc;
     Params p;
@@ -811,6 +814,7 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
         if (count != h->cfg.batch) DS_HIP(h, hipMemsetAsync(h->ref_pow, 0, need * sizeof(float), s));   // utterances outside the range read as zeros
         p.ref_pow = h->ref_pow;
         h->ref_pow_T = p.T;
+        h->ref_pow_stream = s;                              // ds_get_state(DS_FIELD_REF_POWERS) waits for THIS stream (a caller's, possibly)
     }
     // calls of several hops: the hop-pipelined kernel (same results bit for bit; at one or two hops per call it has nothing to overlap)
     const ds::launch_fn launch = (h->ki.launch_pipe && p.T >= h->pipe_min_T && !h->ref_powers) ? h->ki.launch_pipe : h->ki.launch;
@@ -984,7 +988,7 @@ int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y
     if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_process: NULL argument");
     if (n_samples < 0 || n_samples % h->cfg.hop != 0)
         return fail(h, DS_ESHAPE, "ds_process: n_samples must be a multiple of hop");
-    if (n_samples == 0) return DS_OK;
+    if (n_samples == 0) { if (h->ref_powers) h->ref_pow_T = 0; return DS_OK; }
     int rc = set_device(h);
     if (rc) return rc;
     const size_t B = (size_t)h->cfg.batch, M = (size_t)h->cfg.n_mics;
@@ -1108,7 +1112,11 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
         return DS_OK;
     }
     if (field == DS_FIELD_NOTCH_MEM) { DS_HIP(h, hipMemcpy(dst, h->td_mem, need, hipMemcpyDeviceToHost)); return DS_OK; }
-    if (field == DS_FIELD_REF_POWERS) { DS_HIP(h, hipMemcpy(dst, h->ref_pow, need, hipMemcpyDeviceToHost)); return DS_OK; }
+    if (field == DS_FIELD_REF_POWERS) {
+        if (h->ref_pow_stream && h->ref_pow_stream != h->stream) DS_HIP(h, hipStreamSynchronize(h->ref_pow_stream));   // the launch that wrote them
+        DS_HIP(h, hipMemcpy(dst, h->ref_pow, need, hipMemcpyDeviceToHost));
+        return DS_OK;
+    }
     if (field == DS_FIELD_OP_STATE) {
         DS_HIP(h, hipMemcpy(dst, h->tdf_w ? (const void*)h->tdf_w : (const void*)h->opst, need, hipMemcpyDeviceToHost));
         return DS_OK;

@@ -122,7 +122,8 @@ struct ds_handle {
     bool ref_powers;            // DS_PARAM_REF_POWERS (DS_ALGO_GSC): the frame kernel also writes Params::ref_pow ...
     float* ref_pow;             // ... [B][ref_pow_T][K][M] of the last call (grown on demand)
     size_t ref_pow_cap;         // floats allocated
-    int ref_pow_T;              // hops of the last call (0: none yet)
+    int ref_pow_T;              // hops of the last call (0: none yet, or the last call had no hop)
+    hipStream_t ref_pow_stream; // the stream that call's kernel ran on
     std::string err;
 };
 

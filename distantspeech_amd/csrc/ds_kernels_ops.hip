@@ -91,14 +91,14 @@ template <int NFFT> hipError_t launch_istft_rows(const Params& p0, int rows, hip
 }
 KernelInfo lookup_stft_rows(int nfft) {
     KernelInfo ki = {nullptr, 0, 0, 0};
-    if (nfft == 512) ki = KernelInfo{&launch_stft_rows<512>, 0, (512 / 2 + 4) & ~3, 256};
-    if (nfft == 1024) ki = KernelInfo{&launch_stft_rows<1024>, 0, (1024 / 2 + 4) & ~3, 256};
+    if (nfft == 512) ki = KernelInfo{&launch_stft_rows<512>, 0, plane_len(512 / 2 + 1), 256};
+    if (nfft == 1024) ki = KernelInfo{&launch_stft_rows<1024>, 0, plane_len(1024 / 2 + 1), 256};
     return ki;
 }
 KernelInfo lookup_istft_rows(int nfft) {
     KernelInfo ki = {nullptr, 0, 0, 0};
-    if (nfft == 512) ki = KernelInfo{&launch_istft_rows<512>, 0, (512 / 2 + 4) & ~3, 256};
-    if (nfft == 1024) ki = KernelInfo{&launch_istft_rows<1024>, 0, (1024 / 2 + 4) & ~3, 256};
+    if (nfft == 512) ki = KernelInfo{&launch_istft_rows<512>, 0, plane_len(512 / 2 + 1), 256};
+    if (nfft == 1024) ki = KernelInfo{&launch_istft_rows<1024>, 0, plane_len(1024 / 2 + 1), 256};
     return ki;
 }
 
@@ -108,14 +108,14 @@ KernelInfo lookup_istft_rows(int nfft) {
     X(1024, 1) X(1024, 2) X(1024, 3) X(1024, 4) X(1024, 5) X(1024, 6) X(1024, 7) X(1024, 8)
 
 KernelInfo lookup_stft(int nfft, int M, int ov) {
-#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {ov == 4 ? &launch_stft<NFFT_, M_, 4> : &launch_stft<NFFT_, M_, 2>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
+#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {ov == 4 ? &launch_stft<NFFT_, M_, 4> : &launch_stft<NFFT_, M_, 2>, 0, plane_len(NFFT_ / 2 + 1), NFFT_ / 2}; return ki; }
     DS_FOR_EACH_TSHAPE(X)
 #undef X
     KernelInfo none = {nullptr, 0, 0, 0};
     return none;
 }
 KernelInfo lookup_stft_cdr(int nfft, int M) {
-#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {&launch_stft_cdr<NFFT_, M_>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
+#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {&launch_stft_cdr<NFFT_, M_>, 0, plane_len(NFFT_ / 2 + 1), NFFT_ / 2}; return ki; }
     X(256, 4) X(256, 6) X(256, 8) X(512, 4) X(512, 6) X(512, 8) X(1024, 4) X(1024, 6) X(1024, 8)
 #undef X
     KernelInfo none = {nullptr, 0, 0, 0};
@@ -125,7 +125,7 @@ KernelInfo lookup_stft_cdr(int nfft, int M) {
 KernelInfo lookup_front(int nfft, int M, int L) {
 #if defined(DS_WITH_SHELVED)
 #define X(NFFT_, M_) if (nfft == NFFT_ && M == M_ && StftEngine<NFFT_, M_, true, 2, true>::front_fits(L)) { \
-        KernelInfo ki = {&launch_front<NFFT_, M_>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
+        KernelInfo ki = {&launch_front<NFFT_, M_>, 0, plane_len(NFFT_ / 2 + 1), NFFT_ / 2}; return ki; }
     X(512, 4) X(512, 6) X(1024, 4) X(1024, 6)
 #undef X
 #endif
@@ -133,7 +133,7 @@ KernelInfo lookup_front(int nfft, int M, int L) {
     return none;
 }
 KernelInfo lookup_istft(int nfft, int M, int ov) {
-#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {ov == 4 ? &launch_istft<NFFT_, M_, 4> : &launch_istft<NFFT_, M_, 2>, 0, (NFFT_ / 2 + 4) & ~3, NFFT_ / 2}; return ki; }
+#define X(NFFT_, M_) if (nfft == NFFT_ && M == M_) { KernelInfo ki = {ov == 4 ? &launch_istft<NFFT_, M_, 4> : &launch_istft<NFFT_, M_, 2>, 0, plane_len(NFFT_ / 2 + 1), NFFT_ / 2}; return ki; }
     DS_FOR_EACH_TSHAPE(X)
 #undef X
     KernelInfo none = {nullptr, 0, 0, 0};

@@ -155,6 +155,9 @@ __device__ inline void st_load4(const OpCtx& p, int b, int q, int k, float* d) {
 // between a store of more than 8 bytes and a vector write to its data registers, the leading one the five between a vector write to an
 // SGPR (v_readfirstlane) and a memory instruction that reads it: hazards the compiler cannot see into an asm statement for.
 // -DDS_OPSTATE_STORE4_BUILTIN: the four dword stores again (A/B)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(DS_OPSTATE_STORE4_BUILTIN) && !defined(DS_OLD_OPSTATE)
+#error "st_store4 is hand-written gfx950 ISA with hand-counted wait states: this library builds for gfx950 only (make ARCH=gfx950)"
+#endif
 __device__ inline void st_store4(const OpCtx& p, int b, int q, int k, const float* s) {
 #if defined(DS_OPSTATE_STORE4_BUILTIN) || defined(DS_OLD_OPSTATE)
 #pragma unroll

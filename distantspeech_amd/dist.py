@@ -21,7 +21,8 @@ def shard_range(total, rank, world):
 def init(backend=None):
     """Select this rank's GPU, then init torch.distributed from the environment when WORLD_SIZE > 1.
     Returns (rank, local_rank, world).  Env overrides for single-GPU testing: DS_DIST_BACKEND (e.g. gloo),
-    DS_FORCE_DEVICE (ordinal every rank should use)."""
+    DS_FORCE_DEVICE (ordinal every rank should use), DS_DIST_FORCE=1 (form the process group even at WORLD_SIZE = 1, so that
+    the collective path — RCCL with backend "nccl": device tensors, barrier(device_ids) — runs on a one-GPU box)."""
     rank, local_rank, world = env_world()
     dev = int(os.environ.get("DS_FORCE_DEVICE", local_rank))
     try:
@@ -30,7 +31,7 @@ def init(backend=None):
             torch.cuda.set_device(dev)          # before the process group exists: RCCL binds to the current device
     except ImportError:
         torch = None
-    if world > 1:
+    if world > 1 or os.environ.get("DS_DIST_FORCE") == "1":
         import torch.distributed as dist
         if not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -49,6 +50,12 @@ def barrier():
             dist.barrier(device_ids=[torch.cuda.current_device()])
         else:
             dist.barrier()
+
+
+def collective_name():
+    """backend of the process group the reductions run over ("nccl" = RCCL, "gloo"), or "none" (single process, no group)"""
+    dist = _group()
+    return dist.get_backend() if dist is not None else "none"
 
 
 def _group():

@@ -544,6 +544,28 @@ class SubbandRLS(_SubbandBase):
         return self._sq(np.transpose(P, (0, 3, 1, 2)))                      # [half_band, N, N]
 
 
+class _LiveArray(object):
+    """What the reference hands back as `self.W`: an alias of the object's live state, not a snapshot (awpe.py:192 returns the array the
+    next update() mutates in place).  Here the state lives in HBM, so the alias reads it when it is LOOKED AT (np.asarray, indexing, any
+    ndarray attribute) — update() itself moves nothing device-to-host (the prediction filters of a 4 x 20 Wpe are 3.8 MB per utterance)."""
+
+    def __init__(self, fetch):
+        self._fetch = fetch
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._fetch()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __getitem__(self, i):
+        return self._fetch()[i]
+
+    def __len__(self):
+        return len(self._fetch())
+
+    def __getattr__(self, name):
+        return getattr(self._fetch(), name)
+
+
 class Wpe(_SubbandBase):
     """RLS-based online WPE dereverberation — dereverberation/awpe.py:28-192.
 
@@ -572,7 +594,7 @@ class Wpe(_SubbandBase):
         if x.shape[1] % self.hop_length != 0 or x.shape[2] != self.channels:
             raise ValueError("Wpe.update takes [k * hop (%d), channels (%d)] samples per call" % (self.hop_length, self.channels))
         y = self._eng.process(x, L.LAYOUT_SAMPLES_CHANNELS)
-        return self._sq(y.astype(np.float64)), self.W
+        return self._sq(y.astype(np.float64)), _LiveArray(lambda: self.W)
 
     def _blocks(self):
         """per-bin state blocks [B, K, words] complex (wpe_block_layout(): the upper triangle of P by columns, P[i][q] (i <= q) at

@@ -159,8 +159,7 @@ class SubbandGSC(object):
         reference analyses the block's output (transform_fbf, a streaming analysis) and the WHOLE bm_output array of the call as filled so
         far (transform_bm: blocks behind n are still zero, and the transform's carried overlap becomes the array's last block every time),
         takes frame 0 of that, and hands the two powers to NsOmlsaMulti.estimation — which reads the first M - 1 of the M blocking outputs.
-        Reproduced with the native Transform and NsOmlsaMulti operators, block by block like the reference (one block per call, the
-        realtime contract, is one analysis of each; a call of T blocks is T analyses of T frames).  y [B, L], bm [B, M, L] float32."""
+        Reproduced with the native Transform and NsOmlsaMulti operators, block by block like the reference.  y [B, L], bm [B, M, L] float32."""
         from .ops import NsOmlsaMulti, Transform
         if not hasattr(self, "omlsa_multi"):
             dev = self._device
@@ -170,11 +169,17 @@ class SubbandGSC(object):
         FL, B = self.frameLen, self.batch
         T = y.shape[1] // FL
         bm_t = np.ascontiguousarray(np.swapaxes(bm, 1, 2))                 # [B, L, M]
-        so_far = np.zeros_like(bm_t)
+        # Frame 0 of the reference's whole-array analysis depends on the carried overlap and the array's FIRST block only, and the overlap it
+        # leaves behind is the array's LAST block as filled so far (zeros until the final iteration): two one-block analyses per iteration
+        # instead of one of the whole array — O(T) work per call where the literal restatement was O(T^2), same numbers bit for bit
+        first = np.ascontiguousarray(bm_t[:, :FL])
+        last_filled = np.ascontiguousarray(bm_t[:, (T - 1) * FL:])
+        zeros = np.zeros_like(first)
         for n in range(T):
-            so_far[:, n * FL:(n + 1) * FL] = bm_t[:, n * FL:(n + 1) * FL]
             Y = self.transform_fbf._eng.stft(np.ascontiguousarray(y[:, n * FL:(n + 1) * FL, None]), L.LAYOUT_SAMPLES_CHANNELS)   # [B, 1, K, 1]
-            U = self.transform_bm._eng.stft(so_far, L.LAYOUT_SAMPLES_CHANNELS)                                                   # [B, T, K, M]
+            U = self.transform_bm._eng.stft(first, L.LAYOUT_SAMPLES_CHANNELS)                                                    # [B, 1, K, M]
+            if T > 1:                                                       # the carried overlap := the array's last block (T = 1: it already is)
+                self.transform_bm._eng.stft(last_filled if n == T - 1 else zeros, L.LAYOUT_SAMPLES_CHANNELS)
             yp = (Y[:, :1, :, 0].real.astype(np.float64) ** 2 + Y[:, :1, :, 0].imag.astype(np.float64) ** 2)
             up = (U[:, :1, :, : self.M - 1].real.astype(np.float64) ** 2 + U[:, :1, :, : self.M - 1].imag.astype(np.float64) ** 2)
             self.omlsa_multi.estimation_frames(yp, up)

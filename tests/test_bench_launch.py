@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_bench(args, env_extra=None, timeout=300):
     env = dict(os.environ, DS_BENCH_BACKEND="tests.bench_stub:StubBackend", PYTHONPATH=ROOT, DS_BENCH_DETAIL=os.devnull)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DS_DIST_FORCE", "DS_DIST_BACKEND"):
         env.pop(k, None)
     env.update(env_extra or {})
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
@@ -32,7 +32,8 @@ def test_self_launch_two_ranks(tmp_path):
     frames = 2 * 1024 * 20 * R
     assert abs(out["value"] - frames / (out["region_ms"] * 1e-3)) / out["value"] < 1e-3
     assert abs(out["ms_per_step"] - out["region_ms"] / (20 * R)) < 1e-3
-    assert set(out["other_configs"]) >= {"cfg3", "cfg4", "cfg5", "cfg2_10s_chunks", "cfg3_10s_chunks", "cfg4_10s_chunks", "cfg5_10s_chunks"}
+    assert out["collective"] == "gloo"
+    assert set(out["other_configs"]) >= {"mvdr_pf", "mvdr_pf_10s_chunks", "cfg3", "cfg4", "cfg5", "cfg2_10s_chunks", "cfg3_10s_chunks", "cfg4_10s_chunks", "cfg5_10s_chunks"}
     assert all(set(v) >= {"value", "ms_per_step", "bound", "frac"} for v in out["other_configs"].values())
     assert out["roofline"]["bound"] == "hbm" and out["roofline_hbm"]["batch_per_gpu"] == 16384
     # the driver keeps an 8 KB tail of stdout: the line must fit with room to spare (round 3's 20.7 KB line came back parsed = null),
@@ -52,7 +53,19 @@ def test_single_rank_default_path(tmp_path):
     r = run_bench(["--steps", "10", "--warmup", "2", "--min-region-ms", "10", "--no-extras"], {"DS_BENCH_DETAIL": str(tmp_path / "d.json")})
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert out["n_gpus"] == 1 and "other_configs" not in out and "cpu_baseline" not in out
+    assert out["n_gpus"] == 1 and "other_configs" not in out and "cpu_baseline" not in out and out["collective"] == "none"
+
+
+def test_forced_process_group_at_world_size_one(tmp_path):
+    # DS_DIST_FORCE=1: the collective path with ONE rank (what tests/test_gpu_bench.py runs over RCCL on a one-GPU box), here over gloo
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = run_bench(["--gpus", "1", "--steps", "6", "--warmup", "2", "--min-region-ms", "10", "--no-extras"],
+                  {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "DS_DIST_FORCE": "1",
+                   "DS_DIST_BACKEND": "gloo", "DS_BENCH_DETAIL": str(tmp_path / "d.json")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["collective"] == "gloo"
 
 
 def test_rank_count_mismatch_is_an_error():

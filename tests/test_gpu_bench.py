@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(args, tmp_path, extra_env=None):
+def run_bench(args, tmp_path, extra_env=None, drop=()):
     env = dict(os.environ, DS_FORCE_DEVICE="0", DS_DIST_BACKEND="gloo", DS_BENCH_DETAIL=str(tmp_path / "detail.json"), PYTHONPATH=ROOT)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DS_BENCH_BACKEND"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DS_BENCH_BACKEND", "DS_DIST_FORCE") + tuple(drop):
         env.pop(k, None)
     env.update(extra_env or {})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=900)
@@ -27,7 +27,7 @@ def run_bench(args, tmp_path, extra_env=None):
 
 def test_two_ranks_share_one_gpu_weak_scaling(tmp_path):
     out, det = run_bench(["--gpus", "2", "--steps", "5", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--min-region-ms", "20"], tmp_path)
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["data"] == "synthetic"
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["data"] == "synthetic" and out["collective"] == "gloo"
     assert "share GPU 0" in out["config"]["note"]
     assert out["config"]["batch_per_gpu"] == 1024
     frames = 2 * 1024 * out["timed_steps"]                            # both ranks' frames over the slower rank's region
@@ -43,3 +43,19 @@ def test_two_ranks_shard_one_job_strong_scaling(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["total_batch"] == 96 and out["config"]["batch_per_gpu"] == 48
     frames = 96 * out["timed_steps"]
     assert abs(out["value"] - frames / (out["region_ms"] * 1e-3)) / out["value"] < 1e-3
+
+
+def test_rccl_branch_runs_at_world_size_one(tmp_path):
+    """dist.py's RCCL branch (backend "nccl": set_device before init_process_group, device-tensor all_reduce, barrier(device_ids)) on the one
+    GPU there is: bench.py as the single rank of a torchrun-style environment with the process group forced into existence (DS_DIST_FORCE=1).
+    The line names the collective it ran over."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               DS_DIST_FORCE="1", DS_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out, det = run_bench(["--gpus", "1", "--steps", "5", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--min-region-ms", "20"], tmp_path,
+                         extra_env=env, drop=("DS_FORCE_DEVICE",))
+    assert out["collective"] == "nccl" and out["n_gpus"] == 1
+    frames = 1024 * out["timed_steps"]
+    assert abs(out["value"] - frames / (out["region_ms"] * 1e-3)) / out["value"] < 1e-3
+    assert out["roofline"]["bound"] == "hbm" and 0.0 < out["roofline"]["frac"] < 1.0

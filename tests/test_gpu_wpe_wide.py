@@ -42,10 +42,11 @@ def test_wpe_wide_against_the_patched_reference(ds, name):
     T = x.shape[0] // hop
     ys, W_mid = [], None
     for n in range(T):
-        y, _ = wpe.update(x[n * hop:(n + 1) * hop])
+        y, W_ret = wpe.update(x[n * hop:(n + 1) * hop])
         ys.append(y)
         if n == T // 2 - 1:
             W_mid = wpe.W[::8]
+            assert np.array_equal(np.asarray(W_ret)[::8], W_mid) and W_ret.shape == wpe.W.shape      # the returned W: a live alias, read on access
     y = np.concatenate(ys)
     kk, kp = g["bins"], g["bins_P"]
     W, P = wpe.W, wpe.P
