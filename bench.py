@@ -57,6 +57,15 @@ WORKLOADS = {
     "mvdr_pf": dict(algo="ADAPTIVE_PF", M=4, nfft=512, hop=256, batch=1024, S=4096 + 1024 + 257 * 16 * 8 + 5 * 257 * 4 + 2 * 16 * 257 * 4, r=0.032,
                     kernel="ds_frames_kernel<512,4,ADAPTIVE_PF>", launches=1, graph=1,
                     desc="adaptive MVDR + McMcra post-filter gain in one pass (adaptivebeamfomer.process method=2, * spp.G), 4 mics, 16 kHz, 512-FFT/256-hop"),
+    # the only maintained MVDR usage of the reference (example/mvdr.ipynb cell 4, the flow its published PESQ 2.26 was obtained with, 6 microphones):
+    # Transform.stft -> McSpp.estimation -> steering(Phi_xx) -> compute_mvdr_weight(steer, Phi_vv_inv) -> w^H y -> Transform.istft as ONE handle
+    # (DS_ALGO_MCSPP_MVDR).  S = tails (M + 1) * 256 * 4 + 257 * (Phi_yy, Phi_vv complex M x M: 2 * M * M * 8 + McCDR / MCRA / xi, gamma, p rows 12 * 4)
+    "nb_mvdr": dict(algo="MCSPP_MVDR", M=6, nfft=512, hop=256, batch=1024, S=7 * 256 * 4 + 257 * (2 * 36 * 8 + 48), r=0.05,
+                    kernel="DS_ALGO_MCSPP_MVDR chain: ds_binop_kernel<MCSPP,6> (+ analysis, McCDR, synthesis)", launches=4, graph=1,
+                    desc="online MVDR of mvdr.ipynb cell 4 (McSpp + steering + MVDR weights per frame), 6 mics, 16 kHz, 512-FFT/256-hop"),
+    "nb_mvdr_m4": dict(algo="MCSPP_MVDR", M=4, nfft=512, hop=256, batch=1024, S=5 * 256 * 4 + 257 * (2 * 16 * 8 + 48), r=0.032,
+                       kernel="DS_ALGO_MCSPP_MVDR chain: ds_binop_kernel<MCSPP,4> (+ analysis, McCDR, synthesis)", launches=4, graph=1,
+                       desc="online MVDR of mvdr.ipynb cell 4 (McSpp + steering + MVDR weights per frame), 4 mics, 16 kHz, 512-FFT/256-hop"),
     # cfg1 on the GPU (stateless apart from the tails)
     "fixed": dict(algo="FIXED", M=4, nfft=512, hop=256, batch=1024, S=5120, r=0.032,
                   kernel="ds_frames_kernel<512,4,FIXED>", launches=1, graph=1,
@@ -91,8 +100,8 @@ WORKLOADS = {
 }
 
 
-EXTRA_T1 = ("mvdr_pf", "cfg3", "cfg4", "cfg5", "wpe_nb")                                                  # other_configs at one hop per call
-EXTRA_CHUNKED = (("cfg2", 625), ("mvdr_pf", 625), ("cfg3", 625), ("cfg4", 312), ("cfg5", 625), ("wpe_nb", 2500))         # ... and with 10 s per call
+EXTRA_T1 = ("mvdr_pf", "cfg3", "cfg4", "cfg5", "wpe_nb", "nb_mvdr", "nb_mvdr_m4")                                                  # other_configs at one hop per call
+EXTRA_CHUNKED = (("cfg2", 625), ("mvdr_pf", 625), ("cfg3", 625), ("cfg4", 312), ("cfg5", 625), ("wpe_nb", 2500), ("nb_mvdr", 625))         # ... and with 10 s per call
 DATA_NOTE = ("BASELINE.md section 3's recipe in both legs (white noise sigma 0.05 per microphone + a 0.5 s on / off 300-3400 Hz Gaussian source sigma "
              "0.1 steered from 197 degrees, seed 1234 + utterance): the GPU leg draws it on the device with torch's generator (GpuBackend.synth), the "
              "cpu_baseline legs with NumPy's (oracle.synth_utterance) — the same statistics, different random streams; neither leg's arithmetic per "
@@ -288,6 +297,9 @@ class GpuWorkload:
         ang = np.array(ANGLE_DEG) / 180.0 * np.pi
         if w["algo"] == "WPE_TD":
             self.eng.set_wpe_delay(4)                                                       # awpe.py:36 / wpe.ipynb cell 2: delay=4
+        elif w["algo"] == "MCSPP_MVDR":
+            from distantspeech_amd.ops import McSpp
+            self.eng.chain_set_aux(L.CHAIN_AUX_COHERENCE, McSpp.diffuse_coherence(M, nfft))
         elif w["algo"] in ("SUBBAND_GSC", "TDGSC", "FDGSC"):
             from distantspeech_amd.ops import McSpp
             from distantspeech_amd.subband_gsc import fractional_delay_filter_bank
@@ -679,7 +691,7 @@ def main():
     out = None
     if rank == 0:
         regime = "streaming callback regime" if T == 1 else "chunked"
-        mics = {"cfg2": "4-mic, 512-FFT", "cfg3": "4-mic, 512-FFT", "fixed": "4-mic, 512-FFT", "cfg4": "8-mic, 1024-FFT", "cfg5": "6-mic, 512 bands", "wpe_nb": "4-ch WPE, 256 bands", "cfg4_n10": "8-mic, 1024-FFT, 10-tap WPE", "mvdr_pf": "4-mic, 512-FFT, MVDR + post-filter",
+        mics = {"cfg2": "4-mic, 512-FFT", "cfg3": "4-mic, 512-FFT", "fixed": "4-mic, 512-FFT", "cfg4": "8-mic, 1024-FFT", "cfg5": "6-mic, 512 bands", "wpe_nb": "4-ch WPE, 256 bands", "cfg4_n10": "8-mic, 1024-FFT, 10-tap WPE", "mvdr_pf": "4-mic, 512-FFT, MVDR + post-filter", "nb_mvdr": "6-mic, 512-FFT, notebook online MVDR", "nb_mvdr_m4": "4-mic, 512-FFT, notebook online MVDR",
                 "tdgsc": "4-mic, block 256", "fdgsc": "4-mic, block 256"}[args.config]
         out = {
             "metric": "enhanced frames/sec (%s)" % mics, "value": res["value"], "unit": "frames/s",

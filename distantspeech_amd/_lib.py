@@ -24,6 +24,7 @@ ALGO_TDGSC = 20
 ALGO_FDGSC = 21
 ALGO_WPE_TD = 22
 ALGO_ADAPTIVE_PF = 23
+ALGO_MCSPP_MVDR = 24
 PARAM_POSTFILTER = 15
 PARAM_TAIL_ASYNC = 17
 PARAM_REF_POWERS = 18
@@ -70,7 +71,7 @@ EXPORTS = [
     "ds_version", "ds_build_info", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
     "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_set_window", "ds_process", "ds_process_pcm16", "ds_process_device",
     "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcra_estimate_p", "ds_mcmcra_estimate", "ds_mcsppbase_estimate", "ds_set_aux", "ds_mcspp_estimate", "ds_steering",
-    "ds_mvdr_weight", "ds_pmwf_weight", "ds_gev_vector", "ds_blind_analytic_normalization", "ds_phase_correction", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process", "ds_tdgsc_process", "ds_fdgsc_process",
+    "ds_mvdr_weight", "ds_pmwf_weight", "ds_gev_vector", "ds_blind_analytic_normalization", "ds_phase_correction", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process", "ds_tdgsc_process", "ds_fdgsc_process", "ds_mcspp_mvdr_process",
     "ds_omlsa_estimate", "ds_omlsa_postfilter",
     "ds_sublms_update", "ds_subrls_update", "ds_wpe_update", "ds_synchronize",
     "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_state_payload_bytes", "ds_chain_stage_info", "ds_chain_stage_field_bytes", "ds_chain_stage_state", "ds_export_state",
@@ -170,6 +171,8 @@ def load():
     lib.ds_tdfilter_update.argtypes = [vp, vp, vp, ci, cf_, vp, ci]
     lib.ds_chain_set_aux.restype = ci
     lib.ds_chain_set_aux.argtypes = [vp, ci, vp, csz]
+    lib.ds_mcspp_mvdr_process.restype = ci
+    lib.ds_mcspp_mvdr_process.argtypes = [vp, vp, ci, ci, vp, vp, ci]
     lib.ds_subband_gsc_process.restype = ci
     lib.ds_subband_gsc_process.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, ci]
     lib.ds_set_window.restype = ci

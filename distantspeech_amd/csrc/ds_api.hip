@@ -317,6 +317,10 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             if (cfg->n_mics >= 2 && cfg->n_mics <= 8 && cfg->hop * 2 == cfg->nfft &&
                 (cfg->nfft == 128 || cfg->nfft == 256 || cfg->nfft == 512 || cfg->nfft == 1024)) { op = 106; NF = 0; }
             break;
+        case DS_ALGO_MCSPP_MVDR:
+            if (ds::op_supported(ds::OP_MCSPP, cfg->n_mics) && cfg->n_mics >= 3 && cfg->hop * 2 == cfg->nfft &&
+                ds::lookup_stft(cfg->nfft, cfg->n_mics, 2).launch) { op = 108; NF = 0; }
+            break;
         case DS_ALGO_WPE_MVDR:
             if (ds::op_supported(ds::OP_ADAPTIVE, cfg->n_mics) && cfg->hop * 2 == cfg->nfft && cfg->n_mics * flen <= ds::WPEW_CNMAX) { op = 104; NF = 0; }
             break;
@@ -489,6 +493,21 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         // group's analysis, McMcra, MVDR and synthesis stages (+10 % at 1024 utterances); more groups cost the WPE kernel its grid
         h->parts = cfg->batch >= 512 ? 2 : 1;
         if (const char* e = std::getenv("DS_CHAIN_PARTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 8) h->parts = v; }
+    }
+    if (cfg->algo == DS_ALGO_MCSPP_MVDR) {
+        // mvdr.ipynb cell 4: transform = Transform(n_fft, hop, channel=M); noise_estimator = McSpp(nfft, channels=M); the same transform's istft
+        const int algos[3] = {DS_ALGO_TRANSFORM, DS_ALGO_MCSPP, DS_ALGO_TRANSFORM};
+        for (int i = 0; i < 3; ++i) {
+            ds_config c = *cfg;
+            c.algo = algos[i]; c.device = h->device;
+            if (i == 2) c.n_mics = 1;
+            rc = ds_create(&c, &h->sub[i]);
+            if (rc != DS_OK) { std::string m = g_err; ds_destroy(h); return fail(nullptr, rc, "ds_create(DS_ALGO_MCSPP_MVDR): stage " + std::to_string(i) + ": " + m); }
+            (void)hipStreamDestroy(h->sub[i]->stream);
+            h->sub[i]->stream = h->stream; h->sub[i]->owns_stream = false;
+            h->sub[i]->use_dev_cnt = true;                      // uniform counters on the device: a sequence of calls replays as a hipGraph
+            h->sub[i]->owner = h;
+        }
     }
     if (cfg->algo == DS_ALGO_TDGSC || cfg->algo == DS_ALGO_FDGSC) {
         rc = gsc_chain_create(h);
@@ -693,6 +712,12 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
             h->postfilter = value != 0;
             return DS_OK;
         case DS_PARAM_MCSPP_REPEAT:
+            if (h->cfg.algo == DS_ALGO_MCSPP_MVDR) {
+                const int rc = ds_set_param_i(h->sub[1], id, value);
+                if (rc) return fail(h, rc, h->sub[1]->err);
+                h->mcspp_repeat = value != 0; h->graph_valid = false;
+                return DS_OK;
+            }
             if (h->cfg.algo != DS_ALGO_MCSPP) return fail(h, DS_EINVAL, "mcspp repeat: DS_ALGO_MCSPP handles only");
             h->mcspp_repeat = value != 0;
             return DS_OK;
@@ -766,6 +791,14 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
         return fdgsc_run(h, x_dev, x_batch_stride, cs, n_samples, h->postfilter, 1, y_dev, y_batch_stride, nullptr, nullptr, nullptr, nullptr, nullptr,
                          nullptr, nullptr, nullptr);
     }
+    if (h->cfg.algo == DS_ALGO_MCSPP_MVDR) {
+        if (first != 0 || count != h->cfg.batch) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle processes its whole batch");
+        if (stream && (hipStream_t)stream != h->stream) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle runs on its own stream (pass NULL)");
+        if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_process_device: n_samples must be a multiple of hop");
+        if (layout != DS_LAYOUT_SAMPLES_CHANNELS && layout != DS_LAYOUT_CHANNELS_SAMPLES) return fail(h, DS_EINVAL, "ds_process_device: unknown layout");
+        if (n_samples == 0) return DS_OK;
+        return nbmvdr_process_device(h, x_dev, layout, x_batch_stride, x_chan_stride, n_samples, y_dev, y_batch_stride, nullptr);
+    }
     if (wpe_chain(h)) {
         if (first != 0 || count != h->cfg.batch) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle processes its whole batch");
         if (stream && (hipStream_t)stream != h->stream) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle runs on its own stream (pass NULL)");
@@ -833,7 +866,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     if (h->ref_powers && (n_calls > 1 || graph != 0))
         return fail(h, DS_ESTATE, "ds_process_device_seq: DS_PARAM_REF_POWERS keeps the powers of ONE plain call (n_calls 1, graph 0)");
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    const bool chain = wpe_chain(h) || h->cfg.algo == DS_ALGO_SUBBAND_GSC;
+    const bool chain = wpe_chain(h) || h->cfg.algo == DS_ALGO_SUBBAND_GSC || h->cfg.algo == DS_ALGO_MCSPP_MVDR;
     if (h->cfg.algo == DS_ALGO_TDGSC || h->cfg.algo == DS_ALGO_FDGSC) graph = 0;      // their stages keep the frame counters on the host
     // the SubbandGSC chain pipelines its stages over the enqueued blocks on up to five streams; replayed as ONE hipGraph the branches are
     // serialised by the graph executor (measured 0.34-0.50 ms per block against 0.26 ms with plain launches), so the sequence is launched

@@ -152,6 +152,54 @@ int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long
     return flush_tick(h);
 }
 
+// ---- DS_ALGO_MCSPP_MVDR: the notebook's online MVDR (example/mvdr.ipynb cell 4) as a device-resident chain --------------------------
+// chain_buf: [0] D complex [B][T][K][M] (transform.stft), [3] p [B][T][K] (noise_estimator.p), [5] Y complex [B][T][K] (Yout)
+int nbmvdr_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride, int n_samples,
+                          float* y_dev, long long y_batch_stride, float* p_dev) {
+    int rc = set_device(h); if (rc) return rc;
+    const size_t B = h->cfg.batch, M = h->cfg.n_mics, K = h->K;
+    const int T = n_samples / h->cfg.hop;
+    if (h->sub[1]->aux_floats < K) return fail(h, DS_ESTATE, "McSpp-MVDR chain: call ds_chain_set_aux(DS_CHAIN_AUX_COHERENCE) first");
+    const size_t need[8] = {B * T * K * M * 8, 0, 0, p_dev ? 0 : B * T * K * 4, 0, B * T * K * 8, 0, 0};
+    for (int i = 0; i < 8; ++i) {
+        if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
+        DS_HIP(h, hipStreamSynchronize(h->stream));
+        h->graph_valid = false; h->chain_warm_n = -1;
+        (void)hipFree(h->chain_buf[i]); h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0;
+        DS_HIP(h, hipMalloc((void**)&h->chain_buf[i], need[i]));
+        h->chain_bytes[i] = need[i];
+    }
+    float *D = h->chain_buf[0], *P = p_dev ? p_dev : h->chain_buf[3], *Y = h->chain_buf[5];
+    {   // D = transform.stft(x)
+        ds_handle* t = h->sub[0];
+        Params p;
+        fill_params(t, p);
+        p.x = x_dev; p.y = D;
+        p.x_batch_stride = x_batch_stride;
+        p.y_batch_stride = (long long)T * K * M * 2;
+        if (layout == DS_LAYOUT_CHANNELS_SAMPLES) { p.x_sample_stride = 1; p.x_chan_stride = x_chan_stride > 0 ? x_chan_stride : n_samples; }
+        else { p.x_sample_stride = (int)M; p.x_chan_stride = 1; }
+        p.T = T; p.batch0 = 0;
+        take_tick(t, h->stream, p.tick);
+        DS_HIP(h, t->ki.launch(p, (int)B, h->stream));
+    }
+    // per frame: noise_estimator.estimation(y); steer = steering(Phi_xx); w = compute_mvdr_weight(steer, Phi_vv_inv); Yout = w^H y — one kernel
+    rc = ds_mcspp_estimate(h->sub[1], D, T, P, nullptr, Y, nullptr, nullptr, DS_MEM_DEVICE);
+    if (rc) return fail(h, rc, h->sub[1]->err);
+    {   // yout = transform.istft(Yout)
+        ds_handle* t = h->sub[2];
+        Params p;
+        fill_params(t, p);
+        p.x = Y; p.y = y_dev;
+        p.x_batch_stride = (long long)T * K * 2;
+        p.y_batch_stride = y_batch_stride;
+        p.T = T; p.batch0 = 0; p.method = 1;
+        take_tick(t, h->stream, p.tick);                                // McSpp's counter advance
+        DS_HIP(h, launch_transform_istft(t, p, (int)B, h->stream));
+    }
+    return flush_tick(h);
+}
+
 // ---- DS_ALGO_SUBBAND_GSC: SubbandGSC.process (SubbandGSC.py:170-262) as a device-resident chain ------------------------------
 // (the buffer indices G_* are declared in ds_handle.hpp)
 int chain2_reserve(ds_handle* h, int n) {
@@ -449,13 +497,31 @@ extern "C" {
 int ds_chain_set_aux(ds_handle* h, int which, const float* table, size_t n_floats) {
     if (!h || !table) return fail(h, DS_EINVAL, "ds_chain_set_aux: NULL argument");
     const bool gsc = h->cfg.algo == DS_ALGO_TDGSC || h->cfg.algo == DS_ALGO_FDGSC;
-    if (h->cfg.algo != DS_ALGO_SUBBAND_GSC && !gsc) return fail(h, DS_ESTATE, "ds_chain_set_aux: handle is not a SubbandGSC / TDGSC / FDGSC chain");
-    ds_handle* t = which == DS_CHAIN_AUX_FIR ? h->sub[0] : (which == DS_CHAIN_AUX_COHERENCE && !gsc) ? h->sub[2] : nullptr;
+    const bool nb = h->cfg.algo == DS_ALGO_MCSPP_MVDR;
+    if (h->cfg.algo != DS_ALGO_SUBBAND_GSC && !gsc && !nb) return fail(h, DS_ESTATE, "ds_chain_set_aux: handle is not a SubbandGSC / TDGSC / FDGSC / McSpp-MVDR chain");
+    ds_handle* t = nb ? (which == DS_CHAIN_AUX_COHERENCE ? h->sub[1] : nullptr)
+                      : which == DS_CHAIN_AUX_FIR ? h->sub[0] : (which == DS_CHAIN_AUX_COHERENCE && !gsc) ? h->sub[2] : nullptr;
     if (!t) return fail(h, DS_EINVAL, "ds_chain_set_aux: unknown table id");
     { const int jr = set_device(h); if (jr) return jr; }    // stages still running on their own streams come back first
     DS_HIP(h, hipStreamSynchronize(h->stream));
     const int rc = ds_set_aux(t, table, n_floats);
     return rc ? fail(h, rc, t->err) : DS_OK;
+}
+
+int ds_mcspp_mvdr_process(ds_handle* h, const float* x, int layout, int n_samples, float* y, float* pp, int mem) {
+    if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_mcspp_mvdr_process: NULL argument");
+    if (h->cfg.algo != DS_ALGO_MCSPP_MVDR) return fail(h, DS_ESTATE, "ds_mcspp_mvdr_process: handle is not a DS_ALGO_MCSPP_MVDR object");
+    if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_mcspp_mvdr_process: n_samples must be a multiple of hop");
+    if (layout != DS_LAYOUT_SAMPLES_CHANNELS && layout != DS_LAYOUT_CHANNELS_SAMPLES) return fail(h, DS_EINVAL, "ds_mcspp_mvdr_process: unknown layout");
+    if (n_samples == 0) return DS_OK;
+    int rc = set_device(h); if (rc) return rc;
+    const size_t B = h->cfg.batch, M = h->cfg.n_mics, n = n_samples, T = n / h->cfg.hop;
+    IoSpec io = {{x, nullptr, nullptr}, {B * M * n * 4, 0, 0}, {y, pp, nullptr, nullptr, nullptr}, {B * n * 4, pp ? B * T * h->K * 4 : 0, 0, 0, 0}};
+    const float* din[3]; float* dout[5];
+    rc = io_begin(h, mem, io, din, dout); if (rc) return rc;
+    rc = nbmvdr_process_device(h, din[0], layout, (long long)(M * n), 0, n_samples, dout[0], (long long)n, pp ? dout[1] : nullptr);
+    if (rc) return rc;
+    return io_end(h, mem, io, dout);
 }
 
 int ds_subband_gsc_process(ds_handle* h, const float* x, int n_samples, float* y, float* fix_output, float* bm_output, float* pp,

@@ -205,6 +205,9 @@ int chain_reserve(ds_handle* h, int T);
 int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride,
                          int n_samples, float* y_dev, long long y_batch_stride);
 int chain2_reserve(ds_handle* h, int n);
+// DS_ALGO_MCSPP_MVDR (ds_api_chains.hip): analysis -> McSpp + steering + MVDR -> synthesis on device buffers; p_dev optional [B][T][K]
+int nbmvdr_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride, int n_samples,
+                          float* y_dev, long long y_batch_stride, float* p_dev);
 // DS_ALGO_TDGSC / DS_ALGO_FDGSC (ds_api_gsc_chains.hip)
 int gsc_chain_create(ds_handle* h);
 int tdgsc_run(ds_handle* h, const float* x, long long x_bstride, long long x_cstride, int n, int postfilter, float* out, long long out_bstride,

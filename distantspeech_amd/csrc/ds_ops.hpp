@@ -929,48 +929,75 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
             q = 0.99f;
         }
         // estimation_core :201-242 — in double like the reference's complex128 (ds_linalg64.hpp): inv(Phi_vv + dv I) of nearly rank-one
-        // matrices and the cancellation Phi_yy - Phi_vv are conditioning-limited; the carried state stays fp32
-        cd Pyy[M][M], inv[M][M], Zd[M], Pxx[M][M];
-        herm_unpack_d<M>(yd, yo, Pyy);
+        // matrices and the cancellation Phi_yy - Phi_vv are conditioning-limited; the carried state stays fp32.
+        // Register discipline (round 5; the 6-microphone kernel had sat at 512 registers + 260 B of scratch): no double copy of a state
+        // matrix is held across a phase — Phi_yy and Phi_xx = Phi_yy - Phi_vv are re-formed from the fp32 state where they are used (the
+        // same conversions and the same subtraction: the same values), the eigenvector of the notebook's steering() is taken in front of
+        // the LAST estimation_core, while nothing else of size is live (only the 2 M doubles of the vector cross the core), and the
+        // noise update comes after every reader of the frame's Phi_vv.  Same operations on the same operands as before: same results
+        // (between two phases the fp32 state passes through empty asm statements: otherwise the compiler merges the identical conversions of
+        // different phases and keeps the double copies live across them — the very thing this arrangement is there to avoid)
+        auto phase_fence = [&]() {
+#pragma unroll
+            for (int f = 0; f < 2 * M * M; ++f) DS_PIN(mat[f]);
+        };
+        auto pyy = [&](int i, int j) { return to_cd(herm_get<M>(yd, yo, i, j)); };
+        auto pxx = [&](int i, int j) { return cdsub(to_cd(herm_get<M>(yd, yo, i, j)), to_cd(herm_get<M>(vd, vo, i, j))); };   // Phi_xx = Phi_yy - Phi_vv (:212; exact in double)
+        cd inv[M][M], Zd[M], sv[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) Zd[m] = to_cd(Z[m]);
         double xid = 0.0;
-        for (int pass = 0; pass < (p.repeat ? 2 : 1); ++pass) {
+        const int passes = p.repeat ? 2 : 1;
+        for (int pass = 0; pass < passes; ++pass) {
         if (pass == 1) {                                                           // update_noise_psd (alpha_d = 0.92) on the fp32 state, then the
             const float at1 = fma_((float)(1.0 - 0.92), pp, 0.92f);                // second estimation_core of repeat=True (:280-282)
             herm_rank1<M>(vd, vo, Z, at1, 1.0f - at1);
         }
+        if (p.out2 && pass == passes - 1) {                                        // mvdr.ipynb cell 4: steer_vector = steering(noise_estimator.Phi_xx)
+            cd Pxx[M][M];
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+#pragma unroll
+                for (int j = 0; j < M; ++j) Pxx[i][j] = pxx(i, j);
+            herm_principal_d<M>(Pxx, sv);
+            DS_SCHED_FENCE();
+            phase_fence();
+        }
+        {
         cd A[M][M];
-        herm_unpack_d<M>(vd, vo, A);                                                              // Phi_xx = Phi_yy - Phi_vv (:212; exact in double)
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-#pragma unroll
-            for (int j = 0; j < M; ++j) Pxx[i][j] = cdsub(Pyy[i][j], A[i][j]);
+        herm_unpack_d<M>(vd, vo, A);
         const double dvd = (double)dv;
 #pragma unroll
         for (int i = 0; i < M; ++i) A[i][i].x += dvd;
         herm_inverse_d<M>(A, inv);
+        }
+        phase_fence();
         double tr = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i)
 #pragma unroll
-            for (int j = 0; j < M; ++j) tr = fmad_(inv[i][j].x, Pyy[i][j].x, fmad_(inv[i][j].y, Pyy[i][j].y, tr));   // Re(inv_ij Pyy_ji)
+            for (int j = 0; j < M; ++j) { const cd y_ = pyy(i, j); tr = fmad_(inv[i][j].x, y_.x, fmad_(inv[i][j].y, y_.y, tr)); }   // Re(inv_ij Pyy_ji)
+        phase_fence();
         if (tr - (double)M < 0.0) {                                                // :219-228
+            const double dvd = (double)dv;
+            cd A[M][M];
 #pragma unroll
             for (int i = 0; i < M; ++i)
 #pragma unroll
-                for (int j = 0; j < M; ++j) A[i][j] = Pyy[i][j];
+                for (int j = 0; j < M; ++j) A[i][j] = pyy(i, j);
             if (frm < 5) {
 #pragma unroll
                 for (int i = 0; i < M; ++i) A[i][i].x += dvd;
             }
             herm_inverse_d<M>(A, inv);
+            phase_fence();
             tr = 0.0;
 #pragma unroll
             for (int i = 0; i < M; ++i)
 #pragma unroll
-                for (int j = 0; j < M; ++j) tr = fmad_(inv[i][j].x, Pyy[i][j].x, fmad_(inv[i][j].y, Pyy[i][j].y, tr));
+                for (int j = 0; j < M; ++j) { const cd y_ = pyy(i, j); tr = fmad_(inv[i][j].x, y_.x, fmad_(inv[i][j].y, y_.y, tr)); }
         }
+        phase_fence();
         xid = dmin_(dmax_(tr - (double)M, 1e-6), 1e8);                  // :230
         cd v[M];
         double yv = 0.0;
@@ -987,7 +1014,7 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
         for (int i = 0; i < M; ++i) {
             cd acc = mkd(0.0, 0.0);
 #pragma unroll
-            for (int j = 0; j < M; ++j) acc = cdfma(acc, Pyy[i][j], v[j]);
+            for (int j = 0; j < M; ++j) acc = cdfma(acc, pyy(i, j), v[j]);
             vPv = fmad_(v[i].x, acc.x, fmad_(v[i].y, acc.y, vPv));                  // Re(conj(v_i) (Pyy v)_i)
         }
         const double gamd = dmin_(dmax_(vPv - yv, 1e-6), 1e8);                       // :232-236
@@ -995,10 +1022,7 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
         double ppd = 1.0 / (1.0 + qd / (1.0 - qd) * (1.0 + xid) * exp(-1.0 * (gamd / (1.0 + xid))));   // compute_p :75-92
         ppd = dmin_(dmax_(ppd, 0.0), 1.0);
         xi = (float)xid; gam = (float)gamd; pp = (float)ppd;
-        }
-        if (!p.repeat) {                                                           // update_noise_psd (alpha_d = 0.92) on the fp32 state
-            const float at = fma_((float)(1.0 - 0.92), pp, 0.92f);
-            herm_rank1<M>(vd, vo, Z, at, 1.0f - at);
+        phase_fence();
         }
         const long long ob = fb + k;
         p.out0[ob] = pp;
@@ -1008,7 +1032,7 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
             for (int i = 0; i < M; ++i) {
                 cd acc = mkd(0.0, 0.0);
 #pragma unroll
-                for (int j = 0; j < M; ++j) acc = cdfma(acc, inv[i][j], Pxx[j][0]);
+                for (int j = 0; j < M; ++j) acc = cdfma(acc, inv[i][j], pxx(j, 0));
                 p.out1[2 * (ob * M + i)] = (float)(acc.x * wsc); p.out1[2 * (ob * M + i) + 1] = (float)(acc.y * wsc);
             }
         }
@@ -1018,18 +1042,22 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
                     const long long q2 = 2 * ((ob * M + i) * M + j);
-                    p.out3[q2] = (float)Pxx[i][j].x; p.out3[q2 + 1] = (float)Pxx[i][j].y;
+                    const cd x_ = pxx(i, j);
+                    p.out3[q2] = (float)x_.x; p.out3[q2 + 1] = (float)x_.y;
                     p.out4[q2] = (float)inv[i][j].x; p.out4[q2 + 1] = (float)inv[i][j].y;
                 }
         }
-        if (p.out2) {                                                              // mvdr.ipynb cell 4
-            cd sv[M], w[M];
-            herm_principal_d<M>(Pxx, sv);
+        if (p.out2) {                                                              // w = compute_mvdr_weight(steer_vector, Phi_vv_inv); Yout = w^H y
+            cd w[M];
             mvdr_weight_d<M>(inv, sv, w);
             cd Y = mkd(0.0, 0.0);
 #pragma unroll
             for (int m = 0; m < M; ++m) Y = cdfmac(Y, Zd[m], w[m]);
             p.out2[2 * ob] = (float)Y.x; p.out2[2 * ob + 1] = (float)Y.y;
+        }
+        if (!p.repeat) {                                                           // update_noise_psd (alpha_d = 0.92) on the fp32 state: behind
+            const float at = fma_((float)(1.0 - 0.92), pp, 0.92f);                 // every reader of this frame's Phi_vv
+            herm_rank1<M>(vd, vo, Z, at, 1.0f - at);
         }
         frm += 1;
     }

@@ -261,6 +261,18 @@ class BatchEngine:
         t = np.ascontiguousarray(table, dtype=np.float32)
         L.check(self._lib.ds_chain_set_aux(self._h, int(which), self._p(t), t.size), self._h)
 
+    def mcspp_mvdr_process(self, x, layout, want_p=True):
+        """DS_ALGO_MCSPP_MVDR: x [B, n, M] (layout 0) or [B, M, n] (layout 1) -> (y [B, n], p [B, T, K] or None)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[1] if layout == L.LAYOUT_SAMPLES_CHANNELS else x.shape[2]
+        m = x.shape[2] if layout == L.LAYOUT_SAMPLES_CHANNELS else x.shape[1]
+        if x.ndim != 3 or x.shape[0] != self.batch or m != self.M:
+            raise ValueError("x must be [B=%d, n, M=%d] or [B, M, n]" % (self.batch, self.M))
+        y = np.empty((self.batch, n), dtype=np.float32)
+        p = np.empty((self.batch, n // self.hop, self.K), dtype=np.float32) if want_p else None
+        L.check(self._lib.ds_mcspp_mvdr_process(self._h, self._p(x), int(layout), int(n), self._p(y), self._p(p) if want_p else None, L.MEM_HOST), self._h)
+        return y, p
+
     def subband_gsc_process(self, x, extras=True):
         """DS_ALGO_SUBBAND_GSC: x [B, M, n] -> (y [B, n], fix_output [B, n], bm_output [B, M, n], p [B, T, K], aligned [B, M, n])
         (the four extras are None with extras=False)."""

@@ -269,6 +269,36 @@ class McSpp(_Base):
     gamma = property(lambda s: s._sq(s._eng.op_state()[:, s._o + 1, :].astype(np.float64)))
 
 
+class OnlineMvdr(_Base):
+    """The online MVDR of example/mvdr.ipynb cell 4 in ONE native call (DS_ALGO_MCSPP_MVDR): `transform.stft` -> per frame
+    `noise_estimator.estimation(y)` (McSpp with the McCDR prior, mcspp.py:244-305) -> `steering(noise_estimator.Phi_xx)`
+    (beamformer.py:10-31) -> `compute_mvdr_weight(steer_vector, noise_estimator.Phi_vv_inv)` (beamformer.py:133-155) ->
+    `Yout[:, n] = w^H y` -> `transform.istft(Yout)`.  No reference class wraps the cell; the constructor takes what the cell sets up
+    (n_fft = 512, hop 256, the microphone count) and process() takes the array the cell hands to `transform.stft`.
+    A call of T hops is T successive one-hop calls, state carried (analysis / synthesis overlaps, McSpp's matrices and counters)."""
+
+    def __init__(self, nfft=512, hop_length=None, channels=6, repeat=False, batch=1, device=-1):
+        self.nfft, self.hop, self.channels, self.batch = int(nfft), int(nfft // 2 if hop_length is None else hop_length), int(channels), int(batch)
+        self.half_bin = self.nfft // 2 + 1
+        self._eng = BatchEngine(L.ALGO_MCSPP_MVDR, channels, self.nfft, hop=self.hop, batch=batch, device=device)
+        self._eng.chain_set_aux(L.CHAIN_AUX_COHERENCE, McSpp.diffuse_coherence(channels, self.nfft))
+        if repeat:
+            self._eng.set_mcspp_repeat(True)                                  # noise_estimator.estimation(y, repeat=True), mcspp.py:280-282
+        self.p = None
+
+    def process(self, x):
+        """x [samples, channels] (or [B, samples, channels]) -> yout [samples]; self.p [half_bin, frames] as the cell collects it."""
+        x = self._add_batch(x, 2)
+        if x.shape[1] % self.hop != 0 or x.shape[2] != self.channels:
+            raise ValueError("x must be [k * hop (%d) samples, %d channels]" % (self.hop, self.channels))
+        y, p = self._eng.mcspp_mvdr_process(x, L.LAYOUT_SAMPLES_CHANNELS)
+        self.p = self._sq(np.swapaxes(p, 1, 2).astype(np.float64))
+        return self._sq(y.astype(np.float64))
+
+    def reset(self):
+        self._eng.reset()
+
+
 _linalg_engines = {}
 
 

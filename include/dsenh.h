@@ -152,6 +152,13 @@ typedef struct ds_config {
                                   one pass.  Methods src / DS / MVDR; parameters and fields of DS_ALGO_ADAPTIVE (track_ryy = 0) plus
                                   DS_FIELD_PHI_YY / DS_FIELD_PHI_VV; n_mics 2..6 (6: nfft <= 512) */
 
+#define DS_ALGO_MCSPP_MVDR 24   /* the online MVDR of example/mvdr.ipynb cell 4 as ONE handle behind ds_process / ds_process_device / ds_mcspp_mvdr_process:
+                                  Transform.stft of the n_mics channels (transform.py:430-453) -> per frame McSpp.estimation (McCDR prior; mcspp.py:244-305,
+                                  mccdr.py:122-177) -> steering(Phi_xx) (beamformer.py:10-31) -> compute_mvdr_weight(steer, Phi_vv_inv)
+                                  (beamformer.py:133-155) -> Y = w^H y -> Transform.istft (transform.py:455-481).  Stages (ds_chain_stage_info):
+                                  0 analysis transform, 1 DS_ALGO_MCSPP, 2 synthesis transform.  Diffuse coherence via
+                                  ds_chain_set_aux(DS_CHAIN_AUX_COHERENCE) first; DS_PARAM_MCSPP_REPEAT as for DS_ALGO_MCSPP; n_mics 4 or 6 */
+
 /* ds_set_param_* ids */
 #define DS_FDAF_PLAIN 0
 #define DS_FDAF_BM 1
@@ -343,6 +350,9 @@ int ds_tdgsc_process(ds_handle* h, const float* x, int n_samples, int postfilter
 int ds_fdgsc_process(ds_handle* h, const float* x, int n_samples, int postfilter, int dc_notch, float* out, float* p, float* fix_output,
                      float* fix_delayed, float* bm_output, float* aligned, float* aligned_delayed, float* w_aic, float* w_bm, int mem);
 int ds_adaptive_frames(ds_handle* h, const float* Z, const float* gain, int n_frames, float* Y, int mem);
+/* DS_ALGO_MCSPP_MVDR: x [B][n][M] (layout DS_LAYOUT_SAMPLES_CHANNELS, what the notebook hands to Transform.stft) or [B][M][n] -> y [B][n];
+ * optional (NULL to skip) p [B][T][K], McSpp's speech presence probability of every frame (the notebook's `p[:, n]`) */
+int ds_mcspp_mvdr_process(ds_handle* h, const float* x, int layout, int n_samples, float* y, float* p, int mem);
 int ds_fdaf_update(ds_handle* h, const float* x, const float* d, const float* p, int p_mode, int n_blocks, int fir_truncate,
                    float* err, float* w_out, int mem);
 int ds_omlsa_estimate(ds_handle* h, const float* y, const float* u, int n_frames, float* lambda_d, float* G, float* p, int mem);

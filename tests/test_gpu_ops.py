@@ -287,6 +287,94 @@ def test_mcspp_notebook_flow(ds, name):
     assert est.w.shape == (nfft // 2 + 1, M)
 
 
+@pytest.mark.parametrize("name", ["rec1", "synth_m6", "rec1_repeat"])
+def test_notebook_online_mvdr_as_one_handle(ds, name):
+    """example/mvdr.ipynb cell 4 as ONE native call (DS_ALGO_MCSPP_MVDR, ds.OnlineMvdr): time samples in, time samples out, against G11 — the
+    cell run with the reference's own objects — and against the frame-level operator driven hop by hop from Python, bit for bit."""
+    g = load("g11_mcspp_" + name)
+    M, nfft, hop = [int(v) for v in g["params"]]
+    x = as_float(g["x"]).T                                           # [samples, channels], what the cell hands to transform.stft
+    rep = name.endswith("_repeat")
+    om = ds.OnlineMvdr(nfft=nfft, hop_length=hop, channels=M, repeat=rep)
+    y = om.process(x)
+    T = x.shape[0] // hop
+    err = rms(y - g["y"])
+    measured("G11_online_mvdr_handle_" + name, y_rms=err, y_ref_rms=rms(g["y"]), p_max=np.max(np.abs(om.p.T - g["p"])))
+    assert err < 1e-4
+    assert om.p.shape == (nfft // 2 + 1, T)
+    assert np.median(np.abs(om.p.T - g["p"])) < 1e-6 and np.max(np.abs(om.p.T - g["p"])) < 5e-3
+    # hop by hop == one call, bit for bit (samples and probabilities)
+    om2 = ds.OnlineMvdr(nfft=nfft, hop_length=hop, channels=M, repeat=rep)
+    ys, ps = [], []
+    for n in range(T):
+        ys.append(om2.process(x[n * hop:(n + 1) * hop])); ps.append(om2.p[:, 0])
+    assert np.array_equal(np.concatenate(ys), y) and np.array_equal(np.stack(ps, axis=1), om.p)
+    # == the three objects of the cell driven from Python (Transform, McSpp with its fused MVDR output, Transform)
+    tr = ds.Transform(channel=M, n_fft=nfft, hop_length=hop)
+    D = tr.stft(x)
+    est = ds.McSpp(nfft=nfft, channels=M)
+    Yf = np.zeros((T, nfft // 2 + 1), dtype=complex)
+    for n in range(T):
+        est.estimation(D[:, n, :], repeat=rep)
+        Yf[n] = est.mvdr_out
+    y3 = tr.istft(Yf.T[:, :, None])
+    assert np.array_equal(np.asarray(y3, dtype=np.float32).ravel(), y.astype(np.float32))
+
+
+def test_notebook_online_mvdr_batch_and_checkpoint(ds):
+    """B utterances per handle: rows independent, a sequence replayed as a hipGraph equals plain calls, checkpoint / resume mid-stream."""
+    from distantspeech_amd import _lib as L
+    from oracle import ds_oracle as O
+    from _cases import DeviceBuffers, oracle_mic
+    M, nfft, hop, B, T = 4, 512, 256, 6, 36
+    omic = oracle_mic(M, nfft, 0.032)
+    xs = np.stack([O.synth_utterance(70 + b, hop * T, omic) for b in range(B)])      # [B, M, n]
+    def make(batch):
+        e = ds.BatchEngine(L.ALGO_MCSPP_MVDR, M, nfft, batch=batch)
+        e.chain_set_aux(L.CHAIN_AUX_COHERENCE, ds.McSpp.diffuse_coherence(M, nfft))
+        return e
+    eng = make(B)
+    y, p = eng.mcspp_mvdr_process(xs, L.LAYOUT_CHANNELS_SAMPLES)
+    assert np.all(np.isfinite(y)) and rms(y) > 1e-3
+    one = make(1)
+    y1, p1 = one.mcspp_mvdr_process(xs[4:5], L.LAYOUT_CHANNELS_SAMPLES)
+    assert np.array_equal(y1[0], y[4]) and np.array_equal(p1[0], p[4])
+    # the oracle's composition of the notebook cell on one row
+    tf = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop)
+    D = tf.stft(xs[2].T)
+    est = O.OracleMcSpp(nfft=nfft, channels=M)
+    Yo = np.zeros((nfft // 2 + 1, T), dtype=complex)
+    for n in range(T):
+        est.estimation(D[:, n, :])
+        w = O.compute_mvdr_weight(O.steering(est.Phi_xx), est.Phi_vv_inv)
+        Yo[:, n] = np.einsum("ij,ij->i", w.conj(), D[:, n, :])
+    yo = O.OracleTransform(channel=1, n_fft=nfft, hop_length=hop).istft(Yo[:, :, None])
+    assert rms(y[2] - np.asarray(yo).ravel()) < 1e-4
+    # checkpoint / resume
+    cut = hop * 15
+    a = make(B)
+    ya, _ = a.mcspp_mvdr_process(xs[:, :, :cut], L.LAYOUT_CHANNELS_SAMPLES)
+    blob = a.export_state()
+    b = make(B)
+    b.import_state(blob)
+    yb, _ = b.mcspp_mvdr_process(xs[:, :, cut:], L.LAYOUT_CHANNELS_SAMPLES)
+    assert np.array_equal(np.concatenate([ya, yb], axis=1), y)
+    # ds_process (the generic entry) and a device sequence replayed as a hipGraph
+    c = make(B)
+    assert np.array_equal(c.process(xs, L.LAYOUT_CHANNELS_SAMPLES), y)
+    dv = DeviceBuffers()
+    xd = dv.upload(xs.astype(np.float32))
+    d = make(B)
+    n_calls = T // 4
+    for graph in (0, 1, 1):                       # the first replay request runs plainly (buffers sized), the next captures and replays
+        d.reset()
+        yd = dv.zeros(B * hop * T * 4)
+        d.process_device_seq(xd, L.LAYOUT_CHANNELS_SAMPLES, M * hop * T, hop * T, 4 * hop, 4 * hop, n_calls, yd, hop * T, 4 * hop, graph=graph)
+        d.synchronize()
+        assert np.array_equal(dv.download(yd, (B, hop * T)), y), graph
+    dv.free()
+
+
 def test_steering_and_mvdr_weight_random(ds):
     from distantspeech_amd.ops import compute_mvdr_weight
     from oracle import ds_oracle as O
