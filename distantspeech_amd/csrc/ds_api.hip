@@ -58,7 +58,7 @@ int zero_state(ds_handle* h) {
         }
     }
     if (h->cfg.algo == DS_ALGO_FRONTEND) {
-        DS_HIP(h, hipMemsetAsync(h->td_mem, 0, (size_t)h->cfg.batch * h->cfg.n_mics * 2 * sizeof(float), h->stream));
+        DS_HIP(h, hipMemsetAsync(h->td_mem, 0, (size_t)h->cfg.batch * h->cfg.n_mics * 2 * sizeof(double), h->stream));
         for (int i = 0; i < 2; ++i)
             if (h->td_cache[i]) DS_HIP(h, hipMemsetAsync(h->td_cache[i], 0, (size_t)h->cfg.batch * (h->td_L > 1 ? h->td_L - 1 : 1) * h->cfg.n_mics * sizeof(float), h->stream));
     }
@@ -459,8 +459,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         h->rls_lambda = cfg->rls_lambda > 0 ? cfg->rls_lambda : 0.9998f;                 // RLS.py:15
     }
     if (cfg->algo == DS_ALGO_FRONTEND) {
-        DS_CRE(hipMalloc((void**)&h->td_mem, (size_t)cfg->batch * cfg->n_mics * 2 * sizeof(float)));
-        DS_CRE(hipMemset(h->td_mem, 0, (size_t)cfg->batch * cfg->n_mics * 2 * sizeof(float)));
+        DS_CRE(hipMalloc((void**)&h->td_mem, (size_t)cfg->batch * cfg->n_mics * 2 * sizeof(double)));
+        DS_CRE(hipMemset(h->td_mem, 0, (size_t)cfg->batch * cfg->n_mics * 2 * sizeof(double)));
     }
     if (h->op >= 0 && h->NF > 0) DS_CRE(hipMalloc((void**)&h->opst, (size_t)cfg->batch * op_ust(h) * sizeof(float)));
     const int N = cfg->nfft, NC = N / 2;
@@ -1144,7 +1144,12 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
         }
         return DS_OK;
     }
-    if (field == DS_FIELD_NOTCH_MEM) { DS_HIP(h, hipMemcpy(dst, h->td_mem, need, hipMemcpyDeviceToHost)); return DS_OK; }
+    if (field == DS_FIELD_NOTCH_MEM) {                      // carried in double on the device; the field is the float32 view of it
+        std::vector<double> m(need / sizeof(float));
+        DS_HIP(h, hipMemcpy(m.data(), h->td_mem, m.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < m.size(); ++i) ((float*)dst)[i] = (float)m[i];
+        return DS_OK;
+    }
     if (field == DS_FIELD_REF_POWERS) {
         if (h->ref_pow_stream && h->ref_pow_stream != h->stream) DS_HIP(h, hipStreamSynchronize(h->ref_pow_stream));   // the launch that wrote them
         DS_HIP(h, hipMemcpy(dst, h->ref_pow, need, hipMemcpyDeviceToHost));
@@ -1229,7 +1234,7 @@ static int extra_state(const ds_handle* h, ExtraState out[3]) {
     int n = 0;
     const size_t B = h->cfg.batch, M = h->cfg.n_mics, Lf = h->cfg.filter_len;
     if (h->cfg.algo == DS_ALGO_FRONTEND) {
-        out[n++] = {h->td_mem, B * M * 2 * sizeof(float)};
+        out[n++] = {h->td_mem, B * M * 2 * sizeof(double)};
         if (h->td_L > 1) out[n++] = {h->td_cache[h->td_cur], B * (size_t)(h->td_L - 1) * M * sizeof(float)};
     }
     if (h->tdf_w) {

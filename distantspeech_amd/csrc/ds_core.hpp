@@ -312,7 +312,7 @@ struct Params {
     // analysis: x is then the RAW input (strided [B][M][n]).  Same arithmetic, same order as ds_dcnotch_kernel / ds_fir_kernel
     const float* fe_coef;     // FIR taps [L][M]
     int fe_L;
-    float* fe_mem;            // notch memories [B][M][2]
+    double* fe_mem;           // notch memories [B][M][2] (doubles: ds_ops.hpp td_dcnotch)
     const float* fe_cache_in; // FIR history [B][M][L-1] before this call ...
     float* fe_cache_out;      // ... and after it (the other half of the ping-pong pair)
     float* fe_fixed;          // channel mean of the aligned channels, [B][T * hop] (the fixed beamformer's block)
@@ -399,7 +399,7 @@ template <int M, int ALGO, bool RYY, int NPRE> struct Regs {
     float apk, apkn;          // ... and the update probability
     float bmt[2 * M];         // ... and this lane's two samples of the M blocking-matrix overlap tails (lanes < NC / 2; aic_e mode)
     float cdr[9], cdrn[9];    // StftEngine<.., CDR>: McCDR's state of this lane's bin / of the Nyquist bin (lane 0)
-    float nm0, nm1;           // StftEngine<.., FRONT>: the DC notch memory of channel `tid` (lanes < M)
+    double nm0, nm1;          // StftEngine<.., FRONT>: the DC notch memory of channel `tid` (lanes < M)
 };
 
 // state-plane accessors.  Every state line is read once and written once per launch and is next touched by the following launch,
@@ -1834,7 +1834,7 @@ template <int NFFT, int M, bool CDR = false, int OV = 2, bool FRONT = false> str
             if constexpr (FRONT) {
                 const float* cin = p.fe_cache_in + (long long)b * M * (FL - 1);
                 for (int i = tid; i < M * (FL - 1); i += NT) hist[i] = cin[i];
-                r.nm0 = r.nm1 = 0.0f;
+                r.nm0 = r.nm1 = 0.0;
                 if (tid < M) { r.nm0 = p.fe_mem[((long long)b * M + tid) * 2]; r.nm1 = p.fe_mem[((long long)b * M + tid) * 2 + 1]; }
             }
             if constexpr (CDR) {
@@ -1882,16 +1882,15 @@ template <int NFFT, int M, bool CDR = false, int OV = 2, bool FRONT = false> str
                 // ---- DC notch, in place: one lane per channel, serial in time (ds_ops.hpp td_dcnotch: same statements) ----------------------
                 ex.phase([&](int tid, Rg& r) {
                     if (tid >= M) return;
-                    const float rr = p.fe_radius;
-                    const float den2 = fma_(rr, rr, 0.7f * (1.0f - rr) * (1.0f - rr));
+                    const double rr = (double)p.fe_radius, r2 = rr * rr + 0.7 * (1.0 - rr) * (1.0 - rr);   // notch_den2 / notch_step of ds_ops.hpp, word for word
                     float* row = W + tid * WL + OFF;
-                    float m0 = r.nm0, m1 = r.nm1;
+                    double m0 = r.nm0, m1 = r.nm1;
                     for (int i = 0; i < HOP; ++i) {
-                        const float vin = row[i];
-                        const float vout = m0 + vin;
-                        m0 = m1 + 2.0f * (-vin + rr * vout);
-                        m1 = vin - den2 * vout;
-                        row[i] = rr * vout;
+                        const double vin = (double)row[i];
+                        const double vout = m0 + vin;
+                        m0 = m1 + 2.0 * (-vin + rr * vout);
+                        m1 = vin - r2 * vout;
+                        row[i] = (float)(rr * vout);
                     }
                     r.nm0 = m0; r.nm1 = m1;
                 });

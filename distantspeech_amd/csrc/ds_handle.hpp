@@ -59,7 +59,7 @@ struct ds_handle {
     float* dev_buf[10];         // staging for host-pointer frame-level calls (3 in, 1 scratch, 5 out, 1 aux table)
     size_t dev_buf_bytes[10];
     size_t aux_floats;
-    float* td_mem;              // DS_ALGO_FRONTEND: notch memories [B][M][2]
+    double* td_mem;             // DS_ALGO_FRONTEND: notch memories [B][M][2] doubles (the recursion runs in double: ds_ops.hpp td_dcnotch)
     float* td_cache[2];         // FIR history ping-pong [B][M][L-1]
     int td_L, td_cur;
     float* tdf_w; float* tdf_buf; float* tdf_P;     // DS_ALGO_TDNLMS / TDRLS state

@@ -248,10 +248,9 @@ constexpr int NOTCH_ROWS = 32, NOTCH_TS = 256, NOTCH_NT = 256, NOTCH_LD = NOTCH_
 template <bool VEC> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kernel(TdParams p) {
     __shared__ __attribute__((aligned(16))) float tile[2][NOTCH_ROWS][NOTCH_LD];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, row0 = blockIdx.x * NOTCH_ROWS, rows = p.B * p.M;
-    const float r = p.radius;
-    const float den2 = fma_(r, r, 0.7f * (1.0f - r) * (1.0f - r));
+    const double r = (double)p.radius, den2 = notch_den2(p.radius);             // the recursion in double: see td_dcnotch
     const bool rec = wv == 0 && lane < NOTCH_ROWS && row0 + lane < rows;      // this lane runs the recursion of row `lane`
-    float m0 = 0.0f, m1 = 0.0f;
+    double m0 = 0.0, m1 = 0.0;
     if (rec) { m0 = p.mem[(long long)(row0 + lane) * 2]; m1 = p.mem[(long long)(row0 + lane) * 2 + 1]; }
     // the NOTCH_RPT rows this lane moves: wv, wv + 4, ...; column 4 * lane
     const float* src[NOTCH_RPT];
@@ -286,12 +285,7 @@ template <bool VEC> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kerne
         if (s0 + NOTCH_TS < p.n) fetch(s0 + NOTCH_TS);                         // next tile's loads fly behind this tile's recursion
         if (rec) {
             float* row = tile[cur][lane];
-            auto step = [&](float vin) {
-                const float vout = m0 + vin;
-                m0 = m1 + 2.0f * (-vin + r * vout);
-                m1 = vin - den2 * vout;
-                return r * vout;
-            };
+            auto step = [&](float vin) { return notch_step(m0, m1, r, den2, vin); };
             const int nfull = ns & ~15;
             vec4 a[4], nx[4];
 #pragma unroll

@@ -1427,7 +1427,7 @@ struct TdParams {
     int y_chan_major;          // FIR: write y as [B][M][n] (what the per-channel transforms of the SubbandGSC chain read) instead of [B][n][M]
     int x_chan_major;          // FIR: read x as [B][M][n]
     long long x_bstride, x_cstride;   // notch: element strides of x between utterances / channels (0 = dense [B][M][n])
-    float* mem;                // notch: [B][M][2]
+    double* mem;               // notch: [B][M][2] doubles (the recursion and its carried memory run in double, see td_dcnotch)
     const float* coef;         // FIR: [L][M]
     const float* cache_in;     // FIR: [B][M][L-1], channel-major: a channel's history is one contiguous row.  (Interleaved [L-1][M] rows made
                                // every channel pass of the kernel a stride-M partial write of the same lines: 1.3x the history in extra HBM
@@ -1437,19 +1437,28 @@ struct TdParams {
     float radius;
 };
 
+// FilterDcNotch16.filter_dc_notch16 (adaptivefilter/feature.py:32-49) in DOUBLE, memory included (round 5).  The recursion has its poles at
+// radius 0.98: run in fp32 it put 1.4e-5 of relative error on its output (the FIR bank behind it: 1.4e-7), and the chain's speech-presence
+// estimator amplifies exactly that — on a recording at ten times its level, where McSpp's dv I loading no longer damps it, the fp64
+// REFERENCE estimator itself moves p by 4e-3 under a 1e-5 input perturbation (scratch/g22_level2.py) and the blocking filters integrate
+// it: 1.2e-4 of the output on the G22 fixtures, 3e-5 with the recursion in double (scratch/g22_level.py; at recording level 4e-6 -> 1e-6).
+// Four double operations per sample on the one lane per row that runs the recursion anyway (the kernel is bound by that lane's dependent
+// chain, not by the vector rate); samples in and out stay fp32.  (Tried beside it and dropped: xi and gamma of the chain's McSpp in their
+// cancellation-free forms tr(A^-1 (Phi_yy - A)) and v^H (Phi_yy - A) v — no measurable change in p, 32 registers more.)
+DS_HD double notch_den2(float radius) { const double r = (double)radius; return r * r + 0.7 * (1.0 - r) * (1.0 - r); }
+DS_HD float notch_step(double& m0, double& m1, double r, double den2, float vin_) {
+    const double vin = (double)vin_;
+    const double vout = m0 + vin;
+    m0 = m1 + 2.0 * (-vin + r * vout);
+    m1 = vin - den2 * vout;
+    return (float)(r * vout);
+}
 DS_HD void td_dcnotch(const TdParams& p, int b, int m) {
-    const float r = p.radius;
-    const float den2 = fma_(r, r, 0.7f * (1.0f - r) * (1.0f - r));
-    float m0 = p.mem[((long long)b * p.M + m) * 2], m1 = p.mem[((long long)b * p.M + m) * 2 + 1];
+    const double r = (double)p.radius, den2 = notch_den2(p.radius);
+    double m0 = p.mem[((long long)b * p.M + m) * 2], m1 = p.mem[((long long)b * p.M + m) * 2 + 1];
     const float* x = p.x_bstride ? p.x + (long long)b * p.x_bstride + (long long)m * p.x_cstride : p.x + ((long long)b * p.M + m) * p.n;
     float* y = p.y + ((long long)b * p.M + m) * p.n;
-    for (int i = 0; i < p.n; ++i) {
-        const float vin = x[i];
-        const float vout = m0 + vin;
-        m0 = m1 + 2.0f * (-vin + r * vout);
-        m1 = vin - den2 * vout;
-        y[i] = r * vout;
-    }
+    for (int i = 0; i < p.n; ++i) y[i] = notch_step(m0, m1, r, den2, x[i]);
     p.mem[((long long)b * p.M + m) * 2] = m0; p.mem[((long long)b * p.M + m) * 2 + 1] = m1;
 }
 

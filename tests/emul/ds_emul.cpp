@@ -461,7 +461,7 @@ int emul_stft_cdr(int nfft, int M, int batch, const float* x, int n_samples, flo
 // the chain's whole front end as one program (StftEngine<.., FRONT = true>): raw x [B][M][n] -> DC notch -> FIR bank + channel mean -> analysis
 // + McCDR; notch memories mem [B][M][2], FIR history cache_in -> cache_out [B][M][L - 1], fixed [B][n]
 int emul_front(int nfft, int M, int batch, const float* x, int n_samples, float* Y, float* tail_in, float* st, int NF, int frm, int ell,
-               const float* Fn, float* gamma, float* qavg, const float* coef, int L, float* mem, const float* cache_in, float* cache_out,
+               const float* Fn, float* gamma, float* qavg, const float* coef, int L, double* mem, const float* cache_in, float* cache_out,
                float* fixed, float radius) {
     ds::Params p;
     std::memset(&p, 0, sizeof p);
@@ -508,7 +508,7 @@ int emul_aic(int nfft, int M, int batch, const float* x, int n_samples, float* y
 }
 
 // time-domain front-end: serial loops over the same per-thread programs the GPU runs
-int emul_dcnotch(int B, int M, int n, const float* x, float* y, float* mem, float radius) {
+int emul_dcnotch(int B, int M, int n, const float* x, float* y, double* mem, float radius) {
     ds::TdParams p;
     std::memset(&p, 0, sizeof p);
     p.B = B; p.M = M; p.n = n; p.x = x; p.y = y; p.mem = mem; p.radius = radius;

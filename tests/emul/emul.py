@@ -206,7 +206,7 @@ class EmulFrontend:
 
     def __init__(self, M, coef=None, radius=0.9, batch=1):
         self.M, self.B, self.radius = M, batch, radius
-        self.mem = np.zeros((batch, M, 2), dtype=np.float32)
+        self.mem = np.zeros((batch, M, 2), dtype=np.float64)             # the recursion and its memory run in double (ds_ops.hpp td_dcnotch)
         self.coef = None if coef is None else np.ascontiguousarray(coef, dtype=np.float32)
         if coef is not None:
             self.L = self.coef.shape[0]

@@ -466,9 +466,10 @@ def g22_subbandgsc_postfilter(x16):
     import DistantSpeech.beamformer.FDGSC as FD
     FD.DelayObj = object                                                                   # R9
     from DistantSpeech.beamformer.SubbandGSC import SubbandGSC
-    SCALE = 10.0       # the recording at ten times its level: at its own level the powers (1e-20) sit under the estimator's 1e-6 regularisers
-    x = x16.astype(np.float32) / 32768.0 * np.float32(SCALE)
-    for name, xx, M, blocks_per_call in (("rec1_1", x[:, : 256 * 60], 4, 1), ("rec1_5", x[:, : 256 * 60], 4, 5)):
+    # the recording at ten times its level (at its own level the omlsa_multi powers, 1e-20, sit under the estimator's 1e-6 regularisers) and,
+    # for the five returned signals, at its own level as well (rec1_1_lvl1: round 5)
+    for name, SCALE, M, blocks_per_call in (("rec1_1", 10.0, 4, 1), ("rec1_5", 10.0, 4, 5), ("rec1_1_lvl1", 1.0, 4, 1)):
+        xx = (x16.astype(np.float32) / 32768.0 * np.float32(SCALE))[:, : 256 * 60]
         mic = MicArray(arrayType="circular", r=0.032, M=M, n_fft=512)
         with contextlib.redirect_stdout(io.StringIO()):
             g = SubbandGSC(mic, frameLen=256, angle=[197, 0])

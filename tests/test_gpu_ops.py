@@ -452,7 +452,7 @@ def test_subband_gsc_fan_equals_instances(ds, kind):
         assert np.array_equal(np.asarray(y, dtype=np.float32), bm[:n, m].astype(np.float32)), m
 
 
-@pytest.mark.parametrize("name", ["rec1_1", "rec1_5"])
+@pytest.mark.parametrize("name", ["rec1_1", "rec1_5", "rec1_1_lvl1"])
 def test_subband_gsc_postfilter_trace(ds, name):
     """SubbandGSC.process(postfilter=True) (SubbandGSC.py:236-249): the five results are those of postfilter=False, the branch's one trace
     is the object's omlsa_multi — held to the REFERENCE object's own values (G22), one block per call and five blocks per call (where the
@@ -467,9 +467,16 @@ def test_subband_gsc_postfilter_trace(ds, name):
     plain = ds.SubbandGSC(mic, frameLen=FL, angle=[197, 0])
     out0 = np.concatenate([plain.process(x[:, a:a + FL * per_call])[0] for a in range(0, x.shape[1], FL * per_call)])
     assert np.array_equal(out, out0)
-    # (the fixture runs the recording at TEN times its level, where the estimator's 1e-6 regularisers stop masking its inputs: the north
-    # star's 1e-4 RMS at recording level is 1e-3 here; measured 1.0e-4 on an output of 0.81 RMS — the same 1.2e-4 relative as G12)
-    assert rms(out - g["output"]) < 1e-3 and rms(out - g["output"]) < 5e-4 * rms(g["output"])
+    # The north star's 1e-4 RMS, absolute, at TEN times the recording's level too (output 0.81 RMS) and at the recording's own level
+    # (rec1_1_lvl1).  Round 4 measured 1.0e-4 here, 27 x the relative error of the same recording at its own level: the DC notch's fp32
+    # recursion put 1.4e-5 on the aligned channels, and at this level — where McSpp's dv I loading no longer damps it — the speech-presence
+    # estimator amplifies input errors twenty-fold (the fp64 reference estimator does too: scratch/g22_level2.py).  With the recursion in
+    # double: 2.5e-5 here, 8e-8 at recording level (CPU run of the same programs, scratch/g22_level.py)
+    assert rms(out - g["output"]) < 1e-4 and rms(out - g["output"]) < 1e-4 * rms(g["output"])
+    if float(g["scale"]) == 1.0:
+        assert rms(out - g["output"]) < 1e-6
+        measured("G22_subbandgsc_pf_" + name, output_rms=rms(out - g["output"]), output_ref_rms=rms(g["output"]))
+        return                                                # (its omlsa_multi sits under the estimator's regularisers: nothing to compare)
     om = sg.omlsa_multi
     ref = g["omlsa_lambda_d"]
     live = ref > 1e-3 * ref.max()                            # lambda_d here = the first frame's power, numbers at the transform's rounding floor

@@ -772,7 +772,7 @@ def test_emul_fused_front_end_equals_separate_programs(M, nfft, L):
     op = EmulOp("mcspp", nfft, M=M)
     st_a, st_b = op.st.copy(), op.st.copy()
     tin_a, tin_b = np.zeros((1, M, hop), np.float32), np.zeros((1, M, hop), np.float32)
-    mem_b = np.zeros((1, M, 2), np.float32)
+    mem_b = np.zeros((1, M, 2), np.float64)                                   # the notch memory is carried in double
     cache_b = [np.zeros((1, M, L - 1), np.float32) for _ in range(2)]
     cur, frm, ell = 0, 0, 1
     for T in (2, 1, 5):

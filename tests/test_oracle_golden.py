@@ -258,7 +258,7 @@ def test_subband_gsc(golden, name):
     assert np.max(np.abs(p - g["p"])) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["rec1_1", "rec1_5"])
+@pytest.mark.parametrize("name", ["rec1_1", "rec1_5", "rec1_1_lvl1"])
 def test_subband_gsc_postfilter_branch(golden, name):
     """SubbandGSC.process(postfilter=True) (SubbandGSC.py:236-249): same five results; the branch's trace is the object's omlsa_multi —
     driven one block per call and five (where every block re-analyses the whole bm_output array of the call and takes its frame 0)."""
