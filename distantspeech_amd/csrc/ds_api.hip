@@ -385,7 +385,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     // fused frame kernels: two free-running utterance groups from 2048 utterances up (more than one round of workgroups per launch)
     h->split = (dsi::frames_algo(cfg->algo) && cfg->batch >= 2048) ? 2 : 1; h->ev_fork = nullptr;
     h->parts = 1; h->groups_open = false;
-    h->front_async = false; h->tail_async = false; h->front_open = false; h->fr_valid[0] = h->fr_valid[1] = false; h->tf_valid[0] = h->tf_valid[1] = false; h->bf_valid[0] = h->bf_valid[1] = false; h->al_read[0] = h->al_read[1] = false; h->fr_mid[0] = h->fr_mid[1] = false; h->front_set = 0; h->lean_main = false; h->early_front = false;
+    h->front_async = false; h->tail_async = false; h->front_open = false; h->fr_valid[0] = h->fr_valid[1] = false; h->tf_valid[0] = h->tf_valid[1] = false; h->bf_valid[0] = h->bf_valid[1] = false; h->al_read[0] = h->al_read[1] = false; h->fr_mid[0] = h->fr_mid[1] = false; h->front_set = 0; h->lean_main = false; h->early_front = false; h->fan_fused = false;
     for (int i = 0; i < 10; ++i) h->ev_fr[i] = nullptr;
     for (int i = 0; i < 7; ++i) { h->side[i] = nullptr; h->ev_join[i] = nullptr; }
     h->ki_istft = ki_istft; h->op = op;
@@ -587,6 +587,9 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             const char* ff = std::getenv("DS_CHAIN_FRONT_FUSED");        // shelved (make SHELVED=1): the front end as ONE kernel, measured slower
             h->front_fused = h->ki_cdr.launch != nullptr && ff && ff[0] == '1';
         }
+#if defined(DS_WITH_SHELVED)
+        { const char* fs = std::getenv("DS_CHAIN_FAN_FUSED"); h->fan_fused = fs && fs[0] == '1'; }
+#endif
         h->sub[5]->x_fan = M;                 // the M blocking filters of an utterance share its fixed-beamformer spectrum and p ...
         h->sub[5]->d_interleaved = 1;         // ... and take their desired signals straight from the M-channel STFT of the aligned channels
         h->sub[7]->p_complement = 1;          // SubbandGSC.py:232: p = 1 - p

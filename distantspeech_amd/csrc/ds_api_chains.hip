@@ -408,6 +408,21 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
             DS_HIP(h, hipStreamWaitEvent(h->sub[5]->stream, h->ev_fork, 0));
         }
     }
+    // Round 5, SHELVED (make SHELVED=1 + DS_CHAIN_FAN_FUSED=1): the M RLS blocking filters INSIDE the McSpp launch (OP_MCSPP_STEADY_FAN).
+    // They read the same frame of the same bin as McSpp does and do not take its p, so one thread can run both: the spectra D are fetched
+    // once instead of twice and the filters' kernel — a streaming pass with 4 % of its cycles in arithmetic — disappears.  Built,
+    // bit-identical (the chain-variant test), and measured: 9 % slower at one block per call (the pass had been running BESIDE McSpp on the
+    // branch stream; fused it sits on the chain's critical stream), no change with 10 s per call — the hand-off bytes are not what bounds
+    // that regime (profiles/r05a/cfg5_fan_in_mcspp_ab.txt)
+    const bool fan_fused = h->fan_fused && cdr_in_front && fork && h->sub[5]->cfg.algo == DS_ALGO_SUBRLS && h->sub[5]->filter_len == 2 &&
+                           h->sub[2]->op_frm >= 5 && !h->sub[2]->mcspp_repeat && (size_t)B * M * T * K * 8 < ((size_t)1 << 32);
+    if (fan_fused) {
+        rc = chain_stft(h, h->sub[3], cb[G_FIXED], n, cb[G_F]); if (rc) return rc;                               // bm[m].transform_x: F (branch stream)
+        DS_HIP(h, hipEventRecord(h->ev_join[0], h->sub[3]->stream));
+        DS_HIP(h, hipStreamWaitEvent(h->stream, h->ev_join[0], 0));
+        DS_SUB(2, mcspp_from_gamma(h->sub[2], cb[G_D], T, cb[G_GAM], cb[G_GAM] + (size_t)B * T * K, cb[G_P], h->sub[5], cb[G_F], cb[G_E]));   // :208 p, :217-223 E
+        advance_host_counters(h->sub[5], T, h->sub[5]->mcra_L);
+    } else {
     if (cdr_in_front) DS_SUB(2, mcspp_from_gamma(h->sub[2], cb[G_D], T, cb[G_GAM], cb[G_GAM] + (size_t)B * T * K, cb[G_P]));   // :208  p
     else DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[G_D], T, cb[G_P], nullptr, nullptr, nullptr, nullptr, DS_MEM_DEVICE));
     rc = chain_stft(h, h->sub[3], cb[G_FIXED], n, cb[G_F]); if (rc) return rc;                                   // bm[m].transform_x: F
@@ -415,6 +430,7 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
     // aligned channel is the same spectrum), update probability p
     if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[G_F], cb[G_D], T, cb[G_E], DS_MEM_DEVICE));
     else DS_SUB(5, ds_sublms_update(h->sub[5], cb[G_F], cb[G_D], cb[G_P], T, cb[G_E], DS_MEM_DEVICE));
+    }
     if (!fused_tail) {
         rc = chain_istft(h, h->sub[4], cb[G_E], T, cb[G_BM], n); if (rc) return rc;                           // bm outputs, [B*M][n] = [B][M][n]
         rc = chain_stft(h, h->sub[6], cb[G_BM], n, cb[G_XAIC]); if (rc) return rc;                              // :230-234  aic transform_x

@@ -283,7 +283,8 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, 
 
 }  // extern "C"
 namespace dsi {
-int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* gamma, const float* qavg, float* p_out) {
+int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* gamma, const float* qavg, float* p_out, ds_handle* fan,
+                     const float* fan_x, float* fan_e) {
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
     p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames; p.st = h->opst; p.NF = h->NF; p.M = h->cfg.n_mics;
@@ -293,7 +294,12 @@ int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* ga
     p.out0 = p_out;
     p.repeat = h->mcspp_repeat;
     take_tick(h, h->stream, p.tick);
-    const int op = p.repeat ? ds::OP_MCSPP : h->op_frm < 5 ? ds::OP_MCSPP_LEAN : ds::OP_MCSPP_STEADY;
+    int op = p.repeat ? ds::OP_MCSPP : h->op_frm < 5 ? ds::OP_MCSPP_LEAN : ds::OP_MCSPP_STEADY;
+    if (fan) {                                           // the chain's RLS blocking filters in the same threads (mcspp_fan_ok() said so)
+        if (op != ds::OP_MCSPP_STEADY) return fail(h, DS_ESTATE, "mcspp_from_gamma: the fused blocking filters need the steady-state McSpp build");
+        op = ds::OP_MCSPP_STEADY_FAN;
+        p.fan_st = fan->opst; p.fan_NF = fan->NF; p.fan_x = fan_x; p.fan_e = fan_e; p.fan_lam = fan->rls_lambda; p.fan_mu = fan->filt_mu;
+    }
     DS_HIP(h, ds::launch_binop(op, p, h->stream));
     if (h->use_dev_cnt) { const int rc = post_tick(h, h->dev_cnt, n_frames, 65, 0, 0, h->stream); if (rc) return rc; }
     { const int first = h->op_first; advance_host_counters(h, n_frames, 65); h->op_first = first; }

@@ -100,6 +100,7 @@ struct ds_handle {
     // (with the tail on its own stream the branch joins there, not on the chain's stream: nothing but McSpp sits between two McSpp launches)
     bool front_async, tail_async, front_open, fr_valid[2], tf_valid[2], bf_valid[2], al_read[2], fr_mid[2];
     bool early_front;           // ... and the notch / FIR bank of block t + 2 wait for their own readers only (DS_CHAIN_NO_EARLY=1: off, A/B runs)
+    bool fan_fused;             // shelved build + DS_CHAIN_FAN_FUSED=1 at ds_create: the RLS blocking filters inside McSpp's launch (OP_MCSPP_STEADY_FAN)
     bool lean_main;             // pipelined chain: McSpp's counters by value (no counter-advance launch), the blocking-filter branch joins on the tail's stream
     int front_set;
     hipEvent_t ev_fr[10];
@@ -177,7 +178,10 @@ int binop_launch(ds_handle* h, int b0, int nb, int n_frames, const float* const 
 int wpe_launch(ds_handle* h, int b0, int nb, const float* x_delayed, const float* d, int n_frames, float* err, float* ring, int ring_pos,
                int ring_len, const int* dev_ring_pos, hipStream_t stream, float* err0 = nullptr);
 // the McSpp half of ds_mcspp_estimate on device buffers: Gamma and its band mean come from the caller (the chain's front end computes them)
-int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* gamma, const float* qavg, float* p_out);
+// fan (optional): the chain's DS_ALGO_SUBRLS stage, run inside the same launch (OP_MCSPP_STEADY_FAN) on reference input fan_x, errors to fan_e;
+// the caller advances that stage's host counters
+int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* gamma, const float* qavg, float* p_out, ds_handle* fan = nullptr,
+                     const float* fan_x = nullptr, float* fan_e = nullptr);
 int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len,
             const int* dev_ring_pos, float* err0 = nullptr);
 

@@ -164,11 +164,13 @@ __device__ inline void mcspp_qavg_block(const OpParams& p, int b0, float (*band)
     }
 }
 
-template <int OP, int M> __global__ void __launch_bounds__(256) ds_binop_kernel(OpParams p) {
+// (the fused McSpp + blocking-filter operator at 6 microphones is pinned to the two waves per SIMD the plain steady-state build reaches by itself)
+constexpr int binop_min_waves(int op, int M) { return (op == OP_MCSPP_STEADY_FAN && M >= 5) ? 2 : 1; }
+template <int OP, int M> __global__ void __launch_bounds__(256, binop_min_waves(OP, M)) ds_binop_kernel(OpParams p) {
     if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
     const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;
     const int b = (int)(i / p.KP), k = (int)(i - (long long)b * p.KP);
-    if constexpr (OP == OP_MCSPP || OP == OP_MCSPP_LEAN || OP == OP_MCSPP_STEADY) {
+    if constexpr (OP == OP_MCSPP || OP == OP_MCSPP_LEAN || OP == OP_MCSPP_STEADY || OP == OP_MCSPP_STEADY_FAN) {
         const int band_n = (int)(2000.0 * (2 * (p.K - 1)) / 16000.0) - (int)(500.0 * (2 * (p.K - 1)) / 16000.0);
         if (!p.in2 && p.T <= QAVG_TMAX && band_n > 0 && band_n <= QAVG_BAND) {   // otherwise the operator sums the band per bin itself
             __shared__ float band[4][QAVG_BAND];
@@ -181,9 +183,17 @@ template <int OP, int M> __global__ void __launch_bounds__(256) ds_binop_kernel(
     }
     if (b >= p.B || k >= p.K) return;
     OpCtx c = make_op_ctx(p, i0);
-    if constexpr (OP == OP_MCSPP_STEADY && M >= 5) {                        // parking space for Phi_vv (op_mcspp_lean): two waves per SIMD at 6 microphones
-        __shared__ float park[(M * M + 1) * 256];
+    if constexpr ((OP == OP_MCSPP_STEADY || OP == OP_MCSPP_STEADY_FAN) && M >= 5) {   // parking space for Phi_vv (op_mcspp_lean): two waves per SIMD at 6 microphones
+        __shared__ float park[(M * M + 1 + (OP == OP_MCSPP_STEADY_FAN ? RlsFan<2, M>::NW : 0)) * 256];   // ... and, fused, for the blocking filters between their frames
         c.spill = park + threadIdx.x; c.spill_stride = 256;
+    }
+    if constexpr (OP == OP_MCSPP_STEADY_FAN) {                              // the blocking filters' planes: a descriptor of their own, from the first
+        OpParams q = p;                                                     // instance of the workgroup's first utterance on
+        q.st = p.fan_st; q.NF = p.fan_NF; q.B = p.B * M; q.dev_cnt = nullptr;
+        const OpCtx c2 = make_op_ctx(q, (i0 / p.KP) * M * p.KP);
+        c.fan_ctx = &c2;
+        run_op_t<OP, M>(c, b, k);
+        return;
     }
     run_op_t<OP, M>(c, b, k);
 }

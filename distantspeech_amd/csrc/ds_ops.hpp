@@ -18,7 +18,9 @@ namespace ds {
 enum { OP_MCRA = 0, OP_MCMCRA = 1, OP_OMLSA = 2, OP_SUBLMS = 3, OP_SUBRLS = 4, OP_MCSPPBASE = 5, OP_WPE = 6, OP_MCCDR = 7, OP_MCSPP = 8, OP_STEERING = 9,
        OP_MVDRW = 10, OP_ADAPTIVE = 11, OP_MCSPP_LEAN = 12,      // LEAN: McSpp without the MVDR / matrix outputs (the SubbandGSC chain)
        OP_MCSPP_STEADY = 13,                                     // ... and its variant for calls from frame 5 on without PMWF weights
-       OP_PMWFW = 14, OP_GEV = 15, OP_BAN = 16, OP_PHASECORR = 17 };   // the free functions of beamformer/beamformer.py:34-130 (mvdr.ipynb's GEV flow)
+       OP_PMWFW = 14, OP_GEV = 15, OP_BAN = 16, OP_PHASECORR = 17,
+       OP_MCSPP_STEADY_FAN = 18 };  // OP_MCSPP_STEADY with the SubbandGSC chain's M RLS blocking filters (op_subrls_fan) in the same thread: both read the
+                                    // same frame of the same bin, so the spectra are fetched once and the filters' streaming traffic hides behind McSpp's arithmetic   // the free functions of beamformer/beamformer.py:34-130 (mvdr.ipynb's GEV flow)
 
 struct OpParams {
     int B, K, KP, T;          // utterances, bins, padded plane length, frames in this call
@@ -59,6 +61,13 @@ struct OpParams {
     int in2_b0;               // McSpp: in2 (the band average per (utterance, frame)) starts at this utterance (the kernel's own LDS copy)
     TickArgs tick;            // counters of an EARLIER stage of the chain to advance (thread 0 of block 0; cnt null = none)
     int repeat;               // McSpp: estimation(repeat=True), a second estimation_core after the noise update (mcspp.py:280-282)
+    // OP_MCSPP_STEADY_FAN: the blocking filters' side of the fused operator (the McSpp side uses the fields above as OP_MCSPP_STEADY does)
+    float* fan_st;            // state of the B * M SubbandRLS instances (the DS_ALGO_SUBRLS stage's planes, fan form: see op_subrls_fan)
+    int fan_NF;
+    const float* fan_x;       // their shared reference input, complex [B][T][K] (the fixed beamformer's spectrum)
+    float* fan_e;             // their error spectra, complex [B * M][T][K]
+    float fan_lam, fan_mu;
+    const void* fan_ctx;      // set by the kernel: the OpCtx of fan_st (device) / the OpParams copy (CPU emulator)
     float* spill;             // lean McSpp at 6 microphones: per-lane parking space (LDS on the GPU) for Phi_vv while the solves run; element f of
     int spill_stride;         // this lane at spill[f * spill_stride]; null = keep everything in registers
 };
@@ -617,26 +626,56 @@ template <int N> DS_HD void op_subrls_t(const OpCtx& p, int b, int k) {
 // live in the first instance's planes only: the X / P planes of the other F - 1 instances are not maintained (this kernel is their only
 // reader; the chain exports and imports the raw state, so checkpoints round-trip).
 // Needs d_interleaved (the desired signals are the channels of one spectrum) and no d_prev.
-template <int N, int F> DS_HD void op_subrls_fan(const OpCtx& p, int u, int k) {
-    constexpr int oX = 2 * N, oP = 4 * N;
-    const float lam_inv = 1.0f / p.lam;
-    const int b0 = u * F;
+// the fan's state and one frame of it (shared by op_subrls_fan and the fused OP_MCSPP_STEADY_FAN: the same statements, the same results)
+template <int N, int F> struct RlsFan {
+    static constexpr int oX = 2 * N, oP = 4 * N;
     cf W[F][N], X[N], P[N][N];
     // rows 2 i, 2 i + 1 of an instance are (Re, Im) of tap i: a cf array IS the run of rows it mirrors — whole float4 groups per access
-    st_load_span<oX, 2 * N>(p, b0, k, reinterpret_cast<float*>(&X[0]));
-    st_load_span<oP, 2 * N * N>(p, b0, k, reinterpret_cast<float*>(&P[0][0]));
+    DS_HD void load(const OpCtx& p, int b0, int k) {
+        st_load_span<oX, 2 * N>(p, b0, k, reinterpret_cast<float*>(&X[0]));
+        st_load_span<oP, 2 * N * N>(p, b0, k, reinterpret_cast<float*>(&P[0][0]));
 #pragma unroll
-    for (int m = 0; m < F; ++m) st_load_span<0, 2 * N>(p, b0 + m, k, reinterpret_cast<float*>(&W[m][0]));
-    for (int t = 0; t < p.T; ++t) {
-        const long long fx = ((long long)u * p.T + t) * p.K + k;
+        for (int m = 0; m < F; ++m) st_load_span<0, 2 * N>(p, b0 + m, k, reinterpret_cast<float*>(&W[m][0]));
+    }
+    DS_HD void store(const OpCtx& p, int b0, int k) const {
+#pragma unroll
+        for (int m = 0; m < F; ++m) st_store_span<0, 2 * N>(p, b0 + m, k, reinterpret_cast<const float*>(&W[m][0]));
+        st_store_span<oX, 2 * N>(p, b0, k, reinterpret_cast<const float*>(&X[0]));
+        st_store_span<oP, 2 * N * N>(p, b0, k, reinterpret_cast<const float*>(&P[0][0]));
+    }
+    // the state to / from a per-lane parking area (LDS on the device; element f of this lane at area[f * stride]): the fused operator keeps
+    // the filters there between their frames, so that they cost McSpp's estimation core no registers
+    static constexpr int NW = 2 * N * (F + 1 + N);
+    DS_HD void park(float* area, int stride) const {
+        const float* w = reinterpret_cast<const float*>(&W[0][0]);
+#pragma unroll
+        for (int f = 0; f < 2 * N * F; ++f) area[f * stride] = w[f];
+        const float* x = reinterpret_cast<const float*>(&X[0]);
+#pragma unroll
+        for (int f = 0; f < 2 * N; ++f) area[(2 * N * F + f) * stride] = x[f];
+        const float* q = reinterpret_cast<const float*>(&P[0][0]);
+#pragma unroll
+        for (int f = 0; f < 2 * N * N; ++f) area[(2 * N * F + 2 * N + f) * stride] = q[f];
+    }
+    DS_HD void unpark(const float* area, int stride) {
+        float* w = reinterpret_cast<float*>(&W[0][0]);
+#pragma unroll
+        for (int f = 0; f < 2 * N * F; ++f) w[f] = area[f * stride];
+        float* x = reinterpret_cast<float*>(&X[0]);
+#pragma unroll
+        for (int f = 0; f < 2 * N; ++f) x[f] = area[(2 * N * F + f) * stride];
+        float* q = reinterpret_cast<float*>(&P[0][0]);
+#pragma unroll
+        for (int f = 0; f < 2 * N * N; ++f) q[f] = area[(2 * N * F + 2 * N + f) * stride];
+    }
+    // one frame: reference sample x, the F desired samples d -> the F errors (SubbandRLS.py:44-71 for each of the F filters)
+    DS_HD void step(cf x, const cf* d, float lam, float mu, cf* err_out) {
+        const float lam_inv = 1.0f / lam;
 #pragma unroll
         for (int n = N - 1; n > 0; --n) X[n] = X[n - 1];
-        X[0] = mk(p.in0[2 * fx], p.in0[2 * fx + 1]);
-        cf d[F];
-#pragma unroll
-        for (int m = 0; m < F; ++m) d[m] = mk(p.in1[2 * (fx * F + m)], p.in1[2 * (fx * F + m) + 1]);
+        X[0] = x;
         cf num[N], xhP[N], kn[N];
-        cf den = mk(p.lam, 0.0f);
+        cf den = mk(lam, 0.0f);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             cf a = mk(0.0f, 0.0f), r = mk(0.0f, 0.0f);
@@ -663,16 +702,29 @@ template <int N, int F> DS_HD void op_subrls_fan(const OpCtx& p, int u, int k) {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 const cf g = cmulc(kn[i], err);
-                W[m][i] = mk(fma_(2.0f * p.mu, g.x, W[m][i].x), fma_(2.0f * p.mu, g.y, W[m][i].y));
+                W[m][i] = mk(fma_(2.0f * mu, g.x, W[m][i].x), fma_(2.0f * mu, g.y, W[m][i].y));
             }
-            const long long fb = ((long long)(b0 + m) * p.T + t) * p.K + k;
-            p.out0[2 * fb] = err.x; p.out0[2 * fb + 1] = err.y;
+            err_out[m] = err;
         }
     }
+};
+template <int N, int F> DS_HD void op_subrls_fan(const OpCtx& p, int u, int k) {
+    const int b0 = u * F;
+    RlsFan<N, F> fan;
+    fan.load(p, b0, k);
+    for (int t = 0; t < p.T; ++t) {
+        const long long fx = ((long long)u * p.T + t) * p.K + k;
+        cf d[F], err[F];
 #pragma unroll
-    for (int m = 0; m < F; ++m) st_store_span<0, 2 * N>(p, b0 + m, k, reinterpret_cast<const float*>(&W[m][0]));
-    st_store_span<oX, 2 * N>(p, b0, k, reinterpret_cast<const float*>(&X[0]));
-    st_store_span<oP, 2 * N * N>(p, b0, k, reinterpret_cast<const float*>(&P[0][0]));
+        for (int m = 0; m < F; ++m) d[m] = mk(p.in1[2 * (fx * F + m)], p.in1[2 * (fx * F + m) + 1]);
+        fan.step(mk(p.in0[2 * fx], p.in0[2 * fx + 1]), d, p.lam, p.mu, err);
+#pragma unroll
+        for (int m = 0; m < F; ++m) {
+            const long long fb = ((long long)(b0 + m) * p.T + t) * p.K + k;
+            p.out0[2 * fb] = err[m].x; p.out0[2 * fb + 1] = err[m].y;
+        }
+    }
+    fan.store(p, b0, k);
 }
 // can a SubbandRLS call run as op_subrls_fan?
 inline bool subrls_fan_ok(const OpParams& p) {
@@ -1073,9 +1125,47 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
 // needs inv(Phi_vv + dv I) as a matrix — tr(A^-1 Phi_yy), A^-1 y and the PMWF column come from the inverse of the Cholesky factor of the
 // Hermitian-packed state (Chol::invert / trace_with / apply), which is less work and fewer live registers than forming the explicit
 // inverse, and less than a pair of substitutions per column of Phi_yy (the first form of this operator: 233 registers, 211 now at M = 6).
-template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, int b, int k) {
+// where the fused operator's blocking filters put their error spectra, complex [B * M][T][K]: on the device ONE buffer descriptor for the
+// array, the lane's (utterance, bin) as the 32-bit offset and (filter, frame) in the scalar offset — M per-filter 64-bit pointers walked
+// frame by frame were twelve more registers than the operator's two-waves-per-SIMD budget has (the launcher keeps the array under 4 GB)
+#if defined(__HIP_DEVICE_COMPILE__)
+struct FanErrOut {
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff;
+    int T, K;
+    __device__ FanErrOut(const OpParams& p, int b, int k, int M) : T(p.T), K(p.K) {
+        const long long bytes = (long long)p.B * M * p.T * p.K * 8;
+        rs = __builtin_amdgcn_make_buffer_rsrc(p.fan_e, 0, (int)(unsigned)(bytes > 0xffffffffLL ? 0xffffffffLL : bytes), 0x00020000);
+        voff = (unsigned)((((long long)b * M * p.T) * p.K + k) * 8);
+    }
+    __device__ void put(int m, int t, cf e) const {
+        const unsigned soff = (unsigned)((m * T + t) * K * 8);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e.x), rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, e.y), rs, voff + 4, soff, 0);
+    }
+};
+#else
+struct FanErrOut {
+    float* base; int T, K;
+    FanErrOut(const OpParams& p, int b, int k, int M) : base(p.fan_e ? p.fan_e + 2 * ((((long long)b * M * p.T) * p.K) + k) : nullptr), T(p.T), K(p.K) {}
+    void put(int m, int t, cf e) const { float* q = base + 2 * (long long)(m * T + t) * K; q[0] = e.x; q[1] = e.y; }
+};
+#endif
+// FAN (with STEADY; OP_MCSPP_STEADY_FAN): the M RLS blocking filters of the utterance (RlsFan, the program of op_subrls_fan) run on the same
+// frame in the same thread — the frame's M spectra are their desired signals.  Their 36 state floats stay within the 256 registers of the
+// two-waves-per-SIMD budget the operator lives in anyway
+template <int M, bool STEADY = false, bool FAN = false> DS_HD void op_mcspp_lean(const OpCtx& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
     constexpr int o0 = MCSPP_ROW0;
+    RlsFan<2, FAN ? M : 1> fan;
+    const OpCtx* fc = nullptr;
+    const FanErrOut eout(p, b, k, M);
+    float* const fpark = (FAN && p.spill) ? p.spill + (M * M + 1) * p.spill_stride : nullptr;      // behind Phi_vv's parking rows
+    if constexpr (FAN) {
+        fc = static_cast<const OpCtx*>(p.fan_ctx);
+        fan.load(*fc, b * M, k);
+        if (fpark) { fan.park(fpark, p.spill_stride); DS_COMPILER_FENCE(); }
+    }
     // rows o0 .. o0 + 2 M M - 1 = Phi_yy (diagonal, upper triangle), Phi_vv (the same), then xi, gamma, p: one register block, moved as
     // whole float4 groups (o0 is a multiple of 4)
     float mat[2 * M * M + 4];
@@ -1093,6 +1183,14 @@ template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, i
         cf Z[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) Z[m] = mk(p.in0[2 * (base + m)], p.in0[2 * (base + m) + 1]);
+        if constexpr (FAN) {                                                       // SubbandGSC.py:217-223: bm[m].update(fixed, aligned[m]) for every m
+            cf err[M];
+            if (fpark) { DS_COMPILER_FENCE(); fan.unpark(fpark, p.spill_stride); }
+            fan.step(mk(p.fan_x[2 * (fb + k)], p.fan_x[2 * (fb + k) + 1]), Z, p.fan_lam, p.fan_mu, err);
+            if (fpark) { fan.park(fpark, p.spill_stride); DS_COMPILER_FENCE(); }
+#pragma unroll
+            for (int m = 0; m < M; ++m) eout.put(m, t, err[m]);
+        }
         float q = 1.0f - p.in1[fb + k];                                            // compute_q :113-116
         const float q_avg = p.in2 ? p.in2[(long long)(b - p.in2_b0) * p.T + t] : mcspp_qavg(p.in1 + fb, fmin, fmax);
         const float dv = fma_(q_avg, 1e-1f, (1.0f - q_avg) * 1e-4f);               // :254-262
@@ -1177,6 +1275,10 @@ template <int M, bool STEADY = false> DS_HD void op_mcspp_lean(const OpCtx& p, i
         herm_rank1<M>(vd, vo, Z, at, 1.0f - at);
         p.out0[ob] = pp;
         frm += 1;
+    }
+    if constexpr (FAN) {
+        if (fpark) { DS_COMPILER_FENCE(); fan.unpark(fpark, p.spill_stride); }
+        fan.store(*fc, b * M, k);
     }
     if (p.T > 0) {
         mat[2 * M * M] = xi; mat[2 * M * M + 1] = gam; mat[2 * M * M + 2] = pp;
@@ -1377,6 +1479,7 @@ template <int OP, int M> DS_HD void run_op_t(const OpCtx& p, int b, int k) {
     else if constexpr (OP == OP_MCSPP) op_mcspp<M>(p, b, k);
     else if constexpr (OP == OP_MCSPP_LEAN) op_mcspp_lean<M>(p, b, k);
     else if constexpr (OP == OP_MCSPP_STEADY) op_mcspp_lean<M, true>(p, b, k);
+    else if constexpr (OP == OP_MCSPP_STEADY_FAN) op_mcspp_lean<M, true, true>(p, b, k);
     else if constexpr (OP == OP_STEERING) op_steering<M>(p, b, k);
     else if constexpr (OP == OP_MVDRW) op_mvdrw<M>(p, b, k);
     else if constexpr (OP == OP_PMWFW) op_pmwfw<M>(p, b, k);
@@ -1387,12 +1490,12 @@ template <int OP, int M> DS_HD void run_op_t(const OpCtx& p, int b, int k) {
 }
 
 inline bool op_is_linalg(int op) { return op == OP_STEERING || op == OP_MVDRW || op == OP_PMWFW || op == OP_GEV || op == OP_BAN || op == OP_PHASECORR; }
-inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_MCSPP || op == OP_ADAPTIVE || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY || op_is_linalg(op); }
+inline bool op_is_matrix(int op) { return op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_MCSPP || op == OP_ADAPTIVE || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY || op == OP_MCSPP_STEADY_FAN || op_is_linalg(op); }
 
 // is (op, M) a supported combination?  (matrix operators: M in {2, 4, 6, 8}; McSpp / steering / mvdr weight: {2, 4, 6})
 inline bool op_supported(int op, int M) {
     if (op == OP_MCMCRA || op == OP_MCSPPBASE || op == OP_ADAPTIVE) return M == 2 || M == 4 || M == 6 || M == 8;
-    if (op == OP_MCSPP || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY) return M == 2 || M == 4 || M == 6;
+    if (op == OP_MCSPP || op == OP_MCSPP_LEAN || op == OP_MCSPP_STEADY || op == OP_MCSPP_STEADY_FAN) return M == 2 || M == 4 || M == 6;
     if (op_is_linalg(op)) return M >= 2 && M <= 6;          // the stateless helpers also for the 3- and 5-microphone arrays the frame kernels take
     return true;
 }
@@ -1400,10 +1503,16 @@ inline bool op_supported(int op, int M) {
 #define DS_OP_M_LIST(X, OP_) X(OP_, 2) X(OP_, 4) X(OP_, 6) X(OP_, 8)
 #define DS_OP_M3_LIST(X, OP_) X(OP_, 2) X(OP_, 4) X(OP_, 6)
 #define DS_OP_ML_LIST(X, OP_) X(OP_, 2) X(OP_, 3) X(OP_, 4) X(OP_, 5) X(OP_, 6)
+// shelved experiments (make SHELVED=1; the CPU emulator always has them): built, bit-identical to what ships, measured no faster
+#if defined(DS_WITH_SHELVED) || !defined(__HIPCC__)
+#define DS_OP_SHELVED_LIST(X) DS_OP_M3_LIST(X, OP_MCSPP_STEADY_FAN)
+#else
+#define DS_OP_SHELVED_LIST(X)
+#endif
 #define DS_FOR_EACH_OP(X) \
     X(OP_MCRA, 1) X(OP_OMLSA, 1) X(OP_SUBLMS, 1) X(OP_SUBRLS, 1) X(OP_MCCDR, 1) \
     DS_OP_M_LIST(X, OP_MCMCRA) DS_OP_M_LIST(X, OP_MCSPPBASE) DS_OP_M_LIST(X, OP_ADAPTIVE) \
-    DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_MCSPP_LEAN) DS_OP_M3_LIST(X, OP_MCSPP_STEADY) DS_OP_ML_LIST(X, OP_STEERING) DS_OP_ML_LIST(X, OP_MVDRW) \
+    DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_MCSPP_LEAN) DS_OP_M3_LIST(X, OP_MCSPP_STEADY) DS_OP_SHELVED_LIST(X) DS_OP_ML_LIST(X, OP_STEERING) DS_OP_ML_LIST(X, OP_MVDRW) \
     DS_OP_ML_LIST(X, OP_PMWFW) DS_OP_ML_LIST(X, OP_GEV) DS_OP_ML_LIST(X, OP_BAN) DS_OP_ML_LIST(X, OP_PHASECORR)
 
 // runtime dispatch for the serial CPU run in tests/emul (the GPU launches one specialised kernel per (OP, M))

@@ -48,12 +48,24 @@ def budget_rows(cfg, w, stages, B):
              "notch memory, FIR history (%d samples per channel), analysis overlap M x hop, McCDR rows 0..8 of the McSpp state = 3 planes" % (Lt - 1),
              M * 2 * 4 + (Lt - 1) * M * 4 + M * hop * 4 + 3 * P16, M * hop * 4, K * M * 8 + K * 4 + 4 + hop * 4),
         ]
-        rows = (front1 if os.environ.get("DS_CHAIN_FRONT_FUSED") == "1" else front3) + [
-            ("ds_binop_kernel<13", "McSpp, steady-state build (stage 2)", "rows 12.. of the McSpp state: %d planes" % (planes(12 + 2 * M * M + 3) - 3),
-             (planes(12 + 2 * M * M + 3) - 3) * P16, K * M * 8 + K * 4 + 4, K * 4),
-            ("ds_stft_rows_kernel", "analysis of the fixed beamformer output (stage 3)", "analysis overlap, one channel", hop * 4, hop * 4, K * 8),
-            ("ds_subrls_fan_kernel", "M RLS blocking filters, fan form (stage 5)", "filter 0: W, X, P = 4 planes; filters 1..M-1: W = 1 plane each",
-             (4 + (M - 1)) * P16, K * 8 + K * M * 8, M * K * 8),
+        mcspp_planes = planes(12 + 2 * M * M + 3) - 3
+        if os.environ.get("DS_CHAIN_FAN_FUSED") != "1" or w.get("rls_lambda", 0.0) <= 0.0:
+            middle = [
+                ("ds_binop_kernel<13", "McSpp, steady-state build (stage 2)", "rows 12.. of the McSpp state: %d planes" % mcspp_planes,
+                 mcspp_planes * P16, K * M * 8 + K * 4 + 4, K * 4),
+                ("ds_stft_rows_kernel", "analysis of the fixed beamformer output (stage 3)", "analysis overlap, one channel", hop * 4, hop * 4, K * 8),
+                ("ds_subrls_fan_kernel", "M RLS blocking filters, fan form (stage 5)", "filter 0: W, X, P = 4 planes; filters 1..M-1: W = 1 plane each",
+                 (4 + (M - 1)) * P16, K * 8 + K * M * 8, M * K * 8),
+            ]
+        else:
+            # round 5's shelved experiment (make SHELVED=1 + DS_CHAIN_FAN_FUSED=1): the RLS filters inside McSpp's launch — the frame's spectra read once for both
+            middle = [
+                ("ds_stft_rows_kernel", "analysis of the fixed beamformer output (stage 3)", "analysis overlap, one channel", hop * 4, hop * 4, K * 8),
+                ("ds_binop_kernel<18", "McSpp, steady-state build, with the M RLS blocking filters in the same threads (stages 2, 5)",
+                 "rows 12.. of the McSpp state: %d planes; blocking filter 0: W, X, P = 4 planes; filters 1..M-1: W = 1 plane each" % mcspp_planes,
+                 (mcspp_planes + 4 + (M - 1)) * P16, K * M * 8 + K * 4 + 4 + K * 8, K * 4 + M * K * 8),
+            ]
+        rows = (front1 if os.environ.get("DS_CHAIN_FRONT_FUSED") == "1" else front3) + middle + [
             ("ds_frames_kernel", "tail: synthesis of the M blocking outputs, re-analysis, canceller, synthesis (stages 4, 6, 7, 8)",
              "synthesis + analysis overlaps 2 x M x hop, output overlap hop, delayed fixed spectrum K x 8, canceller state %d planes" % planes(4 * N * M + 1),
              2 * M * hop * 4 + hop * 4 + K * 8 + planes(4 * N * M + 1) * P16, M * K * 8 + K * 8 + K * 4, hop * 4),

@@ -273,6 +273,10 @@ int emul_istft(int nfft, int M, int batch, const float* Y, int T, int C, float* 
 static int g_repeat = 0, g_two_path = 0;
 static int g_wpe_generic = 0;     // emul_set_wpe_generic(1): every WPE shape through the run-time-shape program (the A side of an A/B)
 void emul_set_repeat(int on) { g_repeat = on; }
+// OP_MCSPP_STEADY_FAN: the SubbandRLS instances the fused operator runs beside McSpp — state [B * M][NF][KP] logical planes, reference input
+// x complex [B][T][K], errors e complex [B * M][T][K]
+static struct { float* st; int NF; const float* x; float* e; float lam, mu; } g_fan = {nullptr, 0, nullptr, nullptr, 0.0f, 0.0f};
+void emul_set_fan(float* st, int NF, const float* x, float* e, float lam, float mu) { g_fan.st = st; g_fan.NF = NF; g_fan.x = x; g_fan.e = e; g_fan.lam = lam; g_fan.mu = mu; }
 void emul_set_wpe_generic(int on) { g_wpe_generic = on; }
 void emul_set_pipe(int on) { g_pipe = on; }
 int emul_pipe_runs() { return g_pipe_runs; }
@@ -290,6 +294,17 @@ int emul_op(int op, int B, int K, int T, float* st, int NF, const float* in0, co
     p.M = M; p.N = N; p.frm_cnt = frm_cnt; p.ell = ell; p.L = L; p.first_frame = first_frame;
     p.in_complex = in_complex; p.has_p = has_p; p.norm = norm; p.mu = mu; p.alpha = alpha; p.reg = reg; p.lam = lam;
     p.x_fan = 1; p.repeat = g_repeat;
+    if (op == ds::OP_MCSPP_STEADY_FAN) {                // the blocking filters' side: emul_set_fan() before the call
+        if (!g_fan.st) return -2;
+        StPlanes fplanes(g_fan.st, B * M, g_fan.NF, ds::plane_len(K));
+        ds::OpParams q = p;
+        q.st = fplanes.data(); q.NF = g_fan.NF; q.B = B * M;
+        p.fan_st = q.st; p.fan_NF = q.NF; p.fan_x = g_fan.x; p.fan_e = g_fan.e; p.fan_lam = g_fan.lam; p.fan_mu = g_fan.mu;
+        p.fan_ctx = &q;
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < K; ++k) ds::run_op(op, p, b, k);
+        return 0;
+    }
     for (int b = 0; b < B; ++b)
         for (int k = 0; k < K; ++k) ds::run_op(op, p, b, k);
     return 0;

@@ -1061,8 +1061,12 @@ def test_subband_gsc_fused_tail_and_pipelined_stages_equal_separate_kernels(ds, 
                       # the front end (DC notch, FIR bank, analysis + McCDR) as ONE kernel (round 4's ds_front_kernel: shelved, measured slower —
                       # only a `make SHELVED=1` library has it; elsewhere the switch changes nothing and the variant repeats the default)
                       ("fused_pipeline_front1", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", DS_CHAIN_TAIL_ASYNC="1", DS_CHAIN_FRONT_FUSED="1")),
+                      # round 5's shelved experiment (make SHELVED=1): the RLS blocking filters inside McSpp's launch from frame 5 on
+                      # (OP_MCSPP_STEADY_FAN); on the product library the switch changes nothing and the variants repeat the default
+                      ("fused_pipeline_fan_fused", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", DS_CHAIN_TAIL_ASYNC="1", DS_CHAIN_FAN_FUSED="1")),
+                      ("fused_front_fan_fused", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", DS_CHAIN_TAIL_ASYNC="0", DS_CHAIN_FAN_FUSED="1")),
                       ("fused_pipeline", dict(DS_CHAIN_UNFUSED="0", DS_CHAIN_SERIAL_FRONT="0", DS_CHAIN_TAIL_ASYNC="1"))):
-        for k in ("DS_CHAIN_MAIN_JOIN", "DS_CHAIN_NO_EARLY", "DS_CHAIN_PRIO", "DS_CHAIN_FRONT_FUSED"):
+        for k in ("DS_CHAIN_MAIN_JOIN", "DS_CHAIN_NO_EARLY", "DS_CHAIN_PRIO", "DS_CHAIN_FRONT_FUSED", "DS_CHAIN_FAN_FUSED"):
             monkeypatch.setenv(k, "0")
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1083,7 +1087,8 @@ def test_subband_gsc_fused_tail_and_pipelined_stages_equal_separate_kernels(ds, 
                      np.frombuffer(g2._eng.export_state(), dtype=np.float32).copy())
     y0, bm0, s0 = res["separate"][:3]
     assert np.all(np.isfinite(y0)) and np.abs(y0).max() > 0
-    for name in ("fused_serial", "fused_front", "fused_pipeline_main_join", "fused_pipeline_no_early", "fused_pipeline_prio", "fused_pipeline_front1", "fused_pipeline"):
+    for name in ("fused_serial", "fused_front", "fused_pipeline_main_join", "fused_pipeline_no_early", "fused_pipeline_prio", "fused_pipeline_front1",
+                 "fused_pipeline_fan_fused", "fused_front_fan_fused", "fused_pipeline"):
         y1, bm1, s1, yd1, sd1 = res[name]
         assert np.array_equal(bm0, bm1)                                      # everything in front of the tail is the same launch sequence
         assert np.array_equal(y1, res["fused_serial"][0]) and np.array_equal(s1, res["fused_serial"][2])      # scheduling changes nothing

@@ -716,6 +716,54 @@ def emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, p_override=None, fused_tail=
     return out, bm.T, p[0].T, xa[0]
 
 
+@pytest.mark.parametrize("M", [6, 4])
+def test_emul_mcspp_with_fused_blocking_filters_equals_separate_programs(M):
+    """OP_MCSPP_STEADY_FAN (the SubbandGSC chain's steady-state McSpp with the utterance's M RLS blocking filters in the same thread) against
+    the two programs run one after the other: p, the error spectra and both states bit for bit, over two calls."""
+    import ctypes
+    from emul import emul as E
+    from emul.emul import EmulOp
+    from oracle import ds_oracle as O
+    lib = E.lib()
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    f32 = ctypes.c_float
+    nfft, K, B = 512, 257, 2
+    KP = (K + 7) & ~7
+    rng = np.random.default_rng(23)
+    Fn = O.gen_noise_msc(O.OracleMicArray(arrayType="circular", r=0.032, M=M), nfft)[:, 1, 2]
+    N, NF = 2, 4 * 2 + 2 * 2 * 2
+
+    def fan_state():
+        st = np.zeros((B * M, NF, KP), dtype=np.float32)
+        for i in range(N):
+            st[:, 4 * N + 2 * (i * N + i), :] = 1000.0
+        return st
+
+    spa, spb = EmulOp("mcspp", nfft, M=M, batch=B), EmulOp("mcspp", nfft, M=M, batch=B)
+    sta, stb = fan_state(), fan_state()
+    mk = lambda *sh: ((rng.standard_normal(sh) + 1j * rng.standard_normal(sh)) * 0.3).astype(np.complex64)
+    D0, F0 = mk(B, 6, K, M), mk(B, 6, K)
+    for sp, st in ((spa, sta), (spb, stb)):                 # the first six frames through the lean build and the stand-alone filters
+        sp.run_mcspp(D0, Fn, variant=12)
+        e0 = np.zeros((B * M, 6, K), dtype=np.complex64)
+        assert lib.emul_fan(4, 1, M, B * M, K, 6, vp(st), NF, vp(F0), vp(D0), None, vp(e0), 0, 1, f32(0.5), f32(0.9), f32(1e-4), f32(0.998)) == 0
+    assert spa.frm == 6 and np.array_equal(spa.st, spb.st) and np.array_equal(sta, stb)
+    for T in (7, 1, 9):
+        D, F = mk(B, T, K, M), mk(B, T, K)
+        # A: the two programs
+        pa = spa.run_mcspp(D, Fn, variant=13)[0]
+        ea = np.zeros((B * M, T, K), dtype=np.complex64)
+        assert lib.emul_fan(4, 1, M, B * M, K, T, vp(sta), NF, vp(F), vp(D), None, vp(ea), 0, 1, f32(0.5), f32(0.9), f32(1e-4), f32(0.998)) == 0
+        # B: the fused program
+        eb = np.zeros_like(ea)
+        lib.emul_set_fan(vp(stb), NF, vp(F), vp(eb), f32(0.998), f32(0.5))
+        pb = spb.run_mcspp(D, Fn, variant=18)[0]
+        lib.emul_set_fan(None, 0, None, None, f32(0), f32(0))
+        assert np.abs(ea).max() > 0 and np.all(np.isfinite(ea))
+        assert np.array_equal(pa, pb) and np.array_equal(ea, eb)
+        assert np.array_equal(spa.st, spb.st) and np.array_equal(sta, stb)
+
+
 @pytest.mark.parametrize("M,nfft", [(6, 512), (4, 256), (4, 1024)])
 def test_emul_analysis_with_mccdr_equals_separate_programs(M, nfft):
     """The SubbandGSC chain's front-end analysis with McCDR as its per-bin program (StftEngine<.., CDR>: stencil and band mean from LDS)
