@@ -974,12 +974,72 @@ template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag
 // ---------------------------------------------------------------------------------------------
 // Per-bin algorithms.  Return the beamformer output Y[k].
 // ---------------------------------------------------------------------------------------------
+// Where a lane's Ryy lives when the kernel does NOT hold it in registers across the hops of a call (round 5: the 1024-point kernel with Ryy at
+// 6 microphones — a 1024-point workgroup is eight waves, two per SIMD, 256 registers per lane whatever the kernel declares; with Ryy resident
+// it carried 60 B of scratch).  Floats [F0, NF) of the lane's state — F0 = the first whole float4 plane behind the MCRA words — stay in
+// their HBM planes: every hop reads them, updates them and writes them back (the same recursion on the same values: the same results); the
+// few Ryy words in front of F0 share a plane with MCRA's lambda_d and stay in registers.  The TFGSC solve re-reads the columns it needs.
+// (At 8 microphones the same arrangement — also plane by plane, also with Rvv parked in its planes around the solves — left 60 to 500 B
+// of scratch in every form tried: that kernel and the 8-microphone GSC kernel at 1024 points keep theirs)
+struct StreamRef {
+    vec4* planes;      // plane F0 / 4 of this lane's bin: &bins[(F0 / 4) * KP + k]; plane q of the streamed part at planes[q * KP]
+    float* tail;       // the narrow plane's floats of this bin (NF % 4 of them)
+    int KP;
+};
+template <int M> struct RyyStreamLayout {
+    static constexpr int NF = 2 * M * M + 5, RY0 = M * M + 5;
+    static constexpr int F0 = (RY0 + 3) & ~3;                      // first streamed float
+    static constexpr int NPS = NF / 4 - F0 / 4, RT = NF % 4;       // whole streamed planes, floats in the narrow plane
+    static constexpr int HEAD = F0 - RY0;                          // Ryy words that stay in registers (st[RY0 .. F0))
+};
+template <int M> DS_HD void ryy_stream_load(const StreamRef& sr, const float* st, float* ry) {
+    typedef RyyStreamLayout<M> L;
+#pragma unroll
+    for (int f = 0; f < L::HEAD; ++f) ry[f] = st[L::RY0 + f];
+#pragma unroll
+    for (int q = 0; q < L::NPS; ++q) {
+        const vec4 v = load_state(&sr.planes[q * sr.KP]);
+        ry[L::HEAD + 4 * q] = v.x; ry[L::HEAD + 4 * q + 1] = v.y; ry[L::HEAD + 4 * q + 2] = v.z; ry[L::HEAD + 4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < L::RT; ++j) ry[L::HEAD + 4 * L::NPS + j] = sr.tail[j];
+}
+template <int M> DS_HD void ryy_stream_store(const StreamRef& sr, float* st, const float* ry) {
+    typedef RyyStreamLayout<M> L;
+#pragma unroll
+    for (int f = 0; f < L::HEAD; ++f) st[L::RY0 + f] = ry[f];
+#pragma unroll
+    for (int q = 0; q < L::NPS; ++q) {
+        vec4 v; v.x = ry[L::HEAD + 4 * q]; v.y = ry[L::HEAD + 4 * q + 1]; v.z = ry[L::HEAD + 4 * q + 2]; v.w = ry[L::HEAD + 4 * q + 3];
+        store_state(&sr.planes[q * sr.KP], v);
+    }
+#pragma unroll
+    for (int j = 0; j < L::RT; ++j) sr.tail[j] = ry[L::HEAD + 4 * L::NPS + j];
+}
+// one word of the streamed Ryy (ry index = float index - RY0) straight from memory
+template <int M> DS_HD float ryy_stream_word(const StreamRef& sr, const float* st, int w) {
+    typedef RyyStreamLayout<M> L;
+    if (w < L::HEAD) return st[L::RY0 + w];
+    const int f = w - L::HEAD;
+    if (f < 4 * L::NPS) return reinterpret_cast<const float*>(&sr.planes[(f >> 2) * sr.KP])[f & 3];
+    return sr.tail[f - 4 * L::NPS];
+}
+
 template <int M, bool RYY>
-DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
+DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p, const StreamRef* sr = nullptr) {
     typedef StateLayout<M, ALGO_ADAPTIVE, RYY> SL;
     float* d = st + SL::R_DIAG;
     float* o = st + SL::R_OFF;
-    if (RYY) herm_rank1<M>(st + SL::RYY_DIAG, st + SL::RYY_OFF, Z, p.alpha_y, p.beta_y);      // :86-88
+    if (RYY) {
+        if (sr) {                                                                             // streamed: HBM -> update -> HBM, this hop
+            float ry[M * M];
+            ryy_stream_load<M>(*sr, st, ry);
+            herm_rank1<M>(ry, ry + M, Z, p.alpha_y, p.beta_y);
+            ryy_stream_store<M>(*sr, st, ry);
+        } else {
+            herm_rank1<M>(st + SL::RYY_DIAG, st + SL::RYY_OFF, Z, p.alpha_y, p.beta_y);      // :86-88
+        }
+    }
 #ifndef DS_ABLATE_NORANK1      // timing experiment only (scratch/build_variant.sh): the frame program without the covariance accumulate
     if (st[SL::MC_S + 3] < p.gate) herm_rank1<M>(d, o, Z, p.alpha_v, p.beta_v);               // :94-99
 #endif
@@ -1016,7 +1076,12 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p) {
                 // at an odd float of the state for even M — became 8-byte accesses across the 16-byte plane groups, and the Ryy planes
                 // stayed in private memory: 144 - 416 B of scratch in the 6- and 8-microphone kernels)
                 float re, im;
-                if (i == j) { re = yd[i]; im = 0.0f; }
+                if (sr) {                                          // streamed Ryy: the words of column j from their planes (written above, this hop)
+                    if (i == j) { re = ryy_stream_word<M>(*sr, st, i); im = 0.0f; }
+                    else if (i < j) { const int q = off_index(i, j, M); re = ryy_stream_word<M>(*sr, st, M + 2 * q); im = ryy_stream_word<M>(*sr, st, M + 2 * q + 1); }
+                    else { const int q = off_index(j, i, M); re = ryy_stream_word<M>(*sr, st, M + 2 * q); im = -ryy_stream_word<M>(*sr, st, M + 2 * q + 1); }
+                }
+                else if (i == j) { re = yd[i]; im = 0.0f; }
                 else if (i < j) { const int q = off_index(i, j, M); re = yo[2 * q]; im = yo[2 * q + 1]; }
                 else { const int q = off_index(j, i, M); re = yo[2 * q]; im = -yo[2 * q + 1]; }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1295,6 +1360,10 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
     static constexpr int KP = plane_len(K);                  // padded plane length
     typedef StateLayout<M, ALGO, RYY> SL;
     static constexpr int NP = SL::NP;
+    // the 1024-point kernel with Ryy at 6 microphones streams Ryy through its HBM planes hop by hop instead of holding it (StreamRef)
+    static constexpr bool STREAM_RYY = RYY && ALGO == ALGO_ADAPTIVE && NFFT >= 1024 && M == 6;
+    static constexpr int NPLD = STREAM_RYY ? RyyStreamLayout<M>::F0 / 4 : SL::NPF;      // float4 planes a lane keeps in registers for the call
+    static constexpr int RTLD = STREAM_RYY ? 0 : SL::RT;                                // ... and floats of the narrow plane
     static constexpr int NV4 = HOP * M / 4;                  // float4 per hop of input
     static constexpr int NPRE = (NV4 + NT - 1) / NT;
     typedef Shared<NFFT, M, (SL::NP > 0 ? SL::NP * 4 : 4)> Sh;
@@ -1361,7 +1430,8 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
 
     // one frequency bin: MCRA / covariance recursion / solve -> Y[k]
     static DS_HD cf bin_program(float* st, const cf* Z, const cf* steer, int k, const Sh& sh, const Params& p,
-                                int frm_cnt, bool reset, int spp_cnt, cf ad = cf{0.0f, 0.0f}, float apk = 0.0f, long long pw_row0 = -1) {
+                                int frm_cnt, bool reset, int spp_cnt, cf ad = cf{0.0f, 0.0f}, float apk = 0.0f, long long pw_row0 = -1,
+                                const StreamRef* sr = nullptr) {
         if constexpr (ALGO == ALGO_AIC) return aic_bin<M>(st, Z, ad, apk, p);
         cf a[M];
 #pragma unroll
@@ -1371,7 +1441,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             Yk = fixed_bin<M>(Z, a);
         } else if constexpr (ALGO == ALGO_ADAPTIVE) {
             mcra_bin(st + SL::MC_S, k, K, sh.pw[k > 0 ? k - 1 : 0], sh.pw[k], sh.pw[k + 1], frm_cnt, reset, p.mcra_L);
-            Yk = adaptive_bin<M, RYY>(st, Z, a, p);
+            Yk = adaptive_bin<M, RYY>(st, Z, a, p, sr);
         } else if constexpr (ALGO == ALGO_ADAPTIVE_PF) {
             mcra_bin(st + SL::MC_S, k, K, sh.pw[k > 0 ? k - 1 : 0], sh.pw[k], sh.pw[k + 1], frm_cnt, reset, p.mcra_L);
             Yk = adaptive_bin<M, false>(st, Z, a, p);                                          // adaptivebeamformer.py:69-120
@@ -1420,12 +1490,12 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         auto store_lane_state = [&](int tid, Rg& r) {              // bin `tid`'s planes back to HBM
             DS_PIN(tid);                                           // addresses formed here, not hoisted out of the hop loop (registers)
 #pragma unroll
-            for (int q = 0; q < SL::NPF; ++q) {
+            for (int q = 0; q < NPLD; ++q) {
                 vec4 v; v.x = r.st[4 * q]; v.y = r.st[4 * q + 1]; v.z = r.st[4 * q + 2]; v.w = r.st[4 * q + 3];
                 store_state(&bins[q * KP + tid], v);
             }
 #pragma unroll
-            for (int j = 0; j < SL::RT; ++j) {
+            for (int j = 0; j < RTLD; ++j) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DS_NT_TAIL)
                 __builtin_nontemporal_store(r.st[4 * SL::NPF + j], &btail[tid * SL::RT + j]);
 #else
@@ -1473,12 +1543,12 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 r.nyq.x = as.ld(tid < SL::NF ? tid : 0, NC);
             } else {
 #pragma unroll
-                for (int q = 0; q < SL::NPF; ++q) {
+                for (int q = 0; q < NPLD; ++q) {
                     const vec4 v = load_state(&bins[q * KP + tid]);
                     r.st[4 * q] = v.x; r.st[4 * q + 1] = v.y; r.st[4 * q + 2] = v.z; r.st[4 * q + 3] = v.w;
                 }
 #pragma unroll
-                for (int j = 0; j < SL::RT; ++j) {
+                for (int j = 0; j < RTLD; ++j) {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(DS_NT_TAIL)
                     r.st[4 * SL::NPF + j] = __builtin_nontemporal_load(&btail[tid * SL::RT + j]);
 #else
@@ -1624,7 +1694,12 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             const bool reset = (frm_cnt != 0) && (ell % p.mcra_L == 0);
             ex.phase([&](int tid, Rg& r) {
                 DS_SETPRIO(0);                                          // the wide, arithmetic-heavy phase yields to other workgroups' latency-bound ones
-                cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt, r.ad, r.apk, ref_pow_row(t));
+                StreamRef srf; const StreamRef* sr = nullptr;
+                if constexpr (STREAM_RYY) {
+                    srf.planes = &bins[NPLD * KP + tid]; srf.tail = &btail[tid * SL::RT]; srf.KP = KP;
+                    sr = &srf;
+                }
+                cf Yk = bin_program(r.st, r.Z, steer, tid, sh, p, frm_cnt, reset, spp_cnt, r.ad, r.apk, ref_pow_row(t), sr);
                 if (tid == 0) Yk.y = 0.0f;                              // irfft ignores Im Y[0] and Im Y[N/2]
                 sh.Y[tid] = Yk;
                 if constexpr (EARLY_STORE) {

@@ -198,7 +198,7 @@ def test_gsc_vs_reference_golden(ds, name):
 # ------------------------------------------------------------------------------------------------
 # oracle on seeded inputs, batched
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,nfft", [(4, 512), (2, 256), (6, 512), (8, 1024), (3, 256), (5, 1024), (3, 1024), (5, 256)])
+@pytest.mark.parametrize("M,nfft", [(4, 512), (2, 256), (6, 512), (8, 1024), (3, 256), (5, 1024), (3, 1024), (5, 256), (6, 1024)])
 def test_adaptive_batch_vs_oracle(ds, M, nfft):
     hop, B, T = nfft // 2, 5, 48
     r = 0.032 if M == 4 else 0.05
@@ -209,6 +209,25 @@ def test_adaptive_batch_vs_oracle(ds, M, nfft):
     for b in range(B):
         ref = O.OracleAdaptiveMVDR(omic, nfft, hop, nfft).process(xs[b], ANGLE, 2)
         assert rms(y[b] - ref) < 1e-5, (b, rms(y[b] - ref))
+
+
+def test_streamed_ryy_kernel_tfgsc_and_state(ds):
+    """ds_frames_kernel<1024, 6, ADAPTIVE, Ryy> streams Ryy through its HBM planes hop by hop instead of holding it (round 5: the kernel had
+    carried 60 B of scratch): TFGSC (which reads Ryy back column by column) and MVDR against the oracle, Ryy read back, one call == hop by hop."""
+    M, nfft, hop, B, T = 6, 1024, 512, 3, 30
+    omic = oracle_mic(M, nfft, 0.05)
+    xs = np.stack([O.synth_utterance(50 + b, hop * T, omic) for b in range(B)])
+    for method, bar in ((3, 2e-4), (2, 1e-5)):
+        ab = ds.adaptivebeamfomer(_mic(ds, M, nfft, 0.05), frameLen=nfft, hop=hop, nfft=nfft, batch=B)
+        y = ab.process(xs, ANGLE, method=method)["data"]
+        ab2 = ds.adaptivebeamfomer(_mic(ds, M, nfft, 0.05), frameLen=nfft, hop=hop, nfft=nfft, batch=B)
+        y2 = np.concatenate([ab2.process(xs[:, :, t * hop:(t + 1) * hop], ANGLE, method=method)["data"] for t in range(T)], axis=1)
+        assert np.array_equal(y, y2) and np.array_equal(ab._eng.export_state(), ab2._eng.export_state())
+        for b in (0, B - 1):
+            ref = O.OracleAdaptiveMVDR(omic, nfft, hop, nfft)
+            yr = ref.process(xs[b], ANGLE, method)
+            assert rms(y[b] - yr) < bar, (method, b, rms(y[b] - yr))
+            assert relmax(ab.Ryy[b], ref.Ryy) < 1e-5 and relmax(ab.Rvv[b], ref.Rvv) < 1e-4
 
 
 @pytest.mark.parametrize("M,nfft", [(2, 512), (3, 512), (4, 256), (5, 256), (5, 512), (6, 512)])

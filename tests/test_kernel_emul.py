@@ -59,6 +59,32 @@ def test_emul_mvdr_postfilter_one_pass(name):
     assert np.array_equal(y2, y[:n])
 
 
+@pytest.mark.parametrize("method", [2, 3])
+def test_emul_streamed_ryy_kernel(method):
+    """Engine<1024, 6, ADAPTIVE, Ryy>: Ryy is not held in registers across the hops of a call but passes through its HBM planes every hop
+    (StreamRef) — against the oracle (MVDR and TFGSC, which re-reads the columns it solves for), one call == hop by hop bit for bit with the
+    state, and the Ryy it leaves behind is the oracle's."""
+    from oracle import ds_oracle as O
+    from _cases import oracle_mic
+    M, nfft, hop, T = 6, 1024, 512, 24
+    omic = oracle_mic(M, nfft, 0.05)
+    x = O.synth_utterance(9, hop * T, omic).astype(np.float32)
+    a = steering(M, nfft, 0.05)
+    e = EmulEngine(1, nfft, M, 1, ryy=True); e.set_steering(a); e.method = method
+    y = e.process(x[None], 1)[0]
+    ref = O.OracleAdaptiveMVDR(omic, nfft, hop, nfft)
+    yr = ref.process(x, ANGLE, method)
+    assert rms(y - yr) < (2e-4 if method == 3 else 1e-5), rms(y - yr)
+    e2 = EmulEngine(1, nfft, M, 1, ryy=True); e2.set_steering(a); e2.method = method
+    y2 = np.concatenate([e2.process(x[None, :, t * hop:(t + 1) * hop], 1)[0] for t in range(T)])
+    assert np.array_equal(y, y2) and np.array_equal(e.bins, e2.bins)
+    ry0 = M * M + 5
+    Rd = np.stack([e.field(ry0 + i)[0] for i in range(M)], axis=1)                    # Ryy's diagonal as the streamed planes hold it
+    assert np.allclose(Rd, np.real(np.einsum("kii->ki", ref.Ryy)), rtol=2e-4, atol=1e-9)
+    off01 = e.field(ry0 + M)[0] + 1j * e.field(ry0 + M + 1)[0]
+    assert np.allclose(off01, ref.Ryy[:, 0, 1], rtol=2e-3, atol=1e-7)
+
+
 def test_emul_adaptive_chunking_and_layout():
     g = load("g4_adaptive_synth")
     x = as_float(g["x"])[:, : 256 * 30]
