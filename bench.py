@@ -455,7 +455,7 @@ def _profile_json(name):
         return None
 
 
-def attach_traffic(roof, key):
+def attach_traffic(roof, key, warn=True):
     """HBM bytes per step from the committed rocprofv3 PMC passes of this same command (profiles/traffic_latest.json).  PMC counters cannot be
     read inside this process, so the figure is the profile's, under its own keys (`traffic`, `frac_measured`, `traffic_profile`): the live
     `achieved` / `frac` are never replaced by it."""
@@ -468,7 +468,7 @@ def attach_traffic(roof, key):
     gbs = ent["hbm_bytes_per_launch"] / (roof["launch_ms"] * 1e-3) / 1e9
     roof["frac_measured"] = round(gbs / HBM_PEAK_GBS, 4)
     roof["traffic_over_bytes"] = round(ent["hbm_bytes_per_launch"] / roof["bytes_per_launch"], 4)
-    if abs(roof["traffic_over_bytes"] - 1.0) > 0.05 and not os.environ.get("DS_BENCH_BACKEND"):
+    if warn and abs(roof["traffic_over_bytes"] - 1.0) > 0.05 and not os.environ.get("DS_BENCH_BACKEND"):
         sys.stderr.write("bench.py: %s: committed PMC traffic is %.3f x this build's byte budget — profiles/traffic_latest.json is stale for "
                          "this build or the kernel moves bytes it should not\n" % (key, roof["traffic_over_bytes"]))
 
@@ -512,6 +512,8 @@ def compact_line(out, detail_path):
         c = {"value": e["value"], "ms_per_step": e["ms_per_step"]}
         if "valu" in e:
             c.update(bound="valu", frac=e["valu"]["frac_valu_issue"], frac_hbm=e["roofline"]["frac"])
+            if "traffic_over_algorithmic" in e["roofline"]:
+                c["traffic_x"] = e["roofline"]["traffic_over_algorithmic"]       # measured HBM bytes of a 10 s call / SURVEY 8(d)'s algorithmic bytes
         else:
             c.update(bound="hbm", frac=e["roofline"]["frac"])
             if "frac_measured" in e["roofline"]:
@@ -744,6 +746,11 @@ def main():
                 others[name] = {"workload": "%s: %s, batch=%d per GPU, 1 hop per call" % (name, wo["desc"], wo["batch"]),
                                 "value": ro["value"], "unit": "frames/s", "n_gpus": ro["ranks"], "steps": Ko, "rounds": ro["rounds"],
                                 "ms_per_step": ro["ms_per_step"], "roofline": ro["roofline"]}
+                if name == "nb_mvdr":
+                    # the notebook's online MVDR is bound by arithmetic at ANY call length (a 6 x 6 complex Jacobi eigen-solve and a Hermitian
+                    # inverse in double per bin and frame: 35 k vector instructions per wavefront and frame against 254 MB of traffic per step):
+                    # the per-frame instruction count is the 10 s profile's, the vector-issue fraction follows from this run's frame rate
+                    attach_compute(others[name], "nb_mvdr_10s_chunks", ro["value"] / max(1, ro["ranks"]))
         # (3) the BASELINE configs as SURVEY 8(d) words their inputs: 10 s per utterance in ONE call (625 hops at hop 256, 312 at hop 512;
         # cfg5's "10 s streaming chunks").  The carried state then moves once per chunk and the step is bound by the per-hop arithmetic /
         # LDS work of the kernels — the HBM fraction is reported for completeness, not as the limiter
@@ -756,6 +763,10 @@ def main():
                            "value": ro["value"], "unit": "frames/s", "n_gpus": ro["ranks"], "steps": 2, "rounds": ro["rounds"],
                            "ms_per_step": ro["ms_per_step"], "hops_per_call": Tc, "roofline": ro["roofline"]}
                     attach_compute(ent, name + "_10s_chunks", ro["value"] / max(1, ro["ranks"]))
+                    attach_traffic(ent["roofline"], name + "_10s_chunks", warn=False)      # HBM bytes a 10 s call really moves (committed PMC passes)
+                    if ent["roofline"].get("traffic"):
+                        alg_step = algorithmic_bytes_per_frame(wo, Tc) * wo["batch"] * Tc
+                        ent["roofline"]["traffic_over_algorithmic"] = round(ent["roofline"]["traffic"] / alg_step, 3)
                     others[name + "_10s_chunks"] = ent
         if rank == 0 and others:
             out["other_configs"] = others

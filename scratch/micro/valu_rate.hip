@@ -14,10 +14,11 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 enum { OP_FMA, OP_FMAC, OP_MUL, OP_ADD, OP_MOV, OP_PK_FMA, OP_PK_FMA_SEL, OP_PK_MUL, OP_PK_ADD, OP_RCP, OP_CNDMASK, OP_MIX_PK_ADD, OP_MIX_PK_FMA,
-       OP_LDS_R64, OP_LDS_W64, N_OPS };
+       OP_LDS_R64, OP_LDS_W64, OP_FMA64, OP_MUL64, OP_ADD64, OP_CVT64, N_OPS };
 static const char* names[] = {"v_fma_f32 (3 distinct srcs)", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_mov_b32", "v_pk_fma_f32", "v_pk_fma_f32 op_sel/neg",
                               "v_pk_mul_f32", "v_pk_add_f32", "v_rcp_f32", "v_cndmask_b32 (sgpr mask)", "v_pk_fma + v_add (per pair)",
-                              "v_pk_fma + v_fma (per pair)", "ds_read_b64", "ds_write_b64"};
+                              "v_pk_fma + v_fma (per pair)", "ds_read_b64", "ds_write_b64",
+                              "v_fma_f64", "v_mul_f64", "v_add_f64", "v_cvt_f64_f32"};
 
 template <int OP> __global__ void __launch_bounds__(256) rate(long long* out, int reps, float seed) {
     __shared__ f2 lds[256 * 9];
@@ -93,6 +94,29 @@ template <int OP> __global__ void __launch_bounds__(256) rate(long long* out, in
                     asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(b2));
                     asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(s[i + 16 * j]) : "v"(c), "v"(c2));
                 }
+        } else if constexpr (OP == OP_FMA64) {                // the notebook-MVDR operator's estimation core and eigen-solver run in double (ds_linalg64.hpp)
+            double cd_ = (double)c, cd2 = (double)c2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(*reinterpret_cast<double*>(&a[i])) : "v"(cd_), "v"(cd2));
+        } else if constexpr (OP == OP_MUL64) {
+            double cd_ = (double)c;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(*reinterpret_cast<double*>(&a[i])) : "v"(cd_));
+        } else if constexpr (OP == OP_ADD64) {
+            double cd_ = (double)c;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(*reinterpret_cast<double*>(&a[i])) : "v"(cd_));
+        } else if constexpr (OP == OP_CVT64) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(*reinterpret_cast<double*>(&a[i])) : "v"(s[i + 16 * j]));
         } else if constexpr (OP == OP_LDS_R64) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -155,5 +179,6 @@ int main() {
     run<OP_PK_FMA>(d_out, h); run<OP_PK_FMA_SEL>(d_out, h); run<OP_PK_MUL>(d_out, h); run<OP_PK_ADD>(d_out, h);
     run<OP_RCP>(d_out, h); run<OP_CNDMASK>(d_out, h); run<OP_MIX_PK_ADD>(d_out, h); run<OP_MIX_PK_FMA>(d_out, h);
     run<OP_LDS_R64>(d_out, h); run<OP_LDS_W64>(d_out, h);
+    run<OP_FMA64>(d_out, h); run<OP_MUL64>(d_out, h); run<OP_ADD64>(d_out, h); run<OP_CVT64>(d_out, h);
     return 0;
 }

@@ -23,12 +23,15 @@ out = {"source": "scripts/make_compute_latest.py (SQ counters: scripts/profile_b
 for spec in sys.argv[1:]:
     name, rest = spec.split("=", 1)
     pdir, frames = rest.rsplit(":", 1)
-    comp = json.load(open(os.path.join(pdir, "compute.json")))
+    # pdir: a profile directory of scripts/profile_bench.sh (compute.json, pmc_sq.log), or the prefix of its condensed copies
+    # (<prefix>_compute.json, <prefix>_pmc_sq_line.json: what scripts/profile_all.sh keeps and profiles/<round>/ holds)
+    condensed = not os.path.isdir(pdir)
+    comp = json.load(open(pdir + "_compute.json" if condensed else os.path.join(pdir, "compute.json")))
     frames = float(frames)
     ks = comp["kernels"]
     # bench steps of the profiled run: warm-up + the untimed round + the probe round + R timed rounds of K steps (bench.py measure()); the
     # run's own JSON line (pmc_sq.log) says K, W and R.  A step may be several launches of a kernel (utterance groups, 62-block pieces)
-    line = [x for x in open(os.path.join(pdir, "pmc_sq.log")).read().splitlines() if x.startswith("{")][-1]
+    line = [x for x in open(pdir + "_pmc_sq_line.json" if condensed else os.path.join(pdir, "pmc_sq.log")).read().splitlines() if x.startswith("{")][-1]
     bl = json.loads(line)
     steps = bl["warmup"] + bl["steps"] * (2 + bl["rounds"])
     ent = {"profile": os.path.relpath(pdir, ROOT), "frames_per_step": frames, "steps_profiled": steps, "kernels": {}}
