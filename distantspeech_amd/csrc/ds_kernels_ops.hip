@@ -494,6 +494,9 @@ template <int OPL> static void launch_fir_t(const TdParams& p, hipStream_t strea
 }
 hipError_t launch_fir(const TdParams& p, hipStream_t stream) {
     if (p.M > FIR_MMAX || p.L > FIR_LMAX || p.L < 1) return hipErrorInvalidValue;
+    // (round 5 tried the channels two at a time as packed pairs — window words {x_m, x_m+1}, taps {c_m, c_m+1}: one v_pk_fma_f32 per two
+    // multiply-adds by construction.  Bit-identical, and +1.7 % for cfg5 in both regimes, -0.3 % for the 4-channel chains: the compiler
+    // already packs the multiply-adds of neighbouring outputs in this kernel.  scratch/shelved_r05/, profiles/r05a/fir_pairs_ab.txt)
     if (p.n > 256) launch_fir_t<8>(p, stream); else launch_fir_t<4>(p, stream);
     return hipGetLastError();
 }
