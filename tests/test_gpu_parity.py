@@ -77,7 +77,7 @@ def test_mvdr_postfilter_one_pass_vs_reference_golden(ds, name):
              Phi_vv_rel_rms=rms(ab.spp.Phi_vv - g["Phi_vv"]) / rms(g["Phi_vv"]), Phi_yy_rel_rms=rms(ab.spp.Phi_yy - g["Phi_yy"]) / rms(g["Phi_yy"]),
              mcra_p_frac_gt_1e3=np.mean(dp > 1e-3), H_kernel_rel_rms=0.0)
     measured("G23_mvdr_pf_" + name, **m)
-    assert m["y_rms"] < TOL_RMS and m["y_rms"] < 1e-5, m
+    assert m["y_rms"] < TOL_RMS and m["y_rms"] < 2e-5, m                   # measured 1.8e-6, 7.2e-6, 2.1e-6, 1.5e-7 (profiles/r05_parity_measured.jsonl)
     assert m["Rvv_relmax"] < 7e-6 and m["Phi_yy_rel_rms"] < 1e-5 and m["Phi_vv_rel_rms"] < 3e-3 and m["mcra_p_frac_gt_1e3"] < 0.002, m
     ab2 = ds.adaptivebeamfomer(_mic(ds, M, nfft, float(g["r"])), frameLen=nfft, hop=hop, nfft=nfft, postfilter="mcmcra")
     assert np.array_equal(ab2.process(x, ANGLE, method=method)["data"], y)          # one call == hop by hop, bit for bit
