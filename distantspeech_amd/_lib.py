@@ -28,6 +28,7 @@ ALGO_MCSPP_MVDR = 24
 PARAM_POSTFILTER = 15
 PARAM_TAIL_ASYNC = 17
 PARAM_REF_POWERS = 18
+PARAM_WPE_FP64 = 19
 PARAM_FDAF_TWO_PATH = 16
 CHAIN_AUX_FIR, CHAIN_AUX_COHERENCE = 0, 1
 PARAM_WPE_DELAY = 13
@@ -44,6 +45,7 @@ PARAM_METHOD, PARAM_MCRA_L, PARAM_ALPHA_Y, PARAM_ALPHA_V, PARAM_DIAG, PARAM_GATE
  FIELD_PHI_YY, FIELD_PHI_VV, FIELD_G_AIC, FIELD_STFT_TAIL, FIELD_OLA_TAIL, FIELD_COUNTERS, FIELD_OP_STATE, FIELD_NOTCH_MEM) = range(1, 16)
 FIELD_H = 16
 FIELD_REF_POWERS = 17
+FIELD_WPE_STATE64 = 18
 
 
 class ds_config(ctypes.Structure):

@@ -66,7 +66,8 @@ int zero_state(ds_handle* h) {
         // awpe.py:58-77: P = I * 1e-3, everything else zero — on the device (the state of a wide filter is gigabytes: 3.8 MB per utterance
         // at 4 channels x 20 taps, 129 bins)
         DS_HIP(h, ds::launch_wpe_init(h->opst, h->cfg.batch, h->K, (long long)op_ust(h), h->cfg.n_mics, h->filter_len, h->stream));
-        h->op_frm = 0; h->op_ell = 1; h->op_first = 1;
+        if (h->wpe64) DS_HIP(h, ds::launch_wpe64_init(h->wpe64, h->cfg.batch, h->K, (long long)wpe64_ust(h), h->cfg.n_mics, h->filter_len, h->stream));
+        h->op_frm = 0; h->op_ell = 1; h->op_first = 1; h->wpe_started = false;
     } else if (h->op >= 0 && h->NF > 0) {
         // operator state: zeros, except the rows the reference initialises to non-zero values
         std::vector<float> st((size_t)h->cfg.batch * op_ust(h), 0.0f);
@@ -392,7 +393,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->ki_rows = KernelInfo{nullptr, 0, 0, 0}; h->ki_rows_istft = h->ki_rows; h->ki_aic = h->ki_rows; h->ki_cdr = h->ki_rows; h->front_fused = false;
     if (cfg->algo == DS_ALGO_TRANSFORM && cfg->n_mics == 1 && cfg->hop * 2 == cfg->nfft) { h->ki_rows = ds::lookup_stft_rows(cfg->nfft); h->ki_rows_istft = ds::lookup_istft_rows(cfg->nfft); }
  h->opst = nullptr; h->NF = NF;
-    h->op_frm = 0; h->op_ell = 1; h->op_first = 1;
+    h->op_frm = 0; h->op_ell = 1; h->op_first = 1; h->wpe_started = false;
     h->filter_len = flen; h->norm = cfg->no_norm ? 0 : 1;
     h->filt_mu = cfg->filt_mu > 0 ? cfg->filt_mu : (cfg->algo == DS_ALGO_SUBRLS ? 0.5f : 0.1f);
     h->filt_alpha = cfg->filt_alpha > 0 ? cfg->filt_alpha : 0.9f;
@@ -409,7 +410,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     for (int i = 0; i < 24; ++i) { h->chain_buf[i] = nullptr; h->chain_bytes[i] = 0; }
     h->postfilter = 0;
     h->owns_stream = true; h->wpe_delay = 4; h->hist_cur = 0; h->group_enqueue = false;
-    h->wpe_only = cfg->algo == DS_ALGO_WPE_TD;
+    h->wpe_only = cfg->algo == DS_ALGO_WPE_TD; h->wpe64 = nullptr;
     { const char* e = getenv("DS_WPE_GENERIC"); h->wpe_generic = (e && e[0] == '1') ? 1 : 0; }
     h->td_mem = nullptr; h->td_cache[0] = h->td_cache[1] = nullptr; h->td_L = 0; h->td_cur = 0;
     h->method = DS_METHOD_MVDR;
@@ -615,7 +616,7 @@ int ds_destroy(ds_handle* h) {
     (void)hipFree(h->x_stage); (void)hipFree(h->y_stage); (void)hipFree(h->opst);
     for (int i = 0; i < 10; ++i) (void)hipFree(h->dev_buf[i]);
     (void)hipFree(h->tdf_w); (void)hipFree(h->tdf_buf); (void)hipFree(h->tdf_P);
-    (void)hipFree(h->td_mem); (void)hipFree(h->td_cache[0]); (void)hipFree(h->td_cache[1]);
+    (void)hipFree(h->td_mem); (void)hipFree(h->td_cache[0]); (void)hipFree(h->td_cache[1]); (void)hipFree(h->wpe64);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     for (int i = 0; i < 8; ++i) if (h->group_exec[i]) (void)hipGraphExecDestroy(h->group_exec[i]);
     for (int i = 0; i < 7; ++i) { if (h->side[i]) (void)hipStreamDestroy(h->side[i]); if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]); }
@@ -673,6 +674,22 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
         if (rc) return fail(h, rc, h->sub[3]->err);
     }
     switch (id) {
+        case DS_PARAM_WPE_FP64: {
+            ds_handle* t = wpe_chain(h) ? h->sub[1] : h;
+            if (!t || t->cfg.algo != DS_ALGO_WPE) return fail(h, DS_EINVAL, "wpe fp64: DS_ALGO_WPE / DS_ALGO_WPE_TD / DS_ALGO_WPE_MVDR handles only");
+            if (t->wpe_started) return fail(h, DS_ESTATE, "wpe fp64 must be set before the first frame (or after ds_reset)");
+            int rc = set_device(h); if (rc) return rc;
+            DS_HIP(h, hipStreamSynchronize(t->stream));
+            if (value == 0) { (void)hipFree(t->wpe64); t->wpe64 = nullptr; return DS_OK; }
+            if (!t->wpe64) {
+                const size_t bytes = (size_t)t->cfg.batch * wpe64_ust(t) * sizeof(double);
+                DS_HIP(h, hipMalloc((void**)&t->wpe64, bytes));
+            }
+            DS_HIP(h, ds::launch_wpe64_init(t->wpe64, t->cfg.batch, t->K, (long long)wpe64_ust(t), t->cfg.n_mics, t->filter_len, t->stream));
+            DS_HIP(h, hipStreamSynchronize(t->stream));
+            h->graph_valid = false;
+            return DS_OK;
+        }
         case DS_PARAM_WPE_DELAY:
             if (!wpe_chain(h) || value < 0 || value > 64) return fail(h, DS_EINVAL, "wpe delay: chain handles only, 0..64 frames");
             if (h->chain_buf[6]) return fail(h, DS_ESTATE, "wpe delay must be set before the first call");
@@ -1123,6 +1140,7 @@ size_t ds_field_bytes(const ds_handle* h, int field) {
             if (h->tdf_w) return (size_t)h->cfg.batch * h->cfg.filter_len * sizeof(float);
             return opst_bytes(h);
         case DS_FIELD_NOTCH_MEM: return h->td_mem ? B * M * 2 * sizeof(float) : 0;
+        case DS_FIELD_WPE_STATE64: return wpe64_bytes(h);
         case DS_FIELD_H: return (ad && h->method != DS_METHOD_TFGSC) ? B * K * M * 2 * sizeof(float) : 0;
         case DS_FIELD_REF_POWERS: return (gsc && h->ref_powers) ? B * (size_t)h->ref_pow_T * K * M * sizeof(float) : 0;
         default: return 0;
@@ -1153,6 +1171,7 @@ int ds_get_state(ds_handle* h, int field, void* dst, size_t bytes) {
         for (size_t i = 0; i < m.size(); ++i) ((float*)dst)[i] = (float)m[i];
         return DS_OK;
     }
+    if (field == DS_FIELD_WPE_STATE64) { DS_HIP(h, hipMemcpy(dst, h->wpe64, need, hipMemcpyDeviceToHost)); return DS_OK; }
     if (field == DS_FIELD_REF_POWERS) {
         if (h->ref_pow_stream && h->ref_pow_stream != h->stream) DS_HIP(h, hipStreamSynchronize(h->ref_pow_stream));   // the launch that wrote them
         DS_HIP(h, hipMemcpy(dst, h->ref_pow, need, hipMemcpyDeviceToHost));
@@ -1240,6 +1259,7 @@ static int extra_state(const ds_handle* h, ExtraState out[3]) {
         out[n++] = {h->td_mem, B * M * 2 * sizeof(double)};
         if (h->td_L > 1) out[n++] = {h->td_cache[h->td_cur], B * (size_t)(h->td_L - 1) * M * sizeof(float)};
     }
+    if (h->wpe64) out[n++] = {h->wpe64, wpe64_bytes(h)};
     if (h->tdf_w) {
         out[n++] = {h->tdf_w, B * Lf * sizeof(float)};
         out[n++] = {h->tdf_buf, B * Lf * sizeof(float)};
@@ -1258,7 +1278,7 @@ static const int32_t BLOB_LAYOUT = DS_STATE_LAYOUT;      // 3: operator state as
 static BlobHeader blob_header(const ds_handle* h) {
     uint32_t osb;
     std::memcpy(&osb, &h->out_scale, sizeof osb);
-    const int32_t modes = (h->fdaf_two_path ? 1 : 0) | (h->mcspp_repeat ? 2 : 0) | (h->x_fan > 1 ? 4 : 0) | (h->p_complement ? 8 : 0);
+    const int32_t modes = (h->fdaf_two_path ? 1 : 0) | (h->mcspp_repeat ? 2 : 0) | (h->x_fan > 1 ? 4 : 0) | (h->p_complement ? 8 : 0) | (h->wpe64 ? 16 : 0);
     return BlobHeader{BLOB_MAGIC, (uint32_t)DS_VERSION, h->cfg.algo, h->cfg.nfft, h->cfg.hop, h->cfg.n_mics, h->cfg.batch, h->filter_len, h->td_L,
                       h->cfg.track_ryy, BLOB_LAYOUT, modes, h->wpe_delay, osb};
 }
@@ -1421,6 +1441,7 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
         for (int i = 0, k = extra_state(h, ex); i < k; ++i) { DS_HIP(h, hipMemcpy(ex[i].ptr, s, ex[i].bytes, hipMemcpyHostToDevice)); s += ex[i].bytes; }
     }
     h->op_frm = uc[0]; h->op_ell = uc[1]; h->op_first = uc[2]; h->hist_cur = uc[3];
+    h->wpe_started = true;                                  // an imported stream is a started one
     rc = sync_dev_cnt(h); if (rc) return rc;
     h->graph_valid = false;
     for (int i = 0; i < 10; ++i)

@@ -131,6 +131,15 @@ int wpe_launch(ds_handle* h, int b0, int nb, const float* x_delayed, const float
     p.ustride = (long long)op_ust(h);
     p.state = h->opst + (size_t)b0 * p.ustride;
     p.ring = ring; p.ring_pos = ring_pos; p.ring_len = ring_len; p.dev_ring_pos = dev_ring_pos; p.err0 = err0;
+    h->wpe_started = true;                                  // DS_PARAM_WPE_FP64 is refused from here until ds_reset
+    if (h->wpe64) {                                        // DS_PARAM_WPE_FP64: the whole recursion in double (ds_wpe64.hpp)
+        ds::Wpe64Params q;
+        q.w = p;
+        q.ustride64 = (long long)wpe64_ust(h); q.lam64 = ds::wpe64_lambda(h->rls_lambda);
+        q.state64 = h->wpe64 + (size_t)b0 * q.ustride64;
+        DS_HIP(h, ds::launch_wpe64(q, stream));
+        return DS_OK;
+    }
     if (p.C * p.N > ds::WPE_CNMAX) DS_HIP(h, ds::launch_wpe_wide(p, h->wpe_generic, stream));     // wide prediction filters: one wavefront per bin
     else DS_HIP(h, ds::launch_wpe(p, h->wpe_generic, stream));
     return DS_OK;

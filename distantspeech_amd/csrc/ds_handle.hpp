@@ -16,6 +16,7 @@
 #include "ds_ops.hpp"
 #include "ds_tdfilter.hpp"
 #include "ds_fdaf.hpp"
+#include "ds_wpe64.hpp"
 #include "ds_tables.hpp"
 
 using ds::cf;
@@ -50,6 +51,7 @@ struct ds_handle {
     int op;                     // ds::OP_* or -1
     float* opst;                // operator state [B][NF][KP]
     int NF;
+    bool wpe_started;               // OP_WPE: frames went through since creation / ds_reset (or a state was imported)
     int op_frm, op_ell, op_first;   // uniform counters of the operator handle (host mirror; authoritative for host-side decisions)
     int* dev_cnt;               // device copy {frm, ell, first, aux}: aux = FIR ping-pong parity (front end) / WPE ring position (chain)
     bool use_dev_cnt;           // kernels read the counters from dev_cnt and a tick kernel follows every launch (stages of a chain handle: the
@@ -72,6 +74,7 @@ struct ds_handle {
     bool owns_stream;
     int wpe_delay;
     bool wpe_only;              // DS_ALGO_WPE_TD: analysis -> delay line -> WPE -> synthesis of channel 0 (no McMcra / MVDR stages)
+    double* wpe64;              // DS_PARAM_WPE_FP64 (DS_ALGO_WPE): the recursion's state in double, [B][K][wpe64_bin_doubles] (ds_wpe64.hpp); null = fp32 kernels
     int wpe_generic;            // DS_WPE_GENERIC=1 at ds_create: every WPE shape through the run-time-shape kernels (A/B and tests)
     float* chain_buf[24];       // WPE_MVDR: D, -, E, p, G, Y, ring of the last wpe_delay analysis frames; SUBBAND_GSC: see chain2_reserve
     size_t chain_bytes[24];
@@ -148,6 +151,8 @@ size_t tail_out_bytes(const ds_handle* h);
 size_t opst_bytes(const ds_handle* h);
 // floats between the utterances of an operator handle's state: NF rounded up to whole float4 planes (ds_ops.hpp: st_index) times KP
 inline bool wpe_chain(const ds_handle* h) { return h->cfg.algo == DS_ALGO_WPE_MVDR || h->cfg.algo == DS_ALGO_WPE_TD; }
+inline size_t wpe64_ust(const ds_handle* h) { return (size_t)h->K * (size_t)ds::wpe64_bin_doubles(h->cfg.n_mics, h->filter_len); }   // doubles between utterances
+inline size_t wpe64_bytes(const ds_handle* h) { return h->wpe64 ? (size_t)h->cfg.batch * wpe64_ust(h) * sizeof(double) : 0; }
 inline size_t op_ust(const ds_handle* h) { return (size_t)ds::st_floats_per_bin(h->NF) * h->KP; }
 size_t counters_bytes(const ds_handle* h);
 int set_device(ds_handle* h);

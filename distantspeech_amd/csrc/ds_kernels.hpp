@@ -52,6 +52,9 @@ hipError_t launch_mcspp_qavg(const float* gamma, float* out, int rows, int K, hi
 struct WpeParams;
 hipError_t launch_wpe(const WpeParams& p, int generic, hipStream_t stream);          // C N <= 16 (ds_wpe.hpp)
 hipError_t launch_wpe_wide(const WpeParams& p, int generic, hipStream_t stream);     // 16 < C N <= 80: one wavefront per bin (ds_kernels_wpe.hip)
+struct Wpe64Params;
+hipError_t launch_wpe64(const Wpe64Params& p, hipStream_t stream);                   // the whole recursion in double (ds_wpe64.hpp, DS_PARAM_WPE_FP64)
+hipError_t launch_wpe64_init(double* state, int B, int K, long long ustride, int C, int N, hipStream_t stream);
 hipError_t launch_wpe_init(float* state, int B, int K, long long ustride, int C, int N, hipStream_t stream);
 hipError_t launch_wpe_fix_diag(float* state, int B, int K, long long ustride, int C, int N, hipStream_t stream);   // Im(P_ii) = 0 (an imported state)   // P = 1e-3 I, the rest zero (awpe.py:58-77)
 hipError_t launch_mvdr_probe(int M, const float* bins, long long ust, int KP, int NF, int B, int K, const float* steer, long long steer_batch_stride,

@@ -2,6 +2,7 @@
 // Two wavefronts per SIMD (eight per CU): the 80 x 80 matrix is 200 registers per lane, the tile 13 KB of LDS per wavefront.
 #include "ds_kernels.hpp"
 #include "ds_wpe_wide.hpp"
+#include "ds_wpe64.hpp"
 
 namespace ds {
 
@@ -30,6 +31,38 @@ hipError_t launch_wpe_wide(const WpeParams& p, int generic, hipStream_t stream) 
     if (CN <= 64) DS_WPEW(64, 2);
     DS_WPEW(80, 2);
 #undef DS_WPEW
+}
+
+// the double-precision recursion (ds_wpe64.hpp, DS_PARAM_WPE_FP64): one workgroup per (utterance, bin), the whole matrix in LDS
+template <int CNP> __global__ void __launch_bounds__(WPE64_NT) ds_wpe64_kernel(Wpe64Params p) {
+    typedef Wpe64Engine<CNP> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+hipError_t launch_wpe64(const Wpe64Params& p, hipStream_t stream) {
+    const int CN = p.w.C * p.w.N;
+    const long long blocks = (long long)p.w.B * p.w.K;
+    if (CN < 1 || CN > WPEW_CNMAX || p.w.C > WPE_CMAX || blocks <= 0 || blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (CN <= 16) hipLaunchKernelGGL(ds_wpe64_kernel<16>, dim3((unsigned)blocks), dim3(WPE64_NT), 0, stream, p);
+    else if (CN <= 32) hipLaunchKernelGGL(ds_wpe64_kernel<32>, dim3((unsigned)blocks), dim3(WPE64_NT), 0, stream, p);
+    else hipLaunchKernelGGL(ds_wpe64_kernel<80>, dim3((unsigned)blocks), dim3(WPE64_NT), 0, stream, p);
+    return hipGetLastError();
+}
+// its initial state: P = 1e-3 I, everything else zero (awpe.py:58-77)
+__global__ void __launch_bounds__(256) ds_wpe64_init_kernel(double* state, long long n, int K, long long ustride, long long SB, int CN) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
+    const int i = (int)(g % CN);
+    const long long bk = g / CN, b = bk / K, k = bk - b * K;
+    state[b * ustride + k * SB + 2 * ((long long)i * CN + i)] = 1e-3;
+}
+hipError_t launch_wpe64_init(double* state, int B, int K, long long ustride, int C, int N, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(state, 0, (size_t)B * (size_t)ustride * sizeof(double), stream);
+    if (e != hipSuccess) return e;
+    const long long n = (long long)B * K * C * N;
+    hipLaunchKernelGGL(ds_wpe64_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, state, n, K, ustride, wpe64_bin_doubles(C, N), C * N);
+    return hipGetLastError();
 }
 
 // P = 1e-3 I (the diagonal words of the packed triangle, awpe.py:69-73) on a zeroed state: one thread per (utterance, bin, tap)

@@ -525,6 +525,15 @@ class BatchEngine:
         L.check(self._lib.ds_chain_stage_state(self._h, int(i), field, out.ctypes.data_as(ctypes.c_void_p), nbytes), self._h)
         return out.reshape(self.batch, -1)
 
+    def stage_state_f64(self, i, field):
+        """a float64 state field of stage i of a chain handle (DS_FIELD_WPE_STATE64), flat per utterance"""
+        nbytes = self._lib.ds_chain_stage_field_bytes(self._h, int(i), int(field))
+        if nbytes == 0:
+            raise AttributeError("stage %d has no state field %d" % (i, field))
+        out = np.empty(nbytes // 8, dtype=np.float64)
+        L.check(self._lib.ds_chain_stage_state(self._h, int(i), int(field), out.ctypes.data_as(ctypes.c_void_p), nbytes), self._h)
+        return out.reshape(self.batch, -1)
+
     def export_state(self):
         n = self._lib.ds_state_bytes(self._h)
         buf = np.empty(n, dtype=np.uint8)

@@ -608,14 +608,22 @@ class Wpe(_SubbandBase):
     hop_length=64); hop_length = num_bands / 2 or num_bands / 4."""
 
     def __init__(self, channels=2, filter_len=2, num_bands=512, forgetting_factor=0.998, delay=4, mu=0.5,
-                 normalization=True, alpha=0.9, m=2, hop_length=None, input_td=False, batch=1, device=-1):
+                 normalization=True, alpha=0.9, m=2, hop_length=None, input_td=False, batch=1, device=-1, precision="single"):
+        """precision="double" (not in the reference's signature): the RLS recursion — P, W, the tap buffer, var — in double like the
+        reference's complex128 arrays (awpe.py:60-71) instead of fp32 (DS_PARAM_WPE_FP64, csrc/ds_wpe64.hpp): several times slower, for
+        stationary strongly reverberant streams where the fp32 recursion's eps x cond(P) shows (5e-4 of the output at cond(P) = 2.6e5)."""
         self.channels, self.filter_len, self.half_band, self.batch = channels, filter_len, int(num_bands / 2) + 1, int(batch)
         self.hop_length = int(num_bands / 2) if hop_length is None else hop_length
         self.D = delay
         self.forgetting_factor = forgetting_factor
+        if precision not in ("single", "double"):
+            raise ValueError("precision must be 'single' or 'double'")
+        self.precision = precision
         self._eng = BatchEngine(L.ALGO_WPE_TD, channels, num_bands, hop=self.hop_length, batch=batch, device=device,
                                 filter_len=filter_len, rls_lambda=forgetting_factor)
         self._eng.set_wpe_delay(delay)
+        if precision == "double":
+            self._eng.set_param_i(L.PARAM_WPE_FP64, 1)
 
     def update(self, x_n, alpha=1e-4, p=None):
         """x_n [hop, channels] float (or any multiple of hop samples: successive hops, bit for bit the hop-by-hop result)
@@ -634,8 +642,19 @@ class Wpe(_SubbandBase):
         raw = self._eng.stage_state_raw(1).reshape(self.batch, -1)[:, : self.half_band * SB].reshape(self.batch, self.half_band, SB)
         return raw[:, :, : SB & ~1].copy().view(np.complex64)
 
+    def _blocks64(self):
+        """the double-precision state (DS_FIELD_WPE_STATE64): (P [B, K, CN, CN], W [B, K, C, CN]) complex128"""
+        C, CN, K = self.channels, self.channels * self.filter_len, self.half_band
+        sb = 2 * CN * CN + 2 * C * CN + 2 * CN + 2
+        raw = self._eng.stage_state_f64(1, L.FIELD_WPE_STATE64).reshape(self.batch, K, sb)
+        P = raw[:, :, : 2 * CN * CN].copy().view(np.complex128).reshape(self.batch, K, CN, CN)
+        W = raw[:, :, 2 * CN * CN: 2 * CN * CN + 2 * C * CN].copy().view(np.complex128).reshape(self.batch, K, C, CN)
+        return P, W
+
     @property
     def W(self):
+        if self.precision == "double":
+            return self._sq(self._blocks64()[1])
         C, CN = self.channels, self.channels * self.filter_len
         w0 = wpe_block_layout(C, self.filter_len)["w0"]
         w = self._blocks()[:, :, w0:w0 + C * CN].reshape(self.batch, self.half_band, C, CN)
@@ -643,6 +662,8 @@ class Wpe(_SubbandBase):
 
     @property
     def P(self):
+        if self.precision == "double":
+            return self._sq(self._blocks64()[0])
         CN = self.channels * self.filter_len
         blk = self._blocks()
         P = np.zeros((self.batch, self.half_band, CN, CN), dtype=np.complex128)

@@ -192,6 +192,10 @@ typedef struct ds_config {
                                          omlsa_multi.estimation in GSC.process (GSC.py:281-283; the reference computes that estimate and uses nothing of
                                          it).  Read with ds_get_state(DS_FIELD_REF_POWERS) after the call.  One plain call at a time: sequences of several
                                          calls, hipGraph replays and utterance groups are refused while it is on; default 0 */
+#define DS_PARAM_WPE_FP64 19         /* int 0/1, before the first frame, DS_ALGO_WPE / DS_ALGO_WPE_TD / DS_ALGO_WPE_MVDR: run the RLS-WPE recursion (P, W, taps, var) in
+                                         double like the reference's complex128 (awpe.py:60-71,181-186) instead of fp32 — one workgroup per (utterance,
+                                         bin), several times slower and four times the state bytes: for streams where the fp32 recursion's
+                                         eps x cond(P) matters (csrc/ds_wpe64.hpp).  State read-back: DS_FIELD_WPE_STATE64 */
 #define DS_PARAM_POSTFILTER 15       /* int 0/1: DS_ALGO_TDGSC / DS_ALGO_FDGSC handles apply the OMLSA post-filter in ds_process_device; default 0 */
 #define DS_PARAM_SPLIT 8   /* int 1..8: utterance groups.  Fused frame kernels: ds_process_device_seq runs the utterance range as that many groups,
                               each on its own stream at its own pace (its own hipGraph with graph=1); default 2 from 2048 utterances up, else 1.
@@ -218,6 +222,7 @@ typedef struct ds_config {
                                  (adaptivebeamformer.py:105-112: H[:, k]), computed by the kernel's own fused Cholesky solve on the handle's Rvv —
                                  a read-only probe; needs ds_set_steering */
 #define DS_FIELD_REF_POWERS 17 /* DS_ALGO_GSC with DS_PARAM_REF_POWERS: [B][T][K][M] of the LAST call (T = its hops): [0] = |Y|^2, [1 + i] = |U_i|^2 */
+#define DS_FIELD_WPE_STATE64 18 /* DS_ALGO_WPE with DS_PARAM_WPE_FP64: float64 [B][K][2 CN CN + 2 C CN + 2 CN + 2]: P row-major, W [C][CN], taps, var, pad (csrc/ds_wpe64.hpp) */
 #define DS_FIELD_NOTCH_MEM 15 /* DS_ALGO_FRONTEND: [B][M][2] the DC notch memories (FilterDcNotch16.notch_mem, feature.py:34,47) */
 
 int ds_version(void);

@@ -13,6 +13,7 @@
 #include "../../distantspeech_amd/csrc/ds_tdfilter.hpp"
 #include "../../distantspeech_amd/csrc/ds_fdaf.hpp"
 #include "../../distantspeech_amd/csrc/ds_wpe_wide.hpp"
+#include "../../distantspeech_amd/csrc/ds_wpe64.hpp"
 
 namespace {
 
@@ -572,5 +573,27 @@ int emul_fdaf(int nfft, int B, int T, int C, int kind, int constrain, int non_ca
     FD(128) FD(256) FD(512) FD(1024)
 #undef FD
     return -1;
+}
+
+// the RLS-WPE recursion in double (ds_wpe64.hpp): state [B][K][wpe64_bin_doubles] doubles, inputs / outputs complex64 as the fp32 kernels'
+int emul_wpe64(int B, int K, int T, int C, int N, const float* xd, const float* d, float* err, double* state, float lam,
+               float* ring, int ring_pos, int ring_len) {
+    ds::Wpe64Params q;
+    std::memset(&q, 0, sizeof q);
+    q.w.B = B; q.w.K = K; q.w.T = T; q.w.C = C; q.w.N = N; q.w.xd = xd; q.w.d = d; q.w.err = err; q.w.lam = lam;
+    q.w.ring = ring; q.w.ring_pos = ring_pos; q.w.ring_len = ring_len;
+    q.state64 = state; q.ustride64 = (long long)K * ds::wpe64_bin_doubles(C, N); q.lam64 = ds::wpe64_lambda(lam);
+    const int CN = C * N;
+    if (CN < 1 || CN > ds::WPEW_CNMAX || C > ds::WPE_CMAX) return -1;
+    typedef ds::Wpe64Engine<80> E;
+    E::Sh* sh = new E::Sh();
+    for (int g = 0; g < B * K; ++g) {
+        CpuExec<E::Rg> ex;
+        ex.nt = E::NT;
+        ex.R.resize(E::NT);
+        E::run(ex, q, g, *sh);
+    }
+    delete sh;
+    return 0;
 }
 }

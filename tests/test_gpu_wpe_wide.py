@@ -152,6 +152,75 @@ def test_wpe_wide_30_s_stream(ds):
     assert rel[-1] < 1.3 * max(rel[-8:-4])                                         # ... and level over the last 8 s: no drift
 
 
+def test_wpe_double_precision_recursion_30_s_stream(ds):
+    """DS_PARAM_WPE_FP64: the same 32 s stationary, strongly reverberant stream at FOUR times the level of the fp32 test (0.2 RMS) with the
+    recursion in double (ds_wpe64.hpp): the worst 250-frame segment within 1e-4 of the fp64 oracle's output RELATIVE to it (VERDICT r4 item 4b;
+    the fp32 kernel sits at 5 - 7e-4 there), one call == frame by frame bit for bit, checkpoint / resume, and the fp32 kernels untouched."""
+    from oracle import ds_oracle as O
+    from distantspeech_amd import _lib as L
+    C, N, nb, hop, dl = 4, 20, 256, 64, 4
+    x = reverberant(11, 16000 * 32, C)
+    x = x * (0.2 / rms(x))
+    Dn = O.OracleTransform(channel=C, n_fft=nb, hop_length=hop).stft(x)
+    ks = np.linspace(1, nb // 2 - 1, 17).astype(int)
+    D = np.ascontiguousarray(Dn[ks].transpose(1, 0, 2))
+    T = D.shape[0]
+    Xd = np.concatenate([np.zeros((dl, 17, C), complex), D[:-dl]])
+    eng = ds.BatchEngine(L.ALGO_WPE, C, 32, batch=1, filter_len=N, rls_lambda=0.998)
+    eng.set_param_i(L.PARAM_WPE_FP64, 1)
+    o = O.OracleWpe(channels=C, filter_len=N, num_bands=32, delay=dl)
+    rel = []
+    for a in range(0, T, 250):
+        b = min(T, a + 250)
+        err = eng.wpe_update(Xd[None, a:b], D[None, a:b])[0]
+        ref = np.stack([o.update_fd(Xd[t].astype(np.complex64), D[t].astype(np.complex64)) for t in range(a, b)])
+        assert np.all(np.isfinite(err))
+        rel.append(rms(err - ref) / rms(ref))
+    measured("wpe_fp64_32s_stream", worst_segment_rel=max(rel), last_segment_rel=rel[-1], input_rms=rms(x[:, 0]), frames=T)
+    assert T >= 7500 and max(rel) < 1e-4, max(rel)                 # (the outputs are rounded to complex64: 3e-8 relative is the floor)
+    with pytest.raises(Exception):
+        eng.set_param_i(L.PARAM_WPE_FP64, 0)                       # not in the middle of a stream
+    # one call == frame by frame, bit for bit, with the exported state; a checkpoint of one mode is refused by the other
+    rng = np.random.default_rng(3)
+    Dr = ((rng.standard_normal((2, 9, 17, C)) + 1j * rng.standard_normal((2, 9, 17, C))) * 0.3).astype(np.complex64)
+    Xr = np.concatenate([np.zeros((2, dl, 17, C), np.complex64), Dr[:, :-dl]], axis=1)
+    def make(fp64=True):
+        e = ds.BatchEngine(L.ALGO_WPE, C, 32, batch=2, filter_len=N, rls_lambda=0.998)
+        if fp64:
+            e.set_param_i(L.PARAM_WPE_FP64, 1)
+        return e
+    e1, e2 = make(), make()
+    y1 = e1.wpe_update(Xr, Dr)
+    y2 = np.concatenate([e2.wpe_update(Xr[:, t:t + 1], Dr[:, t:t + 1]) for t in range(9)], axis=1)
+    assert np.array_equal(y1, y2) and np.array_equal(e1.export_state(), e2.export_state())
+    e3 = make()
+    e3.wpe_update(Xr[:, :4], Dr[:, :4])
+    blob = e3.export_state()
+    e4 = make()
+    e4.import_state(blob)
+    assert np.array_equal(e4.wpe_update(Xr[:, 4:], Dr[:, 4:]), y1[:, 4:])
+    with pytest.raises(Exception):
+        make(fp64=False).import_state(blob)
+    y32 = make(fp64=False).wpe_update(Xr, Dr)
+    assert rms(y32 - y1) < 1e-5 * rms(y1) and not np.array_equal(y32, y1)          # the fp32 kernel: close, not the same program
+
+
+def test_wpe_update_double_precision_through_the_mirror(ds):
+    """Wpe(precision="double").update: ONE native call per hop like the default, against the patched reference's fixture (G21, 4 x 20 at 256 / 64):
+    output, W and P from the double state."""
+    g = load("g21_wpe_nb_c4n20")
+    C, N, D, nb, hop = [int(v) for v in g["params"]]
+    x = as_float(g["x"]).T
+    wpe = ds.Wpe(channels=C, mu=1e-4, forgetting_factor=0.998, filter_len=N, delay=D, num_bands=nb, hop_length=hop, precision="double")
+    y = np.concatenate([wpe.update(x[n * hop:(n + 1) * hop])[0] for n in range(x.shape[0] // hop)])
+    kk, kp = g["bins"], g["bins_P"]
+    W, P = wpe.W, wpe.P
+    e_y, e_W, e_P = rms(y - g["y"]), rms(W[kk] - g["W"]) / rms(g["W"]), rms(P[kp] - g["P"]) / rms(g["P"])
+    measured("G21_wpe_nb_c4n20_fp64", y_rms=e_y, y_ref_rms=rms(g["y"]), W_rel_rms=e_W, P_rel_rms=e_P)
+    assert e_y < 3e-7 and e_W < 5e-5 and e_P < 1e-5                 # (W 2.9e-5 like the fp32 recursion: the spectra it works on are the fp32 transform's; y 1.2e-8, P 6.3e-6)
+    assert W.dtype == np.complex128 and P.shape == g["P"].shape[:0] + P.shape
+
+
 def test_wpe_mvdr_chain_with_wide_taps(ds):
     """the cfg4 chain (DS_ALGO_WPE_MVDR: STFT -> WPE -> McMcra -> MVDR x gain -> ISTFT) at SURVEY 8(d)'s 10-tap sizing (8 x 10 = 80):
     the oracle's composition on one utterance; utterance groups on two streams equal the whole batch bit for bit"""

@@ -742,6 +742,53 @@ def emul_subband_gsc_chain(x, M, FL, coef, Fn, rls, p_override=None, fused_tail=
     return out, bm.T, p[0].T, xa[0]
 
 
+@pytest.mark.parametrize("C,N,dl", [(4, 20, 4), (8, 2, 4), (2, 3, 0)])
+def test_emul_wpe_double_precision_recursion(C, N, dl):
+    """ds_wpe64.hpp (DS_PARAM_WPE_FP64: P, W, taps and var in double, one workgroup per bin) against the oracle's fp64 core on complex64
+    spectra: the two are the same arithmetic up to summation order — 1e-9 relative —, with the delay ring, one call == frame by frame."""
+    import ctypes
+    from emul import emul as E
+    from oracle import ds_oracle as O
+    lib = E.lib()
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+    K, T, B, CN = 9, 40, 2, C * N
+    rng = np.random.default_rng(5 + C)
+    D = ((rng.standard_normal((B, T, K, C)) + 1j * rng.standard_normal((B, T, K, C))) * 0.3).astype(np.complex64)
+    sb = 2 * CN * CN + 2 * C * CN + 2 * CN + 2
+
+    def fresh():
+        st = np.zeros((B, K, sb), dtype=np.float64)
+        for i in range(CN):
+            st[:, :, 2 * (i * CN + i)] = 1e-3
+        return st
+
+    def run(st, ring, pos, a, b):
+        err = np.zeros((B, b - a, K, C), dtype=np.complex64)
+        Dc = np.ascontiguousarray(D[:, a:b])
+        xd = None if dl else Dc                                    # no delay: the prediction filter sees the current frame
+        assert lib.emul_wpe64(B, K, b - a, C, N, vp(xd), vp(Dc), vp(err), vp(st), ctypes.c_float(0.998), vp(ring), pos, dl) == 0
+        return err
+
+    st1, ring1 = fresh(), (np.zeros((B, dl, K, C), dtype=np.complex64) if dl else None)
+    y1 = run(st1, ring1, 0, 0, T)
+    st2, ring2, pos, ys = fresh(), (np.zeros((B, dl, K, C), dtype=np.complex64) if dl else None), 0, []
+    for a, b in ((0, 1), (1, 2), (2, 9), (9, T)):
+        ys.append(run(st2, ring2, pos, a, b))
+        pos = (pos + (b - a)) % dl if dl else 0
+    assert np.array_equal(np.concatenate(ys, axis=1), y1) and np.array_equal(st1, st2)
+    for b in range(B):
+        o = O.OracleWpe(channels=C, filter_len=N, num_bands=2 * (K - 1), delay=dl)
+        ref = np.zeros((T, K, C), dtype=complex)
+        for t in range(T):
+            xd = D[b, t - dl] if t >= dl else np.zeros((K, C), np.complex64)
+            ref[t] = o.update_fd(xd if dl else D[b, t], D[b, t])
+        assert rms(y1[b] - ref) < 1e-7 * rms(ref)                  # complex64 outputs
+        Pk = st1[b, :, : 2 * CN * CN].copy().view(np.complex128).reshape(K, CN, CN)
+        assert rms(Pk - o.P) < 1e-7 * rms(o.P)                    # (measured 3e-9: the Hermitian-preserving form and the summation order, at double rounding x cond(P))
+        Wk = st1[b, :, 2 * CN * CN: 2 * CN * CN + 2 * C * CN].copy().view(np.complex128).reshape(K, C, CN)
+        assert rms(Wk - o.W) < 1e-7 * max(rms(o.W), 1e-12)
+
+
 @pytest.mark.parametrize("M", [6, 4])
 def test_emul_mcspp_with_fused_blocking_filters_equals_separate_programs(M):
     """OP_MCSPP_STEADY_FAN (the SubbandGSC chain's steady-state McSpp with the utterance's M RLS blocking filters in the same thread) against
