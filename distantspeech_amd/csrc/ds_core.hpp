@@ -1369,6 +1369,14 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
     typedef Shared<NFFT, M, (SL::NP > 0 ? SL::NP * 4 : 4)> Sh;
     typedef Regs<M, ALGO, RYY, NPRE> Rg;
     static constexpr bool FWD_FINAL_IS_FB = (NC != 512);     // 128: 4 stages, 256: 4 stages, 512: 5 stages
+    // 8 microphones at 1024 points (one workgroup of eight waves per CU, 256 registers per lane and all of them in use): the next hop's input
+    // is fetched while the inverse transform runs instead of at the top of the hop (its 2 x 4 values and two addresses are then not live
+    // across the per-bin program), and the lane that runs the Nyquist bin's pass parks part of its own bin's state in the transform
+    // buffer that is idle during the per-bin phase — the two places where this shape left values in scratch (124 B)
+    // (GSC only: measured on the other 8-microphone 1024-point kernels, which had no scratch to lose, the late staging costs 4 - 8 % with 40 hops
+    // per call; the GSC kernel gains 10 - 12 % at one hop per call and at 40: profiles/r05a/m8_1024_late_ab.txt)
+    static constexpr bool LATE_PREFETCH = NFFT >= 1024 && M >= 8 && ALGO == ALGO_GSC;
+    static constexpr int NYQ_PARK = (NFFT >= 1024 && M >= 8 && ALGO == ALGO_GSC) ? M * (M + 1) / 2 : 0;     // floats st[PVV ..) parked
     static constexpr bool INV_FINAL_IS_FA = (NC != 512);
 
     // this lane's first input address (hop 0); the stream is then walked by pointer increments
@@ -1389,7 +1397,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         }
     }
     // issue the global loads of the next hop (all channels) into registers
-    static DS_HD void prefetch(const Params& p, long long, int, int tid, Rg& r) {
+    static DS_HD void prefetch(const Params& p, long long xb, int t, int tid, Rg& r) {
         const int step = p.x_sample_stride == 1 ? HOP / 4 : HOP * M / 4;   // vec4 per hop along this lane's stream
 #pragma unroll
         for (int i = 0; i < NPRE; ++i) {
@@ -1511,6 +1519,34 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
         constexpr int resident = 256 * (by_lds < by_threads ? by_lds : by_threads);      // workgroups the 256 CUs hold at once
         const bool one_round = DS_GRID_BLOCKS() <= resident;
 
+        // LATE_PREFETCH: hop `t` of the input straight into half `half` of the sample buffer.  [M][L] streams go global -> LDS with no register in
+        // between (a wavefront's 64 x 16 bytes are 256 consecutive samples of one channel); the interleaved layout loads and scatters on the spot
+        auto stage_hop_late = [&](int t, int half, int tid, Rg& r) {
+            if (p.x_sample_stride == 1) {
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i) {
+                    const int v = tid + i * NT;
+                    if (v < NV4) {
+                        const int m = v / (HOP / 4), q = v - m * (HOP / 4), lane = tid & 63;
+                        ex.lds_load16(&sh.xbuf[m][half * HOP + 4 * (q - lane)], lane, p.x + xb + (long long)m * p.x_chan_stride + 4 * q + (long long)t * HOP);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NPRE; ++i) {
+                    const int v = tid + i * NT;
+                    if (v < NV4) {
+                        const vec4 q4 = *reinterpret_cast<const vec4*>(p.x + xb + 4 * v + (long long)t * HOP * M);
+                        const float e[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const int lin = 4 * v + c, n = lin / M, m = lin - n * M;
+                            sh.xbuf[m][half * HOP + n] = e[c];
+                        }
+                    }
+                }
+            }
+        };
         // ---- prologue: tables, tails, per-bin state ---------------------------------------------
         ex.phase([&](int tid, Rg& r) {
             {   // tables, STFT tail (-> old half 0) and OLA tail: 16-byte copies
@@ -1527,8 +1563,12 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             bool spectra_in = false;
             if constexpr (ALGO == ALGO_AIC) spectra_in = p.aic_e != nullptr;
             if (!spectra_in) {
-                prefetch_init(p, xb, tid, r);
-                prefetch(p, xb, 0, tid, r);
+                if constexpr (LATE_PREFETCH) {
+                    if (p.T > 0) stage_hop_late(0, 1, tid, r);
+                } else {
+                    prefetch_init(p, xb, tid, r);
+                    prefetch(p, xb, 0, tid, r);
+                }
             } else if (tid < NC / 2) {                                  // this lane's samples of the blocking-matrix overlap tails
                 const float* bt = p.aic_bmtail + (long long)b * M * HOP;
 #pragma unroll
@@ -1565,6 +1605,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                     }
                 }
             }
+            if constexpr (LATE_PREFETCH) ex.lds_load_wait();            // hop 0 has landed (and, with it, the state planes: this shape gives up that overlap)
         });
         // ALGO_AIC: this frame's desired-signal sample (the spectrum one frame back; frame 0 takes the carried one) and update
         // probability for the lane's bin, and for the Nyquist bin on the lane that runs it; issued at the start of a frame, consumed
@@ -1644,11 +1685,11 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                         }
                     }
                 });
-            } else {
+            } else if (!LATE_PREFETCH) {                                // (LATE_PREFETCH: hop t went into LDS in the prologue / in hop t - 1's overlap-add phase)
                 ph(WAVE_FFT && p.x_sample_stride == 1, [&](int tid, Rg& r) {
                     if (one_round) DS_SETPRIO(2);
                     commit(p, sh, new_half, tid, r);
-                    if (t + 1 < p.T) prefetch(p, xb, t + 1, tid, r);
+                    if (!LATE_PREFETCH && t + 1 < p.T) prefetch(p, xb, t + 1, tid, r);
                     if constexpr (ALGO == ALGO_AIC) aic_fetch(t, tid, r);
                 });
             }
@@ -1722,12 +1763,23 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                         cf Zn[M];
 #pragma unroll
                         for (int m = 0; m < M; ++m) { const cf F0 = F[m * Sh::NCP]; Zn[m] = mk(F0.x - F0.y, 0.0f); }
+                        float* const park = reinterpret_cast<float*>(FWD_FINAL_IS_FB ? fa : fb) + 2 * Sh::NCP;     // (row 1 of the idle buffer)
+                        if constexpr (NYQ_PARK > 0) {
+#pragma unroll
+                            for (int j = 0; j < NYQ_PARK; ++j) park[j] = r.st[SL::PVV + j];
+                            DS_COMPILER_FENCE();
+                        }
 #ifdef DS_ABLATE_NYQUIST   // timing experiment only (profiles/r04a/nyquist_ablation.txt): the hop without the Nyquist bin's per-bin program
                         const cf Yn = Zn[0];
 #else
                         const cf Yn = bin_program(sh.nyq, Zn, steer, NC, sh, p, frm_cnt, reset, spp_cnt, r.adn, r.apkn, ref_pow_row(t));
 #endif
                         sh.Y[NC] = mk(Yn.x, 0.0f);
+                        if constexpr (NYQ_PARK > 0) {
+                            DS_COMPILER_FENCE();
+#pragma unroll
+                            for (int j = 0; j < NYQ_PARK; ++j) r.st[SL::PVV + j] = park[j];
+                        }
                     }
                 }
             });
@@ -1746,6 +1798,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             // The merge of the packed real transform (Y[k], Y[NC - k] -> point k) is formed inside the first inverse stage.
             phs(WAVE_FFT, [&](int tid, Rg& r) {
                 DS_SETPRIO(2);                                          // the serial part of a hop: ahead of other workgroups' wide phases
+                if (LATE_PREFETCH && t + 1 < p.T) stage_hop_late(t + 1, old_half, tid, r);     // (that half: read by the first forward stage, idle since)
                 if (tid >= INV_T0) fft_stage<NFFT, M, 4, +1, 2, 0, 1>(tid - INV_T0, NT, sh, nullptr, fb, 1, 0, 1);
                 else if (WAVE_FFT && tid == NYQ_TID) {
                     cf Zn[M];
@@ -1770,7 +1823,8 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             }
             const cf* Zi = INV_FINAL_IS_FA ? fa : fb;
             // ---- window, overlap-add, emit hop t ---------------------------------------------------
-            ex.phase([&](int tid, Rg&) {
+            ex.phase([&](int tid, Rg& r) {
+                if constexpr (LATE_PREFETCH) ex.lds_load_wait();        // the next hop's samples have landed (issued five phases back); the phase's barrier publishes them
                 if (tid < NC / 2) {
                     const int i = tid;
                     const float sc = 1.0f / (float)NC;

@@ -165,7 +165,10 @@ __device__ inline void mcspp_qavg_block(const OpParams& p, int b0, float (*band)
 }
 
 // (the fused McSpp + blocking-filter operator at 6 microphones is pinned to the two waves per SIMD the plain steady-state build reaches by itself)
-constexpr int binop_min_waves(int op, int M) { return (op == OP_MCSPP_STEADY_FAN && M >= 5) ? 2 : 1; }
+#ifndef DS_MCSPP_WAVES
+#define DS_MCSPP_WAVES 1
+#endif
+constexpr int binop_min_waves(int op, int M) { return (op == OP_MCSPP_STEADY_FAN && M >= 5) ? 2 : (op == OP_MCSPP_STEADY && M >= 5) ? DS_MCSPP_WAVES : 1; }
 template <int OP, int M> __global__ void __launch_bounds__(256, binop_min_waves(OP, M)) ds_binop_kernel(OpParams p) {
     if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
     const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;

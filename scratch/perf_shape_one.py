@@ -9,11 +9,11 @@ if sys.argv[1] == "--child":
     dev = torch.device("cuda", 0)
     out = []
     for T in (1, 40):
-        HOP, B = NFFT // 2, 1024
+        HOP, B = NFFT // 2, int(os.environ.get('DS_SHAPE_B', '1024'))
         K = 80 // T; Ltot = (K + 2) * T * HOP
         x = torch.randn((B, M, Ltot), device=dev) * 0.05
         y = torch.empty((B, Ltot), device=dev)
-        eng = BatchEngine(1, M, NFFT, HOP, batch=B, device=0)
+        eng = BatchEngine(int(os.environ.get('DS_SHAPE_ALGO', '1')), M, NFFT, HOP, batch=B, device=0)
         eng.set_steering(np.ones((NFFT // 2 + 1, M), np.complex64)); eng.set_method(2)
         torch.cuda.synchronize()
         best = 1e9

@@ -230,7 +230,7 @@ def test_streamed_ryy_kernel_tfgsc_and_state(ds):
             assert relmax(ab.Ryy[b], ref.Ryy) < 1e-5 and relmax(ab.Rvv[b], ref.Rvv) < 1e-4
 
 
-@pytest.mark.parametrize("M,nfft", [(2, 512), (3, 512), (4, 256), (5, 256), (5, 512), (6, 512)])
+@pytest.mark.parametrize("M,nfft", [(2, 512), (3, 512), (4, 256), (5, 256), (5, 512), (6, 512), (8, 1024)])
 def test_mvdr_kernel_without_ryy_vs_oracle(ds, M, nfft):
     """The adaptive MVDR frame kernel WITHOUT the Ryy recursion (track_ryy = 0: what bench.py runs; the Python adaptivebeamfomer keeps Ryy for
     TFGSC) — the instantiations with hoisted addresses (M <= 5 at 256 / 512 points) and the ones without: rows of a batch against the
@@ -258,7 +258,7 @@ def test_mvdr_kernel_without_ryy_vs_oracle(ds, M, nfft):
         assert rms(y1[b] - ref) < 1e-5, (b, rms(y1[b] - ref))
 
 
-@pytest.mark.parametrize("M,nfft", [(4, 512), (3, 256), (5, 1024)])
+@pytest.mark.parametrize("M,nfft", [(4, 512), (3, 256), (5, 1024), (8, 1024)])
 def test_gsc_batch_vs_oracle(ds, M, nfft):
     hop, B, T = nfft // 2, 4, 40
     omic = oracle_mic(M, nfft, 0.032)

@@ -144,6 +144,34 @@ def test_emul_gsc(name):
         assert np.median(np.abs(om.lambda_d - g["omlsa_lambda_d"]) / (g["omlsa_lambda_d"] + 1e-12)) < 1e-3
 
 
+@pytest.mark.parametrize("algo,ryy", [(2, False), (1, False)])
+def test_emul_late_staged_input_8_mics_1024(algo, ryy):
+    """Engine<1024, 8, .>::LATE_PREFETCH (round 5: the next hop's input goes global -> LDS while the inverse transform runs, hop 0 in the
+    prologue; the GSC kernel's Nyquist lane parks Phi_vv in the idle transform buffer): both input layouts, one call == hop by hop with the
+    state, GSC / MVDR against the oracle."""
+    M, nfft, hop, T = 8, 1024, 512, 6
+    omic = oracle_mic(M, nfft, 0.05)
+    x = (O.synth_utterance(11, hop * T, omic) * 0.3).astype(np.float32)              # [M, L]
+    a = steering(M, nfft, 0.05)
+
+    def run(layout, pieces):
+        e = EmulEngine(algo, nfft, M, 1, ryy=ryy)
+        e.set_steering(a if algo else np.conj(a) / M)
+        xin = x[None] if layout == 1 else np.ascontiguousarray(x.T)[None]
+        cut = [0] + list(pieces) + [T]
+        ys = [e.process(xin[:, :, c0 * hop:c1 * hop] if layout == 1 else xin[:, c0 * hop:c1 * hop], layout) for c0, c1 in zip(cut[:-1], cut[1:])]
+        return np.concatenate(ys, axis=1)[0], e.bins.copy()
+
+    y, st = run(1, [])
+    for layout, pieces in ((1, range(1, T)), (0, []), (0, [2, 3])):
+        y2, st2 = run(layout, pieces)
+        assert np.array_equal(y, y2) and np.array_equal(st, st2), (layout, list(pieces))
+    if algo == 2:
+        assert rms(y - O.OracleGSC(omic, nfft, with_dead_state=False).process(x, ANGLE, 2)) < TOL_RMS
+    elif algo == 1:
+        assert rms(y - O.OracleAdaptiveMVDR(omic, nfft, hop, nfft).process(x, ANGLE, 2)) < 1e-5
+
+
 @pytest.mark.parametrize("M,nfft", [(4, 512), (2, 256), (3, 512)])
 def test_emul_gsc_reference_powers(M, nfft):
     """Params::ref_pow (DS_PARAM_REF_POWERS): the GSC frame program also writes, per frame and bin, |Y|^2 of the canceller output in front
