@@ -5,6 +5,7 @@
 #include "ds_kernels.hpp"
 #include "ds_ops.hpp"
 #include "ds_tdfilter.hpp"
+#include "ds_wpe2.hpp"
 
 namespace ds {
 
@@ -520,9 +521,35 @@ template <int LPB, int CT = 0, int NTAPS = 0> __global__ void __launch_bounds__(
     HipExec<typename E::Rg> ex;
     E::run(ex, p, (int)blockIdx.x, sh);
 }
+// two rows of P per lane (ds_wpe2.hpp) for calls of DS_WPE2_MIN_T frames or more: the shapes with C N = 16 / 8 and a lane per channel.  Hoisted
+// lane geometry (HipExec<.., 2>: the bin split, bounds and LDS addresses once per call instead of once per phase and frame: 520 -> 419 vector
+// instructions per lane and frame at 8 x 2) inside three waves per SIMD (168 registers).  Bit-identical to the one-row kernels, so the choice
+// by call length changes no result; at one frame per call the one-row kernel stays (HBM-bound there: twice the lanes, twice the loads in flight:
+// the two-row kernel is 20 % slower at T = 1, 9 % faster at T = 312 on BASELINE config 4, profiles/r05a/cfg4_wpe2_ab.txt)
+#ifndef DS_WPE2_MIN_T
+#define DS_WPE2_MIN_T 8
+#endif
+template <int CT, int NTAPS> __global__ void __launch_bounds__(WPE_NT, 3) ds_wpe2_kernel(WpeParams p) {
+    typedef WpeEngine2<CT, NTAPS> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg, 2> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
 hipError_t launch_wpe(const WpeParams& p, int generic, hipStream_t stream) {
     const int lpb = wpe_lanes_per_bin(p.C * p.N), bpw = WPE_NT / lpb;
     const unsigned blocks = (unsigned)(((long long)p.B * p.K + bpw - 1) / bpw);
+#ifndef DS_NO_WPE2
+    if (!(generic & 1) && p.T >= DS_WPE2_MIN_T) {
+#define DS_WPE2_SHAPE(C_, N_) \
+        if (p.C == C_ && p.N == N_) { \
+            constexpr int bpw2 = WpeEngine2<C_, N_>::BPW; \
+            hipLaunchKernelGGL((ds_wpe2_kernel<C_, N_>), dim3((unsigned)(((long long)p.B * p.K + bpw2 - 1) / bpw2)), dim3(WPE_NT), 0, stream, p); \
+            return hipGetLastError(); \
+        }
+        DS_WPE2_SHAPE(8, 2) DS_WPE2_SHAPE(4, 4) DS_WPE2_SHAPE(4, 2)
+#undef DS_WPE2_SHAPE
+    }
+#endif
     // the shapes of the BASELINE config (8 channels x 2 taps), of the reference's notebooks and tests (4 x 2, 2 x 3, 4 x 4, 8 x 1) as
     // compile-time shapes; anything else — and everything with `generic` (DS_WPE_GENERIC=1 at ds_create, the A/B and test switch) — through the generic kernels
     if (!(generic & 1)) {

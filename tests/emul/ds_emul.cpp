@@ -13,6 +13,7 @@
 #include "../../distantspeech_amd/csrc/ds_tdfilter.hpp"
 #include "../../distantspeech_amd/csrc/ds_fdaf.hpp"
 #include "../../distantspeech_amd/csrc/ds_wpe_wide.hpp"
+#include "../../distantspeech_amd/csrc/ds_wpe2.hpp"
 #include "../../distantspeech_amd/csrc/ds_wpe64.hpp"
 
 namespace {
@@ -167,6 +168,20 @@ template <int CNP, int NCH, int CT = 0, int NTAPS = 0> int run_wpe_wide(const ds
         ex.nt = E::NT;
         ex.R.resize(E::NT);
         E::run(ex, p, (int)b, *sh);
+    }
+    delete sh;
+    return 0;
+}
+
+template <int CT, int NTAPS> int run_wpe2(const ds::WpeParams& p) {          // two rows of P per lane (ds_wpe2.hpp)
+    typedef ds::WpeEngine2<CT, NTAPS> E;
+    typename E::Sh* sh = new typename E::Sh();
+    const int blocks = (int)(((long long)p.B * p.K + E::BPW - 1) / E::BPW);
+    for (int b = 0; b < blocks; ++b) {
+        CpuExec<typename E::Rg> ex;
+        ex.nt = E::NT;
+        ex.R.resize(E::NT);
+        E::run(ex, p, b, *sh);
     }
     delete sh;
     return 0;
@@ -361,9 +376,9 @@ int emul_wpe(int B, int K, int T, int C, int N, const float* xd, const float* d,
     }
     const int lpb = ds::wpe_lanes_per_bin(C * N);
     if (!g_wpe_generic) {                                        // the compile-time shapes of launch_wpe (ds_kernels_ops.hip)
-        if (C == 8 && N == 2) return run_wpe<16, 8, 2>(p);
-        if (C == 4 && N == 2) return run_wpe<8, 4, 2>(p);
-        if (C == 4 && N == 4) return run_wpe<16, 4, 4>(p);
+        if (C == 8 && N == 2) return run_wpe2<8, 2>(p);
+        if (C == 4 && N == 2) return run_wpe2<4, 2>(p);
+        if (C == 4 && N == 4) return run_wpe2<4, 4>(p);
         if (C == 8 && N == 1) return run_wpe<8, 8, 1>(p);
         if (C == 2 && N == 3) return run_wpe<8, 2, 3>(p);
     }

@@ -15,7 +15,7 @@ SO = os.path.join(HERE, "libds_emul.so")
 SRCS = [os.path.join(HERE, "ds_emul.cpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_core.hpp"),
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_ops.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tables.hpp"),
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_tdfilter.hpp"),
-        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_fdaf.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_wpe.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_wpe_wide.hpp"),
+        os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_fdaf.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_wpe.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_wpe2.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_wpe_wide.hpp"),
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_linalg64.hpp"), os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_quad.hpp"),
         os.path.join(ROOT, "distantspeech_amd", "csrc", "ds_pipe.hpp")]
 

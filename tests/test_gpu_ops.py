@@ -1374,6 +1374,25 @@ def test_wpe_compile_time_shapes_equal_the_generic_kernel(ds, C, N, monkeypatch)
     assert rms(out[1][0][1] - ref) < 2e-4 * rms(ref)
 
 
+@pytest.mark.parametrize("C,N", [(8, 2), (4, 4), (4, 2)])
+def test_wpe_two_rows_per_lane_equals_one_row_per_lane(ds, C, N):
+    """calls of 8 frames or more run these shapes with TWO rows of P per lane (ds_wpe2.hpp: half the LDS reads and per-lane work per row, +10 %
+    on BASELINE config 4 with 10 s per call), shorter calls with one row per lane (HBM-bound, twice the loads in flight): the same statement
+    sequence per row, so a 24-frame call, 24 one-frame calls and a 3 + 8 + 13 split give the same errors and exported state bit for bit."""
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(2000 + 10 * C + N)
+    K, T, B = 129, 24, 5
+    D = ((rng.standard_normal((B, T, K, C)) + 1j * rng.standard_normal((B, T, K, C))) * 0.3).astype(np.complex64)
+    Xd = np.concatenate([np.zeros((B, 2, K, C), np.complex64), D[:, :-2]], axis=1)
+    out = []
+    for cuts in ([0, T], list(range(T + 1)), [0, 3, 11, T]):
+        eng = ds.BatchEngine(L.ALGO_WPE, C, 256, batch=B, filter_len=N, rls_lambda=0.998)
+        err = np.concatenate([eng.wpe_update(Xd[:, a:b], D[:, a:b]) for a, b in zip(cuts[:-1], cuts[1:])], axis=1)
+        out.append((err, eng.export_state()))
+    for e, st in out[1:]:
+        assert np.array_equal(e, out[0][0]) and np.array_equal(st, out[0][1])
+
+
 def test_chain_stage_info_adds_up(ds):
     """ds_chain_stage_info: the stages of the two BASELINE chains in the order of the reference object's members; their carried-state
     bytes + the chain's own delay lines (+ the overlaps and counters every handle allocates) = ds_state_payload_bytes of the chain; a plain
