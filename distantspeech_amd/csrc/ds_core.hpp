@@ -166,6 +166,20 @@ DS_HD cf cfnmac(cf acc, cf a, cf b) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(t));
     return pk_cf(r);
 }
+// conj(acc) - a conj(b) and conj(a) s: the conjugations as the packed instructions' own per-half negations (cfnmac / cscale of a conjugated
+// operand cost a v_xor and a v_mov per use to build the conjugate in a register pair first)
+DS_HD cf cfnmac_ca(cf acc, cf a, cf b) {
+    cf2_t t, r;                                  // t = (-a.y b.y + acc.x, a.x b.y - acc.y);  r = (-a.x b.x + t.lo, -a.y b.x + t.hi)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[0,0,1]" : "=v"(t) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(cf_pk(acc)));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(cf_pk(a)), "v"(cf_pk(b)), "v"(t));
+    return pk_cf(r);
+}
+DS_HD cf cscale_c(cf a, float s) {
+    cf2_t r;
+    const cf2_t sv = {s, s};
+    asm("v_pk_mul_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(r) : "v"(cf_pk(a)), "v"(sv));
+    return pk_cf(r);
+}
 DS_HD cf herm_downdate(cf P, cf gi, cf gj, float lam_inv, float dls) {     // five packed instructions for the eleven of the scalar form
     cf2_t p1, p2, t, q, r;
     const cf2_t sc = {lam_inv, dls};
@@ -188,6 +202,8 @@ DS_HD cf herm_downdate_h(cf P, cf hi, cf hj, float lam_inv) {               // f
 #else
 DS_HD cf herm_downdate_h(cf P, cf hi, cf hj, float lam_inv) { return herm_downdate_h_s(P, hi, hj, lam_inv); }
 DS_HD cf herm_downdate(cf P, cf gi, cf gj, float lam_inv, float dls) { return herm_downdate_s(P, gi, gj, lam_inv, dls); }
+DS_HD cf cfnmac_ca(cf acc, cf a, cf b) { return cfnmac_s(mk(acc.x, -acc.y), a, b); }
+DS_HD cf cscale_c(cf a, float s) { return mk(a.x * s, -a.y * s); }
 DS_HD cf cmul(cf a, cf b) { return cmul_s(a, b); }
 DS_HD cf cmulc(cf a, cf b) { return cmulc_s(a, b); }
 DS_HD cf cfma(cf acc, cf a, cf b) { return cfma_s(acc, a, b); }
@@ -702,8 +718,28 @@ template <int M> DS_HD void herm_rank1(float* d, float* o, const cf* z, float a,
         for (int j = i + 1; j < M; ++j) {
             const int q = off_index(i, j, M);
             const cf zz = cmulc(z[i], z[j]);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DS_SCALAR_COMPLEX) && !defined(DS_RANK1_SCALAR)
+          if constexpr (M >= 5) {      // (up to four microphones the vectoriser's own packing has no moves to lose, and the Nyquist bin's LDS-resident state keeps its paired reads)
+            // the same two roundings per word as the scalar statements below, as ONE packed multiply and ONE packed multiply-add on the (re, im)
+            // pair the product arrives in: left to the vectoriser it paired words of NEIGHBOURING elements and moved them together first (two
+            // v_mov per element: 60 of the 6-microphone McSpp operator's 1080 vector instructions per frame)
+            cf2_t t, r;
+            // (the two words read one by one and pinned: read as a pair, the off-diagonal words that start at an odd float of the state became
+            // 8-byte accesses across the 16-byte plane groups and the planes stayed in private memory — the adaptive_bin note on TFGSC)
+            float ox = o[2 * q], oy = o[2 * q + 1];
+            asm volatile("" : "+v"(ox), "+v"(oy));
+            const cf2_t ab = {a, b}, ov = {ox, oy};
+            asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t) : "v"(cf_pk(zz)), "v"(ab));                       // (zz.x b, zz.y b)
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(ov), "v"(ab), "v"(t));               // (o.x a + t.x, o.y a + t.y)
+            o[2 * q] = r.x; o[2 * q + 1] = r.y;
+          } else {
             o[2 * q] = fma_(a, o[2 * q], b * zz.x);
             o[2 * q + 1] = fma_(a, o[2 * q + 1], b * zz.y);
+          }
+#else
+            o[2 * q] = fma_(a, o[2 * q], b * zz.x);
+            o[2 * q + 1] = fma_(a, o[2 * q + 1], b * zz.y);
+#endif
         }
 }
 
@@ -728,10 +764,17 @@ template <int M> struct Chol {
             inv[j] = r;
 #pragma unroll
             for (int i = j + 1; i < M; ++i) {
-                cf a = herm_get<M>(d, o, i, j);
+                // A_ij = conj(A_ji), the stored word: conjugated inside the first multiply-add (or the scale) instead of in a register pair
+                const int w = off_index(j, i, M);
+                const cf aji = mk(o[2 * w], o[2 * w + 1]);
+                if (j == 0) {
+                    lo[w] = cscale_c(aji, r);
+                } else {
+                    cf a = cfnmac_ca(aji, L(i, 0), L(j, 0));
 #pragma unroll
-                for (int k = 0; k < j; ++k) a = cfnmac(a, L(i, k), L(j, k));
-                lo[off_index(j, i, M)] = cscale(a, r);
+                    for (int k = 1; k < j; ++k) a = cfnmac(a, L(i, k), L(j, k));
+                    lo[w] = cscale(a, r);
+                }
             }
         }
     }
@@ -782,7 +825,7 @@ template <int M> struct Chol {
         for (int j = 0; j < M; ++j) {
             cf a = cscale(u[j], inv[j]);
 #pragma unroll
-            for (int i = j + 1; i < M; ++i) a = cfma(a, cconj(L(i, j)), u[i]);
+            for (int i = j + 1; i < M; ++i) a = cfmac(a, u[i], L(i, j));      // a + conj(L_ij) u_i: the same products in the same nesting as cfma(a, conj(L), u)
             v[j] = a;
         }
     }

@@ -1245,7 +1245,12 @@ template <int M, bool STEADY = false, bool FAN = false> DS_HD void op_mcspp_lean
                 yv = fma_(Z[i].x, v[i].x, fma_(Z[i].y, v[i].y, yv));                // Re(conj(y_i) v_i)
                 cf acc = mk(0.0f, 0.0f);
 #pragma unroll
-                for (int j = 0; j < M; ++j) acc = cfma(acc, herm_get<M>(yd, yo, i, j), v[j]);
+                for (int j = 0; j < M; ++j) {
+                    // (below the diagonal Phi_ij = conj(Phi_ji): acc + conj(Phi_ji) v_j as cfmac(acc, v_j, Phi_ji) — the same products in the same
+                    // nesting, without the conjugate built in a register pair)
+                    if (j < i) { const int w = off_index(j, i, M); acc = cfmac(acc, v[j], mk(yo[2 * w], yo[2 * w + 1])); }
+                    else acc = cfma(acc, herm_get<M>(yd, yo, i, j), v[j]);
+                }
                 vPv = fma_(v[i].x, acc.x, fma_(v[i].y, acc.y, vPv));                // Re(conj(v_i) (Phi_yy v)_i)
             }
             gam = fminf_(fmaxf_(vPv - yv, 1e-6f), 1e8f);                           // :232-236
