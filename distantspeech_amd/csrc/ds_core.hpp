@@ -967,14 +967,19 @@ template <int M> struct MvdrSweep {
         return mk(ut.x * inv, ut.y * inv);
     }
 };
-template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag, const cf* a, const cf* z, float floor_) {
+// CF: the conjugation of the stored words folded into column 0's instructions (below).  Same results bit for bit; off for the one-pass MVDR +
+// post-filter kernel, which it costs 1.6 % at one hop per call (profiles/r05a/mvdr_noconj_ab.txt; + 1.4 % with 10 s per call — the one-hop figure is
+// that workload's headline) while the plain MVDR kernel gains in both regimes (+ 0.5 % / + 2 %)
+template <int M, bool CF = true> DS_HD cf mvdr_output(const float* d, const float* o, float diag, const cf* a, const cf* z, float floor_) {
     float Ad[M];
     cf Al[M * (M - 1) / 2 + 1];          // strictly-lower A_ij (i>j) at off_index(j, i)
     cf u[M], t[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) { Ad[i] = d[i] + diag; u[i] = a[i]; t[i] = z[i]; }
+    // A_ij = conj(R_ji): the stored words as they are — column 0 conjugates them inside its scale and its update (cscale_c / cfnmac_ca: the
+    // packed instructions' own negations) instead of a v_xor and a v_mov per word into fresh register pairs first
 #pragma unroll
-    for (int q = 0; q < M * (M - 1) / 2; ++q) Al[q] = mk(o[2 * q], -o[2 * q + 1]);   // A_ij = conj(R_ji)
+    for (int q = 0; q < M * (M - 1) / 2; ++q) Al[q] = CF ? mk(o[2 * q], o[2 * q + 1]) : mk(o[2 * q], -o[2 * q + 1]);
     float nu = 0.0f;
     cf ut = mk(0.0f, 0.0f);
 #pragma unroll
@@ -992,7 +997,7 @@ template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag
         cf Lc[M];
 #pragma unroll
         for (int i = j + 1; i < M; ++i) {
-            Lc[i] = cscale(Al[off_index(j, i, M)], r);
+            Lc[i] = (CF && j == 0) ? cscale_c(Al[off_index(j, i, M)], r) : cscale(Al[off_index(j, i, M)], r);
             u[i] = cfnma(u[i], Lc[i], uj);
             t[i] = cfnma(t[i], Lc[i], tj);
         }
@@ -1002,7 +1007,7 @@ template <int M> DS_HD cf mvdr_output(const float* d, const float* o, float diag
 #pragma unroll
             for (int k = j + 1; k < i; ++k) {
                 const int q = off_index(k, i, M);
-                Al[q] = cfnmac(Al[q], Lc[i], Lc[k]);             // A_ik -= L_ij conj(L_kj)
+                Al[q] = (CF && j == 0) ? cfnmac_ca(Al[q], Lc[i], Lc[k]) : cfnmac(Al[q], Lc[i], Lc[k]);      // A_ik -= L_ij conj(L_kj)
             }
         }
     }
@@ -1068,7 +1073,7 @@ template <int M> DS_HD float ryy_stream_word(const StreamRef& sr, const float* s
     return sr.tail[f - 4 * L::NPS];
 }
 
-template <int M, bool RYY>
+template <int M, bool RYY, bool CF = true>
 DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p, const StreamRef* sr = nullptr) {
     typedef StateLayout<M, ALGO_ADAPTIVE, RYY> SL;
     float* d = st + SL::R_DIAG;
@@ -1100,7 +1105,7 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p, cons
 #ifdef DS_SOLVE_FP64
         acc = mvdr_output<M>(d, o, p.diag, a, Z);
 #else
-        acc = mvdr_output<M>(d, o, p.diag, a, Z, p.diag_floor);
+        acc = mvdr_output<M, CF>(d, o, p.diag, a, Z, p.diag_floor);
 #endif
 #endif
     } else if (RYY) {                                          // TFGSC, beamformer.py:327-333
@@ -1495,7 +1500,7 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             Yk = adaptive_bin<M, RYY>(st, Z, a, p, sr);
         } else if constexpr (ALGO == ALGO_ADAPTIVE_PF) {
             mcra_bin(st + SL::MC_S, k, K, sh.pw[k > 0 ? k - 1 : 0], sh.pw[k], sh.pw[k + 1], frm_cnt, reset, p.mcra_L);
-            Yk = adaptive_bin<M, false>(st, Z, a, p);                                          // adaptivebeamformer.py:69-120
+            Yk = adaptive_bin<M, false, false>(st, Z, a, p);                                   // adaptivebeamformer.py:69-120
             float pp, G, xi, gam;
             mcmcra_bin<M>(st + SL::PF_PYY, st + SL::PF_PVV, Z, k, spp_cnt, pp, G, xi, gam);    // spp.estimation(Z)  GSC.py:225
             Yk = cscale(Yk, G);                                                                // Y * spp.G         GSC.py:286
