@@ -23,6 +23,31 @@ DS_HD cd to_cd(cf a) { return mkd((double)a.x, (double)a.y); }
 DS_HD cd cdsub(cd a, cd b) { return mkd(a.x - b.x, a.y - b.y); }
 DS_HD cd cdconj(cd a) { return mkd(a.x, -a.y); }
 DS_HD cd cdscale(cd a, double s) { return mkd(a.x * s, a.y * s); }
+// 1 / sqrt(x) and 1 / x for the Jacobi rotation angles (x a normal, positive number): the hardware's seed (v_rsq_f64 / v_rcp_f64) and two
+// Newton steps — a couple of ulp, where IEEE sqrt and division cost 14 instructions each (scaling, class tests, fix-up) and a rotation
+// needed six of them.  An angle that is off by an ulp leaves an off-diagonal residue of that size for the next sweep; c^2 + s^2 = 1 holds to
+// the same couple of ulp.  On the host the plain expressions.
+DS_HD double rsqrt_fast_d(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = fmad_(y, fmad_(-(h * y), y, 0.5), y);
+    y = fmad_(y, fmad_(-(h * y), y, 0.5), y);
+    return y;
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+DS_HD double rcp_fast_d(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    y = fmad_(y, fmad_(-x, y, 1.0), y);
+    y = fmad_(y, fmad_(-x, y, 1.0), y);
+    return y;
+#else
+    return 1.0 / x;
+#endif
+}
 DS_HD double cdabs2(cd a) { return fmad_(a.x, a.x, a.y * a.y); }
 DS_HD cd cdmul(cd a, cd b) { return mkd(fmad_(a.x, b.x, -(a.y * b.y)), fmad_(a.x, b.y, a.y * b.x)); }
 DS_HD cd cdmulc(cd a, cd b) { return mkd(fmad_(a.x, b.x, a.y * b.y), fmad_(a.y, b.x, -(a.x * b.y))); }    // a * conj(b)
@@ -121,13 +146,16 @@ template <int M> DS_HD void herm_principal_d(cd (&A)[M][M], cd* v) {
                 const double mag2 = cdabs2(apq);
                 offmax = mag2 > offmax ? mag2 : offmax;
                 if (mag2 > tiny && mag2 > 1e-300) {
-                    const double mag = sqrt(mag2);
-                    const cd e = cdscale(apq, 1.0 / mag);
+                    // t = sgn(tau) / (|tau| + sqrt(tau^2 + 1)), tau = (a_qq - a_pp) / (2 |a_pq|), written in w = t / |a_pq| = sgn(d) / (|d| +
+                    // sqrt(d^2 + |a_pq|^2)), d = (a_qq - a_pp) / 2: one square root, one reciprocal and one reciprocal square root per rotation
+                    // instead of three square roots and three divisions (|a_pq| itself is never needed: s e^{j phi} = c w a_pq, t |a_pq| = w |a_pq|^2)
                     const double app = A[p][p].x, aqq = A[q][q].x;
-                    const double tau = (aqq - app) / (2.0 * mag);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(fmad_(tau, tau, 1.0)));
-                    const double c = 1.0 / sqrt(fmad_(t, t, 1.0)), sn = t * c;
-                    const cd se = cdscale(e, sn);                                   // s e^{j phi}
+                    const double del = 0.5 * (aqq - app);
+                    const double r2 = fmad_(del, del, mag2);
+                    const double w = (del >= 0.0 ? 1.0 : -1.0) * rcp_fast_d(fabs(del) + r2 * rsqrt_fast_d(r2));
+                    const double c = rsqrt_fast_d(fmad_(w * w, mag2, 1.0));
+                    const double t = w, mag = mag2;                                   // (t mag below = w |a_pq|^2)
+                    const cd se = cdscale(apq, c * w);                                // s e^{j phi}
 #pragma unroll
                     for (int k = 0; k < M; ++k) {
                         if (k != p && k != q) {
