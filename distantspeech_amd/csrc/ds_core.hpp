@@ -658,8 +658,10 @@ DS_HD void mcra_bin(float* st, int k, int K, float Ykm1, float Yk, float Ykp1, i
     const float S1 = fma_(alpha_s, S0, one_m_alpha_s * Sf);                          // :47
     const float Smin_a = fminf_(Smin0, S1), Stmp_a = fminf_(Stmp0, S1);             // :49-50
     const float Smin1 = reset ? fminf_(Stmp_a, S1) : Smin_a, Stmp1 = reset ? S1 : Stmp_a;   // :52-56
-    const float Sr = S1 / (Smin1 + 1e-6f);                                          // :58
-    const float I = Sr > delta_s ? 1.0f : 0.0f;                                     // :60-63
+    // Sr = S / (Smin + 1e-6) > delta (:58-63) as S > delta (Smin + 1e-6): the quotient is used for nothing else, and an IEEE fp32 division is ten
+    // instructions of this 200-instruction program (both sides positive; at an exact tie the two forms may differ in the last ulp — as the fp32 S
+    // already differs from the reference's double)
+    const float I = S1 > delta_s * (Smin1 + 1e-6f) ? 1.0f : 0.0f;
     float p1 = fma_(alpha_p, p0, one_m_alpha_p * I);                                // :65-67
     if (frm_cnt < 2 * L) p1 = 0.0f;                                                 // :68-69
     const bool first = frm_cnt == 0, init = first && k < K - 1;                     // :38-41,68-69
