@@ -321,6 +321,40 @@ def test_notebook_online_mvdr_as_one_handle(ds, name):
     assert np.array_equal(np.asarray(y3, dtype=np.float32).ravel(), y.astype(np.float32))
 
 
+def test_notebook_online_mvdr_full_batch(ds):
+    """the bench workload `nb_mvdr` at its size (1024 utterances, 6 microphones, 512 / 256): rows of the batch equal one-utterance handles bit for
+    bit (first, middle, last), one row against the oracle's composition of the notebook cell, every output finite."""
+    from distantspeech_amd import _lib as L
+    from oracle import ds_oracle as O
+    from _cases import oracle_mic
+    M, nfft, hop, B, T = 6, 512, 256, 1024, 28
+    omic = oracle_mic(M, nfft, 0.05)
+    base = np.stack([O.synth_utterance(900 + b, hop * T, omic) for b in range(8)]).astype(np.float32)     # [8, M, n]
+    gains = (0.5 + np.arange(B) / B).astype(np.float32)
+    xs = base[np.arange(B) % 8] * gains[:, None, None]
+    def make(batch):
+        e = ds.BatchEngine(L.ALGO_MCSPP_MVDR, M, nfft, batch=batch)
+        e.chain_set_aux(L.CHAIN_AUX_COHERENCE, ds.McSpp.diffuse_coherence(M, nfft))
+        return e
+    y, p = make(B).mcspp_mvdr_process(xs, L.LAYOUT_CHANNELS_SAMPLES)
+    assert np.all(np.isfinite(y)) and np.all(np.isfinite(p))
+    for b in (0, 517, B - 1):
+        y1, p1 = make(1).mcspp_mvdr_process(xs[b:b + 1], L.LAYOUT_CHANNELS_SAMPLES)
+        assert np.array_equal(y1[0], y[b]) and np.array_equal(p1[0], p[b]), b
+    b = 517
+    D = O.OracleTransform(channel=M, n_fft=nfft, hop_length=hop).stft(xs[b].T.astype(np.float64))
+    est = O.OracleMcSpp(nfft=nfft, channels=M)
+    Yo = np.zeros((nfft // 2 + 1, T), dtype=complex)
+    for n in range(T):
+        est.estimation(D[:, n, :])
+        w = O.compute_mvdr_weight(O.steering(est.Phi_xx), est.Phi_vv_inv)
+        Yo[:, n] = np.einsum("ij,ij->i", w.conj(), D[:, n, :])
+    yo = np.asarray(O.OracleTransform(channel=1, n_fft=nfft, hop_length=hop).istft(Yo[:, :, None])).ravel()
+    e = rms(y[b] - yo)
+    measured("nb_mvdr_full_batch_row", y_rms=e, y_ref_rms=rms(yo))
+    assert e < 1e-4
+
+
 def test_notebook_online_mvdr_batch_and_checkpoint(ds):
     """B utterances per handle: rows independent, a sequence replayed as a hipGraph equals plain calls, checkpoint / resume mid-stream."""
     from distantspeech_amd import _lib as L
