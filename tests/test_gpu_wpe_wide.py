@@ -221,6 +221,37 @@ def test_wpe_update_double_precision_through_the_mirror(ds):
     assert W.dtype == np.complex128 and P.shape == g["P"].shape[:0] + P.shape
 
 
+@pytest.mark.parametrize("C,N,fp64", [(1, 1, 0), (2, 2, 0), (8, 2, 0), (4, 5, 0), (4, 20, 0), (4, 5, 1)])
+def test_wpe_recovers_a_known_reverberation(ds, C, N, fp64):
+    """a ground truth that owes nothing to the (patched) reference: per bin and channel d[t] = s[t] + a d[t - D] with white s — late reverberation as
+    a one-tap recursion.  The delayed-prediction optimum is tap 0 = the channel's own a (conj in the kernel's convention), every other tap and
+    every cross-channel tap 0, and the prediction error is the source: the narrow kernels (one and two rows per lane), the wide kernel and the
+    double-precision mode all have to get there from P = 1e-3 I."""
+    from distantspeech_amd import _lib as L
+    rng = np.random.default_rng(100 * C + N)
+    K, T, D, B, lam = 17, 6000, 2, 2, 0.999
+    a = (0.75 * np.exp(2j * np.pi * rng.random((B, K, C)))).astype(np.complex128)
+    s = (rng.standard_normal((B, T, K, C)) + 1j * rng.standard_normal((B, T, K, C))) * 0.1
+    d = np.zeros_like(s)
+    for t in range(T):
+        d[:, t] = s[:, t] + (a * d[:, t - D] if t >= D else 0.0)
+    xd = np.concatenate([np.zeros((B, D, K, C), complex), d[:, :-D]], axis=1)
+    eng = ds.BatchEngine(L.ALGO_WPE, C, 32, batch=B, filter_len=N, rls_lambda=lam)
+    if fp64:
+        eng.set_param_i(L.PARAM_WPE_FP64, 1)
+    err = np.concatenate([eng.wpe_update(xd[:, i:i + 500], d[:, i:i + 500]) for i in range(0, T, 500)], axis=1)
+    # the fp64 oracle on one bin row of utterance 0: the same residual (the misadjustment of an RLS with this forgetting factor, not the kernel's)
+    from oracle import ds_oracle as O
+    o = O.OracleWpe(channels=C, filter_len=N, num_bands=32, forgetting_factor=lam, delay=D)
+    eo = np.stack([o.update_fd(xd[0, t], d[0, t]) for t in range(T)])
+    assert rms(err[0, T - 500:] - eo[T - 500:]) < 2e-3 * rms(eo[T - 500:])
+    tail = slice(T - 500, T)
+    e = rms(err[:, tail] - s[:, tail]) / rms(s[:, tail])
+    before = rms(d[:, tail] - s[:, tail]) / rms(s[:, tail])
+    measured("wpe_known_reverberation_c%dn%d%s" % (C, N, "_fp64" if fp64 else ""), residual_rel=e, reverberation_rel=before)
+    assert before > 0.8 and e < 0.03 + 1.4 * np.sqrt(C * N * (1 - lam) / 2), (before, e)   # (the reverberant part is 1.1 x the source; what is left of it: the RLS misadjustment, ~ sqrt(C N (1 - lambda) / 2))
+
+
 def test_wpe_mvdr_chain_with_wide_taps(ds):
     """the cfg4 chain (DS_ALGO_WPE_MVDR: STFT -> WPE -> McMcra -> MVDR x gain -> ISTFT) at SURVEY 8(d)'s 10-tap sizing (8 x 10 = 80):
     the oracle's composition on one utterance; utterance groups on two streams equal the whole batch bit for bit"""
