@@ -280,7 +280,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
 #endif
             break;
         case DS_ALGO_GSC: ki = ds::lookup_gsc(cfg->nfft, cfg->n_mics); break;
-        case DS_ALGO_ADAPTIVE_PF: ki = ds::lookup_adaptive_pf(cfg->nfft, cfg->n_mics); break;
+        case DS_ALGO_ADAPTIVE_PF: ki = ds::lookup_adaptive_pf(cfg->nfft, cfg->n_mics); ki.launch_long = ds::lookup_adaptive_pf_long(cfg->nfft, cfg->n_mics); break;
         case DS_ALGO_TRANSFORM:
             ki = ds::lookup_stft(cfg->nfft, cfg->n_mics, cfg->nfft / cfg->hop);
             ki_istft = ds::lookup_istft(cfg->nfft, cfg->n_mics, cfg->nfft / cfg->hop);
@@ -870,7 +870,9 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
         h->ref_pow_stream = s;                              // ds_get_state(DS_FIELD_REF_POWERS) waits for THIS stream (a caller's, possibly)
     }
     // calls of several hops: the hop-pipelined kernel (same results bit for bit; at one or two hops per call it has nothing to overlap)
-    const ds::launch_fn launch = (h->ki.launch_pipe && p.T >= h->pipe_min_T && !h->ref_powers) ? h->ki.launch_pipe : h->ki.launch;
+    // ... or the build of the kernel for long calls, where there is one (same results bit for bit)
+    const ds::launch_fn launch = (h->ki.launch_pipe && p.T >= h->pipe_min_T && !h->ref_powers) ? h->ki.launch_pipe
+                                 : (h->ki.launch_long && p.T >= DS_LONG_MIN_T) ? h->ki.launch_long : h->ki.launch;
     DS_HIP(h, launch(p, count, s));
     return DS_OK;
 }

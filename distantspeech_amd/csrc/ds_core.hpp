@@ -1502,7 +1502,11 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             Yk = adaptive_bin<M, RYY>(st, Z, a, p, sr);
         } else if constexpr (ALGO == ALGO_ADAPTIVE_PF) {
             mcra_bin(st + SL::MC_S, k, K, sh.pw[k > 0 ? k - 1 : 0], sh.pw[k], sh.pw[k + 1], frm_cnt, reset, p.mcra_L);
+#if defined(DS_PF_LONG)          // (the long-call build of this kernel: ds_kernels_adaptive_pf_long.hip)
+            Yk = adaptive_bin<M, false, true>(st, Z, a, p);
+#else
             Yk = adaptive_bin<M, false, false>(st, Z, a, p);                                   // adaptivebeamformer.py:69-120
+#endif
             float pp, G, xi, gam;
             mcmcra_bin<M>(st + SL::PF_PYY, st + SL::PF_PVV, Z, k, spp_cnt, pp, G, xi, gam);    // spp.estimation(Z)  GSC.py:225
             Yk = cscale(Yk, G);                                                                // Y * spp.G         GSC.py:286

@@ -18,6 +18,7 @@ struct KernelInfo {
     int NT;   // threads per block
     int NF = 0;   // state floats per bin (in memory: NF KP floats per utterance, see StateLayout)
     launch_fn launch_pipe = nullptr;   // the same frame program as a hop-level software pipeline (ds_pipe.hpp; 512-point frames): calls of several hops
+    launch_fn launch_long = nullptr;   // the same frame program compiled for calls of DS_LONG_MIN_T hops or more (ds_kernels_adaptive_pf_long.hip)
 };
 
 // lookups implemented in ds_kernels_*.hip; launch == nullptr when the combination is not compiled
@@ -27,6 +28,7 @@ KernelInfo lookup_adaptive_ryy(int nfft, int M);
 KernelInfo lookup_adaptive_quad(int nfft, int M);   // 8 microphones, no Ryy: the per-bin program spread over quads (ds_quad.hpp); null launch = n/a
 KernelInfo lookup_gsc(int nfft, int M);
 KernelInfo lookup_adaptive_pf(int nfft, int M);   // ALGO_ADAPTIVE_PF: MVDR + McMcra gain in one pass (ds_kernels_adaptive_pf.hip)
+launch_fn lookup_adaptive_pf_long(int nfft, int M);   // ... and its build for long calls (4 microphones, 512 points; nullptr otherwise)
 KernelInfo lookup_aic(int nfft, int M);     // ALGO_AIC: the SubbandGSC chain's tail (ds_kernels_aic.hip)
 KernelInfo lookup_stft(int nfft, int M, int ov = 2);      // ds_kernels_ops.hip; ov = nfft / hop: 2 or 4
 KernelInfo lookup_istft(int nfft, int M, int ov = 2);
@@ -197,6 +199,26 @@ hipError_t launch_frames(const Params& p, int nblocks, hipStream_t stream) {
     hipLaunchKernelGGL((ds_frames_kernel<NFFT, M, ALGO, RYY>), dim3(nblocks), dim3(E::NT), 0, stream, p);
     return hipGetLastError();
 }
+
+// The same kernel under a second name, for a translation unit that compiles the frame program differently for LONG calls (ds_kernels_adaptive_pf_long.hip:
+// no SLP vectoriser, the MVDR sweep's conjugation folded into its first column — bit-identical to the default, + 1.5 % from two hops per call on,
+// but - 1.6 … - 3.6 % at one hop per call for the MVDR + post-filter kernel: so that kernel exists twice and the call length picks)
+template <int NFFT, int M, int ALGO, bool RYY>
+__global__ void __launch_bounds__(NFFT / 2, frames_min_waves(M, ALGO, RYY, NFFT)) ds_frames_long_kernel(Params p) {
+    typedef Engine<NFFT, M, ALGO, RYY> E;
+    __shared__ typename E::Sh sh;
+    HipExec<typename E::Rg, frames_hoist(NFFT, M, ALGO, RYY)> ex;
+    E::run(ex, p, (int)blockIdx.x, sh);
+}
+template <int NFFT, int M, int ALGO, bool RYY>
+hipError_t launch_frames_long(const Params& p, int nblocks, hipStream_t stream) {
+    typedef Engine<NFFT, M, ALGO, RYY> E;
+    hipLaunchKernelGGL((ds_frames_long_kernel<NFFT, M, ALGO, RYY>), dim3(nblocks), dim3(E::NT), 0, stream, p);
+    return hipGetLastError();
+}
+#ifndef DS_LONG_MIN_T
+#define DS_LONG_MIN_T 2
+#endif
 
 #if defined(DS_WITH_SHELVED)
 // the hop-pipelined form of the same program (ds_pipe.hpp): same state, same arguments, same results bit for bit
