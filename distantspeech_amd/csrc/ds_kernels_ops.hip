@@ -522,17 +522,20 @@ template <int LPB, int CT = 0, int NTAPS = 0> __global__ void __launch_bounds__(
     E::run(ex, p, (int)blockIdx.x, sh);
 }
 // two rows of P per lane (ds_wpe2.hpp) for calls of DS_WPE2_MIN_T frames or more: the shapes with C N = 16 / 8 and a lane per channel.  Hoisted
-// lane geometry (HipExec<.., 2>: the bin split, bounds and LDS addresses once per call instead of once per phase and frame: 520 -> 419 vector
+// lane geometry (HipExec<.., 2>: the bin split, bounds and LDS addresses once per call instead of once per phase and frame: 516 -> 435 vector
 // instructions per lane and frame at 8 x 2) inside three waves per SIMD (168 registers).  Bit-identical to the one-row kernels, so the choice
 // by call length changes no result; at one frame per call the one-row kernel stays (HBM-bound there: twice the lanes, twice the loads in flight:
 // the two-row kernel is 20 % slower at T = 1, 9 % faster at T = 312 on BASELINE config 4, profiles/r05a/cfg4_wpe2_ab.txt)
+#ifndef DS_WPE2_HOIST
+#define DS_WPE2_HOIST 2
+#endif
 #ifndef DS_WPE2_MIN_T
 #define DS_WPE2_MIN_T 8
 #endif
 template <int CT, int NTAPS> __global__ void __launch_bounds__(WPE_NT, 3) ds_wpe2_kernel(WpeParams p) {
     typedef WpeEngine2<CT, NTAPS> E;
     __shared__ typename E::Sh sh;
-    HipExec<typename E::Rg, 2> ex;
+    HipExec<typename E::Rg, (CT == 4 && NTAPS == 4) ? 0 : DS_WPE2_HOIST> ex;     // (4 x 4 with hoisted geometry: 60 B of scratch at three waves per SIMD)
     E::run(ex, p, (int)blockIdx.x, sh);
 }
 hipError_t launch_wpe(const WpeParams& p, int generic, hipStream_t stream) {

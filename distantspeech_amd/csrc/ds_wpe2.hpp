@@ -7,6 +7,10 @@
 // partial products from LDS, and computes the bin's denominator on its own.  Two rows per lane halve those reads and the per-lane work (bin
 // split, bounds, addresses, denominator) per row of P; the rows' own arithmetic is the statement sequence of WpeEngine, operand for operand,
 // so the results are bit-identical to it (tests: this engine against the generic one, outputs and exported state).
+// The prediction filters W live as ROWS here: lane c < C keeps W[c][0 .. C N) (the one-row kernel keeps a column per lane).  The filter output
+// err_c = d_c - sum_i conj(W[c][i]) X_i is then lane-local — the same products added in the same order as the one-row kernel's sum over the
+// lanes' partial products, without the partial-product array and the err hand-off in LDS (29 of the ~60 LDS instructions per lane and frame,
+// and the frame's third phase) — and so is the update W[c][i] += conj(err_c) kn_i with the g_i the downdate reads anyway.
 // State layout, parameters and the phase structure (wave-local phases, Exec policy) are ds_wpe.hpp's.
 #pragma once
 #include "ds_wpe.hpp"
@@ -27,17 +31,16 @@ template <int CT, int NTAPS> struct Wpe2Shared {
     typedef Wpe2Dims<CT, NTAPS> D;
     cf X[2][D::BPW][D::CN];               // input buffer, double-buffered across frames
     cf d[D::BPW][D::C];
-    alignas(16) cf part[D::BPW][D::PR][D::CN + 2];  // conj(W[c][i]) X_i; doubles as the tile the packed triangle of P passes through
+    alignas(16) cf part[D::BPW][D::PR][D::CN + 2];  // the tile the packed triangle of P passes through on its way in and out (ds_wpe.hpp's layout of it)
     cf num[D::BPW][D::CN];                // g_i = (P X)_i
     float dre[D::BPW][D::CN];             // Re(conj(X_i) g_i)
-    cf err[D::BPW][D::C];
 };
 
 template <int CT, int NTAPS> struct Wpe2Regs {
     typedef Wpe2Dims<CT, NTAPS> D;
     cf P[2][D::CN];
-    cf W[2][D::C];
-    cf num[2], xin[2], din;
+    cf W[D::CN];                          // row l of W (lanes l < C)
+    cf xin[2], din, err;
     float var;
     long long io0, ring0;
 };
@@ -48,6 +51,7 @@ template <int CT, int NTAPS> struct WpeEngine2 {
     typedef Wpe2Regs<CT, NTAPS> Rg;
     static constexpr int NT = WPE_NT, C = D::C, N = D::N, CN = D::CN, LH = D::LH, BPW = D::BPW;
     static_assert(D::PR * (CN + 2) >= D::TW, "the tile holds the packed triangle");
+    static_assert(D::PR * (CN + 2) >= C * CN, "... and, after it, the C rows of W");
 
     template <class Exec> static DS_HD void run(Exec& ex, const WpeParams& p, int blk, Sh& sh) {
         const int SB = wpe_bin_floats(C, N);
@@ -92,11 +96,8 @@ template <int CT, int NTAPS> struct WpeEngine2 {
             if (Lb.lines) {
                 for (int w = 2 * l; w < Lb.tri_words; w += 2 * LH) *reinterpret_cast<vec4*>(&tri[w]) = load_state(reinterpret_cast<const vec4*>(&st[w]));
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) r.W[h][c] = load_state(&st[Lb.w0 + c * CN + l + h * LH]);
-                    sh.X[0][s][l + h * LH] = load_state(&st[Lb.x0 + l + h * LH]);
-                }
+                for (int h = 0; h < 2; ++h) sh.X[0][s][l + h * LH] = load_state(&st[Lb.x0 + l + h * LH]);
+                r.err = mk(0.0f, 0.0f);
                 r.var = 0.0f;                                     // (arrives with the tile: taken in the next phase)
             } else {
                 if ((Lb.tri_words & 1) == 0) {
@@ -105,11 +106,8 @@ template <int CT, int NTAPS> struct WpeEngine2 {
                     for (int w = l; w < Lb.tri_words; w += LH) tri[w] = st[w];
                 }
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) r.W[h][c] = st[Lb.w0 + c * CN + l + h * LH];
-                    sh.X[0][s][l + h * LH] = st[Lb.x0 + l + h * LH];
-                }
+                for (int h = 0; h < 2; ++h) sh.X[0][s][l + h * LH] = st[Lb.x0 + l + h * LH];
+                r.err = mk(0.0f, 0.0f);
                 r.var = stf[Lb.var_f];
             }
             const long long b = g / p.K, k = g - b * p.K;
@@ -131,6 +129,28 @@ template <int CT, int NTAPS> struct WpeEngine2 {
                 for (int q = 0; q < CN; ++q) r.P[h][q] = q >= i ? tri[q * (q + 1) / 2 + i] : cconj(tri[i * (i + 1) / 2 + q]);
             }
             if (CN == WPE_CNMAX) r.var = tri[wpe_packed(WPE_CNMAX)].x;     // the line layout keeps var behind the triangle (wpe_layout)
+        });
+        // W, C rows of C N words back to back in the block: through the same tile (coalesced 16-byte pieces on the HBM side), then lane l < C takes row l
+        constexpr bool WV4 = (wpe_layout(C, N).w0 & 1) == 0;
+        ex.phase_wave([&](int tid, Rg& r) {
+            int s, l; long long g; bool on;
+            slot(tid, s, l, g, on);
+            if (!on) return;
+            const cf* st = reinterpret_cast<const cf*>(bin_state(g));
+            cf* tri = &sh.part[s][0][0];
+            if (WV4) {
+                for (int w = 2 * l; w < C * CN; w += 2 * LH) *reinterpret_cast<vec4*>(&tri[w]) = load_state(reinterpret_cast<const vec4*>(&st[Lb.w0 + w]));
+            } else {
+                for (int w = l; w < C * CN; w += LH) tri[w] = st[Lb.w0 + w];
+            }
+        });
+        ex.phase_wave([&](int tid, Rg& r) {
+            int s, l; long long g; bool on;
+            slot(tid, s, l, g, on);
+            if (!on) return;
+            const cf* tri = &sh.part[s][0][0];
+#pragma unroll
+            for (int q = 0; q < CN; ++q) r.W[q] = l < C ? tri[l * CN + q] : mk(0.0f, 0.0f);
         });
         int cur = 0;
         for (int t = 0; t < p.T; ++t) {
@@ -155,12 +175,14 @@ template <int CT, int NTAPS> struct WpeEngine2 {
                     }
                 }
             });
-            // ---- per-row products: g_i = (P X)_i, conj(W[c][i]) X_i, Re(conj(X_i) g_i); the tap buffer is read once for both rows
+            // ---- per-row products g_i = (P X)_i and Re(conj(X_i) g_i); err_l = d_l - sum_i conj(W[l][i]) X_i (:158-161: the products one by one,
+            // added in tap order — what the one-row kernel's lanes hand to their channel's lane through LDS).  The tap buffer is read once for all of it
             ex.phase_wave([&](int tid, Rg& r) {
                 int s, l; long long g; bool on;
                 slot(tid, s, l, g, on);
                 if (!on) return;
                 cf a0[2] = {mk(0.0f, 0.0f), mk(0.0f, 0.0f)}, a1[2] = {mk(0.0f, 0.0f), mk(0.0f, 0.0f)};
+                cf o = mk(0.0f, 0.0f);
 #pragma unroll
                 for (int j = 0; j < CN; j += 2) {
                     const cf x0 = sh.X[nxt][s][j], x1 = sh.X[nxt][s][j + 1];
@@ -169,17 +191,23 @@ template <int CT, int NTAPS> struct WpeEngine2 {
                         a0[h] = cfma(a0[h], r.P[h][j], x0);
                         a1[h] = cfma(a1[h], r.P[h][j + 1], x1);
                     }
+                    o = cadd(o, cmulc(x0, r.W[j]));
+                    o = cadd(o, cmulc(x1, r.W[j + 1]));
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int i = l + h * LH;
                     const cf Xi = sh.X[nxt][s][i];
                     const cf a = cadd(a0[h], a1[h]);
-                    r.num[h] = a;
                     sh.num[s][i] = a;
                     sh.dre[s][i] = fma_(Xi.x, a.x, Xi.y * a.y);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) sh.part[s][c][i] = cmulc(Xi, r.W[h][c]);
+                }
+                if (l < C) {
+                    const cf e = csub(r.din, o);
+                    r.err = e;
+                    const long long f = io_at(r, t);
+                    p.err[2 * (f + l)] = e.x; p.err[2 * (f + l) + 1] = e.y;
+                    if (p.err0 != nullptr && l == 0) { const long long f0 = f / C; p.err0[2 * f0] = e.x; p.err0[2 * f0 + 1] = e.y; }   // [B][T][K]
                 }
                 if (t + 1 < p.T) {                                 // next frame's inputs: in flight behind this frame's arithmetic
                     const long long f1 = io_at(r, t + 1);
@@ -187,19 +215,6 @@ template <int CT, int NTAPS> struct WpeEngine2 {
                     for (int h = 0; h < 2; ++h) r.xin[h] = delayed(r, t + 1, (l + h * LH) / N);
                     if (l < C) r.din = mk(p.d[2 * (f1 + l)], p.d[2 * (f1 + l) + 1]);
                 }
-            });
-            // ---- err_c = d_c - sum_i conj(W[c][i]) X_i in lane order  (:158-161)
-            ex.phase_wave([&](int tid, Rg& r) {
-                int s, l; long long g; bool on;
-                slot(tid, s, l, g, on);
-                if (!on || l >= C) return;
-                cf o = mk(0.0f, 0.0f);
-                for (int q = 0; q < CN; ++q) o = cadd(o, sh.part[s][l][q]);
-                const cf e = csub(sh.d[s][l], o);
-                sh.err[s][l] = e;
-                const long long f = io_at(r, t);
-                p.err[2 * (f + l)] = e.x; p.err[2 * (f + l) + 1] = e.y;
-                if (p.err0 != nullptr && l == 0) { const long long f0 = f / C; p.err0[2 * f0] = e.x; p.err0[2 * f0 + 1] = e.y; }   // [B][T][K]
             });
             // ---- gain, P and W updates (g read once for both rows)
             ex.phase_wave([&](int tid, Rg& r) {
@@ -213,22 +228,42 @@ template <int CT, int NTAPS> struct WpeEngine2 {
                 for (int q = 0; q < CN; ++q) den += sh.dre[s][q];                          // :174-180, real part (ds_wpe.hpp)
                 const float dinv = den == 0.0f ? 0.0f : 1.0f / den;                        // (digital silence: ds_wpe.hpp)
                 const float dls = dinv * lam_inv;
+                const cf gi[2] = {sh.num[s][l], sh.num[s][l + LH]};                         // (re-read: four registers less across the phase boundary)
 #pragma unroll
                 for (int j = 0; j < CN; ++j) {
                     const cf gj = sh.num[s][j];
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) r.P[h][j] = herm_downdate(r.P[h][j], r.num[h], gj, lam_inv, dls);     // :183-185 (ds_wpe.hpp)
-                }
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const cf kn = cscale(r.num[h], dinv);
-#pragma unroll
-                    for (int c = 0; c < C; ++c) r.W[h][c] = cadd(r.W[h][c], cmulc(kn, sh.err[s][c]));                 // W_c += conj(err_c) kn  :188-189
+                    for (int h = 0; h < 2; ++h) r.P[h][j] = herm_downdate(r.P[h][j], gi[h], gj, lam_inv, dls);     // :183-185 (ds_wpe.hpp)
+                    r.W[j] = cadd(r.W[j], cmulc(cscale(gj, dinv), r.err));                                            // W_l += conj(err_l) kn  :188-189
                 }
             });
             cur = nxt;
         }
+        ex.phase_wave([&](int tid, Rg& r) {
+            DS_PIN(tid);                                                   // (once per call: the bin's address and the lane's place in it formed again here, not held across the frame loop)                            // W back: rows into the tile ...
+            int s, l; long long g; bool on;
+            slot(tid, s, l, g, on);
+            if (!on || l >= C) return;
+            cf* tri = &sh.part[s][0][0];
+#pragma unroll
+            for (int q = 0; q < CN; ++q) tri[l * CN + q] = r.W[q];
+        });
+        ex.phase_wave([&](int tid, Rg& r) {                            // ... and out of it in coalesced pieces
+            DS_PIN(tid);
+            int s, l; long long g; bool on;
+            slot(tid, s, l, g, on);
+            if (!on) return;
+            cf* st = reinterpret_cast<cf*>(bin_state(g));
+            const cf* tri = &sh.part[s][0][0];
+            if (WV4) {
+                if (Lb.lines) { for (int w = 2 * l; w < C * CN; w += 2 * LH) store_state(reinterpret_cast<vec4*>(&st[Lb.w0 + w]), *reinterpret_cast<const vec4*>(&tri[w])); }
+                else { for (int w = 2 * l; w < C * CN; w += 2 * LH) *reinterpret_cast<vec4*>(&st[Lb.w0 + w]) = *reinterpret_cast<const vec4*>(&tri[w]); }
+            } else {
+                for (int w = l; w < C * CN; w += LH) st[Lb.w0 + w] = tri[w];
+            }
+        });
         ex.phase_wave([&](int tid, Rg& r) {                            // the upper triangle back through the tile
+            DS_PIN(tid);
             int s, l; long long g; bool on;
             slot(tid, s, l, g, on);
             if (!on) return;
@@ -243,6 +278,7 @@ template <int CT, int NTAPS> struct WpeEngine2 {
             if (CN == WPE_CNMAX) tri[wpe_packed(WPE_CNMAX) + l] = mk(l == 0 ? r.var : 0.0f, 0.0f);       // (var, 0) and the line's padding (LH = 8 words)
         });
         ex.phase_wave([&](int tid, Rg& r) {
+            DS_PIN(tid);
             int s, l; long long g; bool on;
             slot(tid, s, l, g, on);
             if (!on) return;
@@ -252,11 +288,7 @@ template <int CT, int NTAPS> struct WpeEngine2 {
             if (Lb.lines) {                                       // (var went into the tile with the rows, one phase back)
                 for (int w = 2 * l; w < Lb.tri_words; w += 2 * LH) store_state(reinterpret_cast<vec4*>(&st[w]), *reinterpret_cast<const vec4*>(&tri[w]));
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) store_state(&st[Lb.w0 + c * CN + l + h * LH], r.W[h][c]);
-                    store_state(&st[Lb.x0 + l + h * LH], sh.X[cur][s][l + h * LH]);
-                }
+                for (int h = 0; h < 2; ++h) store_state(&st[Lb.x0 + l + h * LH], sh.X[cur][s][l + h * LH]);
             } else {
                 if ((Lb.tri_words & 1) == 0) {
                     for (int w = 2 * l; w < Lb.tri_words; w += 2 * LH) *reinterpret_cast<vec4*>(&st[w]) = *reinterpret_cast<const vec4*>(&tri[w]);
@@ -264,11 +296,7 @@ template <int CT, int NTAPS> struct WpeEngine2 {
                     for (int w = l; w < Lb.tri_words; w += LH) st[w] = tri[w];
                 }
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                    for (int c = 0; c < C; ++c) st[Lb.w0 + c * CN + l + h * LH] = r.W[h][c];
-                    st[Lb.x0 + l + h * LH] = sh.X[cur][s][l + h * LH];
-                }
+                for (int h = 0; h < 2; ++h) st[Lb.x0 + l + h * LH] = sh.X[cur][s][l + h * LH];
                 if (l == 0) stf[Lb.var_f] = r.var;
             }
         });
