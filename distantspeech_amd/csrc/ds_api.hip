@@ -192,6 +192,12 @@ static void mirrors_set(ds_handle* h, const ChainMirrors& m) {
     }
     h->hist_cur = m.hist;
 }
+// forget every cached hipGraph of a handle (a captured sequence holds device addresses and kernel choices of the moment it was captured)
+static void drop_graphs(ds_handle* h) {
+    h->graph_valid = false; h->chain_warm_n = -1;
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    for (int g = 0; g < 8; ++g) if (h->group_exec[g]) { (void)hipGraphExecDestroy(h->group_exec[g]); h->group_exec[g] = nullptr; }
+}
 static void advance_host_counters_keep_first(ds_handle* h, int frames, int L) {
     const int first = h->op_first;
     advance_host_counters(h, frames, L);
@@ -262,6 +268,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
         return fail(nullptr, DS_EUNSUPPORTED, "ds_create: the beamformer objects take hop == nfft/2 (the only overlap their reference callers use)");
     if (cfg->algo == DS_ALGO_TRANSFORM && cfg->hop * 2 != cfg->nfft && cfg->hop * 4 != cfg->nfft)
         return fail(nullptr, DS_EUNSUPPORTED, "ds_create: Transform takes hop == nfft/2 or hop == nfft/4");
+    if (cfg->algo == DS_ALGO_ADAPTIVE_PF && cfg->track_ryy)
+        return fail(nullptr, DS_EUNSUPPORTED, "ds_create: DS_ALGO_ADAPTIVE_PF keeps no Ryy (track_ryy must be 0; TFGSC is not one of its methods)");
     KernelInfo ki = {nullptr, 0, 0, 0};
     KernelInfo ki_istft = {nullptr, 0, 0, 0};
     int op = -1, NF = 0;
@@ -680,6 +688,9 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
             if (t->wpe_started) return fail(h, DS_ESTATE, "wpe fp64 must be set before the first frame (or after ds_reset)");
             int rc = set_device(h); if (rc) return rc;
             DS_HIP(h, hipStreamSynchronize(t->stream));
+            // a captured sequence holds the address of the double state (and the kernel that reads it): drop every cached graph of the
+            // chain before the block goes away, and make the next sequence warm up with plain launches again
+            drop_graphs(h); if (t != h) drop_graphs(t);
             if (value == 0) { (void)hipFree(t->wpe64); t->wpe64 = nullptr; return DS_OK; }
             if (!t->wpe64) {
                 const size_t bytes = (size_t)t->cfg.batch * wpe64_ust(t) * sizeof(double);
@@ -687,7 +698,6 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
             }
             DS_HIP(h, ds::launch_wpe64_init(t->wpe64, t->cfg.batch, t->K, (long long)wpe64_ust(t), t->cfg.n_mics, t->filter_len, t->stream));
             DS_HIP(h, hipStreamSynchronize(t->stream));
-            h->graph_valid = false;
             return DS_OK;
         }
         case DS_PARAM_WPE_DELAY:
@@ -816,6 +826,8 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
         if (stream && (hipStream_t)stream != h->stream) return fail(h, DS_EUNSUPPORTED, "ds_process_device: a chain handle runs on its own stream (pass NULL)");
         if (n_samples < 0 || n_samples % h->cfg.hop != 0) return fail(h, DS_ESHAPE, "ds_process_device: n_samples must be a multiple of hop");
         if (layout != DS_LAYOUT_SAMPLES_CHANNELS && layout != DS_LAYOUT_CHANNELS_SAMPLES) return fail(h, DS_EINVAL, "ds_process_device: unknown layout");
+        if (((uintptr_t)x_dev & 15) || ((uintptr_t)y_dev & 15) || (x_batch_stride & 3) || (x_chan_stride & 3) || (y_batch_stride & 3))
+            return fail(h, DS_EINVAL, "ds_process_device: device buffers must be 16-byte aligned (strides multiples of 4 elements)");
         if (n_samples == 0) return DS_OK;
         return nbmvdr_process_device(h, x_dev, layout, x_batch_stride, x_chan_stride, n_samples, y_dev, y_batch_stride, nullptr);
     }
@@ -989,7 +1001,8 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     const long long key[16] = {(long long)(uintptr_t)x_dev, (long long)(uintptr_t)y_dev, layout, x_batch_stride, x_chan_stride,
                                x_call_stride, n_samples_per_call, n_calls, y_batch_stride, y_call_stride,
                                ((long long)first << 32) | (unsigned)count, ((long long)h->method << 32) | (unsigned)h->mcra_L,
-                               fbits[0], fbits[1], fbits[2] ^ ((long long)h->split << 40) ^ ((long long)h->parts << 44), (long long)(uintptr_t)h->steer};
+                               fbits[0], fbits[1], fbits[2] ^ ((long long)h->split << 40) ^ ((long long)h->parts << 44) ^ ((long long)((wpe_chain(h) && h->sub[1] && h->sub[1]->wpe64) ? 1 : 0) << 52),
+                               (long long)(uintptr_t)h->steer};
     if (!h->graph_valid || std::memcmp(key, h->graph_key, sizeof key) != 0) {
         if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
         h->graph_valid = false;
@@ -1032,6 +1045,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
             ds_handle* t = i < 10 ? h->sub[i] : h;
             if (!t) continue;
             advance_host_counters_keep_first(t, h->adv_frames[i], t->cfg.algo == DS_ALGO_MCSPP ? 65 : t->mcra_L);
+            if (t->op == ds::OP_WPE && h->adv_frames[i] > 0) t->wpe_started = true;   // a replay never passes through wpe_launch, which sets it
             t->td_cur ^= h->adv_td[i];
         }
         h->hist_cur = (h->hist_cur + h->adv_hist) % (h->wpe_delay > 0 ? h->wpe_delay : 1);
@@ -1130,7 +1144,7 @@ size_t ds_field_bytes(const ds_handle* h, int field) {
     const bool ad = h->cfg.algo == DS_ALGO_ADAPTIVE || pf, gsc = h->cfg.algo == DS_ALGO_GSC;
     switch (field) {
         case DS_FIELD_RVV: return ad ? B * K * M * M * 2 * sizeof(float) : 0;
-        case DS_FIELD_RYY: return (ad && h->cfg.track_ryy) ? B * K * M * M * 2 * sizeof(float) : 0;
+        case DS_FIELD_RYY: return (ad && !pf && h->cfg.track_ryy) ? B * K * M * M * 2 * sizeof(float) : 0;
         case DS_FIELD_MCRA_S: case DS_FIELD_MCRA_SMIN: case DS_FIELD_MCRA_STMP: case DS_FIELD_MCRA_P:
         case DS_FIELD_MCRA_LAMBDA_D: return ad ? B * K * sizeof(float) : 0;
         case DS_FIELD_PHI_YY: case DS_FIELD_PHI_VV: return (gsc || pf) ? B * K * M * M * sizeof(float) : 0;

@@ -346,7 +346,7 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
         p.cdr_gamma = cb[G_GAM]; p.cdr_qavg = cb[G_GAM] + (size_t)B * T * K;
         // the FIR history's ping-pong halves by value (the host mirror of the parity: a pipelined chain is never replayed as a graph); the
         // device copy of the parity still flips, in this launch, so that the separate kernels could take over at any block
-        p.fe_coef = fe->dev_buf[9]; p.fe_L = Lt; p.fe_mem = fe->td_mem; p.fe_radius = fe->cfg.filt_alpha; p.fe_fixed = cb[G_FIXED];
+        p.fe_coef = fe->dev_buf[9]; p.fe_L = Lt; p.fe_mem = fe->td_mem; p.fe_radius = ds::decimal_double(fe->cfg.filt_alpha); p.fe_fixed = cb[G_FIXED];
         p.fe_cache_in = fe->td_cache[fe->td_cur]; p.fe_cache_out = fe->td_cache[fe->td_cur ^ 1];
         rc = post_tick(fe, fe->dev_cnt, 0, 1, 1, 2, fs); if (rc) return rc;
         fe->td_cur ^= 1;
@@ -357,7 +357,7 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
         ds::TdParams p;
         std::memset(&p, 0, sizeof p);
         p.B = B; p.M = M; p.n = n; p.x = x_dev; p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.y = cb[G_XN]; p.mem = fe->td_mem;
-        p.radius = fe->cfg.filt_alpha;
+        p.radius = ds::decimal_double(fe->cfg.filt_alpha);
         DS_HIP(h, ds::launch_dcnotch(p, fs));
         if (early && h->bf_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[8 + set], 0));    // the FIR bank writes the fixed-beamformer block
         std::memset(&p, 0, sizeof p);

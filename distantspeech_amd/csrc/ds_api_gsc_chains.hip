@@ -150,7 +150,7 @@ static int front_end(ds_handle* h, const float* x, long long x_bstride, long lon
     if (notch) {
         std::memset(&p, 0, sizeof p);
         p.B = B; p.M = M; p.n = n; p.x = x; p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.y = cb[Q_XN]; p.mem = fe->td_mem;
-        p.radius = fe->cfg.filt_alpha;
+        p.radius = ds::decimal_double(fe->cfg.filt_alpha);
         DS_HIP(h, ds::launch_dcnotch(p, h->stream));
         fir_in = cb[Q_XN]; fin_b = (long long)M * n; fin_c = n;
     } else if (x_bstride != (long long)M * n || x_cstride != n) {

@@ -386,7 +386,7 @@ int ds_dcnotch(ds_handle* h, const float* x, int n_samples, float* y, int mem) {
     ds::TdParams p;
     std::memset(&p, 0, sizeof p);
     p.B = h->cfg.batch; p.M = h->cfg.n_mics; p.n = n_samples; p.x = din[0]; p.y = dout[0]; p.mem = h->td_mem;
-    p.radius = h->cfg.filt_alpha > 0 ? h->cfg.filt_alpha : 0.9f;
+    p.radius = ds::decimal_double(h->cfg.filt_alpha > 0 ? h->cfg.filt_alpha : 0.9f);
     DS_HIP(h, ds::launch_dcnotch(p, h->stream));
     return io_end(h, mem, io, dout);
 }

@@ -22,6 +22,8 @@
 //   FD-GSC + McMcra gain  beamformer/GSC.py:174-294, noise_estimation/mc_mcra.py:91-224
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -65,6 +67,15 @@ struct alignas(16) vec4 { float x, y, z, w; };
 #endif
 
 struct cf { float x, y; };
+
+// A coefficient the caller wrote as a decimal (0.98, 0.998) arrives as a float through ds_config; where the recursion that uses it runs in
+// double (the DC notch, the RLS-WPE recursion's double mode) the double the caller MEANT is the shortest decimal that rounds to that float
+// (<= 7 significant digits), which is what the reference's Python float is: 0.98f = 0.98 (1 + 1.9e-8) -> 0.98.  Host side only.
+inline double decimal_double(float v) {
+    char buf[32];
+    snprintf(buf, sizeof buf, "%.7g", (double)v);
+    return strtod(buf, nullptr);
+}
 
 // All floating-point contraction is explicit: the library is compiled with -ffp-contract=off and every
 // fused multiply-add below is written as fma_(), so a value's rounding never depends on which copy of
@@ -332,7 +343,7 @@ struct Params {
     const float* fe_cache_in; // FIR history [B][M][L-1] before this call ...
     float* fe_cache_out;      // ... and after it (the other half of the ping-pong pair)
     float* fe_fixed;          // channel mean of the aligned channels, [B][T * hop] (the fixed beamformer's block)
-    float fe_radius;
+    double fe_radius;         // the decimal the caller wrote, as a double (decimal_double)
     float* cdr_gamma;         // out: Gamma [B][T][K]
     float* cdr_qavg;          // out: mean of 1 - Gamma over the 500-2000 Hz band, [B][T]  (mcspp.py:258-260)
 };
@@ -2065,7 +2076,7 @@ template <int NFFT, int M, bool CDR = false, int OV = 2, bool FRONT = false> str
                 // ---- DC notch, in place: one lane per channel, serial in time (ds_ops.hpp td_dcnotch: same statements) ----------------------
                 ex.phase([&](int tid, Rg& r) {
                     if (tid >= M) return;
-                    const double rr = (double)p.fe_radius, r2 = rr * rr + 0.7 * (1.0 - rr) * (1.0 - rr);   // notch_den2 / notch_step of ds_ops.hpp, word for word
+                    const double rr = p.fe_radius, r2 = rr * rr + 0.7 * (1.0 - rr) * (1.0 - rr);   // notch_den2 / notch_step of ds_ops.hpp, word for word
                     float* row = W + tid * WL + OFF;
                     double m0 = r.nm0, m1 = r.nm1;
                     for (int i = 0; i < HOP; ++i) {

@@ -262,7 +262,7 @@ constexpr int NOTCH_ROWS = 32, NOTCH_TS = 256, NOTCH_NT = 256, NOTCH_LD = NOTCH_
 template <bool VEC> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kernel(TdParams p) {
     __shared__ __attribute__((aligned(16))) float tile[2][NOTCH_ROWS][NOTCH_LD];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, row0 = blockIdx.x * NOTCH_ROWS, rows = p.B * p.M;
-    const double r = (double)p.radius, den2 = notch_den2(p.radius);             // the recursion in double: see td_dcnotch
+    const double r = p.radius, den2 = notch_den2(p.radius);             // the recursion in double: see td_dcnotch
     const bool rec = wv == 0 && lane < NOTCH_ROWS && row0 + lane < rows;      // this lane runs the recursion of row `lane`
     double m0 = 0.0, m1 = 0.0;
     if (rec) { m0 = p.mem[(long long)(row0 + lane) * 2]; m1 = p.mem[(long long)(row0 + lane) * 2 + 1]; }

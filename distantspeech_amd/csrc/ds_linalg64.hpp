@@ -118,6 +118,100 @@ template <int M> DS_HD void herm_inverse_d(const cd (&A)[M][M], cd (&inv)[M][M])
         }
 }
 
+// The inverse of a Hermitian positive-definite A kept as the INVERSE OF ITS CHOLESKY FACTOR (round 6; the double twin of ds_core.hpp's
+// Chol::invert / apply / trace_with): A = L L^H, Li = L^-1 (lower triangular, real diagonal), A^-1 = Li^H Li.  Everything the notebook operator
+// takes from inv(Phi_vv + dv I) is a product with it — tr(A^-1 Phi_yy) = sum over the rows r_i of Li of the quadratic forms r_i Phi_yy r_i^H,
+// A^-1 y = Li^H (Li y), a^H A^-1 a = |Li a|^2 — so the explicit inverse (2 M^2 doubles, both triangles) never has to exist beside the factor:
+// M^2 doubles live instead of 3 M^2 at the peak of herm_inverse_d, for about the same arithmetic.
+template <int M> struct CholInvD {
+    double id[M];                               // diagonal of Li = 1 / diagonal of L
+    cd lo[M * (M - 1) / 2 + 1];                 // strictly lower triangle, row-wise: (i, j), i > j, at i (i - 1) / 2 + j
+    DS_HD cd& at(int i, int j) { return lo[i * (i - 1) / 2 + j]; }
+    DS_HD const cd& at(int i, int j) const { return lo[i * (i - 1) / 2 + j]; }
+    // a(i, j), i >= j: the lower triangle of A (a(j, j).x its real diagonal)
+    template <class Get> DS_HD void factor_invert(Get a) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            double s = a(j, j).x;
+#pragma unroll
+            for (int q = 0; q < j; ++q) s = fmad_(-at(j, q).x, at(j, q).x, fmad_(-at(j, q).y, at(j, q).y, s));
+            s = s > 1e-300 ? s : 1e-300;
+            const double r = 1.0 / sqrt(s);
+            id[j] = r;
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) {
+                cd t = a(i, j);
+#pragma unroll
+                for (int q = 0; q < j; ++q) t = cdfnmac(t, at(i, q), at(j, q));
+                at(i, j) = cdscale(t, r);
+            }
+        }
+        // L -> L^-1 in place, column by column: entry (i, j) from row i of L to the right of column j (not overwritten yet) and the finished
+        // part of column j
+#pragma unroll
+        for (int j = 0; j < M; ++j)
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) {
+                cd t = cdscale(at(i, j), id[j]);
+#pragma unroll
+                for (int q = j + 1; q < i; ++q) t = cdfma(t, at(i, q), at(q, j));
+                at(i, j) = cdscale(t, -id[i]);
+            }
+    }
+    // u = Li b
+    DS_HD void lower(const cd* b, cd* u) const {
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            cd t = cdscale(b[i], id[i]);
+#pragma unroll
+            for (int j = 0; j < i; ++j) t = cdfma(t, at(i, j), b[j]);
+            u[i] = t;
+        }
+    }
+    // v = Li^H u
+    DS_HD void upper(const cd* u, cd* v) const {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            cd t = cdscale(u[j], id[j]);
+#pragma unroll
+            for (int i = j + 1; i < M; ++i) t = cdfmac(t, u[i], at(i, j));          // + conj(Li_ij) u_i
+            v[j] = t;
+        }
+    }
+    // Re tr(A^-1 R), R Hermitian through its getter R(j, k) (any order of the indices)
+    template <class Get> DS_HD double trace_with(Get R) const {
+        double tr = 0.0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            double q = id[i] * id[i] * R(i, i).x, c2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < i; ++j) {
+                const cd rj = at(i, j);
+                q = fmad_(cdabs2(rj), R(j, j).x, q);
+                { const cd rji = R(j, i); c2 = fmad_(rj.x * id[i], rji.x, fmad_(-(rj.y * id[i]), rji.y, c2)); }   // Re(r_ij R_ji r_ii), r_ii real
+#pragma unroll
+                for (int k = j + 1; k < i; ++k) {
+                    const cd c = cdmulc(rj, at(i, k)), rjk = R(j, k);               // r_ij conj(r_ik)
+                    c2 = fmad_(c.x, rjk.x, fmad_(-c.y, rjk.y, c2));                 // Re(r_ij R_jk conj(r_ik))
+                }
+            }
+            tr += fmad_(2.0, c2, q);
+        }
+        return tr;
+    }
+    // entry (i, j) of A^-1 = sum over q >= max(i, j) of conj(Li_qi) Li_qj   (only where a caller wants the matrix itself)
+    DS_HD cd inverse_entry(int i, int j) const {
+        cd t = mkd(0.0, 0.0);
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+            if (q < i || q < j) continue;
+            const cd a = q == i ? mkd(id[q], 0.0) : at(q, i), b = q == j ? mkd(id[q], 0.0) : at(q, j);
+            t = cdfmac(t, b, a);                                                    // + b conj(a)
+        }
+        return t;
+    }
+};
+
 // principal eigenvector (largest eigenvalue) of the Hermitian A (destroyed) by cyclic complex Jacobi, phase-normalised by
 // element 0 (beamformer/beamformer.py:10-31: np.linalg.eigh(...)[1][:, :, -1] / exp(j angle(v0))).  Sweeps stop when no rotation
 // of a sweep was larger than rounding (quadratic convergence: 5-7 sweeps in double for M <= 8).
@@ -195,6 +289,216 @@ template <int M> DS_HD void herm_principal_d(cd (&A)[M][M], cd* v) {
         for (int i = 0; i < M; ++i) if (i == best) vk = V[k][i];
         v[k] = cdmul(vk, ph);
     }
+}
+
+// The same vector by a DIRECT method (round 6): Householder tridiagonalisation -> the largest root of the tridiagonal's characteristic
+// polynomial by Laguerre's iteration from the Gershgorin bound -> inverse iteration on the tridiagonal -> the reflectors applied back.
+// steering() keeps ONE eigenvector (beamformer.py:24: eigh(...)[1][:, :, -1]); the Jacobi solve above diagonalises the whole matrix for it —
+// 5-7 sweeps of M (M - 1) / 2 rotations, each on A and on the M x M accumulator V: 7 345 vector instructions and 428 registers in the
+// 6-microphone notebook operator, 87 % of its step.  Here, for M = 6: four reflectors (rank-2 updates of shrinking trailing blocks), five or
+// six Laguerre steps on three-term recurrences of length M, two triangular solves of a tridiagonal, four reflector applications — about a
+// fifth of the arithmetic, no accumulator matrix.  Why each piece:
+//  * Phi_xx = Phi_yy - Phi_vv is Hermitian and INDEFINITE; the eigenvalue wanted is the algebraically largest.  A real-rooted polynomial
+//    with positive leading coefficient has p, p', p'' > 0 to the right of its largest root, and Laguerre's iteration started there decreases
+//    monotonically onto that root (cubically at a simple root, linearly at a multiple one) without ever passing it: no bracketing, no
+//    Sturm counts, and no way to land on another eigenvalue.
+//  * With the shift at (a hair above) the largest eigenvalue, shift I - T is positive semi-definite: its L D L^H factorisation needs no
+//    pivoting, the pivots are the ratios p_k / p_{k-1} of the recurrence; the one that vanishes is floored at rounding level (a perturbation of
+//    that size of T) and two solves turn any start vector into the eigenvector to eps ||T|| / gap — the conditioning any method has, LAPACK's
+//    included.  A tridiagonal that falls apart into blocks needs no special case: the block that owns the eigenvalue is amplified by 1 / eps.
+//  * The matrix is scaled to unit size first (covariances of quiet recordings are 1e-12), entries below 1e-17 of it are dropped — the
+//    threshold the Jacobi solve stops at.  A matrix that is diagonal to that threshold (Phi_xx = 0 exactly during McSpp's first ten
+//    frames, mcspp.py:273-275) takes the Jacobi solve's exit: the unit vector of the largest diagonal entry, the LAST one on ties, like
+//    eigh's ascending order.
+// Same result as herm_principal_d up to the conditioning of the eigenvector (tests/test_kernel_emul.py holds the two against each other and
+// against numpy on random, indefinite, clustered and block-diagonal matrices).  Only the upper triangle and the diagonal of A are read.
+// (the matrix comes through a getter `a(i, j)`, i <= j, called twice per entry — once for the scale, once for the scaled copy — so that a caller
+// whose matrix is a difference of fp32 state words never holds an unscaled double copy of it beside the working triangle)
+template <int M, class Get> DS_HD void herm_principal_direct_get_d(Get a, cd* v, int* laguerre_steps = nullptr) {
+    // ---- scale, and the diagonal exit -----------------------------------------------------------------------------------------------------
+    double dmax = 0.0, offmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) { const double t = fabs(a(i, i).x); dmax = t > dmax ? t : dmax; }
+#pragma unroll
+    for (int i = 0; i < M - 1; ++i)
+#pragma unroll
+        for (int j = i + 1; j < M; ++j) { const double m2 = cdabs2(a(i, j)); offmax = m2 > offmax ? m2 : offmax; }
+    if (!(offmax > 1e-34 * dmax * dmax && offmax > 1e-300)) {
+        int best = 0;
+        double wmax = a(0, 0).x;
+#pragma unroll
+        for (int i = 1; i < M; ++i) { const double t = a(i, i).x; if (t >= wmax) { wmax = t; best = i; } }
+#pragma unroll
+        for (int k = 0; k < M; ++k) v[k] = mkd(k == best ? 1.0 : 0.0, 0.0);
+        return;
+    }
+    const double big2 = dmax * dmax > offmax ? dmax * dmax : offmax;
+    const double sc = rsqrt_fast_d(big2);                                         // 1 / max |a_ij|
+    // lower triangle of the scaled matrix: L[i][j], i >= j  (a_ij = conj(a_ji))
+    cd Lw[M][M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) { const cd t = a(j, i); Lw[i][j] = i == j ? mkd(t.x * sc, 0.0) : mkd(t.x * sc, -(t.y * sc)); }
+    // ---- Householder: H_k = I - beta_k u_k u_k^H on rows k + 1 .., u_k kept in column k below the diagonal ----------------------------------
+    double d[M], e2[M], beta[M];              // diagonal, |subdiagonal|^2 (e2[k]: between k and k + 1), 2 / (u^H u)
+    cd e[M];                                  // subdiagonal T[k + 1][k]
+#pragma unroll
+    for (int k = 0; k < M - 2; ++k) {
+        constexpr double TINY2 = 1e-34;       // (1e-17)^2 of the unit-size matrix
+        double s2 = 0.0;
+#pragma unroll
+        for (int i = k + 2; i < M; ++i) s2 += cdabs2(Lw[i][k]);
+        const cd x0 = Lw[k + 1][k];
+        const double a02 = cdabs2(x0);
+        d[k] = Lw[k][k].x;
+        if (!(s2 > TINY2)) {                  // nothing below the subdiagonal: no reflector
+            beta[k] = 0.0; e[k] = x0; e2[k] = a02;
+            continue;
+        }
+        const double n2 = s2 + a02, rn = rsqrt_fast_d(n2), nx = n2 * rn;          // ||x||
+        const double ra0 = a02 > 1e-300 ? rsqrt_fast_d(a02) : 0.0, a0 = a02 * ra0;
+        const cd ph = a02 > 1e-300 ? cdscale(x0, ra0) : mkd(1.0, 0.0);            // e^{j arg x0}
+        e[k] = cdscale(ph, -nx); e2[k] = n2;                                     // H x = -e^{j arg x0} ||x|| e_0
+        Lw[k + 1][k] = cdscale(ph, a0 + nx);                                      // u_0 = x_0 + e^{j arg x0} ||x||
+        beta[k] = rcp_fast_d(nx * (nx + a0));                                     // 2 / (u^H u)
+        // trailing block B = A[k+1.., k+1..]: p = beta B u, K = beta (u^H p) / 2, q = p - K u, B -= u q^H + q u^H
+        cd pv[M];
+        double uhp = 0.0;
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) {
+            cd acc = mkd(0.0, 0.0);
+#pragma unroll
+            for (int j = k + 1; j < M; ++j) acc = j <= i ? cdfma(acc, Lw[i][j], Lw[j][k]) : cdfma(acc, cdconj(Lw[j][i]), Lw[j][k]);
+            pv[i] = cdscale(acc, beta[k]);
+            uhp = fmad_(Lw[i][k].x, pv[i].x, fmad_(Lw[i][k].y, pv[i].y, uhp));    // Re(conj(u_i) p_i); the sum is real for a Hermitian B
+        }
+        const double Kh = 0.5 * beta[k] * uhp;
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) pv[i] = mkd(fmad_(-Kh, Lw[i][k].x, pv[i].x), fmad_(-Kh, Lw[i][k].y, pv[i].y));   // q
+#pragma unroll
+        for (int i = k + 1; i < M; ++i)
+#pragma unroll
+            for (int j = k + 1; j <= i; ++j) {
+                cd t = cdfnmac(Lw[i][j], Lw[i][k], pv[j]);                        // - u_i conj(q_j)
+                t = cdfnmac(t, pv[i], Lw[j][k]);                                  // - q_i conj(u_j)
+                if (i == j) t.y = 0.0;
+                Lw[i][j] = t;
+            }
+    }
+    d[M - 2] = Lw[M - 2][M - 2].x;
+    d[M - 1] = Lw[M - 1][M - 1].x;
+    e[M - 2] = Lw[M - 1][M - 2]; e2[M - 2] = cdabs2(e[M - 2]);
+    // ---- largest eigenvalue of the tridiagonal: Laguerre from the Gershgorin bound ---------------------------------------------------------
+    double ae[M];
+#pragma unroll
+    for (int k = 0; k < M - 1; ++k) ae[k] = e2[k] > 1e-300 ? e2[k] * rsqrt_fast_d(e2[k]) : 0.0;
+    double gersh = d[0] + ae[0];
+#pragma unroll
+    for (int k = 1; k < M; ++k) { const double g = d[k] + ae[k - 1] + (k < M - 1 ? ae[k] : 0.0); gersh = g > gersh ? g : gersh; }
+    gersh += 4e-15;
+    double lam = gersh;
+    {   // ... or the Wolkowicz-Styan bound mean + sqrt(n - 1) * deviation of the eigenvalues (from the traces of T and T^2), whichever is lower: it
+        // is EXACT for a rank-one matrix, which is what Phi_xx is close to whenever the source is active.  The variance is a difference of two
+        // numbers of unit size: what its cancellation can have lost is added back, so that the bound stays a bound
+        double tr = 0.0, tr2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) { tr += d[k]; tr2 = fmad_(d[k], d[k], tr2); }
+#pragma unroll
+        for (int k = 0; k < M - 1; ++k) tr2 = fmad_(2.0, e2[k], tr2);
+        const double mean = tr * (1.0 / M), ms = tr2 * (1.0 / M);
+        double var = fmad_(-mean, mean, ms);
+        var = (var > 0.0 ? var : 0.0) + 8e-16 * ms;
+        const double ws = fmad_(sqrt((double)(M - 1) * var), 1.0 + 1e-14, mean) + 4e-15;
+        lam = ws < lam ? ws : lam;
+    }
+    // to the right of the largest root every leading minor p_k of lam I - T is positive (that IS lam I - T positive definite): checked at
+    // every iterate for free, the recurrence produces them.  A start that fails it (never seen; the bounds are bounds) restarts from Gershgorin's
+    for (int it = 0; it < 24; ++it) {
+        double p0 = 1.0, p1 = lam - d[0], q0 = 0.0, q1 = 1.0, r0 = 0.0, r1 = 0.0;    // p, p', p'' of orders k - 1 and k
+        bool pd = p1 > 0.0;
+#pragma unroll
+        for (int k = 1; k < M; ++k) {
+            const double x = lam - d[k], b = e2[k - 1];
+            const double p2 = fmad_(x, p1, -(b * p0));
+            const double q2 = fmad_(x, q1, fmad_(-b, q0, p1));
+            const double r2 = fmad_(x, r1, fmad_(-b, r0, 2.0 * q1));
+            p0 = p1; p1 = p2; q0 = q1; q1 = q2; r0 = r1; r1 = r2;
+            pd = pd && p1 > 0.0;
+        }
+        if (!pd) {
+            if (it == 0 && lam < gersh) { lam = gersh; continue; }
+            break;                                                                 // on the root to rounding
+        }
+        const double ip = rcp_fast_d(p1), G = q1 * ip, Hh = fmad_(G, G, -(r1 * ip));
+        double disc = (double)(M - 1) * fmad_((double)M, Hh, -(G * G));
+        disc = disc > 0.0 ? disc : 0.0;
+        const double sq = disc > 1e-300 ? disc * rsqrt_fast_d(disc) : 0.0;
+        const double step = (double)M * rcp_fast_d(G + sq);
+        lam -= step;
+        if (laguerre_steps) *laguerre_steps = it + 1;
+        if (!(step > 3e-16)) break;                                                 // (of a unit-size matrix)
+    }
+    // ---- inverse iteration: (lam I - T) = L D L^H, pivots floored at rounding level ---------------------------------------------------------
+    double idl[M];                            // 1 / pivot
+    cd l[M];                                  // L[k][k - 1]
+    {
+        // (the computed root may sit a few 1e-14 BELOW the eigenvalue — the recurrence's rounding over p' — and the last pivot is then a small
+        // negative number that carries the eigenvector: only a pivot of rounding size is replaced, its sign is kept otherwise)
+        auto inv_pivot = [](double piv) { return fabs(piv) > 3e-16 ? rcp_fast_d(fabs(piv)) * (piv < 0.0 ? -1.0 : 1.0) : 1.0 / 3e-16; };
+        idl[0] = inv_pivot(lam - d[0]);
+#pragma unroll
+        for (int k = 1; k < M; ++k) {
+            l[k] = cdscale(e[k - 1], -idl[k - 1]);
+            idl[k] = inv_pivot(fmad_(-e2[k - 1], idl[k - 1], lam - d[k]));
+        }
+    }
+    cd x[M];
+#pragma unroll
+    for (int k = 0; k < M; ++k) x[k] = mkd(1.0, 0.0);                             // first pass: L y = b chosen so that y = ones
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {
+        if (pass > 0) {
+#pragma unroll
+            for (int k = 1; k < M; ++k) x[k] = cdfnma(x[k], l[k], x[k - 1]);      // forward: y_k = b_k - l_k y_{k-1}
+        }
+#pragma unroll
+        for (int k = 0; k < M; ++k) x[k] = cdscale(x[k], idl[k]);
+#pragma unroll
+        for (int k = M - 2; k >= 0; --k) x[k] = cdfnma(x[k], cdconj(l[k + 1]), x[k + 1]);   // backward: x_k = z_k - conj(l_{k+1}) x_{k+1}
+        double m2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) m2 += cdabs2(x[k]);
+        const double rs = m2 > 1e-300 ? rsqrt_fast_d(m2) : 1.0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) x[k] = cdscale(x[k], rs);
+    }
+    // ---- back through the reflectors: v = H_0 H_1 ... H_{M-3} x --------------------------------------------------------------------------
+#pragma unroll
+    for (int k = M - 3; k >= 0; --k) {
+        cd uhx = mkd(0.0, 0.0);
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) uhx = cdfmac(uhx, x[i], Lw[i][k]);         // u^H x
+        uhx = cdscale(uhx, beta[k]);
+#pragma unroll
+        for (int i = k + 1; i < M; ++i) x[i] = cdfnma(x[i], Lw[i][k], uhx);
+    }
+    double m2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) m2 += cdabs2(x[k]);
+    const double rs = m2 > 1e-300 ? 1.0 / sqrt(m2) : 1.0;
+    // unit norm, exp(-j angle(v0)); a first component at rounding level (an eigenvector that lives in a trailing block) is the Jacobi solve's exact
+    // zero, whose angle is 0 (beamformer.py:27-28)
+    const double n0 = sqrt(cdabs2(x[0]));
+    const bool v0_zero = !(n0 * rs > 1e-14);
+    if (v0_zero) x[0] = mkd(0.0, 0.0);
+    const cd ph = v0_zero ? mkd(rs, 0.0) : cdscale(cdconj(x[0]), rs / n0);
+#pragma unroll
+    for (int k = 0; k < M; ++k) v[k] = cdmul(x[k], ph);
+}
+
+template <int M> DS_HD void herm_principal_direct_d(const cd (&A)[M][M], cd* v, int* laguerre_steps = nullptr) {
+    herm_principal_direct_get_d<M>([&](int i, int j) { return A[i][j]; }, v, laguerre_steps);
 }
 
 // w = R^-1 a / (a^H R^-1 a)   (beamformer/beamformer.py:133-155)

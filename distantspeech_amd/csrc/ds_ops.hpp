@@ -944,6 +944,9 @@ DS_HD float mcspp_qavg(const float* gamma_frame, int fmin, int fmax) {
     return qsum / (float)(fmax - fmin);
 }
 
+#if !defined(DS_LAGUERRE_STATS)
+#define DS_LAGUERRE_STATS          /* the CPU emulator passes a counter here (tests/emul/ds_emul.cpp) */
+#endif
 template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
     constexpr int o0 = MCSPP_ROW0;                                                 // state row offset of the McSpp part
@@ -995,7 +998,10 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
         };
         auto pyy = [&](int i, int j) { return to_cd(herm_get<M>(yd, yo, i, j)); };
         auto pxx = [&](int i, int j) { return cdsub(to_cd(herm_get<M>(yd, yo, i, j)), to_cd(herm_get<M>(vd, vo, i, j))); };   // Phi_xx = Phi_yy - Phi_vv (:212; exact in double)
-        cd inv[M][M], Zd[M], sv[M];
+        // (round 6) inv(Phi_vv + dv I) is kept as the inverse of its Cholesky factor (CholInvD: A^-1 = Li^H Li) — the trace, A^-1 y, the PMWF column
+        // and the MVDR weights are products with it; the explicit inverse (2 M^2 doubles) was the operator's register peak
+        CholInvD<M> ci;
+        cd Zd[M], sv[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) Zd[m] = to_cd(Z[m]);
         double xid = 0.0;
@@ -1006,61 +1012,29 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
             herm_rank1<M>(vd, vo, Z, at1, 1.0f - at1);
         }
         if (p.out2 && pass == passes - 1) {                                        // mvdr.ipynb cell 4: steer_vector = steering(noise_estimator.Phi_xx)
-            cd Pxx[M][M];
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int j = 0; j < M; ++j) Pxx[i][j] = pxx(i, j);
-            herm_principal_d<M>(Pxx, sv);
+            herm_principal_direct_get_d<M>(pxx, sv DS_LAGUERRE_STATS);              // the ONE eigenvector steering() keeps, by the direct solve
             DS_SCHED_FENCE();
             phase_fence();
         }
-        {
-        cd A[M][M];
-        herm_unpack_d<M>(vd, vo, A);
         const double dvd = (double)dv;
-#pragma unroll
-        for (int i = 0; i < M; ++i) A[i][i].x += dvd;
-        herm_inverse_d<M>(A, inv);
-        }
+        ci.factor_invert([&](int i, int j) { cd t = to_cd(herm_get<M>(vd, vo, i, j)); if (i == j) t.x += dvd; return t; });   // :214
         phase_fence();
-        double tr = 0.0;
-#pragma unroll
-        for (int i = 0; i < M; ++i)
-#pragma unroll
-            for (int j = 0; j < M; ++j) { const cd y_ = pyy(i, j); tr = fmad_(inv[i][j].x, y_.x, fmad_(inv[i][j].y, y_.y, tr)); }   // Re(inv_ij Pyy_ji)
+        double tr = ci.trace_with(pyy);                                            // Re tr(Phi_vv_inv Phi_yy) :217
         phase_fence();
         if (tr - (double)M < 0.0) {                                                // :219-228
-            const double dvd = (double)dv;
-            cd A[M][M];
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int j = 0; j < M; ++j) A[i][j] = pyy(i, j);
-            if (frm < 5) {
-#pragma unroll
-                for (int i = 0; i < M; ++i) A[i][i].x += dvd;
-            }
-            herm_inverse_d<M>(A, inv);
+            const double dl = frm < 5 ? dvd : 0.0;
+            ci.factor_invert([&](int i, int j) { cd t = pyy(i, j); if (i == j) t.x += dl; return t; });
             phase_fence();
-            tr = 0.0;
-#pragma unroll
-            for (int i = 0; i < M; ++i)
-#pragma unroll
-                for (int j = 0; j < M; ++j) { const cd y_ = pyy(i, j); tr = fmad_(inv[i][j].x, y_.x, fmad_(inv[i][j].y, y_.y, tr)); }
+            tr = ci.trace_with(pyy);
         }
         phase_fence();
         xid = dmin_(dmax_(tr - (double)M, 1e-6), 1e8);                  // :230
-        cd v[M];
+        cd u[M], v[M];
+        ci.lower(Zd, u);                                                           // v = Phi_vv_inv y; y^H v = |Li y|^2
         double yv = 0.0;
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-            cd acc = mkd(0.0, 0.0);
-#pragma unroll
-            for (int j = 0; j < M; ++j) acc = cdfma(acc, inv[i][j], Zd[j]);
-            v[i] = acc;
-            yv = fmad_(Zd[i].x, acc.x, fmad_(Zd[i].y, acc.y, yv));                  // Re(conj(y_i) v_i)
-        }
+        for (int i = 0; i < M; ++i) yv += cdabs2(u[i]);
+        ci.upper(u, v);
         double vPv = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
@@ -1080,13 +1054,12 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
         p.out0[ob] = pp;
         const double wsc = 1.0 / (10.0 + xid);                                     // compute_pmwf_weight beta = 10 :283
         if (p.out1) {
+            cd x0[M], u[M], w[M];
 #pragma unroll
-            for (int i = 0; i < M; ++i) {
-                cd acc = mkd(0.0, 0.0);
+            for (int j = 0; j < M; ++j) x0[j] = pxx(j, 0);
+            ci.lower(x0, u); ci.upper(u, w);                                       // Phi_vv_inv Phi_xx[:, 0]
 #pragma unroll
-                for (int j = 0; j < M; ++j) acc = cdfma(acc, inv[i][j], pxx(j, 0));
-                p.out1[2 * (ob * M + i)] = (float)(acc.x * wsc); p.out1[2 * (ob * M + i) + 1] = (float)(acc.y * wsc);
-            }
+            for (int i = 0; i < M; ++i) { p.out1[2 * (ob * M + i)] = (float)(w[i].x * wsc); p.out1[2 * (ob * M + i) + 1] = (float)(w[i].y * wsc); }
         }
         if (p.out3) {
 #pragma unroll
@@ -1094,18 +1067,23 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
 #pragma unroll
                 for (int j = 0; j < M; ++j) {
                     const long long q2 = 2 * ((ob * M + i) * M + j);
-                    const cd x_ = pxx(i, j);
+                    const cd x_ = pxx(i, j), iv_ = ci.inverse_entry(i, j);
                     p.out3[q2] = (float)x_.x; p.out3[q2 + 1] = (float)x_.y;
-                    p.out4[q2] = (float)inv[i][j].x; p.out4[q2 + 1] = (float)inv[i][j].y;
+                    p.out4[q2] = (float)iv_.x; p.out4[q2 + 1] = (float)iv_.y;
                 }
         }
         if (p.out2) {                                                              // w = compute_mvdr_weight(steer_vector, Phi_vv_inv); Yout = w^H y
-            cd w[M];
-            mvdr_weight_d<M>(inv, sv, w);
+            cd u[M], w[M];                                                          // w = A^-1 a / (a^H A^-1 a), a^H A^-1 a = |Li a|^2 (beamformer.py:133-155)
+            ci.lower(sv, u);
+            double den = 0.0;
+#pragma unroll
+            for (int m = 0; m < M; ++m) den += cdabs2(u[m]);
+            ci.upper(u, w);
             cd Y = mkd(0.0, 0.0);
 #pragma unroll
             for (int m = 0; m < M; ++m) Y = cdfmac(Y, Zd[m], w[m]);
-            p.out2[2 * ob] = (float)Y.x; p.out2[2 * ob + 1] = (float)Y.y;
+            const double rden = 1.0 / den;
+            p.out2[2 * ob] = (float)(Y.x * rden); p.out2[2 * ob + 1] = (float)(Y.y * rden);
         }
         if (!p.repeat) {                                                           // update_noise_psd (alpha_d = 0.92) on the fp32 state: behind
             const float at = fma_((float)(1.0 - 0.92), pp, 0.92f);                 // every reader of this frame's Phi_vv
@@ -1514,11 +1492,13 @@ inline bool op_supported(int op, int M) {
 #else
 #define DS_OP_SHELVED_LIST(X)
 #endif
+#if !defined(DS_FOR_EACH_OP)   /* (a scratch build may name the few operators it wants: scripts/asm_ops.sh) */
 #define DS_FOR_EACH_OP(X) \
     X(OP_MCRA, 1) X(OP_OMLSA, 1) X(OP_SUBLMS, 1) X(OP_SUBRLS, 1) X(OP_MCCDR, 1) \
     DS_OP_M_LIST(X, OP_MCMCRA) DS_OP_M_LIST(X, OP_MCSPPBASE) DS_OP_M_LIST(X, OP_ADAPTIVE) \
     DS_OP_M3_LIST(X, OP_MCSPP) DS_OP_M3_LIST(X, OP_MCSPP_LEAN) DS_OP_M3_LIST(X, OP_MCSPP_STEADY) DS_OP_SHELVED_LIST(X) DS_OP_ML_LIST(X, OP_STEERING) DS_OP_ML_LIST(X, OP_MVDRW) \
     DS_OP_ML_LIST(X, OP_PMWFW) DS_OP_ML_LIST(X, OP_GEV) DS_OP_ML_LIST(X, OP_BAN) DS_OP_ML_LIST(X, OP_PHASECORR)
+#endif
 
 // runtime dispatch for the serial CPU run in tests/emul (the GPU launches one specialised kernel per (OP, M))
 inline void run_op(int op, const OpCtx& p, int b, int k) {
@@ -1548,7 +1528,7 @@ struct TdParams {
                                // reads AND writes, profiles/r03e/cfg5_stage_budget.md)
     float* cache_out;          // FIR: [B][M][L-1] (the other half of a ping-pong pair)
     const int* dev_parity;     // FIR: optional device-resident call parity (dev_cnt[3] of the handle): odd = the two halves swap roles
-    float radius;
+    double radius;             // notch: pole radius as the decimal the caller wrote (decimal_double: 0.98f -> 0.98, the reference's Python float)
 };
 
 // FilterDcNotch16.filter_dc_notch16 (adaptivefilter/feature.py:32-49) in DOUBLE, memory included (round 5).  The recursion has its poles at
@@ -1559,7 +1539,7 @@ struct TdParams {
 // Four double operations per sample on the one lane per row that runs the recursion anyway (the kernel is bound by that lane's dependent
 // chain, not by the vector rate); samples in and out stay fp32.  (Tried beside it and dropped: xi and gamma of the chain's McSpp in their
 // cancellation-free forms tr(A^-1 (Phi_yy - A)) and v^H (Phi_yy - A) v — no measurable change in p, 32 registers more.)
-DS_HD double notch_den2(float radius) { const double r = (double)radius; return r * r + 0.7 * (1.0 - r) * (1.0 - r); }
+DS_HD double notch_den2(double r) { return r * r + 0.7 * (1.0 - r) * (1.0 - r); }
 DS_HD float notch_step(double& m0, double& m1, double r, double den2, float vin_) {
     const double vin = (double)vin_;
     const double vout = m0 + vin;
@@ -1568,7 +1548,7 @@ DS_HD float notch_step(double& m0, double& m1, double r, double den2, float vin_
     return (float)(r * vout);
 }
 DS_HD void td_dcnotch(const TdParams& p, int b, int m) {
-    const double r = (double)p.radius, den2 = notch_den2(p.radius);
+    const double r = p.radius, den2 = notch_den2(p.radius);
     double m0 = p.mem[((long long)b * p.M + m) * 2], m1 = p.mem[((long long)b * p.M + m) * 2 + 1];
     const float* x = p.x_bstride ? p.x + (long long)b * p.x_bstride + (long long)m * p.x_cstride : p.x + ((long long)b * p.M + m) * p.n;
     float* y = p.y + ((long long)b * p.M + m) * p.n;

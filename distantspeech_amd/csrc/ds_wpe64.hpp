@@ -33,11 +33,7 @@ struct Wpe64Params {
                             // — forty frames of P / lambda later that is 1e-6 of P against the reference's 0.998.  wpe64_lambda() below
 };
 // the shortest decimal that rounds to the float (<= 7 significant digits), as a double: 0.998f -> 0.998
-inline double wpe64_lambda(float lam) {
-    char buf[32];
-    snprintf(buf, sizeof buf, "%.7g", (double)lam);
-    return strtod(buf, nullptr);
-}
+inline double wpe64_lambda(float lam) { return decimal_double(lam); }
 
 template <int CNP> struct Wpe64Shared {
     static constexpr int RS = CNP + 1;              // row stride of P in complex doubles: odd, so that rows start in different banks

@@ -264,10 +264,14 @@ class BatchEngine:
     def mcspp_mvdr_process(self, x, layout, want_p=True):
         """DS_ALGO_MCSPP_MVDR: x [B, n, M] (layout 0) or [B, M, n] (layout 1) -> (y [B, n], p [B, T, K] or None)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 3:
+            raise ValueError("x must be [B=%d, n, M=%d] or [B, M, n]" % (self.batch, self.M))
         n = x.shape[1] if layout == L.LAYOUT_SAMPLES_CHANNELS else x.shape[2]
         m = x.shape[2] if layout == L.LAYOUT_SAMPLES_CHANNELS else x.shape[1]
-        if x.ndim != 3 or x.shape[0] != self.batch or m != self.M:
+        if x.shape[0] != self.batch or m != self.M:
             raise ValueError("x must be [B=%d, n, M=%d] or [B, M, n]" % (self.batch, self.M))
+        if n % self.hop != 0:
+            raise ValueError("n_samples (%d) must be a multiple of hop (%d)" % (n, self.hop))
         y = np.empty((self.batch, n), dtype=np.float32)
         p = np.empty((self.batch, n // self.hop, self.K), dtype=np.float32) if want_p else None
         L.check(self._lib.ds_mcspp_mvdr_process(self._h, self._p(x), int(layout), int(n), self._p(y), self._p(p) if want_p else None, L.MEM_HOST), self._h)

