@@ -29,6 +29,7 @@ PARAM_POSTFILTER = 15
 PARAM_TAIL_ASYNC = 17
 PARAM_REF_POWERS = 18
 PARAM_WPE_FP64 = 19
+PARAM_EST_POS = 20
 PARAM_FDAF_TWO_PATH = 16
 CHAIN_AUX_FIR, CHAIN_AUX_COHERENCE = 0, 1
 PARAM_WPE_DELAY = 13

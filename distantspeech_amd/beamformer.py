@@ -164,6 +164,17 @@ class _AdaptiveBase(beamformer):
             self._steer_angle = angle.copy()
             self.angle = angle
 
+    def beampattern(self, omega, H):
+        """beamformer.beampattern (beamformer.py:536-553): 10 log10 |H[:, k]^H a(az, k)| over azimuth 0 .. 359 degrees of a circular array of radius
+        0.032 (hard-wired there) at elevation 0: [360, half_bin] (or [B, 360, half_bin] for a batched H [B, M, half_bin])."""
+        H = np.asarray(H)
+        r = 0.032
+        az = np.arange(0, 360, 1) * np.pi / 180
+        tao = -1 * r * np.cos(0) * np.cos(az[:, None] - np.asarray(self.gamma)[None, :]) / self.c            # [360, M]
+        a = np.exp(-1j * np.asarray(omega)[None, :, None] * tao[:, None, :])                             # [360, K, M]
+        with np.errstate(divide="ignore"):
+            return 10 * np.log10(np.abs(np.einsum("...mk,zkm->...zk", H.conj(), a)))
+
     def _run(self, x, angle, method, retH, retWNG, retDI):
         if retWNG or retDI:
             # the reference calls undefined calcWNG / calcDI here (adaptivebeamformer.py:115-117, GSC.py:276-279)
@@ -177,8 +188,18 @@ class _AdaptiveBase(beamformer):
         if method != self.AlgorithmIndex:
             self.AlgorithmIndex = method
             self._eng.set_method(method)
+        self._before_process()
         y = self._eng.process(x, L.LAYOUT_CHANNELS_SAMPLES)
-        return {'data': self._squeeze(y).astype(np.float64), 'WNG': None, 'DI': None, 'beampattern': None}
+        # adaptivebeamformer.py:124-126, GSC.py:290-292: beampattern of the weights the object holds after the call's last frame
+        bp = self.beampattern(self.omega, self._weights_after_call(method)) if retH else None
+        return {'data': self._squeeze(y).astype(np.float64), 'WNG': None, 'DI': None, 'beampattern': bp}
+
+    def _before_process(self):
+        pass
+
+    def _weights_after_call(self, method):
+        """`self.H` [M, half_bin] as the reference object holds it when process() returns."""
+        raise NotImplementedError
 
 
 class _SppView(object):
@@ -214,7 +235,8 @@ class adaptivebeamfomer(_AdaptiveBase):
         self.gamma = mic.gamma
         self.angle = np.array([0, 0]) / 180 * np.pi
         self.method = 'MVDR'
-        self.estPos = None
+        self.estPos = None             # None: the MCRA-based gate; n: Rvv follows the first n (frame, bin) slots only (adaptivebeamformer.py:30,90-93)
+        self._est_pos_native = None
         self.AlgorithmList = ['src', 'DS', 'MVDR', 'TFGSC']
         self.AlgorithmIndex = 0
         self._mcra_L = 15
@@ -226,6 +248,34 @@ class adaptivebeamfomer(_AdaptiveBase):
     def process(self, x, angle, method=2, retH=False, retWNG=False, retDI=False):
         """x [M, samples] (or [B, M, samples]); angle = (azimuth, elevation) in radians."""
         return self._run(x, angle, method, retH, retWNG, retDI)
+
+    def _before_process(self):
+        # `estPos` is an attribute users set after construction (adaptivebeamformer.py:30): handed to the library when it changed
+        if self.estPos != self._est_pos_native:
+            if self.estPos is not None and int(self.estPos) < self.half_bin:
+                # frameCount advances once per BIN (:90-93): with estPos < half_bin the bins from estPos on never see an update, their
+                # Rvv_inv stays the zero matrix of the constructor and getweights() divides 0 by 0 — the reference's output is NaN from the
+                # first sample on.  Refused instead of reproduced
+                raise ValueError("estPos = %r is less than half_bin = %d: the reference's output is NaN (bins that never update keep "
+                                 "Rvv_inv = 0, adaptivebeamformer.py:32-33,90-112); use a multiple of half_bin for whole frames" % (self.estPos, self.half_bin))
+            self._eng.set_param_i(L.PARAM_EST_POS, -1 if self.estPos is None else int(self.estPos))
+            self._est_pos_native = self.estPos
+
+    def _weights_after_call(self, method):
+        a = self._a                                                                  # [K, M]
+        if method == 0:                                                              # beamformer.py:320-322: a with every channel but the first zeroed
+            H = np.zeros((self.M, self.half_bin), dtype=complex); H[0] = a[:, 0]
+            return H if self.batch == 1 else np.broadcast_to(H, (self.batch,) + H.shape)
+        if method == 1:                                                              # :323-324
+            H = a.T / self.M
+            return H if self.batch == 1 else np.broadcast_to(H, (self.batch,) + H.shape)
+        if method == 2:                                                              # :325-326, the kernel's own solve on the resident Rvv
+            return self.H_kernel
+        R = self._eng.get_field(L.FIELD_RVV).astype(np.complex128)                   # :327-333 TFGSC
+        temp = np.linalg.inv(R + 1e-6 * np.eye(self.M)) @ self._eng.get_field(L.FIELD_RYY).astype(np.complex128)
+        tr = np.trace(temp, axis1=-2, axis2=-1)
+        col0 = temp[..., :, 0].copy(); col0[..., 0] -= 1
+        return self._squeeze(np.swapaxes(col0 / (tr - self.M)[..., None], 1, 2))
 
     # state the reference exposes as attributes ---------------------------------------------------
     @property
@@ -294,6 +344,10 @@ class GSC(_AdaptiveBase):
             pw = self._eng.get_field(L.FIELD_REF_POWERS)                    # [B, T, K, M]: |Y|^2, |U_1|^2 .. |U_{M-1}|^2
             self.omlsa_multi.estimation_frames(pw[..., 0], pw[..., 1:])
         return out
+
+    def _weights_after_call(self, method):
+        H = np.ones((self.M, self.half_bin), dtype=complex) / self.M                 # GSC.py:50: set in the constructor and never written again
+        return H if self.batch == 1 else np.broadcast_to(H, (self.batch,) + H.shape)
 
     @property
     def G(self):

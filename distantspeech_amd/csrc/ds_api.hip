@@ -435,6 +435,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
     h->diag = cfg->diag > 0 ? cfg->diag : 1e-6f;
     h->gate = cfg->gate > 0 ? cfg->gate : 0.4f;
     h->mu = cfg->mu > 0 ? cfg->mu : 0.01f;
+    h->est_pos = -1; h->est_used = 0;
     h->ref_powers = false; h->ref_pow = nullptr; h->ref_pow_cap = 0; h->ref_pow_T = 0; h->ref_pow_stream = nullptr;
     if (cfg->device >= 0) h->device = cfg->device;
     else if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
@@ -517,6 +518,8 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             h->sub[i]->use_dev_cnt = true;                      // uniform counters on the device: a sequence of calls replays as a hipGraph
             h->sub[i]->owner = h;
         }
+        const char* unf = std::getenv("DS_CHAIN_UNFUSED");
+        if (!(unf && unf[0] == '1')) h->ki_cdr = ds::lookup_stft_cdr(cfg->nfft, cfg->n_mics);
     }
     if (cfg->algo == DS_ALGO_TDGSC || cfg->algo == DS_ALGO_FDGSC) {
         rc = gsc_chain_create(h);
@@ -650,7 +653,7 @@ int ds_reset(ds_handle* h) {
     if (h->cfg.algo == DS_ALGO_FDGSC)
         for (int i = 16; i <= 18; ++i)                                  // delay_aligned, delay_fbf, last bm_output block (ds_api_gsc_chains.hip)
             if (h->chain_buf[i]) DS_HIP(h, hipMemsetAsync(h->chain_buf[i], 0, h->chain_bytes[i], h->stream));
-    h->hist_cur = 0;
+    h->hist_cur = 0; h->est_used = 0;
     return zero_state(h);
 }
 
@@ -671,6 +674,7 @@ int ds_set_steering(ds_handle* h, const float* steer, int per_utterance) {
     DS_HIP(h, hipMemcpyAsync(h->steer, steer, need, hipMemcpyHostToDevice, h->stream));
     DS_HIP(h, hipStreamSynchronize(h->stream));
     h->steer_set = true;
+    h->est_used = 0;                      // adaptivebeamformer.py:70-79: a new look direction restarts frameCount
     if (h->sub[3]) { rc = ds_set_steering(h->sub[3], steer, per_utterance); if (rc) return fail(h, rc, h->sub[3]->err); }
     return DS_OK;
 }
@@ -711,7 +715,14 @@ int ds_set_param_i(ds_handle* h, int id, int value) {
                 return fail(h, DS_ESTATE, "method TFGSC needs ds_config.track_ryy = 1");
             if (value == DS_METHOD_TFGSC && h->cfg.algo == DS_ALGO_ADAPTIVE_PF)
                 return fail(h, DS_EUNSUPPORTED, "method TFGSC: not on a DS_ALGO_ADAPTIVE_PF handle (it keeps no Ryy)");
+            if (value != h->method) h->est_used = 0;       // adaptivebeamformer.py:74-79: a new method restarts frameCount
             h->method = value;
+            return DS_OK;
+        case DS_PARAM_EST_POS:
+            if (h->cfg.algo != DS_ALGO_ADAPTIVE && h->cfg.algo != DS_ALGO_ADAPTIVE_PF) return fail(h, DS_EINVAL, "est pos: DS_ALGO_ADAPTIVE / DS_ALGO_ADAPTIVE_PF handles only");
+            if (value < -1) return fail(h, DS_EINVAL, "est pos must be -1 (None) or >= 0");
+            { const int jr = join_groups(h); if (jr) return jr; }
+            h->est_pos = value; h->graph_valid = false;
             return DS_OK;
         case DS_PARAM_MCRA_L:
             if (value <= 0) return fail(h, DS_EINVAL, "mcra_L must be > 0");
@@ -885,6 +896,33 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
     // ... or the build of the kernel for long calls, where there is one (same results bit for bit)
     const ds::launch_fn launch = (h->ki.launch_pipe && p.T >= h->pipe_min_T && !h->ref_powers) ? h->ki.launch_pipe
                                  : (h->ki.launch_long && p.T >= DS_LONG_MIN_T) ? h->ki.launch_long : h->ki.launch;
+    if (h->est_pos >= 0 && (h->cfg.algo == DS_ALGO_ADAPTIVE || h->cfg.algo == DS_ALGO_ADAPTIVE_PF)) {
+        // adaptivebeamfomer.estPos (adaptivebeamformer.py:90-93): the call as up to three launches — the frames whose every bin still updates Rvv
+        // (gate always open), the ONE frame in which the slot count runs out (its leading bins only), the frames behind it (gate shut)
+        if (first != 0 || count != h->cfg.batch || h->group_enqueue) return fail(h, DS_EUNSUPPORTED, "ds_process_device: DS_PARAM_EST_POS is on — the whole batch per call, no utterance groups");
+        if (h->ref_powers) return fail(h, DS_EUNSUPPORTED, "ds_process_device: DS_PARAM_EST_POS and DS_PARAM_REF_POWERS exclude each other");
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return fail(h, DS_ESTATE, "ds_process_device: DS_PARAM_EST_POS is on — no hipGraph capture");
+        const long long K = h->K, left = h->est_pos - h->est_used;
+        const int T = p.T, hop = h->cfg.hop;
+        const int n_full = (int)(left / K < T ? left / K : T);
+        const int n_part = (n_full < T && left - (long long)n_full * K > 0) ? 1 : 0;
+        const long long xs = layout == DS_LAYOUT_CHANNELS_SAMPLES ? hop : (long long)hop * h->cfg.n_mics;
+        int t0 = 0;
+        auto seg = [&](int frames, float gate, unsigned kinv) -> hipError_t {
+            if (frames <= 0) return hipSuccess;
+            Params q = p;
+            q.x = x_dev + (long long)t0 * xs; q.y = y_dev + (long long)t0 * hop; q.T = frames; q.gate = gate; q.gate_kinv = kinv;
+            t0 += frames;
+            return ((h->ki.launch_long && frames >= DS_LONG_MIN_T) ? h->ki.launch_long : h->ki.launch)(q, count, s);
+        };
+        DS_HIP(h, seg(n_full, 2.0f, 0u));                                        // mcra.p <= 0.999 < 2: every bin updates
+        DS_HIP(h, seg(n_part, 2.0f, ~(unsigned)(left - (long long)n_full * K))); // bins [0, r)
+        DS_HIP(h, seg(T - n_full - n_part, -1.0f, 0u));                          // mcra.p >= 0.001 > -1: no bin updates
+        h->est_used += (long long)n_full * K + (n_part ? left - (long long)n_full * K : 0);
+        return DS_OK;
+    }
     DS_HIP(h, launch(p, count, s));
     return DS_OK;
 }
@@ -899,6 +937,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     if (n_calls == 0) return DS_OK;
     if (h->ref_powers && (n_calls > 1 || graph != 0))
         return fail(h, DS_ESTATE, "ds_process_device_seq: DS_PARAM_REF_POWERS keeps the powers of ONE plain call (n_calls 1, graph 0)");
+    if (h->est_pos >= 0) graph = 0;                           // DS_PARAM_EST_POS: the slot count lives on the host, every call is laid out for it
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const bool chain = wpe_chain(h) || h->cfg.algo == DS_ALGO_SUBBAND_GSC || h->cfg.algo == DS_ALGO_MCSPP_MVDR;
     if (h->cfg.algo == DS_ALGO_TDGSC || h->cfg.algo == DS_ALGO_FDGSC) graph = 0;      // their stages keep the frame counters on the host
@@ -919,7 +958,7 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     // or its last round of workgroups the other group's kernel fills the CUs: +12..15 % at 2048-4096 utterances per call, +3 % at 16 384,
     // nothing at 1024 (one round of workgroups).  A caller-provided stream keeps everything on that stream.
     const bool frames = dsi::frames_algo(h->cfg.algo);
-    const int ng = (frames && !stream && !h->ref_powers) ? (h->split < count ? h->split : (count > 0 ? count : 1)) : 1;
+    const int ng = (frames && !stream && !h->ref_powers && h->est_pos < 0) ? (h->split < count ? h->split : (count > 0 ? count : 1)) : 1;
     if (ng > 1) {
         DS_HIP(h, hipSetDevice(h->device));                 // not set_device(): the groups stay on their streams between calls
         if (!h->ev_fork) DS_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -1380,7 +1419,7 @@ int ds_export_state(ds_handle* h, void* dst, size_t bytes) {
     DS_HIP(h, hipMemcpy(d, h->counters, counters_bytes(h), hipMemcpyDeviceToHost)); d += counters_bytes(h);
     if (opst_bytes(h)) DS_HIP(h, hipMemcpy(d, h->opst, opst_bytes(h), hipMemcpyDeviceToHost));
     d += opst_bytes(h);
-    const int uc[4] = {h->op_frm, h->op_ell, h->op_first, h->hist_cur};
+    const int uc[4] = {dsi::frames_algo(h->cfg.algo) ? (int)h->est_used : h->op_frm, h->op_ell, h->op_first, h->hist_cur};   // (a frame-kernel handle has no operator counters: the slot carries the estPos count)
     std::memcpy(d, uc, sizeof uc);
     d += sizeof uc;
     {
@@ -1456,7 +1495,8 @@ int ds_import_state(ds_handle* h, const void* src, size_t bytes) {
         ExtraState ex[3];
         for (int i = 0, k = extra_state(h, ex); i < k; ++i) { DS_HIP(h, hipMemcpy(ex[i].ptr, s, ex[i].bytes, hipMemcpyHostToDevice)); s += ex[i].bytes; }
     }
-    h->op_frm = uc[0]; h->op_ell = uc[1]; h->op_first = uc[2]; h->hist_cur = uc[3];
+    if (dsi::frames_algo(h->cfg.algo)) h->est_used = uc[0]; else h->op_frm = uc[0];
+    h->op_ell = uc[1]; h->op_first = uc[2]; h->hist_cur = uc[3];
     h->wpe_started = true;                                  // an imported stream is a started one
     rc = sync_dev_cnt(h); if (rc) return rc;
     h->graph_valid = false;

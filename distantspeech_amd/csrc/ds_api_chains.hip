@@ -160,7 +160,10 @@ int nbmvdr_process_device(ds_handle* h, const float* x_dev, int layout, long lon
     const size_t B = h->cfg.batch, M = h->cfg.n_mics, K = h->K;
     const int T = n_samples / h->cfg.hop;
     if (h->sub[1]->aux_floats < K) return fail(h, DS_ESTATE, "McSpp-MVDR chain: call ds_chain_set_aux(DS_CHAIN_AUX_COHERENCE) first");
-    const size_t need[8] = {B * T * K * M * 8, 0, 0, p_dev ? 0 : B * T * K * 4, 0, B * T * K * 8, 0, 0};
+    // analysis with McCDR as its per-bin program (one launch less per call: the prior's kernel was 12 of a 120 us step at 6 microphones) where that
+    // kernel exists; DS_CHAIN_UNFUSED=1 at ds_create keeps the separate launch (A/B runs and the reference point of the equality test)
+    const bool cdr_fused = h->ki_cdr.launch != nullptr;
+    const size_t need[8] = {B * T * K * M * 8, cdr_fused ? (B * T * K + B * T) * 4 : 0, 0, p_dev ? 0 : B * T * K * 4, 0, B * T * K * 8, 0, 0};
     for (int i = 0; i < 8; ++i) {
         if (need[i] == 0 || need[i] <= h->chain_bytes[i]) continue;
         DS_HIP(h, hipStreamSynchronize(h->stream));
@@ -180,11 +183,18 @@ int nbmvdr_process_device(ds_handle* h, const float* x_dev, int layout, long lon
         if (layout == DS_LAYOUT_CHANNELS_SAMPLES) { p.x_sample_stride = 1; p.x_chan_stride = x_chan_stride > 0 ? x_chan_stride : n_samples; }
         else { p.x_sample_stride = (int)M; p.x_chan_stride = 1; }
         p.T = T; p.batch0 = 0;
+        if (cdr_fused) {                                                 // McCDR.estimation (mccdr.py:122-177) on the frame the workgroup has just analysed
+            ds_handle* sp = h->sub[1];
+            p.cdr_st = sp->opst; p.cdr_NF = sp->NF; p.cdr_frm = sp->op_frm; p.cdr_ell = sp->op_ell; p.cdr_L = 65; p.cdr_fn = sp->dev_buf[9];
+            p.cdr_cnt = sp->use_dev_cnt ? sp->dev_cnt : nullptr;         // the counters as the device holds them: the sequence replays as a hipGraph
+            p.cdr_gamma = h->chain_buf[1]; p.cdr_qavg = h->chain_buf[1] + B * T * K;
+        }
         take_tick(t, h->stream, p.tick);
-        DS_HIP(h, t->ki.launch(p, (int)B, h->stream));
+        DS_HIP(h, (cdr_fused ? h->ki_cdr.launch : t->ki.launch)(p, (int)B, h->stream));
     }
     // per frame: noise_estimator.estimation(y); steer = steering(Phi_xx); w = compute_mvdr_weight(steer, Phi_vv_inv); Yout = w^H y — one kernel
-    rc = ds_mcspp_estimate(h->sub[1], D, T, P, nullptr, Y, nullptr, nullptr, DS_MEM_DEVICE);
+    if (cdr_fused) rc = mcspp_from_gamma(h->sub[1], D, T, h->chain_buf[1], h->chain_buf[1] + B * T * K, P, nullptr, nullptr, nullptr, Y);
+    else rc = ds_mcspp_estimate(h->sub[1], D, T, P, nullptr, Y, nullptr, nullptr, DS_MEM_DEVICE);
     if (rc) return fail(h, rc, h->sub[1]->err);
     {   // yout = transform.istft(Yout)
         ds_handle* t = h->sub[2];

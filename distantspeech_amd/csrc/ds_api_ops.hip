@@ -293,17 +293,17 @@ int ds_mcspp_estimate(ds_handle* h, const float* y, int n_frames, float* p_out, 
 }  // extern "C"
 namespace dsi {
 int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* gamma, const float* qavg, float* p_out, ds_handle* fan,
-                     const float* fan_x, float* fan_e) {
+                     const float* fan_x, float* fan_e, float* yout) {
     ds::OpParams p;
     std::memset(&p, 0, sizeof p);
     p.B = h->cfg.batch; p.K = h->K; p.KP = h->KP; p.T = n_frames; p.st = h->opst; p.NF = h->NF; p.M = h->cfg.n_mics;
     p.frm_cnt = h->op_frm; p.ell = h->op_ell; p.L = 65;
     p.dev_cnt = h->use_dev_cnt ? h->dev_cnt : nullptr;
     p.in0 = y; p.in1 = gamma; p.in2 = qavg;
-    p.out0 = p_out;
+    p.out0 = p_out; p.out2 = yout;
     p.repeat = h->mcspp_repeat;
     take_tick(h, h->stream, p.tick);
-    int op = p.repeat ? ds::OP_MCSPP : h->op_frm < 5 ? ds::OP_MCSPP_LEAN : ds::OP_MCSPP_STEADY;
+    int op = (p.repeat || yout) ? ds::OP_MCSPP : h->op_frm < 5 ? ds::OP_MCSPP_LEAN : ds::OP_MCSPP_STEADY;
     if (fan) {                                           // the chain's RLS blocking filters in the same threads (mcspp_fan_ok() said so)
         if (op != ds::OP_MCSPP_STEADY) return fail(h, DS_ESTATE, "mcspp_from_gamma: the fused blocking filters need the steady-state McSpp build");
         op = ds::OP_MCSPP_STEADY_FAN;

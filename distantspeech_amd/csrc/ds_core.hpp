@@ -306,6 +306,9 @@ struct Params {
                               // loop-invariant vector register held across the whole call (and the one value the one-pass MVDR + post-filter
                               // kernel spilled at four waves per SIMD)
     float gate;               // adaptivebeamformer.py:94
+    unsigned gate_kinv;       // ~(number of leading bins whose gate may open), 0 = every bin: the `estPos` start-frame gate counts (frame, bin) slots
+                              // (adaptivebeamformer.py:90-93: frameCount advances once per BIN), so the one frame in which the count runs out
+                              // updates bins [0, r) only — gate_open(); the complement form keeps a zero-filled Params meaning 'no restriction'
     float mu;                 // GSC.py:202
     float* ref_pow;           // GSC, optional (null = off): [B][T][K][M] float, per frame and bin |Y|^2 of the canceller output in front of the
                               // post-filter gain and |U_i|^2 of the M - 1 blocking-matrix outputs — what GSC.py:281-283 hands to
@@ -332,7 +335,8 @@ struct Params {
     // workgroup holds the utterance, so the MCRA stencil comes from LDS and McSpp's band average of 1 - Gamma is a sum over LDS
     float* cdr_st;            // the DS_ALGO_MCSPP stage's planes [B][cdr_NF][KP]; rows 0..8 are McCDR's (p1, p2, x12, MCRA S..lambda_d)
     int cdr_NF;
-    int cdr_frm, cdr_ell, cdr_L;   // the stage's uniform counters before this call (host mirror; the launch is never part of a replayed graph)
+    int cdr_frm, cdr_ell, cdr_L;   // the stage's uniform counters before this call (host mirror: the SubbandGSC chain's launch is never part of a replayed graph)
+    const int* cdr_cnt;            // ... or, non-null, their device copy {frm, ell, ...} (ds_handle::dev_cnt of the McSpp stage): the notebook-MVDR chain replays as a hipGraph
     const float* cdr_fn;      // diffuse coherence of the microphone pair, [K]
     // StftEngine<.., CDR, 2, FRONT = true>: the chain's WHOLE front end in that kernel — FilterDcNotch16 per channel (feature.py:32-49), the
     // TimeAlignment FIR bank and the channel mean (fixedbeamformer.py:13-93, SubbandGSC.py:143) run on the hop in LDS, in front of the
@@ -1086,8 +1090,9 @@ template <int M> DS_HD float ryy_stream_word(const StreamRef& sr, const float* s
     return sr.tail[f - 4 * L::NPS];
 }
 
+DS_HD bool gate_open(const Params& p, int k) { return (unsigned)k < ~p.gate_kinv; }
 template <int M, bool RYY, bool CF = true>
-DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p, const StreamRef* sr = nullptr) {
+DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p, const StreamRef* sr = nullptr, int k = 0) {
     typedef StateLayout<M, ALGO_ADAPTIVE, RYY> SL;
     float* d = st + SL::R_DIAG;
     float* o = st + SL::R_OFF;
@@ -1102,7 +1107,7 @@ DS_HD cf adaptive_bin(float* st, const cf* Z, const cf* a, const Params& p, cons
         }
     }
 #ifndef DS_ABLATE_NORANK1      // timing experiment only (scratch/build_variant.sh): the frame program without the covariance accumulate
-    if (st[SL::MC_S + 3] < p.gate) herm_rank1<M>(d, o, Z, p.alpha_v, p.beta_v);               // :94-99
+    if (st[SL::MC_S + 3] < p.gate && gate_open(p, k)) herm_rank1<M>(d, o, Z, p.alpha_v, p.beta_v);   // :90-99
 #endif
     cf acc = mk(0.0f, 0.0f);
     if (p.method == METHOD_SRC) {                              // beamformer.py:320-322
@@ -1510,13 +1515,13 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
             Yk = fixed_bin<M>(Z, a);
         } else if constexpr (ALGO == ALGO_ADAPTIVE) {
             mcra_bin(st + SL::MC_S, k, K, sh.pw[k > 0 ? k - 1 : 0], sh.pw[k], sh.pw[k + 1], frm_cnt, reset, p.mcra_L);
-            Yk = adaptive_bin<M, RYY>(st, Z, a, p, sr);
+            Yk = adaptive_bin<M, RYY>(st, Z, a, p, sr, k);
         } else if constexpr (ALGO == ALGO_ADAPTIVE_PF) {
             mcra_bin(st + SL::MC_S, k, K, sh.pw[k > 0 ? k - 1 : 0], sh.pw[k], sh.pw[k + 1], frm_cnt, reset, p.mcra_L);
 #if defined(DS_PF_LONG)          // (the long-call build of this kernel: ds_kernels_adaptive_pf_long.hip)
-            Yk = adaptive_bin<M, false, true>(st, Z, a, p);
+            Yk = adaptive_bin<M, false, true>(st, Z, a, p, nullptr, k);
 #else
-            Yk = adaptive_bin<M, false, false>(st, Z, a, p);                                   // adaptivebeamformer.py:69-120
+            Yk = adaptive_bin<M, false, false>(st, Z, a, p, nullptr, k);                                   // adaptivebeamformer.py:69-120
 #endif
             float pp, G, xi, gam;
             mcmcra_bin<M>(st + SL::PF_PYY, st + SL::PF_PVV, Z, k, spp_cnt, pp, G, xi, gam);    // spp.estimation(Z)  GSC.py:225
@@ -2005,7 +2010,7 @@ template <int NFFT, int M, bool CDR = false, int OV = 2, bool FRONT = false> str
             return p.cdr_st[(((long long)b * (aic_floats_per_bin(p.cdr_NF) >> 2) + (f >> 2)) * KP + k) * 4 + (f & 3)];
         };
         int frm = 0, ell = 0;
-        if constexpr (CDR) { frm = p.cdr_frm; ell = p.cdr_ell; }
+        if constexpr (CDR) { frm = p.cdr_cnt ? p.cdr_cnt[0] : p.cdr_frm; ell = p.cdr_cnt ? p.cdr_cnt[1] : p.cdr_ell; }
         const int fmin = (int)(500.0 * (2 * (K - 1)) / 16000.0), fmax = (int)(2000.0 * (2 * (K - 1)) / 16000.0);   // mcspp.py:258-259
         // band mean of 1 - Gamma of frame t (Gamma in sh.tail), summed in bin order by one lane like mcspp_qavg()
         auto band_mean = [&](int t) {

@@ -123,6 +123,7 @@ struct ds_handle {
     int method;
     int mcra_L;
     float alpha_y, alpha_v, diag, gate, mu, out_scale;
+    long long est_pos, est_used; // DS_PARAM_EST_POS (-1 = off) and the (frame, bin) slots consumed since the last restart (adaptivebeamformer.py:90-93)
     bool ref_powers;            // DS_PARAM_REF_POWERS (DS_ALGO_GSC): the frame kernel also writes Params::ref_pow ...
     float* ref_pow;             // ... [B][ref_pow_T][K][M] of the last call (grown on demand)
     size_t ref_pow_cap;         // floats allocated
@@ -185,8 +186,9 @@ int wpe_launch(ds_handle* h, int b0, int nb, const float* x_delayed, const float
 // the McSpp half of ds_mcspp_estimate on device buffers: Gamma and its band mean come from the caller (the chain's front end computes them)
 // fan (optional): the chain's DS_ALGO_SUBRLS stage, run inside the same launch (OP_MCSPP_STEADY_FAN) on reference input fan_x, errors to fan_e;
 // the caller advances that stage's host counters
+// yout (optional): the notebook's online MVDR output of every frame, complex [B][T][K] (the full operator OP_MCSPP)
 int mcspp_from_gamma(ds_handle* h, const float* y, int n_frames, const float* gamma, const float* qavg, float* p_out, ds_handle* fan = nullptr,
-                     const float* fan_x = nullptr, float* fan_e = nullptr);
+                     const float* fan_x = nullptr, float* fan_e = nullptr, float* yout = nullptr);
 int wpe_run(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem, float* ring, int ring_pos, int ring_len,
             const int* dev_ring_pos, float* err0 = nullptr);
 

@@ -166,10 +166,20 @@ __device__ inline void mcspp_qavg_block(const OpParams& p, int b0, float (*band)
 }
 
 // (the fused McSpp + blocking-filter operator at 6 microphones is pinned to the two waves per SIMD the plain steady-state build reaches by itself)
+// the notebook operator (OP_MCSPP, round 6): pinned to two waves per SIMD at 5 microphones and more — 256 registers and 204 B of scratch against 348
+// registers at one wave: + 11 % (profiles/r06a/nb_mvdr_waves_ab.txt; the state in an LDS column instead of registers, for the whole call or for the
+// eigen-solve only, leaves the same spills — loop invariants and a few doubles of the estimation core — and is no faster: removed).  At 4
+// microphones it reaches two waves by itself (209 registers); pinned to three (148 B scratch) it is 8 % slower, to four 14 %
+#ifndef DS_MCSPP_FULL_WAVES
+#define DS_MCSPP_FULL_WAVES 2
+#endif
+#ifndef DS_MCSPP_FULL_WAVES_M4
+#define DS_MCSPP_FULL_WAVES_M4 1
+#endif
 #ifndef DS_MCSPP_WAVES
 #define DS_MCSPP_WAVES 1
 #endif
-constexpr int binop_min_waves(int op, int M) { return (op == OP_MCSPP_STEADY_FAN && M >= 5) ? 2 : (op == OP_MCSPP_STEADY && M >= 5) ? DS_MCSPP_WAVES : 1; }
+constexpr int binop_min_waves(int op, int M) { return (op == OP_MCSPP_STEADY_FAN && M >= 5) ? 2 : (op == OP_MCSPP_STEADY && M >= 5) ? DS_MCSPP_WAVES : (op == OP_MCSPP && M >= 5) ? DS_MCSPP_FULL_WAVES : (op == OP_MCSPP && M == 4) ? DS_MCSPP_FULL_WAVES_M4 : 1; }
 template <int OP, int M> __global__ void __launch_bounds__(256, binop_min_waves(OP, M)) ds_binop_kernel(OpParams p) {
     if (blockIdx.x == 0 && threadIdx.x == 0) apply_tick(p.tick);
     const long long i0 = (long long)blockIdx.x * blockDim.x, i = i0 + threadIdx.x;

@@ -136,7 +136,7 @@ template <int M> struct CholInvD {
 #pragma unroll
             for (int q = 0; q < j; ++q) s = fmad_(-at(j, q).x, at(j, q).x, fmad_(-at(j, q).y, at(j, q).y, s));
             s = s > 1e-300 ? s : 1e-300;
-            const double r = 1.0 / sqrt(s);
+            const double r = rsqrt_fast_d(s);           // (the hardware's seed + two Newton steps: a couple of ulp; IEEE sqrt and division are 23 instructions a pivot)
             id[j] = r;
 #pragma unroll
             for (int i = j + 1; i < M; ++i) {
@@ -314,7 +314,10 @@ template <int M> DS_HD void herm_principal_d(cd (&A)[M][M], cd* v) {
 // against numpy on random, indefinite, clustered and block-diagonal matrices).  Only the upper triangle and the diagonal of A are read.
 // (the matrix comes through a getter `a(i, j)`, i <= j, called twice per entry — once for the scale, once for the scaled copy — so that a caller
 // whose matrix is a difference of fp32 state words never holds an unscaled double copy of it beside the working triangle)
-template <int M, class Get> DS_HD void herm_principal_direct_get_d(Get a, cd* v, int* laguerre_steps = nullptr) {
+// `between()` runs between the two passes over the getter: a caller passes the fence that keeps the compiler from merging the two reads of an
+// entry into one held double (which is the unscaled copy this arrangement is there to avoid)
+struct NoFence { DS_HD void operator()() const {} };
+template <int M, class Get, class Fence = NoFence> DS_HD void herm_principal_direct_get_d(Get a, cd* v, int* laguerre_steps = nullptr, Fence between = Fence()) {
     // ---- scale, and the diagonal exit -----------------------------------------------------------------------------------------------------
     double dmax = 0.0, offmax = 0.0;
 #pragma unroll
@@ -334,6 +337,7 @@ template <int M, class Get> DS_HD void herm_principal_direct_get_d(Get a, cd* v,
     }
     const double big2 = dmax * dmax > offmax ? dmax * dmax : offmax;
     const double sc = rsqrt_fast_d(big2);                                         // 1 / max |a_ij|
+    between();
     // lower triangle of the scaled matrix: L[i][j], i >= j  (a_ij = conj(a_ji))
     cd Lw[M][M];
 #pragma unroll
@@ -414,7 +418,8 @@ template <int M, class Get> DS_HD void herm_principal_direct_get_d(Get a, cd* v,
     }
     // to the right of the largest root every leading minor p_k of lam I - T is positive (that IS lam I - T positive definite): checked at
     // every iterate for free, the recurrence produces them.  A start that fails it (never seen; the bounds are bounds) restarts from Gershgorin's
-    for (int it = 0; it < 24; ++it) {
+#pragma unroll 1
+    for (int it = 0; it < 12; ++it) {
         double p0 = 1.0, p1 = lam - d[0], q0 = 0.0, q1 = 1.0, r0 = 0.0, r1 = 0.0;    // p, p', p'' of orders k - 1 and k
         bool pd = p1 > 0.0;
 #pragma unroll

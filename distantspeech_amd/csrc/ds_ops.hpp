@@ -944,20 +944,26 @@ DS_HD float mcspp_qavg(const float* gamma_frame, int fmin, int fmax) {
     return qsum / (float)(fmax - fmin);
 }
 
-#if !defined(DS_LAGUERRE_STATS)
-#define DS_LAGUERRE_STATS          /* the CPU emulator passes a counter here (tests/emul/ds_emul.cpp) */
-#endif
 template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
     constexpr int NO = M * (M - 1) / 2;
     constexpr int o0 = MCSPP_ROW0;                                                 // state row offset of the McSpp part
     // rows o0 .. o0 + 2 M M - 1 = Phi_yy (diagonal, upper triangle), Phi_vv (the same), then xi, gamma, p: one register block, moved as
     // whole float4 groups (o0 is a multiple of 4)
     float mat[2 * M * M + 4];
-    float* yd = mat;
-    float* yo = mat + M;
-    float* vd = mat + M * M;
-    float* vo = mat + M * M + M;
+    constexpr int YD = 0, VD = M * M;                                              // Phi_yy / Phi_vv: M diagonal words, then the upper triangle
     st_load_span<o0, 2 * M * M>(p, b, k, mat);
+    auto S = [&](int f) -> float { return mat[f]; };
+    // entry (i, j) of the Hermitian-packed matrix whose words start at `base` (herm_get's reading of the same words)
+    auto hg = [&](int base, int i, int j) -> cf {
+        if (i == j) return mk(S(base + i), 0.0f);
+        const int w = base + M + 2 * off_index(i < j ? i : j, i < j ? j : i, M);
+        const cf v = mk(S(w), S(w + 1));
+        return i < j ? v : mk(v.x, -v.y);
+    };
+    // Hermitian rank-one update of that matrix
+    auto rank1 = [&](int base, const cf* Z, float a_, float b_) {
+        herm_rank1<M>(mat + base, mat + base + M, Z, a_, b_);
+    };
     int frm = p.frm_cnt;
     const int fmin = (int)(500.0 * (2 * (p.K - 1)) / 16000.0), fmax = (int)(2000.0 * (2 * (p.K - 1)) / 16000.0);   // :258-259
     float xi = 0, gam = 0, pp = 0;
@@ -975,12 +981,10 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
             q_avg = mcspp_qavg(p.in1 + fb, fmin, fmax);
         }
         const float dv = fma_(q_avg, 1e-1f, (1.0f - q_avg) * 1e-4f);               // :254-262
-        herm_rank1<M>(yd, yo, Z, 0.92f, (float)(1.0 - 0.92));                      // :264-266
+        rank1(YD, Z, 0.92f, (float)(1.0 - 0.92));                                  // :264-266
         if (frm < 10) {                                                            // :273-275
 #pragma unroll
-            for (int f = 0; f < M; ++f) vd[f] = yd[f];
-#pragma unroll
-            for (int f = 0; f < 2 * NO; ++f) vo[f] = yo[f];
+            for (int f = 0; f < M * M; ++f) mat[VD + f] = mat[YD + f];
             q = 0.99f;
         }
         // estimation_core :201-242 — in double like the reference's complex128 (ds_linalg64.hpp): inv(Phi_vv + dv I) of nearly rank-one
@@ -996,41 +1000,51 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
 #pragma unroll
             for (int f = 0; f < 2 * M * M; ++f) DS_PIN(mat[f]);
         };
-        auto pyy = [&](int i, int j) { return to_cd(herm_get<M>(yd, yo, i, j)); };
-        auto pxx = [&](int i, int j) { return cdsub(to_cd(herm_get<M>(yd, yo, i, j)), to_cd(herm_get<M>(vd, vo, i, j))); };   // Phi_xx = Phi_yy - Phi_vv (:212; exact in double)
+        auto pyy = [&](int i, int j) { return to_cd(hg(YD, i, j)); };
+        auto pvv = [&](int i, int j) { return to_cd(hg(VD, i, j)); };
+        auto pxx = [&](int i, int j) { return cdsub(to_cd(hg(YD, i, j)), to_cd(hg(VD, i, j))); };   // Phi_xx = Phi_yy - Phi_vv (:212; exact in double)
+        auto zd = [&](int m) { return to_cd(Z[m]); };
         // (round 6) inv(Phi_vv + dv I) is kept as the inverse of its Cholesky factor (CholInvD: A^-1 = Li^H Li) — the trace, A^-1 y, the PMWF column
         // and the MVDR weights are products with it; the explicit inverse (2 M^2 doubles) was the operator's register peak
         CholInvD<M> ci;
-        cd Zd[M], sv[M];
-#pragma unroll
-        for (int m = 0; m < M; ++m) Zd[m] = to_cd(Z[m]);
+        cd sv[M];
         double xid = 0.0;
         const int passes = p.repeat ? 2 : 1;
         for (int pass = 0; pass < passes; ++pass) {
         if (pass == 1) {                                                           // update_noise_psd (alpha_d = 0.92) on the fp32 state, then the
             const float at1 = fma_((float)(1.0 - 0.92), pp, 0.92f);                // second estimation_core of repeat=True (:280-282)
-            herm_rank1<M>(vd, vo, Z, at1, 1.0f - at1);
+            rank1(VD, Z, at1, 1.0f - at1);
         }
         if (p.out2 && pass == passes - 1) {                                        // mvdr.ipynb cell 4: steer_vector = steering(noise_estimator.Phi_xx)
-            herm_principal_direct_get_d<M>(pxx, sv DS_LAGUERRE_STATS);              // the ONE eigenvector steering() keeps, by the direct solve
+            // the ONE eigenvector steering() keeps (beamformer.py:24), by the direct solve of ds_linalg64.hpp
+#if defined(DS_LAGUERRE_COUNT)
+            herm_principal_direct_get_d<M>(pxx, sv, DS_LAGUERRE_COUNT, phase_fence);
+#else
+            herm_principal_direct_get_d<M>(pxx, sv, nullptr, phase_fence);
+#endif
             DS_SCHED_FENCE();
             phase_fence();
         }
         const double dvd = (double)dv;
-        ci.factor_invert([&](int i, int j) { cd t = to_cd(herm_get<M>(vd, vo, i, j)); if (i == j) t.x += dvd; return t; });   // :214
+        ci.factor_invert([&](int i, int j) { cd t_ = pvv(i, j); if (i == j) t_.x += dvd; return t_; });   // :214
         phase_fence();
         double tr = ci.trace_with(pyy);                                            // Re tr(Phi_vv_inv Phi_yy) :217
         phase_fence();
         if (tr - (double)M < 0.0) {                                                // :219-228
             const double dl = frm < 5 ? dvd : 0.0;
-            ci.factor_invert([&](int i, int j) { cd t = pyy(i, j); if (i == j) t.x += dl; return t; });
+            ci.factor_invert([&](int i, int j) { cd t_ = pyy(i, j); if (i == j) t_.x += dl; return t_; });
             phase_fence();
             tr = ci.trace_with(pyy);
         }
         phase_fence();
         xid = dmin_(dmax_(tr - (double)M, 1e-6), 1e8);                  // :230
         cd u[M], v[M];
-        ci.lower(Zd, u);                                                           // v = Phi_vv_inv y; y^H v = |Li y|^2
+        {
+            cd Zd[M];
+#pragma unroll
+            for (int m = 0; m < M; ++m) Zd[m] = zd(m);
+            ci.lower(Zd, u);                                                       // v = Phi_vv_inv y; y^H v = |Li y|^2
+        }
         double yv = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i) yv += cdabs2(u[i]);
@@ -1045,14 +1059,18 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
         }
         const double gamd = dmin_(dmax_(vPv - yv, 1e-6), 1e8);                       // :232-236
         const double qd = (double)q;
-        double ppd = 1.0 / (1.0 + qd / (1.0 - qd) * (1.0 + xid) * exp(-1.0 * (gamd / (1.0 + xid))));   // compute_p :75-92
+        const double r1x = rcp_fast_d(1.0 + xid);
+        // compute_p :75-92 (reciprocals: seed + two Newton steps).  e^(-gamma / (1 + xi)) from the fp32 hardware exponential: its 1e-7 of relative
+        // error is 1e-7 of p at most — the double-precision library routine was 80 instructions and a dozen hoisted constants for nothing
+        const double egx = (double)exp2_(-(float)(gamd * r1x) * 1.44269504088896341f);
+        double ppd = rcp_fast_d(1.0 + qd * rcp_fast_d(1.0 - qd) * (1.0 + xid) * egx);
         ppd = dmin_(dmax_(ppd, 0.0), 1.0);
         xi = (float)xid; gam = (float)gamd; pp = (float)ppd;
         phase_fence();
         }
         const long long ob = fb + k;
         p.out0[ob] = pp;
-        const double wsc = 1.0 / (10.0 + xid);                                     // compute_pmwf_weight beta = 10 :283
+        const double wsc = rcp_fast_d(10.0 + xid);                                 // compute_pmwf_weight beta = 10 :283
         if (p.out1) {
             cd x0[M], u[M], w[M];
 #pragma unroll
@@ -1081,13 +1099,13 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
             ci.upper(u, w);
             cd Y = mkd(0.0, 0.0);
 #pragma unroll
-            for (int m = 0; m < M; ++m) Y = cdfmac(Y, Zd[m], w[m]);
-            const double rden = 1.0 / den;
+            for (int m = 0; m < M; ++m) Y = cdfmac(Y, zd(m), w[m]);
+            const double rden = rcp_fast_d(den);
             p.out2[2 * ob] = (float)(Y.x * rden); p.out2[2 * ob + 1] = (float)(Y.y * rden);
         }
         if (!p.repeat) {                                                           // update_noise_psd (alpha_d = 0.92) on the fp32 state: behind
             const float at = fma_((float)(1.0 - 0.92), pp, 0.92f);                 // every reader of this frame's Phi_vv
-            herm_rank1<M>(vd, vo, Z, at, 1.0f - at);
+            rank1(VD, Z, at, 1.0f - at);
         }
         frm += 1;
     }
@@ -1430,7 +1448,7 @@ template <int M> DS_HD void op_adaptive(const OpCtx& p, int b, int k) {
 #pragma unroll
     for (int m = 0; m < M; ++m) a[m] = sv[m];
     Params q;
-    q.method = p.method; q.alpha_y = 0.8f; q.beta_y = (float)(1.0 - 0.8); q.alpha_v = p.alpha_v; q.beta_v = p.beta_v; q.gate = p.gate; q.diag = p.diag; q.diag_floor = p.diag_floor;
+    q.method = p.method; q.alpha_y = 0.8f; q.beta_y = (float)(1.0 - 0.8); q.alpha_v = p.alpha_v; q.beta_v = p.beta_v; q.gate = p.gate; q.gate_kinv = 0; q.diag = p.diag; q.diag_floor = p.diag_floor;
     int frm = p.frm_cnt, ell = p.ell;
     for (int t = 0; t < p.T; ++t) {
         const long long fb = ((long long)b * p.T + t) * p.K;

@@ -75,7 +75,7 @@ template <int M, int ALGO, bool RYY> struct BinParts {
             return fixed_bin<M>(Z, a);
         } else if constexpr (ALGO == ALGO_ADAPTIVE) {
             mcra_bin(st + SL::MC_S, k, K, pw[k > 0 ? k - 1 : 0], pw[k], pw[k + 1], frm_cnt, reset, p.mcra_L);
-            return adaptive_bin<M, RYY>(st, Z, a, p);
+            return adaptive_bin<M, RYY>(st, Z, a, p, nullptr, k);
         } else {
             return gsc_bin<M>(st, Z, a, p, k, spp_cnt);
         }
@@ -96,7 +96,7 @@ template <int M, int ALGO, bool RYY> struct BinParts {
             float* d = st + SL::R_DIAG;
             float* o = st + SL::R_OFF;
             if (RYY) herm_rank1<M>(st + SL::RYY_DIAG, st + SL::RYY_OFF, Z, p.alpha_y, p.beta_y);      // adaptive_bin, word for word
-            if (st[SL::MC_S + 3] < p.gate) herm_rank1<M>(d, o, Z, p.alpha_v, p.beta_v);
+            if (st[SL::MC_S + 3] < p.gate && gate_open(p, k)) herm_rank1<M>(d, o, Z, p.alpha_v, p.beta_v);
             sw.init(d, o, p.diag, a, Z);
         } else {
             columns<col_begin(PART), col_begin(PART + 1)>();

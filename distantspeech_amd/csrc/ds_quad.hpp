@@ -274,7 +274,7 @@ template <int NFFT> struct EngineQ {
         const vec4* s4 = reinterpret_cast<const vec4*>(steer + (long long)k * 8);
 #pragma unroll
         for (int m = 0; m < 4; ++m) { const vec4 v = s4[m]; a[2 * m] = qmk<float>(v.x, v.y); a[2 * m + 1] = qmk<float>(v.z, v.w); }
-        if (pk < p.gate) quad_rank1(q, R, z, p.alpha_v, p.beta_v);                             // adaptivebeamformer.py:94-99
+        if (pk < p.gate && gate_open(p, k)) quad_rank1(q, R, z, p.alpha_v, p.beta_v);                             // adaptivebeamformer.py:94-99
         cf acc = mk(0.0f, 0.0f);
         if (p.method == METHOD_SRC) {
             acc = cmulc(mk(z[0].x, z[0].y), mk(a[0].x, a[0].y));

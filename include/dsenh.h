@@ -196,6 +196,13 @@ typedef struct ds_config {
                                          double like the reference's complex128 (awpe.py:60-71,181-186) instead of fp32 — one workgroup per (utterance,
                                          bin), several times slower and four times the state bytes: for streams where the fp32 recursion's
                                          eps x cond(P) matters (csrc/ds_wpe64.hpp).  State read-back: DS_FIELD_WPE_STATE64 */
+#define DS_PARAM_EST_POS 20          /* int, DS_ALGO_ADAPTIVE / DS_ALGO_ADAPTIVE_PF: adaptivebeamfomer.estPos (adaptivebeamformer.py:30,90-93).  -1 (default) = None:
+                                         the MCRA-based gate (:94).  n >= 0: the noise covariance Rvv is updated for the first n (frame, bin) slots
+                                         after a reset and never afterwards — the reference's frameCount advances once per BIN, so n = 30 * (nfft / 2 + 1)
+                                         is "the first 30 frames", and the one frame in which the count runs out updates its leading bins only.  The
+                                         count restarts at ds_reset, at every ds_set_steering (the reference restarts it when the look direction
+                                         changes, :70-79) and when DS_PARAM_METHOD changes.  While n >= 0 a handle processes its whole batch per call,
+                                         with plain launches (no hipGraph replay, no utterance groups) */
 #define DS_PARAM_POSTFILTER 15       /* int 0/1: DS_ALGO_TDGSC / DS_ALGO_FDGSC handles apply the OMLSA post-filter in ds_process_device; default 0 */
 #define DS_PARAM_SPLIT 8   /* int 1..8: utterance groups.  Fused frame kernels: ds_process_device_seq runs the utterance range as that many groups,
                               each on its own stream at its own pace (its own hipGraph with graph=1); default 2 from 2048 utterances up, else 1.

@@ -275,7 +275,8 @@ METHODS = ["src", "DS", "MVDR", "TFGSC"]     # adaptivebeamformer.py:36
 
 
 class OracleAdaptiveMVDR:
-    """adaptivebeamfomer.process — beamformer/adaptivebeamformer.py:44-128 (estPos=None, VAD-gated).
+    """adaptivebeamfomer.process — beamformer/adaptivebeamformer.py:44-128: VAD-gated (estPos = None, :94) or with the noise covariance taken from
+    the first `estPos` (frame, bin) slots after a restart (:90-93; the count restarts when the look direction or the method changes, :70-79).
 
     Defined for any number of hops per call as "T successive one-hop calls" (SURVEY §8b chunking
     contract; the reference is only valid one hop per call at HEAD, adaptivebeamformer.py:122)."""
@@ -296,6 +297,10 @@ class OracleAdaptiveMVDR:
         self.Ryy = np.zeros((K, M, M), dtype=self.ct)
         self.transformer = OracleTransform(n_fft=self.nfft, hop_length=self.hop, channel=M, dtype=dtype)
         self.mcra = OracleMCRA(nfft=self.nfft, L=mcra_L, dtype=dtype)   # :40
+        self.estPos = None                                              # :30
+        self.frameCount = 0                                             # :28
+        self.angle = np.array([0, 0]) / 180 * np.pi                     # :24
+        self.AlgorithmIndex = 0                                         # :37
 
     def process_frame(self, Zk, angle_rad, method=2):
         """Zk [K, M] one STFT frame -> Y [K].  :69-120."""
@@ -308,7 +313,16 @@ class OracleAdaptiveMVDR:
         self.mcra.estimation(np.abs(Z[:, 0] * np.conj(Z[:, 0])))        # :81
         zz = Z[:, :, None] * np.conj(Z[:, None, :])                     # z z^H  [K, M, M]
         self.Ryy = alpha_y * self.Ryy + (rt(1) - alpha_y) * zz          # :86-88
-        upd = self.mcra.p < rt(0.4)                                     # :94
+        if not np.array_equal(np.asarray(angle_rad), self.angle) or method != self.AlgorithmIndex:   # :70-79
+            self.angle = np.array(angle_rad, dtype=float)
+            self.AlgorithmIndex = method
+            self.frameCount = 0
+        if self.estPos is not None:                                     # :90-93: frameCount advances once per BIN while below estPos
+            n = min(max(int(self.estPos) - self.frameCount, 0), K)
+            upd = np.arange(K) < n
+            self.frameCount += n
+        else:
+            upd = self.mcra.p < rt(0.4)                                 # :94
         self.Rvv[upd] = alpha_v * self.Rvv[upd] + (rt(1) - alpha_v) * zz[upd]   # :97-99
         if upd.any():
             self.Rvv_inv[upd] = np.linalg.inv(self.Rvv[upd] + diag * np.eye(M, dtype=rt))   # :103-104
@@ -332,6 +346,17 @@ class OracleAdaptiveMVDR:
             raise ValueError(name)
         self.H = H.T.copy()                                             # [M, K] like the reference
         return np.sum(np.conj(H) * Z, axis=1)                           # :119-120
+
+    def beampattern(self, omega, H):
+        """beamformer.beampattern, beamformer.py:536-553: [360, half_bin] in dB; r = 0.032 hard-wired there."""
+        half_bin = H.shape[1]
+        out = np.zeros((360, half_bin))
+        for az in range(360):
+            tao = -1 * 0.032 * np.cos(0) * np.cos(az * np.pi / 180 - self.gamma) / self.c
+            a = np.exp(-1j * omega[None, :] * tao[:, None])              # [M, K]
+            out[az] = np.abs(np.sum(np.conj(H) * a, axis=0))
+        with np.errstate(divide="ignore"):
+            return 10 * np.log10(out)
 
     def process(self, x, angle_rad, method=2):
         """x [M, T*hop] -> y [T*hop]; equals T one-hop reference calls concatenated."""

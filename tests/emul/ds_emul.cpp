@@ -7,8 +7,12 @@
 
 // op_mcspp's direct eigen-solve reports its Laguerre step count here (emul_laguerre_stats)
 static int g_lag_it = 0; static int g_laguerre_max = 0; static long long g_laguerre_sum = 0, g_laguerre_n = 0, g_laguerre_hist[32];
-struct LagNote { ~LagNote() { g_laguerre_max = g_lag_it > g_laguerre_max ? g_lag_it : g_laguerre_max; g_laguerre_sum += g_lag_it; g_laguerre_n += 1; g_laguerre_hist[g_lag_it & 31] += 1; } };
-#define DS_LAGUERRE_STATS , (g_lag_it = 0, &g_lag_it)); LagNote note_; ((void)0
+static int* lag_note() {            // the previous solve's count goes into the statistics when the next one asks for the counter (and in emul_laguerre_stats)
+    if (g_lag_it >= 0) { g_laguerre_max = g_lag_it > g_laguerre_max ? g_lag_it : g_laguerre_max; g_laguerre_sum += g_lag_it; g_laguerre_n += 1; g_laguerre_hist[g_lag_it & 31] += 1; }
+    g_lag_it = 0;
+    return &g_lag_it;
+}
+#define DS_LAGUERRE_COUNT lag_note()
 #include "../../distantspeech_amd/csrc/ds_core.hpp"
 #include "../../distantspeech_amd/csrc/ds_pipe.hpp"
 #include "../../distantspeech_amd/csrc/ds_ops.hpp"
@@ -305,7 +309,7 @@ static int g_repeat = 0, g_two_path = 0;
 static int g_wpe_generic = 0;     // emul_set_wpe_generic(1): every WPE shape through the run-time-shape program (the A side of an A/B)
 void emul_laguerre_hist(long long* h, int reset) { for (int i = 0; i < 32; ++i) { h[i] = g_laguerre_hist[i]; if (reset) g_laguerre_hist[i] = 0; } }
 // max steps << 40 | total steps; *n_solves (optional) = solves counted; reset != 0 clears the counters
-long long emul_laguerre_stats(int reset, long long* n_solves) { const long long r = ((long long)g_laguerre_max << 40) | g_laguerre_sum; if (n_solves) *n_solves = g_laguerre_n; if (reset) { g_laguerre_max = 0; g_laguerre_sum = 0; g_laguerre_n = 0; } return r; }
+long long emul_laguerre_stats(int reset, long long* n_solves) { if (g_lag_it >= 0 && g_laguerre_n + g_laguerre_sum + g_lag_it > 0) { lag_note(); } g_lag_it = -1; const long long r = ((long long)g_laguerre_max << 40) | g_laguerre_sum; if (n_solves) *n_solves = g_laguerre_n; if (reset) { g_laguerre_max = 0; g_laguerre_sum = 0; g_laguerre_n = 0; } return r; }
 int emul_principal(int M, int method, int n, const double* A, double* v) {
     for (int q = 0; q < n; ++q) {
         const double* a = A + (size_t)q * 2 * M * M; double* o = v + (size_t)q * 2 * M;

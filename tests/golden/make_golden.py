@@ -878,6 +878,40 @@ def g23_mvdr_postfilter(x16):
              params=np.array([M, nfft, hop, 2]), r=np.array(mic.r))
 
 
+def g24_estpos_reth(x16):
+    """adaptivebeamfomer with `estPos` set (adaptivebeamformer.py:30,90-93: Rvv from the first estPos (frame, bin) slots after a restart; the look
+    direction changes at hop 25, which restarts the count, :70-79) and process(retH=True) (:124-126, beamformer.py:536-553) on the last hop;
+    GSC.process(retH=True) (GSC.py:290-292: its H is the constructor's ones / M)."""
+    M, nfft, hop, K = 4, 512, 256, 257
+    x = synth(11, M, hop * 40)
+    angle2 = np.array([90, 0]) / 180 * np.pi
+    for name, est, method in (("estpos", 12 * K + 100, 2), ("estpos_whole_frames", 8 * K, 2), ("vad_tfgsc", None, 3), ("vad_ds", None, 1)):
+        mic = MicArray(arrayType="circular", r=0.032, M=M, n_fft=nfft)                       # R2
+        ab = make_adaptive(mic, nfft, hop)                                                 # R1
+        ab.estPos = est
+        ys, bp = [], None
+        with contextlib.redirect_stdout(io.StringIO()), np.errstate(divide="ignore"):
+            for t in range(40):                                                            # R3
+                ang = ANGLE if t < 25 else angle2
+                out = ab.process(x[:, t * hop:(t + 1) * hop].astype(np.float64), ang, method=method, retH=(t == 39))
+                ys.append(np.atleast_1d(out["data"]))
+                bp = out["beampattern"]
+        save("g24_adaptive_%s" % name, "adaptivebeamfomer.process(method=%d, retH on the last hop), estPos=%r, look direction 197 -> 90 deg at hop 25; "
+             "adaptivebeamformer.py:44-128 hop-by-hop; R1 R2 R3" % (method, est),
+             x=x, y=np.concatenate(ys), Rvv=ab.Rvv, H=ab.H, beampattern=bp[::6].astype(np.float32), bp_az=np.arange(0, 360, 6), est_pos=np.array(-1 if est is None else est),
+             frame_count=np.array(ab.frameCount), params=np.array([M, nfft, hop, method]), r=np.array(mic.r))
+    mic = MicArray(arrayType="circular", r=0.032, M=M, n_fft=nfft)
+    with contextlib.redirect_stdout(io.StringIO()), np.errstate(divide="ignore"):
+        g = GSC(mic, frameLen=nfft, angle=[197, 0])
+        ys = []
+        for t in range(12):
+            out = g.process(x[:, t * hop:(t + 1) * hop].astype(np.float64), ANGLE, method=2, retH=(t == 11))
+            ys.append(np.atleast_1d(out["data"]))
+    save("g24_gsc_reth", "GSC.process(method=2, retH on the last hop) GSC.py:174-294 hop-by-hop; R2 R3",
+         x=x[:, :12 * hop], y=np.concatenate(ys), beampattern=out["beampattern"][::6].astype(np.float32), bp_az=np.arange(0, 360, 6),
+         params=np.array([M, nfft, hop, 2]), r=np.array(mic.r))
+
+
 def main():
     only = set(sys.argv[1:])     # e.g. `make_golden.py g6` regenerates one family
 
@@ -912,6 +946,7 @@ def main():
     if want("g21"): g21_wpe_wide()
     if want("g22"): g22_subbandgsc_postfilter(x16)
     if want("g23"): g23_mvdr_postfilter(x16)
+    if want("g24"): g24_estpos_reth(x16)
 
 
 if __name__ == "__main__":

@@ -65,11 +65,14 @@ def test_only_the_one_known_kernel_carries_scratch():
     """scripts/kernel_regs.py on the built library: private-memory (scratch) bytes per lane of every kernel.  Round 5 removed the scratch of the
     notebook McSpp operator at 6 microphones (260 B), of the 1024-point Ryy kernel at 6 microphones (60 B) and of the 8-microphone 1024-point GSC
     kernel (124 B: input staged global -> LDS during the inverse transform, the Nyquist lane's state parked in the idle transform buffer); what
-    is left is the 8-microphone 1024-point MVDR kernel with Ryy — listed here so that a new spill anywhere fails this test."""
+    is left is the 8-microphone 1024-point MVDR kernel with Ryy — listed here so that a new spill anywhere fails this test.  Round 6: the notebook
+    operator at 6 microphones is back on the list ON PURPOSE — its eigen-solve became a direct one (a third of the instructions) and the kernel is
+    pinned to two waves per SIMD, which costs 204 B of scratch (loop invariants and a few doubles of the estimation core) and is 11 % faster than
+    the same program at 348 registers and one wave (profiles/r06a/nb_mvdr_waves_ab.txt)."""
     import subprocess, sys
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "kernel_regs.py")], text=True)
     spill = {l.split("\t")[0]: int(l.split("\t")[3]) for l in out.splitlines() if l.count("\t") >= 3 and l.split("\t")[3].isdigit() and int(l.split("\t")[3]) > 0}
-    known = {"void ds::ds_frames_kernel<1024, 8, 1, true>(ds::Params)"}
+    known = {"void ds::ds_frames_kernel<1024, 8, 1, true>(ds::Params)", "void ds::ds_binop_kernel<8, 6>(ds::OpParams)"}
     assert set(spill) <= known, spill
     assert all(v <= 512 for v in spill.values()), spill
 

@@ -60,6 +60,70 @@ def test_adaptive_vs_reference_golden(ds, name):
     assert np.array_equal(y2, y)
 
 
+@pytest.mark.parametrize("name", ["estpos", "estpos_whole_frames", "vad_tfgsc", "vad_ds"])
+def test_adaptive_estpos_and_beampattern_vs_reference_golden(ds, name):
+    """G24 (two silent no-ops at the boundary).  `estPos` — the noise covariance from the first estPos (frame, bin) slots after a
+    restart, restarted by a new look direction (adaptivebeamformer.py:30,70-79,90-93) — and process(retH=True)'s beampattern (:124-126,
+    beamformer.py:536-553), hop by hop like the reference's shell and as calls of several hops (the slot count runs out inside a call)."""
+    g = load("g24_adaptive_" + name)
+    M, nfft, hop, method = [int(v) for v in g["params"]]
+    x = as_float(g["x"])
+    est = None if int(g["est_pos"]) < 0 else int(g["est_pos"])
+    angle2 = np.array([90, 0]) / 180 * np.pi
+
+    def run(splits):
+        ab = ds.adaptivebeamfomer(_mic(ds, M, nfft, float(g["r"])), frameLen=nfft, hop=hop, nfft=nfft)
+        ab.estPos = est
+        ys, out, t0 = [], None, 0
+        for n in splits:
+            out = ab.process(x[:, t0 * hop:(t0 + n) * hop], ANGLE if t0 < 25 else angle2, method=method, retH=(t0 + n == 40))
+            ys.append(out["data"]); t0 += n
+        return ab, np.concatenate(ys), out["beampattern"]
+
+    ab, y, bp = run([1] * 40)
+    err = rms(y - g["y"])
+    measured("G24_adaptive_" + name, y_rms=err, y_ref_rms=rms(g["y"]), Rvv_relmax=relmax(ab.Rvv, g["Rvv"]))
+    assert err < (1e-4 if method == 3 else 1e-5), err                        # (TFGSC: G4's bar; measured 5.2e-5 here, 3.1e-5 there)
+    assert relmax(ab.Rvv, g["Rvv"]) < 7e-6
+    ok = np.isfinite(g["beampattern"])
+    assert bp.shape == (360, nfft // 2 + 1)
+    d = np.abs(bp[g["bp_az"]][ok] - g["beampattern"][ok])
+    # dB of |H^H a|: deep nulls amplify the weights' fp32 rounding, so the bar is on the bulk and on the pattern's linear magnitude
+    lin = np.abs(10 ** (bp[g["bp_az"]][ok] / 10) - 10 ** (g["beampattern"][ok] / 10))
+    assert np.median(d) < 1e-3 and lin.max() < 2e-3, (np.median(d), lin.max())
+    # calls of several hops: 25 + 15 (the restart falls on a call boundary, as it must: one look direction per call), and pieces inside
+    for splits in ([25, 15], [7, 18, 3, 12], [12, 1, 12, 15]):
+        ab2, y2, bp2 = run(splits)
+        assert np.array_equal(y2, y), splits
+        assert np.array_equal(ab2.Rvv, ab.Rvv) and np.array_equal(bp2, bp)
+    if est is not None:
+        with pytest.raises(ValueError):                                      # fewer slots than bins: the reference's output is NaN
+            ab3 = ds.adaptivebeamfomer(_mic(ds, M, nfft, float(g["r"])), frameLen=nfft, hop=hop, nfft=nfft)
+            ab3.estPos = 100
+            ab3.process(x[:, :hop], ANGLE)
+        # checkpoint / resume carries the slot count
+        ab4, _, _ = run([5])
+        blob = ab4._eng.export_state()
+        ab5 = ds.adaptivebeamfomer(_mic(ds, M, nfft, float(g["r"])), frameLen=nfft, hop=hop, nfft=nfft)
+        ab5.estPos = est
+        ab5.process(x[:, :hop] * 0, ANGLE, method=method)                    # (sets the look direction; the import replaces the state and the count)
+        ab5._eng.import_state(blob)
+        ya = ab4.process(x[:, 5 * hop:25 * hop], ANGLE, method=method)["data"]
+        yb = ab5.process(x[:, 5 * hop:25 * hop], ANGLE, method=method)["data"]
+        assert np.array_equal(ya, yb)
+
+
+def test_gsc_beampattern_vs_reference_golden(ds):
+    """GSC.process(retH=True): its H is the constructor's ones / M (GSC.py:50,290-292)."""
+    g = load("g24_gsc_reth")
+    M, nfft, hop, method = [int(v) for v in g["params"]]
+    gsc = ds.GSC(_mic(ds, M, nfft, float(g["r"])), frameLen=nfft)
+    out = gsc.process(as_float(g["x"]), ANGLE, method=method, retH=True)
+    assert rms(out["data"] - g["y"]) < 1e-5
+    ok = np.isfinite(g["beampattern"])
+    assert np.allclose(out["beampattern"][g["bp_az"]][ok], g["beampattern"][ok], rtol=0, atol=2e-4)
+
+
 MVDR_PF_CASES = ["rec1", "synth", "synth_m6", "synth_m2_256"]
 
 

@@ -461,6 +461,66 @@ def test_emul_mcspp_lean_and_steady(name):
     assert np.array_equal(np.concatenate([head, tail], axis=1), p_lean)
 
 
+def test_emul_direct_principal_eigenvector():
+    """herm_principal_direct_d (round 6: Householder tridiagonalisation -> largest root by Laguerre -> inverse iteration; the notebook operator's
+    steering()) against the cyclic Jacobi solve it replaced and against numpy.linalg.eigh: random indefinite matrices over fifteen decades of
+    scale, close and multiple leading eigenvalues, rank-one, negative semi-definite, block-diagonal, nearly diagonal; the zero matrix and a
+    diagonal tie take eigh's LAST eigenvector like the Jacobi solve (McSpp's first ten frames: Phi_xx = 0, mcspp.py:273-275)."""
+    import ctypes
+    from emul import emul as E
+    lib = E.lib()
+
+    def run(M, method, A):
+        A = np.ascontiguousarray(A, dtype=np.complex128)
+        v = np.zeros((A.shape[0], M), dtype=np.complex128)
+        assert lib.emul_principal(M, method, A.shape[0], A.ctypes.data_as(ctypes.c_void_p), v.ctypes.data_as(ctypes.c_void_p)) == 0
+        return v
+
+    rng = np.random.default_rng(1)
+
+    def from_eigs(w):
+        n, M = w.shape
+        Q, _ = np.linalg.qr(rng.standard_normal((n, M, M)) + 1j * rng.standard_normal((n, M, M)))
+        A = (Q * w[:, None, :]) @ np.conj(Q.swapaxes(1, 2))
+        return 0.5 * (A + np.conj(A.swapaxes(1, 2)))
+
+    for M in (2, 3, 4, 5, 6, 8):
+        n = 400
+        w = np.sort(rng.standard_normal((n, M)), axis=1)
+        cases = {"generic": from_eigs(w) * 10.0 ** rng.uniform(-12, 3, (n, 1, 1)), "all negative": from_eigs(-np.abs(w) - 0.1)}
+        w2 = w.copy(); w2[:, -2] = w2[:, -1] - 10.0 ** rng.uniform(-9, -3, n); cases["close pair"] = from_eigs(np.sort(w2, axis=1))
+        w4 = np.zeros((n, M)); w4[:, -1] = rng.uniform(0.1, 1, n); cases["rank one"] = from_eigs(w4)
+        w5 = np.zeros((n, M)); w5[:, 0] = -rng.uniform(0.1, 1, n); cases["negative rank one"] = from_eigs(w5)
+        Ad = from_eigs(w) * 1e-3; Ad[:, np.arange(M), np.arange(M)] += w; cases["nearly diagonal"] = Ad
+        if M >= 4:
+            Ab = from_eigs(w); h = M // 2; Ab[:, :h, h:] = 0; Ab[:, h:, :h] = 0; cases["block diagonal"] = Ab
+        for name, A in cases.items():
+            ev = np.linalg.eigvalsh(A)
+            scale = np.abs(ev).max(axis=1) + 1e-300
+            for method in (0, 1):
+                v = run(M, method, A)
+                assert np.all(np.isfinite(v)), (M, name, method)
+                assert np.max(np.abs(np.linalg.norm(v, axis=1) - 1)) < 1e-12
+                resid = np.abs(np.einsum("nij,nj->ni", A, v) - ev[:, -1:] * v).max(axis=1) / scale
+                # a backward-stable solve: A v = lambda_max v to rounding.  The Laguerre loop is capped at 12 steps (linear convergence onto a
+                # cluster): inside a cluster tighter than ~1e-6 of the matrix the direct solve returns a unit vector of the cluster's invariant
+                # subspace — residual <= the cluster's spread; a state carried in fp32 cannot tell such eigenvectors apart anyway
+                spread = (ev[:, -1] - ev[:, -2]) / scale if name == "close pair" else (1e-7 if name == "negative rank one" else 0.0)
+                assert np.all(resid < 1e-13 + (spread if method == 1 else 0.0)), (M, name, method, resid.max())
+            if name in ("generic", "all negative", "rank one"):                  # well-separated: the two solves and eigh agree, phase included
+                gap = (ev[:, -1] - ev[:, -2]) / scale
+                vj, vd = run(M, 0, A), run(M, 1, A)
+                ref = np.linalg.eigh(A)[1][:, :, -1]
+                ref = ref / np.exp(1j * np.angle(ref[:, :1]))
+                assert np.max(np.abs(vd - vj).max(axis=1) * gap) < 1e-12
+                assert np.max(np.abs(vd - ref).max(axis=1) * gap) < 1e-12
+        Z = np.zeros((1, M, M), complex)
+        D = np.diag([1.0] + [3.0] * (M - 1)).astype(complex)[None]
+        for A in (Z, D):
+            e_last = np.zeros(M); e_last[-1] = 1
+            assert np.array_equal(run(M, 0, A)[0], e_last) and np.array_equal(run(M, 1, A)[0], e_last)
+
+
 def test_emul_steering_and_mvdr_weight():
     from oracle import ds_oracle as O
     rng = np.random.default_rng(4)

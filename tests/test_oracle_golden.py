@@ -110,6 +110,25 @@ def test_mvdr_postfilter_one_pass(golden, name):
     assert rms(y0 - g["y_mvdr"]) < 1e-7 * max(rms(g["y_mvdr"]), 1e-3)
 
 
+@pytest.mark.parametrize("name", ["estpos", "estpos_whole_frames", "vad_tfgsc", "vad_ds"])
+def test_adaptive_estpos_and_beampattern(golden, name):
+    """G24: `estPos` (adaptivebeamformer.py:30,90-93: Rvv from the first estPos (frame, bin) slots after a restart; the look direction changes at
+    hop 25, which restarts the count, :70-79) and process(retH=True)'s beampattern (:124-126, beamformer.py:536-553)."""
+    g = golden("g24_adaptive_" + name)
+    M, nfft, hop, method = [int(v) for v in g["params"]]
+    x = g["x"]
+    ab = O.OracleAdaptiveMVDR(_mic(M, nfft, r=float(g["r"])), frameLen=nfft, hop=hop, nfft=nfft)
+    ab.estPos = None if int(g["est_pos"]) < 0 else int(g["est_pos"])
+    angle2 = np.array([90, 0]) / 180 * np.pi
+    y = np.concatenate([ab.process(x[:, t * hop:(t + 1) * hop], ANGLE if t < 25 else angle2, method=method) for t in range(40)])
+    assert rms(y - g["y"]) < 1e-7 * max(rms(g["y"]), 1e-3)
+    assert np.allclose(ab.Rvv, g["Rvv"], rtol=1e-9, atol=1e-14)
+    assert ab.frameCount == int(g["frame_count"])
+    bp = ab.beampattern(ab.omega, ab.H)[g["bp_az"]]
+    ok = np.isfinite(g["beampattern"])
+    assert np.allclose(bp[ok], g["beampattern"][ok], rtol=0, atol=2e-4)              # dB; the fixture holds float32
+
+
 def test_adaptive_mvdr_chunk_invariance(golden):
     g = golden("g4_adaptive_synth")
     x = g["x"][:, : 256 * 40]
