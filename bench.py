@@ -360,6 +360,20 @@ class GpuWorkload:
     def check(self, first_step):
         assert bool(self.be.torch.isfinite(self.y[:, first_step * self.T * self.hop:]).all()), "non-finite output"
 
+    def checksums(self):
+        """[64-bit sum of the output samples' bit patterns (position-weighted), the same of the exported state]: equal inputs through equal
+        kernels give equal words, on any rank"""
+        import numpy as np
+        torch = self.be.torch
+        bits = self.y.contiguous().view(torch.int32).to(torch.int64).flatten()
+        wts = (torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 65521) + 1
+        ysum = int((bits * wts).sum().item())
+        blob = np.frombuffer(self.eng.export_state(), dtype=np.uint8)
+        pad = (-blob.size) % 4
+        words = np.frombuffer(np.concatenate([blob, np.zeros(pad, np.uint8)]).tobytes(), dtype=np.uint32).astype(np.uint64)
+        ssum = int((words * ((np.arange(words.size, dtype=np.uint64) % np.uint64(65521)) + np.uint64(1))).sum(dtype=np.uint64).astype(np.int64))
+        return [ysum, ssum]
+
     def close(self):
         self.eng.close()
         del self.x, self.y
@@ -434,6 +448,28 @@ def measure(be, dsdist, w, B, T, K, W, rank, world, min_region_ms, graph=None, m
     }
 
 
+def cross_rank_verify(be, dsdist, w, T, rank, world, n_utt=8, hops=12):
+    """Every rank runs the SAME small job — utterances [0, n_utt) of the workload, `hops` hops in calls of min(T, 4) hops — and the ranks
+    all-gather 64-bit checksums of the enhanced samples and of the exported state: on one node they must agree bit for bit (same library, same
+    kernels, same inputs; a rank on a sick GPU, a stale library on one rank or a sharding bug in the input generator shows here, where
+    `isfinite` does not look).  Raises SystemExit(3) on rank 0 on a mismatch; returns {"status": "ok", "what": ...}."""
+    Tc = max(1, min(int(T), 4))
+    K = max(1, hops // Tc)
+    wl = be.make(w, n_utt, Tc, K, 0, seed=0, graph=0)
+    wl.run(0, K)
+    wl.sync()
+    be.device_sync()
+    sums = wl.checksums() if hasattr(wl, "checksums") else [0, 0]
+    wl.close()
+    allv = dsdist.gather_ints(sums, device=getattr(be, "device", None))
+    bad = [r for r, v in enumerate(allv) if v != allv[0]]
+    if bad and rank == 0:
+        sys.stderr.write("bench.py --verify: ranks %s disagree with rank 0 on utterances [0, %d): %s vs %s\n" % (bad, n_utt, [allv[r] for r in bad], allv[0]))
+        sys.exit(3)
+    return {"status": "ok", "what": "%d rank(s): utterances [0, %d) x %d hops on every rank, checksums of samples and exported state equal (%016x, %016x)"
+                                    % (len(allv), n_utt, K * Tc, allv[0][0] & (2 ** 64 - 1), allv[0][1] & (2 ** 64 - 1))}
+
+
 ACCOUNTING = {
     "state": "achieved / frac = the bytes a step must move (the carried state as the library packs it — Hermitian and symmetric matrices as "
              "triangles — once in and once out, plus the step's samples in and out) over THIS run's launch duration (HIP events on the kernel's stream)",
@@ -505,7 +541,7 @@ def compact_roofline(r):
 def compact_line(out, detail_path):
     """the ONE line the driver parses: contract keys + numeric roofline objects + per other config {value, ms_per_step, bound, frac}"""
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                                "dtype", "data", "rounds", "timed_steps", "region_ms", "collective") if k in out}
+                                "dtype", "data", "rounds", "timed_steps", "region_ms", "collective", "verify") if k in out}
     line["config"] = out["config"]
     line["roofline"] = compact_roofline(out["roofline"])
     if "valu" in out:
@@ -647,6 +683,9 @@ def main():
     ap.add_argument("--hbm-batch", type=int, default=16384, help="batch of the roofline_hbm regime (state working set > the 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_hbm and other_configs (profiling runs)")
+    ap.add_argument("--verify", action="store_true", help="every rank also runs utterances [0, 8) of the job for 12 hops; the ranks all-gather 64-bit "
+                                                          "checksums of the enhanced samples and of the exported state, rank 0 asserts that they agree "
+                                                          "(the line then carries \"verify\": \"ok\"); on by default when --gpus > 1")
     args = ap.parse_args()
     if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
         raise SystemExit("--gpus and --steps must be >= 1, --warmup >= 0")
@@ -671,6 +710,8 @@ def main():
 
     from distantspeech_amd import dist as dsdist
     rank, local_rank, world = dsdist.env_world()
+    # this rank's launch thread on the cores of its GPU's NUMA node — before the first GPU call of the process (sysfs only)
+    affinity = dsdist.pin_to_gpu_numa_node(int(os.environ.get("DS_FORCE_DEVICE", local_rank))) if not os.environ.get("DS_BENCH_BACKEND") else "off"
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but %d rank(s) were launched (WORLD_SIZE)\n" % (args.gpus, world))
         sys.exit(2)
@@ -697,6 +738,9 @@ def main():
     if res["ranks"] != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but %d rank(s) contributed to the result\n" % (args.gpus, res["ranks"]))
         sys.exit(2)
+    verify = None
+    if args.verify or world > 1:
+        verify = cross_rank_verify(be, dsdist, w, T, rank, world)
     out = None
     if rank == 0:
         regime = "streaming callback regime" if T == 1 else "chunked"
@@ -717,6 +761,10 @@ def main():
                                                                int(0.5 * FS / w["hop"]))},
             "roofline": res["roofline"],
         }
+        if verify is not None:
+            out["verify"] = verify["status"]
+            out["config"]["verify"] = verify["what"]
+        out["config"]["affinity"] = affinity
         if args.total_batch:
             out["config"]["total_batch"] = args.total_batch
         if getattr(be, "shared_device", False):

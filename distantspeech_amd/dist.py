@@ -88,6 +88,73 @@ def reduce_max(value, device=None):
     return float(t.item())
 
 
+def gather_ints(values, device=None):
+    """all ranks' lists of int64 values, as a list (one list per rank, in rank order) on every rank — the cross-rank comparison of `bench.py
+    --verify` (every rank computes the same utterances; their checksums must agree bit for bit)."""
+    vals = [int(v) for v in values]
+    dist = _group()
+    if dist is None:
+        return [vals]
+    import torch
+    dev = device if dist.get_backend() == "nccl" else None
+    mine = torch.tensor(vals, dtype=torch.int64, device=dev)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [[int(v) for v in t.tolist()] for t in out]
+
+
+def pin_to_gpu_numa_node(device_ordinal):
+    """Restrict this process to the CPU cores of the NUMA node its GPU hangs off (sysfs: /sys/class/drm/card*/device/numa_node and the node's
+    cpulist), so that a rank's launch thread and its pinned staging buffers sit next to its GPU on a multi-socket node.  Call it BEFORE the
+    first GPU call of the process.  Returns a short description of what was done ("numa node 1: 48 cores", "no numa information", ...); never
+    raises — affinity is an optimisation, not a requirement.  DS_NO_AFFINITY=1 turns it off."""
+    if os.environ.get("DS_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return "off"
+    try:
+        import glob
+        import re
+        # render nodes of AMD GPUs in PCI order = HIP's device order on a single-vendor node
+        cards = []
+        for path in glob.glob("/sys/class/drm/card[0-9]*"):
+            if not re.fullmatch(r"card\d+", os.path.basename(path)):
+                continue
+            try:
+                vendor = open(os.path.join(path, "device", "vendor")).read().strip()
+                if vendor != "0x1002" or not os.path.exists(os.path.join(path, "device", "mem_info_vram_total")):
+                    continue
+                cards.append((os.path.basename(os.path.realpath(os.path.join(path, "device"))), path))
+            except OSError:
+                continue
+        cards.sort()
+        # HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES renumber the devices the process sees
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+        if vis:
+            try:
+                order = [int(v) for v in vis.split(",") if v.strip() != ""]
+                cards = [cards[i] for i in order if 0 <= i < len(cards)]
+            except ValueError:
+                pass
+        if not (0 <= int(device_ordinal) < len(cards)):
+            return "no numa information"
+        node = int(open(os.path.join(cards[int(device_ordinal)][1], "device", "numa_node")).read().strip())
+        if node < 0:
+            return "no numa information"
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if not allowed:
+            return "no numa information"
+        os.sched_setaffinity(0, allowed)
+        return "numa node %d: %d cores" % (node, len(allowed))
+    except (OSError, ValueError):
+        return "no numa information"
+
+
 def finalize():
     dist = _group()
     if dist is not None:

@@ -35,6 +35,7 @@ def test_self_launch_two_ranks(tmp_path):
     assert abs(out["value"] - frames / (out["region_ms"] * 1e-3)) / out["value"] < 1e-3
     assert abs(out["ms_per_step"] - out["region_ms"] / (20 * R)) < 1e-3
     assert out["collective"] == "gloo"
+    assert out["verify"] == "ok" and out["config"]["verify"].startswith("2 rank(s)")       # on by default with more than one rank
     assert set(out["other_configs"]) >= {"mvdr_pf", "mvdr_pf_10s_chunks", "cfg3", "cfg4", "cfg5", "cfg2_10s_chunks", "cfg3_10s_chunks", "cfg4_10s_chunks", "cfg5_10s_chunks"}
     assert all(set(v) >= {"value", "ms_per_step", "bound", "frac"} for v in out["other_configs"].values())
     assert out["roofline"]["bound"] == "hbm" and out["roofline_hbm"]["batch_per_gpu"] == 16384
@@ -68,6 +69,16 @@ def test_forced_process_group_at_world_size_one(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["collective"] == "gloo"
+
+
+def test_eight_ranks_shard_cfg4(tmp_path):
+    # the launch form of the 8-GPU node: 8 ranks, BASELINE config 4's 8192 utterances sharded over them, the cross-rank verification on
+    r = run_bench(["--gpus", "8", "--config", "cfg4", "--total-batch", "8192", "--steps", "4", "--warmup", "1", "--min-region-ms", "10", "--no-extras"],
+                  {"DS_BENCH_DETAIL": str(tmp_path / "d.json")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["batch_per_gpu"] == 1024 and out["verify"] == "ok"
+    assert abs(out["value"] - 8192 * out["timed_steps"] / (out["region_ms"] * 1e-3)) / out["value"] < 1e-3
 
 
 def test_rank_count_mismatch_is_an_error():

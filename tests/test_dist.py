@@ -30,8 +30,21 @@ def _worker(rank, world, port, q):
     d.barrier()
     frames, t, ranks = d.reduce_throughput((hi - lo) * 10, 1.0 + r)      # rank 1 is "slower"
     assert ranks == w and d.reduce_max(3.0 + r) == 4.0
+    assert d.gather_ints([7, -(2 ** 62) - r]) == [[7, -(2 ** 62)], [7, -(2 ** 62) - 1]]      # bench.py --verify: every rank sees every rank's words
     q.put((r, lo, hi, frames, t))
     d.finalize()
+
+
+def test_numa_pinning_never_raises_and_keeps_a_core():
+    from distantspeech_amd.dist import gather_ints, pin_to_gpu_numa_node
+    before = os.sched_getaffinity(0)
+    try:
+        for dev in (0, 7, 99):
+            what = pin_to_gpu_numa_node(dev)
+            assert isinstance(what, str) and len(os.sched_getaffinity(0)) >= 1
+    finally:
+        os.sched_setaffinity(0, before)
+    assert gather_ints([1, 2]) == [[1, 2]]                                # no process group: this rank alone
 
 
 def test_gloo_world2_reduce():

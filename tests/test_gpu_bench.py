@@ -34,6 +34,8 @@ def test_two_ranks_share_one_gpu_weak_scaling(tmp_path):
     assert abs(out["value"] - frames / (out["region_ms"] * 1e-3)) / out["value"] < 1e-3
     assert out["roofline"]["bound"] == "hbm" and 0.0 < out["roofline"]["frac"] < 1.0
     assert det["value"] == out["value"]
+    # every rank ran utterances [0, 8) as well; their checksums of samples and exported state agree (bench.py cross_rank_verify)
+    assert out["verify"] == "ok" and out["config"]["verify"].startswith("2 rank(s)") and "affinity" in out["config"]
 
 
 def test_two_ranks_shard_one_job_strong_scaling(tmp_path):
@@ -43,6 +45,22 @@ def test_two_ranks_shard_one_job_strong_scaling(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["total_batch"] == 96 and out["config"]["batch_per_gpu"] == 48
     frames = 96 * out["timed_steps"]
     assert abs(out["value"] - frames / (out["region_ms"] * 1e-3)) / out["value"] < 1e-3
+
+
+def test_eight_ranks_shard_cfg4_as_baseline_words_it(tmp_path):
+    """The launch form of the node this was never run on: 8 ranks (all on GPU 0 here, gloo), BASELINE config 4's 8192 utterances sharded over
+    them with dist.shard_range, the cross-rank checksum comparison on, one line from rank 0."""
+    out, det = run_bench(["--gpus", "8", "--config", "cfg4", "--total-batch", "8192", "--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline",
+                          "--min-region-ms", "10"], tmp_path)
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["total_batch"] == 8192 and out["config"]["batch_per_gpu"] == 1024
+    assert out["verify"] == "ok" and out["config"]["verify"].startswith("8 rank(s)")
+    frames = 8192 * out["timed_steps"]
+    assert abs(out["value"] - frames / (out["region_ms"] * 1e-3)) / out["value"] < 1e-3
+
+
+def test_verify_flag_on_one_rank(tmp_path):
+    out, det = run_bench(["--gpus", "1", "--verify", "--steps", "5", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--min-region-ms", "20"], tmp_path)
+    assert out["verify"] == "ok" and out["config"]["verify"].startswith("1 rank(s)")
 
 
 def test_rccl_branch_runs_at_world_size_one(tmp_path):
