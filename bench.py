@@ -96,12 +96,12 @@ WORKLOADS = {
     # MCRA 5140, analysis tails 2*1024, FIR history 1328, notch 32, delays 4*128*4 + 1024 = 39 316
     "tdgsc": dict(algo="TDGSC", M=4, nfft=512, hop=256, batch=1024, S=18304, r=0.032, kernel="DS_ALGO_TDGSC chain", launches=6, graph=0,
                   desc="TDGSC chain (TDGSC.process: FIR bank + blocking matrix + MCRA-controlled overlap-save canceller), 4 mics, 16 kHz, block 256"),
-    "fdgsc": dict(algo="FDGSC", M=4, nfft=512, hop=256, batch=1024, S=39316, r=0.032, kernel="DS_ALGO_FDGSC chain", launches=14, graph=0,
+    "fdgsc": dict(algo="FDGSC", M=4, nfft=512, hop=256, batch=1024, S=39316, r=0.032, kernel="DS_ALGO_FDGSC chain", launches=8, graph=0,
                   desc="FDGSC chain (FDGSC.process: adaptive blocking filters + norm-limited canceller), 4 mics, 16 kHz, block 256"),
 }
 
 
-EXTRA_T1 = ("mvdr_pf", "cfg3", "cfg4", "cfg5", "wpe_nb", "nb_mvdr", "nb_mvdr_m4")                                                  # other_configs at one hop per call
+EXTRA_T1 = ("mvdr_pf", "cfg3", "cfg4", "cfg5", "wpe_nb", "nb_mvdr", "nb_mvdr_m4", "tdgsc", "fdgsc")                                                  # other_configs at one hop per call
 EXTRA_CHUNKED = (("cfg2", 625), ("mvdr_pf", 625), ("cfg3", 625), ("cfg4", 312), ("cfg5", 625), ("wpe_nb", 2500), ("nb_mvdr", 625))         # ... and with 10 s per call
 DATA_NOTE = ("BASELINE.md section 3's recipe in both legs (white noise sigma 0.05 per microphone + a 0.5 s on / off 300-3400 Hz Gaussian source sigma "
              "0.1 steered from 197 degrees, seed 1234 + utterance): the GPU leg draws it on the device with torch's generator (GpuBackend.synth), the "
@@ -272,6 +272,79 @@ class GpuBackend:
         res["device"]["path"] = "ds_process_device + ds_synchronize: float chunk resident in HBM, output left in HBM"
         res["realtime_factor_p99"] = round(res["chunk_ms_budget"] * 1e3 / res["pcm16_host"]["p99_us"], 1)
         return res
+
+
+def host_api_entry(be, long_calls=True):
+    """The API the reference's users call, at batch: `adaptivebeamfomer.process(x_numpy)` (adaptivebeamformer.py:44-128) with x in HOST memory —
+    every call uploads its chunk, runs the frame kernel and downloads the enhanced samples, so its rate is a PCIe figure.  B = 1024 streams,
+    4 microphones, 512 / 256: one 1024-sample chunk per call (4 hops: the realtime shell's CHUNK, realtime/realtime_processing.py:113-136) and
+    10 s per call (625 hops), through (a) the mirror class (float32 in, float64 out like the reference), (b) the C-ABI entry it sits on
+    (ds_process: float32 both ways) and (c) the shell's wire format (ds_process_pcm16: int16 interleaved 6-channel frames in, int16 out).
+    GB/s = (bytes up + bytes down) / wall time per call; pinned_h2d / d2h = this box's hipMemcpy rate from pinned host memory (16 MB)."""
+    import numpy as np
+    import distantspeech_amd as d
+    from distantspeech_amd import _lib as L
+    torch = be.torch
+    B, M, nfft, hop = 1024, 4, 512, 256
+    ang = np.array(ANGLE_DEG) / 180.0 * np.pi
+    res = {"workload": host_api_entry.__doc__.split("\n")[0].strip(), "batch": B, "n_mics": M, "unit": "frames/s; GB/s = bytes both ways / wall time"}
+    # the machine's own transfer rates (what `frac_of_pinned` is quoted against)
+    pin = torch.empty(16 << 20, dtype=torch.uint8).pin_memory()
+    dev = torch.empty(16 << 20, dtype=torch.uint8, device=be.device)
+    for key, (dst, src) in (("pinned_h2d_gbs", (dev, pin)), ("pinned_d2h_gbs", (pin, dev))):
+        dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        res[key] = round(20 * (16 << 20) / (time.perf_counter() - t0) / 1e9, 2)
+    del pin, dev
+    rng = np.random.default_rng(3)
+    for T in ((4, 625) if long_calls else (4,)):
+        n = T * hop
+        blk = (rng.standard_normal((M, 4096)) * 0.05).astype(np.float32)
+        x = np.ascontiguousarray(np.broadcast_to(np.tile(blk, (1, -(-n // 4096)))[:, :n], (B, M, n)))      # [B, M, n] float32, 16 MB / 2.6 GB
+        pcm = np.zeros((B, n, 6), dtype="<i2")
+        pcm[:, :, 1:5] = (x[0].T * 32768).astype("<i2")[None]
+        reps = 30 if T == 4 else 2
+        ent = {}
+        ab = d.adaptivebeamfomer(d.MicArray(arrayType="circular", r=0.032, M=M, n_fft=nfft), frameLen=nfft, batch=B, device=be.local_rank, track_ryy=False)
+        for _ in range(2):
+            ab.process(x, ang, method=2)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = ab.process(x, ang, method=2)["data"]
+        dt = (time.perf_counter() - t0) / reps
+        ent["mirror"] = {"frames_s": round(B * T / dt, 1), "ms_per_call": round(dt * 1e3, 3), "gbs": round((x.nbytes + B * n * 4) / dt / 1e9, 2),
+                         "path": "adaptivebeamfomer.process(x[B, M, n] float32 NumPy) -> dict, 'data' float64 like the reference's"}
+        assert np.all(np.isfinite(y))
+        del y
+        ab.out_dtype = np.float32                       # the mirror's option: the kernel's own float32 samples, no conversion pass
+        ab.process(x, ang, method=2)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            y = ab.process(x, ang, method=2)["data"]
+        dt = (time.perf_counter() - t0) / reps
+        ent["mirror_f32"] = {"frames_s": round(B * T / dt, 1), "ms_per_call": round(dt * 1e3, 3), "gbs": round((x.nbytes + B * n * 4) / dt / 1e9, 2),
+                             "frac_of_pinned": round((x.nbytes + B * n * 4) / dt / 1e9 / max(res["pinned_h2d_gbs"], 1e-9), 3),
+                             "path": "the same with obj.out_dtype = np.float32"}
+        eng = ab._eng
+        for name, call, up, down in (("c_abi", lambda: eng.process(x, L.LAYOUT_CHANNELS_SAMPLES), x.nbytes, B * n * 4),
+                                     ("pcm16", lambda: eng.process_pcm16(pcm, first_channel=1), pcm.nbytes, B * n * 2)):
+            call()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                call()
+            dt = (time.perf_counter() - t0) / reps
+            ent[name] = {"frames_s": round(B * T / dt, 1), "ms_per_call": round(dt * 1e3, 3), "gbs": round((up + down) / dt / 1e9, 2),
+                         "frac_of_pinned": round((up + down) / dt / 1e9 / max(res["pinned_h2d_gbs"], 1e-9), 3)}
+        ent["c_abi"]["path"] = "ds_process: float32 [B, M, n] in host memory in, float32 [B, n] out"
+        ent["pcm16"]["path"] = "ds_process_pcm16: int16 [B, n, 6] interleaved in host memory in (microphones 1..4), int16 [B, n] out"
+        ent["mirror"]["frac_of_pinned"] = round(ent["mirror"]["gbs"] / max(res["pinned_h2d_gbs"], 1e-9), 3)
+        ab._eng.close()
+        res["T%d" % T] = ent
+        del x, pcm, y
+    return res
 
 
 class GpuWorkload:
@@ -533,8 +606,9 @@ def attach_compute(entry, key, frames_per_s_per_gpu):
 
 
 def compact_roofline(r):
-    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "bytes_per_launch", "bytes_basis", "batch_per_gpu", "resident",
-            "frac_survey_bytes", "frac_measured", "traffic_profile", "value")
+    # (frac_survey_bytes / bytes_basis live in the side file only since round 6: the line needed the room for tdgsc / fdgsc / host_api)
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launch_ms", "bytes_per_launch", "batch_per_gpu", "resident",
+            "frac_measured", "traffic_profile", "value")
     return {k: r[k] for k in keep if k in r}
 
 
@@ -557,6 +631,10 @@ def compact_line(out, detail_path):
             c.update(bound="valu", frac=e["valu"]["frac_valu_issue"], frac_hbm=e["roofline"]["frac"])
             if "traffic_over_algorithmic" in e["roofline"]:
                 c["traffic_x"] = e["roofline"]["traffic_over_algorithmic"]       # measured HBM bytes of a 10 s call / SURVEY 8(d)'s algorithmic bytes
+        elif name in ("tdgsc", "fdgsc"):
+            # one block per call through 6 / 8 dependent launches of 3 .. 12 us each on 19 / 40 MB of state: bound by launch latency, not by
+            # bytes (profiles/r06*/tdgsc_kernel_stats.csv) — `frac` is the HBM fraction all the same, `launches` says why it is small
+            c.update(bound="launch", frac=e["roofline"]["frac"], launches=e["roofline"].get("launches_per_step"))
         else:
             c.update(bound="hbm", frac=e["roofline"]["frac"])
             if "frac_measured" in e["roofline"]:
@@ -570,6 +648,12 @@ def compact_line(out, detail_path):
         la = out["latency"]
         line["latency_us"] = {"chunk_ms_budget": la["chunk_ms_budget"], "pcm16_host_median": la["pcm16_host"]["median_us"], "pcm16_host_p99": la["pcm16_host"]["p99_us"],
                               "device_median": la["device"]["median_us"]}
+    if "host_api" in out:
+        ha = out["host_api"]
+        line["host_api"] = {"pinned_h2d_gbs": ha["pinned_h2d_gbs"]}
+        for T in ("T4", "T625"):
+            if T in ha:
+                line["host_api"][T] = {k: [ha[T][k]["frames_s"], ha[T][k]["gbs"]] for k in ("mirror", "mirror_f32", "c_abi", "pcm16")}      # [frames/s, GB/s both ways]
     line["detail"] = detail_path
     return line
 
@@ -683,6 +767,7 @@ def main():
     ap.add_argument("--hbm-batch", type=int, default=16384, help="batch of the roofline_hbm regime (state working set > the 256 MiB Infinity Cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_hbm and other_configs (profiling runs)")
+    ap.add_argument("--host-api", action="store_true", help="only the host-buffer API entry (adaptivebeamfomer.process(x_numpy) at batch): prints its JSON")
     ap.add_argument("--verify", action="store_true", help="every rank also runs utterances [0, 8) of the job for 12 hops; the ranks all-gather 64-bit "
                                                           "checksums of the enhanced samples and of the exported state, rank 0 asserts that they agree "
                                                           "(the line then carries \"verify\": \"ok\"); on by default when --gpus > 1")
@@ -724,6 +809,11 @@ def main():
     be = load_backend(local_rank, world, tail_async=hw_queues_raised)
     dsdist.init(backend=be.dist_backend)
 
+    if args.host_api:
+        if rank == 0:
+            print(json.dumps(host_api_entry(be)), flush=True)
+        dsdist.finalize()
+        return
     w = WORKLOADS[args.config]
     B = args.batch or w["batch"]
     seed = None
@@ -829,6 +919,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras and args.config == "cfg2" and hasattr(be, "latency"):
         out["latency"] = be.latency()
+        out["host_api"] = host_api_entry(be)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2" and not os.environ.get("DS_BENCH_BACKEND"):
             out["cpu_baseline"] = cpu_baseline()

@@ -72,13 +72,13 @@ _lib = None
 # every symbol include/dsenh.h declares (tests check that the built library exports all of them)
 EXPORTS = [
     "ds_version", "ds_build_info", "ds_device_count", "ds_strerror", "ds_create", "ds_destroy", "ds_reset", "ds_last_error",
-    "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_set_window", "ds_process", "ds_process_pcm16", "ds_process_device",
+    "ds_set_steering", "ds_set_param_i", "ds_set_param_f", "ds_set_window", "ds_process", "ds_process_f64", "ds_process_pcm16", "ds_process_device",
     "ds_process_device_seq", "ds_stft", "ds_istft", "ds_mcra_estimate", "ds_mcra_estimate_p", "ds_mcmcra_estimate", "ds_mcsppbase_estimate", "ds_set_aux", "ds_mcspp_estimate", "ds_steering",
     "ds_mvdr_weight", "ds_pmwf_weight", "ds_gev_vector", "ds_blind_analytic_normalization", "ds_phase_correction", "ds_dcnotch", "ds_firbank", "ds_firbank_bm", "ds_tdfilter_update", "ds_fdaf_update", "ds_adaptive_frames", "ds_chain_set_aux", "ds_subband_gsc_process", "ds_tdgsc_process", "ds_fdgsc_process", "ds_mcspp_mvdr_process",
     "ds_omlsa_estimate", "ds_omlsa_postfilter",
     "ds_sublms_update", "ds_subrls_update", "ds_wpe_update", "ds_synchronize",
     "ds_timing_begin", "ds_timing_end", "ds_get_state", "ds_field_bytes", "ds_state_bytes", "ds_state_payload_bytes", "ds_chain_stage_info", "ds_chain_stage_field_bytes", "ds_chain_stage_state", "ds_export_state",
-    "ds_import_state",
+    "ds_import_state", "ds_host_alloc", "ds_host_free",
 ]
 
 
@@ -135,8 +135,14 @@ def load():
     lib.ds_set_param_i.argtypes = [vp, ci, ci]
     lib.ds_set_param_f.restype = ci
     lib.ds_set_param_f.argtypes = [vp, ci, cf_]
+    lib.ds_host_alloc.restype = vp
+    lib.ds_host_alloc.argtypes = [csz]
+    lib.ds_host_free.restype = ci
+    lib.ds_host_free.argtypes = [vp]
     lib.ds_process.restype = ci
     lib.ds_process.argtypes = [vp, vp, ci, ci, vp]
+    lib.ds_process_f64.restype = ci
+    lib.ds_process_f64.argtypes = [vp, vp, ci, ci, vp]
     lib.ds_process_pcm16.restype = ci
     lib.ds_process_pcm16.argtypes = [vp, vp, ci, ci, ci, vp]
     lib.ds_process_device.restype = ci

@@ -74,6 +74,9 @@ class beamformer(object):
         self.batch = int(batch)
         self._device = device
         self._eng = None
+        # process() returns float64 samples like the reference (transform.py:479 scales a float32 buffer by a Python float): widened on the
+        # device (ds_process_f64; exact).  `out_dtype = np.float32` hands back the kernel's own samples and halves the download
+        self.out_dtype = np.float64
 
     # -- geometry / fixed weights (host set-up) ----------------------------------------------------
     def compute_steering_vector_from_doa(self, look_angle=(0, 0)):
@@ -145,8 +148,8 @@ class FixedBeamformer(beamformer):
             self._eng.set_steering(self.W)
         if x.shape[1] % self.hop != 0:
             raise ValueError("samples (%d) must be a multiple of hop (%d)" % (x.shape[1], self.hop))
-        y = self._eng.process(x, L.LAYOUT_SAMPLES_CHANNELS)
-        return self._squeeze(y).astype(np.float64)
+        y = self._eng.process(x, L.LAYOUT_SAMPLES_CHANNELS, out_dtype=self.out_dtype)
+        return self._squeeze(y).astype(self.out_dtype, copy=False)
 
 
 class _AdaptiveBase(beamformer):
@@ -189,10 +192,10 @@ class _AdaptiveBase(beamformer):
             self.AlgorithmIndex = method
             self._eng.set_method(method)
         self._before_process()
-        y = self._eng.process(x, L.LAYOUT_CHANNELS_SAMPLES)
+        y = self._eng.process(x, L.LAYOUT_CHANNELS_SAMPLES, out_dtype=self.out_dtype)
         # adaptivebeamformer.py:124-126, GSC.py:290-292: beampattern of the weights the object holds after the call's last frame
         bp = self.beampattern(self.omega, self._weights_after_call(method)) if retH else None
-        return {'data': self._squeeze(y).astype(np.float64), 'WNG': None, 'DI': None, 'beampattern': bp}
+        return {'data': self._squeeze(y).astype(self.out_dtype, copy=False), 'WNG': None, 'DI': None, 'beampattern': bp}
 
     def _before_process(self):
         pass

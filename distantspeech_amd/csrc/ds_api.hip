@@ -320,7 +320,7 @@ int ds_create(const ds_config* cfg, ds_handle** out) {
             if (ds::op_supported(ds::OP_ADAPTIVE, cfg->n_mics)) { op = ds::OP_ADAPTIVE; NF = cfg->n_mics * cfg->n_mics + 5; }
             break;
         case DS_ALGO_SUBBAND_GSC:
-            if (ds::op_supported(ds::OP_MCSPP, cfg->n_mics) && cfg->n_mics >= 3 && cfg->hop * 2 == cfg->nfft && flen <= ds::RLS_NMAX) { op = 105; NF = 0; }
+            if (ds::op_supported(ds::OP_MCSPP, cfg->n_mics) && cfg->n_mics >= 4 && cfg->n_mics <= 6 && cfg->hop * 2 == cfg->nfft && flen <= ds::RLS_NMAX) { op = 105; NF = 0; }
             break;
         case DS_ALGO_TDGSC: case DS_ALGO_FDGSC:
             if (cfg->n_mics >= 2 && cfg->n_mics <= 8 && cfg->hop * 2 == cfg->nfft &&
@@ -1092,7 +1092,11 @@ int ds_process_device_seq(ds_handle* h, const float* x_dev, int layout, long lon
     return DS_OK;
 }
 
-int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y) {
+static int process_host(ds_handle* h, const float* x, int layout, int n_samples, void* y, bool f64);
+int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y) { return process_host(h, x, layout, n_samples, y, false); }
+// ... with the enhanced samples widened to float64 on the device (what the reference's process() returns; exact)
+int ds_process_f64(ds_handle* h, const float* x, int layout, int n_samples, double* y) { return process_host(h, x, layout, n_samples, y, true); }
+static int process_host(ds_handle* h, const float* x, int layout, int n_samples, void* y, bool f64) {
     if (!h || !x || !y) return fail(h, DS_EINVAL, "ds_process: NULL argument");
     if (n_samples < 0 || n_samples % h->cfg.hop != 0)
         return fail(h, DS_ESHAPE, "ds_process: n_samples must be a multiple of hop");
@@ -1113,13 +1117,24 @@ int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y
         DS_HIP(h, hipMalloc((void**)&h->y_stage, ye * sizeof(float)));
         h->y_stage_elems = ye;
     }
+    // (round 6: the batch as utterance groups — upload | kernel | download as a pipeline over three streams — was built and measured: 4.8 M
+    // frames/s against 9.4 M for this plain sequence at B = 1024 and 4 hops per call, every group count from 2 to 7 slower than one: a
+    // hipMemcpyAsync from pageable memory pays its fixed part per call, and ONE 16 MB upload already runs at 0.88 of the pinned rate;
+    // profiles/r06a/host_api_io_groups_ab.txt.  Removed.  What a call does lose is the first touch of a freshly allocated output array: the
+    // Python layer hands its outputs out of a pool of page-locked blocks, ds_host_alloc)
     DS_HIP(h, hipMemcpyAsync(h->x_stage, x, xe * sizeof(float), hipMemcpyHostToDevice, h->stream));
     h->front_open = false;                                  // a chain's front-end stream follows the upload
     rc = ds_process_device(h, h->x_stage, layout, (long long)(M * (size_t)n_samples), 0, n_samples, h->y_stage,
                            (long long)n_samples, 0, h->cfg.batch, nullptr);
     if (rc) return rc;
     rc = join_groups(h); if (rc) return rc;
-    DS_HIP(h, hipMemcpyAsync(y, h->y_stage, ye * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (f64) {
+        rc = stage_reserve(h, 6, ye * sizeof(double)); if (rc) return rc;
+        DS_HIP(h, ds::launch_float_to_double(h->y_stage, (double*)h->dev_buf[6], (long long)ye, h->stream));
+        DS_HIP(h, hipMemcpyAsync(y, h->dev_buf[6], ye * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    } else {
+        DS_HIP(h, hipMemcpyAsync(y, h->y_stage, ye * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    }
     DS_HIP(h, hipStreamSynchronize(h->stream));
     return DS_OK;
 }
@@ -1148,6 +1163,18 @@ int ds_process_pcm16(ds_handle* h, const int16_t* pcm, int n_total_channels, int
     DS_HIP(h, hipMemcpyAsync(out, h->dev_buf[5], ye * sizeof(int16_t), hipMemcpyDeviceToHost, h->stream));
     DS_HIP(h, hipStreamSynchronize(h->stream));
     return DS_OK;
+}
+
+// page-locked host memory for the caller's buffers (hipHostMalloc): a download into it needs no page to be faulted in or pinned first — the Python
+// layer hands its output arrays out of a pool of such blocks (distantspeech_amd/engine.py)
+void* ds_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+int ds_host_free(void* p) {
+    if (!p) return DS_OK;
+    return hipHostFree(p) == hipSuccess ? DS_OK : DS_EHIP;
 }
 
 int ds_synchronize(ds_handle* h) {

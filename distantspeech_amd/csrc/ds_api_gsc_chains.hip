@@ -35,6 +35,32 @@ __global__ void __launch_bounds__(256) ds_fdgsc_control_kernel(float* p, float* 
     all = wave_sum(all);
     if (lane == 0) pa[r] = (float)(1.0 - all / (double)K);
 }
+// FDGSC.py:258,270: the two block delays of a call in ONE launch (round 6; they were six strided device copies) — rows [0, BM): aligned channel
+// rows delayed by half a block (delay_aligned, H samples of carried tail), rows [BM, BM + B): the fixed beamformer output delayed by one block
+// (delay_fbf, FL samples of carried tail).  A row's carried tail is read into registers before the row's new tail is written (one workgroup per
+// row).  tf_tail (optional): Transform.previous_input of the transform_fbf the delayed fixed output is analysed with when no post-filter runs —
+// the analysis there only advances that state (FDGSC.py:273), which is the last block of the delayed row: written here instead of launching it.
+__global__ void __launch_bounds__(256) ds_fdgsc_delays_kernel(const float* xa, float* xad, float* altail, const float* fixed, float* fixd, float* fixprev,
+                                                               float* tf_tail, int BM, int N, int H, int FL) {
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const bool al = r < BM;
+    const int D = al ? H : FL;                                          // this row's delay
+    const float* src = al ? xa + (long long)r * N : fixed + (long long)(r - BM) * N;
+    float* dst = al ? xad + (long long)r * N : fixd + (long long)(r - BM) * N;
+    float* tail = al ? altail + (long long)r * H : fixprev + (long long)(r - BM) * FL;
+    float keep[4];                                                      // D <= 1024 samples: four per lane at most
+#pragma unroll
+    for (int j = 0; j < 4; ++j) keep[j] = tid + 256 * j < D ? tail[tid + 256 * j] : 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (tid + 256 * j < D) { dst[tid + 256 * j] = keep[j]; tail[tid + 256 * j] = src[N - D + tid + 256 * j]; }
+    for (int i = D + tid; i < N; i += 256) dst[i] = src[i - D];
+    if (!al && tf_tail) {                                               // the last FL samples of the delayed row
+        float* t = tf_tail + (long long)(r - BM) * FL;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; if (i < FL) t[i] = N > FL ? src[N - 2 * FL + i] : keep[j]; }
+    }
+}
 }  // namespace ds
 
 namespace dsi {
@@ -224,20 +250,13 @@ int fdgsc_run(ds_handle* h, const float* x, long long x_bstride, long long x_cst
     GS_SUB(2, ds_mcra_estimate_p(h->sub[2], cb[Q_D], 1, (int)T, cb[Q_LAM], cb[Q_P], DS_MEM_DEVICE));           // :243-244
     hipLaunchKernelGGL(ds::ds_fdgsc_control_kernel, dim3((unsigned)((B * T + 3) / 4)), dim3(256), 0, h->stream, cb[Q_P], cb[Q_PA], (int)(B * T), (int)K);   // :248-255,282
     DS_HIP(h, hipGetLastError());
-    {   // :258 delay_aligned: half a block, channel-major rows [B * M][n]
-        const size_t row = N * 4, hb = H * 4;
-        DS_HIP(h, hipMemcpy2DAsync(cb[Q_XAD], row, cb[Q_ALTAIL], hb, hb, B * M, hipMemcpyDeviceToDevice, h->stream));
-        if (N > H) DS_HIP(h, hipMemcpy2DAsync((char*)cb[Q_XAD] + hb, row, cb[Q_XA], row, row - hb, B * M, hipMemcpyDeviceToDevice, h->stream));
-        DS_HIP(h, hipMemcpy2DAsync(cb[Q_ALTAIL], hb, (char*)cb[Q_XA] + (row - hb), row, hb, B * M, hipMemcpyDeviceToDevice, h->stream));
-    }
+    // :258 delay_aligned (half a block, channel-major rows [B * M][n]) and :270 delay_fbf (one block) in one launch; without the post-filter the
+    // analysis of the delayed fixed output (:273) only advances transform_fbf's carried input block: that block is written by the same launch
+    hipLaunchKernelGGL(ds::ds_fdgsc_delays_kernel, dim3((unsigned)(B * M + B)), dim3(256), 0, h->stream, cb[Q_XA], cb[Q_XAD], cb[Q_ALTAIL], cb[Q_FIXED], cb[Q_FIXD],
+                       cb[Q_FIXPREV], postfilter ? nullptr : h->sub[5]->tail_in, (int)(B * M), (int)N, (int)H, (int)FL);
+    DS_HIP(h, hipGetLastError());
     // :259-264 -> :185-195: the M blocking filters of an utterance share the fixed-beamformer output; desired = delayed aligned channel m
     GS_SUB(3, fdaf_run_dev(h->sub[3], cb[Q_FIXED], cb[Q_XAD], nullptr, DS_FDAF_P_NONE, (int)T, -1, cb[Q_BM], wbm_dev, (int)M, (long long)N, 1, 0));
-    {   // :270 delay_fbf: one block
-        const size_t row = N * 4, fb = FL * 4;
-        DS_HIP(h, hipMemcpy2DAsync(cb[Q_FIXD], row, cb[Q_FIXPREV], fb, fb, B, hipMemcpyDeviceToDevice, h->stream));
-        if (N > FL) DS_HIP(h, hipMemcpy2DAsync((char*)cb[Q_FIXD] + fb, row, cb[Q_FIXED], row, row - fb, B, hipMemcpyDeviceToDevice, h->stream));
-        DS_HIP(h, hipMemcpy2DAsync(cb[Q_FIXPREV], fb, (char*)cb[Q_FIXED] + (row - fb), row, fb, B, hipMemcpyDeviceToDevice, h->stream));
-    }
     // :278-284: canceller input = the blocking-filter outputs (channel-major), desired = delayed fixed output, p = 1 - mean p per block
     float* o1 = (postfilter || out_bstride != (long long)N) ? cb[Q_OUT] : out;
     GS_SUB(4, fdaf_run_dev(h->sub[4], cb[Q_BM], cb[Q_FIXD], cb[Q_PA], DS_FDAF_P_BLOCK, (int)T, -1, o1, waic_dev, 1, (long long)(M * N), 1, (long long)N));
@@ -259,7 +278,7 @@ int fdgsc_run(ds_handle* h, const float* x, long long x_bstride, long long x_cst
         }
         DS_HIP(h, hipMemcpy2DAsync(cb[Q_BMLAST], FL * 4, (char*)cb[Q_BM] + (N - FL) * 4, N * 4, FL * 4, B * M, hipMemcpyDeviceToDevice, h->stream));
     } else {
-        rc = tf_stft(h, h->sub[5], cb[Q_FIXD], (long long)N, 1, (long long)N, n, cb[Q_SCR]); if (rc) return rc;   // :273 keeps advancing the shared state
+        // (:273 the analysis of the delayed fixed output keeps advancing transform_fbf's state: done by the delays kernel above)
         if (o1 != out) DS_HIP(h, hipMemcpy2DAsync(out, (size_t)out_bstride * 4, o1, N * 4, N * 4, B, hipMemcpyDeviceToDevice, h->stream));
     }
     if (p_dev) DS_HIP(h, hipMemcpyAsync(p_dev, cb[Q_P], B * T * K * 4, hipMemcpyDeviceToDevice, h->stream));

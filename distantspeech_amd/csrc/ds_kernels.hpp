@@ -43,6 +43,7 @@ hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream);
 hipError_t launch_fir(const TdParams& p, hipStream_t stream);
 hipError_t launch_pcm16_to_float(const short* pcm, float* x, long long n, int Ctot, int c0, int M, hipStream_t stream);
 hipError_t launch_float_to_pcm16(const float* y, short* pcm, long long n, hipStream_t stream);
+hipError_t launch_float_to_double(const float* y, double* out, long long n, hipStream_t stream);
 struct TdfParams;
 hipError_t launch_tdfilter(const TdfParams& p, hipStream_t stream);
 // device-resident uniform counters of an operator / front-end / chain handle: cnt = {frm_cnt, ell, first_frame, aux}; advances them by
@@ -254,12 +255,14 @@ template <int NFFT, int M, int ALGO, bool RYY> KernelInfo make_info() {
     X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) X(256, 8) \
     X(512, 2) X(512, 3) X(512, 4) X(512, 5) X(512, 6) X(512, 8) \
     X(1024, 2) X(1024, 3) X(1024, 4) X(1024, 5) X(1024, 6) X(1024, 8)
-// MVDR + post-filter in one thread per bin: 2 .. 6 microphones (at 8 the two programs hold 141 state floats per lane: the chain
-// DS_ALGO_WPE_MVDR runs them as two operators there)
+// MVDR + post-filter in one thread per bin: 2 .. 6 and (round 6) 8 microphones.  At 8 the two programs hold 141 state floats per lane: 344 - 348
+// registers = one wave per SIMD at 256 / 512 points, 380 B of scratch at 1024 points (a 1024-point workgroup is two waves per SIMD whatever
+// it declares) — built so that the handle takes every shape the plain MVDR handle takes; the chain DS_ALGO_WPE_MVDR keeps running the two
+// programs as two operators at two waves each
 #define DS_FOR_EACH_SHAPE_PF(X) \
-    X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) \
-    X(512, 2) X(512, 3) X(512, 4) X(512, 5) X(512, 6) \
-    X(1024, 2) X(1024, 3) X(1024, 4) X(1024, 5)
+    X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) X(256, 8) \
+    X(512, 2) X(512, 3) X(512, 4) X(512, 5) X(512, 6) X(512, 8) \
+    X(1024, 2) X(1024, 3) X(1024, 4) X(1024, 5) X(1024, 6) X(1024, 8)
 #endif
 
 }  // namespace ds

@@ -631,6 +631,20 @@ __global__ void __launch_bounds__(256) ds_float_to_pcm16_kernel(const float* y, 
     v = fminf(fmaxf(v, -32768.0f), 32767.0f);                                   // astype('<i2') would wrap; saturate instead
     pcm[i] = (short)(int)v;                                                     // truncation toward zero like astype
 }
+// float32 -> float64 (exact), four samples per lane: the output of ds_process_f64 — the reference's process() returns float64 samples, and widening
+// 0.65 GB on one host core (NumPy's astype) was longer than the whole rest of a 10 s call at B = 1024
+__global__ void __launch_bounds__(256) ds_float_to_double_kernel(const float* y, double* out, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = reinterpret_cast<const float4*>(y)[i];
+    double2* o = reinterpret_cast<double2*>(out) + 2 * i;
+    o[0] = make_double2((double)v.x, (double)v.y);
+    o[1] = make_double2((double)v.z, (double)v.w);
+}
+hipError_t launch_float_to_double(const float* y, double* out, long long n, hipStream_t stream) {      // n a multiple of 4 (whole hops)
+    hipLaunchKernelGGL(ds_float_to_double_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, y, out, n / 4);
+    return hipGetLastError();
+}
 hipError_t launch_pcm16_to_float(const short* pcm, float* x, long long n, int Ctot, int c0, int M, hipStream_t stream) {
     hipLaunchKernelGGL(ds_pcm16_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, pcm, x, n, Ctot, c0, M);
     return hipGetLastError();

@@ -2,10 +2,65 @@
 
 All signal processing happens in libdsenh.so's HIP kernels; this class only moves pointers."""
 import ctypes
+import threading
+import weakref
 
 import numpy as np
 
 from . import _lib as L
+
+
+class _PinnedPool:
+    """Output arrays of the host-buffer calls out of page-locked blocks (ds_host_alloc = hipHostMalloc).  A fresh `np.empty` is fresh pages:
+    the download has to fault each one in and pin it first (10 s per call at B = 1024 is 0.65 GB of output — 40 % of the call).  An array handed
+    out here owns its block exclusively, like any new array; when the last reference to it (and to every view of it) is gone, a finalizer puts
+    the block back, and the next call of that size gets pages that are resident and pinned already.  A caller who keeps every output just
+    makes the pool allocate a new block per call.  Blocks of at least MIN_BYTES only (small outputs stay ordinary arrays); at most MAX_IDLE
+    idle bytes are kept."""
+    MIN_BYTES = 1 << 20
+    MAX_IDLE = 4 << 30
+
+    def __init__(self, lib):
+        self._lib = lib
+        self._free = {}                  # bytes -> [address, ...]
+        self._idle = 0
+        self._lock = threading.Lock()
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        if nbytes < self.MIN_BYTES:
+            return np.empty(shape, dtype=dtype)
+        with self._lock:
+            lst = self._free.get(nbytes)
+            addr = lst.pop() if lst else None
+            if addr is not None:
+                self._idle -= nbytes
+        if addr is None:
+            addr = self._lib.ds_host_alloc(nbytes)
+            if not addr:
+                return np.empty(shape, dtype=dtype)          # no page-locked memory left: an ordinary array
+        block = (ctypes.c_char * nbytes).from_address(addr)
+        weakref.finalize(block, self._give_back, addr, nbytes)     # the ctypes object is the base of the array and of all its views
+        return np.frombuffer(block, dtype=dtype).reshape(shape)
+
+    def _give_back(self, addr, nbytes):
+        with self._lock:
+            if self._idle + nbytes <= self.MAX_IDLE:
+                self._free.setdefault(nbytes, []).append(addr)
+                self._idle += nbytes
+                return
+        self._lib.ds_host_free(ctypes.c_void_p(addr))
+
+
+_pool = None
+
+
+def _pinned_pool():
+    global _pool
+    if _pool is None:
+        _pool = _PinnedPool(L.load())
+    return _pool
 
 
 class BatchEngine:
@@ -78,8 +133,8 @@ class BatchEngine:
         L.check(self._lib.ds_set_param_f(self._h, int(pid), float(value)), self._h)
 
     # -- hot path -------------------------------------------------------------------------------
-    def process(self, x, layout):
-        """Host arrays.  x: [B, L, M] (layout 0) or [B, M, L] (layout 1) -> y [B, L] float32."""
+    def process(self, x, layout, out_dtype=np.float32):
+        """Host arrays.  x: [B, L, M] (layout 0) or [B, M, L] (layout 1) -> y [B, L] float32 (or float64: widened on the device, ds_process_f64)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         if x.ndim != 3 or x.shape[0] != self.batch:
             raise ValueError("x must be [B=%d, ...] 3-D, got %s" % (self.batch, x.shape))
@@ -87,9 +142,10 @@ class BatchEngine:
         m = x.shape[2] if layout == L.LAYOUT_SAMPLES_CHANNELS else x.shape[1]
         if m != self.M:
             raise ValueError("expected %d channels, got %d" % (self.M, m))
-        y = np.empty((self.batch, n), dtype=np.float32)
-        L.check(self._lib.ds_process(self._h, x.ctypes.data_as(ctypes.c_void_p), int(layout), int(n),
-                                     y.ctypes.data_as(ctypes.c_void_p)), self._h)
+        f64 = np.dtype(out_dtype) == np.float64
+        y = _pinned_pool().empty((self.batch, n), np.float64 if f64 else np.float32)      # (a page-locked block from 1 MB up: see _PinnedPool)
+        L.check((self._lib.ds_process_f64 if f64 else self._lib.ds_process)(self._h, x.ctypes.data_as(ctypes.c_void_p), int(layout), int(n),
+                                                                           y.ctypes.data_as(ctypes.c_void_p)), self._h)
         return y
 
     def process_pcm16(self, pcm, first_channel=0):
@@ -97,7 +153,7 @@ class BatchEngine:
         pcm = np.ascontiguousarray(pcm, dtype="<i2")
         if pcm.ndim != 3 or pcm.shape[0] != self.batch:
             raise ValueError("pcm must be [B=%d, samples, channels]" % self.batch)
-        out = np.empty(pcm.shape[:2], dtype="<i2")
+        out = _pinned_pool().empty(pcm.shape[:2], "<i2")
         L.check(self._lib.ds_process_pcm16(self._h, pcm.ctypes.data_as(ctypes.c_void_p), int(pcm.shape[2]), int(first_channel),
                                            int(pcm.shape[1]), out.ctypes.data_as(ctypes.c_void_p)), self._h)
         return out

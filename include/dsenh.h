@@ -151,14 +151,17 @@ typedef struct ds_config {
                                   applied to its output, Y = w^H z * spp.G — the post-filter convention of GSC.py:225,286 (spp = McMcra,
                                   mc_mcra.py:179-224) — in ONE fused frame kernel behind ds_process / ds_process_device: "MVDR + post-filter" in
                                   one pass.  Methods src / DS / MVDR; parameters and fields of DS_ALGO_ADAPTIVE (track_ryy = 0) plus
-                                  DS_FIELD_PHI_YY / DS_FIELD_PHI_VV; n_mics 2..6 (6: nfft <= 512) */
+                                  DS_FIELD_PHI_YY / DS_FIELD_PHI_VV; n_mics 2..6 or 8 (round 6: 8 microphones and 6 at 1024 points too — at 8 the two
+                                  programs hold 141 state floats per lane: one wave per SIMD, and the 1024-point kernel spills) */
 
 #define DS_ALGO_MCSPP_MVDR 24   /* the online MVDR of example/mvdr.ipynb cell 4 as ONE handle behind ds_process / ds_process_device / ds_mcspp_mvdr_process:
                                   Transform.stft of the n_mics channels (transform.py:430-453) -> per frame McSpp.estimation (McCDR prior; mcspp.py:244-305,
                                   mccdr.py:122-177) -> steering(Phi_xx) (beamformer.py:10-31) -> compute_mvdr_weight(steer, Phi_vv_inv)
                                   (beamformer.py:133-155) -> Y = w^H y -> Transform.istft (transform.py:455-481).  Stages (ds_chain_stage_info):
                                   0 analysis transform, 1 DS_ALGO_MCSPP, 2 synthesis transform.  Diffuse coherence via
-                                  ds_chain_set_aux(DS_CHAIN_AUX_COHERENCE) first; DS_PARAM_MCSPP_REPEAT as for DS_ALGO_MCSPP; n_mics 4 or 6 */
+                                  ds_chain_set_aux(DS_CHAIN_AUX_COHERENCE) first; DS_PARAM_MCSPP_REPEAT as for DS_ALGO_MCSPP; n_mics 4 or 6
+                                  (8: the reference's own McSpp raises LinAlgError on its 8-channel recording — inv(Phi_yy) of a rank-deficient matrix, mcspp.py:226 —
+                                  so there is nothing to be identical to; tests/golden/make_golden.py g11b) */
 
 /* ds_set_param_* ids */
 #define DS_FDAF_PLAIN 0
@@ -258,6 +261,9 @@ int ds_set_param_f(ds_handle* h, int id, float value);
 /* Host-buffer call (the realtime-callback form): x is [B] x layout, y is [B][n_samples];
  * synchronous: returns after the enhanced samples are in y. */
 int ds_process(ds_handle* h, const float* x, int layout, int n_samples, float* y);
+/* The same call with the enhanced samples handed back as float64 [B][n_samples] — what the reference's process() returns (transform.py:479) —
+ * widened on the device (exact): on the host that conversion is the longest part of a call at batch */
+int ds_process_f64(ds_handle* h, const float* x, int layout, int n_samples, double* y);
 
 /* Realtime wire format (realtime/realtime_processing.py:113-136): pcm = int16 little-endian interleaved [B][n_samples][n_total_channels]
  * straight from the capture device; channels [first_channel, first_channel + n_mics) are the microphones; they are scaled by
@@ -375,6 +381,12 @@ int ds_subrls_update(ds_handle* h, const float* x, const float* d, int n_frames,
 int ds_wpe_update(ds_handle* h, const float* x_delayed, const float* d, int n_frames, float* err, int mem);
 
 int ds_synchronize(ds_handle* h);
+
+/* Page-locked host memory (hipHostMalloc / hipHostFree) for buffers handed to the host-pointer entry points: transfers to and from it run at the
+ * link's rate without the pages having to be faulted in and pinned per call — what a freshly allocated output array costs (10 s per call at
+ * B = 1024 is 0.65 GB of output: profiles/r06a/host_api_io_groups_ab.txt).  NULL when the allocation fails. */
+void* ds_host_alloc(size_t bytes);
+int ds_host_free(void* p);
 
 /* hipEvent bracket on the handle's stream (kernel timing for bench.py) */
 int ds_timing_begin(ds_handle* h);

@@ -112,7 +112,7 @@ template <int NFFT, int M> int run_nm(int algo, int ryy, const ds::Params& p, in
     if (algo == ds::ALGO_ADAPTIVE && ryy) return run_t<NFFT, M, ds::ALGO_ADAPTIVE, true>(p, batch);
     if (algo == ds::ALGO_GSC) return run_t<NFFT, M, ds::ALGO_GSC, false>(p, batch);
     if (algo == ds::ALGO_AIC) return run_t<NFFT, M, ds::ALGO_AIC, false>(p, batch);
-    if constexpr (M <= 6) { if (algo == ds::ALGO_ADAPTIVE_PF) return run_t<NFFT, M, ds::ALGO_ADAPTIVE_PF, false>(p, batch); }
+    if (algo == ds::ALGO_ADAPTIVE_PF) return run_t<NFFT, M, ds::ALGO_ADAPTIVE_PF, false>(p, batch);
     return -1;
 }
 

@@ -72,7 +72,8 @@ def test_only_the_one_known_kernel_carries_scratch():
     import subprocess, sys
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "scripts", "kernel_regs.py")], text=True)
     spill = {l.split("\t")[0]: int(l.split("\t")[3]) for l in out.splitlines() if l.count("\t") >= 3 and l.split("\t")[3].isdigit() and int(l.split("\t")[3]) > 0}
-    known = {"void ds::ds_frames_kernel<1024, 8, 1, true>(ds::Params)", "void ds::ds_binop_kernel<8, 6>(ds::OpParams)"}
+    known = {"void ds::ds_frames_kernel<1024, 8, 1, true>(ds::Params)", "void ds::ds_binop_kernel<8, 6>(ds::OpParams)",
+             "void ds::ds_frames_kernel<1024, 8, 4, false>(ds::Params)"}       # (round 6: MVDR + post-filter at 8 microphones / 1024 points, 141 state floats per lane)
     assert set(spill) <= known, spill
     assert all(v <= 512 for v in spill.values()), spill
 

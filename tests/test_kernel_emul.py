@@ -29,7 +29,7 @@ def test_emul_adaptive(name):
     assert np.mean(pdiff > 1e-3) < 0.02          # an fp32 threshold flip may move isolated bins
 
 
-@pytest.mark.parametrize("name", ["rec1", "synth", "synth_m6", "synth_m2_256"])
+@pytest.mark.parametrize("name", ["rec1", "synth", "synth_m6", "synth_m2_256", "synth_m8_1024", "synth_m6_1024"])
 def test_emul_mvdr_postfilter_one_pass(name):
     """ALGO_ADAPTIVE_PF (MVDR + McMcra gain in one per-bin phase) against G23, the same composition run through the reference's objects."""
     g = load("g23_mvdr_pf_" + name)

@@ -88,7 +88,7 @@ def test_adaptive_mvdr(golden, name):
         assert np.allclose(ab.H, g["H"], rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", ["rec1", "synth", "synth_m6", "synth_m2_256"])
+@pytest.mark.parametrize("name", ["rec1", "synth", "synth_m6", "synth_m2_256", "synth_m8_1024", "synth_m6_1024"])
 def test_mvdr_postfilter_one_pass(golden, name):
     """G23: MVDR + McMcra gain in one pass, composed from the reference's own objects (make_golden.py g23)."""
     g = golden("g23_mvdr_pf_" + name)
