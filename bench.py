@@ -616,7 +616,7 @@ def compact_line(out, detail_path):
     """the ONE line the driver parses: contract keys + numeric roofline objects + per other config {value, ms_per_step, bound, frac}"""
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                                 "dtype", "data", "rounds", "timed_steps", "region_ms", "collective", "verify") if k in out}
-    line["config"] = out["config"]
+    line["config"] = {k: v for k, v in out["config"].items() if k != "timed_hops"}      # (which hops a round replays: in the side file)
     line["roofline"] = compact_roofline(out["roofline"])
     if "valu" in out:
         line["valu"] = {k: out["valu"][k] for k in ("bound", "frac_valu_issue", "frac_lds", "valu_profile")}
@@ -650,10 +650,10 @@ def compact_line(out, detail_path):
                               "device_median": la["device"]["median_us"]}
     if "host_api" in out:
         ha = out["host_api"]
-        line["host_api"] = {"pinned_h2d_gbs": ha["pinned_h2d_gbs"]}
+        line["host_api"] = {"unit": "[M frames/s, GB/s up + down]", "pinned_h2d_gbs": ha["pinned_h2d_gbs"]}
         for T in ("T4", "T625"):
             if T in ha:
-                line["host_api"][T] = {k: [ha[T][k]["frames_s"], ha[T][k]["gbs"]] for k in ("mirror", "mirror_f32", "c_abi", "pcm16")}      # [frames/s, GB/s both ways]
+                line["host_api"][T] = {k: [round(ha[T][k]["frames_s"] / 1e6, 2), round(ha[T][k]["gbs"], 1)] for k in ("mirror", "mirror_f32", "c_abi", "pcm16")}   # [M frames/s, GB/s both ways]
     line["detail"] = detail_path
     return line
 

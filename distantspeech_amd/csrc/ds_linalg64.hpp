@@ -9,6 +9,7 @@
 //
 // Same contraction discipline as ds_core.hpp: every fused multiply-add is explicit.
 #pragma once
+#include <type_traits>
 #include "ds_core.hpp"
 
 namespace ds {
@@ -316,16 +317,29 @@ template <int M> DS_HD void herm_principal_d(cd (&A)[M][M], cd* v) {
 // whose matrix is a difference of fp32 state words never holds an unscaled double copy of it beside the working triangle)
 // `between()` runs between the two passes over the getter: a caller passes the fence that keeps the compiler from merging the two reads of an
 // entry into one held double (which is the unscaled copy this arrangement is there to avoid)
+// `mag2(i, j)` (optional): |a_ij|^2 in whatever precision the caller has it cheaply (the notebook operator: the fp32 state words) — it only sizes
+// the matrix (any scale within a few per cent normalises it as well) and decides the diagonal exit, where an entry that is exactly zero is
+// exactly zero in any precision
 struct NoFence { DS_HD void operator()() const {} };
-template <int M, class Get, class Fence = NoFence> DS_HD void herm_principal_direct_get_d(Get a, cd* v, int* laguerre_steps = nullptr, Fence between = Fence()) {
+struct NoMag { };
+template <int M, class Get, class Fence = NoFence, class Mag = NoMag>
+DS_HD void herm_principal_direct_get_d(Get a, cd* v, int* laguerre_steps = nullptr, Fence between = Fence(), Mag mag2 = Mag()) {
     // ---- scale, and the diagonal exit -----------------------------------------------------------------------------------------------------
     double dmax = 0.0, offmax = 0.0;
 #pragma unroll
-    for (int i = 0; i < M; ++i) { const double t = fabs(a(i, i).x); dmax = t > dmax ? t : dmax; }
+    for (int i = 0; i < M; ++i) {
+        double t;
+        if constexpr (std::is_same<Mag, NoMag>::value) t = fabs(a(i, i).x); else t = sqrt((double)mag2(i, i));
+        dmax = t > dmax ? t : dmax;
+    }
 #pragma unroll
     for (int i = 0; i < M - 1; ++i)
 #pragma unroll
-        for (int j = i + 1; j < M; ++j) { const double m2 = cdabs2(a(i, j)); offmax = m2 > offmax ? m2 : offmax; }
+        for (int j = i + 1; j < M; ++j) {
+            double m2;
+            if constexpr (std::is_same<Mag, NoMag>::value) m2 = cdabs2(a(i, j)); else m2 = (double)mag2(i, j);
+            offmax = m2 > offmax ? m2 : offmax;
+        }
     if (!(offmax > 1e-34 * dmax * dmax && offmax > 1e-300)) {
         int best = 0;
         double wmax = a(0, 0).x;

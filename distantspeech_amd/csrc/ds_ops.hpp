@@ -1017,10 +1017,12 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
         }
         if (p.out2 && pass == passes - 1) {                                        // mvdr.ipynb cell 4: steer_vector = steering(noise_estimator.Phi_xx)
             // the ONE eigenvector steering() keeps (beamformer.py:24), by the direct solve of ds_linalg64.hpp
+            // |Phi_xx_ij|^2 for the solver's scale from the fp32 words (a magnitude is all it is used for)
+            auto pxx_mag2 = [&](int i, int j) { const cf y_ = hg(YD, i, j), v_ = hg(VD, i, j); const float re = y_.x - v_.x, im = y_.y - v_.y; return fma_(re, re, im * im); };
 #if defined(DS_LAGUERRE_COUNT)
-            herm_principal_direct_get_d<M>(pxx, sv, DS_LAGUERRE_COUNT, phase_fence);
+            herm_principal_direct_get_d<M>(pxx, sv, DS_LAGUERRE_COUNT, phase_fence, pxx_mag2);
 #else
-            herm_principal_direct_get_d<M>(pxx, sv, nullptr, phase_fence);
+            herm_principal_direct_get_d<M>(pxx, sv, nullptr, phase_fence, pxx_mag2);
 #endif
             DS_SCHED_FENCE();
             phase_fence();
@@ -1033,8 +1035,9 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
         if (tr - (double)M < 0.0) {                                                // :219-228
             const double dl = frm < 5 ? dvd : 0.0;
             ci.factor_invert([&](int i, int j) { cd t_ = pyy(i, j); if (i == j) t_.x += dl; return t_; });
-            phase_fence();
-            tr = ci.trace_with(pyy);
+            // (round 6) with Phi_vv_inv = inv(Phi_yy + dl I) the trace is sum lambda_i / (lambda_i + dl) <= M: xi = tr - M is zero or negative up to
+            // rounding (1e-15) and takes its floor — the second trace (M^2 (M + 1) / 2 complex products) computed nothing else
+            tr = (double)M;
         }
         phase_fence();
         xid = dmin_(dmax_(tr - (double)M, 1e-6), 1e8);                  // :230
@@ -1049,14 +1052,18 @@ template <int M> DS_HD void op_mcspp(const OpCtx& p, int b, int k) {
 #pragma unroll
         for (int i = 0; i < M; ++i) yv += cdabs2(u[i]);
         ci.upper(u, v);
-        double vPv = 0.0;
+        // v^H Phi_yy v of a Hermitian matrix by its triangle: sum_i Pyy_ii |v_i|^2 + 2 Re sum_{i<j} conj(v_i) Pyy_ij v_j
+        double vPv = 0.0, vPo = 0.0;
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            cd acc = mkd(0.0, 0.0);
+            vPv = fmad_(pyy(i, i).x, cdabs2(v[i]), vPv);
 #pragma unroll
-            for (int j = 0; j < M; ++j) acc = cdfma(acc, pyy(i, j), v[j]);
-            vPv = fmad_(v[i].x, acc.x, fmad_(v[i].y, acc.y, vPv));                  // Re(conj(v_i) (Pyy v)_i)
+            for (int j = i + 1; j < M; ++j) {
+                const cd c_ = cdmulc(v[j], v[i]), y_ = pyy(i, j);                    // conj(v_i) v_j
+                vPo = fmad_(c_.x, y_.x, fmad_(-c_.y, y_.y, vPo));                    // Re(conj(v_i) v_j Pyy_ij)
+            }
         }
+        vPv = fmad_(2.0, vPo, vPv);
         const double gamd = dmin_(dmax_(vPv - yv, 1e-6), 1e8);                       // :232-236
         const double qd = (double)q;
         const double r1x = rcp_fast_d(1.0 + xid);

@@ -34,7 +34,8 @@ for spec in sys.argv[1:]:
     line = [x for x in open(pdir + "_pmc_sq_line.json" if condensed else os.path.join(pdir, "pmc_sq.log")).read().splitlines() if x.startswith("{")][-1]
     bl = json.loads(line)
     steps = bl["warmup"] + bl["steps"] * (2 + bl["rounds"])
-    ent = {"profile": os.path.relpath(pdir, ROOT), "frames_per_step": frames, "steps_profiled": steps, "kernels": {}}
+    # (the tracked name of the source: a round's gpurun_out/<tag>/ is committed as profiles/<tag>/)
+    ent = {"profile": os.path.relpath(pdir, ROOT).replace("gpurun_out/", "profiles/", 1), "frames_per_step": frames, "steps_profiled": steps, "kernels": {}}
     valu = lds = insts = 0.0
     for k, v in ks.items():
         if "SQ_INSTS_VALU" not in v:

@@ -6,7 +6,7 @@
 set -u
 R=${1:-rXX}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"
 O=gpurun_out/$R; mkdir -p $O
-T1=${2:-"cfg2 cfg2_hbm mvdr_pf cfg3 cfg4 cfg5 wpe_nb cfg4_n10 nb_mvdr nb_mvdr_m4"}
+T1=${2:-"cfg2 cfg2_hbm mvdr_pf cfg3 cfg4 cfg5 wpe_nb cfg4_n10 nb_mvdr nb_mvdr_m4 tdgsc fdgsc"}
 declare -A CH=( [cfg2]=625 [mvdr_pf]=625 [cfg3]=625 [cfg4]=312 [cfg5]=625 [wpe_nb]=2500 [nb_mvdr]=625 )
 declare -A FR=( [cfg2]=640000 [mvdr_pf]=640000 [cfg3]=2560000 [cfg4]=319488 [cfg5]=1280000 [wpe_nb]=2560000 [nb_mvdr]=640000 )
 keep() {   # prof dir, key: the condensed files only
@@ -29,10 +29,12 @@ specs=""
 for c in $T1; do
   T=${CH[$c]:-}; [ -z "$T" ] && continue
   PROFILE_SQ=1 bash scripts/profile_bench.sh ${R}_${c}_T$T --config $c --hops-per-step $T --steps 2 --warmup 1 > /dev/null 2>&1
-  specs="$specs ${c}_10s_chunks=gpurun_out/prof_${R}_${c}_T$T:${FR[$c]}"
+  # how the chain's kernels share the GPU in time (the timeline that says why the stream pipeline stops where it does)
+  python scripts/concurrency.py gpurun_out/prof_${R}_${c}_T$T > $O/${c}_T${T}_concurrency.txt 2>&1
+  keep gpurun_out/prof_${R}_${c}_T$T ${c}_T$T
+  specs="$specs ${c}_10s_chunks=$O/${c}_T$T:${FR[$c]}"            # the condensed copies: the table then names files that are committed
 done
 python scripts/make_compute_latest.py $specs > $O/compute_latest.json 2> $O/make_compute.err
-for c in $T1; do T=${CH[$c]:-}; [ -z "$T" ] && continue; keep gpurun_out/prof_${R}_${c}_T$T ${c}_T$T; done
 python scripts/make_traffic_latest.py $O > $O/traffic_latest.json 2> $O/make_traffic.err
 for c in cfg4 cfg5; do [ -f $O/${c}_traffic.json ] && python scripts/stage_budget.py $c $O/${c}_traffic.json > $O/${c}_stage_budget.md 2>> $O/make_traffic.err; done
 ls $O | head -100; tail -3 $O/make_compute.err $O/make_traffic.err
