@@ -892,11 +892,12 @@ def main():
                 others[name] = {"workload": "%s: %s, batch=%d per GPU, 1 hop per call" % (name, wo["desc"], wo["batch"]),
                                 "value": ro["value"], "unit": "frames/s", "n_gpus": ro["ranks"], "steps": Ko, "rounds": ro["rounds"],
                                 "ms_per_step": ro["ms_per_step"], "roofline": ro["roofline"]}
-                if name == "nb_mvdr":
-                    # the notebook's online MVDR is bound by arithmetic at ANY call length (a 6 x 6 complex Jacobi eigen-solve and a Hermitian
-                    # inverse in double per bin and frame: 35 k vector instructions per wavefront and frame against 254 MB of traffic per step):
-                    # the per-frame instruction count is the 10 s profile's, the vector-issue fraction follows from this run's frame rate
-                    attach_compute(others[name], "nb_mvdr_10s_chunks", ro["value"] / max(1, ro["ranks"]))
+                if name in ("nb_mvdr", "nb_mvdr_m4"):
+                    # the notebook's online MVDR is bound by arithmetic at ANY call length (the estimation core and the principal eigenvector in
+                    # double per bin and frame: 16.7 k vector instructions per frame against 0.3 MB of traffic per step at 6 microphones; SQ passes:
+                    # SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES = 0.86): the per-frame instruction count is the 10 s profile's, the vector-issue
+                    # fraction follows from this run's frame rate
+                    attach_compute(others[name], name + "_10s_chunks", ro["value"] / max(1, ro["ranks"]))
         # (3) the BASELINE configs as SURVEY 8(d) words their inputs: 10 s per utterance in ONE call (625 hops at hop 256, 312 at hop 512;
         # cfg5's "10 s streaming chunks").  The carried state then moves once per chunk and the step is bound by the per-hop arithmetic /
         # LDS work of the kernels — the HBM fraction is reported for completeness, not as the limiter

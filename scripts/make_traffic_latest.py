@@ -15,7 +15,7 @@ d = sys.argv[1]
 # utterance groups per step: the summariser's step count is the launch count of the once-per-"step" kernels, which for a workload that runs
 # as G groups is G x the bench's steps (every kernel is launched once per group) — its per-"step" bytes are then one group's
 GROUPS = {"cfg2": 1, "cfg2_hbm": 2, "cfg3": 2, "cfg4": 2, "cfg5": 1, "wpe_nb": 1, "cfg4_n10": 1, "mvdr_pf": 1, "nb_mvdr": 1, "nb_mvdr_m4": 1, "tdgsc": 1, "fdgsc": 1}
-CHUNKED = {"cfg2": 625, "mvdr_pf": 625, "cfg3": 625, "cfg4": 312, "cfg5": 625, "wpe_nb": 2500, "nb_mvdr": 625}
+CHUNKED = {"cfg2": 625, "mvdr_pf": 625, "cfg3": 625, "cfg4": 312, "cfg5": 625, "wpe_nb": 2500, "nb_mvdr": 625, "nb_mvdr_m4": 625}
 SRC = ("%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, scripts/profile_bench.sh) of `%s`; HBM bytes = FETCH_SIZE*1024*2 "
        "(gfx950 wide-read correction) + WRITE_SIZE*1024, mean per launch, summed over the launches of one bench step")
 
