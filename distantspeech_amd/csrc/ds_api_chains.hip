@@ -173,6 +173,9 @@ int nbmvdr_process_device(ds_handle* h, const float* x_dev, int layout, long lon
         h->chain_bytes[i] = need[i];
     }
     float *D = h->chain_buf[0], *P = p_dev ? p_dev : h->chain_buf[3], *Y = h->chain_buf[5];
+    // (round 6: the batch as two or three utterance groups on their own streams, as the frame kernels and the WPE chain have them, was built —
+    // bit-identical — and measured: - 8 % with two groups, worse with three (profiles/r06a/nb_mvdr_utterance_groups_ab.txt): the operator's
+    // launch already fills every wave slot twice over and the groups only add launches.  Removed.)
     {   // D = transform.stft(x)
         ds_handle* t = h->sub[0];
         Params p;
