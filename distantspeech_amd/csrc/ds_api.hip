@@ -904,7 +904,7 @@ int ds_process_device(ds_handle* h, const float* x_dev, int layout, long long x_
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
             return fail(h, DS_ESTATE, "ds_process_device: DS_PARAM_EST_POS is on — no hipGraph capture");
-        const long long K = h->K, left = h->est_pos - h->est_used;
+        const long long K = h->K, left = h->est_pos > h->est_used ? h->est_pos - h->est_used : 0;      // (estPos lowered below the count so far: nothing left)
         const int T = p.T, hop = h->cfg.hop;
         const int n_full = (int)(left / K < T ? left / K : T);
         const int n_part = (n_full < T && left - (long long)n_full * K > 0) ? 1 : 0;

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DS_VERSION 107
+#define DS_VERSION 108   /* 108 (round 6): ds_process_f64, ds_host_alloc / ds_host_free, DS_PARAM_EST_POS, DS_ALGO_ADAPTIVE_PF at 8 microphones */
 #define DS_STATE_LAYOUT 5   /* 5 (round 5): the DC notch memories of a front-end handle are doubles ([B][M][2] x 8 bytes in a checkpoint; DS_FIELD_NOTCH_MEM
                                reads them back as float32).  Before that, 4: serialised arrangement of the carried state (checkpoint header; measurement records quote it).  4 (round 4): plane rows of
                                KP = K rounded up to 8 lanes (whole 128-byte lines per row of float4 words), RLS-WPE blocks on 128-byte lines (csrc/ds_wpe.hpp

@@ -28,9 +28,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_strerror():
     lib = L.load()
-    assert lib.ds_version() == 107
+    assert lib.ds_version() == 108
     bi = L.build_info()
-    assert bi["version"] == "107" and bi["arch"] == "gfx950" and bi["shelved"] in ("0", "1") and int(bi["state_layout"]) >= 3
+    assert bi["version"] == "108" and bi["arch"] == "gfx950" and bi["shelved"] in ("0", "1") and int(bi["state_layout"]) >= 3
     assert lib.ds_strerror(-2).decode().startswith("shape")
 
 
