@@ -777,6 +777,13 @@ def main():
 
     profiled = under_profiler()
     hw_queues_raised = False
+    if profiled:
+        # the profiler's library brought the runtime up before main(): only a limit that was in the environment BEFORE the profiler started
+        # is the one the runtime has (scripts/profile_bench.sh exports it, so that the traced run is the pipelined chain the bench measures)
+        try:
+            hw_queues_raised = int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) >= 6
+        except ValueError:
+            hw_queues_raised = False
     if not profiled:
         # this PROCESS is the application: hardware queues per device for the HIP runtime (default 4) — the chain handles run their stages on
         # up to five streams and two streams that share a queue serialise.  Must be in the environment before the first HIP call (the child

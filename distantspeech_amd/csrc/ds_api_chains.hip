@@ -26,6 +26,21 @@ int chain_reserve(ds_handle* h, int T) {
     return DS_OK;
 }
 
+#ifdef DS_ABLATE_CHAIN   // timing experiments only (scratch/jobs_r06/jobs_r06_abl.sh): the pipelined chain WITHOUT one of its stages' launches —
+// what that stage costs the chain next to the others (its time alone says little: the stages share the chip).  Never in the shipped library
+// DS_ABL_AFTER=<n>: the stage runs in the first n chain calls (pieces), so that what the others read afterwards is stale but REAL data —
+// a stage that never ran leaves zeros behind, and the operators' data-dependent paths (Laguerre steps, fallbacks) then cost something else
+static int g_abl_calls = 0;
+static bool abl_skip(const char* stage) {
+    const char* e = std::getenv("DS_ABL_SKIP");
+    if (!e || std::strstr(e, stage) == nullptr) return false;
+    const char* a = std::getenv("DS_ABL_AFTER");
+    return g_abl_calls > (a ? std::atoi(a) : 0);
+}
+#define DS_ABL_RUN(stage) (!abl_skip(stage))
+#else
+#define DS_ABL_RUN(stage) true
+#endif
 // The same chain with the batch cut into `S` utterance groups, each running the whole chain on its own stream at its own pace: nothing
 // joins the groups between calls (join_groups() does when anything else touches the handle), so one group's HBM-bound WPE kernel runs
 // next to the other groups' analysis / McMcra / MVDR / synthesis stages, whichever step those are in.  Utterances never interact and
@@ -34,6 +49,9 @@ static int chain_process_groups(ds_handle* h, const float* x_dev, int layout, lo
                                 int n_samples, float* y_dev, long long y_batch_stride, int S) {
     const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, T = n_samples / h->cfg.hop, dl = h->wpe_delay;
     float *D = h->chain_buf[0], *E = h->chain_buf[2], *pp = h->chain_buf[3], *G = h->chain_buf[4], *Y = h->chain_buf[5];
+#ifdef DS_ABLATE_CHAIN
+    ++g_abl_calls;
+#endif
     if (!h->ev_fork) DS_HIP(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     for (int g = 0; g < S - 1; ++g) {
         if (!h->side[g]) DS_HIP(h, hipStreamCreateWithFlags(&h->side[g], hipStreamNonBlocking));
@@ -62,20 +80,21 @@ static int chain_process_groups(ds_handle* h, const float* x_dev, int layout, lo
             if (layout == DS_LAYOUT_CHANNELS_SAMPLES) { p.x_sample_stride = 1; p.x_chan_stride = x_chan_stride > 0 ? x_chan_stride : n_samples; }
             else { p.x_sample_stride = M; p.x_chan_stride = 1; }
             p.T = T; p.batch0 = lo;
-            DS_HIP(h, t->ki.launch(p, nb, sg));
+            if (DS_ABL_RUN("stft")) DS_HIP(h, t->ki.launch(p, nb, sg));
         }
-        if (dl > 0) rc = wpe_launch(h->sub[1], lo, nb, nullptr, D + oz, T, E + oz, h->chain_buf[6] + (size_t)lo * dl * K * M * 2, h->hist_cur, dl, h->dev_cnt + 8 * g + 3, sg);
+        if (!DS_ABL_RUN("wpe")) rc = 0;
+        else if (dl > 0) rc = wpe_launch(h->sub[1], lo, nb, nullptr, D + oz, T, E + oz, h->chain_buf[6] + (size_t)lo * dl * K * M * 2, h->hist_cur, dl, h->dev_cnt + 8 * g + 3, sg);
         else rc = wpe_launch(h->sub[1], lo, nb, D + oz, D + oz, T, E + oz, nullptr, 0, 0, nullptr, sg);
         if (rc) return fail(h, rc, h->sub[1]->err);
         {
             const float* in[3] = {E + oz, nullptr, nullptr};
             float* out[5] = {pp + o1, G + o1, nullptr, nullptr, nullptr};
-            rc = binop_launch(h->sub[2], lo, nb, T, in, out, 0, 0, sg, none, g); if (rc) return fail(h, rc, h->sub[2]->err);
+            rc = DS_ABL_RUN("mcmcra") ? binop_launch(h->sub[2], lo, nb, T, in, out, 0, 0, sg, none, g) : 0; if (rc) return fail(h, rc, h->sub[2]->err);
         }
         {
             const float* in[3] = {E + oz, G + o1, nullptr};
             float* out[5] = {Y + o1 * 2, nullptr, nullptr, nullptr, nullptr};
-            rc = binop_launch(h->sub[3], lo, nb, T, in, out, 0, 1, sg, none, g); if (rc) return fail(h, rc, h->sub[3]->err);
+            rc = DS_ABL_RUN("mvdr") ? binop_launch(h->sub[3], lo, nb, T, in, out, 0, 1, sg, none, g) : 0; if (rc) return fail(h, rc, h->sub[3]->err);
         }
         {   // synthesis into the caller's rows; the group is addressed through the pointers so that the one-row-per-wavefront kernel applies,
             // and the launch carries the advance of the McMcra counters (the operator that read them is behind it on this stream)
@@ -92,7 +111,7 @@ static int chain_process_groups(ds_handle* h, const float* x_dev, int layout, lo
             // launch on the stream as well): no counter kernel of its own at the end of a group's step (it was 6 us of each 390 us)
             p.tick2 = dl > 0 ? ds::TickArgs{h->dev_cnt + 8 * g, 0, 1, T % dl, dl} : none;
             p.tick3 = ds::TickArgs{h->sub[3]->dev_cnt + 8 * g, T, h->sub[3]->mcra_L > 0 ? h->sub[3]->mcra_L : 1, 0, 0};
-            DS_HIP(h, launch_transform_istft(t, p, nb, sg));
+            if (DS_ABL_RUN("istft")) DS_HIP(h, launch_transform_istft(t, p, nb, sg));
         }
     }
     h->groups_open = true;                                  // (a capture joins them before it ends: ds_process_device_seq)
@@ -284,7 +303,12 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
     // (the optional outputs are dense arrays whose rows are as long as the call: a call that asks for them runs as one piece)
     if (T <= DS_CHAIN2_PIECE + DS_CHAIN2_PIECE / 2 || !h->front_async || fix_dev || bm_dev || p_dev || al_dev)
         return chain2_block(h, x_dev, x_bstride, x_cstride, n, y_dev, y_bstride, fix_dev, bm_dev, p_dev, al_dev);
+#ifdef DS_ABLATE_CHAIN
+    static const int piece_len = std::getenv("DS_ABL_PIECE") ? std::atoi(std::getenv("DS_ABL_PIECE")) : DS_CHAIN2_PIECE;
+    const int pieces = (T + piece_len - 1) / piece_len;
+#else
     const int pieces = (T + DS_CHAIN2_PIECE - 1) / DS_CHAIN2_PIECE;
+#endif
     for (int i = 0, t0 = 0; i < pieces; ++i) {
         const int tn = T / pieces + (i < T % pieces ? 1 : 0);                 // the longer pieces first: the buffers are sized once
         const int rc = chain2_block(h, x_dev + (size_t)t0 * hop, x_bstride, x_cstride, tn * hop, y_dev + (size_t)t0 * hop, y_bstride,
@@ -298,6 +322,9 @@ int chain2_run(ds_handle* h, const float* x_dev, long long x_bstride, long long 
 static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, long long x_cstride, int n, float* y_dev, long long y_bstride,
                         float* fix_dev, float* bm_dev, float* p_dev, float* al_dev) {
     DS_HIP(h, hipSetDevice(h->device));                      // not set_device(): the tail of the previous block stays on its own stream
+#ifdef DS_ABLATE_CHAIN
+    ++g_abl_calls;
+#endif
     int rc = DS_OK;
     ds_handle* fe = h->sub[0];
     const int B = h->cfg.batch, M = h->cfg.n_mics, K = h->K, hop = h->cfg.hop, T = n / hop;
@@ -371,13 +398,13 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
         std::memset(&p, 0, sizeof p);
         p.B = B; p.M = M; p.n = n; p.x = x_dev; p.x_bstride = x_bstride; p.x_cstride = x_cstride; p.y = cb[G_XN]; p.mem = fe->td_mem;
         p.radius = ds::decimal_double(fe->cfg.filt_alpha);
-        DS_HIP(h, ds::launch_dcnotch(p, fs));
+        if (DS_ABL_RUN("notch")) DS_HIP(h, ds::launch_dcnotch(p, fs));
         if (early && h->bf_valid[set]) DS_HIP(h, hipStreamWaitEvent(fs, h->ev_fr[8 + set], 0));    // the FIR bank writes the fixed-beamformer block
         std::memset(&p, 0, sizeof p);
         p.B = B; p.M = M; p.n = n; p.L = Lt; p.x = cb[G_XN]; p.x_chan_major = 1; p.y = cb[G_XA]; p.y_chan_major = 1; p.mean = cb[G_FIXED];
         // the ping-pong parity of the FIR history is device-resident (dev_cnt[3], flipped by the tick behind the launch): graph replay
         p.coef = fe->dev_buf[9]; p.cache_in = fe->td_cache[0]; p.cache_out = fe->td_cache[1]; p.dev_parity = fe->dev_cnt + 3;
-        DS_HIP(h, ds::launch_fir(p, fs));
+        if (DS_ABL_RUN("fir")) DS_HIP(h, ds::launch_fir(p, fs));
         rc = post_tick(fe, fe->dev_cnt, 0, 1, 1, 2, fs); if (rc) return rc;            // rides in the analysis launch that follows
         fe->td_cur ^= 1;
     }
@@ -395,7 +422,7 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
         p.cdr_st = sp->opst; p.cdr_NF = sp->NF; p.cdr_frm = sp->op_frm; p.cdr_ell = sp->op_ell; p.cdr_L = 65; p.cdr_fn = sp->dev_buf[9];
         p.cdr_gamma = cb[G_GAM]; p.cdr_qavg = cb[G_GAM] + (size_t)B * T * K;
         take_tick(t, fs, p.tick);
-        DS_HIP(h, h->ki_cdr.launch(p, B, fs));
+        if (DS_ABL_RUN("cdr")) DS_HIP(h, h->ki_cdr.launch(p, B, fs));
     } else {
         rc = chain_stft(h, h->sub[1], cb[G_XA], n, cb[G_D]); if (rc) return rc;                               // :204  D
     }
@@ -436,12 +463,14 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
         DS_SUB(2, mcspp_from_gamma(h->sub[2], cb[G_D], T, cb[G_GAM], cb[G_GAM] + (size_t)B * T * K, cb[G_P], h->sub[5], cb[G_F], cb[G_E]));   // :208 p, :217-223 E
         advance_host_counters(h->sub[5], T, h->sub[5]->mcra_L);
     } else {
-    if (cdr_in_front) DS_SUB(2, mcspp_from_gamma(h->sub[2], cb[G_D], T, cb[G_GAM], cb[G_GAM] + (size_t)B * T * K, cb[G_P]));   // :208  p
+    if (!DS_ABL_RUN("mcspp")) advance_host_counters(h->sub[2], T, h->sub[2]->mcra_L);
+    else if (cdr_in_front) DS_SUB(2, mcspp_from_gamma(h->sub[2], cb[G_D], T, cb[G_GAM], cb[G_GAM] + (size_t)B * T * K, cb[G_P]));   // :208  p
     else DS_SUB(2, ds_mcspp_estimate(h->sub[2], cb[G_D], T, cb[G_P], nullptr, nullptr, nullptr, nullptr, DS_MEM_DEVICE));
-    rc = chain_stft(h, h->sub[3], cb[G_FIXED], n, cb[G_F]); if (rc) return rc;                                   // bm[m].transform_x: F
+    if (DS_ABL_RUN("rows")) { rc = chain_stft(h, h->sub[3], cb[G_FIXED], n, cb[G_F]); if (rc) return rc; }                                   // bm[m].transform_x: F
     // :217-223 the M blocking filters: reference input F (shared), desired signal = channel m of D (bm[m].transform_d's analysis of the
     // aligned channel is the same spectrum), update probability p
-    if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[G_F], cb[G_D], T, cb[G_E], DS_MEM_DEVICE));
+    if (!DS_ABL_RUN("fan")) {}
+    else if (h->sub[5]->cfg.algo == DS_ALGO_SUBRLS) DS_SUB(5, ds_subrls_update(h->sub[5], cb[G_F], cb[G_D], T, cb[G_E], DS_MEM_DEVICE));
     else DS_SUB(5, ds_sublms_update(h->sub[5], cb[G_F], cb[G_D], cb[G_P], T, cb[G_E], DS_MEM_DEVICE));
     }
     if (!fused_tail) {
@@ -490,7 +519,7 @@ static int chain2_block(ds_handle* h, const float* x_dev, long long x_bstride, l
             DS_HIP(h, hipEventRecord(h->ev_fr[4 + set], h->stream));
             DS_HIP(h, hipStreamWaitEvent(h->side[2], h->ev_fr[4 + set], 0));
             if (join_at_tail) DS_HIP(h, hipStreamWaitEvent(h->side[2], h->ev_fr[8 + set], 0));
-            DS_HIP(h, h->ki_aic.launch(p, B, h->side[2]));
+            if (DS_ABL_RUN("tail")) DS_HIP(h, h->ki_aic.launch(p, B, h->side[2]));
             DS_HIP(h, hipEventRecord(h->ev_fr[6 + set], h->side[2]));
             h->tf_valid[set] = true;
             h->groups_open = true;                                          // join_groups(): side[2] comes back before anything else touches the handle

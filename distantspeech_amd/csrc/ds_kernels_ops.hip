@@ -264,33 +264,41 @@ hipError_t launch_binop(int op, const OpParams& p, hipStream_t stream) {
 }
 
 // FilterDcNotch16 (ds_ops.hpp td_dcnotch is the definition; same arithmetic, same order).  The recursion is serial in time, so one
-// lane owns one (utterance, channel) row and the rows are the only parallelism the arithmetic has: a workgroup takes 32 rows, and
-// its four wavefronts split the work by role.  All 256 lanes move 32 x 256-sample tiles between HBM and LDS as 16-byte accesses
-// (1 KB row segments per wave instruction, the next tile's loads in flight behind the current tile); wave 0 runs the recursion of
-// its 32 rows in place in LDS, 16 samples per register chunk with the next chunk already loading.
-constexpr int NOTCH_ROWS = 32, NOTCH_TS = 256, NOTCH_NT = 256, NOTCH_LD = NOTCH_TS + 4, NOTCH_RPT = NOTCH_ROWS * NOTCH_TS / 4 / NOTCH_NT;
-template <bool VEC> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kernel(TdParams p) {
-    __shared__ __attribute__((aligned(16))) float tile[2][NOTCH_ROWS][NOTCH_LD];
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, row0 = blockIdx.x * NOTCH_ROWS, rows = p.B * p.M;
+// lane owns one (utterance, channel) row and the rows are the only parallelism the arithmetic has: a workgroup takes 32 or 64 rows, and
+// its four wavefronts split the work by role.  All 256 lanes move the tiles (32 rows x 256 samples, or 64 x 128: NotchShape) between
+// HBM and LDS as 16-byte accesses (1 KB of one row, or 512 B of two, per wave instruction; the next tile's loads in flight behind the
+// current tile); wave 0 runs the recursion of the rows in place in LDS, 16 samples per register chunk with the next chunk already loading.
+constexpr int NOTCH_NT = 256;
+template <int ROWS_, int TS_> struct NotchShape {
+    static constexpr int ROWS = ROWS_, TS = TS_, LD = TS + 4;
+    static constexpr int LPR = TS / 4;                  // lanes across one row segment (16 bytes each)
+    static constexpr int RPW = 64 / LPR;                // rows one wave instruction covers
+    static constexpr int RPT = ROWS / (4 * RPW);        // row groups a wave moves per tile: wv, wv + 4, ...
+};
+template <bool VEC, typename S> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kernel(TdParams p) {
+    __shared__ __attribute__((aligned(16))) float tile[2][S::ROWS][S::LD];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, row0 = blockIdx.x * S::ROWS, rows = p.B * p.M;
+    const int lr = lane / S::LPR, col = 4 * (lane % S::LPR);            // this lane's row within a group, and its column
     const double r = p.radius, den2 = notch_den2(p.radius);             // the recursion in double: see td_dcnotch
-    const bool rec = wv == 0 && lane < NOTCH_ROWS && row0 + lane < rows;      // this lane runs the recursion of row `lane`
+    const bool rec = wv == 0 && lane < S::ROWS && row0 + lane < rows;         // this lane runs the recursion of row `lane`
     double m0 = 0.0, m1 = 0.0;
     if (rec) { m0 = p.mem[(long long)(row0 + lane) * 2]; m1 = p.mem[(long long)(row0 + lane) * 2 + 1]; }
-    // the NOTCH_RPT rows this lane moves: wv, wv + 4, ...; column 4 * lane
-    const float* src[NOTCH_RPT];
-    float* dst[NOTCH_RPT];
+    // the RPT rows this lane moves: group wv, wv + 4, ... (RPW rows each); column `col`
+    const float* src[S::RPT];
+    float* dst[S::RPT];
 #pragma unroll
-    for (int j = 0; j < NOTCH_RPT; ++j) {
-        const int rr = row0 + wv + 4 * j < rows ? row0 + wv + 4 * j : rows - 1;
+    for (int j = 0; j < S::RPT; ++j) {
+        const int rl = (wv + 4 * j) * S::RPW + lr;
+        const int rr = row0 + rl < rows ? row0 + rl : rows - 1;
         const int b = rr / p.M, m = rr - b * p.M;
-        src[j] = (p.x_bstride ? p.x + (long long)b * p.x_bstride + (long long)m * p.x_cstride : p.x + (long long)rr * p.n) + 4 * lane;
-        dst[j] = p.y + (long long)rr * p.n + 4 * lane;
+        src[j] = (p.x_bstride ? p.x + (long long)b * p.x_bstride + (long long)m * p.x_cstride : p.x + (long long)rr * p.n) + col;
+        dst[j] = p.y + (long long)rr * p.n + col;
     }
-    vec4 v[NOTCH_RPT];
+    vec4 v[S::RPT];
     auto fetch = [&](int s0) {
-        const int left = p.n - s0 - 4 * lane;                                 // samples of the row at or after this lane's column
+        const int left = p.n - s0 - col;                                      // samples of the row at or after this lane's column
 #pragma unroll
-        for (int j = 0; j < NOTCH_RPT; ++j) {
+        for (int j = 0; j < S::RPT; ++j) {
             if (VEC) {
                 v[j] = left > 0 ? *reinterpret_cast<const vec4*>(src[j] + s0) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             } else {
@@ -301,12 +309,12 @@ template <bool VEC> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kerne
     };
     fetch(0);
     int cur = 0;
-    for (int s0 = 0; s0 < p.n; s0 += NOTCH_TS, cur ^= 1) {
-        const int ns = p.n - s0 < NOTCH_TS ? p.n - s0 : NOTCH_TS;
+    for (int s0 = 0; s0 < p.n; s0 += S::TS, cur ^= 1) {
+        const int ns = p.n - s0 < S::TS ? p.n - s0 : S::TS;
 #pragma unroll
-        for (int j = 0; j < NOTCH_RPT; ++j) *reinterpret_cast<vec4*>(&tile[cur][wv + 4 * j][4 * lane]) = v[j];
+        for (int j = 0; j < S::RPT; ++j) *reinterpret_cast<vec4*>(&tile[cur][(wv + 4 * j) * S::RPW + lr][col]) = v[j];
         __syncthreads();
-        if (s0 + NOTCH_TS < p.n) fetch(s0 + NOTCH_TS);                         // next tile's loads fly behind this tile's recursion
+        if (s0 + S::TS < p.n) fetch(s0 + S::TS);                               // next tile's loads fly behind this tile's recursion
         if (rec) {
             float* row = tile[cur][lane];
             auto step = [&](float vin) { return notch_step(m0, m1, r, den2, vin); };
@@ -327,11 +335,12 @@ template <bool VEC> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kerne
             for (int i = nfull; i < ns; ++i) row[i] = step(row[i]);
         }
         __syncthreads();
-        const int left = ns - 4 * lane;
+        const int left = ns - col;
 #pragma unroll
-        for (int j = 0; j < NOTCH_RPT; ++j) {
-            if (row0 + wv + 4 * j >= rows || left <= 0) continue;
-            const vec4 o = *reinterpret_cast<const vec4*>(&tile[cur][wv + 4 * j][4 * lane]);
+        for (int j = 0; j < S::RPT; ++j) {
+            const int rl = (wv + 4 * j) * S::RPW + lr;
+            if (row0 + rl >= rows || left <= 0) continue;
+            const vec4 o = *reinterpret_cast<const vec4*>(&tile[cur][rl][col]);
             if (VEC) {
                 *reinterpret_cast<vec4*>(dst[j] + s0) = o;
             } else {
@@ -344,6 +353,8 @@ template <bool VEC> __global__ void __launch_bounds__(NOTCH_NT) ds_dcnotch_kerne
     }
     if (rec) { p.mem[(long long)(row0 + lane) * 2] = m0; p.mem[(long long)(row0 + lane) * 2 + 1] = m1; }
 }
+typedef NotchShape<32, 256> NotchS;          // 32 rows x 256 samples per tile
+typedef NotchShape<64, 128> NotchW;          // 64 rows x 128 samples: every lane of the recursion wave owns a row
 
 // TimeAlignment FIR bank (td_fir is the definition).  One single-wave block = one utterance x 64 * OPL consecutive outputs, a lane =
 // OPL consecutive outputs of every channel (OPL = 8, or 4 for calls of one 256-sample block).  Channels go through the block one at a
@@ -492,12 +503,20 @@ template <int OPL> __global__ void __launch_bounds__(FIR_NT) ds_fir_kernel(TdPar
 }
 
 hipError_t launch_dcnotch(const TdParams& p, hipStream_t stream) {
-    const dim3 grid((p.B * p.M + NOTCH_ROWS - 1) / NOTCH_ROWS);
     // 16-byte accesses when every row of x and y starts on a 16-byte boundary and holds a multiple of 4 samples
     const bool vec = p.n % 4 == 0 && (reinterpret_cast<uintptr_t>(p.x) | reinterpret_cast<uintptr_t>(p.y)) % 16 == 0 &&
                      (p.x_bstride ? (p.x_bstride % 4 == 0 && p.x_cstride % 4 == 0) : true);
-    if (vec) hipLaunchKernelGGL(ds_dcnotch_kernel<true>, grid, dim3(NOTCH_NT), 0, stream, p);
-    else hipLaunchKernelGGL(ds_dcnotch_kernel<false>, grid, dim3(NOTCH_NT), 0, stream, p);
+    // 64 rows x 128 samples per tile where there are rows for it: the recursion wave has a row on every lane, so half as many workgroups hold
+    // LDS for as long.  Same arithmetic per row; cfg5 + 2.6 % with 10 s per call, + 1.3 % at one block per call, TDGSC + 0.6 %
+    // (profiles/r06a/notch_shape_ab.txt)
+    const int rows = p.B * p.M;
+    if (vec && rows > NotchS::ROWS) {
+        hipLaunchKernelGGL((ds_dcnotch_kernel<true, NotchW>), dim3((rows + NotchW::ROWS - 1) / NotchW::ROWS), dim3(NOTCH_NT), 0, stream, p);
+        return hipGetLastError();
+    }
+    const dim3 grid((rows + NotchS::ROWS - 1) / NotchS::ROWS);
+    if (vec) hipLaunchKernelGGL((ds_dcnotch_kernel<true, NotchS>), grid, dim3(NOTCH_NT), 0, stream, p);
+    else hipLaunchKernelGGL((ds_dcnotch_kernel<false, NotchS>), grid, dim3(NOTCH_NT), 0, stream, p);
     return hipGetLastError();
 }
 template <int OPL> static void launch_fir_t(const TdParams& p, hipStream_t stream) {
@@ -511,6 +530,9 @@ hipError_t launch_fir(const TdParams& p, hipStream_t stream) {
     // (round 5 tried the channels two at a time as packed pairs — window words {x_m, x_m+1}, taps {c_m, c_m+1}: one v_pk_fma_f32 per two
     // multiply-adds by construction.  Bit-identical, and +1.7 % for cfg5 in both regimes, -0.3 % for the 4-channel chains: the compiler
     // already packs the multiply-adds of neighbouring outputs in this kernel.  scratch/shelved_r05/, profiles/r05a/fir_pairs_ab.txt)
+#ifdef DS_ABLATE_CHAIN   // timing experiment only: the 4-outputs-per-lane build (145 registers against 241) on long calls
+    { static const bool opl4 = std::getenv("DS_ABL_FIR_OPL4") != nullptr; if (opl4) { launch_fir_t<4>(p, stream); return hipGetLastError(); } }
+#endif
     if (p.n > 256) launch_fir_t<8>(p, stream); else launch_fir_t<4>(p, stream);
     return hipGetLastError();
 }

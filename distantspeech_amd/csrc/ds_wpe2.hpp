@@ -29,6 +29,10 @@ template <int CT, int NTAPS> struct Wpe2Dims {
 
 template <int CT, int NTAPS> struct Wpe2Shared {
     typedef Wpe2Dims<CT, NTAPS> D;
+    // (rows of X, num, dre are one bin's and 128 / 128 / 64 B apart: the 4 bins of a 32-lane group read two rows per bank, SQ_LDS_BANK_CONFLICT is
+    // 0.44 of SQ_LDS_IDX_ACTIVE.  Round 6 padded the rows to 144 / 144 / 80 B — conflict-free by the bank rule, 16-byte aligned: cfg4 with
+    // 10 s per call 8.45 M against 8.80 M frames/s, 12 B of scratch in the 8 x 2 kernel.  The phases are wave-local and their LDS cycles hide
+    // behind the arithmetic; the odd strides cost address arithmetic and a register.  profiles/r06a/wpe_pad_ab.txt)
     cf X[2][D::BPW][D::CN];               // input buffer, double-buffered across frames
     cf d[D::BPW][D::C];
     alignas(16) cf part[D::BPW][D::PR][D::CN + 2];  // the tile the packed triangle of P passes through on its way in and out (ds_wpe.hpp's layout of it)

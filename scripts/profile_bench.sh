@@ -18,6 +18,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+export GPU_MAX_HW_QUEUES=8      # what bench.py asks the runtime for when it is the application: the traced chain then pipelines as the measured one does
 export DS_BENCH_SYNTH=white      # white-noise input: same traffic, no torch FFT kernels in the trace
 cd /tmp
 ARGS="--steps 50 --warmup 5 --min-region-ms 20 --no-cpu-baseline --no-extras $*"
