@@ -73,7 +73,7 @@ WORKLOADS = {
                   desc="delay-and-sum (FixedBeamformer.process), 4 mics, 16 kHz, 512-FFT/256-hop"),
     # cfg4: WPE (N = 2 taps, delay 4) -> adaptive MVDR -> SPP gain; 8 mics, 1024/512; 8192 utterances over 8 GPUs = 1024 per GPU
     "cfg4": dict(algo="WPE_MVDR", M=8, nfft=1024, hop=512, batch=1024, S=2197656, r=0.05, filter_len=2,
-                 kernel="DS_ALGO_WPE_MVDR chain", launches=5, graph=1,
+                 kernel="DS_ALGO_WPE_MVDR chain", launches=5, graph=0,     # plain launches: a captured step joins the two utterance groups at its end (+3 %, profiles/r06a/graph_ab.txt)
                  desc="WPE dereverberation (2 taps) + adaptive MVDR + SPP gain chain, 8 mics, 16 kHz, 1024-FFT/512-hop"),
     # cfg5: SubbandGSC structure with SubbandRLS blocking filters; 6 mics, 512 bands; 16384 utterances over 8 GPUs = 2048 per GPU
     "cfg5": dict(algo="SUBBAND_GSC", M=6, nfft=512, hop=256, batch=2048, S=313440, r=0.05, filter_len=2, rls_lambda=0.998,

@@ -64,6 +64,9 @@ static int chain_process_groups(ds_handle* h, const float* x_dev, int layout, lo
         DS_HIP(h, hipEventRecord(h->ev_fork, h->stream));
         for (int g = 1; g < S; ++g) DS_HIP(h, hipStreamWaitEvent(h->side[g - 1], h->ev_fork, 0));
     }
+    // (The groups of a call start together and their stages take the same time, so they run IN STEP: WPE next to WPE, operators next to
+    // operators.  Round 6 held group 1 back by a WPE kernel once, so that a group's WPE ran next to the other's operators from then on: 8.78 M
+    // against 8.83 M frames/s with 10 s per call — the stages' costs add up whichever way they overlap.  profiles/r06a/cfg4_stagger_ab.txt)
     const ds::TickArgs none = {nullptr, 0, 1, 0, 0};
     for (int g = 0; g < S; ++g) {
         const int lo = (int)((long long)B * g / S), nb = (int)((long long)B * (g + 1) / S) - lo;
