@@ -1712,6 +1712,9 @@ template <int NFFT, int M, int ALGO, bool RYY> struct Engine {
                 ex.phase([&](int tid, Rg& r) {
                     if (one_round) DS_SETPRIO(2);
                     if constexpr (ALGO == ALGO_AIC) aic_fetch(t, tid, r);
+                    // (these 2 M loads open every frame.  Round 6 issued them one frame ahead, behind the output's inverse transform — 24 more
+                    // words in flight, no more registers at the kernel's peak: cfg5 26.6 - 26.9 M against 27.1 - 27.3 M frames/s with 10 s per
+                    // call, no change per block.  The other two workgroups of the CU already cover the wait.  profiles/r06a/tail_prefetch_ab.txt)
                     const int k = tid;
                     const cf w = cconj(sh.tb.tw[k]);
 #pragma unroll
