@@ -96,7 +96,7 @@ WORKLOADS = {
     # MCRA 5140, analysis tails 2*1024, FIR history 1328, notch 32, delays 4*128*4 + 1024 = 39 316
     "tdgsc": dict(algo="TDGSC", M=4, nfft=512, hop=256, batch=1024, S=18304, r=0.032, kernel="DS_ALGO_TDGSC chain", launches=6, graph=0,
                   desc="TDGSC chain (TDGSC.process: FIR bank + blocking matrix + MCRA-controlled overlap-save canceller), 4 mics, 16 kHz, block 256"),
-    "fdgsc": dict(algo="FDGSC", M=4, nfft=512, hop=256, batch=1024, S=39316, r=0.032, kernel="DS_ALGO_FDGSC chain", launches=8, graph=0,
+    "fdgsc": dict(algo="FDGSC", M=4, nfft=512, hop=256, batch=1024, S=39316, r=0.032, kernel="DS_ALGO_FDGSC chain", launches=7, graph=0,
                   desc="FDGSC chain (FDGSC.process: adaptive blocking filters + norm-limited canceller), 4 mics, 16 kHz, block 256"),
 }
 

@@ -17,8 +17,8 @@ __device__ inline double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__global__ void __launch_bounds__(256) ds_fdgsc_control_kernel(float* p, float* pa, int rows, int K) {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = blockIdx.x * 4 + wv;
+__device__ __forceinline__ void fdgsc_control_rows(float* p, float* pa, int rows, int K, int block) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, r = block * 4 + wv;
     if (r >= rows) return;
     float* row = p + (long long)r * K;
     double mid = 0.0, all = 0.0;
@@ -35,14 +35,14 @@ __global__ void __launch_bounds__(256) ds_fdgsc_control_kernel(float* p, float* 
     all = wave_sum(all);
     if (lane == 0) pa[r] = (float)(1.0 - all / (double)K);
 }
-// FDGSC.py:258,270: the two block delays of a call in ONE launch (round 6; they were six strided device copies) — rows [0, BM): aligned channel
+// FDGSC.py:258,270: the two block delays of a call together (round 6; they were six strided device copies) — rows [0, BM): aligned channel
 // rows delayed by half a block (delay_aligned, H samples of carried tail), rows [BM, BM + B): the fixed beamformer output delayed by one block
 // (delay_fbf, FL samples of carried tail).  A row's carried tail is read into registers before the row's new tail is written (one workgroup per
 // row).  tf_tail (optional): Transform.previous_input of the transform_fbf the delayed fixed output is analysed with when no post-filter runs —
 // the analysis there only advances that state (FDGSC.py:273), which is the last block of the delayed row: written here instead of launching it.
-__global__ void __launch_bounds__(256) ds_fdgsc_delays_kernel(const float* xa, float* xad, float* altail, const float* fixed, float* fixd, float* fixprev,
-                                                               float* tf_tail, int BM, int N, int H, int FL) {
-    const int r = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void fdgsc_delay_row(const float* xa, float* xad, float* altail, const float* fixed, float* fixd, float* fixprev,
+                                                float* tf_tail, int BM, int N, int H, int FL, int r) {
+    const int tid = threadIdx.x;
     const bool al = r < BM;
     const int D = al ? H : FL;                                          // this row's delay
     const float* src = al ? xa + (long long)r * N : fixed + (long long)(r - BM) * N;
@@ -60,6 +60,15 @@ __global__ void __launch_bounds__(256) ds_fdgsc_delays_kernel(const float* xa, f
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; if (i < FL) t[i] = N > FL ? src[N - 2 * FL + i] : keep[j]; }
     }
+}
+// ... and both in ONE launch (they are independent: the control reads the MCRA's p, the delays the FIR bank's outputs): workgroups [0, BM + B)
+// take a delay row each, the rest four rows of p each
+__global__ void __launch_bounds__(256) ds_fdgsc_prep_kernel(float* p, float* pa, int rows, int K, const float* xa, float* xad, float* altail,
+                                                             const float* fixed, float* fixd, float* fixprev, float* tf_tail, int BM, int B, int N,
+                                                             int H, int FL) {
+    const int blk = blockIdx.x;
+    if (blk < BM + B) fdgsc_delay_row(xa, xad, altail, fixed, fixd, fixprev, tf_tail, BM, N, H, FL, blk);
+    else fdgsc_control_rows(p, pa, rows, K, blk - (BM + B));
 }
 }  // namespace ds
 
@@ -248,12 +257,12 @@ int fdgsc_run(ds_handle* h, const float* x, long long x_bstride, long long x_cst
     const float* xin = dc_notch ? cb[Q_XN] : x;                                                              // the MCRA watches channel 0 of the (notched) input
     rc = tf_stft(h, h->sub[1], xin, dc_notch ? (long long)(M * N) : x_bstride, 1, N, n, cb[Q_D]); if (rc) return rc;   // :241
     GS_SUB(2, ds_mcra_estimate_p(h->sub[2], cb[Q_D], 1, (int)T, cb[Q_LAM], cb[Q_P], DS_MEM_DEVICE));           // :243-244
-    hipLaunchKernelGGL(ds::ds_fdgsc_control_kernel, dim3((unsigned)((B * T + 3) / 4)), dim3(256), 0, h->stream, cb[Q_P], cb[Q_PA], (int)(B * T), (int)K);   // :248-255,282
-    DS_HIP(h, hipGetLastError());
-    // :258 delay_aligned (half a block, channel-major rows [B * M][n]) and :270 delay_fbf (one block) in one launch; without the post-filter the
-    // analysis of the delayed fixed output (:273) only advances transform_fbf's carried input block: that block is written by the same launch
-    hipLaunchKernelGGL(ds::ds_fdgsc_delays_kernel, dim3((unsigned)(B * M + B)), dim3(256), 0, h->stream, cb[Q_XA], cb[Q_XAD], cb[Q_ALTAIL], cb[Q_FIXED], cb[Q_FIXD],
-                       cb[Q_FIXPREV], postfilter ? nullptr : h->sub[5]->tail_in, (int)(B * M), (int)N, (int)H, (int)FL);
+    // :248-255,282 the adaptation control from the MCRA's p, :258 delay_aligned (half a block, channel-major rows [B * M][n]) and :270 delay_fbf (one
+    // block) in one launch; without the post-filter the analysis of the delayed fixed output (:273) only advances transform_fbf's carried
+    // input block: that block is written by the same launch
+    hipLaunchKernelGGL(ds::ds_fdgsc_prep_kernel, dim3((unsigned)(B * M + B + (B * T + 3) / 4)), dim3(256), 0, h->stream, cb[Q_P], cb[Q_PA], (int)(B * T), (int)K,
+                       cb[Q_XA], cb[Q_XAD], cb[Q_ALTAIL], cb[Q_FIXED], cb[Q_FIXD], cb[Q_FIXPREV], postfilter ? nullptr : h->sub[5]->tail_in, (int)(B * M),
+                       (int)B, (int)N, (int)H, (int)FL);
     DS_HIP(h, hipGetLastError());
     // :259-264 -> :185-195: the M blocking filters of an utterance share the fixed-beamformer output; desired = delayed aligned channel m
     GS_SUB(3, fdaf_run_dev(h->sub[3], cb[Q_FIXED], cb[Q_XAD], nullptr, DS_FDAF_P_NONE, (int)T, -1, cb[Q_BM], wbm_dev, (int)M, (long long)N, 1, 0));
