@@ -1,6 +1,6 @@
 #!/bin/bash
 # the committed build once more: GPU suite (parity log), smoke, the driver's bench command
-O=gpurun_out/r06m; mkdir -p $O
+O=gpurun_out/${1:-r06m}; mkdir -p $O
 rm -f gpurun_out/parity_measured.jsonl
 python -m pytest tests -q -m gpu > $O/gpu_tests.txt 2>&1; tail -3 $O/gpu_tests.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
