@@ -96,6 +96,14 @@ def test_library_is_not_older_than_its_sources():
     assert os.path.getmtime(L.LIB_PATH) >= newest, "libdsenh.so is older than its sources: run __graft_entry__.build()"
 
 
+def test_shipped_library_carries_no_timing_experiment_switch():
+    """-DDS_ABLATE_CHAIN builds (a chain without one stage's launch) are timing experiments whose samples are garbage: the
+    shipped library must not read their switches."""
+    blob = open(L.LIB_PATH, "rb").read()
+    for name in (b"DS_ABL_SKIP", b"DS_ABL_AFTER", b"DS_ABL_PIECE", b"DS_ABL_FIR_OPL4"):
+        assert name not in blob, name
+
+
 def test_integration_stub_matches_the_header():
     """the ctypes struct a reference maintainer would paste from INTEGRATION.md has the size ds_create() checks."""
     import ctypes

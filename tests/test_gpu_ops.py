@@ -645,13 +645,15 @@ def test_single_channel_rows_kernels(ds, nfft):
 
 
 def test_dcnotch_shapes(ds):
-    """The notch kernel's tiling (32-row workgroups, 256-sample tiles, 16-sample register chunks) over ragged shapes: rows that do not
-    fill a workgroup, lengths that are not multiples of 16 or 4 (the scalar-access variant), several tiles, chunked == one call."""
+    """The notch kernel's tilings (32-row workgroups with 256-sample tiles; 64-row workgroups with 128-sample tiles where a call has more than
+    32 rows of a multiple of 4 samples; 16-sample register chunks) over ragged shapes: rows that do not fill a workgroup, lengths that are
+    not multiples of 16 or 4 (the scalar-access variant), several tiles, chunked == one call — the chunks of the last two shapes go through
+    the other tiling than the whole call does, bit for bit the same."""
     from oracle import ds_oracle as O
     from distantspeech_amd.engine import BatchEngine
     from distantspeech_amd import _lib as L
     rng = np.random.default_rng(11)
-    for B, M, n in [(5, 3, 1000), (11, 6, 777), (1, 1, 3), (40, 2, 530)]:
+    for B, M, n in [(5, 3, 1000), (11, 6, 777), (1, 1, 3), (40, 2, 530), (20, 4, 1000), (70, 1, 516)]:
         x = (rng.standard_normal((B, M, n)) * 0.1 + 0.05).astype(np.float32)
         e1 = BatchEngine(L.ALGO_FRONTEND, M, 512, batch=B, filt_alpha=0.97)
         y = e1.dcnotch(x)
