@@ -633,7 +633,7 @@ def compact_line(out, detail_path):
                 c["traffic_x"] = e["roofline"]["traffic_over_algorithmic"]       # measured HBM bytes of a 10 s call / SURVEY 8(d)'s algorithmic bytes
         elif name in ("tdgsc", "fdgsc"):
             # one block per call through 6 / 8 dependent launches of 5 .. 35 us each that move 80 / 154 MB in all: bound by launch latency, not by
-            # bytes (profiles/r06x/tdgsc_kernel_stats.csv) — `frac` is the HBM fraction of the MEASURED traffic (PMC passes), `launches` says why it is small
+            # bytes (profiles/r06z/tdgsc_kernel_stats.csv) — `frac` is the HBM fraction of the MEASURED traffic (PMC passes), `launches` says why it is small
             c.update(bound="launch", frac=e["roofline"].get("frac_measured", e["roofline"]["frac"]), launches=e["roofline"].get("launches_per_step"))
         else:
             c.update(bound="hbm", frac=e["roofline"]["frac"])
