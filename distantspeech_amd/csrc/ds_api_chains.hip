@@ -179,6 +179,9 @@ int chain_process_device(ds_handle* h, const float* x_dev, int layout, long long
 int nbmvdr_process_device(ds_handle* h, const float* x_dev, int layout, long long x_batch_stride, long long x_chan_stride, int n_samples,
                           float* y_dev, long long y_batch_stride, float* p_dev) {
     int rc = set_device(h); if (rc) return rc;
+#ifdef DS_ABLATE_CHAIN
+    ++g_abl_calls;
+#endif
     const size_t B = h->cfg.batch, M = h->cfg.n_mics, K = h->K;
     const int T = n_samples / h->cfg.hop;
     if (h->sub[1]->aux_floats < K) return fail(h, DS_ESTATE, "McSpp-MVDR chain: call ds_chain_set_aux(DS_CHAIN_AUX_COHERENCE) first");
@@ -198,6 +201,12 @@ int nbmvdr_process_device(ds_handle* h, const float* x_dev, int layout, long lon
     // (round 6: the batch as two or three utterance groups on their own streams, as the frame kernels and the WPE chain have them, was built —
     // bit-identical — and measured: - 8 % with two groups, worse with three (profiles/r06a/nb_mvdr_utterance_groups_ab.txt): the operator's
     // launch already fills every wave slot twice over and the groups only add launches.  Removed.)
+    // (also round 6: the three kernels of a call on three streams with two sets of the buffers between them, so that call t + 1's analysis +
+    // McCDR and call t - 1's synthesis run next to call t's operator — which alone is 64 of the 91 us of a 6-microphone step, 28 of 46 at 4
+    // (profiles/r06a/nb_mvdr_stage_ablation.txt).  Built, bit-identical over 36 one-block calls, resets and checkpoints, and measured:
+    // one block per call 94 against 90 us at 6 microphones, 52 - 56 against 46 us at 4 — the four event waits per call cost more than the
+    // overlap returns, since the operator already fills the chip; + 5 % at 6 microphones from 4 blocks per call on, nothing at 4.  Removed.
+    // profiles/r06a/nb_mvdr_pipeline_ab.txt)
     {   // D = transform.stft(x)
         ds_handle* t = h->sub[0];
         Params p;
@@ -215,7 +224,7 @@ int nbmvdr_process_device(ds_handle* h, const float* x_dev, int layout, long lon
             p.cdr_gamma = h->chain_buf[1]; p.cdr_qavg = h->chain_buf[1] + B * T * K;
         }
         take_tick(t, h->stream, p.tick);
-        DS_HIP(h, (cdr_fused ? h->ki_cdr.launch : t->ki.launch)(p, (int)B, h->stream));
+        if (DS_ABL_RUN("nbcdr")) DS_HIP(h, (cdr_fused ? h->ki_cdr.launch : t->ki.launch)(p, (int)B, h->stream));
     }
     // per frame: noise_estimator.estimation(y); steer = steering(Phi_xx); w = compute_mvdr_weight(steer, Phi_vv_inv); Yout = w^H y — one kernel
     if (cdr_fused) rc = mcspp_from_gamma(h->sub[1], D, T, h->chain_buf[1], h->chain_buf[1] + B * T * K, P, nullptr, nullptr, nullptr, Y);
@@ -230,7 +239,8 @@ int nbmvdr_process_device(ds_handle* h, const float* x_dev, int layout, long lon
         p.y_batch_stride = y_batch_stride;
         p.T = T; p.batch0 = 0; p.method = 1;
         take_tick(t, h->stream, p.tick);                                // McSpp's counter advance
-        DS_HIP(h, launch_transform_istft(t, p, (int)B, h->stream));
+        if (DS_ABL_RUN("nbistft")) DS_HIP(h, launch_transform_istft(t, p, (int)B, h->stream));
+        else { const int rc2 = flush_tick(h); if (rc2) return rc2; }
     }
     return flush_tick(h);
 }
