@@ -228,7 +228,6 @@ class GpuBackend:
         two synchronisations inside the timed call) and the same chunk through ds_process_device (device-resident float chunk; timed with
         the stream synchronisation).  Median and p99 of the wall time per chunk."""
         import numpy as np
-        import ctypes
         from distantspeech_amd import BatchEngine, _lib as L
         from distantspeech_amd.mic_array import MicArray
         torch = self.torch
