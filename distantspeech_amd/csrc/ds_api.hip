@@ -251,6 +251,17 @@ const char* ds_last_error(const ds_handle* h) { return h ? h->err.c_str() : g_er
 // on one of two levels, 8.3 - 8.7 or 9.3 - 9.6 M frames/s, with every kernel of the step scaled alike: the device's clock state,
 // profiles/r03f/cfg5_step_length.txt) — not the default (profiles/r03f/chain_prio_ab.txt)
 static hipError_t chain_stream(hipStream_t* s, int bit) {
+#ifdef DS_ABLATE_CHAIN   // timing experiment only: the chain's streams on disjoint sets of CUs (DS_ABL_CU_<bit>="lo-hi": mask bits lo .. hi-1)
+    { char name[32]; std::snprintf(name, sizeof name, "DS_ABL_CU_%d", bit);
+      if (const char* e = std::getenv(name)) {
+          int lo = 0, hi = 0;
+          if (std::sscanf(e, "%d-%d", &lo, &hi) == 2 && lo >= 0 && hi > lo && hi <= 256) {
+              uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+              for (int i = lo; i < hi; ++i) mask[i >> 5] |= 1u << (i & 31);
+              return hipExtStreamCreateWithCUMask(s, 8, mask);
+          }
+      } }
+#endif
     const char* pr = std::getenv("DS_CHAIN_PRIO");
     const int mask = pr ? std::atoi(pr) : 0;
     int lo = 0, hi = 0;
