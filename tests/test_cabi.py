@@ -100,7 +100,7 @@ def test_shipped_library_carries_no_timing_experiment_switch():
     """-DDS_ABLATE_CHAIN builds (a chain without one stage's launch) are timing experiments whose samples are garbage: the
     shipped library must not read their switches."""
     blob = open(L.LIB_PATH, "rb").read()
-    for name in (b"DS_ABL_SKIP", b"DS_ABL_AFTER", b"DS_ABL_PIECE", b"DS_ABL_FIR_OPL4"):
+    for name in (b"DS_ABL_SKIP", b"DS_ABL_AFTER", b"DS_ABL_PIECE", b"DS_ABL_FIR_OPL4", b"DS_ABL_CU_"):
         assert name not in blob, name
 
 
