@@ -61,10 +61,12 @@ WORKLOADS = {
     # the only maintained MVDR usage of the reference (example/mvdr.ipynb cell 4, the flow its published PESQ 2.26 was obtained with, 6 microphones):
     # Transform.stft -> McSpp.estimation -> steering(Phi_xx) -> compute_mvdr_weight(steer, Phi_vv_inv) -> w^H y -> Transform.istft as ONE handle
     # (DS_ALGO_MCSPP_MVDR).  S = tails (M + 1) * 256 * 4 + 257 * (Phi_yy, Phi_vv complex M x M: 2 * M * M * 8 + McCDR / MCRA / xi, gamma, p rows 12 * 4)
-    "nb_mvdr": dict(algo="MCSPP_MVDR", M=6, nfft=512, hop=256, batch=1024, S=7 * 256 * 4 + 257 * (2 * 36 * 8 + 48), r=0.05,
+    # (batch 4096 at one hop per call since the end of round 6: the operator's launch at 1024 utterances is 1056 workgroups for 1024 slots — 11.4 M /
+    # 22.5 M frames/s at 1024, 13.9 M / 26.1 M at 2048, 15.0 M / 29.2 M at 4096; the 10 s regime keeps 1024: its spectra are 7.9 GB per 1024)
+    "nb_mvdr": dict(algo="MCSPP_MVDR", M=6, nfft=512, hop=256, batch=4096, batch_chunked=1024, S=7 * 256 * 4 + 257 * (2 * 36 * 8 + 48), r=0.05,
                     kernel="DS_ALGO_MCSPP_MVDR chain: ds_binop_kernel<MCSPP,6> (+ analysis, McCDR, synthesis)", launches=4, graph=1,
                     desc="online MVDR of mvdr.ipynb cell 4 (McSpp + steering + MVDR weights per frame), 6 mics, 16 kHz, 512-FFT/256-hop"),
-    "nb_mvdr_m4": dict(algo="MCSPP_MVDR", M=4, nfft=512, hop=256, batch=1024, S=5 * 256 * 4 + 257 * (2 * 16 * 8 + 48), r=0.032,
+    "nb_mvdr_m4": dict(algo="MCSPP_MVDR", M=4, nfft=512, hop=256, batch=4096, batch_chunked=1024, S=5 * 256 * 4 + 257 * (2 * 16 * 8 + 48), r=0.032,
                        kernel="DS_ALGO_MCSPP_MVDR chain: ds_binop_kernel<MCSPP,4> (+ analysis, McCDR, synthesis)", launches=4, graph=1,
                        desc="online MVDR of mvdr.ipynb cell 4 (McSpp + steering + MVDR weights per frame), 4 mics, 16 kHz, 512-FFT/256-hop"),
     # cfg1 on the GPU (stateless apart from the tails)
@@ -101,6 +103,11 @@ WORKLOADS = {
     "fdgsc": dict(algo="FDGSC", M=4, nfft=512, hop=256, batch=4096, S=39316, r=0.032, kernel="DS_ALGO_FDGSC chain", launches=7, graph=0,
                   desc="FDGSC chain (FDGSC.process: adaptive blocking filters + norm-limited canceller), 4 mics, 16 kHz, block 256"),
 }
+
+
+def batch_of(w, hops_per_call):
+    """utterances per GPU of a workload: `batch`, or `batch_chunked` for calls of more than one hop where the workload names one"""
+    return w.get("batch_chunked", w["batch"]) if hops_per_call > 1 else w["batch"]
 
 
 EXTRA_T1 = ("mvdr_pf", "cfg3", "cfg4", "cfg5", "wpe_nb", "nb_mvdr", "nb_mvdr_m4", "tdgsc", "fdgsc")                                                  # other_configs at one hop per call
@@ -823,7 +830,7 @@ def main():
         dsdist.finalize()
         return
     w = WORKLOADS[args.config]
-    B = args.batch or w["batch"]
+    B = args.batch or batch_of(w, args.hops_per_step)
     seed = None
     if args.total_batch:
         lo, hi = dsdist.shard_range(args.total_batch, rank, world)     # utterances [lo, hi) of the job live on this rank's GPU
@@ -867,7 +874,7 @@ def main():
             out["config"]["total_batch"] = args.total_batch
         if getattr(be, "shared_device", False):
             out["config"]["note"] = "all %d ranks share GPU %d (DS_FORCE_DEVICE, gloo): rank-path check, not a scaling measurement" % (world, be.local_rank)
-        if T == 1 and B == w["batch"]:
+        if T == 1 and B == batch_of(w, 1):
             attach_traffic(out["roofline"], args.config)
         if T > 1:
             attach_compute(out, "%s_10s_chunks" % args.config if T >= 300 else "none", out["value"] / max(1, res["ranks"]))
@@ -914,15 +921,16 @@ def main():
         if args.config == "cfg2" and T == 1 and not args.total_batch:
             for name, Tc in EXTRA_CHUNKED:
                 wo = WORKLOADS[name]
-                ro = measure(be, dsdist, wo, wo["batch"], Tc, 2, 1, rank, world, min(args.min_region_ms, 120.0))
+                Bc = batch_of(wo, Tc)
+                ro = measure(be, dsdist, wo, Bc, Tc, 2, 1, rank, world, min(args.min_region_ms, 120.0))
                 if rank == 0:
-                    ent = {"workload": "%s: %s, batch=%d per GPU, 10 s per call (%d hops)" % (name, wo["desc"], wo["batch"], Tc),
+                    ent = {"workload": "%s: %s, batch=%d per GPU, 10 s per call (%d hops)" % (name, wo["desc"], Bc, Tc),
                            "value": ro["value"], "unit": "frames/s", "n_gpus": ro["ranks"], "steps": 2, "rounds": ro["rounds"],
                            "ms_per_step": ro["ms_per_step"], "hops_per_call": Tc, "roofline": ro["roofline"]}
                     attach_compute(ent, name + "_10s_chunks", ro["value"] / max(1, ro["ranks"]))
                     attach_traffic(ent["roofline"], name + "_10s_chunks", warn=False)      # HBM bytes a 10 s call really moves (committed PMC passes)
                     if ent["roofline"].get("traffic"):
-                        alg_step = algorithmic_bytes_per_frame(wo, Tc) * wo["batch"] * Tc
+                        alg_step = algorithmic_bytes_per_frame(wo, Tc) * Bc * Tc
                         ent["roofline"]["traffic_over_algorithmic"] = round(ent["roofline"]["traffic"] / alg_step, 3)
                     others[name + "_10s_chunks"] = ent
         if rank == 0 and others:
