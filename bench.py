@@ -62,11 +62,11 @@ WORKLOADS = {
     # Transform.stft -> McSpp.estimation -> steering(Phi_xx) -> compute_mvdr_weight(steer, Phi_vv_inv) -> w^H y -> Transform.istft as ONE handle
     # (DS_ALGO_MCSPP_MVDR).  S = tails (M + 1) * 256 * 4 + 257 * (Phi_yy, Phi_vv complex M x M: 2 * M * M * 8 + McCDR / MCRA / xi, gamma, p rows 12 * 4)
     # (batch 4096 at one hop per call since the end of round 6: the operator's launch at 1024 utterances is 1056 workgroups for 1024 slots — 11.4 M /
-    # 22.5 M frames/s at 1024, 13.9 M / 26.1 M at 2048, 15.0 M / 29.2 M at 4096; the 10 s regime keeps 1024: its spectra are 7.9 GB per 1024)
-    "nb_mvdr": dict(algo="MCSPP_MVDR", M=6, nfft=512, hop=256, batch=4096, batch_chunked=1024, S=7 * 256 * 4 + 257 * (2 * 36 * 8 + 48), r=0.05,
+    # 22.5 M frames/s at 1024, 13.9 M / 26.1 M at 2048, 15.0 M / 29.2 M at 4096; the 10 s regime runs 2048 — 17.7 M at 1024, 20.2 M at 2048, 21.7 M at 4096 with 32 GB of spectra)
+    "nb_mvdr": dict(algo="MCSPP_MVDR", M=6, nfft=512, hop=256, batch=4096, batch_chunked=2048, S=7 * 256 * 4 + 257 * (2 * 36 * 8 + 48), r=0.05,
                     kernel="DS_ALGO_MCSPP_MVDR chain: ds_binop_kernel<MCSPP,6> (+ analysis, McCDR, synthesis)", launches=4, graph=1,
                     desc="online MVDR of mvdr.ipynb cell 4 (McSpp + steering + MVDR weights per frame), 6 mics, 16 kHz, 512-FFT/256-hop"),
-    "nb_mvdr_m4": dict(algo="MCSPP_MVDR", M=4, nfft=512, hop=256, batch=4096, batch_chunked=1024, S=5 * 256 * 4 + 257 * (2 * 16 * 8 + 48), r=0.032,
+    "nb_mvdr_m4": dict(algo="MCSPP_MVDR", M=4, nfft=512, hop=256, batch=4096, batch_chunked=2048, S=5 * 256 * 4 + 257 * (2 * 16 * 8 + 48), r=0.032,
                        kernel="DS_ALGO_MCSPP_MVDR chain: ds_binop_kernel<MCSPP,4> (+ analysis, McCDR, synthesis)", launches=4, graph=1,
                        desc="online MVDR of mvdr.ipynb cell 4 (McSpp + steering + MVDR weights per frame), 4 mics, 16 kHz, 512-FFT/256-hop"),
     # cfg1 on the GPU (stateless apart from the tails)

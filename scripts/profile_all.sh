@@ -8,7 +8,7 @@ R=${1:-rXX}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; cd "$ROOT"
 O=gpurun_out/$R; mkdir -p $O
 T1=${2:-"cfg2 cfg2_hbm mvdr_pf cfg3 cfg4 cfg5 wpe_nb cfg4_n10 nb_mvdr nb_mvdr_m4 tdgsc fdgsc"}
 declare -A CH=( [cfg2]=625 [mvdr_pf]=625 [cfg3]=625 [cfg4]=312 [cfg5]=625 [wpe_nb]=2500 [nb_mvdr]=625 [nb_mvdr_m4]=625 )
-declare -A FR=( [cfg2]=640000 [mvdr_pf]=640000 [cfg3]=2560000 [cfg4]=319488 [cfg5]=1280000 [wpe_nb]=2560000 [nb_mvdr]=640000 [nb_mvdr_m4]=640000 )
+declare -A FR=( [cfg2]=640000 [mvdr_pf]=640000 [cfg3]=2560000 [cfg4]=319488 [cfg5]=1280000 [wpe_nb]=2560000 [nb_mvdr]=1280000 [nb_mvdr_m4]=1280000 )
 keep() {   # prof dir, key: the condensed files only
   d=$1; k=$2
   for f in traffic.json kernel_stats.csv summary.txt compute.json bench_line.json; do [ -f $d/$f ] && cp $d/$f $O/${k}_$f; done
